@@ -1,0 +1,121 @@
+// gunrock/bfs/bfs_enactor.hxx -- BFS superstep loops.
+//   enact_pushpull : the reference's loop, operator per superstep
+//                    (gunrock/src/bfs/bfs_enactor.hxx:41-117): push until
+//                    num_unvisited < frontier_length * threshold, then the pull phase.
+//   enact_fused    : same labels from the device-resident fused path (mgx/bfs_fused.hpp):
+//                    one kernel per level, no host round trip per level.
+#pragma once
+#include "../advance.hxx"
+#include "../enactor.hxx"
+#include "../filter.hxx"
+#include "../frontier.hxx"
+#include "../graph.hxx"
+#include "../../mgx/bfs_fused.hpp"
+#include "bfs_functor.hxx"
+#include "bfs_problem.hxx"
+
+namespace gunrock {
+namespace bfs {
+
+struct bfs_enactor_t : enactor_t {
+  // counters of the last enact_* call
+  int pushed_iterations = 0;
+  int total_iterations = 0;
+  long long pushed_edges = 0;   // sum of advance fronts
+  long long pulled_edges = 0;   // in-edges inspected by the pull phase
+  bool verbose = false;
+
+  bfs_enactor_t(standard_context_t& context, int num_nodes, int num_edges)
+      : enactor_t(context, num_nodes, num_edges) {}
+
+  bfs_enactor_t(const bfs_enactor_t& rhs) = delete;
+  bfs_enactor_t& operator=(const bfs_enactor_t& rhs) = delete;
+
+  void init_frontier(std::shared_ptr<bfs_problem_t> bfs_problem) {
+    std::vector<int> node_idx(1, bfs_problem->src);
+    (void)buffers[0]->load(node_idx);
+  }
+
+  void enact_pushpull(std::shared_ptr<bfs_problem_t> bfs_problem, float threshold, standard_context_t& context) {
+    using namespace gunrock::oprtr::advance;
+    using namespace gunrock::oprtr::filter;
+    init_frontier(bfs_problem);
+    // the index frontiers are consumed by a pull phase; restore them for re-use of the enactor
+    unvisited[0] = indices;
+    unvisited[1] = filtered_indices;
+    const int num_nodes = bfs_problem->gslice->num_nodes;
+    indices->resize(num_nodes);
+    filtered_indices->resize(num_nodes);
+
+    int frontier_length = 1;
+    int selector = 0;
+    int num_unvisited = num_nodes - 1;
+    int iteration;
+    pushed_edges = pulled_edges = 0;
+
+    for (iteration = 0;; ++iteration) {
+      frontier_length = advance_forward_kernel<bfs_problem_t, bfs_functor_t, false, true>(
+          bfs_problem, buffers[selector], buffers[selector ^ 1], iteration, context);
+      pushed_edges += frontier_length;
+      selector ^= 1;
+      if (!frontier_length) break;
+      frontier_length = filter_kernel<bfs_problem_t, bfs_functor_t>(bfs_problem, buffers[selector],
+                                                                   buffers[selector ^ 1], iteration, context);
+      num_unvisited -= frontier_length;
+      if ((float)num_unvisited < (float)frontier_length * threshold) break;
+      if (!frontier_length) break;
+      selector ^= 1;
+    }
+    pushed_iterations = total_iterations = iteration;
+    if (verbose) std::cout << "pushed iterations: " << iteration << std::endl;
+
+    if (frontier_length) {
+      // switch to pull: unvisited list + int-per-vertex bitmap of the current frontier
+      ++iteration;
+      frontier_length = gen_unvisited_kernel<bfs_problem_t, bfs_functor_t>(bfs_problem, unvisited[selector ^ 1],
+                                                                          unvisited[selector], 0, context);
+      int new_frontier_length;
+      mem_t<int> bitmap_array = mgx::fill<int>(0, num_nodes, context);
+      (void)buffers[selector]->load(bitmap_array);
+      sparse_to_dense_kernel<bfs_problem_t, bfs_functor_t>(bfs_problem, buffers[selector ^ 1], buffers[selector],
+                                                           iteration, context);
+      for (;; ++iteration) {
+        (void)buffers[selector ^ 1]->load(bitmap_array);
+        pulled_edges += advance_backward_kernel<bfs_problem_t, bfs_functor_t>(
+            bfs_problem, unvisited[selector], buffers[selector], buffers[selector ^ 1], iteration, context);
+        new_frontier_length = filter_kernel<bfs_problem_t, bfs_functor_t>(bfs_problem, unvisited[selector],
+                                                                         unvisited[selector ^ 1], iteration, context);
+        if (!new_frontier_length || new_frontier_length == frontier_length) break;
+        frontier_length = new_frontier_length;
+        selector ^= 1;
+      }
+      total_iterations = iteration;
+      if (verbose) std::cout << "total iterations: " << iteration << std::endl;
+      // the pull phase leaves -1 holes in the index frontiers: refill the iota for the next run
+      mem_t<int> iota = mgx::fill_function<int>([] __device__(int i) { return i; }, num_nodes, context);
+      (void)indices->load(iota);
+      (void)filtered_indices->load(iota);
+    }
+  }
+
+};
+
+// Device-resident fused traversal (mgx/bfs_fused.hpp).  Needs only O(n) state: no
+// edge-capacity ping-pong buffers.  Counters of the last run are in fused.host_ctrl
+// (levels, sum_edges == m_t, sum_frontier, reached, per-level trace).
+struct bfs_fused_enactor_t {
+  mgx::bfs_fused_state_t fused;
+  bfs_fused_enactor_t(standard_context_t& context, int num_nodes) : fused(num_nodes, context) {}
+  bfs_fused_enactor_t(const bfs_fused_enactor_t&) = delete;
+  bfs_fused_enactor_t& operator=(const bfs_fused_enactor_t&) = delete;
+
+  // labels are (re)initialised by the run itself; bfs_problem->src is the source
+  void enact(std::shared_ptr<bfs_problem_t> bfs_problem, standard_context_t& context) {
+    mgx::bfs_fused_push_run(fused, bfs_problem->gslice->d_row_offsets.data(),
+                            bfs_problem->gslice->d_col_indices.data(), bfs_problem->d_labels.data(),
+                            bfs_problem->src, context);
+  }
+};
+
+}  // namespace bfs
+}  // namespace gunrock

@@ -1,0 +1,52 @@
+// gunrock/bfs/bfs_functor.hxx -- the device functor the operators inline for BFS.
+// Same static members and semantics as the reference's bfs_functor_t
+// (gunrock/src/bfs/bfs_functor.hxx:7-53):
+//   cond_filter            keep anything that is not the -1 "loser" marker        (:9-11)
+//   cond_uniq              idempotent-mode relabel                                 (:13-24)
+//   cond_advance           destination still unlabelled                            (:26-28)
+//   apply_advance          claim it: CAS labels[dst] -1 -> iteration+1             (:30-33)
+//   cond_sparse_to_dense   vertex belongs to the level being turned into a bitmap  (:35-37)
+//   cond_gen_unvisited     vertex still unlabelled                                 (:39-41)
+//   get_value_to_reduce / write_reduced_value   unused by BFS, kept for the concept (:43-51)
+#pragma once
+#include "bfs_problem.hxx"
+
+namespace gunrock {
+namespace bfs {
+
+struct bfs_functor_t {
+  typedef bfs_problem_t::data_slice_t slice_t;
+
+  static __device__ __forceinline__ bool cond_filter(int idx, slice_t*, int) { return idx != -1; }
+
+  static __device__ __forceinline__ bool cond_uniq(int idx, slice_t* data, int iteration) {
+    if (idx <= 0) return false;   // the reference skips vertex 0 here as well
+    const int seen = data->d_labels[idx];
+    if (seen > 0 && seen <= iteration) return false;
+    data->d_labels[idx] = iteration + 1;
+    return true;
+  }
+
+  static __device__ __forceinline__ bool cond_advance(int, int dst, int, int, int, slice_t* data, int) {
+    return data->d_labels[dst] == -1;
+  }
+
+  static __device__ __forceinline__ bool apply_advance(int, int dst, int, int, int, slice_t* data, int iteration) {
+    return atomicCAS(&data->d_labels[dst], -1, iteration + 1) == -1;
+  }
+
+  static __device__ __forceinline__ bool cond_sparse_to_dense(int idx, slice_t* data, int iteration) {
+    return data->d_labels[idx] == iteration;
+  }
+
+  static __device__ __forceinline__ bool cond_gen_unvisited(int idx, slice_t* data, int) {
+    return data->d_labels[idx] == -1;
+  }
+
+  static __device__ __forceinline__ int get_value_to_reduce(int, slice_t*, int iteration) { return iteration; }
+
+  static __device__ __forceinline__ void write_reduced_value(int, int, slice_t*, int) {}
+};
+
+}  // namespace bfs
+}  // namespace gunrock

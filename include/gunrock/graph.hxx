@@ -1,0 +1,192 @@
+// gunrock/graph.hxx -- host CSR, device graph, MTX loader.
+// Drop-in for the reference's gunrock/src/graph.hxx (csr_t :19-26, graph_t :28-35,
+// graph_device_t :37-58, graph_to_device :60-83, load_graph :96-223): same type and member
+// names, so problem/enactor/functor code written against the reference compiles against
+// this file.  Memory layer is mgx::mem_t (HIP), not moderngpu.
+#pragma once
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <limits>
+#include <memory>
+#include <tuple>
+#include <vector>
+
+#include "../mgx/runtime.hpp"
+
+// The reference's sources say `using namespace mgpu;` and `mgpu::fill<...>` for the memory
+// layer (graph.hxx:15, bfs_enactor.hxx:83); mgx is that layer here.
+namespace mgpu = mgx;
+using namespace mgx;
+
+namespace gunrock {
+
+struct csr_t {
+  int num_nodes;
+  int num_edges;
+  std::vector<int> offsets;
+  std::vector<int> indices;
+  std::vector<float> edge_weights;
+  std::vector<int> sources;
+};
+
+struct graph_t {
+  bool undirected;
+  int num_nodes;
+  int num_edges;
+  std::shared_ptr<csr_t> csr;
+  std::shared_ptr<csr_t> csc;
+};
+
+struct graph_device_t {
+  int num_nodes;
+  int num_edges;
+  mem_t<int> d_row_offsets;
+  mem_t<int> d_col_indices;
+  mem_t<float> d_col_values;
+  mem_t<int> d_col_offsets;
+  mem_t<int> d_row_indices;
+  mem_t<float> d_row_values;
+  mem_t<int> d_csr_srcs;
+  mem_t<int> d_csc_srcs;
+
+  // exclusive degree scan of the frontier currently being advanced (advance.hxx:28,40).
+  // The reference sizes it num_nodes although it is indexed by frontier slot;
+  // here operators grow it once to the input frontier's capacity (ensure_scanned).
+  mem_t<int> d_scanned_row_offsets;
+
+  // true when the CSC slots alias the CSR arrays (what the reference always has)
+  bool csc_is_csr = true;
+
+  graph_device_t() : num_nodes(0), num_edges(0) {}
+
+  void ensure_scanned(size_t slots, standard_context_t& ctx) {
+    if (d_scanned_row_offsets.size() >= slots + 1) return;
+    ctx.synchronize();
+    d_scanned_row_offsets = mem_t<int>(slots + 1, ctx);
+  }
+};
+
+// graph.hxx:60-83.  The reference uploads the CSC copies as separate buffers; the CSC slots
+// here borrow the CSR buffers unless the host graph carries a genuine CSC.
+inline void graph_to_device(std::shared_ptr<graph_device_t> d_graph, std::shared_ptr<graph_t> graph,
+                            standard_context_t& context) {
+  d_graph->num_nodes = graph->num_nodes;
+  d_graph->num_edges = graph->num_edges;
+  d_graph->d_row_offsets = to_mem(graph->csr->offsets, context);
+  d_graph->d_col_values = to_mem(graph->csr->edge_weights, context);
+  d_graph->d_col_indices = to_mem(graph->csr->indices, context);
+  d_graph->d_csr_srcs = to_mem(graph->csr->sources, context);
+  const bool own_csc = graph->csc && graph->csc != graph->csr;
+  if (own_csc) {
+    d_graph->d_col_offsets = to_mem(graph->csc->offsets, context);
+    d_graph->d_row_indices = to_mem(graph->csc->indices, context);
+    d_graph->d_row_values = to_mem(graph->csc->edge_weights, context);
+    d_graph->d_csc_srcs = to_mem(graph->csc->sources, context);
+    d_graph->csc_is_csr = false;
+  } else {
+    d_graph->d_col_offsets = mem_t<int>::borrow(d_graph->d_row_offsets.data(), d_graph->d_row_offsets.size());
+    d_graph->d_row_indices = mem_t<int>::borrow(d_graph->d_col_indices.data(), d_graph->d_col_indices.size());
+    d_graph->d_row_values = mem_t<float>::borrow(d_graph->d_col_values.data(), d_graph->d_col_values.size());
+    d_graph->d_csc_srcs = mem_t<int>::borrow(d_graph->d_csr_srcs.data(), d_graph->d_csr_srcs.size());
+    d_graph->csc_is_csr = true;
+  }
+  d_graph->d_scanned_row_offsets = mem_t<int>((size_t)graph->num_nodes + 1, context);
+  // every operator on this graph may scan/compact up to num_edges work items
+  context.reserve_scratch((size_t)graph->num_edges / 2 + ((size_t)graph->num_nodes + 4096) * 2 + (1 << 20));
+}
+
+inline void display_csr(std::shared_ptr<csr_t> csr) {
+  std::cout << "offsets: \n";
+  for (int x : csr->offsets) std::cout << x << ' ';
+  std::cout << "\nindices: \n";
+  for (int x : csr->indices) std::cout << x << ' ';
+  std::cout << std::endl;
+}
+
+// Build a CSR whose row is tuple field `row_field` and whose neighbour is the other field,
+// rows ascending, neighbours ascending inside a row, duplicates and self loops kept.
+inline std::shared_ptr<csr_t> csr_from_tuples(int num_vertices, std::vector<std::tuple<int, int, float>> tuples,
+                                              int row_field) {
+  auto row_of = [row_field](const std::tuple<int, int, float>& t) { return row_field ? std::get<1>(t) : std::get<0>(t); };
+  auto nbr_of = [row_field](const std::tuple<int, int, float>& t) { return row_field ? std::get<0>(t) : std::get<1>(t); };
+  std::stable_sort(tuples.begin(), tuples.end(),
+                   [&](const std::tuple<int, int, float>& a, const std::tuple<int, int, float>& b) {
+                     if (row_of(a) != row_of(b)) return row_of(a) < row_of(b);
+                     return nbr_of(a) < nbr_of(b);
+                   });
+  const int m = (int)tuples.size();
+  auto out = std::make_shared<csr_t>();
+  out->num_nodes = num_vertices;
+  out->num_edges = m;
+  out->offsets.assign((size_t)num_vertices + 1, m);
+  out->indices.resize(m);
+  out->sources.resize(m);
+  out->edge_weights.resize(m);
+  int cur = -1;
+  for (int e = 0; e < m; ++e) {
+    while (cur < row_of(tuples[e])) out->offsets[++cur] = e;
+    out->sources[e] = cur;
+    out->indices[e] = nbr_of(tuples[e]);
+    out->edge_weights[e] = std::get<2>(tuples[e]);
+  }
+  return out;
+}
+
+// MTX text loader with the reference's conventions (graph.hxx:96-223):
+//  * first non-'%' line "rows cols nnz"; entries "a b [w]", 1-based;
+//  * a line "a b" becomes CSR row b-1 with neighbour a-1 (row = 2nd field);
+//  * _undir appends the swapped copy of every entry, nothing is de-duplicated;
+//  * missing weight -> 1.0f, or rand()%64 when _random_edge_value;
+//  * the returned csc IS the csr (the reference builds a genuine CSC into a shadowed local
+//    and discards it); pass _genuine_csc to get the transpose instead (needed for pull-BFS
+//    on directed inputs, BASELINE config 4).
+// Returns nullptr when the file cannot be opened (as the reference) and also on a parse
+// error (the reference prints and exit(0)s there).
+inline std::shared_ptr<graph_t> load_graph(const char* _name, bool _undir = false, bool _random_edge_value = false,
+                                           bool _genuine_csc = false) {
+  FILE* f = fopen(_name, "r");
+  if (!f) return nullptr;
+  char line[100];
+  bool header = false;
+  while (fgets(line, 100, f)) {
+    if (line[0] != '%') { header = true; break; }
+  }
+  int height, width, nnz;
+  if (!header || 3 != sscanf(line, "%d %d %d", &height, &width, &nnz)) {
+    printf("Error reading %s\n", _name);
+    fclose(f);
+    return nullptr;
+  }
+  std::vector<std::tuple<int, int, float>> tuples;
+  tuples.reserve((size_t)nnz * (_undir ? 2 : 1));
+  for (int e = 0; e < nnz; ++e) {
+    int a, b, items;
+    float w;
+    if (!fgets(line, 100, f) || (items = sscanf(line, "%d %d %f", &a, &b, &w)) < 2) {
+      printf("Error reading edge lists %s\n", _name);
+      fclose(f);
+      return nullptr;
+    }
+    if (items == 2) w = _random_edge_value ? (float)(rand() % 64) : 1.0f;
+    tuples.emplace_back(a - 1, b - 1, w);
+  }
+  fclose(f);
+  if (_undir) {
+    for (int e = 0; e < nnz; ++e)
+      tuples.emplace_back(std::get<1>(tuples[e]), std::get<0>(tuples[e]), std::get<2>(tuples[e]));
+  }
+  auto csr = csr_from_tuples(height, tuples, 1);
+  std::shared_ptr<csr_t> csc = csr;
+  if (_genuine_csc && !_undir) csc = csr_from_tuples(height, tuples, 0);
+  auto g = std::make_shared<graph_t>();
+  g->undirected = _undir;
+  g->num_nodes = height;
+  g->num_edges = (int)tuples.size();
+  g->csr = csr;
+  g->csc = csc;
+  return g;
+}
+
+}  // namespace gunrock

@@ -1,0 +1,39 @@
+// gunrock/sssp/sssp_functor.hxx -- device functor for frontier Bellman-Ford SSSP.
+// Same members and semantics as the reference's sssp_functor_t
+// (gunrock/src/sssp/sssp_functor.hxx:10-36):
+//   cond_advance   nd = dist[src] + w[e]; old = atomicMin(dist+dst, nd); true iff nd < old (:20-29)
+//   apply_advance  preds[dst] = src for EVERY expanded edge, returns true (:31-34; racy by
+//                  design upstream, SURVEY F7 -- distances are what is schedule-independent)
+//   cond_filter    drop -1, drop ids already stamped this iteration, else stamp (:12-18)
+// util::atomicMin is one integer atomic on gfx950 (intrinsics.hxx) instead of a CAS loop.
+#pragma once
+#include "../intrinsics.hxx"
+#include "sssp_problem.hxx"
+
+namespace gunrock {
+namespace sssp {
+
+struct sssp_functor_t {
+  typedef sssp_problem_t::data_slice_t slice_t;
+
+  static __device__ __forceinline__ bool cond_filter(int idx, slice_t* data, int iteration) {
+    if (idx == -1) return false;
+    if (data->d_visited[idx] == iteration) return false;
+    data->d_visited[idx] = iteration;
+    return true;
+  }
+
+  static __device__ __forceinline__ bool cond_advance(int src, int dst, int edge_id, int, int, slice_t* data, int) {
+    const float new_distance = data->d_labels[src] + data->d_weights[edge_id];
+    const float old_distance = gunrock::util::atomicMin(data->d_labels + dst, new_distance);
+    return new_distance < old_distance;
+  }
+
+  static __device__ __forceinline__ bool apply_advance(int src, int dst, int, int, int, slice_t* data, int) {
+    data->d_preds[dst] = src;
+    return true;
+  }
+};
+
+}  // namespace sssp
+}  // namespace gunrock

@@ -1,0 +1,184 @@
+/*
+ * mgx.h -- C-ABI of the MI355X-native frontier traversal engine (libmgx.so).
+ *
+ * The reference (gunrock/mini) has no FFI: its boundary is a set of C++ function
+ * templates parameterised by device functors.  Device functors cannot
+ * cross a C ABI, so this header carries the operators PRE-INSTANTIATED for the
+ * in-scope functors (BFS, SSSP, PR), the building blocks (scan, load-balanced
+ * search, compaction, segmented reduce) and whole-algorithm runs.  The
+ * source-compatible template API itself lives in include/gunrock/ (*.hxx).
+ *
+ * Conventions: every entry point returns an int status (MGX_OK == 0, negative ==
+ * error), never calls exit() (the reference does: frontier.hxx:53-59,83-93,
+ * graph.hxx:107-110), never throws across the boundary.  Handles are opaque.
+ * Host buffers are caller-owned.  `stream` arguments are hipStream_t passed as
+ * void* (NULL == legacy default stream, which is what the reference uses).
+ * All ids/offsets are 32-bit like the reference (graph.hxx:19-26); counts that
+ * can exceed 2^31 are int64_t.
+ */
+#ifndef MGX_H_
+#define MGX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGX_API __attribute__((visibility("default")))
+
+/* status codes */
+#define MGX_OK 0
+#define MGX_E_INVALID (-1)           /* bad argument                                         */
+#define MGX_E_HIP (-2)               /* a HIP runtime call failed (see mgx_last_error)        */
+#define MGX_E_FRONTIER_OVERFLOW (-4) /* frontier.hxx:53-59,83-93: the reference exit(0)s here */
+#define MGX_E_NEGATIVE_WEIGHT (-5)   /* SSSP relaxes on the int view of non-negative floats   */
+#define MGX_E_NO_DEVICE (-6)
+
+typedef struct mgx_ctx_s* mgx_ctx_t;
+typedef struct mgx_graph_s* mgx_graph_t;
+typedef struct mgx_frontier_s* mgx_frontier_t;
+typedef struct mgx_bfs_s* mgx_bfs_t;
+typedef struct mgx_sssp_s* mgx_sssp_t;
+typedef struct mgx_pr_s* mgx_pr_t;
+
+MGX_API int mgx_version(void);
+MGX_API const char* mgx_strerror(int status);
+MGX_API const char* mgx_last_error(void); /* thread-local detail of the last failure */
+
+/* ---- context: replaces mgpu::standard_context_t (tests/bfs/test_bfs.cu:22) ---- */
+MGX_API int mgx_ctx_create(int device, void* stream, mgx_ctx_t* out);
+MGX_API int mgx_ctx_set_stream(mgx_ctx_t ctx, void* stream);
+MGX_API int mgx_ctx_synchronize(mgx_ctx_t ctx);
+MGX_API int mgx_ctx_destroy(mgx_ctx_t ctx);
+MGX_API int mgx_ctx_num_cus(mgx_ctx_t ctx, int* out);
+
+/* ---- graph: replaces graph_device_t + graph_to_device (graph.hxx:37-83) ----
+ * col_offsets/row_indices/row_weights == NULL mirrors the CSR into the "CSC" slots, which
+ * is what the reference always ends up doing.  weights == NULL means all 1.0f
+ * (graph.hxx:126).  upload copies from host; wrap_device borrows device pointers (e.g.
+ * torch tensors) that must outlive the graph.                                           */
+MGX_API int mgx_graph_upload(mgx_ctx_t ctx, int num_nodes, int64_t num_edges,
+                             const int* row_offsets, const int* col_indices, const float* weights,
+                             const int* col_offsets, const int* row_indices, const float* row_weights,
+                             mgx_graph_t* out);
+MGX_API int mgx_graph_wrap_device(mgx_ctx_t ctx, int num_nodes, int64_t num_edges,
+                                  const int* d_row_offsets, const int* d_col_indices, const float* d_weights,
+                                  const int* d_col_offsets, const int* d_row_indices, const float* d_row_weights,
+                                  mgx_graph_t* out);
+MGX_API int mgx_graph_free(mgx_graph_t g);
+MGX_API int mgx_graph_dims(mgx_graph_t g, int* num_nodes, int64_t* num_edges);
+/* host-side MTX text loader, bug-compatible with load_graph (graph.hxx:96-223): row = 2nd
+ * field, neighbour = 1st field, multi-edges and self loops kept, undir appends the swapped
+ * copies.  Returns malloc'd arrays to be released with mgx_host_free.                    */
+MGX_API int mgx_load_mtx(const char* path, int undir, int random_edge_value,
+                         int* num_nodes, int64_t* num_edges,
+                         int** row_offsets, int** col_indices, float** weights);
+MGX_API void mgx_host_free(void* p);
+
+/* ---- frontier: replaces frontier_t<int> (frontier.hxx:12-99) ---- */
+MGX_API int mgx_frontier_create(mgx_ctx_t ctx, int64_t capacity, mgx_frontier_t* out);
+MGX_API int mgx_frontier_free(mgx_frontier_t f);
+MGX_API int mgx_frontier_load(mgx_frontier_t f, const int* host, int64_t n);   /* load(vector)  :65-79 */
+MGX_API int mgx_frontier_fill_iota(mgx_frontier_t f, int64_t n);              /* enactor.hxx:29-34   */
+MGX_API int mgx_frontier_fill(mgx_frontier_t f, int value, int64_t n);        /* fill + load(mem_t)  */
+MGX_API int mgx_frontier_read(mgx_frontier_t f, int* host, int64_t cap, int64_t* n);
+MGX_API int mgx_frontier_resize(mgx_frontier_t f, int64_t n);                 /* resize :82-93       */
+MGX_API int mgx_frontier_size(mgx_frontier_t f, int64_t* n);
+MGX_API int mgx_frontier_capacity(mgx_frontier_t f, int64_t* n);
+MGX_API int mgx_frontier_device_ptr(mgx_frontier_t f, int** d_ptr);
+
+/* ---- building blocks (moderngpu call sites: advance.hxx:40,62; filter.hxx:18-29;
+ *      neighborhood.hxx:35,58).  Device pointers in, counts out.                       */
+/* out[i] = sum_{j<i} in[j]; *total = sum of all (transform_scan<int>, plus_t)          */
+MGX_API int mgx_scan_exclusive_i32(mgx_ctx_t ctx, const int* d_in, int64_t n, int* d_out, int64_t* total);
+/* degree scan of a frontier over the graph's row offsets (push) or col offsets (pull):
+ * d_scanned_row_offsets[i] = sum_{j<i} deg(in[j])   (advance.hxx:32-43)                 */
+MGX_API int mgx_scan_frontier_degrees(mgx_graph_t g, mgx_frontier_t in, int use_csc, int64_t* total);
+/* transform_lbs made visible: (seg, rank) of every work item of the last degree scan  */
+MGX_API int mgx_lbs_expand_debug(mgx_graph_t g, mgx_frontier_t in, int64_t total,
+                                 int* host_seg, int* host_rank);
+/* stable compaction of d_in by (d_in[i] != drop_value) -- transform_compact            */
+MGX_API int mgx_compact_i32(mgx_ctx_t ctx, const int* d_in, int64_t n, int drop_value, int* d_out, int64_t* kept);
+/* neighborhood_kernel (neighborhood.hxx:12-70) with get_value_to_reduce = d_vertex_value[nbr]:
+ * d_reduced[seg] = op over the segment's neighbours, identity for empty segments.
+ * push != 0 walks the CSR, 0 the CSC slots.                                             */
+MGX_API int mgx_segreduce_f32_plus(mgx_graph_t g, mgx_frontier_t in, int push,
+                                   const float* d_vertex_value, float identity, float* d_reduced, int64_t* nonzeros);
+MGX_API int mgx_segreduce_i32_min(mgx_graph_t g, mgx_frontier_t in, int push,
+                                  const int* d_vertex_value, int identity, int* d_reduced, int64_t* nonzeros);
+MGX_API int mgx_segreduce_i32_max(mgx_graph_t g, mgx_frontier_t in, int push,
+                                  const int* d_vertex_value, int identity, int* d_reduced, int64_t* nonzeros);
+
+/* ---- BFS: bfs_problem_t / bfs_functor_t / bfs_enactor_t (gunrock/src/bfs/) ---- */
+MGX_API int mgx_bfs_create(mgx_graph_t g, int src, mgx_bfs_t* out);       /* bfs_problem.hxx:34-46 */
+MGX_API int mgx_bfs_reset(mgx_bfs_t p, int src);
+MGX_API int mgx_bfs_free(mgx_bfs_t p);
+MGX_API int mgx_bfs_labels(mgx_bfs_t p, int* host_labels);                /* extract() :48-50      */
+MGX_API int mgx_bfs_preds(mgx_bfs_t p, int* host_preds);                  /* stay -1   */
+MGX_API int mgx_bfs_labels_device(mgx_bfs_t p, int** d_labels);
+/* advance_forward_kernel<bfs_problem_t,bfs_functor_t,false,true>  (bfs_enactor.hxx:52-57) */
+MGX_API int mgx_bfs_advance(mgx_bfs_t p, mgx_frontier_t in, mgx_frontier_t out, int iteration, int64_t* front);
+/* filter_kernel<bfs_problem_t,bfs_functor_t>                      (bfs_enactor.hxx:60-65) */
+MGX_API int mgx_bfs_filter(mgx_bfs_t p, mgx_frontier_t in, mgx_frontier_t out, int iteration, int64_t* kept);
+/* the two above in one pass over the edges: out = ids whose label this call set          */
+MGX_API int mgx_bfs_advance_filter_fused(mgx_bfs_t p, mgx_frontier_t in, mgx_frontier_t out, int iteration, int64_t* kept);
+/* gen_unvisited_kernel / sparse_to_dense_kernel / advance_backward_kernel (advance.hxx:69-160) */
+MGX_API int mgx_bfs_gen_unvisited(mgx_bfs_t p, mgx_frontier_t indices, mgx_frontier_t unvisited, int iteration, int64_t* kept);
+MGX_API int mgx_bfs_sparse_to_dense(mgx_bfs_t p, mgx_frontier_t sparse, mgx_frontier_t dense, int iteration);
+MGX_API int mgx_bfs_advance_backward(mgx_bfs_t p, mgx_frontier_t unvisited, mgx_frontier_t bitmap,
+                                     mgx_frontier_t bitmap_out, int iteration, int64_t* front);
+/* bfs_enactor_t::enact_pushpull (bfs_enactor.hxx:41-117) on the operator-per-superstep path.
+ * stats[0]=pushed iterations, [1]=total iterations, [2]=edges expanded by push,
+ * [3]=in-edges inspected by pull.                                                        */
+MGX_API int mgx_bfs_enact_pushpull(mgx_bfs_t p, float threshold, int64_t* stats);
+
+/* Whole traversal on the fused device-resident path (no per-level host round trip):
+ * labels identical to enact_pushpull's.  mode: MGX_BFS_PUSH (config 2) or
+ * MGX_BFS_DIRECTION_OPT (config 4; needs a genuine CSC for directed graphs).
+ * The call is asynchronous on the context's stream except for one 8-byte read-back per
+ * `MGX_BFS_LEVELS_PER_SYNC` levels.  stats (may be NULL):
+ *   [0] levels run  [1] vertices reached (incl. source)  [2] m_t = sum of out-degrees of
+ *   reached vertices (the TEPS numerator)  [3] edges inspected by push levels
+ *   [4] edges inspected by pull levels [5] push levels [6] level-kernel launches (incl. the
+ *   empty ones behind the last level) [7] device time of those launches in ns (HIP events on
+ *   the context's stream) [8] frontier vertices expanded (sum of per-level frontier sizes)
+ *   [9] reserved.  stats must hold 10 entries.                                            */
+#define MGX_BFS_PUSH 0
+#define MGX_BFS_DIRECTION_OPT 1
+MGX_API int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats);
+/* per-level trace of the last mgx_bfs_run: level_nf[i], level_edges[i] for i < *levels  */
+MGX_API int mgx_bfs_level_trace(mgx_bfs_t p, int cap, int64_t* level_nf, int64_t* level_edges, int* levels);
+
+/* ---- SSSP: sssp_problem_t / sssp_functor_t / sssp_enactor_t (gunrock/src/sssp/) ---- */
+MGX_API int mgx_sssp_create(mgx_graph_t g, int src, mgx_sssp_t* out);     /* sssp_problem.hxx:40-52 */
+MGX_API int mgx_sssp_reset(mgx_sssp_t p, int src);
+MGX_API int mgx_sssp_free(mgx_sssp_t p);
+MGX_API int mgx_sssp_distances(mgx_sssp_t p, float* host_dist);           /* extract() :54-57       */
+MGX_API int mgx_sssp_preds(mgx_sssp_t p, int* host_preds);
+MGX_API int mgx_sssp_distances_device(mgx_sssp_t p, float** d_dist);
+/* advance_forward_kernel<sssp_problem_t,sssp_functor_t,false,true> (sssp_enactor.hxx:49-54) */
+MGX_API int mgx_sssp_advance(mgx_sssp_t p, mgx_frontier_t in, mgx_frontier_t out, int iteration, int64_t* front);
+/* filter_kernel<sssp_problem_t,sssp_functor_t>                     (sssp_enactor.hxx:60-65) */
+MGX_API int mgx_sssp_filter(mgx_sssp_t p, mgx_frontier_t in, mgx_frontier_t out, int iteration, int64_t* kept);
+/* sssp_enactor_t::enact (sssp_enactor.hxx:40-72).  stats[0]=iterations, [1]=edge relaxations,
+ * [2]=sum of input frontier lengths.                                                      */
+MGX_API int mgx_sssp_enact(mgx_sssp_t p, float queue_sizing, int64_t* stats);
+/* fused device-resident SSSP (same fixed point): stats as above                          */
+MGX_API int mgx_sssp_run(mgx_sssp_t p, int src, int64_t* stats);
+
+/* ---- PR: pr_problem_t / pr_functor_t / pr_enactor_t (gunrock/src/pr/) ---- */
+MGX_API int mgx_pr_create(mgx_graph_t g, int max_iter, mgx_pr_t* out);    /* pr_problem.hxx:33-44   */
+MGX_API int mgx_pr_free(mgx_pr_t p);
+MGX_API int mgx_pr_enact(mgx_pr_t p, int64_t* frontier_len_per_iter, int* iterations); /* pr_enactor.hxx:41-79 */
+MGX_API int mgx_pr_ranks(mgx_pr_t p, float* host_ranks);
+
+/* ---- synthetic input: counter-based R-MAT (the reference ships none, F4) ----
+ * Writes edges [first_edge, first_edge+count) of the (scale, seed) stream to device arrays. */
+MGX_API int mgx_rmat_edges(mgx_ctx_t ctx, int scale, int64_t first_edge, int64_t count, uint64_t seed,
+                           int scramble, int* d_src, int* d_dst, float* d_weight);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGX_H_ */

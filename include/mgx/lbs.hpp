@@ -1,0 +1,234 @@
+// mgx/lbs.hpp -- load-balanced search over a scanned segment list, and its segmented reduce.
+//
+// Replaces moderngpu's transform_lbs / lbs_segreduce (reference call sites advance.hxx:62,157;
+// neighborhood.hxx:58).  Work item idx in [0,count) belongs to the segment seg with
+// segments[seg] <= idx < segments[seg+1] (segments[] is the exclusive degree scan kept in
+// graph_device_t::d_scanned_row_offsets); rank = idx - segments[seg].  Empty segments own
+// nothing and may appear in any number.
+//
+// Shape (gfx950): one 256-thread workgroup per tile of LBS_TILE consecutive work items, so
+// the dependent col_indices loads of one CSR row are consecutive lanes of a wave.  Each
+// tile finds its first/last segment with a wave-cooperative 64-ary search (4 probes for
+// 2^24 segments instead of 24 dependent loads), stages that slice of the scan in LDS and
+// every lane resolves its own item with a binary search in LDS.  Slices longer than the LDS
+// window (only possible with long runs of empty segments) fall back to searching global memory.
+#pragma once
+#include "runtime.hpp"
+#include "wave.hpp"
+
+namespace mgx {
+
+constexpr int LBS_ITEMS = 4;
+constexpr int LBS_TILE = BLOCK * LBS_ITEMS;     // 1024 work items per workgroup
+constexpr int LBS_WINDOW = LBS_TILE + 64;       // segment offsets staged in LDS
+
+// number of j in [0,n) with a[j] <= key (a sorted ascending), a in LDS or global
+template <typename A>
+__device__ __forceinline__ int upper_bound_small(const A& a, int n, int key) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] <= key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+struct lbs_tile_t {
+  long long seg_lo;     // first segment overlapping the tile
+  int nseg;             // segments staged (0 => global fallback)
+  long long seg_hi;     // last segment overlapping the tile
+};
+
+// Locate the tile's segment slice and stage it.  Must be called by all BLOCK threads.
+// s_off must hold LBS_WINDOW ints.
+__device__ __forceinline__ lbs_tile_t lbs_stage_tile(const int* __restrict__ segments, long long num_segments,
+                                                     long long first, long long last /*inclusive*/,
+                                                     int* s_off, long long* s_bounds) {
+  const int wave = threadIdx.x / WAVE;
+  if (wave == 0) {
+    long long ub = wave_upper_bound(segments, num_segments, (int)first);
+    if (lane_id() == 0) s_bounds[0] = ub - 1;
+  } else if (wave == 1) {
+    long long ub = wave_upper_bound(segments, num_segments, (int)last);
+    if (lane_id() == 0) s_bounds[1] = ub - 1;
+  }
+  __syncthreads();
+  lbs_tile_t t;
+  t.seg_lo = s_bounds[0];
+  t.seg_hi = s_bounds[1];
+  const long long span = t.seg_hi - t.seg_lo + 1;
+  t.nseg = (span <= LBS_WINDOW) ? (int)span : 0;
+  if (t.nseg) {
+    for (int j = threadIdx.x; j < t.nseg; j += BLOCK) s_off[j] = segments[t.seg_lo + j];
+  }
+  __syncthreads();
+  return t;
+}
+
+// f(idx, seg, rank) for every work item
+template <typename F>
+__global__ __launch_bounds__(BLOCK) void k_transform_lbs(F f, long long count, const int* __restrict__ segments,
+                                                          long long num_segments) {
+  __shared__ int s_off[LBS_WINDOW];
+  __shared__ long long s_bounds[2];
+  for (long long tile = blockIdx.x; tile * LBS_TILE < count; tile += gridDim.x) {
+    const long long first = tile * LBS_TILE;
+    const long long last = (first + LBS_TILE < count ? first + LBS_TILE : count) - 1;
+    lbs_tile_t t = lbs_stage_tile(segments, num_segments, first, last, s_off, s_bounds);
+#pragma unroll
+    for (int k = 0; k < LBS_ITEMS; ++k) {
+      const long long idx = first + k * BLOCK + threadIdx.x;
+      if (idx <= last) {
+        long long seg;
+        int start;
+        if (t.nseg) {
+          const int j = upper_bound_small(s_off, t.nseg, (int)idx) - 1;
+          seg = t.seg_lo + j;
+          start = s_off[j];
+        } else {
+          const int* a = segments + t.seg_lo;
+          const int j = upper_bound_small(a, (int)(t.seg_hi - t.seg_lo + 1), (int)idx) - 1;
+          seg = t.seg_lo + j;
+          start = a[j];
+        }
+        f((int)idx, (int)seg, (int)idx - start);
+      }
+    }
+    __syncthreads();   // s_off / s_bounds are reused by the next tile
+  }
+}
+
+template <typename F>
+inline void transform_lbs(F f, long long count, const int* segments, long long num_segments,
+                          standard_context_t& ctx) {
+  if (count <= 0) return;
+  long long tiles = (count + LBS_TILE - 1) / LBS_TILE;
+  const long long cap = (long long)ctx.num_cus * 32;
+  hipLaunchKernelGGL(k_transform_lbs<F>, dim3((unsigned)(tiles < cap ? tiles : cap)), dim3(BLOCK), 0, ctx.stream(), f,
+                     count, segments, num_segments);
+}
+
+// ---- segmented reduce over the same enumeration ----------------------------------------------
+// reduced[seg] = op-fold of f(idx, seg, rank) over the segment's items, identity for empty
+// segments.  Deterministic: inside a tile items fold left-to-right per segment; a segment
+// that spans tiles gets one partial per tile (carry_val/carry_seg, tile order) folded by a
+// second single-pass kernel in tile order.
+template <typename T, typename F, typename Op>
+__global__ __launch_bounds__(BLOCK) void k_lbs_segreduce(F f, long long count, const int* __restrict__ segments,
+                                                          long long num_segments, T* __restrict__ reduced, Op op,
+                                                          T identity, T* __restrict__ carry_val,
+                                                          long long* __restrict__ carry_seg) {
+  __shared__ int s_off[LBS_WINDOW];
+  __shared__ long long s_bounds[2];
+  __shared__ T s_val[LBS_TILE];
+  __shared__ int s_seg[LBS_TILE];    // segment index relative to seg_lo (global fallback: clipped)
+  const long long tile = blockIdx.x;
+  const long long first = tile * LBS_TILE;
+  const long long last = (first + LBS_TILE < count ? first + LBS_TILE : count) - 1;
+  lbs_tile_t t = lbs_stage_tile(segments, num_segments, first, last, s_off, s_bounds);
+  const int nitems = (int)(last - first + 1);
+#pragma unroll
+  for (int k = 0; k < LBS_ITEMS; ++k) {
+    const int li = k * BLOCK + threadIdx.x;
+    const long long idx = first + li;
+    if (idx <= last) {
+      long long seg;
+      int start;
+      if (t.nseg) {
+        const int j = upper_bound_small(s_off, t.nseg, (int)idx) - 1;
+        seg = t.seg_lo + j;
+        start = s_off[j];
+      } else {
+        const int* a = segments + t.seg_lo;
+        const int j = upper_bound_small(a, (int)(t.seg_hi - t.seg_lo + 1), (int)idx) - 1;
+        seg = t.seg_lo + j;
+        start = a[j];
+      }
+      s_val[li] = f((int)idx, (int)seg, (int)idx - start);
+      s_seg[li] = (int)(seg - t.seg_lo);
+    }
+  }
+  __syncthreads();
+  // one lane per run of equal segment ids: the lane holding the run's first item folds it.
+  // Runs are contiguous because items are enumerated in segment order.
+  for (int li = threadIdx.x; li < nitems; li += BLOCK) {
+    const int sg = s_seg[li];
+    if (li == 0 || s_seg[li - 1] != sg) {
+      T acc = s_val[li];
+      int e = li + 1;
+      while (e < nitems && s_seg[e] == sg) { acc = op(acc, s_val[e]); ++e; }
+      const long long seg = t.seg_lo + sg;
+      const bool opens_here = (li > 0) || (segments[seg] == (int)first);   // segment starts in this tile
+      const long long seg_end = (seg + 1 < num_segments) ? (long long)segments[seg + 1] : count;
+      const bool closes_here = (e < nitems) || (seg_end - 1 == last);
+      if (opens_here && closes_here) {
+        reduced[seg] = acc;
+      } else {
+        // spans tiles: slot 0 = piece that continues a segment begun earlier, slot 1 = piece left open
+        const int slot = opens_here ? 1 : 0;
+        carry_val[tile * 2 + slot] = acc;
+        carry_seg[tile * 2 + slot] = seg;
+      }
+    }
+  }
+}
+
+// empty segments get the identity (they own no item so no tile ever writes them)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_segreduce_fill_empty(const int* __restrict__ segments, long long num_segments,
+                                                                long long count, T* __restrict__ reduced, T identity) {
+  long long s = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (; s < num_segments; s += stride) {
+    const long long b = segments[s];
+    const long long e = (s + 1 < num_segments) ? (long long)segments[s + 1] : count;
+    if (e == b) reduced[s] = identity;
+  }
+}
+
+// fold the per-tile carries in tile order (one thread: the carry list has at most 2 entries per tile)
+template <typename T, typename Op>
+__global__ void k_segreduce_fixup(long long ntiles, const T* __restrict__ carry_val,
+                                  const long long* __restrict__ carry_seg, T* __restrict__ reduced, Op op) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  long long cur = -1;
+  T acc = T();
+  for (long long i = 0; i < ntiles * 2; ++i) {
+    const long long sg = carry_seg[i];
+    if (sg < 0) continue;
+    if (sg != cur) {
+      if (cur >= 0) reduced[cur] = acc;
+      cur = sg;
+      acc = carry_val[i];
+    } else {
+      acc = op(acc, carry_val[i]);
+    }
+  }
+  if (cur >= 0) reduced[cur] = acc;
+}
+
+inline size_t segreduce_scratch_bytes(long long count, size_t value_size) {
+  const long long tiles = (count + LBS_TILE - 1) / LBS_TILE + 1;
+  return (size_t)tiles * 2 * (value_size + sizeof(long long)) + 512;
+}
+
+template <typename T, typename F, typename Op>
+inline void lbs_segreduce(F f, long long count, const int* segments, long long num_segments, T* reduced, Op op,
+                          T identity, standard_context_t& ctx) {
+  hipStream_t st = ctx.stream();
+  if (num_segments > 0)
+    hipLaunchKernelGGL(k_segreduce_fill_empty<T>, dim3(grid_for(num_segments)), dim3(BLOCK), 0, st, segments,
+                       num_segments, count, reduced, identity);
+  if (count <= 0) return;
+  const long long tiles = (count + LBS_TILE - 1) / LBS_TILE;
+  if (segreduce_scratch_bytes(count, sizeof(T)) > ctx.scratch_bytes)
+    throw mgx_error(MGX_E_INVALID, "segreduce: scratch arena too small");
+  long long* carry_seg = (long long*)ctx.scratch;
+  T* carry_val = (T*)(carry_seg + tiles * 2);
+  MGX_HIP(hipMemsetAsync(carry_seg, 0xFF, (size_t)tiles * 2 * sizeof(long long), st));
+  hipLaunchKernelGGL((k_lbs_segreduce<T, F, Op>), dim3((unsigned)tiles), dim3(BLOCK), 0, st, f, count, segments,
+                     num_segments, reduced, op, identity, carry_val, carry_seg);
+  hipLaunchKernelGGL((k_segreduce_fixup<T, Op>), dim3(1), dim3(64), 0, st, tiles, carry_val, carry_seg, reduced, op);
+}
+
+}  // namespace mgx

@@ -1,0 +1,191 @@
+// mgx/runtime.hpp -- host-side memory/context layer of the engine (HIP, gfx950).
+//
+// Re-states the slice of the reference's memory layer that its data model touches
+// (SURVEY 2.3): mem_t<T>, standard_context_t, to_mem/from_mem/fill/dtoh/htod/dtod
+// (reference call sites: gunrock/src/graph.hxx:40-83, frontier.hxx:18-79,
+// bfs/bfs_problem.hxx:42-50, advance.hxx:30,43).  Differences by design:
+//   * operators never allocate: every context owns a scratch arena and a pinned
+//     host mailbox, sized when graphs/frontiers are created (the reference
+//     allocates 4-5 temporaries per superstep);
+//   * errors are status codes / exceptions, never exit() (frontier.hxx:53-59).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../mgx.h"
+
+namespace mgx {
+
+struct hip_error : std::runtime_error {
+  hipError_t code;
+  hip_error(hipError_t c, const char* what_, const char* file, int line)
+      : std::runtime_error(std::string(what_) + ": " + hipGetErrorString(c) + " @" + file + ":" +
+                           std::to_string(line)),
+        code(c) {}
+};
+struct mgx_error : std::runtime_error {
+  int code;
+  mgx_error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define MGX_HIP(expr)                                                  \
+  do {                                                                 \
+    hipError_t _e = (expr);                                            \
+    if (_e != hipSuccess) throw ::mgx::hip_error(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// context: one device, one stream, a scratch arena, a pinned mailbox
+// ---------------------------------------------------------------------------
+struct context_t {
+  virtual ~context_t() {}
+  virtual hipStream_t stream() const = 0;
+};
+
+struct standard_context_t : context_t {
+  int device = 0;
+  hipStream_t _stream = nullptr;   // nullptr == the legacy default stream, like the reference
+  bool own_stream = false;
+  // scratch arena (device) -- grows only outside operators
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  // pinned mailbox for the 8-byte count read-backs (advance.hxx:43, filter.hxx:21)
+  long long* mailbox = nullptr;
+  int num_cus = 256;
+
+  explicit standard_context_t(bool print_prop = false, hipStream_t s = nullptr) : _stream(s) {
+    MGX_HIP(hipGetDevice(&device));
+    hipDeviceProp_t prop;
+    MGX_HIP(hipGetDeviceProperties(&prop, device));
+    num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (print_prop) std::printf("%s : %d CUs\n", prop.name, num_cus);
+    MGX_HIP(hipHostMalloc((void**)&mailbox, 64 * sizeof(long long), hipHostMallocDefault));
+    reserve_scratch(1 << 20);
+  }
+  standard_context_t(const standard_context_t&) = delete;
+  standard_context_t& operator=(const standard_context_t&) = delete;
+  ~standard_context_t() override {
+    if (scratch) (void)hipFree(scratch);
+    if (mailbox) (void)hipHostFree(mailbox);
+  }
+  hipStream_t stream() const override { return _stream; }
+  void set_stream(hipStream_t s) { _stream = s; }
+  void synchronize() { MGX_HIP(hipStreamSynchronize(_stream)); }
+
+  // Make sure the arena holds `bytes`.  Called from constructors of graphs,
+  // frontiers and problems -- never from an operator in steady state.
+  void reserve_scratch(size_t bytes) {
+    if (bytes <= scratch_bytes) return;
+    bytes = (bytes + 4095) & ~size_t(4095);
+    if (scratch) { MGX_HIP(hipStreamSynchronize(_stream)); MGX_HIP(hipFree(scratch)); scratch = nullptr; }
+    MGX_HIP(hipMalloc(&scratch, bytes));
+    scratch_bytes = bytes;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// mem_t<T>: RAII device array (may also borrow an external device pointer)
+// ---------------------------------------------------------------------------
+template <typename T>
+class mem_t {
+  T* _ptr = nullptr;
+  size_t _size = 0;
+  bool _owned = true;
+
+ public:
+  mem_t() {}
+  mem_t(size_t count, context_t&) : _size(count) {
+    if (count) MGX_HIP(hipMalloc((void**)&_ptr, count * sizeof(T)));
+  }
+  // borrow: the caller keeps ownership (used by mgx_graph_wrap_device)
+  static mem_t borrow(T* p, size_t count) {
+    mem_t m; m._ptr = p; m._size = count; m._owned = false; return m;
+  }
+  mem_t(const mem_t&) = delete;
+  mem_t& operator=(const mem_t&) = delete;
+  mem_t(mem_t&& r) noexcept { swap(r); }
+  mem_t& operator=(mem_t&& r) noexcept { swap(r); return *this; }
+  ~mem_t() { if (_ptr && _owned) (void)hipFree(_ptr); }
+  void swap(mem_t& r) noexcept { std::swap(_ptr, r._ptr); std::swap(_size, r._size); std::swap(_owned, r._owned); }
+  T* data() const { return _ptr; }
+  size_t size() const { return _size; }
+};
+
+template <typename T>
+inline hipError_t htod(T* dst, const T* src, size_t n) {
+  return n ? hipMemcpy(dst, src, n * sizeof(T), hipMemcpyHostToDevice) : hipSuccess;
+}
+template <typename T>
+inline hipError_t htod(T* dst, const std::vector<T>& src) { return htod(dst, src.data(), src.size()); }
+template <typename T>
+inline hipError_t dtoh(T* dst, const T* src, size_t n) {
+  return n ? hipMemcpy(dst, src, n * sizeof(T), hipMemcpyDeviceToHost) : hipSuccess;
+}
+template <typename T>
+inline hipError_t dtoh(std::vector<T>& dst, const T* src, size_t n) { dst.resize(n); return dtoh(dst.data(), src, n); }
+template <typename T>
+inline hipError_t dtod(T* dst, const T* src, size_t n) {
+  return n ? hipMemcpy(dst, src, n * sizeof(T), hipMemcpyDeviceToDevice) : hipSuccess;
+}
+
+template <typename T>
+inline mem_t<T> to_mem(const std::vector<T>& h, context_t& c) {
+  mem_t<T> m(h.size(), c);
+  MGX_HIP(htod(m.data(), h));
+  return m;
+}
+template <typename T>
+inline std::vector<T> from_mem(const mem_t<T>& m) {
+  std::vector<T> h;
+  MGX_HIP(dtoh(h, m.data(), m.size()));
+  return h;
+}
+
+// fill / fill_function / transform: generic element kernels -------------------
+template <typename F>
+__global__ void k_transform(F f, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) f((int)i);
+}
+inline int grid_for(long long n, int block = 256, int max_blocks = 4096) {
+  long long g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > max_blocks) g = max_blocks;
+  return (int)g;
+}
+template <typename F>
+inline void transform(F f, long long n, context_t& c) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_transform<F>, dim3(grid_for(n)), dim3(256), 0, c.stream(), f, n);
+}
+template <typename T>
+inline mem_t<T> fill(T value, size_t n, context_t& c) {
+  mem_t<T> m(n, c);
+  T* p = m.data();
+  transform([=] __device__(int i) { p[i] = value; }, (long long)n, c);
+  return m;
+}
+template <typename T, typename F>
+inline mem_t<T> fill_function(F f, size_t n, context_t& c) {
+  mem_t<T> m(n, c);
+  T* p = m.data();
+  transform([=] __device__(int i) { p[i] = f(i); }, (long long)n, c);
+  return m;
+}
+
+// reduction operators the operator API names (advance.hxx:40, pr_enactor.hxx:53)
+template <typename T> struct plus_t    { __host__ __device__ T operator()(T a, T b) const { return a + b; } };
+template <typename T> struct maximum_t { __host__ __device__ T operator()(T a, T b) const { return a > b ? a : b; } };
+template <typename T> struct minimum_t { __host__ __device__ T operator()(T a, T b) const { return a < b ? a : b; } };
+
+template <typename T>
+__device__ __forceinline__ T ldg(const T* p) { return *p; }   // no read-only path on CDNA
+
+}  // namespace mgx

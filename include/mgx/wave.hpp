@@ -1,0 +1,94 @@
+// mgx/wave.hpp -- wave64 / workgroup building blocks for gfx950 (CDNA4).
+// Everything here assumes 64-lane wavefronts and 256-thread workgroups (4 waves, one per SIMD).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace mgx {
+
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;
+constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+__device__ __forceinline__ int lane_id() {
+  return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+// number of set bits of `mask` strictly below the calling lane (v_mbcnt pair)
+__device__ __forceinline__ int rank_in_mask(u64 mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+}
+// XCD (accelerator complex die) this wave runs on, 0..7: s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4).
+// Used for placement-dependent SPEED only, never correctness.
+__device__ __forceinline__ int xcc_id() {
+  return (int)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 0xF;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_sum(T x) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    T y = __shfl_up(x, d, WAVE);
+    if (lane >= d) x += y;
+  }
+  return x;
+}
+template <typename T>
+__device__ __forceinline__ T wave_sum(T x) {
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) x += __shfl_xor(x, d, WAVE);
+  return x;
+}
+
+// Exclusive sum over the BLOCK threads of a workgroup.  `smem` needs WAVES_PER_BLOCK+1 slots of T.
+// Returns the exclusive prefix of x; *total gets the block sum.  Contains two barriers.
+template <typename T>
+__device__ __forceinline__ T block_exclusive_sum(T x, T* smem, T* total) {
+  const int lane = lane_id();
+  const int wave = threadIdx.x / WAVE;
+  T inc = wave_inclusive_sum(x);
+  if (lane == WAVE - 1) smem[wave] = inc;
+  __syncthreads();
+  T base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
+    T s = smem[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - x;
+}
+
+// Wave-cooperative upper bound on a sorted global array: returns the number of elements
+// a[i] <= key for i in [0,n) (so the last position with a[pos] <= key is result-1).
+// 64-ary search: every step narrows the window by 64x with one coalescable probe per lane.
+// All lanes of the wave must call it with identical arguments; all lanes get the result.
+template <typename T>
+__device__ __forceinline__ long long wave_upper_bound(const T* __restrict__ a, long long n, T key) {
+  const int lane = lane_id();
+  long long lo = 0, hi = n;   // invariant: a[i] <= key for i < lo, a[i] > key for i >= hi
+  while (hi - lo > WAVE) {
+    const long long step = (hi - lo + WAVE - 1) / WAVE;     // >= 2
+    const long long probe = lo + (long long)(lane + 1) * step - 1;   // last element of my slice
+    bool le = (probe < hi) ? (a[probe] <= key) : false;
+    const u64 m = __ballot(le);
+    const int k = __popcll(m);             // slices fully <= key (monotone, so a prefix)
+    const long long nlo = lo + (long long)k * step;
+    const long long nhi = (nlo + step < hi) ? nlo + step : hi;
+    lo = nlo < hi ? nlo : hi;
+    hi = nhi;
+  }
+  {
+    const long long probe = lo + lane;
+    bool le = (probe < hi) ? (a[probe] <= key) : false;
+    lo += __popcll(__ballot(le));
+  }
+  return lo;
+}
+
+}  // namespace mgx

@@ -1,0 +1,117 @@
+"""ctypes binding of libmgx.so (the C-ABI declared in include/mgx.h).
+
+The library is the product: importing this module FAILS LOUDLY when it is missing -- there is
+no Python/CPU fallback for any operator.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("MGX_LIB", os.path.join(_HERE, "libmgx.so"))
+
+MGX_OK = 0
+MGX_E_INVALID = -1
+MGX_E_HIP = -2
+MGX_E_FRONTIER_OVERFLOW = -4
+MGX_E_NEGATIVE_WEIGHT = -5
+MGX_E_NO_DEVICE = -6
+MGX_BFS_PUSH = 0
+MGX_BFS_DIRECTION_OPT = 1
+
+
+class MgxError(RuntimeError):
+    def __init__(self, status, detail):
+        super().__init__("mgx status %d: %s" % (status, detail))
+        self.status = status
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libmgx.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no fallback path." % LIB_PATH)
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_vp, _i, _i64, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+_pi, _pi64, _pf, _pvp = C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_void_p)
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "mgx_version": [],
+    "mgx_strerror": [_i],
+    "mgx_last_error": [],
+    "mgx_ctx_create": [_i, _vp, _pvp],
+    "mgx_ctx_set_stream": [_vp, _vp],
+    "mgx_ctx_synchronize": [_vp],
+    "mgx_ctx_destroy": [_vp],
+    "mgx_ctx_num_cus": [_vp, _pi],
+    "mgx_graph_upload": [_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _pvp],
+    "mgx_graph_wrap_device": [_vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _pvp],
+    "mgx_graph_free": [_vp],
+    "mgx_graph_dims": [_vp, _pi, _pi64],
+    "mgx_load_mtx": [C.c_char_p, _i, _i, _pi, _pi64, C.POINTER(_pi), C.POINTER(_pi), C.POINTER(_pf)],
+    "mgx_host_free": [_vp],
+    "mgx_frontier_create": [_vp, _i64, _pvp],
+    "mgx_frontier_free": [_vp],
+    "mgx_frontier_load": [_vp, _vp, _i64],
+    "mgx_frontier_fill_iota": [_vp, _i64],
+    "mgx_frontier_fill": [_vp, _i, _i64],
+    "mgx_frontier_read": [_vp, _vp, _i64, _pi64],
+    "mgx_frontier_resize": [_vp, _i64],
+    "mgx_frontier_size": [_vp, _pi64],
+    "mgx_frontier_capacity": [_vp, _pi64],
+    "mgx_frontier_device_ptr": [_vp, _pvp],
+    "mgx_scan_exclusive_i32": [_vp, _vp, _i64, _vp, _pi64],
+    "mgx_scan_frontier_degrees": [_vp, _vp, _i, _pi64],
+    "mgx_lbs_expand_debug": [_vp, _vp, _i64, _vp, _vp],
+    "mgx_compact_i32": [_vp, _vp, _i64, _i, _vp, _pi64],
+    "mgx_segreduce_f32_plus": [_vp, _vp, _i, _vp, _f, _vp, _pi64],
+    "mgx_segreduce_i32_min": [_vp, _vp, _i, _vp, _i, _vp, _pi64],
+    "mgx_segreduce_i32_max": [_vp, _vp, _i, _vp, _i, _vp, _pi64],
+    "mgx_bfs_create": [_vp, _i, _pvp],
+    "mgx_bfs_reset": [_vp, _i],
+    "mgx_bfs_free": [_vp],
+    "mgx_bfs_labels": [_vp, _vp],
+    "mgx_bfs_preds": [_vp, _vp],
+    "mgx_bfs_labels_device": [_vp, _pvp],
+    "mgx_bfs_advance": [_vp, _vp, _vp, _i, _pi64],
+    "mgx_bfs_filter": [_vp, _vp, _vp, _i, _pi64],
+    "mgx_bfs_advance_filter_fused": [_vp, _vp, _vp, _i, _pi64],
+    "mgx_bfs_gen_unvisited": [_vp, _vp, _vp, _i, _pi64],
+    "mgx_bfs_sparse_to_dense": [_vp, _vp, _vp, _i],
+    "mgx_bfs_advance_backward": [_vp, _vp, _vp, _vp, _i, _pi64],
+    "mgx_bfs_enact_pushpull": [_vp, _f, _pi64],
+    "mgx_bfs_run": [_vp, _i, _i, _f, _pi64],
+    "mgx_bfs_level_trace": [_vp, _i, _pi64, _pi64, _pi],
+    "mgx_sssp_create": [_vp, _i, _pvp],
+    "mgx_sssp_reset": [_vp, _i],
+    "mgx_sssp_free": [_vp],
+    "mgx_sssp_distances": [_vp, _vp],
+    "mgx_sssp_preds": [_vp, _vp],
+    "mgx_sssp_distances_device": [_vp, _pvp],
+    "mgx_sssp_advance": [_vp, _vp, _vp, _i, _pi64],
+    "mgx_sssp_filter": [_vp, _vp, _vp, _i, _pi64],
+    "mgx_sssp_enact": [_vp, _f, _pi64],
+    "mgx_sssp_run": [_vp, _i, _pi64],
+    "mgx_pr_create": [_vp, _i, _pvp],
+    "mgx_pr_free": [_vp],
+    "mgx_pr_enact": [_vp, _pi64, _pi],
+    "mgx_pr_ranks": [_vp, _vp],
+    "mgx_rmat_edges": [_vp, _i, _i64, _i64, _u64, _i, _vp, _vp, _vp],
+}
+_RESTYPES = {"mgx_strerror": C.c_char_p, "mgx_last_error": C.c_char_p, "mgx_host_free": None}
+
+for _name, _args in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError here == header/library drift
+    _fn.argtypes = _args
+    _fn.restype = _RESTYPES.get(_name, C.c_int)
+
+
+def check(status):
+    if status != MGX_OK:
+        detail = lib.mgx_last_error()
+        raise MgxError(status, (detail or b"").decode() or lib.mgx_strerror(status).decode())
+    return status

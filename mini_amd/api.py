@@ -1,0 +1,381 @@
+"""Host-side mirror of the reference's data model and operator interface over the C-ABI.
+
+Names follow the reference (gunrock/src/*.hxx): Graph ~ graph_device_t, Frontier ~ frontier_t<int>,
+BfsProblem ~ bfs_problem_t + bfs_enactor_t, SsspProblem ~ sssp_problem_t + sssp_enactor_t,
+PrProblem ~ pr_problem_t + pr_enactor_t.  Every method is one C-ABI call; nothing is computed here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+
+def _np_i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _dev_ptr(x):
+    """int device address, or an object with data_ptr() (torch tensor), or None"""
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(int(x))
+
+
+class Context:
+    """standard_context_t: one device, one stream, scratch arena (tests/bfs/test_bfs.cu:22)."""
+
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        check(lib.mgx_ctx_create(int(device), C.c_void_p(stream or 0), C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def set_stream(self, stream):
+        check(lib.mgx_ctx_set_stream(self._h, C.c_void_p(stream or 0)))
+
+    def synchronize(self):
+        check(lib.mgx_ctx_synchronize(self._h))
+
+    @property
+    def num_cus(self):
+        v = C.c_int()
+        check(lib.mgx_ctx_num_cus(self._h, C.byref(v)))
+        return v.value
+
+    def close(self):
+        if self._h:
+            lib.mgx_ctx_destroy(self._h)
+            self._h = None
+
+
+class Graph:
+    """graph_device_t (graph.hxx:37-83).  CSC slots mirror the CSR unless a CSC is given."""
+
+    def __init__(self, ctx, handle, keepalive=None):
+        self.ctx, self._h, self._keep = ctx, handle, keepalive
+        n, m = C.c_int(), C.c_int64()
+        check(lib.mgx_graph_dims(self._h, C.byref(n), C.byref(m)))
+        self.num_nodes, self.num_edges = n.value, m.value
+
+    @classmethod
+    def from_host(cls, ctx, row_offsets, col_indices, weights=None, col_offsets=None, row_indices=None,
+                  row_weights=None):
+        ro, ci = _np_i32(row_offsets), _np_i32(col_indices)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float32)
+        co = None if col_offsets is None else _np_i32(col_offsets)
+        ri = None if row_indices is None else _np_i32(row_indices)
+        rw = None if row_weights is None else np.ascontiguousarray(row_weights, dtype=np.float32)
+        h = C.c_void_p()
+        check(lib.mgx_graph_upload(ctx._h, len(ro) - 1, len(ci), _ptr(ro), _ptr(ci), _ptr(w), _ptr(co), _ptr(ri),
+                                   _ptr(rw), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_device(cls, ctx, num_nodes, num_edges, row_offsets, col_indices, weights=None, col_offsets=None,
+                    row_indices=None, row_weights=None):
+        """Borrow device arrays (torch tensors or raw addresses); they are kept alive by the Graph."""
+        h = C.c_void_p()
+        check(lib.mgx_graph_wrap_device(ctx._h, int(num_nodes), int(num_edges), _dev_ptr(row_offsets),
+                                        _dev_ptr(col_indices), _dev_ptr(weights), _dev_ptr(col_offsets),
+                                        _dev_ptr(row_indices), _dev_ptr(row_weights), C.byref(h)))
+        return cls(ctx, h, keepalive=(row_offsets, col_indices, weights, col_offsets, row_indices, row_weights))
+
+    def close(self):
+        if self._h:
+            lib.mgx_graph_free(self._h)
+            self._h = None
+
+
+def load_mtx(path, undir=False, random_edge_value=False):
+    """load_graph (graph.hxx:96-223) -> (n, row_offsets, col_indices, weights) on the host."""
+    n, m = C.c_int(), C.c_int64()
+    ro, ci, w = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_float)()
+    check(lib.mgx_load_mtx(str(path).encode(), int(undir), int(random_edge_value), C.byref(n), C.byref(m),
+                           C.byref(ro), C.byref(ci), C.byref(w)))
+    N, M = n.value, m.value
+    try:
+        offsets = np.ctypeslib.as_array(ro, (N + 1,)).copy()
+        indices = np.ctypeslib.as_array(ci, (max(M, 1),))[:M].copy()
+        weights = np.ctypeslib.as_array(w, (max(M, 1),))[:M].copy()
+    finally:
+        lib.mgx_host_free(ro)
+        lib.mgx_host_free(ci)
+        lib.mgx_host_free(w)
+    return N, offsets, indices, weights
+
+
+class Frontier:
+    """frontier_t<int> (frontier.hxx:12-99)."""
+
+    def __init__(self, ctx, capacity):
+        h = C.c_void_p()
+        check(lib.mgx_frontier_create(ctx._h, int(capacity), C.byref(h)))
+        self.ctx, self._h = ctx, h
+
+    def load(self, ids):
+        a = _np_i32(ids)
+        check(lib.mgx_frontier_load(self._h, _ptr(a), len(a)))
+        return self
+
+    def fill_iota(self, n):
+        check(lib.mgx_frontier_fill_iota(self._h, int(n)))
+        return self
+
+    def fill(self, value, n):
+        check(lib.mgx_frontier_fill(self._h, int(value), int(n)))
+        return self
+
+    def resize(self, n):
+        check(lib.mgx_frontier_resize(self._h, int(n)))
+
+    @property
+    def size(self):
+        v = C.c_int64()
+        check(lib.mgx_frontier_size(self._h, C.byref(v)))
+        return v.value
+
+    @property
+    def capacity(self):
+        v = C.c_int64()
+        check(lib.mgx_frontier_capacity(self._h, C.byref(v)))
+        return v.value
+
+    @property
+    def device_ptr(self):
+        p = C.c_void_p()
+        check(lib.mgx_frontier_device_ptr(self._h, C.byref(p)))
+        return p.value
+
+    def read(self):
+        n = self.size
+        out = np.empty(max(n, 1), dtype=np.int32)
+        got = C.c_int64()
+        check(lib.mgx_frontier_read(self._h, _ptr(out), len(out), C.byref(got)))
+        return out[:got.value]
+
+    def close(self):
+        if self._h:
+            lib.mgx_frontier_free(self._h)
+            self._h = None
+
+
+def _i64():
+    return C.c_int64()
+
+
+class BfsProblem:
+    """bfs_problem_t + bfs_enactor_t (gunrock/src/bfs/)."""
+
+    def __init__(self, graph, src=0):
+        h = C.c_void_p()
+        check(lib.mgx_bfs_create(graph._h, int(src), C.byref(h)))
+        self.graph, self._h = graph, h
+
+    def reset(self, src):
+        check(lib.mgx_bfs_reset(self._h, int(src)))
+
+    def labels(self):
+        out = np.empty(self.graph.num_nodes, dtype=np.int32)
+        check(lib.mgx_bfs_labels(self._h, _ptr(out)))
+        return out
+
+    def preds(self):
+        out = np.empty(self.graph.num_nodes, dtype=np.int32)
+        check(lib.mgx_bfs_preds(self._h, _ptr(out)))
+        return out
+
+    @property
+    def labels_device_ptr(self):
+        p = C.c_void_p()
+        check(lib.mgx_bfs_labels_device(self._h, C.byref(p)))
+        return p.value
+
+    # operators ------------------------------------------------------------------------------
+    def advance(self, fin, fout, iteration):
+        v = _i64()
+        check(lib.mgx_bfs_advance(self._h, fin._h, fout._h, int(iteration), C.byref(v)))
+        return v.value
+
+    def filter(self, fin, fout, iteration):
+        v = _i64()
+        check(lib.mgx_bfs_filter(self._h, fin._h, fout._h, int(iteration), C.byref(v)))
+        return v.value
+
+    def advance_filter_fused(self, fin, fout, iteration):
+        v = _i64()
+        check(lib.mgx_bfs_advance_filter_fused(self._h, fin._h, fout._h, int(iteration), C.byref(v)))
+        return v.value
+
+    def gen_unvisited(self, indices, unvisited, iteration=0):
+        v = _i64()
+        check(lib.mgx_bfs_gen_unvisited(self._h, indices._h, unvisited._h, int(iteration), C.byref(v)))
+        return v.value
+
+    def sparse_to_dense(self, sparse, dense, iteration):
+        check(lib.mgx_bfs_sparse_to_dense(self._h, sparse._h, dense._h, int(iteration)))
+
+    def advance_backward(self, unvisited, bitmap, bitmap_out, iteration):
+        v = _i64()
+        check(lib.mgx_bfs_advance_backward(self._h, unvisited._h, bitmap._h, bitmap_out._h, int(iteration),
+                                           C.byref(v)))
+        return v.value
+
+    # enactors -------------------------------------------------------------------------------
+    def enact_pushpull(self, threshold=None):
+        """bfs_enactor_t::enact_pushpull; default threshold 1/n like test_bfs.cu:30."""
+        if threshold is None:
+            threshold = 1.0 / max(self.graph.num_nodes, 1)
+        st = (C.c_int64 * 4)()
+        check(lib.mgx_bfs_enact_pushpull(self._h, C.c_float(threshold), st))
+        return {"pushed_iterations": st[0], "total_iterations": st[1], "pushed_edges": st[2], "pulled_edges": st[3]}
+
+    def run(self, src, mode=_lib.MGX_BFS_PUSH, alpha=0.0):
+        """Fused device-resident traversal."""
+        st = (C.c_int64 * 10)()
+        check(lib.mgx_bfs_run(self._h, int(src), int(mode), C.c_float(alpha), st))
+        return {"levels": st[0], "reached": st[1], "m_t": st[2], "push_edges": st[3], "pull_edges": st[4],
+                "push_levels": st[5], "kernel_launches": st[6], "kernel_ns": st[7], "frontier_vertices": st[8]}
+
+    def level_trace(self, cap=4096):
+        nf, ne, lv = (C.c_int64 * cap)(), (C.c_int64 * cap)(), C.c_int()
+        check(lib.mgx_bfs_level_trace(self._h, cap, nf, ne, C.byref(lv)))
+        L = min(lv.value, cap)
+        return [(nf[i], ne[i]) for i in range(L)]
+
+    def close(self):
+        if self._h:
+            lib.mgx_bfs_free(self._h)
+            self._h = None
+
+
+class SsspProblem:
+    """sssp_problem_t + sssp_enactor_t (gunrock/src/sssp/)."""
+
+    def __init__(self, graph, src=0):
+        h = C.c_void_p()
+        check(lib.mgx_sssp_create(graph._h, int(src), C.byref(h)))
+        self.graph, self._h = graph, h
+
+    def reset(self, src):
+        check(lib.mgx_sssp_reset(self._h, int(src)))
+
+    def distances(self):
+        out = np.empty(self.graph.num_nodes, dtype=np.float32)
+        check(lib.mgx_sssp_distances(self._h, _ptr(out)))
+        return out
+
+    def preds(self):
+        out = np.empty(self.graph.num_nodes, dtype=np.int32)
+        check(lib.mgx_sssp_preds(self._h, _ptr(out)))
+        return out
+
+    @property
+    def distances_device_ptr(self):
+        p = C.c_void_p()
+        check(lib.mgx_sssp_distances_device(self._h, C.byref(p)))
+        return p.value
+
+    def advance(self, fin, fout, iteration):
+        v = _i64()
+        check(lib.mgx_sssp_advance(self._h, fin._h, fout._h, int(iteration), C.byref(v)))
+        return v.value
+
+    def filter(self, fin, fout, iteration):
+        v = _i64()
+        check(lib.mgx_sssp_filter(self._h, fin._h, fout._h, int(iteration), C.byref(v)))
+        return v.value
+
+    def enact(self, queue_sizing=1.0):
+        st = (C.c_int64 * 3)()
+        check(lib.mgx_sssp_enact(self._h, C.c_float(queue_sizing), st))
+        return {"iterations": st[0], "relaxations": st[1], "frontier_total": st[2]}
+
+    def run(self, src):
+        st = (C.c_int64 * 3)()
+        check(lib.mgx_sssp_run(self._h, int(src), st))
+        return {"iterations": st[0], "relaxations": st[1], "frontier_total": st[2]}
+
+    def close(self):
+        if self._h:
+            lib.mgx_sssp_free(self._h)
+            self._h = None
+
+
+class PrProblem:
+    """pr_problem_t + pr_enactor_t (gunrock/src/pr/)."""
+
+    def __init__(self, graph, max_iter=10):
+        h = C.c_void_p()
+        check(lib.mgx_pr_create(graph._h, int(max_iter), C.byref(h)))
+        self.graph, self._h, self.max_iter = graph, h, max_iter
+
+    def enact(self):
+        lens = (C.c_int64 * max(self.max_iter, 1))()
+        it = C.c_int()
+        check(lib.mgx_pr_enact(self._h, lens, C.byref(it)))
+        return [lens[i] for i in range(it.value)]
+
+    def ranks(self):
+        out = np.empty(self.graph.num_nodes, dtype=np.float32)
+        check(lib.mgx_pr_ranks(self._h, _ptr(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            lib.mgx_pr_free(self._h)
+            self._h = None
+
+
+# building blocks ------------------------------------------------------------------------------
+def scan_exclusive_i32(ctx, d_in, n, d_out):
+    v = _i64()
+    check(lib.mgx_scan_exclusive_i32(ctx._h, _dev_ptr(d_in), int(n), _dev_ptr(d_out), C.byref(v)))
+    return v.value
+
+
+def scan_frontier_degrees(graph, frontier, use_csc=False):
+    v = _i64()
+    check(lib.mgx_scan_frontier_degrees(graph._h, frontier._h, int(use_csc), C.byref(v)))
+    return v.value
+
+
+def lbs_expand_debug(graph, frontier, total):
+    seg = np.empty(max(total, 1), dtype=np.int32)
+    rank = np.empty(max(total, 1), dtype=np.int32)
+    check(lib.mgx_lbs_expand_debug(graph._h, frontier._h, int(total), _ptr(seg), _ptr(rank)))
+    return seg[:total], rank[:total]
+
+
+def compact_i32(ctx, d_in, n, drop_value, d_out):
+    v = _i64()
+    check(lib.mgx_compact_i32(ctx._h, _dev_ptr(d_in), int(n), int(drop_value), _dev_ptr(d_out), C.byref(v)))
+    return v.value
+
+
+def segreduce(graph, frontier, d_vertex_value, identity, d_reduced, op="f32_plus", push=True):
+    v = _i64()
+    if op == "f32_plus":
+        check(lib.mgx_segreduce_f32_plus(graph._h, frontier._h, int(push), _dev_ptr(d_vertex_value),
+                                         C.c_float(identity), _dev_ptr(d_reduced), C.byref(v)))
+    elif op == "i32_min":
+        check(lib.mgx_segreduce_i32_min(graph._h, frontier._h, int(push), _dev_ptr(d_vertex_value), int(identity),
+                                        _dev_ptr(d_reduced), C.byref(v)))
+    elif op == "i32_max":
+        check(lib.mgx_segreduce_i32_max(graph._h, frontier._h, int(push), _dev_ptr(d_vertex_value), int(identity),
+                                        _dev_ptr(d_reduced), C.byref(v)))
+    else:
+        raise ValueError(op)
+    return v.value
+
+
+def rmat_edges(ctx, scale, first_edge, count, seed, scramble, d_src, d_dst, d_weight=None):
+    check(lib.mgx_rmat_edges(ctx._h, int(scale), int(first_edge), int(count), C.c_uint64(seed), int(bool(scramble)),
+                             _dev_ptr(d_src), _dev_ptr(d_dst), _dev_ptr(d_weight)))

@@ -1,0 +1,809 @@
+// mgx_capi.hip -- implementation of the C-ABI declared in include/mgx.h.
+// Pre-instantiates the operator templates of include/gunrock/*.hxx for the in-scope functors
+// (BFS, SSSP, PR) and exposes the building blocks.  Built with
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Iinclude
+// into mini_amd/libmgx.so (see __graft_entry__.build()).
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "gunrock/bfs/bfs_enactor.hxx"
+#include "gunrock/pr/pr_enactor.hxx"
+#include "gunrock/sssp/sssp_enactor.hxx"
+#include "mgx.h"
+
+using namespace gunrock;
+
+// ------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------
+struct mgx_ctx_s {
+  int device;
+  std::unique_ptr<standard_context_t> ctx;
+};
+struct mgx_graph_s {
+  mgx_ctx_s* c;
+  std::shared_ptr<graph_device_t> g;
+  bool weights_checked = false;
+  bool weights_ok = true;
+};
+struct mgx_frontier_s {
+  mgx_ctx_s* c;
+  std::shared_ptr<frontier_t<int>> f;
+};
+struct mgx_bfs_s {
+  mgx_graph_s* g;
+  std::shared_ptr<bfs::bfs_problem_t> p;
+  std::unique_ptr<bfs::bfs_enactor_t> e;              // lazily: holds two m-capacity buffers
+  std::unique_ptr<bfs::bfs_fused_enactor_t> fe;       // lazily: O(n)
+  int64_t last_stats[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+};
+struct mgx_sssp_s {
+  mgx_graph_s* g;
+  std::shared_ptr<sssp::sssp_problem_t> p;
+  std::unique_ptr<sssp::sssp_enactor_t> e;
+  float e_sizing = 0.f;
+};
+struct mgx_pr_s {
+  mgx_graph_s* g;
+  std::shared_ptr<pr::pr_problem_t> p;
+  std::unique_ptr<pr::pr_enactor_t> e;
+};
+
+static thread_local std::string g_last_error;
+
+#define MGX_TRY try {
+#define MGX_CATCH                                                  \
+  }                                                                \
+  catch (const mgx::mgx_error& e) {                                \
+    g_last_error = e.what();                                       \
+    return e.code;                                                 \
+  }                                                                \
+  catch (const mgx::hip_error& e) {                                \
+    g_last_error = e.what();                                       \
+    return MGX_E_HIP;                                              \
+  }                                                                \
+  catch (const std::exception& e) {                                \
+    g_last_error = e.what();                                       \
+    return MGX_E_INVALID;                                          \
+  }                                                                \
+  return MGX_OK;
+
+#define MGX_REQUIRE(cond, msg)                                    \
+  do {                                                             \
+    if (!(cond)) throw mgx::mgx_error(MGX_E_INVALID, msg);         \
+  } while (0)
+
+static inline void use_device(mgx_ctx_s* c) { MGX_HIP(hipSetDevice(c->device)); }
+
+// neighbourhood reduce with a plain per-vertex gather as the functor
+namespace {
+template <typename V>
+struct gather_problem_t : problem_t {
+  struct data_slice_t { const V* values; };
+  mem_t<data_slice_t> d_data_slice;
+  gather_problem_t(std::shared_ptr<graph_device_t> g, const V* values, standard_context_t& ctx) : problem_t(g) {
+    std::vector<data_slice_t> h(1);
+    h[0].values = values;
+    d_data_slice = to_mem(h, ctx);
+  }
+};
+template <typename V>
+struct gather_functor_t {
+  typedef typename gather_problem_t<V>::data_slice_t slice_t;
+  static __device__ __forceinline__ bool cond_advance(int, int, int, int, int, slice_t*, int) { return true; }
+  static __device__ __forceinline__ bool apply_advance(int, int, int, int, int, slice_t*, int) { return true; }
+  static __device__ __forceinline__ V get_value_to_reduce(int idx, slice_t* d, int) { return d->values[idx]; }
+};
+
+template <typename V, typename Op>
+int segreduce_impl(mgx_graph_t g, mgx_frontier_t in, int push, const V* vals, V identity, V* reduced, int64_t* nz) {
+  MGX_TRY
+  MGX_REQUIRE(g && in && vals && reduced, "segreduce: NULL argument");
+  use_device(g->c);
+  standard_context_t& ctx = *g->c->ctx;
+  auto prob = std::make_shared<gather_problem_t<V>>(g->g, vals, ctx);
+  std::shared_ptr<frontier_t<int>> dummy;
+  int r;
+  if (push)
+    r = oprtr::neighborhood::neighborhood_kernel<gather_problem_t<V>, gather_functor_t<V>, V, Op, false, true>(
+        prob, in->f, dummy, reduced, identity, 0, ctx);
+  else
+    r = oprtr::neighborhood::neighborhood_kernel<gather_problem_t<V>, gather_functor_t<V>, V, Op, false, false>(
+        prob, in->f, dummy, reduced, identity, 0, ctx);
+  ctx.synchronize();
+  if (nz) *nz = r;
+  MGX_CATCH
+}
+}  // namespace
+
+
+extern "C" {
+
+int mgx_version(void) { return 100; }
+
+const char* mgx_strerror(int status) {
+  switch (status) {
+    case MGX_OK: return "ok";
+    case MGX_E_INVALID: return "invalid argument";
+    case MGX_E_HIP: return "HIP runtime error";
+    case MGX_E_FRONTIER_OVERFLOW: return "frontier capacity overflow";
+    case MGX_E_NEGATIVE_WEIGHT: return "negative edge weight";
+    case MGX_E_NO_DEVICE: return "no HIP device";
+    default: return "unknown status";
+  }
+}
+const char* mgx_last_error(void) { return g_last_error.c_str(); }
+
+// ---- context -------------------------------------------------------------------------------
+int mgx_ctx_create(int device, void* stream, mgx_ctx_t* out) {
+  MGX_TRY
+  MGX_REQUIRE(out, "mgx_ctx_create: out is NULL");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    g_last_error = "no HIP device visible";
+    return MGX_E_NO_DEVICE;
+  }
+  MGX_REQUIRE(device >= 0 && device < count, "mgx_ctx_create: device ordinal out of range");
+  MGX_HIP(hipSetDevice(device));
+  auto* c = new mgx_ctx_s();
+  c->device = device;
+  c->ctx.reset(new standard_context_t(false, (hipStream_t)stream));
+  *out = c;
+  MGX_CATCH
+}
+int mgx_ctx_set_stream(mgx_ctx_t c, void* stream) {
+  MGX_TRY
+  MGX_REQUIRE(c, "ctx is NULL");
+  c->ctx->set_stream((hipStream_t)stream);
+  MGX_CATCH
+}
+int mgx_ctx_synchronize(mgx_ctx_t c) {
+  MGX_TRY
+  MGX_REQUIRE(c, "ctx is NULL");
+  use_device(c);
+  c->ctx->synchronize();
+  MGX_CATCH
+}
+int mgx_ctx_destroy(mgx_ctx_t c) {
+  MGX_TRY
+  if (c) { use_device(c); delete c; }
+  MGX_CATCH
+}
+int mgx_ctx_num_cus(mgx_ctx_t c, int* out) {
+  MGX_TRY
+  MGX_REQUIRE(c && out, "NULL argument");
+  *out = c->ctx->num_cus;
+  MGX_CATCH
+}
+
+// ---- graph ---------------------------------------------------------------------------------
+static void finish_graph(mgx_ctx_s* c, graph_device_t& g) {
+  g.d_scanned_row_offsets = mem_t<int>((size_t)g.num_nodes + 1, *c->ctx);
+  c->ctx->reserve_scratch((size_t)g.num_edges / 2 + ((size_t)g.num_nodes + 4096) * 2 + (1 << 20));
+}
+
+int mgx_graph_upload(mgx_ctx_t c, int n, int64_t m, const int* ro, const int* ci, const float* w, const int* co,
+                     const int* ri, const float* rw, mgx_graph_t* out) {
+  MGX_TRY
+  MGX_REQUIRE(c && out && ro && (ci || m == 0), "mgx_graph_upload: NULL argument");
+  MGX_REQUIRE(n >= 0 && m >= 0 && m <= 2147483647LL, "mgx_graph_upload: sizes must fit int32 (graph.hxx:19-26)");
+  MGX_REQUIRE((co == nullptr) == (ri == nullptr), "mgx_graph_upload: col_offsets and row_indices go together");
+  use_device(c);
+  auto g = std::make_shared<graph_device_t>();
+  g->num_nodes = n;
+  g->num_edges = (int)m;
+  g->d_row_offsets = mem_t<int>((size_t)n + 1, *c->ctx);
+  MGX_HIP(mgx::htod(g->d_row_offsets.data(), ro, (size_t)n + 1));
+  g->d_col_indices = mem_t<int>((size_t)m, *c->ctx);
+  MGX_HIP(mgx::htod(g->d_col_indices.data(), ci, (size_t)m));
+  if (w) {
+    g->d_col_values = mem_t<float>((size_t)m, *c->ctx);
+    MGX_HIP(mgx::htod(g->d_col_values.data(), w, (size_t)m));
+  } else {
+    g->d_col_values = mgx::fill(1.0f, (size_t)m, *c->ctx);
+  }
+  if (co) {
+    g->d_col_offsets = mem_t<int>((size_t)n + 1, *c->ctx);
+    MGX_HIP(mgx::htod(g->d_col_offsets.data(), co, (size_t)n + 1));
+    g->d_row_indices = mem_t<int>((size_t)m, *c->ctx);
+    MGX_HIP(mgx::htod(g->d_row_indices.data(), ri, (size_t)m));
+    if (rw) {
+      g->d_row_values = mem_t<float>((size_t)m, *c->ctx);
+      MGX_HIP(mgx::htod(g->d_row_values.data(), rw, (size_t)m));
+    } else {
+      g->d_row_values = mgx::fill(1.0f, (size_t)m, *c->ctx);
+    }
+    g->csc_is_csr = false;
+  } else {
+    g->d_col_offsets = mem_t<int>::borrow(g->d_row_offsets.data(), g->d_row_offsets.size());
+    g->d_row_indices = mem_t<int>::borrow(g->d_col_indices.data(), g->d_col_indices.size());
+    g->d_row_values = mem_t<float>::borrow(g->d_col_values.data(), g->d_col_values.size());
+    g->csc_is_csr = true;
+  }
+  finish_graph(c, *g);
+  c->ctx->synchronize();
+  auto* h = new mgx_graph_s();
+  h->c = c;
+  h->g = g;
+  *out = h;
+  MGX_CATCH
+}
+
+int mgx_graph_wrap_device(mgx_ctx_t c, int n, int64_t m, const int* ro, const int* ci, const float* w, const int* co,
+                          const int* ri, const float* rw, mgx_graph_t* out) {
+  MGX_TRY
+  MGX_REQUIRE(c && out && ro && (ci || m == 0), "mgx_graph_wrap_device: NULL argument");
+  MGX_REQUIRE(n >= 0 && m >= 0 && m <= 2147483647LL, "mgx_graph_wrap_device: sizes must fit int32");
+  MGX_REQUIRE((co == nullptr) == (ri == nullptr), "mgx_graph_wrap_device: col_offsets and row_indices go together");
+  use_device(c);
+  auto g = std::make_shared<graph_device_t>();
+  g->num_nodes = n;
+  g->num_edges = (int)m;
+  g->d_row_offsets = mem_t<int>::borrow((int*)ro, (size_t)n + 1);
+  g->d_col_indices = mem_t<int>::borrow((int*)ci, (size_t)m);
+  if (w) g->d_col_values = mem_t<float>::borrow((float*)w, (size_t)m);
+  else g->d_col_values = mgx::fill(1.0f, (size_t)m, *c->ctx);
+  if (co) {
+    g->d_col_offsets = mem_t<int>::borrow((int*)co, (size_t)n + 1);
+    g->d_row_indices = mem_t<int>::borrow((int*)ri, (size_t)m);
+    if (rw) g->d_row_values = mem_t<float>::borrow((float*)rw, (size_t)m);
+    else g->d_row_values = mgx::fill(1.0f, (size_t)m, *c->ctx);
+    g->csc_is_csr = false;
+  } else {
+    g->d_col_offsets = mem_t<int>::borrow(g->d_row_offsets.data(), (size_t)n + 1);
+    g->d_row_indices = mem_t<int>::borrow(g->d_col_indices.data(), (size_t)m);
+    g->d_row_values = mem_t<float>::borrow(g->d_col_values.data(), (size_t)m);
+    g->csc_is_csr = true;
+  }
+  finish_graph(c, *g);
+  c->ctx->synchronize();
+  auto* h = new mgx_graph_s();
+  h->c = c;
+  h->g = g;
+  *out = h;
+  MGX_CATCH
+}
+int mgx_graph_free(mgx_graph_t g) {
+  MGX_TRY
+  if (g) { use_device(g->c); delete g; }
+  MGX_CATCH
+}
+int mgx_graph_dims(mgx_graph_t g, int* n, int64_t* m) {
+  MGX_TRY
+  MGX_REQUIRE(g, "graph is NULL");
+  if (n) *n = g->g->num_nodes;
+  if (m) *m = g->g->num_edges;
+  MGX_CATCH
+}
+
+int mgx_load_mtx(const char* path, int undir, int random_w, int* n, int64_t* m, int** ro, int** ci, float** w) {
+  MGX_TRY
+  MGX_REQUIRE(path && n && m && ro && ci && w, "mgx_load_mtx: NULL argument");
+  auto g = load_graph(path, undir != 0, random_w != 0);
+  MGX_REQUIRE(g != nullptr, std::string("mgx_load_mtx: cannot read ") + path);
+  *n = g->num_nodes;
+  *m = g->num_edges;
+  *ro = (int*)malloc(((size_t)g->num_nodes + 1) * sizeof(int));
+  *ci = (int*)malloc(((size_t)g->num_edges + 1) * sizeof(int));
+  *w = (float*)malloc(((size_t)g->num_edges + 1) * sizeof(float));
+  memcpy(*ro, g->csr->offsets.data(), ((size_t)g->num_nodes + 1) * sizeof(int));
+  memcpy(*ci, g->csr->indices.data(), (size_t)g->num_edges * sizeof(int));
+  memcpy(*w, g->csr->edge_weights.data(), (size_t)g->num_edges * sizeof(float));
+  MGX_CATCH
+}
+void mgx_host_free(void* p) { free(p); }
+
+// ---- frontier ------------------------------------------------------------------------------
+int mgx_frontier_create(mgx_ctx_t c, int64_t capacity, mgx_frontier_t* out) {
+  MGX_TRY
+  MGX_REQUIRE(c && out && capacity >= 0, "mgx_frontier_create: bad argument");
+  use_device(c);
+  auto* h = new mgx_frontier_s();
+  h->c = c;
+  h->f = std::make_shared<frontier_t<int>>(*c->ctx, (size_t)capacity);
+  *out = h;
+  MGX_CATCH
+}
+int mgx_frontier_free(mgx_frontier_t f) {
+  MGX_TRY
+  if (f) { use_device(f->c); delete f; }
+  MGX_CATCH
+}
+int mgx_frontier_load(mgx_frontier_t f, const int* host, int64_t n) {
+  MGX_TRY
+  MGX_REQUIRE(f && (host || n == 0) && n >= 0, "mgx_frontier_load: bad argument");
+  use_device(f->c);
+  f->f->resize((size_t)n);   // throws MGX_E_FRONTIER_OVERFLOW
+  MGX_HIP(mgx::htod(f->f->data()->data(), host, (size_t)n));
+  MGX_CATCH
+}
+int mgx_frontier_fill_iota(mgx_frontier_t f, int64_t n) {
+  MGX_TRY
+  MGX_REQUIRE(f && n >= 0, "mgx_frontier_fill_iota: bad argument");
+  use_device(f->c);
+  f->f->resize((size_t)n);
+  int* p = f->f->data()->data();
+  mgx::transform([=] __device__(int i) { p[i] = i; }, n, *f->c->ctx);
+  MGX_CATCH
+}
+int mgx_frontier_fill(mgx_frontier_t f, int value, int64_t n) {
+  MGX_TRY
+  MGX_REQUIRE(f && n >= 0, "mgx_frontier_fill: bad argument");
+  use_device(f->c);
+  f->f->resize((size_t)n);
+  int* p = f->f->data()->data();
+  mgx::transform([=] __device__(int i) { p[i] = value; }, n, *f->c->ctx);
+  MGX_CATCH
+}
+int mgx_frontier_read(mgx_frontier_t f, int* host, int64_t cap, int64_t* n) {
+  MGX_TRY
+  MGX_REQUIRE(f && n, "mgx_frontier_read: bad argument");
+  use_device(f->c);
+  f->c->ctx->synchronize();
+  *n = (int64_t)f->f->size();
+  if (host) {
+    MGX_REQUIRE(cap >= *n, "mgx_frontier_read: host buffer too small");
+    MGX_HIP(mgx::dtoh(host, f->f->data()->data(), f->f->size()));
+  }
+  MGX_CATCH
+}
+int mgx_frontier_resize(mgx_frontier_t f, int64_t n) {
+  MGX_TRY
+  MGX_REQUIRE(f && n >= 0, "mgx_frontier_resize: bad argument");
+  f->f->resize((size_t)n);
+  MGX_CATCH
+}
+int mgx_frontier_size(mgx_frontier_t f, int64_t* n) {
+  MGX_TRY
+  MGX_REQUIRE(f && n, "NULL argument");
+  *n = (int64_t)f->f->size();
+  MGX_CATCH
+}
+int mgx_frontier_capacity(mgx_frontier_t f, int64_t* n) {
+  MGX_TRY
+  MGX_REQUIRE(f && n, "NULL argument");
+  *n = (int64_t)f->f->capacity();
+  MGX_CATCH
+}
+int mgx_frontier_device_ptr(mgx_frontier_t f, int** p) {
+  MGX_TRY
+  MGX_REQUIRE(f && p, "NULL argument");
+  *p = f->f->data()->data();
+  MGX_CATCH
+}
+
+// ---- building blocks -----------------------------------------------------------------------
+int mgx_scan_exclusive_i32(mgx_ctx_t c, const int* d_in, int64_t n, int* d_out, int64_t* total) {
+  MGX_TRY
+  MGX_REQUIRE(c && (d_in || n == 0) && (d_out || n == 0) && n >= 0, "mgx_scan_exclusive_i32: bad argument");
+  use_device(c);
+  c->ctx->reserve_scratch(mgx::scan_scratch_bytes(n));
+  long long t = 0;
+  mgx::transform_scan([=] __device__(long long i) { return d_in[i]; }, n, d_out, *c->ctx, &t);
+  if (total) *total = t;
+  MGX_CATCH
+}
+
+int mgx_scan_frontier_degrees(mgx_graph_t g, mgx_frontier_t in, int use_csc, int64_t* total) {
+  MGX_TRY
+  MGX_REQUIRE(g && in, "NULL argument");
+  use_device(g->c);
+  standard_context_t& ctx = *g->c->ctx;
+  g->g->ensure_scanned(in->f->capacity(), ctx);
+  const int* input_data = in->f->data()->data();
+  const int* offsets = use_csc ? g->g->d_col_offsets.data() : g->g->d_row_offsets.data();
+  long long t = 0;
+  mgx::transform_scan(
+      [=] __device__(long long i) {
+        const int v = input_data[i];
+        return offsets[v + 1] - offsets[v];
+      },
+      (long long)in->f->size(), g->g->d_scanned_row_offsets.data(), ctx, &t);
+  if (total) *total = t;
+  MGX_CATCH
+}
+
+int mgx_lbs_expand_debug(mgx_graph_t g, mgx_frontier_t in, int64_t total, int* host_seg, int* host_rank) {
+  MGX_TRY
+  MGX_REQUIRE(g && in && total >= 0 && (total == 0 || (host_seg && host_rank)), "bad argument");
+  use_device(g->c);
+  standard_context_t& ctx = *g->c->ctx;
+  if (total == 0) return MGX_OK;
+  mem_t<int> seg((size_t)total, ctx), rank((size_t)total, ctx);
+  int* ps = seg.data();
+  int* pr = rank.data();
+  mgx::transform_lbs([=] __device__(int idx, int s, int r) { ps[idx] = s; pr[idx] = r; }, total,
+                     g->g->d_scanned_row_offsets.data(), (long long)in->f->size(), ctx);
+  ctx.synchronize();
+  MGX_HIP(mgx::dtoh(host_seg, ps, (size_t)total));
+  MGX_HIP(mgx::dtoh(host_rank, pr, (size_t)total));
+  MGX_CATCH
+}
+
+int mgx_compact_i32(mgx_ctx_t c, const int* d_in, int64_t n, int drop_value, int* d_out, int64_t* kept) {
+  MGX_TRY
+  MGX_REQUIRE(c && (d_in || n == 0) && n >= 0, "mgx_compact_i32: bad argument");
+  use_device(c);
+  c->ctx->reserve_scratch(mgx::scan_scratch_bytes(n));
+  auto compact = mgx::transform_compact(n, *c->ctx);
+  const long long k = compact.upsweep([=] __device__(long long i) { return d_in[i] != drop_value; });
+  compact.downsweep([=] __device__(long long d, long long s) { d_out[d] = d_in[s]; });
+  c->ctx->synchronize();
+  if (kept) *kept = k;
+  MGX_CATCH
+}
+
+int mgx_segreduce_f32_plus(mgx_graph_t g, mgx_frontier_t in, int push, const float* v, float id, float* red,
+                           int64_t* nz) {
+  return segreduce_impl<float, mgx::plus_t<float>>(g, in, push, v, id, red, nz);
+}
+int mgx_segreduce_i32_min(mgx_graph_t g, mgx_frontier_t in, int push, const int* v, int id, int* red, int64_t* nz) {
+  return segreduce_impl<int, mgx::minimum_t<int>>(g, in, push, v, id, red, nz);
+}
+int mgx_segreduce_i32_max(mgx_graph_t g, mgx_frontier_t in, int push, const int* v, int id, int* red, int64_t* nz) {
+  return segreduce_impl<int, mgx::maximum_t<int>>(g, in, push, v, id, red, nz);
+}
+
+// ---- BFS -----------------------------------------------------------------------------------
+static bfs::bfs_enactor_t& bfs_enactor(mgx_bfs_t p) {
+  if (!p->e) p->e.reset(new bfs::bfs_enactor_t(*p->g->c->ctx, p->g->g->num_nodes, p->g->g->num_edges));
+  return *p->e;
+}
+
+int mgx_bfs_create(mgx_graph_t g, int src, mgx_bfs_t* out) {
+  MGX_TRY
+  MGX_REQUIRE(g && out, "NULL argument");
+  MGX_REQUIRE(src >= 0 && src < g->g->num_nodes, "mgx_bfs_create: src out of range");
+  use_device(g->c);
+  auto* h = new mgx_bfs_s();
+  h->g = g;
+  h->p = std::make_shared<bfs::bfs_problem_t>(g->g, (size_t)src, *g->c->ctx);
+  *out = h;
+  MGX_CATCH
+}
+int mgx_bfs_reset(mgx_bfs_t p, int src) {
+  MGX_TRY
+  MGX_REQUIRE(p, "NULL argument");
+  MGX_REQUIRE(src >= 0 && src < p->g->g->num_nodes, "mgx_bfs_reset: src out of range");
+  use_device(p->g->c);
+  p->p->reset((size_t)src, *p->g->c->ctx);
+  MGX_CATCH
+}
+int mgx_bfs_free(mgx_bfs_t p) {
+  MGX_TRY
+  if (p) { use_device(p->g->c); delete p; }
+  MGX_CATCH
+}
+int mgx_bfs_labels(mgx_bfs_t p, int* host) {
+  MGX_TRY
+  MGX_REQUIRE(p && host, "NULL argument");
+  use_device(p->g->c);
+  p->g->c->ctx->synchronize();
+  MGX_HIP(mgx::dtoh(host, p->p->d_labels.data(), (size_t)p->g->g->num_nodes));
+  MGX_CATCH
+}
+int mgx_bfs_preds(mgx_bfs_t p, int* host) {
+  MGX_TRY
+  MGX_REQUIRE(p && host, "NULL argument");
+  use_device(p->g->c);
+  p->g->c->ctx->synchronize();
+  MGX_HIP(mgx::dtoh(host, p->p->d_preds.data(), (size_t)p->g->g->num_nodes));
+  MGX_CATCH
+}
+int mgx_bfs_labels_device(mgx_bfs_t p, int** d) {
+  MGX_TRY
+  MGX_REQUIRE(p && d, "NULL argument");
+  *d = p->p->d_labels.data();
+  MGX_CATCH
+}
+
+int mgx_bfs_advance(mgx_bfs_t p, mgx_frontier_t in, mgx_frontier_t out, int iteration, int64_t* front) {
+  MGX_TRY
+  MGX_REQUIRE(p && in && out, "NULL argument");
+  use_device(p->g->c);
+  const int r = oprtr::advance::advance_forward_kernel<bfs::bfs_problem_t, bfs::bfs_functor_t, false, true>(
+      p->p, in->f, out->f, iteration, *p->g->c->ctx);
+  if (front) *front = r;
+  MGX_CATCH
+}
+int mgx_bfs_filter(mgx_bfs_t p, mgx_frontier_t in, mgx_frontier_t out, int iteration, int64_t* kept) {
+  MGX_TRY
+  MGX_REQUIRE(p && in && out, "NULL argument");
+  use_device(p->g->c);
+  const int r = oprtr::filter::filter_kernel<bfs::bfs_problem_t, bfs::bfs_functor_t>(p->p, in->f, out->f, iteration,
+                                                                                   *p->g->c->ctx);
+  if (kept) *kept = r;
+  MGX_CATCH
+}
+int mgx_bfs_advance_filter_fused(mgx_bfs_t p, mgx_frontier_t in, mgx_frontier_t out, int iteration, int64_t* kept) {
+  MGX_TRY
+  MGX_REQUIRE(p && in && out, "NULL argument");
+  use_device(p->g->c);
+  const int r = oprtr::advance::advance_filter_fused_kernel<bfs::bfs_problem_t, bfs::bfs_functor_t>(
+      p->p, in->f, out->f, iteration, *p->g->c->ctx);
+  if (kept) *kept = r;
+  MGX_CATCH
+}
+int mgx_bfs_gen_unvisited(mgx_bfs_t p, mgx_frontier_t indices, mgx_frontier_t unvisited, int iteration,
+                          int64_t* kept) {
+  MGX_TRY
+  MGX_REQUIRE(p && indices && unvisited, "NULL argument");
+  use_device(p->g->c);
+  const int r = oprtr::advance::gen_unvisited_kernel<bfs::bfs_problem_t, bfs::bfs_functor_t>(
+      p->p, indices->f, unvisited->f, iteration, *p->g->c->ctx);
+  if (kept) *kept = r;
+  MGX_CATCH
+}
+int mgx_bfs_sparse_to_dense(mgx_bfs_t p, mgx_frontier_t sparse, mgx_frontier_t dense, int iteration) {
+  MGX_TRY
+  MGX_REQUIRE(p && sparse && dense, "NULL argument");
+  use_device(p->g->c);
+  oprtr::advance::sparse_to_dense_kernel<bfs::bfs_problem_t, bfs::bfs_functor_t>(p->p, sparse->f, dense->f,
+                                                                                iteration, *p->g->c->ctx);
+  MGX_CATCH
+}
+int mgx_bfs_advance_backward(mgx_bfs_t p, mgx_frontier_t unvisited, mgx_frontier_t bitmap, mgx_frontier_t bitmap_out,
+                             int iteration, int64_t* front) {
+  MGX_TRY
+  MGX_REQUIRE(p && unvisited && bitmap && bitmap_out, "NULL argument");
+  use_device(p->g->c);
+  const int r = oprtr::advance::advance_backward_kernel<bfs::bfs_problem_t, bfs::bfs_functor_t>(
+      p->p, unvisited->f, bitmap->f, bitmap_out->f, iteration, *p->g->c->ctx);
+  if (front) *front = r;
+  MGX_CATCH
+}
+int mgx_bfs_enact_pushpull(mgx_bfs_t p, float threshold, int64_t* stats) {
+  MGX_TRY
+  MGX_REQUIRE(p, "NULL argument");
+  use_device(p->g->c);
+  bfs::bfs_enactor_t& e = bfs_enactor(p);
+  e.enact_pushpull(p->p, threshold, *p->g->c->ctx);
+  p->g->c->ctx->synchronize();
+  if (stats) {
+    stats[0] = e.pushed_iterations;
+    stats[1] = e.total_iterations;
+    stats[2] = e.pushed_edges;
+    stats[3] = e.pulled_edges;
+  }
+  MGX_CATCH
+}
+
+int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats) {
+  MGX_TRY
+  MGX_REQUIRE(p, "NULL argument");
+  MGX_REQUIRE(src >= 0 && src < p->g->g->num_nodes, "mgx_bfs_run: src out of range");
+  MGX_REQUIRE(mode == MGX_BFS_PUSH, "mgx_bfs_run: only MGX_BFS_PUSH is implemented in this build");
+  (void)alpha;
+  use_device(p->g->c);
+  standard_context_t& ctx = *p->g->c->ctx;
+  if (!p->fe) p->fe.reset(new bfs::bfs_fused_enactor_t(ctx, p->g->g->num_nodes));
+  p->p->src = src;
+  p->fe->enact(p->p, ctx);
+  const mgx::bfs_ctrl_t* hc = p->fe->fused.host_ctrl;
+  p->last_stats[0] = hc->levels;
+  p->last_stats[1] = (int64_t)hc->reached;
+  p->last_stats[2] = (int64_t)hc->sum_edges;
+  p->last_stats[3] = (int64_t)hc->sum_edges;
+  p->last_stats[4] = 0;
+  p->last_stats[5] = hc->levels;
+  p->last_stats[6] = p->fe->fused.level_kernel_launches;
+  p->last_stats[7] = (int64_t)(p->fe->fused.level_kernel_ms * 1e6);
+  p->last_stats[8] = (int64_t)hc->sum_frontier;
+  p->last_stats[9] = 0;
+  if (stats) memcpy(stats, p->last_stats, sizeof(p->last_stats));
+  MGX_CATCH
+}
+int mgx_bfs_level_trace(mgx_bfs_t p, int cap, int64_t* level_nf, int64_t* level_edges, int* levels) {
+  MGX_TRY
+  MGX_REQUIRE(p && levels, "NULL argument");
+  MGX_REQUIRE(p->fe != nullptr, "mgx_bfs_level_trace: no mgx_bfs_run yet");
+  const mgx::bfs_ctrl_t* hc = p->fe->fused.host_ctrl;
+  const int L = hc->levels < mgx::BFS_MAX_TRACE ? hc->levels : mgx::BFS_MAX_TRACE;
+  *levels = L;
+  for (int i = 0; i < L && i < cap; ++i) {
+    if (level_nf) level_nf[i] = (int64_t)(hc->trace[i] >> mgx::BFS_VSHIFT);
+    if (level_edges) level_edges[i] = (int64_t)(hc->trace[i] & mgx::BFS_EMASK);
+  }
+  MGX_CATCH
+}
+
+// ---- SSSP ----------------------------------------------------------------------------------
+static void check_weights(mgx_graph_t g) {
+  if (g->weights_checked) return;
+  standard_context_t& ctx = *g->c->ctx;
+  mem_t<int> flag = mgx::fill<int>(0, 1, ctx);
+  int* pf = flag.data();
+  const float* w = g->g->d_col_values.data();
+  mgx::transform([=] __device__(int i) { if (!(w[i] >= 0.0f)) *pf = 1; }, g->g->num_edges, ctx);
+  ctx.synchronize();
+  g->weights_ok = (mgx::from_mem(flag)[0] == 0);
+  g->weights_checked = true;
+}
+
+int mgx_sssp_create(mgx_graph_t g, int src, mgx_sssp_t* out) {
+  MGX_TRY
+  MGX_REQUIRE(g && out, "NULL argument");
+  MGX_REQUIRE(src >= 0 && src < g->g->num_nodes, "mgx_sssp_create: src out of range");
+  use_device(g->c);
+  check_weights(g);
+  if (!g->weights_ok) throw mgx::mgx_error(MGX_E_NEGATIVE_WEIGHT, "mgx_sssp_create: negative or NaN edge weight");
+  auto* h = new mgx_sssp_s();
+  h->g = g;
+  h->p = std::make_shared<sssp::sssp_problem_t>(g->g, (size_t)src, *g->c->ctx);
+  *out = h;
+  MGX_CATCH
+}
+int mgx_sssp_reset(mgx_sssp_t p, int src) {
+  MGX_TRY
+  MGX_REQUIRE(p, "NULL argument");
+  MGX_REQUIRE(src >= 0 && src < p->g->g->num_nodes, "mgx_sssp_reset: src out of range");
+  use_device(p->g->c);
+  p->p->reset((size_t)src, *p->g->c->ctx);
+  MGX_CATCH
+}
+int mgx_sssp_free(mgx_sssp_t p) {
+  MGX_TRY
+  if (p) { use_device(p->g->c); delete p; }
+  MGX_CATCH
+}
+int mgx_sssp_distances(mgx_sssp_t p, float* host) {
+  MGX_TRY
+  MGX_REQUIRE(p && host, "NULL argument");
+  use_device(p->g->c);
+  p->g->c->ctx->synchronize();
+  MGX_HIP(mgx::dtoh(host, p->p->d_labels.data(), (size_t)p->g->g->num_nodes));
+  MGX_CATCH
+}
+int mgx_sssp_preds(mgx_sssp_t p, int* host) {
+  MGX_TRY
+  MGX_REQUIRE(p && host, "NULL argument");
+  use_device(p->g->c);
+  p->g->c->ctx->synchronize();
+  MGX_HIP(mgx::dtoh(host, p->p->d_preds.data(), (size_t)p->g->g->num_nodes));
+  MGX_CATCH
+}
+int mgx_sssp_distances_device(mgx_sssp_t p, float** d) {
+  MGX_TRY
+  MGX_REQUIRE(p && d, "NULL argument");
+  *d = p->p->d_labels.data();
+  MGX_CATCH
+}
+int mgx_sssp_advance(mgx_sssp_t p, mgx_frontier_t in, mgx_frontier_t out, int iteration, int64_t* front) {
+  MGX_TRY
+  MGX_REQUIRE(p && in && out, "NULL argument");
+  use_device(p->g->c);
+  const int r = oprtr::advance::advance_forward_kernel<sssp::sssp_problem_t, sssp::sssp_functor_t, false, true>(
+      p->p, in->f, out->f, iteration, *p->g->c->ctx);
+  if (front) *front = r;
+  MGX_CATCH
+}
+int mgx_sssp_filter(mgx_sssp_t p, mgx_frontier_t in, mgx_frontier_t out, int iteration, int64_t* kept) {
+  MGX_TRY
+  MGX_REQUIRE(p && in && out, "NULL argument");
+  use_device(p->g->c);
+  const int r = oprtr::filter::filter_kernel<sssp::sssp_problem_t, sssp::sssp_functor_t>(p->p, in->f, out->f,
+                                                                                       iteration, *p->g->c->ctx);
+  if (kept) *kept = r;
+  MGX_CATCH
+}
+int mgx_sssp_enact(mgx_sssp_t p, float queue_sizing, int64_t* stats) {
+  MGX_TRY
+  MGX_REQUIRE(p && queue_sizing > 0, "bad argument");
+  use_device(p->g->c);
+  standard_context_t& ctx = *p->g->c->ctx;
+  if (!p->e || p->e_sizing != queue_sizing) {
+    p->e.reset();
+    p->e.reset(new sssp::sssp_enactor_t(ctx, p->g->g->num_nodes, p->g->g->num_edges, queue_sizing));
+    p->e_sizing = queue_sizing;
+  }
+  p->e->enact(p->p, ctx);
+  ctx.synchronize();
+  if (stats) {
+    stats[0] = p->e->iterations;
+    stats[1] = p->e->relaxations;
+    stats[2] = p->e->frontier_total;
+  }
+  MGX_CATCH
+}
+int mgx_sssp_run(mgx_sssp_t p, int src, int64_t* stats) {
+  // first build: the whole-run entry point resets and drives the operator-per-superstep loop
+  // with queue_sizing 1.5 (tests/sssp/run.sh:1); a device-resident fused loop replaces it later.
+  int rc = mgx_sssp_reset(p, src);
+  if (rc != MGX_OK) return rc;
+  return mgx_sssp_enact(p, 1.5f, stats);
+}
+
+// ---- PR ------------------------------------------------------------------------------------
+int mgx_pr_create(mgx_graph_t g, int max_iter, mgx_pr_t* out) {
+  MGX_TRY
+  MGX_REQUIRE(g && out && max_iter >= 0, "bad argument");
+  use_device(g->c);
+  auto* h = new mgx_pr_s();
+  h->g = g;
+  h->p = std::make_shared<pr::pr_problem_t>(g->g, max_iter, *g->c->ctx);
+  *out = h;
+  MGX_CATCH
+}
+int mgx_pr_free(mgx_pr_t p) {
+  MGX_TRY
+  if (p) { use_device(p->g->c); delete p; }
+  MGX_CATCH
+}
+int mgx_pr_enact(mgx_pr_t p, int64_t* lens, int* iterations) {
+  MGX_TRY
+  MGX_REQUIRE(p, "NULL argument");
+  use_device(p->g->c);
+  standard_context_t& ctx = *p->g->c->ctx;
+  if (!p->e) p->e.reset(new pr::pr_enactor_t(ctx, p->g->g->num_nodes, p->g->g->num_edges));
+  p->e->enact(p->p, ctx);
+  ctx.synchronize();
+  if (iterations) *iterations = (int)p->e->frontier_lengths.size();
+  if (lens)
+    for (size_t i = 0; i < p->e->frontier_lengths.size(); ++i) lens[i] = p->e->frontier_lengths[i];
+  MGX_CATCH
+}
+int mgx_pr_ranks(mgx_pr_t p, float* host) {
+  MGX_TRY
+  MGX_REQUIRE(p && host, "NULL argument");
+  use_device(p->g->c);
+  p->g->c->ctx->synchronize();
+  MGX_HIP(mgx::dtoh(host, p->p->d_current_ranks.data(), (size_t)p->g->g->num_nodes));
+  MGX_CATCH
+}
+
+}  // extern "C"
+
+// ---- R-MAT generator (spec: oracle/oracle.c orc_rmat_edges) -----------------------
+namespace {
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ unsigned scramble(unsigned v, int scale, unsigned mask) {
+  v = (v * 0x9E3779B1u + 0x7F4A7C15u) & mask;
+  v = __brev(v) >> (32 - scale);
+  v = (v * 0x85EBCA6Bu + 0xC2B2AE35u) & mask;
+  return v;
+}
+__global__ void k_rmat_edges(int scale, long long first_edge, long long count, unsigned long long seed, int do_scramble,
+                             int* __restrict__ src, int* __restrict__ dst, float* __restrict__ weight) {
+  const unsigned long long K0 = 0xD1B54A32D192ED03ull, K1 = 0x8CB92BA72F3D8DD7ull, K2 = 0xA24BAED4963EE407ull;
+  const unsigned A = 2448131358u, AB = 3264175144u, ABC = 4080218931u;
+  const unsigned mask = (scale >= 32) ? 0xFFFFFFFFu : ((1u << scale) - 1u);
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) {
+    const unsigned long long e = (unsigned long long)(first_edge + i);
+    const unsigned long long x = mix64(seed * K0 + e);
+    unsigned s = 0, d = 0;
+    for (int l = 0; l < scale; ++l) {
+      const unsigned u = (unsigned)(mix64(x + (unsigned long long)(l + 1) * K1) >> 32);
+      const unsigned sb = (u >= AB) ? 1u : 0u;
+      const unsigned db = (u < A) ? 0u : (u < AB) ? 1u : (u < ABC) ? 0u : 1u;
+      s = (s << 1) | sb;
+      d = (d << 1) | db;
+    }
+    if (do_scramble) { s = scramble(s, scale, mask); d = scramble(d, scale, mask); }
+    src[i] = (int)s;
+    dst[i] = (int)d;
+    if (weight) weight[i] = (float)(mix64(seed * K0 + e + K2) % 64ull);
+  }
+}
+}  // namespace
+
+extern "C" int mgx_rmat_edges(mgx_ctx_t c, int scale, int64_t first_edge, int64_t count, uint64_t seed, int scramble_ids,
+                              int* d_src, int* d_dst, float* d_weight) {
+  MGX_TRY
+  MGX_REQUIRE(c && d_src && d_dst && scale >= 1 && scale <= 31 && count >= 0 && first_edge >= 0,
+              "mgx_rmat_edges: bad argument");
+  use_device(c);
+  if (count > 0)
+    hipLaunchKernelGGL(k_rmat_edges, dim3(mgx::grid_for(count, 256, 8192)), dim3(256), 0, c->ctx->stream(), scale,
+                       (long long)first_edge, (long long)count, (unsigned long long)seed, scramble_ids, d_src, d_dst,
+                       d_weight);
+  MGX_CATCH
+}

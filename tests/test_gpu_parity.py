@@ -1,0 +1,409 @@
+"""GPU suite (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle on the same
+seeded inputs, the committed golden fixtures, and size-independent properties at large sizes.
+Bar: bit-exact for every integer array; SSSP distances bit-exact (weights are small integers, so
+every float32 path sum is exact -- tolerance stated by the north star is 1e-6 relative)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASES = json.load(open(os.path.join(GOLD, "reference_goldens.json")))["cases"]
+FLT_MAX = np.finfo(np.float32).max
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    return torch
+
+
+def _graph(ctx, ro, ci, w=None, csc=None):
+    import mini_amd
+    if csc is None:
+        return mini_amd.Graph.from_host(ctx, ro, ci, w)
+    return mini_amd.Graph.from_host(ctx, ro, ci, w, csc[0], csc[1])
+
+
+@pytest.fixture(scope="module")
+def rmat_graphs(oracle):
+    """oracle-built CSRs (host) for several scales; seeded"""
+    out = {}
+    for scale, seed in ((8, 1), (10, 10), (13, 13), (16, 16)):
+        out[scale] = oracle.rmat_csr(scale, 16, seed)
+    return out
+
+
+# ---- generator -----------------------------------------------------------------------------
+@pytest.mark.parametrize("scale,seed,scramble", [(6, 3, True), (10, 10, True), (10, 10, False), (17, 99, True)])
+def test_rmat_generator_matches_spec(gpu_ctx, oracle, torch_mod, scale, seed, scramble):
+    import mini_amd
+    torch = torch_mod
+    count, first = 5000, 12345
+    s = torch.empty(count, dtype=torch.int32, device="cuda")
+    d = torch.empty(count, dtype=torch.int32, device="cuda")
+    w = torch.empty(count, dtype=torch.float32, device="cuda")
+    mini_amd.rmat_edges(gpu_ctx, scale, first, count, seed, scramble, s, d, w)
+    gpu_ctx.synchronize()
+    es, ed, ew = oracle.rmat_edges(scale, first, count, seed, scramble)
+    assert np.array_equal(s.cpu().numpy(), es)
+    assert np.array_equal(d.cpu().numpy(), ed)
+    assert np.array_equal(w.cpu().numpy(), ew)
+
+
+def test_rmat_csr_builder_matches_oracle_loader_semantics(gpu_ctx, oracle):
+    from mini_amd import rmat
+    g = rmat.rmat_csr(gpu_ctx, scale=11, edgefactor=16, seed=11, weighted=True)
+    n, ro, ci, w = oracle.rmat_csr(11, 16, 11)
+    assert g["n"] == n and g["m"] == len(ci)
+    assert np.array_equal(g["row_offsets"].cpu().numpy(), ro)
+    assert np.array_equal(g["col_indices"].cpu().numpy(), ci)
+    assert np.array_equal(g["weights"].cpu().numpy(), w)
+
+
+# ---- building blocks -----------------------------------------------------------------------
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 2047, 2048, 2049, 100000, 1 << 21])
+def test_scan_exclusive(gpu_ctx, torch_mod, n):
+    import mini_amd
+    torch = torch_mod
+    rng = np.random.default_rng(n)
+    h = rng.integers(0, 1000, size=max(n, 1), dtype=np.int32)[:n]
+    d_in = torch.from_numpy(np.ascontiguousarray(h)).cuda() if n else torch.empty(1, dtype=torch.int32, device="cuda")
+    d_out = torch.empty(max(n, 1), dtype=torch.int32, device="cuda")
+    total = mini_amd.scan_exclusive_i32(gpu_ctx, d_in, n, d_out)
+    want = np.concatenate([[0], np.cumsum(h, dtype=np.int64)])
+    assert total == want[-1]
+    assert np.array_equal(d_out.cpu().numpy()[:n], want[:-1].astype(np.int32))
+
+
+@pytest.mark.parametrize("n,keep", [(0, 0.5), (1, 1.0), (64, 0.0), (2049, 0.3), (1 << 20, 0.02), (1 << 20, 0.97)])
+def test_compact_is_stable_and_exact(gpu_ctx, torch_mod, n, keep):
+    import mini_amd
+    torch = torch_mod
+    rng = np.random.default_rng(n + int(keep * 100))
+    h = rng.integers(0, 1 << 30, size=max(n, 1), dtype=np.int32)[:n]
+    h[rng.random(n) >= keep] = -1
+    d_in = torch.from_numpy(np.ascontiguousarray(h)).cuda() if n else torch.empty(1, dtype=torch.int32, device="cuda")
+    d_out = torch.full((max(n, 1),), -7, dtype=torch.int32, device="cuda")
+    kept = mini_amd.compact_i32(gpu_ctx, d_in, n, -1, d_out)
+    want = h[h != -1]
+    assert kept == len(want)
+    assert np.array_equal(d_out.cpu().numpy()[:kept], want)
+
+
+def test_lbs_enumeration_with_empty_and_huge_segments(gpu_ctx, oracle):
+    import mini_amd
+    # degrees: a hub of 5000, runs of empty rows, small rows
+    deg = np.array([0, 0, 5000, 1, 0, 0, 0, 3, 2000, 0, 1, 1, 1, 0, 700], dtype=np.int64)
+    ro = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    ci = np.zeros(ro[-1], dtype=np.int32)
+    g = _graph(gpu_ctx, ro, ci)
+    rng = np.random.default_rng(5)
+    ids = np.concatenate([rng.integers(0, len(deg), size=300), np.zeros(1500, dtype=np.int64),
+                          [2, 8, 2]]).astype(np.int32)
+    f = mini_amd.Frontier(gpu_ctx, len(ids)).load(ids)
+    total = mini_amd.scan_frontier_degrees(g, f)
+    scanned, want_total = oracle.scan_degrees(ro, ids)
+    assert total == want_total
+    seg, rank = mini_amd.lbs_expand_debug(g, f, total)
+    wseg, wrank = oracle.lbs(scanned, want_total)
+    assert np.array_equal(seg, wseg) and np.array_equal(rank, wrank)
+    # empty frontier / frontier of isolated vertices
+    f0 = mini_amd.Frontier(gpu_ctx, 4).load(np.array([0, 1, 4], dtype=np.int32))
+    assert mini_amd.scan_frontier_degrees(g, f0) == 0
+    f1 = mini_amd.Frontier(gpu_ctx, 4).load(np.zeros(0, dtype=np.int32))
+    assert mini_amd.scan_frontier_degrees(g, f1) == 0
+
+
+@pytest.mark.parametrize("op", ["f32_plus", "i32_min", "i32_max"])
+def test_neighbour_reduce_matches_oracle(gpu_ctx, oracle, torch_mod, rmat_graphs, op):
+    import mini_amd
+    torch = torch_mod
+    n, ro, ci, w = rmat_graphs[13]
+    g = _graph(gpu_ctx, ro, ci)
+    rng = np.random.default_rng(3)
+    ids = rng.permutation(n)[: n // 2].astype(np.int32)
+    ids[:3] = int(np.argmax(np.diff(ro)))          # the hub three times: segments that span tiles
+    f = mini_amd.Frontier(gpu_ctx, n).load(ids)
+    if op == "f32_plus":
+        vals = rng.integers(0, 8, size=n).astype(np.float32)   # small ints: float sums are exact
+        dv = torch.from_numpy(vals).cuda()
+        red = torch.full((len(ids),), -1, dtype=torch.float32, device="cuda")
+        nz = mini_amd.segreduce(g, f, dv, 0.0, red, op)
+        want, wnz = oracle.neighbor_reduce_f32_plus(ro, ci, ids, vals, 0.0)
+    else:
+        vals = rng.integers(-1000, 1000, size=n).astype(np.int32)
+        dv = torch.from_numpy(vals).cuda()
+        ident = 2**31 - 1 if op == "i32_min" else -2**31
+        red = torch.full((len(ids),), 12345, dtype=torch.int32, device="cuda")
+        nz = mini_amd.segreduce(g, f, dv, ident, red, op)
+        want, wnz = oracle.neighbor_reduce_i32(ro, ci, ids, vals, ident, op == "i32_max")
+    assert nz == wnz
+    assert np.array_equal(red.cpu().numpy(), want)
+
+
+# ---- golden fixtures through the C-ABI -------------------------------------------------------
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_reference_fixtures_bfs_and_sssp(gpu_ctx, oracle, case):
+    import mini_amd
+    n, ro, ci, w = mini_amd.load_mtx(os.path.join(GOLD, case["file"]), undir=case["undir"])
+    g = _graph(gpu_ctx, ro, ci, w)
+    want = np.array(case["bfs_labels"], dtype=np.int32)
+    bfs = mini_amd.BfsProblem(g, 0)
+    st = bfs.run(0)
+    assert bfs.labels().tolist() == want.tolist()
+    assert st["reached"] == int((want >= 0).sum())
+    assert st["m_t"] == int(np.diff(ro)[want >= 0].sum())
+    assert np.all(bfs.preds() == -1)
+    if len(ci) >= 1:
+        bfs.reset(0)
+        bfs.enact_pushpull()                                          # alpha = 1/n (test_bfs.cu:30)
+        assert bfs.labels().tolist() == want.tolist()
+        if case["undir"] and len(ci) >= n:
+            for alpha in (0.5, 4.0):
+                bfs.reset(0)
+                bfs.enact_pushpull(alpha)
+                assert bfs.labels().tolist() == want.tolist(), alpha
+    # SSSP distances == the reference CPU validator's int distances (exact), unreachable = FLT_MAX
+    _, idist = oracle.sssp_cpu(ro, ci, w, 0)
+    sssp = mini_amd.SsspProblem(g, 0)
+    sssp.enact(1.5 if len(ci) else 1.0) if len(ci) else None
+    if len(ci):
+        dist = sssp.distances()
+        reach = idist < np.iinfo(np.int32).max
+        assert np.array_equal(dist[reach], idist[reach].astype(np.float32))
+        assert np.all(dist[~reach] == FLT_MAX)
+        if "sssp_dist" in case:
+            assert dist.tolist() == [float(x) for x in case["sssp_dist"]]
+
+
+# ---- operators, one superstep at a time --------------------------------------------------------
+def test_bfs_operators_superstep_by_superstep(gpu_ctx, oracle, rmat_graphs):
+    import mini_amd
+    n, ro, ci, w = rmat_graphs[10]
+    m = len(ci)
+    g = _graph(gpu_ctx, ro, ci)
+    src = int(np.argmax(np.diff(ro)))
+    bfs = mini_amd.BfsProblem(g, src)
+    fa, fb = mini_amd.Frontier(gpu_ctx, m), mini_amd.Frontier(gpu_ctx, m)
+    fa.load(np.array([src], dtype=np.int32))
+    o_labels = np.full(n, -1, dtype=np.int32)
+    o_labels[src] = 0
+    o_front = np.array([src], dtype=np.int32)
+    for it in range(32):
+        front = bfs.advance(fa, fb, it)
+        raw = fb.read()
+        o_raw = oracle.bfs_advance(ro, ci, o_labels, o_front, it)
+        assert front == len(o_raw) == len(raw)
+        # which duplicate edge wins the CAS is schedule dependent; the SET of winners and the
+        # positions of -1 for already-labelled targets are not
+        assert set(raw[raw >= 0].tolist()) == set(o_raw[o_raw >= 0].tolist())
+        assert len(raw[raw >= 0]) == len(o_raw[o_raw >= 0])            # exactly one winner each
+        assert np.array_equal(bfs.labels(), o_labels)
+        if front == 0:
+            break
+        kept = bfs.filter(fb, fa, it)
+        out = fa.read()
+        assert kept == len(out)
+        assert np.array_equal(out, raw[raw != -1])                      # stable compaction
+        o_front = np.sort(oracle.bfs_filter(o_raw))
+        assert np.array_equal(np.sort(out), o_front)
+        if kept == 0:
+            break
+        fa.load(o_front)     # same order on both sides from here
+    assert np.array_equal(bfs.labels(), oracle.bfs_cpu(ro, ci, src))
+
+
+def test_bfs_fused_operator_equals_advance_plus_filter(gpu_ctx, oracle, rmat_graphs):
+    import mini_amd
+    n, ro, ci, w = rmat_graphs[13]
+    g = _graph(gpu_ctx, ro, ci)
+    src = int(np.argmax(np.diff(ro)))
+    bfs = mini_amd.BfsProblem(g, src)
+    fa, fb = mini_amd.Frontier(gpu_ctx, n), mini_amd.Frontier(gpu_ctx, n)
+    fa.load(np.array([src], dtype=np.int32))
+    want = oracle.bfs_cpu(ro, ci, src)
+    for it in range(64):
+        kept = bfs.advance_filter_fused(fa, fb, it)
+        ids = fb.read()
+        assert kept == len(ids)
+        assert np.array_equal(np.sort(ids), np.where(want == it + 1)[0])
+        if kept == 0:
+            break
+        fa, fb = fb, fa
+    assert np.array_equal(bfs.labels(), want)
+
+
+# ---- whole traversals ---------------------------------------------------------------------------
+@pytest.mark.parametrize("scale", [8, 10, 13, 16])
+def test_bfs_rmat_parity_all_paths(gpu_ctx, oracle, rmat_graphs, scale):
+    import mini_amd
+    from mini_amd import rmat
+    n, ro, ci, w = rmat_graphs[scale]
+    g = _graph(gpu_ctx, ro, ci)
+    deg = np.diff(ro)
+    sources = [int(np.argmax(deg))] + rmat.pick_sources(ro, 3, scale)
+    iso = np.where(deg == 0)[0]
+    if len(iso):
+        sources.append(int(iso[0]))                                    # isolated source: only itself
+    bfs = mini_amd.BfsProblem(g, sources[0])
+    for src in sources:
+        want = oracle.bfs_cpu(ro, ci, src)
+        st = bfs.run(src)
+        got = bfs.labels()
+        assert np.array_equal(got, want), "fused, src=%d" % src
+        assert st["reached"] == int((want >= 0).sum())
+        assert st["m_t"] == int(deg[want >= 0].sum())
+        assert st["levels"] == (int(want.max()) + (1 if deg[want == want.max()].sum() > 0 else 0) if deg[src] else 0)
+        trace = bfs.level_trace()
+        for lv, (nf, ne) in enumerate(trace):
+            on = (want == lv) & (deg > 0)
+            assert nf == int(on.sum()) and ne == int(deg[on].sum())
+        for alpha in (None, 0.2, 3.0):
+            bfs.reset(src)
+            bfs.enact_pushpull(alpha)
+            assert np.array_equal(bfs.labels(), want), "pushpull alpha=%s src=%d" % (alpha, src)
+
+
+def test_bfs_directed_graph_with_zero_outdegree_vertices(gpu_ctx, oracle):
+    """directed (undir=false) graphs have reachable vertices with no out-edges: they get a label
+    but never enter the fused frontier."""
+    import mini_amd
+    rng = np.random.default_rng(7)
+    n, e = 5000, 20000
+    t0 = rng.integers(0, n, size=e).astype(np.int32)
+    t1 = rng.integers(0, n // 4, size=e).astype(np.int32)              # only a quarter have out-edges
+    ro, ci, w = oracle.csr_from_tuples(n, t0, t1, None, undir=False)
+    g = _graph(gpu_ctx, ro, ci)
+    bfs = mini_amd.BfsProblem(g, 0)
+    for src in (int(t1[0]), int(t1[1]), n - 1):
+        want = oracle.bfs_cpu(ro, ci, src)
+        bfs.run(src)
+        assert np.array_equal(bfs.labels(), want)
+        bfs.reset(src)
+        bfs.enact_pushpull()
+        assert np.array_equal(bfs.labels(), want)
+
+
+def test_bfs_long_chain_many_levels(gpu_ctx, oracle):
+    """a path graph: > levels_per_sync levels, frontier of one vertex each"""
+    import mini_amd
+    n = 300
+    t0 = np.arange(0, n - 1, dtype=np.int32)
+    t1 = np.arange(1, n, dtype=np.int32)
+    ro, ci, w = oracle.csr_from_tuples(n, t0, t1, None, undir=True)
+    g = _graph(gpu_ctx, ro, ci)
+    bfs = mini_amd.BfsProblem(g, 0)
+    st = bfs.run(0)
+    assert np.array_equal(bfs.labels(), np.arange(n, dtype=np.int32))
+    assert st["levels"] == n          # frontiers at depth 0..n-1 all expand an edge
+
+
+@pytest.mark.parametrize("scale", [8, 10, 13])
+def test_sssp_rmat_parity(gpu_ctx, oracle, rmat_graphs, scale):
+    import mini_amd
+    from mini_amd import rmat
+    n, ro, ci, w = rmat_graphs[scale]
+    g = _graph(gpu_ctx, ro, ci, w)
+    sssp = mini_amd.SsspProblem(g, 0)
+    for src in [int(np.argmax(np.diff(ro)))] + rmat.pick_sources(ro, 2, scale + 100):
+        sssp.reset(src)
+        st = sssp.enact(1.5)
+        want, _, ost = oracle.sssp_enact(ro, ci, w, src, 1.5)
+        dist = sssp.distances()
+        assert np.array_equal(dist, want), "src=%d" % src                # bit-exact (<= 1e-6 rel required)
+        preds = sssp.preds()
+        # preds are racy upstream; what must hold: pred is -1 exactly for src/unreached,
+        # and is an in-neighbour otherwise
+        fin = dist < FLT_MAX
+        assert np.all(preds[~fin] == -1)
+        for v in np.where(fin)[0][:300]:
+            if v == src:
+                continue
+            p = preds[v]
+            assert p >= 0 and v in ci[ro[p]:ro[p + 1]]
+        st2 = sssp.run(src)
+        assert np.array_equal(sssp.distances(), want)
+        assert st2["iterations"] >= 1
+
+
+def test_pr_matches_oracle(gpu_ctx, oracle, rmat_graphs):
+    import mini_amd
+    n, ro, ci, w = rmat_graphs[10]
+    g = _graph(gpu_ctx, ro, ci)
+    for iters in (1, 3):
+        pr = mini_amd.PrProblem(g, iters)
+        lens = pr.enact()
+        want, wlens = oracle.pr_enact(ro, ci, iters)
+        got = pr.ranks()
+        # float sums: segment order differs between the serial oracle and the tiled reduce
+        assert np.allclose(got, want, rtol=2e-5, atol=1e-6)
+        assert len(lens) == len(wlens)
+        if iters == 1:
+            assert lens[0] == wlens[0]
+
+
+# ---- error behaviour ------------------------------------------------------------------------------
+def test_frontier_overflow_and_bad_arguments_are_statuses(gpu_ctx, oracle, rmat_graphs):
+    import mini_amd
+    n, ro, ci, w = rmat_graphs[8]
+    g = _graph(gpu_ctx, ro, ci, w)
+    f = mini_amd.Frontier(gpu_ctx, 4)
+    with pytest.raises(mini_amd.MgxError) as e:
+        f.load(np.arange(5, dtype=np.int32))
+    assert e.value.status == mini_amd.MGX_E_FRONTIER_OVERFLOW
+    with pytest.raises(mini_amd.MgxError):
+        mini_amd.BfsProblem(g, n)                   # src out of range
+    # advance into a too-small output frontier: reference exit(0)s, we return the status
+    src = int(np.argmax(np.diff(ro)))
+    bfs = mini_amd.BfsProblem(g, src)
+    fin = mini_amd.Frontier(gpu_ctx, 4).load(np.array([src], dtype=np.int32))
+    with pytest.raises(mini_amd.MgxError) as e:
+        bfs.advance(fin, f, 0)
+    assert e.value.status == mini_amd.MGX_E_FRONTIER_OVERFLOW
+    wneg = w.copy()
+    wneg[3] = -1.0
+    gneg = _graph(gpu_ctx, ro, ci, wneg)
+    with pytest.raises(mini_amd.MgxError) as e:
+        mini_amd.SsspProblem(gneg, 0)
+    assert e.value.status == mini_amd.MGX_E_NEGATIVE_WEIGHT
+
+
+# ---- size-independent properties at a large size ---------------------------------------------------
+def test_bfs_large_rmat_properties(gpu_ctx, torch_mod):
+    """RMAT scale 20 on the device (33.5 M CSR entries): BFS-tree validity checked with device ops
+    (no oracle at this size): label[src]=0; |label[u]-label[v]|<=1 over every edge with both ends
+    reached; an edge never leaves the reached set; every reached v != src has a neighbour one
+    level closer; the fused path and the operator path agree bit for bit."""
+    import mini_amd
+    from mini_amd import rmat
+    torch = torch_mod
+    g = rmat.rmat_csr(gpu_ctx, scale=20, edgefactor=16, seed=20)
+    graph = mini_amd.Graph.from_device(gpu_ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"])
+    ro = g["row_offsets"].to(torch.int64)
+    deg = ro[1:] - ro[:-1]
+    rows = torch.repeat_interleave(torch.arange(g["n"], device="cuda"), deg)
+    cols = g["col_indices"].to(torch.int64)
+    src = rmat.pick_sources(g["row_offsets"].cpu().numpy(), 1, 20)[0]
+    bfs = mini_amd.BfsProblem(graph, src)
+    st = bfs.run(src)
+    lab = torch.from_numpy(bfs.labels()).cuda().to(torch.int64)
+    assert lab[src] == 0
+    lr, lc = lab[rows], lab[cols]
+    assert bool(((lr >= 0) == (lc >= 0)).all())
+    both = lr >= 0
+    assert int((lr[both] - lc[both]).abs().max()) <= 1
+    big = torch.full((g["n"],), 1 << 40, dtype=torch.int64, device="cuda")
+    mn = big.scatter_reduce(0, rows[both], lc[both], reduce="amin", include_self=True)
+    reached = lab >= 0
+    chk = reached.clone()
+    chk[src] = False
+    assert bool((mn[chk] == lab[chk] - 1).all())
+    assert st["reached"] == int(reached.sum()) and st["m_t"] == int(deg[reached].sum())
+    fused = bfs.labels().copy()
+    bfs.reset(src)
+    bfs.enact_pushpull()
+    assert np.array_equal(bfs.labels(), fused)

@@ -1,0 +1,112 @@
+"""CPU suite (-m "not gpu"): pins the oracle (oracle/oracle.c) to the reference's golden vectors
+(tests/golden/reference_goldens.json) and checks the restatements against each other."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASES = json.load(open(os.path.join(GOLD, "reference_goldens.json")))["cases"]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_loader_and_cpu_validators_match_reference_goldens(oracle, case):
+    n, ro, ci, w, srcs = oracle.load_mtx(os.path.join(GOLD, case["file"]), undir=case["undir"])
+    assert n == case["n"] and len(ci) == case["m"]
+    if "offsets" in case:
+        assert ro.tolist() == case["offsets"]
+        assert ci.tolist() == case["indices"]
+    if "weights" in case:
+        assert w.tolist() == case["weights"]
+    # csr.sources = row id per entry (graph.hxx:169)
+    assert srcs.tolist() == np.repeat(np.arange(n), np.diff(ro)).tolist()
+    assert oracle.bfs_cpu(ro, ci, 0).tolist() == case["bfs_labels"]          # bfs_problem.hxx:52-72
+    preds, dist = oracle.sssp_cpu(ro, ci, w, 0)                              # sssp_problem.hxx:59-88
+    assert preds.tolist() == case["sssp_preds"]
+    if "sssp_dist" in case:
+        assert dist.tolist() == case["sssp_dist"]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_enactor_restatements_agree_with_cpu_validators(oracle, case):
+    n, ro, ci, w, _ = oracle.load_mtx(os.path.join(GOLD, case["file"]), undir=case["undir"])
+    want = np.array(case["bfs_labels"], dtype=np.int32)
+    # push only (alpha = 1/n, test_bfs.cu:30)
+    rc, labels, stats = oracle.bfs_enact_pushpull(ro, ci, 0, 1.0 / n)
+    assert rc == 0 and labels.tolist() == want.tolist()
+    if case["undir"] and len(ci) >= n:
+        # the reference's pull phase walks the CSR copy (F8): right only on symmetric graphs
+        for alpha in (0.05, 0.5, 1.0, 4.0):
+            rc, labels, _ = oracle.bfs_enact_pushpull(ro, ci, 0, alpha)
+            assert rc == 0 and labels.tolist() == want.tolist(), alpha
+    # SSSP: frontier Bellman-Ford fixed point == float Dijkstra == the reference's int distances
+    dist, preds, st = oracle.sssp_enact(ro, ci, w, 0, 1.5)
+    dj = oracle.sssp_dijkstra_f32(ro, ci, w, 0)
+    assert np.array_equal(dist, dj)
+    _, idist = oracle.sssp_cpu(ro, ci, w, 0)
+    reach = idist < np.iinfo(np.int32).max
+    assert np.array_equal(dist[reach], idist[reach].astype(np.float32))
+    assert np.all(dist[~reach] == np.finfo(np.float32).max)
+
+
+def test_pull_phase_overflow_is_reported_not_exit(oracle):
+    # n > m: the reference loads an n-int bitmap into an m-capacity frontier and exit(0)s (F14)
+    ro = np.array([0, 1, 2, 2, 2, 2, 2, 2, 2], dtype=np.int32)
+    ci = np.array([1, 0], dtype=np.int32)
+    rc, _, _ = oracle.bfs_enact_pushpull(ro, ci, 0, 100.0)
+    assert rc == -4
+
+
+@pytest.mark.parametrize("scale,seed", [(8, 1), (10, 10), (12, 12), (14, 14)])
+def test_rmat_restatements_consistent(oracle, scale, seed):
+    n, ro, ci, w = oracle.rmat_csr(scale, 16, seed)
+    assert len(ci) == 2 * 16 * n and ro[-1] == len(ci)
+    # symmetric, rows sorted by neighbour
+    rows = np.repeat(np.arange(n), np.diff(ro))
+    assert np.all(np.diff(rows.astype(np.int64) * n + ci) >= 0)
+    fwd = np.sort(rows.astype(np.int64) * n + ci)
+    bwd = np.sort(ci.astype(np.int64) * n + rows)
+    assert np.array_equal(fwd, bwd)
+    assert w.min() >= 0 and w.max() <= 63 and np.all(w == np.floor(w))
+    deg = np.diff(ro)
+    src = int(np.argmax(deg))
+    want = oracle.bfs_cpu(ro, ci, src)
+    for alpha in (1.0 / n, 0.1, 2.0):
+        rc, labels, _ = oracle.bfs_enact_pushpull(ro, ci, src, alpha)
+        assert rc == 0 and np.array_equal(labels, want)
+    dist, preds, _ = oracle.sssp_enact(ro, ci, w, src, 1.5)
+    assert np.array_equal(dist, oracle.sssp_dijkstra_f32(ro, ci, w, src))
+    # every finite vertex except src has a tight predecessor edge
+    fin = np.where((dist < np.finfo(np.float32).max) & (np.arange(n) != src))[0]
+    for v in fin[:200]:
+        p = preds[v]
+        es = np.arange(ro[p], ro[p + 1])
+        assert np.any((ci[es] == v)), "pred is not a neighbour"
+
+
+def test_scramble_is_a_bijection(oracle):
+    for scale in (1, 5, 10, 16):
+        ids = np.array([oracle.lib.orc_rmat_scramble(v, scale) for v in range(1 << min(scale, 12))])
+        assert len(np.unique(ids)) == len(ids) and ids.max() < (1 << scale)
+
+
+def test_scan_and_lbs_semantics(oracle):
+    ro = np.array([0, 3, 3, 4, 4, 4, 9], dtype=np.int32)      # degrees 3 0 1 0 0 5
+    fin = np.array([1, 0, 3, 5, 4, 2, 1], dtype=np.int32)     # ragged, with empty segments
+    scanned, total = oracle.scan_degrees(ro, fin)
+    assert scanned.tolist() == [0, 0, 3, 3, 8, 8, 9] and total == 9
+    seg, rank = oracle.lbs(scanned, total)
+    assert seg.tolist() == [1, 1, 1, 3, 3, 3, 3, 3, 5]
+    assert rank.tolist() == [0, 1, 2, 0, 1, 2, 3, 4, 0]
+    s0, t0 = oracle.scan_degrees(ro, np.zeros(0, dtype=np.int32))
+    assert len(s0) == 0 and t0 == 0
+
+
+def test_pr_restatement_first_iteration_is_a_pagerank_step(oracle):
+    n, ro, ci, w, _ = oracle.load_mtx(os.path.join(GOLD, "pr_test.mtx"), undir=True)
+    ranks, lens = oracle.pr_enact(ro, ci, 1)
+    deg = np.diff(ro).astype(np.float32)
+    want = np.float32(0.15) + np.float32(0.85) * (np.float32(0.15) * deg) / deg
+    assert np.allclose(ranks, want, rtol=1e-6)
+    assert len(lens) == 1
