@@ -4,7 +4,11 @@
 //   cond_advance   nd = dist[src] + w[e]; old = atomicMin(dist+dst, nd); true iff nd < old (:20-29)
 //   apply_advance  preds[dst] = src for EVERY expanded edge, returns true (:31-34; racy by
 //                  design upstream, SURVEY F7 -- distances are what is schedule-independent)
-//   cond_filter    drop -1, drop ids already stamped this iteration, else stamp (:12-18)
+//   cond_filter    drop -1, drop ids already stamped this iteration, else stamp (:12-18).  The
+//                  reference stamps with a plain load + store, which on a 64-lane wave lets up to
+//                  64 copies of one id through and overflows an m*queue_sizing frontier on skewed
+//                  graphs; the stamp here is ONE atomicExch (exact dedup: |frontier| <= n, so the
+//                  next advance never exceeds m work items).  Same fixed point.
 // util::atomicMin is one integer atomic on gfx950 (intrinsics.hxx) instead of a CAS loop.
 #pragma once
 #include "../intrinsics.hxx"
@@ -18,9 +22,7 @@ struct sssp_functor_t {
 
   static __device__ __forceinline__ bool cond_filter(int idx, slice_t* data, int iteration) {
     if (idx == -1) return false;
-    if (data->d_visited[idx] == iteration) return false;
-    data->d_visited[idx] = iteration;
-    return true;
+    return atomicExch(data->d_visited + idx, iteration) != iteration;
   }
 
   static __device__ __forceinline__ bool cond_advance(int src, int dst, int edge_id, int, int, slice_t* data, int) {

@@ -143,12 +143,21 @@ MGX_API int mgx_bfs_enact_pushpull(mgx_bfs_t p, float threshold, int64_t* stats)
  *   [4] edges inspected by pull levels [5] push levels [6] level-kernel launches (incl. the
  *   empty ones behind the last level) [7] device time of those launches in ns (HIP events on
  *   the context's stream) [8] frontier vertices expanded (sum of per-level frontier sizes)
- *   [9] reserved.  stats must hold 10 entries.                                            */
+ *   [9] visited-bit claims (atomicOr) issued.  stats must hold 10 entries.                                            */
 #define MGX_BFS_PUSH 0
 #define MGX_BFS_DIRECTION_OPT 1
 MGX_API int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats);
 /* per-level trace of the last mgx_bfs_run: level_nf[i], level_edges[i] for i < *levels  */
 MGX_API int mgx_bfs_level_trace(mgx_bfs_t p, int cap, int64_t* level_nf, int64_t* level_edges, int* levels);
+
+/* device time (ms, HIP events) of each launch batch of the last mgx_bfs_run; with the environment
+ * variable MGX_BFS_LEVELS_PER_SYNC=1 a batch is exactly one level kernel                   */
+/* diagnostic builds only (environment MGX_BFS_DIAG=1): cycles per kernel stage of the last run,
+ * summed over workgroups: staging, search, col_indices, visited, claim, barrier, flush, unused */
+MGX_API int mgx_bfs_diag(mgx_bfs_t p, int64_t* cycles8);
+/* atomicOr claims issued per level of the last run (first 64 levels) */
+MGX_API int mgx_bfs_level_claims(mgx_bfs_t p, int cap, int64_t* claims);
+MGX_API int mgx_bfs_batch_times(mgx_bfs_t p, int cap, float* ms, int* batches);
 
 /* ---- SSSP: sssp_problem_t / sssp_functor_t / sssp_enactor_t (gunrock/src/sssp/) ---- */
 MGX_API int mgx_sssp_create(mgx_graph_t g, int src, mgx_sssp_t* out);     /* sssp_problem.hxx:40-52 */

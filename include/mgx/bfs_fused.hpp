@@ -30,9 +30,7 @@
 
 namespace mgx {
 
-constexpr int BFS_TILE = 1024;                 // edge ranks per tile
-constexpr int BFS_EPT = BFS_TILE / BLOCK;      // 4 per lane, strided by the workgroup
-constexpr int BFS_STAGE = 2 * BFS_TILE;        // LDS-staged discoveries before a flush
+constexpr int BFS_FLUSH_AT = 512;              // staged discoveries that trigger a flush
 constexpr int BFS_MAX_TRACE = 4096;            // per-level trace slots
 constexpr int BFS_VSHIFT = 38;                 // cursor = (vertices << 38) | edges
 constexpr u64 BFS_EMASK = (1ull << BFS_VSHIFT) - 1ull;
@@ -42,6 +40,9 @@ struct bfs_ctrl_t {
   u64 sum_edges;     // sum over levels of E  == m_t (out-degrees of reached vertices)
   u64 sum_frontier;  // sum over levels of frontier sizes (reached vertices with degree >= 1)
   u64 reached;       // vertices labelled (incl. source and zero-degree discoveries)
+  u64 claims;        // atomicOr claims issued (>= reached-1; the excess is lost races / stale reads)
+  u64 claims_level[64];
+  u64 diag[8];       // DIAG builds only: cycles per stage, summed over workgroups (thread 0 stamps)
   int done;
   int levels;        // number of levels that expanded at least one edge
   u64 trace[BFS_MAX_TRACE];   // cursor value each level started from
@@ -51,11 +52,13 @@ struct bfs_fused_args_t {
   const u32* row_offsets;
   const int* col_indices;
   int* labels;
-  u32* visited;        // (n+31)/32 words
+  u32* visited;        // (n+31)/32 words: claimed with atomicOr (memory-side: every atomic drops its L2 line)
+  const u32* snapshot; // copy of `visited` taken between levels: read-only while a level runs, stays L2-resident
   u32* fr_row[2];      // frontier: CSR row start of each frontier vertex
   u32* fr_off[2];      // frontier: exclusive scan of degrees (edge rank of its first edge)
   bfs_ctrl_t* ctrl;
   int n;
+  int flags;           // diagnostics only: bit 0 = skip the claims (results are then wrong by design)
 };
 
 __global__ void k_bfs_fused_init(bfs_fused_args_t a, int src) {
@@ -73,19 +76,47 @@ __global__ void k_bfs_fused_init(bfs_fused_args_t a, int src) {
   c->sum_edges = 0;
   c->sum_frontier = 0;
   c->reached = 1;
+  c->claims = 0;
+  for (int i = 0; i < 64; ++i) c->claims_level[i] = 0;
+  for (int i = 0; i < 8; ++i) c->diag[i] = 0;
   c->done = 0;
   c->levels = 0;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_bfs_push_level(bfs_fused_args_t a, int level) {
-  __shared__ u32 s_off[BFS_TILE + 1];
-  __shared__ u32 s_row[BFS_TILE];
-  __shared__ u32 st_row[BFS_STAGE];
-  __shared__ u32 st_deg[BFS_STAGE];
-  __shared__ u32 s_scan[WAVES_PER_BLOCK + 1];
+// EPT = edge ranks per lane per tile (tile = BLOCK*EPT ranks, strided by the workgroup so a wave's
+// 64 lanes read 64 consecutive col_indices).  The per-edge dependency chain is
+//   LDS search -> col_indices load -> visited-word load -> atomicOr claim
+// and every stage is issued for all EPT ranks before the next stage starts, so a lane keeps EPT
+// independent memory operations in flight.  Two round trips are kept OFF the per-tile chain:
+//   * the (offset,row) slice of the next tile is prefetched into registers while this tile runs;
+//   * winners are staged in LDS as bare vertex ids; their row extents are fetched, scanned and
+//     appended to the next frontier in batches (flush), one round trip per ~BFS_FLUSH_AT winners.
+// DIAG builds stamp s_memtime at the stage boundaries (thread 0 of every workgroup) and add the
+// per-stage cycle totals to ctrl->diag[]; they are never used for timing claims.
+template <int EPT, bool DIAG = false>
+__global__ __launch_bounds__(BLOCK, (EPT <= 4 ? 6 : 4)) void k_bfs_push_level(bfs_fused_args_t a, int level) {
+  long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long dt = 0;
+#define MGX_STAMP(slot)                                                        \
+  if (DIAG) {                                                                  \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                \
+    const long long now_ = (long long)__builtin_readcyclecounter();            \
+    dg[slot] += now_ - dt;                                                     \
+    dt = now_;                                                                 \
+  }
+
+  constexpr int TILE = BLOCK * EPT;
+  constexpr int STAGE = BFS_FLUSH_AT + TILE;       // multiple of BLOCK
+  constexpr int PER = STAGE / BLOCK;
+  constexpr u64 CNT1 = 1ull << 40;                 // flush scan item = (kept << 40) | degree
+  constexpr u64 DEGMASK = CNT1 - 1ull;
+  __shared__ u32 s_off[TILE + 1];
+  __shared__ u32 s_row[TILE];
+  __shared__ u32 st_v[STAGE];
+  __shared__ u64 s_scan[WAVES_PER_BLOCK + 1];
   __shared__ u64 s_base;
   __shared__ long long s_seg;
-  __shared__ int s_count, s_wins, s_nseg;
+  __shared__ int s_count, s_wins, s_nseg, s_claims;
 
   bfs_ctrl_t* const c = a.ctrl;
   const u64 cur = c->cursor[level % 3];
@@ -111,12 +142,12 @@ __global__ __launch_bounds__(BLOCK) void k_bfs_push_level(bfs_fused_args_t a, in
 
   // this workgroup's slice of edge ranks, tile aligned
   u64 per = (E + gridDim.x - 1) / gridDim.x;
-  per = (per + BFS_TILE - 1) / BFS_TILE * BFS_TILE;
+  per = (per + TILE - 1) / TILE * TILE;
   const u64 e_begin = (u64)blockIdx.x * per;
   if (e_begin >= E) return;
   const u64 e_end = (e_begin + per < E) ? e_begin + per : E;
 
-  if (threadIdx.x == 0) { s_count = 0; s_wins = 0; }
+  if (threadIdx.x == 0) { s_count = 0; s_wins = 0; s_claims = 0; }
   if (threadIdx.x < WAVE) {
     const long long ub = wave_upper_bound(fr_off, nf, (u32)e_begin);
     if (threadIdx.x == 0) s_seg = ub - 1;
@@ -126,118 +157,213 @@ __global__ __launch_bounds__(BLOCK) void k_bfs_push_level(bfs_fused_args_t a, in
   const int lane = lane_id();
   const int new_label = level + 1;
 
-  // flush the staged discoveries: one packed atomic gives frontier slots AND their degree scan
+  // Flush the staged CANDIDATES (vertices whose visited bit read as clear): claim them with one
+  // atomicOr each -- all in flight together, ONE round trip for the whole batch instead of one
+  // per tile (a returning atomic executes at the memory side, ~5 us under load, and stalls the
+  // whole wave: measured 0.8 ms of a 1.3 ms level for 1 % of the edges) -- then winners get
+  // their label, their row extent is fetched, zero-degree ones are dropped and the rest is
+  // appended to the next frontier.  ONE packed 64-bit atomicAdd hands back the frontier slot
+  // AND the exclusive degree scan at that slot.
   auto flush = [&](int cnt) {
-    constexpr int PER = BFS_STAGE / BLOCK;   // 8 consecutive staged entries per lane
-    u32 loc[PER];      // sums stay below E < 2^32
-    u32 sum = 0;
+    u32 v[PER], old[PER];
+    // (1) the staged vertices were unvisited in the level-start snapshot; most duplicates (same
+    //     vertex reached again later in this level) are weeded out by a plain read of the LIVE
+    //     bitmap, (2) the rest is claimed.
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
       const int i = threadIdx.x * PER + q;
-      const u32 d = (i < cnt) ? st_deg[i] : 0u;
+      v[q] = (i < cnt) ? st_v[i] : 0u;
+      old[q] = (i < cnt) ? a.visited[v[q] >> 5] : 0xFFFFFFFFu;
+    }
+    u32 livemask = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+      if (!(old[q] & (1u << (v[q] & 31)))) livemask |= 1u << q;
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(livemask) : : "memory");
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      old[q] = 0xFFFFFFFFu;
+      if ((livemask >> q) & 1u) old[q] = atomicOr(a.visited + (v[q] >> 5), 1u << (v[q] & 31));
+    }
+    const int nclaim = wave_sum((int)__popc(livemask));
+    if (lane == 0 && nclaim) atomicAdd(&s_claims, nclaim);
+    u32 winmask = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+      if (!(old[q] & (1u << (v[q] & 31)))) winmask |= 1u << q;
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(winmask) : : "memory");
+    u32 ro[PER], ro1[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const bool win = (winmask >> q) & 1u;
+      const u32 w = win ? v[q] : 0u;
+      ro[q] = a.row_offsets[w];
+      ro1[q] = a.row_offsets[w + 1];
+      if (win) a.labels[v[q]] = new_label;
+    }
+    u64 loc[PER];
+    u64 sum = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const u32 deg = ((winmask >> q) & 1u) ? ro1[q] - ro[q] : 0u;
       loc[q] = sum;
-      sum += d;
+      sum += deg ? (CNT1 | (u64)deg) : 0ull;
     }
-    u32 total;
-    const u32 ex = block_exclusive_sum(sum, s_scan, &total);
-    if (threadIdx.x == 0) s_base = atomicAdd(out_cursor, ((u64)cnt << BFS_VSHIFT) | (u64)total);
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      const int i = threadIdx.x * PER + q;
-      if (i < cnt) st_deg[i] = ex + loc[q];
-    }
+    u64 total;
+    const u64 ex = block_exclusive_sum(sum, s_scan, &total);
+    const int nwin = wave_sum((int)__popc(winmask));
+    if (lane == 0 && nwin) atomicAdd(&s_wins, nwin);
+    if (threadIdx.x == 0)
+      s_base = (total >> 40) ? atomicAdd(out_cursor, ((total >> 40) << BFS_VSHIFT) | (total & DEGMASK)) : 0ull;
     __syncthreads();
     const u64 base = s_base;
     const u64 base_v = base >> BFS_VSHIFT;
     const u64 base_e = base & BFS_EMASK;
-    for (int i = threadIdx.x; i < cnt; i += BLOCK) {
-      out_row[base_v + i] = st_row[i];
-      out_off[base_v + i] = (u32)(base_e + st_deg[i]);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      if (((winmask >> q) & 1u) && ro1[q] != ro[q]) {
+        const u64 at = ex + loc[q];
+        out_row[base_v + (at >> 40)] = ro[q];
+        out_off[base_v + (at >> 40)] = (u32)(base_e + (at & DEGMASK));
+      }
     }
     if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
   };
 
-  for (u64 E0 = e_begin; E0 < e_end; E0 += BFS_TILE) {
-    const u64 E1 = (E0 + BFS_TILE < e_end) ? E0 + BFS_TILE : e_end;
-    // stage (scanned offset, row start) of the segments beginning at `seg`, BLOCK at a time,
-    // until the staged slice covers the tile.  Segments are non-empty, so BFS_TILE+1 offsets
-    // always suffice; a hub row needs one round.
-    int limit = 0;   // index of the last staged offset
-    for (int loaded = 0;;) {
-      const int j = loaded + threadIdx.x;
-      if (j <= BFS_TILE) {
+  // prefetch registers for the first BLOCK+1 (offset,row) pairs of the coming tile
+  u32 pf_off = 0, pf_row = 0, pf_off_last = 0;
+  auto prefetch = [&](long long sg) {
+    const long long s0 = sg + threadIdx.x;
+    pf_off = (s0 < nf) ? fr_off[s0] : (u32)E;
+    pf_row = (s0 < nf) ? fr_row[s0] : 0u;
+    const long long s1 = sg + BLOCK;                 // one extra offset so BLOCK segments are usable
+    pf_off_last = (s1 < nf) ? fr_off[s1] : (u32)E;
+  };
+  prefetch(seg);
+
+  if (DIAG) dt = (long long)__builtin_readcyclecounter();
+  for (u64 E0 = e_begin; E0 < e_end; E0 += TILE) {
+    const u64 E1 = (E0 + TILE < e_end) ? E0 + TILE : e_end;
+    // stage (scanned offset, row start) of the segments beginning at `seg`: the prefetched round
+    // first, more rounds of BLOCK only if the tile spans more than BLOCK segments.  Segments are
+    // non-empty, so TILE+1 offsets always suffice.
+    s_off[threadIdx.x] = pf_off;
+    s_row[threadIdx.x] = pf_row;
+    if (threadIdx.x == 0) s_off[BLOCK] = pf_off_last;
+    __syncthreads();
+    int limit = BLOCK;   // index of the last staged offset
+    while ((u64)s_off[limit] < E1 && limit < TILE) {
+      const int j = limit + 1 + threadIdx.x;
+      if (j <= TILE) {
         const long long s = seg + j;
         s_off[j] = (s < nf) ? fr_off[s] : (u32)E;
-        if (j < BFS_TILE) s_row[j] = (s < nf) ? fr_row[s] : 0u;
       }
-      loaded += BLOCK;
+      const int jr = limit + threadIdx.x;
+      if (jr < TILE) {
+        const long long s = seg + jr;
+        s_row[jr] = (s < nf) ? fr_row[s] : 0u;
+      }
+      limit = (limit + BLOCK < TILE) ? limit + BLOCK : TILE;
       __syncthreads();
-      limit = (loaded - 1 < BFS_TILE) ? loaded - 1 : BFS_TILE;
-      if ((u64)s_off[limit] >= E1 || limit == BFS_TILE) break;
     }
     // exactly one j has s_off[j] < E1 <= s_off[j+1]
     for (int j = threadIdx.x; j < limit; j += BLOCK)
       if ((u64)s_off[j] < E1 && (u64)s_off[j + 1] >= E1) s_nseg = j + 1;
     __syncthreads();
     const int nseg = s_nseg;
+    MGX_STAMP(0)                         // staging + nseg
     const u32 next_off = s_off[nseg];   // start of the first segment not touched by this tile
+    const long long seg_next = seg + (((u64)next_off == E1) ? nseg : nseg - 1);
+    if (E1 < e_end) prefetch(seg_next);  // lands while this tile is processed
 
+    // ---- stage 1: resolve (segment, rank) of every edge rank: uniform-step binary search ----
+    u32 r32[EPT];
+    int sj[EPT];
+    bool act[EPT];
 #pragma unroll
-    for (int k = 0; k < BFS_EPT; ++k) {
+    for (int k = 0; k < EPT; ++k) {
       const u64 r = E0 + (u64)(k * BLOCK + threadIdx.x);
-      bool win = false;
-      u32 ro = 0, deg = 0;
-      if (r < E1) {
-        int lo = 0, hi = nseg;          // largest j with s_off[j] <= r
-        while (hi - lo > 1) {
-          const int mid = (lo + hi) >> 1;
-          if ((u64)s_off[mid] <= r) lo = mid; else hi = mid;
-        }
-        const u32 e = s_row[lo] + (u32)(r - s_off[lo]);
-        const int dst = a.col_indices[e];
-        const u32 bit = 1u << (dst & 31);
-        u32* const word = a.visited + (dst >> 5);
-        if (!(*word & bit)) {
-          const u32 old = atomicOr(word, bit);
-          if (!(old & bit)) {
-            win = true;
-            a.labels[dst] = new_label;
-            ro = a.row_offsets[dst];
-            deg = a.row_offsets[dst + 1] - ro;
-          }
-        }
-      }
-      const u64 mw = __ballot(win);
-      if (mw) {
-        const u64 ms = __ballot(win && deg != 0);
-        int base = 0;
-        if (lane == 0) {
-          atomicAdd(&s_wins, __popcll(mw));
-          if (ms) base = atomicAdd(&s_count, __popcll(ms));
-        }
-        base = __shfl(base, 0, WAVE);
-        if (win && deg != 0) {
-          const int pos = base + rank_in_mask(ms);
-          st_row[pos] = ro;
-          st_deg[pos] = deg;
+      act[k] = r < E1;
+      r32[k] = act[k] ? (u32)r : (u32)E0;
+      sj[k] = 0;
+    }
+    if (nseg > 1) {
+      int top = 1;
+      while (top * 2 < nseg) top *= 2;      // largest power of two < nseg (block-uniform)
+      for (int step = top; step > 0; step >>= 1) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+          const int j = sj[k] + step;
+          const u32 v = s_off[j < nseg ? j : nseg - 1];
+          if (j < nseg && v <= r32[k]) sj[k] = j;
         }
       }
     }
+    u32 eidx[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) eidx[k] = s_row[sj[k]] + (r32[k] - s_off[sj[k]]);
+
+    MGX_STAMP(1)                         // search (also absorbs the prefetch round trip in DIAG builds)
+    // ---- stage 2: neighbour ids (one coalesced 256 B read per wave and k) --------------------
+    int dst[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) dst[k] = a.col_indices[eidx[k]];
+    MGX_STAMP(2)                         // col_indices round trip
+
+    // ---- stage 3: visited words -----------------------------------------------------------
+    u32 word[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) word[k] = a.snapshot[(u32)dst[k] >> 5];
+    u32 candmask = 0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k)
+      if (act[k] && !(word[k] & (1u << (dst[k] & 31)))) candmask |= 1u << k;
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(candmask) : : "memory");
+    MGX_STAMP(3)                         // visited-word round trip
+
+    // ---- stage 4: stage the candidates in LDS (claimed in batches by flush) ----------------------
+    if (DIAG && (a.flags & 1) && level == (a.flags >> 8)) candmask = 0;
+    {
+      const int mine = (int)__popc(candmask);
+      const int inc = wave_inclusive_sum(mine);
+      const int ncand = __shfl(inc, WAVE - 1, WAVE);
+      if (ncand) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_count, ncand);
+        base = __shfl(base, 0, WAVE);
+        int pos = base + inc - mine;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k)
+          if (candmask & (1u << k)) st_v[pos++] = (u32)dst[k];
+      }
+    }
+    MGX_STAMP(4)                         // staging of candidates
     __syncthreads();
+    MGX_STAMP(5)                         // tile-end barrier (waiting for the slowest wave)
     const int cnt = s_count;
-    if (cnt >= BFS_TILE) flush(cnt);
-    seg += ((u64)next_off == E1) ? nseg : nseg - 1;
+    if (cnt >= BFS_FLUSH_AT) flush(cnt);
+    MGX_STAMP(6)                         // flush: batched claims + frontier append
+    seg = seg_next;
   }
   {
     const int cnt = s_count;   // stable: last loop iteration ended with a barrier
     if (cnt > 0) flush(cnt);
   }
   if (threadIdx.x == 0 && s_wins) atomicAdd(&c->reached, (u64)s_wins);
+  if (threadIdx.x == 0 && s_claims) {
+    atomicAdd(&c->claims, (u64)s_claims);
+    if (level < 64) atomicAdd(&c->claims_level[level], (u64)s_claims);
+  }
+  if (DIAG && threadIdx.x == 0)
+    for (int i = 0; i < 8; ++i)
+      if (dg[i]) atomicAdd(&c->diag[i], (u64)dg[i]);
+#undef MGX_STAMP
 }
 
 struct bfs_fused_state_t {
   mem_t<u32> visited;
+  mem_t<u32> snapshot;
   mem_t<u32> fr_row[2];
   mem_t<u32> fr_off[2];
   mem_t<bfs_ctrl_t> ctrl;
@@ -245,14 +371,19 @@ struct bfs_fused_state_t {
   int n = 0;
   int levels_per_sync = 8;
   int grid = 0;
+  int ept = 4;                       // edge ranks per lane per tile (4 or 8)
+  bool diag = false;                 // MGX_BFS_DIAG=1: stage-stamped diagnostic kernel (EPT 4)
   // timing of the level kernels of the last run (HIP events around each batch of launches)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double level_kernel_ms = 0.0;
   long long level_kernel_launches = 0;
+  float batch_ms[256];               // duration of each launch batch of the last run (per level when levels_per_sync == 1)
+  int batches = 0;
 
   bfs_fused_state_t() {}
   bfs_fused_state_t(int num_nodes, standard_context_t& ctx) : n(num_nodes) {
     visited = mem_t<u32>((size_t)(num_nodes + 31) / 32 + 1, ctx);
+    snapshot = mem_t<u32>((size_t)(num_nodes + 31) / 32 + 1, ctx);
     for (int i = 0; i < 2; ++i) {
       fr_row[i] = mem_t<u32>((size_t)num_nodes + 1, ctx);
       fr_off[i] = mem_t<u32>((size_t)num_nodes + 1, ctx);
@@ -261,19 +392,22 @@ struct bfs_fused_state_t {
     MGX_HIP(hipHostMalloc((void**)&host_ctrl, sizeof(bfs_ctrl_t), hipHostMallocDefault));
     MGX_HIP(hipEventCreate(&ev0));
     MGX_HIP(hipEventCreate(&ev1));
-    grid = ctx.num_cus * 6;
+    if (const char* e = getenv("MGX_BFS_EPT")) ept = (atoi(e) == 8) ? 8 : 4;
+    if (const char* e = getenv("MGX_BFS_DIAG")) diag = atoi(e) != 0;
+    grid = ctx.num_cus * (ept == 8 ? 4 : 6);
     if (const char* e = getenv("MGX_BFS_LEVELS_PER_SYNC")) levels_per_sync = atoi(e) > 0 ? atoi(e) : 8;
     if (const char* e = getenv("MGX_BFS_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
   }
   bfs_fused_state_t(bfs_fused_state_t&& r) noexcept { *this = std::move(r); }
   bfs_fused_state_t& operator=(bfs_fused_state_t&& r) noexcept {
     visited = std::move(r.visited);
+    snapshot = std::move(r.snapshot);
     for (int i = 0; i < 2; ++i) { fr_row[i] = std::move(r.fr_row[i]); fr_off[i] = std::move(r.fr_off[i]); }
     ctrl = std::move(r.ctrl);
     std::swap(host_ctrl, r.host_ctrl);
     std::swap(ev0, r.ev0);
     std::swap(ev1, r.ev1);
-    n = r.n; levels_per_sync = r.levels_per_sync; grid = r.grid;
+    n = r.n; levels_per_sync = r.levels_per_sync; grid = r.grid; ept = r.ept; diag = r.diag;
     return *this;
   }
   ~bfs_fused_state_t() {
@@ -293,25 +427,36 @@ inline void bfs_fused_push_run(bfs_fused_state_t& st, const int* row_offsets, co
   a.col_indices = col_indices;
   a.labels = labels;
   a.visited = st.visited.data();
+  a.snapshot = st.snapshot.data();
   for (int i = 0; i < 2; ++i) { a.fr_row[i] = st.fr_row[i].data(); a.fr_off[i] = st.fr_off[i].data(); }
   a.ctrl = st.ctrl.data();
   a.n = st.n;
+  a.flags = 0;
+  if (const char* e = getenv("MGX_BFS_FLAGS")) a.flags = atoi(e);
   MGX_HIP(hipMemsetAsync(labels, 0xFF, (size_t)st.n * sizeof(int), s));
   MGX_HIP(hipMemsetAsync(st.visited.data(), 0, st.visited.size() * sizeof(u32), s));
   hipLaunchKernelGGL(k_bfs_fused_init, dim3(1), dim3(64), 0, s, a, src);
   int level = 0;
   st.level_kernel_ms = 0.0;
   st.level_kernel_launches = 0;
+  st.batches = 0;
   for (;;) {
     MGX_HIP(hipEventRecord(st.ev0, s));
-    for (int i = 0; i < st.levels_per_sync; ++i, ++level)
-      hipLaunchKernelGGL(k_bfs_push_level, dim3(st.grid), dim3(BLOCK), 0, s, a, level);
+    for (int i = 0; i < st.levels_per_sync; ++i, ++level) {
+      // level-start snapshot of the visited bitmap (n/8 bytes, device to device)
+      MGX_HIP(hipMemcpyAsync(st.snapshot.data(), st.visited.data(), st.visited.size() * sizeof(u32),
+                             hipMemcpyDeviceToDevice, s));
+      if (st.diag) hipLaunchKernelGGL((k_bfs_push_level<4, true>), dim3(st.grid), dim3(BLOCK), 0, s, a, level);
+      else if (st.ept == 8) hipLaunchKernelGGL((k_bfs_push_level<8, false>), dim3(st.grid), dim3(BLOCK), 0, s, a, level);
+      else hipLaunchKernelGGL((k_bfs_push_level<4, false>), dim3(st.grid), dim3(BLOCK), 0, s, a, level);
+    }
     MGX_HIP(hipEventRecord(st.ev1, s));
     MGX_HIP(hipMemcpyAsync(&st.host_ctrl->done, &st.ctrl.data()->done, sizeof(int), hipMemcpyDeviceToHost, s));
     MGX_HIP(hipStreamSynchronize(s));
     float ms = 0.f;
     MGX_HIP(hipEventElapsedTime(&ms, st.ev0, st.ev1));
     st.level_kernel_ms += ms;
+    if (st.batches < 256) st.batch_ms[st.batches++] = ms;
     st.level_kernel_launches += st.levels_per_sync;
     if (st.host_ctrl->done) break;
   }

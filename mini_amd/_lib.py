@@ -26,6 +26,16 @@ class MgxError(RuntimeError):
 
 
 def _load():
+    # When PyTorch is in the process, let it load ITS bundled HIP runtime first: libmgx.so needs
+    # libamdhip64.so.7 and then binds to the copy already loaded instead of bringing /opt/rocm's
+    # second runtime into the process (two runtimes => the second one sees no device).
+    if os.environ.get("MGX_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "libmgx.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -86,6 +96,9 @@ SIGNATURES = {
     "mgx_bfs_enact_pushpull": [_vp, _f, _pi64],
     "mgx_bfs_run": [_vp, _i, _i, _f, _pi64],
     "mgx_bfs_level_trace": [_vp, _i, _pi64, _pi64, _pi],
+    "mgx_bfs_diag": [_vp, _pi64],
+    "mgx_bfs_level_claims": [_vp, _i, _pi64],
+    "mgx_bfs_batch_times": [_vp, _i, _pf, _pi],
     "mgx_sssp_create": [_vp, _i, _pvp],
     "mgx_sssp_reset": [_vp, _i],
     "mgx_sssp_free": [_vp],

@@ -242,13 +242,29 @@ class BfsProblem:
         st = (C.c_int64 * 10)()
         check(lib.mgx_bfs_run(self._h, int(src), int(mode), C.c_float(alpha), st))
         return {"levels": st[0], "reached": st[1], "m_t": st[2], "push_edges": st[3], "pull_edges": st[4],
-                "push_levels": st[5], "kernel_launches": st[6], "kernel_ns": st[7], "frontier_vertices": st[8]}
+                "push_levels": st[5], "kernel_launches": st[6], "kernel_ns": st[7], "frontier_vertices": st[8],
+                "claims": st[9]}
 
     def level_trace(self, cap=4096):
         nf, ne, lv = (C.c_int64 * cap)(), (C.c_int64 * cap)(), C.c_int()
         check(lib.mgx_bfs_level_trace(self._h, cap, nf, ne, C.byref(lv)))
         L = min(lv.value, cap)
         return [(nf[i], ne[i]) for i in range(L)]
+
+    def diag_cycles(self):
+        c = (C.c_int64 * 8)()
+        check(lib.mgx_bfs_diag(self._h, c))
+        return [c[i] for i in range(8)]
+
+    def level_claims(self, cap=64):
+        c = (C.c_int64 * cap)()
+        check(lib.mgx_bfs_level_claims(self._h, cap, c))
+        return [c[i] for i in range(cap)]
+
+    def batch_times_ms(self, cap=256):
+        ms, nb = (C.c_float * cap)(), C.c_int()
+        check(lib.mgx_bfs_batch_times(self._h, cap, ms, C.byref(nb)))
+        return [ms[i] for i in range(min(nb.value, cap))]
 
     def close(self):
         if self._h:

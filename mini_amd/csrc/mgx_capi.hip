@@ -591,7 +591,7 @@ int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats) {
   p->last_stats[6] = p->fe->fused.level_kernel_launches;
   p->last_stats[7] = (int64_t)(p->fe->fused.level_kernel_ms * 1e6);
   p->last_stats[8] = (int64_t)hc->sum_frontier;
-  p->last_stats[9] = 0;
+  p->last_stats[9] = (int64_t)hc->claims;
   if (stats) memcpy(stats, p->last_stats, sizeof(p->last_stats));
   MGX_CATCH
 }
@@ -606,6 +606,30 @@ int mgx_bfs_level_trace(mgx_bfs_t p, int cap, int64_t* level_nf, int64_t* level_
     if (level_nf) level_nf[i] = (int64_t)(hc->trace[i] >> mgx::BFS_VSHIFT);
     if (level_edges) level_edges[i] = (int64_t)(hc->trace[i] & mgx::BFS_EMASK);
   }
+  MGX_CATCH
+}
+
+int mgx_bfs_diag(mgx_bfs_t p, int64_t* cycles8) {
+  MGX_TRY
+  MGX_REQUIRE(p && cycles8, "NULL argument");
+  MGX_REQUIRE(p->fe != nullptr, "mgx_bfs_diag: no mgx_bfs_run yet");
+  for (int i = 0; i < 8; ++i) cycles8[i] = (int64_t)p->fe->fused.host_ctrl->diag[i];
+  MGX_CATCH
+}
+int mgx_bfs_level_claims(mgx_bfs_t p, int cap, int64_t* claims) {
+  MGX_TRY
+  MGX_REQUIRE(p && claims, "NULL argument");
+  MGX_REQUIRE(p->fe != nullptr, "mgx_bfs_level_claims: no mgx_bfs_run yet");
+  for (int i = 0; i < cap && i < 64; ++i) claims[i] = (int64_t)p->fe->fused.host_ctrl->claims_level[i];
+  MGX_CATCH
+}
+int mgx_bfs_batch_times(mgx_bfs_t p, int cap, float* ms, int* batches) {
+  MGX_TRY
+  MGX_REQUIRE(p && batches, "NULL argument");
+  MGX_REQUIRE(p->fe != nullptr, "mgx_bfs_batch_times: no mgx_bfs_run yet");
+  *batches = p->fe->fused.batches;
+  for (int i = 0; i < p->fe->fused.batches && i < cap; ++i)
+    if (ms) ms[i] = p->fe->fused.batch_ms[i];
   MGX_CATCH
 }
 
