@@ -41,6 +41,7 @@ typedef struct mgx_frontier_s* mgx_frontier_t;
 typedef struct mgx_bfs_s* mgx_bfs_t;
 typedef struct mgx_sssp_s* mgx_sssp_t;
 typedef struct mgx_pr_s* mgx_pr_t;
+typedef struct mgx_dbfs_s* mgx_dbfs_t;
 
 MGX_API int mgx_version(void);
 MGX_API const char* mgx_strerror(int status);
@@ -158,6 +159,27 @@ MGX_API int mgx_bfs_diag(mgx_bfs_t p, int64_t* cycles8);
 /* atomicOr claims issued per level of the last run (first 64 levels) */
 MGX_API int mgx_bfs_level_claims(mgx_bfs_t p, int cap, int64_t* claims);
 MGX_API int mgx_bfs_batch_times(mgx_bfs_t p, int cap, float* ms, int* batches);
+
+/* ---- vertex-range partitioned BFS: the per-rank pieces (the reference has no
+ *      multi-GPU path, README.md:4).  Rank r of `ranks` owns global ids [r*chunk, (r+1)*chunk),
+ *      chunk = ceil(n_global/ranks): their CSR rows (local row_offsets, GLOBAL col_indices) and
+ *      labels.  Per superstep the host calls expand (-> per-owner bins of neighbour ids, each id at
+ *      most once per traversal per rank), exchanges bin r of every rank to rank r (all-to-all over
+ *      RCCL/xGMI), calls receive for what arrived (and for its own bin) and swap.  Labels equal the
+ *      single-GPU depths bit for bit.  Device pointers are borrowed.                          */
+/* d_bins: optional caller-owned send buffer of ranks*bin_capacity ints (bin_capacity >= chunk), so the
+ * host can hand slices of it straight to its collective; NULL = library-owned.                  */
+MGX_API int mgx_dbfs_create(mgx_ctx_t ctx, int n_global, int ranks, int rank, int64_t m_local,
+                            const int* d_row_offsets_local, const int* d_col_indices_global,
+                            int* d_bins, int64_t bin_capacity, mgx_dbfs_t* out);
+MGX_API int mgx_dbfs_free(mgx_dbfs_t h);
+MGX_API int mgx_dbfs_range(mgx_dbfs_t h, int* v_lo, int* v_hi);
+MGX_API int mgx_dbfs_reset(mgx_dbfs_t h, int src_global);
+MGX_API int mgx_dbfs_expand(mgx_dbfs_t h, int64_t* host_counts_per_rank, int64_t* edges_expanded);
+MGX_API int mgx_dbfs_bins(mgx_dbfs_t h, int** d_bins, int64_t* bin_capacity); /* bin r at d_bins + r*capacity */
+MGX_API int mgx_dbfs_receive(mgx_dbfs_t h, const int* d_global_ids, int64_t count, int label);
+MGX_API int mgx_dbfs_swap(mgx_dbfs_t h, int64_t* next_frontier_size);
+MGX_API int mgx_dbfs_labels(mgx_dbfs_t h, int* host_labels_local);
 
 /* ---- SSSP: sssp_problem_t / sssp_functor_t / sssp_enactor_t (gunrock/src/sssp/) ---- */
 MGX_API int mgx_sssp_create(mgx_graph_t g, int src, mgx_sssp_t* out);     /* sssp_problem.hxx:40-52 */

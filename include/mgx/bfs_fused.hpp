@@ -93,8 +93,8 @@ __global__ void k_bfs_fused_init(bfs_fused_args_t a, int src) {
 //     appended to the next frontier in batches (flush), one round trip per ~BFS_FLUSH_AT winners.
 // DIAG builds stamp s_memtime at the stage boundaries (thread 0 of every workgroup) and add the
 // per-stage cycle totals to ctrl->diag[]; they are never used for timing claims.
-template <int EPT, bool DIAG = false>
-__global__ __launch_bounds__(BLOCK, (EPT <= 4 ? 6 : 4)) void k_bfs_push_level(bfs_fused_args_t a, int level) {
+template <int EPT, int OCC, bool DIAG = false>
+__global__ __launch_bounds__(BLOCK, OCC) void k_bfs_push_level(bfs_fused_args_t a, int level) {
   long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long dt = 0;
 #define MGX_STAMP(slot)                                                        \
@@ -242,8 +242,11 @@ __global__ __launch_bounds__(BLOCK, (EPT <= 4 ? 6 : 4)) void k_bfs_push_level(bf
   };
   prefetch(seg);
 
-  if (DIAG) dt = (long long)__builtin_readcyclecounter();
-  for (u64 E0 = e_begin; E0 < e_end; E0 += TILE) {
+  // S1: resolve the CSR position of every edge rank of the tile starting at E0 (LDS only, apart
+  // from extra staging rounds for tiles spanning more than BLOCK segments).
+  u32 eidxC[EPT];
+  u32 actC = 0;
+  auto prepare_tile = [&](u64 E0) {
     const u64 E1 = (E0 + TILE < e_end) ? E0 + TILE : e_end;
     // stage (scanned offset, row start) of the segments beginning at `seg`: the prefetched round
     // first, more rounds of BLOCK only if the tile spans more than BLOCK segments.  Segments are
@@ -272,20 +275,19 @@ __global__ __launch_bounds__(BLOCK, (EPT <= 4 ? 6 : 4)) void k_bfs_push_level(bf
       if ((u64)s_off[j] < E1 && (u64)s_off[j + 1] >= E1) s_nseg = j + 1;
     __syncthreads();
     const int nseg = s_nseg;
-    MGX_STAMP(0)                         // staging + nseg
     const u32 next_off = s_off[nseg];   // start of the first segment not touched by this tile
     const long long seg_next = seg + (((u64)next_off == E1) ? nseg : nseg - 1);
-    if (E1 < e_end) prefetch(seg_next);  // lands while this tile is processed
+    if (E1 < e_end) prefetch(seg_next);  // lands while the pipeline works on older tiles
 
-    // ---- stage 1: resolve (segment, rank) of every edge rank: uniform-step binary search ----
     u32 r32[EPT];
     int sj[EPT];
-    bool act[EPT];
+    actC = 0;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       const u64 r = E0 + (u64)(k * BLOCK + threadIdx.x);
-      act[k] = r < E1;
-      r32[k] = act[k] ? (u32)r : (u32)E0;
+      const bool act = r < E1;
+      if (act) actC |= 1u << k;
+      r32[k] = act ? (u32)r : (u32)E0;
       sj[k] = 0;
     }
     if (nseg > 1) {
@@ -300,31 +302,35 @@ __global__ __launch_bounds__(BLOCK, (EPT <= 4 ? 6 : 4)) void k_bfs_push_level(bf
         }
       }
     }
-    u32 eidx[EPT];
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) eidx[k] = s_row[sj[k]] + (r32[k] - s_off[sj[k]]);
+    for (int k = 0; k < EPT; ++k) eidxC[k] = s_row[sj[k]] + (r32[k] - s_off[sj[k]]);
+    seg = seg_next;
+  };
 
-    MGX_STAMP(1)                         // search (also absorbs the prefetch round trip in DIAG builds)
-    // ---- stage 2: neighbour ids (one coalesced 256 B read per wave and k) --------------------
-    int dst[EPT];
+  // Software pipeline over the workgroup's tiles, three tiles deep, one iteration per tile:
+  //   S1(it+1) search            (LDS)
+  //   S2(it)   col_indices loads (HBM stream)      -> dstB, in flight across the iteration
+  //   S3(it-1) snapshot words    (L2-resident)     -> wordA, in flight across the iteration
+  //   S4(it-2) candidates -> LDS staging
+  // so the two dependent global round trips of a tile overlap the LDS work of the next tiles
+  // instead of being paid back to back.
+  const int ntiles = (int)((e_end - e_begin + TILE - 1) / TILE);
+  int dstA[EPT], dstB[EPT];
+  u32 wordA[EPT];
+  u32 actA = 0, actB = 0;
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) dst[k] = a.col_indices[eidx[k]];
-    MGX_STAMP(2)                         // col_indices round trip
-
-    // ---- stage 3: visited words -----------------------------------------------------------
-    u32 word[EPT];
+  for (int k = 0; k < EPT; ++k) { dstA[k] = 0; dstB[k] = 0; wordA[k] = 0xFFFFFFFFu; }
+  if (DIAG) dt = (long long)__builtin_readcyclecounter();
+  prepare_tile(e_begin);
+  MGX_STAMP(0)
+  for (int it = 0; it < ntiles + 2; ++it) {
+    // ---- S4: tile it-2: snapshot words have landed -> candidates -> LDS staging ----------------
+    if (it >= 2) {
+      u32 candmask = 0;
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) word[k] = a.snapshot[(u32)dst[k] >> 5];
-    u32 candmask = 0;
-#pragma unroll
-    for (int k = 0; k < EPT; ++k)
-      if (act[k] && !(word[k] & (1u << (dst[k] & 31)))) candmask |= 1u << k;
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(candmask) : : "memory");
-    MGX_STAMP(3)                         // visited-word round trip
-
-    // ---- stage 4: stage the candidates in LDS (claimed in batches by flush) ----------------------
-    if (DIAG && (a.flags & 1) && level == (a.flags >> 8)) candmask = 0;
-    {
+      for (int k = 0; k < EPT; ++k)
+        if (((actA >> k) & 1u) && !(wordA[k] & (1u << (dstA[k] & 31)))) candmask |= 1u << k;
+      if (DIAG && (a.flags & 1) && level == (a.flags >> 8)) candmask = 0;
       const int mine = (int)__popc(candmask);
       const int inc = wave_inclusive_sum(mine);
       const int ncand = __shfl(inc, WAVE - 1, WAVE);
@@ -335,16 +341,36 @@ __global__ __launch_bounds__(BLOCK, (EPT <= 4 ? 6 : 4)) void k_bfs_push_level(bf
         int pos = base + inc - mine;
 #pragma unroll
         for (int k = 0; k < EPT; ++k)
-          if (candmask & (1u << k)) st_v[pos++] = (u32)dst[k];
+          if (candmask & (1u << k)) st_v[pos++] = (u32)dstA[k];
       }
     }
-    MGX_STAMP(4)                         // staging of candidates
+    MGX_STAMP(1)                         // wait for snapshot words + candidate staging
+    // ---- S3: tile it-1: neighbour ids have landed -> issue the snapshot-word gathers -------------
+    if (it >= 1 && it - 1 < ntiles) {
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        dstA[k] = dstB[k];
+        wordA[k] = a.snapshot[(u32)dstA[k] >> 5];
+      }
+      actA = actB;
+    } else {
+      actA = 0;
+    }
+    MGX_STAMP(2)                         // wait for col_indices
+    // ---- S2: tile it: issue the col_indices reads ------------------------------------------------
+    if (it < ntiles) {
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) dstB[k] = a.col_indices[eidxC[k]];
+      actB = actC;
+    }
+    // ---- S1: tile it+1: staging + search ----------------------------------------------------------
+    if (it + 1 < ntiles) prepare_tile(e_begin + (u64)(it + 1) * TILE);
+    MGX_STAMP(3)                         // staging + search of the next tile
     __syncthreads();
     MGX_STAMP(5)                         // tile-end barrier (waiting for the slowest wave)
     const int cnt = s_count;
     if (cnt >= BFS_FLUSH_AT) flush(cnt);
     MGX_STAMP(6)                         // flush: batched claims + frontier append
-    seg = seg_next;
   }
   {
     const int cnt = s_count;   // stable: last loop iteration ended with a barrier
@@ -372,6 +398,7 @@ struct bfs_fused_state_t {
   int levels_per_sync = 8;
   int grid = 0;
   int ept = 4;                       // edge ranks per lane per tile (4 or 8)
+  int occ = 5;                       // workgroups per CU the kernel is register-budgeted for
   bool diag = false;                 // MGX_BFS_DIAG=1: stage-stamped diagnostic kernel (EPT 4)
   // timing of the level kernels of the last run (HIP events around each batch of launches)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -394,7 +421,9 @@ struct bfs_fused_state_t {
     MGX_HIP(hipEventCreate(&ev1));
     if (const char* e = getenv("MGX_BFS_EPT")) ept = (atoi(e) == 8) ? 8 : 4;
     if (const char* e = getenv("MGX_BFS_DIAG")) diag = atoi(e) != 0;
-    grid = ctx.num_cus * (ept == 8 ? 4 : 6);
+    occ = (ept == 8) ? 4 : 5;
+    if (const char* e = getenv("MGX_BFS_OCC")) occ = atoi(e) > 0 ? atoi(e) : occ;
+    grid = ctx.num_cus * occ;
     if (const char* e = getenv("MGX_BFS_LEVELS_PER_SYNC")) levels_per_sync = atoi(e) > 0 ? atoi(e) : 8;
     if (const char* e = getenv("MGX_BFS_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
   }
@@ -407,7 +436,7 @@ struct bfs_fused_state_t {
     std::swap(host_ctrl, r.host_ctrl);
     std::swap(ev0, r.ev0);
     std::swap(ev1, r.ev1);
-    n = r.n; levels_per_sync = r.levels_per_sync; grid = r.grid; ept = r.ept; diag = r.diag;
+    n = r.n; levels_per_sync = r.levels_per_sync; grid = r.grid; ept = r.ept; diag = r.diag; occ = r.occ;
     return *this;
   }
   ~bfs_fused_state_t() {
@@ -446,9 +475,15 @@ inline void bfs_fused_push_run(bfs_fused_state_t& st, const int* row_offsets, co
       // level-start snapshot of the visited bitmap (n/8 bytes, device to device)
       MGX_HIP(hipMemcpyAsync(st.snapshot.data(), st.visited.data(), st.visited.size() * sizeof(u32),
                              hipMemcpyDeviceToDevice, s));
-      if (st.diag) hipLaunchKernelGGL((k_bfs_push_level<4, true>), dim3(st.grid), dim3(BLOCK), 0, s, a, level);
-      else if (st.ept == 8) hipLaunchKernelGGL((k_bfs_push_level<8, false>), dim3(st.grid), dim3(BLOCK), 0, s, a, level);
-      else hipLaunchKernelGGL((k_bfs_push_level<4, false>), dim3(st.grid), dim3(BLOCK), 0, s, a, level);
+#define MGX_LAUNCH_LEVEL(E_, O_, D_) \
+  hipLaunchKernelGGL((k_bfs_push_level<E_, O_, D_>), dim3(st.grid), dim3(BLOCK), 0, s, a, level)
+      if (st.diag) MGX_LAUNCH_LEVEL(4, 5, true);
+      else if (st.ept == 8 && st.occ <= 3) MGX_LAUNCH_LEVEL(8, 3, false);
+      else if (st.ept == 8) MGX_LAUNCH_LEVEL(8, 4, false);
+      else if (st.occ >= 6) MGX_LAUNCH_LEVEL(4, 6, false);
+      else if (st.occ == 5) MGX_LAUNCH_LEVEL(4, 5, false);
+      else MGX_LAUNCH_LEVEL(4, 4, false);
+#undef MGX_LAUNCH_LEVEL
     }
     MGX_HIP(hipEventRecord(st.ev1, s));
     MGX_HIP(hipMemcpyAsync(&st.host_ctrl->done, &st.ctrl.data()->done, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -99,6 +99,15 @@ SIGNATURES = {
     "mgx_bfs_diag": [_vp, _pi64],
     "mgx_bfs_level_claims": [_vp, _i, _pi64],
     "mgx_bfs_batch_times": [_vp, _i, _pf, _pi],
+    "mgx_dbfs_create": [_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _i64, _pvp],
+    "mgx_dbfs_free": [_vp],
+    "mgx_dbfs_range": [_vp, _pi, _pi],
+    "mgx_dbfs_reset": [_vp, _i],
+    "mgx_dbfs_expand": [_vp, _pi64, _pi64],
+    "mgx_dbfs_bins": [_vp, _pvp, _pi64],
+    "mgx_dbfs_receive": [_vp, _vp, _i64, _i],
+    "mgx_dbfs_swap": [_vp, _pi64],
+    "mgx_dbfs_labels": [_vp, _vp],
     "mgx_sssp_create": [_vp, _i, _pvp],
     "mgx_sssp_reset": [_vp, _i],
     "mgx_sssp_free": [_vp],

@@ -11,6 +11,7 @@
 #include "gunrock/bfs/bfs_enactor.hxx"
 #include "gunrock/pr/pr_enactor.hxx"
 #include "gunrock/sssp/sssp_enactor.hxx"
+#include "mgx/bfs_dist.hpp"
 #include "mgx.h"
 
 using namespace gunrock;
@@ -49,6 +50,11 @@ struct mgx_pr_s {
   mgx_graph_s* g;
   std::shared_ptr<pr::pr_problem_t> p;
   std::unique_ptr<pr::pr_enactor_t> e;
+};
+
+struct mgx_dbfs_s {
+  mgx_ctx_s* c;
+  mgx::dbfs_state_t st;
 };
 
 static thread_local std::string g_last_error;
@@ -630,6 +636,87 @@ int mgx_bfs_batch_times(mgx_bfs_t p, int cap, float* ms, int* batches) {
   *batches = p->fe->fused.batches;
   for (int i = 0; i < p->fe->fused.batches && i < cap; ++i)
     if (ms) ms[i] = p->fe->fused.batch_ms[i];
+  MGX_CATCH
+}
+
+// ---- vertex-range partitioned BFS (per-rank pieces; the exchange is the host's job) -----------
+int mgx_dbfs_create(mgx_ctx_t c, int n_global, int ranks, int rank, int64_t m_local, const int* d_row_offsets,
+                    const int* d_col_indices, int* d_bins, int64_t bin_capacity, mgx_dbfs_t* out) {
+  MGX_TRY
+  MGX_REQUIRE(c && out && d_row_offsets && (d_col_indices || m_local == 0), "mgx_dbfs_create: NULL argument");
+  MGX_REQUIRE(n_global > 0 && ranks >= 1 && ranks <= mgx::DBFS_MAX_RANKS && rank >= 0 && rank < ranks,
+              "mgx_dbfs_create: bad partition");
+  use_device(c);
+  const int chunk = (n_global + ranks - 1) / ranks;
+  const int lo = rank * chunk < n_global ? rank * chunk : n_global;
+  const int hi = (rank + 1) * chunk < n_global ? (rank + 1) * chunk : n_global;
+  auto* h = new mgx_dbfs_s();
+  h->c = c;
+  MGX_REQUIRE(d_bins == nullptr || bin_capacity >= chunk, "mgx_dbfs_create: bin capacity must be >= ceil(n/ranks)");
+  h->st.init(*c->ctx, n_global, lo, hi, ranks, rank, d_row_offsets, d_col_indices, m_local, d_bins, bin_capacity);
+  *out = h;
+  MGX_CATCH
+}
+int mgx_dbfs_free(mgx_dbfs_t h) {
+  MGX_TRY
+  if (h) { use_device(h->c); delete h; }
+  MGX_CATCH
+}
+int mgx_dbfs_range(mgx_dbfs_t h, int* lo, int* hi) {
+  MGX_TRY
+  MGX_REQUIRE(h, "NULL argument");
+  if (lo) *lo = h->st.v_lo;
+  if (hi) *hi = h->st.v_hi;
+  MGX_CATCH
+}
+int mgx_dbfs_reset(mgx_dbfs_t h, int src_global) {
+  MGX_TRY
+  MGX_REQUIRE(h && src_global >= 0 && src_global < h->st.n_global, "mgx_dbfs_reset: bad argument");
+  use_device(h->c);
+  mgx::dbfs_reset(h->st, src_global, *h->c->ctx);
+  MGX_CATCH
+}
+int mgx_dbfs_expand(mgx_dbfs_t h, int64_t* counts, int64_t* edges) {
+  MGX_TRY
+  MGX_REQUIRE(h && counts, "NULL argument");
+  use_device(h->c);
+  long long e = 0;
+  mgx::dbfs_expand(h->st, *h->c->ctx, &e);
+  for (int r = 0; r < h->st.ranks; ++r) {
+    counts[r] = (int64_t)h->st.host_counters[r];
+    if (counts[r] > h->st.bin_cap) throw mgx::mgx_error(MGX_E_FRONTIER_OVERFLOW, "mgx_dbfs_expand: send bin overflow");
+  }
+  if (edges) *edges = e;
+  MGX_CATCH
+}
+int mgx_dbfs_bins(mgx_dbfs_t h, int** d_bins, int64_t* bin_cap) {
+  MGX_TRY
+  MGX_REQUIRE(h && d_bins && bin_cap, "NULL argument");
+  *d_bins = h->st.bins.data();
+  *bin_cap = h->st.bin_cap;
+  MGX_CATCH
+}
+int mgx_dbfs_receive(mgx_dbfs_t h, const int* d_ids, int64_t count, int label) {
+  MGX_TRY
+  MGX_REQUIRE(h && (d_ids || count == 0) && count >= 0, "bad argument");
+  use_device(h->c);
+  mgx::dbfs_receive(h->st, d_ids, count, label, *h->c->ctx);
+  MGX_CATCH
+}
+int mgx_dbfs_swap(mgx_dbfs_t h, int64_t* frontier_size) {
+  MGX_TRY
+  MGX_REQUIRE(h, "NULL argument");
+  use_device(h->c);
+  const long long f = mgx::dbfs_swap(h->st, *h->c->ctx);
+  if (frontier_size) *frontier_size = f;
+  MGX_CATCH
+}
+int mgx_dbfs_labels(mgx_dbfs_t h, int* host_labels) {
+  MGX_TRY
+  MGX_REQUIRE(h && host_labels, "NULL argument");
+  use_device(h->c);
+  h->c->ctx->synchronize();
+  MGX_HIP(mgx::dtoh(host_labels, h->st.labels.data(), (size_t)h->st.n_local));
   MGX_CATCH
 }
 

@@ -1,0 +1,95 @@
+"""Multi-process tests of the vertex-range partitioned BFS (mini_amd/dist_bfs.py).
+CPU (not gpu): world_size 2 and 3 over gloo with the numpy rank engine -- exercises partitioning,
+the all_to_all_v exchange, the own-bin shortcut and the all_reduce termination.
+GPU (-m gpu): the same driver with the HIP rank engine, 2 ranks sharing cuda:0, exchange staged
+through gloo (the box has one GPU; RCCL itself only comes into play in bench.py --gpus N)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard(ro, ci, lo, hi):
+    return (ro[lo:hi + 1] - ro[lo]).astype(np.int32), ci[ro[lo]:ro[hi]].astype(np.int32)
+
+
+def _worker(rank, world, port, use_gpu, scale, seed, sources, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mini_amd.dist_bfs import DistBfs, range_of
+    from tests.oracle_binding import Oracle
+    orc = Oracle()
+    n, ro, ci, _ = orc.rmat_csr(scale, 16, seed)
+    lo, hi = range_of(n, world, rank)
+    ro_l, ci_l = _shard(ro, ci, lo, hi)
+    if use_gpu:
+        import mini_amd
+        from mini_amd.dist_bfs import HipRankEngine
+        torch.cuda.set_device(0)
+        ctx = mini_amd.Context(0, torch.cuda.current_stream().cuda_stream)
+        eng = HipRankEngine(ctx, n, world, rank, torch.from_numpy(ro_l).cuda(), torch.from_numpy(ci_l).cuda())
+    else:
+        from tests.dist_cpu_engine import NumpyRankEngine
+        eng = NumpyRankEngine(n, world, rank, ro_l, ci_l)
+    bfs = DistBfs(eng, rank, world, "cpu")
+    ok = True
+    deg = np.diff(ro)
+    for src in sources:
+        st = bfs.run(src)
+        got = bfs.gather_labels()
+        want = orc.bfs_cpu(ro, ci, src)
+        e = torch.tensor([st["edges_local"]], dtype=torch.int64)
+        dist.all_reduce(e)
+        ok = ok and np.array_equal(got, want) and int(e.item()) == int(deg[want >= 0].sum())
+    if rank == 0:
+        q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, use_gpu, scale, seed):
+    from tests.oracle_binding import Oracle
+    n, ro, ci, _ = Oracle().rmat_csr(scale, 16, seed)
+    deg = np.diff(ro)
+    sources = [int(np.argmax(deg)), int(np.where(deg > 0)[0][-1]), int(np.where(deg == 0)[0][0])]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, use_gpu, scale, seed, sources, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0, "rank exited with %s" % p.exitcode
+    assert q.get(timeout=10) is True
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_bfs_gloo_cpu(built, world):
+    _run(world, False, 9, 9)
+
+
+@pytest.mark.gpu
+def test_partitioned_bfs_hip_engine_two_ranks_one_gpu(built):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _run(2, True, 12, 12)

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Produces the evidence bundle of a round under gpurun_out/round/: test log, smoke, bench line,
+# rocprofv3 kernel-trace stats of the SAME bench command, and FETCH/WRITE PMC passes.
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/round
+mkdir -p $O
+cd $R
+timeout 1800 python -m pytest tests -q -m gpu --timeout 900 > $O/pytest_gpu.log 2>&1
+echo "pytest rc=$?"; tail -4 $O/pytest_gpu.log
+timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1
+echo "smoke rc=$?"; tail -1 $O/smoke.log
+timeout 300 ./tools/microbench > $O/microbench.jsonl 2>&1
+timeout 900 python bench.py --steps 16 --warmup 2 > $O/bench.log 2>&1
+echo "bench rc=$?"; tail -1 $O/bench.log
+timeout 600 python tools/bfs_levels.py --scale 22 --runs 2 > $O/levels.log 2>&1
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 16 --warmup 2 --no-cpu-baseline --no-check > $O/trace_bench.log 2>&1
+echo "trace rc=$?"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-check > $O/pmc_$c.log 2>&1
+  echo "pmc $c rc=$?"
+done
+timeout 900 rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $O/pmc_TCC -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-check > $O/pmc_TCC.log 2>&1
+cd $R
+python3 tools/summarize_profiles.py $O > $O/summary.txt 2>&1
+cat $O/summary.txt
