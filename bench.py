@@ -37,6 +37,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--mode", choices=["push", "do"], default="push",
+                    help="push = BASELINE config 2 (headline); do = direction-optimising (config 4)")
+    ap.add_argument("--alpha", type=float, default=4.0, help="bottom-up switch: unvisited < frontier*alpha")
+    ap.add_argument("--no-layout", action="store_true", help="keep generator vertex ids (no hub-first relabelling)")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     return ap.parse_args()
 
@@ -76,18 +80,26 @@ def main():
     graph = mini_amd.Graph.from_device(ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"])
     ro_host = g["row_offsets"].cpu().numpy()
     t_build = time.time() - t_build
+    t_layout = time.time()
+    if not args.no_layout:
+        # hub-first layout (vertex ids by descending degree) for the LDS-resident hot bitmap; part of
+        # graph construction like the CSR build, not of the timed traversal; labels stay in original ids
+        graph.attach_layout(*rmat.degree_order(g["row_offsets"], g["col_indices"]))
+        torch.cuda.synchronize()
+    t_layout = time.time() - t_layout
     sources = rmat.pick_sources(ro_host, args.steps + args.warmup, seed)
     bfs = mini_amd.BfsProblem(graph, sources[0])
 
+    mode = mini_amd.MGX_BFS_DIRECTION_OPT if args.mode == "do" else mini_amd.MGX_BFS_PUSH
     for s in sources[:args.warmup]:
-        bfs.run(s)
+        bfs.run(s, mode, args.alpha)
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     stats = []
     t0 = time.perf_counter()
     ev0.record(stream)
     for s in sources[args.warmup:]:
-        stats.append(bfs.run(s))
+        stats.append(bfs.run(s, mode, args.alpha))
     ev1.record(stream)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -98,7 +110,11 @@ def main():
     launches = sum(st["kernel_launches"] for st in stats)
     kernel_ns = sum(st["kernel_ns"] for st in stats)
     nf_total = sum(st["frontier_vertices"] for st in stats)   # vertices expanded (degree >= 1)
-    alg_bytes = 8.0 * m_t + 20.0 * nf_total
+    # algorithmic bytes: top-down levels 8 B/edge expanded, bottom-up levels 4.125 B per inspected in-edge
+    # (SURVEY 8d), 20 B per frontier vertex either way
+    push_edges = sum(st["push_edges"] for st in stats)
+    pull_edges = sum(st["pull_edges"] for st in stats)
+    alg_bytes = 8.0 * push_edges + 4.125 * pull_edges + 20.0 * nf_total
     value = m_t / elapsed / 1e6
 
     avg_launch_s = (kernel_ns / 1e9) / max(launches, 1)
@@ -133,7 +149,7 @@ def main():
             cpu_edges += int(deg[want >= 0].sum())
             used += 1
             if used == 1 and not args.no_check:
-                bfs.run(s)
+                bfs.run(s, mode, args.alpha)
                 parity = bool(np.array_equal(bfs.labels(), want))
             if cpu_time > args.cpu_seconds or args.no_cpu_baseline:
                 break
@@ -147,14 +163,16 @@ def main():
            "value": round(value, 2), "unit": "MTEPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-           "config": {"workload": "BFS push (fused LB advance + idempotent-visited filter) on RMAT scale %d ef %d, "
-                                  "symmetrised, n=%d m=%d, %d seeded sources" % (args.scale, args.edgefactor, g["n"],
-                                                                                g["m"], args.steps),
-                      "scale": args.scale, "edgefactor": args.edgefactor, "seed": seed, "parallelism": "1 GPU"},
+           "config": {"workload": "BFS %s (fused LB advance + idempotent-visited filter) on RMAT scale %d ef %d, "
+                                  "symmetrised, n=%d m=%d, %d seeded sources"
+                                  % ("push" if args.mode == "push" else "direction-optimising alpha=%g" % args.alpha,
+                                     args.scale, args.edgefactor, g["n"], g["m"], args.steps),
+                      "scale": args.scale, "edgefactor": args.edgefactor, "seed": seed, "parallelism": "1 GPU",
+                      "layout": "generator ids" if args.no_layout else "hub-first (degree-sorted) copy for the fused kernel"},
            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity,
            "device_ms_per_step": round(dev_ms / max(args.steps, 1), 4),
            "avg_levels": round(sum(st["levels"] for st in stats) / max(len(stats), 1), 2),
-           "avg_reached": reached // max(len(stats), 1), "graph_build_s": round(t_build, 2)}
+           "avg_reached": reached // max(len(stats), 1), "graph_build_s": round(t_build, 2), "layout_build_s": round(t_layout, 2)}
     print(json.dumps(out), flush=True)
 
 

@@ -10,7 +10,7 @@
 #include "../filter.hxx"
 #include "../frontier.hxx"
 #include "../graph.hxx"
-#include "../../mgx/bfs_fused.hpp"
+#include "../../mgx/bfs_fused_hot.hpp"
 #include "bfs_functor.hxx"
 #include "bfs_problem.hxx"
 
@@ -109,11 +109,25 @@ struct bfs_fused_enactor_t {
   bfs_fused_enactor_t(const bfs_fused_enactor_t&) = delete;
   bfs_fused_enactor_t& operator=(const bfs_fused_enactor_t&) = delete;
 
-  // labels are (re)initialised by the run itself; bfs_problem->src is the source
-  void enact(std::shared_ptr<bfs_problem_t> bfs_problem, standard_context_t& context) {
-    mgx::bfs_fused_push_run(fused, bfs_problem->gslice->d_row_offsets.data(),
-                            bfs_problem->gslice->d_col_indices.data(), bfs_problem->d_labels.data(),
-                            bfs_problem->src, context);
+  // labels are (re)initialised by the run itself; bfs_problem->src is the source.
+  // direction_optimizing: bottom-up levels once num_unvisited < frontier_length * alpha
+  // (the reference's rule, bfs_enactor.hxx:68); in-edges come from the graph's CSC slots.
+  void enact(std::shared_ptr<bfs_problem_t> bfs_problem, standard_context_t& context,
+             bool direction_optimizing = false, float alpha = 0.f) {
+    mgx::bfs_layout_t layout;
+    auto& g = *bfs_problem->gslice;
+    if (g.has_layout) {
+      layout.row_offsets = g.d_layout_row_offsets.data();
+      layout.col_indices = g.d_layout_col_indices.data();
+      layout.new_of_old = g.d_new_of_old.data();
+      layout.old_of_new = g.d_old_of_new.data();
+    }
+    // the hub-first layout carries no separate CSC: bottom-up levels can use it only on graphs whose
+    // CSC slots alias the CSR (symmetric input, what the reference always has)
+    const bool use_layout = g.has_layout && (!direction_optimizing || g.csc_is_csr);
+    mgx::bfs_fused_run(fused, g.d_row_offsets.data(), g.d_col_indices.data(), bfs_problem->d_labels.data(),
+                       bfs_problem->src, context, use_layout ? &layout : nullptr, direction_optimizing ? 1 : 0, alpha,
+                       g.d_col_offsets.data(), g.d_row_indices.data());
   }
 };
 

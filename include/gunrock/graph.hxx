@@ -59,6 +59,15 @@ struct graph_device_t {
   // true when the CSC slots alias the CSR arrays (what the reference always has)
   bool csc_is_csr = true;
 
+  // Optional hub-first layout for the fused traversal (not in the reference): the same graph with
+  // vertex ids renumbered by descending degree, plus both id maps.  Operators keep using the
+  // arrays above; results are always reported in original ids.
+  mem_t<int> d_layout_row_offsets;
+  mem_t<int> d_layout_col_indices;
+  mem_t<int> d_new_of_old;
+  mem_t<int> d_old_of_new;
+  bool has_layout = false;
+
   graph_device_t() : num_nodes(0), num_edges(0) {}
 
   void ensure_scanned(size_t slots, standard_context_t& ctx) {

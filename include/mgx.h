@@ -67,6 +67,13 @@ MGX_API int mgx_graph_wrap_device(mgx_ctx_t ctx, int num_nodes, int64_t num_edge
                                   const int* d_row_offsets, const int* d_col_indices, const float* d_weights,
                                   const int* d_col_offsets, const int* d_row_indices, const float* d_row_weights,
                                   mgx_graph_t* out);
+/* Optional hub-first layout used by mgx_bfs_run (not in the reference): the same graph with vertex
+ * ids renumbered by DESCENDING DEGREE (layout id 0 = highest degree), as CSR, plus the two id maps
+ * (new_of_old[old] = layout id, old_of_new = inverse).  With it the hot prefix of the visited
+ * bitmap (the vertices that receive most edges) is kept in LDS.  Device pointers are borrowed.
+ * Results (labels) are always in original ids; the operator entry points ignore the layout.   */
+MGX_API int mgx_graph_attach_layout(mgx_graph_t g, const int* d_layout_row_offsets, const int* d_layout_col_indices,
+                                    const int* d_new_of_old, const int* d_old_of_new);
 MGX_API int mgx_graph_free(mgx_graph_t g);
 MGX_API int mgx_graph_dims(mgx_graph_t g, int* num_nodes, int64_t* num_edges);
 /* host-side MTX text loader, bug-compatible with load_graph (graph.hxx:96-223): row = 2nd

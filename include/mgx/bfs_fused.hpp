@@ -45,7 +45,10 @@ struct bfs_ctrl_t {
   u64 diag[8];       // DIAG builds only: cycles per stage, summed over workgroups (thread 0 stamps)
   int done;
   int levels;        // number of levels that expanded at least one edge
-  u64 trace[BFS_MAX_TRACE];   // cursor value each level started from
+  int pull;          // direction of the level about to run (set by k_bfs_level_begin; sticky once 1)
+  int push_levels;   // levels run top-down
+  u64 pull_edges;    // in-edges inspected by bottom-up levels
+  u64 trace[BFS_MAX_TRACE];   // cursor value each level started from (kept LAST: read back only up to `levels`)
 };
 
 struct bfs_fused_args_t {
@@ -57,14 +60,23 @@ struct bfs_fused_args_t {
   u32* fr_row[2];      // frontier: CSR row start of each frontier vertex
   u32* fr_off[2];      // frontier: exclusive scan of degrees (edge rank of its first edge)
   bfs_ctrl_t* ctrl;
+  u32* frontier_bits;      // direction-optimising runs: bitmap of the level's frontier (visited now & ~snapshot before)
+  const u32* in_offsets;   // in-edges for bottom-up levels (== row_offsets/col_indices on symmetric graphs)
+  const int* in_indices;
+  int mode;                // MGX_BFS_PUSH / MGX_BFS_DIRECTION_OPT
+  float alpha;             // switch to bottom-up when unvisited < frontier_vertices * alpha (bfs_enactor.hxx:68)
+  const int* old_of_new;   // hub-first layout: original id of layout vertex v (NULL = identity)
+  const int* new_of_old;   // and its inverse
   int n;
+  int hot_min_tiles;   // hot-bitmap kernel: LDS copy is used when a workgroup streams at least this many tiles
   int flags;           // diagnostics only: bit 0 = skip the claims (results are then wrong by design)
 };
 
 __global__ void k_bfs_fused_init(bfs_fused_args_t a, int src) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   bfs_ctrl_t* c = a.ctrl;
-  a.labels[src] = 0;
+  a.labels[src] = 0;                                   // labels live in ORIGINAL id space
+  if (a.new_of_old) src = a.new_of_old[src];           // everything else in layout space
   a.visited[src >> 5] = 1u << (src & 31);
   const u32 ro = a.row_offsets[src];
   const u32 deg = a.row_offsets[src + 1] - ro;
@@ -81,6 +93,42 @@ __global__ void k_bfs_fused_init(bfs_fused_args_t a, int src) {
   for (int i = 0; i < 8; ++i) c->diag[i] = 0;
   c->done = 0;
   c->levels = 0;
+  c->pull = 0;
+  c->push_levels = 0;
+  c->pull_edges = 0;
+}
+
+// Runs before the kernel(s) of every level: per-level bookkeeping (termination flag, trace, TEPS
+// numerator), the direction decision, and the level-start snapshot of the visited bitmap --
+// plus, for direction-optimising runs, the frontier bitmap (what became visited since the last snapshot).
+__global__ __launch_bounds__(BLOCK) void k_bfs_level_begin(bfs_fused_args_t a, int level, long long nwords) {
+  bfs_ctrl_t* const c = a.ctrl;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const u64 cur = c->cursor[level % 3];
+    const long long nf = (long long)(cur >> BFS_VSHIFT);
+    const u64 E = cur & BFS_EMASK;
+    c->cursor[(level + 2) % 3] = 0;
+    if (nf == 0) {
+      if (!c->done) { c->done = 1; c->levels = level; }
+    } else {
+      if (level < BFS_MAX_TRACE) c->trace[level] = cur;
+      c->sum_edges += E;
+      c->sum_frontier += (u64)nf;
+      if (a.mode == 1 && !c->pull) {
+        const float unvisited = (float)((long long)a.n - (long long)c->reached);
+        if (unvisited < (float)nf * a.alpha) c->pull = 1;      // bfs_enactor.hxx:68; never switches back (:74-112)
+      }
+      if (!c->pull) c->push_levels += 1;
+    }
+  }
+  const bool want_frontier = a.mode == 1;
+  const u32* __restrict__ vis = a.visited;
+  u32* __restrict__ snap = (u32*)a.snapshot;
+  for (long long w = (long long)blockIdx.x * BLOCK + threadIdx.x; w < nwords; w += (long long)gridDim.x * BLOCK) {
+    const u32 now = vis[w];
+    if (want_frontier) a.frontier_bits[w] = now & ~snap[w];
+    snap[w] = now;
+  }
 }
 
 // EPT = edge ranks per lane per tile (tile = BLOCK*EPT ranks, strided by the workgroup so a wave's
@@ -122,17 +170,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_bfs_push_level(bfs_fused_args_t 
   const u64 cur = c->cursor[level % 3];
   const long long nf = (long long)(cur >> BFS_VSHIFT);
   const u64 E = cur & BFS_EMASK;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    c->cursor[(level + 2) % 3] = 0;
-    if (nf == 0) {
-      if (!c->done) { c->done = 1; c->levels = level; }
-    } else {
-      if (level < BFS_MAX_TRACE) c->trace[level] = cur;
-      c->sum_edges += E;
-      c->sum_frontier += (u64)nf;
-    }
-  }
-  if (nf == 0) return;
+  if (nf == 0 || c->pull) return;   // bookkeeping and direction: k_bfs_level_begin
 
   const u32* __restrict__ fr_row = a.fr_row[level & 1];
   const u32* __restrict__ fr_off = a.fr_off[level & 1];
@@ -199,7 +237,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_bfs_push_level(bfs_fused_args_t 
       const u32 w = win ? v[q] : 0u;
       ro[q] = a.row_offsets[w];
       ro1[q] = a.row_offsets[w + 1];
-      if (win) a.labels[v[q]] = new_label;
+      if (win) a.labels[a.old_of_new ? a.old_of_new[v[q]] : (int)v[q]] = new_label;
     }
     u64 loc[PER];
     u64 sum = 0;
@@ -232,13 +270,20 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_bfs_push_level(bfs_fused_args_t 
   };
 
   // prefetch registers for the first BLOCK+1 (offset,row) pairs of the coming tile
+  // Prefetch registers for the (offset,row) pairs of the coming tile.  The loads are UNCONDITIONAL
+  // (index clamped, validity applied where the values are consumed): a load inside a branch makes
+  // the number of outstanding loads unknowable to hipcc, which then drains everything with
+  // s_waitcnt vmcnt(0) at the next use and serialises the software pipeline.
   u32 pf_off = 0, pf_row = 0, pf_off_last = 0;
+  bool pf_ok = false, pf_last_ok = false;
   auto prefetch = [&](long long sg) {
     const long long s0 = sg + threadIdx.x;
-    pf_off = (s0 < nf) ? fr_off[s0] : (u32)E;
-    pf_row = (s0 < nf) ? fr_row[s0] : 0u;
     const long long s1 = sg + BLOCK;                 // one extra offset so BLOCK segments are usable
-    pf_off_last = (s1 < nf) ? fr_off[s1] : (u32)E;
+    pf_ok = s0 < nf;
+    pf_last_ok = s1 < nf;
+    pf_off = fr_off[pf_ok ? s0 : nf - 1];
+    pf_row = fr_row[pf_ok ? s0 : nf - 1];
+    pf_off_last = fr_off[pf_last_ok ? s1 : nf - 1];
   };
   prefetch(seg);
 
@@ -251,9 +296,9 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_bfs_push_level(bfs_fused_args_t 
     // stage (scanned offset, row start) of the segments beginning at `seg`: the prefetched round
     // first, more rounds of BLOCK only if the tile spans more than BLOCK segments.  Segments are
     // non-empty, so TILE+1 offsets always suffice.
-    s_off[threadIdx.x] = pf_off;
-    s_row[threadIdx.x] = pf_row;
-    if (threadIdx.x == 0) s_off[BLOCK] = pf_off_last;
+    s_off[threadIdx.x] = pf_ok ? pf_off : (u32)E;
+    s_row[threadIdx.x] = pf_ok ? pf_row : 0u;
+    if (threadIdx.x == 0) s_off[BLOCK] = pf_last_ok ? pf_off_last : (u32)E;
     __syncthreads();
     int limit = BLOCK;   // index of the last staged offset
     while ((u64)s_off[limit] < E1 && limit < TILE) {
@@ -390,6 +435,7 @@ __global__ __launch_bounds__(BLOCK, OCC) void k_bfs_push_level(bfs_fused_args_t 
 struct bfs_fused_state_t {
   mem_t<u32> visited;
   mem_t<u32> snapshot;
+  mem_t<u32> frontier_bits;
   mem_t<u32> fr_row[2];
   mem_t<u32> fr_off[2];
   mem_t<bfs_ctrl_t> ctrl;
@@ -400,6 +446,8 @@ struct bfs_fused_state_t {
   int ept = 4;                       // edge ranks per lane per tile (4 or 8)
   int occ = 5;                       // workgroups per CU the kernel is register-budgeted for
   bool diag = false;                 // MGX_BFS_DIAG=1: stage-stamped diagnostic kernel (EPT 4)
+  int hot_min_tiles = 4;
+  int hot = -1;                      // LDS-resident hot bitmap kernel: -1 auto (on when a hub-first layout is attached), 0/1 forced
   // timing of the level kernels of the last run (HIP events around each batch of launches)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double level_kernel_ms = 0.0;
@@ -410,7 +458,13 @@ struct bfs_fused_state_t {
   bfs_fused_state_t() {}
   bfs_fused_state_t(int num_nodes, standard_context_t& ctx) : n(num_nodes) {
     visited = mem_t<u32>((size_t)(num_nodes + 31) / 32 + 1, ctx);
-    snapshot = mem_t<u32>((size_t)(num_nodes + 31) / 32 + 1, ctx);
+    {
+      size_t words = (size_t)(num_nodes + 31) / 32 + 1;
+      if (words < 65536) words = 65536;            // the hot-bitmap kernel copies a fixed 64 KB prefix
+      snapshot = mem_t<u32>(words, ctx);
+      MGX_HIP(hipMemsetAsync(snapshot.data(), 0, words * sizeof(u32), ctx.stream()));
+      frontier_bits = mem_t<u32>(words, ctx);
+    }
     for (int i = 0; i < 2; ++i) {
       fr_row[i] = mem_t<u32>((size_t)num_nodes + 1, ctx);
       fr_off[i] = mem_t<u32>((size_t)num_nodes + 1, ctx);
@@ -421,6 +475,8 @@ struct bfs_fused_state_t {
     MGX_HIP(hipEventCreate(&ev1));
     if (const char* e = getenv("MGX_BFS_EPT")) ept = (atoi(e) == 8) ? 8 : 4;
     if (const char* e = getenv("MGX_BFS_DIAG")) diag = atoi(e) != 0;
+    if (const char* e = getenv("MGX_BFS_HOT")) hot = atoi(e);
+    if (const char* e = getenv("MGX_BFS_HOT_MIN_TILES")) hot_min_tiles = atoi(e);
     occ = (ept == 8) ? 4 : 5;
     if (const char* e = getenv("MGX_BFS_OCC")) occ = atoi(e) > 0 ? atoi(e) : occ;
     grid = ctx.num_cus * occ;
@@ -431,12 +487,13 @@ struct bfs_fused_state_t {
   bfs_fused_state_t& operator=(bfs_fused_state_t&& r) noexcept {
     visited = std::move(r.visited);
     snapshot = std::move(r.snapshot);
+    frontier_bits = std::move(r.frontier_bits);
     for (int i = 0; i < 2; ++i) { fr_row[i] = std::move(r.fr_row[i]); fr_off[i] = std::move(r.fr_off[i]); }
     ctrl = std::move(r.ctrl);
     std::swap(host_ctrl, r.host_ctrl);
     std::swap(ev0, r.ev0);
     std::swap(ev1, r.ev1);
-    n = r.n; levels_per_sync = r.levels_per_sync; grid = r.grid; ept = r.ept; diag = r.diag; occ = r.occ;
+    n = r.n; levels_per_sync = r.levels_per_sync; grid = r.grid; ept = r.ept; diag = r.diag; occ = r.occ; hot = r.hot; hot_min_tiles = r.hot_min_tiles;
     return *this;
   }
   ~bfs_fused_state_t() {
@@ -445,58 +502,5 @@ struct bfs_fused_state_t {
     if (ev1) (void)hipEventDestroy(ev1);
   }
 };
-
-// Runs a whole push BFS from `src` on the context's stream.  labels[] is (re)initialised here.
-// Returns with the stream synchronised and host_ctrl holding the final counters.
-inline void bfs_fused_push_run(bfs_fused_state_t& st, const int* row_offsets, const int* col_indices, int* labels,
-                               int src, standard_context_t& ctx) {
-  hipStream_t s = ctx.stream();
-  bfs_fused_args_t a;
-  a.row_offsets = (const u32*)row_offsets;
-  a.col_indices = col_indices;
-  a.labels = labels;
-  a.visited = st.visited.data();
-  a.snapshot = st.snapshot.data();
-  for (int i = 0; i < 2; ++i) { a.fr_row[i] = st.fr_row[i].data(); a.fr_off[i] = st.fr_off[i].data(); }
-  a.ctrl = st.ctrl.data();
-  a.n = st.n;
-  a.flags = 0;
-  if (const char* e = getenv("MGX_BFS_FLAGS")) a.flags = atoi(e);
-  MGX_HIP(hipMemsetAsync(labels, 0xFF, (size_t)st.n * sizeof(int), s));
-  MGX_HIP(hipMemsetAsync(st.visited.data(), 0, st.visited.size() * sizeof(u32), s));
-  hipLaunchKernelGGL(k_bfs_fused_init, dim3(1), dim3(64), 0, s, a, src);
-  int level = 0;
-  st.level_kernel_ms = 0.0;
-  st.level_kernel_launches = 0;
-  st.batches = 0;
-  for (;;) {
-    MGX_HIP(hipEventRecord(st.ev0, s));
-    for (int i = 0; i < st.levels_per_sync; ++i, ++level) {
-      // level-start snapshot of the visited bitmap (n/8 bytes, device to device)
-      MGX_HIP(hipMemcpyAsync(st.snapshot.data(), st.visited.data(), st.visited.size() * sizeof(u32),
-                             hipMemcpyDeviceToDevice, s));
-#define MGX_LAUNCH_LEVEL(E_, O_, D_) \
-  hipLaunchKernelGGL((k_bfs_push_level<E_, O_, D_>), dim3(st.grid), dim3(BLOCK), 0, s, a, level)
-      if (st.diag) MGX_LAUNCH_LEVEL(4, 5, true);
-      else if (st.ept == 8 && st.occ <= 3) MGX_LAUNCH_LEVEL(8, 3, false);
-      else if (st.ept == 8) MGX_LAUNCH_LEVEL(8, 4, false);
-      else if (st.occ >= 6) MGX_LAUNCH_LEVEL(4, 6, false);
-      else if (st.occ == 5) MGX_LAUNCH_LEVEL(4, 5, false);
-      else MGX_LAUNCH_LEVEL(4, 4, false);
-#undef MGX_LAUNCH_LEVEL
-    }
-    MGX_HIP(hipEventRecord(st.ev1, s));
-    MGX_HIP(hipMemcpyAsync(&st.host_ctrl->done, &st.ctrl.data()->done, sizeof(int), hipMemcpyDeviceToHost, s));
-    MGX_HIP(hipStreamSynchronize(s));
-    float ms = 0.f;
-    MGX_HIP(hipEventElapsedTime(&ms, st.ev0, st.ev1));
-    st.level_kernel_ms += ms;
-    if (st.batches < 256) st.batch_ms[st.batches++] = ms;
-    st.level_kernel_launches += st.levels_per_sync;
-    if (st.host_ctrl->done) break;
-  }
-  MGX_HIP(hipMemcpyAsync(st.host_ctrl, st.ctrl.data(), sizeof(bfs_ctrl_t), hipMemcpyDeviceToHost, s));
-  MGX_HIP(hipStreamSynchronize(s));
-}
 
 }  // namespace mgx

@@ -271,6 +271,19 @@ int mgx_graph_wrap_device(mgx_ctx_t c, int n, int64_t m, const int* ro, const in
   *out = h;
   MGX_CATCH
 }
+int mgx_graph_attach_layout(mgx_graph_t g, const int* d_row_offsets, const int* d_col_indices, const int* d_new_of_old,
+                            const int* d_old_of_new) {
+  MGX_TRY
+  MGX_REQUIRE(g && d_row_offsets && (d_col_indices || g->g->num_edges == 0) && d_new_of_old && d_old_of_new,
+              "mgx_graph_attach_layout: NULL argument");
+  graph_device_t& G = *g->g;
+  G.d_layout_row_offsets = mem_t<int>::borrow((int*)d_row_offsets, (size_t)G.num_nodes + 1);
+  G.d_layout_col_indices = mem_t<int>::borrow((int*)d_col_indices, (size_t)G.num_edges);
+  G.d_new_of_old = mem_t<int>::borrow((int*)d_new_of_old, (size_t)G.num_nodes);
+  G.d_old_of_new = mem_t<int>::borrow((int*)d_old_of_new, (size_t)G.num_nodes);
+  G.has_layout = true;
+  MGX_CATCH
+}
 int mgx_graph_free(mgx_graph_t g) {
   MGX_TRY
   if (g) { use_device(g->c); delete g; }
@@ -580,20 +593,21 @@ int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats) {
   MGX_TRY
   MGX_REQUIRE(p, "NULL argument");
   MGX_REQUIRE(src >= 0 && src < p->g->g->num_nodes, "mgx_bfs_run: src out of range");
-  MGX_REQUIRE(mode == MGX_BFS_PUSH, "mgx_bfs_run: only MGX_BFS_PUSH is implemented in this build");
-  (void)alpha;
+  MGX_REQUIRE(mode == MGX_BFS_PUSH || mode == MGX_BFS_DIRECTION_OPT, "mgx_bfs_run: unknown mode");
   use_device(p->g->c);
   standard_context_t& ctx = *p->g->c->ctx;
   if (!p->fe) p->fe.reset(new bfs::bfs_fused_enactor_t(ctx, p->g->g->num_nodes));
   p->p->src = src;
-  p->fe->enact(p->p, ctx);
+  p->fe->enact(p->p, ctx, mode == MGX_BFS_DIRECTION_OPT, alpha);
   const mgx::bfs_ctrl_t* hc = p->fe->fused.host_ctrl;
   p->last_stats[0] = hc->levels;
   p->last_stats[1] = (int64_t)hc->reached;
   p->last_stats[2] = (int64_t)hc->sum_edges;
-  p->last_stats[3] = (int64_t)hc->sum_edges;
-  p->last_stats[4] = 0;
-  p->last_stats[5] = hc->levels;
+  p->last_stats[3] = 0;   // filled below: edges expanded by the top-down levels
+  p->last_stats[4] = (int64_t)hc->pull_edges;
+  p->last_stats[5] = hc->push_levels;
+  for (int i = 0; i < hc->push_levels && i < mgx::BFS_MAX_TRACE; ++i)
+    p->last_stats[3] += (int64_t)(hc->trace[i] & mgx::BFS_EMASK);   // direction never switches back
   p->last_stats[6] = p->fe->fused.level_kernel_launches;
   p->last_stats[7] = (int64_t)(p->fe->fused.level_kernel_ms * 1e6);
   p->last_stats[8] = (int64_t)hc->sum_frontier;

@@ -68,6 +68,30 @@ def rmat_csr(ctx, scale, edgefactor=16, seed=None, weighted=False, scramble=True
     return {"n": n, "m": int(ci.numel()), "row_offsets": ro, "col_indices": ci, "weights": weights}
 
 
+def degree_order(row_offsets, col_indices):
+    """Hub-first layout of a CSR (device tensors): vertex ids renumbered by descending degree (stable).
+
+    Returns (layout_row_offsets, layout_col_indices, new_of_old, old_of_new), all int32 on the device.
+    Setup plumbing (untimed graph construction, like the CSR build itself); rows stay sorted by
+    (new) neighbour id.
+    """
+    n = row_offsets.numel() - 1
+    ro = row_offsets.to(torch.int64)
+    deg = ro[1:] - ro[:-1]
+    old_of_new = torch.sort(deg, descending=True, stable=True).indices
+    new_of_old = torch.empty_like(old_of_new)
+    new_of_old[old_of_new] = torch.arange(n, device=ro.device)
+    rows_old = torch.repeat_interleave(torch.arange(n, device=ro.device), deg)
+    key = (new_of_old[rows_old] << 32) | new_of_old[col_indices.to(torch.int64)]
+    del rows_old
+    key, _ = torch.sort(key)
+    lcol = (key & 0xFFFFFFFF).to(torch.int32)
+    del key
+    lro = torch.zeros(n + 1, dtype=torch.int64, device=ro.device)
+    torch.cumsum(deg[old_of_new], 0, out=lro[1:])
+    return lro.to(torch.int32), lcol, new_of_old.to(torch.int32), old_of_new.to(torch.int32)
+
+
 def pick_sources(row_offsets_host, count, seed):
     """`count` vertices with degree > 0: splitmix64(seed + i) mod n, skipping isolated ones."""
     n = len(row_offsets_host) - 1

@@ -268,6 +268,86 @@ def test_bfs_rmat_parity_all_paths(gpu_ctx, oracle, rmat_graphs, scale):
             assert np.array_equal(bfs.labels(), want), "pushpull alpha=%s src=%d" % (alpha, src)
 
 
+@pytest.mark.parametrize("scale,min_tiles", [(10, 0), (13, 0), (16, 0), (16, 4)])
+def test_bfs_hub_first_layout_and_lds_hot_bitmap(gpu_ctx, oracle, torch_mod, rmat_graphs, scale, min_tiles, monkeypatch):
+    """fused traversal on the degree-sorted layout (LDS-resident hot bitmap kernel): labels must come
+    back in ORIGINAL ids and equal the oracle's; min_tiles=0 forces the LDS path on small graphs."""
+    import mini_amd
+    from mini_amd import rmat
+    torch = torch_mod
+    monkeypatch.setenv("MGX_BFS_HOT_MIN_TILES", str(min_tiles))
+    n, ro, ci, w = rmat_graphs[scale]
+    d_ro, d_ci = torch.from_numpy(ro).cuda(), torch.from_numpy(ci).cuda()
+    g = mini_amd.Graph.from_device(gpu_ctx, n, len(ci), d_ro, d_ci)
+    lro, lci, new_of_old, old_of_new = rmat.degree_order(d_ro, d_ci)
+    # the layout is the same graph: degrees sorted descending, maps inverse of each other
+    ldeg = np.diff(lro.cpu().numpy())
+    assert np.all(np.diff(ldeg) <= 0)
+    assert np.array_equal(new_of_old.cpu().numpy()[old_of_new.cpu().numpy()], np.arange(n))
+    g.attach_layout(lro, lci, new_of_old, old_of_new)
+    deg = np.diff(ro)
+    bfs = mini_amd.BfsProblem(g, 0)
+    iso = np.where(deg == 0)[0]
+    for src in [int(np.argmax(deg))] + rmat.pick_sources(ro, 3, scale + 7) + ([int(iso[0])] if len(iso) else []):
+        want = oracle.bfs_cpu(ro, ci, src)
+        st = bfs.run(src)
+        assert np.array_equal(bfs.labels(), want), "src=%d" % src
+        assert st["reached"] == int((want >= 0).sum()) and st["m_t"] == int(deg[want >= 0].sum())
+        # the operator path ignores the layout
+        bfs.reset(src)
+        bfs.enact_pushpull()
+        assert np.array_equal(bfs.labels(), want)
+
+
+@pytest.mark.parametrize("scale", [10, 13, 16])
+@pytest.mark.parametrize("layout", [False, True])
+def test_bfs_direction_optimizing_fused(gpu_ctx, oracle, torch_mod, rmat_graphs, scale, layout, monkeypatch):
+    """fused direction-optimising traversal (bottom-up levels once unvisited < frontier*alpha,
+    bfs_enactor.hxx:68): labels equal the top-down oracle for every switch point, incl. pull from level 0."""
+    import mini_amd
+    from mini_amd import rmat
+    torch = torch_mod
+    monkeypatch.setenv("MGX_BFS_HOT_MIN_TILES", "0")
+    n, ro, ci, w = rmat_graphs[scale]
+    d_ro, d_ci = torch.from_numpy(ro).cuda(), torch.from_numpy(ci).cuda()
+    g = mini_amd.Graph.from_device(gpu_ctx, n, len(ci), d_ro, d_ci)
+    if layout:
+        g.attach_layout(*rmat.degree_order(d_ro, d_ci))
+    deg = np.diff(ro)
+    bfs = mini_amd.BfsProblem(g, 0)
+    for src in [int(np.argmax(deg))] + rmat.pick_sources(ro, 2, scale + 3):
+        want = oracle.bfs_cpu(ro, ci, src)
+        seen_pull = False
+        for alpha in (0.05, 1.0, 4.0, 64.0, 1e9):
+            st = bfs.run(src, mode=mini_amd.MGX_BFS_DIRECTION_OPT, alpha=alpha)
+            assert np.array_equal(bfs.labels(), want), "alpha=%g src=%d" % (alpha, src)
+            assert st["reached"] == int((want >= 0).sum()) and st["m_t"] == int(deg[want >= 0].sum())
+            assert st["push_levels"] <= st["levels"]
+            seen_pull = seen_pull or st["pull_edges"] > 0
+            if alpha == 1e9:
+                assert st["push_levels"] == 0 and st["push_edges"] == 0
+        assert seen_pull
+
+
+def test_bfs_direction_optimizing_directed_needs_genuine_csc(gpu_ctx, oracle):
+    """directed input: bottom-up levels walk IN-edges, so the graph must carry a genuine CSC
+    (the reference's CSC is a CSR copy and its pull phase is wrong there)"""
+    import mini_amd
+    rng = np.random.default_rng(11)
+    n, e = 4000, 30000
+    t0 = rng.integers(0, n, size=e).astype(np.int32)
+    t1 = rng.integers(0, n, size=e).astype(np.int32)
+    ro, ci, _ = oracle.csr_from_tuples(n, t0, t1, None, undir=False)       # row t1 -> neighbour t0
+    co, ri, _ = oracle.csr_from_tuples(n, t1, t0, None, undir=False)       # transpose: row t0 <- t1
+    g = mini_amd.Graph.from_host(gpu_ctx, ro, ci, None, co, ri)
+    bfs = mini_amd.BfsProblem(g, 0)
+    for src in (int(t1[0]), int(t1[5])):
+        want = oracle.bfs_cpu(ro, ci, src)
+        for alpha in (0.5, 8.0, 1e9):
+            bfs.run(src, mode=mini_amd.MGX_BFS_DIRECTION_OPT, alpha=alpha)
+            assert np.array_equal(bfs.labels(), want), alpha
+
+
 def test_bfs_directed_graph_with_zero_outdegree_vertices(gpu_ctx, oracle):
     """directed (undir=false) graphs have reachable vertices with no out-edges: they get a label
     but never enter the fused frontier."""
@@ -407,3 +487,10 @@ def test_bfs_large_rmat_properties(gpu_ctx, torch_mod):
     bfs.reset(src)
     bfs.enact_pushpull()
     assert np.array_equal(bfs.labels(), fused)
+    # hub-first layout + LDS hot bitmap kernel: same labels, original ids
+    lay = rmat.degree_order(g["row_offsets"], g["col_indices"])
+    graph2 = mini_amd.Graph.from_device(gpu_ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"]).attach_layout(*lay)
+    bfs2 = mini_amd.BfsProblem(graph2, src)
+    st2 = bfs2.run(src)
+    assert np.array_equal(bfs2.labels(), fused)
+    assert st2["m_t"] == st["m_t"] and st2["reached"] == st["reached"]

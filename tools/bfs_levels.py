@@ -7,26 +7,28 @@ import numpy as np, torch
 import mini_amd
 from mini_amd import rmat
 
-ap = argparse.ArgumentParser(); ap.add_argument("--scale", type=int, default=22); ap.add_argument("--runs", type=int, default=3)
+ap = argparse.ArgumentParser(); ap.add_argument("--scale", type=int, default=22); ap.add_argument("--runs", type=int, default=3); ap.add_argument("--layout", type=int, default=1); ap.add_argument("--mode", type=int, default=0); ap.add_argument("--alpha", type=float, default=4.0)
 a = ap.parse_args()
 ctx = mini_amd.Context(0, torch.cuda.current_stream().cuda_stream)
 g = rmat.rmat_csr(ctx, a.scale, 16, seed=a.scale)
 graph = mini_amd.Graph.from_device(ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"])
+if a.layout:
+    graph.attach_layout(*rmat.degree_order(g["row_offsets"], g["col_indices"]))
 ro = g["row_offsets"].cpu().numpy()
 srcs = rmat.pick_sources(ro, a.runs + 1, a.scale)
 bfs = mini_amd.BfsProblem(graph, srcs[0])
-bfs.run(srcs[0])
+bfs.run(srcs[0], a.mode, a.alpha)
 for s in srcs[1:]:
-    st = bfs.run(s)
+    st = bfs.run(s, a.mode, a.alpha)
     tr, ms, cl = bfs.level_trace(), bfs.batch_times_ms(), bfs.level_claims()
     print("src %d: levels %d reached %d m_t %d kernel_ms %.3f" % (s, st["levels"], st["reached"], st["m_t"], st["kernel_ns"] / 1e6))
-    print("  claims %d" % st["claims"])
+    print("  claims %d  push_levels %d  push_edges %d  pull_edges %d" % (st["claims"], st["push_levels"], st["push_edges"], st["pull_edges"]))
     for lv, ((nf, ne), t) in enumerate(zip(tr, ms)):
         b = 8.0 * ne + 20.0 * nf
         print("  level %2d  nf %9d  edges %10d  %8.3f ms  %8.1f GTEPS  %7.1f algGB/s  claims %9d" % (lv, nf, ne, t, ne / t / 1e6 if t > 0 else 0, b / t / 1e6 if t > 0 else 0, cl[lv] if lv < 64 else -1))
     if os.environ.get("MGX_BFS_DIAG") == "1":
         d = bfs.diag_cycles(); tot = float(sum(d)) or 1.0
-        names = ["staging", "search", "col", "visited", "claim", "barrier", "flush", "-"]
+        names = ["S4a+words", "midbar", "midflush", "S4b", "col+issue", "prepare", "endbar", "endflush"]
         print("  diag (share of stamped cycles, whole run): " + "  ".join("%s %.1f%%" % (n, 100 * x / tot) for n, x in zip(names, d)))
         print("  diag cycles per workgroup-tile: total %.0f" % (tot / max(1, st["m_t"] / 1024)))
     print("  tail batches:", ["%.4f" % x for x in ms[len(tr):]])
