@@ -10,7 +10,7 @@
 #include "../filter.hxx"
 #include "../frontier.hxx"
 #include "../graph.hxx"
-#include "../../mgx/bfs_fused_hot.hpp"
+#include "../../mgx/bfs_fused_wave.hpp"
 #include "bfs_functor.hxx"
 #include "bfs_problem.hxx"
 

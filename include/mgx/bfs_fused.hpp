@@ -47,6 +47,8 @@ struct bfs_ctrl_t {
   int levels;        // number of levels that expanded at least one edge
   int pull;          // direction of the level about to run (set by k_bfs_level_begin; sticky once 1)
   int push_levels;   // levels run top-down
+  int kind;          // top-down kernel for the level about to run: 0 = workgroup-synchronous tiles
+                     // (discovery-heavy levels: big flushes), 1 = wave-private streaming (k_bfs_level_begin)
   u64 pull_edges;    // in-edges inspected by bottom-up levels
   u64 trace[BFS_MAX_TRACE];   // cursor value each level started from (kept LAST: read back only up to `levels`)
 };
@@ -63,6 +65,8 @@ struct bfs_fused_args_t {
   u32* frontier_bits;      // direction-optimising runs: bitmap of the level's frontier (visited now & ~snapshot before)
   const u32* in_offsets;   // in-edges for bottom-up levels (== row_offsets/col_indices on symmetric graphs)
   const int* in_indices;
+  int wave_kernel;         // 1: levels whose average frontier degree is below wave_max_avg_degree use the wave kernel
+  int wave_max_avg_degree;
   int mode;                // MGX_BFS_PUSH / MGX_BFS_DIRECTION_OPT
   float alpha;             // switch to bottom-up when unvisited < frontier_vertices * alpha (bfs_enactor.hxx:68)
   const int* old_of_new;   // hub-first layout: original id of layout vertex v (NULL = identity)
@@ -95,6 +99,7 @@ __global__ void k_bfs_fused_init(bfs_fused_args_t a, int src) {
   c->levels = 0;
   c->pull = 0;
   c->push_levels = 0;
+  c->kind = 0;
   c->pull_edges = 0;
 }
 
@@ -119,6 +124,9 @@ __global__ __launch_bounds__(BLOCK) void k_bfs_level_begin(bfs_fused_args_t a, i
         if (unvisited < (float)nf * a.alpha) c->pull = 1;      // bfs_enactor.hxx:68; never switches back (:74-112)
       }
       if (!c->pull) c->push_levels += 1;
+      // long rows (a hub frontier) discover a lot per edge: batch the claims per workgroup; short rows
+      // (the big levels of a skewed graph) mostly hit visited vertices: stream them wave by wave
+      c->kind = (a.wave_kernel && E / (u64)nf < (u64)a.wave_max_avg_degree) ? 1 : 0;
     }
   }
   const bool want_frontier = a.mode == 1;

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_hot(bfs_fused_args_t a, i
   const u64 cur = c->cursor[level % 3];
   const long long nf = (long long)(cur >> BFS_VSHIFT);
   const u64 E = cur & BFS_EMASK;
-  if (nf == 0 || c->pull) return;   // bookkeeping and direction: k_bfs_level_begin
+  if (nf == 0 || c->pull || c->kind != 0) return;   // bookkeeping, direction and kernel choice: k_bfs_level_begin
 
   const u32* __restrict__ fr_row = a.fr_row[level & 1];
   const u32* __restrict__ fr_off = a.fr_off[level & 1];
@@ -487,119 +487,6 @@ __global__ __launch_bounds__(NT) void k_bfs_pull_level(bfs_fused_args_t a, int l
   if (threadIdx.x == 0) {
     if (s_wins) atomicAdd(&c->reached, (u64)s_wins);
     if (s_insp) atomicAdd(&c->pull_edges, (u64)s_insp);
-  }
-}
-
-// layout (optional): a hub-first relabelled copy of the CSR plus the two id maps; labels stay in the
-// original id space either way.
-struct bfs_layout_t {
-  const int* row_offsets = nullptr;
-  const int* col_indices = nullptr;
-  const int* new_of_old = nullptr;
-  const int* old_of_new = nullptr;
-};
-
-// mode/alpha: MGX_BFS_PUSH (0) or MGX_BFS_DIRECTION_OPT (1) with the reference's switch rule
-// num_unvisited < frontier_length * alpha (bfs_enactor.hxx:68).  in_offsets/in_indices: in-edges for the
-// bottom-up levels (pass the CSR for symmetric graphs, the reference's behaviour -- SURVEY F8).
-inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const int* col_indices, int* labels,
-                          int src, standard_context_t& ctx, const bfs_layout_t* layout = nullptr, int mode = 0,
-                          float alpha = 0.f, const int* in_offsets = nullptr, const int* in_indices = nullptr) {
-  hipStream_t s = ctx.stream();
-  bfs_fused_args_t a;
-  const bool relabelled = layout && layout->row_offsets;
-  a.row_offsets = (const u32*)(relabelled ? layout->row_offsets : row_offsets);
-  a.col_indices = relabelled ? layout->col_indices : col_indices;
-  a.old_of_new = relabelled ? layout->old_of_new : nullptr;
-  a.new_of_old = relabelled ? layout->new_of_old : nullptr;
-  const bool hot = (st.hot < 0) ? relabelled : (st.hot != 0);
-  // hot-kernel shapes: 0 = 512 threads x 64 KB bitmap x 2 per CU; 1 = 256 threads x 32 KB x 4 per CU;
-  // 2 = 256 threads, 8 ranks per lane, 32 KB x 4 per CU
-  static int shape = getenv("MGX_BFS_HOT_SHAPE") ? atoi(getenv("MGX_BFS_HOT_SHAPE")) : 1;
-  const int grid = hot ? ctx.num_cus * (shape == 0 ? 2 : 4) : st.grid;
-  const size_t hot_lds = shape == 0 ? bfs_hot_lds_bytes(512, 4, 16384)
-                                    : (shape == 1 ? bfs_hot_lds_bytes(256, 4, 8192) : bfs_hot_lds_bytes(256, 8, 8192));
-  if (hot) {
-    static bool attr_set = false;
-    if (!attr_set) {
-#define MGX_SET_LDS(K_) MGX_HIP(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-      MGX_SET_LDS((k_bfs_push_level_hot<512, 4, 16384, false>));
-      MGX_SET_LDS((k_bfs_push_level_hot<512, 4, 16384, true>));
-      MGX_SET_LDS((k_bfs_push_level_hot<256, 4, 8192, false>));
-      MGX_SET_LDS((k_bfs_push_level_hot<256, 8, 8192, false>));
-#undef MGX_SET_LDS
-      attr_set = true;
-    }
-  }
-  a.labels = labels;
-  a.visited = st.visited.data();
-  a.snapshot = st.snapshot.data();
-  a.frontier_bits = st.frontier_bits.data();
-  a.mode = mode;
-  a.alpha = alpha;
-  a.in_offsets = (const u32*)(relabelled ? layout->row_offsets : (in_offsets ? in_offsets : row_offsets));
-  a.in_indices = relabelled ? layout->col_indices : (in_indices ? in_indices : col_indices);
-  for (int i = 0; i < 2; ++i) { a.fr_row[i] = st.fr_row[i].data(); a.fr_off[i] = st.fr_off[i].data(); }
-  a.ctrl = st.ctrl.data();
-  a.n = st.n;
-  a.hot_min_tiles = st.hot_min_tiles;
-  a.flags = 0;
-  if (const char* e = getenv("MGX_BFS_FLAGS")) a.flags = atoi(e);
-  MGX_HIP(hipMemsetAsync(labels, 0xFF, (size_t)st.n * sizeof(int), s));
-  MGX_HIP(hipMemsetAsync(st.visited.data(), 0, st.visited.size() * sizeof(u32), s));
-  // the snapshot must start empty: level 0's frontier bitmap is (visited & ~snapshot)
-  MGX_HIP(hipMemsetAsync(st.snapshot.data(), 0, st.snapshot.size() * sizeof(u32), s));
-  hipLaunchKernelGGL(k_bfs_fused_init, dim3(1), dim3(64), 0, s, a, src);
-  int level = 0;
-  st.level_kernel_ms = 0.0;
-  st.level_kernel_launches = 0;
-  st.batches = 0;
-  for (;;) {
-    MGX_HIP(hipEventRecord(st.ev0, s));
-    for (int i = 0; i < st.levels_per_sync; ++i, ++level) {
-      // bookkeeping + direction decision + level-start snapshot of the visited bitmap (n/8 bytes)
-      {
-        const long long nwords = ((long long)st.n + 31) / 32;
-        hipLaunchKernelGGL(k_bfs_level_begin, dim3(grid_for(nwords, BLOCK, 256)), dim3(BLOCK), 0, s, a, level, nwords);
-      }
-#define MGX_LAUNCH_LEVEL(E_, O_, D_) \
-  hipLaunchKernelGGL((k_bfs_push_level<E_, O_, D_>), dim3(st.grid), dim3(BLOCK), 0, s, a, level)
-      if (hot && st.diag)
-        hipLaunchKernelGGL((k_bfs_push_level_hot<512, 4, 16384, true>), dim3(ctx.num_cus * 2), dim3(512),
-                           bfs_hot_lds_bytes(512, 4, 16384), s, a, level);
-      else if (hot && shape == 0)
-        hipLaunchKernelGGL((k_bfs_push_level_hot<512, 4, 16384, false>), dim3(grid), dim3(512), hot_lds, s, a, level);
-      else if (hot && shape == 1)
-        hipLaunchKernelGGL((k_bfs_push_level_hot<256, 4, 8192, false>), dim3(grid), dim3(256), hot_lds, s, a, level);
-      else if (hot)
-        hipLaunchKernelGGL((k_bfs_push_level_hot<256, 8, 8192, false>), dim3(grid), dim3(256), hot_lds, s, a, level);
-      else if (st.diag) MGX_LAUNCH_LEVEL(4, 5, true);
-      else if (st.ept == 8 && st.occ <= 3) MGX_LAUNCH_LEVEL(8, 3, false);
-      else if (st.ept == 8) MGX_LAUNCH_LEVEL(8, 4, false);
-      else if (st.occ >= 6) MGX_LAUNCH_LEVEL(4, 6, false);
-      else if (st.occ == 5) MGX_LAUNCH_LEVEL(4, 5, false);
-      else MGX_LAUNCH_LEVEL(4, 4, false);
-#undef MGX_LAUNCH_LEVEL
-      if (mode == 1)
-        hipLaunchKernelGGL(k_bfs_pull_level<256>, dim3(ctx.num_cus * 8), dim3(256), 0, s, a, level);
-    }
-    MGX_HIP(hipEventRecord(st.ev1, s));
-    MGX_HIP(hipMemcpyAsync(&st.host_ctrl->done, &st.ctrl.data()->done, sizeof(int), hipMemcpyDeviceToHost, s));
-    MGX_HIP(hipStreamSynchronize(s));
-    float ms = 0.f;
-    MGX_HIP(hipEventElapsedTime(&ms, st.ev0, st.ev1));
-    st.level_kernel_ms += ms;
-    if (st.batches < 256) st.batch_ms[st.batches++] = ms;
-    st.level_kernel_launches += st.levels_per_sync;
-    if (st.host_ctrl->done) break;
-  }
-  // counters first, then only the part of the per-level trace that was written
-  MGX_HIP(hipMemcpyAsync(st.host_ctrl, st.ctrl.data(), offsetof(bfs_ctrl_t, trace), hipMemcpyDeviceToHost, s));
-  MGX_HIP(hipStreamSynchronize(s));
-  const int lv = st.host_ctrl->levels < BFS_MAX_TRACE ? st.host_ctrl->levels : BFS_MAX_TRACE;
-  if (lv > 0) {
-    MGX_HIP(hipMemcpyAsync(st.host_ctrl->trace, st.ctrl.data()->trace, (size_t)lv * sizeof(u64), hipMemcpyDeviceToHost, s));
-    MGX_HIP(hipStreamSynchronize(s));
   }
 }
 

@@ -1,0 +1,21 @@
+#!/bin/bash
+# PMC passes over the push bench (k_bfs_push_level_hot): instruction mix and stall reasons
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc2; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_WAVES SQ_LEVEL_WAVES"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $set --output-format csv -d $O/p$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check > $O/p$i.log 2>&1
+  echo "pmc set $i rc=$?"
+done
+cd $R
+python3 - <<'PY'
+import csv,glob,collections,os
+O=os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/pmc2'
+for f in sorted(glob.glob(O+'/p*/**/*counter_collection.csv', recursive=True)):
+    agg=collections.Counter(); cnt=collections.Counter()
+    for r in csv.DictReader(open(f)):
+        if 'push_level' in r['Kernel_Name']:
+            agg[r['Counter_Name']]+=float(r['Counter_Value']); cnt[r['Counter_Name']]+=1
+    for k in agg: print('%-24s total=%.4g dispatches=%d'%(k,agg[k],cnt[k]))
+PY
