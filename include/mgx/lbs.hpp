@@ -110,21 +110,39 @@ inline void transform_lbs(F f, long long count, const int* segments, long long n
 
 // ---- segmented reduce over the same enumeration ----------------------------------------------
 // reduced[seg] = op-fold of f(idx, seg, rank) over the segment's items, identity for empty
-// segments.  Deterministic: inside a tile items fold left-to-right per segment; a segment
-// that spans tiles gets one partial per tile (carry_val/carry_seg, tile order) folded by a
-// second single-pass kernel in tile order.
+// segments.  Deterministic (fixed association order, no atomics on values):
+//   * a run of <= 32 items inside a tile is folded left to right by the lane holding its first item;
+//   * a longer run is folded by a whole wave (lane l takes items l, l+64, ... left to right, then a
+//     shuffle tree) -- RMAT hub rows span hundreds of tiles, one lane per run would serialise them;
+//   * a segment that spans tiles leaves one partial per tile (carry_val/carry_seg); the fix-up
+//     kernel gives every such segment to the thread of its opening tile, which walks the following
+//     tiles' continuation slots in order.
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_reduce_op(T x, Op op) {
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) {
+    const T y = __shfl_down(x, d, WAVE);
+    x = op(x, y);          // lanes >= WAVE-d combine with their own value's copy; only lane 0 is used
+  }
+  return x;
+}
+
 template <typename T, typename F, typename Op>
 __global__ __launch_bounds__(BLOCK) void k_lbs_segreduce(F f, long long count, const int* __restrict__ segments,
                                                           long long num_segments, T* __restrict__ reduced, Op op,
                                                           T identity, T* __restrict__ carry_val,
                                                           long long* __restrict__ carry_seg) {
+  constexpr int SHORT_RUN = 32;
   __shared__ int s_off[LBS_WINDOW];
   __shared__ long long s_bounds[2];
   __shared__ T s_val[LBS_TILE];
-  __shared__ int s_seg[LBS_TILE];    // segment index relative to seg_lo (global fallback: clipped)
+  __shared__ int s_seg[LBS_TILE];    // segment index relative to seg_lo
+  __shared__ int s_long[LBS_TILE / SHORT_RUN + 1];
+  __shared__ int s_nlong;
   const long long tile = blockIdx.x;
   const long long first = tile * LBS_TILE;
   const long long last = (first + LBS_TILE < count ? first + LBS_TILE : count) - 1;
+  if (threadIdx.x == 0) s_nlong = 0;
   lbs_tile_t t = lbs_stage_tile(segments, num_segments, first, last, s_off, s_bounds);
   const int nitems = (int)(last - first + 1);
 #pragma unroll
@@ -149,27 +167,51 @@ __global__ __launch_bounds__(BLOCK) void k_lbs_segreduce(F f, long long count, c
     }
   }
   __syncthreads();
-  // one lane per run of equal segment ids: the lane holding the run's first item folds it.
-  // Runs are contiguous because items are enumerated in segment order.
+  // where a finished run goes: straight to reduced[] if the segment lies inside this tile, else a carry
+  auto emit = [&](int li, int e, T acc) {
+    const int sg = s_seg[li];
+    const long long seg = t.seg_lo + sg;
+    const bool opens_here = (li > 0) || (segments[seg] == (int)first);
+    const long long seg_end = (seg + 1 < num_segments) ? (long long)segments[seg + 1] : count;
+    const bool closes_here = (e < nitems) || (seg_end - 1 == last);
+    if (opens_here && closes_here) {
+      reduced[seg] = acc;
+    } else {
+      const int slot = opens_here ? 1 : 0;     // 0: continues a segment begun earlier, 1: left open
+      carry_val[tile * 2 + slot] = acc;
+      carry_seg[tile * 2 + slot] = seg;
+    }
+  };
+  // phase A: run heads fold short runs, register long ones
   for (int li = threadIdx.x; li < nitems; li += BLOCK) {
     const int sg = s_seg[li];
     if (li == 0 || s_seg[li - 1] != sg) {
       T acc = s_val[li];
       int e = li + 1;
-      while (e < nitems && s_seg[e] == sg) { acc = op(acc, s_val[e]); ++e; }
-      const long long seg = t.seg_lo + sg;
-      const bool opens_here = (li > 0) || (segments[seg] == (int)first);   // segment starts in this tile
-      const long long seg_end = (seg + 1 < num_segments) ? (long long)segments[seg + 1] : count;
-      const bool closes_here = (e < nitems) || (seg_end - 1 == last);
-      if (opens_here && closes_here) {
-        reduced[seg] = acc;
-      } else {
-        // spans tiles: slot 0 = piece that continues a segment begun earlier, slot 1 = piece left open
-        const int slot = opens_here ? 1 : 0;
-        carry_val[tile * 2 + slot] = acc;
-        carry_seg[tile * 2 + slot] = seg;
-      }
+      while (e < nitems && e - li <= SHORT_RUN && s_seg[e] == sg) { acc = op(acc, s_val[e]); ++e; }
+      if (e - li > SHORT_RUN) s_long[atomicAdd(&s_nlong, 1)] = li;
+      else emit(li, e, acc);
     }
+  }
+  __syncthreads();
+  // phase B: one wave per long run
+  const int nlong = s_nlong;
+  const int lane = lane_id();
+  for (int r = threadIdx.x / WAVE; r < nlong; r += WAVES_PER_BLOCK) {
+    const int li = s_long[r];
+    const int sg = s_seg[li];
+    T acc = identity;
+    int e = li;
+    for (;;) {                                   // wave-uniform loop over 64-item strides of the run
+      const int i = e + lane;
+      const bool in = (i < nitems) && (s_seg[i] == sg);
+      if (in) acc = op(acc, s_val[i]);
+      const u64 m = __ballot(in);
+      if (m != ~0ull) { e += __popcll(m); break; }   // runs are contiguous: the mask is a prefix
+      e += WAVE;
+    }
+    acc = wave_reduce_op(acc, op);
+    if (lane == 0) emit(li, e, acc);
   }
 }
 
@@ -186,25 +228,21 @@ __global__ __launch_bounds__(BLOCK) void k_segreduce_fill_empty(const int* __res
   }
 }
 
-// fold the per-tile carries in tile order (one thread: the carry list has at most 2 entries per tile)
+// fold the per-tile carries: the thread of the tile that OPENED a segment (slot 1) walks the
+// continuation slots (slot 0) of the following tiles, in tile order.
 template <typename T, typename Op>
-__global__ void k_segreduce_fixup(long long ntiles, const T* __restrict__ carry_val,
-                                  const long long* __restrict__ carry_seg, T* __restrict__ reduced, Op op) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  long long cur = -1;
-  T acc = T();
-  for (long long i = 0; i < ntiles * 2; ++i) {
-    const long long sg = carry_seg[i];
+__global__ __launch_bounds__(BLOCK) void k_segreduce_fixup(long long ntiles, const T* __restrict__ carry_val,
+                                                            const long long* __restrict__ carry_seg,
+                                                            T* __restrict__ reduced, Op op) {
+  long long tile = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (; tile < ntiles; tile += stride) {
+    const long long sg = carry_seg[tile * 2 + 1];
     if (sg < 0) continue;
-    if (sg != cur) {
-      if (cur >= 0) reduced[cur] = acc;
-      cur = sg;
-      acc = carry_val[i];
-    } else {
-      acc = op(acc, carry_val[i]);
-    }
+    T acc = carry_val[tile * 2 + 1];
+    for (long long u = tile + 1; u < ntiles && carry_seg[u * 2] == sg; ++u) acc = op(acc, carry_val[u * 2]);
+    reduced[sg] = acc;
   }
-  if (cur >= 0) reduced[cur] = acc;
 }
 
 inline size_t segreduce_scratch_bytes(long long count, size_t value_size) {
@@ -228,7 +266,8 @@ inline void lbs_segreduce(F f, long long count, const int* segments, long long n
   MGX_HIP(hipMemsetAsync(carry_seg, 0xFF, (size_t)tiles * 2 * sizeof(long long), st));
   hipLaunchKernelGGL((k_lbs_segreduce<T, F, Op>), dim3((unsigned)tiles), dim3(BLOCK), 0, st, f, count, segments,
                      num_segments, reduced, op, identity, carry_val, carry_seg);
-  hipLaunchKernelGGL((k_segreduce_fixup<T, Op>), dim3(1), dim3(64), 0, st, tiles, carry_val, carry_seg, reduced, op);
+  hipLaunchKernelGGL((k_segreduce_fixup<T, Op>), dim3(grid_for(tiles)), dim3(BLOCK), 0, st, tiles, carry_val, carry_seg,
+                     reduced, op);
 }
 
 }  // namespace mgx

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Neighbourhood-reduce / PR timing on RMAT (row f1 of SURVEY 8f): one pr iteration = segreduce over all edges + filter."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import mini_amd
+from mini_amd import rmat
+ap = argparse.ArgumentParser(); ap.add_argument("--scale", type=int, default=22); ap.add_argument("--iters", type=int, default=3)
+a = ap.parse_args()
+ctx = mini_amd.Context(0, torch.cuda.current_stream().cuda_stream)
+g = rmat.rmat_csr(ctx, a.scale, 16, seed=a.scale)
+graph = mini_amd.Graph.from_device(ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"])
+f = mini_amd.Frontier(ctx, g["n"]).fill_iota(g["n"])
+vals = torch.rand(g["n"], device="cuda")
+red = torch.empty(g["n"], device="cuda")
+mini_amd.segreduce(graph, f, vals, 0.0, red, "f32_plus"); ctx.synchronize()
+for _ in range(3):
+    t0 = time.perf_counter(); nz = mini_amd.segreduce(graph, f, vals, 0.0, red, "f32_plus"); ctx.synchronize(); dt = time.perf_counter() - t0
+    print("segreduce f32_plus all vertices: %d edges %.3f ms  %.1f GTEPS  alg %.1f GB/s" % (nz, dt * 1e3, nz / dt / 1e9, (8.0 * nz + 16.0 * g["n"]) / dt / 1e9))
+want = torch.zeros(g["n"], device="cuda").index_add_(0, torch.repeat_interleave(torch.arange(g["n"], device="cuda"), (g["row_offsets"][1:] - g["row_offsets"][:-1]).long()), vals[g["col_indices"].long()])
+print("max rel err vs torch index_add: %.3g" % float(((red - want).abs() / want.abs().clamp(min=1)).max()))
+pr = mini_amd.PrProblem(graph, a.iters)
+t0 = time.perf_counter(); lens = pr.enact(); ctx.synchronize(); dt = time.perf_counter() - t0
+print("pr enact %d iterations: %.3f ms (%s)" % (len(lens), dt * 1e3, lens))
