@@ -151,7 +151,11 @@ MGX_API int mgx_bfs_enact_pushpull(mgx_bfs_t p, float threshold, int64_t* stats)
  *   [4] edges inspected by pull levels [5] push levels [6] level-kernel launches (incl. the
  *   empty ones behind the last level) [7] device time of those launches in ns (HIP events on
  *   the context's stream) [8] frontier vertices expanded (sum of per-level frontier sizes)
- *   [9] visited-bit claims (atomicOr) issued.  stats must hold 10 entries.                                            */
+ *   [9] visited-bit claims (atomicOr) issued.
+ *   Dominant kernel (the wave-private streaming push kernel, which most edges go through):
+ *   [10] its launches (incl. the ones that find nothing to do) [11] their device time in ns (HIP events
+ *   around every launch) [12] edges and [13] frontier vertices of the levels it processed
+ *   [14] engine (0 fused, 1 chunk) [15] reserved.  stats must hold 16 entries.                                            */
 #define MGX_BFS_PUSH 0
 #define MGX_BFS_DIRECTION_OPT 1
 MGX_API int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats);

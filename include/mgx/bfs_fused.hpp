@@ -47,6 +47,7 @@ struct bfs_ctrl_t {
   int levels;        // number of levels that expanded at least one edge
   int pull;          // direction of the level about to run (set by k_bfs_level_begin; sticky once 1)
   int push_levels;   // levels run top-down
+  u64 kind_mask;     // bit L set: level L (< 64) ran on the wave-private streaming kernel
   int kind;          // top-down kernel for the level about to run: 0 = workgroup-synchronous tiles
                      // (discovery-heavy levels: big flushes), 1 = wave-private streaming (k_bfs_level_begin)
   u64 pull_edges;    // in-edges inspected by bottom-up levels
@@ -100,6 +101,7 @@ __global__ void k_bfs_fused_init(bfs_fused_args_t a, int src) {
   c->pull = 0;
   c->push_levels = 0;
   c->kind = 0;
+  c->kind_mask = 0;
   c->pull_edges = 0;
 }
 
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(BLOCK) void k_bfs_level_begin(bfs_fused_args_t a, i
       // long rows (a hub frontier) discover a lot per edge: batch the claims per workgroup; short rows
       // (the big levels of a skewed graph) mostly hit visited vertices: stream them wave by wave
       c->kind = (a.wave_kernel && E / (u64)nf < (u64)a.wave_max_avg_degree) ? 1 : 0;
+      if (c->kind == 1 && !c->pull && level < 64) c->kind_mask |= 1ull << level;
     }
   }
   const bool want_frontier = a.mode == 1;
@@ -462,6 +465,11 @@ struct bfs_fused_state_t {
   long long level_kernel_launches = 0;
   float batch_ms[256];               // duration of each launch batch of the last run (per level when levels_per_sync == 1)
   int batches = 0;
+  // per-launch timing of the wave-private streaming kernel (the kernel most edges go through)
+  static constexpr int EV_POOL = 64;
+  hipEvent_t wev[EV_POOL] = {};
+  double wave_kernel_ms = 0.0;
+  long long wave_kernel_launches = 0;
 
   bfs_fused_state_t() {}
   bfs_fused_state_t(int num_nodes, standard_context_t& ctx) : n(num_nodes) {
@@ -481,6 +489,7 @@ struct bfs_fused_state_t {
     MGX_HIP(hipHostMalloc((void**)&host_ctrl, sizeof(bfs_ctrl_t), hipHostMallocDefault));
     MGX_HIP(hipEventCreate(&ev0));
     MGX_HIP(hipEventCreate(&ev1));
+    for (int i = 0; i < EV_POOL; ++i) MGX_HIP(hipEventCreate(&wev[i]));
     if (const char* e = getenv("MGX_BFS_EPT")) ept = (atoi(e) == 8) ? 8 : 4;
     if (const char* e = getenv("MGX_BFS_DIAG")) diag = atoi(e) != 0;
     if (const char* e = getenv("MGX_BFS_HOT")) hot = atoi(e);
@@ -501,6 +510,7 @@ struct bfs_fused_state_t {
     std::swap(host_ctrl, r.host_ctrl);
     std::swap(ev0, r.ev0);
     std::swap(ev1, r.ev1);
+    for (int i = 0; i < EV_POOL; ++i) std::swap(wev[i], r.wev[i]);
     n = r.n; levels_per_sync = r.levels_per_sync; grid = r.grid; ept = r.ept; diag = r.diag; occ = r.occ; hot = r.hot; hot_min_tiles = r.hot_min_tiles;
     return *this;
   }
@@ -508,6 +518,7 @@ struct bfs_fused_state_t {
     if (host_ctrl) (void)hipHostFree(host_ctrl);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    for (int i = 0; i < EV_POOL; ++i) if (wev[i]) (void)hipEventDestroy(wev[i]);
   }
 };
 

@@ -366,6 +366,8 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   int level = 0;
   st.level_kernel_ms = 0.0;
   st.level_kernel_launches = 0;
+  st.wave_kernel_ms = 0.0;
+  st.wave_kernel_launches = 0;
   st.batches = 0;
   for (;;) {
     MGX_HIP(hipEventRecord(st.ev0, s));
@@ -393,12 +395,15 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
       else if (st.occ == 5) MGX_LAUNCH_LEVEL(4, 5, false);
       else MGX_LAUNCH_LEVEL(4, 4, false);
 #undef MGX_LAUNCH_LEVEL
+      const bool time_wave = a.wave_kernel && 2 * i + 1 < bfs_fused_state_t::EV_POOL;
+      if (time_wave) MGX_HIP(hipEventRecord(st.wev[2 * i], s));
       if (a.wave_kernel && wave_shape == 2)
         hipLaunchKernelGGL((k_bfs_push_level_wave<1024, 24576>), dim3(ctx.num_cus), dim3(1024),
                            bfs_wave_lds_bytes(1024, 24576), s, a, level);
       else if (a.wave_kernel)
         hipLaunchKernelGGL((k_bfs_push_level_wave<512, 12288>), dim3(ctx.num_cus * 2), dim3(512),
                            bfs_wave_lds_bytes(512, 12288), s, a, level);
+      if (time_wave) MGX_HIP(hipEventRecord(st.wev[2 * i + 1], s));
       if (mode == 1)
         hipLaunchKernelGGL(k_bfs_pull_level<256>, dim3(ctx.num_cus * 8), dim3(256), 0, s, a, level);
     }
@@ -408,6 +413,13 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
     float ms = 0.f;
     MGX_HIP(hipEventElapsedTime(&ms, st.ev0, st.ev1));
     st.level_kernel_ms += ms;
+    if (a.wave_kernel)
+      for (int i = 0; i < st.levels_per_sync && 2 * i + 1 < bfs_fused_state_t::EV_POOL; ++i) {
+        float wms = 0.f;
+        MGX_HIP(hipEventElapsedTime(&wms, st.wev[2 * i], st.wev[2 * i + 1]));
+        st.wave_kernel_ms += wms;
+        st.wave_kernel_launches += 1;
+      }
     if (st.batches < 256) st.batch_ms[st.batches++] = ms;
     st.level_kernel_launches += st.levels_per_sync;
     if (st.host_ctrl->done) break;

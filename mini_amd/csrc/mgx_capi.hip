@@ -38,7 +38,7 @@ struct mgx_bfs_s {
   std::shared_ptr<bfs::bfs_problem_t> p;
   std::unique_ptr<bfs::bfs_enactor_t> e;              // lazily: holds two m-capacity buffers
   std::unique_ptr<bfs::bfs_fused_enactor_t> fe;       // lazily: O(n)
-  int64_t last_stats[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t last_stats[16] = {0};
 };
 struct mgx_sssp_s {
   mgx_graph_s* g;
@@ -599,19 +599,23 @@ int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats) {
   if (!p->fe) p->fe.reset(new bfs::bfs_fused_enactor_t(ctx, p->g->g->num_nodes));
   p->p->src = src;
   p->fe->enact(p->p, ctx, mode == MGX_BFS_DIRECTION_OPT, alpha);
-  const mgx::bfs_ctrl_t* hc = p->fe->fused.host_ctrl;
-  p->last_stats[0] = hc->levels;
-  p->last_stats[1] = (int64_t)hc->reached;
-  p->last_stats[2] = (int64_t)hc->sum_edges;
-  p->last_stats[3] = 0;   // filled below: edges expanded by the top-down levels
-  p->last_stats[4] = (int64_t)hc->pull_edges;
-  p->last_stats[5] = hc->push_levels;
-  for (int i = 0; i < hc->push_levels && i < mgx::BFS_MAX_TRACE; ++i)
-    p->last_stats[3] += (int64_t)(hc->trace[i] & mgx::BFS_EMASK);   // direction never switches back
-  p->last_stats[6] = p->fe->fused.level_kernel_launches;
-  p->last_stats[7] = (int64_t)(p->fe->fused.level_kernel_ms * 1e6);
-  p->last_stats[8] = (int64_t)hc->sum_frontier;
-  p->last_stats[9] = (int64_t)hc->claims;
+  const bfs::bfs_run_stats_t& L = p->fe->last;
+  p->last_stats[0] = L.levels;
+  p->last_stats[1] = L.reached;
+  p->last_stats[2] = L.m_t;
+  p->last_stats[3] = L.push_edges;
+  p->last_stats[4] = L.pull_edges;
+  p->last_stats[5] = L.push_levels;
+  p->last_stats[6] = L.kernel_launches;
+  p->last_stats[7] = L.kernel_ns;
+  p->last_stats[8] = L.frontier_vertices;
+  p->last_stats[9] = L.claims;
+  p->last_stats[10] = L.dom_launches;
+  p->last_stats[11] = L.dom_ns;
+  p->last_stats[12] = L.dom_edges;
+  p->last_stats[13] = L.dom_vertices;
+  p->last_stats[14] = p->fe->use_chunk ? 1 : 0;
+  p->last_stats[15] = 0;
   if (stats) memcpy(stats, p->last_stats, sizeof(p->last_stats));
   MGX_CATCH
 }
@@ -619,37 +623,36 @@ int mgx_bfs_level_trace(mgx_bfs_t p, int cap, int64_t* level_nf, int64_t* level_
   MGX_TRY
   MGX_REQUIRE(p && levels, "NULL argument");
   MGX_REQUIRE(p->fe != nullptr, "mgx_bfs_level_trace: no mgx_bfs_run yet");
-  const mgx::bfs_ctrl_t* hc = p->fe->fused.host_ctrl;
-  const int L = hc->levels < mgx::BFS_MAX_TRACE ? hc->levels : mgx::BFS_MAX_TRACE;
-  *levels = L;
-  for (int i = 0; i < L && i < cap; ++i) {
-    if (level_nf) level_nf[i] = (int64_t)(hc->trace[i] >> mgx::BFS_VSHIFT);
-    if (level_edges) level_edges[i] = (int64_t)(hc->trace[i] & mgx::BFS_EMASK);
+  const auto& tr = p->fe->last.trace;
+  *levels = (int)tr.size();
+  for (int i = 0; i < (int)tr.size() && i < cap; ++i) {
+    if (level_nf) level_nf[i] = tr[i].first;
+    if (level_edges) level_edges[i] = tr[i].second;
   }
   MGX_CATCH
 }
-
 int mgx_bfs_diag(mgx_bfs_t p, int64_t* cycles8) {
   MGX_TRY
   MGX_REQUIRE(p && cycles8, "NULL argument");
   MGX_REQUIRE(p->fe != nullptr, "mgx_bfs_diag: no mgx_bfs_run yet");
-  for (int i = 0; i < 8; ++i) cycles8[i] = (int64_t)p->fe->fused.host_ctrl->diag[i];
+  for (int i = 0; i < 8; ++i) cycles8[i] = p->fe->last.diag[i];
   MGX_CATCH
 }
 int mgx_bfs_level_claims(mgx_bfs_t p, int cap, int64_t* claims) {
   MGX_TRY
   MGX_REQUIRE(p && claims, "NULL argument");
   MGX_REQUIRE(p->fe != nullptr, "mgx_bfs_level_claims: no mgx_bfs_run yet");
-  for (int i = 0; i < cap && i < 64; ++i) claims[i] = (int64_t)p->fe->fused.host_ctrl->claims_level[i];
+  for (int i = 0; i < cap && i < 64; ++i) claims[i] = p->fe->last.claims_level[i];
   MGX_CATCH
 }
 int mgx_bfs_batch_times(mgx_bfs_t p, int cap, float* ms, int* batches) {
   MGX_TRY
   MGX_REQUIRE(p && batches, "NULL argument");
   MGX_REQUIRE(p->fe != nullptr, "mgx_bfs_batch_times: no mgx_bfs_run yet");
-  *batches = p->fe->fused.batches;
-  for (int i = 0; i < p->fe->fused.batches && i < cap; ++i)
-    if (ms) ms[i] = p->fe->fused.batch_ms[i];
+  const auto& b = p->fe->last.batch_ms;
+  *batches = (int)b.size();
+  for (int i = 0; i < (int)b.size() && i < cap; ++i)
+    if (ms) ms[i] = b[i];
   MGX_CATCH
 }
 
