@@ -42,6 +42,7 @@ typedef struct mgx_bfs_s* mgx_bfs_t;
 typedef struct mgx_sssp_s* mgx_sssp_t;
 typedef struct mgx_pr_s* mgx_pr_t;
 typedef struct mgx_dbfs_s* mgx_dbfs_t;
+typedef struct mgx_dbfs2_s* mgx_dbfs2_t;
 
 MGX_API int mgx_version(void);
 MGX_API const char* mgx_strerror(int status);
@@ -191,6 +192,23 @@ MGX_API int mgx_dbfs_bins(mgx_dbfs_t h, int** d_bins, int64_t* bin_capacity); /*
 MGX_API int mgx_dbfs_receive(mgx_dbfs_t h, const int* d_global_ids, int64_t count, int label);
 MGX_API int mgx_dbfs_swap(mgx_dbfs_t h, int64_t* next_frontier_size);
 MGX_API int mgx_dbfs_labels(mgx_dbfs_t h, int* host_labels_local);
+
+/* ---- partitioned BFS, generation 2 (include/mgx/bfs_dist2.hpp): every rank runs the FUSED level
+ *      kernels on its rows and ranks exchange dense "newly visited" bitmaps (one all-gather of n/8 bytes
+ *      per rank and level) instead of id lists.  Ids are global and hub-first (descending global degree);
+ *      vertex v belongs to rank v % ranks, local row v / ranks.  d_newbits: caller-owned buffer of
+ *      (n_global+31)/32 words that mgx_dbfs2_push fills with the rank's discoveries of the level;
+ *      mgx_dbfs2_merge takes the all-gathered ranks x words array, ORs it into every rank's visited
+ *      bitmap, labels the owned vertices and builds the rank's next frontier (returns its size/edges). */
+MGX_API int mgx_dbfs2_create(mgx_ctx_t ctx, int n_global, int ranks, int rank, const int* d_row_offsets_local,
+                             const int* d_col_indices_global, unsigned* d_newbits, mgx_dbfs2_t* out);
+MGX_API int mgx_dbfs2_free(mgx_dbfs2_t h);
+/* first_edges (may be NULL): edges of this rank's level-0 frontier = deg(src) on the owner, 0 elsewhere */
+MGX_API int mgx_dbfs2_reset(mgx_dbfs2_t h, int src_global, int64_t* first_edges);
+MGX_API int mgx_dbfs2_push(mgx_dbfs2_t h, int level);
+MGX_API int mgx_dbfs2_merge(mgx_dbfs2_t h, int level, const unsigned* d_gathered, int64_t* next_frontier_size,
+                            int64_t* next_frontier_edges);
+MGX_API int mgx_dbfs2_labels(mgx_dbfs2_t h, int* host_labels_local);
 
 /* ---- SSSP: sssp_problem_t / sssp_functor_t / sssp_enactor_t (gunrock/src/sssp/) ---- */
 MGX_API int mgx_sssp_create(mgx_graph_t g, int src, mgx_sssp_t* out);     /* sssp_problem.hxx:40-52 */

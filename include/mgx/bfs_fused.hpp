@@ -68,6 +68,8 @@ struct bfs_fused_args_t {
   const int* in_indices;
   int wave_kernel;         // 1: levels whose average frontier degree is below wave_max_avg_degree use the wave kernel
   int wave_max_avg_degree;
+  int append;              // 1: winners are appended to the next frontier (single GPU); 0: claims only -- the
+                           // partitioned BFS rebuilds every rank's frontier from the exchanged bitmaps
   int mode;                // MGX_BFS_PUSH / MGX_BFS_DIRECTION_OPT
   float alpha;             // switch to bottom-up when unvisited < frontier_vertices * alpha (bfs_enactor.hxx:68)
   const int* old_of_new;   // hub-first layout: original id of layout vertex v (NULL = identity)

@@ -144,6 +144,7 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_hot(bfs_fused_args_t a, i
     for (int q = 0; q < PER; ++q)
       if (!(old[q] & (1u << (v[q] & 31)))) winmask |= 1u << q;
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(winmask) : : "memory");
+    if (a.append) {
     u32 ro[PER], ro1[PER];
     int lab_at[PER];
 #pragma unroll
@@ -182,6 +183,10 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_hot(bfs_fused_args_t a, i
         out_row[base_v + (at >> 40)] = ro[q];
         out_off[base_v + (at >> 40)] = (u32)(base_e + (at & DEGMASK));
       }
+    }
+    } else {
+      const int nwin = wave_sum((int)__popc(winmask));
+      if (lane == 0 && nwin) atomicAdd(&s_int[1], nwin);
     }
     if (threadIdx.x == 0) s_int[0] = 0;
     __syncthreads();

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_wave(bfs_fused_args_t a, 
     for (int q = 0; q < PER; ++q)
       if (!(old[q] & (1u << (v[q] & 31)))) winmask |= 1u << q;
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(winmask) : : "memory");
+    if (!a.append) { wins += wave_sum((int)__popc(winmask)); return; }
     u32 ro[PER], ro1[PER];
     int lab_at[PER];
 #pragma unroll
@@ -353,6 +354,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.ctrl = st.ctrl.data();
   a.n = st.n;
   a.hot_min_tiles = st.hot_min_tiles;
+  a.append = 1;
   static int wave_shape = getenv("MGX_BFS_WAVE") ? atoi(getenv("MGX_BFS_WAVE")) : 1;   // 0 off, 1: 512 thr x 48 KB, 2: 1024 thr x 96 KB
   a.wave_kernel = (hot && wave_shape != 0) ? 1 : 0;
   a.wave_max_avg_degree = getenv("MGX_BFS_WAVE_MAX_DEG") ? atoi(getenv("MGX_BFS_WAVE_MAX_DEG")) : 512;

@@ -12,6 +12,7 @@
 #include "gunrock/pr/pr_enactor.hxx"
 #include "gunrock/sssp/sssp_enactor.hxx"
 #include "mgx/bfs_dist.hpp"
+#include "mgx/bfs_dist2.hpp"
 #include "mgx.h"
 
 using namespace gunrock;
@@ -55,6 +56,11 @@ struct mgx_pr_s {
 struct mgx_dbfs_s {
   mgx_ctx_s* c;
   mgx::dbfs_state_t st;
+};
+
+struct mgx_dbfs2_s {
+  mgx_ctx_s* c;
+  mgx::d2_state_t st;
 };
 
 static thread_local std::string g_last_error;
@@ -734,6 +740,59 @@ int mgx_dbfs_labels(mgx_dbfs_t h, int* host_labels) {
   use_device(h->c);
   h->c->ctx->synchronize();
   MGX_HIP(mgx::dtoh(host_labels, h->st.labels.data(), (size_t)h->st.n_local));
+  MGX_CATCH
+}
+
+// ---- partitioned BFS, generation 2: fused kernels per rank + bitmap exchange (mgx/bfs_dist2.hpp) ----
+int mgx_dbfs2_create(mgx_ctx_t c, int n_global, int ranks, int rank, const int* d_row_offsets_local,
+                     const int* d_col_indices_global, unsigned* d_newbits, mgx_dbfs2_t* out) {
+  MGX_TRY
+  MGX_REQUIRE(c && out && d_row_offsets_local && d_newbits, "mgx_dbfs2_create: NULL argument");
+  MGX_REQUIRE(n_global > 0 && ranks >= 1 && ranks <= 64 && rank >= 0 && rank < ranks, "mgx_dbfs2_create: bad partition");
+  use_device(c);
+  auto* h = new mgx_dbfs2_s();
+  h->c = c;
+  h->st.init(*c->ctx, n_global, ranks, rank, d_row_offsets_local, d_col_indices_global, d_newbits);
+  c->ctx->synchronize();
+  *out = h;
+  MGX_CATCH
+}
+int mgx_dbfs2_free(mgx_dbfs2_t h) {
+  MGX_TRY
+  if (h) { use_device(h->c); delete h; }
+  MGX_CATCH
+}
+int mgx_dbfs2_reset(mgx_dbfs2_t h, int src, int64_t* first_edges) {
+  MGX_TRY
+  MGX_REQUIRE(h && src >= 0 && src < h->st.n_global, "mgx_dbfs2_reset: bad argument");
+  use_device(h->c);
+  const long long e = mgx::d2_reset(h->st, src, *h->c->ctx);
+  if (first_edges) *first_edges = e;
+  MGX_CATCH
+}
+int mgx_dbfs2_push(mgx_dbfs2_t h, int level) {
+  MGX_TRY
+  MGX_REQUIRE(h && level >= 0, "bad argument");
+  use_device(h->c);
+  mgx::d2_push(h->st, level, *h->c->ctx);
+  MGX_CATCH
+}
+int mgx_dbfs2_merge(mgx_dbfs2_t h, int level, const unsigned* d_gathered, int64_t* next_frontier, int64_t* next_edges) {
+  MGX_TRY
+  MGX_REQUIRE(h && d_gathered && level >= 0, "bad argument");
+  use_device(h->c);
+  long long e = 0;
+  const long long nf = mgx::d2_merge(h->st, level, d_gathered, *h->c->ctx, &e);
+  if (next_frontier) *next_frontier = nf;
+  if (next_edges) *next_edges = e;
+  MGX_CATCH
+}
+int mgx_dbfs2_labels(mgx_dbfs2_t h, int* host_labels_local) {
+  MGX_TRY
+  MGX_REQUIRE(h && host_labels_local, "NULL argument");
+  use_device(h->c);
+  h->c->ctx->synchronize();
+  MGX_HIP(mgx::dtoh(host_labels_local, h->st.labels.data(), (size_t)h->st.n_local));
   MGX_CATCH
 }
 

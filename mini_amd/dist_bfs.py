@@ -147,6 +147,167 @@ class DistBfs:
         return full.numpy()
 
 
+# =====================================================================================================
+# Generation 2: fused kernels per rank + bitmap exchange (include/mgx/bfs_dist2.hpp)
+# =====================================================================================================
+def local_rows(n_global, ranks, rank):
+    """number of vertices owned by `rank` under the cyclic partition v % ranks"""
+    return (n_global - rank + ranks - 1) // ranks
+
+
+class HipRankEngine2:
+    """Per-rank device side of the bitmap-exchange BFS (C-ABI mgx_dbfs2_*).  Ids are global, hub-first."""
+
+    def __init__(self, ctx, n_global, ranks, rank, row_offsets_local, col_indices_global):
+        self.ctx, self.n_global, self.ranks, self.rank = ctx, n_global, ranks, rank
+        self.n_local = local_rows(n_global, ranks, rank)
+        self.nwords = (n_global + 31) // 32
+        self._keep = (row_offsets_local, col_indices_global)
+        self.newbits = torch.zeros(self.nwords, dtype=torch.int32, device=row_offsets_local.device)
+        h = C.c_void_p()
+        check(lib.mgx_dbfs2_create(ctx._h, int(n_global), int(ranks), int(rank),
+                                   C.c_void_p(row_offsets_local.data_ptr()), C.c_void_p(col_indices_global.data_ptr()),
+                                   C.c_void_p(self.newbits.data_ptr()), C.byref(h)))
+        self._h = h
+
+    def reset(self, src):
+        e = C.c_int64()
+        check(lib.mgx_dbfs2_reset(self._h, int(src), C.byref(e)))
+        return e.value
+
+    def push(self, level):
+        check(lib.mgx_dbfs2_push(self._h, int(level)))
+        return self.newbits
+
+    def merge(self, level, gathered):
+        nf, ne = C.c_int64(), C.c_int64()
+        check(lib.mgx_dbfs2_merge(self._h, int(level), C.c_void_p(gathered.data_ptr()), C.byref(nf), C.byref(ne)))
+        return nf.value, ne.value
+
+    def labels(self):
+        out = np.empty(self.n_local, dtype=np.int32)
+        check(lib.mgx_dbfs2_labels(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def close(self):
+        if self._h:
+            lib.mgx_dbfs2_free(self._h)
+            self._h = None
+
+
+class DistBfs2:
+    """Superstep driver of generation 2: push (device) -> all_gather of the new-bit maps -> merge (device)
+    -> all_reduce of the next frontier sizes.  `engine` needs reset/push/merge/labels."""
+
+    def __init__(self, engine, rank, world, comm_device):
+        self.e, self.rank, self.world, self.comm_device = engine, rank, world, torch.device(comm_device)
+
+    def run(self, src, src_degree_hint=None):
+        e, W = self.e, self.world
+        level, edges_local = 0, e.reset(src)
+        while True:
+            new = e.push(level)
+            if W > 1:
+                mine = new if new.device == self.comm_device else new.to(self.comm_device)
+                gathered = torch.empty(W * mine.numel(), dtype=mine.dtype, device=self.comm_device)
+                dist.all_gather_into_tensor(gathered, mine.contiguous())
+                if gathered.device != new.device:
+                    gathered = gathered.to(new.device)
+            else:
+                gathered = new
+            nf_local, ne_local = e.merge(level, gathered)
+            edges_local += ne_local
+            level += 1
+            nf = nf_local
+            if W > 1:
+                t = torch.tensor([nf_local], dtype=torch.int64, device=self.comm_device)
+                dist.all_reduce(t)
+                nf = int(t.item())
+            if nf == 0:
+                break
+        self.levels = level
+        return {"levels": level, "edges_local": edges_local}
+
+    def gather_labels(self):
+        """Global label array in (hub-first) global ids on every rank (validation only)."""
+        loc = torch.from_numpy(self.e.labels())
+        n, W = self.e.n_global, self.world
+        if W == 1:
+            return loc.numpy()
+        cap = (n + W - 1) // W
+        pad = torch.full((cap,), -2, dtype=torch.int32)
+        pad[: loc.numel()] = loc
+        out = [torch.empty(cap, dtype=torch.int32, device=self.comm_device) for _ in range(W)]
+        dist.all_gather(out, pad.to(self.comm_device))
+        full = torch.stack([o.cpu() for o in out], dim=1).reshape(-1)[:n]   # vertex v = i*W + r
+        return full.numpy()
+
+
+def cyclic_shard_from_csr(ro, ci, ranks, rank):
+    """Host (numpy) version of the generation-2 layout for a CSR that fits in memory: returns
+    (row_offsets_local, col_indices_global_new, new_of_old, old_of_new).  Used by the tests."""
+    ro = np.asarray(ro, dtype=np.int64)
+    n = len(ro) - 1
+    deg = np.diff(ro)
+    old_of_new = np.argsort(-deg, kind="stable")
+    new_of_old = np.empty(n, dtype=np.int64)
+    new_of_old[old_of_new] = np.arange(n)
+    mine_new = np.arange(rank, n, ranks)
+    mine_old = old_of_new[mine_new]
+    d = deg[mine_old]
+    ro_l = np.zeros(len(mine_old) + 1, dtype=np.int64)
+    np.cumsum(d, out=ro_l[1:])
+    ci_l = np.empty(int(ro_l[-1]), dtype=np.int32)
+    ci = np.asarray(ci)
+    for i, v in enumerate(mine_old):
+        ci_l[ro_l[i]:ro_l[i + 1]] = np.sort(new_of_old[ci[ro[v]:ro[v + 1]]])
+    return ro_l.astype(np.int32), ci_l, new_of_old.astype(np.int32), old_of_new.astype(np.int32)
+
+
+def rmat_cyclic_shard(ctx, scale, edgefactor, seed, ranks, rank, device, pairs_per_chunk=1 << 26):
+    """Local CSR of the symmetrised R-MAT graph under the generation-2 layout: vertices renumbered
+    hub-first by GLOBAL degree (every rank derives the same permutation from the same pair stream),
+    vertex v owned by rank v % ranks, local row v // ranks, neighbour ids global.
+    Returns (row_offsets_local, col_indices, new_of_old, old_of_new, degree_of_new) as device tensors."""
+    n = 1 << scale
+    total = edgefactor * n
+    deg = torch.zeros(n, dtype=torch.int64, device=device)
+
+    def chunks():
+        for first in range(0, total, pairs_per_chunk):
+            cnt = min(pairs_per_chunk, total - first)
+            s = torch.empty(cnt, dtype=torch.int32, device=device)
+            d = torch.empty(cnt, dtype=torch.int32, device=device)
+            torch.cuda.synchronize(device)
+            api.rmat_edges(ctx, scale, first, cnt, seed, True, s, d, None)
+            ctx.synchronize()
+            yield s, d
+
+    for s, d in chunks():                       # pass 1: global degrees (row = dst, and row = src for the swapped copy)
+        deg += torch.bincount(d.to(torch.int64), minlength=n)
+        deg += torch.bincount(s.to(torch.int64), minlength=n)
+    old_of_new = torch.sort(deg, descending=True, stable=True).indices
+    new_of_old = torch.empty_like(old_of_new)
+    new_of_old[old_of_new] = torch.arange(n, device=device)
+    keys = []
+    for s, d in chunks():                       # pass 2: keep the entries whose (new) row this rank owns
+        ns, nd = new_of_old[s.to(torch.int64)], new_of_old[d.to(torch.int64)]
+        for row, nbr in ((nd, ns), (ns, nd)):
+            m = (row % ranks) == rank
+            keys.append(((row[m] // ranks) << 32) | nbr[m])
+    key = torch.cat(keys)
+    del keys
+    key, _ = torch.sort(key)
+    col = (key & 0xFFFFFFFF).to(torch.int32)
+    lrow = key >> 32
+    del key
+    nl = local_rows(n, ranks, rank)
+    counts = torch.bincount(lrow, minlength=nl)
+    ro = torch.zeros(nl + 1, dtype=torch.int64, device=device)
+    torch.cumsum(counts, 0, out=ro[1:])
+    return ro.to(torch.int32), col, new_of_old.to(torch.int32), old_of_new.to(torch.int32), deg[old_of_new]
+
+
 # ---- shard construction ---------------------------------------------------------------------------
 def rmat_shard_csr(ctx, scale, edgefactor, seed, ranks, rank, device, pairs_per_chunk=1 << 26):
     """Local CSR rows [lo,hi) of the symmetrised R-MAT graph, GLOBAL neighbour ids.
@@ -213,13 +374,27 @@ def bench_main(args, rank, world, local_rank):
     seed = gscale if args.seed is None else args.seed
     n = 1 << gscale
     t_build = time.time()
-    ro, col = rmat_shard_csr(ctx, gscale, args.edgefactor, seed, world, rank, device)
-    torch.cuda.synchronize()
-    t_build = time.time() - t_build
-    eng = HipRankEngine(ctx, n, world, rank, ro, col)
-    bfs = DistBfs(eng, rank, world, "cuda")
-    ro_host = ro.cpu().numpy()
-    sources = pick_sources_dist(ro_host, eng.lo, eng.hi, n, args.steps + args.warmup, seed, device)
+    gen = int(os.environ.get("MGX_DIST_GEN", "2"))
+    if gen == 2:
+        ro, col, new_of_old, old_of_new, deg_new = rmat_cyclic_shard(ctx, gscale, args.edgefactor, seed, world, rank, device)
+        torch.cuda.synchronize()
+        t_build = time.time() - t_build
+        eng = HipRankEngine2(ctx, n, world, rank, ro, col)
+        bfs = DistBfs2(eng, rank, world, "cuda")
+        from .rmat import _mix64_py
+        sources, i, deg_host = [], 0, None
+        cand = [int(_mix64_py(seed + k) % n) for k in range(8 * (args.steps + args.warmup) + 64)]
+        cand_new = new_of_old[torch.tensor(cand, device=device)].cpu().tolist()
+        cand_deg = deg_new[torch.tensor(cand_new, device=device)].cpu().tolist()
+        sources = [v for v, dg in zip(cand_new, cand_deg) if dg > 0][: args.steps + args.warmup]
+    else:
+        ro, col = rmat_shard_csr(ctx, gscale, args.edgefactor, seed, world, rank, device)
+        torch.cuda.synchronize()
+        t_build = time.time() - t_build
+        eng = HipRankEngine(ctx, n, world, rank, ro, col)
+        bfs = DistBfs(eng, rank, world, "cuda")
+        ro_host = ro.cpu().numpy()
+        sources = pick_sources_dist(ro_host, eng.lo, eng.hi, n, args.steps + args.warmup, seed, device)
     for s in sources[: args.warmup]:
         bfs.run(s)
     torch.cuda.synchronize()
@@ -249,11 +424,11 @@ def bench_main(args, rank, world, local_rank):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
                "data": "synthetic",
                "config": {"workload": "BFS push on RMAT scale %d (= %d per GPU + log2 N) ef %d, symmetrised, "
-                                      "1-D vertex-range partition over %d GPUs, all-to-all frontier exchange (RCCL), "
+                                      "hub-first ids, cyclic vertex partition over %d GPUs, fused level kernels per rank, all-gather of new-visited bitmaps (RCCL), "
                                       "%d seeded sources" % (gscale, args.scale, args.edgefactor, world, args.steps),
                           "scale": gscale, "edgefactor": args.edgefactor, "seed": seed,
-                          "parallelism": "vertex-range x%d" % world},
-               "roofline": {"bound": "hbm", "kernel": "k_transform_lbs (dist expand)",
+                          "parallelism": "vertex-cyclic x%d" % world},
+               "roofline": {"bound": "hbm", "kernel": "k_bfs_push_level_wave (per rank)",
                             "achieved": round(8.0 * m_t / world / elapsed / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
                             "frac": round(8.0 * m_t / world / elapsed / 1e9 / 8000.0, 5), "traffic": None,
                             "note": "per-GPU algorithmic bytes (8 B/edge) over the whole superstep loop incl. exchange"},

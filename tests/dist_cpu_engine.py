@@ -53,3 +53,60 @@ class NumpyRankEngine:
 
     def labels(self):
         return self.lab.copy()
+
+
+class NumpyRankEngine2:
+    """numpy stand-in for mini_amd.dist_bfs.HipRankEngine2 (generation 2: replicated visited bitmap,
+    cyclic ownership, new-bit maps exchanged by all-gather).  Same reset/push/merge/labels contract."""
+
+    def __init__(self, n_global, ranks, rank, ro_local, ci_global):
+        self.n_global, self.ranks, self.rank = n_global, ranks, rank
+        self.n_local = (n_global - rank + ranks - 1) // ranks
+        self.nwords = (n_global + 31) // 32
+        self.ro = np.asarray(ro_local, dtype=np.int64)
+        self.ci = np.asarray(ci_global, dtype=np.int64)
+
+    @staticmethod
+    def _bits_to_words(bits, nwords):
+        pad = np.zeros(nwords * 32, dtype=np.uint8)
+        pad[: len(bits)] = bits
+        return np.packbits(pad.reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).reshape(-1).view(np.int32)
+
+    @staticmethod
+    def _words_to_bits(words, n):
+        w = np.asarray(words).view(np.uint32).astype(">u4")
+        return np.unpackbits(w.view(np.uint8).reshape(-1, 4), axis=1)[:, ::-1].reshape(-1)[:n].astype(bool)
+
+    def reset(self, src):
+        self.lab = np.full(self.n_local, -1, dtype=np.int32)
+        self.visited = np.zeros(self.n_global, dtype=bool)
+        self.visited[src] = True
+        self.front = []
+        if src % self.ranks == self.rank:
+            i = src // self.ranks
+            self.lab[i] = 0
+            if self.ro[i + 1] > self.ro[i]:
+                self.front = [i]
+            return int(self.ro[i + 1] - self.ro[i])
+        return 0
+
+    def push(self, level):
+        nbrs = [self.ci[self.ro[i]:self.ro[i + 1]] for i in self.front]
+        g = np.concatenate(nbrs) if nbrs else np.zeros(0, dtype=np.int64)
+        new = np.zeros(self.n_global, dtype=bool)
+        new[g[~self.visited[g]]] = True
+        return torch.from_numpy(self._bits_to_words(new.astype(np.uint8), self.nwords).copy())
+
+    def merge(self, level, gathered):
+        g = gathered.numpy().reshape(self.ranks, self.nwords)
+        merged = np.bitwise_or.reduce(g.view(np.uint32), axis=0)
+        bits = self._words_to_bits(merged, self.n_global)
+        self.visited |= bits
+        mine = np.nonzero(bits[self.rank::self.ranks])[0]
+        self.lab[mine] = level + 1
+        deg = self.ro[mine + 1] - self.ro[mine]
+        self.front = mine[deg > 0].tolist()
+        return len(self.front), int(deg.sum())
+
+    def labels(self):
+        return self.lab.copy()

@@ -66,7 +66,46 @@ def _worker(rank, world, port, use_gpu, scale, seed, sources, q):
     dist.destroy_process_group()
 
 
-def _run(world, use_gpu, scale, seed):
+def _worker2(rank, world, port, use_gpu, scale, seed, sources, q):
+    """generation 2: hub-first global ids, cyclic ownership, bitmap all-gather"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mini_amd.dist_bfs import DistBfs2, cyclic_shard_from_csr
+    from tests.oracle_binding import Oracle
+    orc = Oracle()
+    n, ro, ci, _ = orc.rmat_csr(scale, 16, seed)
+    ro_l, ci_l, new_of_old, old_of_new = cyclic_shard_from_csr(ro, ci, world, rank)
+    if use_gpu:
+        import mini_amd
+        from mini_amd.dist_bfs import HipRankEngine2
+        torch.cuda.set_device(0)
+        ctx = mini_amd.Context(0, torch.cuda.current_stream().cuda_stream)
+        eng = HipRankEngine2(ctx, n, world, rank, torch.from_numpy(ro_l).cuda(), torch.from_numpy(ci_l).cuda())
+    else:
+        from tests.dist_cpu_engine import NumpyRankEngine2
+        eng = NumpyRankEngine2(n, world, rank, ro_l, ci_l)
+    bfs = DistBfs2(eng, rank, world, "cpu")
+    ok = True
+    deg = np.diff(ro)
+    for src in sources:
+        st = bfs.run(int(new_of_old[src]))
+        got_new = bfs.gather_labels()
+        got = np.empty(n, dtype=np.int32)
+        got[old_of_new] = got_new
+        want = orc.bfs_cpu(ro, ci, src)
+        e = torch.tensor([st["edges_local"]], dtype=torch.int64)
+        dist.all_reduce(e)
+        ok = ok and np.array_equal(got, want) and int(e.item()) == int(deg[want >= 0].sum())
+        ok = ok and st["levels"] == int(want.max()) + 1
+    if rank == 0:
+        q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, use_gpu, scale, seed, worker=None):
     from tests.oracle_binding import Oracle
     n, ro, ci, _ = Oracle().rmat_csr(scale, 16, seed)
     deg = np.diff(ro)
@@ -74,7 +113,7 @@ def _run(world, use_gpu, scale, seed):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, use_gpu, scale, seed, sources, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker or _worker, args=(r, world, port, use_gpu, scale, seed, sources, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -93,3 +132,16 @@ def test_partitioned_bfs_hip_engine_two_ranks_one_gpu(built):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     _run(2, True, 12, 12)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_bitmap_exchange_bfs_gloo_cpu(built, world):
+    _run(world, False, 9, 9, _worker2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,scale", [(1, 12), (2, 12), (2, 16), (3, 14)])
+def test_bitmap_exchange_bfs_hip_engine_ranks_share_one_gpu(built, world, scale):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _run(world, True, scale, scale, _worker2)

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Generation-2 partitioned BFS on ONE GPU: G rank engines share the device and run one after another
+(the all-gather becomes a concatenation), so the time per rank = total / G is what each GPU of a G-GPU
+job would spend in kernels per BFS (no xGMI time).  usage: dist2_single.py [scale] [G]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import mini_amd
+from mini_amd.dist_bfs import HipRankEngine2, rmat_cyclic_shard
+scale = int(sys.argv[1]) if len(sys.argv) > 1 else 22
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+dev = torch.device("cuda", 0)
+ctx = mini_amd.Context(0, torch.cuda.current_stream().cuda_stream)
+n = 1 << scale
+engs = []
+for r in range(G):
+    ro, col, new_of_old, old_of_new, deg_new = rmat_cyclic_shard(ctx, scale, 16, scale, G, r, dev)
+    engs.append(HipRankEngine2(ctx, n, G, r, ro, col))
+srcs = [int(v) for v in torch.nonzero(deg_new > 0)[:: max(1, n // 64)][:6, 0].tolist()]
+for it, s in enumerate(srcs):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    edges = sum(e.reset(s) for e in engs)
+    level = 0
+    while True:
+        gathered = torch.cat([e.push(level) for e in engs]) if G > 1 else engs[0].push(level)
+        nf = 0
+        for e in engs:
+            a, b = e.merge(level, gathered)
+            nf += a; edges += b
+        level += 1
+        if nf == 0:
+            break
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    if it:
+        print("src %d levels %d edges %d  total %.3f ms  per-rank %.3f ms  -> %.1f GTEPS aggregate (no exchange time)"
+              % (s, level, edges, dt * 1e3, dt * 1e3 / G, edges / (dt / G) / 1e9))
