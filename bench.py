@@ -57,7 +57,10 @@ def main():
     if world != args.gpus and world > 1:
         args.gpus = world
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # MGX_BENCH_FORCE_DIST=1 under a one-rank torchrun: run the N>1 code path (RCCL group of one) -- a
+    # pre-flight for the multi-GPU bench on a one-GPU box, never a reported number
+    force_dist = os.environ.get("MGX_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as ge
@@ -68,7 +71,7 @@ def main():
     import mini_amd
     from mini_amd import rmat
 
-    if world > 1:
+    if world > 1 or force_dist:
         from mini_amd import dist_bfs
         return dist_bfs.bench_main(args, rank, world, local_rank)
 

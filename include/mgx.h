@@ -206,8 +206,10 @@ MGX_API int mgx_dbfs2_free(mgx_dbfs2_t h);
 /* first_edges (may be NULL): edges of this rank's level-0 frontier = deg(src) on the owner, 0 elsewhere */
 MGX_API int mgx_dbfs2_reset(mgx_dbfs2_t h, int src_global, int64_t* first_edges);
 MGX_API int mgx_dbfs2_push(mgx_dbfs2_t h, int level);
+/* new_global: vertices discovered by all ranks together in this level -- the same number on every rank,
+ * so "new_global == 0" ends the traversal everywhere without a reduction */
 MGX_API int mgx_dbfs2_merge(mgx_dbfs2_t h, int level, const unsigned* d_gathered, int64_t* next_frontier_size,
-                            int64_t* next_frontier_edges);
+                            int64_t* next_frontier_edges, int64_t* new_global);
 MGX_API int mgx_dbfs2_labels(mgx_dbfs2_t h, int* host_labels_local);
 
 /* ---- SSSP: sssp_problem_t / sssp_functor_t / sssp_enactor_t (gunrock/src/sssp/) ---- */

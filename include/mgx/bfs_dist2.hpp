@@ -16,6 +16,7 @@
 //     its next local frontier (row start, scanned degree; packed-cursor append as everywhere else).
 // Labels are the global BFS depths, identical to the single-GPU result.
 #pragma once
+#include <cstddef>
 #include <memory>
 
 #include "bfs_fused_wave.hpp"
@@ -23,20 +24,26 @@
 namespace mgx {
 
 __global__ __launch_bounds__(BLOCK) void k_d2_newbits(const u32* __restrict__ visited, const u32* __restrict__ snapshot,
-                                                      u32* __restrict__ out, long long nwords) {
+                                                      u32* __restrict__ out, long long nwords, bfs_ctrl_t* c) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) c->merged_new = 0;     // k_d2_or of this level counts into it
   for (long long w = (long long)blockIdx.x * BLOCK + threadIdx.x; w < nwords; w += (long long)gridDim.x * BLOCK)
     out[w] = visited[w] & ~snapshot[w];
 }
 
-// merged[w] = OR over ranks of gathered[r][w]; visited |= merged
+// merged[w] = OR over ranks of gathered[r][w]; visited |= merged; ctrl->merged_new += popcount(merged).
+// Every rank computes the same count, so the traversal ends on all ranks together without a reduction.
 __global__ __launch_bounds__(BLOCK) void k_d2_or(const u32* __restrict__ gathered, int ranks, long long nwords,
-                                                 u32* __restrict__ merged, u32* __restrict__ visited) {
+                                                 u32* __restrict__ merged, u32* __restrict__ visited, bfs_ctrl_t* c) {
+  int found = 0;
   for (long long w = (long long)blockIdx.x * BLOCK + threadIdx.x; w < nwords; w += (long long)gridDim.x * BLOCK) {
     u32 g = 0;
     for (int r = 0; r < ranks; ++r) g |= gathered[(long long)r * nwords + w];
     merged[w] = g;
     if (g) visited[w] |= g;
+    found += __popc(g);
   }
+  found = wave_sum(found);
+  if (lane_id() == 0 && found) atomicAdd(&c->merged_new, (u64)found);
 }
 
 // owned vertices whose bit is set in `merged`: label them and append them to the next local frontier
@@ -225,21 +232,25 @@ inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx) {
   hipLaunchKernelGGL((k_bfs_push_level_wave<512, 12288>), dim3(ctx.num_cus * 2), dim3(512),
                      bfs_wave_lds_bytes(512, 12288), s, a, level);
   hipLaunchKernelGGL(k_d2_newbits, dim3(grid_for(st.nwords, BLOCK, 256)), dim3(BLOCK), 0, s, st.fs->visited.data(),
-                     st.fs->snapshot.data(), st.newbits, st.nwords);
+                     st.fs->snapshot.data(), st.newbits, st.nwords, a.ctrl);
 }
 
-// gathered: ranks x nwords words (every rank's new_bits).  Returns the size of this rank's next frontier.
-inline long long d2_merge(d2_state_t& st, int level, const u32* gathered, standard_context_t& ctx, long long* next_edges) {
+// gathered: ranks x nwords words (every rank's new_bits).  Returns the size of this rank's next frontier;
+// *new_global = vertices all ranks discovered in this level (0 on every rank at once: the traversal is over).
+inline long long d2_merge(d2_state_t& st, int level, const u32* gathered, standard_context_t& ctx, long long* next_edges,
+                          long long* new_global) {
   hipStream_t s = ctx.stream();
   bfs_fused_args_t a = st.args();
   hipLaunchKernelGGL(k_d2_or, dim3(grid_for(st.nwords, BLOCK, 512)), dim3(BLOCK), 0, s, gathered, st.ranks, st.nwords,
-                     st.merged.data(), st.fs->visited.data());
+                     st.merged.data(), st.fs->visited.data(), a.ctrl);
   hipLaunchKernelGGL(k_d2_build<256>, dim3(ctx.num_cus * 4), dim3(256), 0, s, a, st.merged.data(), st.labels.data(),
                      st.n_local, st.ranks, st.rank, level);
   u64* hc = (u64*)ctx.mailbox;
-  MGX_HIP(hipMemcpyAsync(hc, &st.fs->ctrl.data()->cursor[(level + 1) % 3], sizeof(u64), hipMemcpyDeviceToHost, s));
+  static_assert(offsetof(bfs_ctrl_t, merged_new) == 3 * sizeof(u64), "cursor[3] and merged_new are read back together");
+  MGX_HIP(hipMemcpyAsync(hc, st.fs->ctrl.data(), 4 * sizeof(u64), hipMemcpyDeviceToHost, s));
   MGX_HIP(hipStreamSynchronize(s));
-  const u64 cur = hc[0];
+  const u64 cur = hc[(level + 1) % 3];
+  if (new_global) *new_global = (long long)hc[3];
   if (next_edges) *next_edges = (long long)(cur & BFS_EMASK);
   return (long long)(cur >> BFS_VSHIFT);
 }

@@ -37,6 +37,7 @@ constexpr u64 BFS_EMASK = (1ull << BFS_VSHIFT) - 1ull;
 
 struct bfs_ctrl_t {
   u64 cursor[3];     // level L reads [L%3], appends into [(L+1)%3], clears [(L+2)%3]
+  u64 merged_new;    // partitioned BFS (bfs_dist2.hpp): vertices discovered by ALL ranks in the level just merged
   u64 sum_edges;     // sum over levels of E  == m_t (out-degrees of reached vertices)
   u64 sum_frontier;  // sum over levels of frontier sizes (reached vertices with degree >= 1)
   u64 reached;       // vertices labelled (incl. source and zero-degree discoveries)

@@ -777,12 +777,14 @@ int mgx_dbfs2_push(mgx_dbfs2_t h, int level) {
   mgx::d2_push(h->st, level, *h->c->ctx);
   MGX_CATCH
 }
-int mgx_dbfs2_merge(mgx_dbfs2_t h, int level, const unsigned* d_gathered, int64_t* next_frontier, int64_t* next_edges) {
+int mgx_dbfs2_merge(mgx_dbfs2_t h, int level, const unsigned* d_gathered, int64_t* next_frontier, int64_t* next_edges,
+                    int64_t* new_global) {
   MGX_TRY
   MGX_REQUIRE(h && d_gathered && level >= 0, "bad argument");
   use_device(h->c);
-  long long e = 0;
-  const long long nf = mgx::d2_merge(h->st, level, d_gathered, *h->c->ctx, &e);
+  long long e = 0, g = 0;
+  const long long nf = mgx::d2_merge(h->st, level, d_gathered, *h->c->ctx, &e, &g);
+  if (new_global) *new_global = g;
   if (next_frontier) *next_frontier = nf;
   if (next_edges) *next_edges = e;
   MGX_CATCH

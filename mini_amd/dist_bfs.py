@@ -130,8 +130,8 @@ class DistBfs:
                 nf = int(t.item())
             if nf == 0:
                 break
-        self.levels = level
-        return {"levels": level, "edges_local": edges_local}
+        self.levels = level + 1          # levels 0..level hold vertices (reference "iterations")
+        return {"levels": level + 1, "edges_local": edges_local}
 
     def gather_labels(self):
         """Global label array on every rank (validation only)."""
@@ -180,9 +180,9 @@ class HipRankEngine2:
         return self.newbits
 
     def merge(self, level, gathered):
-        nf, ne = C.c_int64(), C.c_int64()
-        check(lib.mgx_dbfs2_merge(self._h, int(level), C.c_void_p(gathered.data_ptr()), C.byref(nf), C.byref(ne)))
-        return nf.value, ne.value
+        nf, ne, ng = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib.mgx_dbfs2_merge(self._h, int(level), C.c_void_p(gathered.data_ptr()), C.byref(nf), C.byref(ne), C.byref(ng)))
+        return nf.value, ne.value, ng.value
 
     def labels(self):
         out = np.empty(self.n_local, dtype=np.int32)
@@ -196,8 +196,8 @@ class HipRankEngine2:
 
 
 class DistBfs2:
-    """Superstep driver of generation 2: push (device) -> all_gather of the new-bit maps -> merge (device)
-    -> all_reduce of the next frontier sizes.  `engine` needs reset/push/merge/labels."""
+    """Superstep driver of generation 2: push (device) -> all_gather of the new-bit maps -> merge (device);
+    every rank counts the merged discoveries itself, so a level costs ONE collective.  `engine` needs reset/push/merge/labels."""
 
     def __init__(self, engine, rank, world, comm_device):
         self.e, self.rank, self.world, self.comm_device = engine, rank, world, torch.device(comm_device)
@@ -215,18 +215,13 @@ class DistBfs2:
                     gathered = gathered.to(new.device)
             else:
                 gathered = new
-            nf_local, ne_local = e.merge(level, gathered)
+            _, ne_local, new_global = e.merge(level, gathered)
             edges_local += ne_local
-            level += 1
-            nf = nf_local
-            if W > 1:
-                t = torch.tensor([nf_local], dtype=torch.int64, device=self.comm_device)
-                dist.all_reduce(t)
-                nf = int(t.item())
-            if nf == 0:
+            if new_global == 0:       # the same count on every rank (merged bitmap): no reduction needed
                 break
-        self.levels = level
-        return {"levels": level, "edges_local": edges_local}
+            level += 1
+        self.levels = level + 1          # levels 0..level hold vertices (reference "iterations")
+        return {"levels": level + 1, "edges_local": edges_local}
 
     def gather_labels(self):
         """Global label array in (hub-first) global ids on every rank (validation only)."""

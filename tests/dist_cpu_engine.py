@@ -106,7 +106,7 @@ class NumpyRankEngine2:
         self.lab[mine] = level + 1
         deg = self.ro[mine + 1] - self.ro[mine]
         self.front = mine[deg > 0].tolist()
-        return len(self.front), int(deg.sum())
+        return len(self.front), int(deg.sum()), int(bits.sum())
 
     def labels(self):
         return self.lab.copy()

@@ -23,12 +23,11 @@ for it, s in enumerate(srcs):
     level = 0
     while True:
         gathered = torch.cat([e.push(level) for e in engs]) if G > 1 else engs[0].push(level)
-        nf = 0
         for e in engs:
-            a, b = e.merge(level, gathered)
-            nf += a; edges += b
+            a, b, ng = e.merge(level, gathered)
+            edges += b
         level += 1
-        if nf == 0:
+        if ng == 0:
             break
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     if it:
