@@ -99,10 +99,12 @@ def main():
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     stats = []
+    kernel_times = []
     t0 = time.perf_counter()
     ev0.record(stream)
     for s in sources[args.warmup:]:
         stats.append(bfs.run(s, mode, args.alpha))
+        kernel_times.append(bfs.kernel_times())
     ev1.record(stream)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -120,17 +122,21 @@ def main():
     alg_bytes = 8.0 * push_edges + 4.125 * pull_edges + 20.0 * nf_total
     value = m_t / elapsed / 1e6
 
-    # Dominant kernel: k_bfs_push_level_wave (wave-private streaming push; the device sends every level
-    # with a small average frontier degree to it -- on RMAT that is ~90 % of the edges).  achieved =
-    # algorithmic bytes of the levels it processed / device time of ALL its launches in the timed region
-    # (HIP events around every launch on the launch stream; launches that find nothing to do are
-    # included, as rocprofv3 --stats averages over them too).
-    dom_launches = sum(st["dom_launches"] for st in stats)
-    dom_ns = sum(st["dom_ns"] for st in stats)
-    dom_edges = sum(st["dom_edges"] for st in stats)
-    dom_vertices = sum(st["dom_vertices"] for st in stats)
-    if dom_launches and dom_ns:
-        kname = "k_bfs_push_level_wave"
+    # Dominant kernel: of the two push kernels (k_bfs_push_level_stream: rows of >= 64 edges read row-wise;
+    # k_bfs_push_level_wave: shorter rows, searched per edge rank) the one with more device time in the timed
+    # region.  achieved = algorithmic bytes of the edges / frontier vertices it processed / device time of
+    # ALL its launches (HIP events around every launch on the launch stream; launches that find nothing to
+    # do are included, as rocprofv3 --stats averages over them too).
+    kt = {"stream": {"launches": 0, "ns": 0, "edges": 0, "vertices": 0}, "wave": {"launches": 0, "ns": 0, "edges": 0, "vertices": 0}}
+    for k in kernel_times:
+        for name in kt:
+            for f in kt[name]:
+                kt[name][f] += k[name][f]
+    dom = "stream" if kt["stream"]["ns"] > kt["wave"]["ns"] else "wave"
+    dom_launches, dom_ns = kt[dom]["launches"], kt[dom]["ns"]
+    dom_edges, dom_vertices = kt[dom]["edges"], kt[dom]["vertices"]
+    if dom_launches and dom_ns and dom_edges:
+        kname = "k_bfs_push_level_" + dom
         dom_bytes = 8.0 * dom_edges + 20.0 * dom_vertices
         avg_launch_s = (dom_ns / 1e9) / dom_launches
         bytes_per_launch = dom_bytes / dom_launches

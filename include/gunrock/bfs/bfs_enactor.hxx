@@ -14,7 +14,7 @@
 #include "../filter.hxx"
 #include "../frontier.hxx"
 #include "../graph.hxx"
-#include "../../mgx/bfs_chunk.hpp"
+#include "../../mgx/bfs_fused_run.hpp"
 #include "bfs_functor.hxx"
 #include "bfs_problem.hxx"
 
@@ -104,36 +104,30 @@ struct bfs_enactor_t : enactor_t {
 
 };
 
-// Device-resident fused traversal.  Needs only O(n) state: no edge-capacity ping-pong buffers.
-// Two generations of the engine live side by side (environment MGX_BFS_ENGINE=fused|chunk):
-//   fused (default): mgx/bfs_fused*.hpp -- per-edge load balancing; workgroup-synchronous tiles for
-//                    hub levels, wave-private streaming for the rest
-//   chunk:           mgx/bfs_chunk.hpp  -- experimental: chunk-granular (256 edges) load balancing,
-//                    sharded cursors; slower on RMAT push (short rows waste lanes), kept for comparison
-// Counters of the last run are in `last`.
+// Device-resident fused traversal (mgx/bfs_fused*.hpp).  Needs only O(n) state: no edge-capacity
+// ping-pong buffers.  Counters of the last run are in `last`.
+struct bfs_kernel_stats_t {
+  long long launches = 0, ns = 0, edges = 0, vertices = 0;   // launches incl. the ones that find nothing to do
+};
 struct bfs_run_stats_t {
   int levels = 0, push_levels = 0;
   long long reached = 0, m_t = 0, push_edges = 0, pull_edges = 0, frontier_vertices = 0, claims = 0;
   long long kernel_launches = 0, kernel_ns = 0;          // all level kernels of the run (batch events)
-  // the dominant kernel (wave-private streaming push): its launches, device time, and the edges /
-  // frontier vertices of the levels it processed
-  long long dom_launches = 0, dom_ns = 0, dom_edges = 0, dom_vertices = 0;
+  // the two push kernels, timed per launch: row-wise streaming of the long-row queue, per-edge search over
+  // the short-row queue; and which of them took longer (1 = stream, 0 = wave)
+  bfs_kernel_stats_t stream, wave;
+  int dominant = 0;
   std::vector<std::pair<long long, long long>> trace;   // (frontier vertices, frontier edges) per level
   std::vector<float> batch_ms;
-  long long diag[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long claims_level[64] = {0};
 };
 
 struct bfs_fused_enactor_t {
   std::unique_ptr<mgx::bfs_fused_state_t> fused;
-  std::unique_ptr<mgx::cb_state_t> chunk;
   bfs_run_stats_t last;
-  bool use_chunk = false;
 
   bfs_fused_enactor_t(standard_context_t& context, int num_nodes) {
-    if (const char* e = getenv("MGX_BFS_ENGINE")) use_chunk = std::string(e) == "chunk";
-    if (use_chunk) chunk.reset(new mgx::cb_state_t(num_nodes, context));
-    else fused.reset(new mgx::bfs_fused_state_t(num_nodes, context));
+    fused.reset(new mgx::bfs_fused_state_t(num_nodes, context));
   }
   bfs_fused_enactor_t(const bfs_fused_enactor_t&) = delete;
   bfs_fused_enactor_t& operator=(const bfs_fused_enactor_t&) = delete;
@@ -155,40 +149,34 @@ struct bfs_fused_enactor_t {
     // CSC slots alias the CSR (symmetric input, what the reference always has)
     const bool use_layout = g.has_layout && (!direction_optimizing || g.csc_is_csr);
     last = bfs_run_stats_t();
-    if (use_chunk) {
-      mgx::cb_run(*chunk, g.d_row_offsets.data(), g.d_col_indices.data(), (unsigned)g.num_edges, bfs_problem->d_labels.data(),
-                  bfs_problem->src, context, use_layout ? &layout : nullptr, direction_optimizing ? 1 : 0, alpha,
-                  g.d_col_offsets.data(), g.d_row_indices.data());
-      const mgx::cb_ctrl_t* hc = chunk->host_ctrl;
-      last.levels = hc->levels; last.push_levels = hc->push_levels;
-      last.reached = (long long)hc->reached; last.m_t = (long long)hc->sum_edges;
-      last.pull_edges = (long long)hc->pull_edges; last.frontier_vertices = (long long)hc->sum_frontier;
-      last.claims = (long long)hc->claims;
-      last.kernel_launches = chunk->level_kernel_launches; last.kernel_ns = (long long)(chunk->level_kernel_ms * 1e6);
-      for (int i = 0; i < hc->levels && i < mgx::BFS_MAX_TRACE; ++i)
-        last.trace.emplace_back((long long)(hc->trace[i] >> mgx::BFS_VSHIFT), (long long)(hc->trace[i] & mgx::BFS_EMASK));
-      for (int i = 0; i < chunk->batches; ++i) last.batch_ms.push_back(chunk->batch_ms[i]);
-    } else {
-      mgx::bfs_fused_run(*fused, g.d_row_offsets.data(), g.d_col_indices.data(), bfs_problem->d_labels.data(),
-                         bfs_problem->src, context, use_layout ? &layout : nullptr, direction_optimizing ? 1 : 0, alpha,
-                         g.d_col_offsets.data(), g.d_row_indices.data());
-      const mgx::bfs_ctrl_t* hc = fused->host_ctrl;
-      last.levels = hc->levels; last.push_levels = hc->push_levels;
-      last.reached = (long long)hc->reached; last.m_t = (long long)hc->sum_edges;
-      last.pull_edges = (long long)hc->pull_edges; last.frontier_vertices = (long long)hc->sum_frontier;
-      last.claims = (long long)hc->claims;
-      last.kernel_launches = fused->level_kernel_launches; last.kernel_ns = (long long)(fused->level_kernel_ms * 1e6);
-      for (int i = 0; i < hc->levels && i < mgx::BFS_MAX_TRACE; ++i)
-        last.trace.emplace_back((long long)(hc->trace[i] >> mgx::BFS_VSHIFT), (long long)(hc->trace[i] & mgx::BFS_EMASK));
-      for (int i = 0; i < fused->batches; ++i) last.batch_ms.push_back(fused->batch_ms[i]);
-      last.dom_launches = fused->wave_kernel_launches;
-      last.dom_ns = (long long)(fused->wave_kernel_ms * 1e6);
-      for (int i = 0; i < (int)last.trace.size() && i < 64; ++i)
-        if ((hc->kind_mask >> i) & 1ull) { last.dom_edges += last.trace[i].second; last.dom_vertices += last.trace[i].first; }
-      for (int i = 0; i < 8; ++i) last.diag[i] = (long long)hc->diag[i];
-      for (int i = 0; i < 64; ++i) last.claims_level[i] = (long long)hc->claims_level[i];
-    }
+    mgx::bfs_fused_run(*fused, g.d_row_offsets.data(), g.d_col_indices.data(), bfs_problem->d_labels.data(),
+                       bfs_problem->src, context, use_layout ? &layout : nullptr, direction_optimizing ? 1 : 0, alpha,
+                       g.d_col_offsets.data(), g.d_row_indices.data());
+    const mgx::bfs_ctrl_t* hc = fused->host_ctrl;
+    last.levels = hc->levels; last.push_levels = hc->push_levels;
+    last.reached = (long long)hc->reached; last.m_t = (long long)hc->sum_edges;
+    last.pull_edges = (long long)hc->pull_edges; last.frontier_vertices = (long long)hc->sum_frontier;
+    last.claims = (long long)hc->claims;
+    last.kernel_launches = fused->level_kernel_launches; last.kernel_ns = (long long)(fused->level_kernel_ms * 1e6);
+    for (int i = 0; i < hc->levels && i < mgx::BFS_MAX_TRACE; ++i)
+      last.trace.emplace_back((long long)(hc->trace[i] >> mgx::BFS_VSHIFT), (long long)(hc->trace[i] & mgx::BFS_EMASK));
+    for (int i = 0; i < fused->batches; ++i) last.batch_ms.push_back(fused->batch_ms[i]);
     for (int i = 0; i < last.push_levels && i < (int)last.trace.size(); ++i) last.push_edges += last.trace[i].second;
+    // the long-row queue only exists on push levels; the short-row queue gets the rest of the push edges
+    last.stream.launches = fused->stream_kernel_launches;
+    last.stream.ns = (long long)(fused->stream_kernel_ms * 1e6);
+    last.wave.launches = fused->wave_kernel_launches;
+    last.wave.ns = (long long)(fused->wave_kernel_ms * 1e6);
+    long long push_vertices = 0;
+    for (int i = 0; i < last.push_levels && i < (int)last.trace.size(); ++i) push_vertices += last.trace[i].first;
+    if (!direction_optimizing) {
+      last.stream.edges = (long long)hc->sum_long_edges;
+      last.stream.vertices = (long long)hc->sum_long_vertices;
+      last.wave.edges = last.push_edges - last.stream.edges;
+      last.wave.vertices = push_vertices - last.stream.vertices;
+    }
+    last.dominant = last.stream.ns > last.wave.ns ? 1 : 0;
+    for (int i = 0; i < 64; ++i) last.claims_level[i] = (long long)hc->claims_level[i];
   }
 };
 

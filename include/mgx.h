@@ -153,10 +153,11 @@ MGX_API int mgx_bfs_enact_pushpull(mgx_bfs_t p, float threshold, int64_t* stats)
  *   empty ones behind the last level) [7] device time of those launches in ns (HIP events on
  *   the context's stream) [8] frontier vertices expanded (sum of per-level frontier sizes)
  *   [9] visited-bit claims (atomicOr) issued.
- *   Dominant kernel (the wave-private streaming push kernel, which most edges go through):
+ *   Dominant push kernel = the one of the two (mgx_bfs_kernel_times) with more device time in this run:
  *   [10] its launches (incl. the ones that find nothing to do) [11] their device time in ns (HIP events
- *   around every launch) [12] edges and [13] frontier vertices of the levels it processed
- *   [14] engine (0 fused, 1 chunk) [15] reserved.  stats must hold 16 entries.                                            */
+ *   around every launch) [12] edges and [13] frontier vertices it processed
+ *   [14] which one (1 = k_bfs_push_level_stream, 0 = k_bfs_push_level_wave) [15] reserved.
+ *   stats must hold 16 entries.                                                                 */
 #define MGX_BFS_PUSH 0
 #define MGX_BFS_DIRECTION_OPT 1
 MGX_API int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats);
@@ -165,9 +166,13 @@ MGX_API int mgx_bfs_level_trace(mgx_bfs_t p, int cap, int64_t* level_nf, int64_t
 
 /* device time (ms, HIP events) of each launch batch of the last mgx_bfs_run; with the environment
  * variable MGX_BFS_LEVELS_PER_SYNC=1 a batch is exactly one level kernel                   */
-/* diagnostic builds only (environment MGX_BFS_DIAG=1): cycles per kernel stage of the last run,
- * summed over workgroups: staging, search, col_indices, visited, claim, barrier, flush, unused */
-MGX_API int mgx_bfs_diag(mgx_bfs_t p, int64_t* cycles8);
+/* the two push kernels of the last mgx_bfs_run, timed per launch with HIP events on the context's stream:
+ * out8 = { stream launches, ns, edges, frontier vertices,  wave launches, ns, edges, frontier vertices }
+ * (k_bfs_push_level_stream: rows of >= MGX_BFS_LONG_MIN edges, read row-wise;
+ *  k_bfs_push_level_wave: the shorter rows, load-balanced search per edge rank)                 */
+MGX_API int mgx_bfs_kernel_times(mgx_bfs_t p, int64_t* out8);
+/* the same per level (ms), first min(cap, 64) levels of the last run */
+MGX_API int mgx_bfs_level_kernel_times(mgx_bfs_t p, int cap, float* stream_ms, float* wave_ms);
 /* atomicOr claims issued per level of the last run (first 64 levels) */
 MGX_API int mgx_bfs_level_claims(mgx_bfs_t p, int cap, int64_t* claims);
 MGX_API int mgx_bfs_batch_times(mgx_bfs_t p, int cap, float* ms, int* batches);

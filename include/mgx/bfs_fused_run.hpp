@@ -1,0 +1,165 @@
+// mgx/bfs_fused_run.hpp -- host driver of the fused BFS: per level
+//   k_bfs_level_begin (one thread) -> k_bfs_push_level_stream (long rows) -> k_bfs_push_level_wave (short rows)
+//   [-> k_bfs_pull_level in direction-optimising runs] -> k_bfs_build
+// launched back to back; the host reads one flag every `levels_per_sync` levels.
+#pragma once
+#include "bfs_fused.hpp"
+#include "bfs_fused_pull.hpp"
+#include "bfs_fused_stream.hpp"
+#include "bfs_fused_wave.hpp"
+
+namespace mgx {
+
+// layout (optional): a hub-first relabelled copy of the CSR plus the two id maps; labels stay in the
+// original id space either way.
+struct bfs_layout_t {
+  const int* row_offsets = nullptr;
+  const int* col_indices = nullptr;
+  const int* new_of_old = nullptr;
+  const int* old_of_new = nullptr;
+};
+
+// Template instances of the two push kernels.  cold_test: probe the bitmap word of neighbours outside the LDS
+// prefix (big graphs: many cold endpoints) or mark them untested (k_bfs_build tests the bitmap anyway).
+constexpr int BFS_WAVE_HOTW = 19200;      // 75 KB of bitmap per workgroup, two workgroups per CU
+
+inline void bfs_set_kernel_attributes() {
+  static bool attr_set = false;
+  if (attr_set) return;
+#define MGX_SET_LDS(K_) MGX_HIP(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+  MGX_SET_LDS((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, false>));
+  MGX_SET_LDS((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, true>));
+  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 16, false>));
+  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, false>));
+  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, true>));
+#undef MGX_SET_LDS
+  attr_set = true;
+}
+
+// -1: decide by size (cold test when the bitmap is at least 8 x the LDS prefix), 0 / 1: forced (MGX_BFS_COLD_TEST)
+inline bool bfs_cold_test(int n) {
+  static const int forced = getenv("MGX_BFS_COLD_TEST") ? atoi(getenv("MGX_BFS_COLD_TEST")) : -1;
+  if (forced >= 0) return forced != 0;
+  return (long long)n >= 8ll * 32 * BFS_STREAM_HOTW;
+}
+
+inline void bfs_launch_stream(const bfs_fused_args_t& a, int level, standard_context_t& ctx) {
+  static const int ept = getenv("MGX_BFS_STREAM_EPT") ? atoi(getenv("MGX_BFS_STREAM_EPT")) : 16;
+  hipStream_t s = ctx.stream();
+  if (a.long_min <= 0) return;
+  const size_t lds = bfs_stream_lds_bytes(BFS_STREAM_HOTW);
+  if (bfs_cold_test(a.n))
+    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, true>), dim3(ctx.num_cus), dim3(1024), lds, s, a, level);
+  else if (ept == 8)
+    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, false>), dim3(ctx.num_cus), dim3(1024), lds, s, a, level);
+  else
+    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 16, false>), dim3(ctx.num_cus), dim3(1024), lds, s, a, level);
+}
+
+inline void bfs_launch_wave(const bfs_fused_args_t& a, int level, standard_context_t& ctx) {
+  hipStream_t s = ctx.stream();
+  const size_t lds = bfs_wave_lds_bytes(512, BFS_WAVE_HOTW);
+  if (bfs_cold_test(a.n))
+    hipLaunchKernelGGL((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, true>), dim3(ctx.num_cus * 2), dim3(512), lds, s, a, level);
+  else
+    hipLaunchKernelGGL((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, false>), dim3(ctx.num_cus * 2), dim3(512), lds, s, a, level);
+}
+
+// Runs a whole BFS from `src` on the context's stream.  labels[] is (re)initialised here.  Returns with the
+// stream synchronised and host_ctrl holding the final counters.
+// mode/alpha: MGX_BFS_PUSH (0) or MGX_BFS_DIRECTION_OPT (1) with the reference's switch rule
+// num_unvisited < frontier_length * alpha (bfs_enactor.hxx:68).  in_offsets/in_indices: in-edges for the
+// bottom-up levels (pass the CSR for symmetric graphs, the reference's behaviour -- SURVEY F8).
+inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const int* col_indices, int* labels,
+                          int src, standard_context_t& ctx, const bfs_layout_t* layout = nullptr, int mode = 0,
+                          float alpha = 0.f, const int* in_offsets = nullptr, const int* in_indices = nullptr) {
+  hipStream_t s = ctx.stream();
+  bfs_fused_args_t a;
+  const bool relabelled = layout && layout->row_offsets;
+  a.row_offsets = (const u32*)(relabelled ? layout->row_offsets : row_offsets);
+  a.col_indices = relabelled ? layout->col_indices : col_indices;
+  a.old_of_new = relabelled ? layout->old_of_new : nullptr;
+  a.new_of_old = relabelled ? layout->new_of_old : nullptr;
+  bfs_set_kernel_attributes();
+  a.labels = labels;
+  a.visited = st.visited.data();
+  a.mark = st.mark.data();
+  a.frontier_bits = st.frontier_bits.data();
+  a.mode = mode;
+  a.alpha = alpha;
+  a.in_offsets = (const u32*)(relabelled ? layout->row_offsets : (in_offsets ? in_offsets : row_offsets));
+  a.in_indices = relabelled ? layout->col_indices : (in_indices ? in_indices : col_indices);
+  for (int i = 0; i < 2; ++i) {
+    a.fr_row[i] = st.fr_row[i].data(); a.fr_off[i] = st.fr_off[i].data();
+    a.lq_row[i] = st.lq_row[i].data(); a.lq_off[i] = st.lq_off[i].data();
+  }
+  a.long_min = st.long_min;
+  a.hot_min_edges = st.hot_min_edges;
+  a.ctrl = st.ctrl.data();
+  a.n = st.n;
+  a.flags = 0;
+  if (const char* e = getenv("MGX_BFS_FLAGS")) a.flags = atoi(e);
+  const long long nwords = ((long long)st.n + 31) / 32;
+  MGX_HIP(hipMemsetAsync(labels, 0xFF, (size_t)st.n * sizeof(int), s));
+  MGX_HIP(hipMemsetAsync(st.visited.data(), 0, (size_t)(nwords + 1) * sizeof(u32), s));
+  MGX_HIP(hipMemsetAsync(st.mark.data(), 0, (size_t)st.n, s));
+  if (mode == 1) MGX_HIP(hipMemsetAsync(st.frontier_bits.data(), 0, (size_t)(nwords + 1) * sizeof(u32), s));
+  hipLaunchKernelGGL(k_bfs_fused_init, dim3(1), dim3(64), 0, s, a, src);
+  int level = 0;
+  st.level_kernel_ms = 0.0;
+  st.level_kernel_launches = 0;
+  st.wave_kernel_ms = 0.0;
+  st.wave_kernel_launches = 0;
+  st.stream_kernel_ms = 0.0;
+  st.stream_kernel_launches = 0;
+  st.batches = 0;
+  for (;;) {
+    MGX_HIP(hipEventRecord(st.ev0, s));
+    for (int i = 0; i < st.levels_per_sync; ++i, ++level) {
+      hipLaunchKernelGGL(k_bfs_level_begin, dim3(1), dim3(64), 0, s, a, level);
+      const bool timed = 3 * i + 2 < bfs_fused_state_t::EV_POOL;
+      if (timed) MGX_HIP(hipEventRecord(st.wev[3 * i], s));
+      bfs_launch_stream(a, level, ctx);
+      if (timed) MGX_HIP(hipEventRecord(st.wev[3 * i + 1], s));
+      bfs_launch_wave(a, level, ctx);
+      if (timed) MGX_HIP(hipEventRecord(st.wev[3 * i + 2], s));
+      if (mode == 1)
+        hipLaunchKernelGGL(k_bfs_pull_level<256>, dim3(ctx.num_cus * 8), dim3(256), 0, s, a, level);
+      hipLaunchKernelGGL((k_bfs_build<BFS_BUILD_NT, true>), dim3(ctx.num_cus), dim3(BFS_BUILD_NT), 0, s, a, level,
+                         (const u32*)nullptr, labels, st.n, 1, 0, 1);
+    }
+    MGX_HIP(hipEventRecord(st.ev1, s));
+    MGX_HIP(hipMemcpyAsync(&st.host_ctrl->done, &st.ctrl.data()->done, sizeof(int), hipMemcpyDeviceToHost, s));
+    MGX_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    MGX_HIP(hipEventElapsedTime(&ms, st.ev0, st.ev1));
+    st.level_kernel_ms += ms;
+    for (int i = 0; i < st.levels_per_sync && 3 * i + 2 < bfs_fused_state_t::EV_POOL; ++i) {
+      const int lv = level - st.levels_per_sync + i;
+      float wms = 0.f;
+      MGX_HIP(hipEventElapsedTime(&wms, st.wev[3 * i + 1], st.wev[3 * i + 2]));
+      st.wave_kernel_ms += wms;
+      st.wave_kernel_launches += 1;
+      if (lv < 64) st.level_wave_ms[lv] = wms;
+      if (a.long_min > 0) {
+        MGX_HIP(hipEventElapsedTime(&wms, st.wev[3 * i], st.wev[3 * i + 1]));
+        st.stream_kernel_ms += wms;
+        st.stream_kernel_launches += 1;
+        if (lv < 64) st.level_stream_ms[lv] = wms;
+      }
+    }
+    if (st.batches < 256) st.batch_ms[st.batches++] = ms;
+    st.level_kernel_launches += st.levels_per_sync;
+    if (st.host_ctrl->done) break;
+  }
+  // counters first, then only the part of the per-level trace that was written
+  MGX_HIP(hipMemcpyAsync(st.host_ctrl, st.ctrl.data(), offsetof(bfs_ctrl_t, trace), hipMemcpyDeviceToHost, s));
+  MGX_HIP(hipStreamSynchronize(s));
+  const int lv = st.host_ctrl->levels < BFS_MAX_TRACE ? st.host_ctrl->levels : BFS_MAX_TRACE;
+  if (lv > 0) {
+    MGX_HIP(hipMemcpyAsync(st.host_ctrl->trace, st.ctrl.data()->trace, (size_t)lv * sizeof(u64), hipMemcpyDeviceToHost, s));
+    MGX_HIP(hipStreamSynchronize(s));
+  }
+}
+
+}  // namespace mgx

@@ -64,6 +64,26 @@ __device__ __forceinline__ T block_exclusive_sum(T x, T* smem, T* total) {
   return base + inc - x;
 }
 
+// Same for a workgroup of NW waves (any block size); `smem` needs NW slots of T.  Two barriers.
+template <int NW, typename T>
+__device__ __forceinline__ T block_exclusive_sum_nw(T x, T* smem, T* total) {
+  const int lane = lane_id();
+  const int wave = threadIdx.x / WAVE;
+  T inc = wave_inclusive_sum(x);
+  if (lane == WAVE - 1) smem[wave] = inc;
+  __syncthreads();
+  T base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    T s = smem[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - x;
+}
+
 // Wave-cooperative upper bound on a sorted global array: returns the number of elements
 // a[i] <= key for i in [0,n) (so the last position with a[pos] <= key is result-1).
 // 64-ary search: every step narrows the window by 64x with one coalescable probe per lane.

@@ -97,7 +97,8 @@ SIGNATURES = {
     "mgx_bfs_enact_pushpull": [_vp, _f, _pi64],
     "mgx_bfs_run": [_vp, _i, _i, _f, _pi64],
     "mgx_bfs_level_trace": [_vp, _i, _pi64, _pi64, _pi],
-    "mgx_bfs_diag": [_vp, _pi64],
+    "mgx_bfs_kernel_times": [_vp, _pi64],
+    "mgx_bfs_level_kernel_times": [_vp, _i, _pf, _pf],
     "mgx_bfs_level_claims": [_vp, _i, _pi64],
     "mgx_bfs_batch_times": [_vp, _i, _pf, _pi],
     "mgx_dbfs_create": [_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _i64, _pvp],

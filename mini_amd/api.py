@@ -251,7 +251,8 @@ class BfsProblem:
         return {"levels": st[0], "reached": st[1], "m_t": st[2], "push_edges": st[3], "pull_edges": st[4],
                 "push_levels": st[5], "kernel_launches": st[6], "kernel_ns": st[7], "frontier_vertices": st[8],
                 "claims": st[9], "dom_launches": st[10], "dom_ns": st[11], "dom_edges": st[12],
-                "dom_vertices": st[13], "engine": "chunk" if st[14] else "fused"}
+                "dom_vertices": st[13],
+                "dom_kernel": "k_bfs_push_level_stream" if st[14] else "k_bfs_push_level_wave"}
 
     def level_trace(self, cap=4096):
         nf, ne, lv = (C.c_int64 * cap)(), (C.c_int64 * cap)(), C.c_int()
@@ -259,10 +260,17 @@ class BfsProblem:
         L = min(lv.value, cap)
         return [(nf[i], ne[i]) for i in range(L)]
 
-    def diag_cycles(self):
+    def kernel_times(self):
+        """per-launch timing of the two push kernels of the last run()"""
         c = (C.c_int64 * 8)()
-        check(lib.mgx_bfs_diag(self._h, c))
-        return [c[i] for i in range(8)]
+        check(lib.mgx_bfs_kernel_times(self._h, c))
+        keys = ("launches", "ns", "edges", "vertices")
+        return {"stream": dict(zip(keys, c[0:4])), "wave": dict(zip(keys, c[4:8]))}
+
+    def level_kernel_times_ms(self, cap=64):
+        a, b = (C.c_float * cap)(), (C.c_float * cap)()
+        check(lib.mgx_bfs_level_kernel_times(self._h, cap, a, b))
+        return [(a[i], b[i]) for i in range(cap)]
 
     def level_claims(self, cap=64):
         c = (C.c_int64 * cap)()

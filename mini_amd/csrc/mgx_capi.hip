@@ -616,11 +616,12 @@ int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats) {
   p->last_stats[7] = L.kernel_ns;
   p->last_stats[8] = L.frontier_vertices;
   p->last_stats[9] = L.claims;
-  p->last_stats[10] = L.dom_launches;
-  p->last_stats[11] = L.dom_ns;
-  p->last_stats[12] = L.dom_edges;
-  p->last_stats[13] = L.dom_vertices;
-  p->last_stats[14] = p->fe->use_chunk ? 1 : 0;
+  const bfs::bfs_kernel_stats_t& D = L.dominant ? L.stream : L.wave;
+  p->last_stats[10] = D.launches;
+  p->last_stats[11] = D.ns;
+  p->last_stats[12] = D.edges;
+  p->last_stats[13] = D.vertices;
+  p->last_stats[14] = L.dominant;
   p->last_stats[15] = 0;
   if (stats) memcpy(stats, p->last_stats, sizeof(p->last_stats));
   MGX_CATCH
@@ -637,11 +638,23 @@ int mgx_bfs_level_trace(mgx_bfs_t p, int cap, int64_t* level_nf, int64_t* level_
   }
   MGX_CATCH
 }
-int mgx_bfs_diag(mgx_bfs_t p, int64_t* cycles8) {
+int mgx_bfs_kernel_times(mgx_bfs_t p, int64_t* out8) {
   MGX_TRY
-  MGX_REQUIRE(p && cycles8, "NULL argument");
-  MGX_REQUIRE(p->fe != nullptr, "mgx_bfs_diag: no mgx_bfs_run yet");
-  for (int i = 0; i < 8; ++i) cycles8[i] = p->fe->last.diag[i];
+  MGX_REQUIRE(p && out8, "NULL argument");
+  MGX_REQUIRE(p->fe != nullptr, "mgx_bfs_kernel_times: no mgx_bfs_run yet");
+  const bfs::bfs_run_stats_t& L = p->fe->last;
+  out8[0] = L.stream.launches; out8[1] = L.stream.ns; out8[2] = L.stream.edges; out8[3] = L.stream.vertices;
+  out8[4] = L.wave.launches; out8[5] = L.wave.ns; out8[6] = L.wave.edges; out8[7] = L.wave.vertices;
+  MGX_CATCH
+}
+int mgx_bfs_level_kernel_times(mgx_bfs_t p, int cap, float* stream_ms, float* wave_ms) {
+  MGX_TRY
+  MGX_REQUIRE(p && stream_ms && wave_ms, "NULL argument");
+  MGX_REQUIRE(p->fe != nullptr, "mgx_bfs_level_kernel_times: no mgx_bfs_run yet");
+  for (int i = 0; i < cap && i < 64; ++i) {
+    stream_ms[i] = p->fe->fused->level_stream_ms[i];
+    wave_ms[i] = p->fe->fused->level_wave_ms[i];
+  }
   MGX_CATCH
 }
 int mgx_bfs_level_claims(mgx_bfs_t p, int cap, int64_t* claims) {

@@ -268,14 +268,19 @@ def test_bfs_rmat_parity_all_paths(gpu_ctx, oracle, rmat_graphs, scale):
             assert np.array_equal(bfs.labels(), want), "pushpull alpha=%s src=%d" % (alpha, src)
 
 
-@pytest.mark.parametrize("scale,min_tiles", [(10, 0), (13, 0), (16, 0), (16, 4)])
-def test_bfs_hub_first_layout_and_lds_hot_bitmap(gpu_ctx, oracle, torch_mod, rmat_graphs, scale, min_tiles, monkeypatch):
-    """fused traversal on the degree-sorted layout (LDS-resident hot bitmap kernel): labels must come
-    back in ORIGINAL ids and equal the oracle's; min_tiles=0 forces the LDS path on small graphs."""
+@pytest.mark.parametrize("scale,hot_min_edges,long_min", [(10, 0, 64), (13, 0, 8), (13, 0, 0), (16, 0, 64), (16, 65536, 64),
+                                                          (16, 0, 1), (16, 1 << 30, 16)])
+def test_bfs_hub_first_layout_and_lds_hot_bitmap(gpu_ctx, oracle, torch_mod, rmat_graphs, scale, hot_min_edges, long_min,
+                                                 monkeypatch):
+    """fused traversal on the degree-sorted layout (hot prefix of the visited snapshot in LDS): labels must
+    come back in ORIGINAL ids and equal the oracle's.  hot_min_edges=0 forces the LDS path on small graphs,
+    2^30 keeps every probe in L2; long_min moves rows between the row-wise streaming kernel and the
+    per-edge-rank kernel (0: no long-row queue, 1: every row is streamed)."""
     import mini_amd
     from mini_amd import rmat
     torch = torch_mod
-    monkeypatch.setenv("MGX_BFS_HOT_MIN_TILES", str(min_tiles))
+    monkeypatch.setenv("MGX_BFS_HOT_MIN_EDGES", str(hot_min_edges))
+    monkeypatch.setenv("MGX_BFS_LONG_MIN", str(long_min))
     n, ro, ci, w = rmat_graphs[scale]
     d_ro, d_ci = torch.from_numpy(ro).cuda(), torch.from_numpy(ci).cuda()
     g = mini_amd.Graph.from_device(gpu_ctx, n, len(ci), d_ro, d_ci)
@@ -307,7 +312,7 @@ def test_bfs_direction_optimizing_fused(gpu_ctx, oracle, torch_mod, rmat_graphs,
     import mini_amd
     from mini_amd import rmat
     torch = torch_mod
-    monkeypatch.setenv("MGX_BFS_HOT_MIN_TILES", "0")
+    monkeypatch.setenv("MGX_BFS_HOT_MIN_EDGES", "0")
     n, ro, ci, w = rmat_graphs[scale]
     d_ro, d_ci = torch.from_numpy(ro).cuda(), torch.from_numpy(ci).cuda()
     g = mini_amd.Graph.from_device(gpu_ctx, n, len(ci), d_ro, d_ci)

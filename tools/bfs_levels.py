@@ -23,12 +23,12 @@ for s in srcs[1:]:
     tr, ms, cl = bfs.level_trace(), bfs.batch_times_ms(), bfs.level_claims()
     print("src %d: levels %d reached %d m_t %d kernel_ms %.3f" % (s, st["levels"], st["reached"], st["m_t"], st["kernel_ns"] / 1e6))
     print("  claims %d  push_levels %d  push_edges %d  pull_edges %d" % (st["claims"], st["push_levels"], st["push_edges"], st["pull_edges"]))
+    kt = bfs.level_kernel_times_ms()
     for lv, ((nf, ne), t) in enumerate(zip(tr, ms)):
         b = 8.0 * ne + 20.0 * nf
-        print("  level %2d  nf %9d  edges %10d  %8.3f ms  %8.1f GTEPS  %7.1f algGB/s  claims %9d" % (lv, nf, ne, t, ne / t / 1e6 if t > 0 else 0, b / t / 1e6 if t > 0 else 0, cl[lv] if lv < 64 else -1))
-    if os.environ.get("MGX_BFS_DIAG") == "1":
-        d = bfs.diag_cycles(); tot = float(sum(d)) or 1.0
-        names = ["S4a+words", "midbar", "midflush", "S4b", "col+issue", "prepare", "endbar", "endflush"]
-        print("  diag (share of stamped cycles, whole run): " + "  ".join("%s %.1f%%" % (n, 100 * x / tot) for n, x in zip(names, d)))
-        print("  diag cycles per workgroup-tile: total %.0f" % (tot / max(1, st["m_t"] / 1024)))
+        print("  level %2d  nf %9d  edges %10d  %8.3f ms (stream %.3f wave %.3f)  %8.1f GTEPS  %7.1f algGB/s  claims %9d" % (lv, nf, ne, t, kt[lv][0], kt[lv][1], ne / t / 1e6 if t > 0 else 0, b / t / 1e6 if t > 0 else 0, cl[lv] if lv < 64 else -1))
+    k = bfs.kernel_times()
+    for name in ("stream", "wave"):
+        q = k[name]
+        print("  %-6s launches %d  %.3f ms  edges %d (%.1f GTEPS)" % (name, q["launches"], q["ns"] / 1e6, q["edges"], q["edges"] / max(q["ns"], 1)))
     print("  tail batches:", ["%.4f" % x for x in ms[len(tr):]])
