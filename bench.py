@@ -104,11 +104,19 @@ def main():
     ev0.record(stream)
     for s in sources[args.warmup:]:
         stats.append(bfs.run(s, mode, args.alpha))
-        kernel_times.append(bfs.kernel_times())
     ev1.record(stream)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
+    # Roofline pass: the SAME K sources again, now with HIP events around every launch of the two push kernels
+    # (on the launch stream).  It is a second pass because every event record between two kernels leaves a
+    # ~6 us gap on the stream (rocprofv3 kernel trace, profiles/), 3 events x ~8 levels per BFS: inside the timed
+    # region they would cost ~10 % of `value`.
+    bfs.set_kernel_timing(True)
+    for s in sources[args.warmup:]:
+        bfs.run(s, mode, args.alpha)
+        kernel_times.append(bfs.kernel_times())
+    bfs.set_kernel_timing(False)
 
     m_t = sum(st["m_t"] for st in stats)
     reached = sum(st["reached"] for st in stats)
@@ -156,6 +164,8 @@ def main():
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": traffic, "launches": dom_launches if dom_launches else launches,
+                "timing": "HIP events around every launch of this kernel, second pass over the same %d sources "
+                          "(events kept out of the timed region: each leaves a ~6 us gap on the stream)" % len(stats),
                 "avg_launch_us": round(avg_launch_s * 1e6, 3),
                 "alg_bytes_per_launch": round(bytes_per_launch, 1),
                 "share_of_edges": round(dom_edges / max(m_t, 1), 4) if dom_launches else 1.0,

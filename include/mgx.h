@@ -166,6 +166,10 @@ MGX_API int mgx_bfs_level_trace(mgx_bfs_t p, int cap, int64_t* level_nf, int64_t
 
 /* device time (ms, HIP events) of each launch batch of the last mgx_bfs_run; with the environment
  * variable MGX_BFS_LEVELS_PER_SYNC=1 a batch is exactly one level kernel                   */
+/* Per-launch timing of the push kernels is OFF by default: every hipEventRecord between two kernels leaves a
+ * ~6 us gap on the stream (measured, rocprofv3 kernel trace).  on != 0: following mgx_bfs_run calls record events
+ * around both push kernels of every level and fill mgx_bfs_kernel_times / mgx_bfs_level_kernel_times. */
+MGX_API int mgx_bfs_set_kernel_timing(mgx_bfs_t p, int on);
 /* the two push kernels of the last mgx_bfs_run, timed per launch with HIP events on the context's stream:
  * out8 = { stream launches, ns, edges, frontier vertices,  wave launches, ns, edges, frontier vertices }
  * (k_bfs_push_level_stream: rows of >= MGX_BFS_LONG_MIN edges, read row-wise;

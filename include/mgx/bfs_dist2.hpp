@@ -146,7 +146,7 @@ inline long long d2_merge(d2_state_t& st, int level, const u32* gathered, standa
   bfs_fused_args_t a = st.args();
   hipLaunchKernelGGL(k_d2_or, dim3(grid_for(st.nwords, BLOCK, 512)), dim3(BLOCK), 0, s, gathered, st.ranks, st.nwords,
                      st.merged.data(), st.fs->visited.data(), a.ctrl);
-  hipLaunchKernelGGL((k_bfs_build<BFS_BUILD_NT, false>), dim3(ctx.num_cus), dim3(BFS_BUILD_NT), 0, s, a, level,
+  hipLaunchKernelGGL((k_bfs_build<BFS_BUILD_NT, false>), dim3(bfs_build_grid(st.n_local)), dim3(BFS_BUILD_NT), 0, s, a, level,
                      (const u32*)st.merged.data(), st.labels.data(), st.n_local, st.ranks, st.rank, 0);
   u64* hc = (u64*)ctx.mailbox;
   static_assert(offsetof(bfs_ctrl_t, merged_new) == 3 * sizeof(u64), "cursor[3] and merged_new are read back together");

@@ -107,14 +107,35 @@ __device__ __forceinline__ void bfs_seed_queue(const bfs_fused_args_t& a, u32 ro
   (is_long ? c->lcursor : c->cursor)[0] = deg ? ((1ull << BFS_VSHIFT) | (u64)deg) : 0ull;
 }
 
-__global__ void k_bfs_fused_init(bfs_fused_args_t a, int src) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  bfs_ctrl_reset(a.ctrl);
-  a.labels[src] = 0;                                   // labels live in ORIGINAL id space
-  if (a.new_of_old) src = a.new_of_old[src];           // everything else in layout space
-  a.visited[src >> 5] = 1u << (src & 31);
-  if (a.mode == 1) a.frontier_bits[src >> 5] = 1u << (src & 31);
-  bfs_seed_queue(a, (u32)src);
+// Start of a traversal, one launch: clears labels (-1), bitmap(s) and marks, and seeds the source.  The thread that
+// clears the element holding the source's label / bit writes the seed value instead, so there is no ordering
+// between workgroups to worry about.
+__global__ __launch_bounds__(BLOCK) void k_bfs_fused_init(bfs_fused_args_t a, int src, long long nwords) {
+  const int src_old = src;
+  if (a.new_of_old) src = a.new_of_old[src];           // labels live in ORIGINAL id space, everything else in layout space
+  const long long tid = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  const long long nth = (long long)gridDim.x * BLOCK;
+  const long long n = a.n;
+  for (long long i = tid; i < (n + 3) / 4; i += nth) {              // 4 labels / 4 marks per step
+    if (i * 4 + 4 <= n) {
+      int4 l = make_int4(-1, -1, -1, -1);
+      if (src_old >> 2 == i) (&l.x)[src_old & 3] = 0;
+      *(int4*)(a.labels + i * 4) = l;
+      *(u32*)(a.mark + i * 4) = 0u;
+    } else {
+      for (long long j = i * 4; j < n; ++j) { a.labels[j] = (j == src_old) ? 0 : -1; a.mark[j] = 0; }
+    }
+  }
+  const u32 src_bit = 1u << (src & 31);
+  for (long long w = tid; w < nwords; w += nth) {
+    const u32 seed = (w == (src >> 5)) ? src_bit : 0u;
+    a.visited[w] = seed;
+    if (a.mode == 1) a.frontier_bits[w] = seed;
+  }
+  if (tid == 0) {
+    bfs_ctrl_reset(a.ctrl);
+    bfs_seed_queue(a, (u32)src);
+  }
 }
 
 // Runs before the traversal kernels of every level: per-level bookkeeping (termination flag, trace, TEPS
@@ -149,38 +170,69 @@ __global__ void k_bfs_level_begin(bfs_fused_args_t a, int level) {
 // the bit (and frontier_bits for direction-optimising runs).  Otherwise (partitioned runs): `bits` already holds
 // the discoveries of all ranks, and this rank owns the vertices `local * ranks + rank`; rows and labels are
 // addressed by the local index.  Every discovery gets label level+1; those with edges are appended to the
-// short- or long-row queue of level+1.  A workgroup sweeps a contiguous range and appends in batches of up to
-// BUILD_FLUSH discoveries: two cursor atomics per batch, a few hundred per level for the whole device.
+// short- or long-row queue of level+1.
+// A workgroup owns BUILD_VPB vertices, 16 per thread: one 16-byte load of marks and one 16-bit load / store of
+// the bitmap per thread (the half-word is the thread's own: plain stores), a workgroup scan of the counts,
+// compaction into an LDS list, then per batch of up to BUILD_LIST discoveries: row extents, labels, and ONE
+// 64-bit atomic per queue (slot and exclusive degree scan at once, see above).  The vertices of a workgroup are
+// four separate runs of 4096, a quarter of the id range apart: under the hub-first layout a level's discoveries
+// are concentrated in a prefix of the ids, and contiguous ownership would leave most workgroups idle.
 constexpr int BFS_BUILD_NT = 1024;
-constexpr int BFS_BUILD_FLUSH = 4096;
+constexpr int BFS_BUILD_VPB = 16 * BFS_BUILD_NT;      // vertices per workgroup
+constexpr int BFS_BUILD_LIST = 8 * BFS_BUILD_NT;      // discoveries appended per batch
+
+inline int bfs_build_grid(long long n_local) { return (int)((n_local + BFS_BUILD_VPB - 1) / BFS_BUILD_VPB); }
 
 template <int NT, bool FROM_MARKS>
 __global__ __launch_bounds__(NT) void k_bfs_build(bfs_fused_args_t a, int level, const u32* __restrict__ bits,
                                                   int* __restrict__ labels, int n_local, int ranks, int rank,
                                                   int stop_when_done) {
   constexpr int NW = NT / WAVE;
-  constexpr int STAGE = BFS_BUILD_FLUSH + NT;
-  constexpr int PER = STAGE / NT;
+  constexpr int LIST = 8 * NT;
+  constexpr int PER = LIST / NT;
   constexpr u64 CNT1 = 1ull << 40;
   constexpr u64 DEGMASK = CNT1 - 1ull;
-  static_assert(STAGE % NT == 0, "stage shape");
-  __shared__ u32 st_v[STAGE];
+  __shared__ u32 st_v[LIST];
   __shared__ u64 s_scan[NW + 1];
   __shared__ u64 s_base[2];
-  __shared__ int s_count, s_found;
   bfs_ctrl_t* const c = a.ctrl;
   if (stop_when_done && c->done) return;        // (a rank of a partitioned run may be handed work with an empty frontier)
-  long long per_v = ((long long)n_local + gridDim.x - 1) / gridDim.x;
-  per_v = (per_v + NT - 1) / NT * NT;
-  const long long i_begin = (long long)blockIdx.x * per_v;
-  if (i_begin >= n_local) return;
-  const long long i_end = (i_begin + per_v < n_local) ? i_begin + per_v : n_local;
-  if (threadIdx.x == 0) { s_count = 0; s_found = 0; }
-  __syncthreads();
-  const int lane = lane_id();
+  // first of this thread's 16 vertices: run (blockIdx + k * gridDim) of 4096 vertices, k = threadIdx / 256
+  static_assert(NT == 1024, "four runs of 256 threads");
+  const long long i0 = (((long long)blockIdx.x + (long long)(threadIdx.x >> 8) * gridDim.x) * 256 + (threadIdx.x & 255)) * 16;
   const int new_label = level + 1;
   const int* __restrict__ old_of_new = a.old_of_new;
   const u32 long_min = a.long_min > 0 ? (u32)a.long_min : 0xFFFFFFFFu;
+
+  // ---- which of my 16 vertices are new ----------------------------------------------------------------------
+  u32 new16 = 0;
+  if (i0 < n_local) {
+    const u32 valid = (n_local - i0 >= 16) ? 0xFFFFu : ((1u << (int)(n_local - i0)) - 1u);
+    if (FROM_MARKS) {
+      const uint4 m = *(const uint4*)(a.mark + i0);                          // mark[] is padded: always readable
+      const u32 x[4] = {m.x, m.y, m.z, m.w};
+      u32 m16 = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) m16 |= (((x[q] & 0x01010101u) * 0x10204080u) >> 28) << (4 * q);   // 4 marks -> 4 bits
+      unsigned short* const vis16 = (unsigned short*)a.visited + (i0 >> 4);
+      const u32 old16 = *vis16;
+      new16 = m16 & ~old16 & valid;
+      if (new16) *vis16 = (unsigned short)(old16 | new16);                   // this thread is the half-word's only writer
+      if (a.mode == 1) ((unsigned short*)a.frontier_bits)[i0 >> 4] = (unsigned short)new16;
+    } else {
+      for (int q = 0; q < 16; ++q) {
+        const long long v = (i0 + q) * ranks + rank;
+        if (((valid >> q) & 1u) && ((bits[v >> 5] >> (v & 31)) & 1u)) new16 |= 1u << q;
+      }
+    }
+  }
+  // ---- compaction: positions by a workgroup scan of the counts ------------------------------------------------
+  u64 total64;
+  const u64 before = block_exclusive_sum_nw<NW>((u64)__popc(new16), s_scan, &total64);
+  const int total = (int)total64;
+  if (total == 0) return;
+  if (threadIdx.x == 0) atomicAdd(&c->reached, (u64)total);
+
   u64* const cur_s = &c->cursor[(level + 1) % 3];
   u64* const cur_l = &c->lcursor[(level + 1) % 3];
   u32* __restrict__ const out_row_s = a.fr_row[(level + 1) & 1];
@@ -188,7 +240,20 @@ __global__ __launch_bounds__(NT) void k_bfs_build(bfs_fused_args_t a, int level,
   u32* __restrict__ const out_row_l = a.lq_row[(level + 1) & 1];
   u32* __restrict__ const out_off_l = a.lq_off[(level + 1) & 1];
 
-  auto flush = [&](int cnt) {
+  for (int first = 0; first < total; first += LIST) {
+    // my discoveries whose list position falls into [first, first + LIST)
+    {
+      u32 rest = new16;
+      int at = (int)before - first;
+      while (rest) {
+        const int q = __ffs((int)rest) - 1;
+        rest &= rest - 1;
+        if (at >= 0 && at < LIST) st_v[at] = (u32)(i0 + q);
+        ++at;
+      }
+    }
+    __syncthreads();
+    const int cnt = (total - first < LIST) ? total - first : LIST;
     u32 li[PER], ro[PER], ro1[PER];
     int lab_at[PER];
 #pragma unroll
@@ -219,7 +284,6 @@ __global__ __launch_bounds__(NT) void k_bfs_build(bfs_fused_args_t a, int level,
     if (threadIdx.x == 0) {
       s_base[0] = (tot_s >> 40) ? atomicAdd(cur_s, ((tot_s >> 40) << BFS_VSHIFT) | (tot_s & DEGMASK)) : 0ull;
       s_base[1] = (tot_l >> 40) ? atomicAdd(cur_l, ((tot_l >> 40) << BFS_VSHIFT) | (tot_l & DEGMASK)) : 0ull;
-      s_found += cnt;
     }
     __syncthreads();
 #pragma unroll
@@ -234,47 +298,8 @@ __global__ __launch_bounds__(NT) void k_bfs_build(bfs_fused_args_t a, int level,
         (is_long ? out_off_l : out_off_s)[slot] = (u32)((base & BFS_EMASK) + (at & DEGMASK));
       }
     }
-    if (threadIdx.x == 0) s_count = 0;
-    __syncthreads();
-  };
-
-  const bool want_frontier = FROM_MARKS && a.mode == 1;
-  for (long long base = i_begin; base < i_end; base += NT) {          // i_begin is a multiple of NT (and of 64)
-    const long long i = base + threadIdx.x;
-    bool found = false;
-    u32 word = 0;
-    if (i < i_end) {
-      if (FROM_MARKS) {
-        word = a.visited[i >> 5];
-        found = a.mark[i] != 0 && !((word >> (i & 31)) & 1u);
-      } else {
-        const long long v = i * ranks + rank;
-        found = (bits[v >> 5] >> (v & 31)) & 1u;
-      }
-    }
-    const u64 bal = __ballot(found);
-    if (FROM_MARKS && i < i_end && (lane & 31) == 0) {
-      // this wave is the only writer of the two words of its 64 vertices
-      const u32 nb = (u32)(bal >> lane);
-      if (nb) a.visited[i >> 5] = word | nb;
-      if (want_frontier) a.frontier_bits[i >> 5] = nb;
-    }
-    const int nfound = __popcll(bal);
-    if (nfound) {
-      int at = 0;
-      if (lane == 0) at = atomicAdd(&s_count, nfound);
-      at = __builtin_amdgcn_readfirstlane(at);
-      if (found) st_v[at + rank_in_mask(bal)] = (u32)i;
-    }
-    __syncthreads();
-    const int cnt = s_count;
-    if (cnt >= BFS_BUILD_FLUSH) flush(cnt);
+    __syncthreads();       // st_v and s_base are reused by the next batch
   }
-  {
-    const int cnt = s_count;
-    if (cnt > 0) flush(cnt);
-  }
-  if (threadIdx.x == 0 && s_found) atomicAdd(&c->reached, (u64)s_found);
 }
 
 // per-BFS device state of the fused engine
@@ -291,6 +316,8 @@ struct bfs_fused_state_t {
   int n = 0;
   int levels_per_sync = 8;
   int long_min = 64;                 // rows at least this long go to the long-row queue (0: no such queue)
+  bool time_kernels = false;         // record HIP events around the two push kernels of every level (each event
+                                     // leaves a ~6 us gap on the stream: profiling runs only)
   unsigned hot_min_edges = 65536;    // smaller levels probe the bitmap in L2 instead of copying its hot prefix to LDS
   // timing of the level kernels of the last run (HIP events around each batch of launches)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -328,6 +355,7 @@ struct bfs_fused_state_t {
     MGX_HIP(hipEventCreate(&ev1));
     for (int i = 0; i < EV_POOL; ++i) MGX_HIP(hipEventCreate(&wev[i]));
     if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = getenv("MGX_BFS_TIME_KERNELS")) time_kernels = atoi(e) != 0;
     if (const char* e = getenv("MGX_BFS_HOT_MIN_EDGES")) hot_min_edges = (unsigned)atoll(e);
     if (const char* e = getenv("MGX_BFS_LEVELS_PER_SYNC")) levels_per_sync = atoi(e) > 0 ? atoi(e) : 8;
   }

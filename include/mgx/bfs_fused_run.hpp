@@ -29,6 +29,8 @@ inline void bfs_set_kernel_attributes() {
 #define MGX_SET_LDS(K_) MGX_HIP(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
   MGX_SET_LDS((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, false>));
   MGX_SET_LDS((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, true>));
+  MGX_SET_LDS((k_bfs_push_level_wave<1024, 18000, false>));
+  MGX_SET_LDS((k_bfs_push_level_wave<256, 8192, false>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 16, false>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, false>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, true>));
@@ -59,8 +61,15 @@ inline void bfs_launch_stream(const bfs_fused_args_t& a, int level, standard_con
 inline void bfs_launch_wave(const bfs_fused_args_t& a, int level, standard_context_t& ctx) {
   hipStream_t s = ctx.stream();
   const size_t lds = bfs_wave_lds_bytes(512, BFS_WAVE_HOTW);
+  static const int shape = getenv("MGX_BFS_WAVE_SHAPE") ? atoi(getenv("MGX_BFS_WAVE_SHAPE")) : 1;
   if (bfs_cold_test(a.n))
     hipLaunchKernelGGL((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, true>), dim3(ctx.num_cus * 2), dim3(512), lds, s, a, level);
+  else if (shape == 1)      // default: 32 waves per CU (the kernel needs ~45 VGPRs): 2 x 1024 threads
+    hipLaunchKernelGGL((k_bfs_push_level_wave<1024, 18000, false>), dim3(ctx.num_cus * 2), dim3(1024),
+                       bfs_wave_lds_bytes(1024, 18000), s, a, level);
+  else if (shape == 2)      // 32 waves per CU: 8 x 256 threads, 32 KB of bitmap each
+    hipLaunchKernelGGL((k_bfs_push_level_wave<256, 8192, false>), dim3(ctx.num_cus * 8), dim3(256),
+                       bfs_wave_lds_bytes(256, 8192), s, a, level);
   else
     hipLaunchKernelGGL((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, false>), dim3(ctx.num_cus * 2), dim3(512), lds, s, a, level);
 }
@@ -100,11 +109,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.flags = 0;
   if (const char* e = getenv("MGX_BFS_FLAGS")) a.flags = atoi(e);
   const long long nwords = ((long long)st.n + 31) / 32;
-  MGX_HIP(hipMemsetAsync(labels, 0xFF, (size_t)st.n * sizeof(int), s));
-  MGX_HIP(hipMemsetAsync(st.visited.data(), 0, (size_t)(nwords + 1) * sizeof(u32), s));
-  MGX_HIP(hipMemsetAsync(st.mark.data(), 0, (size_t)st.n, s));
-  if (mode == 1) MGX_HIP(hipMemsetAsync(st.frontier_bits.data(), 0, (size_t)(nwords + 1) * sizeof(u32), s));
-  hipLaunchKernelGGL(k_bfs_fused_init, dim3(1), dim3(64), 0, s, a, src);
+  hipLaunchKernelGGL(k_bfs_fused_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src, nwords);
   int level = 0;
   st.level_kernel_ms = 0.0;
   st.level_kernel_launches = 0;
@@ -117,7 +122,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
     MGX_HIP(hipEventRecord(st.ev0, s));
     for (int i = 0; i < st.levels_per_sync; ++i, ++level) {
       hipLaunchKernelGGL(k_bfs_level_begin, dim3(1), dim3(64), 0, s, a, level);
-      const bool timed = 3 * i + 2 < bfs_fused_state_t::EV_POOL;
+      const bool timed = st.time_kernels && 3 * i + 2 < bfs_fused_state_t::EV_POOL;
       if (timed) MGX_HIP(hipEventRecord(st.wev[3 * i], s));
       bfs_launch_stream(a, level, ctx);
       if (timed) MGX_HIP(hipEventRecord(st.wev[3 * i + 1], s));
@@ -125,16 +130,17 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
       if (timed) MGX_HIP(hipEventRecord(st.wev[3 * i + 2], s));
       if (mode == 1)
         hipLaunchKernelGGL(k_bfs_pull_level<256>, dim3(ctx.num_cus * 8), dim3(256), 0, s, a, level);
-      hipLaunchKernelGGL((k_bfs_build<BFS_BUILD_NT, true>), dim3(ctx.num_cus), dim3(BFS_BUILD_NT), 0, s, a, level,
+      hipLaunchKernelGGL((k_bfs_build<BFS_BUILD_NT, true>), dim3(bfs_build_grid(st.n)), dim3(BFS_BUILD_NT), 0, s, a, level,
                          (const u32*)nullptr, labels, st.n, 1, 0, 1);
     }
     MGX_HIP(hipEventRecord(st.ev1, s));
-    MGX_HIP(hipMemcpyAsync(&st.host_ctrl->done, &st.ctrl.data()->done, sizeof(int), hipMemcpyDeviceToHost, s));
+    // one read-back per batch: the counters and the first 64 trace slots (the flag alone would cost the same trip)
+    MGX_HIP(hipMemcpyAsync(st.host_ctrl, st.ctrl.data(), offsetof(bfs_ctrl_t, trace) + 64 * sizeof(u64), hipMemcpyDeviceToHost, s));
     MGX_HIP(hipStreamSynchronize(s));
     float ms = 0.f;
     MGX_HIP(hipEventElapsedTime(&ms, st.ev0, st.ev1));
     st.level_kernel_ms += ms;
-    for (int i = 0; i < st.levels_per_sync && 3 * i + 2 < bfs_fused_state_t::EV_POOL; ++i) {
+    for (int i = 0; st.time_kernels && i < st.levels_per_sync && 3 * i + 2 < bfs_fused_state_t::EV_POOL; ++i) {
       const int lv = level - st.levels_per_sync + i;
       float wms = 0.f;
       MGX_HIP(hipEventElapsedTime(&wms, st.wev[3 * i + 1], st.wev[3 * i + 2]));
@@ -152,12 +158,9 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
     st.level_kernel_launches += st.levels_per_sync;
     if (st.host_ctrl->done) break;
   }
-  // counters first, then only the part of the per-level trace that was written
-  MGX_HIP(hipMemcpyAsync(st.host_ctrl, st.ctrl.data(), offsetof(bfs_ctrl_t, trace), hipMemcpyDeviceToHost, s));
-  MGX_HIP(hipStreamSynchronize(s));
   const int lv = st.host_ctrl->levels < BFS_MAX_TRACE ? st.host_ctrl->levels : BFS_MAX_TRACE;
-  if (lv > 0) {
-    MGX_HIP(hipMemcpyAsync(st.host_ctrl->trace, st.ctrl.data()->trace, (size_t)lv * sizeof(u64), hipMemcpyDeviceToHost, s));
+  if (lv > 64) {                // the rest of the per-level trace (deep traversals only)
+    MGX_HIP(hipMemcpyAsync(st.host_ctrl->trace + 64, st.ctrl.data()->trace + 64, (size_t)(lv - 64) * sizeof(u64), hipMemcpyDeviceToHost, s));
     MGX_HIP(hipStreamSynchronize(s));
   }
 }

@@ -97,6 +97,7 @@ SIGNATURES = {
     "mgx_bfs_enact_pushpull": [_vp, _f, _pi64],
     "mgx_bfs_run": [_vp, _i, _i, _f, _pi64],
     "mgx_bfs_level_trace": [_vp, _i, _pi64, _pi64, _pi],
+    "mgx_bfs_set_kernel_timing": [_vp, _i],
     "mgx_bfs_kernel_times": [_vp, _pi64],
     "mgx_bfs_level_kernel_times": [_vp, _i, _pf, _pf],
     "mgx_bfs_level_claims": [_vp, _i, _pi64],

@@ -260,6 +260,10 @@ class BfsProblem:
         L = min(lv.value, cap)
         return [(nf[i], ne[i]) for i in range(L)]
 
+    def set_kernel_timing(self, on=True):
+        """events around every push-kernel launch (costs ~6 us of stream gap per event: profiling runs only)"""
+        check(lib.mgx_bfs_set_kernel_timing(self._h, int(bool(on))))
+
     def kernel_times(self):
         """per-launch timing of the two push kernels of the last run()"""
         c = (C.c_int64 * 8)()

@@ -40,6 +40,7 @@ struct mgx_bfs_s {
   std::unique_ptr<bfs::bfs_enactor_t> e;              // lazily: holds two m-capacity buffers
   std::unique_ptr<bfs::bfs_fused_enactor_t> fe;       // lazily: O(n)
   int64_t last_stats[16] = {0};
+  int time_kernels = -1;                              // -1: environment default
 };
 struct mgx_sssp_s {
   mgx_graph_s* g;
@@ -603,6 +604,7 @@ int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats) {
   use_device(p->g->c);
   standard_context_t& ctx = *p->g->c->ctx;
   if (!p->fe) p->fe.reset(new bfs::bfs_fused_enactor_t(ctx, p->g->g->num_nodes));
+  if (p->time_kernels >= 0) p->fe->fused->time_kernels = p->time_kernels != 0;
   p->p->src = src;
   p->fe->enact(p->p, ctx, mode == MGX_BFS_DIRECTION_OPT, alpha);
   const bfs::bfs_run_stats_t& L = p->fe->last;
@@ -636,6 +638,12 @@ int mgx_bfs_level_trace(mgx_bfs_t p, int cap, int64_t* level_nf, int64_t* level_
     if (level_nf) level_nf[i] = tr[i].first;
     if (level_edges) level_edges[i] = tr[i].second;
   }
+  MGX_CATCH
+}
+int mgx_bfs_set_kernel_timing(mgx_bfs_t p, int on) {
+  MGX_TRY
+  MGX_REQUIRE(p, "NULL argument");
+  p->time_kernels = on ? 1 : 0;
   MGX_CATCH
 }
 int mgx_bfs_kernel_times(mgx_bfs_t p, int64_t* out8) {

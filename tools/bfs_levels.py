@@ -17,6 +17,7 @@ if a.layout:
 ro = g["row_offsets"].cpu().numpy()
 srcs = rmat.pick_sources(ro, a.runs + 1, a.scale)
 bfs = mini_amd.BfsProblem(graph, srcs[0])
+bfs.set_kernel_timing(True)
 bfs.run(srcs[0], a.mode, a.alpha)
 for s in srcs[1:]:
     st = bfs.run(s, a.mode, a.alpha)

@@ -1,0 +1,7 @@
+#!/bin/bash
+mkdir -p gpurun_out
+cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests -q -m gpu --timeout 600 -x > gpurun_out/pytest_gpu.log 2>&1
+echo "pytest rc=$?"; tail -5 gpurun_out/pytest_gpu.log
+timeout 600 python bench.py --steps 16 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-1200
+bash tools/gpu_trace.sh 2>&1 | grep -E "mgx|MTEPS|fillBuffer"
