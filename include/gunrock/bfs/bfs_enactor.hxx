@@ -119,6 +119,8 @@ struct bfs_run_stats_t {
   int dominant = 0;
   std::vector<std::pair<long long, long long>> trace;   // (frontier vertices, frontier edges) per level
   std::vector<float> batch_ms;
+  std::vector<float> level_ms;       // device-side stamps (100 MHz) taken when each level is opened
+  int small_levels = 0;              // levels the single-workgroup kernel ran
   long long claims_level[64] = {0};
 };
 
@@ -161,6 +163,8 @@ struct bfs_fused_enactor_t {
     for (int i = 0; i < hc->levels && i < mgx::BFS_MAX_TRACE; ++i)
       last.trace.emplace_back((long long)(hc->trace[i] >> mgx::BFS_VSHIFT), (long long)(hc->trace[i] & mgx::BFS_EMASK));
     for (int i = 0; i < fused->batches; ++i) last.batch_ms.push_back(fused->batch_ms[i]);
+    for (int i = 0; i < hc->levels && i < 63; ++i) last.level_ms.push_back((float)((double)(hc->stamp[i + 1] - hc->stamp[i]) / 1e5));
+    last.small_levels = hc->small_levels;
     for (int i = 0; i < last.push_levels && i < (int)last.trace.size(); ++i) last.push_edges += last.trace[i].second;
     // the long-row queue only exists on push levels; the short-row queue gets the rest of the push edges
     last.stream.launches = fused->stream_kernel_launches;

@@ -156,7 +156,8 @@ MGX_API int mgx_bfs_enact_pushpull(mgx_bfs_t p, float threshold, int64_t* stats)
  *   Dominant push kernel = the one of the two (mgx_bfs_kernel_times) with more device time in this run:
  *   [10] its launches (incl. the ones that find nothing to do) [11] their device time in ns (HIP events
  *   around every launch) [12] edges and [13] frontier vertices it processed
- *   [14] which one (1 = k_bfs_push_level_stream, 0 = k_bfs_push_level_wave) [15] reserved.
+ *   [14] which one (1 = k_bfs_push_level_stream, 0 = k_bfs_push_level_wave)
+ *   [15] levels run by the single-workgroup kernel (k_bfs_small_levels).
  *   stats must hold 16 entries.                                                                 */
 #define MGX_BFS_PUSH 0
 #define MGX_BFS_DIRECTION_OPT 1
@@ -175,7 +176,11 @@ MGX_API int mgx_bfs_set_kernel_timing(mgx_bfs_t p, int on);
  * (k_bfs_push_level_stream: rows of >= MGX_BFS_LONG_MIN edges, read row-wise;
  *  k_bfs_push_level_wave: the shorter rows, load-balanced search per edge rank)                 */
 MGX_API int mgx_bfs_kernel_times(mgx_bfs_t p, int64_t* out8);
-/* the same per level (ms), first min(cap, 64) levels of the last run */
+/* duration of each level of the last run (ms), from device-side timestamps taken when a level is opened: no host
+ * synchronisation involved; first min(cap, 63) levels */
+MGX_API int mgx_bfs_level_times(mgx_bfs_t p, int cap, float* ms, int* levels);
+/* the same per launch slot (ms), first min(cap, 64) slots of the last run; a slot = the small-level kernel plus one
+ * round of the device-wide kernels (include/mgx/bfs_fused_run.hpp) */
 MGX_API int mgx_bfs_level_kernel_times(mgx_bfs_t p, int cap, float* stream_ms, float* wave_ms);
 /* atomicOr claims issued per level of the last run (first 64 levels) */
 MGX_API int mgx_bfs_level_claims(mgx_bfs_t p, int cap, int64_t* claims);

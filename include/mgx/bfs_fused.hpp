@@ -58,6 +58,11 @@ struct bfs_ctrl_t {
   int levels;        // number of levels that expanded at least one edge
   int pull;          // direction of the level about to run (set by k_bfs_level_begin; sticky once 1)
   int push_levels;   // levels run top-down
+  int level;         // device-resident level counter (launches with level < 0 read it; see k_bfs_small_levels)
+  int big;           // level `level` has been opened for the device-wide kernels of this slot
+  int small_levels;  // levels the single-workgroup kernel ran
+  int slots;         // launch slots that found work (k_bfs_small_levels counts them)
+  u64 stamp[64];     // s_memrealtime (100 MHz) when each level was opened: per-level times without host syncs
   u64 trace[BFS_MAX_TRACE];   // (vertices << 38 | edges) of each level, both queues (kept LAST: read back up to `levels`)
 };
 
@@ -94,6 +99,8 @@ __device__ __forceinline__ void bfs_ctrl_reset(bfs_ctrl_t* c) {
   for (int i = 0; i < 64; ++i) c->claims_level[i] = 0;
   c->pull_edges = 0;
   c->done = c->levels = c->pull = c->push_levels = 0;
+  c->level = c->big = c->small_levels = c->slots = 0;
+  for (int i = 0; i < 64; ++i) c->stamp[i] = 0;
 }
 
 // level-0 queue entry of the source (its row is `row`, e.g. a local row of a partition)
@@ -138,10 +145,9 @@ __global__ __launch_bounds__(BLOCK) void k_bfs_fused_init(bfs_fused_args_t a, in
   }
 }
 
-// Runs before the traversal kernels of every level: per-level bookkeeping (termination flag, trace, TEPS
-// numerator) and the direction decision.  One thread.
-__global__ void k_bfs_level_begin(bfs_fused_args_t a, int level) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// Opening a level (one thread): termination flag, trace, TEPS numerator, direction decision.  Returns false when
+// the frontier is empty (the traversal is over).
+__device__ __forceinline__ bool bfs_open_level(const bfs_fused_args_t& a, int level) {
   bfs_ctrl_t* const c = a.ctrl;
   const u64 cur = c->cursor[level % 3];
   const u64 lcur = c->lcursor[level % 3];
@@ -149,9 +155,10 @@ __global__ void k_bfs_level_begin(bfs_fused_args_t a, int level) {
   const u64 E = (cur & BFS_EMASK) + (lcur & BFS_EMASK);
   c->cursor[(level + 2) % 3] = 0;
   c->lcursor[(level + 2) % 3] = 0;
+  if (level < 64) c->stamp[level] = __builtin_amdgcn_s_memrealtime();
   if (nf == 0) {
     if (!c->done) { c->done = 1; c->levels = level; }
-    return;
+    return false;
   }
   if (level < BFS_MAX_TRACE) c->trace[level] = ((u64)nf << BFS_VSHIFT) | E;
   c->sum_edges += E;
@@ -163,6 +170,21 @@ __global__ void k_bfs_level_begin(bfs_fused_args_t a, int level) {
     if (unvisited < (float)nf * a.alpha) c->pull = 1;      // bfs_enactor.hxx:68; never switches back (:74-112)
   }
   if (!c->pull) c->push_levels += 1;
+  return true;
+}
+
+// Explicit-level variant of the above as a kernel of its own (partitioned runs: the host counts the levels).
+__global__ void k_bfs_level_begin(bfs_fused_args_t a, int level) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  (void)bfs_open_level(a, level);
+}
+
+// Device-wide kernels are launched either with an explicit level (>= 0) or with level < 0: then the level is
+// ctrl->level and the kernel runs only if k_bfs_small_levels has opened it for this slot (ctrl->big).
+__device__ __forceinline__ bool bfs_resolve_level(const bfs_ctrl_t* c, int& level) {
+  if (level >= 0) return true;
+  level = c->level;
+  return c->big != 0;
 }
 
 // ---- a level's discoveries -> bitmap, labels, next level's queues ----------------------------------------------
@@ -196,6 +218,7 @@ __global__ __launch_bounds__(NT) void k_bfs_build(bfs_fused_args_t a, int level,
   __shared__ u64 s_scan[NW + 1];
   __shared__ u64 s_base[2];
   bfs_ctrl_t* const c = a.ctrl;
+  if (!bfs_resolve_level(c, level)) return;
   if (stop_when_done && c->done) return;        // (a rank of a partitioned run may be handed work with an empty frontier)
   // first of this thread's 16 vertices: run (blockIdx + k * gridDim) of 4096 vertices, k = threadIdx / 256
   static_assert(NT == 1024, "four runs of 256 threads");
@@ -314,7 +337,11 @@ struct bfs_fused_state_t {
   mem_t<bfs_ctrl_t> ctrl;
   bfs_ctrl_t* host_ctrl = nullptr;   // pinned copy for stats
   int n = 0;
-  int levels_per_sync = 8;
+  int levels_per_sync = 2;           // slots (see bfs_fused_run.hpp) launched between two read-backs of the control block ...
+  int slots_hint = 6;                // ... except for the first batch: as many slots as the previous traversal needed
+  unsigned small_max_edges = 256;    // levels up to this size run inside the single-workgroup kernel (0: never);
+                                     // measured on RMAT-22: beyond a few hundred edges one workgroup's dependent
+                                     // round trips cost more than the four launches of a device-wide level
   int long_min = 64;                 // rows at least this long go to the long-row queue (0: no such queue)
   bool time_kernels = false;         // record HIP events around the two push kernels of every level (each event
                                      // leaves a ~6 us gap on the stream: profiling runs only)
@@ -332,7 +359,7 @@ struct bfs_fused_state_t {
   long long wave_kernel_launches = 0;
   double stream_kernel_ms = 0.0;     // k_bfs_push_level_stream: row-wise streaming of the long-row queue
   long long stream_kernel_launches = 0;
-  float level_stream_ms[64] = {};    // the same per level (first 64 levels)
+  float level_stream_ms[64] = {};    // the same per slot (first 64 slots)
   float level_wave_ms[64] = {};
 
   bfs_fused_state_t(int num_nodes, standard_context_t& ctx) : n(num_nodes) {
@@ -357,7 +384,8 @@ struct bfs_fused_state_t {
     if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("MGX_BFS_TIME_KERNELS")) time_kernels = atoi(e) != 0;
     if (const char* e = getenv("MGX_BFS_HOT_MIN_EDGES")) hot_min_edges = (unsigned)atoll(e);
-    if (const char* e = getenv("MGX_BFS_LEVELS_PER_SYNC")) levels_per_sync = atoi(e) > 0 ? atoi(e) : 8;
+    if (const char* e = getenv("MGX_BFS_LEVELS_PER_SYNC")) levels_per_sync = atoi(e) > 0 ? atoi(e) : 2;
+    if (const char* e = getenv("MGX_BFS_SMALL_MAX_EDGES")) small_max_edges = (unsigned)atoll(e);
   }
   bfs_fused_state_t(const bfs_fused_state_t&) = delete;
   bfs_fused_state_t& operator=(const bfs_fused_state_t&) = delete;

@@ -12,6 +12,7 @@ template <int NT>
 __global__ __launch_bounds__(NT) void k_bfs_pull_level(bfs_fused_args_t a, int level) {
   __shared__ unsigned long long s_insp;
   bfs_ctrl_t* const c = a.ctrl;
+  if (!bfs_resolve_level(c, level)) return;
   if (c->done || !c->pull) return;                 // k_bfs_level_begin: termination and direction
   const int n = a.n;
   long long per_v = ((long long)n + gridDim.x - 1) / gridDim.x;

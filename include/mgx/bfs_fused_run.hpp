@@ -1,10 +1,14 @@
 // mgx/bfs_fused_run.hpp -- host driver of the fused BFS: per level
-//   k_bfs_level_begin (one thread) -> k_bfs_push_level_stream (long rows) -> k_bfs_push_level_wave (short rows)
+// slots of
+//   k_bfs_small_levels (one workgroup: runs the small levels itself, opens the next big one)
+//   -> k_bfs_push_level_stream (long rows) -> k_bfs_push_level_wave (short rows)
 //   [-> k_bfs_pull_level in direction-optimising runs] -> k_bfs_build
-// launched back to back; the host reads one flag every `levels_per_sync` levels.
+// launched back to back with level = -1 (the level counter lives on the device); the host reads the control
+// block back once every `levels_per_sync` slots.
 #pragma once
 #include "bfs_fused.hpp"
 #include "bfs_fused_pull.hpp"
+#include "bfs_fused_small.hpp"
 #include "bfs_fused_stream.hpp"
 #include "bfs_fused_wave.hpp"
 
@@ -27,6 +31,7 @@ inline void bfs_set_kernel_attributes() {
   static bool attr_set = false;
   if (attr_set) return;
 #define MGX_SET_LDS(K_) MGX_HIP(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+  MGX_SET_LDS((k_bfs_small_levels<BFS_SMALL_NT>));
   MGX_SET_LDS((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, false>));
   MGX_SET_LDS((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, true>));
   MGX_SET_LDS((k_bfs_push_level_wave<1024, 18000, false>));
@@ -110,7 +115,6 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   if (const char* e = getenv("MGX_BFS_FLAGS")) a.flags = atoi(e);
   const long long nwords = ((long long)st.n + 31) / 32;
   hipLaunchKernelGGL(k_bfs_fused_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src, nwords);
-  int level = 0;
   st.level_kernel_ms = 0.0;
   st.level_kernel_launches = 0;
   st.wave_kernel_ms = 0.0;
@@ -118,19 +122,24 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   st.stream_kernel_ms = 0.0;
   st.stream_kernel_launches = 0;
   st.batches = 0;
-  for (;;) {
+  int slot = 0;
+  for (int batch = 0;; ++batch) {
+    // first batch: what the previous traversal of this graph needed (sources differ, level structure hardly)
+    int nslots = batch == 0 ? st.slots_hint : st.levels_per_sync;
+    if (nslots > bfs_fused_state_t::EV_POOL / 3) nslots = bfs_fused_state_t::EV_POOL / 3;
     MGX_HIP(hipEventRecord(st.ev0, s));
-    for (int i = 0; i < st.levels_per_sync; ++i, ++level) {
-      hipLaunchKernelGGL(k_bfs_level_begin, dim3(1), dim3(64), 0, s, a, level);
+    for (int i = 0; i < nslots; ++i, ++slot) {
+      hipLaunchKernelGGL(k_bfs_small_levels<BFS_SMALL_NT>, dim3(1), dim3(BFS_SMALL_NT), bfs_small_lds_bytes(), s, a,
+                         st.small_max_edges);
       const bool timed = st.time_kernels && 3 * i + 2 < bfs_fused_state_t::EV_POOL;
       if (timed) MGX_HIP(hipEventRecord(st.wev[3 * i], s));
-      bfs_launch_stream(a, level, ctx);
+      bfs_launch_stream(a, -1, ctx);
       if (timed) MGX_HIP(hipEventRecord(st.wev[3 * i + 1], s));
-      bfs_launch_wave(a, level, ctx);
+      bfs_launch_wave(a, -1, ctx);
       if (timed) MGX_HIP(hipEventRecord(st.wev[3 * i + 2], s));
       if (mode == 1)
-        hipLaunchKernelGGL(k_bfs_pull_level<256>, dim3(ctx.num_cus * 8), dim3(256), 0, s, a, level);
-      hipLaunchKernelGGL((k_bfs_build<BFS_BUILD_NT, true>), dim3(bfs_build_grid(st.n)), dim3(BFS_BUILD_NT), 0, s, a, level,
+        hipLaunchKernelGGL(k_bfs_pull_level<256>, dim3(ctx.num_cus * 8), dim3(256), 0, s, a, -1);
+      hipLaunchKernelGGL((k_bfs_build<BFS_BUILD_NT, true>), dim3(bfs_build_grid(st.n)), dim3(BFS_BUILD_NT), 0, s, a, -1,
                          (const u32*)nullptr, labels, st.n, 1, 0, 1);
     }
     MGX_HIP(hipEventRecord(st.ev1, s));
@@ -140,24 +149,25 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
     float ms = 0.f;
     MGX_HIP(hipEventElapsedTime(&ms, st.ev0, st.ev1));
     st.level_kernel_ms += ms;
-    for (int i = 0; st.time_kernels && i < st.levels_per_sync && 3 * i + 2 < bfs_fused_state_t::EV_POOL; ++i) {
-      const int lv = level - st.levels_per_sync + i;
+    for (int i = 0; st.time_kernels && i < nslots && 3 * i + 2 < bfs_fused_state_t::EV_POOL; ++i) {
+      const int sl = slot - nslots + i;
       float wms = 0.f;
       MGX_HIP(hipEventElapsedTime(&wms, st.wev[3 * i + 1], st.wev[3 * i + 2]));
       st.wave_kernel_ms += wms;
       st.wave_kernel_launches += 1;
-      if (lv < 64) st.level_wave_ms[lv] = wms;
+      if (sl < 64) st.level_wave_ms[sl] = wms;
       if (a.long_min > 0) {
         MGX_HIP(hipEventElapsedTime(&wms, st.wev[3 * i], st.wev[3 * i + 1]));
         st.stream_kernel_ms += wms;
         st.stream_kernel_launches += 1;
-        if (lv < 64) st.level_stream_ms[lv] = wms;
+        if (sl < 64) st.level_stream_ms[sl] = wms;
       }
     }
     if (st.batches < 256) st.batch_ms[st.batches++] = ms;
-    st.level_kernel_launches += st.levels_per_sync;
+    st.level_kernel_launches += nslots;
     if (st.host_ctrl->done) break;
   }
+  st.slots_hint = st.host_ctrl->slots > 0 ? st.host_ctrl->slots : 1;
   const int lv = st.host_ctrl->levels < BFS_MAX_TRACE ? st.host_ctrl->levels : BFS_MAX_TRACE;
   if (lv > 64) {                // the rest of the per-level trace (deep traversals only)
     MGX_HIP(hipMemcpyAsync(st.host_ctrl->trace + 64, st.ctrl.data()->trace + 64, (size_t)(lv - 64) * sizeof(u64), hipMemcpyDeviceToHost, s));

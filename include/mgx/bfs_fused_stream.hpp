@@ -42,6 +42,7 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_stream(bfs_fused_args_t a
   const int lane = lane_id();
 
   bfs_ctrl_t* const c = a.ctrl;
+  if (!bfs_resolve_level(c, level)) return;
   const u64 cur = c->lcursor[level % 3];
   const u32 nf = (u32)(cur >> BFS_VSHIFT);
   const u32 E = (u32)(cur & BFS_EMASK);

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_wave(bfs_fused_args_t a, 
   int* const s_int = (int*)(hot + HOTW + NW * (BFS_WAVE_LDS_PER_WAVE / 4));   // [0] marks stored
 
   bfs_ctrl_t* const c = a.ctrl;
+  if (!bfs_resolve_level(c, level)) return;
   const u64 cur = c->cursor[level % 3];
   const long long nf = (long long)(cur >> BFS_VSHIFT);
   const u32 E = (u32)(cur & BFS_EMASK);

@@ -100,6 +100,7 @@ SIGNATURES = {
     "mgx_bfs_set_kernel_timing": [_vp, _i],
     "mgx_bfs_kernel_times": [_vp, _pi64],
     "mgx_bfs_level_kernel_times": [_vp, _i, _pf, _pf],
+    "mgx_bfs_level_times": [_vp, _i, _pf, _pi],
     "mgx_bfs_level_claims": [_vp, _i, _pi64],
     "mgx_bfs_batch_times": [_vp, _i, _pf, _pi],
     "mgx_dbfs_create": [_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _i64, _pvp],

@@ -252,7 +252,8 @@ class BfsProblem:
                 "push_levels": st[5], "kernel_launches": st[6], "kernel_ns": st[7], "frontier_vertices": st[8],
                 "claims": st[9], "dom_launches": st[10], "dom_ns": st[11], "dom_edges": st[12],
                 "dom_vertices": st[13],
-                "dom_kernel": "k_bfs_push_level_stream" if st[14] else "k_bfs_push_level_wave"}
+                "dom_kernel": "k_bfs_push_level_stream" if st[14] else "k_bfs_push_level_wave",
+                "small_levels": st[15]}
 
     def level_trace(self, cap=4096):
         nf, ne, lv = (C.c_int64 * cap)(), (C.c_int64 * cap)(), C.c_int()
@@ -270,6 +271,12 @@ class BfsProblem:
         check(lib.mgx_bfs_kernel_times(self._h, c))
         keys = ("launches", "ns", "edges", "vertices")
         return {"stream": dict(zip(keys, c[0:4])), "wave": dict(zip(keys, c[4:8]))}
+
+    def level_times_ms(self, cap=63):
+        """per-level duration from device-side timestamps (no host synchronisation per level)"""
+        ms, lv = (C.c_float * cap)(), C.c_int()
+        check(lib.mgx_bfs_level_times(self._h, cap, ms, C.byref(lv)))
+        return [ms[i] for i in range(min(lv.value, cap))]
 
     def level_kernel_times_ms(self, cap=64):
         a, b = (C.c_float * cap)(), (C.c_float * cap)()

@@ -624,7 +624,7 @@ int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats) {
   p->last_stats[12] = D.edges;
   p->last_stats[13] = D.vertices;
   p->last_stats[14] = L.dominant;
-  p->last_stats[15] = 0;
+  p->last_stats[15] = L.small_levels;
   if (stats) memcpy(stats, p->last_stats, sizeof(p->last_stats));
   MGX_CATCH
 }
@@ -663,6 +663,16 @@ int mgx_bfs_level_kernel_times(mgx_bfs_t p, int cap, float* stream_ms, float* wa
     stream_ms[i] = p->fe->fused->level_stream_ms[i];
     wave_ms[i] = p->fe->fused->level_wave_ms[i];
   }
+  MGX_CATCH
+}
+int mgx_bfs_level_times(mgx_bfs_t p, int cap, float* ms, int* levels) {
+  MGX_TRY
+  MGX_REQUIRE(p && levels, "NULL argument");
+  MGX_REQUIRE(p->fe != nullptr, "mgx_bfs_level_times: no mgx_bfs_run yet");
+  const auto& t = p->fe->last.level_ms;
+  *levels = (int)t.size();
+  for (int i = 0; i < (int)t.size() && i < cap; ++i)
+    if (ms) ms[i] = t[i];
   MGX_CATCH
 }
 int mgx_bfs_level_claims(mgx_bfs_t p, int cap, int64_t* claims) {

@@ -268,19 +268,22 @@ def test_bfs_rmat_parity_all_paths(gpu_ctx, oracle, rmat_graphs, scale):
             assert np.array_equal(bfs.labels(), want), "pushpull alpha=%s src=%d" % (alpha, src)
 
 
-@pytest.mark.parametrize("scale,hot_min_edges,long_min", [(10, 0, 64), (13, 0, 8), (13, 0, 0), (16, 0, 64), (16, 65536, 64),
-                                                          (16, 0, 1), (16, 1 << 30, 16)])
+@pytest.mark.parametrize("scale,hot_min_edges,long_min,small_max",
+                         [(10, 0, 64, 0), (10, 0, 64, 8192), (13, 0, 8, 100), (13, 0, 0, 8192), (16, 0, 64, 8192),
+                          (16, 65536, 64, 0), (16, 0, 1, 3000), (16, 1 << 30, 16, 8192)])
 def test_bfs_hub_first_layout_and_lds_hot_bitmap(gpu_ctx, oracle, torch_mod, rmat_graphs, scale, hot_min_edges, long_min,
-                                                 monkeypatch):
+                                                 small_max, monkeypatch):
     """fused traversal on the degree-sorted layout (hot prefix of the visited snapshot in LDS): labels must
     come back in ORIGINAL ids and equal the oracle's.  hot_min_edges=0 forces the LDS path on small graphs,
     2^30 keeps every probe in L2; long_min moves rows between the row-wise streaming kernel and the
-    per-edge-rank kernel (0: no long-row queue, 1: every row is streamed)."""
+    per-edge-rank kernel (0: no long-row queue, 1: every row is streamed); small_max: levels up to that many
+    edges run inside the single-workgroup kernel (0: none)."""
     import mini_amd
     from mini_amd import rmat
     torch = torch_mod
     monkeypatch.setenv("MGX_BFS_HOT_MIN_EDGES", str(hot_min_edges))
     monkeypatch.setenv("MGX_BFS_LONG_MIN", str(long_min))
+    monkeypatch.setenv("MGX_BFS_SMALL_MAX_EDGES", str(small_max))
     n, ro, ci, w = rmat_graphs[scale]
     d_ro, d_ci = torch.from_numpy(ro).cuda(), torch.from_numpy(ci).cuda()
     g = mini_amd.Graph.from_device(gpu_ctx, n, len(ci), d_ro, d_ci)
@@ -373,9 +376,12 @@ def test_bfs_directed_graph_with_zero_outdegree_vertices(gpu_ctx, oracle):
         assert np.array_equal(bfs.labels(), want)
 
 
-def test_bfs_long_chain_many_levels(gpu_ctx, oracle):
-    """a path graph: > levels_per_sync levels, frontier of one vertex each"""
+@pytest.mark.parametrize("small_max", [8192, 0])
+def test_bfs_long_chain_many_levels(gpu_ctx, oracle, monkeypatch, small_max):
+    """a path graph: > levels_per_sync levels, frontier of one vertex each.  small_max=8192: all 300 levels run
+    inside ONE launch of the single-workgroup kernel; 0: every level goes through the device-wide kernels."""
     import mini_amd
+    monkeypatch.setenv("MGX_BFS_SMALL_MAX_EDGES", str(small_max))
     n = 300
     t0 = np.arange(0, n - 1, dtype=np.int32)
     t1 = np.arange(1, n, dtype=np.int32)
@@ -385,6 +391,7 @@ def test_bfs_long_chain_many_levels(gpu_ctx, oracle):
     st = bfs.run(0)
     assert np.array_equal(bfs.labels(), np.arange(n, dtype=np.int32))
     assert st["levels"] == n          # frontiers at depth 0..n-1 all expand an edge
+    assert st["small_levels"] == (n if small_max else 0)
 
 
 @pytest.mark.parametrize("scale", [8, 10, 13])

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
-"""Per-level breakdown of the fused BFS (run with MGX_BFS_LEVELS_PER_SYNC=1 so a batch is one level)."""
+"""Per-level breakdown of the fused BFS: level times from device-side stamps, push kernels per launch slot."""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("MGX_BFS_LEVELS_PER_SYNC", "1")
 import numpy as np, torch
 import mini_amd
 from mini_amd import rmat
@@ -21,15 +20,17 @@ bfs.set_kernel_timing(True)
 bfs.run(srcs[0], a.mode, a.alpha)
 for s in srcs[1:]:
     st = bfs.run(s, a.mode, a.alpha)
-    tr, ms, cl = bfs.level_trace(), bfs.batch_times_ms(), bfs.level_claims()
-    print("src %d: levels %d reached %d m_t %d kernel_ms %.3f" % (s, st["levels"], st["reached"], st["m_t"], st["kernel_ns"] / 1e6))
-    print("  claims %d  push_levels %d  push_edges %d  pull_edges %d" % (st["claims"], st["push_levels"], st["push_edges"], st["pull_edges"]))
-    kt = bfs.level_kernel_times_ms()
+    tr, ms, cl = bfs.level_trace(), bfs.level_times_ms(), bfs.level_claims()
+    print("src %d: levels %d (small %d) reached %d m_t %d kernel_ms %.3f" % (s, st["levels"], st["small_levels"], st["reached"], st["m_t"], st["kernel_ns"] / 1e6))
+    print("  marks %d  push_levels %d  push_edges %d  pull_edges %d" % (st["claims"], st["push_levels"], st["push_edges"], st["pull_edges"]))
     for lv, ((nf, ne), t) in enumerate(zip(tr, ms)):
         b = 8.0 * ne + 20.0 * nf
-        print("  level %2d  nf %9d  edges %10d  %8.3f ms (stream %.3f wave %.3f)  %8.1f GTEPS  %7.1f algGB/s  claims %9d" % (lv, nf, ne, t, kt[lv][0], kt[lv][1], ne / t / 1e6 if t > 0 else 0, b / t / 1e6 if t > 0 else 0, cl[lv] if lv < 64 else -1))
+        print("  level %2d  nf %9d  edges %10d  %8.3f ms  %8.1f GTEPS  %7.1f algGB/s  marks %9d" % (lv, nf, ne, t, ne / t / 1e6 if t > 0 else 0, b / t / 1e6 if t > 0 else 0, cl[lv] if lv < 64 else -1))
+    kt = bfs.level_kernel_times_ms()
+    print("  slots (stream ms, wave ms): " + "  ".join("(%.3f, %.3f)" % x for x in kt[:8]))
     k = bfs.kernel_times()
     for name in ("stream", "wave"):
         q = k[name]
         print("  %-6s launches %d  %.3f ms  edges %d (%.1f GTEPS)" % (name, q["launches"], q["ns"] / 1e6, q["edges"], q["edges"] / max(q["ns"], 1)))
-    print("  tail batches:", ["%.4f" % x for x in ms[len(tr):]])
+    ms = bfs.batch_times_ms()
+    print("  batches:", ["%.4f" % x for x in ms])
