@@ -125,9 +125,10 @@ __global__ __launch_bounds__(BLOCK) void k_bfs_fused_init(bfs_fused_args_t a, in
   const long long n = a.n;
   for (long long i = tid; i < (n + 3) / 4; i += nth) {              // 4 labels / 4 marks per step
     if (i * 4 + 4 <= n) {
-      int4 l = make_int4(-1, -1, -1, -1);
-      if (src_old >> 2 == i) (&l.x)[src_old & 3] = 0;
-      *(int4*)(a.labels + i * 4) = l;
+      const long long j = i * 4;                                     // (no dynamic indexing of the vector: scratch)
+      const int4 l = make_int4(src_old == j ? 0 : -1, src_old == j + 1 ? 0 : -1, src_old == j + 2 ? 0 : -1,
+                               src_old == j + 3 ? 0 : -1);
+      *(int4*)(a.labels + j) = l;
       *(u32*)(a.mark + i * 4) = 0u;
     } else {
       for (long long j = i * 4; j < n; ++j) { a.labels[j] = (j == src_old) ? 0 : -1; a.mark[j] = 0; }
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(NT) void k_bfs_build(bfs_fused_args_t a, int level,
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
       const int i = threadIdx.x * PER + q;
-      if (i < cnt) labels[lab_at[q]] = new_label;
+      if (i < cnt && !(a.flags & 8)) labels[lab_at[q]] = new_label;
       const u32 deg = (i < cnt) ? ro1[q] - ro[q] : 0u;
       const bool is_long = deg >= long_min;
       if (is_long) longmask |= 1u << q;

@@ -27,6 +27,8 @@ struct bfs_layout_t {
 // prefix (big graphs: many cold endpoints) or mark them untested (k_bfs_build tests the bitmap anyway).
 constexpr int BFS_WAVE_HOTW = 19200;      // 75 KB of bitmap per workgroup, two workgroups per CU
 
+constexpr int BFS_STREAM_HOTW2 = 20400;   // two workgroups per CU: 80 KB of bitmap each
+
 inline void bfs_set_kernel_attributes() {
   static bool attr_set = false;
   if (attr_set) return;
@@ -35,10 +37,12 @@ inline void bfs_set_kernel_attributes() {
   MGX_SET_LDS((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, false>));
   MGX_SET_LDS((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, true>));
   MGX_SET_LDS((k_bfs_push_level_wave<1024, 18000, false>));
-  MGX_SET_LDS((k_bfs_push_level_wave<256, 8192, false>));
+  MGX_SET_LDS((k_bfs_push_level_wave<1024, 18000, true>));
+  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false>));
+  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, true>));
+  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 16, false>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 16, false>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, false>));
-  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, true>));
 #undef MGX_SET_LDS
   attr_set = true;
 }
@@ -50,33 +54,43 @@ inline bool bfs_cold_test(int n) {
   return (long long)n >= 8ll * 32 * BFS_STREAM_HOTW;
 }
 
+// Stream-kernel shapes (MGX_BFS_STREAM_SHAPE), measured on RMAT-22 (stream kernel of the big level / whole BFS):
+//   0 (default) 2 workgroups x 1024 threads per CU = 32 waves, 80 KB of bitmap each, 8 loads per lane: 167 us / 0.66 ms
+//   1           the same with 16 loads per lane:                                                         190 us / 0.68 ms
+//   2           1 workgroup per CU (16 waves), 160 KB of bitmap, 16 loads per lane:                      213 us / 0.69 ms
+//   3           the same with 8 loads per lane:                                                          217 us / 0.71 ms
 inline void bfs_launch_stream(const bfs_fused_args_t& a, int level, standard_context_t& ctx) {
-  static const int ept = getenv("MGX_BFS_STREAM_EPT") ? atoi(getenv("MGX_BFS_STREAM_EPT")) : 16;
+  static const int shape = getenv("MGX_BFS_STREAM_SHAPE") ? atoi(getenv("MGX_BFS_STREAM_SHAPE")) : 0;
   hipStream_t s = ctx.stream();
   if (a.long_min <= 0) return;
-  const size_t lds = bfs_stream_lds_bytes(BFS_STREAM_HOTW);
+  const size_t lds2 = bfs_stream_lds_bytes(BFS_STREAM_HOTW2), lds1 = bfs_stream_lds_bytes(BFS_STREAM_HOTW);
   if (bfs_cold_test(a.n))
-    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, true>), dim3(ctx.num_cus), dim3(1024), lds, s, a, level);
-  else if (ept == 8)
-    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, false>), dim3(ctx.num_cus), dim3(1024), lds, s, a, level);
+    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, true>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
+  else if (shape == 1)
+    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 16, false>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
+  else if (shape == 2)
+    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 16, false>), dim3(ctx.num_cus), dim3(1024), lds1, s, a, level);
+  else if (shape == 3)
+    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, false>), dim3(ctx.num_cus), dim3(1024), lds1, s, a, level);
   else
-    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 16, false>), dim3(ctx.num_cus), dim3(1024), lds, s, a, level);
+    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
 }
 
+// Wave-kernel shapes (MGX_BFS_WAVE_SHAPE): 1 (default) 2 x 1024 threads per CU = 32 waves (the kernel needs ~45
+// VGPRs); 0: 2 x 512 threads = 16 waves, more bitmap in LDS.  RMAT-22 big level: 67 us vs 82 us.
 inline void bfs_launch_wave(const bfs_fused_args_t& a, int level, standard_context_t& ctx) {
-  hipStream_t s = ctx.stream();
-  const size_t lds = bfs_wave_lds_bytes(512, BFS_WAVE_HOTW);
   static const int shape = getenv("MGX_BFS_WAVE_SHAPE") ? atoi(getenv("MGX_BFS_WAVE_SHAPE")) : 1;
-  if (bfs_cold_test(a.n))
-    hipLaunchKernelGGL((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, true>), dim3(ctx.num_cus * 2), dim3(512), lds, s, a, level);
-  else if (shape == 1)      // default: 32 waves per CU (the kernel needs ~45 VGPRs): 2 x 1024 threads
-    hipLaunchKernelGGL((k_bfs_push_level_wave<1024, 18000, false>), dim3(ctx.num_cus * 2), dim3(1024),
-                       bfs_wave_lds_bytes(1024, 18000), s, a, level);
-  else if (shape == 2)      // 32 waves per CU: 8 x 256 threads, 32 KB of bitmap each
-    hipLaunchKernelGGL((k_bfs_push_level_wave<256, 8192, false>), dim3(ctx.num_cus * 8), dim3(256),
-                       bfs_wave_lds_bytes(256, 8192), s, a, level);
-  else
-    hipLaunchKernelGGL((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, false>), dim3(ctx.num_cus * 2), dim3(512), lds, s, a, level);
+  hipStream_t s = ctx.stream();
+  const bool cold = bfs_cold_test(a.n);
+  if (shape == 0) {
+    const size_t lds = bfs_wave_lds_bytes(512, BFS_WAVE_HOTW);
+    if (cold) hipLaunchKernelGGL((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, true>), dim3(ctx.num_cus * 2), dim3(512), lds, s, a, level);
+    else hipLaunchKernelGGL((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, false>), dim3(ctx.num_cus * 2), dim3(512), lds, s, a, level);
+  } else {
+    const size_t lds = bfs_wave_lds_bytes(1024, 18000);
+    if (cold) hipLaunchKernelGGL((k_bfs_push_level_wave<1024, 18000, true>), dim3(ctx.num_cus * 2), dim3(1024), lds, s, a, level);
+    else hipLaunchKernelGGL((k_bfs_push_level_wave<1024, 18000, false>), dim3(ctx.num_cus * 2), dim3(1024), lds, s, a, level);
+  }
 }
 
 // Runs a whole BFS from `src` on the context's stream.  labels[] is (re)initialised here.  Returns with the

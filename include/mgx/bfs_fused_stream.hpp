@@ -137,14 +137,23 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_stream(bfs_fused_args_t a
         idL[k] = p[((u32)lane < nL[k]) ? (u32)lane : 0u];
       }
     };
-    // test one neighbour: returns true when it has to be marked
-    auto is_new = [&](u32 d, u32 cold_word) -> bool {
-      const u32 bit = 1u << (d & 31);
-      if (d < hot_n) {
-        // the LDS copy is the bitmap + this workgroup's own marks: claim the bit locally
-        return !(hot[d >> 5] & bit) && ((diag & 2) || !(atomicOr(&hot[d >> 5], bit) & bit));
+    // test one round.  A hot miss claims the bit in the LDS copy (the bitmap + this workgroup's own marks): exact
+    // intra-workgroup dedup.  (Probing all EPT words first and deciding afterwards was measured slower.)
+    auto test_round = [&](const int (&id)[EPT], const u32 (&nn)[EPT], const u32* cold_word) {
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        const u32 d = (u32)id[k];
+        const u32 bit = 1u << (d & 31);
+        if ((u32)lane < nn[k]) {
+          bool is_new;
+          if (d < hot_n) is_new = !(hot[d >> 5] & bit) && ((diag & 2) || !(atomicOr(&hot[d >> 5], bit) & bit));
+          else is_new = COLDT ? !(cold_word[k] & bit) : true;
+          if (is_new) {
+            if (!(diag & 1)) mark[d] = 1;
+            ++marks;
+          }
+        }
       }
-      return COLDT ? !(cold_word & bit) : true;
     };
 
     walk();
@@ -162,14 +171,7 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_stream(bfs_fused_args_t a
         walk();                  // needs the prefetched window: every load issued so far has landed
         issue();
         prefetch(seg);
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) {
-          const u32 d = (u32)idT[k];
-          if ((u32)lane < nT[k] && is_new(d, 0u)) {
-            if (!(diag & 1)) mark[d] = 1;
-            ++marks;
-          }
-        }
+        test_round(idT, nT, nullptr);
       }
     } else {
       // three stages: round t+1 loads its neighbours, round t the bitmap words of its cold ones, round t-1
@@ -192,14 +194,7 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_stream(bfs_fused_args_t a
 #pragma unroll
         for (int k = 0; k < EPT; ++k) wordL[k] = vis[((u32)idW[k] >= hot_n) ? ((u32)idW[k] >> 5) : 0u];
         prefetch(seg);
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) {
-          const u32 d = (u32)idT[k];
-          if ((u32)lane < nT[k] && is_new(d, wordT[k])) {
-            if (!(diag & 1)) mark[d] = 1;
-            ++marks;
-          }
-        }
+        test_round(idT, nT, wordT);
       }
     }
   }

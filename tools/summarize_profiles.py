@@ -11,7 +11,7 @@ for f in glob.glob(os.path.join(O, "trace", "**", "*kernel_stats.csv"), recursiv
         for r in keep:
             r = dict(r); r["Name"] = r["Name"][:120]; w.writerow(r)
     for r in rows:
-        for kn in ("k_bfs_push_level_wave", "k_bfs_push_level_hot", "k_bfs_level_begin", "k_bfs_pull_level"):
+        for kn in ("k_bfs_push_level_stream", "k_bfs_push_level_wave", "k_bfs_build", "k_bfs_small_levels", "k_bfs_fused_init", "k_bfs_pull_level"):
             if kn in r["Name"]:
                 out[kn] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "total_ns": int(r["TotalDurationNs"])}
                 print("kernel-trace: %s calls=%s avg=%.1f us total=%.3f ms" % (kn, r["Calls"], float(r["AverageNs"]) / 1e3, int(r["TotalDurationNs"]) / 1e6))
@@ -19,7 +19,7 @@ pm = {}
 for f in glob.glob(os.path.join(O, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     agg, cnt = collections.Counter(), collections.Counter()
     for r in csv.DictReader(open(f)):
-        if "k_bfs_push_level_wave" in r["Kernel_Name"]:
+        if "k_bfs_push_level_stream" in r["Kernel_Name"]:
             agg[r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Counter_Name"]] += 1
     for k in agg:
         pm[k] = {"sum": agg[k], "dispatches": cnt[k], "per_dispatch": agg[k] / cnt[k]}
