@@ -121,20 +121,36 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_wave(bfs_fused_args_t a, 
         r[k] = act ? rr : E0;
         sj[k] = 0;
       }
-      if (nseg > 1) {
-        int top = 1;
-        while (top * 2 < nseg) top *= 2;
-        for (int step = top; step > 0; step >>= 1) {
+      // The queue is built in vertex order (k_bfs_build) and the hub-first layout sorts vertices by degree, so the
+      // 64 staged rows usually all have the SAME degree d: then rank x (relative to the first staged row) belongs
+      // to row x / d -- one multiply-high with a per-tile reciprocal instead of a 6-step search in LDS.
+      const u32 off0 = w_off[0];
+      const u32 d0 = w_off[1] - off0;
+      const bool uniform = __ballot(lane < nseg && (nxt - my) != d0) == 0ull;
+      if (uniform) {
+        const u32 recip = d0 > 1u ? 0xFFFFFFFFu / d0 + 1u : 0u;         // ceil(2^32 / d0); x < 64 * 64: exact
 #pragma unroll
-          for (int k = 0; k < EPT; ++k) {
-            const int j = sj[k] + step;
-            const u32 vv = w_off[j < nseg ? j : nseg - 1];
-            if (j < nseg && vv <= r[k]) sj[k] = j;
+        for (int k = 0; k < EPT; ++k) {
+          const u32 x = r[k] - off0;
+          const u32 j = d0 > 1u ? __umulhi(x, recip) : x;
+          eidxC[k] = w_row[j] + (x - j * d0);
+        }
+      } else {
+        if (nseg > 1) {
+          int top = 1;
+          while (top * 2 < nseg) top *= 2;
+          for (int step = top; step > 0; step >>= 1) {
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+              const int j = sj[k] + step;
+              const u32 vv = w_off[j < nseg ? j : nseg - 1];
+              if (j < nseg && vv <= r[k]) sj[k] = j;
+            }
           }
         }
-      }
 #pragma unroll
-      for (int k = 0; k < EPT; ++k) eidxC[k] = w_row[sj[k]] + (r[k] - w_off[sj[k]]);
+        for (int k = 0; k < EPT; ++k) eidxC[k] = w_row[sj[k]] + (r[k] - w_off[sj[k]]);
+      }
       seg = seg_next;
       e_next = E1;
     };
