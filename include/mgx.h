@@ -211,19 +211,26 @@ MGX_API int mgx_dbfs_labels(mgx_dbfs_t h, int* host_labels_local);
  *      kernels on its rows and ranks exchange dense "newly visited" bitmaps (one all-gather of n/8 bytes
  *      per rank and level) instead of id lists.  Ids are global and hub-first (descending global degree);
  *      vertex v belongs to rank v % ranks, local row v / ranks.  d_newbits: caller-owned buffer of
- *      (n_global+31)/32 words that mgx_dbfs2_push fills with the rank's discoveries of the level;
+ *      mgx_dbfs2_words(n_global) words that mgx_dbfs2_push fills with the rank's discoveries of the level;
  *      mgx_dbfs2_merge takes the all-gathered ranks x words array, ORs it into every rank's visited
  *      bitmap, labels the owned vertices and builds the rank's next frontier (returns its size/edges). */
 MGX_API int mgx_dbfs2_create(mgx_ctx_t ctx, int n_global, int ranks, int rank, const int* d_row_offsets_local,
                              const int* d_col_indices_global, unsigned* d_newbits, mgx_dbfs2_t* out);
 MGX_API int mgx_dbfs2_free(mgx_dbfs2_t h);
-/* first_edges (may be NULL): edges of this rank's level-0 frontier = deg(src) on the owner, 0 elsewhere */
-MGX_API int mgx_dbfs2_reset(mgx_dbfs2_t h, int src_global, int64_t* first_edges);
+/* All of reset / push / merge are asynchronous on the context's stream: a level is
+ *   push(level) -> all-gather of d_newbits into d_gathered (the caller's collective, stream-ordered) -> merge(level)
+ * and several levels can be enqueued before mgx_dbfs2_status synchronises.  Levels enqueued after the traversal has
+ * ended are no-ops on every rank (their new-bit maps are empty).  Bitmaps are mgx_dbfs2_words(n) 32-bit words long
+ * (padded to 16 bytes). */
+MGX_API int mgx_dbfs2_words(int n_global, int64_t* words);
+MGX_API int mgx_dbfs2_reset(mgx_dbfs2_t h, int src_global);
 MGX_API int mgx_dbfs2_push(mgx_dbfs2_t h, int level);
-/* new_global: vertices discovered by all ranks together in this level -- the same number on every rank,
- * so "new_global == 0" ends the traversal everywhere without a reduction */
-MGX_API int mgx_dbfs2_merge(mgx_dbfs2_t h, int level, const unsigned* d_gathered, int64_t* next_frontier_size,
-                            int64_t* next_frontier_edges, int64_t* new_global);
+MGX_API int mgx_dbfs2_merge(mgx_dbfs2_t h, int level, const unsigned* d_gathered);
+/* Synchronises.  next_level = number of levels enqueued so far.  out6: [0] traversal over (a level discovered nothing
+ * on ANY rank -- the same on every rank, no reduction needed) [1] levels that hold vertices [2] edges this rank has
+ * expanded [3] vertices discovered by all ranks in the level merged last [4] size and [5] edges of this rank's next
+ * queues */
+MGX_API int mgx_dbfs2_status(mgx_dbfs2_t h, int next_level, int64_t* out6);
 MGX_API int mgx_dbfs2_labels(mgx_dbfs2_t h, int* host_labels_local);
 
 /* ---- SSSP: sssp_problem_t / sssp_functor_t / sssp_enactor_t (gunrock/src/sssp/) ---- */

@@ -44,15 +44,23 @@ __global__ __launch_bounds__(BLOCK) void k_d2_newbits(const u32* __restrict__ vi
 
 // merged[w] = OR over ranks of gathered[r][w]; visited |= merged; ctrl->merged_new += popcount(merged).
 // Every rank computes the same count, so the traversal ends on all ranks together without a reduction.
-__global__ __launch_bounds__(BLOCK) void k_d2_or(const u32* __restrict__ gathered, int ranks, long long nwords,
-                                                 u32* __restrict__ merged, u32* __restrict__ visited, bfs_ctrl_t* c) {
+// 16 bytes per lane (nwords4 = words / 4; the buffers are padded to a multiple of 4 words).
+__global__ __launch_bounds__(BLOCK) void k_d2_or(const uint4* __restrict__ gathered, int ranks, long long nwords4,
+                                                 uint4* __restrict__ merged, uint4* __restrict__ visited, bfs_ctrl_t* c) {
   int found = 0;
-  for (long long w = (long long)blockIdx.x * BLOCK + threadIdx.x; w < nwords; w += (long long)gridDim.x * BLOCK) {
-    u32 g = 0;
-    for (int r = 0; r < ranks; ++r) g |= gathered[(long long)r * nwords + w];
+  for (long long w = (long long)blockIdx.x * BLOCK + threadIdx.x; w < nwords4; w += (long long)gridDim.x * BLOCK) {
+    uint4 g = make_uint4(0, 0, 0, 0);
+    for (int r = 0; r < ranks; ++r) {
+      const uint4 x = gathered[(long long)r * nwords4 + w];
+      g.x |= x.x; g.y |= x.y; g.z |= x.z; g.w |= x.w;
+    }
     merged[w] = g;
-    if (g) visited[w] |= g;
-    found += __popc(g);
+    if (g.x | g.y | g.z | g.w) {
+      uint4 v = visited[w];
+      v.x |= g.x; v.y |= g.y; v.z |= g.z; v.w |= g.w;
+      visited[w] = v;
+    }
+    found += __popc(g.x) + __popc(g.y) + __popc(g.z) + __popc(g.w);
   }
   found = wave_sum(found);
   if (lane_id() == 0 && found) atomicAdd(&c->merged_new, (u64)found);
@@ -83,10 +91,10 @@ struct d2_state_t {
     n_global = n_global_; ranks = ranks_; rank = rank_;
     n_local = (n_global - rank + ranks - 1) / ranks;
     row_offsets = ro; col_indices = ci; newbits = newbits_;
-    nwords = ((long long)n_global + 31) / 32;
+    nwords = (((long long)n_global + 31) / 32 + 3) / 4 * 4;     // padded to 16 bytes: the OR-merge reads uint4
     fs.reset(new bfs_fused_state_t(n_global, ctx));
     labels = mem_t<int>((size_t)n_local + 1, ctx);
-    merged = mem_t<u32>((size_t)nwords + 1, ctx);
+    merged = mem_t<u32>((size_t)nwords + 4, ctx);
   }
   bfs_fused_args_t args() const {
     bfs_fused_args_t a;
@@ -112,18 +120,13 @@ struct d2_state_t {
   }
 };
 
-// Returns the number of edges of this rank's level-0 frontier (the source's degree on its owner, else 0).
-inline long long d2_reset(d2_state_t& st, int src, standard_context_t& ctx) {
+// Start of a traversal (asynchronous).
+inline void d2_reset(d2_state_t& st, int src, standard_context_t& ctx) {
   hipStream_t s = ctx.stream();
   MGX_HIP(hipMemsetAsync(st.labels.data(), 0xFF, (size_t)st.n_local * sizeof(int), s));
   MGX_HIP(hipMemsetAsync(st.fs->visited.data(), 0, st.fs->visited.size() * sizeof(u32), s));
   MGX_HIP(hipMemsetAsync(st.fs->mark.data(), 0, st.fs->mark.size(), s));
   hipLaunchKernelGGL(k_d2_init, dim3(1), dim3(64), 0, s, st.args(), st.labels.data(), src, st.ranks, st.rank);
-  if (src % st.ranks != st.rank) return 0;
-  u64* hc = (u64*)ctx.mailbox;
-  MGX_HIP(hipMemcpyAsync(hc, st.fs->ctrl.data(), 7 * sizeof(u64), hipMemcpyDeviceToHost, s));
-  MGX_HIP(hipStreamSynchronize(s));
-  return (long long)((hc[0] & BFS_EMASK) + (hc[4] & BFS_EMASK));
 }
 
 // level kernels on the local queues (marks), then new_bits = marks & ~bitmap
@@ -131,32 +134,41 @@ inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx) {
   hipStream_t s = ctx.stream();
   bfs_fused_args_t a = st.args();
   bfs_set_kernel_attributes();
-  hipLaunchKernelGGL(k_bfs_level_begin, dim3(1), dim3(64), 0, s, a, level);
+  hipLaunchKernelGGL(k_bfs_level_begin, dim3(1), dim3(64), 0, s, a, level, 1);
   bfs_launch_stream(a, level, ctx);
   bfs_launch_wave(a, level, ctx);
   hipLaunchKernelGGL(k_d2_newbits, dim3(grid_for(st.nwords, BLOCK, 256)), dim3(BLOCK), 0, s, st.fs->visited.data(),
                      st.fs->mark.data(), st.newbits, st.nwords, (long long)st.n_global, a.ctrl);
 }
 
-// gathered: ranks x nwords words (every rank's new_bits).  Returns the size of this rank's next frontier;
-// *new_global = vertices all ranks discovered in this level (0 on every rank at once: the traversal is over).
-inline long long d2_merge(d2_state_t& st, int level, const u32* gathered, standard_context_t& ctx, long long* next_edges,
-                          long long* new_global) {
+// gathered: ranks x nwords words (every rank's new_bits).  Asynchronous: OR-merge and queue build are enqueued
+// on the context's stream, nothing is read back.
+inline void d2_merge(d2_state_t& st, int level, const u32* gathered, standard_context_t& ctx) {
   hipStream_t s = ctx.stream();
   bfs_fused_args_t a = st.args();
-  hipLaunchKernelGGL(k_d2_or, dim3(grid_for(st.nwords, BLOCK, 512)), dim3(BLOCK), 0, s, gathered, st.ranks, st.nwords,
-                     st.merged.data(), st.fs->visited.data(), a.ctrl);
+  hipLaunchKernelGGL(k_d2_or, dim3(grid_for(st.nwords / 4, BLOCK, 1024)), dim3(BLOCK), 0, s, (const uint4*)gathered, st.ranks,
+                     st.nwords / 4, (uint4*)st.merged.data(), (uint4*)st.fs->visited.data(), a.ctrl);
   hipLaunchKernelGGL((k_bfs_build<BFS_BUILD_NT, false>), dim3(bfs_build_grid(st.n_local)), dim3(BFS_BUILD_NT), 0, s, a, level,
                      (const u32*)st.merged.data(), st.labels.data(), st.n_local, st.ranks, st.rank, 0);
-  u64* hc = (u64*)ctx.mailbox;
-  static_assert(offsetof(bfs_ctrl_t, merged_new) == 3 * sizeof(u64), "cursor[3] and merged_new are read back together");
-  static_assert(offsetof(bfs_ctrl_t, lcursor) == 4 * sizeof(u64), "lcursor[3] follows");
-  MGX_HIP(hipMemcpyAsync(hc, st.fs->ctrl.data(), 7 * sizeof(u64), hipMemcpyDeviceToHost, s));
+}
+
+// Synchronises and reports: out[0] traversal over (a level discovered nothing on any rank), [1] levels that hold
+// vertices, [2] edges this rank expanded so far, [3] vertices of the level merged last (all ranks), [4] size and
+// [5] edges of this rank's next queues.
+inline void d2_status(d2_state_t& st, int next_level, standard_context_t& ctx, long long* out) {
+  hipStream_t s = ctx.stream();
+  bfs_ctrl_t* hc = st.fs->host_ctrl;
+  MGX_HIP(hipMemcpyAsync(hc, st.fs->ctrl.data(), offsetof(bfs_ctrl_t, trace), hipMemcpyDeviceToHost, s));
   MGX_HIP(hipStreamSynchronize(s));
-  const u64 cur = hc[(level + 1) % 3], lcur = hc[4 + (level + 1) % 3];
-  if (new_global) *new_global = (long long)hc[3];
-  if (next_edges) *next_edges = (long long)((cur & BFS_EMASK) + (lcur & BFS_EMASK));
-  return (long long)((cur >> BFS_VSHIFT) + (lcur >> BFS_VSHIFT));
+  const u64 cur = hc->cursor[next_level % 3], lcur = hc->lcursor[next_level % 3];
+  // the level merged last may itself be the empty one: the device notices at the next level's opening, the host here
+  const bool over = hc->dist_done || (next_level > 0 && hc->merged_new == 0);
+  out[0] = over ? 1 : 0;
+  out[1] = hc->dist_done ? hc->dist_levels : next_level;
+  out[2] = (long long)hc->sum_edges;
+  out[3] = (long long)hc->merged_new;
+  out[4] = (long long)((cur >> BFS_VSHIFT) + (lcur >> BFS_VSHIFT));
+  out[5] = (long long)((cur & BFS_EMASK) + (lcur & BFS_EMASK));
 }
 
 }  // namespace mgx

@@ -62,6 +62,9 @@ struct bfs_ctrl_t {
   int big;           // level `level` has been opened for the device-wide kernels of this slot
   int small_levels;  // levels the single-workgroup kernel ran
   int slots;         // launch slots that found work (k_bfs_small_levels counts them)
+  int dist_done;     // partitioned runs: a level ended with no discovery on any rank ...
+  int dist_levels;   // ... and this many levels hold vertices
+  int pad_[2];
   u64 stamp[64];     // s_memrealtime (100 MHz) when each level was opened: per-level times without host syncs
   u64 trace[BFS_MAX_TRACE];   // (vertices << 38 | edges) of each level, both queues (kept LAST: read back up to `levels`)
 };
@@ -100,6 +103,7 @@ __device__ __forceinline__ void bfs_ctrl_reset(bfs_ctrl_t* c) {
   c->pull_edges = 0;
   c->done = c->levels = c->pull = c->push_levels = 0;
   c->level = c->big = c->small_levels = c->slots = 0;
+  c->dist_done = c->dist_levels = 0;
   for (int i = 0; i < 64; ++i) c->stamp[i] = 0;
 }
 
@@ -175,8 +179,12 @@ __device__ __forceinline__ bool bfs_open_level(const bfs_fused_args_t& a, int le
 }
 
 // Explicit-level variant of the above as a kernel of its own (partitioned runs: the host counts the levels).
-__global__ void k_bfs_level_begin(bfs_fused_args_t a, int level) {
+// There the traversal is over when the level before discovered nothing on ANY rank (ctrl->merged_new, the same
+// number on every rank), whatever this rank's own queues hold.
+__global__ void k_bfs_level_begin(bfs_fused_args_t a, int level, int partitioned) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  bfs_ctrl_t* const c = a.ctrl;
+  if (partitioned && level > 0 && c->merged_new == 0 && !c->dist_done) { c->dist_done = 1; c->dist_levels = level; }
   (void)bfs_open_level(a, level);
 }
 
@@ -364,7 +372,7 @@ struct bfs_fused_state_t {
   float level_wave_ms[64] = {};
 
   bfs_fused_state_t(int num_nodes, standard_context_t& ctx) : n(num_nodes) {
-    size_t words = (size_t)(num_nodes + 31) / 32 + 1;
+    size_t words = (size_t)(num_nodes + 31) / 32 + 8;
     if (words < 65536) words = 65536;              // the kernels copy a fixed-size prefix of the bitmap into LDS
     visited = mem_t<u32>(words, ctx);
     frontier_bits = mem_t<u32>(words, ctx);

@@ -114,9 +114,11 @@ SIGNATURES = {
     "mgx_dbfs_labels": [_vp, _vp],
     "mgx_dbfs2_create": [_vp, _i, _i, _i, _vp, _vp, _vp, _pvp],
     "mgx_dbfs2_free": [_vp],
-    "mgx_dbfs2_reset": [_vp, _i, _pi64],
+    "mgx_dbfs2_reset": [_vp, _i],
+    "mgx_dbfs2_words": [_i, _pi64],
+    "mgx_dbfs2_status": [_vp, _i, _pi64],
     "mgx_dbfs2_push": [_vp, _i],
-    "mgx_dbfs2_merge": [_vp, _i, _vp, _pi64, _pi64, _pi64],
+    "mgx_dbfs2_merge": [_vp, _i, _vp],
     "mgx_dbfs2_labels": [_vp, _vp],
     "mgx_sssp_create": [_vp, _i, _pvp],
     "mgx_sssp_reset": [_vp, _i],

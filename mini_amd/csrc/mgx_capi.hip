@@ -793,12 +793,11 @@ int mgx_dbfs2_free(mgx_dbfs2_t h) {
   if (h) { use_device(h->c); delete h; }
   MGX_CATCH
 }
-int mgx_dbfs2_reset(mgx_dbfs2_t h, int src, int64_t* first_edges) {
+int mgx_dbfs2_reset(mgx_dbfs2_t h, int src) {
   MGX_TRY
   MGX_REQUIRE(h && src >= 0 && src < h->st.n_global, "mgx_dbfs2_reset: bad argument");
   use_device(h->c);
-  const long long e = mgx::d2_reset(h->st, src, *h->c->ctx);
-  if (first_edges) *first_edges = e;
+  mgx::d2_reset(h->st, src, *h->c->ctx);
   MGX_CATCH
 }
 int mgx_dbfs2_push(mgx_dbfs2_t h, int level) {
@@ -808,16 +807,26 @@ int mgx_dbfs2_push(mgx_dbfs2_t h, int level) {
   mgx::d2_push(h->st, level, *h->c->ctx);
   MGX_CATCH
 }
-int mgx_dbfs2_merge(mgx_dbfs2_t h, int level, const unsigned* d_gathered, int64_t* next_frontier, int64_t* next_edges,
-                    int64_t* new_global) {
+int mgx_dbfs2_merge(mgx_dbfs2_t h, int level, const unsigned* d_gathered) {
   MGX_TRY
   MGX_REQUIRE(h && d_gathered && level >= 0, "bad argument");
   use_device(h->c);
-  long long e = 0, g = 0;
-  const long long nf = mgx::d2_merge(h->st, level, d_gathered, *h->c->ctx, &e, &g);
-  if (new_global) *new_global = g;
-  if (next_frontier) *next_frontier = nf;
-  if (next_edges) *next_edges = e;
+  mgx::d2_merge(h->st, level, d_gathered, *h->c->ctx);
+  MGX_CATCH
+}
+int mgx_dbfs2_status(mgx_dbfs2_t h, int next_level, int64_t* out6) {
+  MGX_TRY
+  MGX_REQUIRE(h && out6 && next_level >= 0, "bad argument");
+  use_device(h->c);
+  long long o[6];
+  mgx::d2_status(h->st, next_level, *h->c->ctx, o);
+  for (int i = 0; i < 6; ++i) out6[i] = o[i];
+  MGX_CATCH
+}
+int mgx_dbfs2_words(int n_global, int64_t* words) {
+  MGX_TRY
+  MGX_REQUIRE(words && n_global > 0, "bad argument");
+  *words = (((long long)n_global + 31) / 32 + 3) / 4 * 4;
   MGX_CATCH
 }
 int mgx_dbfs2_labels(mgx_dbfs2_t h, int* host_labels_local) {

@@ -155,13 +155,22 @@ def local_rows(n_global, ranks, rank):
     return (n_global - rank + ranks - 1) // ranks
 
 
+def bitmap_words(n_global):
+    """32-bit words of a generation-2 bitmap (padded to 16 bytes; == mgx_dbfs2_words)"""
+    return ((n_global + 31) // 32 + 3) // 4 * 4
+
+
 class HipRankEngine2:
-    """Per-rank device side of the bitmap-exchange BFS (C-ABI mgx_dbfs2_*).  Ids are global, hub-first."""
+    """Per-rank device side of the bitmap-exchange BFS (C-ABI mgx_dbfs2_*).  Ids are global, hub-first.
+    reset / push / merge only enqueue work on the context's stream; status() synchronises."""
 
     def __init__(self, ctx, n_global, ranks, rank, row_offsets_local, col_indices_global):
         self.ctx, self.n_global, self.ranks, self.rank = ctx, n_global, ranks, rank
         self.n_local = local_rows(n_global, ranks, rank)
-        self.nwords = (n_global + 31) // 32
+        w = C.c_int64()
+        check(lib.mgx_dbfs2_words(int(n_global), C.byref(w)))
+        self.nwords = w.value
+        assert self.nwords == bitmap_words(n_global)
         self._keep = (row_offsets_local, col_indices_global)
         self.newbits = torch.zeros(self.nwords, dtype=torch.int32, device=row_offsets_local.device)
         h = C.c_void_p()
@@ -171,18 +180,19 @@ class HipRankEngine2:
         self._h = h
 
     def reset(self, src):
-        e = C.c_int64()
-        check(lib.mgx_dbfs2_reset(self._h, int(src), C.byref(e)))
-        return e.value
+        check(lib.mgx_dbfs2_reset(self._h, int(src)))
 
     def push(self, level):
         check(lib.mgx_dbfs2_push(self._h, int(level)))
         return self.newbits
 
     def merge(self, level, gathered):
-        nf, ne, ng = C.c_int64(), C.c_int64(), C.c_int64()
-        check(lib.mgx_dbfs2_merge(self._h, int(level), C.c_void_p(gathered.data_ptr()), C.byref(nf), C.byref(ne), C.byref(ng)))
-        return nf.value, ne.value, ng.value
+        check(lib.mgx_dbfs2_merge(self._h, int(level), C.c_void_p(gathered.data_ptr())))
+
+    def status(self, next_level):
+        o = (C.c_int64 * 6)()
+        check(lib.mgx_dbfs2_status(self._h, int(next_level), o))
+        return {"over": bool(o[0]), "levels": o[1], "edges_local": o[2], "new_global": o[3]}
 
     def labels(self):
         out = np.empty(self.n_local, dtype=np.int32)
@@ -196,32 +206,45 @@ class HipRankEngine2:
 
 
 class DistBfs2:
-    """Superstep driver of generation 2: push (device) -> all_gather of the new-bit maps -> merge (device);
-    every rank counts the merged discoveries itself, so a level costs ONE collective.  `engine` needs reset/push/merge/labels."""
+    """Superstep driver of generation 2: push (device) -> all_gather of the new-bit maps -> merge (device), all
+    stream-ordered.  Every rank counts the merged discoveries itself, so a level costs ONE collective and no
+    reduction; the host looks at the device state once per BATCH of levels: the first batch is as long as the
+    previous traversal was (sources differ, the level structure of a graph hardly), later ones two levels.  Levels
+    enqueued past the end are no-ops.  The batch schedule depends only on numbers every rank agrees on, so all ranks
+    issue the same collectives.  `engine` needs reset/push/merge/status/labels."""
 
     def __init__(self, engine, rank, world, comm_device):
         self.e, self.rank, self.world, self.comm_device = engine, rank, world, torch.device(comm_device)
+        self.levels_hint = 8
+        self._gathered = None
 
-    def run(self, src, src_degree_hint=None):
-        e, W = self.e, self.world
-        level, edges_local = 0, e.reset(src)
+    def _exchange(self, new):
+        W = self.world
+        if W == 1:
+            return new
+        mine = new if new.device == self.comm_device else new.to(self.comm_device)
+        if self._gathered is None or self._gathered.numel() != W * mine.numel() or self._gathered.device != self.comm_device:
+            self._gathered = torch.empty(W * mine.numel(), dtype=mine.dtype, device=self.comm_device)
+        dist.all_gather_into_tensor(self._gathered, mine.contiguous())
+        return self._gathered if self._gathered.device == new.device else self._gathered.to(new.device)
+
+    def run(self, src):
+        e = self.e
+        e.reset(src)
+        level = 0
+        batch = self.levels_hint
         while True:
-            new = e.push(level)
-            if W > 1:
-                mine = new if new.device == self.comm_device else new.to(self.comm_device)
-                gathered = torch.empty(W * mine.numel(), dtype=mine.dtype, device=self.comm_device)
-                dist.all_gather_into_tensor(gathered, mine.contiguous())
-                if gathered.device != new.device:
-                    gathered = gathered.to(new.device)
-            else:
-                gathered = new
-            _, ne_local, new_global = e.merge(level, gathered)
-            edges_local += ne_local
-            if new_global == 0:       # the same count on every rank (merged bitmap): no reduction needed
+            for _ in range(batch):
+                new = e.push(level)
+                e.merge(level, self._exchange(new))
+                level += 1
+            st = e.status(level)
+            if st["over"]:
                 break
-            level += 1
-        self.levels = level + 1          # levels 0..level hold vertices (reference "iterations")
-        return {"levels": level + 1, "edges_local": edges_local}
+            batch = 2
+        self.levels = st["levels"]
+        self.levels_hint = max(1, st["levels"] + 1)      # + the level that finds nothing
+        return {"levels": st["levels"], "edges_local": st["edges_local"]}
 
     def gather_labels(self):
         """Global label array in (hub-first) global ids on every rank (validation only)."""

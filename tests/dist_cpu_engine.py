@@ -57,12 +57,14 @@ class NumpyRankEngine:
 
 class NumpyRankEngine2:
     """numpy stand-in for mini_amd.dist_bfs.HipRankEngine2 (generation 2: replicated visited bitmap,
-    cyclic ownership, new-bit maps exchanged by all-gather).  Same reset/push/merge/labels contract."""
+    cyclic ownership, new-bit maps exchanged by all-gather).  Same reset/push/merge/status/labels contract,
+    including "levels enqueued past the end are no-ops"."""
 
     def __init__(self, n_global, ranks, rank, ro_local, ci_global):
+        from mini_amd.dist_bfs import bitmap_words
         self.n_global, self.ranks, self.rank = n_global, ranks, rank
         self.n_local = (n_global - rank + ranks - 1) // ranks
-        self.nwords = (n_global + 31) // 32
+        self.nwords = bitmap_words(n_global)
         self.ro = np.asarray(ro_local, dtype=np.int64)
         self.ci = np.asarray(ci_global, dtype=np.int64)
 
@@ -82,17 +84,20 @@ class NumpyRankEngine2:
         self.visited = np.zeros(self.n_global, dtype=bool)
         self.visited[src] = True
         self.front = []
+        self.edges = 0
+        self.over, self.levels, self.new_global = False, 0, -1
         if src % self.ranks == self.rank:
             i = src // self.ranks
             self.lab[i] = 0
             if self.ro[i + 1] > self.ro[i]:
                 self.front = [i]
-            return int(self.ro[i + 1] - self.ro[i])
-        return 0
 
     def push(self, level):
+        if level > 0 and self.new_global == 0 and not self.over:
+            self.over, self.levels = True, level
         nbrs = [self.ci[self.ro[i]:self.ro[i + 1]] for i in self.front]
         g = np.concatenate(nbrs) if nbrs else np.zeros(0, dtype=np.int64)
+        self.edges += len(g)
         new = np.zeros(self.n_global, dtype=bool)
         new[g[~self.visited[g]]] = True
         return torch.from_numpy(self._bits_to_words(new.astype(np.uint8), self.nwords).copy())
@@ -106,7 +111,12 @@ class NumpyRankEngine2:
         self.lab[mine] = level + 1
         deg = self.ro[mine + 1] - self.ro[mine]
         self.front = mine[deg > 0].tolist()
-        return len(self.front), int(deg.sum()), int(bits.sum())
+        self.new_global = int(bits.sum())
+
+    def status(self, next_level):
+        over = self.over or (next_level > 0 and self.new_global == 0)
+        return {"over": over, "levels": self.levels if self.over else next_level, "edges_local": self.edges,
+                "new_global": self.new_global}
 
     def labels(self):
         return self.lab.copy()

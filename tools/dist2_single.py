@@ -17,19 +17,25 @@ for r in range(G):
     ro, col, new_of_old, old_of_new, deg_new = rmat_cyclic_shard(ctx, scale, 16, scale, G, r, dev)
     engs.append(HipRankEngine2(ctx, n, G, r, ro, col))
 srcs = [int(v) for v in torch.nonzero(deg_new > 0)[:: max(1, n // 64)][:6, 0].tolist()]
+hint = 8
 for it, s in enumerate(srcs):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    edges = sum(e.reset(s) for e in engs)
-    level = 0
+    for e in engs:
+        e.reset(s)
+    level, batch = 0, hint
     while True:
-        gathered = torch.cat([e.push(level) for e in engs]) if G > 1 else engs[0].push(level)
-        for e in engs:
-            a, b, ng = e.merge(level, gathered)
-            edges += b
-        level += 1
-        if ng == 0:
+        for _ in range(batch):
+            gathered = torch.cat([e.push(level) for e in engs]) if G > 1 else engs[0].push(level)
+            for e in engs:
+                e.merge(level, gathered)
+            level += 1
+        sts = [e.status(level) for e in engs]
+        if sts[0]["over"]:
             break
+        batch = 2
+    hint = sts[0]["levels"] + 1
+    edges = sum(st["edges_local"] for st in sts)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     if it:
         print("src %d levels %d edges %d  total %.3f ms  per-rank %.3f ms  -> %.1f GTEPS aggregate (no exchange time)"
-              % (s, level, edges, dt * 1e3, dt * 1e3 / G, edges / (dt / G) / 1e9))
+              % (s, sts[0]["levels"], edges, dt * 1e3, dt * 1e3 / G, edges / (dt / G) / 1e9))
