@@ -209,11 +209,13 @@ __device__ __forceinline__ bool bfs_resolve_level(const bfs_ctrl_t* c, int& leve
 // sixteen separate runs of 1024 (one per wave), a sixteenth of the id range apart: under the hub-first layout a
 // level's discoveries are concentrated in a prefix of the ids, and contiguous ownership would leave most
 // workgroups idle (measured: 64 us vs 26 us for two levels with the same number of discoveries).
+struct __attribute__((aligned(4))) bfs_u32x2 { u32 x, y; };   // 8-byte load at 4-byte alignment
+
 constexpr int BFS_BUILD_NT = 1024;
 constexpr int BFS_BUILD_VPB = 16 * BFS_BUILD_NT;      // vertices per workgroup
 constexpr int BFS_BUILD_LIST = 8 * BFS_BUILD_NT;      // discoveries appended per batch
 
-inline int bfs_build_grid(long long n_local) { return (int)((n_local + BFS_BUILD_VPB - 1) / BFS_BUILD_VPB); }
+inline int bfs_build_grid(long long n_local, int nt = BFS_BUILD_NT) { return (int)((n_local + 16 * nt - 1) / (16 * nt)); }
 
 template <int NT, bool FROM_MARKS>
 __global__ __launch_bounds__(NT) void k_bfs_build(bfs_fused_args_t a, int level, const u32* __restrict__ bits,
@@ -292,8 +294,9 @@ __global__ __launch_bounds__(NT) void k_bfs_build(bfs_fused_args_t a, int level,
     for (int q = 0; q < PER; ++q) {
       const int i = threadIdx.x * PER + q;
       li[q] = (i < cnt) ? st_v[i] : 0u;
-      ro[q] = a.row_offsets[li[q]];
-      ro1[q] = a.row_offsets[li[q] + 1];
+      const bfs_u32x2 ext = *(const bfs_u32x2*)(a.row_offsets + li[q]);     // both ends of the row in one 8-byte load
+      ro[q] = ext.x;
+      ro1[q] = ext.y;
       lab_at[q] = old_of_new ? old_of_new[li[q]] : (int)li[q];
     }
     u64 loc[PER];

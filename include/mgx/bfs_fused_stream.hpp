@@ -144,7 +144,7 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_stream(bfs_fused_args_t a
       for (int k = 0; k < EPT; ++k) {
         const u32 d = (u32)id[k];
         const u32 bit = 1u << (d & 31);
-        if ((u32)lane < nn[k]) {
+        if ((u32)lane < nn[k] && !(diag & 16)) {      // diag 16: stream only, no test
           bool is_new;
           if (d < hot_n) is_new = !(hot[d >> 5] & bit) && ((diag & 2) || !(atomicOr(&hot[d >> 5], bit) & bit));
           else is_new = COLDT ? !(cold_word[k] & bit) : true;

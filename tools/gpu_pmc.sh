@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over the push bench (k_bfs_push_level_hot): instruction mix and stall reasons
+# PMC passes over the push bench: instruction mix and stall reasons of the push kernels and the queue build
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc2; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -15,7 +15,8 @@ O=os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/pmc2'
 for f in sorted(glob.glob(O+'/p*/**/*counter_collection.csv', recursive=True)):
     agg=collections.Counter(); cnt=collections.Counter()
     for r in csv.DictReader(open(f)):
-        if 'push_level' in r['Kernel_Name']:
-            agg[r['Counter_Name']]+=float(r['Counter_Value']); cnt[r['Counter_Name']]+=1
-    for k in agg: print('%-24s total=%.4g dispatches=%d'%(k,agg[k],cnt[k]))
+        for kn in ('push_level_stream','push_level_wave','k_bfs_build'):
+            if kn in r['Kernel_Name']:
+                agg[(kn,r['Counter_Name'])]+=float(r['Counter_Value']); cnt[(kn,r['Counter_Name'])]+=1
+    for k in sorted(agg): print('%-18s %-24s total=%.4g dispatches=%d'%(k[0],k[1],agg[k],cnt[k]))
 PY
