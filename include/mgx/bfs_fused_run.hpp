@@ -39,6 +39,7 @@ inline void bfs_set_kernel_attributes() {
   MGX_SET_LDS((k_bfs_push_level_wave<1024, 18000, false>));
   MGX_SET_LDS((k_bfs_push_level_wave<1024, 18000, true>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false>));
+  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, true>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, true>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 16, false>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 16, false>));
@@ -74,6 +75,8 @@ inline void bfs_launch_stream(const bfs_fused_args_t& a, int level, standard_con
     hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 16, false>), dim3(ctx.num_cus), dim3(1024), lds1, s, a, level);
   else if (shape == 3)
     hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, false>), dim3(ctx.num_cus), dim3(1024), lds1, s, a, level);
+  else if (a.flags)     // MGX_BFS_FLAGS set: the instrumented build of the default shape
+    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, true>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
   else
     hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
 }

@@ -30,7 +30,8 @@ constexpr int BFS_STREAM_HOTW = 40896;     // words of the bitmap kept in LDS: 1
 
 constexpr size_t bfs_stream_lds_bytes(int hotw) { return (size_t)hotw * 4 + 64; }
 
-template <int NT, int HOTW, int EPT, bool COLDT>
+// DIAG: honour MGX_BFS_FLAGS (switch parts of the kernel off for measurements; results are then wrong by design).
+template <int NT, int HOTW, int EPT, bool COLDT, bool DIAG = false>
 __global__ __launch_bounds__(NT) void k_bfs_push_level_stream(bfs_fused_args_t a, int level) {
   constexpr int NW = NT / WAVE;
   static_assert(EPT + 2 <= WAVE, "round shape");
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_stream(bfs_fused_args_t a
   if (threadIdx.x == 0) s_int[0] = 0;
   __syncthreads();
 
-  const int diag = ((a.flags >> 8) == level) ? (a.flags & 255) : 0;   // MGX_BFS_FLAGS = level << 8 | bits
+  const int diag = (DIAG && (a.flags >> 8) == level) ? (a.flags & 255) : 0;   // MGX_BFS_FLAGS = level << 8 | bits
   int marks = 0;                 // per lane
 
   if (has_work) {
@@ -144,14 +145,15 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_stream(bfs_fused_args_t a
       for (int k = 0; k < EPT; ++k) {
         const u32 d = (u32)id[k];
         const u32 bit = 1u << (d & 31);
-        if ((u32)lane < nn[k] && !(diag & 16)) {      // diag 16: stream only, no test
-          bool is_new;
-          if (d < hot_n) is_new = !(hot[d >> 5] & bit) && ((diag & 2) || !(atomicOr(&hot[d >> 5], bit) & bit));
-          else is_new = COLDT ? !(cold_word[k] & bit) : true;
-          if (is_new) {
-            if (!(diag & 1)) mark[d] = 1;
-            ++marks;
-          }
+        const bool act = (u32)lane < nn[k] && !(diag & 16);       // diag 16: stream only, no test
+        const bool hotm = act && d < hot_n;
+        // every lane probes (the others word 0): two nested branches less than "if active, if hot" per sub-round
+        const u32 w = hot[hotm ? (d >> 5) : 0u];
+        bool is_new = act && !hotm && (COLDT ? !(cold_word[k] & bit) : true);
+        if (hotm && !(w & bit)) is_new = (diag & 2) || !(atomicOr(&hot[d >> 5], bit) & bit);
+        if (is_new) {
+          if (!(diag & 1)) mark[d] = 1;
+          ++marks;
         }
       }
     };
