@@ -104,7 +104,8 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_wave(bfs_fused_args_t a, 
       if (lane == 0) w_off[WAVE] = off64;
       u32 E1 = (r_end - E0 > (u32)BFS_WAVE_TILE) ? E0 + BFS_WAVE_TILE : r_end;
       if (off64 < E1) E1 = off64;                          // the 64 staged segments end here
-      const u32 nxt = w_off[lane + 1];                     // same-wave LDS traffic is ordered
+      wave_lds_fence();                                    // the reads below are of OTHER lanes' slots (wave.hpp)
+      const u32 nxt = w_off[lane + 1];
       const u64 m = __ballot(my < E1 && nxt >= E1);        // exactly one lane
       const int nseg = __ffsll((long long)m);              // 1..64
       const u32 next_off = w_off[nseg];
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_wave(bfs_fused_args_t a, 
       // to row x / d -- one multiply-high with a per-tile reciprocal instead of a 6-step search in LDS.
       const u32 off0 = w_off[0];
       const u32 d0 = w_off[1] - off0;
-      const bool uniform = __ballot(lane < nseg && (nxt - my) != d0) == 0ull;
+      const bool uniform = d0 < 64u && __ballot(lane < nseg && (nxt - my) != d0) == 0ull;   // (x < 4096: the reciprocal is exact)
       if (uniform) {
         const u32 recip = d0 > 1u ? 0xFFFFFFFFu / d0 + 1u : 0u;         // ceil(2^32 / d0); x < 64 * 64: exact
 #pragma unroll

@@ -1,0 +1,403 @@
+// mgx/sssp_fused.hpp -- device-resident SSSP (frontier Bellman-Ford, the reference's sssp_enactor_t loop,
+// sssp_enactor.hxx:40-72) without a host round trip per iteration and without the per-edge output frontier.
+//
+// The operator path (advance writing one slot per EDGE, then a compaction that reads them back; two size
+// read-backs per iteration) spends 7 ms of an 8.6 ms RMAT-22 run in the advance kernel.  Here an iteration is
+//   k_sssp_open    bookkeeping (one thread)
+//   k_sssp_relax   the frontier's edges, load-balanced per edge rank (wave-private, same scheme as
+//                  bfs_fused_wave.hpp); per edge: neighbour and weight (coalesced),
+//                  candidate = distance the row entered the frontier with + weight, one gather of the neighbour's
+//                  distance; only an improving candidate issues the atomicMin (on the integer view of the
+//                  non-negative float: order preserving, intrinsics.hxx:12-22 does a CAS loop) and stores mark[v] = 1
+//   k_sssp_build   sweep over the marks: marked vertices form the next frontier -- (row start, exclusive degree
+//                  scan, current distance) appended in batches with ONE packed 64-bit cursor atomic (bfs_fused.hpp);
+//                  marks are cleared on the way.  A vertex improved several times in an iteration enters once: the
+//                  reference's filter (stamp dedup, sssp_functor.hxx cond_filter) comes for free.
+// The fixpoint of min-plus relaxation is unique whatever the order of the relaxations (float addition is
+// monotone), so the distances are bit-identical to the reference algorithm's.  Predecessors are not maintained
+// (the reference's are racy); the operator path keeps them.
+#pragma once
+#include "bfs_fused.hpp"
+
+namespace mgx {
+
+struct sssp_args_t {
+  const u32* row_offsets;
+  const int* col_indices;
+  const float* weights;
+  u32* dist;             // float bits, n entries
+  unsigned char* mark;   // n bytes (+ padding)
+  u32* q_row[2];         // frontier queue: CSR row start
+  u32* q_off[2];         //                 exclusive degree scan
+  u32* q_du[2];          //                 distance (float bits) the vertex had when it was queued
+  bfs_ctrl_t* ctrl;      // cursor[3] (packed, rotating), sums, done, levels = iterations
+  int n;
+};
+
+constexpr u32 SSSP_INF_BITS = 0x7f7fffffu;      // FLT_MAX: what the reference stores for "not reached" (sssp_problem.hxx:45)
+
+__global__ __launch_bounds__(BLOCK) void k_sssp_init(sssp_args_t a, int src) {
+  const long long tid = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  const long long nth = (long long)gridDim.x * BLOCK;
+  const long long n = a.n;
+  for (long long i = tid; i < (n + 3) / 4; i += nth) {
+    const long long j = i * 4;
+    if (j + 4 <= n) {
+      *(uint4*)(a.dist + j) = make_uint4(src == j ? 0u : SSSP_INF_BITS, src == j + 1 ? 0u : SSSP_INF_BITS,
+                                         src == j + 2 ? 0u : SSSP_INF_BITS, src == j + 3 ? 0u : SSSP_INF_BITS);
+      *(u32*)(a.mark + j) = 0u;
+    } else {
+      for (long long k = j; k < n; ++k) { a.dist[k] = (k == src) ? 0u : SSSP_INF_BITS; a.mark[k] = 0; }
+    }
+  }
+  if (tid == 0) {
+    bfs_ctrl_reset(a.ctrl);
+    const u32 ro = a.row_offsets[src];
+    const u32 deg = a.row_offsets[src + 1] - ro;
+    a.q_row[0][0] = ro;
+    a.q_off[0][0] = 0;
+    a.q_du[0][0] = 0u;
+    a.ctrl->cursor[0] = deg ? ((1ull << BFS_VSHIFT) | (u64)deg) : 0ull;
+  }
+}
+
+__global__ void k_sssp_open(sssp_args_t a, int it) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  bfs_ctrl_t* const c = a.ctrl;
+  const u64 cur = c->cursor[it % 3];
+  c->cursor[(it + 2) % 3] = 0;
+  if (it < 64) c->stamp[it] = __builtin_amdgcn_s_memrealtime();
+  if ((cur >> BFS_VSHIFT) == 0) {
+    if (!c->done) { c->done = 1; c->levels = it; }
+    return;
+  }
+  if (it < BFS_MAX_TRACE) c->trace[it] = cur;
+  c->sum_edges += cur & BFS_EMASK;            // relaxations
+  c->sum_frontier += cur >> BFS_VSHIFT;
+}
+
+// debug only (MGX_SSSP_HOSTDBG & 8): consistency of the queue an iteration is about to read
+__global__ void k_sssp_check(sssp_args_t a, int it, long long m, unsigned long long* bad) {
+  const u64 cur = a.ctrl->cursor[it % 3];
+  const long long nf = (long long)(cur >> BFS_VSHIFT);
+  const u32 E = (u32)(cur & BFS_EMASK);
+  const u32* row = a.q_row[it & 1];
+  const u32* off = a.q_off[it & 1];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += (long long)gridDim.x * blockDim.x) {
+    const u32 o0 = off[i], o1 = (i + 1 < nf) ? off[i + 1] : E;
+    if (i == 0 && o0 != 0) atomicAdd(&bad[0], 1ull);
+    if (o1 <= o0) atomicAdd(&bad[1], 1ull);
+    else if ((long long)row[i] + (o1 - o0) > m) atomicAdd(&bad[2], 1ull);
+  }
+}
+
+constexpr int SSSP_EPT = 4;
+constexpr int SSSP_TILE = WAVE * SSSP_EPT;
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_sssp_relax(sssp_args_t a, int it) {
+  constexpr int NW = NT / WAVE;
+  constexpr int EPT = SSSP_EPT;
+  __shared__ u32 s_off[NW][68];
+  __shared__ u32 s_row[NW][64];
+  __shared__ u32 s_du[NW][64];
+  const int wave = threadIdx.x / WAVE;
+  const int lane = lane_id();
+  u32* const w_off = s_off[wave];
+  u32* const w_row = s_row[wave];
+  u32* const w_du = s_du[wave];
+
+  bfs_ctrl_t* const c = a.ctrl;
+  const u64 cur = c->cursor[it % 3];
+  const long long nf = (long long)(cur >> BFS_VSHIFT);
+  const u32 E = (u32)(cur & BFS_EMASK);
+  if (nf == 0) return;
+  const u32* __restrict__ fr_row = a.q_row[it & 1];
+  const u32* __restrict__ fr_off = a.q_off[it & 1];
+  const u32* __restrict__ fr_du = a.q_du[it & 1];
+  const int* __restrict__ col = a.col_indices;
+  const float* __restrict__ wts = a.weights;
+  u32* dist = a.dist;
+  unsigned char* mark = a.mark;
+
+  const u32 total_waves = gridDim.x * NW;
+  u32 per = (E + total_waves - 1) / total_waves;
+  per = (per + SSSP_TILE - 1) / SSSP_TILE * SSSP_TILE;
+  const u64 rb = (u64)(blockIdx.x * NW + wave) * per;
+  const bool has_work = rb < (u64)E;
+  const u32 r_begin = has_work ? (u32)rb : E;
+  const u32 r_end = (rb + per < (u64)E) ? (u32)(rb + per) : E;
+  if (has_work) {
+
+  long long seg = wave_upper_bound(fr_off, nf, r_begin) - 1;
+  u32 pf_off = 0, pf_row = 0, pf_du = 0, pf_off_last = 0;
+  bool pf_ok = false, pf_last_ok = false;
+  auto prefetch = [&](long long sg) {
+    const long long s0 = sg + lane;
+    const long long s1 = sg + WAVE;
+    pf_ok = s0 < nf;
+    pf_last_ok = s1 < nf;
+    pf_off = fr_off[pf_ok ? s0 : nf - 1];
+    pf_row = fr_row[pf_ok ? s0 : nf - 1];
+    pf_du = fr_du[pf_ok ? s0 : nf - 1];
+    pf_off_last = fr_off[pf_last_ok ? s1 : nf - 1];
+  };
+  prefetch(seg);
+
+  u32 eidxC[EPT], duC[EPT];
+  u32 actC = 0;
+  u32 e_next = r_begin;
+  auto prepare_tile = [&]() {
+    const u32 E0 = e_next;
+    const u32 my = pf_ok ? pf_off : E;
+    w_off[lane] = my;
+    w_row[lane] = pf_ok ? pf_row : 0u;
+    w_du[lane] = pf_du;
+    const u32 off64 = pf_last_ok ? pf_off_last : E;
+    if (lane == 0) w_off[WAVE] = off64;
+    wave_lds_fence();          // the reads below are of OTHER lanes' slots
+    u32 E1 = (r_end - E0 > (u32)SSSP_TILE) ? E0 + SSSP_TILE : r_end;
+    if (off64 < E1) E1 = off64;
+    const u32 nxt = w_off[lane + 1];
+    const u64 m = __ballot(my < E1 && nxt >= E1);
+    const int nseg = __ffsll((long long)m);
+    const u32 next_off = w_off[nseg];
+    const long long seg_next = seg + ((next_off == E1) ? nseg : nseg - 1);
+    prefetch(seg_next);
+    u32 r[EPT];
+    int sj[EPT];
+    actC = 0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const u32 rr = E0 + (u32)(k * WAVE + lane);
+      const bool act = rr < E1;
+      if (act) actC |= 1u << k;
+      r[k] = act ? rr : E0;
+      sj[k] = 0;
+    }
+    const u32 off0 = w_off[0];
+    const u32 d0 = w_off[1] - off0;
+    if (nseg > 1) {
+      int top = 1;
+      while (top * 2 < nseg) top *= 2;
+      for (int step = top; step > 0; step >>= 1) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+          const int j = sj[k] + step;
+          const u32 vv = w_off[j < nseg ? j : nseg - 1];
+          if (j < nseg && vv <= r[k]) sj[k] = j;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      eidxC[k] = w_row[sj[k]] + (r[k] - w_off[sj[k]]);
+      duC[k] = w_du[sj[k]];
+    }
+    seg = seg_next;
+    e_next = E1;
+  };
+
+  // three stages, all loads unconditional: tile t loads (neighbour, weight), tile t-1 gathers the neighbours'
+  // distances, tile t-2 is tested
+  int vA[EPT], vB[EPT];
+  u32 ndA[EPT], oldA[EPT], duB[EPT];
+  float wB[EPT];
+  u32 actA = 0, actB = 0;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) { vA[k] = 0; vB[k] = 0; ndA[k] = SSSP_INF_BITS; oldA[k] = 0; duB[k] = 0; wB[k] = 0.f; }
+  bool haveA = false, haveB = false, haveC = true;
+  prepare_tile();
+  while (haveA || haveB || haveC) {
+    if (haveA) {
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        if (((actA >> k) & 1u) && ndA[k] < oldA[k]) {
+          atomicMin(dist + vA[k], ndA[k]);
+          mark[vA[k]] = 1;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      vA[k] = vB[k];
+      ndA[k] = __float_as_uint(__uint_as_float(duB[k]) + wB[k]);
+    }
+    actA = haveB ? actB : 0u;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      u32 ei = haveC ? eidxC[k] : 0u;
+      vB[k] = col[ei];
+      wB[k] = wts[ei];
+      duB[k] = duC[k];
+    }
+    actB = haveC ? actC : 0u;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      oldA[k] = dist[vA[k]];
+    }
+    haveA = haveB;
+    haveB = haveC;
+    haveC = e_next < r_end;
+    if (haveC) prepare_tile();
+  }
+  }
+}
+
+// marked vertices -> next frontier; marks cleared.  16 vertices per thread, see k_bfs_build.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_sssp_build(sssp_args_t a, int it) {
+  constexpr int NW = NT / WAVE;
+  constexpr int LIST = 8 * NT;
+  constexpr int PER = LIST / NT;
+  constexpr u64 CNT1 = 1ull << 40;
+  constexpr u64 DEGMASK = CNT1 - 1ull;
+  __shared__ u32 st_v[LIST];
+  __shared__ u64 s_scan[NW + 1];
+  __shared__ u64 s_base;
+  bfs_ctrl_t* const c = a.ctrl;
+  if (c->done) return;
+  const long long i0 = (((long long)blockIdx.x + (long long)(threadIdx.x >> 6) * gridDim.x) * 64 + (threadIdx.x & 63)) * 16;
+  u32 new16 = 0;
+  if (i0 < a.n) {
+    const u32 valid = (a.n - i0 >= 16) ? 0xFFFFu : ((1u << (int)(a.n - i0)) - 1u);
+    uint4* mp = (uint4*)(a.mark + i0);
+    const uint4 m = *mp;
+    if (m.x | m.y | m.z | m.w) {
+      const u32 x[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) new16 |= (((x[q] & 0x01010101u) * 0x10204080u) >> 28) << (4 * q);
+      new16 &= valid;
+      *mp = make_uint4(0, 0, 0, 0);
+    }
+  }
+  u64 total64;
+  const u64 before = block_exclusive_sum_nw<NW>((u64)__popc(new16), s_scan, &total64);
+  const int total = (int)total64;
+  if (total == 0) return;
+  u64* const cur = &c->cursor[(it + 1) % 3];
+  u32* __restrict__ const out_row = a.q_row[(it + 1) & 1];
+  u32* __restrict__ const out_off = a.q_off[(it + 1) & 1];
+  u32* __restrict__ const out_du = a.q_du[(it + 1) & 1];
+  for (int first = 0; first < total; first += LIST) {
+    {
+      u32 rest = new16;
+      int at = (int)before - first;
+      while (rest) {
+        const int q = __ffs((int)rest) - 1;
+        rest &= rest - 1;
+        if (at >= 0 && at < LIST) st_v[at] = (u32)(i0 + q);
+        ++at;
+      }
+    }
+    __syncthreads();
+    const int cnt = (total - first < LIST) ? total - first : LIST;
+    u32 ro[PER], ro1[PER], du[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int i = threadIdx.x * PER + q;
+      const u32 v = (i < cnt) ? st_v[i] : 0u;
+      const bfs_u32x2 ext = *(const bfs_u32x2*)(a.row_offsets + v);
+      ro[q] = ext.x;
+      ro1[q] = ext.y;
+      du[q] = a.dist[v];
+    }
+    u64 loc[PER];
+    u64 sum = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int i = threadIdx.x * PER + q;
+      const u32 deg = (i < cnt) ? ro1[q] - ro[q] : 0u;
+      loc[q] = sum;
+      sum += deg ? (CNT1 | (u64)deg) : 0ull;
+    }
+    u64 tot;
+    const u64 ex = block_exclusive_sum_nw<NW>(sum, s_scan, &tot);
+    if (threadIdx.x == 0) s_base = (tot >> 40) ? atomicAdd(cur, ((tot >> 40) << BFS_VSHIFT) | (tot & DEGMASK)) : 0ull;
+    __syncthreads();
+    const u64 base = s_base;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int i = threadIdx.x * PER + q;
+      if (i < cnt && ro1[q] != ro[q]) {
+        const u64 at = ex + loc[q];
+        const u64 slot = (base >> BFS_VSHIFT) + (at >> 40);
+        out_row[slot] = ro[q];
+        out_off[slot] = (u32)((base & BFS_EMASK) + (at & DEGMASK));
+        out_du[slot] = du[q];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+struct sssp_fused_state_t {
+  mem_t<unsigned char> mark;
+  mem_t<u32> q_row[2], q_off[2], q_du[2];
+  mem_t<bfs_ctrl_t> ctrl;
+  bfs_ctrl_t* host_ctrl = nullptr;
+  int n = 0;
+  long long num_edges = 0;           // debug checks only
+  int iters_hint = 12;
+  sssp_fused_state_t(int num_nodes, standard_context_t& ctx) : n(num_nodes) {
+    mark = mem_t<unsigned char>((size_t)num_nodes + 64, ctx);
+    for (int i = 0; i < 2; ++i) {
+      q_row[i] = mem_t<u32>((size_t)num_nodes + 1, ctx);
+      q_off[i] = mem_t<u32>((size_t)num_nodes + 1, ctx);
+      q_du[i] = mem_t<u32>((size_t)num_nodes + 1, ctx);
+    }
+    ctrl = mem_t<bfs_ctrl_t>(1, ctx);
+    MGX_HIP(hipHostMalloc((void**)&host_ctrl, sizeof(bfs_ctrl_t), hipHostMallocDefault));
+  }
+  sssp_fused_state_t(const sssp_fused_state_t&) = delete;
+  sssp_fused_state_t& operator=(const sssp_fused_state_t&) = delete;
+  ~sssp_fused_state_t() { if (host_ctrl) (void)hipHostFree(host_ctrl); }
+};
+
+// Whole run from `src`; d_dist (n floats) holds the distances afterwards (+inf: unreachable is reported as the
+// reference does, see the caller).  Returns with the stream synchronised and host_ctrl filled.
+inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const int* col_indices, const float* weights,
+                           float* d_dist, int src, standard_context_t& ctx) {
+  hipStream_t s = ctx.stream();
+  sssp_args_t a;
+  a.row_offsets = (const u32*)row_offsets;
+  a.col_indices = col_indices;
+  a.weights = weights;
+  a.dist = (u32*)d_dist;
+  a.mark = st.mark.data();
+  for (int i = 0; i < 2; ++i) { a.q_row[i] = st.q_row[i].data(); a.q_off[i] = st.q_off[i].data(); a.q_du[i] = st.q_du[i].data(); }
+  a.ctrl = st.ctrl.data();
+  a.n = st.n;
+  hipLaunchKernelGGL(k_sssp_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src);
+  int it = 0;
+  for (int batch = 0;; ++batch) {
+    const int nit = batch == 0 ? st.iters_hint : 2;
+    for (int i = 0; i < nit; ++i, ++it) {
+      static const int hdbg = getenv("MGX_SSSP_HOSTDBG") ? atoi(getenv("MGX_SSSP_HOSTDBG")) : 0;
+      hipLaunchKernelGGL(k_sssp_open, dim3(1), dim3(64), 0, s, a, it);
+      if (hdbg & 1) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { fprintf(stderr, "fault after open it %d\n", it); MGX_HIP(e); } }
+      if (hdbg & 8) {
+        static unsigned long long* bad = nullptr;
+        if (!bad) MGX_HIP(hipMalloc((void**)&bad, 32));
+        MGX_HIP(hipMemsetAsync(bad, 0, 32, s));
+        hipLaunchKernelGGL(k_sssp_check, dim3(256), dim3(256), 0, s, a, it, st.num_edges, bad);
+        unsigned long long hb[4];
+        MGX_HIP(hipMemcpy(hb, bad, 32, hipMemcpyDeviceToHost));
+        u64 cur3[3];
+        MGX_HIP(hipMemcpy(cur3, st.ctrl.data(), sizeof(cur3), hipMemcpyDeviceToHost));
+        fprintf(stderr, "it %d queue nf %llu E %llu: off0!=0 %llu, non-increasing %llu, row out of range %llu\n", it,
+                (unsigned long long)(cur3[it % 3] >> BFS_VSHIFT), (unsigned long long)(cur3[it % 3] & BFS_EMASK), hb[0], hb[1], hb[2]);
+      }
+      hipLaunchKernelGGL(k_sssp_relax<1024>, dim3(ctx.num_cus * 2), dim3(1024), 0, s, a, it);
+      if (hdbg & 2) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { fprintf(stderr, "fault after relax it %d\n", it); MGX_HIP(e); } }
+      hipLaunchKernelGGL(k_sssp_build<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, it);
+      if (hdbg & 4) { hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) { fprintf(stderr, "fault after build it %d\n", it); MGX_HIP(e); } }
+    }
+    MGX_HIP(hipMemcpyAsync(st.host_ctrl, st.ctrl.data(), offsetof(bfs_ctrl_t, trace) + 64 * sizeof(u64), hipMemcpyDeviceToHost, s));
+    MGX_HIP(hipStreamSynchronize(s));
+    if (st.host_ctrl->done) break;
+  }
+  st.iters_hint = st.host_ctrl->levels + 1;
+}
+
+}  // namespace mgx

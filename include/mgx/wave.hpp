@@ -64,6 +64,16 @@ __device__ __forceinline__ T block_exclusive_sum(T x, T* smem, T* total) {
   return base + inc - x;
 }
 
+// Lanes of ONE wave exchanging data through LDS without a workgroup barrier: the hardware executes a wave's LDS
+// instructions in order, but the COMPILER reasons per thread -- a store to p[lane] and a load from p[lane + 1] do
+// not alias for it, and it may hoist the load above the store (seen: k_sssp_relax read stale row offsets and
+// faulted).  Call this between the writes and the reads of other lanes' slots.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Same for a workgroup of NW waves (any block size); `smem` needs NW slots of T.  Two barriers.
 template <int NW, typename T>
 __device__ __forceinline__ T block_exclusive_sum_nw(T x, T* smem, T* total) {

@@ -13,6 +13,7 @@
 #include "gunrock/sssp/sssp_enactor.hxx"
 #include "mgx/bfs_dist.hpp"
 #include "mgx/bfs_dist2.hpp"
+#include "mgx/sssp_fused.hpp"
 #include "mgx.h"
 
 using namespace gunrock;
@@ -47,6 +48,7 @@ struct mgx_sssp_s {
   std::shared_ptr<sssp::sssp_problem_t> p;
   std::unique_ptr<sssp::sssp_enactor_t> e;
   float e_sizing = 0.f;
+  std::unique_ptr<mgx::sssp_fused_state_t> fused;     // lazily: O(n)
 };
 struct mgx_pr_s {
   mgx_graph_s* g;
@@ -937,11 +939,27 @@ int mgx_sssp_enact(mgx_sssp_t p, float queue_sizing, int64_t* stats) {
   MGX_CATCH
 }
 int mgx_sssp_run(mgx_sssp_t p, int src, int64_t* stats) {
-  // first build: the whole-run entry point resets and drives the operator-per-superstep loop
-  // with queue_sizing 1.5 (tests/sssp/run.sh:1); a device-resident fused loop replaces it later.
+  // device-resident loop (include/mgx/sssp_fused.hpp): distances identical to mgx_sssp_enact's; predecessors are
+  // left at -1 (the reference's are racy, the operator path keeps them)
   int rc = mgx_sssp_reset(p, src);
   if (rc != MGX_OK) return rc;
-  return mgx_sssp_enact(p, 1.5f, stats);
+  MGX_TRY
+  use_device(p->g->c);
+  standard_context_t& ctx = *p->g->c->ctx;
+  graph_device_t& G = *p->g->g;
+  MGX_REQUIRE(G.d_col_values.size() >= (size_t)G.num_edges, "mgx_sssp_run: the graph has no weights");
+  check_weights(p->g);
+  MGX_REQUIRE(p->g->weights_ok, "mgx_sssp_run: negative or NaN weight");
+  if (!p->fused) p->fused.reset(new mgx::sssp_fused_state_t(G.num_nodes, ctx));
+  p->fused->num_edges = G.num_edges;
+  mgx::sssp_fused_run(*p->fused, G.d_row_offsets.data(), G.d_col_indices.data(), G.d_col_values.data(),
+                      p->p->d_labels.data(), src, ctx);
+  if (stats) {
+    stats[0] = p->fused->host_ctrl->levels;
+    stats[1] = (int64_t)p->fused->host_ctrl->sum_edges;
+    stats[2] = (int64_t)p->fused->host_ctrl->sum_frontier;
+  }
+  MGX_CATCH
 }
 
 // ---- PR ------------------------------------------------------------------------------------

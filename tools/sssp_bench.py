@@ -23,7 +23,18 @@ for s in srcs[1:]:
     print("src %d: iterations %d relaxations %d frontier_total %d  %.3f ms  %.1f MTEPS  alg %.1f GB/s" % (
         s, st["iterations"], st["relaxations"], st["frontier_total"], dt * 1e3, st["relaxations"] / dt / 1e6,
         (12.0 * st["relaxations"] + 24.0 * st["frontier_total"]) / dt / 1e9))
-print("SSSP RMAT-%d: %.1f MTEPS (relaxations/s) over %d sources, %.3f ms per source" % (a.scale, tot_relax / tot_t / 1e6, a.runs, tot_t / a.runs * 1e3))
+print("SSSP RMAT-%d operator path: %.1f MTEPS (relaxations/s) over %d sources, %.3f ms per source" % (a.scale, tot_relax / tot_t / 1e6, a.runs, tot_t / a.runs * 1e3))
+op_dist = sssp.distances()
+sssp.run(srcs[0])
+tot_t, tot_relax = 0.0, 0
+for s in srcs[1:]:
+    ctx.synchronize()
+    t0 = time.perf_counter(); st = sssp.run(s); ctx.synchronize(); dt = time.perf_counter() - t0
+    tot_t += dt; tot_relax += st["relaxations"]
+    print("fused src %d: iterations %d relaxations %d frontier_total %d  %.3f ms  %.1f MTEPS" % (
+        s, st["iterations"], st["relaxations"], st["frontier_total"], dt * 1e3, st["relaxations"] / dt / 1e6))
+print("SSSP RMAT-%d fused loop: %.1f MTEPS (relaxations/s) over %d sources, %.3f ms per source; distances == operator path: %s" % (
+    a.scale, tot_relax / tot_t / 1e6, a.runs, tot_t / a.runs * 1e3, bool(np.array_equal(sssp.distances(), op_dist))))
 if a.check:
     from tests.oracle_binding import Oracle
     orc = Oracle(); ci = g["col_indices"].cpu().numpy(); w = g["weights"].cpu().numpy()
