@@ -951,7 +951,6 @@ int mgx_sssp_run(mgx_sssp_t p, int src, int64_t* stats) {
   check_weights(p->g);
   MGX_REQUIRE(p->g->weights_ok, "mgx_sssp_run: negative or NaN weight");
   if (!p->fused) p->fused.reset(new mgx::sssp_fused_state_t(G.num_nodes, ctx));
-  p->fused->num_edges = G.num_edges;
   mgx::sssp_fused_run(*p->fused, G.d_row_offsets.data(), G.d_col_indices.data(), G.d_col_values.data(),
                       p->p->d_labels.data(), src, ctx);
   if (stats) {

@@ -178,6 +178,8 @@ def test_reference_fixtures_bfs_and_sssp(gpu_ctx, oracle, case):
         assert np.all(dist[~reach] == FLT_MAX)
         if "sssp_dist" in case:
             assert dist.tolist() == [float(x) for x in case["sssp_dist"]]
+        sssp.run(0)                                                   # the fused device-resident loop: same fixed point
+        assert np.array_equal(sssp.distances(), dist)
 
 
 # ---- operators, one superstep at a time --------------------------------------------------------
@@ -392,6 +394,26 @@ def test_bfs_long_chain_many_levels(gpu_ctx, oracle, monkeypatch, small_max):
     assert np.array_equal(bfs.labels(), np.arange(n, dtype=np.int32))
     assert st["levels"] == n          # frontiers at depth 0..n-1 all expand an edge
     assert st["small_levels"] == (n if small_max else 0)
+
+
+def test_sssp_fused_float_weights_and_big_frontiers(gpu_ctx, oracle, rmat_graphs):
+    """fused SSSP loop on RMAT-16 (frontiers of several thousand marked vertices per workgroup: the queue build
+    runs more than one batch) with NON-integer weights: the min-plus fixed point is unique, so distances are
+    bit-identical to Dijkstra's in float32 (oracle.sssp_dijkstra_f32)."""
+    import mini_amd
+    from mini_amd import rmat
+    n, ro, ci, w = rmat_graphs[16]
+    rng = np.random.default_rng(7)
+    wf = (rng.random(len(ci), dtype=np.float32) * 9.0 + 0.125).astype(np.float32)
+    g = _graph(gpu_ctx, ro, ci, wf)
+    sssp = mini_amd.SsspProblem(g, 0)
+    for src in [int(np.argmax(np.diff(ro)))] + rmat.pick_sources(ro, 2, 1234):
+        st = sssp.run(src)
+        want = oracle.sssp_dijkstra_f32(ro, ci, wf, src)
+        got = sssp.distances()
+        fin = want < FLT_MAX
+        assert np.array_equal(got[fin], want[fin]) and np.all(got[~fin] == FLT_MAX), "src=%d" % src
+        assert st["iterations"] >= 1 and st["relaxations"] >= int(np.diff(ro)[src])
 
 
 @pytest.mark.parametrize("scale", [8, 10, 13])
