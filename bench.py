@@ -56,12 +56,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    # Pre-flight switches for a one-GPU box (never a reported number): MGX_BENCH_ALL_ON_GPU0=1 puts every rank on
+    # cuda:0, MGX_BENCH_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one device)
+    if os.environ.get("MGX_BENCH_ALL_ON_GPU0") == "1":
+        local_rank = 0
+    backend = os.environ.get("MGX_BENCH_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     # MGX_BENCH_FORCE_DIST=1 under a one-rank torchrun: run the N>1 code path (RCCL group of one) -- a
     # pre-flight for the multi-GPU bench on a one-GPU box, never a reported number
     force_dist = os.environ.get("MGX_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
     if world > 1 or force_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__ as ge
     if rank == 0 and not os.path.exists(ge.LIB_OUT):

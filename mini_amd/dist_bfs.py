@@ -398,7 +398,7 @@ def bench_main(args, rank, world, local_rank):
         torch.cuda.synchronize()
         t_build = time.time() - t_build
         eng = HipRankEngine2(ctx, n, world, rank, ro, col)
-        bfs = DistBfs2(eng, rank, world, "cuda")
+        bfs = DistBfs2(eng, rank, world, "cuda" if dist.get_backend() == "nccl" else "cpu")
         from .rmat import _mix64_py
         sources, i, deg_host = [], 0, None
         cand = [int(_mix64_py(seed + k) % n) for k in range(8 * (args.steps + args.warmup) + 64)]
@@ -446,7 +446,7 @@ def bench_main(args, rank, world, local_rank):
                                       "%d seeded sources" % (gscale, args.scale, args.edgefactor, world, args.steps),
                           "scale": gscale, "edgefactor": args.edgefactor, "seed": seed,
                           "parallelism": "vertex-cyclic x%d" % world},
-               "roofline": {"bound": "hbm", "kernel": "k_bfs_push_level_wave (per rank)",
+               "roofline": {"bound": "hbm", "kernel": "k_bfs_push_level_stream + k_bfs_push_level_wave (per rank)",
                             "achieved": round(8.0 * m_t / world / elapsed / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
                             "frac": round(8.0 * m_t / world / elapsed / 1e9 / 8000.0, 5), "traffic": None,
                             "note": "per-GPU algorithmic bytes (8 B/edge) over the whole superstep loop incl. exchange"},
