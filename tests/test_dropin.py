@@ -1,4 +1,4 @@
-"""Drop-in boundary: the reference's own BFS/SSSP/PR enactors, problems, functors and test
+"""Drop-in boundary: the reference's own BFS/SSSP/PR (and k-core) enactors, problems, functors and test
 drivers, unmodified, compiled against this repo's operator headers (tests/dropin/build_dropin.sh)."""
 import os
 import subprocess
@@ -13,7 +13,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 @pytest.mark.skipif(not os.path.isdir("/root/reference/gunrock/src"), reason="reference tree not present")
 def test_reference_sources_compile_unchanged_against_our_operator_headers():
     subprocess.check_call(["bash", os.path.join(ROOT, "tests", "dropin", "build_dropin.sh")])
-    for t in ("bfs", "sssp", "pr"):
+    for t in ("bfs", "sssp", "pr", "kcore"):
         assert os.path.exists(os.path.join(BIN, "ref_test_" + t))
 
 
@@ -45,3 +45,14 @@ def test_reference_sssp_and_pr_drivers_run_on_our_operators():
     assert r.returncode == 0, r.stderr
     r = _run("ref_test_pr", "--file=" + os.path.join(GOLD, "pr_test.mtx"), "--max_iter=5")
     assert r.returncode == 0 and "finished iteration:0" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture", ["kcore_test.mtx", "bfs_test.mtx"])
+def test_reference_kcore_driver_validates_on_our_operators(fixture):
+    """k-core is outside the hot-path scope but free coverage: test_kcore.cu drives filter with three
+    functors and a has_output=false advance whose functor does atomicAdd, then compares core numbers with the
+    reference's own CPU routine (kcore_problem.hxx:54-105)."""
+    r = _run("ref_test_kcore", "--file=" + os.path.join(GOLD, fixture))
+    assert r.returncode == 0, r.stderr
+    assert "Correct." in r.stdout and "Validation Error" not in r.stdout, r.stdout
