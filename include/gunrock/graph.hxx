@@ -64,6 +64,8 @@ struct graph_device_t {
   // arrays above; results are always reported in original ids.
   mem_t<int> d_layout_row_offsets;
   mem_t<int> d_layout_col_indices;
+  mem_t<float> d_layout_col_values;   // optional: weights in layout order (fused SSSP)
+  bool has_layout_weights = false;
   mem_t<int> d_new_of_old;
   mem_t<int> d_old_of_new;
   bool has_layout = false;

@@ -75,6 +75,9 @@ MGX_API int mgx_graph_wrap_device(mgx_ctx_t ctx, int num_nodes, int64_t num_edge
  * Results (labels) are always in original ids; the operator entry points ignore the layout.   */
 MGX_API int mgx_graph_attach_layout(mgx_graph_t g, const int* d_layout_row_offsets, const int* d_layout_col_indices,
                                     const int* d_new_of_old, const int* d_old_of_new);
+/* weights of the layout's edges, in the layout's order (optional): mgx_sssp_run then relaxes in layout space, where
+ * the distances of the high-degree vertices -- the targets of most relaxations -- sit together in L2 */
+MGX_API int mgx_graph_attach_layout_weights(mgx_graph_t g, const float* d_layout_weights);
 MGX_API int mgx_graph_free(mgx_graph_t g);
 MGX_API int mgx_graph_dims(mgx_graph_t g, int* num_nodes, int64_t* num_edges);
 /* host-side MTX text loader, bug-compatible with load_graph (graph.hxx:96-223): row = 2nd

@@ -37,9 +37,20 @@ struct sssp_args_t {
   int n;
 };
 
+// layout (optional): hub-first relabelled CSR with its weights and the two id maps; distances are reported in
+// original ids either way
+struct sssp_layout_t {
+  const int* row_offsets = nullptr;
+  const int* col_indices = nullptr;
+  const float* weights = nullptr;
+  const int* new_of_old = nullptr;
+  const int* old_of_new = nullptr;
+};
+
 constexpr u32 SSSP_INF_BITS = 0x7f7fffffu;      // FLT_MAX: what the reference stores for "not reached" (sssp_problem.hxx:45)
 
-__global__ __launch_bounds__(BLOCK) void k_sssp_init(sssp_args_t a, int src) {
+__global__ __launch_bounds__(BLOCK) void k_sssp_init(sssp_args_t a, int src, const int* __restrict__ new_of_old) {
+  if (new_of_old) src = new_of_old[src];               // the loop runs in layout space
   const long long tid = (long long)blockIdx.x * BLOCK + threadIdx.x;
   const long long nth = (long long)gridDim.x * BLOCK;
   const long long n = a.n;
@@ -319,8 +330,16 @@ __global__ __launch_bounds__(NT) void k_sssp_build(sssp_args_t a, int it) {
   }
 }
 
+// dist_out[old_of_new[v]] = dist_layout[v]
+__global__ __launch_bounds__(BLOCK) void k_sssp_unpermute(const u32* __restrict__ dist_layout, const int* __restrict__ old_of_new,
+                                                         u32* __restrict__ dist_out, long long n) {
+  for (long long v = (long long)blockIdx.x * BLOCK + threadIdx.x; v < n; v += (long long)gridDim.x * BLOCK)
+    dist_out[old_of_new[v]] = dist_layout[v];
+}
+
 struct sssp_fused_state_t {
   mem_t<unsigned char> mark;
+  mem_t<u32> dist_layout;            // only with a layout: distances in layout order
   mem_t<u32> q_row[2], q_off[2], q_du[2];
   mem_t<bfs_ctrl_t> ctrl;
   bfs_ctrl_t* host_ctrl = nullptr;
@@ -328,6 +347,7 @@ struct sssp_fused_state_t {
   int iters_hint = 12;
   sssp_fused_state_t(int num_nodes, standard_context_t& ctx) : n(num_nodes) {
     mark = mem_t<unsigned char>((size_t)num_nodes + 64, ctx);
+    dist_layout = mem_t<u32>((size_t)num_nodes + 4, ctx);
     for (int i = 0; i < 2; ++i) {
       q_row[i] = mem_t<u32>((size_t)num_nodes + 1, ctx);
       q_off[i] = mem_t<u32>((size_t)num_nodes + 1, ctx);
@@ -344,18 +364,19 @@ struct sssp_fused_state_t {
 // Whole run from `src`; d_dist (n floats) holds the distances afterwards (+inf: unreachable is reported as the
 // reference does, see the caller).  Returns with the stream synchronised and host_ctrl filled.
 inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const int* col_indices, const float* weights,
-                           float* d_dist, int src, standard_context_t& ctx) {
+                           float* d_dist, int src, standard_context_t& ctx, const sssp_layout_t* layout = nullptr) {
   hipStream_t s = ctx.stream();
   sssp_args_t a;
-  a.row_offsets = (const u32*)row_offsets;
-  a.col_indices = col_indices;
-  a.weights = weights;
-  a.dist = (u32*)d_dist;
+  a.row_offsets = (const u32*)(layout ? layout->row_offsets : row_offsets);
+  a.col_indices = layout ? layout->col_indices : col_indices;
+  a.weights = layout ? layout->weights : weights;
+  a.dist = layout ? st.dist_layout.data() : (u32*)d_dist;
   a.mark = st.mark.data();
   for (int i = 0; i < 2; ++i) { a.q_row[i] = st.q_row[i].data(); a.q_off[i] = st.q_off[i].data(); a.q_du[i] = st.q_du[i].data(); }
   a.ctrl = st.ctrl.data();
   a.n = st.n;
-  hipLaunchKernelGGL(k_sssp_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src);
+  hipLaunchKernelGGL(k_sssp_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src,
+                     layout ? layout->new_of_old : (const int*)nullptr);
   int it = 0;
   for (int batch = 0;; ++batch) {
     const int nit = batch == 0 ? st.iters_hint : 2;
@@ -369,6 +390,11 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
     if (st.host_ctrl->done) break;
   }
   st.iters_hint = st.host_ctrl->levels + 1;
+  if (layout) {
+    hipLaunchKernelGGL(k_sssp_unpermute, dim3(grid_for(st.n, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, st.dist_layout.data(),
+                       layout->old_of_new, (u32*)d_dist, (long long)st.n);
+    MGX_HIP(hipStreamSynchronize(s));
+  }
 }
 
 }  // namespace mgx

@@ -88,11 +88,14 @@ class Graph:
                                         _dev_ptr(row_indices), _dev_ptr(row_weights), C.byref(h)))
         return cls(ctx, h, keepalive=(row_offsets, col_indices, weights, col_offsets, row_indices, row_weights))
 
-    def attach_layout(self, layout_row_offsets, layout_col_indices, new_of_old, old_of_new):
-        """Hub-first (degree-descending) relabelled CSR + id maps for the fused traversal (device tensors)."""
+    def attach_layout(self, layout_row_offsets, layout_col_indices, new_of_old, old_of_new, layout_weights=None):
+        """Hub-first (degree-descending) relabelled CSR + id maps for the fused traversals (device tensors);
+        layout_weights (optional, the layout's edge order) lets the fused SSSP loop run in layout space too."""
         check(lib.mgx_graph_attach_layout(self._h, _dev_ptr(layout_row_offsets), _dev_ptr(layout_col_indices),
                                           _dev_ptr(new_of_old), _dev_ptr(old_of_new)))
-        self._layout = (layout_row_offsets, layout_col_indices, new_of_old, old_of_new)
+        if layout_weights is not None:
+            check(lib.mgx_graph_attach_layout_weights(self._h, _dev_ptr(layout_weights)))
+        self._layout = (layout_row_offsets, layout_col_indices, new_of_old, old_of_new, layout_weights)
         return self
 
     def close(self):

@@ -293,6 +293,15 @@ int mgx_graph_attach_layout(mgx_graph_t g, const int* d_row_offsets, const int* 
   G.has_layout = true;
   MGX_CATCH
 }
+int mgx_graph_attach_layout_weights(mgx_graph_t g, const float* d_layout_weights) {
+  MGX_TRY
+  MGX_REQUIRE(g && d_layout_weights, "mgx_graph_attach_layout_weights: NULL argument");
+  MGX_REQUIRE(g->g->has_layout, "mgx_graph_attach_layout_weights: attach the layout first");
+  graph_device_t& G = *g->g;
+  G.d_layout_col_values = mem_t<float>::borrow((float*)d_layout_weights, (size_t)G.num_edges);
+  G.has_layout_weights = true;
+  MGX_CATCH
+}
 int mgx_graph_free(mgx_graph_t g) {
   MGX_TRY
   if (g) { use_device(g->c); delete g; }
@@ -951,8 +960,16 @@ int mgx_sssp_run(mgx_sssp_t p, int src, int64_t* stats) {
   check_weights(p->g);
   MGX_REQUIRE(p->g->weights_ok, "mgx_sssp_run: negative or NaN weight");
   if (!p->fused) p->fused.reset(new mgx::sssp_fused_state_t(G.num_nodes, ctx));
+  mgx::sssp_layout_t layout;
+  if (G.has_layout && G.has_layout_weights) {
+    layout.row_offsets = G.d_layout_row_offsets.data();
+    layout.col_indices = G.d_layout_col_indices.data();
+    layout.weights = G.d_layout_col_values.data();
+    layout.new_of_old = G.d_new_of_old.data();
+    layout.old_of_new = G.d_old_of_new.data();
+  }
   mgx::sssp_fused_run(*p->fused, G.d_row_offsets.data(), G.d_col_indices.data(), G.d_col_values.data(),
-                      p->p->d_labels.data(), src, ctx);
+                      p->p->d_labels.data(), src, ctx, layout.row_offsets ? &layout : nullptr);
   if (stats) {
     stats[0] = p->fused->host_ctrl->levels;
     stats[1] = (int64_t)p->fused->host_ctrl->sum_edges;

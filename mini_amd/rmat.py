@@ -68,10 +68,11 @@ def rmat_csr(ctx, scale, edgefactor=16, seed=None, weighted=False, scramble=True
     return {"n": n, "m": int(ci.numel()), "row_offsets": ro, "col_indices": ci, "weights": weights}
 
 
-def degree_order(row_offsets, col_indices):
+def degree_order(row_offsets, col_indices, weights=None):
     """Hub-first layout of a CSR (device tensors): vertex ids renumbered by descending degree (stable).
 
-    Returns (layout_row_offsets, layout_col_indices, new_of_old, old_of_new), all int32 on the device.
+    Returns (layout_row_offsets, layout_col_indices, new_of_old, old_of_new), all int32 on the device --
+    plus the weights in the layout's edge order when `weights` is given.
     Setup plumbing (untimed graph construction, like the CSR build itself); rows stay sorted by
     (new) neighbour id.
     """
@@ -84,12 +85,14 @@ def degree_order(row_offsets, col_indices):
     rows_old = torch.repeat_interleave(torch.arange(n, device=ro.device), deg)
     key = (new_of_old[rows_old] << 32) | new_of_old[col_indices.to(torch.int64)]
     del rows_old
-    key, _ = torch.sort(key)
+    key, order = torch.sort(key)
     lcol = (key & 0xFFFFFFFF).to(torch.int32)
-    del key
+    lw = weights[order] if weights is not None else None
+    del key, order
     lro = torch.zeros(n + 1, dtype=torch.int64, device=ro.device)
     torch.cumsum(deg[old_of_new], 0, out=lro[1:])
-    return lro.to(torch.int32), lcol, new_of_old.to(torch.int32), old_of_new.to(torch.int32)
+    out = (lro.to(torch.int32), lcol, new_of_old.to(torch.int32), old_of_new.to(torch.int32))
+    return out + (lw,) if weights is not None else out
 
 
 def pick_sources(row_offsets_host, count, seed):

@@ -442,6 +442,15 @@ def test_sssp_rmat_parity(gpu_ctx, oracle, rmat_graphs, scale):
         st2 = sssp.run(src)
         assert np.array_equal(sssp.distances(), want)
         assert st2["iterations"] >= 1
+    # the fused loop in layout space (hub-first ids, weights permuted with the edges): distances come back in
+    # original ids and equal the oracle's
+    import torch
+    d_ro, d_ci, d_w = torch.from_numpy(ro).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(w).cuda()
+    g.attach_layout(*rmat.degree_order(d_ro, d_ci, d_w))
+    for src in [int(np.argmax(np.diff(ro)))] + rmat.pick_sources(ro, 2, scale + 100):
+        want, _, _ = oracle.sssp_enact(ro, ci, w, src, 1.5)
+        sssp.run(src)
+        assert np.array_equal(sssp.distances(), want), "layout src=%d" % src
 
 
 def test_pr_matches_oracle(gpu_ctx, oracle, rmat_graphs):

@@ -25,6 +25,8 @@ for s in srcs[1:]:
         (12.0 * st["relaxations"] + 24.0 * st["frontier_total"]) / dt / 1e9))
 print("SSSP RMAT-%d operator path: %.1f MTEPS (relaxations/s) over %d sources, %.3f ms per source" % (a.scale, tot_relax / tot_t / 1e6, a.runs, tot_t / a.runs * 1e3))
 op_dist = sssp.distances()
+if os.environ.get("MGX_SSSP_LAYOUT", "1") != "0":
+    graph.attach_layout(*rmat.degree_order(g["row_offsets"], g["col_indices"], g["weights"]))
 sssp.run(srcs[0])
 tot_t, tot_relax = 0.0, 0
 for s in srcs[1:]:
