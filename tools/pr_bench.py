@@ -22,3 +22,17 @@ print("max rel err vs torch index_add: %.3g" % float(((red - want).abs() / want.
 pr = mini_amd.PrProblem(graph, a.iters)
 t0 = time.perf_counter(); lens = pr.enact(); ctx.synchronize(); dt = time.perf_counter() - t0
 print("pr enact %d iterations: %.3f ms (%s)" % (len(lens), dt * 1e3, lens))
+# The same operators on the hub-first relabelled copy of the graph (a plain CSR as far as they are concerned): the
+# value gather then finds the hubs' values -- the targets of most edges -- next to each other in L2.
+lro, lci, new_of_old, old_of_new = rmat.degree_order(g["row_offsets"], g["col_indices"])
+lgraph = mini_amd.Graph.from_device(ctx, g["n"], g["m"], lro, lci)
+lvals = vals[old_of_new.long()].contiguous()
+lred = torch.empty(g["n"], device="cuda")
+mini_amd.segreduce(lgraph, f, lvals, 0.0, lred, "f32_plus"); ctx.synchronize()
+for _ in range(3):
+    t0 = time.perf_counter(); nz = mini_amd.segreduce(lgraph, f, lvals, 0.0, lred, "f32_plus"); ctx.synchronize(); dt = time.perf_counter() - t0
+    print("hub-first copy: segreduce f32_plus all vertices: %d edges %.3f ms  %.1f GTEPS  alg %.1f GB/s" % (nz, dt * 1e3, nz / dt / 1e9, (8.0 * nz + 16.0 * g["n"]) / dt / 1e9))
+print("hub-first copy: max rel err vs original order: %.3g" % float(((lred[new_of_old.long()] - want).abs() / want.abs().clamp(min=1)).max()))
+lpr = mini_amd.PrProblem(lgraph, a.iters)
+t0 = time.perf_counter(); lens = lpr.enact(); ctx.synchronize(); dt = time.perf_counter() - t0
+print("hub-first copy: pr enact %d iterations: %.3f ms (%s)" % (len(lens), dt * 1e3, lens))
