@@ -55,8 +55,10 @@ inline bool bfs_cold_test(int n) {
   return (long long)n >= 8ll * 32 * BFS_STREAM_HOTW;
 }
 
-// (16-byte-per-lane reads of aligned 256-edge windows were tried for this kernel and measured slower: 205-245 us
-// for the big RMAT-22 level against 165 us -- the kernel is not bound by the number of load instructions.)
+// (16-byte-per-lane reads -- sub-rounds of 256 consecutive edges of a row, aligned windows or not -- were tried
+// twice and measured slower: 190-245 us for the big RMAT-22 level against 160-165 us.  Rows of 64..255 edges then
+// fill a quarter to all of a sub-round but pay for all of it; neither the number of load instructions nor the
+// scalar walk is what bounds this kernel.)
 // Stream-kernel shapes (MGX_BFS_STREAM_SHAPE), measured on RMAT-22 (stream kernel of the big level / whole BFS):
 //   0 (default) 2 workgroups x 1024 threads per CU = 32 waves, 80 KB of bitmap each, 8 loads per lane: 167 us / 0.66 ms
 //   1           the same with 16 loads per lane:                                                         190 us / 0.68 ms
