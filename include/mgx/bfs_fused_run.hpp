@@ -37,9 +37,11 @@ inline void bfs_set_kernel_attributes() {
   MGX_SET_LDS((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, false>));
   MGX_SET_LDS((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, true>));
   MGX_SET_LDS((k_bfs_push_level_wave<1024, 18000, false>));
+  MGX_SET_LDS((k_bfs_push_level_wave<1024, 18000, false, true>));
   MGX_SET_LDS((k_bfs_push_level_wave<1024, 18000, true>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, true>));
+  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, false, true>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, true>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 16, false>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 16, false>));
@@ -60,7 +62,8 @@ inline bool bfs_cold_test(int n) {
 // fill a quarter to all of a sub-round but pay for all of it; neither the number of load instructions nor the
 // scalar walk is what bounds this kernel.)
 // Stream-kernel shapes (MGX_BFS_STREAM_SHAPE), measured on RMAT-22 (stream kernel of the big level / whole BFS):
-//   0 (default) 2 workgroups x 1024 threads per CU = 32 waves, 80 KB of bitmap each, 8 loads per lane: 167 us / 0.66 ms
+//   0 (default) 2 workgroups x 1024 threads per CU = 32 waves, 80 KB of bitmap each, 8 non-temporal loads per lane
+//               (167 us / 0.66 ms when the shapes were compared)
 //   1           the same with 16 loads per lane:                                                         190 us / 0.68 ms
 //   2           1 workgroup per CU (16 waves), 160 KB of bitmap, 16 loads per lane:                      213 us / 0.69 ms
 //   3           the same with 8 loads per lane:                                                          217 us / 0.71 ms
@@ -79,8 +82,10 @@ inline void bfs_launch_stream(const bfs_fused_args_t& a, int level, standard_con
     hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, false>), dim3(ctx.num_cus), dim3(1024), lds1, s, a, level);
   else if (a.flags)     // MGX_BFS_FLAGS set: the instrumented build of the default shape
     hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, true>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
-  else
+  else if (shape == 8)      // default shape with ordinary (cached) col_indices loads: 0.582 vs 0.565 ms per traversal
     hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
+  else                      // col_indices are read once: non-temporal loads leave L2 to the bitmap, marks and queues
+    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, false, true>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
 }
 
 // Wave-kernel shapes (MGX_BFS_WAVE_SHAPE): 1 (default) 2 x 1024 threads per CU = 32 waves (the kernel needs ~45
@@ -96,6 +101,7 @@ inline void bfs_launch_wave(const bfs_fused_args_t& a, int level, standard_conte
   } else {
     const size_t lds = bfs_wave_lds_bytes(1024, 18000);
     if (cold) hipLaunchKernelGGL((k_bfs_push_level_wave<1024, 18000, true>), dim3(ctx.num_cus * 2), dim3(1024), lds, s, a, level);
+    else if (shape == 3) hipLaunchKernelGGL((k_bfs_push_level_wave<1024, 18000, false, true>), dim3(ctx.num_cus * 2), dim3(1024), lds, s, a, level);
     else hipLaunchKernelGGL((k_bfs_push_level_wave<1024, 18000, false>), dim3(ctx.num_cus * 2), dim3(1024), lds, s, a, level);
   }
 }

@@ -31,7 +31,7 @@ constexpr int BFS_STREAM_HOTW = 40896;     // words of the bitmap kept in LDS: 1
 constexpr size_t bfs_stream_lds_bytes(int hotw) { return (size_t)hotw * 4 + 64; }
 
 // DIAG: honour MGX_BFS_FLAGS (switch parts of the kernel off for measurements; results are then wrong by design).
-template <int NT, int HOTW, int EPT, bool COLDT, bool DIAG = false>
+template <int NT, int HOTW, int EPT, bool COLDT, bool DIAG = false, bool NTLOAD = false>
 __global__ __launch_bounds__(NT) void k_bfs_push_level_stream(bfs_fused_args_t a, int level) {
   constexpr int NW = NT / WAVE;
   static_assert(EPT + 2 <= WAVE, "round shape");
@@ -135,7 +135,8 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_stream(bfs_fused_args_t a
 #pragma unroll
       for (int k = 0; k < EPT; ++k) {
         const int* __restrict__ p = col + baseL[k];            // uniform base, 32-bit lane offset
-        idL[k] = p[((u32)lane < nL[k]) ? (u32)lane : 0u];
+        idL[k] = NTLOAD ? __builtin_nontemporal_load(p + (((u32)lane < nL[k]) ? (u32)lane : 0u))
+                        : p[((u32)lane < nL[k]) ? (u32)lane : 0u];
       }
     };
     // test one round.  A hot miss claims the bit in the LDS copy (the bitmap + this workgroup's own marks): exact

@@ -27,7 +27,7 @@ constexpr size_t bfs_wave_lds_bytes(int nt, int hotw) {
   return (size_t)hotw * 4 + (size_t)(nt / 64) * BFS_WAVE_LDS_PER_WAVE + 64;
 }
 
-template <int NT, int HOTW, bool COLDT>
+template <int NT, int HOTW, bool COLDT, bool NTLOAD = false>
 __global__ __launch_bounds__(NT) void k_bfs_push_level_wave(bfs_fused_args_t a, int level) {
   constexpr int NW = NT / WAVE;
   constexpr int EPT = BFS_WAVE_EPT;
@@ -186,7 +186,8 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_wave(bfs_fused_args_t a, 
       for (int k = 0; k < EPT; ++k) dstA[k] = dstB[k];
       actA = haveB ? actB : 0u;
 #pragma unroll
-      for (int k = 0; k < EPT; ++k) dstB[k] = a.col_indices[haveC ? eidxC[k] : 0u];
+      for (int k = 0; k < EPT; ++k)
+        dstB[k] = NTLOAD ? __builtin_nontemporal_load(a.col_indices + (haveC ? eidxC[k] : 0u)) : a.col_indices[haveC ? eidxC[k] : 0u];
       actB = haveC ? actC : 0u;
       if constexpr (COLDT) {
 #pragma unroll
