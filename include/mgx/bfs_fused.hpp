@@ -305,7 +305,7 @@ __global__ __launch_bounds__(NT) void k_bfs_build(bfs_fused_args_t a, int level,
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
       const int i = threadIdx.x * PER + q;
-      if (i < cnt && !(a.flags & 8)) labels[lab_at[q]] = new_label;
+      if (i < cnt) labels[lab_at[q]] = new_label;      // (non-temporal stores here were measured slower)
       const u32 deg = (i < cnt) ? ro1[q] - ro[q] : 0u;
       const bool is_long = deg >= long_min;
       if (is_long) longmask |= 1u << q;
