@@ -215,6 +215,106 @@ __global__ __launch_bounds__(BLOCK) void k_lbs_segreduce(F f, long long count, c
   }
 }
 
+// ---- the same reduce, second generation: wave-level segmented scans instead of LDS-staged serial folds ------------
+// In k_lbs_segreduce one lane folds a run of up to 32 items while its neighbours idle (RMAT rows average 32 items),
+// and every value makes a round trip through LDS.  Here a wave holds 64 CONSECUTIVE items of the tile in registers
+// (item = k * BLOCK + thread, so wave w of slab k holds items [64 (4k + w), +64)) and folds them with a segmented
+// inclusive scan over the lanes (6 shuffle steps, earlier items on the left: deterministic).  A run that lies
+// strictly inside a slab is complete and written at once; the first and the last run of a slab may continue in
+// the neighbouring slabs: their partials go to LDS (16 slabs x 2) and one thread stitches them in slab order,
+// handing complete segments to reduced[] and tile-spanning ones to the same carry slots k_segreduce_fixup reads.
+template <typename T, typename F, typename Op>
+__global__ __launch_bounds__(BLOCK) void k_lbs_segreduce2(F f, long long count, const int* __restrict__ segments,
+                                                           long long num_segments, T* __restrict__ reduced, Op op,
+                                                           T identity, T* __restrict__ carry_val,
+                                                           long long* __restrict__ carry_seg) {
+  constexpr int NSLAB = LBS_TILE / WAVE;          // 16
+  __shared__ int s_off[LBS_WINDOW];
+  __shared__ long long s_bounds[2];
+  __shared__ T s_hval[NSLAB], s_tval[NSLAB];
+  __shared__ long long s_hseg[NSLAB], s_tseg[NSLAB];
+  const long long tile = blockIdx.x;
+  const long long first = tile * LBS_TILE;
+  const long long last = (first + LBS_TILE < count ? first + LBS_TILE : count) - 1;
+  lbs_tile_t t = lbs_stage_tile(segments, num_segments, first, last, s_off, s_bounds);
+  const int lane = lane_id();
+  const int wave = threadIdx.x / WAVE;
+  if (threadIdx.x < NSLAB) { s_hseg[threadIdx.x] = -1; s_tseg[threadIdx.x] = -1; }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < LBS_ITEMS; ++k) {
+    const int slab = k * WAVES_PER_BLOCK + wave;
+    const long long idx = first + k * BLOCK + threadIdx.x;
+    const bool valid = idx <= last;
+    long long seg = -1;
+    T x = identity;
+    if (valid) {
+      int start;
+      if (t.nseg) {
+        const int j = upper_bound_small(s_off, t.nseg, (int)idx) - 1;
+        seg = t.seg_lo + j;
+        start = s_off[j];
+      } else {
+        const int* a = segments + t.seg_lo;
+        const int j = upper_bound_small(a, (int)(t.seg_hi - t.seg_lo + 1), (int)idx) - 1;
+        seg = t.seg_lo + j;
+        start = a[j];
+      }
+      x = f((int)idx, (int)seg, (int)idx - start);
+    }
+    const int sg = (int)(seg - t.seg_lo);                    // -1 - seg_lo for invalid lanes: never equals a valid one
+    // segmented inclusive scan: lane i ends up with the fold of its run's items up to itself
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const T y = __shfl_up(x, d, WAVE);
+      const int sy = __shfl_up(sg, d, WAVE);
+      if (lane >= d && sy == sg && valid) x = op(y, x);
+    }
+    const int sg_next = __shfl_down(sg, 1, WAVE);
+    const bool valid_next = __shfl_down((int)valid, 1, WAVE) != 0;
+    const bool is_tail = valid && (lane == WAVE - 1 || !valid_next || sg_next != sg);
+    const int sg_first = __shfl(sg, 0, WAVE);                // lane 0 of a slab that has items is valid
+    const u64 vmask = __ballot(valid);
+    const int last_lane = vmask ? 63 - __builtin_clzll(vmask) : -1;
+    const int sg_last = __shfl(sg, last_lane < 0 ? 0 : last_lane, WAVE);
+    if (is_tail) {
+      const bool in_first = sg == sg_first, in_last = sg == sg_last;
+      if (!in_first && !in_last) reduced[seg] = x;           // strictly inside the slab: complete
+      if (in_first) { s_hseg[slab] = seg; s_hval[slab] = x; }
+      if (in_last) { s_tseg[slab] = seg; s_tval[slab] = x; }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // where a stitched run goes: straight to reduced[] if the segment lies inside this tile, else a carry
+    auto flush = [&](long long seg, T acc) {
+      if (seg < 0) return;
+      const long long seg_begin = segments[seg];
+      const long long seg_end = (seg + 1 < num_segments) ? (long long)segments[seg + 1] : count;
+      const bool opens_here = seg_begin >= first;
+      const bool closes_here = seg_end - 1 <= last;
+      if (opens_here && closes_here) {
+        reduced[seg] = acc;
+      } else {
+        const int slot = opens_here ? 1 : 0;     // 0: continues a segment begun earlier, 1: left open
+        carry_val[tile * 2 + slot] = acc;
+        carry_seg[tile * 2 + slot] = seg;
+      }
+    };
+    long long acc_seg = -1;
+    T acc = identity;
+    for (int sl = 0; sl < NSLAB; ++sl) {
+      const long long hs = s_hseg[sl];
+      if (hs < 0) continue;                      // slab without items (end of the data)
+      if (hs == acc_seg) acc = op(acc, s_hval[sl]);
+      else { flush(acc_seg, acc); acc_seg = hs; acc = s_hval[sl]; }
+      const long long ts = s_tseg[sl];
+      if (ts != hs) { flush(acc_seg, acc); acc_seg = ts; acc = s_tval[sl]; }
+    }
+    flush(acc_seg, acc);
+  }
+}
+
 // empty segments get the identity (they own no item so no tile ever writes them)
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_segreduce_fill_empty(const int* __restrict__ segments, long long num_segments,
@@ -264,8 +364,13 @@ inline void lbs_segreduce(F f, long long count, const int* segments, long long n
   long long* carry_seg = (long long*)ctx.scratch;
   T* carry_val = (T*)(carry_seg + tiles * 2);
   MGX_HIP(hipMemsetAsync(carry_seg, 0xFF, (size_t)tiles * 2 * sizeof(long long), st));
-  hipLaunchKernelGGL((k_lbs_segreduce<T, F, Op>), dim3((unsigned)tiles), dim3(BLOCK), 0, st, f, count, segments,
-                     num_segments, reduced, op, identity, carry_val, carry_seg);
+  static const int gen = getenv("MGX_SEGREDUCE_GEN") ? atoi(getenv("MGX_SEGREDUCE_GEN")) : 2;
+  if (gen == 1)
+    hipLaunchKernelGGL((k_lbs_segreduce<T, F, Op>), dim3((unsigned)tiles), dim3(BLOCK), 0, st, f, count, segments,
+                       num_segments, reduced, op, identity, carry_val, carry_seg);
+  else
+    hipLaunchKernelGGL((k_lbs_segreduce2<T, F, Op>), dim3((unsigned)tiles), dim3(BLOCK), 0, st, f, count, segments,
+                       num_segments, reduced, op, identity, carry_val, carry_seg);
   hipLaunchKernelGGL((k_segreduce_fixup<T, Op>), dim3(grid_for(tiles)), dim3(BLOCK), 0, st, tiles, carry_val, carry_seg,
                      reduced, op);
 }
