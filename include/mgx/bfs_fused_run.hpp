@@ -43,6 +43,8 @@ inline void bfs_set_kernel_attributes() {
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, true>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, false, true>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, true>));
+  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, true, false, true>));
+  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, true, false, true>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 16, false>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 16, false>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, false>));
@@ -72,8 +74,13 @@ inline void bfs_launch_stream(const bfs_fused_args_t& a, int level, standard_con
   hipStream_t s = ctx.stream();
   if (a.long_min <= 0) return;
   const size_t lds2 = bfs_stream_lds_bytes(BFS_STREAM_HOTW2), lds1 = bfs_stream_lds_bytes(BFS_STREAM_HOTW);
-  if (bfs_cold_test(a.n))
+  static const int cshape = getenv("MGX_BFS_COLD_SHAPE") ? atoi(getenv("MGX_BFS_COLD_SHAPE")) : 0;
+  if (bfs_cold_test(a.n) && cshape == 1)      // cached col_indices loads
     hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, true>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
+  else if (bfs_cold_test(a.n) && cshape == 2) // one workgroup per CU with the 160 KB prefix
+    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, true, false, true>), dim3(ctx.num_cus), dim3(1024), lds1, s, a, level);
+  else if (bfs_cold_test(a.n))
+    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, true, false, true>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
   else if (shape == 1)
     hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 16, false>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
   else if (shape == 2)
