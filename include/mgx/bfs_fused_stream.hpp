@@ -31,8 +31,10 @@ constexpr int BFS_STREAM_HOTW = 40896;     // words of the bitmap kept in LDS: 1
 constexpr size_t bfs_stream_lds_bytes(int hotw) { return (size_t)hotw * 4 + 64; }
 
 // DIAG: honour MGX_BFS_FLAGS (switch parts of the kernel off for measurements; results are then wrong by design).
+// The kernel body as a device function: block `block` of `nblocks` (k_bfs_push_level_stream launches it for a grid
+// of its own, k_bfs_push_level in bfs_fused_run.hpp gives it the first part of a grid shared with the wave body).
 template <int NT, int HOTW, int EPT, bool COLDT, bool DIAG = false, bool NTLOAD = false>
-__global__ __launch_bounds__(NT) void k_bfs_push_level_stream(bfs_fused_args_t a, int level) {
+__device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int level, u32 block, u32 nblocks) {
   constexpr int NW = NT / WAVE;
   static_assert(EPT + 2 <= WAVE, "round shape");
 
@@ -56,10 +58,10 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_stream(bfs_fused_args_t a
   unsigned char* __restrict__ mark = a.mark;
 
   // slice of this wave
-  const u32 total_waves = gridDim.x * NW;
+  const u32 total_waves = nblocks * NW;
   u32 per = (E + total_waves - 1) / total_waves;
   per = (per + WAVE - 1) / WAVE * WAVE;
-  const u64 rb = (u64)(blockIdx.x * NW + wave) * per;
+  const u64 rb = (u64)(block * NW + wave) * per;
   const bool has_work = rb < (u64)E;
   const u32 r_begin = has_work ? (u32)rb : E;
   const u32 r_end = (rb + per < (u64)E) ? (u32)(rb + per) : E;
@@ -208,6 +210,11 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_stream(bfs_fused_args_t a
     atomicAdd(&c->claims, (u64)s_int[0]);
     if (level < 64) atomicAdd(&c->claims_level[level], (u64)s_int[0]);
   }
+}
+
+template <int NT, int HOTW, int EPT, bool COLDT, bool DIAG = false, bool NTLOAD = false>
+__global__ __launch_bounds__(NT) void k_bfs_push_level_stream(bfs_fused_args_t a, int level) {
+  bfs_stream_body<NT, HOTW, EPT, COLDT, DIAG, NTLOAD>(a, level, blockIdx.x, gridDim.x);
 }
 
 }  // namespace mgx

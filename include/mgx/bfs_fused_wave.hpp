@@ -28,7 +28,7 @@ constexpr size_t bfs_wave_lds_bytes(int nt, int hotw) {
 }
 
 template <int NT, int HOTW, bool COLDT, bool NTLOAD = false>
-__global__ __launch_bounds__(NT) void k_bfs_push_level_wave(bfs_fused_args_t a, int level) {
+__device__ __forceinline__ void bfs_wave_body(const bfs_fused_args_t& a, int level, u32 block, u32 nblocks) {
   constexpr int NW = NT / WAVE;
   constexpr int EPT = BFS_WAVE_EPT;
 
@@ -53,10 +53,10 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_wave(bfs_fused_args_t a, 
   unsigned char* __restrict__ mark = a.mark;
 
   // slice of this wave
-  const u32 total_waves = gridDim.x * NW;
+  const u32 total_waves = nblocks * NW;
   u32 per = (E + total_waves - 1) / total_waves;
   per = (per + BFS_WAVE_TILE - 1) / BFS_WAVE_TILE * BFS_WAVE_TILE;
-  const u64 rb = (u64)(blockIdx.x * NW + wave) * per;
+  const u64 rb = (u64)(block * NW + wave) * per;
   const bool has_work = rb < (u64)E;
   const u32 r_begin = has_work ? (u32)rb : E;
   const u32 r_end = (rb + per < (u64)E) ? (u32)(rb + per) : E;
@@ -208,6 +208,11 @@ __global__ __launch_bounds__(NT) void k_bfs_push_level_wave(bfs_fused_args_t a, 
     atomicAdd(&c->claims, (u64)s_int[0]);
     if (level < 64) atomicAdd(&c->claims_level[level], (u64)s_int[0]);
   }
+}
+
+template <int NT, int HOTW, bool COLDT, bool NTLOAD = false>
+__global__ __launch_bounds__(NT) void k_bfs_push_level_wave(bfs_fused_args_t a, int level) {
+  bfs_wave_body<NT, HOTW, COLDT, NTLOAD>(a, level, blockIdx.x, gridDim.x);
 }
 
 }  // namespace mgx
