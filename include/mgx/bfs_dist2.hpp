@@ -167,7 +167,7 @@ inline void d2_status(d2_state_t& st, int next_level, standard_context_t& ctx, l
   out[2] = (long long)hc->sum_edges;
   out[3] = (long long)hc->merged_new;
   out[4] = (long long)((cur >> BFS_VSHIFT) + (lcur >> BFS_VSHIFT));
-  out[5] = (long long)((cur & BFS_EMASK) + (lcur & BFS_EMASK));
+  out[5] = (long long)((cur & BFS_EMASK) + hc->ledges[next_level % 3]);
 }
 
 }  // namespace mgx

@@ -45,7 +45,9 @@ constexpr u64 BFS_EMASK = (1ull << BFS_VSHIFT) - 1ull;
 struct bfs_ctrl_t {
   u64 cursor[3];     // short-row queue: level L reads [L%3], level L's build fills [(L+1)%3], begin clears [(L+2)%3]
   u64 merged_new;    // partitioned BFS (bfs_dist2.hpp): vertices discovered by ALL ranks in the level just merged
-  u64 lcursor[3];    // long-row queue (rows of degree >= args.long_min), same packing and rotation
+  u64 lcursor[3];    // long-row queue (rows of degree >= args.long_min), same packing and rotation -- but its
+                     // "edges" are the degrees rounded up to 64 (see bfs_lq_* below) ...
+  u64 ledges[3];     // ... and these are the true ones
   u64 sum_edges;     // sum over levels of E  == m_t (out-degrees of reached vertices)
   u64 sum_frontier;  // sum over levels of frontier sizes (reached vertices with degree >= 1)
   u64 sum_long_edges;     // the part of sum_edges / sum_frontier that went through the long-row queue
@@ -94,7 +96,7 @@ struct bfs_fused_args_t {
 };
 
 __device__ __forceinline__ void bfs_ctrl_reset(bfs_ctrl_t* c) {
-  for (int i = 0; i < 3; ++i) { c->cursor[i] = 0; c->lcursor[i] = 0; }
+  for (int i = 0; i < 3; ++i) { c->cursor[i] = 0; c->lcursor[i] = 0; c->ledges[i] = 0; }
   c->merged_new = 0;
   c->sum_edges = c->sum_frontier = c->sum_long_edges = c->sum_long_vertices = 0;
   c->reached = 1;
@@ -107,6 +109,18 @@ __device__ __forceinline__ void bfs_ctrl_reset(bfs_ctrl_t* c) {
   for (int i = 0; i < 64; ++i) c->stamp[i] = 0;
 }
 
+// Long-row queue entries.  The stream kernel (bfs_fused_stream.hpp) reads a row in sub-rounds of up to 64 consecutive
+// edges, so a row of d edges costs ceil(d / 64) sub-rounds whatever d is: a slice of 4096 edges made of 65-edge rows is
+// twice the work of one inside a hub row (measured on RMAT-22's big level: 44 rounds for the slowest wave against
+// 26.7 on average, and the slowest wave is the kernel's duration).  The queue's offsets are therefore prefix sums of
+// the PADDED degrees (multiples of 64: one unit = one sub-round) and equal slices are equal work; the low 6 bits of
+// an entry, free in a multiple of 64, carry degree & 63 so that the true row end can be recovered:
+//   entry i = P_i | (d_i & 63),  P_{i+1} - P_i = pad64(d_i),  d_i = P_{i+1} - P_i - ((64 - (entry_i & 63)) & 63)
+__host__ __device__ __forceinline__ u32 bfs_lq_pad(u32 deg) { return (deg + 63u) & ~63u; }
+__host__ __device__ __forceinline__ u32 bfs_lq_degree(u32 entry, u32 next_entry) {
+  return ((next_entry & ~63u) - (entry & ~63u)) - ((64u - (entry & 63u)) & 63u);
+}
+
 // level-0 queue entry of the source (its row is `row`, e.g. a local row of a partition)
 __device__ __forceinline__ void bfs_seed_queue(const bfs_fused_args_t& a, u32 row) {
   bfs_ctrl_t* c = a.ctrl;
@@ -114,8 +128,9 @@ __device__ __forceinline__ void bfs_seed_queue(const bfs_fused_args_t& a, u32 ro
   const u32 deg = a.row_offsets[row + 1] - ro;
   const bool is_long = a.long_min > 0 && deg >= (u32)a.long_min;
   (is_long ? a.lq_row : a.fr_row)[0][0] = ro;
-  (is_long ? a.lq_off : a.fr_off)[0][0] = 0;
-  (is_long ? c->lcursor : c->cursor)[0] = deg ? ((1ull << BFS_VSHIFT) | (u64)deg) : 0ull;
+  (is_long ? a.lq_off : a.fr_off)[0][0] = is_long ? (deg & 63u) : 0u;
+  (is_long ? c->lcursor : c->cursor)[0] = deg ? ((1ull << BFS_VSHIFT) | (u64)(is_long ? bfs_lq_pad(deg) : deg)) : 0ull;
+  if (is_long) c->ledges[0] = deg;
 }
 
 // Start of a traversal, one launch: clears labels (-1), bitmap(s) and marks, and seeds the source.  The thread that
@@ -157,9 +172,11 @@ __device__ __forceinline__ bool bfs_open_level(const bfs_fused_args_t& a, int le
   const u64 cur = c->cursor[level % 3];
   const u64 lcur = c->lcursor[level % 3];
   const long long nf = (long long)(cur >> BFS_VSHIFT) + (long long)(lcur >> BFS_VSHIFT);
-  const u64 E = (cur & BFS_EMASK) + (lcur & BFS_EMASK);
+  const u64 long_edges = c->ledges[level % 3];
+  const u64 E = (cur & BFS_EMASK) + long_edges;
   c->cursor[(level + 2) % 3] = 0;
   c->lcursor[(level + 2) % 3] = 0;
+  c->ledges[(level + 2) % 3] = 0;
   if (level < 64) c->stamp[level] = __builtin_amdgcn_s_memrealtime();
   if (nf == 0) {
     if (!c->done) { c->done = 1; c->levels = level; }
@@ -168,7 +185,7 @@ __device__ __forceinline__ bool bfs_open_level(const bfs_fused_args_t& a, int le
   if (level < BFS_MAX_TRACE) c->trace[level] = ((u64)nf << BFS_VSHIFT) | E;
   c->sum_edges += E;
   c->sum_frontier += (u64)nf;
-  c->sum_long_edges += lcur & BFS_EMASK;
+  c->sum_long_edges += long_edges;
   c->sum_long_vertices += lcur >> BFS_VSHIFT;
   if (a.mode == 1 && !c->pull) {
     const float unvisited = (float)((long long)a.n - (long long)c->reached);
@@ -229,6 +246,7 @@ __global__ __launch_bounds__(NT) void k_bfs_build(bfs_fused_args_t a, int level,
   __shared__ u32 st_v[LIST];
   __shared__ u64 s_scan[NW + 1];
   __shared__ u64 s_base[2];
+  __shared__ u32 s_long_edges;                   // true edges of the batch's long rows (their offsets count padded ones)
   bfs_ctrl_t* const c = a.ctrl;
   if (!bfs_resolve_level(c, level)) return;
   if (stop_when_done && c->done) return;        // (a rank of a partitioned run may be handed work with an empty frontier)
@@ -286,6 +304,7 @@ __global__ __launch_bounds__(NT) void k_bfs_build(bfs_fused_args_t a, int level,
         ++at;
       }
     }
+    if (threadIdx.x == 0) s_long_edges = 0;
     __syncthreads();
     const int cnt = (total - first < LIST) ? total - first : LIST;
     u32 li[PER], ro[PER], ro1[PER];
@@ -301,24 +320,27 @@ __global__ __launch_bounds__(NT) void k_bfs_build(bfs_fused_args_t a, int level,
     }
     u64 loc[PER];
     u64 sum_s = 0, sum_l = 0;
-    u32 longmask = 0;
+    u32 longmask = 0, long_true = 0;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
       const int i = threadIdx.x * PER + q;
       if (i < cnt) labels[lab_at[q]] = new_label;      // (non-temporal stores here were measured slower)
       const u32 deg = (i < cnt) ? ro1[q] - ro[q] : 0u;
       const bool is_long = deg >= long_min;
-      if (is_long) longmask |= 1u << q;
+      if (is_long) { longmask |= 1u << q; long_true += deg; }
       loc[q] = is_long ? sum_l : sum_s;
-      const u64 add = deg ? (CNT1 | (u64)deg) : 0ull;
+      const u64 add = deg ? (CNT1 | (u64)(is_long ? bfs_lq_pad(deg) : deg)) : 0ull;
       if (is_long) sum_l += add; else sum_s += add;
     }
+    long_true = wave_sum(long_true);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && long_true) atomicAdd(&s_long_edges, long_true);
     u64 tot_s, tot_l;
     const u64 ex_s = block_exclusive_sum_nw<NW>(sum_s, s_scan, &tot_s);
     const u64 ex_l = block_exclusive_sum_nw<NW>(sum_l, s_scan, &tot_l);
     if (threadIdx.x == 0) {
       s_base[0] = (tot_s >> 40) ? atomicAdd(cur_s, ((tot_s >> 40) << BFS_VSHIFT) | (tot_s & DEGMASK)) : 0ull;
       s_base[1] = (tot_l >> 40) ? atomicAdd(cur_l, ((tot_l >> 40) << BFS_VSHIFT) | (tot_l & DEGMASK)) : 0ull;
+      if (tot_l >> 40) atomicAdd(&c->ledges[(level + 1) % 3], (u64)s_long_edges);     // (complete: two barriers ago)
     }
     __syncthreads();
 #pragma unroll
@@ -330,7 +352,8 @@ __global__ __launch_bounds__(NT) void k_bfs_build(bfs_fused_args_t a, int level,
         const u64 at = (is_long ? ex_l : ex_s) + loc[q];
         const u64 slot = (base >> BFS_VSHIFT) + (at >> 40);
         (is_long ? out_row_l : out_row_s)[slot] = ro[q];
-        (is_long ? out_off_l : out_off_s)[slot] = (u32)((base & BFS_EMASK) + (at & DEGMASK));
+        (is_long ? out_off_l : out_off_s)[slot] =
+            (u32)((base & BFS_EMASK) + (at & DEGMASK)) | (is_long ? ((ro1[q] - ro[q]) & 63u) : 0u);
       }
     }
     __syncthreads();       // st_v and s_base are reused by the next batch

@@ -83,6 +83,8 @@ __global__ __launch_bounds__(NT) void k_bfs_small_levels(bfs_fused_args_t a, u32
       const volatile u32* q_off = (which ? a.fr_off : a.lq_off)[level & 1];
       for (int i = threadIdx.x; i < nf; i += NT) { s_off[i] = q_off[i]; s_row[i] = q_row[i]; }
       if (threadIdx.x == 0) s_off[nf] = E;
+      // long-row queue: padded offsets with degree & 63 in the low bits (bfs_lq_* in bfs_fused.hpp)
+      const u32 omask = which ? 0xFFFFFFFFu : ~63u;
       __syncthreads();
       int top = 1;
       while (top * 2 < nf) top *= 2;
@@ -102,12 +104,17 @@ __global__ __launch_bounds__(NT) void k_bfs_small_levels(bfs_fused_args_t a, u32
 #pragma unroll
             for (int k = 0; k < EPT; ++k) {
               const int j = sj[k] + step;
-              if (j < nf && s_off[j] <= r[k]) sj[k] = j;
+              if (j < nf && (s_off[j] & omask) <= r[k]) sj[k] = j;
             }
           }
         int d[EPT];
 #pragma unroll
-        for (int k = 0; k < EPT; ++k) d[k] = a.col_indices[act[k] ? s_row[sj[k]] + (r[k] - s_off[sj[k]]) : 0u];
+        for (int k = 0; k < EPT; ++k) {
+          const u32 e0 = s_off[sj[k]];
+          const u32 in_row = r[k] - (e0 & omask);
+          if (!which) act[k] = act[k] && in_row < bfs_lq_degree(e0, s_off[sj[k] + 1]);     // ranks in a row's padding
+          d[k] = a.col_indices[act[k] ? s_row[sj[k]] + in_row : 0u];
+        }
         u32 word[EPT];
 #pragma unroll
         for (int k = 0; k < EPT; ++k) word[k] = a.visited[(u32)d[k] >> 5];
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(NT) void k_bfs_small_levels(bfs_fused_args_t a, u32
       lab_at[q] = a.old_of_new ? a.old_of_new[v] : (int)v;
     }
     u64 loc[PER];
-    u64 sum_s = 0, sum_l = 0;
+    u64 sum_s = 0, sum_l = 0, true_l = 0;
     u32 longmask = 0;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
@@ -156,14 +163,15 @@ __global__ __launch_bounds__(NT) void k_bfs_small_levels(bfs_fused_args_t a, u32
       if (i < W) a.labels[lab_at[q]] = new_label;
       const u32 deg = (i < W) ? ro1[q] - ro[q] : 0u;
       const bool is_long = deg >= long_min;
-      if (is_long) longmask |= 1u << q;
+      if (is_long) { longmask |= 1u << q; true_l += deg; }
       loc[q] = is_long ? sum_l : sum_s;
-      const u64 add = deg ? (CNT1 | (u64)deg) : 0ull;
+      const u64 add = deg ? (CNT1 | (u64)(is_long ? bfs_lq_pad(deg) : deg)) : 0ull;
       if (is_long) sum_l += add; else sum_s += add;
     }
-    u64 tot_s, tot_l;
+    u64 tot_s, tot_l, tot_true;
     const u64 ex_s = block_exclusive_sum_nw<NW>(sum_s, s_scan, &tot_s);
     const u64 ex_l = block_exclusive_sum_nw<NW>(sum_l, s_scan, &tot_l);
+    (void)block_exclusive_sum_nw<NW>(true_l, s_scan, &tot_true);
     u32* __restrict__ const out_row_s = a.fr_row[(level + 1) & 1];
     u32* __restrict__ const out_off_s = a.fr_off[(level + 1) & 1];
     u32* __restrict__ const out_row_l = a.lq_row[(level + 1) & 1];
@@ -175,12 +183,13 @@ __global__ __launch_bounds__(NT) void k_bfs_small_levels(bfs_fused_args_t a, u32
         const bool is_long = (longmask >> q) & 1u;
         const u64 at = (is_long ? ex_l : ex_s) + loc[q];
         (is_long ? out_row_l : out_row_s)[at >> 40] = ro[q];
-        (is_long ? out_off_l : out_off_s)[at >> 40] = (u32)(at & DEGMASK);
+        (is_long ? out_off_l : out_off_s)[at >> 40] = (u32)(at & DEGMASK) | (is_long ? ((ro1[q] - ro[q]) & 63u) : 0u);
       }
     }
     if (threadIdx.x == 0) {
       c->cursor[(level + 1) % 3] = ((tot_s >> 40) << BFS_VSHIFT) | (tot_s & DEGMASK);
       c->lcursor[(level + 1) % 3] = ((tot_l >> 40) << BFS_VSHIFT) | (tot_l & DEGMASK);
+      c->ledges[(level + 1) % 3] = tot_true;
       c->reached += (u64)W;
       c->claims += (u64)W;
       if (level < 64) c->claims_level[level] += (u64)W;

@@ -7,7 +7,8 @@
 // instruction.  So discoveries are split by degree when the next level's queues are built (k_bfs_build): rows of
 // at least args.long_min edges go to the long-row queue, and this kernel streams them:
 //
-//   * the level's long edges are cut into equal contiguous slices of edge ranks, one per wave (perfect balance
+//   * the level's long rows are cut into equal contiguous slices of PADDED edge ranks (degrees rounded up to 64,
+//     bfs_lq_* in bfs_fused.hpp: a unit is one sub-round below), one per wave (perfect balance
 //     whatever the row lengths: a hub row spans many slices); one 64-ary search finds the slice's first row;
 //   * the walk over (row, position) is wave-uniform and lives in SGPRs: a sub-round is up to 64 consecutive
 //     edges of the current row, a round is EPT sub-rounds; the rows of the next round (at most EPT+1) are
@@ -33,6 +34,17 @@ constexpr size_t bfs_stream_lds_bytes(int hotw) { return (size_t)hotw * 4 + 64; 
 // DIAG: honour MGX_BFS_FLAGS (switch parts of the kernel off for measurements; results are then wrong by design).
 // The kernel body as a device function: block `block` of `nblocks` (k_bfs_push_level_stream launches it for a grid
 // of its own, k_bfs_push_level in bfs_fused_run.hpp gives it the first part of a grid shared with the wave body).
+//
+// What bounds it (RMAT-22's big level, 98 M long edges: 151 us alone, 2.6 TB/s of col_indices): the latency of the
+// memory pipeline under load.  8192 waves x 8 loads x 256 B = 16.8 MB in flight, returned in ~4 us -- the same ~4 TB/s
+// tools/microbench3.hip gets from bare loads of this shape (profiles/r01/microbench3_inflight.jsonl), less the partial
+// sub-rounds (88 % of the lanes carry an edge), the copy of the bitmap and the slice search in front.  Tried against
+// that, each A/B'd on one box over the 16-source bench and each within +-1 % or slower: rounds that lie inside one
+// row skipping the per-sub-round walk and lane masks; one ds_or with return instead of read-then-or; buffer loads
+// (descriptor + scalar offset: no address arithmetic per sub-round); 16-byte loads for rounds inside one row, with
+// and without 128-byte aligned starts (3 % slower); a ring that reloads a register right after its test so that
+// seven loads stay in flight across rounds (2 % slower, although bare loads gain 20 % from it).  Instruction count,
+// load width, alignment and issue order are not what this kernel waits for.
 template <int NT, int HOTW, int EPT, bool COLDT, bool DIAG = false, bool NTLOAD = false>
 __device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int level, u32 block, u32 nblocks) {
   constexpr int NW = NT / WAVE;
@@ -48,7 +60,7 @@ __device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int l
   if (!bfs_resolve_level(c, level)) return;
   const u64 cur = c->lcursor[level % 3];
   const u32 nf = (u32)(cur >> BFS_VSHIFT);
-  const u32 E = (u32)(cur & BFS_EMASK);
+  const u32 E = (u32)(cur & BFS_EMASK);                     // in units of padded edges: a multiple of 64 (bfs_lq_*)
   if (nf == 0 || c->pull) return;                           // k_bfs_level_begin: bookkeeping and direction
 
   const u32* __restrict__ q_row = a.lq_row[level & 1];
@@ -92,15 +104,18 @@ __device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int l
       w_row = ok ? ld_row : 0u;
     };
     // first row of the slice
-    u32 seg = (u32)(wave_upper_bound(q_off, (long long)nf, r_begin) - 1);
+    u32 seg = (u32)(wave_upper_bound(q_off, (long long)nf, r_begin + 63u) - 1);     // (+63: the entries' low bits)
     prefetch(seg);
     u32 pos, end;                // col_indices range still to read of the current row (wave-uniform)
     {
       const u32 start = __builtin_amdgcn_readlane(w_row, 0);
-      const u32 o0 = __builtin_amdgcn_readlane(w_off, 0);
-      const u32 o1 = __builtin_amdgcn_readlane(w_off, 1);
+      const u32 e0 = __builtin_amdgcn_readlane(w_off, 0);
+      const u32 e1 = __builtin_amdgcn_readlane(w_off, 1);
+      const u32 o0 = e0 & ~63u, o1 = e1 & ~63u;
+      const u32 deg = bfs_lq_degree(e0, e1);
+      const u32 lim = (o1 < r_end ? o1 : r_end) - o0;          // the slice may end inside the row (at a multiple of 64)
       pos = start + (r_begin - o0);
-      end = start + ((o1 < r_end ? o1 : r_end) - o0);
+      end = start + (deg < lim ? deg : lim);
     }
     seg += 1;                    // next row to start
     prefetch(seg);
@@ -114,14 +129,18 @@ __device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int l
 #pragma unroll
       for (int k = 0; k < EPT; ++k) {
         if (pos == end && !fin) {
-          const u32 o0 = __builtin_amdgcn_readlane(w_off, j);
+          const u32 e0 = __builtin_amdgcn_readlane(w_off, j);
+          const u32 o0 = e0 & ~63u;
           if (o0 >= r_end) {
             fin = true;
           } else {
             const u32 start = __builtin_amdgcn_readlane(w_row, j);
-            const u32 o1 = __builtin_amdgcn_readlane(w_off, j + 1);
+            const u32 e1 = __builtin_amdgcn_readlane(w_off, j + 1);
+            const u32 o1 = e1 & ~63u;
+            const u32 deg = bfs_lq_degree(e0, e1);
+            const u32 lim = (o1 < r_end ? o1 : r_end) - o0;
             pos = start;
-            end = start + ((o1 < r_end ? o1 : r_end) - o0);
+            end = start + (deg < lim ? deg : lim);
             ++j;
           }
         }

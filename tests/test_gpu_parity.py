@@ -396,6 +396,46 @@ def test_bfs_long_chain_many_levels(gpu_ctx, oracle, monkeypatch, small_max):
     assert st["small_levels"] == (n if small_max else 0)
 
 
+@pytest.mark.parametrize("small_max", [256, 0, 1 << 20])
+@pytest.mark.parametrize("long_min", [64, 1])
+def test_bfs_long_row_queue_padding_boundaries(gpu_ctx, oracle, monkeypatch, small_max, long_min):
+    """The long-row queue counts degrees rounded up to 64 and keeps degree & 63 in the low bits of its offsets
+    (bfs_lq_* in include/mgx/bfs_fused.hpp).  A tree whose second level has rows of every length around the
+    multiples of 64 (and a 5000-edge row that spans several slices), expanded by the stream kernel (small_max 0 /
+    256), by the single-workgroup kernel (small_max 2^20) and with every row in the long queue (long_min 1):
+    labels, levels and the traversed-edge count (true edges, not padded ones) must equal the oracle's."""
+    import mini_amd
+    monkeypatch.setenv("MGX_BFS_SMALL_MAX_EDGES", str(small_max))
+    monkeypatch.setenv("MGX_BFS_LONG_MIN", str(long_min))
+    monkeypatch.setenv("MGX_BFS_HOT_MIN_EDGES", "0")
+    degs = [1, 2, 62, 63, 64, 65, 66, 126, 127, 128, 129, 190, 191, 192, 193, 255, 256, 257, 511, 512, 513, 5000]
+    t0, t1 = [], []
+    nxt = 1 + len(degs)
+    for i, d in enumerate(degs):
+        hub = 1 + i
+        t0.append(0); t1.append(hub)                 # source -> hub
+        for _ in range(d - 1):                       # the hub's other d - 1 neighbours (its degree is d with the source)
+            t0.append(hub); t1.append(nxt); nxt += 1
+    n = nxt
+    ro, ci, w = oracle.csr_from_tuples(n, np.array(t0, dtype=np.int32), np.array(t1, dtype=np.int32), None, undir=True)
+    deg = np.diff(ro)
+    assert sorted(deg[1:1 + len(degs)].tolist()) == sorted(degs)
+    g = _graph(gpu_ctx, ro, ci)
+    bfs = mini_amd.BfsProblem(g, 0)
+    for src in (0, 5, len(degs), n - 1):             # the root, a 64-edge hub, the 5000-edge hub, a leaf
+        want = oracle.bfs_cpu(ro, ci, src)
+        st = bfs.run(src)
+        assert np.array_equal(bfs.labels(), want), src
+        reached = want >= 0
+        assert st["reached"] == int(reached.sum())
+        assert st["m_t"] == int(deg[reached].sum())
+        assert st["levels"] == int(want.max()) + 1
+        tr = bfs.level_trace()
+        for lv, (nf, ne) in enumerate(tr):
+            at = want == lv
+            assert nf == int((at & (deg > 0)).sum()) and ne == int(deg[at].sum()), (src, lv)
+
+
 def test_sssp_fused_float_weights_and_big_frontiers(gpu_ctx, oracle, rmat_graphs):
     """fused SSSP loop on RMAT-16 (frontiers of several thousand marked vertices per workgroup: the queue build
     runs more than one batch) with NON-integer weights: the min-plus fixed point is unique, so distances are
