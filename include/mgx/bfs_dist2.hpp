@@ -116,6 +116,7 @@ struct d2_state_t {
     a.n = n_global;
     a.mode = 0; a.alpha = 0.f;
     a.flags = 0;
+    a.count_marks = 0;
     return a;
   }
 };

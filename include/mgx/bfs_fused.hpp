@@ -43,16 +43,23 @@ constexpr int BFS_VSHIFT = 38;                 // cursor = (vertices << 38) | ed
 constexpr u64 BFS_EMASK = (1ull << BFS_VSHIFT) - 1ull;
 
 struct bfs_ctrl_t {
+  // The four words k_bfs_build's workgroups add to, each on a 128-byte line of its own: device-scope atomics on one
+  // line are served one after the other (~12 ns each, profiles/r01/microbench.jsonl: hot_counter), and 500 workgroups
+  // arrive at them at about the same time.
   u64 cursor[3];     // short-row queue: level L reads [L%3], level L's build fills [(L+1)%3], begin clears [(L+2)%3]
-  u64 merged_new;    // partitioned BFS (bfs_dist2.hpp): vertices discovered by ALL ranks in the level just merged
+  u64 pad_a_[13];
   u64 lcursor[3];    // long-row queue (rows of degree >= args.long_min), same packing and rotation -- but its
                      // "edges" are the degrees rounded up to 64 (see bfs_lq_* below) ...
+  u64 pad_b_[13];
   u64 ledges[3];     // ... and these are the true ones
+  u64 pad_c_[13];
+  u64 reached;       // vertices labelled (incl. source and zero-degree discoveries)
+  u64 pad_d_[15];
+  u64 merged_new;    // partitioned BFS (bfs_dist2.hpp): vertices discovered by ALL ranks in the level just merged
   u64 sum_edges;     // sum over levels of E  == m_t (out-degrees of reached vertices)
   u64 sum_frontier;  // sum over levels of frontier sizes (reached vertices with degree >= 1)
   u64 sum_long_edges;     // the part of sum_edges / sum_frontier that went through the long-row queue
   u64 sum_long_vertices;
-  u64 reached;       // vertices labelled (incl. source and zero-degree discoveries)
   u64 claims;        // mark stores issued (>= reached-1: several edges may mark the same vertex)
   u64 claims_level[64];
   u64 pull_edges;    // in-edges inspected by bottom-up levels
@@ -93,6 +100,7 @@ struct bfs_fused_args_t {
   float alpha;             // switch to bottom-up when unvisited < frontier_vertices * alpha (bfs_enactor.hxx:68)
   int n;
   int flags;               // diagnostics only
+  int count_marks;         // the push kernels count their mark stores into ctrl->claims / claims_level (tools only)
 };
 
 __device__ __forceinline__ void bfs_ctrl_reset(bfs_ctrl_t* c) {
@@ -378,6 +386,7 @@ struct bfs_fused_state_t {
                                      // measured on RMAT-22: beyond a few hundred edges one workgroup's dependent
                                      // round trips cost more than the four launches of a device-wide level
   int long_min = 64;                 // rows at least this long go to the long-row queue (0: no such queue)
+  bool count_marks = false;          // see bfs_fused_args_t::count_marks (MGX_BFS_COUNT_MARKS; on with time_kernels)
   bool time_kernels = false;         // record HIP events around the two push kernels of every level (each event
                                      // leaves a ~6 us gap on the stream: profiling runs only)
   unsigned hot_min_edges = 65536;    // smaller levels probe the bitmap in L2 instead of copying its hot prefix to LDS
@@ -418,6 +427,7 @@ struct bfs_fused_state_t {
     for (int i = 0; i < EV_POOL; ++i) MGX_HIP(hipEventCreate(&wev[i]));
     if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("MGX_BFS_TIME_KERNELS")) time_kernels = atoi(e) != 0;
+    if (const char* e = getenv("MGX_BFS_COUNT_MARKS")) count_marks = atoi(e) != 0;
     if (const char* e = getenv("MGX_BFS_HOT_MIN_EDGES")) hot_min_edges = (unsigned)atoll(e);
     if (const char* e = getenv("MGX_BFS_LEVELS_PER_SYNC")) levels_per_sync = atoi(e) > 0 ? atoi(e) : 2;
     if (const char* e = getenv("MGX_BFS_SMALL_MAX_EDGES")) small_max_edges = (unsigned)atoll(e);

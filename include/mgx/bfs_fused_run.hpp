@@ -178,6 +178,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.ctrl = st.ctrl.data();
   a.n = st.n;
   a.flags = 0;
+  a.count_marks = (st.count_marks || st.time_kernels) ? 1 : 0;
   if (const char* e = getenv("MGX_BFS_FLAGS")) a.flags = atoi(e);
   const long long nwords = ((long long)st.n + 31) / 32;
   hipLaunchKernelGGL(k_bfs_fused_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src, nwords);

@@ -201,12 +201,14 @@ __device__ __forceinline__ void bfs_wave_body(const bfs_fused_args_t& a, int lev
     }
   }
 
-  marks = wave_sum(marks);
-  if (lane == 0 && marks) atomicAdd(&s_int[0], marks);
-  __syncthreads();
-  if (threadIdx.x == 0 && s_int[0]) {
-    atomicAdd(&c->claims, (u64)s_int[0]);
-    if (level < 64) atomicAdd(&c->claims_level[level], (u64)s_int[0]);
+  if (a.count_marks) {           // statistics for the tools: two device-scope atomics per workgroup on one line
+    marks = wave_sum(marks);
+    if (lane == 0 && marks) atomicAdd(&s_int[0], marks);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_int[0]) {
+      atomicAdd(&c->claims, (u64)s_int[0]);
+      if (level < 64) atomicAdd(&c->claims_level[level], (u64)s_int[0]);
+    }
   }
 }
 
