@@ -229,6 +229,11 @@ MGX_API int mgx_dbfs2_words(int n_global, int64_t* words);
 MGX_API int mgx_dbfs2_reset(mgx_dbfs2_t h, int src_global);
 MGX_API int mgx_dbfs2_push(mgx_dbfs2_t h, int level);
 MGX_API int mgx_dbfs2_merge(mgx_dbfs2_t h, int level, const unsigned* d_gathered);
+/* The same for `maps` new-bit maps that lie `stride_words` apart (a multiple of 4, >= mgx_dbfs2_words): the padded
+ * buffers of an all-gather, or ONE map that already is the OR of every rank's -- what a caller has after a
+ * reduce-scatter (all-to-all of slices + OR) followed by an all-gather of the merged slices, which moves
+ * 2 (R-1)/R bitmaps per rank and level instead of R-1. */
+MGX_API int mgx_dbfs2_merge_maps(mgx_dbfs2_t h, int level, const unsigned* d_maps, int maps, int64_t stride_words);
 /* Synchronises.  next_level = number of levels enqueued so far.  out6: [0] traversal over (a level discovered nothing
  * on ANY rank -- the same on every rank, no reduction needed) [1] levels that hold vertices [2] edges this rank has
  * expanded [3] vertices discovered by all ranks in the level merged last [4] size and [5] edges of this rank's next

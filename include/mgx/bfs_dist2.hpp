@@ -42,16 +42,18 @@ __global__ __launch_bounds__(BLOCK) void k_d2_newbits(const u32* __restrict__ vi
   }
 }
 
-// merged[w] = OR over ranks of gathered[r][w]; visited |= merged; ctrl->merged_new += popcount(merged).
+// merged[w] = OR over the maps of gathered[r][w]; visited |= merged; ctrl->merged_new += popcount(merged).
 // Every rank computes the same count, so the traversal ends on all ranks together without a reduction.
-// 16 bytes per lane (nwords4 = words / 4; the buffers are padded to a multiple of 4 words).
-__global__ __launch_bounds__(BLOCK) void k_d2_or(const uint4* __restrict__ gathered, int ranks, long long nwords4,
-                                                 uint4* __restrict__ merged, uint4* __restrict__ visited, bfs_ctrl_t* c) {
+// 16 bytes per lane (nwords4 = words / 4; the buffers are padded to a multiple of 4 words); map r starts
+// stride4 x 16 bytes after map r - 1.
+__global__ __launch_bounds__(BLOCK) void k_d2_or(const uint4* __restrict__ gathered, int maps, long long stride4,
+                                                 long long nwords4, uint4* __restrict__ merged,
+                                                 uint4* __restrict__ visited, bfs_ctrl_t* c) {
   int found = 0;
   for (long long w = (long long)blockIdx.x * BLOCK + threadIdx.x; w < nwords4; w += (long long)gridDim.x * BLOCK) {
     uint4 g = make_uint4(0, 0, 0, 0);
-    for (int r = 0; r < ranks; ++r) {
-      const uint4 x = gathered[(long long)r * nwords4 + w];
+    for (int r = 0; r < maps; ++r) {
+      const uint4 x = gathered[(long long)r * stride4 + w];
       g.x |= x.x; g.y |= x.y; g.z |= x.z; g.w |= x.w;
     }
     merged[w] = g;
@@ -141,13 +143,15 @@ inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx) {
                      st.fs->mark.data(), st.newbits, st.nwords, (long long)st.n_global, a.ctrl);
 }
 
-// gathered: ranks x nwords words (every rank's new_bits).  Asynchronous: OR-merge and queue build are enqueued
-// on the context's stream, nothing is read back.
-inline void d2_merge(d2_state_t& st, int level, const u32* gathered, standard_context_t& ctx) {
+// gathered: `maps` new-bit maps, `stride_words` apart (a multiple of 4): every rank's map after an all-gather, or
+// ONE map that is already the OR of all ranks' (reduce-scatter + all-gather by the caller).  Asynchronous: OR-merge
+// and queue build are enqueued on the context's stream, nothing is read back.
+inline void d2_merge(d2_state_t& st, int level, const u32* gathered, int maps, long long stride_words,
+                     standard_context_t& ctx) {
   hipStream_t s = ctx.stream();
   bfs_fused_args_t a = st.args();
-  hipLaunchKernelGGL(k_d2_or, dim3(grid_for(st.nwords / 4, BLOCK, 1024)), dim3(BLOCK), 0, s, (const uint4*)gathered, st.ranks,
-                     st.nwords / 4, (uint4*)st.merged.data(), (uint4*)st.fs->visited.data(), a.ctrl);
+  hipLaunchKernelGGL(k_d2_or, dim3(grid_for(st.nwords / 4, BLOCK, 1024)), dim3(BLOCK), 0, s, (const uint4*)gathered, maps,
+                     stride_words / 4, st.nwords / 4, (uint4*)st.merged.data(), (uint4*)st.fs->visited.data(), a.ctrl);
   hipLaunchKernelGGL((k_bfs_build<BFS_BUILD_NT, false>), dim3(bfs_build_grid(st.n_local)), dim3(BFS_BUILD_NT), 0, s, a, level,
                      (const u32*)st.merged.data(), st.labels.data(), st.n_local, st.ranks, st.rank, 0);
 }

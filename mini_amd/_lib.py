@@ -120,6 +120,7 @@ SIGNATURES = {
     "mgx_dbfs2_status": [_vp, _i, _pi64],
     "mgx_dbfs2_push": [_vp, _i],
     "mgx_dbfs2_merge": [_vp, _i, _vp],
+    "mgx_dbfs2_merge_maps": [_vp, _i, _vp, _i, _i64],
     "mgx_dbfs2_labels": [_vp, _vp],
     "mgx_sssp_create": [_vp, _i, _pvp],
     "mgx_sssp_reset": [_vp, _i],

@@ -822,7 +822,16 @@ int mgx_dbfs2_merge(mgx_dbfs2_t h, int level, const unsigned* d_gathered) {
   MGX_TRY
   MGX_REQUIRE(h && d_gathered && level >= 0, "bad argument");
   use_device(h->c);
-  mgx::d2_merge(h->st, level, d_gathered, *h->c->ctx);
+  mgx::d2_merge(h->st, level, d_gathered, h->st.ranks, h->st.nwords, *h->c->ctx);
+  MGX_CATCH
+}
+int mgx_dbfs2_merge_maps(mgx_dbfs2_t h, int level, const unsigned* d_maps, int maps, int64_t stride_words) {
+  MGX_TRY
+  MGX_REQUIRE(h && d_maps && level >= 0, "bad argument");
+  MGX_REQUIRE(maps >= 1 && maps <= 64 && stride_words >= h->st.nwords && stride_words % 4 == 0,
+              "mgx_dbfs2_merge_maps: maps must be 1..64 and the stride a multiple of 4 words, at least a bitmap long");
+  use_device(h->c);
+  mgx::d2_merge(h->st, level, d_maps, maps, (long long)stride_words, *h->c->ctx);
   MGX_CATCH
 }
 int mgx_dbfs2_status(mgx_dbfs2_t h, int next_level, int64_t* out6) {

@@ -15,6 +15,7 @@ exchange/termination logic without a GPU.
 """
 import ctypes as C
 import os
+import sys
 import time
 
 import numpy as np
@@ -160,6 +161,13 @@ def bitmap_words(n_global):
     return ((n_global + 31) // 32 + 3) // 4 * 4
 
 
+def exchange_words(n_global, ranks):
+    """length of the buffer a rank's new-bit map is exchanged in: bitmap_words padded so that it splits into
+    `ranks` slices of whole 16-byte units (the reduce-scatter exchange sends slice r to rank r)"""
+    unit = 4 * ranks
+    return (bitmap_words(n_global) + unit - 1) // unit * unit
+
+
 class HipRankEngine2:
     """Per-rank device side of the bitmap-exchange BFS (C-ABI mgx_dbfs2_*).  Ids are global, hub-first.
     reset / push / merge only enqueue work on the context's stream; status() synchronises."""
@@ -172,7 +180,8 @@ class HipRankEngine2:
         self.nwords = w.value
         assert self.nwords == bitmap_words(n_global)
         self._keep = (row_offsets_local, col_indices_global)
-        self.newbits = torch.zeros(self.nwords, dtype=torch.int32, device=row_offsets_local.device)
+        # (the words past nwords are never written: they stay zero in every exchange)
+        self.newbits = torch.zeros(exchange_words(n_global, ranks), dtype=torch.int32, device=row_offsets_local.device)
         h = C.c_void_p()
         check(lib.mgx_dbfs2_create(ctx._h, int(n_global), int(ranks), int(rank),
                                    C.c_void_p(row_offsets_local.data_ptr()), C.c_void_p(col_indices_global.data_ptr()),
@@ -186,8 +195,10 @@ class HipRankEngine2:
         check(lib.mgx_dbfs2_push(self._h, int(level)))
         return self.newbits
 
-    def merge(self, level, gathered):
-        check(lib.mgx_dbfs2_merge(self._h, int(level), C.c_void_p(gathered.data_ptr())))
+    def merge(self, level, maps, nmaps):
+        """maps: nmaps new-bit maps, each as long as the buffer push() returned"""
+        check(lib.mgx_dbfs2_merge_maps(self._h, int(level), C.c_void_p(maps.data_ptr()), int(nmaps),
+                                       int(maps.numel() // nmaps)))
 
     def status(self, next_level):
         o = (C.c_int64 * 6)()
@@ -206,9 +217,14 @@ class HipRankEngine2:
 
 
 class DistBfs2:
-    """Superstep driver of generation 2: push (device) -> all_gather of the new-bit maps -> merge (device), all
-    stream-ordered.  Every rank counts the merged discoveries itself, so a level costs ONE collective and no
-    reduction; the host looks at the device state once per BATCH of levels: the first batch is as long as the
+    """Superstep driver of generation 2: push (device) -> exchange of the new-bit maps -> merge (device), all
+    stream-ordered.  The exchange is an OR-all-reduce of bitmaps, which RCCL does not have as such:
+      "gather": one all_gather, every rank ORs the R maps itself -- R-1 bitmaps received per rank and level;
+      "reduce": all_to_all of slices (rank r gets slice r of every map and ORs them), then all_gather of the merged
+                slices -- 2 (R-1)/R bitmaps per rank and level, two collectives.
+    Default: "reduce" from 4 ranks on (MGX_DIST_EXCHANGE overrides).  Every rank counts the merged discoveries
+    itself, so there is no reduction for the termination test; the host looks at the device state once per BATCH
+    of levels: the first batch is as long as the
     previous traversal was (sources differ, the level structure of a graph hardly), later ones two levels.  Levels
     enqueued past the end are no-ops.  The batch schedule depends only on numbers every rank agrees on, so all ranks
     issue the same collectives.  `engine` needs reset/push/merge/status/labels."""
@@ -217,16 +233,41 @@ class DistBfs2:
         self.e, self.rank, self.world, self.comm_device = engine, rank, world, torch.device(comm_device)
         self.levels_hint = 8
         self._gathered = None
+        self._bufs = None
+        mode = os.environ.get("MGX_DIST_EXCHANGE", "auto")
+        if mode not in ("gather", "reduce"):
+            mode = "reduce" if world >= 4 else "gather"
+        self.exchange = mode
 
     def _exchange(self, new):
+        """-> (maps, nmaps): what merge() takes"""
         W = self.world
         if W == 1:
-            return new
+            return new, 1
         mine = new if new.device == self.comm_device else new.to(self.comm_device)
-        if self._gathered is None or self._gathered.numel() != W * mine.numel() or self._gathered.device != self.comm_device:
-            self._gathered = torch.empty(W * mine.numel(), dtype=mine.dtype, device=self.comm_device)
-        dist.all_gather_into_tensor(self._gathered, mine.contiguous())
-        return self._gathered if self._gathered.device == new.device else self._gathered.to(new.device)
+        if self.exchange == "gather":
+            if self._gathered is None or self._gathered.numel() != W * mine.numel() or self._gathered.device != self.comm_device:
+                self._gathered = torch.empty(W * mine.numel(), dtype=mine.dtype, device=self.comm_device)
+            dist.all_gather_into_tensor(self._gathered, mine.contiguous())
+            out = self._gathered
+            return (out if out.device == new.device else out.to(new.device)), W
+        L = mine.numel()
+        S = (L + W - 1) // W                      # words per slice (engines pad their maps: L % W == 0 then)
+        if self._bufs is None or self._bufs[0].numel() != S * W or self._bufs[0].device != self.comm_device:
+            self._bufs = tuple(torch.zeros(S * W, dtype=mine.dtype, device=self.comm_device) for _ in range(3))
+        send, recv, full = self._bufs
+        if L == S * W:
+            send = mine.contiguous()
+        else:
+            send[:L].copy_(mine)
+        dist.all_to_all_single(recv, send)        # recv slice r = rank r's bits of MY slice
+        parts = recv.view(W, S)
+        acc = parts[0]
+        for r in range(1, W):
+            torch.bitwise_or(acc, parts[r], out=acc)
+        dist.all_gather_into_tensor(full, acc)    # every rank's merged slice: the OR of all maps
+        out = full[:L] if L != S * W else full
+        return (out if out.device == new.device else out.to(new.device)), 1
 
     def run(self, src):
         e = self.e
@@ -236,7 +277,7 @@ class DistBfs2:
         while True:
             for _ in range(batch):
                 new = e.push(level)
-                e.merge(level, self._exchange(new))
+                e.merge(level, *self._exchange(new))
                 level += 1
             st = e.status(level)
             if st["over"]:
@@ -392,11 +433,19 @@ def bench_main(args, rank, world, local_rank):
     seed = gscale if args.seed is None else args.seed
     n = 1 << gscale
     t_build = time.time()
+    verbose = os.environ.get("MGX_BENCH_VERBOSE") == "1"
+
+    def say(what):
+        if verbose:
+            print("[rank %d %.1f s] %s" % (rank, time.time() - t_build0, what), file=sys.stderr, flush=True)
+
+    t_build0 = t_build
     gen = int(os.environ.get("MGX_DIST_GEN", "2"))
     if gen == 2:
         ro, col, new_of_old, old_of_new, deg_new = rmat_cyclic_shard(ctx, gscale, args.edgefactor, seed, world, rank, device)
         torch.cuda.synchronize()
         t_build = time.time() - t_build
+        say("shard built: %d rows %d edges" % (ro.numel() - 1, col.numel()))
         eng = HipRankEngine2(ctx, n, world, rank, ro, col)
         bfs = DistBfs2(eng, rank, world, "cuda" if dist.get_backend() == "nccl" else "cpu")
         from .rmat import _mix64_py
@@ -413,8 +462,10 @@ def bench_main(args, rank, world, local_rank):
         bfs = DistBfs(eng, rank, world, "cuda")
         ro_host = ro.cpu().numpy()
         sources = pick_sources_dist(ro_host, eng.lo, eng.hi, n, args.steps + args.warmup, seed, device)
+    say("sources picked")
     for s in sources[: args.warmup]:
-        bfs.run(s)
+        st = bfs.run(s)
+        say("warmup traversal done: %s" % (st,))
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -422,6 +473,7 @@ def bench_main(args, rank, world, local_rank):
     edges_local, levels = 0, 0
     for s in sources[args.warmup:]:
         st = bfs.run(s)
+        say("traversal done: %s" % (st,))
         edges_local += st["edges_local"]
         levels += st["levels"]
     torch.cuda.synchronize()
@@ -442,8 +494,10 @@ def bench_main(args, rank, world, local_rank):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
                "data": "synthetic",
                "config": {"workload": "BFS push on RMAT scale %d (= %d per GPU + log2 N) ef %d, symmetrised, "
-                                      "hub-first ids, cyclic vertex partition over %d GPUs, fused level kernels per rank, all-gather of new-visited bitmaps (RCCL), "
-                                      "%d seeded sources" % (gscale, args.scale, args.edgefactor, world, args.steps),
+                                      "hub-first ids, cyclic vertex partition over %d GPUs, fused level kernels per rank, new-visited bitmaps OR-ed across ranks (%s), "
+                                      "%d seeded sources" % (gscale, args.scale, args.edgefactor, world,
+                                                             "one RCCL all-gather per level" if getattr(bfs, "exchange", "gather") == "gather"
+                                                             else "RCCL all-to-all of slices + all-gather of the merged slices per level", args.steps),
                           "scale": gscale, "edgefactor": args.edgefactor, "seed": seed,
                           "parallelism": "vertex-cyclic x%d" % world},
                "roofline": {"bound": "hbm", "kernel": "k_bfs_push_level_stream + k_bfs_push_level_wave (per rank)",

@@ -102,8 +102,8 @@ class NumpyRankEngine2:
         new[g[~self.visited[g]]] = True
         return torch.from_numpy(self._bits_to_words(new.astype(np.uint8), self.nwords).copy())
 
-    def merge(self, level, gathered):
-        g = gathered.numpy().reshape(self.ranks, self.nwords)
+    def merge(self, level, maps, nmaps):
+        g = maps.numpy().reshape(nmaps, -1)[:, : self.nwords]
         merged = np.bitwise_or.reduce(g.view(np.uint32), axis=0)
         bits = self._words_to_bits(merged, self.n_global)
         self.visited |= bits

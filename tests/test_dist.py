@@ -134,14 +134,20 @@ def test_partitioned_bfs_hip_engine_two_ranks_one_gpu(built):
     _run(2, True, 12, 12)
 
 
+@pytest.mark.parametrize("exchange", ["gather", "reduce"])
 @pytest.mark.parametrize("world", [1, 2, 3])
-def test_bitmap_exchange_bfs_gloo_cpu(built, world):
+def test_bitmap_exchange_bfs_gloo_cpu(built, world, exchange, monkeypatch):
+    """exchange: one all_gather of the ranks' maps, or all_to_all of slices + OR + all_gather of the merged slices
+    (DistBfs2; world 3 does not divide the bitmap: the slices are padded)"""
+    monkeypatch.setenv("MGX_DIST_EXCHANGE", exchange)
     _run(world, False, 9, 9, _worker2)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,scale", [(1, 12), (2, 12), (2, 16), (3, 14)])
-def test_bitmap_exchange_bfs_hip_engine_ranks_share_one_gpu(built, world, scale):
+@pytest.mark.parametrize("world,scale,exchange", [(1, 12, "gather"), (2, 12, "gather"), (2, 16, "reduce"),
+                                                  (3, 14, "gather"), (3, 14, "reduce")])
+def test_bitmap_exchange_bfs_hip_engine_ranks_share_one_gpu(built, world, scale, exchange, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    monkeypatch.setenv("MGX_DIST_EXCHANGE", exchange)
     _run(world, True, scale, scale, _worker2)

@@ -27,7 +27,7 @@ for it, s in enumerate(srcs):
         for _ in range(batch):
             gathered = torch.cat([e.push(level) for e in engs]) if G > 1 else engs[0].push(level)
             for e in engs:
-                e.merge(level, gathered)
+                e.merge(level, gathered, G)
             level += 1
         sts = [e.status(level) for e in engs]
         if sts[0]["over"]:
