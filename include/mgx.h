@@ -234,6 +234,10 @@ MGX_API int mgx_dbfs2_merge(mgx_dbfs2_t h, int level, const unsigned* d_gathered
  * reduce-scatter (all-to-all of slices + OR) followed by an all-gather of the merged slices, which moves
  * 2 (R-1)/R bitmaps per rank and level instead of R-1. */
 MGX_API int mgx_dbfs2_merge_maps(mgx_dbfs2_t h, int level, const unsigned* d_maps, int maps, int64_t stride_words);
+/* The reduce step of that exchange: d_out[w] = OR over r < maps of d_maps[r * stride_words + w], w < words (words and
+ * stride multiples of 4; d_out may be d_maps itself).  Asynchronous on the context's stream. */
+MGX_API int mgx_dbfs2_or_maps(mgx_dbfs2_t h, const unsigned* d_maps, int maps, int64_t stride_words, int64_t words,
+                              unsigned* d_out);
 /* Synchronises.  next_level = number of levels enqueued so far.  out6: [0] traversal over (a level discovered nothing
  * on ANY rank -- the same on every rank, no reduction needed) [1] levels that hold vertices [2] edges this rank has
  * expanded [3] vertices discovered by all ranks in the level merged last [4] size and [5] edges of this rank's next

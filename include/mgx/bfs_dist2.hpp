@@ -68,6 +68,20 @@ __global__ __launch_bounds__(BLOCK) void k_d2_or(const uint4* __restrict__ gathe
   if (lane_id() == 0 && found) atomicAdd(&c->merged_new, (u64)found);
 }
 
+// out[w] = OR over the maps of maps[r][w] (the reduce step of the slice exchange: the maps are the ranks' versions of
+// this rank's slice)
+__global__ __launch_bounds__(BLOCK) void k_d2_or_maps(const uint4* __restrict__ maps, int nmaps, long long stride4,
+                                                      long long nwords4, uint4* __restrict__ out) {
+  for (long long w = (long long)blockIdx.x * BLOCK + threadIdx.x; w < nwords4; w += (long long)gridDim.x * BLOCK) {
+    uint4 g = maps[w];
+    for (int r = 1; r < nmaps; ++r) {
+      const uint4 x = maps[(long long)r * stride4 + w];
+      g.x |= x.x; g.y |= x.y; g.z |= x.z; g.w |= x.w;
+    }
+    out[w] = g;
+  }
+}
+
 __global__ void k_d2_init(bfs_fused_args_t a, int* labels_local, int src, int ranks, int rank) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   bfs_ctrl_reset(a.ctrl);

@@ -834,6 +834,19 @@ int mgx_dbfs2_merge_maps(mgx_dbfs2_t h, int level, const unsigned* d_maps, int m
   mgx::d2_merge(h->st, level, d_maps, maps, (long long)stride_words, *h->c->ctx);
   MGX_CATCH
 }
+int mgx_dbfs2_or_maps(mgx_dbfs2_t h, const unsigned* d_maps, int maps, int64_t stride_words, int64_t words,
+                      unsigned* d_out) {
+  MGX_TRY
+  MGX_REQUIRE(h && d_maps && d_out, "NULL argument");
+  MGX_REQUIRE(maps >= 1 && maps <= 64 && words >= 0 && words % 4 == 0 && stride_words % 4 == 0 && stride_words >= words,
+              "mgx_dbfs2_or_maps: maps must be 1..64, words and stride multiples of 4, stride >= words");
+  use_device(h->c);
+  if (words)
+    hipLaunchKernelGGL(mgx::k_d2_or_maps, dim3(mgx::grid_for(words / 4, mgx::BLOCK, 1024)), dim3(mgx::BLOCK), 0,
+                       h->c->ctx->stream(), (const uint4*)d_maps, maps, (long long)(stride_words / 4), (long long)(words / 4),
+                       (uint4*)d_out);
+  MGX_CATCH
+}
 int mgx_dbfs2_status(mgx_dbfs2_t h, int next_level, int64_t* out6) {
   MGX_TRY
   MGX_REQUIRE(h && out6 && next_level >= 0, "bad argument");

@@ -200,6 +200,12 @@ class HipRankEngine2:
         check(lib.mgx_dbfs2_merge_maps(self._h, int(level), C.c_void_p(maps.data_ptr()), int(nmaps),
                                        int(maps.numel() // nmaps)))
 
+    def or_maps(self, maps, nmaps, out):
+        """out[w] = OR of the nmaps equally long maps (device tensors on this engine's GPU; out may alias maps)"""
+        words = maps.numel() // nmaps
+        check(lib.mgx_dbfs2_or_maps(self._h, C.c_void_p(maps.data_ptr()), int(nmaps), int(words), int(words),
+                                    C.c_void_p(out.data_ptr())))
+
     def status(self, next_level):
         o = (C.c_int64 * 6)()
         check(lib.mgx_dbfs2_status(self._h, int(next_level), o))
@@ -263,8 +269,11 @@ class DistBfs2:
         dist.all_to_all_single(recv, send)        # recv slice r = rank r's bits of MY slice
         parts = recv.view(W, S)
         acc = parts[0]
-        for r in range(1, W):
-            torch.bitwise_or(acc, parts[r], out=acc)
+        if hasattr(self.e, "or_maps") and recv.is_cuda and S % 4 == 0:
+            self.e.or_maps(recv, W, acc)          # one kernel (out aliases map 0: every word is read before it is written)
+        else:
+            for r in range(1, W):
+                torch.bitwise_or(acc, parts[r], out=acc)
         dist.all_gather_into_tensor(full, acc)    # every rank's merged slice: the OR of all maps
         out = full[:L] if L != S * W else full
         return (out if out.device == new.device else out.to(new.device)), 1

@@ -151,3 +151,32 @@ def test_bitmap_exchange_bfs_hip_engine_ranks_share_one_gpu(built, world, scale,
         pytest.skip("no GPU")
     monkeypatch.setenv("MGX_DIST_EXCHANGE", exchange)
     _run(world, True, scale, scale, _worker2)
+
+
+@pytest.mark.gpu
+def test_or_maps_kernel_matches_numpy(built):
+    """mgx_dbfs2_or_maps (the reduce step of the slice exchange, used when the collectives run on the GPU)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import mini_amd
+    from mini_amd.dist_bfs import HipRankEngine2
+    ctx = mini_amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    ro = torch.tensor([0, 1, 2], dtype=torch.int32).cuda()           # two vertices joined by an edge
+    ci = torch.tensor([1, 0], dtype=torch.int32).cuda()
+    eng = HipRankEngine2(ctx, 2, 1, 0, ro, ci)
+    rng = np.random.default_rng(5)
+    for nmaps, words in ((1, 4), (2, 8), (3, 1028), (8, 65536)):
+        maps = rng.integers(-2**31, 2**31 - 1, size=nmaps * words, dtype=np.int64).astype(np.int32)
+        want = np.bitwise_or.reduce(maps.reshape(nmaps, words), axis=0)
+        d = torch.from_numpy(maps).cuda()
+        out = torch.empty(words, dtype=torch.int32).cuda()
+        eng.or_maps(d, nmaps, out)
+        ctx.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+        if words:
+            eng.or_maps(d, nmaps, d[:words])                          # in place, as DistBfs2 uses it
+            ctx.synchronize()
+            assert np.array_equal(d[:words].cpu().numpy(), want)
+    with pytest.raises(mini_amd.MgxError):
+        eng.or_maps(torch.zeros(6, dtype=torch.int32).cuda(), 2, torch.zeros(3, dtype=torch.int32).cuda())   # words % 4
+    eng.close()

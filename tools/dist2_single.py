@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Generation-2 partitioned BFS on ONE GPU: G rank engines share the device and run one after another
 (the all-gather becomes a concatenation), so the time per rank = total / G is what each GPU of a G-GPU
-job would spend in kernels per BFS (no xGMI time).  usage: dist2_single.py [scale] [G]"""
+job would spend in kernels per BFS (no xGMI time).  usage: dist2_single.py [scale] [G] [gather|reduce]
+reduce: the slice exchange of DistBfs2 (all-to-all of slices -> OR -> all-gather of merged slices), the two
+collectives again as copies."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,6 +11,7 @@ import mini_amd
 from mini_amd.dist_bfs import HipRankEngine2, rmat_cyclic_shard
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+mode = sys.argv[3] if len(sys.argv) > 3 else "gather"
 dev = torch.device("cuda", 0)
 ctx = mini_amd.Context(0, torch.cuda.current_stream().cuda_stream)
 n = 1 << scale
@@ -25,9 +28,21 @@ for it, s in enumerate(srcs):
     level, batch = 0, hint
     while True:
         for _ in range(batch):
-            gathered = torch.cat([e.push(level) for e in engs]) if G > 1 else engs[0].push(level)
-            for e in engs:
-                e.merge(level, gathered, G)
+            if mode == "reduce" and G > 1:
+                maps = [e.push(level) for e in engs]
+                S = maps[0].numel() // G
+                merged = []
+                for r, e in enumerate(engs):                       # rank r: slice r of every map, OR-ed
+                    recv = torch.cat([m[r * S:(r + 1) * S] for m in maps])
+                    e.or_maps(recv, G, recv[:S])
+                    merged.append(recv[:S])
+                full = torch.cat(merged)
+                for e in engs:
+                    e.merge(level, full, 1)
+            else:
+                gathered = torch.cat([e.push(level) for e in engs]) if G > 1 else engs[0].push(level)
+                for e in engs:
+                    e.merge(level, gathered, G)
             level += 1
         sts = [e.status(level) for e in engs]
         if sts[0]["over"]:
@@ -37,5 +52,5 @@ for it, s in enumerate(srcs):
     edges = sum(st["edges_local"] for st in sts)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     if it:
-        print("src %d levels %d edges %d  total %.3f ms  per-rank %.3f ms  -> %.1f GTEPS aggregate (no exchange time)"
+        print(mode + " src %d levels %d edges %d  total %.3f ms  per-rank %.3f ms  -> %.1f GTEPS aggregate (no exchange time)"
               % (s, sts[0]["levels"], edges, dt * 1e3, dt * 1e3 / G, edges / (dt / G) / 1e9))
