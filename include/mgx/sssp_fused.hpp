@@ -95,9 +95,16 @@ __global__ void k_sssp_open(sssp_args_t a, int it) {
 
 constexpr int SSSP_EPT = 4;
 constexpr int SSSP_TILE = WAVE * SSSP_EPT;
+// Upper bounds of the distances of the first SSSP_HOTN vertices (the hubs under the hub-first layout: the targets
+// of a large share of the edges), 16 bits each, in LDS: a candidate that is not below the bound cannot improve the
+// distance and skips the gather from the 16 MB distance array -- what bounds this kernel (80 G relaxations/s is the
+// rate of 4-byte gathers from a table of that size, profiles/r01/microbench.jsonl).  A bound is the distance at the
+// time the workgroup started, rounded UP to bfloat16: distances only decrease, so it stays a bound.
+constexpr int SSSP_HOTN = 32768;                   // 64 KB per workgroup, two workgroups per CU (65536 with one: same rate)
+constexpr u32 SSSP_HOT_MIN_EDGES = 1u << 20;       // smaller iterations do not pay for the copy
 
 template <int NT>
-__global__ __launch_bounds__(NT) void k_sssp_relax(sssp_args_t a, int it) {
+__global__ __launch_bounds__(NT, 8) void k_sssp_relax(sssp_args_t a, int it) {
   constexpr int NW = NT / WAVE;
   constexpr int EPT = SSSP_EPT;
   __shared__ u32 s_off[NW][68];
@@ -121,6 +128,18 @@ __global__ __launch_bounds__(NT) void k_sssp_relax(sssp_args_t a, int it) {
   const float* __restrict__ wts = a.weights;
   u32* dist = a.dist;
   unsigned char* mark = a.mark;
+
+  extern __shared__ __attribute__((aligned(16))) u32 s_hot[];        // SSSP_HOTN / 2 words: two bounds per word
+  const bool use_hot = E >= SSSP_HOT_MIN_EDGES;
+  const u32 hot_n = use_hot ? ((u32)a.n < (u32)SSSP_HOTN ? ((u32)a.n & ~1u) : (u32)SSSP_HOTN) : 0u;
+  if (use_hot) {
+    for (u32 i = threadIdx.x; i < hot_n / 2; i += NT) {
+      const uint2 d = *(const uint2*)(dist + 2 * i);
+      s_hot[i] = ((d.x + 0xFFFFu) >> 16) | (((d.y + 0xFFFFu) >> 16) << 16);
+    }
+    __syncthreads();
+  }
+  const unsigned short* const hot16 = (const unsigned short*)s_hot;
 
   const u32 total_waves = gridDim.x * NW;
   u32 per = (E + total_waves - 1) / total_waves;
@@ -226,6 +245,16 @@ __global__ __launch_bounds__(NT) void k_sssp_relax(sssp_args_t a, int it) {
       ndA[k] = __float_as_uint(__uint_as_float(duB[k]) + wB[k]);
     }
     actA = haveB ? actB : 0u;
+    // candidates that cannot beat the bound of a hot neighbour: no gather (the lane reads dist[0] with the others)
+    u32 gA[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const bool hotm = (u32)vA[k] < hot_n;
+      const u32 ub = hot16[hotm ? (u32)vA[k] : 0u];
+      const bool skip = hotm && ndA[k] >= (ub << 16);
+      if (skip) actA &= ~(1u << k);
+      gA[k] = skip ? 0u : (u32)vA[k];
+    }
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       u32 ei = haveC ? eidxC[k] : 0u;
@@ -236,7 +265,7 @@ __global__ __launch_bounds__(NT) void k_sssp_relax(sssp_args_t a, int it) {
     actB = haveC ? actC : 0u;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      oldA[k] = dist[vA[k]];
+      oldA[k] = dist[gA[k]];
     }
     haveA = haveB;
     haveB = haveC;
@@ -380,12 +409,17 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   a.n = st.n;
   hipLaunchKernelGGL(k_sssp_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src,
                      layout ? layout->new_of_old : (const int*)nullptr);
+  static bool attr_set = false;
+  if (!attr_set) {
+    MGX_HIP(hipFuncSetAttribute((const void*)k_sssp_relax<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SSSP_HOTN * 2));
+    attr_set = true;
+  }
   int it = 0;
   for (int batch = 0;; ++batch) {
     const int nit = batch == 0 ? st.iters_hint : 2;
     for (int i = 0; i < nit; ++i, ++it) {
       hipLaunchKernelGGL(k_sssp_open, dim3(1), dim3(64), 0, s, a, it);
-      hipLaunchKernelGGL(k_sssp_relax<1024>, dim3(ctx.num_cus * 2), dim3(1024), 0, s, a, it);
+      hipLaunchKernelGGL(k_sssp_relax<1024>, dim3(ctx.num_cus * 2), dim3(1024), SSSP_HOTN * 2, s, a, it);
       hipLaunchKernelGGL(k_sssp_build<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, it);
     }
     MGX_HIP(hipMemcpyAsync(st.host_ctrl, st.ctrl.data(), offsetof(bfs_ctrl_t, trace) + 64 * sizeof(u64), hipMemcpyDeviceToHost, s));
