@@ -121,15 +121,16 @@ def main():
     # ~6 us gap on the stream (rocprofv3 kernel trace, profiles/), 3 events x ~8 levels per BFS: inside the timed
     # region they would cost ~10 % of `value`.
     bfs.set_kernel_timing(True)
+    stats_timed = []
     for s in sources[args.warmup:]:
-        bfs.run(s, mode, args.alpha)
+        stats_timed.append(bfs.run(s, mode, args.alpha))
         kernel_times.append(bfs.kernel_times())
     bfs.set_kernel_timing(False)
 
     m_t = sum(st["m_t"] for st in stats)
     reached = sum(st["reached"] for st in stats)
-    launches = sum(st["kernel_launches"] for st in stats)
-    kernel_ns = sum(st["kernel_ns"] for st in stats)
+    launches = sum(st["kernel_launches"] for st in stats_timed)      # (batch events only exist in the second pass)
+    kernel_ns = sum(st["kernel_ns"] for st in stats_timed)
     nf_total = sum(st["frontier_vertices"] for st in stats)   # vertices expanded (degree >= 1)
     # algorithmic bytes: top-down levels 8 B/edge expanded, bottom-up levels 4.125 B per inspected in-edge
     # (SURVEY 8d), 20 B per frontier vertex either way
@@ -173,7 +174,9 @@ def main():
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": traffic, "launches": dom_launches if dom_launches else launches,
                 "timing": "HIP events around every launch of this kernel, second pass over the same %d sources "
-                          "(events kept out of the timed region: each leaves a ~6 us gap on the stream)" % len(stats),
+                          "(events kept out of the timed region: each leaves a ~6 us gap on the stream; the timed "
+                          "region launches this kernel's body and the short-row body as ONE grid per level, "
+                          "k_bfs_push_level)" % len(stats),
                 "avg_launch_us": round(avg_launch_s * 1e6, 3),
                 "alg_bytes_per_launch": round(bytes_per_launch, 1),
                 "share_of_edges": round(dom_edges / max(m_t, 1), 4) if dom_launches else 1.0,

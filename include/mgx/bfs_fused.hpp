@@ -382,6 +382,10 @@ struct bfs_fused_state_t {
   int n = 0;
   int levels_per_sync = 2;           // slots (see bfs_fused_run.hpp) launched between two read-backs of the control block ...
   int slots_hint = 6;                // ... except for the first batch: as many slots as the previous traversal needed
+  int levels_hint = 8;               // the same for the direct scheme (bfs_fused_run.hpp): levels of the previous traversal + 1
+  bool direct_levels = true;         // scheme of the next top-down traversal: direct unless the previous one was deep
+  int direct_max_levels = 32;
+  bool time_batches = false;         // HIP events around every batch of launches (-> level_kernel_ms; ~6 us each)
   unsigned small_max_edges = 256;    // levels up to this size run inside the single-workgroup kernel (0: never);
                                      // measured on RMAT-22: beyond a few hundred edges one workgroup's dependent
                                      // round trips cost more than the four launches of a device-wide level
@@ -428,6 +432,7 @@ struct bfs_fused_state_t {
     if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("MGX_BFS_TIME_KERNELS")) time_kernels = atoi(e) != 0;
     if (const char* e = getenv("MGX_BFS_COUNT_MARKS")) count_marks = atoi(e) != 0;
+    if (const char* e = getenv("MGX_BFS_TIME_BATCHES")) time_batches = atoi(e) != 0;
     if (const char* e = getenv("MGX_BFS_HOT_MIN_EDGES")) hot_min_edges = (unsigned)atoll(e);
     if (const char* e = getenv("MGX_BFS_LEVELS_PER_SYNC")) levels_per_sync = atoi(e) > 0 ? atoi(e) : 2;
     if (const char* e = getenv("MGX_BFS_SMALL_MAX_EDGES")) small_max_edges = (unsigned)atoll(e);

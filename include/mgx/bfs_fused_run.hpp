@@ -34,8 +34,12 @@ constexpr int BFS_STREAM_HOTW2 = 20400;   // two workgroups per CU: 80 KB of bit
 // Saves a launch per level (~6 us of device time each, measured) and lets the short rows start while the last
 // slices of the long rows drain.  Profiling runs (bfs_fused_state_t::time_kernels) launch the two kernels
 // separately so that each can be bracketed by events.
+// open_here (direct scheme, see bfs_fused_run: explicit level numbers, no k_bfs_small_levels in front): the level's
+// bookkeeping is done by one thread of this grid.  Nothing it writes is read by the level's own kernels in a
+// top-down run: they take the queue sizes from the cursors, which the previous level's k_bfs_build completed.
 template <bool COLDT>
-__global__ __launch_bounds__(1024) void k_bfs_push_level(bfs_fused_args_t a, int level, u32 nstream) {
+__global__ __launch_bounds__(1024) void k_bfs_push_level(bfs_fused_args_t a, int level, u32 nstream, int open_here) {
+  if (open_here && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) (void)bfs_open_level(a, level);
   if (blockIdx.x < nstream) bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, COLDT, false, true>(a, level, blockIdx.x, nstream);
   else bfs_wave_body<1024, 18000, COLDT, false>(a, level, blockIdx.x - nstream, gridDim.x - nstream);
 }
@@ -126,10 +130,11 @@ inline void bfs_launch_wave(const bfs_fused_args_t& a, int level, standard_conte
   }
 }
 
-inline void bfs_launch_push(const bfs_fused_args_t& a, int level, standard_context_t& ctx) {
+inline void bfs_launch_push(const bfs_fused_args_t& a, int level, standard_context_t& ctx, bool open_here = false) {
   static const int merged = getenv("MGX_BFS_MERGED_PUSH") ? atoi(getenv("MGX_BFS_MERGED_PUSH")) : 1;
   static const bool custom_shapes = getenv("MGX_BFS_STREAM_SHAPE") || getenv("MGX_BFS_WAVE_SHAPE") || getenv("MGX_BFS_COLD_SHAPE");
   if (!merged || custom_shapes || a.flags) {
+    if (open_here) hipLaunchKernelGGL(k_bfs_level_begin, dim3(1), dim3(64), 0, ctx.stream(), a, level, 0);
     bfs_launch_stream(a, level, ctx);
     bfs_launch_wave(a, level, ctx);
     return;
@@ -140,9 +145,9 @@ inline void bfs_launch_push(const bfs_fused_args_t& a, int level, standard_conte
   const u32 nstream = a.long_min > 0 ? (u32)ctx.num_cus * 2 : 0u;
   const u32 nwave = (u32)ctx.num_cus * 2;
   if (bfs_cold_test(a.n))
-    hipLaunchKernelGGL(k_bfs_push_level<true>, dim3(nstream + nwave), dim3(1024), lds, s, a, level, nstream);
+    hipLaunchKernelGGL(k_bfs_push_level<true>, dim3(nstream + nwave), dim3(1024), lds, s, a, level, nstream, open_here ? 1 : 0);
   else
-    hipLaunchKernelGGL(k_bfs_push_level<false>, dim3(nstream + nwave), dim3(1024), lds, s, a, level, nstream);
+    hipLaunchKernelGGL(k_bfs_push_level<false>, dim3(nstream + nwave), dim3(1024), lds, s, a, level, nstream, open_here ? 1 : 0);
 }
 
 // Runs a whole BFS from `src` on the context's stream.  labels[] is (re)initialised here.  Returns with the
@@ -189,44 +194,60 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   st.stream_kernel_ms = 0.0;
   st.stream_kernel_launches = 0;
   st.batches = 0;
+  // Two launch schemes.
+  //   slots  [k_bfs_small_levels, push, (pull), build] with the level counter on the device: the single-workgroup
+  //          kernel runs any number of small levels inside one launch (deep graphs: hundreds of tiny levels) and
+  //          opens the next big one; on a shallow graph it is an idle ~5 us launch in front of every big level.
+  //   direct [push, build] per level with the level number as an argument; the level's bookkeeping rides on the push
+  //          launch.  Top-down runs only (a bottom-up level needs the direction decided before it starts).
+  // The scheme follows the previous traversal of the graph: direct unless that one was deep (MGX_BFS_DIRECT forces).
+  const char* const direct_str = getenv("MGX_BFS_DIRECT");          // (read per run: the tests switch it)
+  const int direct_env = direct_str ? atoi(direct_str) : -1;
+  // (profiling runs with events around the two push kernels keep the slot scheme unless forced: there the tiny levels
+  //  stay inside the single-workgroup kernel instead of adding no-op launches to the kernels' averages)
+  const bool direct = mode == 0 && (direct_env >= 0 ? direct_env != 0 : (st.direct_levels && !st.time_kernels));
+  const bool batch_events = st.time_kernels || st.time_batches;    // (an event costs ~6 us of stream gap)
   int slot = 0;
   for (int batch = 0;; ++batch) {
     // first batch: what the previous traversal of this graph needed (sources differ, level structure hardly)
-    int nslots = batch == 0 ? st.slots_hint : st.levels_per_sync;
+    int nslots = batch == 0 ? (direct ? st.levels_hint : st.slots_hint) : st.levels_per_sync;
     if (nslots > bfs_fused_state_t::EV_POOL / 3) nslots = bfs_fused_state_t::EV_POOL / 3;
-    MGX_HIP(hipEventRecord(st.ev0, s));
+    if (batch_events) MGX_HIP(hipEventRecord(st.ev0, s));
     for (int i = 0; i < nslots; ++i, ++slot) {
-      hipLaunchKernelGGL(k_bfs_small_levels<BFS_SMALL_NT>, dim3(1), dim3(BFS_SMALL_NT), bfs_small_lds_bytes(), s, a,
-                         st.small_max_edges);
+      const int lv_arg = direct ? slot : -1;
+      if (!direct)
+        hipLaunchKernelGGL(k_bfs_small_levels<BFS_SMALL_NT>, dim3(1), dim3(BFS_SMALL_NT), bfs_small_lds_bytes(), s, a,
+                           st.small_max_edges);
       const bool timed = st.time_kernels && 3 * i + 2 < bfs_fused_state_t::EV_POOL;
       if (timed) {
+        if (direct) hipLaunchKernelGGL(k_bfs_level_begin, dim3(1), dim3(64), 0, s, a, lv_arg, 0);
         MGX_HIP(hipEventRecord(st.wev[3 * i], s));
-        bfs_launch_stream(a, -1, ctx);
+        bfs_launch_stream(a, lv_arg, ctx);
         MGX_HIP(hipEventRecord(st.wev[3 * i + 1], s));
-        bfs_launch_wave(a, -1, ctx);
+        bfs_launch_wave(a, lv_arg, ctx);
         MGX_HIP(hipEventRecord(st.wev[3 * i + 2], s));
       } else {
-        bfs_launch_push(a, -1, ctx);
+        bfs_launch_push(a, lv_arg, ctx, direct);
       }
       if (mode == 1)
         hipLaunchKernelGGL(k_bfs_pull_level<256>, dim3(ctx.num_cus * 8), dim3(256), 0, s, a, -1);
       static const int build_nt = getenv("MGX_BFS_BUILD_NT") ? atoi(getenv("MGX_BFS_BUILD_NT")) : 512;   // 2 workgroups per CU overlap their phases: 0.585 vs 0.599 ms
       if (build_nt == 512)
-        hipLaunchKernelGGL((k_bfs_build<512, true>), dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, -1,
+        hipLaunchKernelGGL((k_bfs_build<512, true>), dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, lv_arg,
                            (const u32*)nullptr, labels, st.n, 1, 0, 1);
       else if (build_nt == 256)
-        hipLaunchKernelGGL((k_bfs_build<256, true>), dim3(bfs_build_grid(st.n, 256)), dim3(256), 0, s, a, -1,
+        hipLaunchKernelGGL((k_bfs_build<256, true>), dim3(bfs_build_grid(st.n, 256)), dim3(256), 0, s, a, lv_arg,
                            (const u32*)nullptr, labels, st.n, 1, 0, 1);
       else
-        hipLaunchKernelGGL((k_bfs_build<BFS_BUILD_NT, true>), dim3(bfs_build_grid(st.n)), dim3(BFS_BUILD_NT), 0, s, a, -1,
+        hipLaunchKernelGGL((k_bfs_build<BFS_BUILD_NT, true>), dim3(bfs_build_grid(st.n)), dim3(BFS_BUILD_NT), 0, s, a, lv_arg,
                            (const u32*)nullptr, labels, st.n, 1, 0, 1);
     }
-    MGX_HIP(hipEventRecord(st.ev1, s));
+    if (batch_events) MGX_HIP(hipEventRecord(st.ev1, s));
     // one read-back per batch: the counters and the first 64 trace slots (the flag alone would cost the same trip)
     MGX_HIP(hipMemcpyAsync(st.host_ctrl, st.ctrl.data(), offsetof(bfs_ctrl_t, trace) + 64 * sizeof(u64), hipMemcpyDeviceToHost, s));
     MGX_HIP(hipStreamSynchronize(s));
     float ms = 0.f;
-    MGX_HIP(hipEventElapsedTime(&ms, st.ev0, st.ev1));
+    if (batch_events) MGX_HIP(hipEventElapsedTime(&ms, st.ev0, st.ev1));
     st.level_kernel_ms += ms;
     for (int i = 0; st.time_kernels && i < nslots && 3 * i + 2 < bfs_fused_state_t::EV_POOL; ++i) {
       const int sl = slot - nslots + i;
@@ -246,7 +267,9 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
     st.level_kernel_launches += nslots;
     if (st.host_ctrl->done) break;
   }
-  st.slots_hint = st.host_ctrl->slots > 0 ? st.host_ctrl->slots : 1;
+  if (direct) st.levels_hint = st.host_ctrl->levels + 1;       // + the level that finds the frontier empty
+  else st.slots_hint = st.host_ctrl->slots > 0 ? st.host_ctrl->slots : 1;
+  st.direct_levels = st.host_ctrl->levels <= st.direct_max_levels;
   const int lv = st.host_ctrl->levels < BFS_MAX_TRACE ? st.host_ctrl->levels : BFS_MAX_TRACE;
   if (lv > 64) {                // the rest of the per-level trace (deep traversals only)
     MGX_HIP(hipMemcpyAsync(st.host_ctrl->trace + 64, st.ctrl.data()->trace + 64, (size_t)(lv - 64) * sizeof(u64), hipMemcpyDeviceToHost, s));

@@ -240,10 +240,13 @@ def test_bfs_fused_operator_equals_advance_plus_filter(gpu_ctx, oracle, rmat_gra
 
 
 # ---- whole traversals ---------------------------------------------------------------------------
+@pytest.mark.parametrize("direct", [1, 0])
 @pytest.mark.parametrize("scale", [8, 10, 13, 16])
-def test_bfs_rmat_parity_all_paths(gpu_ctx, oracle, rmat_graphs, scale):
+def test_bfs_rmat_parity_all_paths(gpu_ctx, oracle, rmat_graphs, scale, direct, monkeypatch):
+    """direct: the two launch schemes of the fused traversal (include/mgx/bfs_fused_run.hpp)"""
     import mini_amd
     from mini_amd import rmat
+    monkeypatch.setenv("MGX_BFS_DIRECT", str(direct))
     n, ro, ci, w = rmat_graphs[scale]
     g = _graph(gpu_ctx, ro, ci)
     deg = np.diff(ro)
@@ -272,20 +275,22 @@ def test_bfs_rmat_parity_all_paths(gpu_ctx, oracle, rmat_graphs, scale):
 
 @pytest.mark.parametrize("scale,hot_min_edges,long_min,small_max",
                          [(10, 0, 64, 0), (10, 0, 64, 8192), (13, 0, 8, 100), (13, 0, 0, 8192), (16, 0, 64, 8192),
-                          (16, 65536, 64, 0), (16, 0, 1, 3000), (16, 1 << 30, 16, 8192)])
+                          (16, 65536, 64, 0), (16, 0, 1, 3000), (16, 1 << 30, 16, 8192),
+                          (10, 0, 64, -1), (13, 0, 8, -1), (16, 0, 64, -1), (16, 65536, 0, -1), (16, 1 << 30, 1, -1)])
 def test_bfs_hub_first_layout_and_lds_hot_bitmap(gpu_ctx, oracle, torch_mod, rmat_graphs, scale, hot_min_edges, long_min,
                                                  small_max, monkeypatch):
     """fused traversal on the degree-sorted layout (hot prefix of the visited snapshot in LDS): labels must
     come back in ORIGINAL ids and equal the oracle's.  hot_min_edges=0 forces the LDS path on small graphs,
     2^30 keeps every probe in L2; long_min moves rows between the row-wise streaming kernel and the
     per-edge-rank kernel (0: no long-row queue, 1: every row is streamed); small_max: levels up to that many
-    edges run inside the single-workgroup kernel (0: none)."""
+    edges run inside the single-workgroup kernel (0: none; -1: the direct launch scheme, which has no such kernel)."""
     import mini_amd
     from mini_amd import rmat
     torch = torch_mod
     monkeypatch.setenv("MGX_BFS_HOT_MIN_EDGES", str(hot_min_edges))
     monkeypatch.setenv("MGX_BFS_LONG_MIN", str(long_min))
-    monkeypatch.setenv("MGX_BFS_SMALL_MAX_EDGES", str(small_max))
+    monkeypatch.setenv("MGX_BFS_DIRECT", "1" if small_max < 0 else "0")
+    monkeypatch.setenv("MGX_BFS_SMALL_MAX_EDGES", str(max(small_max, 0)))
     n, ro, ci, w = rmat_graphs[scale]
     d_ro, d_ci = torch.from_numpy(ro).cuda(), torch.from_numpy(ci).cuda()
     g = mini_amd.Graph.from_device(gpu_ctx, n, len(ci), d_ro, d_ci)
@@ -381,7 +386,9 @@ def test_bfs_directed_graph_with_zero_outdegree_vertices(gpu_ctx, oracle):
 @pytest.mark.parametrize("small_max", [8192, 0])
 def test_bfs_long_chain_many_levels(gpu_ctx, oracle, monkeypatch, small_max):
     """a path graph: > levels_per_sync levels, frontier of one vertex each.  small_max=8192: all 300 levels run
-    inside ONE launch of the single-workgroup kernel; 0: every level goes through the device-wide kernels."""
+    inside ONE launch of the single-workgroup kernel; 0: every level goes through the device-wide kernels.
+    The first traversal of a graph uses the direct launch scheme (a push and a build launch per level); having seen
+    300 levels, the engine switches to the slot scheme with the single-workgroup kernel for the next one."""
     import mini_amd
     monkeypatch.setenv("MGX_BFS_SMALL_MAX_EDGES", str(small_max))
     n = 300
@@ -393,10 +400,16 @@ def test_bfs_long_chain_many_levels(gpu_ctx, oracle, monkeypatch, small_max):
     st = bfs.run(0)
     assert np.array_equal(bfs.labels(), np.arange(n, dtype=np.int32))
     assert st["levels"] == n          # frontiers at depth 0..n-1 all expand an edge
+    assert st["small_levels"] == 0    # direct scheme
+    st = bfs.run(n - 1)               # deep graph seen: slot scheme
+    assert np.array_equal(bfs.labels(), np.arange(n - 1, -1, -1, dtype=np.int32))
+    assert st["levels"] == n
     assert st["small_levels"] == (n if small_max else 0)
+    bfs.run(n // 2)                   # 150 levels: still deep
+    assert np.array_equal(bfs.labels(), np.abs(np.arange(n) - n // 2).astype(np.int32))
 
 
-@pytest.mark.parametrize("small_max", [256, 0, 1 << 20])
+@pytest.mark.parametrize("small_max", [256, 0, 1 << 20, -1])
 @pytest.mark.parametrize("long_min", [64, 1])
 def test_bfs_long_row_queue_padding_boundaries(gpu_ctx, oracle, monkeypatch, small_max, long_min):
     """The long-row queue counts degrees rounded up to 64 and keeps degree & 63 in the low bits of its offsets
@@ -405,7 +418,9 @@ def test_bfs_long_row_queue_padding_boundaries(gpu_ctx, oracle, monkeypatch, sma
     256), by the single-workgroup kernel (small_max 2^20) and with every row in the long queue (long_min 1):
     labels, levels and the traversed-edge count (true edges, not padded ones) must equal the oracle's."""
     import mini_amd
-    monkeypatch.setenv("MGX_BFS_SMALL_MAX_EDGES", str(small_max))
+    # small_max -1: the direct launch scheme (no single-workgroup kernel at all); otherwise the slot scheme
+    monkeypatch.setenv("MGX_BFS_DIRECT", "1" if small_max < 0 else "0")
+    monkeypatch.setenv("MGX_BFS_SMALL_MAX_EDGES", str(max(small_max, 0)))
     monkeypatch.setenv("MGX_BFS_LONG_MIN", str(long_min))
     monkeypatch.setenv("MGX_BFS_HOT_MIN_EDGES", "0")
     degs = [1, 2, 62, 63, 64, 65, 66, 126, 127, 128, 129, 190, 191, 192, 193, 255, 256, 257, 511, 512, 513, 5000]
