@@ -151,8 +151,7 @@ inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx) {
   hipStream_t s = ctx.stream();
   bfs_fused_args_t a = st.args();
   bfs_set_kernel_attributes();
-  hipLaunchKernelGGL(k_bfs_level_begin, dim3(1), dim3(64), 0, s, a, level, 1);
-  bfs_launch_push(a, level, ctx);
+  bfs_launch_push(a, level, ctx, 2);          // (the level's bookkeeping rides on the push launch)
   hipLaunchKernelGGL(k_d2_newbits, dim3(grid_for(st.nwords, BLOCK, 256)), dim3(BLOCK), 0, s, st.fs->visited.data(),
                      st.fs->mark.data(), st.newbits, st.nwords, (long long)st.n_global, a.ctrl);
 }

@@ -206,11 +206,14 @@ __device__ __forceinline__ bool bfs_open_level(const bfs_fused_args_t& a, int le
 // Explicit-level variant of the above as a kernel of its own (partitioned runs: the host counts the levels).
 // There the traversal is over when the level before discovered nothing on ANY rank (ctrl->merged_new, the same
 // number on every rank), whatever this rank's own queues hold.
-__global__ void k_bfs_level_begin(bfs_fused_args_t a, int level, int partitioned) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+__device__ __forceinline__ void bfs_begin_level(const bfs_fused_args_t& a, int level, int partitioned) {
   bfs_ctrl_t* const c = a.ctrl;
   if (partitioned && level > 0 && c->merged_new == 0 && !c->dist_done) { c->dist_done = 1; c->dist_levels = level; }
   (void)bfs_open_level(a, level);
+}
+__global__ void k_bfs_level_begin(bfs_fused_args_t a, int level, int partitioned) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  bfs_begin_level(a, level, partitioned);
 }
 
 // Device-wide kernels are launched either with an explicit level (>= 0) or with level < 0: then the level is

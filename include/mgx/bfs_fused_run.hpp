@@ -34,12 +34,12 @@ constexpr int BFS_STREAM_HOTW2 = 20400;   // two workgroups per CU: 80 KB of bit
 // Saves a launch per level (~6 us of device time each, measured) and lets the short rows start while the last
 // slices of the long rows drain.  Profiling runs (bfs_fused_state_t::time_kernels) launch the two kernels
 // separately so that each can be bracketed by events.
-// open_here (direct scheme, see bfs_fused_run: explicit level numbers, no k_bfs_small_levels in front): the level's
-// bookkeeping is done by one thread of this grid.  Nothing it writes is read by the level's own kernels in a
+// open_here (direct scheme, see bfs_fused_run: explicit level numbers, no k_bfs_small_levels in front; 2: a rank of a
+// partitioned run): the level's bookkeeping is done by one thread of this grid.  Nothing it writes is read by the level's own kernels in a
 // top-down run: they take the queue sizes from the cursors, which the previous level's k_bfs_build completed.
 template <bool COLDT>
 __global__ __launch_bounds__(1024) void k_bfs_push_level(bfs_fused_args_t a, int level, u32 nstream, int open_here) {
-  if (open_here && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) (void)bfs_open_level(a, level);
+  if (open_here && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) bfs_begin_level(a, level, open_here == 2);
   if (blockIdx.x < nstream) bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, COLDT, false, true>(a, level, blockIdx.x, nstream);
   else bfs_wave_body<1024, 18000, COLDT, false>(a, level, blockIdx.x - nstream, gridDim.x - nstream);
 }
@@ -130,11 +130,11 @@ inline void bfs_launch_wave(const bfs_fused_args_t& a, int level, standard_conte
   }
 }
 
-inline void bfs_launch_push(const bfs_fused_args_t& a, int level, standard_context_t& ctx, bool open_here = false) {
+inline void bfs_launch_push(const bfs_fused_args_t& a, int level, standard_context_t& ctx, int open_here = 0) {
   static const int merged = getenv("MGX_BFS_MERGED_PUSH") ? atoi(getenv("MGX_BFS_MERGED_PUSH")) : 1;
   static const bool custom_shapes = getenv("MGX_BFS_STREAM_SHAPE") || getenv("MGX_BFS_WAVE_SHAPE") || getenv("MGX_BFS_COLD_SHAPE");
   if (!merged || custom_shapes || a.flags) {
-    if (open_here) hipLaunchKernelGGL(k_bfs_level_begin, dim3(1), dim3(64), 0, ctx.stream(), a, level, 0);
+    if (open_here) hipLaunchKernelGGL(k_bfs_level_begin, dim3(1), dim3(64), 0, ctx.stream(), a, level, open_here == 2 ? 1 : 0);
     bfs_launch_stream(a, level, ctx);
     bfs_launch_wave(a, level, ctx);
     return;
@@ -145,9 +145,9 @@ inline void bfs_launch_push(const bfs_fused_args_t& a, int level, standard_conte
   const u32 nstream = a.long_min > 0 ? (u32)ctx.num_cus * 2 : 0u;
   const u32 nwave = (u32)ctx.num_cus * 2;
   if (bfs_cold_test(a.n))
-    hipLaunchKernelGGL(k_bfs_push_level<true>, dim3(nstream + nwave), dim3(1024), lds, s, a, level, nstream, open_here ? 1 : 0);
+    hipLaunchKernelGGL(k_bfs_push_level<true>, dim3(nstream + nwave), dim3(1024), lds, s, a, level, nstream, open_here);
   else
-    hipLaunchKernelGGL(k_bfs_push_level<false>, dim3(nstream + nwave), dim3(1024), lds, s, a, level, nstream, open_here ? 1 : 0);
+    hipLaunchKernelGGL(k_bfs_push_level<false>, dim3(nstream + nwave), dim3(1024), lds, s, a, level, nstream, open_here);
 }
 
 // Runs a whole BFS from `src` on the context's stream.  labels[] is (re)initialised here.  Returns with the
@@ -227,7 +227,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
         bfs_launch_wave(a, lv_arg, ctx);
         MGX_HIP(hipEventRecord(st.wev[3 * i + 2], s));
       } else {
-        bfs_launch_push(a, lv_arg, ctx, direct);
+        bfs_launch_push(a, lv_arg, ctx, direct ? 1 : 0);
       }
       if (mode == 1)
         hipLaunchKernelGGL(k_bfs_pull_level<256>, dim3(ctx.num_cus * 8), dim3(256), 0, s, a, -1);
