@@ -3,7 +3,7 @@
 # rocprofv3 kernel-trace stats of the SAME bench command, and FETCH/WRITE PMC passes.
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/round
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 cd $R
 timeout 1800 python -m pytest tests -q -m gpu --timeout 900 > $O/pytest_gpu.log 2>&1
 echo "pytest rc=$?"; tail -4 $O/pytest_gpu.log
