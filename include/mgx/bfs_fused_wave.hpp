@@ -55,7 +55,8 @@ __device__ __forceinline__ void bfs_wave_body(const bfs_fused_args_t& a, int lev
   // slice of this wave
   const u32 total_waves = nblocks * NW;
   u32 per = (E + total_waves - 1) / total_waves;
-  per = (per + BFS_WAVE_TILE - 1) / BFS_WAVE_TILE * BFS_WAVE_TILE;
+  per = (per + WAVE - 1) / WAVE * WAVE;      // (not whole tiles: a level of a few thousand one-edge rows is spread over
+                                             //  four times the waves, one tile of 64 rows each instead of four in a row)
   const u64 rb = (u64)(block * NW + wave) * per;
   const bool has_work = rb < (u64)E;
   const u32 r_begin = has_work ? (u32)rb : E;

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NT, 8) void k_sssp_relax(sssp_args_t a, int it) {
 
   const u32 total_waves = gridDim.x * NW;
   u32 per = (E + total_waves - 1) / total_waves;
-  per = (per + SSSP_TILE - 1) / SSSP_TILE * SSSP_TILE;
+  per = (per + WAVE - 1) / WAVE * WAVE;
   const u64 rb = (u64)(blockIdx.x * NW + wave) * per;
   const bool has_work = rb < (u64)E;
   const u32 r_begin = has_work ? (u32)rb : E;
