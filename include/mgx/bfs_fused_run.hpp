@@ -266,8 +266,18 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
     if (st.batches < 256) st.batch_ms[st.batches++] = ms;
     st.level_kernel_launches += nslots;
     if (st.host_ctrl->done) break;
+    if (direct) {
+      // all `slot` levels launched so far have run; if the last build left both queues empty the traversal is over
+      // (no need to launch the level that would find that out)
+      const u64 next = st.host_ctrl->cursor[slot % 3] | st.host_ctrl->lcursor[slot % 3];
+      if ((next >> BFS_VSHIFT) == 0) {
+        st.host_ctrl->done = 1;
+        st.host_ctrl->levels = slot;
+        break;
+      }
+    }
   }
-  if (direct) st.levels_hint = st.host_ctrl->levels + 1;       // + the level that finds the frontier empty
+  if (direct) st.levels_hint = st.host_ctrl->levels > 0 ? st.host_ctrl->levels : 1;
   else st.slots_hint = st.host_ctrl->slots > 0 ? st.host_ctrl->slots : 1;
   st.direct_levels = st.host_ctrl->levels <= st.direct_max_levels;
   const int lv = st.host_ctrl->levels < BFS_MAX_TRACE ? st.host_ctrl->levels : BFS_MAX_TRACE;
