@@ -37,10 +37,10 @@ constexpr int BFS_STREAM_HOTW2 = 20400;   // two workgroups per CU: 80 KB of bit
 // open_here (direct scheme, see bfs_fused_run: explicit level numbers, no k_bfs_small_levels in front; 2: a rank of a
 // partitioned run): the level's bookkeeping is done by one thread of this grid.  Nothing it writes is read by the level's own kernels in a
 // top-down run: they take the queue sizes from the cursors, which the previous level's k_bfs_build completed.
-template <bool COLDT>
-__global__ __launch_bounds__(1024) void k_bfs_push_level(bfs_fused_args_t a, int level, u32 nstream, int open_here) {
+template <bool COLDT, int EPT = 8>
+__global__ __launch_bounds__(1024, 8) void k_bfs_push_level(bfs_fused_args_t a, int level, u32 nstream, int open_here) {
   if (open_here && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) bfs_begin_level(a, level, open_here == 2);
-  if (blockIdx.x < nstream) bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, COLDT, false, true>(a, level, blockIdx.x, nstream);
+  if (blockIdx.x < nstream) bfs_stream_body<1024, BFS_STREAM_HOTW2, EPT, COLDT, false, true>(a, level, blockIdx.x, nstream);
   else bfs_wave_body<1024, 18000, COLDT, false>(a, level, blockIdx.x - nstream, gridDim.x - nstream);
 }
 
@@ -51,13 +51,15 @@ inline void bfs_set_kernel_attributes() {
   MGX_SET_LDS((k_bfs_small_levels<BFS_SMALL_NT>));
   MGX_SET_LDS(k_bfs_push_level<false>);
   MGX_SET_LDS(k_bfs_push_level<true>);
+  MGX_SET_LDS((k_bfs_push_level<false, 16>));
+  MGX_SET_LDS((k_bfs_push_level<false, 12>));
   MGX_SET_LDS((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, false>));
   MGX_SET_LDS((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, true>));
   MGX_SET_LDS((k_bfs_push_level_wave<1024, 18000, false>));
   MGX_SET_LDS((k_bfs_push_level_wave<1024, 18000, false, true>));
   MGX_SET_LDS((k_bfs_push_level_wave<1024, 18000, true>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false>));
-  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, true>));
+  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, true, true>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, false, true>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, true>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, true, false, true>));
@@ -105,7 +107,7 @@ inline void bfs_launch_stream(const bfs_fused_args_t& a, int level, standard_con
   else if (shape == 3)
     hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, false>), dim3(ctx.num_cus), dim3(1024), lds1, s, a, level);
   else if (a.flags)     // MGX_BFS_FLAGS set: the instrumented build of the default shape
-    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, true>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
+    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, true, true>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
   else if (shape == 8)      // default shape with ordinary (cached) col_indices loads: 0.582 vs 0.565 ms per traversal
     hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
   else                      // col_indices are read once: non-temporal loads leave L2 to the bitmap, marks and queues
@@ -144,8 +146,13 @@ inline void bfs_launch_push(const bfs_fused_args_t& a, int level, standard_conte
   const size_t lds = lds_s > lds_w ? lds_s : lds_w;
   const u32 nstream = a.long_min > 0 ? (u32)ctx.num_cus * 2 : 0u;
   const u32 nwave = (u32)ctx.num_cus * 2;
+  static const int ept = getenv("MGX_BFS_STREAM_EPT") ? atoi(getenv("MGX_BFS_STREAM_EPT")) : 8;
   if (bfs_cold_test(a.n))
     hipLaunchKernelGGL(k_bfs_push_level<true>, dim3(nstream + nwave), dim3(1024), lds, s, a, level, nstream, open_here);
+  else if (ept == 16)
+    hipLaunchKernelGGL((k_bfs_push_level<false, 16>), dim3(nstream + nwave), dim3(1024), lds, s, a, level, nstream, open_here);
+  else if (ept == 12)
+    hipLaunchKernelGGL((k_bfs_push_level<false, 12>), dim3(nstream + nwave), dim3(1024), lds, s, a, level, nstream, open_here);
   else
     hipLaunchKernelGGL(k_bfs_push_level<false>, dim3(nstream + nwave), dim3(1024), lds, s, a, level, nstream, open_here);
 }

@@ -43,8 +43,12 @@ constexpr size_t bfs_stream_lds_bytes(int hotw) { return (size_t)hotw * 4 + 64; 
 // row skipping the per-sub-round walk and lane masks; one ds_or with return instead of read-then-or; buffer loads
 // (descriptor + scalar offset: no address arithmetic per sub-round); 16-byte loads for rounds inside one row, with
 // and without 128-byte aligned starts (3 % slower); a ring that reloads a register right after its test so that
-// seven loads stay in flight across rounds (2 % slower, although bare loads gain 20 % from it).  Instruction count,
-// load width, alignment and issue order are not what this kernel waits for.
+// seven loads stay in flight across rounds (2 % slower, although bare loads gain 20 % from it); 16 loads per lane
+// and round instead of 8 (same).  What does move it: 16 extra VALU instructions per sub-round cost +28 us on that
+// level (+13 %), 16 s_nop +15 us -- about half of any added issue time shows, so the ~47 instructions a sub-round
+// costs now (~20 scalar for the walk, ~16 vector, the LDS probe, branches) are the lever, not the memory side.  The
+// fast path for rounds inside one row did not help because that level has few of them: its long rows are the
+// mid-degree ones (a few sub-rounds each); the hubs were expanded a level earlier.
 template <int NT, int HOTW, int EPT, bool COLDT, bool DIAG = false, bool NTLOAD = false>
 __device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int level, u32 block, u32 nblocks) {
   constexpr int NW = NT / WAVE;
