@@ -128,6 +128,7 @@ __device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int l
     u32 baseL[EPT], nL[EPT];     // landing tile: where its loads read from (uniform)
     int idL[EPT];                // landing registers of the col_indices loads
     // one round of the walk: EPT sub-rounds of up to 64 consecutive edges of one row each
+    u32 lastp = pos;             // some edge of this slice (has_work: there is one)
     auto walk = [&]() {
       int j = 0;
 #pragma unroll
@@ -150,7 +151,8 @@ __device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int l
         }
         const u32 left = end - pos;
         const u32 n = left < (u32)WAVE ? left : (u32)WAVE;
-        baseL[k] = n ? pos : 0u;
+        baseL[k] = n ? pos : lastp;              // an empty sub-round re-reads (and re-tests) an edge of the slice
+        lastp = n ? pos : lastp;
         nL[k] = n;
         pos += n;
       }
@@ -171,7 +173,9 @@ __device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int l
       for (int k = 0; k < EPT; ++k) {
         const u32 d = (u32)id[k];
         const u32 bit = 1u << (d & 31);
-        const bool act = (u32)lane < nn[k] && !(diag & 16);       // diag 16: stream only, no test
+        // lanes past the end of the sub-round hold the row's first neighbour again (issue() clamps them to lane 0):
+        // testing it twice is harmless, and not masking them saves a compare and two mask operations per sub-round
+        const bool act = !(diag & 16);                            // diag 16: stream only, no test
         const bool hotm = act && d < hot_n;
         // every lane probes (the others word 0): two nested branches less than "if active, if hot" per sub-round
         const u32 w = hot[hotm ? (d >> 5) : 0u];
