@@ -203,6 +203,17 @@ __device__ __forceinline__ bool bfs_open_level(const bfs_fused_args_t& a, int le
   return true;
 }
 
+// Is level `level` a bottom-up one?  The level's opener writes the decision to ctrl->pull, but in the direct launch
+// scheme it runs inside the push grid, next to the workgroups that need the answer: they derive it themselves from
+// the same, stable inputs (queue sizes left by the previous build, vertices reached so far) with the same arithmetic.
+__device__ __forceinline__ bool bfs_level_pulls(const bfs_fused_args_t& a, const bfs_ctrl_t* c, int level) {
+  if (a.mode != 1) return false;
+  if (c->pull) return true;
+  const long long nf = (long long)(c->cursor[level % 3] >> BFS_VSHIFT) + (long long)(c->lcursor[level % 3] >> BFS_VSHIFT);
+  const float unvisited = (float)((long long)a.n - (long long)c->reached);
+  return unvisited < (float)nf * a.alpha;
+}
+
 // Explicit-level variant of the above as a kernel of its own (partitioned runs: the host counts the levels).
 // There the traversal is over when the level before discovered nothing on ANY rank (ctrl->merged_new, the same
 // number on every rank), whatever this rank's own queues hold.

@@ -205,14 +205,14 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   //   slots  [k_bfs_small_levels, push, (pull), build] with the level counter on the device: the single-workgroup
   //          kernel runs any number of small levels inside one launch (deep graphs: hundreds of tiny levels) and
   //          opens the next big one; on a shallow graph it is an idle ~5 us launch in front of every big level.
-  //   direct [push, build] per level with the level number as an argument; the level's bookkeeping rides on the push
-  //          launch.  Top-down runs only (a bottom-up level needs the direction decided before it starts).
+  //   direct [push, (pull), build] per level with the level number as an argument; the level's bookkeeping rides on
+  //          the push launch (the direction of a direction-optimising level too: bfs_level_pulls).
   // The scheme follows the previous traversal of the graph: direct unless that one was deep (MGX_BFS_DIRECT forces).
   const char* const direct_str = getenv("MGX_BFS_DIRECT");          // (read per run: the tests switch it)
   const int direct_env = direct_str ? atoi(direct_str) : -1;
   // (profiling runs with events around the two push kernels keep the slot scheme unless forced: there the tiny levels
   //  stay inside the single-workgroup kernel instead of adding no-op launches to the kernels' averages)
-  const bool direct = mode == 0 && (direct_env >= 0 ? direct_env != 0 : (st.direct_levels && !st.time_kernels));
+  const bool direct = direct_env >= 0 ? direct_env != 0 : (st.direct_levels && !st.time_kernels);
   const bool batch_events = st.time_kernels || st.time_batches;    // (an event costs ~6 us of stream gap)
   int slot = 0;
   for (int batch = 0;; ++batch) {
@@ -237,7 +237,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
         bfs_launch_push(a, lv_arg, ctx, direct ? 1 : 0);
       }
       if (mode == 1)
-        hipLaunchKernelGGL(k_bfs_pull_level<256>, dim3(ctx.num_cus * 8), dim3(256), 0, s, a, -1);
+        hipLaunchKernelGGL(k_bfs_pull_level<256>, dim3(ctx.num_cus * 8), dim3(256), 0, s, a, lv_arg);
       static const int build_nt = getenv("MGX_BFS_BUILD_NT") ? atoi(getenv("MGX_BFS_BUILD_NT")) : 512;   // 2 workgroups per CU overlap their phases: 0.585 vs 0.599 ms
       if (build_nt == 512)
         hipLaunchKernelGGL((k_bfs_build<512, true>), dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, lv_arg,

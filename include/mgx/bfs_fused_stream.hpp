@@ -65,7 +65,7 @@ __device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int l
   const u64 cur = c->lcursor[level % 3];
   const u32 nf = (u32)(cur >> BFS_VSHIFT);
   const u32 E = (u32)(cur & BFS_EMASK);                     // in units of padded edges: a multiple of 64 (bfs_lq_*)
-  if (nf == 0 || c->pull) return;                           // k_bfs_level_begin: bookkeeping and direction
+  if (nf == 0 || bfs_level_pulls(a, c, level)) return;
 
   const u32* __restrict__ q_row = a.lq_row[level & 1];
   const u32* __restrict__ q_off = a.lq_off[level & 1];

@@ -45,7 +45,7 @@ __device__ __forceinline__ void bfs_wave_body(const bfs_fused_args_t& a, int lev
   const u64 cur = c->cursor[level % 3];
   const long long nf = (long long)(cur >> BFS_VSHIFT);
   const u32 E = (u32)(cur & BFS_EMASK);
-  if (nf == 0 || c->pull) return;                      // k_bfs_level_begin: bookkeeping and direction
+  if (nf == 0 || bfs_level_pulls(a, c, level)) return;
 
   const u32* __restrict__ fr_row = a.fr_row[level & 1];
   const u32* __restrict__ fr_off = a.fr_off[level & 1];

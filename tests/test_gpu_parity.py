@@ -314,15 +314,18 @@ def test_bfs_hub_first_layout_and_lds_hot_bitmap(gpu_ctx, oracle, torch_mod, rma
         assert np.array_equal(bfs.labels(), want)
 
 
+@pytest.mark.parametrize("direct", [1, 0])
 @pytest.mark.parametrize("scale", [10, 13, 16])
 @pytest.mark.parametrize("layout", [False, True])
-def test_bfs_direction_optimizing_fused(gpu_ctx, oracle, torch_mod, rmat_graphs, scale, layout, monkeypatch):
+def test_bfs_direction_optimizing_fused(gpu_ctx, oracle, torch_mod, rmat_graphs, scale, layout, direct, monkeypatch):
     """fused direction-optimising traversal (bottom-up levels once unvisited < frontier*alpha,
-    bfs_enactor.hxx:68): labels equal the top-down oracle for every switch point, incl. pull from level 0."""
+    bfs_enactor.hxx:68): labels equal the top-down oracle for every switch point, incl. pull from level 0.
+    direct: both launch schemes (in the direct one the workgroups of a level derive its direction themselves)."""
     import mini_amd
     from mini_amd import rmat
     torch = torch_mod
     monkeypatch.setenv("MGX_BFS_HOT_MIN_EDGES", "0")
+    monkeypatch.setenv("MGX_BFS_DIRECT", str(direct))
     n, ro, ci, w = rmat_graphs[scale]
     d_ro, d_ci = torch.from_numpy(ro).cuda(), torch.from_numpy(ci).cuda()
     g = mini_amd.Graph.from_device(gpu_ctx, n, len(ci), d_ro, d_ci)
