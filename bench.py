@@ -95,7 +95,7 @@ def main():
     if not args.no_layout:
         # hub-first layout (vertex ids by descending degree) for the LDS-resident hot bitmap; part of
         # graph construction like the CSR build, not of the timed traversal; labels stay in original ids
-        graph.attach_layout(*rmat.degree_order(g["row_offsets"], g["col_indices"]))
+        graph.build_layout()          # mgx_graph_build_layout: device-side, inside the library
         torch.cuda.synchronize()
     t_layout = time.time() - t_layout
     sources = rmat.pick_sources(ro_host, args.steps + args.warmup, seed)

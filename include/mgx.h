@@ -78,6 +78,13 @@ MGX_API int mgx_graph_attach_layout(mgx_graph_t g, const int* d_layout_row_offse
 /* weights of the layout's edges, in the layout's order (optional): mgx_sssp_run then relaxes in layout space, where
  * the distances of the high-degree vertices -- the targets of most relaxations -- sit together in L2 */
 MGX_API int mgx_graph_attach_layout_weights(mgx_graph_t g, const float* d_layout_weights);
+/* The same layout built by the library from the graph's own CSR (device-side degree sort, renumbering, rows sorted by
+ * neighbour; one-time setup, rocPRIM sort / scan) and owned by the graph; with_weights != 0 carries the edge weights
+ * along for the fused SSSP loop.  mgx_graph_layout_read copies the pieces to host buffers (NULL: skip; sizes n + 1,
+ * m, n, n, m) -- what the tests compare with the torch construction in mini_amd/rmat.py. */
+MGX_API int mgx_graph_build_layout(mgx_graph_t g, int with_weights);
+MGX_API int mgx_graph_layout_read(mgx_graph_t g, int* h_row_offsets, int* h_col_indices, int* h_new_of_old,
+                                  int* h_old_of_new, float* h_weights);
 MGX_API int mgx_graph_free(mgx_graph_t g);
 MGX_API int mgx_graph_dims(mgx_graph_t g, int* num_nodes, int64_t* num_edges);
 /* host-side MTX text loader, bug-compatible with load_graph (graph.hxx:96-223): row = 2nd

@@ -98,6 +98,23 @@ class Graph:
         self._layout = (layout_row_offsets, layout_col_indices, new_of_old, old_of_new, layout_weights)
         return self
 
+    def build_layout(self, weights=False):
+        """The same layout, built by the library from the graph's own CSR (mgx_graph_build_layout) and owned by it."""
+        check(lib.mgx_graph_build_layout(self._h, int(bool(weights))))
+        return self
+
+    def layout_arrays(self, weights=False):
+        """(layout_row_offsets, layout_col_indices, new_of_old, old_of_new[, layout_weights]) as host numpy arrays"""
+        n, m = self.num_nodes, self.num_edges
+        lro, lci = np.empty(n + 1, dtype=np.int32), np.empty(max(m, 1), dtype=np.int32)
+        n2o, o2n = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+        lw = np.empty(max(m, 1), dtype=np.float32) if weights else None
+        check(lib.mgx_graph_layout_read(self._h, lro.ctypes.data_as(C.c_void_p), lci.ctypes.data_as(C.c_void_p),
+                                        n2o.ctypes.data_as(C.c_void_p), o2n.ctypes.data_as(C.c_void_p),
+                                        lw.ctypes.data_as(C.c_void_p) if weights else None))
+        out = (lro, lci[:m], n2o, o2n)
+        return out + (lw[:m],) if weights else out
+
     def close(self):
         if self._h:
             lib.mgx_graph_free(self._h)

@@ -302,6 +302,52 @@ int mgx_graph_attach_layout_weights(mgx_graph_t g, const float* d_layout_weights
   G.has_layout_weights = true;
   MGX_CATCH
 }
+extern "C" int mgx_layout_build_device(const int* ro, const int* ci, const float* w, int n, long long m, int* lro, int* lci,
+                                       float* lw, int* new_of_old, int* old_of_new, hipStream_t stream);   // mgx_layout.hip
+int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
+  MGX_TRY
+  MGX_REQUIRE(g, "graph is NULL");
+  use_device(g->c);
+  standard_context_t& ctx = *g->c->ctx;
+  graph_device_t& G = *g->g;
+  const size_t n = (size_t)G.num_nodes, m = (size_t)G.num_edges;
+  MGX_REQUIRE(!with_weights || G.d_col_values.size() >= m, "mgx_graph_build_layout: the graph has no weights");
+  ctx.synchronize();
+  mem_t<int> lro(n + 1, ctx), lci(m, ctx), n2o(n, ctx), o2n(n, ctx);
+  mem_t<float> lw;
+  if (with_weights) lw = mem_t<float>(m, ctx);
+  const int rc = mgx_layout_build_device(G.d_row_offsets.data(), G.d_col_indices.data(),
+                                         with_weights ? G.d_col_values.data() : (const float*)nullptr, (int)n, (long long)m,
+                                         lro.data(), lci.data(), with_weights ? lw.data() : (float*)nullptr, n2o.data(),
+                                         o2n.data(), ctx.stream());
+  if (rc != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("mgx_graph_build_layout: ") + hipGetErrorString((hipError_t)rc));
+  G.d_layout_row_offsets = std::move(lro);
+  G.d_layout_col_indices = std::move(lci);
+  G.d_new_of_old = std::move(n2o);
+  G.d_old_of_new = std::move(o2n);
+  G.has_layout = true;
+  if (with_weights) { G.d_layout_col_values = std::move(lw); G.has_layout_weights = true; }
+  MGX_CATCH
+}
+int mgx_graph_layout_read(mgx_graph_t g, int* h_row_offsets, int* h_col_indices, int* h_new_of_old, int* h_old_of_new,
+                          float* h_weights) {
+  MGX_TRY
+  MGX_REQUIRE(g, "graph is NULL");
+  MGX_REQUIRE(g->g->has_layout, "mgx_graph_layout_read: the graph has no layout");
+  use_device(g->c);
+  g->c->ctx->synchronize();
+  graph_device_t& G = *g->g;
+  const size_t n = (size_t)G.num_nodes, m = (size_t)G.num_edges;
+  if (h_row_offsets) MGX_HIP(mgx::dtoh(h_row_offsets, G.d_layout_row_offsets.data(), n + 1));
+  if (h_col_indices && m) MGX_HIP(mgx::dtoh(h_col_indices, G.d_layout_col_indices.data(), m));
+  if (h_new_of_old) MGX_HIP(mgx::dtoh(h_new_of_old, G.d_new_of_old.data(), n));
+  if (h_old_of_new) MGX_HIP(mgx::dtoh(h_old_of_new, G.d_old_of_new.data(), n));
+  if (h_weights && m) {
+    MGX_REQUIRE(G.has_layout_weights, "mgx_graph_layout_read: the layout carries no weights");
+    MGX_HIP(mgx::dtoh(h_weights, G.d_layout_col_values.data(), m));
+  }
+  MGX_CATCH
+}
 int mgx_graph_free(mgx_graph_t g) {
   MGX_TRY
   if (g) { use_device(g->c); delete g; }

@@ -454,6 +454,40 @@ def test_bfs_long_row_queue_padding_boundaries(gpu_ctx, oracle, monkeypatch, sma
             assert nf == int((at & (deg > 0)).sum()) and ne == int(deg[at].sum()), (src, lv)
 
 
+@pytest.mark.parametrize("scale", [8, 13, 16])
+def test_library_built_layout_equals_torch_construction(gpu_ctx, oracle, torch_mod, rmat_graphs, scale):
+    """mgx_graph_build_layout (device-side degree sort + renumbering, rocPRIM) against mini_amd.rmat.degree_order
+    (torch ops): identical id maps, offsets and neighbour lists; weights travel with their edges (compared as the
+    multiset of (neighbour, weight) per row: equal neighbours may come in either order); traversals on the built
+    layout equal the oracle."""
+    import mini_amd
+    from mini_amd import rmat
+    torch = torch_mod
+    n, ro, ci, w = rmat_graphs[scale]
+    d_ro, d_ci, d_w = torch.from_numpy(ro).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(w).cuda()
+    g = mini_amd.Graph.from_device(gpu_ctx, n, len(ci), d_ro, d_ci, d_w)
+    g.build_layout(weights=True)
+    lro, lci, n2o, o2n, lw = g.layout_arrays(weights=True)
+    t_lro, t_lci, t_n2o, t_o2n, t_lw = [t.cpu().numpy() for t in rmat.degree_order(d_ro, d_ci, d_w)]
+    assert np.array_equal(o2n, t_o2n) and np.array_equal(n2o, t_n2o)
+    assert np.array_equal(lro, t_lro) and np.array_equal(lci, t_lci)
+    key = lambda nb, ww: np.lexsort((ww, nb, np.repeat(np.arange(n), np.diff(lro))))
+    a, b = key(lci, lw), key(t_lci, t_lw)
+    assert np.array_equal(lci[a], t_lci[b]) and np.array_equal(lw[a], t_lw[b])
+    deg = np.diff(ro)
+    bfs = mini_amd.BfsProblem(g, 0)
+    sssp = mini_amd.SsspProblem(g, 0)
+    for src in [int(np.argmax(deg))] + rmat.pick_sources(ro, 2, scale + 11):
+        bfs.run(src)
+        assert np.array_equal(bfs.labels(), oracle.bfs_cpu(ro, ci, src))
+        sssp.run(src)
+        want, _, _ = oracle.sssp_enact(ro, ci, w, src, 8.0)
+        assert np.array_equal(sssp.distances(), want)
+    # a graph wrapped without weights has unit weights (graph.hxx:126's default): its layout carries those
+    g1 = mini_amd.Graph.from_device(gpu_ctx, n, len(ci), d_ro, d_ci).build_layout(weights=True)
+    assert np.all(g1.layout_arrays(weights=True)[4] == 1.0)
+
+
 def test_sssp_fused_float_weights_and_big_frontiers(gpu_ctx, oracle, rmat_graphs):
     """fused SSSP loop on RMAT-16 (frontiers of several thousand marked vertices per workgroup: the queue build
     runs more than one batch) with NON-integer weights: the min-plus fixed point is unique, so distances are
