@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Randomised parity campaign (not a test: minutes of GPU time): fused BFS (both launch schemes, push and
+direction-optimising with random alpha) and the fused SSSP loop against the oracle, on R-MAT graphs of several scales
+and on random / structured graphs (uniform random, star forests, grids, long paths with shortcuts).
+usage: fuzz_parity.py [seconds]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import mini_amd
+from tests.oracle_binding import Oracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+orc = Oracle()
+ctx = mini_amd.Context(0, torch.cuda.current_stream().cuda_stream)
+rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
+
+
+def graphs():
+    k = 0
+    while True:
+        k += 1
+        kind = k % 5
+        if kind == 0:
+            s = int(rng.integers(8, 19))
+            n, ro, ci, w = orc.rmat_csr(s, int(rng.integers(2, 24)), int(rng.integers(1, 1 << 30)))
+            yield "rmat-%d" % s, n, ro, ci, w
+            continue
+        if kind == 1:       # uniform random, directed or not
+            n = int(rng.integers(2, 200000)); e = int(rng.integers(1, 8 * n))
+            t0 = rng.integers(0, n, size=e).astype(np.int32); t1 = rng.integers(0, n, size=e).astype(np.int32)
+            name = "uniform"
+        elif kind == 2:     # star forest: hubs of every size, leaves shared between hubs now and then
+            h = int(rng.integers(1, 300)); n = 100000
+            deg = rng.integers(1, 3000, size=h)
+            t0 = np.repeat(np.arange(h), deg).astype(np.int32); t1 = rng.integers(h, n, size=int(deg.sum())).astype(np.int32)
+            name = "stars"
+        elif kind == 3:     # grid
+            a, b = int(rng.integers(2, 400)), int(rng.integers(2, 400)); n = a * b
+            idx = np.arange(n).reshape(a, b)
+            t0 = np.concatenate([idx[:, :-1].ravel(), idx[:-1, :].ravel()]).astype(np.int32)
+            t1 = np.concatenate([idx[:, 1:].ravel(), idx[1:, :].ravel()]).astype(np.int32)
+            name = "grid"
+        else:               # long path with random shortcuts
+            n = int(rng.integers(100, 3000)); sc = int(rng.integers(0, 20))
+            t0 = np.concatenate([np.arange(n - 1), rng.integers(0, n, size=sc)]).astype(np.int32)
+            t1 = np.concatenate([np.arange(1, n), rng.integers(0, n, size=sc)]).astype(np.int32)
+            name = "path"
+        undir = bool(rng.integers(0, 2)) or name in ("grid", "path")
+        wv = rng.integers(0, 64, size=len(t0)).astype(np.float32)
+        ro, ci, w = orc.csr_from_tuples(n, t0, t1, wv, undir=undir)
+        yield name + ("" if undir else "-directed"), n, ro, ci, w
+
+
+t_end = time.time() + budget
+ran = 0
+for name, n, ro, ci, w in graphs():
+    if time.time() > t_end:
+        break
+    deg = np.diff(ro)
+    d_ro, d_ci, d_w = torch.from_numpy(ro).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(w).cuda()
+    g = mini_amd.Graph.from_device(ctx, n, len(ci), d_ro, d_ci, d_w)
+    symmetric = "directed" not in name
+    layout = bool(rng.integers(0, 2))
+    if layout:
+        g.build_layout(weights=True)
+    bfs, sssp = mini_amd.BfsProblem(g, 0), mini_amd.SsspProblem(g, 0)
+    srcs = [int(np.argmax(deg))] + [int(x) for x in rng.integers(0, n, size=4)]
+    for src in srcs:
+        want = orc.bfs_cpu(ro, ci, src)
+        for direct in ("1", "0"):
+            os.environ["MGX_BFS_DIRECT"] = direct
+            st = bfs.run(src)
+            assert np.array_equal(bfs.labels(), want), (name, n, src, "push", direct, layout)
+            assert st["m_t"] == int(deg[want >= 0].sum()), (name, n, src, "m_t", direct, layout)
+            if symmetric:
+                alpha = float(10.0 ** rng.uniform(-2, 4))
+                bfs.run(src, mode=mini_amd.MGX_BFS_DIRECTION_OPT, alpha=alpha)
+                assert np.array_equal(bfs.labels(), want), (name, n, src, "do", alpha, direct, layout)
+        os.environ.pop("MGX_BFS_DIRECT", None)
+        dist, _, _ = orc.sssp_enact(ro, ci, w, src, 8.0)
+        sssp.run(src)
+        assert np.array_equal(sssp.distances(), dist), (name, n, src, "sssp", layout)
+    ran += 1
+    print("ok %-18s n=%-7d m=%-9d layout=%d" % (name, n, len(ci), layout), flush=True)
+print("fuzz: %d graphs, all equal to the oracle" % ran)
