@@ -51,6 +51,47 @@ def graphs():
         yield name + ("" if undir else "-directed"), n, ro, ci, w
 
 
+def partitioned_labels(n, ro, ci, src, G, mode):
+    """generation-2 partitioned BFS with G rank engines in this process (the collectives as copies): global labels in
+    original ids"""
+    from mini_amd.dist_bfs import HipRankEngine2, cyclic_shard_from_csr
+    engs, maps = [], None
+    for r in range(G):
+        ro_l, ci_l, new_of_old, old_of_new = cyclic_shard_from_csr(ro, ci, G, r)
+        engs.append(HipRankEngine2(ctx, n, G, r, torch.from_numpy(ro_l).cuda(), torch.from_numpy(ci_l).cuda()))
+    s_new = int(new_of_old[src])
+    for e in engs:
+        e.reset(s_new)
+    level = 0
+    while True:
+        for _ in range(3):
+            bits = [e.push(level) for e in engs]
+            if mode == "reduce" and G > 1:
+                S = bits[0].numel() // G
+                merged = []
+                for r, e in enumerate(engs):
+                    recv = torch.cat([m[r * S:(r + 1) * S] for m in bits])
+                    e.or_maps(recv, G, recv[:S])
+                    merged.append(recv[:S])
+                full = torch.cat(merged)
+                for e in engs:
+                    e.merge(level, full, 1)
+            else:
+                gathered = torch.cat(bits)
+                for e in engs:
+                    e.merge(level, gathered, G)
+            level += 1
+        if engs[0].status(level)["over"]:
+            break
+    lab_new = np.empty(n, dtype=np.int32)
+    for r, e in enumerate(engs):
+        lab_new[r::G] = e.labels()
+        e.close()
+    out = np.empty(n, dtype=np.int32)
+    out[old_of_new] = lab_new
+    return out
+
+
 t_end = time.time() + budget
 ran = 0
 for name, n, ro, ci, w in graphs():
@@ -77,6 +118,11 @@ for name, n, ro, ci, w in graphs():
                 bfs.run(src, mode=mini_amd.MGX_BFS_DIRECTION_OPT, alpha=alpha)
                 assert np.array_equal(bfs.labels(), want), (name, n, src, "do", alpha, direct, layout)
         os.environ.pop("MGX_BFS_DIRECT", None)
+        if src == srcs[0] and n <= 150000:
+            G = int(rng.choice([2, 3, 5, 8]))
+            mode = str(rng.choice(["gather", "reduce"]))
+            got = partitioned_labels(n, ro, ci, src, G, mode)
+            assert np.array_equal(got, want), (name, n, src, "partitioned", G, mode)
         dist, _, _ = orc.sssp_enact(ro, ci, w, src, 8.0)
         sssp.run(src)
         assert np.array_equal(sssp.distances(), dist), (name, n, src, "sssp", layout)
