@@ -25,8 +25,6 @@ struct bfs_layout_t {
 
 // Template instances of the two push kernels.  cold_test: probe the bitmap word of neighbours outside the LDS
 // prefix (big graphs: many cold endpoints) or mark them untested (k_bfs_build tests the bitmap anyway).
-constexpr int BFS_WAVE_HOTW = 19200;      // 75 KB of bitmap per workgroup, two workgroups per CU
-
 constexpr int BFS_STREAM_HOTW2 = 20400;   // two workgroups per CU: 80 KB of bitmap each
 
 // Both push kernels of a level in ONE launch: the first `nstream` workgroups run the streaming body over the
@@ -37,10 +35,10 @@ constexpr int BFS_STREAM_HOTW2 = 20400;   // two workgroups per CU: 80 KB of bit
 // open_here (direct scheme, see bfs_fused_run: explicit level numbers, no k_bfs_small_levels in front; 2: a rank of a
 // partitioned run): the level's bookkeeping is done by one thread of this grid.  Nothing it writes is read by the level's own kernels in a
 // top-down run: they take the queue sizes from the cursors, which the previous level's k_bfs_build completed.
-template <bool COLDT, int EPT = 8>
+template <bool COLDT>
 __global__ __launch_bounds__(1024, 8) void k_bfs_push_level(bfs_fused_args_t a, int level, u32 nstream, int open_here) {
   if (open_here && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) bfs_begin_level(a, level, open_here == 2);
-  if (blockIdx.x < nstream) bfs_stream_body<1024, BFS_STREAM_HOTW2, EPT, COLDT, false, true>(a, level, blockIdx.x, nstream);
+  if (blockIdx.x < nstream) bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, COLDT, false, true>(a, level, blockIdx.x, nstream);
   else bfs_wave_body<1024, 18000, COLDT, false>(a, level, blockIdx.x - nstream, gridDim.x - nstream);
 }
 
@@ -51,22 +49,11 @@ inline void bfs_set_kernel_attributes() {
   MGX_SET_LDS((k_bfs_small_levels<BFS_SMALL_NT>));
   MGX_SET_LDS(k_bfs_push_level<false>);
   MGX_SET_LDS(k_bfs_push_level<true>);
-  MGX_SET_LDS((k_bfs_push_level<false, 16>));
-  MGX_SET_LDS((k_bfs_push_level<false, 12>));
-  MGX_SET_LDS((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, false>));
-  MGX_SET_LDS((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, true>));
   MGX_SET_LDS((k_bfs_push_level_wave<1024, 18000, false>));
-  MGX_SET_LDS((k_bfs_push_level_wave<1024, 18000, false, true>));
   MGX_SET_LDS((k_bfs_push_level_wave<1024, 18000, true>));
-  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, true, true>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, false, true>));
-  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, true>));
   MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, true, false, true>));
-  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, true, false, true>));
-  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 16, false>));
-  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 16, false>));
-  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, false>));
 #undef MGX_SET_LDS
   attr_set = true;
 }
@@ -78,64 +65,37 @@ inline bool bfs_cold_test(int n) {
   return (long long)n >= 8ll * 32 * BFS_STREAM_HOTW;
 }
 
-// (16-byte-per-lane reads -- sub-rounds of 256 consecutive edges of a row, aligned windows or not -- were tried
-// twice and measured slower: 190-245 us for the big RMAT-22 level against 160-165 us.  Rows of 64..255 edges then
-// fill a quarter to all of a sub-round but pay for all of it; neither the number of load instructions nor the
-// scalar walk is what bounds this kernel.)
-// Stream-kernel shapes (MGX_BFS_STREAM_SHAPE), measured on RMAT-22 (stream kernel of the big level / whole BFS):
-//   0 (default) 2 workgroups x 1024 threads per CU = 32 waves, 80 KB of bitmap each, 8 non-temporal loads per lane
-//               (167 us / 0.66 ms when the shapes were compared)
-//   1           the same with 16 loads per lane:                                                         190 us / 0.68 ms
-//   2           1 workgroup per CU (16 waves), 160 KB of bitmap, 16 loads per lane:                      213 us / 0.69 ms
-//   3           the same with 8 loads per lane:                                                          217 us / 0.71 ms
+// The two push kernels as launches of their own (profiling runs, MGX_BFS_MERGED_PUSH=0, the instrumented build).
+// Shapes that were measured and dropped, RMAT-22 (stream kernel of the big level / whole BFS at the time):
+//   stream  2 workgroups x 1024 threads per CU = 32 waves, 80 KB of bitmap each, 8 non-temporal loads per lane (kept):
+//           167 us / 0.66 ms; 16 loads per lane 190 / 0.68; 1 workgroup per CU with 160 KB of bitmap 213-217 / 0.69-0.71;
+//           cached instead of non-temporal col_indices loads 0.582 vs 0.565 ms per traversal; 16-byte-per-lane reads
+//           (sub-rounds of 256 consecutive edges) 190-245 us; on partitioned RMAT-25 (cold test) one workgroup per CU
+//           with 160 KB was 3 % faster than two with 80 KB -- not enough for a second merged shape;
+//   wave    2 x 1024 threads per CU (kept) 67 us, 2 x 512 threads with more bitmap in LDS 82 us; non-temporal loads: same;
+//   build   512 threads (kept) 0.445 ms per traversal, 256: 0.453-0.461, 1024: 0.476.
 inline void bfs_launch_stream(const bfs_fused_args_t& a, int level, standard_context_t& ctx) {
-  static const int shape = getenv("MGX_BFS_STREAM_SHAPE") ? atoi(getenv("MGX_BFS_STREAM_SHAPE")) : 0;
   hipStream_t s = ctx.stream();
   if (a.long_min <= 0) return;
-  const size_t lds2 = bfs_stream_lds_bytes(BFS_STREAM_HOTW2), lds1 = bfs_stream_lds_bytes(BFS_STREAM_HOTW);
-  static const int cshape = getenv("MGX_BFS_COLD_SHAPE") ? atoi(getenv("MGX_BFS_COLD_SHAPE")) : 0;
-  if (bfs_cold_test(a.n) && cshape == 1)      // cached col_indices loads
-    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, true>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
-  else if (bfs_cold_test(a.n) && cshape == 2) // one workgroup per CU with the 160 KB prefix
-    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, true, false, true>), dim3(ctx.num_cus), dim3(1024), lds1, s, a, level);
-  else if (bfs_cold_test(a.n))
+  const size_t lds2 = bfs_stream_lds_bytes(BFS_STREAM_HOTW2);
+  if (bfs_cold_test(a.n))
     hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, true, false, true>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
-  else if (shape == 1)
-    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 16, false>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
-  else if (shape == 2)
-    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 16, false>), dim3(ctx.num_cus), dim3(1024), lds1, s, a, level);
-  else if (shape == 3)
-    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW, 8, false>), dim3(ctx.num_cus), dim3(1024), lds1, s, a, level);
-  else if (a.flags)     // MGX_BFS_FLAGS set: the instrumented build of the default shape
+  else if (a.flags)     // MGX_BFS_FLAGS set: the instrumented build
     hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, true, true>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
-  else if (shape == 8)      // default shape with ordinary (cached) col_indices loads: 0.582 vs 0.565 ms per traversal
-    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
-  else                      // col_indices are read once: non-temporal loads leave L2 to the bitmap, marks and queues
+  else                  // col_indices are read once: non-temporal loads leave L2 to the bitmap, marks and queues
     hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, false, true>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
 }
 
-// Wave-kernel shapes (MGX_BFS_WAVE_SHAPE): 1 (default) 2 x 1024 threads per CU = 32 waves (the kernel needs ~45
-// VGPRs); 0: 2 x 512 threads = 16 waves, more bitmap in LDS.  RMAT-22 big level: 67 us vs 82 us.
 inline void bfs_launch_wave(const bfs_fused_args_t& a, int level, standard_context_t& ctx) {
-  static const int shape = getenv("MGX_BFS_WAVE_SHAPE") ? atoi(getenv("MGX_BFS_WAVE_SHAPE")) : 1;
   hipStream_t s = ctx.stream();
-  const bool cold = bfs_cold_test(a.n);
-  if (shape == 0) {
-    const size_t lds = bfs_wave_lds_bytes(512, BFS_WAVE_HOTW);
-    if (cold) hipLaunchKernelGGL((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, true>), dim3(ctx.num_cus * 2), dim3(512), lds, s, a, level);
-    else hipLaunchKernelGGL((k_bfs_push_level_wave<512, BFS_WAVE_HOTW, false>), dim3(ctx.num_cus * 2), dim3(512), lds, s, a, level);
-  } else {
-    const size_t lds = bfs_wave_lds_bytes(1024, 18000);
-    if (cold) hipLaunchKernelGGL((k_bfs_push_level_wave<1024, 18000, true>), dim3(ctx.num_cus * 2), dim3(1024), lds, s, a, level);
-    else if (shape == 3) hipLaunchKernelGGL((k_bfs_push_level_wave<1024, 18000, false, true>), dim3(ctx.num_cus * 2), dim3(1024), lds, s, a, level);
-    else hipLaunchKernelGGL((k_bfs_push_level_wave<1024, 18000, false>), dim3(ctx.num_cus * 2), dim3(1024), lds, s, a, level);
-  }
+  const size_t lds = bfs_wave_lds_bytes(1024, 18000);
+  if (bfs_cold_test(a.n)) hipLaunchKernelGGL((k_bfs_push_level_wave<1024, 18000, true>), dim3(ctx.num_cus * 2), dim3(1024), lds, s, a, level);
+  else hipLaunchKernelGGL((k_bfs_push_level_wave<1024, 18000, false>), dim3(ctx.num_cus * 2), dim3(1024), lds, s, a, level);
 }
 
 inline void bfs_launch_push(const bfs_fused_args_t& a, int level, standard_context_t& ctx, int open_here = 0) {
   static const int merged = getenv("MGX_BFS_MERGED_PUSH") ? atoi(getenv("MGX_BFS_MERGED_PUSH")) : 1;
-  static const bool custom_shapes = getenv("MGX_BFS_STREAM_SHAPE") || getenv("MGX_BFS_WAVE_SHAPE") || getenv("MGX_BFS_COLD_SHAPE");
-  if (!merged || custom_shapes || a.flags) {
+  if (!merged || a.flags) {
     if (open_here) hipLaunchKernelGGL(k_bfs_level_begin, dim3(1), dim3(64), 0, ctx.stream(), a, level, open_here == 2 ? 1 : 0);
     bfs_launch_stream(a, level, ctx);
     bfs_launch_wave(a, level, ctx);
@@ -146,13 +106,8 @@ inline void bfs_launch_push(const bfs_fused_args_t& a, int level, standard_conte
   const size_t lds = lds_s > lds_w ? lds_s : lds_w;
   const u32 nstream = a.long_min > 0 ? (u32)ctx.num_cus * 2 : 0u;
   const u32 nwave = (u32)ctx.num_cus * 2;
-  static const int ept = getenv("MGX_BFS_STREAM_EPT") ? atoi(getenv("MGX_BFS_STREAM_EPT")) : 8;
   if (bfs_cold_test(a.n))
     hipLaunchKernelGGL(k_bfs_push_level<true>, dim3(nstream + nwave), dim3(1024), lds, s, a, level, nstream, open_here);
-  else if (ept == 16)
-    hipLaunchKernelGGL((k_bfs_push_level<false, 16>), dim3(nstream + nwave), dim3(1024), lds, s, a, level, nstream, open_here);
-  else if (ept == 12)
-    hipLaunchKernelGGL((k_bfs_push_level<false, 12>), dim3(nstream + nwave), dim3(1024), lds, s, a, level, nstream, open_here);
   else
     hipLaunchKernelGGL(k_bfs_push_level<false>, dim3(nstream + nwave), dim3(1024), lds, s, a, level, nstream, open_here);
 }
@@ -238,16 +193,8 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
       }
       if (mode == 1)
         hipLaunchKernelGGL(k_bfs_pull_level<256>, dim3(ctx.num_cus * 8), dim3(256), 0, s, a, lv_arg);
-      static const int build_nt = getenv("MGX_BFS_BUILD_NT") ? atoi(getenv("MGX_BFS_BUILD_NT")) : 512;   // 2 workgroups per CU overlap their phases: 0.585 vs 0.599 ms
-      if (build_nt == 512)
-        hipLaunchKernelGGL((k_bfs_build<512, true>), dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, lv_arg,
-                           (const u32*)nullptr, labels, st.n, 1, 0, 1);
-      else if (build_nt == 256)
-        hipLaunchKernelGGL((k_bfs_build<256, true>), dim3(bfs_build_grid(st.n, 256)), dim3(256), 0, s, a, lv_arg,
-                           (const u32*)nullptr, labels, st.n, 1, 0, 1);
-      else
-        hipLaunchKernelGGL((k_bfs_build<BFS_BUILD_NT, true>), dim3(bfs_build_grid(st.n)), dim3(BFS_BUILD_NT), 0, s, a, lv_arg,
-                           (const u32*)nullptr, labels, st.n, 1, 0, 1);
+      hipLaunchKernelGGL((k_bfs_build<512, true>), dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, lv_arg,
+                         (const u32*)nullptr, labels, st.n, 1, 0, 1);       // (2 workgroups per CU overlap their phases)
     }
     if (batch_events) MGX_HIP(hipEventRecord(st.ev1, s));
     // one read-back per batch: the counters and the first 64 trace slots (the flag alone would cost the same trip)
