@@ -248,7 +248,7 @@ class DistBfs2:
     def _exchange(self, new):
         """-> (maps, nmaps): what merge() takes"""
         W = self.world
-        if W == 1:
+        if W == 1 and os.environ.get("MGX_DIST_FORCE_COLLECTIVES") != "1":    # (pre-flight: a group of one through RCCL)
             return new, 1
         mine = new if new.device == self.comm_device else new.to(self.comm_device)
         if self.exchange == "gather":
