@@ -346,7 +346,11 @@ __global__ __launch_bounds__(NT) void k_bfs_build(bfs_fused_args_t a, int level,
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
       const int i = threadIdx.x * PER + q;
-      if (i < cnt) labels[lab_at[q]] = new_label;      // (non-temporal stores here were measured slower)
+      // (non-temporal stores here were measured slower.  So was moving this scatter out of the build -- vertex ids in
+      //  the queues, labels written by 64 workgroups of the launch that consumes the queue: the builds of the two big
+      //  RMAT-22 levels went from 30 to 23-25 us, but the push launches grew by more, 0.44 -> 0.46 ms per traversal:
+      //  a million random 4-byte stores cost their ~20 us wherever they run, and here they have the most threads)
+      if (i < cnt) labels[lab_at[q]] = new_label;
       const u32 deg = (i < cnt) ? ro1[q] - ro[q] : 0u;
       const bool is_long = deg >= long_min;
       if (is_long) { longmask |= 1u << q; long_true += deg; }
