@@ -488,6 +488,33 @@ def test_library_built_layout_equals_torch_construction(gpu_ctx, oracle, torch_m
     assert np.all(g1.layout_arrays(weights=True)[4] == 1.0)
 
 
+@pytest.mark.parametrize("direct", [1, 0])
+def test_degenerate_graphs_through_the_fused_loops(gpu_ctx, oracle, direct, monkeypatch):
+    """one vertex without edges, a single edge, a self-loop, 100 isolated vertices, 33 vertices in a ring: fused BFS
+    (push and direction-optimising), fused SSSP, with and without the library-built hub-first copy"""
+    import mini_amd
+    monkeypatch.setenv("MGX_BFS_DIRECT", str(direct))
+    cases = [(1, [], []), (2, [0], [1]), (3, [1], [1]), (100, [], []), (33, list(range(33)), [(i + 1) % 33 for i in range(33)])]
+    for n, t0, t1 in cases:
+        wv = (np.arange(len(t0)) % 7).astype(np.float32)
+        ro, ci, w = oracle.csr_from_tuples(n, np.array(t0, dtype=np.int32), np.array(t1, dtype=np.int32), wv, undir=True)
+        for layout in (False, True):
+            g = _graph(gpu_ctx, ro, ci, w)
+            if layout:
+                g.build_layout(weights=True)
+            bfs, sssp = mini_amd.BfsProblem(g, 0), mini_amd.SsspProblem(g, 0)
+            for src in sorted({0, n - 1, n // 2}):
+                want = oracle.bfs_cpu(ro, ci, src)
+                st = bfs.run(src)
+                assert np.array_equal(bfs.labels(), want), (n, src, layout)
+                assert st["reached"] == int((want >= 0).sum())
+                bfs.run(src, mode=mini_amd.MGX_BFS_DIRECTION_OPT, alpha=2.0)
+                assert np.array_equal(bfs.labels(), want), (n, src, layout, "do")
+                dist, _, _ = oracle.sssp_enact(ro, ci, w, src, 8.0)
+                sssp.run(src)
+                assert np.array_equal(sssp.distances(), dist), (n, src, layout, "sssp")
+
+
 def test_sssp_fused_float_weights_and_big_frontiers(gpu_ctx, oracle, rmat_graphs):
     """fused SSSP loop on RMAT-16 (frontiers of several thousand marked vertices per workgroup: the queue build
     runs more than one batch) with NON-integer weights: the min-plus fixed point is unique, so distances are
