@@ -45,6 +45,10 @@ int advance_forward_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fro
   const int* col_indices = problem->gslice->d_col_indices.data();
   int* output_data = has_output ? output->data()->data() : nullptr;
   typename Problem::data_slice_t* data = problem->d_data_slice.data();
+  // (Staging (v, row start) per segment in LDS instead of the two gathers per edge below changed nothing: 16.5 ms per
+  //  RMAT-22 traversal either way.  The time is the functor's: the contract calls apply_advance for EVERY edge,
+  //  whatever cond_advance said (advance.hxx:57-58), and bfs_functor_t's is an atomicCAS on labels[dst] -- 134 M
+  //  device-scope atomics per traversal at ~25 G/s, profiles/r01/microbench.jsonl.)
   auto neighbors_expand = [=] __device__(int idx, int seg, int rank) {
     const int v = input_data[seg];
     const int start_idx = row_offsets[v];
