@@ -45,10 +45,11 @@ int advance_forward_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fro
   const int* col_indices = problem->gslice->d_col_indices.data();
   int* output_data = has_output ? output->data()->data() : nullptr;
   typename Problem::data_slice_t* data = problem->d_data_slice.data();
-  // (Staging (v, row start) per segment in LDS instead of the two gathers per edge below changed nothing: 16.5 ms per
-  //  RMAT-22 traversal either way.  The time is the functor's: the contract calls apply_advance for EVERY edge,
-  //  whatever cond_advance said (advance.hxx:57-58), and bfs_functor_t's is an atomicCAS on labels[dst] -- 134 M
-  //  device-scope atomics per traversal at ~25 G/s, profiles/r01/microbench.jsonl.)
+  // (Staging (v, row start) per segment in LDS instead of the two gathers per edge below changed nothing.  The time
+  //  of this kernel is the functor's: the contract calls apply_advance for EVERY edge, whatever cond_advance said
+  //  (advance.hxx:57-58), and the reference's bfs_functor_t does an atomicCAS on labels[dst] there -- 134 M
+  //  device-scope atomics per RMAT-22 traversal at ~25 G/s: 16.5 ms.  Our restatement of the functor reads the label
+  //  first (bfs/bfs_functor.hxx): 2.5 ms.)
   auto neighbors_expand = [=] __device__(int idx, int seg, int rank) {
     const int v = input_data[seg];
     const int start_idx = row_offsets[v];

@@ -32,6 +32,10 @@ struct bfs_functor_t {
   }
 
   static __device__ __forceinline__ bool apply_advance(int, int dst, int, int, int, slice_t* data, int iteration) {
+    // The operators call this for EVERY edge (advance.hxx:57-58).  A label only ever goes from -1 to a level, so a
+    // plain read that does not see -1 already is the answer the CAS would give; device-scope atomics run at the
+    // memory side on MI355X (~25 G/s), and nine edges in ten of an R-MAT traversal point at labelled vertices.
+    if (data->d_labels[dst] != -1) return false;
     return atomicCAS(&data->d_labels[dst], -1, iteration + 1) == -1;
   }
 
