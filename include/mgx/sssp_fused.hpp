@@ -3,7 +3,7 @@
 //
 // The operator path (advance writing one slot per EDGE, then a compaction that reads them back; two size
 // read-backs per iteration) spends 7 ms of an 8.6 ms RMAT-22 run in the advance kernel.  Here an iteration is
-//   k_sssp_open    bookkeeping (one thread)
+//   (bookkeeping: one thread of the relax launch, sssp_open)
 //   k_sssp_relax   the frontier's edges, load-balanced per edge rank (wave-private, same scheme as
 //                  bfs_fused_wave.hpp); per edge: neighbour and weight (coalesced),
 //                  candidate = distance the row entered the frontier with + weight, one gather of the neighbour's
@@ -78,8 +78,8 @@ __global__ __launch_bounds__(BLOCK) void k_sssp_init(sssp_args_t a, int src, con
   }
 }
 
-__global__ void k_sssp_open(sssp_args_t a, int it) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// bookkeeping of iteration `it` (one thread; rides on the relax launch: nothing it writes is read by that launch)
+__device__ __forceinline__ void sssp_open(const sssp_args_t& a, int it) {
   bfs_ctrl_t* const c = a.ctrl;
   const u64 cur = c->cursor[it % 3];
   c->cursor[(it + 2) % 3] = 0;
@@ -118,6 +118,7 @@ __global__ __launch_bounds__(NT, 8) void k_sssp_relax(sssp_args_t a, int it) {
 
   bfs_ctrl_t* const c = a.ctrl;
   const u64 cur = c->cursor[it % 3];
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) sssp_open(a, it);
   const long long nf = (long long)(cur >> BFS_VSHIFT);
   const u32 E = (u32)(cur & BFS_EMASK);
   if (nf == 0) return;
@@ -418,15 +419,21 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   for (int batch = 0;; ++batch) {
     const int nit = batch == 0 ? st.iters_hint : 2;
     for (int i = 0; i < nit; ++i, ++it) {
-      hipLaunchKernelGGL(k_sssp_open, dim3(1), dim3(64), 0, s, a, it);
       hipLaunchKernelGGL(k_sssp_relax<1024>, dim3(ctx.num_cus * 2), dim3(1024), SSSP_HOTN * 2, s, a, it);
       hipLaunchKernelGGL(k_sssp_build<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, it);
     }
     MGX_HIP(hipMemcpyAsync(st.host_ctrl, st.ctrl.data(), offsetof(bfs_ctrl_t, trace) + 64 * sizeof(u64), hipMemcpyDeviceToHost, s));
     MGX_HIP(hipStreamSynchronize(s));
     if (st.host_ctrl->done) break;
+    // every iteration launched so far has run: an empty next frontier ends the loop here, without the launch that
+    // would find that out
+    if ((st.host_ctrl->cursor[it % 3] >> BFS_VSHIFT) == 0) {
+      st.host_ctrl->done = 1;
+      st.host_ctrl->levels = it;
+      break;
+    }
   }
-  st.iters_hint = st.host_ctrl->levels + 1;
+  st.iters_hint = st.host_ctrl->levels > 0 ? st.host_ctrl->levels : 1;
   if (layout) {
     hipLaunchKernelGGL(k_sssp_unpermute, dim3(grid_for(st.n, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, st.dist_layout.data(),
                        layout->old_of_new, (u32*)d_dist, (long long)st.n);
