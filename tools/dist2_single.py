@@ -52,5 +52,21 @@ for it, s in enumerate(srcs):
     edges = sum(st["edges_local"] for st in sts)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     if it:
+        if os.environ.get("DIST2_CHECK") == "1" and it == 1:
+            # the same traversal on the unpartitioned graph (fused single-GPU path), labels compared vertex by vertex
+            from mini_amd import rmat
+            g = rmat.rmat_csr(ctx, scale, 16, seed=scale)
+            graph = mini_amd.Graph.from_device(ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"]).build_layout()
+            n2o = new_of_old.long()
+            src_old = int(torch.nonzero(n2o == s)[0, 0])
+            bfs = mini_amd.BfsProblem(graph, src_old)
+            bfs.run(src_old)
+            single = torch.from_numpy(bfs.labels())
+            lab_new = torch.empty(n, dtype=torch.int32)
+            for r, e in enumerate(engs):
+                lab_new[r::G] = torch.from_numpy(e.labels())
+            same = bool(torch.equal(lab_new[n2o.cpu()], single))
+            print("check vs the single-GPU traversal of the unpartitioned graph: labels equal = %s (reached %d)" % (same, int((single >= 0).sum())))
+            assert same
         print(mode + " src %d levels %d edges %d  total %.3f ms  per-rank %.3f ms  -> %.1f GTEPS aggregate (no exchange time)"
               % (s, sts[0]["levels"], edges, dt * 1e3, dt * 1e3 / G, edges / (dt / G) / 1e9))
