@@ -60,7 +60,8 @@ inline void bfs_set_kernel_attributes() {
 
 // -1: decide by size (cold test when the bitmap is at least 8 x the LDS prefix), 0 / 1: forced (MGX_BFS_COLD_TEST)
 inline bool bfs_cold_test(int n) {
-  static const int forced = getenv("MGX_BFS_COLD_TEST") ? atoi(getenv("MGX_BFS_COLD_TEST")) : -1;
+  const char* const e = getenv("MGX_BFS_COLD_TEST");               // (read per call: the tests switch it)
+  const int forced = e ? atoi(e) : -1;
   if (forced >= 0) return forced != 0;
   return (long long)n >= 8ll * 32 * BFS_STREAM_HOTW;
 }

@@ -213,6 +213,7 @@ __device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int l
 #pragma unroll
       for (int k = 0; k < EPT; ++k) { idW[k] = 0; nW[k] = 0; wordL[k] = 0xFFFFFFFFu; }
       bool moreW = true;         // a tile is waiting for its words
+      bool haveT = false;        // the first pass has nothing to test yet (and no lane mask would hide the placeholders)
       while (more || moreW) {
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
@@ -226,7 +227,8 @@ __device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int l
 #pragma unroll
         for (int k = 0; k < EPT; ++k) wordL[k] = vis[((u32)idW[k] >= hot_n) ? ((u32)idW[k] >> 5) : 0u];
         prefetch(seg);
-        test_round(idT, nT, wordT);
+        if (haveT) test_round(idT, nT, wordT);
+        haveT = true;
       }
     }
   }

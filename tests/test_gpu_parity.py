@@ -515,6 +515,36 @@ def test_degenerate_graphs_through_the_fused_loops(gpu_ctx, oracle, direct, monk
                 assert np.array_equal(sssp.distances(), dist), (n, src, layout, "sssp")
 
 
+@pytest.mark.parametrize("cold", [1, 0])
+@pytest.mark.parametrize("direct", [1, 0])
+def test_bfs_far_hub_is_not_discovered_early(gpu_ctx, oracle, monkeypatch, cold, direct):
+    """The biggest hub (layout vertex 0) sits six levels away from the source, while a medium hub next to the source
+    gives the stream kernel long rows to read from level 1 on.  Guards the placeholders of the stream kernel's
+    software pipeline (vertex id 0): the cold-test variant once tested them for real and discovered layout vertex 0
+    at the first level that had a long row (found by tools/fuzz_parity.py with MGX_BFS_COLD_TEST=1)."""
+    import mini_amd
+    monkeypatch.setenv("MGX_BFS_COLD_TEST", str(cold))
+    monkeypatch.setenv("MGX_BFS_HOT_MIN_EDGES", "0")
+    monkeypatch.setenv("MGX_BFS_DIRECT", str(direct))
+    t0, t1 = [], []
+    nxt = 8
+    for k in range(300):            # medium hub 1 next to the source 0
+        t0.append(1); t1.append(nxt); nxt += 1
+    t0.append(0); t1.append(1)
+    for a, b in ((0, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7)):      # a path from the source to the big hub 7
+        t0.append(a); t1.append(b)
+    for k in range(5000):
+        t0.append(7); t1.append(nxt); nxt += 1
+    n = nxt
+    ro, ci, w = oracle.csr_from_tuples(n, np.array(t0, dtype=np.int32), np.array(t1, dtype=np.int32), None, undir=True)
+    g = _graph(gpu_ctx, ro, ci).build_layout()
+    bfs = mini_amd.BfsProblem(g, 0)
+    for src in (0, 1, 8, n - 1):
+        want = oracle.bfs_cpu(ro, ci, src)
+        bfs.run(src)
+        assert np.array_equal(bfs.labels(), want), (src, cold, direct)
+
+
 def test_sssp_fused_float_weights_and_big_frontiers(gpu_ctx, oracle, rmat_graphs):
     """fused SSSP loop on RMAT-16 (frontiers of several thousand marked vertices per workgroup: the queue build
     runs more than one batch) with NON-integer weights: the min-plus fixed point is unique, so distances are
