@@ -95,7 +95,8 @@ inline void bfs_launch_wave(const bfs_fused_args_t& a, int level, standard_conte
 }
 
 inline void bfs_launch_push(const bfs_fused_args_t& a, int level, standard_context_t& ctx, int open_here = 0) {
-  static const int merged = getenv("MGX_BFS_MERGED_PUSH") ? atoi(getenv("MGX_BFS_MERGED_PUSH")) : 1;
+  const char* const merged_str = getenv("MGX_BFS_MERGED_PUSH");      // (read per call: the tests switch it)
+  const int merged = merged_str ? atoi(merged_str) : 1;
   if (!merged || a.flags) {
     if (open_here) hipLaunchKernelGGL(k_bfs_level_begin, dim3(1), dim3(64), 0, ctx.stream(), a, level, open_here == 2 ? 1 : 0);
     bfs_launch_stream(a, level, ctx);

@@ -545,6 +545,47 @@ def test_bfs_far_hub_is_not_discovered_early(gpu_ctx, oracle, monkeypatch, cold,
         assert np.array_equal(bfs.labels(), want), (src, cold, direct)
 
 
+VARIANTS = [{}, {"MGX_BFS_COLD_TEST": "1"}, {"MGX_BFS_COLD_TEST": "1", "MGX_BFS_HOT_MIN_EDGES": "0"},
+            {"MGX_BFS_LONG_MIN": "1", "MGX_BFS_COLD_TEST": "1"}, {"MGX_BFS_LONG_MIN": "0"},
+            {"MGX_BFS_HOT_MIN_EDGES": "1000000000", "MGX_BFS_LONG_MIN": "8"}, {"MGX_BFS_MERGED_PUSH": "0", "MGX_BFS_COLD_TEST": "1"},
+            {"MGX_BFS_DIRECT": "0", "MGX_BFS_SMALL_MAX_EDGES": "100000"}, {"MGX_BFS_DIRECT": "0", "MGX_BFS_SMALL_MAX_EDGES": "0"}]
+
+
+@pytest.mark.parametrize("variant", range(len(VARIANTS)))
+def test_bfs_kernel_variants_on_random_graphs(gpu_ctx, oracle, monkeypatch, variant):
+    """A small randomised campaign (tools/fuzz_parity.py is the long one) with the kernel variants forced that the
+    default thresholds only pick on big or unusual inputs: cold-test instances, every / no row in the long-row queue,
+    no LDS prefix, unmerged launches, the slot scheme with and without the single-workgroup kernel."""
+    import mini_amd
+    for k, v in VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(100 + variant)
+    for trial in range(6):
+        kind = trial % 3
+        if kind == 0:      # star forest, hubs of every size
+            h, n = int(rng.integers(1, 200)), 30000
+            deg = rng.integers(1, 2000, size=h)
+            t0 = np.repeat(np.arange(h), deg).astype(np.int32)
+            t1 = rng.integers(h, n, size=int(deg.sum())).astype(np.int32)
+        elif kind == 1:    # uniform random
+            n = int(rng.integers(2, 50000)); e = int(rng.integers(1, 6 * n))
+            t0 = rng.integers(0, n, size=e).astype(np.int32); t1 = rng.integers(0, n, size=e).astype(np.int32)
+        else:              # R-MAT
+            n, ro, ci, w = oracle.rmat_csr(int(rng.integers(8, 15)), int(rng.integers(2, 20)), int(rng.integers(1, 1 << 20)))
+        if kind != 2:
+            ro, ci, w = oracle.csr_from_tuples(n, t0, t1, None, undir=bool(trial % 2 == 0) or kind == 0)
+        g = _graph(gpu_ctx, ro, ci)
+        if trial % 2 == 0:
+            g.build_layout()
+        deg = np.diff(ro)
+        bfs = mini_amd.BfsProblem(g, 0)
+        for src in [int(np.argmax(deg))] + [int(x) for x in rng.integers(0, n, size=3)]:
+            want = oracle.bfs_cpu(ro, ci, src)
+            st = bfs.run(src)
+            assert np.array_equal(bfs.labels(), want), (variant, trial, src)
+            assert st["m_t"] == int(deg[want >= 0].sum())
+
+
 def test_sssp_fused_float_weights_and_big_frontiers(gpu_ctx, oracle, rmat_graphs):
     """fused SSSP loop on RMAT-16 (frontiers of several thousand marked vertices per workgroup: the queue build
     runs more than one batch) with NON-integer weights: the min-plus fixed point is unique, so distances are
