@@ -38,6 +38,7 @@ struct sssp_args_t {
                          //                 relaxations than with the distance frozen at queue time)
   bfs_ctrl_t* ctrl;      // cursor[3] (packed, rotating), sums, done, levels = iterations
   int n;
+  u32 hot_min_edges;     // iterations with at least this many edges keep distance bounds of the hubs in LDS
 };
 
 // layout (optional): hub-first relabelled CSR with its weights and the two id maps; distances are reported in
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(NT, 8) void k_sssp_relax(sssp_args_t a, int it) {
   unsigned char* mark = a.mark;
 
   extern __shared__ __attribute__((aligned(16))) u32 s_hot[];        // SSSP_HOTN / 2 words: two bounds per word
-  const bool use_hot = E >= SSSP_HOT_MIN_EDGES;
+  const bool use_hot = E >= a.hot_min_edges;
   const u32 hot_n = use_hot ? ((u32)a.n < (u32)SSSP_HOTN ? ((u32)a.n & ~1u) : (u32)SSSP_HOTN) : 0u;
   if (use_hot) {
     for (u32 i = threadIdx.x; i < hot_n / 2; i += NT) {
@@ -408,6 +409,8 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   for (int i = 0; i < 2; ++i) { a.q_row[i] = st.q_row[i].data(); a.q_off[i] = st.q_off[i].data(); a.q_du[i] = st.q_du[i].data(); }
   a.ctrl = st.ctrl.data();
   a.n = st.n;
+  const char* const hme = getenv("MGX_SSSP_HOT_MIN_EDGES");        // (tests force the LDS bounds on small graphs)
+  a.hot_min_edges = hme ? (u32)atoll(hme) : SSSP_HOT_MIN_EDGES;
   hipLaunchKernelGGL(k_sssp_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src,
                      layout ? layout->new_of_old : (const int*)nullptr);
   static bool attr_set = false;

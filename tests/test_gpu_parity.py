@@ -586,6 +586,28 @@ def test_bfs_kernel_variants_on_random_graphs(gpu_ctx, oracle, monkeypatch, vari
             assert st["m_t"] == int(deg[want >= 0].sum())
 
 
+@pytest.mark.parametrize("hot_min_edges", [0, 1 << 30])
+def test_sssp_fused_with_and_without_lds_distance_bounds(gpu_ctx, oracle, monkeypatch, hot_min_edges):
+    """the bfloat16 upper bounds of the hubs' distances (sssp_fused.hpp) forced on for every iteration, and off"""
+    import mini_amd
+    monkeypatch.setenv("MGX_SSSP_HOT_MIN_EDGES", str(hot_min_edges))
+    rng = np.random.default_rng(5 + (hot_min_edges > 0))
+    for trial in range(4):
+        n, ro, ci, _ = oracle.rmat_csr(int(rng.integers(8, 15)), int(rng.integers(2, 20)), int(rng.integers(1, 1 << 20)))
+        w = (rng.random(len(ci)) * (64.0 if trial % 2 else 1.0)).astype(np.float32)
+        if trial % 2:
+            w = np.floor(w)
+        g = _graph(gpu_ctx, ro, ci, w)
+        if trial < 3:
+            g.build_layout(weights=True)
+        sssp = mini_amd.SsspProblem(g, 0)
+        deg = np.diff(ro)
+        for src in [int(np.argmax(deg))] + [int(x) for x in rng.integers(0, n, size=2)]:
+            want, _, _ = oracle.sssp_enact(ro, ci, w, src, 8.0)
+            sssp.run(src)
+            assert np.array_equal(sssp.distances(), want), (trial, src)
+
+
 def test_sssp_fused_float_weights_and_big_frontiers(gpu_ctx, oracle, rmat_graphs):
     """fused SSSP loop on RMAT-16 (frontiers of several thousand marked vertices per workgroup: the queue build
     runs more than one batch) with NON-integer weights: the min-plus fixed point is unique, so distances are
