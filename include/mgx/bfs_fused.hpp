@@ -8,7 +8,8 @@
 // -> downsweep (K5); ~10 launches, 2 host syncs, 4-5 cudaMalloc/cudaFree pairs, and
 // 16 B/edge + 40 B/vertex of traffic.  Here a level is
 //
-//   k_bfs_level_begin   bookkeeping (sizes, termination flag, TEPS numerator, direction): one thread.
+//   bfs_open_level      bookkeeping (sizes, termination flag, TEPS numerator, direction): one thread -- of the push
+//                       grid (direct scheme), of k_bfs_small_levels (slot scheme) or of k_bfs_level_begin.
 //   push kernels        MARK ONLY: a neighbour that is not in the visited bitmap gets mark[v] = 1, a plain byte
 //                       store.  No atomics anywhere: measured on MI355X, device-scope atomics execute at the
 //                       memory side (the per-XCD L2s are not coherent with each other), drop their L2 line,
@@ -27,8 +28,8 @@
 // atomicAdd on a packed (vertex_count << 38 | edge_count) cursor, so the slot it gets back is at once the
 // queue position and the exclusive degree scan of that position -- the scan the reference recomputes every
 // level (K1) comes for free, and the next level can cut its edges into equal slices.  There are two queues per
-// level: rows of at least args.long_min edges (streamed row-wise) and the rest (searched per edge rank).
-// Zero-degree discoveries are labelled but never queued.
+// level: rows of at least args.long_min edges (streamed row-wise; their offsets count the degrees rounded up to
+// 64, bfs_lq_*) and the rest (searched per edge rank).  Zero-degree discoveries are labelled but never queued.
 //
 // Algorithmic traffic: 8 B per traversed edge (col index + visited/label probe) and 20 B per
 // frontier vertex -- the figure BASELINE.md's roofline uses.

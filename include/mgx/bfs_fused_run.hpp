@@ -1,10 +1,8 @@
-// mgx/bfs_fused_run.hpp -- host driver of the fused BFS: per level
-// slots of
-//   k_bfs_small_levels (one workgroup: runs the small levels itself, opens the next big one)
-//   -> k_bfs_push_level_stream (long rows) -> k_bfs_push_level_wave (short rows)
-//   [-> k_bfs_pull_level in direction-optimising runs] -> k_bfs_build
-// launched back to back with level = -1 (the level counter lives on the device); the host reads the control
-// block back once every `levels_per_sync` slots.
+// mgx/bfs_fused_run.hpp -- host driver of the fused BFS.  One init kernel, then per level
+//   k_bfs_push_level (long rows streamed + short rows searched, one grid)  [-> k_bfs_pull_level]  -> k_bfs_build
+// launched back to back for as many levels as the previous traversal of the graph had; the host reads the control
+// block back once per batch.  Two launch schemes (see bfs_fused_run): "direct" with the level number as a kernel
+// argument, and "slots" with k_bfs_small_levels in front of every level and the level counter on the device.
 #pragma once
 #include "bfs_fused.hpp"
 #include "bfs_fused_pull.hpp"
