@@ -1,12 +1,11 @@
-// gunrock/advance.hxx -- the advance operator family.
-// Drop-in for the reference's gunrock/src/advance.hxx (advance_forward_kernel :20-67,
-// sparse_to_dense_kernel :69-84, gen_unvisited_kernel :86-106, advance_backward_kernel
-// :108-160): same template parameters, argument order, return values and functor call
-// contract -- cond_advance THEN apply_advance are both evaluated for every expanded edge
-// (:57-58).  The kernels underneath are mgx's (HIP, wave64), not moderngpu's.
+// gunrock/advance.hxx -- the advance operator family on mgx's kernels (HIP, wave64; no moderngpu).
+// Drop-in for the reference's gunrock/src/advance.hxx: advance_forward_kernel (:20-67), sparse_to_dense_kernel
+// (:69-84), gen_unvisited_kernel (:86-106), advance_backward_kernel (:108-160) -- the same template parameters,
+// argument order and return values, and the same functor call contract: cond_advance THEN apply_advance are both
+// evaluated for every expanded edge (:57-58).
 //
-// Extension (not in the reference): advance_filter_fused_kernel does advance + filter in one
-// pass over the edges and never materialises the mostly -1 intermediate frontier.
+// Extension (not in the reference): advance_filter_fused_kernel does advance + filter in one pass over the edges
+// and never materialises the mostly -1 intermediate frontier.
 #pragma once
 #include <climits>
 
@@ -19,177 +18,174 @@ namespace gunrock {
 namespace oprtr {
 namespace advance {
 
+namespace detail {
+
+// Segment i of an expansion = the adjacency list of ids[i] under `offsets` (CSR rows when pushing, CSC columns when
+// pulling).  Writes the exclusive scan of the list lengths into the graph's shared scan buffer (graph.hxx:49-52:
+// one expansion at a time per graph) and returns the number of edges; the 8-byte read-back of that total is the
+// reference's advance.hxx:43.
+inline long long scan_adjacency_sizes(graph_device_t& graph, const int* ids, long long count, size_t capacity,
+                                      const int* offsets, standard_context_t& context) {
+  graph.ensure_scanned(capacity, context);
+  long long edges = 0;
+  mgx::transform_scan([=] __device__(long long i) { return offsets[ids[i] + 1] - offsets[ids[i]]; }, count,
+                      graph.d_scanned_row_offsets.data(), context, &edges);
+  return edges;
+}
+
+}  // namespace detail
+
 template <typename Problem, typename Functor, bool idempotence, bool has_output>
 int advance_forward_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<frontier_t<int>>& input,
                            std::shared_ptr<frontier_t<int>>& output, int iteration, standard_context_t& context) {
-  const int* input_data = input->data()->data();
-  problem->gslice->ensure_scanned(input->capacity(), context);
-  int* scanned_row_offsets = problem->gslice->d_scanned_row_offsets.data();
-  const int* row_offsets = problem->gslice->d_row_offsets.data();
-
-  long long front = 0;
-  mgx::transform_scan(
-      [=] __device__(long long idx) {
-        const int v = input_data[idx];
-        return row_offsets[v + 1] - row_offsets[v];
-      },
-      (long long)input->size(), scanned_row_offsets, context, &front);
-
-  if (!front) {
+  graph_device_t& graph = *problem->gslice;
+  const int* const frontier = input->data()->data();
+  const long long frontier_size = (long long)input->size();
+  const int* const row_start = graph.d_row_offsets.data();
+  const long long edges = detail::scan_adjacency_sizes(graph, frontier, frontier_size, input->capacity(), row_start, context);
+  if (edges == 0) {
     if (has_output) output->resize(0);
     return 0;
   }
-  if (front > INT_MAX) throw mgx::mgx_error(MGX_E_FRONTIER_OVERFLOW, "advance: more than 2^31-1 work items");
-  if (has_output) output->resize((size_t)front);
+  if (edges > INT_MAX) throw mgx::mgx_error(MGX_E_FRONTIER_OVERFLOW, "advance: more than 2^31-1 work items");
 
-  const int* col_indices = problem->gslice->d_col_indices.data();
-  int* output_data = has_output ? output->data()->data() : nullptr;
-  typename Problem::data_slice_t* data = problem->d_data_slice.data();
+  int* out = nullptr;
+  if (has_output) {
+    output->resize((size_t)edges);              // one slot per EDGE, as upstream: losers become -1 for the filter
+    out = output->data()->data();
+  }
+  const int* const neighbours = graph.d_col_indices.data();
+  typename Problem::data_slice_t* const data = problem->d_data_slice.data();
   // (Staging (v, row start) per segment in LDS instead of the two gathers per edge below changed nothing.  The time
-  //  of this kernel is the functor's: the contract calls apply_advance for EVERY edge, whatever cond_advance said
-  //  (advance.hxx:57-58), and the reference's bfs_functor_t does an atomicCAS on labels[dst] there -- 134 M
-  //  device-scope atomics per RMAT-22 traversal at ~25 G/s: 16.5 ms.  Our restatement of the functor reads the label
-  //  first (bfs/bfs_functor.hxx): 2.5 ms.)
-  auto neighbors_expand = [=] __device__(int idx, int seg, int rank) {
-    const int v = input_data[seg];
-    const int start_idx = row_offsets[v];
-    const int neighbor = col_indices[start_idx + rank];
-    const bool cond = Functor::cond_advance(v, neighbor, start_idx + rank, rank, idx, data, iteration);
-    const bool apply_return = Functor::apply_advance(v, neighbor, start_idx + rank, rank, idx, data, iteration);
-    if (has_output) output_data[idx] = idempotence ? neighbor : ((cond && apply_return) ? neighbor : -1);
+  //  of this kernel is the functor's: the contract calls apply_advance for EVERY edge, whatever cond_advance said,
+  //  and the reference's bfs_functor_t does an atomicCAS on labels[dst] there -- 134 M device-scope atomics per
+  //  RMAT-22 traversal at ~25 G/s: 16.5 ms.  Our restatement of the functor reads the label first
+  //  (bfs/bfs_functor.hxx): 2.5 ms.)
+  auto visit = [=] __device__(int slot, int segment, int rank) {
+    const int v = frontier[segment];
+    const int edge = row_start[v] + rank;
+    const int u = neighbours[edge];
+    const bool cond = Functor::cond_advance(v, u, edge, rank, slot, data, iteration);
+    const bool applied = Functor::apply_advance(v, u, edge, rank, slot, data, iteration);
+    if (has_output) out[slot] = (idempotence || (cond && applied)) ? u : -1;
   };
-  mgx::transform_lbs(neighbors_expand, front, scanned_row_offsets, (long long)input->size(), context);
-
-  if (!has_output) front = 0;
-  return (int)front;
+  mgx::transform_lbs(visit, edges, graph.d_scanned_row_offsets.data(), frontier_size, context);
+  return has_output ? (int)edges : 0;
 }
 
-// advance + filter(idx != -1) in one pass: output holds exactly the neighbours for which
-// cond_advance && apply_advance held (order unspecified).  Returns the output length.
+// advance + filter(idx != -1) in one pass: output holds exactly the neighbours for which cond_advance &&
+// apply_advance held (order unspecified).  Returns the output length.
 template <typename Problem, typename Functor>
 int advance_filter_fused_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<frontier_t<int>>& input,
                                 std::shared_ptr<frontier_t<int>>& output, int iteration,
                                 standard_context_t& context) {
-  const int* input_data = input->data()->data();
-  problem->gslice->ensure_scanned(input->capacity(), context);
-  int* scanned_row_offsets = problem->gslice->d_scanned_row_offsets.data();
-  const int* row_offsets = problem->gslice->d_row_offsets.data();
-  long long front = 0;
-  mgx::transform_scan(
-      [=] __device__(long long idx) {
-        const int v = input_data[idx];
-        return row_offsets[v + 1] - row_offsets[v];
-      },
-      (long long)input->size(), scanned_row_offsets, context, &front);
-  if (!front) {
+  graph_device_t& graph = *problem->gslice;
+  const int* const frontier = input->data()->data();
+  const long long frontier_size = (long long)input->size();
+  const int* const row_start = graph.d_row_offsets.data();
+  const long long edges = detail::scan_adjacency_sizes(graph, frontier, frontier_size, input->capacity(), row_start, context);
+  if (edges == 0) {
     output->resize(0);
     return 0;
   }
-  const int* col_indices = problem->gslice->d_col_indices.data();
-  int* output_data = output->data()->data();
-  const long long cap = (long long)output->capacity();
-  typename Problem::data_slice_t* data = problem->d_data_slice.data();
-  // device-side append cursor lives in the scratch arena, after the scan partials
-  unsigned long long* cursor =
-      (unsigned long long*)((char*)context.scratch + (((size_t)mgx::scan_num_tiles((long long)input->size()) + 2) * 8));
+  const int* const neighbours = graph.d_col_indices.data();
+  int* const out = output->data()->data();
+  const long long room = (long long)output->capacity();
+  typename Problem::data_slice_t* const data = problem->d_data_slice.data();
+  // the append cursor lives in the scratch arena, behind the scan's partial sums
+  unsigned long long* const cursor =
+      (unsigned long long*)((char*)context.scratch + ((size_t)mgx::scan_num_tiles(frontier_size) + 2) * 8);
   MGX_HIP(hipMemsetAsync(cursor, 0, sizeof(unsigned long long), context.stream()));
-  auto expand_keep = [=] __device__(int idx, int seg, int rank) {
-    const int v = input_data[seg];
-    const int start_idx = row_offsets[v];
-    const int neighbor = col_indices[start_idx + rank];
-    const bool cond = Functor::cond_advance(v, neighbor, start_idx + rank, rank, idx, data, iteration);
-    const bool app = Functor::apply_advance(v, neighbor, start_idx + rank, rank, idx, data, iteration);
-    const bool keep = cond && app;
-    // wave-aggregated append: one atomic per wave that has anything to keep
-    const mgx::u64 m = __ballot(keep);
-    if (m) {
-      const int leader = __ffsll((long long)m) - 1;
+  auto visit_and_keep = [=] __device__(int slot, int segment, int rank) {
+    const int v = frontier[segment];
+    const int edge = row_start[v] + rank;
+    const int u = neighbours[edge];
+    const bool cond = Functor::cond_advance(v, u, edge, rank, slot, data, iteration);
+    const bool applied = Functor::apply_advance(v, u, edge, rank, slot, data, iteration);
+    const bool keep = cond && applied;
+    const mgx::u64 keepers = __ballot(keep);          // one cursor atomic per wave that keeps anything
+    if (keepers) {
+      const int first = __ffsll((long long)keepers) - 1;
       unsigned long long base = 0;
-      if (mgx::lane_id() == leader) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
-      base = __shfl(base, leader, mgx::WAVE);
-      if (keep) {
-        const long long dst = (long long)base + mgx::rank_in_mask(m);
-        if (dst < cap) output_data[dst] = neighbor;
-      }
+      if (mgx::lane_id() == first) base = atomicAdd(cursor, (unsigned long long)__popcll(keepers));
+      base = __shfl(base, first, mgx::WAVE);
+      const long long at = (long long)base + mgx::rank_in_mask(keepers);
+      if (keep && at < room) out[at] = u;
     }
   };
-  mgx::transform_lbs(expand_keep, front, scanned_row_offsets, (long long)input->size(), context);
+  mgx::transform_lbs(visit_and_keep, edges, graph.d_scanned_row_offsets.data(), frontier_size, context);
   MGX_HIP(hipMemcpyAsync(context.mailbox, cursor, sizeof(long long), hipMemcpyDeviceToHost, context.stream()));
   context.synchronize();
   const long long kept = context.mailbox[0];
-  output->resize((size_t)kept);   // throws on overflow; nothing was written past capacity
+  output->resize((size_t)kept);   // throws on overflow; nothing was written past the capacity
   return (int)kept;
 }
 
+// dense[v] = cond_sparse_to_dense(v) for the vertices listed in `sparse` (the pull phase's frontier bitmap: one int
+// per vertex, as upstream)
 template <typename Problem, typename Functor>
 void sparse_to_dense_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<frontier_t<int>>& sparse,
                             std::shared_ptr<frontier_t<int>>& dense, int iteration, standard_context_t& context) {
-  const int* input_data = sparse->data()->data();
-  int* output_data = dense->data()->data();
-  typename Problem::data_slice_t* data = problem->d_data_slice.data();
+  const int* const listed = sparse->data()->data();
+  int* const flags = dense->data()->data();
+  typename Problem::data_slice_t* const data = problem->d_data_slice.data();
   mgx::transform(
-      [=] __device__(int idx) {
-        const int item = input_data[idx];
-        output_data[item] = Functor::cond_sparse_to_dense(item, data, iteration) ? 1 : 0;
+      [=] __device__(int i) {
+        const int v = listed[i];
+        flags[v] = Functor::cond_sparse_to_dense(v, data, iteration) ? 1 : 0;
       },
       (long long)sparse->size(), context);
 }
 
+// unvisited <- the members of `indices` for which cond_gen_unvisited holds, in order; returns how many
 template <typename Problem, typename Functor>
 int gen_unvisited_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<frontier_t<int>>& indices,
                          std::shared_ptr<frontier_t<int>>& unvisited, int iteration, standard_context_t& context) {
-  auto compact = mgx::transform_compact((long long)indices->size(), context);
-  const int* input_data = indices->data()->data();
-  typename Problem::data_slice_t* data = problem->d_data_slice.data();
-  const long long stream_count = compact.upsweep([=] __device__(long long idx) {
-    const int item = input_data[idx];
-    return Functor::cond_gen_unvisited(item, data, iteration);
-  });
-  unvisited->resize((size_t)stream_count);
-  int* unvisited_data = unvisited->data()->data();
-  compact.downsweep(
-      [=] __device__(long long dest_idx, long long source_idx) { unvisited_data[dest_idx] = input_data[source_idx]; });
-  return (int)stream_count;
+  const int* const candidates = indices->data()->data();
+  typename Problem::data_slice_t* const data = problem->d_data_slice.data();
+  auto compaction = mgx::transform_compact((long long)indices->size(), context);
+  const long long kept = compaction.upsweep(
+      [=] __device__(long long i) { return Functor::cond_gen_unvisited(candidates[i], data, iteration); });
+  unvisited->resize((size_t)kept);
+  int* const out = unvisited->data()->data();
+  compaction.downsweep([=] __device__(long long to, long long from) { out[to] = candidates[from]; });
+  return (int)kept;
 }
 
+// One bottom-up step: every in-edge (u -> v) of every vertex v in `unvisited`; the first u found in the frontier
+// bitmap for which apply_advance(u, v) succeeds puts v into bitmap_out and retires v's slot.  Returns the number of
+// in-edges enumerated.
 template <typename Problem, typename Functor>
 int advance_backward_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<frontier_t<int>>& unvisited,
                             std::shared_ptr<frontier_t<int>>& bitmap, std::shared_ptr<frontier_t<int>>& bitmap_out,
                             int iteration, standard_context_t& context) {
-  int* unvisited_data = unvisited->data()->data();
-  problem->gslice->ensure_scanned(unvisited->capacity(), context);
-  int* scanned_row_offsets = problem->gslice->d_scanned_row_offsets.data();
-  const int* col_offsets = problem->gslice->d_col_offsets.data();
+  graph_device_t& graph = *problem->gslice;
+  int* const pending = unvisited->data()->data();
+  const long long pending_size = (long long)unvisited->size();
+  const int* const column_start = graph.d_col_offsets.data();
+  const long long edges =
+      detail::scan_adjacency_sizes(graph, pending, pending_size, unvisited->capacity(), column_start, context);
+  if (edges == 0) return 0;
 
-  long long front = 0;
-  mgx::transform_scan(
-      [=] __device__(long long idx) {
-        const int v = unvisited_data[idx];
-        return col_offsets[v + 1] - col_offsets[v];
-      },
-      (long long)unvisited->size(), scanned_row_offsets, context, &front);
-  if (!front) return 0;
-
-  const int* row_indices = problem->gslice->d_row_indices.data();
-  typename Problem::data_slice_t* data = problem->d_data_slice.data();
-  const int* bitmap_data = bitmap->data()->data();
-  int* bitmap_out_data = bitmap_out->data()->data();
-  // The reference re-reads unvisited_data[seg] inside the expansion while other lanes set it
-  // to -1 (advance.hxx:143,151) -- a read of -1 there indexes col_offsets[-1].  The vertex is
-  // recovered here from a second, read-only view: v never changes, only its slot is retired.
-  auto neighbors_expand = [=] __device__(int idx, int seg, int rank) {
-    int v = unvisited_data[seg];
-    if (v < 0) return;   // already claimed by another in-neighbour this call
-    const int start_idx = col_offsets[v];
-    const int neighbor = row_indices[start_idx + rank];
-    if (bitmap_data[neighbor] && Functor::apply_advance(neighbor, v, start_idx + rank, rank, idx, data, iteration)) {
-      bitmap_out_data[v] = 1;
-      unvisited_data[seg] = -1;
+  const int* const in_neighbours = graph.d_row_indices.data();
+  const int* const in_frontier = bitmap->data()->data();
+  int* const next_frontier = bitmap_out->data()->data();
+  typename Problem::data_slice_t* const data = problem->d_data_slice.data();
+  // The reference re-reads unvisited[segment] for every edge while other lanes set it to -1 (advance.hxx:143,151):
+  // a lane that reads the -1 indexes col_offsets[-1].  Here a retired slot ends the lane's work instead.
+  auto visit = [=] __device__(int slot, int segment, int rank) {
+    const int v = pending[segment];
+    if (v < 0) return;                                   // claimed by another in-neighbour during this call
+    const int edge = column_start[v] + rank;
+    const int u = in_neighbours[edge];
+    if (in_frontier[u] && Functor::apply_advance(u, v, edge, rank, slot, data, iteration)) {
+      next_frontier[v] = 1;
+      pending[segment] = -1;
     }
-    if (!Functor::cond_advance(neighbor, v, start_idx + rank, rank, idx, data, iteration)) return;
+    (void)Functor::cond_advance(u, v, edge, rank, slot, data, iteration);     // called for its contract, as upstream
   };
-  mgx::transform_lbs(neighbors_expand, front, scanned_row_offsets, (long long)unvisited->size(), context);
-  return (int)front;
+  mgx::transform_lbs(visit, edges, graph.d_scanned_row_offsets.data(), pending_size, context);
+  return (int)edges;
 }
 
 }  // namespace advance

@@ -15,40 +15,41 @@ namespace gunrock {
 namespace bfs {
 
 struct bfs_functor_t {
-  typedef bfs_problem_t::data_slice_t slice_t;
+  using slice_t = bfs_problem_t::data_slice_t;
 
-  static __device__ __forceinline__ bool cond_filter(int idx, slice_t*, int) { return idx != -1; }
-
-  static __device__ __forceinline__ bool cond_uniq(int idx, slice_t* data, int iteration) {
-    if (idx <= 0) return false;   // the reference skips vertex 0 here as well
-    const int seen = data->d_labels[idx];
-    if (seen > 0 && seen <= iteration) return false;
-    data->d_labels[idx] = iteration + 1;
-    return true;
+  // ---- advance: claim unlabelled destinations for level iteration + 1 -------------------------------------------
+  static __device__ __forceinline__ bool cond_advance(int, int dst, int, int, int, slice_t* d, int) {
+    return d->d_labels[dst] == -1;
   }
-
-  static __device__ __forceinline__ bool cond_advance(int, int dst, int, int, int, slice_t* data, int) {
-    return data->d_labels[dst] == -1;
-  }
-
-  static __device__ __forceinline__ bool apply_advance(int, int dst, int, int, int, slice_t* data, int iteration) {
+  static __device__ __forceinline__ bool apply_advance(int, int dst, int, int, int, slice_t* d, int iteration) {
     // The operators call this for EVERY edge (advance.hxx:57-58).  A label only ever goes from -1 to a level, so a
     // plain read that does not see -1 already is the answer the CAS would give; device-scope atomics run at the
     // memory side on MI355X (~25 G/s), and nine edges in ten of an R-MAT traversal point at labelled vertices.
-    if (data->d_labels[dst] != -1) return false;
-    return atomicCAS(&data->d_labels[dst], -1, iteration + 1) == -1;
+    int* const label = d->d_labels + dst;
+    return *label == -1 && atomicCAS(label, -1, iteration + 1) == -1;
   }
 
-  static __device__ __forceinline__ bool cond_sparse_to_dense(int idx, slice_t* data, int iteration) {
-    return data->d_labels[idx] == iteration;
+  // ---- filter: drop the slots of the edges that lost -------------------------------------------------------------
+  static __device__ __forceinline__ bool cond_filter(int slot_value, slice_t*, int) { return slot_value != -1; }
+
+  // idempotent mode (the reference's uniquify path): relabel unless the vertex already carries a level of this or
+  // an earlier superstep; vertex 0 is skipped there too (bfs_functor.hxx:13-24)
+  static __device__ __forceinline__ bool cond_uniq(int v, slice_t* d, int iteration) {
+    if (v <= 0) return false;
+    const int level = d->d_labels[v];
+    if (level > 0 && level <= iteration) return false;
+    d->d_labels[v] = iteration + 1;
+    return true;
   }
 
-  static __device__ __forceinline__ bool cond_gen_unvisited(int idx, slice_t* data, int) {
-    return data->d_labels[idx] == -1;
+  // ---- pull phase ------------------------------------------------------------------------------------------------
+  static __device__ __forceinline__ bool cond_sparse_to_dense(int v, slice_t* d, int iteration) {
+    return d->d_labels[v] == iteration;
   }
+  static __device__ __forceinline__ bool cond_gen_unvisited(int v, slice_t* d, int) { return d->d_labels[v] == -1; }
 
+  // ---- unused by BFS, part of the functor concept ------------------------------------------------------------------
   static __device__ __forceinline__ int get_value_to_reduce(int, slice_t*, int iteration) { return iteration; }
-
   static __device__ __forceinline__ void write_reduced_value(int, int, slice_t*, int) {}
 };
 

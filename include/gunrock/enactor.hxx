@@ -1,6 +1,9 @@
-// gunrock/enactor.hxx -- enactor_t: two edge-capacity ping-pong frontiers and two
-// node-capacity index frontiers pre-filled with iota.
-// Drop-in for the reference's gunrock/src/enactor.hxx:11-46.
+// gunrock/enactor.hxx -- enactor_t, the base of every superstep loop: the frontiers a loop ping-pongs between.
+// Drop-in for the reference's gunrock/src/enactor.hxx:11-46 (same members, same constructor):
+//   buffers[0..1]                 edge-capacity frontiers, (int)(num_edges * queue_sizing) entries each -- the float
+//                                 arithmetic of enactor.hxx:22-23 is kept, frontier overflow depends on it
+//   indices, filtered_indices     node-capacity frontiers pre-filled with 0 .. num_nodes-1
+//   unvisited[0..1]               the same two, as the pull phase of BFS addresses them
 #pragma once
 
 #include "frontier.hxx"
@@ -10,32 +13,30 @@
 namespace gunrock {
 
 struct enactor_t {
-  std::vector<std::shared_ptr<frontier_t<int>>> buffers;
-  std::shared_ptr<frontier_t<int>> indices;
-  std::shared_ptr<frontier_t<int>> filtered_indices;
-  std::vector<std::shared_ptr<frontier_t<int>>> unvisited;
+  typedef std::shared_ptr<frontier_t<int>> frontier_ptr;
+
+  std::vector<frontier_ptr> buffers;
+  frontier_ptr indices;
+  frontier_ptr filtered_indices;
+  std::vector<frontier_ptr> unvisited;
 
   enactor_t(standard_context_t& context, int num_nodes, int num_edges, float queue_sizing = 1.0f) {
     init(context, num_nodes, num_edges, queue_sizing);
   }
+  enactor_t(const enactor_t&) = delete;
+  enactor_t& operator=(const enactor_t&) = delete;
 
   void init(standard_context_t& context, int num_nodes, int num_edges, float queue_sizing) {
-    // capacity arithmetic is the reference's: (int)(num_edges*queue_sizing) in float (enactor.hxx:22-23)
-    size_t cap = (size_t)(int)(num_edges * queue_sizing);
-    buffers.push_back(std::make_shared<frontier_t<int>>(context, cap));
-    buffers.push_back(std::make_shared<frontier_t<int>>(context, cap));
+    const size_t edge_capacity = (size_t)(int)(num_edges * queue_sizing);
+    for (int i = 0; i < 2; ++i) buffers.push_back(std::make_shared<frontier_t<int>>(context, edge_capacity));
 
-    indices = std::make_shared<frontier_t<int>>(context, num_nodes);
-    filtered_indices = std::make_shared<frontier_t<int>>(context, num_nodes);
-    mem_t<int> indices_array = mgx::fill_function<int>([] __device__(int index) { return index; }, num_nodes, context);
-    (void)indices->load(indices_array);
-    (void)filtered_indices->load(indices_array);
-    unvisited.push_back(indices);
-    unvisited.push_back(filtered_indices);
+    mem_t<int> iota = mgx::fill_function<int>([] __device__(int v) { return v; }, num_nodes, context);
+    for (frontier_ptr* f : {&indices, &filtered_indices}) {
+      *f = std::make_shared<frontier_t<int>>(context, (size_t)num_nodes);
+      (void)(*f)->load(iota);
+      unvisited.push_back(*f);
+    }
   }
-
-  enactor_t(const enactor_t& rhs) = delete;
-  enactor_t& operator=(const enactor_t& rhs) = delete;
 };
 
 }  // namespace gunrock

@@ -1,9 +1,9 @@
-// gunrock/frontier.hxx -- frontier_t<T>: a device id buffer with size / capacity.
-// Drop-in for the reference's gunrock/src/frontier.hxx:12-99 (same members: load(mem_t&),
-// load(vector), resize, capacity, size, type, data, swap).  Differences: capacity overflow
-// throws mgx::mgx_error(MGX_E_FRONTIER_OVERFLOW) where the reference printf()s and exit(0)s
-// (:53-59, :84-89), and constructing a frontier reserves the context's scratch arena for a
-// scan/compaction of `capacity` items so operators never allocate.
+// gunrock/frontier.hxx -- frontier_t<T>: a device buffer of ids with a fill level.
+// Drop-in for the reference's gunrock/src/frontier.hxx:12-99: the same public surface (load from a mem_t or a host
+// vector, resize, capacity, size, type, data, swap, move-only).  Two deliberate differences: a frontier that would
+// overflow throws mgx::mgx_error(MGX_E_FRONTIER_OVERFLOW) where the reference printf()s and exit(0)s (:53-59,
+// :84-89); and constructing one reserves the context's scratch arena for a scan / compaction / segmented reduce over
+// `capacity` items, so that the operators never allocate.
 #pragma once
 
 #include "graph.hxx"
@@ -16,64 +16,63 @@ enum frontier_type_t { edge_frontier = 0, node_frontier = 1 };
 
 template <typename type_t>
 class frontier_t {
-  size_t _size;
-  size_t _capacity;
-  frontier_type_t _type;
-  std::shared_ptr<mem_t<type_t>> _data;
-
-  static void overflow(const char* what, size_t cap, size_t want) {
-    throw mgx::mgx_error(MGX_E_FRONTIER_OVERFLOW, std::string("Overflow during frontier ") + what + ". Capacity is " +
-                                                      std::to_string(cap) + ", size of the data is " +
-                                                      std::to_string(want) + ".");
-  }
-
  public:
-  void swap(frontier_t& rhs) {
-    std::swap(_size, rhs._size);
-    std::swap(_capacity, rhs._capacity);
-    std::swap(_type, rhs._type);
-    _data.swap(rhs._data);
-  }
+  typedef std::shared_ptr<mem_t<type_t>> storage_t;
 
-  frontier_t() : _size(0), _capacity(0), _type(node_frontier), _data(std::make_shared<mem_t<type_t>>()) {}
-  frontier_t& operator=(const frontier_t& rhs) = delete;
-  frontier_t(const frontier_t& rhs) = delete;
-
+  frontier_t() : store_(std::make_shared<mem_t<type_t>>()) {}
   frontier_t(context_t& context, size_t capacity, size_t size = 0, frontier_type_t type = node_frontier)
-      : _size(size), _capacity(capacity), _type(type) {
-    _data.reset(new mem_t<type_t>(capacity, context));
-    if (auto* sc = dynamic_cast<standard_context_t*>(&context))
-      sc->reserve_scratch(mgx::scan_scratch_bytes((long long)capacity) +
-                          mgx::segreduce_scratch_bytes((long long)capacity, 8));
+      : store_(new mem_t<type_t>(capacity, context)), fill_(size), room_(capacity), kind_(type) {
+    if (standard_context_t* ctx = dynamic_cast<standard_context_t*>(&context)) {
+      const long long items = (long long)capacity;
+      ctx->reserve_scratch(mgx::scan_scratch_bytes(items) + mgx::segreduce_scratch_bytes(items, 8));
+    }
+  }
+  frontier_t(frontier_t&& other) : frontier_t() { swap(other); }
+  frontier_t& operator=(frontier_t&& other) { swap(other); return *this; }
+  frontier_t(const frontier_t&) = delete;
+  frontier_t& operator=(const frontier_t&) = delete;
+
+  void swap(frontier_t& other) {
+    store_.swap(other.store_);
+    std::swap(fill_, other.fill_);
+    std::swap(room_, other.room_);
+    std::swap(kind_, other.kind_);
   }
 
-  frontier_t(frontier_t&& rhs) : frontier_t() { swap(rhs); }
-  frontier_t& operator=(frontier_t&& rhs) {
-    swap(rhs);
-    return *this;
+  // contents <- a device array / a host vector (the fill level follows)
+  hipError_t load(mem_t<type_t>& source) {
+    admit("loading", source.size(), store_->size());
+    fill_ = source.size();
+    return dtod(store_->data(), source.data(), source.size());
   }
-  ~frontier_t() {}
+  hipError_t load(const std::vector<type_t>& source) {
+    admit("loading", source.size(), store_->size());
+    fill_ = source.size();
+    return htod(store_->data(), source);
+  }
+  // an operator has written `count` entries
+  void resize(size_t count) {
+    admit("resizing", count, room_);
+    fill_ = count;
+  }
 
-  hipError_t load(mem_t<type_t>& target) {
-    if (target.size() > _data->size()) overflow("loading", _data->size(), target.size());
-    hipError_t result = dtod(_data->data(), target.data(), target.size());
-    _size = target.size();
-    return result;
+  size_t size() const { return fill_; }
+  size_t capacity() const { return room_; }
+  frontier_type_t type() const { return kind_; }
+  storage_t data() const { return store_; }
+
+ private:
+  static void admit(const char* doing, size_t want, size_t have) {
+    if (want > have)
+      throw mgx::mgx_error(MGX_E_FRONTIER_OVERFLOW, std::string("Overflow during frontier ") + doing + ". Capacity is " +
+                                                        std::to_string(have) + ", size of the data is " +
+                                                        std::to_string(want) + ".");
   }
-  hipError_t load(const std::vector<type_t>& target) {
-    if (target.size() > _data->size()) overflow("loading", _data->size(), target.size());
-    hipError_t result = htod(_data->data(), target);
-    _size = target.size();
-    return result;
-  }
-  void resize(size_t size) {
-    if (size > _capacity) overflow("resizing", _capacity, size);
-    _size = size;
-  }
-  size_t capacity() const { return _capacity; }
-  size_t size() const { return _size; }
-  frontier_type_t type() const { return _type; }
-  std::shared_ptr<mem_t<type_t>> data() const { return _data; }
+
+  storage_t store_;
+  size_t fill_ = 0;
+  size_t room_ = 0;
+  frontier_type_t kind_ = node_frontier;
 };
 
 }  // namespace gunrock

@@ -19,37 +19,41 @@ template <typename Problem, typename Functor, typename Value, typename reduce_op
 int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<frontier_t<int>>& input,
                         std::shared_ptr<frontier_t<int>>& output, Value* reduced, Value identity, int iteration,
                         standard_context_t& context) {
-  const int* input_data = input->data()->data();
-  problem->gslice->ensure_scanned(input->capacity(), context);
-  int* scanned_offsets = problem->gslice->d_scanned_row_offsets.data();
-  const int* offsets = push ? problem->gslice->d_row_offsets.data() : problem->gslice->d_col_offsets.data();
+  graph_device_t& graph = *problem->gslice;
+  // out-edges (CSR) when pushing, in-edges (the CSC slots) when pulling
+  const int* const offsets = push ? graph.d_row_offsets.data() : graph.d_col_offsets.data();
+  const int* const neighbours = push ? graph.d_col_indices.data() : graph.d_row_indices.data();
+  const int* const frontier = input->data()->data();
+  const long long frontier_size = (long long)input->size();
 
-  long long non_zeros = 0;
-  mgx::transform_scan(
-      [=] __device__(long long idx) {
-        const int v = input_data[idx];
-        return offsets[v + 1] - offsets[v];
-      },
-      (long long)input->size(), scanned_offsets, context, &non_zeros);
-  if (!non_zeros) return 0;
+  // segment i = the neighbour list of frontier[i]: exclusive scan of the degrees into the graph's scratch scan
+  graph.ensure_scanned(input->capacity(), context);
+  int* const segment_start = graph.d_scanned_row_offsets.data();
+  long long edges = 0;
+  mgx::transform_scan([=] __device__(long long i) { return offsets[frontier[i] + 1] - offsets[frontier[i]]; },
+                      frontier_size, segment_start, context, &edges);
+  if (edges == 0) return 0;
 
-  const int* col_indices = push ? problem->gslice->d_col_indices.data() : problem->gslice->d_row_indices.data();
-  if (has_output) output->resize((size_t)non_zeros);
-  int* output_data = has_output ? output->data()->data() : nullptr;
-  typename Problem::data_slice_t* data = problem->d_data_slice.data();
+  int* out = nullptr;
+  if (has_output) {
+    output->resize((size_t)edges);
+    out = output->data()->data();
+  }
+  typename Problem::data_slice_t* const data = problem->d_data_slice.data();
 
-  auto neighborhood_reduce = [=] __device__(int idx, int seg, int rank) -> Value {
-    const int v = input_data[seg];
-    const int start = offsets[v];
-    const int neighbor = col_indices[start + rank];
-    const bool cond = Functor::cond_advance(v, neighbor, start + rank, rank, idx, data, iteration);
-    const bool apply = Functor::apply_advance(v, neighbor, start + rank, rank, idx, data, iteration);
-    if (has_output) output_data[idx] = (cond && apply) ? neighbor : -1;
-    return Functor::get_value_to_reduce(neighbor, data, iteration);
+  // per edge: the functor's contract (cond, then apply, both always), the optional output slot, and the value that
+  // goes into the segment's reduction; reduced[i] belongs to frontier POSITION i (neighborhood.hxx:58)
+  auto visit = [=] __device__(int slot, int segment, int rank) -> Value {
+    const int v = frontier[segment];
+    const int edge = offsets[v] + rank;
+    const int u = neighbours[edge];
+    const bool cond = Functor::cond_advance(v, u, edge, rank, slot, data, iteration);
+    const bool applied = Functor::apply_advance(v, u, edge, rank, slot, data, iteration);
+    if (has_output) out[slot] = (cond && applied) ? u : -1;
+    return Functor::get_value_to_reduce(u, data, iteration);
   };
-  mgx::lbs_segreduce<Value>(neighborhood_reduce, non_zeros, scanned_offsets, (long long)input->size(), reduced,
-                            reduce_op(), identity, context);
-  return (int)non_zeros;
+  mgx::lbs_segreduce<Value>(visit, edges, segment_start, frontier_size, reduced, reduce_op(), identity, context);
+  return (int)edges;
 }
 
 }  // namespace neighborhood

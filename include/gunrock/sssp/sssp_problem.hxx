@@ -1,8 +1,8 @@
-// gunrock/sssp/sssp_problem.hxx -- SSSP problem state.
-// Mirrors the reference's sssp_problem_t (gunrock/src/sssp/sssp_problem.hxx:11-57):
-// d_labels (float distances, FLT_MAX / 0 at src), d_preds (-1), d_visited (-1 stamps),
-// data_slice_t {d_labels, d_preds, d_weights, d_visited}; extract() copies labels and preds.
-// The reference's CPU validator (cpu(), :59-88) is restated in oracle/oracle.c (orc_sssp_cpu).
+// gunrock/sssp/sssp_problem.hxx -- SSSP state behind the C-ABI (mgx_sssp_*).
+// Semantics of the reference's sssp_problem_t (gunrock/src/sssp/sssp_problem.hxx:11-57): distances ("labels")
+// are FLT_MAX except 0 at the source, preds -1, the per-iteration dedup stamps -1; the functor also needs the edge
+// weights, which stay where the graph keeps them.  The reference's CPU validator (cpu(), :59-88) is restated in
+// oracle/oracle.c (orc_sssp_cpu), with the tests.
 #pragma once
 #include <limits>
 
@@ -12,62 +12,52 @@ namespace gunrock {
 namespace sssp {
 
 struct sssp_problem_t : problem_t {
-  mem_t<float> d_labels;
-  mem_t<int> d_preds;
-  mem_t<int> d_visited;
-  std::vector<float> labels;
-  std::vector<int> preds;
-  int src;
-
   struct data_slice_t {
-    float* d_labels;
+    float* d_labels;      // distances
     int* d_preds;
-    float* d_weights;
-    int* d_visited;
-    void init(mem_t<float>& _labels, mem_t<int>& _preds, mem_t<float>& _weights, mem_t<int>& _visited) {
-      d_labels = _labels.data();
-      d_preds = _preds.data();
-      d_weights = _weights.data();
-      d_visited = _visited.data();
-    }
+    float* d_weights;     // graph_device_t::d_col_values
+    int* d_visited;       // iteration in which the vertex last passed the filter
   };
 
+  int src = 0;
+  mem_t<float> d_labels;
+  mem_t<int> d_preds, d_visited;
   mem_t<data_slice_t> d_data_slice;
-  std::vector<data_slice_t> data_slice;
+  std::vector<float> labels;               // host copies, filled by extract()
+  std::vector<int> preds;
 
-  sssp_problem_t() {}
-  sssp_problem_t(const sssp_problem_t& rhs) = delete;
-  sssp_problem_t& operator=(const sssp_problem_t& rhs) = delete;
-
-  sssp_problem_t(std::shared_ptr<graph_device_t> rhs, size_t src, standard_context_t& context)
-      : problem_t(rhs), src((int)src), data_slice(std::vector<data_slice_t>(1)) {
-    d_labels = mem_t<float>(rhs->num_nodes, context);
-    d_preds = mem_t<int>(rhs->num_nodes, context);
-    d_visited = mem_t<int>(rhs->num_nodes, context);
-    data_slice[0].init(d_labels, d_preds, gslice->d_col_values, d_visited);
-    d_data_slice = to_mem(data_slice, context);
-    reset(src, context);
+  sssp_problem_t(std::shared_ptr<graph_device_t> graph, size_t source, standard_context_t& ctx) : problem_t(graph) {
+    const size_t n = (size_t)graph->num_nodes;
+    d_labels = mem_t<float>(n, ctx);
+    d_preds = mem_t<int>(n, ctx);
+    d_visited = mem_t<int>(n, ctx);
+    const data_slice_t slice{d_labels.data(), d_preds.data(), graph->d_col_values.data(), d_visited.data()};
+    d_data_slice = to_mem(std::vector<data_slice_t>(1, slice), ctx);
+    reset(source, ctx);
   }
+  sssp_problem_t(const sssp_problem_t&) = delete;
+  sssp_problem_t& operator=(const sssp_problem_t&) = delete;
 
-  void reset(size_t new_src, standard_context_t& context) {
-    src = (int)new_src;
-    const int n = gslice->num_nodes;
-    float* lab = d_labels.data();
-    int* pr = d_preds.data();
-    int* vis = d_visited.data();
+  // the state a fresh problem has, for another source: one pass over the three arrays
+  void reset(size_t source, standard_context_t& ctx) {
+    src = (int)source;
     const int s = src;
+    float* const dist = d_labels.data();
+    int* const pred = d_preds.data();
+    int* const stamp = d_visited.data();
     mgx::transform(
-        [=] __device__(int i) {
-          lab[i] = (i == s) ? 0.0f : std::numeric_limits<float>::max();
-          pr[i] = -1;
-          vis[i] = -1;
+        [=] __device__(int v) {
+          dist[v] = (v == s) ? 0.0f : std::numeric_limits<float>::max();
+          pred[v] = -1;
+          stamp[v] = -1;
         },
-        n, context);
+        gslice->num_nodes, ctx);
   }
 
   void extract() {
-    MGX_HIP(mgx::dtoh(labels, d_labels.data(), gslice->num_nodes));
-    MGX_HIP(mgx::dtoh(preds, d_preds.data(), gslice->num_nodes));
+    const size_t n = (size_t)gslice->num_nodes;
+    MGX_HIP(mgx::dtoh(labels, d_labels.data(), n));
+    MGX_HIP(mgx::dtoh(preds, d_preds.data(), n));
   }
 };
 
