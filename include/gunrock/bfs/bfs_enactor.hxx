@@ -163,7 +163,10 @@ struct bfs_fused_enactor_t {
     for (int i = 0; i < hc->levels && i < mgx::BFS_MAX_TRACE; ++i)
       last.trace.emplace_back((long long)(hc->trace[i] >> mgx::BFS_VSHIFT), (long long)(hc->trace[i] & mgx::BFS_EMASK));
     for (int i = 0; i < fused->batches; ++i) last.batch_ms.push_back(fused->batch_ms[i]);
-    for (int i = 0; i < hc->levels && i < 63; ++i) last.level_ms.push_back((float)((double)(hc->stamp[i + 1] - hc->stamp[i]) / 1e5));
+    // (a level's duration needs the stamp of the NEXT level's opening: the direct scheme ends a traversal from the
+    //  read-back cursors without opening the level behind the last one -- no time for that last level then)
+    for (int i = 0; i < hc->levels && i < 63 && hc->stamp[i + 1] >= hc->stamp[i] && hc->stamp[i + 1] != 0; ++i)
+      last.level_ms.push_back((float)((double)(hc->stamp[i + 1] - hc->stamp[i]) / 1e5));
     last.small_levels = hc->small_levels;
     for (int i = 0; i < last.push_levels && i < (int)last.trace.size(); ++i) last.push_edges += last.trace[i].second;
     // the long-row queue only exists on push levels; the short-row queue gets the rest of the push edges

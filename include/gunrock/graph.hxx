@@ -165,7 +165,8 @@ inline std::shared_ptr<graph_t> load_graph(const char* _name, bool _undir = fals
     if (line[0] != '%') { header = true; break; }
   }
   int height, width, nnz;
-  if (!header || 3 != sscanf(line, "%d %d %d", &height, &width, &nnz)) {
+  if (!header || 3 != sscanf(line, "%d %d %d", &height, &width, &nnz) || height < 0 || nnz < 0 ||
+      (long long)nnz * (_undir ? 2 : 1) > 2147483647LL) {
     printf("Error reading %s\n", _name);
     fclose(f);
     return nullptr;
@@ -177,6 +178,13 @@ inline std::shared_ptr<graph_t> load_graph(const char* _name, bool _undir = fals
     float w;
     if (!fgets(line, 100, f) || (items = sscanf(line, "%d %d %f", &a, &b, &w)) < 2) {
       printf("Error reading edge lists %s\n", _name);
+      fclose(f);
+      return nullptr;
+    }
+    // ids are 1-based and index an n x n adjacency (num_nodes = height): an id outside [1, height] would index past
+    // offsets[] in csr_from_tuples and past every per-vertex device array later (the reference has the same hole)
+    if (a < 1 || b < 1 || a > height || b > height) {
+      printf("Error reading edge lists %s: entry %d (%d %d) outside 1..%d\n", _name, e, a, b, height);
       fclose(f);
       return nullptr;
     }

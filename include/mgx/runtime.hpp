@@ -40,6 +40,26 @@ struct mgx_error : std::runtime_error {
     if (_e != hipSuccess) throw ::mgx::hip_error(_e, #expr, __FILE__, __LINE__); \
   } while (0)
 
+// A kernel launch reports a bad configuration (too much dynamic LDS, a grid the device refuses) only through
+// hipGetLastError: checked after the launches of a batch, before their results are read back -- an unchecked failed
+// launch leaves the control block untouched and would read as "traversal finished".
+#define MGX_CHECK_LAUNCH(what)                                                          \
+  do {                                                                                  \
+    hipError_t _e = hipGetLastError();                                                  \
+    if (_e != hipSuccess) throw ::mgx::hip_error(_e, what, __FILE__, __LINE__);         \
+  } while (0)
+
+// Per-DEVICE one-time setup (hipFuncSetAttribute is per device: a second context on another GPU of the same process
+// needs it again).  Returns true the first time it is called for the current device with this tag.
+inline bool first_use_on_device(unsigned char (&seen)[64]) {
+  int dev = 0;
+  MGX_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return true;
+  if (seen[dev]) return false;
+  seen[dev] = 1;
+  return true;
+}
+
 // ---------------------------------------------------------------------------
 // context: one device, one stream, a scratch arena, a pinned mailbox
 // ---------------------------------------------------------------------------
@@ -47,6 +67,18 @@ struct context_t {
   virtual ~context_t() {}
   virtual hipStream_t stream() const = 0;
 };
+
+// The stream the context-less copies below (htod / dtoh / dtod, the reference's signatures: graph.hxx:40-83,
+// frontier.hxx:65-79) are ordered on: the stream of the context this host thread used last (set by
+// standard_context_t's constructor / set_stream and by every C-ABI entry point).  A blocking hipMemcpy on the NULL
+// stream is NOT ordered against a non-blocking stream (hipStreamNonBlocking, any torch.cuda.Stream()): a D2D copy
+// could overtake the kernel that fills its source, an H2D copy could overwrite a buffer a queued kernel still reads.
+inline hipStream_t& current_stream_ref() {
+  static thread_local hipStream_t s = nullptr;
+  return s;
+}
+inline hipStream_t current_stream() { return current_stream_ref(); }
+inline void set_current_stream(hipStream_t s) { current_stream_ref() = s; }
 
 struct standard_context_t : context_t {
   int device = 0;
@@ -60,6 +92,7 @@ struct standard_context_t : context_t {
   int num_cus = 256;
 
   explicit standard_context_t(bool print_prop = false, hipStream_t s = nullptr) : _stream(s) {
+    set_current_stream(s);
     MGX_HIP(hipGetDevice(&device));
     hipDeviceProp_t prop;
     MGX_HIP(hipGetDeviceProperties(&prop, device));
@@ -75,7 +108,8 @@ struct standard_context_t : context_t {
     if (mailbox) (void)hipHostFree(mailbox);
   }
   hipStream_t stream() const override { return _stream; }
-  void set_stream(hipStream_t s) { _stream = s; }
+  void set_stream(hipStream_t s) { _stream = s; set_current_stream(s); }
+  void make_current() const { set_current_stream(_stream); }
   void synchronize() { MGX_HIP(hipStreamSynchronize(_stream)); }
 
   // Make sure the arena holds `bytes`.  Called from constructors of graphs,
@@ -117,27 +151,40 @@ class mem_t {
   size_t size() const { return _size; }
 };
 
+// Copies are stream-ordered: issued on `s` (default: the calling thread's current context stream, see above).
+// Host <-> device copies return when the data has arrived (the host buffer may be pageable and short-lived);
+// device -> device copies are asynchronous on the stream like any kernel.
 template <typename T>
-inline hipError_t htod(T* dst, const T* src, size_t n) {
-  return n ? hipMemcpy(dst, src, n * sizeof(T), hipMemcpyHostToDevice) : hipSuccess;
+inline hipError_t htod(T* dst, const T* src, size_t n, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hipError_t e = hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, s);
+  return e != hipSuccess ? e : hipStreamSynchronize(s);
 }
+template <typename T>
+inline hipError_t htod(T* dst, const T* src, size_t n) { return htod(dst, src, n, current_stream()); }
 template <typename T>
 inline hipError_t htod(T* dst, const std::vector<T>& src) { return htod(dst, src.data(), src.size()); }
 template <typename T>
-inline hipError_t dtoh(T* dst, const T* src, size_t n) {
-  return n ? hipMemcpy(dst, src, n * sizeof(T), hipMemcpyDeviceToHost) : hipSuccess;
+inline hipError_t dtoh(T* dst, const T* src, size_t n, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hipError_t e = hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, s);
+  return e != hipSuccess ? e : hipStreamSynchronize(s);
 }
+template <typename T>
+inline hipError_t dtoh(T* dst, const T* src, size_t n) { return dtoh(dst, src, n, current_stream()); }
 template <typename T>
 inline hipError_t dtoh(std::vector<T>& dst, const T* src, size_t n) { dst.resize(n); return dtoh(dst.data(), src, n); }
 template <typename T>
-inline hipError_t dtod(T* dst, const T* src, size_t n) {
-  return n ? hipMemcpy(dst, src, n * sizeof(T), hipMemcpyDeviceToDevice) : hipSuccess;
+inline hipError_t dtod(T* dst, const T* src, size_t n, hipStream_t s) {
+  return n ? hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToDevice, s) : hipSuccess;
 }
+template <typename T>
+inline hipError_t dtod(T* dst, const T* src, size_t n) { return dtod(dst, src, n, current_stream()); }
 
 template <typename T>
 inline mem_t<T> to_mem(const std::vector<T>& h, context_t& c) {
   mem_t<T> m(h.size(), c);
-  MGX_HIP(htod(m.data(), h));
+  MGX_HIP(htod(m.data(), h.data(), h.size(), c.stream()));
   return m;
 }
 template <typename T>

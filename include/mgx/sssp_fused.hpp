@@ -413,10 +413,9 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   a.hot_min_edges = hme ? (u32)atoll(hme) : SSSP_HOT_MIN_EDGES;
   hipLaunchKernelGGL(k_sssp_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src,
                      layout ? layout->new_of_old : (const int*)nullptr);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned char attr_seen[64] = {};
+  if (first_use_on_device(attr_seen)) {
     MGX_HIP(hipFuncSetAttribute((const void*)k_sssp_relax<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SSSP_HOTN * 2));
-    attr_set = true;
   }
   int it = 0;
   for (int batch = 0;; ++batch) {
@@ -425,6 +424,7 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
       hipLaunchKernelGGL(k_sssp_relax<1024>, dim3(ctx.num_cus * 2), dim3(1024), SSSP_HOTN * 2, s, a, it);
       hipLaunchKernelGGL(k_sssp_build<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, it);
     }
+    MGX_CHECK_LAUNCH("fused SSSP: kernel launch");
     MGX_HIP(hipMemcpyAsync(st.host_ctrl, st.ctrl.data(), offsetof(bfs_ctrl_t, trace) + 64 * sizeof(u64), hipMemcpyDeviceToHost, s));
     MGX_HIP(hipStreamSynchronize(s));
     if (st.host_ctrl->done) break;
@@ -440,6 +440,7 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   if (layout) {
     hipLaunchKernelGGL(k_sssp_unpermute, dim3(grid_for(st.n, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, st.dist_layout.data(),
                        layout->old_of_new, (u32*)d_dist, (long long)st.n);
+    MGX_CHECK_LAUNCH("fused SSSP: unpermute launch");
     MGX_HIP(hipStreamSynchronize(s));
   }
 }

@@ -90,7 +90,8 @@ static thread_local std::string g_last_error;
     if (!(cond)) throw mgx::mgx_error(MGX_E_INVALID, msg);         \
   } while (0)
 
-static inline void use_device(mgx_ctx_s* c) { MGX_HIP(hipSetDevice(c->device)); }
+// every entry point: the handle's device, and its stream as the one the context-less copies are ordered on
+static inline void use_device(mgx_ctx_s* c) { MGX_HIP(hipSetDevice(c->device)); c->ctx->make_current(); }
 
 // neighbourhood reduce with a plain per-vertex gather as the functor
 namespace {
@@ -205,6 +206,15 @@ int mgx_graph_upload(mgx_ctx_t c, int n, int64_t m, const int* ro, const int* ci
   MGX_REQUIRE(c && out && ro && (ci || m == 0), "mgx_graph_upload: NULL argument");
   MGX_REQUIRE(n >= 0 && m >= 0 && m <= 2147483647LL, "mgx_graph_upload: sizes must fit int32 (graph.hxx:19-26)");
   MGX_REQUIRE((co == nullptr) == (ri == nullptr), "mgx_graph_upload: col_offsets and row_indices go together");
+  // host arrays: cheap to validate (the kernels index with them unchecked)
+  MGX_REQUIRE(ro[0] == 0 && (int64_t)ro[n] == m, "mgx_graph_upload: row_offsets must start at 0 and end at num_edges");
+  for (int v = 0; v < n; ++v) MGX_REQUIRE(ro[v] <= ro[v + 1], "mgx_graph_upload: row_offsets must be non-decreasing");
+  for (int64_t e = 0; e < m; ++e) MGX_REQUIRE(ci[e] >= 0 && ci[e] < n, "mgx_graph_upload: col_indices outside [0, num_nodes)");
+  if (co) {
+    MGX_REQUIRE(co[0] == 0 && (int64_t)co[n] == m, "mgx_graph_upload: col_offsets must start at 0 and end at num_edges");
+    for (int v = 0; v < n; ++v) MGX_REQUIRE(co[v] <= co[v + 1], "mgx_graph_upload: col_offsets must be non-decreasing");
+    for (int64_t e = 0; e < m; ++e) MGX_REQUIRE(ri[e] >= 0 && ri[e] < n, "mgx_graph_upload: row_indices outside [0, num_nodes)");
+  }
   use_device(c);
   auto g = std::make_shared<graph_device_t>();
   g->num_nodes = n;

@@ -68,6 +68,11 @@ def test_mtx_loader_error_paths(built, tmp_path):
     bad.write_text("%%MatrixMarket\n3 3 2\n1 2\nnot an edge\n")
     with pytest.raises(mini_amd.MgxError):
         mini_amd.load_mtx(bad)
+    # ids outside 1..n (a rectangular matrix, a 0-based file): a status, not a heap overflow
+    for body in ("3 3 1\n1 4\n", "3 3 1\n4 1\n", "3 3 1\n0 1\n", "3 5 1\n1 5\n", "3 3 -1\n"):
+        bad.write_text("%%MatrixMarket\n" + body)
+        with pytest.raises(mini_amd.MgxError):
+            mini_amd.load_mtx(bad)
     # comment lines, weights, 1-based ids, transposed orientation (F9)
     ok = tmp_path / "ok.mtx"
     ok.write_text("%%MatrixMarket matrix coordinate real general\n% c\n3 3 2\n1 2 0.5\n3 2 7\n")
