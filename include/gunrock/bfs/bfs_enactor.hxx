@@ -120,7 +120,9 @@ struct bfs_run_stats_t {
   std::vector<std::pair<long long, long long>> trace;   // (frontier vertices, frontier edges) per level
   std::vector<float> batch_ms;
   std::vector<float> level_ms;       // device-side stamps (100 MHz) taken when each level is opened
-  int small_levels = 0;              // levels the single-workgroup kernel ran
+  int small_levels = 0;              // levels run inside a push launch's block 0 (chains of small levels)
+  int slots = 0;                     // launch slots the run used
+  int dense_slots = 0;               // slots whose long rows were read from the unit blocks
   long long claims_level[64] = {0};
 };
 
@@ -146,6 +148,13 @@ struct bfs_fused_enactor_t {
       layout.col_indices = g.d_layout_col_indices.data();
       layout.new_of_old = g.d_new_of_old.data();
       layout.old_of_new = g.d_old_of_new.data();
+      if (g.ub_units > 0) {
+        layout.ub_col = g.d_ub_col.data();
+        layout.ub_owner = g.d_ub_owner.data();
+        layout.ub_units = g.ub_units;
+        layout.ub_units_pad = g.ub_units_pad;
+        layout.ub_min_degree = g.ub_min_degree;
+      }
     }
     // the hub-first layout carries no separate CSC: bottom-up levels can use it only on graphs whose
     // CSC slots alias the CSR (symmetric input, what the reference always has)
@@ -168,6 +177,8 @@ struct bfs_fused_enactor_t {
     for (int i = 0; i < hc->levels && i < 63 && hc->stamp[i + 1] >= hc->stamp[i] && hc->stamp[i + 1] != 0; ++i)
       last.level_ms.push_back((float)((double)(hc->stamp[i + 1] - hc->stamp[i]) / 1e5));
     last.small_levels = hc->small_levels;
+    last.slots = fused->slots_used;
+    last.dense_slots = hc->dense_slots;
     for (int i = 0; i < last.push_levels && i < (int)last.trace.size(); ++i) last.push_edges += last.trace[i].second;
     // the long-row queue only exists on push levels; the short-row queue gets the rest of the push edges
     last.stream.launches = fused->stream_kernel_launches;

@@ -69,6 +69,12 @@ struct graph_device_t {
   mem_t<int> d_new_of_old;
   mem_t<int> d_old_of_new;
   bool has_layout = false;
+  // Unit blocks of the layout's long rows (mgx_layout.hip, mgx/bfs_fused_dense.hpp): rows of >= ub_min_degree edges
+  // padded to 64-entry units, owner[u] = the row of unit u.  Built with the layout; optional.
+  mem_t<int> d_ub_col;
+  mem_t<int> d_ub_owner;
+  long long ub_units = 0, ub_units_pad = 0;
+  int ub_min_degree = 0;
 
   graph_device_t() : num_nodes(0), num_edges(0) {}
 

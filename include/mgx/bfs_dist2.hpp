@@ -102,6 +102,7 @@ struct d2_state_t {
   u32* newbits = nullptr;             // caller-owned (n_global bits): what this rank discovered in the level
   long long nwords = 0;
   long long last_edges = 0;           // edges of the frontier the last push expanded
+  int cold_forced = -1;               // MGX_BFS_COLD_TEST at creation (-1: by size)
 
   void init(standard_context_t& ctx, int n_global_, int ranks_, int rank_, const int* ro, const int* ci, u32* newbits_) {
     n_global = n_global_; ranks = ranks_; rank = rank_;
@@ -109,6 +110,7 @@ struct d2_state_t {
     row_offsets = ro; col_indices = ci; newbits = newbits_;
     nwords = (((long long)n_global + 31) / 32 + 3) / 4 * 4;     // padded to 16 bytes: the OR-merge reads uint4
     fs.reset(new bfs_fused_state_t(n_global, ctx));
+    if (const char* e = getenv("MGX_BFS_COLD_TEST")) cold_forced = atoi(e);
     labels = mem_t<int>((size_t)n_local + 1, ctx);
     merged = mem_t<u32>((size_t)nwords + 4, ctx);
   }
@@ -133,6 +135,8 @@ struct d2_state_t {
     a.mode = 0; a.alpha = 0.f;
     a.flags = 0;
     a.count_marks = 0;
+    a.ub_col = nullptr; a.ub_owner = nullptr; a.ub_units = 0; a.ub_units_pad = 0; a.dense_div = 0; a.dense_diag = 0;
+    a.chain_max_edges = 0;               // (levels are counted by the host here: no chains of small levels)
     return a;
   }
 };
@@ -151,7 +155,7 @@ inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx) {
   hipStream_t s = ctx.stream();
   bfs_fused_args_t a = st.args();
   bfs_set_kernel_attributes();
-  bfs_launch_push(a, level, ctx, 2);          // (the level's bookkeeping rides on the push launch)
+  bfs_launch_push(a, level, ctx, 2, bfs_cold_test(a.n, st.cold_forced));   // (the level's bookkeeping rides on the push launch)
   hipLaunchKernelGGL(k_d2_newbits, dim3(grid_for(st.nwords, BLOCK, 256)), dim3(BLOCK), 0, s, st.fs->visited.data(),
                      st.fs->mark.data(), st.newbits, st.nwords, (long long)st.n_global, a.ctrl);
 }

@@ -68,12 +68,20 @@ struct bfs_ctrl_t {
   int levels;        // number of levels that expanded at least one edge
   int pull;          // direction of the level about to run (set by k_bfs_level_begin; sticky once 1)
   int push_levels;   // levels run top-down
-  int level;         // device-resident level counter (launches with level < 0 read it; see k_bfs_small_levels)
-  int big;           // level `level` has been opened for the device-wide kernels of this slot
-  int small_levels;  // levels the single-workgroup kernel ran
-  int slots;         // launch slots that found work (k_bfs_small_levels counts them)
+  int level;         // (unused)
+  int big;           // (unused)
+  int small_levels;  // levels run by the chains of small levels (bfs_fused_chain.hpp)
+  int slots;         // launch slots that found work (their opener / chain counts them)
   int dist_done;     // partitioned runs: a level ended with no discovery on any rank ...
   int dist_levels;   // ... and this many levels hold vertices
+  // Slot scheme (bfs_fused_run.hpp): launch slot s = [push, (pull), build]; the rings above are indexed by SLOT there
+  // (s % 3), the queue buffers by s & 1, and the level a slot works on is slot_level[s & 3] -- written one slot ahead
+  // (by the slot's opener, or by the chain of small levels that ran inside the push launch), so that nothing a
+  // workgroup bases its decisions on changes while the slot's kernels run.
+  int slot_level[4];
+  int skip_build[4]; // slot s & 3: the push launch ran its level(s) itself (bfs_fused_chain.hpp): k_bfs_build has nothing to do
+  int fb_slot;       // frontier_bits holds exactly the frontier of this slot (written by the k_bfs_build of the slot before)
+  int dense_slots;   // slots whose long rows were read from the unit blocks (bfs_fused_dense.hpp)
   int pad_[2];
   u64 stamp[64];     // s_memrealtime (100 MHz) when each level was opened: per-level times without host syncs
   u64 trace[BFS_MAX_TRACE];   // (vertices << 38 | edges) of each level, both queues (kept LAST: read back up to `levels`)
@@ -102,6 +110,14 @@ struct bfs_fused_args_t {
   int n;
   int flags;               // diagnostics only
   int count_marks;         // the push kernels count their mark stores into ctrl->claims / claims_level (tools only)
+  // unit blocks of the long rows (mgx_layout.hip: rows of >= long_min edges padded to 64-entry units; NULL: none)
+  const int* ub_col;       // units_pad * 64 entries + 4 x (-1)
+  const int* ub_owner;     // units_pad owners (vertex id in the space of row_offsets; n for padding units)
+  u32 ub_units;            // real units
+  u32 ub_units_pad;        // multiple of 16
+  u32 dense_div;           // a slot reads its long rows from the unit blocks when frontier units * dense_div >= ub_units (0: never)
+  int dense_diag;          // measurements only (MGX_BFS_DENSE_DIAG): 1 the unit-block body stores no marks, 2 tests nothing
+  u32 chain_max_edges;     // a level of at most this many edges (and BFS_CHAIN_CQ rows) runs inside block 0 of the push launch (0: never)
 };
 
 __device__ __forceinline__ void bfs_ctrl_reset(bfs_ctrl_t* c) {
@@ -115,6 +131,9 @@ __device__ __forceinline__ void bfs_ctrl_reset(bfs_ctrl_t* c) {
   c->done = c->levels = c->pull = c->push_levels = 0;
   c->level = c->big = c->small_levels = c->slots = 0;
   c->dist_done = c->dist_levels = 0;
+  for (int i = 0; i < 4; ++i) { c->slot_level[i] = 0; c->skip_build[i] = 0; }
+  c->fb_slot = 0;                                  // k_bfs_fused_init seeds frontier_bits with the source
+  c->dense_slots = 0;
   for (int i = 0; i < 64; ++i) c->stamp[i] = 0;
 }
 
@@ -166,7 +185,7 @@ __global__ __launch_bounds__(BLOCK) void k_bfs_fused_init(bfs_fused_args_t a, in
   for (long long w = tid; w < nwords; w += nth) {
     const u32 seed = (w == (src >> 5)) ? src_bit : 0u;
     a.visited[w] = seed;
-    if (a.mode == 1) a.frontier_bits[w] = seed;
+    a.frontier_bits[w] = seed;
   }
   if (tid == 0) {
     bfs_ctrl_reset(a.ctrl);
@@ -176,16 +195,17 @@ __global__ __launch_bounds__(BLOCK) void k_bfs_fused_init(bfs_fused_args_t a, in
 
 // Opening a level (one thread): termination flag, trace, TEPS numerator, direction decision.  Returns false when
 // the frontier is empty (the traversal is over).
-__device__ __forceinline__ bool bfs_open_level(const bfs_fused_args_t& a, int level) {
+// `slot` indexes the rings (== level in the explicit-level scheme of the partitioned path).
+__device__ __forceinline__ bool bfs_open_level(const bfs_fused_args_t& a, int level, int slot) {
   bfs_ctrl_t* const c = a.ctrl;
-  const u64 cur = c->cursor[level % 3];
-  const u64 lcur = c->lcursor[level % 3];
+  const u64 cur = c->cursor[slot % 3];
+  const u64 lcur = c->lcursor[slot % 3];
   const long long nf = (long long)(cur >> BFS_VSHIFT) + (long long)(lcur >> BFS_VSHIFT);
-  const u64 long_edges = c->ledges[level % 3];
+  const u64 long_edges = c->ledges[slot % 3];
   const u64 E = (cur & BFS_EMASK) + long_edges;
-  c->cursor[(level + 2) % 3] = 0;
-  c->lcursor[(level + 2) % 3] = 0;
-  c->ledges[(level + 2) % 3] = 0;
+  c->cursor[(slot + 2) % 3] = 0;
+  c->lcursor[(slot + 2) % 3] = 0;
+  c->ledges[(slot + 2) % 3] = 0;
   if (level < 64) c->stamp[level] = __builtin_amdgcn_s_memrealtime();
   if (nf == 0) {
     if (!c->done) { c->done = 1; c->levels = level; }
@@ -207,10 +227,10 @@ __device__ __forceinline__ bool bfs_open_level(const bfs_fused_args_t& a, int le
 // Is level `level` a bottom-up one?  The level's opener writes the decision to ctrl->pull, but in the direct launch
 // scheme it runs inside the push grid, next to the workgroups that need the answer: they derive it themselves from
 // the same, stable inputs (queue sizes left by the previous build, vertices reached so far) with the same arithmetic.
-__device__ __forceinline__ bool bfs_level_pulls(const bfs_fused_args_t& a, const bfs_ctrl_t* c, int level) {
+__device__ __forceinline__ bool bfs_level_pulls(const bfs_fused_args_t& a, const bfs_ctrl_t* c, int slot) {
   if (a.mode != 1) return false;
   if (c->pull) return true;
-  const long long nf = (long long)(c->cursor[level % 3] >> BFS_VSHIFT) + (long long)(c->lcursor[level % 3] >> BFS_VSHIFT);
+  const long long nf = (long long)(c->cursor[slot % 3] >> BFS_VSHIFT) + (long long)(c->lcursor[slot % 3] >> BFS_VSHIFT);
   const float unvisited = (float)((long long)a.n - (long long)c->reached);
   return unvisited < (float)nf * a.alpha;
 }
@@ -221,20 +241,21 @@ __device__ __forceinline__ bool bfs_level_pulls(const bfs_fused_args_t& a, const
 __device__ __forceinline__ void bfs_begin_level(const bfs_fused_args_t& a, int level, int partitioned) {
   bfs_ctrl_t* const c = a.ctrl;
   if (partitioned && level > 0 && c->merged_new == 0 && !c->dist_done) { c->dist_done = 1; c->dist_levels = level; }
-  (void)bfs_open_level(a, level);
+  (void)bfs_open_level(a, level, level);
 }
 __global__ void k_bfs_level_begin(bfs_fused_args_t a, int level, int partitioned) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   bfs_begin_level(a, level, partitioned);
 }
 
-// Device-wide kernels are launched either with an explicit level (>= 0) or with level < 0: then the level is
-// ctrl->level and the kernel runs only if k_bfs_small_levels has opened it for this slot (ctrl->big).
-__device__ __forceinline__ bool bfs_resolve_level(const bfs_ctrl_t* c, int& level) {
-  if (level >= 0) return true;
-  level = c->level;
-  return c->big != 0;
+// Kernel argument `arg` of the level kernels: >= 0 is an explicit level (the partitioned path: the host counts the
+// levels, slot == level); -1 - s is launch slot s of the slot scheme, whose level is ctrl->slot_level[s & 3].
+__device__ __forceinline__ void bfs_resolve(const bfs_ctrl_t* c, int arg, int& slot, int& level) {
+  if (arg >= 0) { slot = level = arg; return; }
+  slot = -1 - arg;
+  level = c->slot_level[slot & 3];
 }
+__host__ __device__ __forceinline__ int bfs_slot_arg(int slot) { return -1 - slot; }
 
 // ---- a level's discoveries -> bitmap, labels, next level's queues ----------------------------------------------
 // FROM_MARKS (single GPU): vertex v is new when mark[v] != 0 and its bit is not set in `visited`; the kernel sets
@@ -258,7 +279,7 @@ constexpr int BFS_BUILD_LIST = 8 * BFS_BUILD_NT;      // discoveries appended pe
 inline int bfs_build_grid(long long n_local, int nt = BFS_BUILD_NT) { return (int)((n_local + 16 * nt - 1) / (16 * nt)); }
 
 template <int NT, bool FROM_MARKS>
-__global__ __launch_bounds__(NT) void k_bfs_build(bfs_fused_args_t a, int level, const u32* __restrict__ bits,
+__global__ __launch_bounds__(NT, NT == 512 ? 4 : 4) void k_bfs_build(bfs_fused_args_t a, int arg, const u32* __restrict__ bits,
                                                   int* __restrict__ labels, int n_local, int ranks, int rank,
                                                   int stop_when_done) {
   constexpr int NW = NT / WAVE;
@@ -271,8 +292,11 @@ __global__ __launch_bounds__(NT) void k_bfs_build(bfs_fused_args_t a, int level,
   __shared__ u64 s_base[2];
   __shared__ u32 s_long_edges;                   // true edges of the batch's long rows (their offsets count padded ones)
   bfs_ctrl_t* const c = a.ctrl;
-  if (!bfs_resolve_level(c, level)) return;
+  int slot, level;
+  bfs_resolve(c, arg, slot, level);
   if (stop_when_done && c->done) return;        // (a rank of a partitioned run may be handed work with an empty frontier)
+  if (arg < 0 && c->skip_build[slot & 3]) return;   // the push launch of this slot ran its level(s) itself
+  if (FROM_MARKS && blockIdx.x == 0 && threadIdx.x == 0) c->fb_slot = slot + 1;   // frontier_bits: written in full below
   // first of this thread's 16 vertices: run (blockIdx + k * gridDim) of 1024 vertices, k = the thread's wave
   const long long i0 = (((long long)blockIdx.x + (long long)(threadIdx.x >> 6) * gridDim.x) * 64 + (threadIdx.x & 63)) * 16;
   const int new_label = level + 1;
@@ -293,7 +317,7 @@ __global__ __launch_bounds__(NT) void k_bfs_build(bfs_fused_args_t a, int level,
       const u32 old16 = *vis16;
       new16 = m16 & ~old16 & valid;
       if (new16) *vis16 = (unsigned short)(old16 | new16);                   // this thread is the half-word's only writer
-      if (a.mode == 1) ((unsigned short*)a.frontier_bits)[i0 >> 4] = (unsigned short)new16;
+      ((unsigned short*)a.frontier_bits)[i0 >> 4] = (unsigned short)new16;     // bottom-up levels, unit blocks
     } else {
       for (int q = 0; q < 16; ++q) {
         const long long v = (i0 + q) * ranks + rank;
@@ -303,17 +327,17 @@ __global__ __launch_bounds__(NT) void k_bfs_build(bfs_fused_args_t a, int level,
   }
   // ---- compaction: positions by a workgroup scan of the counts ------------------------------------------------
   u64 total64;
-  const u64 before = block_exclusive_sum_nw<NW>((u64)__popc(new16), s_scan, &total64);
+  const u64 before = block_exclusive_sum_lean<NW>((u64)__popc(new16), s_scan, &total64);
   const int total = (int)total64;
   if (total == 0) return;
   if (threadIdx.x == 0) atomicAdd(&c->reached, (u64)total);
 
-  u64* const cur_s = &c->cursor[(level + 1) % 3];
-  u64* const cur_l = &c->lcursor[(level + 1) % 3];
-  u32* __restrict__ const out_row_s = a.fr_row[(level + 1) & 1];
-  u32* __restrict__ const out_off_s = a.fr_off[(level + 1) & 1];
-  u32* __restrict__ const out_row_l = a.lq_row[(level + 1) & 1];
-  u32* __restrict__ const out_off_l = a.lq_off[(level + 1) & 1];
+  u64* const cur_s = &c->cursor[(slot + 1) % 3];
+  u64* const cur_l = &c->lcursor[(slot + 1) % 3];
+  u32* __restrict__ const out_row_s = a.fr_row[(slot + 1) & 1];
+  u32* __restrict__ const out_off_s = a.fr_off[(slot + 1) & 1];
+  u32* __restrict__ const out_row_l = a.lq_row[(slot + 1) & 1];
+  u32* __restrict__ const out_off_l = a.lq_off[(slot + 1) & 1];
 
   for (int first = 0; first < total; first += LIST) {
     // my discoveries whose list position falls into [first, first + LIST)
@@ -362,12 +386,12 @@ __global__ __launch_bounds__(NT) void k_bfs_build(bfs_fused_args_t a, int level,
     long_true = wave_sum(long_true);
     if ((threadIdx.x & (WAVE - 1)) == 0 && long_true) atomicAdd(&s_long_edges, long_true);
     u64 tot_s, tot_l;
-    const u64 ex_s = block_exclusive_sum_nw<NW>(sum_s, s_scan, &tot_s);
-    const u64 ex_l = block_exclusive_sum_nw<NW>(sum_l, s_scan, &tot_l);
+    const u64 ex_s = block_exclusive_sum_lean<NW>(sum_s, s_scan, &tot_s);
+    const u64 ex_l = block_exclusive_sum_lean<NW>(sum_l, s_scan, &tot_l);
     if (threadIdx.x == 0) {
       s_base[0] = (tot_s >> 40) ? atomicAdd(cur_s, ((tot_s >> 40) << BFS_VSHIFT) | (tot_s & DEGMASK)) : 0ull;
       s_base[1] = (tot_l >> 40) ? atomicAdd(cur_l, ((tot_l >> 40) << BFS_VSHIFT) | (tot_l & DEGMASK)) : 0ull;
-      if (tot_l >> 40) atomicAdd(&c->ledges[(level + 1) % 3], (u64)s_long_edges);     // (complete: two barriers ago)
+      if (tot_l >> 40) atomicAdd(&c->ledges[(slot + 1) % 3], (u64)s_long_edges);     // (complete: two barriers ago)
     }
     __syncthreads();
 #pragma unroll
@@ -399,15 +423,14 @@ struct bfs_fused_state_t {
   mem_t<bfs_ctrl_t> ctrl;
   bfs_ctrl_t* host_ctrl = nullptr;   // pinned copy for stats
   int n = 0;
-  int levels_per_sync = 2;           // slots (see bfs_fused_run.hpp) launched between two read-backs of the control block ...
-  int slots_hint = 6;                // ... except for the first batch: as many slots as the previous traversal needed
-  int levels_hint = 8;               // the same for the direct scheme (bfs_fused_run.hpp): levels of the previous traversal + 1
-  bool direct_levels = true;         // scheme of the next top-down traversal: direct unless the previous one was deep
-  int direct_max_levels = 32;
+  int levels_per_sync = 2;           // slots (bfs_fused_run.hpp) launched between two read-backs of the control block ...
+  int slots_hint = 5;                // ... except for the first batch: as many slots as the previous traversal needed
+  int slots_used = 0;                // slots the last run launched
   bool time_batches = false;         // HIP events around every batch of launches (-> level_kernel_ms; ~6 us each)
-  unsigned small_max_edges = 256;    // levels up to this size run inside the single-workgroup kernel (0: never);
-                                     // measured on RMAT-22: beyond a few hundred edges one workgroup's dependent
-                                     // round trips cost more than the four launches of a device-wide level
+  unsigned chain_max_edges = 6144;   // levels up to this size (and BFS_CHAIN_CAP) run inside block 0 of the push launch,
+                                     // chained with the small levels behind them (bfs_fused_chain.hpp; 0: never)
+  unsigned dense_div = 16;           // long rows are read from the unit blocks when the frontier holds at least
+                                     // 1 / dense_div of the units (bfs_fused_dense.hpp; 0: never)
   int long_min = 64;                 // rows at least this long go to the long-row queue (0: no such queue)
   bool count_marks = false;          // see bfs_fused_args_t::count_marks (MGX_BFS_COUNT_MARKS; on with time_kernels)
   bool time_kernels = false;         // record HIP events around the two push kernels of every level (each event
@@ -454,7 +477,6 @@ struct bfs_fused_state_t {
     if (const char* e = getenv("MGX_BFS_TIME_BATCHES")) time_batches = atoi(e) != 0;
     if (const char* e = getenv("MGX_BFS_HOT_MIN_EDGES")) hot_min_edges = (unsigned)atoll(e);
     if (const char* e = getenv("MGX_BFS_LEVELS_PER_SYNC")) levels_per_sync = atoi(e) > 0 ? atoi(e) : 2;
-    if (const char* e = getenv("MGX_BFS_SMALL_MAX_EDGES")) small_max_edges = (unsigned)atoll(e);
   }
   bfs_fused_state_t(const bfs_fused_state_t&) = delete;
   bfs_fused_state_t& operator=(const bfs_fused_state_t&) = delete;

@@ -1,0 +1,254 @@
+// mgx/bfs_fused_chain.hpp -- the levels that are too small for a device-wide pass, run by ONE workgroup of the push
+// launch, back to back.
+//
+// A traversal of a skewed graph has 2-3 levels that carry the work and 4-5 that hold a handful of vertices (the source's
+// neighbourhood at the start, the stragglers at the end).  Device-wide, such a level costs a push launch over 1024
+// workgroups and a sweep over n marks whatever its size: ~20 us for 30 edges, and RMAT-22 has four of them (~80 of
+// 450 us).  Here the push launch looks at the level first (every workgroup reads the same stable sizes,
+// bfs_level_is_chained): a level of at most BFS_CHAIN_CAP edges is expanded by block 0 alone, which then keeps going with
+// the levels behind it as long as they are small too -- no launch, no sweep and no cross-workgroup hand-off between them
+// (one workgroup sees its own writes).  The other workgroups return at once.
+//
+//   stage in   the slot's two global queues -> ONE list in LDS: (row start, exclusive scan of TRUE degrees)
+//   per level  bookkeeping (one thread); load-balanced search per edge rank in LDS; visited test + atomicOr claim on the
+//              live bitmap (a few thousand device atomics at most: cheap at this size, and the winner is known at once);
+//              winners -> labels, row extents, workgroup scan -> the next level's list, again in LDS
+//   stage out  when the next level is big (or the chain limit is reached): its list -> the two global queues of the next
+//              slot (long rows with offsets in padded units, bfs_lq_*), cursors, slot_level[s + 1]; skip_build[s] tells
+//              the slot's k_bfs_build that there is nothing to sweep.
+//
+// What the other workgroups of the launch (which may start late) base their decision on -- ring entry s % 3, slot_level[s]
+// -- is never written here: the chain keeps its sizes in LDS and publishes only into the NEXT slot's entries.
+// Direction-optimising runs keep every level device-wide (the bottom-up kernel needs the frontier bitmap of k_bfs_build).
+#pragma once
+#include "bfs_fused.hpp"
+
+namespace mgx {
+
+constexpr int BFS_CHAIN_NT = 1024;
+constexpr int BFS_CHAIN_CAP = 6144;          // edges (>= winners >= rows of the next level) of a chained level
+constexpr int BFS_CHAIN_EPT = 2;             // edge ranks per thread in flight
+constexpr size_t bfs_chain_lds_bytes() {
+  return (size_t)(BFS_CHAIN_NT / 64 + 2) * 8 + (size_t)(3 * BFS_CHAIN_CAP + 4) * 4 + 64;
+}
+
+// grid-uniform: sizes of ring entry slot % 3 (complete since the previous launch)
+__device__ __forceinline__ bool bfs_level_is_chained(const bfs_fused_args_t& a, u64 cur, u64 lcur, u64 ledges) {
+  if (a.mode != 0 || a.chain_max_edges == 0u) return false;
+  const u64 nf = (cur >> BFS_VSHIFT) + (lcur >> BFS_VSHIFT);
+  const u64 E = (cur & BFS_EMASK) + ledges;
+  const u64 cap = a.chain_max_edges < (u32)BFS_CHAIN_CAP ? a.chain_max_edges : (u32)BFS_CHAIN_CAP;
+  return nf <= (u64)BFS_CHAIN_CAP && E <= cap;
+}
+
+// Runs level `level` of slot `slot` and the small levels behind it.  Whole workgroup (NT threads).
+template <int NT>
+__device__ __forceinline__ void bfs_chain_body(const bfs_fused_args_t& a, int slot, int level) {
+  constexpr int NW = NT / WAVE;
+  constexpr int CAP = BFS_CHAIN_CAP;
+  constexpr int EPT = BFS_CHAIN_EPT;
+  constexpr u64 CNT1 = 1ull << 40;
+  constexpr u64 DEGMASK = CNT1 - 1ull;
+  static_assert(CAP % NT == 0, "chain list shape");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u64* const s_scan = (u64*)smem;                      // NW + 1
+  u32* const s_off = (u32*)(s_scan + NW + 2);          // CAP + 2: exclusive scan of true degrees, s_off[nf] = E
+  u32* const s_row = s_off + CAP + 2;                  // CAP
+  u32* const s_win = s_row + CAP;                      // CAP: vertices claimed in the level being expanded
+  int* const s_i = (int*)(s_win + CAP);                // [0] winners
+  bfs_ctrl_t* const c = a.ctrl;
+  const int lane = lane_id();
+  const u32 long_min = a.long_min > 0 ? (u32)a.long_min : 0xFFFFFFFFu;
+  const u32 max_e = a.chain_max_edges < (u32)CAP ? a.chain_max_edges : (u32)CAP;
+
+  // ---- stage in: the slot's two queues as one list (long rows first) ---------------------------------------------
+  int nf;
+  u32 E;
+  {
+    const u64 cur = c->cursor[slot % 3], lcur = c->lcursor[slot % 3];
+    const int nf_l = (int)(lcur >> BFS_VSHIFT), nf_s = (int)(cur >> BFS_VSHIFT);
+    const u32 El = (u32)(lcur & BFS_EMASK), Es = (u32)(cur & BFS_EMASK);
+    const u32* __restrict__ lq_row = a.lq_row[slot & 1];
+    const u32* __restrict__ lq_off = a.lq_off[slot & 1];
+    const u32* __restrict__ fr_row = a.fr_row[slot & 1];
+    const u32* __restrict__ fr_off = a.fr_off[slot & 1];
+    nf = nf_l + nf_s;
+    u64 run = 0;                       // edges of the list so far (rounds of NT entries: no per-thread arrays, this
+                                       // body shares its launch's 64-register budget with the streaming bodies)
+    for (int first = 0; first < nf; first += NT) {
+      const int i = first + threadIdx.x;
+      u32 row = 0, deg = 0;
+      if (i < nf_l) {
+        const u32 e0 = lq_off[i], e1 = (i + 1 < nf_l) ? lq_off[i + 1] : El;
+        row = lq_row[i];
+        deg = bfs_lq_degree(e0, e1);
+      } else if (i < nf) {
+        const int j = i - nf_l;
+        const u32 e0 = fr_off[j], e1 = (j + 1 < nf_s) ? fr_off[j + 1] : Es;
+        row = fr_row[j];
+        deg = e1 - e0;
+      }
+      u64 tot;
+      const u64 ex = run + block_exclusive_sum_lean<NW>((u64)deg, s_scan, &tot);
+      if (i < nf) { s_row[i] = row; s_off[i] = (u32)ex; }
+      run += tot;
+    }
+    E = (u32)run;
+    if (threadIdx.x == 0) s_off[nf] = E;
+  }
+
+  for (int chained = 0;; ++chained) {
+    if (threadIdx.x == 0) {
+      // the level's bookkeeping (what bfs_open_level does for a device-wide level)
+      if (level < 64) c->stamp[level] = __builtin_amdgcn_s_memrealtime();
+      if (level < BFS_MAX_TRACE) c->trace[level] = ((u64)nf << BFS_VSHIFT) | (u64)E;
+      c->sum_edges += (u64)E;
+      c->sum_frontier += (u64)nf;
+      c->push_levels += 1;
+      c->small_levels += 1;
+      if (chained == 0) c->slots += 1;
+      s_i[0] = 0;
+    }
+    __syncthreads();
+
+    // ---- expand: load-balanced search per edge rank, claim on the live bitmap --------------------------------------
+    {
+      int top = 1;
+      while (top * 2 < nf) top *= 2;
+      for (u32 base = 0; base < E; base += NT * EPT) {
+        u32 r[EPT];
+        int sj[EPT];
+        bool act[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+          r[k] = base + (u32)(k * NT) + threadIdx.x;
+          act[k] = r[k] < E;
+          if (!act[k]) r[k] = 0;
+          sj[k] = 0;
+        }
+        if (nf > 1)
+          for (int step = top; step > 0; step >>= 1) {
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+              const int j = sj[k] + step;
+              if (j < nf && s_off[j] <= r[k]) sj[k] = j;
+            }
+          }
+        int d[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) d[k] = a.col_indices[act[k] ? s_row[sj[k]] + (r[k] - s_off[sj[k]]) : 0u];
+        u32 word[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) word[k] = a.visited[(u32)d[k] >> 5];     // (a stale word only costs an atomic)
+        u32 old[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+          const u32 bit = 1u << (d[k] & 31);
+          old[k] = 0xFFFFFFFFu;
+          if (act[k] && !(word[k] & bit)) old[k] = atomicOr(a.visited + ((u32)d[k] >> 5), bit);
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+          const bool win = !(old[k] & (1u << (d[k] & 31)));
+          const u64 bal = __ballot(win);
+          if (bal) {
+            int at = 0;
+            if (lane == 0) at = atomicAdd(&s_i[0], __popcll(bal));
+            at = __builtin_amdgcn_readfirstlane(at);
+            if (win) s_win[at + rank_in_mask(bal)] = (u32)d[k];
+          }
+        }
+      }
+    }
+    __syncthreads();                    // winners complete; the list in s_off / s_row is dead from here
+
+    // ---- winners -> labels, the next level's list (in place of the old one) ---------------------------------------
+    const int W = s_i[0];               // <= E <= CAP
+    const int new_label = level + 1;
+    u64 run = 0;                        // (count << 40 | edges) of the list so far
+    for (int first = 0; first < W; first += 2 * NT) {
+      u32 ro[2], dg[2];
+      u64 mine = 0;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int i = first + threadIdx.x * 2 + q;
+        ro[q] = 0; dg[q] = 0;
+        if (i < W) {
+          const u32 v = s_win[i];
+          const bfs_u32x2 ext = *(const bfs_u32x2*)(a.row_offsets + v);
+          ro[q] = ext.x;
+          dg[q] = ext.y - ext.x;
+          a.labels[a.old_of_new ? a.old_of_new[v] : (int)v] = new_label;
+        }
+        if (dg[q]) mine += CNT1 | (u64)dg[q];
+      }
+      u64 tot;
+      u64 ex = run + block_exclusive_sum_lean<NW>(mine, s_scan, &tot);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (dg[q]) {
+          s_row[ex >> 40] = ro[q];
+          s_off[ex >> 40] = (u32)(ex & DEGMASK);
+          ex += CNT1 | (u64)dg[q];
+        }
+      }
+      run += tot;
+    }
+    const int nf2 = (int)(run >> 40);
+    const u32 E2 = (u32)(run & DEGMASK);          // (a level reached from <= CAP edges: far below 2^32)
+    if (threadIdx.x == 0) {
+      s_off[nf2] = E2;
+      c->reached += (u64)W;
+      if (a.count_marks) { c->claims += (u64)W; if (level < 64) c->claims_level[level] += (u64)W; }
+    }
+    __syncthreads();
+
+    if (nf2 != 0 && (run & DEGMASK) <= (u64)max_e) {     // the next level is small too: keep going
+      nf = nf2;
+      E = E2;
+      level += 1;
+      continue;
+    }
+
+    // ---- stage out: the next level's list -> the global queues of slot + 1 ----------------------------------------
+    u32* __restrict__ const out_row_s = a.fr_row[(slot + 1) & 1];
+    u32* __restrict__ const out_off_s = a.fr_off[(slot + 1) & 1];
+    u32* __restrict__ const out_row_l = a.lq_row[(slot + 1) & 1];
+    u32* __restrict__ const out_off_l = a.lq_off[(slot + 1) & 1];
+    u64 tot_s = 0, tot_l = 0, tot_true = 0;        // (count << 40 | edges) of the two queues so far; true edges of the long one
+    for (int first = 0; first < nf2; first += NT) {
+      const int i = first + threadIdx.x;
+      u32 ro = 0, dg = 0;
+      if (i < nf2) { ro = s_row[i]; dg = s_off[i + 1] - s_off[i]; }
+      const bool is_long = dg >= long_min;
+      const u64 add_s = (!is_long && dg) ? (CNT1 | (u64)dg) : 0ull;
+      const u64 add_l = is_long ? (CNT1 | (u64)bfs_lq_pad(dg)) : 0ull;
+      u64 ts, tl, tt;
+      const u64 ex_s = tot_s + block_exclusive_sum_lean<NW>(add_s, s_scan, &ts);
+      const u64 ex_l = tot_l + block_exclusive_sum_lean<NW>(add_l, s_scan, &tl);
+      (void)block_exclusive_sum_lean<NW>(is_long ? (u64)dg : 0ull, s_scan, &tt);
+      if (is_long) {
+        out_row_l[ex_l >> 40] = ro;
+        out_off_l[ex_l >> 40] = (u32)(ex_l & DEGMASK) | (dg & 63u);
+      } else if (dg) {
+        out_row_s[ex_s >> 40] = ro;
+        out_off_s[ex_s >> 40] = (u32)(ex_s & DEGMASK);
+      }
+      tot_s += ts; tot_l += tl; tot_true += tt;
+    }
+    if (threadIdx.x == 0) {
+      c->cursor[(slot + 1) % 3] = ((tot_s >> 40) << BFS_VSHIFT) | (tot_s & DEGMASK);
+      c->lcursor[(slot + 1) % 3] = ((tot_l >> 40) << BFS_VSHIFT) | (tot_l & DEGMASK);
+      c->ledges[(slot + 1) % 3] = tot_true;
+      c->cursor[(slot + 2) % 3] = 0;
+      c->lcursor[(slot + 2) % 3] = 0;
+      c->ledges[(slot + 2) % 3] = 0;
+      c->slot_level[(slot + 1) & 3] = level + 1;
+      c->skip_build[slot & 3] = 1;
+      if (nf2 == 0 && !c->done) { c->done = 1; c->levels = level + 1; }
+    }
+    return;
+  }
+}
+
+}  // namespace mgx

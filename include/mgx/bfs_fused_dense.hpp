@@ -1,0 +1,176 @@
+// mgx/bfs_fused_dense.hpp -- push over the LONG rows of a level read from the graph's UNIT BLOCKS.
+//
+// bfs_fused_stream.hpp walks the level's long-row queue: per 64-edge sub-round ~20 scalar instructions of (row,
+// position) bookkeeping, ~16 vector ones, a 4-byte-per-lane load whose address depends on the walk -- and the level
+// that carries a skewed graph's work (RMAT-22: 116 M of 134 M edges) has nearly ALL long rows in its frontier (89 % of
+// their edges), mid-degree ones, a few sub-rounds each, so the walk never amortises.  Here nothing is walked:
+//
+//   * the long rows live a second time as unit blocks (mgx_layout.hip): every row padded to a multiple of 64 entries
+//     (padding repeats the row's first neighbour), so a UNIT of 64 consecutive entries belongs to exactly one row,
+//     owner[u] says which;
+//   * a wave takes groups of 16 consecutive units (4 KB of entries), interleaved over all waves of the grid -- equal
+//     shares whatever the frontier looks like (a level of a few thousand hubs activates one contiguous stretch of units);
+//   * per batch of 4 groups: one coalesced load of 64 owners, one gather of their frontier bits (k_bfs_build leaves the
+//     level's frontier as a bitmap), one ballot -> the 64 activity bits of the batch in two SGPRs.  Issued a batch
+//     ahead: the two dependent loads never stall the stream;
+//   * the entries are read 16 bytes per lane (1 KB per wave instruction, 4 units), four instructions per stage, two
+//     stages in flight; lanes of inactive units read the four -1 behind the blocks instead (one cached line, no HBM
+//     traffic, no branch, and the load count stays static for hipcc's s_waitcnt bookkeeping);
+//   * visited test per entry: 3 VALU + one LDS read + 2 VALU on the fast path -- the LDS bitmap has a word of ones in
+//     front (-1 entries read as visited) and a word of zeros behind (vertices outside the prefix read as unvisited), so
+//     one clamp replaces the range checks; a miss claims the bit in LDS (exact intra-workgroup dedup) and stores
+//     mark[v] = 1 as everywhere else.
+//
+// Chosen per slot and by every workgroup alike (bfs_long_is_dense): the frontier bitmap must describe this slot's
+// frontier (ctrl->fb_slot) and the frontier must hold at least 1 / dense_div of the units; otherwise the queue walk of
+// bfs_fused_stream.hpp runs.  Labels are the same either way: both mark exactly the unvisited neighbours of the
+// frontier's long rows.
+#pragma once
+#include "bfs_fused.hpp"
+
+namespace mgx {
+
+typedef unsigned int bfs_u32x4 __attribute__((ext_vector_type(4)));   // (a builtin vector: __builtin_nontemporal_load wants one)
+
+constexpr int BFS_DENSE_GROUP = 16;                 // units per group (the unit of interleaving)
+constexpr size_t bfs_dense_lds_bytes(int hotw) { return (size_t)hotw * 4 + 128; }
+
+// the slot's long rows are read from the unit blocks (grid-uniform: every workgroup sees the same stable inputs)
+__device__ __forceinline__ bool bfs_long_is_dense(const bfs_fused_args_t& a, const bfs_ctrl_t* c, int slot, u64 lcur) {
+  if (!a.ub_col || a.dense_div == 0u || c->fb_slot != slot) return false;
+  const u64 units = (lcur & BFS_EMASK) >> 6;        // the long-row queue's offsets count padded edges: 64 per unit
+  return units * (u64)a.dense_div >= (u64)a.ub_units;
+}
+
+template <int NT, int HOTW>
+__device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int slot, u32 block, u32 nblocks, int stat_level) {
+  constexpr int NW = NT / WAVE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [0..3] word of ones at hot[-1] (index 3), hot[0..HOTW), hot[HOTW] = 0
+  u32* const hot = (u32*)smem + 4;
+  int* const s_int = (int*)(hot + HOTW + 4);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+  const int lane = lane_id();
+  bfs_ctrl_t* const c = a.ctrl;
+
+  const u32* __restrict__ vis = a.visited;
+  unsigned char* __restrict__ mark = a.mark;
+  const int* __restrict__ ucol = a.ub_col;
+  const int* __restrict__ owner = a.ub_owner;
+  const u32* __restrict__ fbits = a.frontier_bits;
+
+  const u32 hot_n = ((u32)a.n < (u32)(HOTW * 32)) ? (u32)a.n : (u32)(HOTW * 32);
+  {
+    const uint4* src = (const uint4*)vis;
+    uint4* dstp = (uint4*)hot;
+    for (int i = threadIdx.x; i < HOTW / 4; i += NT) dstp[i] = src[i];
+    if (threadIdx.x == 0) { hot[-1] = 0xFFFFFFFFu; hot[HOTW] = 0u; s_int[0] = 0; }
+  }
+  __syncthreads();
+
+  const u32 G = a.ub_units_pad / BFS_DENSE_GROUP;              // groups of 16 units
+  const u32 W = nblocks * NW;                                  // waves of the grid
+  const u32 w = block * NW + (u32)wave;
+  const u32 dummy = a.ub_units_pad << 6;                       // entry index of the four -1
+  const u32 lane_unit = (u32)lane & 15u;                       // my unit inside its group, for the owner load ...
+  const u32 lane_grp = (u32)lane >> 4;                         // ... and which of the batch's 4 groups
+  const u32 lane_q = (u32)lane >> 4;                           // col loads: lane l reads entries 4l..4l+3 of a 256-entry chunk = unit l >> 4 of the chunk
+  int marks = 0;
+  const int diag = a.dense_diag;     // MGX_BFS_DENSE_DIAG (measurements; results are wrong by design): 1 no mark stores, 2 no test
+
+  // batch b of this wave: groups w + (4 b + k) W, k = 0..3
+  const u32 nbatch = (w < G) ? ((G - w + W - 1) / W + 3) / 4 : 0u;
+  if (nbatch != 0u) {
+    auto load_owner = [&](u32 b) -> u32 {
+      const u32 g = w + (4u * b + lane_grp) * W;
+      const u32 u = (g < G ? g : G - 1u) * BFS_DENSE_GROUP + lane_unit;
+      const u32 o = (u32)owner[u];
+      return g < G ? o : (u32)a.n;                             // vertex n: never in a frontier (its bit exists and stays 0)
+    };
+    auto gather_bits = [&](u32 own) -> u32 { return fbits[own >> 5]; };
+    // entry index of the first entry of group k of batch b
+    auto group_base = [&](u32 b, u32 k) -> u32 {
+      const u32 g = w + (4u * b + k) * W;
+      return (g < G ? g : 0u) * (BFS_DENSE_GROUP * 64u);
+    };
+
+    bfs_u32x4 dL[4], dT[4];
+    // issue the four 16-byte loads of group k of a batch whose activity bits are `act`
+    auto issue = [&](u32 b, u32 k, u64 act) {
+      const u32 base = group_base(b, k);
+      const u32 bits16 = (u32)(act >> (16u * k)) & 0xFFFFu;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool on = (bits16 >> (4u * j + lane_q)) & 1u;
+        const u32 e = on ? base + (u32)j * 256u + (u32)lane * 4u : dummy;
+        dL[j] = __builtin_nontemporal_load((const bfs_u32x4*)(ucol + e));
+      }
+    };
+    auto probe = [&](u32 d) -> u32 {
+      int idx = (int)d >> 5;
+      idx = idx < -1 ? -1 : idx;
+      idx = idx > HOTW ? HOTW : idx;
+      return hot[idx];
+    };
+    auto decide = [&](u32 d, u32 wd) {
+      if (!((wd >> (d & 31u)) & 1u)) {
+        const u32 bit = 1u << (d & 31u);
+        bool is_new = true;
+        if (d < hot_n) is_new = !(atomicOr(&hot[d >> 5], bit) & bit);
+        if (is_new) { if (!(diag & 1)) mark[d] = 1; ++marks; }
+      }
+    };
+    // four LDS probes in flight, then the four decisions (a probe that waits for its own result before the next one
+    // is issued leaves the LDS pipe idle: 16 dependent round trips per stage)
+    auto test = [&]() {
+      if (diag & 2) {                  // measurement only: consume the loads, test nothing
+#pragma unroll
+        for (int j = 0; j < 4; ++j) marks += (int)((dT[j].x ^ dT[j].y ^ dT[j].z ^ dT[j].w) == 0x12345678u);
+        return;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 w0 = probe(dT[j].x), w1 = probe(dT[j].y), w2 = probe(dT[j].z), w3 = probe(dT[j].w);
+        decide(dT[j].x, w0); decide(dT[j].y, w1); decide(dT[j].z, w2); decide(dT[j].w, w3);
+      }
+    };
+
+    u32 own_next = load_owner(0);
+    u64 act;
+    {
+      const u32 fw = gather_bits(own_next);
+      act = __ballot((fw >> (own_next & 31u)) & 1u);
+    }
+    own_next = load_owner(1);
+    issue(0, 0, act);
+    for (u32 b = 0; b < nbatch; ++b) {
+      // activity of batch b + 1: its owners were loaded a batch ago
+      const u32 own_cur = own_next;
+      const u32 fw = gather_bits(own_cur);
+      own_next = load_owner(b + 2);
+#pragma unroll
+      for (u32 k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dT[j] = dL[j];
+        if (k < 3) {
+          issue(b, k + 1, act);
+        } else {
+          act = __ballot((fw >> (own_cur & 31u)) & 1u);
+          issue(b + 1, 0, act);          // (past the last batch: all owners are n, every lane reads the -1s)
+        }
+        test();
+      }
+    }
+  }
+  if (a.count_marks) {
+    marks = wave_sum(marks);
+    if (lane == 0 && marks) atomicAdd(&s_int[0], marks);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_int[0]) {
+      atomicAdd(&c->claims, (u64)s_int[0]);
+      if (stat_level < 64) atomicAdd(&c->claims_level[stat_level], (u64)s_int[0]);
+    }
+  }
+}
+
+}  // namespace mgx

@@ -9,11 +9,10 @@
 namespace mgx {
 
 template <int NT>
-__global__ __launch_bounds__(NT) void k_bfs_pull_level(bfs_fused_args_t a, int level) {
+__global__ __launch_bounds__(NT) void k_bfs_pull_level(bfs_fused_args_t a, int arg) {
   __shared__ unsigned long long s_insp;
   bfs_ctrl_t* const c = a.ctrl;
-  if (!bfs_resolve_level(c, level)) return;
-  if (c->done || !c->pull) return;                 // k_bfs_level_begin: termination and direction
+  if (c->done || !c->pull) return;                 // the level's opener (push launch): termination and direction
   const int n = a.n;
   long long per_v = ((long long)n + gridDim.x - 1) / gridDim.x;
   per_v = (per_v + NT - 1) / NT * NT;

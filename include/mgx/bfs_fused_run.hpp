@@ -1,70 +1,158 @@
-// mgx/bfs_fused_run.hpp -- host driver of the fused BFS.  One init kernel, then per level
-//   k_bfs_push_level (long rows streamed + short rows searched, one grid)  [-> k_bfs_pull_level]  -> k_bfs_build
-// launched back to back for as many levels as the previous traversal of the graph had; the host reads the control
-// block back once per batch.  Two launch schemes (see bfs_fused_run): "direct" with the level number as a kernel
-// argument, and "slots" with k_bfs_small_levels in front of every level and the level counter on the device.
+// mgx/bfs_fused_run.hpp -- host driver of the fused BFS.  One init kernel, then per launch SLOT
+//   k_bfs_push (long rows: unit blocks or queue walk | short rows searched | or: block 0 runs a chain of small levels)
+//   [-> k_bfs_pull_level]  -> k_bfs_build
+// enqueued back to back for as many slots as the previous traversal of the graph needed; the host reads the control
+// block back once per batch.  A slot works on the level ctrl->slot_level[slot & 3]: one device-wide level, or -- when
+// the level is small -- that level and every small level behind it, inside block 0 of the push launch
+// (bfs_fused_chain.hpp; k_bfs_build then returns at once).  RMAT-22: init + 5 slots instead of init + 7 levels x 2.
+// The partitioned path (bfs_dist2.hpp) drives the same kernel bodies with explicit level numbers (k_bfs_push_level).
 #pragma once
 #include "bfs_fused.hpp"
+#include "bfs_fused_chain.hpp"
+#include "bfs_fused_dense.hpp"
 #include "bfs_fused_pull.hpp"
-#include "bfs_fused_small.hpp"
 #include "bfs_fused_stream.hpp"
 #include "bfs_fused_wave.hpp"
 
 namespace mgx {
 
 // layout (optional): a hub-first relabelled copy of the CSR plus the two id maps; labels stay in the
-// original id space either way.
+// original id space either way.  Unit blocks (optional, of the same CSR): see bfs_fused_dense.hpp.
 struct bfs_layout_t {
   const int* row_offsets = nullptr;
   const int* col_indices = nullptr;
   const int* new_of_old = nullptr;
   const int* old_of_new = nullptr;
+  const int* ub_col = nullptr;
+  const int* ub_owner = nullptr;
+  long long ub_units = 0, ub_units_pad = 0;
+  int ub_min_degree = 0;            // the rows the unit blocks hold: degree >= this (must equal the long-row threshold)
 };
 
-// Template instances of the two push kernels.  cold_test: probe the bitmap word of neighbours outside the LDS
-// prefix (big graphs: many cold endpoints) or mark them untested (k_bfs_build tests the bitmap anyway).
 constexpr int BFS_STREAM_HOTW2 = 20400;   // two workgroups per CU: 80 KB of bitmap each
+constexpr int BFS_WAVE_HOTW = 18000;
+constexpr int BFS_DENSE_HOTW = BFS_STREAM_HOTW2 - 16;   // (the dense body's two sentinel words fit the same 81 664 bytes)
 
-// Both push kernels of a level in ONE launch: the first `nstream` workgroups run the streaming body over the
-// long-row queue, the others the wave body over the short-row queue (default shapes of the two kernels above).
-// Saves a launch per level (~6 us of device time each, measured) and lets the short rows start while the last
-// slices of the long rows drain.  Profiling runs (bfs_fused_state_t::time_kernels) launch the two kernels
-// separately so that each can be bracketed by events.
-// open_here (direct scheme, see bfs_fused_run: explicit level numbers, no k_bfs_small_levels in front; 2: a rank of a
-// partitioned run): the level's bookkeeping is done by one thread of this grid.  Nothing it writes is read by the level's own kernels in a
-// top-down run: they take the queue sizes from the cursors, which the previous level's k_bfs_build completed.
+constexpr size_t bfs_push_lds_bytes() {
+  size_t m = bfs_stream_lds_bytes(BFS_STREAM_HOTW2);
+  if (bfs_wave_lds_bytes(1024, BFS_WAVE_HOTW) > m) m = bfs_wave_lds_bytes(1024, BFS_WAVE_HOTW);
+  if (bfs_dense_lds_bytes(BFS_DENSE_HOTW) > m) m = bfs_dense_lds_bytes(BFS_DENSE_HOTW);
+  if (bfs_chain_lds_bytes() > m) m = bfs_chain_lds_bytes();
+  return m;
+}
+
+// what a slot's push launch does, derived by every workgroup from the same stable inputs
+struct bfs_slot_plan_t {
+  int slot, level;
+  bool empty, chained, dense;
+};
+__device__ __forceinline__ bfs_slot_plan_t bfs_slot_plan(const bfs_fused_args_t& a, int arg) {
+  const bfs_ctrl_t* const c = a.ctrl;
+  bfs_slot_plan_t p;
+  bfs_resolve(c, arg, p.slot, p.level);
+  const u64 cur = c->cursor[p.slot % 3], lcur = c->lcursor[p.slot % 3], ledges = c->ledges[p.slot % 3];
+  p.empty = ((cur | lcur) >> BFS_VSHIFT) == 0 || c->done;
+  p.chained = !p.empty && bfs_level_is_chained(a, cur, lcur, ledges);
+  p.dense = !p.empty && !p.chained && bfs_long_is_dense(a, c, p.slot, lcur) && !bfs_level_pulls(a, c, p.slot);
+  return p;
+}
+
+// The opener of a device-wide level (one thread of the push launch): the level's bookkeeping, and the next slot's level.
+// Nothing it writes is read by the slot's own push kernels: they take the queue sizes from the ring entry of the
+// slot, which the previous launch completed.
+__device__ __forceinline__ void bfs_slot_open(const bfs_fused_args_t& a, const bfs_slot_plan_t& p) {
+  bfs_ctrl_t* const c = a.ctrl;
+  if (c->done) return;
+  if (!bfs_open_level(a, p.level, p.slot)) return;  // (an empty frontier: done = 1, levels = level)
+  c->slots += 1;
+  c->slot_level[(p.slot + 1) & 3] = p.level + 1;
+  c->skip_build[p.slot & 3] = 0;
+  if (p.dense) c->dense_slots += 1;
+}
+
+// Push of one slot, ONE launch: block 0 opens the level (or runs the chain of small levels and everybody else
+// returns); the first `nstream` workgroups take the long rows -- from the unit blocks or by walking the long-row queue
+// -- the others the short-row queue.  One launch per level instead of two (~6 us of device time each, measured), and
+// the short rows start while the last long-row slices drain.  Profiling runs (bfs_fused_state_t::time_kernels) launch
+// the parts separately so that each can be bracketed by events.
+// COLDT: probe the bitmap word of neighbours outside the LDS prefix (big graphs: many cold endpoints) or mark them
+// untested (k_bfs_build tests the bitmap anyway).  PART: 0 all, 1 opener / chain only, 2 long rows only, 3 short rows only.
+template <bool COLDT, int PART>
+__global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int arg, u32 nstream) {
+  const bfs_slot_plan_t p = bfs_slot_plan(a, arg);
+  if (p.chained) {
+    if ((PART == 0 || PART == 1) && blockIdx.x == 0) bfs_chain_body<1024>(a, p.slot, p.level);
+    return;
+  }
+  if ((PART == 0 || PART == 1) && blockIdx.x == 0 && threadIdx.x == 0) bfs_slot_open(a, p);
+  if (p.empty || PART == 1) return;
+  if (PART == 2 || (PART == 0 && blockIdx.x < nstream)) {
+    const u32 nb = PART == 0 ? nstream : gridDim.x;
+    if (!COLDT && p.dense) bfs_dense_body<1024, BFS_DENSE_HOTW>(a, p.slot, blockIdx.x, nb, p.level);
+    else bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, COLDT, false, true>(a, p.slot, blockIdx.x, nb, p.level);
+  } else {
+    const u32 first = PART == 0 ? nstream : 0u;
+    bfs_wave_body<1024, BFS_WAVE_HOTW, COLDT, false>(a, p.slot, blockIdx.x - first, gridDim.x - first, p.level);
+  }
+}
+
+// The instrumented stream kernel (MGX_BFS_FLAGS: parts of the body switched off for measurements; results are wrong
+// by design).  Queue walk only.
+__global__ __launch_bounds__(1024, 8) void k_bfs_push_stream_diag(bfs_fused_args_t a, int arg) {
+  const bfs_slot_plan_t p = bfs_slot_plan(a, arg);
+  if (p.empty || p.chained) return;
+  bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, false, true, true>(a, p.slot, blockIdx.x, gridDim.x, p.level);
+}
+
+// Explicit-level variant for the partitioned path (bfs_dist2.hpp): slot == level, the level's bookkeeping rides on
+// the launch (open_here == 2: a rank of a partitioned run), no chain, no unit blocks.
 template <bool COLDT>
 __global__ __launch_bounds__(1024, 8) void k_bfs_push_level(bfs_fused_args_t a, int level, u32 nstream, int open_here) {
   if (open_here && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) bfs_begin_level(a, level, open_here == 2);
-  if (blockIdx.x < nstream) bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, COLDT, false, true>(a, level, blockIdx.x, nstream);
-  else bfs_wave_body<1024, 18000, COLDT, false>(a, level, blockIdx.x - nstream, gridDim.x - nstream);
+  if (blockIdx.x < nstream) bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, COLDT, false, true>(a, level, blockIdx.x, nstream, level);
+  else bfs_wave_body<1024, BFS_WAVE_HOTW, COLDT, false>(a, level, blockIdx.x - nstream, gridDim.x - nstream, level);
 }
 
 inline void bfs_set_kernel_attributes() {
-  static bool attr_set = false;
-  if (attr_set) return;
+  static unsigned char seen[64] = {};
+  if (!first_use_on_device(seen)) return;
 #define MGX_SET_LDS(K_) MGX_HIP(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-  MGX_SET_LDS((k_bfs_small_levels<BFS_SMALL_NT>));
+  MGX_SET_LDS((k_bfs_push<false, 0>)); MGX_SET_LDS((k_bfs_push<true, 0>));
+  MGX_SET_LDS((k_bfs_push<false, 1>)); MGX_SET_LDS((k_bfs_push<true, 1>));
+  MGX_SET_LDS((k_bfs_push<false, 2>)); MGX_SET_LDS((k_bfs_push<true, 2>));
+  MGX_SET_LDS((k_bfs_push<false, 3>)); MGX_SET_LDS((k_bfs_push<true, 3>));
+  MGX_SET_LDS(k_bfs_push_stream_diag);
   MGX_SET_LDS(k_bfs_push_level<false>);
   MGX_SET_LDS(k_bfs_push_level<true>);
-  MGX_SET_LDS((k_bfs_push_level_wave<1024, 18000, false>));
-  MGX_SET_LDS((k_bfs_push_level_wave<1024, 18000, true>));
-  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, true, true>));
-  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, false, true>));
-  MGX_SET_LDS((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, true, false, true>));
 #undef MGX_SET_LDS
-  attr_set = true;
 }
 
 // -1: decide by size (cold test when the bitmap is at least 8 x the LDS prefix), 0 / 1: forced (MGX_BFS_COLD_TEST)
-inline bool bfs_cold_test(int n) {
-  const char* const e = getenv("MGX_BFS_COLD_TEST");               // (read per call: the tests switch it)
-  const int forced = e ? atoi(e) : -1;
+inline bool bfs_cold_test(int n, int forced) {
   if (forced >= 0) return forced != 0;
   return (long long)n >= 8ll * 32 * BFS_STREAM_HOTW;
 }
 
-// The two push kernels as launches of their own (profiling runs, MGX_BFS_MERGED_PUSH=0, the instrumented build).
+// Environment switches of a run, read ONCE per traversal (the tests flip them between runs), never per launch.
+struct bfs_run_opts_t {
+  int cold_test = -1;      // MGX_BFS_COLD_TEST
+  int merged = 1;          // MGX_BFS_MERGED_PUSH
+  int flags = 0;           // MGX_BFS_FLAGS (instrumented stream kernel)
+  int dense = -1;          // MGX_BFS_DENSE: 0 never, N > 0 dense_div = N (default 16)
+  long long chain = -1;    // MGX_BFS_CHAIN_MAX_EDGES: 0 never (default BFS_CHAIN_CAP)
+  int dense_diag = 0;      // MGX_BFS_DENSE_DIAG: parts of the unit-block body switched off (measurements only)
+  static bfs_run_opts_t from_env() {
+    bfs_run_opts_t o;
+    if (const char* e = getenv("MGX_BFS_COLD_TEST")) o.cold_test = atoi(e);
+    if (const char* e = getenv("MGX_BFS_MERGED_PUSH")) o.merged = atoi(e);
+    if (const char* e = getenv("MGX_BFS_FLAGS")) o.flags = atoi(e);
+    if (const char* e = getenv("MGX_BFS_DENSE")) o.dense = atoi(e);
+    if (const char* e = getenv("MGX_BFS_CHAIN_MAX_EDGES")) o.chain = atoll(e);
+    if (const char* e = getenv("MGX_BFS_DENSE_DIAG")) o.dense_diag = atoi(e);
+    return o;
+  }
+};
+
 // Shapes that were measured and dropped, RMAT-22 (stream kernel of the big level / whole BFS at the time):
 //   stream  2 workgroups x 1024 threads per CU = 32 waves, 80 KB of bitmap each, 8 non-temporal loads per lane (kept):
 //           167 us / 0.66 ms; 16 loads per lane 190 / 0.68; 1 workgroup per CU with 160 KB of bitmap 213-217 / 0.69-0.71;
@@ -73,43 +161,18 @@ inline bool bfs_cold_test(int n) {
 //           with 160 KB was 3 % faster than two with 80 KB -- not enough for a second merged shape;
 //   wave    2 x 1024 threads per CU (kept) 67 us, 2 x 512 threads with more bitmap in LDS 82 us; non-temporal loads: same;
 //   build   512 threads (kept) 0.445 ms per traversal, 256: 0.453-0.461, 1024: 0.476.
-inline void bfs_launch_stream(const bfs_fused_args_t& a, int level, standard_context_t& ctx) {
-  hipStream_t s = ctx.stream();
-  if (a.long_min <= 0) return;
-  const size_t lds2 = bfs_stream_lds_bytes(BFS_STREAM_HOTW2);
-  if (bfs_cold_test(a.n))
-    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, true, false, true>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
-  else if (a.flags)     // MGX_BFS_FLAGS set: the instrumented build
-    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, true, true>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
-  else                  // col_indices are read once: non-temporal loads leave L2 to the bitmap, marks and queues
-    hipLaunchKernelGGL((k_bfs_push_level_stream<1024, BFS_STREAM_HOTW2, 8, false, false, true>), dim3(ctx.num_cus * 2), dim3(1024), lds2, s, a, level);
+template <int PART>
+inline void bfs_launch_push_part(const bfs_fused_args_t& a, int arg, standard_context_t& ctx, bool coldt, unsigned grid, u32 nstream) {
+  if (coldt) hipLaunchKernelGGL((k_bfs_push<true, PART>), dim3(grid), dim3(1024), bfs_push_lds_bytes(), ctx.stream(), a, arg, nstream);
+  else hipLaunchKernelGGL((k_bfs_push<false, PART>), dim3(grid), dim3(1024), bfs_push_lds_bytes(), ctx.stream(), a, arg, nstream);
 }
 
-inline void bfs_launch_wave(const bfs_fused_args_t& a, int level, standard_context_t& ctx) {
-  hipStream_t s = ctx.stream();
-  const size_t lds = bfs_wave_lds_bytes(1024, 18000);
-  if (bfs_cold_test(a.n)) hipLaunchKernelGGL((k_bfs_push_level_wave<1024, 18000, true>), dim3(ctx.num_cus * 2), dim3(1024), lds, s, a, level);
-  else hipLaunchKernelGGL((k_bfs_push_level_wave<1024, 18000, false>), dim3(ctx.num_cus * 2), dim3(1024), lds, s, a, level);
-}
-
-inline void bfs_launch_push(const bfs_fused_args_t& a, int level, standard_context_t& ctx, int open_here = 0) {
-  const char* const merged_str = getenv("MGX_BFS_MERGED_PUSH");      // (read per call: the tests switch it)
-  const int merged = merged_str ? atoi(merged_str) : 1;
-  if (!merged || a.flags) {
-    if (open_here) hipLaunchKernelGGL(k_bfs_level_begin, dim3(1), dim3(64), 0, ctx.stream(), a, level, open_here == 2 ? 1 : 0);
-    bfs_launch_stream(a, level, ctx);
-    bfs_launch_wave(a, level, ctx);
-    return;
-  }
-  hipStream_t s = ctx.stream();
-  const size_t lds_s = bfs_stream_lds_bytes(BFS_STREAM_HOTW2), lds_w = bfs_wave_lds_bytes(1024, 18000);
-  const size_t lds = lds_s > lds_w ? lds_s : lds_w;
+// explicit-level push of the partitioned path
+inline void bfs_launch_push(const bfs_fused_args_t& a, int level, standard_context_t& ctx, int open_here, bool coldt) {
   const u32 nstream = a.long_min > 0 ? (u32)ctx.num_cus * 2 : 0u;
   const u32 nwave = (u32)ctx.num_cus * 2;
-  if (bfs_cold_test(a.n))
-    hipLaunchKernelGGL(k_bfs_push_level<true>, dim3(nstream + nwave), dim3(1024), lds, s, a, level, nstream, open_here);
-  else
-    hipLaunchKernelGGL(k_bfs_push_level<false>, dim3(nstream + nwave), dim3(1024), lds, s, a, level, nstream, open_here);
+  if (coldt) hipLaunchKernelGGL(k_bfs_push_level<true>, dim3(nstream + nwave), dim3(1024), bfs_push_lds_bytes(), ctx.stream(), a, level, nstream, open_here);
+  else hipLaunchKernelGGL(k_bfs_push_level<false>, dim3(nstream + nwave), dim3(1024), bfs_push_lds_bytes(), ctx.stream(), a, level, nstream, open_here);
 }
 
 // Runs a whole BFS from `src` on the context's stream.  labels[] is (re)initialised here.  Returns with the
@@ -121,6 +184,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
                           int src, standard_context_t& ctx, const bfs_layout_t* layout = nullptr, int mode = 0,
                           float alpha = 0.f, const int* in_offsets = nullptr, const int* in_indices = nullptr) {
   hipStream_t s = ctx.stream();
+  const bfs_run_opts_t opt = bfs_run_opts_t::from_env();
   bfs_fused_args_t a;
   const bool relabelled = layout && layout->row_offsets;
   a.row_offsets = (const u32*)(relabelled ? layout->row_offsets : row_offsets);
@@ -144,9 +208,20 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.hot_min_edges = st.hot_min_edges;
   a.ctrl = st.ctrl.data();
   a.n = st.n;
-  a.flags = 0;
+  a.flags = opt.flags;
   a.count_marks = (st.count_marks || st.time_kernels) ? 1 : 0;
-  if (const char* e = getenv("MGX_BFS_FLAGS")) a.flags = atoi(e);
+  const bool coldt = bfs_cold_test(a.n, opt.cold_test);
+  // unit blocks: only for the CSR they were built from, with the long-row threshold they were built for, and not on
+  // graphs whose cold neighbours are probed (the dense body marks them untested)
+  const bool units = relabelled && layout->ub_col && layout->ub_units > 0 && layout->ub_min_degree == st.long_min &&
+                     st.long_min > 0 && !coldt && !opt.flags;
+  a.ub_col = units ? layout->ub_col : nullptr;
+  a.ub_owner = units ? layout->ub_owner : nullptr;
+  a.ub_units = units ? (u32)layout->ub_units : 0u;
+  a.ub_units_pad = units ? (u32)layout->ub_units_pad : 0u;
+  a.dense_div = !units ? 0u : (opt.dense >= 0 ? (u32)opt.dense : st.dense_div);
+  a.dense_diag = opt.dense_diag;
+  a.chain_max_edges = mode != 0 ? 0u : (opt.chain >= 0 ? (u32)(opt.chain > BFS_CHAIN_CAP ? BFS_CHAIN_CAP : opt.chain) : st.chain_max_edges);
   const long long nwords = ((long long)st.n + 31) / 32;
   hipLaunchKernelGGL(k_bfs_fused_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src, nwords);
   st.level_kernel_ms = 0.0;
@@ -156,47 +231,39 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   st.stream_kernel_ms = 0.0;
   st.stream_kernel_launches = 0;
   st.batches = 0;
-  // Two launch schemes.
-  //   slots  [k_bfs_small_levels, push, (pull), build] with the level counter on the device: the single-workgroup
-  //          kernel runs any number of small levels inside one launch (deep graphs: hundreds of tiny levels) and
-  //          opens the next big one; on a shallow graph it is an idle ~5 us launch in front of every big level.
-  //   direct [push, (pull), build] per level with the level number as an argument; the level's bookkeeping rides on
-  //          the push launch (the direction of a direction-optimising level too: bfs_level_pulls).
-  // The scheme follows the previous traversal of the graph: direct unless that one was deep (MGX_BFS_DIRECT forces).
-  const char* const direct_str = getenv("MGX_BFS_DIRECT");          // (read per run: the tests switch it)
-  const int direct_env = direct_str ? atoi(direct_str) : -1;
-  // (profiling runs with events around the two push kernels keep the slot scheme unless forced: there the tiny levels
-  //  stay inside the single-workgroup kernel instead of adding no-op launches to the kernels' averages)
-  const bool direct = direct_env >= 0 ? direct_env != 0 : (st.direct_levels && !st.time_kernels);
   const bool batch_events = st.time_kernels || st.time_batches;    // (an event costs ~6 us of stream gap)
+  const u32 nstream = a.long_min > 0 ? (u32)ctx.num_cus * 2 : 0u;
+  const u32 nwave = (u32)ctx.num_cus * 2;
   int slot = 0;
   for (int batch = 0;; ++batch) {
     // first batch: what the previous traversal of this graph needed (sources differ, level structure hardly)
-    int nslots = batch == 0 ? (direct ? st.levels_hint : st.slots_hint) : st.levels_per_sync;
+    int nslots = batch == 0 ? st.slots_hint : st.levels_per_sync;
     if (nslots > bfs_fused_state_t::EV_POOL / 3) nslots = bfs_fused_state_t::EV_POOL / 3;
     if (batch_events) MGX_HIP(hipEventRecord(st.ev0, s));
     for (int i = 0; i < nslots; ++i, ++slot) {
-      const int lv_arg = direct ? slot : -1;
-      if (!direct)
-        hipLaunchKernelGGL(k_bfs_small_levels<BFS_SMALL_NT>, dim3(1), dim3(BFS_SMALL_NT), bfs_small_lds_bytes(), s, a,
-                           st.small_max_edges);
+      const int arg = bfs_slot_arg(slot);
       const bool timed = st.time_kernels && 3 * i + 2 < bfs_fused_state_t::EV_POOL;
-      if (timed) {
-        if (direct) hipLaunchKernelGGL(k_bfs_level_begin, dim3(1), dim3(64), 0, s, a, lv_arg, 0);
-        MGX_HIP(hipEventRecord(st.wev[3 * i], s));
-        bfs_launch_stream(a, lv_arg, ctx);
-        MGX_HIP(hipEventRecord(st.wev[3 * i + 1], s));
-        bfs_launch_wave(a, lv_arg, ctx);
-        MGX_HIP(hipEventRecord(st.wev[3 * i + 2], s));
+      if (timed || !opt.merged || a.flags) {
+        // the parts as launches of their own: opener / chain, long rows, short rows
+        bfs_launch_push_part<1>(a, arg, ctx, coldt, 1, 0);
+        if (timed) MGX_HIP(hipEventRecord(st.wev[3 * i], s));
+        if (a.long_min > 0) {
+          if (a.flags) hipLaunchKernelGGL(k_bfs_push_stream_diag, dim3(nstream), dim3(1024), bfs_push_lds_bytes(), s, a, arg);
+          else bfs_launch_push_part<2>(a, arg, ctx, coldt, nstream, 0);
+        }
+        if (timed) MGX_HIP(hipEventRecord(st.wev[3 * i + 1], s));
+        bfs_launch_push_part<3>(a, arg, ctx, coldt, nwave, 0);
+        if (timed) MGX_HIP(hipEventRecord(st.wev[3 * i + 2], s));
       } else {
-        bfs_launch_push(a, lv_arg, ctx, direct ? 1 : 0);
+        bfs_launch_push_part<0>(a, arg, ctx, coldt, nstream + nwave, nstream);
       }
       if (mode == 1)
-        hipLaunchKernelGGL(k_bfs_pull_level<256>, dim3(ctx.num_cus * 8), dim3(256), 0, s, a, lv_arg);
-      hipLaunchKernelGGL((k_bfs_build<512, true>), dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, lv_arg,
+        hipLaunchKernelGGL(k_bfs_pull_level<256>, dim3(ctx.num_cus * 8), dim3(256), 0, s, a, arg);
+      hipLaunchKernelGGL((k_bfs_build<512, true>), dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, arg,
                          (const u32*)nullptr, labels, st.n, 1, 0, 1);       // (2 workgroups per CU overlap their phases)
     }
     if (batch_events) MGX_HIP(hipEventRecord(st.ev1, s));
+    MGX_CHECK_LAUNCH("fused BFS: kernel launch");
     // one read-back per batch: the counters and the first 64 trace slots (the flag alone would cost the same trip)
     MGX_HIP(hipMemcpyAsync(st.host_ctrl, st.ctrl.data(), offsetof(bfs_ctrl_t, trace) + 64 * sizeof(u64), hipMemcpyDeviceToHost, s));
     MGX_HIP(hipStreamSynchronize(s));
@@ -220,20 +287,17 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
     if (st.batches < 256) st.batch_ms[st.batches++] = ms;
     st.level_kernel_launches += nslots;
     if (st.host_ctrl->done) break;
-    if (direct) {
-      // all `slot` levels launched so far have run; if the last build left both queues empty the traversal is over
-      // (no need to launch the level that would find that out)
-      const u64 next = st.host_ctrl->cursor[slot % 3] | st.host_ctrl->lcursor[slot % 3];
-      if ((next >> BFS_VSHIFT) == 0) {
-        st.host_ctrl->done = 1;
-        st.host_ctrl->levels = slot;
-        break;
-      }
+    // all `slot` slots launched so far have run; if the last one left both queues empty the traversal is over (no need
+    // to launch the slot that would find that out)
+    const u64 next = st.host_ctrl->cursor[slot % 3] | st.host_ctrl->lcursor[slot % 3];
+    if ((next >> BFS_VSHIFT) == 0) {
+      st.host_ctrl->done = 1;
+      st.host_ctrl->levels = st.host_ctrl->slot_level[slot & 3];
+      break;
     }
   }
-  if (direct) st.levels_hint = st.host_ctrl->levels > 0 ? st.host_ctrl->levels : 1;
-  else st.slots_hint = st.host_ctrl->slots > 0 ? st.host_ctrl->slots : 1;
-  st.direct_levels = st.host_ctrl->levels <= st.direct_max_levels;
+  st.slots_used = slot;
+  st.slots_hint = st.host_ctrl->slots > 0 ? st.host_ctrl->slots : 1;    // slots that found work
   const int lv = st.host_ctrl->levels < BFS_MAX_TRACE ? st.host_ctrl->levels : BFS_MAX_TRACE;
   if (lv > 64) {                // the rest of the per-level trace (deep traversals only)
     MGX_HIP(hipMemcpyAsync(st.host_ctrl->trace + 64, st.ctrl.data()->trace + 64, (size_t)(lv - 64) * sizeof(u64), hipMemcpyDeviceToHost, s));

@@ -50,7 +50,7 @@ constexpr size_t bfs_stream_lds_bytes(int hotw) { return (size_t)hotw * 4 + 64; 
 // fast path for rounds inside one row did not help because that level has few of them: its long rows are the
 // mid-degree ones (a few sub-rounds each); the hubs were expanded a level earlier.
 template <int NT, int HOTW, int EPT, bool COLDT, bool DIAG = false, bool NTLOAD = false>
-__device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int level, u32 block, u32 nblocks) {
+__device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int level, u32 block, u32 nblocks, int stat_level) {
   constexpr int NW = NT / WAVE;
   static_assert(EPT + 2 <= WAVE, "round shape");
 
@@ -60,8 +60,7 @@ __device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int l
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);   // uniform: the walk stays in SGPRs
   const int lane = lane_id();
 
-  bfs_ctrl_t* const c = a.ctrl;
-  if (!bfs_resolve_level(c, level)) return;
+  bfs_ctrl_t* const c = a.ctrl;          // (`level` is the slot: ring and queue-buffer index, see bfs_resolve)
   const u64 cur = c->lcursor[level % 3];
   const u32 nf = (u32)(cur >> BFS_VSHIFT);
   const u32 E = (u32)(cur & BFS_EMASK);                     // in units of padded edges: a multiple of 64 (bfs_lq_*)
@@ -93,7 +92,7 @@ __device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int l
   if (threadIdx.x == 0) s_int[0] = 0;
   __syncthreads();
 
-  const int diag = (DIAG && (a.flags >> 8) == level) ? (a.flags & 255) : 0;   // MGX_BFS_FLAGS = level << 8 | bits
+  const int diag = (DIAG && (a.flags >> 8) == stat_level) ? (a.flags & 255) : 0;   // MGX_BFS_FLAGS = level << 8 | bits
   int marks = 0;                 // per lane
 
   if (has_work) {
@@ -238,14 +237,10 @@ __device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int l
     __syncthreads();
     if (threadIdx.x == 0 && s_int[0]) {
       atomicAdd(&c->claims, (u64)s_int[0]);
-      if (level < 64) atomicAdd(&c->claims_level[level], (u64)s_int[0]);
+      if (stat_level < 64) atomicAdd(&c->claims_level[stat_level], (u64)s_int[0]);
     }
   }
 }
 
-template <int NT, int HOTW, int EPT, bool COLDT, bool DIAG = false, bool NTLOAD = false>
-__global__ __launch_bounds__(NT) void k_bfs_push_level_stream(bfs_fused_args_t a, int level) {
-  bfs_stream_body<NT, HOTW, EPT, COLDT, DIAG, NTLOAD>(a, level, blockIdx.x, gridDim.x);
-}
 
 }  // namespace mgx

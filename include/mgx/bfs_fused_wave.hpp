@@ -28,7 +28,7 @@ constexpr size_t bfs_wave_lds_bytes(int nt, int hotw) {
 }
 
 template <int NT, int HOTW, bool COLDT, bool NTLOAD = false>
-__device__ __forceinline__ void bfs_wave_body(const bfs_fused_args_t& a, int level, u32 block, u32 nblocks) {
+__device__ __forceinline__ void bfs_wave_body(const bfs_fused_args_t& a, int level, u32 block, u32 nblocks, int stat_level) {
   constexpr int NW = NT / WAVE;
   constexpr int EPT = BFS_WAVE_EPT;
 
@@ -40,8 +40,7 @@ __device__ __forceinline__ void bfs_wave_body(const bfs_fused_args_t& a, int lev
   u32* const w_row = w_off + 68;                                         // 64
   int* const s_int = (int*)(hot + HOTW + NW * (BFS_WAVE_LDS_PER_WAVE / 4));   // [0] marks stored
 
-  bfs_ctrl_t* const c = a.ctrl;
-  if (!bfs_resolve_level(c, level)) return;
+  bfs_ctrl_t* const c = a.ctrl;          // (`level` is the slot: ring and queue-buffer index, see bfs_resolve)
   const u64 cur = c->cursor[level % 3];
   const long long nf = (long long)(cur >> BFS_VSHIFT);
   const u32 E = (u32)(cur & BFS_EMASK);
@@ -208,14 +207,10 @@ __device__ __forceinline__ void bfs_wave_body(const bfs_fused_args_t& a, int lev
     __syncthreads();
     if (threadIdx.x == 0 && s_int[0]) {
       atomicAdd(&c->claims, (u64)s_int[0]);
-      if (level < 64) atomicAdd(&c->claims_level[level], (u64)s_int[0]);
+      if (stat_level < 64) atomicAdd(&c->claims_level[stat_level], (u64)s_int[0]);
     }
   }
 }
 
-template <int NT, int HOTW, bool COLDT, bool NTLOAD = false>
-__global__ __launch_bounds__(NT) void k_bfs_push_level_wave(bfs_fused_args_t a, int level) {
-  bfs_wave_body<NT, HOTW, COLDT, NTLOAD>(a, level, blockIdx.x, gridDim.x);
-}
 
 }  // namespace mgx

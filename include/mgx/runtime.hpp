@@ -141,6 +141,10 @@ class mem_t {
   static mem_t borrow(T* p, size_t count) {
     mem_t m; m._ptr = p; m._size = count; m._owned = false; return m;
   }
+  // adopt: take ownership of a hipMalloc'ed array
+  static mem_t adopt(T* p, size_t count) {
+    mem_t m; m._ptr = p; m._size = count; m._owned = true; return m;
+  }
   mem_t(const mem_t&) = delete;
   mem_t& operator=(const mem_t&) = delete;
   mem_t(mem_t&& r) noexcept { swap(r); }

@@ -94,6 +94,30 @@ __device__ __forceinline__ T block_exclusive_sum_nw(T x, T* smem, T* total) {
   return base + inc - x;
 }
 
+// The same with the wave totals scanned by wave 0's lanes instead of every thread reading all NW of them: the loop above
+// reads NW uniform LDS words, which hipcc moves to scalar registers (2 NW SGPRs per call for 64-bit sums; several calls
+// in flight spilled the chain of small levels).  `smem` needs NW + 1 slots.  Three barriers.
+template <int NW, typename T>
+__device__ __forceinline__ T block_exclusive_sum_lean(T x, T* smem, T* total) {
+  static_assert(NW <= WAVE, "one lane per wave total");
+  const int lane = lane_id();
+  const int wave = threadIdx.x / WAVE;
+  const T inc = wave_inclusive_sum(x);
+  if (lane == WAVE - 1) smem[wave] = inc;
+  __syncthreads();
+  if (wave == 0) {
+    const T v = lane < NW ? smem[lane] : T(0);
+    const T s = wave_inclusive_sum(v);
+    if (lane < NW) smem[lane] = s - v;
+    if (lane == NW - 1) smem[NW] = s;
+  }
+  __syncthreads();
+  const T base = smem[wave];
+  *total = smem[NW];
+  __syncthreads();
+  return base + inc - x;
+}
+
 // Wave-cooperative upper bound on a sorted global array: returns the number of elements
 // a[i] <= key for i in [0,n) (so the last position with a[pos] <= key is result-1).
 // 64-ary search: every step narrows the window by 64x with one coalescable probe per lane.

@@ -40,7 +40,7 @@ struct mgx_bfs_s {
   std::shared_ptr<bfs::bfs_problem_t> p;
   std::unique_ptr<bfs::bfs_enactor_t> e;              // lazily: holds two m-capacity buffers
   std::unique_ptr<bfs::bfs_fused_enactor_t> fe;       // lazily: O(n)
-  int64_t last_stats[16] = {0};
+  int64_t last_stats[20] = {0};
   int time_kernels = -1;                              // -1: environment default
 };
 struct mgx_sssp_s {
@@ -290,6 +290,7 @@ int mgx_graph_wrap_device(mgx_ctx_t c, int n, int64_t m, const int* ro, const in
   *out = h;
   MGX_CATCH
 }
+static void build_unit_blocks(mgx_graph_s* g);
 int mgx_graph_attach_layout(mgx_graph_t g, const int* d_row_offsets, const int* d_col_indices, const int* d_new_of_old,
                             const int* d_old_of_new) {
   MGX_TRY
@@ -301,6 +302,9 @@ int mgx_graph_attach_layout(mgx_graph_t g, const int* d_row_offsets, const int* 
   G.d_new_of_old = mem_t<int>::borrow((int*)d_new_of_old, (size_t)G.num_nodes);
   G.d_old_of_new = mem_t<int>::borrow((int*)d_old_of_new, (size_t)G.num_nodes);
   G.has_layout = true;
+  use_device(g->c);
+  g->c->ctx->synchronize();
+  build_unit_blocks(g);
   MGX_CATCH
 }
 int mgx_graph_attach_layout_weights(mgx_graph_t g, const float* d_layout_weights) {
@@ -314,6 +318,29 @@ int mgx_graph_attach_layout_weights(mgx_graph_t g, const float* d_layout_weights
 }
 extern "C" int mgx_layout_build_device(const int* ro, const int* ci, const float* w, int n, long long m, int* lro, int* lci,
                                        float* lw, int* new_of_old, int* old_of_new, hipStream_t stream);   // mgx_layout.hip
+extern "C" int mgx_units_build_device(const int* ro, const int* ci, int n, int min_deg, int max_deg, int ushift, int** owner,
+                                      int** ucol, long long* units, long long* units_pad, hipStream_t stream);
+
+// Unit blocks of the layout's long rows (mgx/bfs_fused_dense.hpp); MGX_BFS_UNITS=0 skips them.  The threshold is the
+// fused traversal's long-row threshold at build time (MGX_BFS_LONG_MIN, default 64; a unit is 64 entries whatever the
+// threshold); a run with another threshold ignores the blocks.
+static void build_unit_blocks(mgx_graph_s* g) {
+  graph_device_t& G = *g->g;
+  G.d_ub_col = mem_t<int>(); G.d_ub_owner = mem_t<int>(); G.ub_units = G.ub_units_pad = 0; G.ub_min_degree = 0;
+  if (const char* e = getenv("MGX_BFS_UNITS")) if (atoi(e) == 0) return;
+  int long_min = 64;
+  if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
+  if (long_min <= 0 || !G.has_layout || G.num_edges <= 0) return;
+  int *owner = nullptr, *ucol = nullptr;
+  long long units = 0, units_pad = 0;
+  const int rc = mgx_units_build_device(G.d_layout_row_offsets.data(), G.d_layout_col_indices.data(), G.num_nodes, long_min,
+                                        0x7FFFFFFF, 6, &owner, &ucol, &units, &units_pad, g->c->ctx->stream());
+  if (rc != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("unit blocks: ") + hipGetErrorString((hipError_t)rc));
+  if (units <= 0) return;
+  G.d_ub_owner = mem_t<int>::adopt(owner, (size_t)units_pad);
+  G.d_ub_col = mem_t<int>::adopt(ucol, ((size_t)units_pad << 6) + 4);
+  G.ub_units = units; G.ub_units_pad = units_pad; G.ub_min_degree = long_min;
+}
 int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
   MGX_TRY
   MGX_REQUIRE(g, "graph is NULL");
@@ -337,6 +364,7 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
   G.d_old_of_new = std::move(o2n);
   G.has_layout = true;
   if (with_weights) { G.d_layout_col_values = std::move(lw); G.has_layout_weights = true; }
+  build_unit_blocks(g);
   MGX_CATCH
 }
 int mgx_graph_layout_read(mgx_graph_t g, int* h_row_offsets, int* h_col_indices, int* h_new_of_old, int* h_old_of_new,
@@ -692,6 +720,8 @@ int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats) {
   p->last_stats[13] = D.vertices;
   p->last_stats[14] = L.dominant;
   p->last_stats[15] = L.small_levels;
+  p->last_stats[16] = L.slots;
+  p->last_stats[17] = L.dense_slots;
   if (stats) memcpy(stats, p->last_stats, sizeof(p->last_stats));
   MGX_CATCH
 }

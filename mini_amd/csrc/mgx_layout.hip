@@ -110,3 +110,87 @@ extern "C" int mgx_layout_build_device(const int* ro, const int* ci, const float
   LAY_TRY(hipStreamSynchronize(stream));
   return 0;
 }
+
+// ---- unit-blocked copy of a degree class ("unit blocks") -------------------------------------------------
+// The rows of a CSR whose degree lies in [min_deg, max_deg) copied so that every row starts on a multiple of
+// U = 1 << ushift entries and is padded to a multiple of U (padding repeats the row's first neighbour: testing an edge
+// twice is harmless for a traversal), plus owner[u] = the row unit u belongs to.  A unit is U consecutive entries of ONE
+// row: a kernel can stream the copy in fixed-size pieces (bfs_fused_dense.hpp) and decide per unit whether its row is in
+// the frontier, with no row walk and no search.  The number of units is padded to a multiple of 16 (owner = n for the
+// padding: a vertex that is never in a frontier) and the copy ends with four entries of -1 (where lanes of inactive
+// units read from).
+namespace {
+
+__global__ void k_unit_counts(const int* __restrict__ ro, int n, int min_deg, int max_deg, int ushift, int* __restrict__ cnt) {
+  const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  const int deg = ro[v + 1] - ro[v];
+  const int U = 1 << ushift;
+  cnt[v] = (deg >= min_deg && deg < max_deg) ? (deg + U - 1) >> ushift : 0;
+}
+
+// one wave per row of the class: owners and padded entries
+__global__ void k_unit_fill(const int* __restrict__ ro, const int* __restrict__ ci, int n, const int* __restrict__ uoff,
+                            int ushift, int* __restrict__ owner, int* __restrict__ ucol) {
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long v = wave0; v < n; v += nwaves) {
+    const int u0 = uoff[v], u1 = uoff[v + 1];
+    if (u1 == u0) continue;
+    const int r0 = ro[v], deg = ro[v + 1] - r0;
+    const int first = ci[r0];
+    for (int u = u0 + lane; u < u1; u += 64) owner[u] = (int)v;
+    const long long e0 = (long long)u0 << ushift, e1 = (long long)u1 << ushift;
+    for (long long e = e0 + lane; e < e1; e += 64) {
+      const long long k = e - e0;
+      ucol[e] = k < deg ? ci[r0 + k] : first;
+    }
+  }
+}
+
+__global__ void k_unit_tail(int n, int units, int units_pad, int ushift, int* __restrict__ owner, int* __restrict__ ucol) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long tail_entries = ((long long)(units_pad - units) << ushift) + 4;
+  if (i < units_pad - units) owner[units + i] = n;
+  if (i < tail_entries) ucol[((long long)units << ushift) + i] = -1;
+}
+
+}  // namespace
+
+// Allocates *owner (units_pad ints) and *ucol ((units_pad << ushift) + 4 ints) with hipMalloc; the caller owns them.
+// *units = real units, *units_pad = padded to a multiple of 16.  Returns 0 or the hipError_t that stopped it.
+extern "C" int mgx_units_build_device(const int* ro, const int* ci, int n, int min_deg, int max_deg, int ushift, int** owner,
+                                      int** ucol, long long* units, long long* units_pad, hipStream_t stream) {
+  *owner = nullptr; *ucol = nullptr; *units = 0; *units_pad = 0;
+  if (n <= 0) return 0;
+  const int threads = 256;
+  const unsigned nblocks = (unsigned)(((long long)n + threads - 1) / threads);
+  tmp_t cnt, uoff, st;
+  LAY_TRY(cnt.alloc((size_t)n * 4)); LAY_TRY(uoff.alloc(((size_t)n + 1) * 4));
+  hipLaunchKernelGGL(k_unit_counts, dim3(nblocks), dim3(threads), 0, stream, ro, n, min_deg, max_deg, ushift, cnt.as<int>());
+  size_t sb = 0;
+  LAY_TRY(rocprim::exclusive_scan(nullptr, sb, cnt.as<int>(), uoff.as<int>(), 0, (size_t)n, rocprim::plus<int>(), stream));
+  LAY_TRY(st.alloc(sb));
+  LAY_TRY(rocprim::exclusive_scan(st.p, sb, cnt.as<int>(), uoff.as<int>(), 0, (size_t)n, rocprim::plus<int>(), stream));
+  int last_off = 0, last_cnt = 0;
+  LAY_TRY(hipMemcpyAsync(&last_off, uoff.as<int>() + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+  LAY_TRY(hipMemcpyAsync(&last_cnt, cnt.as<int>() + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+  LAY_TRY(hipStreamSynchronize(stream));
+  const long long U = (long long)last_off + last_cnt;
+  if (U <= 0) return 0;
+  if ((U << ushift) > 2000000000LL) return 0;              // 32-bit entry offsets in the kernels: no unit blocks then
+  const int tot = (int)U;
+  LAY_TRY(hipMemcpyAsync(uoff.as<int>() + n, &tot, 4, hipMemcpyHostToDevice, stream));
+  const long long Up = (U + 15) / 16 * 16;
+  LAY_TRY(hipMalloc((void**)owner, (size_t)Up * 4));
+  hipError_t e = hipMalloc((void**)ucol, (((size_t)Up << ushift) + 4) * 4);
+  if (e != hipSuccess) { (void)hipFree(*owner); *owner = nullptr; return (int)e; }
+  hipLaunchKernelGGL(k_unit_fill, dim3(4096), dim3(256), 0, stream, ro, ci, n, uoff.as<int>(), ushift, *owner, *ucol);
+  const long long tail = ((Up - U) << ushift) + 4;
+  hipLaunchKernelGGL(k_unit_tail, dim3((unsigned)((tail + 255) / 256)), dim3(256), 0, stream, n, (int)U, (int)Up, ushift, *owner, *ucol);
+  e = hipStreamSynchronize(stream);                       // (tot lives on this frame)
+  if (e != hipSuccess) { (void)hipFree(*owner); (void)hipFree(*ucol); *owner = nullptr; *ucol = nullptr; return (int)e; }
+  *units = U; *units_pad = Up;
+  return 0;
+}

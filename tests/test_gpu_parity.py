@@ -243,10 +243,10 @@ def test_bfs_fused_operator_equals_advance_plus_filter(gpu_ctx, oracle, rmat_gra
 @pytest.mark.parametrize("direct", [1, 0])
 @pytest.mark.parametrize("scale", [8, 10, 13, 16])
 def test_bfs_rmat_parity_all_paths(gpu_ctx, oracle, rmat_graphs, scale, direct, monkeypatch):
-    """direct: the two launch schemes of the fused traversal (include/mgx/bfs_fused_run.hpp)"""
+    """direct = 1: small levels chained inside a push launch (include/mgx/bfs_fused_chain.hpp), 0: every level device-wide"""
     import mini_amd
     from mini_amd import rmat
-    monkeypatch.setenv("MGX_BFS_DIRECT", str(direct))
+    monkeypatch.setenv("MGX_BFS_CHAIN_MAX_EDGES", "6144" if direct else "0")
     n, ro, ci, w = rmat_graphs[scale]
     g = _graph(gpu_ctx, ro, ci)
     deg = np.diff(ro)
@@ -283,14 +283,16 @@ def test_bfs_hub_first_layout_and_lds_hot_bitmap(gpu_ctx, oracle, torch_mod, rma
     come back in ORIGINAL ids and equal the oracle's.  hot_min_edges=0 forces the LDS path on small graphs,
     2^30 keeps every probe in L2; long_min moves rows between the row-wise streaming kernel and the
     per-edge-rank kernel (0: no long-row queue, 1: every row is streamed); small_max: levels up to that many
-    edges run inside the single-workgroup kernel (0: none; -1: the direct launch scheme, which has no such kernel)."""
+    edges are chained inside block 0 of a push launch (0 / -1: none).  The unit blocks of the long rows are built when
+    the layout is attached (with this long_min); small_max 8192 / 3000 also force them on for every level that may use
+    them, 0 keeps every level on the queue walk."""
     import mini_amd
     from mini_amd import rmat
     torch = torch_mod
     monkeypatch.setenv("MGX_BFS_HOT_MIN_EDGES", str(hot_min_edges))
     monkeypatch.setenv("MGX_BFS_LONG_MIN", str(long_min))
-    monkeypatch.setenv("MGX_BFS_DIRECT", "1" if small_max < 0 else "0")
-    monkeypatch.setenv("MGX_BFS_SMALL_MAX_EDGES", str(max(small_max, 0)))
+    monkeypatch.setenv("MGX_BFS_CHAIN_MAX_EDGES", str(max(small_max, 0)))
+    monkeypatch.setenv("MGX_BFS_DENSE", {8192: "1000000", 3000: "1000000", 0: "0"}.get(small_max, "16"))
     n, ro, ci, w = rmat_graphs[scale]
     d_ro, d_ci = torch.from_numpy(ro).cuda(), torch.from_numpy(ci).cuda()
     g = mini_amd.Graph.from_device(gpu_ctx, n, len(ci), d_ro, d_ci)
@@ -320,12 +322,12 @@ def test_bfs_hub_first_layout_and_lds_hot_bitmap(gpu_ctx, oracle, torch_mod, rma
 def test_bfs_direction_optimizing_fused(gpu_ctx, oracle, torch_mod, rmat_graphs, scale, layout, direct, monkeypatch):
     """fused direction-optimising traversal (bottom-up levels once unvisited < frontier*alpha,
     bfs_enactor.hxx:68): labels equal the top-down oracle for every switch point, incl. pull from level 0.
-    direct: both launch schemes (in the direct one the workgroups of a level derive its direction themselves)."""
+    direct = 0: the top-down levels read their long rows from the unit blocks whenever they may (layout runs)."""
     import mini_amd
     from mini_amd import rmat
     torch = torch_mod
     monkeypatch.setenv("MGX_BFS_HOT_MIN_EDGES", "0")
-    monkeypatch.setenv("MGX_BFS_DIRECT", str(direct))
+    monkeypatch.setenv("MGX_BFS_DENSE", "16" if direct else "1000000")
     n, ro, ci, w = rmat_graphs[scale]
     d_ro, d_ci = torch.from_numpy(ro).cuda(), torch.from_numpy(ci).cuda()
     g = mini_amd.Graph.from_device(gpu_ctx, n, len(ci), d_ro, d_ci)
@@ -389,11 +391,9 @@ def test_bfs_directed_graph_with_zero_outdegree_vertices(gpu_ctx, oracle):
 @pytest.mark.parametrize("small_max", [8192, 0])
 def test_bfs_long_chain_many_levels(gpu_ctx, oracle, monkeypatch, small_max):
     """a path graph: > levels_per_sync levels, frontier of one vertex each.  small_max=8192: all 300 levels run
-    inside ONE launch of the single-workgroup kernel; 0: every level goes through the device-wide kernels.
-    The first traversal of a graph uses the direct launch scheme (a push and a build launch per level); having seen
-    300 levels, the engine switches to the slot scheme with the single-workgroup kernel for the next one."""
+    inside ONE push launch, chained by its block 0; 0: every level goes through the device-wide kernels, slot by slot."""
     import mini_amd
-    monkeypatch.setenv("MGX_BFS_SMALL_MAX_EDGES", str(small_max))
+    monkeypatch.setenv("MGX_BFS_CHAIN_MAX_EDGES", str(small_max))
     n = 300
     t0 = np.arange(0, n - 1, dtype=np.int32)
     t1 = np.arange(1, n, dtype=np.int32)
@@ -403,12 +403,16 @@ def test_bfs_long_chain_many_levels(gpu_ctx, oracle, monkeypatch, small_max):
     st = bfs.run(0)
     assert np.array_equal(bfs.labels(), np.arange(n, dtype=np.int32))
     assert st["levels"] == n          # frontiers at depth 0..n-1 all expand an edge
-    assert st["small_levels"] == 0    # direct scheme
-    st = bfs.run(n - 1)               # deep graph seen: slot scheme
+    assert st["small_levels"] == (n if small_max else 0)
+    tr = bfs.level_trace()
+    assert len(tr) == n and all(t == (1, 2) for t in tr[1:-1]) and tr[0] == (1, 1) and tr[-1] == (1, 1)
+    st = bfs.run(n - 1)
     assert np.array_equal(bfs.labels(), np.arange(n - 1, -1, -1, dtype=np.int32))
     assert st["levels"] == n
     assert st["small_levels"] == (n if small_max else 0)
-    bfs.run(n // 2)                   # 150 levels: still deep
+    if small_max:
+        assert st["slots"] == 1       # one launch slot ran the whole traversal
+    bfs.run(n // 2)                   # 150 levels
     assert np.array_equal(bfs.labels(), np.abs(np.arange(n) - n // 2).astype(np.int32))
 
 
@@ -418,12 +422,12 @@ def test_bfs_long_row_queue_padding_boundaries(gpu_ctx, oracle, monkeypatch, sma
     """The long-row queue counts degrees rounded up to 64 and keeps degree & 63 in the low bits of its offsets
     (bfs_lq_* in include/mgx/bfs_fused.hpp).  A tree whose second level has rows of every length around the
     multiples of 64 (and a 5000-edge row that spans several slices), expanded by the stream kernel (small_max 0 /
-    256), by the single-workgroup kernel (small_max 2^20) and with every row in the long queue (long_min 1):
-    labels, levels and the traversed-edge count (true edges, not padded ones) must equal the oracle's."""
+    256 / -1), by the chain of small levels where a level fits (small_max 2^20: capped at BFS_CHAIN_CAP) and with every
+    row in the long queue (long_min 1): labels, levels and the traversed-edge count (true edges, not padded ones) must
+    equal the oracle's.  Also through the unit blocks of a library-built layout (forced on)."""
     import mini_amd
-    # small_max -1: the direct launch scheme (no single-workgroup kernel at all); otherwise the slot scheme
-    monkeypatch.setenv("MGX_BFS_DIRECT", "1" if small_max < 0 else "0")
-    monkeypatch.setenv("MGX_BFS_SMALL_MAX_EDGES", str(max(small_max, 0)))
+    monkeypatch.setenv("MGX_BFS_CHAIN_MAX_EDGES", str(max(small_max, 0)))
+    monkeypatch.setenv("MGX_BFS_DENSE", "1000000")
     monkeypatch.setenv("MGX_BFS_LONG_MIN", str(long_min))
     monkeypatch.setenv("MGX_BFS_HOT_MIN_EDGES", "0")
     degs = [1, 2, 62, 63, 64, 65, 66, 126, 127, 128, 129, 190, 191, 192, 193, 255, 256, 257, 511, 512, 513, 5000]
@@ -439,11 +443,15 @@ def test_bfs_long_row_queue_padding_boundaries(gpu_ctx, oracle, monkeypatch, sma
     deg = np.diff(ro)
     assert sorted(deg[1:1 + len(degs)].tolist()) == sorted(degs)
     g = _graph(gpu_ctx, ro, ci)
+    if small_max in (0, -1):
+        g.build_layout()                             # + unit blocks, read by every level whose frontier bitmap is current
     bfs = mini_amd.BfsProblem(g, 0)
     for src in (0, 5, len(degs), n - 1):             # the root, a 64-edge hub, the 5000-edge hub, a leaf
         want = oracle.bfs_cpu(ro, ci, src)
         st = bfs.run(src)
         assert np.array_equal(bfs.labels(), want), src
+        if small_max in (0, -1) and src == 0:
+            assert st["dense_slots"] >= 1            # the hubs' level: 22 long rows read from the unit blocks
         reached = want >= 0
         assert st["reached"] == int(reached.sum())
         assert st["m_t"] == int(deg[reached].sum())
@@ -493,7 +501,8 @@ def test_degenerate_graphs_through_the_fused_loops(gpu_ctx, oracle, direct, monk
     """one vertex without edges, a single edge, a self-loop, 100 isolated vertices, 33 vertices in a ring: fused BFS
     (push and direction-optimising), fused SSSP, with and without the library-built hub-first copy"""
     import mini_amd
-    monkeypatch.setenv("MGX_BFS_DIRECT", str(direct))
+    monkeypatch.setenv("MGX_BFS_CHAIN_MAX_EDGES", "6144" if direct else "0")
+    monkeypatch.setenv("MGX_BFS_DENSE", "16" if direct else "1000000")
     cases = [(1, [], []), (2, [0], [1]), (3, [1], [1]), (100, [], []), (33, list(range(33)), [(i + 1) % 33 for i in range(33)])]
     for n, t0, t1 in cases:
         wv = (np.arange(len(t0)) % 7).astype(np.float32)
@@ -525,7 +534,8 @@ def test_bfs_far_hub_is_not_discovered_early(gpu_ctx, oracle, monkeypatch, cold,
     import mini_amd
     monkeypatch.setenv("MGX_BFS_COLD_TEST", str(cold))
     monkeypatch.setenv("MGX_BFS_HOT_MIN_EDGES", "0")
-    monkeypatch.setenv("MGX_BFS_DIRECT", str(direct))
+    monkeypatch.setenv("MGX_BFS_CHAIN_MAX_EDGES", "6144" if direct else "0")
+    monkeypatch.setenv("MGX_BFS_DENSE", "0" if direct else "1000000")
     t0, t1 = [], []
     nxt = 8
     for k in range(300):            # medium hub 1 next to the source 0
@@ -548,14 +558,17 @@ def test_bfs_far_hub_is_not_discovered_early(gpu_ctx, oracle, monkeypatch, cold,
 VARIANTS = [{}, {"MGX_BFS_COLD_TEST": "1"}, {"MGX_BFS_COLD_TEST": "1", "MGX_BFS_HOT_MIN_EDGES": "0"},
             {"MGX_BFS_LONG_MIN": "1", "MGX_BFS_COLD_TEST": "1"}, {"MGX_BFS_LONG_MIN": "0"},
             {"MGX_BFS_HOT_MIN_EDGES": "1000000000", "MGX_BFS_LONG_MIN": "8"}, {"MGX_BFS_MERGED_PUSH": "0", "MGX_BFS_COLD_TEST": "1"},
-            {"MGX_BFS_DIRECT": "0", "MGX_BFS_SMALL_MAX_EDGES": "100000"}, {"MGX_BFS_DIRECT": "0", "MGX_BFS_SMALL_MAX_EDGES": "0"}]
+            {"MGX_BFS_CHAIN_MAX_EDGES": "0"}, {"MGX_BFS_CHAIN_MAX_EDGES": "64", "MGX_BFS_DENSE": "1000000", "MGX_BFS_HOT_MIN_EDGES": "0"},
+            {"MGX_BFS_DENSE": "1000000"}, {"MGX_BFS_DENSE": "0", "MGX_BFS_CHAIN_MAX_EDGES": "100000"},
+            {"MGX_BFS_DENSE": "1000000", "MGX_BFS_LONG_MIN": "1"}, {"MGX_BFS_DENSE": "1000000", "MGX_BFS_MERGED_PUSH": "0"}]
 
 
 @pytest.mark.parametrize("variant", range(len(VARIANTS)))
 def test_bfs_kernel_variants_on_random_graphs(gpu_ctx, oracle, monkeypatch, variant):
     """A small randomised campaign (tools/fuzz_parity.py is the long one) with the kernel variants forced that the
     default thresholds only pick on big or unusual inputs: cold-test instances, every / no row in the long-row queue,
-    no LDS prefix, unmerged launches, the slot scheme with and without the single-workgroup kernel."""
+    no LDS prefix, unmerged launches, no chains of small levels / short ones, the unit blocks forced on for every level
+    that may use them (also with every row in them) / off."""
     import mini_amd
     for k, v in VARIANTS[variant].items():
         monkeypatch.setenv(k, v)

@@ -108,8 +108,11 @@ for name, n, ro, ci, w in graphs():
     srcs = [int(np.argmax(deg))] + [int(x) for x in rng.integers(0, n, size=4)]
     for src in srcs:
         want = orc.bfs_cpu(ro, ci, src)
+        # the traversal's per-level choices forced both ways: chains of small levels (cap), unit blocks (never /
+        # whenever the frontier bitmap allows)
         for direct in ("1", "0"):
-            os.environ["MGX_BFS_DIRECT"] = direct
+            os.environ["MGX_BFS_CHAIN_MAX_EDGES"] = str(int(rng.choice([0, 1, 64, 6144]))) if direct == "0" else "6144"
+            os.environ["MGX_BFS_DENSE"] = "1000000" if direct == "0" else str(int(rng.choice([0, 16])))
             st = bfs.run(src)
             assert np.array_equal(bfs.labels(), want), (name, n, src, "push", direct, layout)
             assert st["m_t"] == int(deg[want >= 0].sum()), (name, n, src, "m_t", direct, layout)
@@ -117,7 +120,8 @@ for name, n, ro, ci, w in graphs():
                 alpha = float(10.0 ** rng.uniform(-2, 4))
                 bfs.run(src, mode=mini_amd.MGX_BFS_DIRECTION_OPT, alpha=alpha)
                 assert np.array_equal(bfs.labels(), want), (name, n, src, "do", alpha, direct, layout)
-        os.environ.pop("MGX_BFS_DIRECT", None)
+        os.environ.pop("MGX_BFS_CHAIN_MAX_EDGES", None)
+        os.environ.pop("MGX_BFS_DENSE", None)
         if src == srcs[0] and n <= 150000:
             G = int(rng.choice([2, 3, 5, 8]))
             mode = str(rng.choice(["gather", "reduce"]))
