@@ -27,7 +27,7 @@ namespace mgx {
 
 constexpr int BFS_CHAIN_NT = 1024;
 constexpr int BFS_CHAIN_CAP = 6144;          // edges (>= winners >= rows of the next level) of a chained level
-constexpr int BFS_CHAIN_EPT = 2;             // edge ranks per thread in flight
+constexpr int BFS_CHAIN_EPT = 4;             // edge ranks per thread in flight
 constexpr size_t bfs_chain_lds_bytes() {
   return (size_t)(BFS_CHAIN_NT / 64 + 2) * 8 + (size_t)(3 * BFS_CHAIN_CAP + 4) * 4 + 64;
 }
@@ -166,12 +166,13 @@ __device__ __forceinline__ void bfs_chain_body(const bfs_fused_args_t& a, int sl
     const int W = s_i[0];               // <= E <= CAP
     const int new_label = level + 1;
     u64 run = 0;                        // (count << 40 | edges) of the list so far
-    for (int first = 0; first < W; first += 2 * NT) {
-      u32 ro[2], dg[2];
+    constexpr int WPT = 4;              // winners per thread and round (4096 per round: one round for most chained levels)
+    for (int first = 0; first < W; first += WPT * NT) {
+      u32 ro[WPT], dg[WPT];
       u64 mine = 0;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int i = first + threadIdx.x * 2 + q;
+      for (int q = 0; q < WPT; ++q) {
+        const int i = first + threadIdx.x * WPT + q;
         ro[q] = 0; dg[q] = 0;
         if (i < W) {
           const u32 v = s_win[i];
@@ -185,7 +186,7 @@ __device__ __forceinline__ void bfs_chain_body(const bfs_fused_args_t& a, int sl
       u64 tot;
       u64 ex = run + block_exclusive_sum_lean<NW>(mine, s_scan, &tot);
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < WPT; ++q) {
         if (dg[q]) {
           s_row[ex >> 40] = ro[q];
           s_off[ex >> 40] = (u32)(ex & DEGMASK);

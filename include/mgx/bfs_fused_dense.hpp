@@ -13,9 +13,10 @@
 //   * per batch of 4 groups: one coalesced load of 64 owners, one gather of their frontier bits (k_bfs_build leaves the
 //     level's frontier as a bitmap), one ballot -> the 64 activity bits of the batch in two SGPRs.  Issued a batch
 //     ahead: the two dependent loads never stall the stream;
-//   * the entries are read 16 bytes per lane (1 KB per wave instruction, 4 units), four instructions per stage, two
-//     stages in flight; lanes of inactive units read the four -1 behind the blocks instead (one cached line, no HBM
-//     traffic, no branch, and the load count stays static for hipcc's s_waitcnt bookkeeping);
+//   * the entries are read 16 bytes per lane (1 KB per wave instruction, 4 units), four instructions per group, the next
+//     active group's loads in flight while the last one is tested; a group without an active unit is skipped altogether,
+//     lanes of inactive units in an active group read the four -1 behind the blocks instead (one cached line, no HBM
+//     traffic, no divergent branch);
 //   * visited test per entry: 3 VALU + one LDS read + 2 VALU on the fast path -- the LDS bitmap has a word of ones in
 //     front (-1 entries read as visited) and a word of zeros behind (vertices outside the prefix read as unvisited), so
 //     one clamp replaces the range checks; a miss claims the bit in LDS (exact intra-workgroup dedup) and stores
@@ -135,6 +136,20 @@ __device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int sl
       }
     };
 
+    // A group of 16 units whose activity bits are all 0 costs nothing: no load, no test.  The loads of the last active
+    // group stay in flight until the next active one is found (or the wave runs out of groups): wait for the old,
+    // issue the new, test the old.
+    bool pend = false;
+    auto step = [&](u32 b, u32 k, u64 act) {
+      if (((u32)(act >> (16u * k)) & 0xFFFFu) == 0u) return;     // wave-uniform
+      if (pend) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dT[j] = dL[j];
+      }
+      issue(b, k, act);
+      if (pend) test();
+      pend = true;
+    };
     u32 own_next = load_owner(0);
     u64 act;
     {
@@ -142,24 +157,19 @@ __device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int sl
       act = __ballot((fw >> (own_next & 31u)) & 1u);
     }
     own_next = load_owner(1);
-    issue(0, 0, act);
     for (u32 b = 0; b < nbatch; ++b) {
       // activity of batch b + 1: its owners were loaded a batch ago
       const u32 own_cur = own_next;
       const u32 fw = gather_bits(own_cur);
       own_next = load_owner(b + 2);
 #pragma unroll
-      for (u32 k = 0; k < 4; ++k) {
+      for (u32 k = 0; k < 4; ++k) step(b, k, act);
+      act = __ballot((fw >> (own_cur & 31u)) & 1u);
+    }
+    if (pend) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dT[j] = dL[j];
-        if (k < 3) {
-          issue(b, k + 1, act);
-        } else {
-          act = __ballot((fw >> (own_cur & 31u)) & 1u);
-          issue(b + 1, 0, act);          // (past the last batch: all owners are n, every lane reads the -1s)
-        }
-        test();
-      }
+      for (int j = 0; j < 4; ++j) dT[j] = dL[j];
+      test();
     }
   }
   if (a.count_marks) {
