@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py -- BFS advance+filter MTEPS on synthetic R-MAT (BASELINE.json metric, config 2).
+"""bench.py -- BFS advance+filter MTEPS on synthetic R-MAT (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps K --warmup W            (N>1: launched by torch.distributed.run)
+  python bench.py [--gpus 1] [--steps K] [--warmup W]           config 2: RMAT-22 ef 16 on one MI355X
+  python -m torch.distributed.run ... bench.py --gpus N ...     RMAT-22 over N GPUs (strong scaling, the metric's
+                                                                "RMAT-22 @1/2/4/8"); --scale 26 at N = 8 is config 5;
+                                                                --scaling weak: RMAT-(scale + log2 N)
+  python bench.py --file g.mtx [--undirected] --src S --validate the reference's own driver flags (tests/bfs/test_bfs.cu:14-31)
 
-A "step" is one whole BFS traversal (reset + every advance+filter level) from one seeded source
-on the RMAT graph, inputs resident in HBM.  value = sum over steps of m_t (CSR entries of reached
-vertices) / wall time of the K steps / 1e6, max over ranks.
+A "step" is one whole BFS traversal (label reset + every advance+filter level) from one seeded source, inputs resident
+in HBM.  value = sum over steps of m_t (CSR entries of reached vertices) / wall time of the K steps / 1e6,
+max over ranks.  The line is only printed with exit status 0 when the first timed source's labels equal the oracle's
+(or, at RMAT-26, pass the BFS-tree property check): a wrong traversal that ends early would report a HIGHER rate.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel k_bfs_push_level: algorithmic bytes (8 B/edge + 20 B/frontier vertex)
-               per launch / average launch duration (HIP events on the launch stream), vs 8 TB/s.
-  cpu_baseline the CPU oracle's restatement of bfs_problem_t::cpu (bfs_problem.hxx:52-72), one host
-               thread, on a bounded sample of the same sources ("port": the reference itself
-               cannot be built here).
+  roofline     the product kernel k_bfs_push (one launch per slot: long rows + short rows, or a chain of small levels):
+               algorithmic bytes (8 B/edge + 20 B/frontier vertex) per launch / average launch duration (HIP
+               events around every launch, on the launch stream, in a second pass over the same sources), vs 8 TB/s.
+               traffic: HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json: 2 x FETCH_SIZE +
+               WRITE_SIZE, gfx950 correction) -- only when that file was measured on exactly these sources (source hash).
+  cpu_baseline the CPU oracle's restatement of bfs_problem_t::cpu (bfs_problem.hxx:52-72), one host thread, on a bounded
+               sample of the same sources ("port": the reference itself cannot be built here).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -34,6 +42,9 @@ def parse():
     ap.add_argument("--scale", type=int, default=22)
     ap.add_argument("--edgefactor", type=int, default=16)
     ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = the SAME RMAT-<scale> over N GPUs (the metric's RMAT-22 @1/2/4/8; --scale 26 "
+                         "--gpus 8 is config 5); weak = RMAT-(scale + log2 N)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
@@ -42,7 +53,24 @@ def parse():
     ap.add_argument("--alpha", type=float, default=4.0, help="bottom-up switch: unvisited < frontier*alpha")
     ap.add_argument("--no-layout", action="store_true", help="keep generator vertex ids (no hub-first relabelling)")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+    # the reference's driver flags (tests/bfs/test_bfs.cu:14-31)
+    ap.add_argument("--file", default=None, help="MatrixMarket file instead of the synthetic R-MAT")
+    ap.add_argument("--undirected", action="store_true", help="--file: append the swapped copy of every entry")
+    ap.add_argument("--src", type=int, default=None, help="source vertex (default: seeded sources; --file: 0)")
+    ap.add_argument("--validate", action="store_true", help="compare EVERY timed source with the oracle (default: the first)")
     return ap.parse_args()
+
+
+def source_sha():
+    """hash of the product sources (kernels + C-ABI): ties a committed PMC measurement to the code it was taken on"""
+    h = hashlib.sha256()
+    for base in ("include", os.path.join("mini_amd", "csrc")):
+        for d, _, files in sorted(os.walk(os.path.join(ROOT, base))):
+            for f in sorted(files):
+                if f.endswith((".hpp", ".hxx", ".h", ".hip")):
+                    h.update(f.encode())
+                    h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -80,25 +108,40 @@ def main():
     from mini_amd import rmat
 
     if world > 1 or force_dist:
-        from mini_amd import dist_bfs
-        return dist_bfs.bench_main(args, rank, world, local_rank)
+        import bench_dist
+        return bench_dist.bench_main(args, rank, world, local_rank)
 
     stream = torch.cuda.current_stream()
     ctx = mini_amd.Context(local_rank, stream.cuda_stream)
     seed = args.scale if args.seed is None else args.seed
     t_build = time.time()
-    g = rmat.rmat_csr(ctx, args.scale, args.edgefactor, seed=seed, weighted=False)
-    graph = mini_amd.Graph.from_device(ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"])
-    ro_host = g["row_offsets"].cpu().numpy()
+    if args.file:
+        n, ro_host, ci_host, w_host = mini_amd.load_mtx(args.file, undir=args.undirected)
+        graph = mini_amd.Graph.from_host(ctx, ro_host, ci_host, w_host)
+        if args.mode == "do" and not args.undirected:
+            graph.build_csc()
+        m = len(ci_host)
+        what = "%s%s" % (os.path.basename(args.file), " (undirected)" if args.undirected else "")
+    else:
+        g = rmat.rmat_csr(ctx, args.scale, args.edgefactor, seed=seed, weighted=False)
+        graph = mini_amd.Graph.from_device(ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"])
+        ro_host = g["row_offsets"].cpu().numpy()
+        ci_host = None
+        n, m = g["n"], g["m"]
+        what = "RMAT scale %d ef %d, symmetrised" % (args.scale, args.edgefactor)
     t_build = time.time() - t_build
     t_layout = time.time()
-    if not args.no_layout:
-        # hub-first layout (vertex ids by descending degree) for the LDS-resident hot bitmap; part of
-        # graph construction like the CSR build, not of the timed traversal; labels stay in original ids
+    use_layout = not args.no_layout and not (args.mode == "do" and args.file and not args.undirected)
+    if use_layout:
+        # hub-first layout (vertex ids by descending degree) + unit blocks of its long rows: part of graph construction
+        # like the CSR build, not of the timed traversal; labels stay in original ids
         graph.build_layout()          # mgx_graph_build_layout: device-side, inside the library
         torch.cuda.synchronize()
     t_layout = time.time() - t_layout
-    sources = rmat.pick_sources(ro_host, args.steps + args.warmup, seed)
+    if args.src is not None or args.file:
+        sources = [args.src or 0] * (args.steps + args.warmup)
+    else:
+        sources = rmat.pick_sources(ro_host, args.steps + args.warmup, seed)
     bfs = mini_amd.BfsProblem(graph, sources[0])
 
     mode = mini_amd.MGX_BFS_DIRECTION_OPT if args.mode == "do" else mini_amd.MGX_BFS_PUSH
@@ -107,7 +150,6 @@ def main():
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     stats = []
-    kernel_times = []
     t0 = time.perf_counter()
     ev0.record(stream)
     for s in sources[args.warmup:]:
@@ -116,16 +158,24 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
-    # Roofline pass: the SAME K sources again, now with HIP events around every launch of the two push kernels
-    # (on the launch stream).  It is a second pass because every event record between two kernels leaves a
-    # ~6 us gap on the stream (rocprofv3 kernel trace, profiles/), 3 events x ~8 levels per BFS: inside the timed
-    # region they would cost ~10 % of `value`.
-    bfs.set_kernel_timing(True)
-    stats_timed = []
+    # Roofline pass: the SAME K sources again, now with HIP events around every launch of the product kernel k_bfs_push
+    # (on the launch stream).  A second pass because every event record between two kernels leaves a ~6 us gap on the
+    # stream (rocprofv3 kernel trace, profiles/): inside the timed region they would cost several % of `value`.
+    bfs.set_kernel_timing(2)
+    stats_timed, kernel_times = [], []
     for s in sources[args.warmup:]:
         stats_timed.append(bfs.run(s, mode, args.alpha))
-        kernel_times.append(bfs.kernel_times())
-    bfs.set_kernel_timing(False)
+        kernel_times.append(bfs.kernel_times()["stream"])
+    # ... and once more with the launch split into its parts (long rows / short rows), for the breakdown only
+    bfs.set_kernel_timing(1)
+    parts = {"stream": {"launches": 0, "ns": 0, "edges": 0, "vertices": 0}, "wave": {"launches": 0, "ns": 0, "edges": 0, "vertices": 0}}
+    for s in sources[args.warmup:]:
+        bfs.run(s, mode, args.alpha)
+        k = bfs.kernel_times()
+        for name in parts:
+            for f in parts[name]:
+                parts[name][f] += k[name][f]
+    bfs.set_kernel_timing(0)
 
     m_t = sum(st["m_t"] for st in stats)
     reached = sum(st["reached"] for st in stats)
@@ -139,56 +189,57 @@ def main():
     alg_bytes = 8.0 * push_edges + 4.125 * pull_edges + 20.0 * nf_total
     value = m_t / elapsed / 1e6
 
-    # Dominant kernel: of the two push kernels (k_bfs_push_level_stream: rows of >= 64 edges read row-wise;
-    # k_bfs_push_level_wave: shorter rows, searched per edge rank) the one with more device time in the timed
-    # region.  achieved = algorithmic bytes of the edges / frontier vertices it processed / device time of
-    # ALL its launches (HIP events around every launch on the launch stream; launches that find nothing to
-    # do are included, as rocprofv3 --stats averages over them too).
-    kt = {"stream": {"launches": 0, "ns": 0, "edges": 0, "vertices": 0}, "wave": {"launches": 0, "ns": 0, "edges": 0, "vertices": 0}}
-    for k in kernel_times:
-        for name in kt:
-            for f in kt[name]:
-                kt[name][f] += k[name][f]
-    dom = "stream" if kt["stream"]["ns"] > kt["wave"]["ns"] else "wave"
-    dom_launches, dom_ns = kt[dom]["launches"], kt[dom]["ns"]
-    dom_edges, dom_vertices = kt[dom]["edges"], kt[dom]["vertices"]
-    if dom_launches and dom_ns and dom_edges:
-        kname = "k_bfs_push_level_" + dom
-        dom_bytes = 8.0 * dom_edges + 20.0 * dom_vertices
-        avg_launch_s = (dom_ns / 1e9) / dom_launches
-        bytes_per_launch = dom_bytes / dom_launches
-    else:                     # direction-optimising / other engines: all level kernels together
-        kname = "bfs level kernels (all)"
+    # Dominant kernel: k_bfs_push, ONE launch per slot.  achieved = algorithmic bytes of the edges / frontier vertices
+    # the push levels expanded / device time of ALL its launches (the ones that run a chain of small levels or find
+    # nothing to do included, as rocprofv3 --stats averages over them too).
+    dom = {f: sum(k[f] for k in kernel_times) for f in ("launches", "ns", "edges", "vertices")}
+    kname = "k_bfs_push<false, 0>"
+    if dom["launches"] and dom["ns"] and dom["edges"]:
+        dom_bytes = 8.0 * dom["edges"] + 20.0 * dom["vertices"]
+        avg_launch_s = (dom["ns"] / 1e9) / dom["launches"]
+        bytes_per_launch = dom_bytes / dom["launches"]
+    else:
         avg_launch_s = (kernel_ns / 1e9) / max(launches, 1)
         bytes_per_launch = alg_bytes / max(launches, 1)
+        kname = "bfs level kernels (all)"
     achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-    traffic = None
-    if os.path.exists(args.pmc_json):
+    sha = source_sha()
+    traffic, traffic_note = None, "no PMC measurement for these sources (profiles/pmc_traffic.json)"
+    if os.path.exists(args.pmc_json) and not args.file:
         try:
             pj = json.load(open(args.pmc_json))
-            if pj.get("scale") == args.scale and pj.get("kernel") == kname:
+            if pj.get("scale") == args.scale and pj.get("kernel") == kname and pj.get("source_sha") == sha and pj.get("mode") == args.mode:
                 traffic = pj.get("hbm_bytes_per_launch")
+                traffic_note = "2 x FETCH_SIZE + WRITE_SIZE per dispatch of this kernel, separate --pmc passes of this command (profiles/)"
+            else:
+                traffic_note = "profiles/pmc_traffic.json was measured on other sources/kernels (%s vs %s): not reported" % (pj.get("source_sha"), sha)
         except Exception:
             traffic = None
+    long_ns, short_ns = parts["stream"]["ns"], parts["wave"]["ns"]
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": traffic, "launches": dom_launches if dom_launches else launches,
-                "timing": "HIP events around every launch of this kernel, second pass over the same %d sources "
-                          "(events kept out of the timed region: each leaves a ~6 us gap on the stream; the timed "
-                          "region launches this kernel's body and the short-row body as ONE grid per level, "
-                          "k_bfs_push_level)" % len(stats),
+                "traffic": traffic, "traffic_note": traffic_note, "launches": dom["launches"] if dom["launches"] else launches,
+                "timing": "HIP events around every launch of this kernel on the launch stream, second pass over the same %d "
+                          "sources (events kept out of the timed region: each leaves a ~6 us gap on the stream)" % len(stats),
                 "avg_launch_us": round(avg_launch_s * 1e6, 3),
                 "alg_bytes_per_launch": round(bytes_per_launch, 1),
-                "share_of_edges": round(dom_edges / max(m_t, 1), 4) if dom_launches else 1.0,
+                "share_of_edges": round(dom["edges"] / max(m_t, 1), 4) if dom["launches"] else 1.0,
+                "parts": {"long_rows": {"alg_GBps": round((8.0 * parts["stream"]["edges"] + 20.0 * parts["stream"]["vertices"]) / max(long_ns, 1), 2),
+                                        "us_per_traversal": round(long_ns / 1e3 / max(len(stats), 1), 2), "edges_share": round(parts["stream"]["edges"] / max(m_t, 1), 4)},
+                          "short_rows": {"alg_GBps": round((8.0 * parts["wave"]["edges"] + 20.0 * parts["wave"]["vertices"]) / max(short_ns, 1), 2),
+                                         "us_per_traversal": round(short_ns / 1e3 / max(len(stats), 1), 2), "edges_share": round(parts["wave"]["edges"] / max(m_t, 1), 4)},
+                          "note": "third pass, the launch split into its parts (k_bfs_push<false, 2> / <false, 3>) with events around each"},
                 "all_level_kernels_alg_GBps": round(alg_bytes / max(kernel_ns / 1e9, 1e-12) / 1e9, 2),
-                "whole_bfs_alg_GBps": round(alg_bytes / (dev_ms / 1e3) / 1e9, 2)}
+                "whole_bfs_alg_GBps": round(alg_bytes / (dev_ms / 1e3) / 1e9, 2),
+                "whole_bfs_frac": round(alg_bytes / (dev_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 5)}
 
     cpu = None
     parity = None
     if not args.no_cpu_baseline or not args.no_check:
         from tests.oracle_binding import Oracle
         orc = Oracle()
-        ci_host = g["col_indices"].cpu().numpy()
+        if ci_host is None:
+            ci_host = g["col_indices"].cpu().numpy()
         deg = np.diff(ro_host)
         cpu_edges, cpu_time, used = 0, 0.0, 0
         for s in sources[args.warmup:]:
@@ -197,32 +248,39 @@ def main():
             cpu_time += time.perf_counter() - tc
             cpu_edges += int(deg[want >= 0].sum())
             used += 1
-            if used == 1 and not args.no_check:
+            if (used == 1 or args.validate) and not args.no_check:
                 bfs.run(s, mode, args.alpha)
-                parity = bool(np.array_equal(bfs.labels(), want))
-            if cpu_time > args.cpu_seconds or args.no_cpu_baseline:
+                ok = bool(np.array_equal(bfs.labels(), want))
+                parity = ok if parity is None else (parity and ok)
+            if (cpu_time > args.cpu_seconds or args.no_cpu_baseline) and not args.validate:
                 break
         if not args.no_cpu_baseline:
-            cpu = {"value": round(cpu_edges / cpu_time / 1e6, 2), "unit": "MTEPS", "cores": 1, "kind": "port",
+            cpu = {"value": round(cpu_edges / max(cpu_time, 1e-9) / 1e6, 2), "unit": "MTEPS", "cores": 1, "kind": "port",
                    "host_cpus": os.cpu_count(),
                    "sample": "oracle orc_bfs_cpu (restated bfs_problem_t::cpu) on %d of the %d timed sources, "
                              "same in-memory CSR, 1 thread, %.1f s" % (used, len(stats), cpu_time)}
 
-    out = {"metric": "MTEPS (million traversed edges/sec) BFS advance+filter, RMAT-%d" % args.scale,
+    out = {"metric": "MTEPS (million traversed edges/sec) BFS advance+filter, %s" % ("RMAT-%d" % args.scale if not args.file else os.path.basename(args.file)),
            "value": round(value, 2), "unit": "MTEPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 4), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-           "config": {"workload": "BFS %s (fused LB advance + idempotent-visited filter) on RMAT scale %d ef %d, "
-                                  "symmetrised, n=%d m=%d, %d seeded sources"
+           "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic" if not args.file else "file",
+           "config": {"workload": "BFS %s (fused LB advance + idempotent-visited filter) on %s, n=%d m=%d, %d %s; "
+                                  "untimed one-time preprocessing per graph: hub-first copy + unit blocks (layout_build_s)"
                                   % ("push" if args.mode == "push" else "direction-optimising alpha=%g" % args.alpha,
-                                     args.scale, args.edgefactor, g["n"], g["m"], args.steps),
-                      "scale": args.scale, "edgefactor": args.edgefactor, "seed": seed, "parallelism": "1 GPU",
-                      "layout": "generator ids" if args.no_layout else "hub-first (degree-sorted) copy for the fused kernel"},
+                                     what, n, m, args.steps, "seeded sources" if args.src is None and not args.file else "runs from source %d" % sources[0]),
+                      "scale": args.scale if not args.file else None, "edgefactor": args.edgefactor if not args.file else None,
+                      "seed": seed, "parallelism": "1 GPU",
+                      "layout": "hub-first (degree-sorted) copy + unit blocks for the fused kernel" if use_layout else "generator ids"},
            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity,
            "device_ms_per_step": round(dev_ms / max(args.steps, 1), 4),
            "avg_levels": round(sum(st["levels"] for st in stats) / max(len(stats), 1), 2),
-           "avg_reached": reached // max(len(stats), 1), "graph_build_s": round(t_build, 2), "layout_build_s": round(t_layout, 2)}
+           "avg_slots": round(sum(st["slots"] for st in stats) / max(len(stats), 1), 2),
+           "avg_reached": reached // max(len(stats), 1), "graph_build_s": round(t_build, 2), "layout_build_s": round(t_layout, 2),
+           "source_sha": sha}
     print(json.dumps(out), flush=True)
+    if parity is False:
+        print("bench.py: labels differ from the oracle's -- the line above is NOT a valid measurement", file=sys.stderr)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,192 @@
+"""bench_dist.py -- bench.py's body for N > 1 (one process per GPU, launched by torch.distributed.run; RCCL over xGMI).
+
+Part of the benchmark, not of the product: it drives mini_amd.dist_bfs (the partitioned traversal) and -- as bench.py
+does at N = 1 -- checks the first timed source against the CPU oracle before it prints the line.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from mini_amd.dist_bfs import (DistBfs, DistBfs2, HipRankEngine, HipRankEngine2, pick_sources_dist, rmat_cyclic_shard,
+                               rmat_shard_csr)
+
+
+def _tree_check_local(labels_new, ro_local, col, ranks, rank, src_new):
+    """BFS-tree properties of a gathered label array (hub-first global ids, device tensor) over the rows THIS rank owns
+    (vertex v = local row * ranks + rank; the graph is symmetric, so a vertex's row lists all its neighbours): every edge
+    spans at most one level and stays inside the reached set; every reached vertex other than the source has a neighbour
+    one level up.  Returns a bool."""
+    lab = labels_new.to(torch.int64)
+    nl = ro_local.numel() - 1
+    deg = (ro_local[1:] - ro_local[:-1]).to(torch.int64)
+    rows_local = torch.repeat_interleave(torch.arange(nl, device=lab.device), deg)
+    lu = lab[rows_local * ranks + rank]
+    lv = lab[col.to(torch.int64)]
+    reached = lu >= 0
+    ok = bool(((lv[reached] >= 0) & ((lv[reached] - lu[reached]).abs() <= 1)).all())
+    ok = ok and bool((lv[~reached] < 0).all())
+    big = torch.iinfo(torch.int64).max
+    best = torch.full((nl,), big, dtype=torch.int64, device=lab.device)
+    best.scatter_reduce_(0, rows_local, torch.where(lv >= 0, lv, torch.full_like(lv, big)), reduce="amin", include_self=True)
+    mine = lab[torch.arange(nl, device=lab.device) * ranks + rank]
+    need = (mine > 0)
+    ok = ok and bool((best[need] == mine[need] - 1).all())
+    if src_new % ranks == rank:
+        ok = ok and int(mine[src_new // ranks]) == 0
+    return ok
+
+
+def bench_main(args, rank, world, local_rank):
+    """bench.py body for N > 1 (one process per GPU, RCCL).  --scaling strong (default): the SAME RMAT-<scale> graph
+    partitioned over the N GPUs (the metric's "RMAT-22 @1/2/4/8"; --scale 26 at N = 8 is BASELINE config 5);
+    --scaling weak: RMAT-(scale + log2 N), a fixed share per GPU.  The first timed source is verified before the line
+    is printed: against the oracle (rank 0 rebuilds the whole graph; scales <= 23) or, above that, by the BFS-tree
+    properties over every rank's own rows."""
+    import json
+    import mini_amd
+    device = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream()
+    ctx = mini_amd.Context(local_rank, stream.cuda_stream)
+    weak = getattr(args, "scaling", "strong") == "weak"
+    gscale = args.scale + (int(np.log2(world)) if weak else 0)
+    seed = gscale if args.seed is None else args.seed
+    n = 1 << gscale
+    t_build = time.time()
+    verbose = os.environ.get("MGX_BENCH_VERBOSE") == "1"
+
+    def say(what):
+        if verbose:
+            print("[rank %d %.1f s] %s" % (rank, time.time() - t_build0, what), file=sys.stderr, flush=True)
+
+    t_build0 = t_build
+    gen = int(os.environ.get("MGX_DIST_GEN", "2"))
+    comm_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    if gen == 2:
+        ro, col, new_of_old, old_of_new, deg_new = rmat_cyclic_shard(ctx, gscale, args.edgefactor, seed, world, rank, device)
+        torch.cuda.synchronize()
+        t_build = time.time() - t_build
+        say("shard built: %d rows %d edges" % (ro.numel() - 1, col.numel()))
+        eng = HipRankEngine2(ctx, n, world, rank, ro, col)
+        bfs = DistBfs2(eng, rank, world, comm_dev)
+        from mini_amd.rmat import _mix64_py
+        cand = [int(_mix64_py(seed + k) % n) for k in range(8 * (args.steps + args.warmup) + 64)]
+        cand_new = new_of_old[torch.tensor(cand, device=device)].cpu().tolist()
+        cand_deg = deg_new[torch.tensor(cand_new, device=device)].cpu().tolist()
+        sources = [v for v, dg in zip(cand_new, cand_deg) if dg > 0][: args.steps + args.warmup]
+    else:
+        ro, col = rmat_shard_csr(ctx, gscale, args.edgefactor, seed, world, rank, device)
+        torch.cuda.synchronize()
+        t_build = time.time() - t_build
+        eng = HipRankEngine(ctx, n, world, rank, ro, col)
+        bfs = DistBfs(eng, rank, world, comm_dev)
+        ro_host = ro.cpu().numpy()
+        sources = pick_sources_dist(ro_host, eng.lo, eng.hi, n, args.steps + args.warmup, seed, device)
+        new_of_old = old_of_new = None
+    say("sources picked")
+    for s in sources[: args.warmup]:
+        st = bfs.run(s)
+        say("warmup traversal done: %s" % (st,))
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    edges_local, levels = 0, 0
+    for s in sources[args.warmup:]:
+        st = bfs.run(s)
+        say("traversal done: %s" % (st,))
+        edges_local += st["edges_local"]
+        levels += st["levels"]
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if comm_dev == "cuda" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    e = torch.tensor([edges_local], dtype=torch.int64, device=device if comm_dev == "cuda" else "cpu")
+    dist.all_reduce(e)
+    m_t = int(e.item())
+
+    # ---- parity of the first timed source (untimed) ---------------------------------------------------------------
+    parity, parity_how, cpu = None, None, None
+    if not args.no_check and args.steps > 0:
+        src = sources[args.warmup]
+        bfs.run(src)
+        labels = bfs.gather_labels()                       # every rank: global labels (generation 2: hub-first ids)
+        if gscale <= 23 and os.environ.get("MGX_BENCH_TREE_CHECK") != "1":     # (the switch: pre-flight of the other branch)
+            ok = 1
+            if rank == 0:
+                from mini_amd import rmat as rmat_mod
+                from tests.oracle_binding import Oracle
+                orc = Oracle()
+                g = rmat_mod.rmat_csr(ctx, gscale, args.edgefactor, seed=seed, weighted=False)
+                ro_h, ci_h = g["row_offsets"].cpu().numpy(), g["col_indices"].cpu().numpy()
+                del g
+                if gen == 2:
+                    o2n = old_of_new.cpu().numpy()
+                    src_old = int(o2n[src])
+                else:
+                    o2n, src_old = None, src
+                tc = time.perf_counter()
+                want = orc.bfs_cpu(ro_h, ci_h, src_old)
+                cpu_time = time.perf_counter() - tc
+                deg_h = np.diff(ro_h)
+                cpu_edges, used = int(deg_h[want >= 0].sum()), 1
+                ok = int(np.array_equal(labels, want[o2n] if o2n is not None else want))
+                if not args.no_cpu_baseline:
+                    for s2 in sources[args.warmup + 1:]:
+                        if cpu_time > args.cpu_seconds:
+                            break
+                        s2_old = int(o2n[s2]) if o2n is not None else s2
+                        tc = time.perf_counter()
+                        w2 = orc.bfs_cpu(ro_h, ci_h, s2_old)
+                        cpu_time += time.perf_counter() - tc
+                        cpu_edges += int(deg_h[w2 >= 0].sum()); used += 1
+                    cpu = {"value": round(cpu_edges / max(cpu_time, 1e-9) / 1e6, 2), "unit": "MTEPS", "cores": 1, "kind": "port",
+                           "host_cpus": os.cpu_count(),
+                           "sample": "oracle orc_bfs_cpu (restated bfs_problem_t::cpu) on %d of the %d timed sources, the whole "
+                                     "graph rebuilt on rank 0, 1 thread, %.1f s" % (used, args.steps, cpu_time)}
+            flag = torch.tensor([ok], dtype=torch.int64, device=device if comm_dev == "cuda" else "cpu")
+            dist.broadcast(flag, 0)
+            parity, parity_how = bool(flag.item()), "labels of the first timed source == oracle (rank 0, whole graph)"
+        elif gen == 2:
+            lab_dev = torch.from_numpy(labels).to(device)
+            ok = int(_tree_check_local(lab_dev, ro, col, world, rank, src))
+            flag = torch.tensor([ok], dtype=torch.int64, device=device if comm_dev == "cuda" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            parity, parity_how = bool(flag.item()), "BFS-tree properties of the first timed source's labels over every rank's rows"
+    if rank == 0:
+        value = m_t / elapsed / 1e6
+        exch = ("one RCCL all-gather per level" if getattr(bfs, "exchange", "gather") == "gather"
+                else "RCCL all-to-all of slices + all-gather of the merged slices per level")
+        out = {"metric": "MTEPS (million traversed edges/sec) BFS advance+filter, RMAT-%d" % gscale,
+               "value": round(value, 2), "unit": "MTEPS", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 4),
+               "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "int32",
+               "data": "synthetic",
+               "config": {"workload": "BFS push on RMAT scale %d ef %d, symmetrised (%s), hub-first ids, cyclic vertex partition "
+                                      "over %d GPUs, fused level kernels per rank, new-visited bitmaps OR-ed across ranks (%s), "
+                                      "%d seeded sources" % (gscale, args.edgefactor,
+                                                             "weak scaling: scale %d per GPU + log2 N" % args.scale if weak else
+                                                             "strong scaling: the same graph for every N" + ("; BASELINE config 5" if gscale == 26 and world == 8 else ""),
+                                                             world, exch, args.steps),
+                          "scale": gscale, "edgefactor": args.edgefactor, "seed": seed,
+                          "parallelism": "vertex-cyclic x%d" % world},
+               "roofline": {"bound": "hbm", "kernel": "k_bfs_push_level (per rank)",
+                            "achieved": round(8.0 * m_t / world / elapsed / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
+                            "frac": round(8.0 * m_t / world / elapsed / 1e9 / 8000.0, 5), "traffic": None,
+                            "note": "per-GPU algorithmic bytes (8 B/edge) over the whole superstep loop incl. exchange"},
+               "cpu_baseline": cpu, "parity_vs_oracle": parity, "parity_check": parity_how,
+               "avg_levels": round(levels / max(args.steps, 1), 2),
+               "graph_build_s": round(t_build, 2)}
+        print(json.dumps(out), flush=True)
+        if parity is False:
+            print("bench.py: the partitioned traversal's labels failed the check -- the line above is NOT a valid measurement", file=sys.stderr)
+    dist.barrier()
+    dist.destroy_process_group()
+    if parity is False:
+        sys.exit(1)

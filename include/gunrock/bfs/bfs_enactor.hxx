@@ -187,7 +187,10 @@ struct bfs_fused_enactor_t {
     last.wave.ns = (long long)(fused->wave_kernel_ms * 1e6);
     long long push_vertices = 0;
     for (int i = 0; i < last.push_levels && i < (int)last.trace.size(); ++i) push_vertices += last.trace[i].first;
-    if (!direction_optimizing) {
+    if (fused->time_kernels == 2) {            // the merged push launch: everything the push levels expanded
+      last.stream.edges = last.push_edges;
+      last.stream.vertices = push_vertices;
+    } else if (!direction_optimizing) {
       last.stream.edges = (long long)hc->sum_long_edges;
       last.stream.vertices = (long long)hc->sum_long_vertices;
       last.wave.edges = last.push_edges - last.stream.edges;

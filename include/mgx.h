@@ -85,6 +85,13 @@ MGX_API int mgx_graph_attach_layout_weights(mgx_graph_t g, const float* d_layout
 MGX_API int mgx_graph_build_layout(mgx_graph_t g, int with_weights);
 MGX_API int mgx_graph_layout_read(mgx_graph_t g, int* h_row_offsets, int* h_col_indices, int* h_new_of_old,
                                   int* h_old_of_new, float* h_weights);
+/* Genuine CSC (the transpose) built by the library from the graph's own CSR, device-side (one stable radix sort of the
+ * edges by destination), owned by the graph: col_offsets / row_indices (sources of every vertex's in-edges, ascending) /
+ * row_values.  What bottom-up BFS levels need on DIRECTED inputs (BASELINE config 4); the reference's load_graph means to
+ * build it (graph.hxx:176-222) but returns the CSR in the CSC slots.  mgx_graph_csc_read copies the CSC slots
+ * to host buffers (NULL: skip; sizes n + 1, m, m) -- whatever they hold, alias or transpose. */
+MGX_API int mgx_graph_build_csc(mgx_graph_t g);
+MGX_API int mgx_graph_csc_read(mgx_graph_t g, int* h_col_offsets, int* h_row_indices, float* h_row_values);
 MGX_API int mgx_graph_free(mgx_graph_t g);
 MGX_API int mgx_graph_dims(mgx_graph_t g, int* num_nodes, int64_t* num_edges);
 /* host-side MTX text loader, bug-compatible with load_graph (graph.hxx:96-223): row = 2nd
@@ -93,6 +100,12 @@ MGX_API int mgx_graph_dims(mgx_graph_t g, int* num_nodes, int64_t* num_edges);
 MGX_API int mgx_load_mtx(const char* path, int undir, int random_edge_value,
                          int* num_nodes, int64_t* num_edges,
                          int** row_offsets, int** col_indices, float** weights);
+/* The same plus the loader's CSC slots: the CSR again (what the reference always returns) or, with
+ * genuine_csc != 0 and undir == 0, the transpose (load_graph's _genuine_csc option: what graph.hxx:176-222 means to
+ * build).  Six malloc'd arrays to be released with mgx_host_free.                                  */
+MGX_API int mgx_load_mtx_csc(const char* path, int undir, int random_edge_value, int genuine_csc,
+                             int* num_nodes, int64_t* num_edges, int** row_offsets, int** col_indices, float** weights,
+                             int** col_offsets, int** row_indices, float** row_weights);
 MGX_API void mgx_host_free(void* p);
 
 /* ---- frontier: replaces frontier_t<int> (frontier.hxx:12-99) ---- */
@@ -179,8 +192,11 @@ MGX_API int mgx_bfs_level_trace(mgx_bfs_t p, int cap, int64_t* level_nf, int64_t
 /* device time (ms, HIP events) of each launch batch of the last mgx_bfs_run; with the environment
  * variable MGX_BFS_LEVELS_PER_SYNC=1 a batch is exactly one level kernel                   */
 /* Per-launch timing of the push kernels is OFF by default: every hipEventRecord between two kernels leaves a
- * ~6 us gap on the stream (measured, rocprofv3 kernel trace).  on != 0: following mgx_bfs_run calls record events
- * around both push kernels of every level and fill mgx_bfs_kernel_times / mgx_bfs_level_kernel_times. */
+ * ~6 us gap on the stream (measured, rocprofv3 kernel trace).  on == 1: following mgx_bfs_run calls launch the parts of
+ * a slot's push (long rows, short rows) separately with events around each and fill mgx_bfs_kernel_times /
+ * mgx_bfs_level_kernel_times; on == 2: events around the ONE merged push launch of every slot (k_bfs_push, the kernel a
+ * traversal actually runs): its launches and time are reported in the "stream" half of mgx_bfs_kernel_times with ALL
+ * push edges and frontier vertices, the "wave" half is zero. */
 MGX_API int mgx_bfs_set_kernel_timing(mgx_bfs_t p, int on);
 /* the two push kernels of the last mgx_bfs_run, timed per launch with HIP events on the context's stream:
  * out8 = { stream launches, ns, edges, frontier vertices,  wave launches, ns, edges, frontier vertices }

@@ -433,7 +433,8 @@ struct bfs_fused_state_t {
                                      // 1 / dense_div of the units (bfs_fused_dense.hpp; 0: never)
   int long_min = 64;                 // rows at least this long go to the long-row queue (0: no such queue)
   bool count_marks = false;          // see bfs_fused_args_t::count_marks (MGX_BFS_COUNT_MARKS; on with time_kernels)
-  bool time_kernels = false;         // record HIP events around the two push kernels of every level (each event
+  int time_kernels = 0;              // 1: the push parts as separate launches, HIP events around each; 2: events around the
+                                     // ONE merged push launch of every slot (the product kernel; -> stream_kernel_ms) (each event
                                      // leaves a ~6 us gap on the stream: profiling runs only)
   unsigned hot_min_edges = 65536;    // smaller levels probe the bitmap in L2 instead of copying its hot prefix to LDS
   // timing of the level kernels of the last run (HIP events around each batch of launches)
@@ -472,7 +473,7 @@ struct bfs_fused_state_t {
     MGX_HIP(hipEventCreate(&ev1));
     for (int i = 0; i < EV_POOL; ++i) MGX_HIP(hipEventCreate(&wev[i]));
     if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e) > 0 ? atoi(e) : 0;
-    if (const char* e = getenv("MGX_BFS_TIME_KERNELS")) time_kernels = atoi(e) != 0;
+    if (const char* e = getenv("MGX_BFS_TIME_KERNELS")) time_kernels = atoi(e);
     if (const char* e = getenv("MGX_BFS_COUNT_MARKS")) count_marks = atoi(e) != 0;
     if (const char* e = getenv("MGX_BFS_TIME_BATCHES")) time_batches = atoi(e) != 0;
     if (const char* e = getenv("MGX_BFS_HOT_MIN_EDGES")) hot_min_edges = (unsigned)atoll(e);

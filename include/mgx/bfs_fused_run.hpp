@@ -209,7 +209,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.ctrl = st.ctrl.data();
   a.n = st.n;
   a.flags = opt.flags;
-  a.count_marks = (st.count_marks || st.time_kernels) ? 1 : 0;
+  a.count_marks = (st.count_marks || st.time_kernels == 1) ? 1 : 0;
   const bool coldt = bfs_cold_test(a.n, opt.cold_test);
   // unit blocks: only for the CSR they were built from, with the long-row threshold they were built for, and not on
   // graphs whose cold neighbours are probed (the dense body marks them untested)
@@ -231,7 +231,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   st.stream_kernel_ms = 0.0;
   st.stream_kernel_launches = 0;
   st.batches = 0;
-  const bool batch_events = st.time_kernels || st.time_batches;    // (an event costs ~6 us of stream gap)
+  const bool batch_events = st.time_kernels != 0 || st.time_batches;    // (an event costs ~6 us of stream gap)
   const u32 nstream = a.long_min > 0 ? (u32)ctx.num_cus * 2 : 0u;
   const u32 nwave = (u32)ctx.num_cus * 2;
   int slot = 0;
@@ -242,8 +242,16 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
     if (batch_events) MGX_HIP(hipEventRecord(st.ev0, s));
     for (int i = 0; i < nslots; ++i, ++slot) {
       const int arg = bfs_slot_arg(slot);
-      const bool timed = st.time_kernels && 3 * i + 2 < bfs_fused_state_t::EV_POOL;
-      if (timed || !opt.merged || a.flags) {
+      const bool in_pool = 3 * i + 2 < bfs_fused_state_t::EV_POOL;
+      const bool timed = st.time_kernels == 1 && in_pool;
+      const bool timed_merged = st.time_kernels == 2 && in_pool && opt.merged && !a.flags;
+      if (timed_merged) {
+        // the product launch itself between two events: its average duration is what rocprofv3 --stats reports for
+        // k_bfs_push<., 0> too (launches of small or empty slots included on both sides)
+        MGX_HIP(hipEventRecord(st.wev[3 * i], s));
+        bfs_launch_push_part<0>(a, arg, ctx, coldt, nstream + nwave, nstream);
+        MGX_HIP(hipEventRecord(st.wev[3 * i + 1], s));
+      } else if (timed || !opt.merged || a.flags) {
         // the parts as launches of their own: opener / chain, long rows, short rows
         bfs_launch_push_part<1>(a, arg, ctx, coldt, 1, 0);
         if (timed) MGX_HIP(hipEventRecord(st.wev[3 * i], s));
@@ -273,6 +281,14 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
     for (int i = 0; st.time_kernels && i < nslots && 3 * i + 2 < bfs_fused_state_t::EV_POOL; ++i) {
       const int sl = slot - nslots + i;
       float wms = 0.f;
+      if (st.time_kernels == 2) {
+        if (!(opt.merged && !a.flags)) break;
+        MGX_HIP(hipEventElapsedTime(&wms, st.wev[3 * i], st.wev[3 * i + 1]));
+        st.stream_kernel_ms += wms;
+        st.stream_kernel_launches += 1;
+        if (sl < 64) { st.level_stream_ms[sl] = wms; st.level_wave_ms[sl] = 0.f; }
+        continue;
+      }
       MGX_HIP(hipEventElapsedTime(&wms, st.wev[3 * i + 1], st.wev[3 * i + 2]));
       st.wave_kernel_ms += wms;
       st.wave_kernel_launches += 1;

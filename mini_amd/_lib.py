@@ -63,10 +63,14 @@ SIGNATURES = {
     "mgx_graph_attach_layout": [_vp, _vp, _vp, _vp, _vp],
     "mgx_graph_attach_layout_weights": [_vp, _vp],
     "mgx_graph_build_layout": [_vp, _i],
+    "mgx_graph_build_csc": [_vp],
+    "mgx_graph_csc_read": [_vp, _vp, _vp, _vp],
     "mgx_graph_layout_read": [_vp, _vp, _vp, _vp, _vp, _vp],
     "mgx_graph_free": [_vp],
     "mgx_graph_dims": [_vp, _pi, _pi64],
     "mgx_load_mtx": [C.c_char_p, _i, _i, _pi, _pi64, C.POINTER(_pi), C.POINTER(_pi), C.POINTER(_pf)],
+    "mgx_load_mtx_csc": [C.c_char_p, _i, _i, _i, _pi, _pi64, C.POINTER(_pi), C.POINTER(_pi), C.POINTER(_pf),
+                         C.POINTER(_pi), C.POINTER(_pi), C.POINTER(_pf)],
     "mgx_host_free": [_vp],
     "mgx_frontier_create": [_vp, _i64, _pvp],
     "mgx_frontier_free": [_vp],

@@ -103,6 +103,21 @@ class Graph:
         check(lib.mgx_graph_build_layout(self._h, int(bool(weights))))
         return self
 
+    def build_csc(self):
+        """Genuine CSC (transpose) built by the library on the device (mgx_graph_build_csc): in-edges for the bottom-up
+        levels on directed graphs."""
+        check(lib.mgx_graph_build_csc(self._h))
+        return self
+
+    def csc_arrays(self):
+        """(col_offsets, row_indices, row_values) of the CSC slots as host numpy arrays"""
+        n, m = self.num_nodes, self.num_edges
+        co, ri = np.empty(n + 1, dtype=np.int32), np.empty(max(m, 1), dtype=np.int32)
+        rv = np.empty(max(m, 1), dtype=np.float32)
+        check(lib.mgx_graph_csc_read(self._h, co.ctypes.data_as(C.c_void_p), ri.ctypes.data_as(C.c_void_p),
+                                     rv.ctypes.data_as(C.c_void_p)))
+        return co, ri[:m], rv[:m]
+
     def layout_arrays(self, weights=False):
         """(layout_row_offsets, layout_col_indices, new_of_old, old_of_new[, layout_weights]) as host numpy arrays"""
         n, m = self.num_nodes, self.num_edges
@@ -121,22 +136,28 @@ class Graph:
             self._h = None
 
 
-def load_mtx(path, undir=False, random_edge_value=False):
-    """load_graph (graph.hxx:96-223) -> (n, row_offsets, col_indices, weights) on the host."""
+def load_mtx(path, undir=False, random_edge_value=False, genuine_csc=None):
+    """load_graph (graph.hxx:96-223) -> (n, row_offsets, col_indices, weights) on the host; with genuine_csc given
+    (True / False) also the loader's CSC slots: (..., col_offsets, row_indices, row_weights)."""
     n, m = C.c_int(), C.c_int64()
-    ro, ci, w = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_float)()
-    check(lib.mgx_load_mtx(str(path).encode(), int(undir), int(random_edge_value), C.byref(n), C.byref(m),
-                           C.byref(ro), C.byref(ci), C.byref(w)))
+    ptrs = [C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_float)()]
+    if genuine_csc is None:
+        check(lib.mgx_load_mtx(str(path).encode(), int(undir), int(random_edge_value), C.byref(n), C.byref(m),
+                               *[C.byref(p) for p in ptrs]))
+    else:
+        ptrs += [C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_float)()]
+        check(lib.mgx_load_mtx_csc(str(path).encode(), int(undir), int(random_edge_value), int(bool(genuine_csc)),
+                                   C.byref(n), C.byref(m), *[C.byref(p) for p in ptrs]))
     N, M = n.value, m.value
     try:
-        offsets = np.ctypeslib.as_array(ro, (N + 1,)).copy()
-        indices = np.ctypeslib.as_array(ci, (max(M, 1),))[:M].copy()
-        weights = np.ctypeslib.as_array(w, (max(M, 1),))[:M].copy()
+        out = []
+        for i, p in enumerate(ptrs):
+            cnt = N + 1 if i % 3 == 0 else M
+            out.append(np.ctypeslib.as_array(p, (max(cnt, 1),))[:cnt].copy())
     finally:
-        lib.mgx_host_free(ro)
-        lib.mgx_host_free(ci)
-        lib.mgx_host_free(w)
-    return N, offsets, indices, weights
+        for p in ptrs:
+            lib.mgx_host_free(p)
+    return (N,) + tuple(out)
 
 
 class Frontier:
@@ -282,8 +303,9 @@ class BfsProblem:
         return [(nf[i], ne[i]) for i in range(L)]
 
     def set_kernel_timing(self, on=True):
-        """events around every push-kernel launch (costs ~6 us of stream gap per event: profiling runs only)"""
-        check(lib.mgx_bfs_set_kernel_timing(self._h, int(bool(on))))
+        """events around every push-kernel launch (costs ~6 us of stream gap per event: profiling runs only).
+        True / 1: the parts of a slot's push as separate launches; 2: the one merged launch a traversal really runs"""
+        check(lib.mgx_bfs_set_kernel_timing(self._h, int(on)))
 
     def kernel_times(self):
         """per-launch timing of the two push kernels of the last run()"""

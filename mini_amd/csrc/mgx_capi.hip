@@ -367,6 +367,39 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
   build_unit_blocks(g);
   MGX_CATCH
 }
+extern "C" int mgx_csc_build_device(const int* ro, const int* ci, const float* w, int n, long long m, int* co, int* ri, float* rv,
+                                    hipStream_t stream);   // mgx_layout.hip
+int mgx_graph_build_csc(mgx_graph_t g) {
+  MGX_TRY
+  MGX_REQUIRE(g, "graph is NULL");
+  use_device(g->c);
+  standard_context_t& ctx = *g->c->ctx;
+  graph_device_t& G = *g->g;
+  const size_t n = (size_t)G.num_nodes, m = (size_t)G.num_edges;
+  ctx.synchronize();
+  mem_t<int> co(n + 1, ctx), ri(m, ctx);
+  mem_t<float> rv(m, ctx);
+  const int rc = mgx_csc_build_device(G.d_row_offsets.data(), G.d_col_indices.data(), G.d_col_values.data(), (int)n, (long long)m,
+                                      co.data(), ri.data(), rv.data(), ctx.stream());
+  if (rc != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("mgx_graph_build_csc: ") + hipGetErrorString((hipError_t)rc));
+  G.d_col_offsets = std::move(co);
+  G.d_row_indices = std::move(ri);
+  G.d_row_values = std::move(rv);
+  G.csc_is_csr = false;
+  MGX_CATCH
+}
+int mgx_graph_csc_read(mgx_graph_t g, int* h_col_offsets, int* h_row_indices, float* h_row_values) {
+  MGX_TRY
+  MGX_REQUIRE(g, "graph is NULL");
+  use_device(g->c);
+  g->c->ctx->synchronize();
+  graph_device_t& G = *g->g;
+  const size_t n = (size_t)G.num_nodes, m = (size_t)G.num_edges;
+  if (h_col_offsets) MGX_HIP(mgx::dtoh(h_col_offsets, G.d_col_offsets.data(), n + 1));
+  if (h_row_indices && m) MGX_HIP(mgx::dtoh(h_row_indices, G.d_row_indices.data(), m));
+  if (h_row_values && m) MGX_HIP(mgx::dtoh(h_row_values, G.d_row_values.data(), m));
+  MGX_CATCH
+}
 int mgx_graph_layout_read(mgx_graph_t g, int* h_row_offsets, int* h_col_indices, int* h_new_of_old, int* h_old_of_new,
                           float* h_weights) {
   MGX_TRY
@@ -412,6 +445,21 @@ int mgx_load_mtx(const char* path, int undir, int random_w, int* n, int64_t* m, 
   memcpy(*ro, g->csr->offsets.data(), ((size_t)g->num_nodes + 1) * sizeof(int));
   memcpy(*ci, g->csr->indices.data(), (size_t)g->num_edges * sizeof(int));
   memcpy(*w, g->csr->edge_weights.data(), (size_t)g->num_edges * sizeof(float));
+  MGX_CATCH
+}
+int mgx_load_mtx_csc(const char* path, int undir, int random_w, int genuine_csc, int* n, int64_t* m, int** ro, int** ci,
+                     float** w, int** co, int** ri, float** rw) {
+  MGX_TRY
+  MGX_REQUIRE(path && n && m && ro && ci && w && co && ri && rw, "mgx_load_mtx_csc: NULL argument");
+  auto g = load_graph(path, undir != 0, random_w != 0, genuine_csc != 0);
+  MGX_REQUIRE(g != nullptr, std::string("mgx_load_mtx_csc: cannot read ") + path);
+  *n = g->num_nodes;
+  *m = g->num_edges;
+  const size_t N = (size_t)g->num_nodes, M = (size_t)g->num_edges;
+  auto dup_i = [](const std::vector<int>& v, size_t cnt) { int* p = (int*)malloc((cnt + 1) * sizeof(int)); memcpy(p, v.data(), cnt * sizeof(int)); return p; };
+  auto dup_f = [](const std::vector<float>& v, size_t cnt) { float* p = (float*)malloc((cnt + 1) * sizeof(float)); memcpy(p, v.data(), cnt * sizeof(float)); return p; };
+  *ro = dup_i(g->csr->offsets, N + 1); *ci = dup_i(g->csr->indices, M); *w = dup_f(g->csr->edge_weights, M);
+  *co = dup_i(g->csc->offsets, N + 1); *ri = dup_i(g->csc->indices, M); *rw = dup_f(g->csc->edge_weights, M);
   MGX_CATCH
 }
 void mgx_host_free(void* p) { free(p); }
@@ -699,7 +747,7 @@ int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats) {
   use_device(p->g->c);
   standard_context_t& ctx = *p->g->c->ctx;
   if (!p->fe) p->fe.reset(new bfs::bfs_fused_enactor_t(ctx, p->g->g->num_nodes));
-  if (p->time_kernels >= 0) p->fe->fused->time_kernels = p->time_kernels != 0;
+  if (p->time_kernels >= 0) p->fe->fused->time_kernels = p->time_kernels;
   p->p->src = src;
   p->fe->enact(p->p, ctx, mode == MGX_BFS_DIRECTION_OPT, alpha);
   const bfs::bfs_run_stats_t& L = p->fe->last;
@@ -740,7 +788,7 @@ int mgx_bfs_level_trace(mgx_bfs_t p, int cap, int64_t* level_nf, int64_t* level_
 int mgx_bfs_set_kernel_timing(mgx_bfs_t p, int on) {
   MGX_TRY
   MGX_REQUIRE(p, "NULL argument");
-  p->time_kernels = on ? 1 : 0;
+  p->time_kernels = on < 0 ? 0 : on;
   MGX_CATCH
 }
 int mgx_bfs_kernel_times(mgx_bfs_t p, int64_t* out8) {

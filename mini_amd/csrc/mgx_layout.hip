@@ -194,3 +194,69 @@ extern "C" int mgx_units_build_device(const int* ro, const int* ci, int n, int m
   *units = U; *units_pad = Up;
   return 0;
 }
+
+// ---- genuine CSC (transpose) of a device CSR ------------------------------------------------------------------------
+// The reference's loader always ends up with csc == csr (its transposed copy goes into a shadowed local), which
+// is only right for symmetric inputs.  Bottom-up BFS levels on a DIRECTED graph need the in-edges: col_offsets[v] ..
+// col_offsets[v + 1] index row_indices (the sources of v's in-edges, ascending) and row_values (their weights).
+// One stable radix sort of the edge numbers by destination: sources come out ascending inside every column because the
+// CSR lists its edges by ascending row.
+namespace {
+
+__global__ void k_edge_rows(const int* __restrict__ ro, int n, long long m, int* __restrict__ row_of_edge, int* __restrict__ edge_id) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < m; e += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n;                       // last row with ro[row] <= e
+    while (hi - lo > 1) {
+      const int mid = lo + (hi - lo) / 2;
+      if ((long long)ro[mid] <= e) lo = mid; else hi = mid;
+    }
+    row_of_edge[e] = lo;
+    edge_id[e] = (int)e;
+  }
+}
+
+__global__ void k_csc_gather(const int* __restrict__ sorted_edge, const int* __restrict__ row_of_edge, const float* __restrict__ w,
+                             long long m, int* __restrict__ row_indices, float* __restrict__ row_values) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
+    const int e = sorted_edge[i];
+    row_indices[i] = row_of_edge[e];
+    if (row_values) row_values[i] = w ? w[e] : 1.0f;
+  }
+}
+
+// col_offsets[v] = first position of the sorted destinations that is >= v
+__global__ void k_csc_offsets(const int* __restrict__ sorted_dst, long long m, int n, int* __restrict__ col_offsets) {
+  const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v > n) return;
+  long long lo = 0, hi = m;                   // first i with sorted_dst[i] >= v
+  while (lo < hi) {
+    const long long mid = lo + (hi - lo) / 2;
+    if (sorted_dst[mid] < (int)v) lo = mid + 1; else hi = mid;
+  }
+  col_offsets[v] = (int)lo;
+}
+
+}  // namespace
+
+// co: n + 1 ints, ri: m ints, rv: m floats or NULL (device, caller-allocated).  w may be NULL (unit weights).
+extern "C" int mgx_csc_build_device(const int* ro, const int* ci, const float* w, int n, long long m, int* co, int* ri, float* rv,
+                                    hipStream_t stream) {
+  if (n < 0) return 0;
+  if (m <= 0) { LAY_TRY(hipMemsetAsync(co, 0, ((size_t)n + 1) * 4, stream)); return (int)hipStreamSynchronize(stream); }
+  tmp_t row_of_edge, edge_id, sorted_dst, sorted_edge, scratch;
+  LAY_TRY(row_of_edge.alloc((size_t)m * 4)); LAY_TRY(edge_id.alloc((size_t)m * 4));
+  LAY_TRY(sorted_dst.alloc((size_t)m * 4)); LAY_TRY(sorted_edge.alloc((size_t)m * 4));
+  hipLaunchKernelGGL(k_edge_rows, dim3(8192), dim3(256), 0, stream, ro, n, m, row_of_edge.as<int>(), edge_id.as<int>());
+  int bits = 1;
+  while (bits < 32 && (1ll << bits) < (long long)n) ++bits;
+  size_t bytes = 0;
+  LAY_TRY(rocprim::radix_sort_pairs(nullptr, bytes, ci, sorted_dst.as<int>(), edge_id.as<int>(), sorted_edge.as<int>(), (size_t)m, 0,
+                                    bits, stream));
+  LAY_TRY(scratch.alloc(bytes));
+  LAY_TRY(rocprim::radix_sort_pairs(scratch.p, bytes, ci, sorted_dst.as<int>(), edge_id.as<int>(), sorted_edge.as<int>(), (size_t)m,
+                                    0, bits, stream));
+  hipLaunchKernelGGL(k_csc_gather, dim3(8192), dim3(256), 0, stream, sorted_edge.as<int>(), row_of_edge.as<int>(), w, m, ri, rv);
+  hipLaunchKernelGGL(k_csc_offsets, dim3((unsigned)(((long long)n + 1 + 255) / 256)), dim3(256), 0, stream, sorted_dst.as<int>(), m, n, co);
+  LAY_TRY(hipStreamSynchronize(stream));
+  return 0;
+}

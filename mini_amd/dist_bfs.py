@@ -428,93 +428,3 @@ def pick_sources_dist(row_offsets_local, lo, hi, n_global, count, seed, comm_dev
         dist.all_reduce(f)
         flags = f.cpu()
     return [v for v, ok in zip(cand, flags.tolist()) if ok][:count]
-
-
-def bench_main(args, rank, world, local_rank):
-    """bench.py body for N > 1 (one process per GPU, RCCL).  Weak scaling: per-GPU graph share fixed,
-    global scale = --scale + log2(N) (Graph500-style)."""
-    import json
-    import mini_amd
-    device = torch.device("cuda", local_rank)
-    stream = torch.cuda.current_stream()
-    ctx = mini_amd.Context(local_rank, stream.cuda_stream)
-    gscale = args.scale + int(np.log2(world))
-    seed = gscale if args.seed is None else args.seed
-    n = 1 << gscale
-    t_build = time.time()
-    verbose = os.environ.get("MGX_BENCH_VERBOSE") == "1"
-
-    def say(what):
-        if verbose:
-            print("[rank %d %.1f s] %s" % (rank, time.time() - t_build0, what), file=sys.stderr, flush=True)
-
-    t_build0 = t_build
-    gen = int(os.environ.get("MGX_DIST_GEN", "2"))
-    if gen == 2:
-        ro, col, new_of_old, old_of_new, deg_new = rmat_cyclic_shard(ctx, gscale, args.edgefactor, seed, world, rank, device)
-        torch.cuda.synchronize()
-        t_build = time.time() - t_build
-        say("shard built: %d rows %d edges" % (ro.numel() - 1, col.numel()))
-        eng = HipRankEngine2(ctx, n, world, rank, ro, col)
-        bfs = DistBfs2(eng, rank, world, "cuda" if dist.get_backend() == "nccl" else "cpu")
-        from .rmat import _mix64_py
-        sources, i, deg_host = [], 0, None
-        cand = [int(_mix64_py(seed + k) % n) for k in range(8 * (args.steps + args.warmup) + 64)]
-        cand_new = new_of_old[torch.tensor(cand, device=device)].cpu().tolist()
-        cand_deg = deg_new[torch.tensor(cand_new, device=device)].cpu().tolist()
-        sources = [v for v, dg in zip(cand_new, cand_deg) if dg > 0][: args.steps + args.warmup]
-    else:
-        ro, col = rmat_shard_csr(ctx, gscale, args.edgefactor, seed, world, rank, device)
-        torch.cuda.synchronize()
-        t_build = time.time() - t_build
-        eng = HipRankEngine(ctx, n, world, rank, ro, col)
-        bfs = DistBfs(eng, rank, world, "cuda")
-        ro_host = ro.cpu().numpy()
-        sources = pick_sources_dist(ro_host, eng.lo, eng.hi, n, args.steps + args.warmup, seed, device)
-    say("sources picked")
-    for s in sources[: args.warmup]:
-        st = bfs.run(s)
-        say("warmup traversal done: %s" % (st,))
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    edges_local, levels = 0, 0
-    for s in sources[args.warmup:]:
-        st = bfs.run(s)
-        say("traversal done: %s" % (st,))
-        edges_local += st["edges_local"]
-        levels += st["levels"]
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    e = torch.tensor([edges_local], dtype=torch.int64, device=device)
-    dist.all_reduce(e)
-    m_t = int(e.item())
-    if rank == 0:
-        value = m_t / elapsed / 1e6
-        out = {"metric": "MTEPS (million traversed edges/sec) BFS advance+filter, RMAT-%d" % gscale,
-               "value": round(value, 2), "unit": "MTEPS", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 4),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
-               "data": "synthetic",
-               "config": {"workload": "BFS push on RMAT scale %d (= %d per GPU + log2 N) ef %d, symmetrised, "
-                                      "hub-first ids, cyclic vertex partition over %d GPUs, fused level kernels per rank, new-visited bitmaps OR-ed across ranks (%s), "
-                                      "%d seeded sources" % (gscale, args.scale, args.edgefactor, world,
-                                                             "one RCCL all-gather per level" if getattr(bfs, "exchange", "gather") == "gather"
-                                                             else "RCCL all-to-all of slices + all-gather of the merged slices per level", args.steps),
-                          "scale": gscale, "edgefactor": args.edgefactor, "seed": seed,
-                          "parallelism": "vertex-cyclic x%d" % world},
-               "roofline": {"bound": "hbm", "kernel": "k_bfs_push_level_stream + k_bfs_push_level_wave (per rank)",
-                            "achieved": round(8.0 * m_t / world / elapsed / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
-                            "frac": round(8.0 * m_t / world / elapsed / 1e9 / 8000.0, 5), "traffic": None,
-                            "note": "per-GPU algorithmic bytes (8 B/edge) over the whole superstep loop incl. exchange"},
-               "cpu_baseline": None, "avg_levels": round(levels / max(args.steps, 1), 2),
-               "graph_build_s": round(t_build, 2)}
-        print(json.dumps(out), flush=True)
-    dist.barrier()
-    dist.destroy_process_group()

@@ -27,6 +27,12 @@ def oracle(built):
 
 
 @pytest.fixture(scope="session")
+def torch_mod():
+    import torch
+    return torch
+
+
+@pytest.fixture(scope="session")
 def gpu_ctx(built):
     import torch
     if not torch.cuda.is_available():

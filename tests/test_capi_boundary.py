@@ -80,6 +80,32 @@ def test_mtx_loader_error_paths(built, tmp_path):
     assert n == 3 and ro.tolist() == [0, 0, 2, 2] and ci.tolist() == [0, 2] and w.tolist() == [0.5, 7.0]
 
 
+def test_loader_genuine_csc_flag(built, oracle, tmp_path):
+    """load_graph's _genuine_csc option (include/gunrock/graph.hxx): off, the CSC slots are the CSR again (the
+    reference's behaviour); on, they are the transpose -- against the oracle's loader restatement with the
+    tuple fields swapped, on the reference's directed fixture and on a file with duplicates and self loops"""
+    import mini_amd
+    files = [os.path.join(ROOT, "tests", "golden", "sssp_test.mtx"), os.path.join(ROOT, "tests", "golden", "synthetic_dup.mtx")]
+    extra = tmp_path / "dups.mtx"
+    extra.write_text("%%MatrixMarket matrix coordinate real general\n6 6 8\n1 2 3\n1 2 5\n2 2 1\n3 1 2\n6 5 7\n5 6 1\n4 1 9\n1 4 4\n")
+    files.append(str(extra))
+    for path in files:
+        n, ro, ci, w, co, ri, cw = mini_amd.load_mtx(path, undir=False, genuine_csc=False)
+        assert np.array_equal(co, ro) and np.array_equal(ri, ci) and np.array_equal(cw, w)
+        n2, ro2, ci2, w2, co2, ri2, cw2 = mini_amd.load_mtx(path, undir=False, genuine_csc=True)
+        assert n2 == n and np.array_equal(ro2, ro) and np.array_equal(ci2, ci) and np.array_equal(w2, w)
+        # the transpose by hand: entry (row r, neighbour c, weight) -> column c lists r; rows ascending inside a column,
+        # equal (c, r) pairs in CSR order (the loader's sort is stable)
+        rows = np.repeat(np.arange(n), np.diff(ro))
+        order = np.lexsort((np.arange(len(ci)), rows, ci))
+        assert np.array_equal(ri2, rows[order].astype(np.int32))
+        assert np.array_equal(co2, np.concatenate([[0], np.cumsum(np.bincount(ci, minlength=n))]).astype(np.int32))
+        assert np.array_equal(cw2, w[order])
+        # undirected input: the CSC is the CSR whatever the flag says (the matrix is symmetric)
+        u = mini_amd.load_mtx(path, undir=True, genuine_csc=True)
+        assert np.array_equal(u[4], u[1]) and np.array_equal(u[5], u[2])
+
+
 def test_product_does_not_reference_the_oracle():
     """The oracle is test infrastructure: nothing shipped may import, link or call it."""
     for base in ("mini_amd", "include"):

@@ -180,3 +180,44 @@ def test_or_maps_kernel_matches_numpy(built):
     with pytest.raises(mini_amd.MgxError):
         eng.or_maps(torch.zeros(6, dtype=torch.int32).cuda(), 2, torch.zeros(3, dtype=torch.int32).cuda())   # words % 4
     eng.close()
+
+
+def _bench_preflight(world, extra_args, env_extra):
+    """bench.py's N > 1 body (bench_dist.bench_main) under torch.distributed.run with `world` ranks sharing the
+    one GPU of the test box over gloo (RCCL refuses two ranks on one device): the launch contract, the partition, the
+    exchange, the parity check and the JSON line -- everything of the multi-GPU bench except xGMI."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MGX_BENCH_ALL_ON_GPU0="1", MGX_BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1"] + extra_args
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,extra,env_extra,scale_out,scaling", [
+    (2, ["--scale", "14"], {}, 14, "strong"),
+    (4, ["--scale", "13", "--scaling", "weak"], {}, 15, "weak"),
+    (2, ["--scale", "14", "--no-cpu-baseline"], {"MGX_BENCH_TREE_CHECK": "1"}, 14, "strong"),
+    (3, ["--scale", "12"], {"MGX_DIST_EXCHANGE": "reduce"}, 12, "strong")])
+def test_bench_main_preflight_ranks_share_one_gpu(built, world, extra, env_extra, scale_out, scaling):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    j = _bench_preflight(world, extra, env_extra)
+    assert j["n_gpus"] == world and j["scaling"] == scaling and j["config"]["scale"] == scale_out
+    assert j["parity_vs_oracle"] is True and j["value"] > 0
+    if "MGX_BENCH_TREE_CHECK" in env_extra:
+        assert "BFS-tree" in j["parity_check"] and j["cpu_baseline"] is None
+    else:
+        assert "oracle" in j["parity_check"]
+        if "--no-cpu-baseline" not in extra:
+            assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] == 1

@@ -1,0 +1,206 @@
+"""BASELINE.json configs at their NAMED shapes, through the C-ABI on the GPU:
+
+  config 2  BFS push on RMAT-22 ef 16, symmetrised        -> full size, one source against the oracle
+  config 3  SSSP on the same topology, integer weights      -> full size, one source against the oracle's float Dijkstra
+  config 4  direction-optimal BFS on a DIRECTED graph with a genuine CSC built by the library (the stand-in SURVEY 8d
+            names for soc-LiveJournal: R-MAT without symmetrisation), alpha in {1/n, .01, .05, .1, 1}: oracle at scale
+            16, size-independent BFS-tree properties at scale 20 and 22; the real file through mgx_load_mtx when
+            MGX_DATA_DIR holds it
+  config 5  (8 GPUs) is covered by tests/test_dist.py (gloo, CPU) and the bench's own parity check.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ALPHAS = ("1/n", 0.01, 0.05, 0.1, 1.0)
+
+
+def _alpha(a, n):
+    return 1.0 / n if a == "1/n" else float(a)
+
+
+def _directed_rmat_host(oracle, scale, seed):
+    """(n, ro, ci, w, co, ri, cw): directed R-MAT CSR (pair (u, v): row v, neighbour u -- graph.hxx:139-157) and its
+    transpose, both by the oracle's loader restatement"""
+    n = 1 << scale
+    s, d, w = oracle.rmat_edges(scale, 0, 16 * n, seed, True)
+    ro, ci, ww = oracle.csr_from_tuples(n, s, d, w, undir=False)
+    co, ri, cw = oracle.csr_from_tuples(n, d, s, w, undir=False)
+    return n, ro, ci, ww, co, ri, cw
+
+
+@pytest.mark.parametrize("scale", [8, 13])
+def test_library_built_csc_is_the_transpose(gpu_ctx, oracle, scale):
+    """mgx_graph_build_csc (device radix sort of the edges by destination) against the oracle's transpose: offsets,
+    sources of every in-edge list (ascending, duplicates kept) and the weights that travel with them"""
+    import mini_amd
+    n, ro, ci, w, co, ri, cw = _directed_rmat_host(oracle, scale, 7 + scale)
+    g = mini_amd.Graph.from_host(gpu_ctx, ro, ci, w)
+    a0 = g.csc_arrays()
+    assert np.array_equal(a0[0], ro) and np.array_equal(a0[1], ci)          # before: the CSC slots alias the CSR (F8)
+    g.build_csc()
+    got_co, got_ri, got_w = g.csc_arrays()
+    assert np.array_equal(got_co, co)
+    assert np.array_equal(got_ri, ri)
+    # equal (column, source) pairs may carry their weights in either order: compare per pair as multisets
+    key = np.repeat(np.arange(n, dtype=np.int64), np.diff(co)) * n + ri
+    o1, o2 = np.lexsort((got_w, key)), np.lexsort((cw, key))
+    assert np.array_equal(got_w[o1], cw[o2])
+
+
+def test_loader_output_through_the_library_csc(gpu_ctx):
+    """the reference's own directed fixture: product loader (mgx_load_mtx) -> upload -> mgx_graph_build_csc, against the
+    loader's own _genuine_csc transpose (mgx_load_mtx_csc, host side: tests/test_capi_boundary.py pins that one)"""
+    import mini_amd
+    path = os.path.join(os.path.dirname(__file__), "golden", "sssp_test.mtx")
+    n, ro, ci, w, co, ri, cw = mini_amd.load_mtx(path, undir=False, genuine_csc=True)
+    g = mini_amd.Graph.from_host(gpu_ctx, ro, ci, w).build_csc()
+    got_co, got_ri, got_w = g.csc_arrays()
+    assert np.array_equal(got_co, co) and np.array_equal(got_ri, ri) and np.array_equal(got_w, cw)
+
+
+def test_config4_directed_rmat16_direction_optimal_vs_oracle(gpu_ctx, oracle):
+    """config 4 stand-in at a size the oracle finishes in seconds: directed R-MAT-16, genuine CSC built by the library;
+    fused direction-optimising run and the reference's enact_pushpull loop on the operators, alpha swept over
+    SURVEY 8d's list -- labels equal the top-down oracle for every switch point"""
+    import mini_amd
+    scale = 16
+    n, ro, ci, w, co, ri, cw = _directed_rmat_host(oracle, scale, 16)
+    g = mini_amd.Graph.from_host(gpu_ctx, ro, ci, w).build_csc()
+    deg = np.diff(ro)
+    srcs = [int(np.argmax(deg))] + [int(v) for v in np.where(deg > 0)[0][[5, 1000]]]
+    bfs = mini_amd.BfsProblem(g, srcs[0])
+    pulled = 0
+    for src in srcs:
+        want = oracle.bfs_cpu(ro, ci, src)
+        st = bfs.run(src)
+        assert np.array_equal(bfs.labels(), want), ("push", src)
+        for a in ALPHAS:
+            alpha = _alpha(a, n)
+            st = bfs.run(src, mode=mini_amd.MGX_BFS_DIRECTION_OPT, alpha=alpha)
+            assert np.array_equal(bfs.labels(), want), ("fused do", src, a)
+            assert st["reached"] == int((want >= 0).sum()) and st["m_t"] == int(deg[want >= 0].sum())
+            pulled += st["pull_edges"]
+            bfs.reset(src)
+            bfs.enact_pushpull(alpha)
+            assert np.array_equal(bfs.labels(), want), ("enact_pushpull", src, a)
+            rc, olabels, _ = oracle.bfs_enact_pushpull(ro, ci, src, alpha, co, ri)
+            assert np.array_equal(olabels, want), ("oracle loop", src, a)
+    assert pulled > 0             # some alpha of the list did switch to bottom-up
+
+
+def _bfs_tree_properties(torch, ro, ci, co, ri, labels, src):
+    """Size-independent check of a label array on the device (all tensors int32/int64 on cuda): source 0; every edge
+    row -> neighbour goes at most one level down; every reached vertex other than the source has an in-neighbour one
+    level up; unreached vertices have no reached in-neighbour."""
+    n = labels.numel()
+    lab = labels.to(torch.int64)
+    assert int(lab[src]) == 0
+    rows = torch.repeat_interleave(torch.arange(n, device=lab.device), (ro[1:] - ro[:-1]).to(torch.int64))
+    lr, lc = lab[rows], lab[ci.to(torch.int64)]
+    reached_r = lr >= 0
+    assert bool(((lc[reached_r] >= 0) & (lc[reached_r] <= lr[reached_r] + 1)).all()), "an edge skips a level"
+    del rows, lr, lc, reached_r
+    cols = torch.repeat_interleave(torch.arange(n, device=lab.device), (co[1:] - co[:-1]).to(torch.int64))
+    lin = lab[ri.to(torch.int64)]
+    big = torch.iinfo(torch.int64).max
+    lin = torch.where(lin >= 0, lin, torch.full_like(lin, big))
+    best = torch.full((n,), big, dtype=torch.int64, device=lab.device)
+    best.scatter_reduce_(0, cols, lin, reduce="amin", include_self=True)
+    reached = lab >= 0
+    not_src = torch.ones(n, dtype=torch.bool, device=lab.device)
+    not_src[src] = False
+    assert bool((best[reached & not_src] == lab[reached & not_src] - 1).all()), "a vertex without a parent one level up"
+    assert bool((best[~reached] == big).all()), "an unreached vertex with a reached in-neighbour"
+
+
+@pytest.mark.parametrize("scale", [20, 22])
+def test_config4_directed_rmat_full_size_properties(gpu_ctx, torch_mod, scale):
+    """config 4 stand-in at scale 20 and at the named scale 22: directed R-MAT built on the device, genuine CSC by the
+    library; push-only and direction-optimising runs over the alpha list give ONE label array, and that array has the
+    BFS-tree properties"""
+    import mini_amd
+    from mini_amd import rmat
+    torch = torch_mod
+    g = rmat.rmat_csr(gpu_ctx, scale, 16, seed=scale, undirected=False)
+    n = g["n"]
+    graph = mini_amd.Graph.from_device(gpu_ctx, n, g["m"], g["row_offsets"], g["col_indices"]).build_csc()
+    co_h, ri_h, _ = graph.csc_arrays()
+    co, ri = torch.from_numpy(co_h).cuda(), torch.from_numpy(ri_h).cuda()
+    ro_h = g["row_offsets"].cpu().numpy()
+    src = rmat.pick_sources(ro_h, 1, scale)[0]
+    bfs = mini_amd.BfsProblem(graph, src)
+    st0 = bfs.run(src)
+    ref = torch.from_numpy(bfs.labels()).cuda()
+    _bfs_tree_properties(torch, g["row_offsets"], g["col_indices"], co, ri, ref, src)
+    pulled = 0
+    for a in ALPHAS:
+        st = bfs.run(src, mode=mini_amd.MGX_BFS_DIRECTION_OPT, alpha=_alpha(a, n))
+        assert torch.equal(torch.from_numpy(bfs.labels()).cuda(), ref), a
+        assert st["reached"] == st0["reached"] and st["m_t"] == st0["m_t"]
+        pulled += st["pull_edges"]
+    assert pulled > 0
+
+
+def test_config2_rmat22_bfs_full_size_vs_oracle(gpu_ctx, oracle, torch_mod):
+    """config 2 at the benchmarked size: RMAT-22 ef 16 symmetrised (n = 4 194 304, m = 134 217 728), hub-first layout and
+    unit blocks built by the library, one seeded source: labels bit-exact against the oracle's bfs_problem_t::cpu"""
+    import mini_amd
+    from mini_amd import rmat
+    g = rmat.rmat_csr(gpu_ctx, 22, 16, seed=22)
+    assert g["n"] == 4194304 and g["m"] == 134217728
+    graph = mini_amd.Graph.from_device(gpu_ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"]).build_layout()
+    ro, ci = g["row_offsets"].cpu().numpy(), g["col_indices"].cpu().numpy()
+    src = rmat.pick_sources(ro, 3, 22)[2]
+    want = oracle.bfs_cpu(ro, ci, src)
+    bfs = mini_amd.BfsProblem(graph, src)
+    st = bfs.run(src)
+    assert np.array_equal(bfs.labels(), want)
+    deg = np.diff(ro)
+    assert st["reached"] == int((want >= 0).sum()) and st["m_t"] == int(deg[want >= 0].sum())
+    assert st["dense_slots"] >= 1          # the big level read its long rows from the unit blocks
+    st = bfs.run(src, mode=mini_amd.MGX_BFS_DIRECTION_OPT, alpha=4.0)
+    assert np.array_equal(bfs.labels(), want)
+
+
+def test_config3_rmat22_sssp_full_size_vs_oracle(gpu_ctx, oracle, torch_mod):
+    """config 3 at the benchmarked size: the same topology with integer weights in [0, 63] (every float32 path sum is
+    exact, so the north star's 1e-6 relative tolerance is met with equality): fused SSSP distances against the oracle's
+    independent float Dijkstra"""
+    import mini_amd
+    from mini_amd import rmat
+    g = rmat.rmat_csr(gpu_ctx, 22, 16, seed=22, weighted=True)
+    graph = mini_amd.Graph.from_device(gpu_ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"], g["weights"])
+    graph.build_layout(weights=True)
+    ro, ci, w = g["row_offsets"].cpu().numpy(), g["col_indices"].cpu().numpy(), g["weights"].cpu().numpy()
+    src = rmat.pick_sources(ro, 1, 22)[0]
+    want = oracle.sssp_dijkstra_f32(ro, ci, w, src)
+    sssp = mini_amd.SsspProblem(graph, src)
+    sssp.run(src)
+    got = sssp.distances()
+    assert np.array_equal(got, want)            # (unreachable: FLT_MAX on both sides)
+    assert int((want < np.finfo(np.float32).max).sum()) > g["n"] // 3
+
+
+def test_real_dataset_if_supplied(gpu_ctx, oracle, torch_mod):
+    """soc-LiveJournal1 (config 4's named input) is not available offline; when MGX_DATA_DIR holds
+    soc-LiveJournal1.mtx (or MGX_DATASET names any MTX file) it goes through the product's own loader, a library-built
+    CSC, the fused push and direction-optimising runs and the oracle (one source)."""
+    import mini_amd
+    path = os.environ.get("MGX_DATASET") or os.path.join(os.environ.get("MGX_DATA_DIR", "/nonexistent"), "soc-LiveJournal1.mtx")
+    if not os.path.exists(path):
+        pytest.skip("no dataset supplied (MGX_DATA_DIR / MGX_DATASET)")
+    n, ro, ci, w = mini_amd.load_mtx(path, undir=False)
+    g = mini_amd.Graph.from_host(gpu_ctx, ro, ci, w).build_csc()
+    deg = np.diff(ro)
+    src = int(np.argmax(deg))
+    want = oracle.bfs_cpu(ro, ci, src)
+    bfs = mini_amd.BfsProblem(g, src)
+    bfs.run(src)
+    assert np.array_equal(bfs.labels(), want)
+    for a in ALPHAS:
+        bfs.run(src, mode=mini_amd.MGX_BFS_DIRECTION_OPT, alpha=_alpha(a, n))
+        assert np.array_equal(bfs.labels(), want), a

@@ -15,12 +15,6 @@ CASES = json.load(open(os.path.join(GOLD, "reference_goldens.json")))["cases"]
 FLT_MAX = np.finfo(np.float32).max
 
 
-@pytest.fixture(scope="module")
-def torch_mod():
-    import torch
-    return torch
-
-
 def _graph(ctx, ro, ci, w=None, csc=None):
     import mini_amd
     if csc is None:

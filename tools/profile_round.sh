@@ -24,3 +24,8 @@ timeout 900 rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_
 cd $R
 python3 tools/summarize_profiles.py $O > $O/summary.txt 2>&1
 cat $O/summary.txt
+# what goes under profiles/ (the caller copies gpurun_out/round/keep/* to profiles/rNN/ and pmc_traffic.json to profiles/)
+mkdir -p $O/keep
+cp $O/summary.txt $O/summary.json $O/kernel_stats_mgx.csv $O/levels.log $O/microbench.jsonl $O/keep/ 2>/dev/null
+cp $O/pmc_traffic.json $O/keep/ 2>/dev/null
+grep '^{' $O/bench.log | tail -1 > $O/keep/bench_line.json

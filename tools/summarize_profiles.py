@@ -16,21 +16,41 @@ for f in glob.glob(os.path.join(O, "trace", "**", "*kernel_stats.csv"), recursiv
                 out[kn] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "total_ns": int(r["TotalDurationNs"])}
                 print("kernel-trace: %s calls=%s avg=%.1f us total=%.3f ms" % (kn, r["Calls"], float(r["AverageNs"]) / 1e3, int(r["TotalDurationNs"]) / 1e6))
 pm = {}
+KERNEL = "k_bfs_push<false, 0>"          # the product kernel: one launch per slot (bench.py's roofline.kernel)
 for f in glob.glob(os.path.join(O, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     agg, cnt = collections.Counter(), collections.Counter()
     for r in csv.DictReader(open(f)):
-        if "k_bfs_push_level_stream" in r["Kernel_Name"]:
+        if KERNEL in r["Kernel_Name"]:
             agg[r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Counter_Name"]] += 1
     for k in agg:
         pm[k] = {"sum": agg[k], "dispatches": cnt[k], "per_dispatch": agg[k] / cnt[k]}
         print("pmc %-22s dispatches=%d per_dispatch=%.6g" % (k, cnt[k], agg[k] / cnt[k]))
 out["pmc"] = pm
 if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
-    # rocprofv3 reports KiB-ish units (x1024 B per MI355X_MICROARCH.md / cdna guide section 7); FETCH_SIZE is NOT
-    # doubled here: the 2x correction of the guide is calibrated for 16 B/lane streams only, this kernel reads 4 B/lane
-    raw = (pm["FETCH_SIZE"]["per_dispatch"] + pm["WRITE_SIZE"]["per_dispatch"]) * 1024.0
-    out["hbm_bytes_per_launch_raw"] = raw
-    print("HBM bytes per launch (FETCH+WRITE, x1024, uncorrected): %.4g" % raw)
+    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE is
+    # TCC_EA0_RDREQ x 64 B while the requests are 128 B -- HALF of the streamed bytes, doubled here.  Round 1's own data
+    # shows the same for this kernel's 4-byte-per-lane stream (raw FETCH below the compulsory col_indices bytes).
+    # WRITE_SIZE is exact.
+    fetch_raw = pm["FETCH_SIZE"]["per_dispatch"] * 1024.0
+    write_raw = pm["WRITE_SIZE"]["per_dispatch"] * 1024.0
+    out["hbm_bytes_per_launch_raw"] = fetch_raw + write_raw
+    out["hbm_bytes_per_launch"] = 2.0 * fetch_raw + write_raw
+    print("HBM bytes per launch: FETCH raw %.4g (x2 = %.4g)  WRITE %.4g  -> corrected %.4g" % (fetch_raw, 2 * fetch_raw, write_raw, 2 * fetch_raw + write_raw))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    scale, mode = 22, "push"
+    for f in glob.glob(os.path.join(O, "bench.log")):
+        line = [l for l in open(f) if l.startswith("{")]
+        if line:
+            j = json.loads(line[-1]); scale = j["config"]["scale"]
+    traffic = {"kernel": KERNEL, "scale": scale, "mode": mode, "source_sha": bench.source_sha(),
+               "fetch_size_kib_per_dispatch_raw": pm["FETCH_SIZE"]["per_dispatch"], "write_size_kib_per_dispatch_raw": pm["WRITE_SIZE"]["per_dispatch"],
+               "dispatches": pm["FETCH_SIZE"]["dispatches"],
+               "fetch_bytes_corrected": 2.0 * fetch_raw, "write_bytes": write_raw, "hbm_bytes_per_launch": 2.0 * fetch_raw + write_raw,
+               "correction": "2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM: gfx950 FETCH_SIZE counts 128-B read requests as 64 B)",
+               "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-check; "
+                          "average over every dispatch of the kernel (all slots of all traversals, as bench.py's alg_bytes_per_launch)"}
+    json.dump(traffic, open(os.path.join(O, "pmc_traffic.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(O, "summary.json"), "w"), indent=1)
 for f in glob.glob(os.path.join(O, "bench.log")):
     line = [l for l in open(f) if l.startswith("{")]
