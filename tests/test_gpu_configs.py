@@ -15,7 +15,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-ALPHAS = ("1/n", 0.01, 0.05, 0.1, 1.0)
+ALPHAS = ("1/n", 0.01, 0.05, 0.1, 1.0)      # SURVEY 8d's list
+ALPHAS_PULL = ALPHAS + (64.0, 1e9)           # ... plus two that do reach the bottom-up phase on a directed graph (many vertices unreachable)
 
 
 def _alpha(a, n):
@@ -78,7 +79,7 @@ def test_config4_directed_rmat16_direction_optimal_vs_oracle(gpu_ctx, oracle):
         want = oracle.bfs_cpu(ro, ci, src)
         st = bfs.run(src)
         assert np.array_equal(bfs.labels(), want), ("push", src)
-        for a in ALPHAS:
+        for a in ALPHAS_PULL:
             alpha = _alpha(a, n)
             st = bfs.run(src, mode=mini_amd.MGX_BFS_DIRECTION_OPT, alpha=alpha)
             assert np.array_equal(bfs.labels(), want), ("fused do", src, a)
@@ -137,7 +138,7 @@ def test_config4_directed_rmat_full_size_properties(gpu_ctx, torch_mod, scale):
     ref = torch.from_numpy(bfs.labels()).cuda()
     _bfs_tree_properties(torch, g["row_offsets"], g["col_indices"], co, ri, ref, src)
     pulled = 0
-    for a in ALPHAS:
+    for a in ALPHAS_PULL:
         st = bfs.run(src, mode=mini_amd.MGX_BFS_DIRECTION_OPT, alpha=_alpha(a, n))
         assert torch.equal(torch.from_numpy(bfs.labels()).cuda(), ref), a
         assert st["reached"] == st0["reached"] and st["m_t"] == st0["m_t"]
