@@ -102,6 +102,34 @@ struct bfs_enactor_t : enactor_t {
     }
   }
 
+  // BFS in the reference's IDEMPOTENT mode (advance.hxx:60 with idempotence = true, filter.hxx:95-119; no upstream
+  // enactor instantiates it): advance emits EVERY neighbour of the frontier -- no label test, no atomicCAS per edge --
+  // and uniquify keeps one copy of each vertex not seen before (intra-wave cull, then the exact visited-bitmask cull)
+  // and labels it (bfs_idempotent_functor_t::cond_uniq).  visited_mask: (num_nodes + 31) / 32 words, cleared here.
+  // Same labels as enact_pushpull's push phase; what it trades is the CAS per edge for an int per edge written and read.
+  long long idempotent_edges = 0;     // sum of advance fronts of the last enact_idempotent
+  void enact_idempotent(std::shared_ptr<bfs_problem_t> bfs_problem, mem_t<unsigned>& visited_mask,
+                        standard_context_t& context) {
+    using namespace gunrock::oprtr::advance;
+    using namespace gunrock::oprtr::filter;
+    init_frontier(bfs_problem);
+    const int src = bfs_problem->src;
+    unsigned* const mask = visited_mask.data();
+    MGX_HIP(hipMemsetAsync(mask, 0, visited_mask.size() * sizeof(unsigned), context.stream()));
+    mgx::transform([=] __device__(int) { mask[src >> 5] = 1u << (src & 31); }, 1, context);
+    idempotent_edges = 0;
+    int selector = 0, iteration;
+    for (iteration = 0;; ++iteration) {
+      const int front = advance_forward_kernel<bfs_problem_t, bfs_idempotent_functor_t, true, true>(
+          bfs_problem, buffers[selector], buffers[selector ^ 1], iteration, context);
+      idempotent_edges += front;
+      if (!front) break;
+      uniquify_kernel<bfs_problem_t, bfs_idempotent_functor_t>(bfs_problem, (unsigned char*)mask, buffers[selector ^ 1],
+                                                               buffers[selector], iteration, context);
+      if (!buffers[selector]->size()) { ++iteration; break; }
+    }
+    pushed_iterations = total_iterations = iteration;
+  }
 };
 
 // Device-resident fused traversal (mgx/bfs_fused*.hpp).  Needs only O(n) state: no edge-capacity

@@ -53,5 +53,20 @@ struct bfs_functor_t {
   static __device__ __forceinline__ void write_reduced_value(int, int, slice_t*, int) {}
 };
 
+// The functor of the IDEMPOTENT traversal (advance<idempotence = true> + uniquify_kernel, advance.hxx:60,
+// filter.hxx:95-119): advance claims nothing -- every neighbour goes to the output, no atomics on labels -- and the label
+// is written by cond_uniq, for the one edge per vertex that uniquify's exact bitmask cull lets through.  cond_uniq here is
+// what upstream's (bfs_functor.hxx:13-24, restated above with its quirks) means to be: it does not skip vertex 0 and
+// does not relabel the source when an edge leads back to it.
+struct bfs_idempotent_functor_t : bfs_functor_t {
+  static __device__ __forceinline__ bool cond_advance(int, int, int, int, int, slice_t*, int) { return true; }
+  static __device__ __forceinline__ bool apply_advance(int, int, int, int, int, slice_t*, int) { return true; }
+  static __device__ __forceinline__ bool cond_uniq(int v, slice_t* d, int iteration) {
+    if (v < 0 || d->d_labels[v] != -1) return false;
+    d->d_labels[v] = iteration + 1;
+    return true;
+  }
+};
+
 }  // namespace bfs
 }  // namespace gunrock

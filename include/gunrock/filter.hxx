@@ -27,12 +27,19 @@ int filter_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<frontier_t<i
   return (int)stream_count;
 }
 
-// uniquify_kernel (filter.hxx:95-119): the reference's heuristic culls (bitmask / warp hash /
-// history hash, :33-91) are dead code upstream -- no enactor instantiates them, bitmask_cull
-// has an operator-precedence bug (`1 << item & 7`) and every cull skips vertex 0.
-// What is implemented is their INTENT for wave64: an exact visited-bitmask cull (atomicOr on
-// the caller's d_visited_mask, one bit per vertex) followed by Functor::cond_uniq.  Items
-// culled are dropped from the output; the input frontier is left untouched.
+// uniquify_kernel (filter.hxx:95-119): the filter of the IDEMPOTENT traversal mode -- advance<idempotence = true>
+// emits every neighbour of the frontier, visited or not and with all duplicates (advance.hxx:60); uniquify removes what
+// has been seen and hands the rest to ProblemFunctor::cond_uniq.  Upstream, the three heuristic culls in front of
+// cond_uniq (bitmask / warp hash / history hash, :33-91) are dead code: no enactor instantiates them, bitmask_cull has an
+// operator-precedence bug (`1 << item & 7`), none of them is exact (plain byte read-modify-write of the mask) and every
+// one skips vertex 0.  Here is their INTENT for wave64:
+//   1. intra-wave cull: of the lanes of a wave that hold the same vertex one goes on (mgx::wave_first_of_equal: LDS hash
+//      + one shuffle) -- duplicates cluster, because a hub is the neighbour of many frontier vertices;
+//   2. EXACT visited-bitmask cull: atomicOr on the caller's d_visited_mask, one bit per vertex ((n + 31) / 32 words);
+//      exactly one edge per vertex and traversal gets past it, so what cond_uniq does to the vertex is race-free;
+//   3. ProblemFunctor::cond_uniq.
+// Items culled are dropped from the output (stable: survivors keep their order); the input frontier is left untouched
+// (upstream overwrites culled slots with -1).  Returns nothing, like upstream: the output's size() is the count.
 template <typename Problem, typename ProblemFunctor>
 void uniquify_kernel(std::shared_ptr<Problem> problem, unsigned char* d_visited_mask,
                      std::shared_ptr<frontier_t<int>>& input, std::shared_ptr<frontier_t<int>>& output,
@@ -45,6 +52,8 @@ void uniquify_kernel(std::shared_ptr<Problem> problem, unsigned char* d_visited_
     const int item = input_data[idx];
     if (item < 0) return false;
     const unsigned bit = 1u << (item & 31);
+    if (mask_words[item >> 5] & bit) return false;     // seen in an earlier call (or earlier in this one)
+    if (!mgx::wave_first_of_equal(item)) return false;  // another lane of this wave carries it on
     const unsigned old = atomicOr(mask_words + (item >> 5), bit);
     if (old & bit) return false;   // seen it
     return ProblemFunctor::cond_uniq(item, data, iteration);

@@ -155,6 +155,18 @@ MGX_API int mgx_bfs_advance(mgx_bfs_t p, mgx_frontier_t in, mgx_frontier_t out, 
 MGX_API int mgx_bfs_filter(mgx_bfs_t p, mgx_frontier_t in, mgx_frontier_t out, int iteration, int64_t* kept);
 /* the two above in one pass over the edges: out = ids whose label this call set          */
 MGX_API int mgx_bfs_advance_filter_fused(mgx_bfs_t p, mgx_frontier_t in, mgx_frontier_t out, int iteration, int64_t* kept);
+/* The reference's IDEMPOTENT mode (no upstream enactor uses it):
+ * advance_forward_kernel<bfs_problem_t, F, idempotence = true, true> (advance.hxx:60): out = EVERY neighbour of the
+ * frontier, duplicates and visited vertices included, no atomics on labels; front = edges expanded.
+ * uniquify_kernel<bfs_problem_t, F> (filter.hxx:95-119): out = the vertices of `in` not seen before in this traversal,
+ * one copy each, stable (wave64 intra-wave cull, then an exact visited-bitmask cull: the mask, (n + 31) / 32 words,
+ * belongs to the problem handle and is reset by mgx_bfs_reset with the source's bit set), labelled iteration + 1 by
+ * F::cond_uniq.  F = bfs_idempotent_functor_t (include/gunrock/bfs/bfs_functor.hxx).
+ * mgx_bfs_enact_idempotent: the superstep loop over the two from the problem's source (labels as mgx_bfs_reset left
+ * them); stats[0] = iterations, [1] = edges expanded.  Labels equal enact_pushpull's. */
+MGX_API int mgx_bfs_advance_idempotent(mgx_bfs_t p, mgx_frontier_t in, mgx_frontier_t out, int iteration, int64_t* front);
+MGX_API int mgx_bfs_uniquify(mgx_bfs_t p, mgx_frontier_t in, mgx_frontier_t out, int iteration, int64_t* kept);
+MGX_API int mgx_bfs_enact_idempotent(mgx_bfs_t p, int64_t* stats);
 /* gen_unvisited_kernel / sparse_to_dense_kernel / advance_backward_kernel (advance.hxx:69-160) */
 MGX_API int mgx_bfs_gen_unvisited(mgx_bfs_t p, mgx_frontier_t indices, mgx_frontier_t unvisited, int iteration, int64_t* kept);
 MGX_API int mgx_bfs_sparse_to_dense(mgx_bfs_t p, mgx_frontier_t sparse, mgx_frontier_t dense, int iteration);

@@ -74,6 +74,24 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Intra-wave duplicate cull (the reference's UniquifyFunctor::warp_cull, filter.hxx:58-76, for wave64): returns true
+// for every calling lane but those that hold the same `item` as another calling lane of the wave which won their shared
+// hash slot -- of k lanes with one item, at least one survives (exactly one unless a different item takes the slot:
+// then all k survive; the cull is an optimisation in front of an exact test, never the test itself).  Lanes may call it
+// under divergence (the tail of an array); workgroups of at most 16 waves.  1 LDS write, 1 LDS read, 1 shuffle.
+__device__ __forceinline__ bool wave_first_of_equal(int item) {
+  __shared__ int slots[16][256];
+  const int lane = lane_id();
+  int* const mine = slots[(threadIdx.x / WAVE) & 15];
+  const unsigned h = ((unsigned)item * 2654435761u) >> 24;     // 256 slots
+  mine[h] = lane;
+  wave_lds_fence();
+  const int winner = mine[h];                                   // a lane that wrote in THIS call (mine or a later one)
+  const int theirs = __shfl(item, winner, WAVE);
+  wave_lds_fence();                                             // (the slots are rewritten by the next call)
+  return winner == lane || theirs != item;
+}
+
 // Same for a workgroup of NW waves (any block size); `smem` needs NW slots of T.  Two barriers.
 template <int NW, typename T>
 __device__ __forceinline__ T block_exclusive_sum_nw(T x, T* smem, T* total) {

@@ -102,6 +102,9 @@ SIGNATURES = {
     "mgx_bfs_sparse_to_dense": [_vp, _vp, _vp, _i],
     "mgx_bfs_advance_backward": [_vp, _vp, _vp, _vp, _i, _pi64],
     "mgx_bfs_enact_pushpull": [_vp, _f, _pi64],
+    "mgx_bfs_advance_idempotent": [_vp, _vp, _vp, _i, _pi64],
+    "mgx_bfs_uniquify": [_vp, _vp, _vp, _i, _pi64],
+    "mgx_bfs_enact_idempotent": [_vp, _pi64],
     "mgx_bfs_run": [_vp, _i, _i, _f, _pi64],
     "mgx_bfs_level_trace": [_vp, _i, _pi64, _pi64, _pi],
     "mgx_bfs_set_kernel_timing": [_vp, _i],

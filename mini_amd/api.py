@@ -285,6 +285,22 @@ class BfsProblem:
         check(lib.mgx_bfs_enact_pushpull(self._h, C.c_float(threshold), st))
         return {"pushed_iterations": st[0], "total_iterations": st[1], "pushed_edges": st[2], "pulled_edges": st[3]}
 
+    def enact_idempotent(self):
+        """the reference's idempotent mode as a loop: advance<idempotence> (every neighbour, no atomics) + uniquify"""
+        st = (C.c_int64 * 2)()
+        check(lib.mgx_bfs_enact_idempotent(self._h, st))
+        return {"iterations": st[0], "edges": st[1]}
+
+    def advance_idempotent(self, fin, fout, iteration):
+        v = C.c_int64()
+        check(lib.mgx_bfs_advance_idempotent(self._h, fin._h, fout._h, int(iteration), C.byref(v)))
+        return v.value
+
+    def uniquify(self, fin, fout, iteration):
+        v = C.c_int64()
+        check(lib.mgx_bfs_uniquify(self._h, fin._h, fout._h, int(iteration), C.byref(v)))
+        return v.value
+
     def run(self, src, mode=_lib.MGX_BFS_PUSH, alpha=0.0):
         """Fused device-resident traversal."""
         st = (C.c_int64 * 20)()

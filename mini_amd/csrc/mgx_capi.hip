@@ -41,6 +41,7 @@ struct mgx_bfs_s {
   std::unique_ptr<bfs::bfs_enactor_t> e;              // lazily: holds two m-capacity buffers
   std::unique_ptr<bfs::bfs_fused_enactor_t> fe;       // lazily: O(n)
   int64_t last_stats[20] = {0};
+  mem_t<unsigned> visited_mask;                       // lazily: the idempotent mode's bitmask ((n + 31) / 32 words)
   int time_kernels = -1;                              // -1: environment default
 };
 struct mgx_sssp_s {
@@ -638,6 +639,11 @@ int mgx_bfs_reset(mgx_bfs_t p, int src) {
   MGX_REQUIRE(src >= 0 && src < p->g->g->num_nodes, "mgx_bfs_reset: src out of range");
   use_device(p->g->c);
   p->p->reset((size_t)src, *p->g->c->ctx);
+  if (p->visited_mask.size()) {        // the idempotent mode's bitmask: only the source seen
+    unsigned* const mask = p->visited_mask.data();
+    MGX_HIP(hipMemsetAsync(mask, 0, p->visited_mask.size() * sizeof(unsigned), p->g->c->ctx->stream()));
+    mgx::transform([=] __device__(int) { mask[src >> 5] = 1u << (src & 31); }, 1, *p->g->c->ctx);
+  }
   MGX_CATCH
 }
 int mgx_bfs_free(mgx_bfs_t p) {
@@ -735,6 +741,50 @@ int mgx_bfs_enact_pushpull(mgx_bfs_t p, float threshold, int64_t* stats) {
     stats[1] = e.total_iterations;
     stats[2] = e.pushed_edges;
     stats[3] = e.pulled_edges;
+  }
+  MGX_CATCH
+}
+
+static mem_t<unsigned>& bfs_mask(mgx_bfs_t p) {
+  if (!p->visited_mask.size()) {
+    const size_t words = ((size_t)p->g->g->num_nodes + 31) / 32 + 1;
+    p->visited_mask = mem_t<unsigned>(words, *p->g->c->ctx);
+    unsigned* const mask = p->visited_mask.data();
+    const int src = p->p->src;           // the state mgx_bfs_reset leaves: only the source seen
+    MGX_HIP(hipMemsetAsync(mask, 0, words * sizeof(unsigned), p->g->c->ctx->stream()));
+    mgx::transform([=] __device__(int) { mask[src >> 5] = 1u << (src & 31); }, 1, *p->g->c->ctx);
+  }
+  return p->visited_mask;
+}
+int mgx_bfs_advance_idempotent(mgx_bfs_t p, mgx_frontier_t in, mgx_frontier_t out, int iteration, int64_t* front) {
+  MGX_TRY
+  MGX_REQUIRE(p && in && out, "NULL argument");
+  use_device(p->g->c);
+  const int r = oprtr::advance::advance_forward_kernel<bfs::bfs_problem_t, bfs::bfs_idempotent_functor_t, true, true>(
+      p->p, in->f, out->f, iteration, *p->g->c->ctx);
+  if (front) *front = r;
+  MGX_CATCH
+}
+int mgx_bfs_uniquify(mgx_bfs_t p, mgx_frontier_t in, mgx_frontier_t out, int iteration, int64_t* kept) {
+  MGX_TRY
+  MGX_REQUIRE(p && in && out, "NULL argument");
+  use_device(p->g->c);
+  mem_t<unsigned>& mask = bfs_mask(p);
+  oprtr::filter::uniquify_kernel<bfs::bfs_problem_t, bfs::bfs_idempotent_functor_t>(p->p, (unsigned char*)mask.data(), in->f,
+                                                                                    out->f, iteration, *p->g->c->ctx);
+  if (kept) *kept = (int64_t)out->f->size();
+  MGX_CATCH
+}
+int mgx_bfs_enact_idempotent(mgx_bfs_t p, int64_t* stats) {
+  MGX_TRY
+  MGX_REQUIRE(p, "NULL argument");
+  use_device(p->g->c);
+  bfs::bfs_enactor_t& e = bfs_enactor(p);
+  e.enact_idempotent(p->p, bfs_mask(p), *p->g->c->ctx);
+  p->g->c->ctx->synchronize();
+  if (stats) {
+    stats[0] = e.total_iterations;
+    stats[1] = e.idempotent_edges;
   }
   MGX_CATCH
 }

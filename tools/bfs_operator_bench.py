@@ -23,6 +23,14 @@ for alpha, name in ((None, "push only (alpha = 1/n)"), (4.0, "push/pull alpha = 
         t0 = time.perf_counter(); bfs.enact_pushpull(alpha); ctx.synchronize(); dt = time.perf_counter() - t0
         lab = bfs.labels(); tot_t += dt; tot_e += int(deg[lab >= 0].sum())
     print("operator path, %s: %.3f ms per traversal, %.1f GTEPS" % (name, tot_t / 4 * 1e3, tot_e / tot_t / 1e9))
+# the reference's idempotent mode: advance emits every neighbour (no label test, no CAS), uniquify culls + labels
+bfs.reset(srcs[0]); bfs.enact_idempotent(); ctx.synchronize()
+tot_t, tot_e = 0.0, 0
+for s in srcs[1:]:
+    bfs.reset(s); ctx.synchronize()
+    t0 = time.perf_counter(); bfs.enact_idempotent(); ctx.synchronize(); dt = time.perf_counter() - t0
+    lab = bfs.labels(); tot_t += dt; tot_e += int(deg[lab >= 0].sum())
+print("operator path, idempotent advance + uniquify: %.3f ms per traversal, %.1f GTEPS" % (tot_t / 4 * 1e3, tot_e / tot_t / 1e9))
 tot_t, tot_e = 0.0, 0
 for s in srcs[1:]:
     ctx.synchronize(); t0 = time.perf_counter(); st = bfs.run(s); ctx.synchronize(); dt = time.perf_counter() - t0
