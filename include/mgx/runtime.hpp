@@ -87,9 +87,18 @@ struct standard_context_t : context_t {
   // scratch arena (device) -- grows only outside operators
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
-  // pinned mailbox for the 8-byte count read-backs (advance.hxx:43, filter.hxx:21)
+  // pinned mailbox for the 8-byte count read-backs (advance.hxx:43, filter.hxx:21).  Device-visible: the kernel that
+  // produces a count stores it here itself (a hipMemcpyAsync D2H of 8 bytes is a blit kernel of its own: ~20 us)
   long long* mailbox = nullptr;
   int num_cus = 256;
+  // single-pass scans (scan.hpp): one 64-bit status word per tile, tagged with the launch's epoch so that the array never
+  // needs clearing, and the dynamic tile counter.  Private to those kernels (nothing else writes here: a stale word
+  // can only carry an OLDER epoch).
+  unsigned long long* lookback_status = nullptr;
+  size_t lookback_tiles = 0;
+  unsigned* lookback_ticket = nullptr;      // monotonically increasing across launches; a launch subtracts its base
+  unsigned lookback_ticket_base = 0;        // (host mirror: tickets handed out by the launches enqueued so far)
+  unsigned lookback_epoch = 0;
 
   explicit standard_context_t(bool print_prop = false, hipStream_t s = nullptr) : _stream(s) {
     set_current_stream(s);
@@ -104,6 +113,8 @@ struct standard_context_t : context_t {
   standard_context_t(const standard_context_t&) = delete;
   standard_context_t& operator=(const standard_context_t&) = delete;
   ~standard_context_t() override {
+    if (lookback_status) (void)hipFree(lookback_status);
+    if (lookback_ticket) (void)hipFree(lookback_ticket);
     if (scratch) (void)hipFree(scratch);
     if (mailbox) (void)hipHostFree(mailbox);
   }
@@ -120,6 +131,29 @@ struct standard_context_t : context_t {
     if (scratch) { MGX_HIP(hipStreamSynchronize(_stream)); MGX_HIP(hipFree(scratch)); scratch = nullptr; }
     MGX_HIP(hipMalloc(&scratch, bytes));
     scratch_bytes = bytes;
+    // status words for a scan over as many items as this arena serves (scan_scratch_bytes: >= n / 8 bytes for n items,
+    // 2048 items per tile)
+    const size_t tiles = bytes / 256 + 64;
+    if (tiles > lookback_tiles) {
+      if (lookback_status) { MGX_HIP(hipStreamSynchronize(_stream)); MGX_HIP(hipFree(lookback_status)); lookback_status = nullptr; }
+      MGX_HIP(hipMalloc((void**)&lookback_status, tiles * sizeof(unsigned long long)));
+      MGX_HIP(hipMemsetAsync(lookback_status, 0, tiles * sizeof(unsigned long long), _stream));
+      lookback_tiles = tiles;
+      lookback_epoch = 0;
+    }
+    if (!lookback_ticket) {
+      MGX_HIP(hipMalloc((void**)&lookback_ticket, 64));
+      MGX_HIP(hipMemsetAsync(lookback_ticket, 0, 64, _stream));
+      lookback_ticket_base = 0;
+    }
+  }
+  // epoch of the next single-pass launch: 1 .. 2^30 - 1, never 0 (cleared words); at wrap-around the words are cleared
+  unsigned next_lookback_epoch() {
+    if (++lookback_epoch >= (1u << 30)) {
+      MGX_HIP(hipMemsetAsync(lookback_status, 0, lookback_tiles * sizeof(unsigned long long), _stream));
+      lookback_epoch = 1;
+    }
+    return lookback_epoch;
   }
 };
 
