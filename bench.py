@@ -116,7 +116,17 @@ def main():
     seed = args.scale if args.seed is None else args.seed
     t_build = time.time()
     if args.file:
-        n, ro_host, ci_host, w_host = mini_amd.load_mtx(args.file, undir=args.undirected)
+        # a MatrixMarket file is parsed and sorted once; its binary CSR cache (mgx_graph_save_csr) is used from then on
+        cache = args.file if args.file.endswith(".mgxcsr") else args.file + (".undir" if args.undirected else "") + ".mgxcsr"
+        if os.path.exists(cache):
+            c = mini_amd.load_csr_cache(cache)
+            n, ro_host, ci_host, w_host = c["n"], c["row_offsets"], c["col_indices"], c["weights"]
+        else:
+            n, ro_host, ci_host, w_host = mini_amd.load_mtx(args.file, undir=args.undirected)
+            try:
+                mini_amd.save_csr_cache(cache, ro_host, ci_host, w_host, undirected=args.undirected)
+            except mini_amd.MgxError:
+                pass                    # (a read-only directory: no cache, nothing else changes)
         graph = mini_amd.Graph.from_host(ctx, ro_host, ci_host, w_host)
         if args.mode == "do" and not args.undirected:
             graph.build_csc()

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <limits>
 #include <memory>
@@ -212,6 +213,90 @@ inline std::shared_ptr<graph_t> load_graph(const char* _name, bool _undir = fals
   g->csr = csr;
   g->csc = csc;
   return g;
+}
+
+// ---- binary CSR cache ----------------------------------------------------------------------------------
+// load_graph parses MatrixMarket TEXT and sorts the tuples on every run: minutes for a 69 M-edge file.  save_graph_cache
+// writes what it produced -- CSR (and the CSC when it is a genuine one) -- as raw arrays behind a small header;
+// load_graph_cache maps it back into a graph_t without parsing or sorting.  Layout (little endian, as the host):
+//   char magic[8] = "MGXCSR1\0"; int32 num_nodes, num_edges, undirected, has_csc; uint64 checksum (FNV-1a over the arrays)
+//   int32 offsets[n + 1]; int32 indices[m]; float weights[m];  [ int32 col_offsets[n + 1]; int32 row_indices[m]; float row_weights[m] ]
+// A file that is truncated, has another magic or fails the checksum is rejected (nullptr / false): a cache is never trusted.
+namespace detail {
+inline unsigned long long fnv1a(const void* data, size_t bytes, unsigned long long h) {
+  const unsigned char* p = (const unsigned char*)data;
+  for (size_t i = 0; i < bytes; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+  return h;
+}
+inline unsigned long long csr_checksum(const csr_t& c, unsigned long long h) {
+  h = fnv1a(c.offsets.data(), c.offsets.size() * sizeof(int), h);
+  h = fnv1a(c.indices.data(), c.indices.size() * sizeof(int), h);
+  return fnv1a(c.edge_weights.data(), c.edge_weights.size() * sizeof(float), h);
+}
+}  // namespace detail
+
+inline bool save_graph_cache(const char* path, const graph_t& g) {
+  if (!g.csr || (int)g.csr->offsets.size() != g.num_nodes + 1 || (int)g.csr->indices.size() != g.num_edges ||
+      (int)g.csr->edge_weights.size() != g.num_edges)
+    return false;
+  const bool has_csc = g.csc && g.csc != g.csr;
+  FILE* f = fopen(path, "wb");
+  if (!f) return false;
+  unsigned long long sum = detail::csr_checksum(*g.csr, 1469598103934665603ull);
+  if (has_csc) sum = detail::csr_checksum(*g.csc, sum);
+  const char magic[8] = {'M', 'G', 'X', 'C', 'S', 'R', '1', 0};
+  const int head[4] = {g.num_nodes, g.num_edges, g.undirected ? 1 : 0, has_csc ? 1 : 0};
+  bool ok = fwrite(magic, 1, 8, f) == 8 && fwrite(head, sizeof(int), 4, f) == 4 && fwrite(&sum, sizeof(sum), 1, f) == 1;
+  auto put = [&](const csr_t& c) {
+    ok = ok && fwrite(c.offsets.data(), sizeof(int), c.offsets.size(), f) == c.offsets.size();
+    ok = ok && fwrite(c.indices.data(), sizeof(int), c.indices.size(), f) == c.indices.size();
+    ok = ok && fwrite(c.edge_weights.data(), sizeof(float), c.edge_weights.size(), f) == c.edge_weights.size();
+  };
+  put(*g.csr);
+  if (has_csc) put(*g.csc);
+  ok = (fclose(f) == 0) && ok;
+  return ok;
+}
+
+inline std::shared_ptr<graph_t> load_graph_cache(const char* path) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return nullptr;
+  char magic[8];
+  int head[4];
+  unsigned long long sum = 0;
+  const char want[8] = {'M', 'G', 'X', 'C', 'S', 'R', '1', 0};
+  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, want, 8) != 0 || fread(head, sizeof(int), 4, f) != 4 ||
+      fread(&sum, sizeof(sum), 1, f) != 1 || head[0] < 0 || head[1] < 0) {
+    fclose(f);
+    return nullptr;
+  }
+  const size_t n = (size_t)head[0], m = (size_t)head[1];
+  auto get = [&](std::shared_ptr<csr_t>& c) -> bool {
+    c = std::make_shared<csr_t>();
+    c->num_nodes = (int)n; c->num_edges = (int)m;
+    c->offsets.resize(n + 1); c->indices.resize(m); c->edge_weights.resize(m);
+    if (fread(c->offsets.data(), sizeof(int), n + 1, f) != n + 1 || fread(c->indices.data(), sizeof(int), m, f) != m ||
+        fread(c->edge_weights.data(), sizeof(float), m, f) != m)
+      return false;
+    // structural sanity before anything indexes with these arrays
+    if (c->offsets[0] != 0 || c->offsets[n] != (int)m) return false;
+    for (size_t v = 0; v < n; ++v) if (c->offsets[v] > c->offsets[v + 1]) return false;
+    for (size_t e = 0; e < m; ++e) if (c->indices[e] < 0 || (size_t)c->indices[e] >= n) return false;
+    c->sources.resize(m);
+    for (size_t v = 0; v < n; ++v) for (int e = c->offsets[v]; e < c->offsets[v + 1]; ++e) c->sources[e] = (int)v;
+    return true;
+  };
+  auto g = std::make_shared<graph_t>();
+  g->num_nodes = (int)n; g->num_edges = (int)m; g->undirected = head[2] != 0;
+  bool ok = get(g->csr);
+  if (ok && head[3]) ok = get(g->csc); else g->csc = g->csr;
+  char extra;
+  ok = ok && fread(&extra, 1, 1, f) == 0;                 // nothing behind the arrays
+  fclose(f);
+  if (!ok) return nullptr;
+  unsigned long long have = detail::csr_checksum(*g->csr, 1469598103934665603ull);
+  if (g->csc != g->csr) have = detail::csr_checksum(*g->csc, have);
+  return have == sum ? g : nullptr;
 }
 
 }  // namespace gunrock

@@ -106,6 +106,17 @@ MGX_API int mgx_load_mtx(const char* path, int undir, int random_edge_value,
 MGX_API int mgx_load_mtx_csc(const char* path, int undir, int random_edge_value, int genuine_csc,
                              int* num_nodes, int64_t* num_edges, int** row_offsets, int** col_indices, float** weights,
                              int** col_offsets, int** row_indices, float** row_weights);
+/* Binary CSR cache: the loader's output as raw arrays behind a header with a checksum, so that a big
+ * MatrixMarket file is parsed and sorted once (mgx_load_mtx / mgx_load_mtx_csc, then mgx_graph_save_csr) and mapped
+ * back without parsing afterwards (mgx_graph_load_csr).  col_offsets / row_indices / row_weights: a genuine CSC to store
+ * with it, or all NULL.  load: a file that is missing, truncated, of another format or fails its checksum or the
+ * structural checks (monotone offsets, ids in range) is MGX_E_INVALID -- a cache is never trusted; the CSC outputs are
+ * NULL when the file holds none.  Arrays are malloc'd: release with mgx_host_free. */
+MGX_API int mgx_graph_save_csr(const char* path, int num_nodes, int64_t num_edges, int undirected, const int* row_offsets,
+                               const int* col_indices, const float* weights, const int* col_offsets, const int* row_indices,
+                               const float* row_weights);
+MGX_API int mgx_graph_load_csr(const char* path, int* num_nodes, int64_t* num_edges, int* undirected, int** row_offsets,
+                               int** col_indices, float** weights, int** col_offsets, int** row_indices, float** row_weights);
 MGX_API void mgx_host_free(void* p);
 
 /* ---- frontier: replaces frontier_t<int> (frontier.hxx:12-99) ---- */

@@ -43,7 +43,9 @@ __device__ __forceinline__ bool bfs_long_is_dense(const bfs_fused_args_t& a, con
   return units * (u64)a.dense_div >= (u64)a.ub_units;
 }
 
-template <int NT, int HOTW>
+// GPS: groups per step (1: four 16-byte loads in flight per lane while the previous four are tested; 2: eight -- for
+// launches with half the waves per CU)
+template <int NT, int HOTW, int GPS = 1>
 __device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int slot, u32 block, u32 nblocks, int stat_level) {
   constexpr int NW = NT / WAVE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -95,16 +97,20 @@ __device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int sl
       return (g < G ? g : 0u) * (BFS_DENSE_GROUP * 64u);
     };
 
-    bfs_u32x4 dL[4], dT[4];
-    // issue the four 16-byte loads of group k of a batch whose activity bits are `act`
+    constexpr int NL = 4 * GPS;               // loads per step
+    bfs_u32x4 dL[NL], dT[NL];
+    // issue the 16-byte loads of groups k .. k + GPS - 1 of a batch whose activity bits are `act`
     auto issue = [&](u32 b, u32 k, u64 act) {
-      const u32 base = group_base(b, k);
-      const u32 bits16 = (u32)(act >> (16u * k)) & 0xFFFFu;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool on = (bits16 >> (4u * j + lane_q)) & 1u;
-        const u32 e = on ? base + (u32)j * 256u + (u32)lane * 4u : dummy;
-        dL[j] = __builtin_nontemporal_load((const bfs_u32x4*)(ucol + e));
+      for (int g = 0; g < GPS; ++g) {
+        const u32 base = group_base(b, k + (u32)g);
+        const u32 bits16 = (u32)(act >> (16u * (k + (u32)g))) & 0xFFFFu;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool on = (bits16 >> (4u * j + lane_q)) & 1u;
+          const u32 e = on ? base + (u32)j * 256u + (u32)lane * 4u : dummy;
+          dL[4 * g + j] = __builtin_nontemporal_load((const bfs_u32x4*)(ucol + e));
+        }
       }
     };
     auto probe = [&](u32 d) -> u32 {
@@ -126,11 +132,11 @@ __device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int sl
     auto test = [&]() {
       if (diag & 2) {                  // measurement only: consume the loads, test nothing
 #pragma unroll
-        for (int j = 0; j < 4; ++j) marks += (int)((dT[j].x ^ dT[j].y ^ dT[j].z ^ dT[j].w) == 0x12345678u);
+        for (int j = 0; j < NL; ++j) marks += (int)((dT[j].x ^ dT[j].y ^ dT[j].z ^ dT[j].w) == 0x12345678u);
         return;
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NL; ++j) {
         const u32 w0 = probe(dT[j].x), w1 = probe(dT[j].y), w2 = probe(dT[j].z), w3 = probe(dT[j].w);
         decide(dT[j].x, w0); decide(dT[j].y, w1); decide(dT[j].z, w2); decide(dT[j].w, w3);
       }
@@ -141,10 +147,11 @@ __device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int sl
     // issue the new, test the old.
     bool pend = false;
     auto step = [&](u32 b, u32 k, u64 act) {
-      if (((u32)(act >> (16u * k)) & 0xFFFFu) == 0u) return;     // wave-uniform
+      const u64 mask = GPS == 2 ? 0xFFFFFFFFull : 0xFFFFull;
+      if (((act >> (16u * k)) & mask) == 0ull) return;     // wave-uniform
       if (pend) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dT[j] = dL[j];
+        for (int j = 0; j < NL; ++j) dT[j] = dL[j];
       }
       issue(b, k, act);
       if (pend) test();
@@ -163,12 +170,12 @@ __device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int sl
       const u32 fw = gather_bits(own_cur);
       own_next = load_owner(b + 2);
 #pragma unroll
-      for (u32 k = 0; k < 4; ++k) step(b, k, act);
+      for (u32 k = 0; k < 4; k += GPS) step(b, k, act);
       act = __ballot((fw >> (own_cur & 31u)) & 1u);
     }
     if (pend) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dT[j] = dL[j];
+      for (int j = 0; j < NL; ++j) dT[j] = dL[j];
       test();
     }
   }

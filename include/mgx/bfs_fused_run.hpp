@@ -96,6 +96,16 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
   }
 }
 
+// Experiment (MGX_BFS_BIGLDS=1, timed mode only): the unit-block body with ONE workgroup per CU and twice the bitmap
+// prefix in LDS (fewer cold neighbours marked untested), 128 VGPRs.
+constexpr int BFS_DENSE_HOTW_BIG = 40800;
+__global__ __launch_bounds__(1024, 4) void k_bfs_push_dense_big(bfs_fused_args_t a, int arg) {
+  const bfs_slot_plan_t p = bfs_slot_plan(a, arg);
+  if (p.empty || p.chained) return;
+  if (p.dense) bfs_dense_body<1024, BFS_DENSE_HOTW_BIG, 2>(a, p.slot, blockIdx.x, gridDim.x, p.level);
+  else bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, false, false, true>(a, p.slot, blockIdx.x, gridDim.x, p.level);
+}
+
 // The instrumented stream kernel (MGX_BFS_FLAGS: parts of the body switched off for measurements; results are wrong
 // by design).  Queue walk only.
 __global__ __launch_bounds__(1024, 8) void k_bfs_push_stream_diag(bfs_fused_args_t a, int arg) {
@@ -122,6 +132,7 @@ inline void bfs_set_kernel_attributes() {
   MGX_SET_LDS((k_bfs_push<false, 2>)); MGX_SET_LDS((k_bfs_push<true, 2>));
   MGX_SET_LDS((k_bfs_push<false, 3>)); MGX_SET_LDS((k_bfs_push<true, 3>));
   MGX_SET_LDS(k_bfs_push_stream_diag);
+  MGX_SET_LDS(k_bfs_push_dense_big);
   MGX_SET_LDS(k_bfs_push_level<false>);
   MGX_SET_LDS(k_bfs_push_level<true>);
 #undef MGX_SET_LDS
@@ -140,6 +151,7 @@ struct bfs_run_opts_t {
   int flags = 0;           // MGX_BFS_FLAGS (instrumented stream kernel)
   int dense = -1;          // MGX_BFS_DENSE: 0 never, N > 0 dense_div = N (default 16)
   long long chain = -1;    // MGX_BFS_CHAIN_MAX_EDGES: 0 never (default BFS_CHAIN_CAP)
+  int biglds = 0;          // MGX_BFS_BIGLDS (experiment, timed mode)
   int dense_diag = 0;      // MGX_BFS_DENSE_DIAG: parts of the unit-block body switched off (measurements only)
   static bfs_run_opts_t from_env() {
     bfs_run_opts_t o;
@@ -149,6 +161,7 @@ struct bfs_run_opts_t {
     if (const char* e = getenv("MGX_BFS_DENSE")) o.dense = atoi(e);
     if (const char* e = getenv("MGX_BFS_CHAIN_MAX_EDGES")) o.chain = atoll(e);
     if (const char* e = getenv("MGX_BFS_DENSE_DIAG")) o.dense_diag = atoi(e);
+    if (const char* e = getenv("MGX_BFS_BIGLDS")) o.biglds = atoi(e);
     return o;
   }
 };
@@ -257,6 +270,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
         if (timed) MGX_HIP(hipEventRecord(st.wev[3 * i], s));
         if (a.long_min > 0) {
           if (a.flags) hipLaunchKernelGGL(k_bfs_push_stream_diag, dim3(nstream), dim3(1024), bfs_push_lds_bytes(), s, a, arg);
+          else if (opt.biglds && !coldt) hipLaunchKernelGGL(k_bfs_push_dense_big, dim3(ctx.num_cus), dim3(1024), bfs_dense_lds_bytes(BFS_DENSE_HOTW_BIG), s, a, arg);
           else bfs_launch_push_part<2>(a, arg, ctx, coldt, nstream, 0);
         }
         if (timed) MGX_HIP(hipEventRecord(st.wev[3 * i + 1], s));

@@ -69,6 +69,9 @@ SIGNATURES = {
     "mgx_graph_free": [_vp],
     "mgx_graph_dims": [_vp, _pi, _pi64],
     "mgx_load_mtx": [C.c_char_p, _i, _i, _pi, _pi64, C.POINTER(_pi), C.POINTER(_pi), C.POINTER(_pf)],
+    "mgx_graph_save_csr": [C.c_char_p, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mgx_graph_load_csr": [C.c_char_p, _pi, _pi64, _pi, C.POINTER(_pi), C.POINTER(_pi), C.POINTER(_pf), C.POINTER(_pi),
+                           C.POINTER(_pi), C.POINTER(_pf)],
     "mgx_load_mtx_csc": [C.c_char_p, _i, _i, _i, _pi, _pi64, C.POINTER(_pi), C.POINTER(_pi), C.POINTER(_pf),
                          C.POINTER(_pi), C.POINTER(_pi), C.POINTER(_pf)],
     "mgx_host_free": [_vp],

@@ -160,6 +160,37 @@ def load_mtx(path, undir=False, random_edge_value=False, genuine_csc=None):
     return (N,) + tuple(out)
 
 
+def save_csr_cache(path, row_offsets, col_indices, weights=None, csc=None, undirected=False):
+    """binary CSR cache (mgx_graph_save_csr); csc = (col_offsets, row_indices, row_weights) to store a genuine CSC too"""
+    ro, ci = _np_i32(row_offsets), _np_i32(col_indices)
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float32)
+    co = ri = rw = None
+    if csc is not None:
+        co, ri = _np_i32(csc[0]), _np_i32(csc[1])
+        rw = None if csc[2] is None else np.ascontiguousarray(csc[2], dtype=np.float32)
+    check(lib.mgx_graph_save_csr(str(path).encode(), len(ro) - 1, len(ci), int(bool(undirected)), _ptr(ro), _ptr(ci), _ptr(w),
+                                 _ptr(co), _ptr(ri), _ptr(rw)))
+
+
+def load_csr_cache(path):
+    """-> dict(n, undirected, row_offsets, col_indices, weights, csc = (col_offsets, row_indices, row_weights) | None)"""
+    n, m, u = C.c_int(), C.c_int64(), C.c_int()
+    ptrs = [C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_float)(), C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_float)()]
+    check(lib.mgx_graph_load_csr(str(path).encode(), C.byref(n), C.byref(m), C.byref(u), *[C.byref(p) for p in ptrs]))
+    N, M = n.value, m.value
+    try:
+        arrs = []
+        for i, p in enumerate(ptrs):
+            cnt = N + 1 if i % 3 == 0 else M
+            arrs.append(np.ctypeslib.as_array(p, (max(cnt, 1),))[:cnt].copy() if p else None)
+    finally:
+        for p in ptrs:
+            if p:
+                lib.mgx_host_free(p)
+    return {"n": N, "undirected": bool(u.value), "row_offsets": arrs[0], "col_indices": arrs[1], "weights": arrs[2],
+            "csc": None if arrs[3] is None else (arrs[3], arrs[4], arrs[5])}
+
+
 class Frontier:
     """frontier_t<int> (frontier.hxx:12-99)."""
 

@@ -463,6 +463,46 @@ int mgx_load_mtx_csc(const char* path, int undir, int random_w, int genuine_csc,
   *co = dup_i(g->csc->offsets, N + 1); *ri = dup_i(g->csc->indices, M); *rw = dup_f(g->csc->edge_weights, M);
   MGX_CATCH
 }
+// binary CSR cache (include/gunrock/graph.hxx: save_graph_cache / load_graph_cache)
+int mgx_graph_save_csr(const char* path, int num_nodes, int64_t num_edges, int undirected, const int* ro, const int* ci,
+                       const float* w, const int* co, const int* ri, const float* rw) {
+  MGX_TRY
+  MGX_REQUIRE(path && ro && (ci || num_edges == 0) && num_nodes >= 0 && num_edges >= 0 && num_edges <= 2147483647LL,
+              "mgx_graph_save_csr: bad argument");
+  MGX_REQUIRE((co == nullptr) == (ri == nullptr), "mgx_graph_save_csr: col_offsets and row_indices go together");
+  graph_t g;
+  g.num_nodes = num_nodes; g.num_edges = (int)num_edges; g.undirected = undirected != 0;
+  auto mk = [&](const int* o, const int* i, const float* v) {
+    auto c = std::make_shared<csr_t>();
+    c->num_nodes = num_nodes; c->num_edges = (int)num_edges;
+    c->offsets.assign(o, o + num_nodes + 1);
+    c->indices.assign(i, i + num_edges);
+    if (v) c->edge_weights.assign(v, v + num_edges); else c->edge_weights.assign((size_t)num_edges, 1.0f);
+    return c;
+  };
+  g.csr = mk(ro, ci, w);
+  g.csc = co ? mk(co, ri, rw) : g.csr;
+  MGX_REQUIRE(save_graph_cache(path, g), std::string("mgx_graph_save_csr: cannot write ") + path);
+  MGX_CATCH
+}
+int mgx_graph_load_csr(const char* path, int* n, int64_t* m, int* undirected, int** ro, int** ci, float** w, int** co, int** ri,
+                       float** rw) {
+  MGX_TRY
+  MGX_REQUIRE(path && n && m && ro && ci && w, "mgx_graph_load_csr: NULL argument");
+  auto g = load_graph_cache(path);
+  MGX_REQUIRE(g != nullptr, std::string("mgx_graph_load_csr: not a valid CSR cache (missing, truncated, or checksum mismatch): ") + path);
+  *n = g->num_nodes; *m = g->num_edges;
+  if (undirected) *undirected = g->undirected ? 1 : 0;
+  const size_t N = (size_t)g->num_nodes, M = (size_t)g->num_edges;
+  auto dup_i = [](const std::vector<int>& v, size_t cnt) { int* p = (int*)malloc((cnt + 1) * sizeof(int)); memcpy(p, v.data(), cnt * sizeof(int)); return p; };
+  auto dup_f = [](const std::vector<float>& v, size_t cnt) { float* p = (float*)malloc((cnt + 1) * sizeof(float)); memcpy(p, v.data(), cnt * sizeof(float)); return p; };
+  *ro = dup_i(g->csr->offsets, N + 1); *ci = dup_i(g->csr->indices, M); *w = dup_f(g->csr->edge_weights, M);
+  const bool has_csc = g->csc != g->csr;
+  if (co) *co = has_csc ? dup_i(g->csc->offsets, N + 1) : nullptr;
+  if (ri) *ri = has_csc ? dup_i(g->csc->indices, M) : nullptr;
+  if (rw) *rw = has_csc ? dup_f(g->csc->edge_weights, M) : nullptr;
+  MGX_CATCH
+}
 void mgx_host_free(void* p) { free(p); }
 
 // ---- frontier ------------------------------------------------------------------------------
