@@ -135,7 +135,8 @@ struct d2_state_t {
     a.mode = 0; a.alpha = 0.f;
     a.flags = 0;
     a.count_marks = 0;
-    a.ub_col = nullptr; a.ub_owner = nullptr; a.ub_units = 0; a.ub_units_pad = 0; a.dense_div = 0; a.dense_diag = 0;
+    a.ub_col = nullptr; a.ub_owner = nullptr; a.ub_units = 0; a.ub_units_pad = 0; a.dense_div = 0; a.dense_diag = 0; a.build_diag = 0;
+    a.flush_buf = nullptr; a.defer_min_marks = 0;     // (k_d2_newbits reads the marks: nothing is deferred)
     a.chain_max_edges = 0;               // (levels are counted by the host here: no chains of small levels)
     return a;
   }
@@ -169,7 +170,7 @@ inline void d2_merge(d2_state_t& st, int level, const u32* gathered, int maps, l
   bfs_fused_args_t a = st.args();
   hipLaunchKernelGGL(k_d2_or, dim3(grid_for(st.nwords / 4, BLOCK, 1024)), dim3(BLOCK), 0, s, (const uint4*)gathered, maps,
                      stride_words / 4, st.nwords / 4, (uint4*)st.merged.data(), (uint4*)st.fs->visited.data(), a.ctrl);
-  hipLaunchKernelGGL((k_bfs_build<BFS_BUILD_NT, false>), dim3(bfs_build_grid(st.n_local)), dim3(BFS_BUILD_NT), 0, s, a, level,
+  hipLaunchKernelGGL((k_bfs_build<512, false>), dim3(bfs_build_grid(st.n_local, 512)), dim3(512), 0, s, a, level,
                      (const u32*)st.merged.data(), st.labels.data(), st.n_local, st.ranks, st.rank, 0);
 }
 

@@ -80,6 +80,9 @@ struct bfs_ctrl_t {
   // workgroup bases its decisions on changes while the slot's kernels run.
   int slot_level[4];
   int skip_build[4]; // slot s & 3: the push launch ran its level(s) itself (bfs_fused_chain.hpp): k_bfs_build has nothing to do
+  // Deferred hot marks (bfs_hot_epilogue below): flush_count[s & 1] = workgroups of slot s that wrote their discoveries
+  // as a bitmap into flush buffer 0 .. count - 1 instead of storing marks; zeroed one slot ahead by the opener.
+  u32 flush_count[2];
   int fb_slot;       // frontier_bits holds exactly the frontier of this slot (written by the k_bfs_build of the slot before)
   int dense_slots;   // slots whose long rows were read from the unit blocks (bfs_fused_dense.hpp)
   int pad_[2];
@@ -116,6 +119,9 @@ struct bfs_fused_args_t {
   u32 ub_units;            // real units
   u32 ub_units_pad;        // multiple of 16
   u32 dense_div;           // a slot reads its long rows from the unit blocks when frontier units * dense_div >= ub_units (0: never)
+  u32* flush_buf;          // BFS_FLUSH_MAX buffers of BFS_FLUSH_WORDS words (NULL: hot marks are never deferred)
+  u32 defer_min_marks;     // a workgroup with more deferred discoveries than this flushes them as a bitmap (else: byte marks)
+  int build_diag;          // measurements only (MGX_BFS_BUILD_DIAG; results wrong): 1 no label stores, 2 no extent gathers, 4 no cursor atomics
   int dense_diag;          // measurements only (MGX_BFS_DENSE_DIAG): 1 the unit-block body stores no marks, 2 tests nothing
   u32 chain_max_edges;     // a level of at most this many edges (and BFS_CHAIN_CQ rows) runs inside block 0 of the push launch (0: never)
 };
@@ -132,6 +138,7 @@ __device__ __forceinline__ void bfs_ctrl_reset(bfs_ctrl_t* c) {
   c->level = c->big = c->small_levels = c->slots = 0;
   c->dist_done = c->dist_levels = 0;
   for (int i = 0; i < 4; ++i) { c->slot_level[i] = 0; c->skip_build[i] = 0; }
+  c->flush_count[0] = c->flush_count[1] = 0;
   c->fb_slot = 0;                                  // k_bfs_fused_init seeds frontier_bits with the source
   c->dense_slots = 0;
   for (int i = 0; i < 64; ++i) c->stamp[i] = 0;
@@ -257,6 +264,88 @@ __device__ __forceinline__ void bfs_resolve(const bfs_ctrl_t* c, int arg, int& s
 }
 __host__ __device__ __forceinline__ int bfs_slot_arg(int slot) { return -1 - slot; }
 
+// ---- deferred hot marks ------------------------------------------------------------------------------------------------
+// A push workgroup claims the bit of a neighbour it finds unvisited in ITS LDS copy of the bitmap prefix (exact dedup
+// inside the workgroup) -- but 512 workgroups each do, so a vertex that many edges of the level lead to is marked by most
+// of them: a level of a few thousand hubs stored 11.3 M marks for 1.28 M discoveries (RMAT-22), and mark stores are
+// bound by the L2s' request rate (~230 G/s: 50 us of that 110 us level; a discovery-heavy level spent 130 of its 210 us
+// on them).  So the marks of the vertices in the first BFS_FLUSH_WORDS words of the prefix are DEFERRED: the claim in
+// LDS is all a workgroup does while it runs; at its end it compares its LDS words with the bitmap it started from
+// (read-only during the level) and either
+//   * stores the few marks it has (no more than defer_min_marks: the same stores, later), or
+//   * writes the difference as a bitmap, coalesced, into a flush buffer of its own (72 KB = 562 cache lines, instead of
+//     tens of thousands of scattered one-byte requests), numbered by a ticket; k_bfs_build ORs the slot's flush buffers
+//     into its sweep (all waves of a workgroup share the reads of a run: a few coalesced loads each).
+// Vertices behind the deferred range, cold neighbours and small levels (no LDS copy) keep their immediate byte marks.
+// The epilogue costs every workgroup a second read of its 72 KB of bitmap (~4 us per level, measured), which only pays
+// while discoveries are dense: a level defers when less than a quarter of the deferred range has been reached before it
+// (bfs_defer_limit: grid-uniform, ctrl->reached is stable while a level runs) -- the hub levels at the start of a
+// traversal; later levels find most of the prefix visited and store the few marks they have at once.
+constexpr int BFS_FLUSH_WORDS = 17984;                 // 562 runs of 1024 vertices: inside every body's LDS prefix
+constexpr int BFS_FLUSH_MAX = 1024;                    // one buffer per push workgroup of a slot at most
+constexpr int BFS_FLUSH_RUNS = BFS_FLUSH_WORDS / 32;
+
+// vertices [0, limit) defer their marks in this level (0: nothing is deferred)
+__device__ __forceinline__ u32 bfs_defer_limit(const bfs_fused_args_t& a, u32 hot_n) {
+  if (!a.flush_buf || hot_n == 0u) return 0u;
+  const u32 range = hot_n < (u32)(BFS_FLUSH_WORDS * 32) ? hot_n : (u32)(BFS_FLUSH_WORDS * 32);
+  return a.ctrl->reached * 4ull < (u64)range ? range : 0u;
+}
+
+// End of a push workgroup (all threads; contains barriers).  hot: the LDS copy, deferred words = min(hot words in use,
+// BFS_FLUSH_WORDS); s_red: 2 ints of LDS.  Returns the marks it stored or flushed (for the statistics).
+template <int NT>
+__device__ __forceinline__ int bfs_hot_epilogue(const bfs_fused_args_t& a, const u32* hot, u32 defer_words, int slot,
+                                                int* s_red) {
+  if (defer_words == 0u) return 0;
+  constexpr int PERT = (BFS_FLUSH_WORDS + NT - 1) / NT;          // words per thread (18 at 1024 threads)
+  __syncthreads();                                                // every wave's claims are in
+  u32 diff[PERT];
+  int cnt = 0;
+#pragma unroll
+  for (int q = 0; q < PERT; ++q) {
+    const u32 i = (u32)q * NT + threadIdx.x;
+    diff[q] = i < defer_words ? (hot[i] & ~a.visited[i]) : 0u;
+    cnt += __popc(diff[q]);
+  }
+  if (threadIdx.x == 0) { s_red[0] = 0; s_red[1] = -1; }
+  __syncthreads();
+  cnt = wave_sum(cnt);
+  if (lane_id() == 0 && cnt) atomicAdd(&s_red[0], cnt);
+  __syncthreads();
+  const int total = s_red[0];
+  if (total == 0) return 0;
+  if ((u32)total > a.defer_min_marks) {
+    if (threadIdx.x == 0) {
+      const u32 k = atomicAdd(&a.ctrl->flush_count[slot & 1], 1u);
+      s_red[1] = k < (u32)BFS_FLUSH_MAX ? (int)k : -1;            // (cannot overflow: one ticket per workgroup of the slot)
+    }
+    __syncthreads();
+    const int k = s_red[1];
+    if (k >= 0) {
+      u32* const out = a.flush_buf + (size_t)k * BFS_FLUSH_WORDS;
+#pragma unroll
+      for (int q = 0; q < PERT; ++q) {
+        const u32 i = (u32)q * NT + threadIdx.x;
+        if (i < (u32)BFS_FLUSH_WORDS) out[i] = diff[q];          // (words behind defer_words: zeros)
+      }
+      return total;
+    }
+  }
+  // few: the marks themselves
+#pragma unroll
+  for (int q = 0; q < PERT; ++q) {
+    u32 w = diff[q];
+    const u32 base = ((u32)q * NT + threadIdx.x) * 32u;
+    while (w) {
+      const int b = __ffs((int)w) - 1;
+      w &= w - 1u;
+      a.mark[base + (u32)b] = 1;
+    }
+  }
+  return total;
+}
+
 // ---- a level's discoveries -> bitmap, labels, next level's queues ----------------------------------------------
 // FROM_MARKS (single GPU): vertex v is new when mark[v] != 0 and its bit is not set in `visited`; the kernel sets
 // the bit (and frontier_bits for direction-optimising runs).  Otherwise (partitioned runs): `bits` already holds
@@ -287,7 +376,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 4) void k_bfs_build(bfs_fused_a
   constexpr int PER = LIST / NT;
   constexpr u64 CNT1 = 1ull << 40;
   constexpr u64 DEGMASK = CNT1 - 1ull;
-  __shared__ u32 st_v[LIST];
+  __shared__ u32 st_v[LIST];                     // the batch's discoveries, then their row starts
+  __shared__ u32 st_d[LIST];                     // ... and degrees
   __shared__ u64 s_scan[NW + 1];
   __shared__ u64 s_base[2];
   __shared__ u32 s_long_edges;                   // true edges of the batch's long rows (their offsets count padded ones)
@@ -303,6 +393,32 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 4) void k_bfs_build(bfs_fused_a
   const int* __restrict__ old_of_new = a.old_of_new;
   const u32 long_min = a.long_min > 0 ? (u32)a.long_min : 0xFFFFFFFFu;
 
+  // ---- deferred hot marks of the slot: the flush buffers' bits for this workgroup's runs (see bfs_hot_epilogue) -------
+  u32 flushed16 = 0;
+  if (FROM_MARKS && a.flush_buf) {
+    const u32 F = c->flush_count[slot & 1];
+    if (F) {                                                     // (grid-uniform)
+      __shared__ u32 s_or[NW][WAVE];
+      const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      for (int hr = 0; hr < NW; ++hr) {
+        const long long run = (long long)blockIdx.x + (long long)hr * gridDim.x;       // the run wave `hr` owns
+        if (run >= BFS_FLUSH_RUNS) break;
+        // all waves share the reads: wave w takes buffers w, w + NW, ...; a lane's halfword = its 16 vertices of the run
+        const unsigned short* const col = (const unsigned short*)a.flush_buf + run * 64 + lane;
+        u32 acc = 0;
+#pragma unroll 16
+        for (u32 k = (u32)wave; k < F; k += NW) acc |= col[(size_t)k * (BFS_FLUSH_WORDS * 2)];
+        s_or[wave][lane] = acc;
+        __syncthreads();
+        if (wave == hr) {
+#pragma unroll
+          for (int w = 0; w < NW; ++w) flushed16 |= s_or[w][lane];
+        }
+        __syncthreads();
+      }
+    }
+  }
+
   // ---- which of my 16 vertices are new ----------------------------------------------------------------------
   u32 new16 = 0;
   if (i0 < n_local) {
@@ -313,6 +429,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 4) void k_bfs_build(bfs_fused_a
       u32 m16 = 0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) m16 |= (((x[q] & 0x01010101u) * 0x10204080u) >> 28) << (4 * q);   // 4 marks -> 4 bits
+      m16 |= flushed16;
       unsigned short* const vis16 = (unsigned short*)a.visited + (i0 >> 4);
       const u32 old16 = *vis16;
       new16 = m16 & ~old16 & valid;
@@ -354,29 +471,41 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 4) void k_bfs_build(bfs_fused_a
     if (threadIdx.x == 0) s_long_edges = 0;
     __syncthreads();
     const int cnt = (total - first < LIST) ? total - first : LIST;
-    u32 li[PER], ro[PER], ro1[PER];
-    int lab_at[PER];
+    // Row extents, labels: STRIDED over the list (entry q * NT + thread), so that the lanes of a wave instruction
+    // gather the extents and layout ids of 64 consecutive list entries -- neighbouring vertices, a few cache lines --
+    // instead of 64 entries eight apart (the L2s are bound by requests, not bytes: this kernel's time is its gathers
+    // and the label scatter).  The extents go back to LDS for the blocked pass below.
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int i = q * NT + threadIdx.x;
+      if (i < cnt) {
+        const u32 v = st_v[i];
+        bfs_u32x2 ext;
+        if (a.build_diag & 2) { ext.x = v * 8u; ext.y = v * 8u + 3u; }
+        else ext = *(const bfs_u32x2*)(a.row_offsets + v);                  // both ends of the row in one 8-byte load
+        // (non-temporal stores here were measured slower.  So was moving this scatter out of the build -- vertex ids in
+        //  the queues, labels written by 64 workgroups of the launch that consumes the queue: the builds of the two big
+        //  RMAT-22 levels went from 30 to 23-25 us, but the push launches grew by more, 0.44 -> 0.46 ms per traversal:
+        //  a million random 4-byte stores cost their ~20 us wherever they run, and here they have the most threads)
+        if (!(a.build_diag & 1)) labels[old_of_new ? old_of_new[v] : (int)v] = new_label;
+        st_v[i] = ext.x;
+        st_d[i] = ext.y - ext.x;
+      }
+    }
+    __syncthreads();
+    u32 ro[PER], dg[PER];
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
       const int i = threadIdx.x * PER + q;
-      li[q] = (i < cnt) ? st_v[i] : 0u;
-      const bfs_u32x2 ext = *(const bfs_u32x2*)(a.row_offsets + li[q]);     // both ends of the row in one 8-byte load
-      ro[q] = ext.x;
-      ro1[q] = ext.y;
-      lab_at[q] = old_of_new ? old_of_new[li[q]] : (int)li[q];
+      ro[q] = (i < cnt) ? st_v[i] : 0u;
+      dg[q] = (i < cnt) ? st_d[i] : 0u;
     }
     u64 loc[PER];
     u64 sum_s = 0, sum_l = 0;
     u32 longmask = 0, long_true = 0;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-      const int i = threadIdx.x * PER + q;
-      // (non-temporal stores here were measured slower.  So was moving this scatter out of the build -- vertex ids in
-      //  the queues, labels written by 64 workgroups of the launch that consumes the queue: the builds of the two big
-      //  RMAT-22 levels went from 30 to 23-25 us, but the push launches grew by more, 0.44 -> 0.46 ms per traversal:
-      //  a million random 4-byte stores cost their ~20 us wherever they run, and here they have the most threads)
-      if (i < cnt) labels[lab_at[q]] = new_label;
-      const u32 deg = (i < cnt) ? ro1[q] - ro[q] : 0u;
+      const u32 deg = dg[q];
       const bool is_long = deg >= long_min;
       if (is_long) { longmask |= 1u << q; long_true += deg; }
       loc[q] = is_long ? sum_l : sum_s;
@@ -389,25 +518,186 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 4) void k_bfs_build(bfs_fused_a
     const u64 ex_s = block_exclusive_sum_lean<NW>(sum_s, s_scan, &tot_s);
     const u64 ex_l = block_exclusive_sum_lean<NW>(sum_l, s_scan, &tot_l);
     if (threadIdx.x == 0) {
+      if (a.build_diag & 4) { s_base[0] = ((u64)blockIdx.x * 4096) << BFS_VSHIFT; s_base[1] = ((u64)blockIdx.x * 4096) << BFS_VSHIFT; }
+      else {
       s_base[0] = (tot_s >> 40) ? atomicAdd(cur_s, ((tot_s >> 40) << BFS_VSHIFT) | (tot_s & DEGMASK)) : 0ull;
       s_base[1] = (tot_l >> 40) ? atomicAdd(cur_l, ((tot_l >> 40) << BFS_VSHIFT) | (tot_l & DEGMASK)) : 0ull;
+      }
       if (tot_l >> 40) atomicAdd(&c->ledges[(slot + 1) % 3], (u64)s_long_edges);     // (complete: two barriers ago)
     }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-      const int i = threadIdx.x * PER + q;
-      if (i < cnt && ro1[q] != ro[q]) {
+      if (dg[q] != 0u) {
         const bool is_long = (longmask >> q) & 1u;
         const u64 base = is_long ? s_base[1] : s_base[0];
         const u64 at = (is_long ? ex_l : ex_s) + loc[q];
         const u64 slot = (base >> BFS_VSHIFT) + (at >> 40);
         (is_long ? out_row_l : out_row_s)[slot] = ro[q];
         (is_long ? out_off_l : out_off_s)[slot] =
-            (u32)((base & BFS_EMASK) + (at & DEGMASK)) | (is_long ? ((ro1[q] - ro[q]) & 63u) : 0u);
+            (u32)((base & BFS_EMASK) + (at & DEGMASK)) | (is_long ? (dg[q] & 63u) : 0u);
       }
     }
     __syncthreads();       // st_v and s_base are reused by the next batch
+  }
+}
+
+// ---- the same for the single-GPU path, without the detour through a list -------------------------------------------
+// k_bfs_build above compacts a workgroup's discoveries into an LDS list and redistributes them over its threads before it
+// touches their row extents and labels.  A thread's 16 vertices are CONSECUTIVE, though: row_offsets[i0 .. i0 + 16] and
+// old_of_new[i0 .. i0 + 15] are two contiguous pieces (68 + 64 bytes per thread, 4 KB + 4 KB contiguous per wave), read
+// with a few wide loads by every thread that found anything -- no gathers at all -- and everything a discovery needs is
+// then in the registers of the thread that found it: degree, class, label target.  One packed workgroup scan per queue
+// gives the positions; a thread writes its own discoveries (consecutive queue slots per class) and labels.  No list, no
+// batches, no second distribution: three barriers' worth of scans instead of seven plus the list's.
+// (Measured, RMAT-22, the level with 2 M discoveries: 46 us for the list version, 12.5 of them the label scatter.)
+template <int NT>
+__global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int arg, int* __restrict__ labels, int n) {
+  constexpr int NW = NT / WAVE;
+  constexpr u64 CNT1 = 1ull << 40;
+  constexpr u64 DEGMASK = CNT1 - 1ull;
+  __shared__ u64 s_scan[NW + 1];
+  __shared__ u64 s_base[2];
+  __shared__ u32 s_long_edges;
+  __shared__ u32 s_or[NW][WAVE];
+  bfs_ctrl_t* const c = a.ctrl;
+  int slot, level;
+  bfs_resolve(c, arg, slot, level);
+  if (c->done || c->skip_build[slot & 3]) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) c->fb_slot = slot + 1;     // frontier_bits: written in full below
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long i0 = (((long long)blockIdx.x + (long long)wave * gridDim.x) * 64 + lane) * 16;
+  const int new_label = level + 1;
+  const u32 long_min = a.long_min > 0 ? (u32)a.long_min : 0xFFFFFFFFu;
+
+  // deferred hot marks of the slot (bfs_hot_epilogue): the flush buffers' bits for this workgroup's runs
+  u32 flushed16 = 0;
+  if (a.flush_buf) {
+    const u32 F = c->flush_count[slot & 1];
+    if (F) {                                                     // (grid-uniform)
+      for (int hr = 0; hr < NW; ++hr) {
+        const long long run = (long long)blockIdx.x + (long long)hr * gridDim.x;
+        if (run >= BFS_FLUSH_RUNS) break;
+        const unsigned short* const col = (const unsigned short*)a.flush_buf + run * 64 + lane;
+        u32 acc = 0;
+#pragma unroll 16
+        for (u32 k = (u32)wave; k < F; k += NW) acc |= col[(size_t)k * (BFS_FLUSH_WORDS * 2)];
+        s_or[wave][lane] = acc;
+        __syncthreads();
+        if (wave == hr) {
+#pragma unroll
+          for (int w = 0; w < NW; ++w) flushed16 |= s_or[w][lane];
+        }
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- which of my 16 vertices are new -------------------------------------------------------------------------------
+  u32 new16 = 0;
+  if (i0 < n) {
+    const u32 valid = (n - i0 >= 16) ? 0xFFFFu : ((1u << (int)(n - i0)) - 1u);
+    const uint4 m = *(const uint4*)(a.mark + i0);                            // mark[] is padded: always readable
+    const u32 x[4] = {m.x, m.y, m.z, m.w};
+    u32 m16 = flushed16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m16 |= (((x[q] & 0x01010101u) * 0x10204080u) >> 28) << (4 * q);   // 4 marks -> 4 bits
+    unsigned short* const vis16 = (unsigned short*)a.visited + (i0 >> 4);
+    const u32 old16 = *vis16;
+    new16 = m16 & ~old16 & valid;
+    if (new16) *vis16 = (unsigned short)(old16 | new16);                     // this thread is the half-word's only writer
+    ((unsigned short*)a.frontier_bits)[i0 >> 4] = (unsigned short)new16;     // bottom-up levels, unit blocks
+  }
+  const int mine = __popc(new16);
+
+  // ---- my discoveries' row extents and label targets: contiguous, no gathers ----------------------------------------
+  u32 ro[17];
+  int target[16];
+  u64 sum_s = 0, sum_l = 0;
+  u32 long_true = 0;
+  if (new16 && (a.build_diag & 16)) {
+#pragma unroll
+    for (int q = 0; q < 17; ++q) ro[q] = (u32)(i0 + q) * 3u;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) target[q] = (int)(i0 + q);
+  } else if (new16) {
+    if (i0 + 16 < (long long)n) {                                            // (row_offsets has n + 1 entries)
+      const u32* const p = a.row_offsets + i0;                               // i0 is a multiple of 16: 64-byte aligned
+      const uint4 r0 = *(const uint4*)p, r1 = *(const uint4*)(p + 4), r2 = *(const uint4*)(p + 8), r3 = *(const uint4*)(p + 12);
+      ro[0] = r0.x; ro[1] = r0.y; ro[2] = r0.z; ro[3] = r0.w; ro[4] = r1.x; ro[5] = r1.y; ro[6] = r1.z; ro[7] = r1.w;
+      ro[8] = r2.x; ro[9] = r2.y; ro[10] = r2.z; ro[11] = r2.w; ro[12] = r3.x; ro[13] = r3.y; ro[14] = r3.z; ro[15] = r3.w;
+      ro[16] = p[16];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 17; ++q) ro[q] = a.row_offsets[(i0 + q <= (long long)n) ? i0 + q : (long long)n];
+    }
+    if (a.old_of_new) {
+      if (i0 + 16 <= (long long)n) {
+        const int* const p = a.old_of_new + i0;
+        const int4 t0 = *(const int4*)p, t1 = *(const int4*)(p + 4), t2 = *(const int4*)(p + 8), t3 = *(const int4*)(p + 12);
+        target[0] = t0.x; target[1] = t0.y; target[2] = t0.z; target[3] = t0.w; target[4] = t1.x; target[5] = t1.y; target[6] = t1.z; target[7] = t1.w;
+        target[8] = t2.x; target[9] = t2.y; target[10] = t2.z; target[11] = t2.w; target[12] = t3.x; target[13] = t3.y; target[14] = t3.z; target[15] = t3.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) target[q] = a.old_of_new[(i0 + q < (long long)n) ? i0 + q : (long long)n - 1];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) target[q] = (int)(i0 + q);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      if ((new16 >> q) & 1u) {
+        if (!(a.build_diag & 1)) labels[target[q]] = new_label;
+        const u32 deg = ro[q + 1] - ro[q];
+        if (deg >= long_min) { sum_l += CNT1 | (u64)bfs_lq_pad(deg); long_true += deg; }
+        else if (deg) sum_s += CNT1 | (u64)deg;
+      }
+    }
+  }
+
+  // ---- positions: one packed scan per queue; batches of a workgroup are appended with one atomic per queue -------------
+  if (threadIdx.x == 0) s_long_edges = 0;
+  u64 tot_n;
+  (void)block_exclusive_sum_lean<NW>((u64)mine, s_scan, &tot_n);             // (also orders s_long_edges = 0 before the adds)
+  if (tot_n == 0) return;
+  long_true = wave_sum(long_true);
+  if (lane == 0 && long_true) atomicAdd(&s_long_edges, long_true);
+  u64 tot_s, tot_l;
+  u64 ex_s = block_exclusive_sum_lean<NW>(sum_s, s_scan, &tot_s);
+  u64 ex_l = block_exclusive_sum_lean<NW>(sum_l, s_scan, &tot_l);
+  if (threadIdx.x == 0) {
+    atomicAdd(&c->reached, tot_n);
+    if (a.build_diag & 4) { s_base[0] = s_base[1] = ((u64)blockIdx.x * 8192) << BFS_VSHIFT; }
+    else {
+    s_base[0] = (tot_s >> 40) ? atomicAdd(&c->cursor[(slot + 1) % 3], ((tot_s >> 40) << BFS_VSHIFT) | (tot_s & DEGMASK)) : 0ull;
+    s_base[1] = (tot_l >> 40) ? atomicAdd(&c->lcursor[(slot + 1) % 3], ((tot_l >> 40) << BFS_VSHIFT) | (tot_l & DEGMASK)) : 0ull;
+    if (tot_l >> 40) atomicAdd(&c->ledges[(slot + 1) % 3], (u64)s_long_edges);
+    }
+  }
+  __syncthreads();
+  if (!new16 || (a.build_diag & 8)) return;
+  u32* __restrict__ const out_row_s = a.fr_row[(slot + 1) & 1];
+  u32* __restrict__ const out_off_s = a.fr_off[(slot + 1) & 1];
+  u32* __restrict__ const out_row_l = a.lq_row[(slot + 1) & 1];
+  u32* __restrict__ const out_off_l = a.lq_off[(slot + 1) & 1];
+  const u64 base_s = s_base[0], base_l = s_base[1];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    if ((new16 >> q) & 1u) {
+      const u32 deg = ro[q + 1] - ro[q];
+      if (deg >= long_min) {
+        const u64 at = (base_l >> BFS_VSHIFT) + (ex_l >> 40);
+        out_row_l[at] = ro[q];
+        out_off_l[at] = (u32)((base_l & BFS_EMASK) + (ex_l & DEGMASK)) | (deg & 63u);
+        ex_l += CNT1 | (u64)bfs_lq_pad(deg);
+      } else if (deg) {
+        const u64 at = (base_s >> BFS_VSHIFT) + (ex_s >> 40);
+        out_row_s[at] = ro[q];
+        out_off_s[at] = (u32)((base_s & BFS_EMASK) + (ex_s & DEGMASK));
+        ex_s += CNT1 | (u64)deg;
+      }
+    }
   }
 }
 
@@ -421,6 +711,8 @@ struct bfs_fused_state_t {
   mem_t<u32> lq_row[2];
   mem_t<u32> lq_off[2];
   mem_t<bfs_ctrl_t> ctrl;
+  mem_t<u32> flush_buf;              // deferred hot marks: BFS_FLUSH_MAX bitmaps of BFS_FLUSH_WORDS words (allocated on demand)
+  unsigned defer_min_marks = 2048;   // a push workgroup with more deferred discoveries flushes a bitmap (MGX_BFS_DEFER: 0 = never defer)
   bfs_ctrl_t* host_ctrl = nullptr;   // pinned copy for stats
   int n = 0;
   int levels_per_sync = 2;           // slots (bfs_fused_run.hpp) launched between two read-backs of the control block ...
@@ -429,7 +721,7 @@ struct bfs_fused_state_t {
   bool time_batches = false;         // HIP events around every batch of launches (-> level_kernel_ms; ~6 us each)
   unsigned chain_max_edges = 6144;   // levels up to this size (and BFS_CHAIN_CAP) run inside block 0 of the push launch,
                                      // chained with the small levels behind them (bfs_fused_chain.hpp; 0: never)
-  unsigned dense_div = 16;           // long rows are read from the unit blocks when the frontier holds at least
+  unsigned dense_div = 2;            // long rows are read from the unit blocks when the frontier holds at least
                                      // 1 / dense_div of the units (bfs_fused_dense.hpp; 0: never)
   int long_min = 64;                 // rows at least this long go to the long-row queue (0: no such queue)
   bool count_marks = false;          // see bfs_fused_args_t::count_marks (MGX_BFS_COUNT_MARKS; on with time_kernels)

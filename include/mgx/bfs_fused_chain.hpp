@@ -237,6 +237,20 @@ __device__ __forceinline__ void bfs_chain_body(const bfs_fused_args_t& a, int sl
       }
       tot_s += ts; tot_l += tl; tot_true += tt;
     }
+    // ... and, when that level will read its long rows from the unit blocks (bfs_long_is_dense's rule), its frontier as
+    // a bitmap -- what k_bfs_build leaves behind a device-wide level: s_win still holds the vertices this level discovered.
+    if (nf2 != 0 && a.ub_col && a.dense_div && ((tot_l & DEGMASK) >> 6) * (u64)a.dense_div >= (u64)a.ub_units) {
+      uint4* const fb4 = (uint4*)a.frontier_bits;
+      const int quads = (a.n + 127) / 128;
+      for (int i = threadIdx.x; i < quads; i += NT) fb4[i] = make_uint4(0u, 0u, 0u, 0u);
+      __threadfence();                 // (the atomics below must land on cleared words: same workgroup, through L2)
+      __syncthreads();
+      for (int i = threadIdx.x; i < W; i += NT) {
+        const u32 v = s_win[i];
+        atomicOr(a.frontier_bits + (v >> 5), 1u << (v & 31u));
+      }
+      if (threadIdx.x == 0) c->fb_slot = slot + 1;
+    }
     if (threadIdx.x == 0) {
       c->cursor[(slot + 1) % 3] = ((tot_s >> 40) << BFS_VSHIFT) | (tot_s & DEGMASK);
       c->lcursor[(slot + 1) % 3] = ((tot_l >> 40) << BFS_VSHIFT) | (tot_l & DEGMASK);
@@ -246,6 +260,7 @@ __device__ __forceinline__ void bfs_chain_body(const bfs_fused_args_t& a, int sl
       c->ledges[(slot + 2) % 3] = 0;
       c->slot_level[(slot + 1) & 3] = level + 1;
       c->skip_build[slot & 3] = 1;
+      c->flush_count[(slot + 1) & 1] = 0;
       if (nf2 == 0 && !c->done) { c->done = 1; c->levels = level + 1; }
     }
     return;

@@ -79,6 +79,8 @@ __device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int sl
   const u32 lane_grp = (u32)lane >> 4;                         // ... and which of the batch's 4 groups
   const u32 lane_q = (u32)lane >> 4;                           // col loads: lane l reads entries 4l..4l+3 of a 256-entry chunk = unit l >> 4 of the chunk
   int marks = 0;
+  // marks of the vertices in [0, defer_n) wait for the end of the workgroup (bfs_hot_epilogue)
+  const u32 defer_n = bfs_defer_limit(a, hot_n);
   const int diag = a.dense_diag;     // MGX_BFS_DENSE_DIAG (measurements; results are wrong by design): 1 no mark stores, 2 no test
 
   // batch b of this wave: groups w + (4 b + k) W, k = 0..3
@@ -124,7 +126,7 @@ __device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int sl
         const u32 bit = 1u << (d & 31u);
         bool is_new = true;
         if (d < hot_n) is_new = !(atomicOr(&hot[d >> 5], bit) & bit);
-        if (is_new) { if (!(diag & 1)) mark[d] = 1; ++marks; }
+        if (is_new) { if (!(diag & 1) && d >= defer_n) mark[d] = 1; ++marks; }
       }
     };
     // four LDS probes in flight, then the four decisions (a probe that waits for its own result before the next one
@@ -179,6 +181,7 @@ __device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int sl
       test();
     }
   }
+  (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, slot, s_int + 4);
   if (a.count_marks) {
     marks = wave_sum(marks);
     if (lane == 0 && marks) atomicAdd(&s_int[0], marks);

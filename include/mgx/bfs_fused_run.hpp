@@ -65,6 +65,7 @@ __device__ __forceinline__ void bfs_slot_open(const bfs_fused_args_t& a, const b
   if (c->done) return;
   if (!bfs_open_level(a, p.level, p.slot)) return;  // (an empty frontier: done = 1, levels = level)
   c->slots += 1;
+  c->flush_count[(p.slot + 1) & 1] = 0;
   c->slot_level[(p.slot + 1) & 3] = p.level + 1;
   c->skip_build[p.slot & 3] = 0;
   if (p.dense) c->dense_slots += 1;
@@ -151,7 +152,10 @@ struct bfs_run_opts_t {
   int flags = 0;           // MGX_BFS_FLAGS (instrumented stream kernel)
   int dense = -1;          // MGX_BFS_DENSE: 0 never, N > 0 dense_div = N (default 16)
   long long chain = -1;    // MGX_BFS_CHAIN_MAX_EDGES: 0 never (default BFS_CHAIN_CAP)
+  long long defer = -1;    // MGX_BFS_DEFER: 0 never defer hot marks, N: flush a bitmap above N deferred marks per workgroup
   int biglds = 0;          // MGX_BFS_BIGLDS (experiment, timed mode)
+  int build_list = 0;      // MGX_BFS_BUILD_LIST=1: the list-based queue build (k_bfs_build) instead of k_bfs_build2
+  int build_diag = 0;      // MGX_BFS_BUILD_DIAG: parts of k_bfs_build switched off (measurements only)
   int dense_diag = 0;      // MGX_BFS_DENSE_DIAG: parts of the unit-block body switched off (measurements only)
   static bfs_run_opts_t from_env() {
     bfs_run_opts_t o;
@@ -161,7 +165,10 @@ struct bfs_run_opts_t {
     if (const char* e = getenv("MGX_BFS_DENSE")) o.dense = atoi(e);
     if (const char* e = getenv("MGX_BFS_CHAIN_MAX_EDGES")) o.chain = atoll(e);
     if (const char* e = getenv("MGX_BFS_DENSE_DIAG")) o.dense_diag = atoi(e);
+    if (const char* e = getenv("MGX_BFS_BUILD_DIAG")) o.build_diag = atoi(e);
+    if (const char* e = getenv("MGX_BFS_BUILD_LIST")) o.build_list = atoi(e);
     if (const char* e = getenv("MGX_BFS_BIGLDS")) o.biglds = atoi(e);
+    if (const char* e = getenv("MGX_BFS_DEFER")) o.defer = atoll(e);
     return o;
   }
 };
@@ -234,6 +241,12 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.ub_units_pad = units ? (u32)layout->ub_units_pad : 0u;
   a.dense_div = !units ? 0u : (opt.dense >= 0 ? (u32)opt.dense : st.dense_div);
   a.dense_diag = opt.dense_diag;
+  a.build_diag = opt.build_diag;
+  // deferred hot marks (bfs_hot_epilogue): the flush buffers are allocated at the first traversal that may use them
+  const long long defer = opt.defer >= 0 ? opt.defer : (long long)st.defer_min_marks;
+  if (defer > 0 && !a.flags && !st.flush_buf.size()) st.flush_buf = mem_t<u32>((size_t)BFS_FLUSH_MAX * BFS_FLUSH_WORDS, ctx);
+  a.flush_buf = (defer > 0 && !a.flags) ? st.flush_buf.data() : nullptr;
+  a.defer_min_marks = (u32)defer;
   a.chain_max_edges = mode != 0 ? 0u : (opt.chain >= 0 ? (u32)(opt.chain > BFS_CHAIN_CAP ? BFS_CHAIN_CAP : opt.chain) : st.chain_max_edges);
   const long long nwords = ((long long)st.n + 31) / 32;
   hipLaunchKernelGGL(k_bfs_fused_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src, nwords);
@@ -244,6 +257,8 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   st.stream_kernel_ms = 0.0;
   st.stream_kernel_launches = 0;
   st.batches = 0;
+  // k_bfs_build2 reads a thread's 17 row offsets and 16 layout ids with 16-byte loads: borrowed arrays must be aligned
+  const bool build2_ok = ((uintptr_t)a.row_offsets % 16 == 0) && ((uintptr_t)a.old_of_new % 16 == 0);
   const bool batch_events = st.time_kernels != 0 || st.time_batches;    // (an event costs ~6 us of stream gap)
   const u32 nstream = a.long_min > 0 ? (u32)ctx.num_cus * 2 : 0u;
   const u32 nwave = (u32)ctx.num_cus * 2;
@@ -281,8 +296,11 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
       }
       if (mode == 1)
         hipLaunchKernelGGL(k_bfs_pull_level<256>, dim3(ctx.num_cus * 8), dim3(256), 0, s, a, arg);
-      hipLaunchKernelGGL((k_bfs_build<512, true>), dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, arg,
-                         (const u32*)nullptr, labels, st.n, 1, 0, 1);       // (2 workgroups per CU overlap their phases)
+      if (opt.build_list || !build2_ok)
+        hipLaunchKernelGGL((k_bfs_build<512, true>), dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, arg,
+                           (const u32*)nullptr, labels, st.n, 1, 0, 1);
+      else
+        hipLaunchKernelGGL(k_bfs_build2<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, arg, labels, st.n);   // (2 workgroups per CU overlap their phases)
     }
     if (batch_events) MGX_HIP(hipEventRecord(st.ev1, s));
     MGX_CHECK_LAUNCH("fused BFS: kernel launch");

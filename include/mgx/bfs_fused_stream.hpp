@@ -92,6 +92,8 @@ __device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int l
   if (threadIdx.x == 0) s_int[0] = 0;
   __syncthreads();
 
+  // marks of the vertices in [0, defer_n) wait for the end of the workgroup (bfs_hot_epilogue)
+  const u32 defer_n = DIAG ? 0u : bfs_defer_limit(a, hot_n);
   const int diag = (DIAG && (a.flags >> 8) == stat_level) ? (a.flags & 255) : 0;   // MGX_BFS_FLAGS = level << 8 | bits
   int marks = 0;                 // per lane
 
@@ -181,7 +183,7 @@ __device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int l
         bool is_new = act && !hotm && (COLDT ? !(cold_word[k] & bit) : true);
         if (hotm && !(w & bit)) is_new = (diag & 2) || !(atomicOr(&hot[d >> 5], bit) & bit);
         if (is_new) {
-          if (!(diag & 1)) mark[d] = 1;
+          if (!(diag & 1) && d >= defer_n) mark[d] = 1;
           ++marks;
         }
       }
@@ -231,6 +233,7 @@ __device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int l
       }
     }
   }
+  (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, level, s_int + 4);
   if (a.count_marks) {           // statistics for the tools: two device-scope atomics per workgroup on one line
     marks = wave_sum(marks);
     if (lane == 0 && marks) atomicAdd(&s_int[0], marks);

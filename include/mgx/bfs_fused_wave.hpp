@@ -73,6 +73,8 @@ __device__ __forceinline__ void bfs_wave_body(const bfs_fused_args_t& a, int lev
   __syncthreads();
 
   int marks = 0;       // per lane
+  // marks of the vertices in [0, defer_n) wait for the end of the workgroup (bfs_hot_epilogue)
+  const u32 defer_n = bfs_defer_limit(a, hot_n);
 
   if (has_work) {
     // first segment of the slice
@@ -176,7 +178,7 @@ __device__ __forceinline__ void bfs_wave_body(const bfs_fused_args_t& a, int lev
             bool is_new;
             if (d < hot_n) is_new = !(hot[d >> 5] & bit) && !(atomicOr(&hot[d >> 5], bit) & bit);
             else is_new = COLDT ? !(wordA[k] & bit) : true;
-            if (is_new) { mark[d] = 1; ++marks; }
+            if (is_new) { if (d >= defer_n) mark[d] = 1; ++marks; }
           }
         }
       }
@@ -201,6 +203,7 @@ __device__ __forceinline__ void bfs_wave_body(const bfs_fused_args_t& a, int lev
     }
   }
 
+  (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, level, s_int + 4);
   if (a.count_marks) {           // statistics for the tools: two device-scope atomics per workgroup on one line
     marks = wave_sum(marks);
     if (lane == 0 && marks) atomicAdd(&s_int[0], marks);

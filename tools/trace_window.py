@@ -3,7 +3,7 @@
    python tools/trace_window.py <dir> <first-kernel-substring> <occurrence> <count>"""
 import csv, glob, sys
 d, key, occ, cnt = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-f = glob.glob(d + '/trace/**/*kernel_trace.csv', recursive=True)[0]
+f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 hits = [i for i, r in enumerate(rows) if key in r['Kernel_Name']]
 i0 = hits[occ]
