@@ -175,7 +175,9 @@ def bench_main(args, rank, world, local_rank):
                                                              "strong scaling: the same graph for every N" + ("; BASELINE config 5" if gscale == 26 and world == 8 else ""),
                                                              world, exch, args.steps),
                           "scale": gscale, "edgefactor": args.edgefactor, "seed": seed,
-                          "parallelism": "vertex-cyclic x%d" % world},
+                          "parallelism": "vertex-cyclic x%d" % world,
+                          "native_loop": bool(getattr(bfs, "native", False)),
+                          "rccl": getattr(getattr(bfs, "comm", None), "library", None)},
                "roofline": {"bound": "hbm", "kernel": "k_bfs_push_level (per rank)",
                             "achieved": round(8.0 * m_t / world / elapsed / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
                             "frac": round(8.0 * m_t / world / elapsed / 1e9 / 8000.0, 5), "traffic": None,

@@ -43,6 +43,8 @@ typedef struct mgx_sssp_s* mgx_sssp_t;
 typedef struct mgx_pr_s* mgx_pr_t;
 typedef struct mgx_dbfs_s* mgx_dbfs_t;
 typedef struct mgx_dbfs2_s* mgx_dbfs2_t;
+typedef struct mgx_dsssp_s* mgx_dsssp_t;
+typedef struct mgx_comm_s* mgx_comm_t;
 
 MGX_API int mgx_version(void);
 MGX_API const char* mgx_strerror(int status);
@@ -257,6 +259,26 @@ MGX_API int mgx_dbfs_receive(mgx_dbfs_t h, const int* d_global_ids, int64_t coun
 MGX_API int mgx_dbfs_swap(mgx_dbfs_t h, int64_t* next_frontier_size);
 MGX_API int mgx_dbfs_labels(mgx_dbfs_t h, int* host_labels_local);
 
+/* ---- vertex-range partitioned SSSP: the per-rank pieces ("(dst, dist) pairs with min-combining"; the
+ *      reference has no multi-GPU path).  Same partition as mgx_dbfs_*: rank r owns [r*chunk, (r+1)*chunk), their rows
+ *      (local row_offsets, GLOBAL col_indices, weights) and distances.  A superstep is frontier Bellman-Ford
+ *      (sssp_enactor.hxx:40-72): expand relaxes the local frontier's edges -- local targets at once, remote ones into
+ *      per-owner bins of 8-byte pairs (vertex << 32 | float bits), ONE pair per target vertex and superstep carrying the
+ *      minimum over all of this rank's edges to it (min-combining before send) and only if it beats everything this
+ *      rank sent for that vertex before; the host exchanges bin r of every rank to rank r (all-to-all-v); receive keeps
+ *      the minimum and queues the vertices whose distance dropped; swap returns the next local frontier size (the host
+ *      all-reduces it: zero everywhere ends the run).  Distances equal the single-GPU ones bit for bit; unreachable
+ *      vertices hold FLT_MAX.  Device pointers are borrowed. */
+MGX_API int mgx_dsssp_create(mgx_ctx_t ctx, int n_global, int ranks, int rank, int64_t m_local, const int* d_row_offsets_local,
+                             const int* d_col_indices_global, const float* d_weights, mgx_dsssp_t* out);
+MGX_API int mgx_dsssp_free(mgx_dsssp_t h);
+MGX_API int mgx_dsssp_reset(mgx_dsssp_t h, int src_global);
+MGX_API int mgx_dsssp_expand(mgx_dsssp_t h, int64_t* host_counts_per_rank, int64_t* edges_relaxed);
+MGX_API int mgx_dsssp_bins(mgx_dsssp_t h, uint64_t** d_bins, int64_t* bin_capacity); /* bin r at d_bins + r*capacity */
+MGX_API int mgx_dsssp_receive(mgx_dsssp_t h, const uint64_t* d_pairs, int64_t count);
+MGX_API int mgx_dsssp_swap(mgx_dsssp_t h, int64_t* next_frontier_size);
+MGX_API int mgx_dsssp_distances(mgx_dsssp_t h, float* host_dist_local);
+
 /* ---- partitioned BFS, generation 2 (include/mgx/bfs_dist2.hpp): every rank runs the FUSED level
  *      kernels on its rows and ranks exchange dense "newly visited" bitmaps (one all-gather of n/8 bytes
  *      per rank and level) instead of id lists.  Ids are global and hub-first (descending global degree);
@@ -291,6 +313,22 @@ MGX_API int mgx_dbfs2_or_maps(mgx_dbfs2_t h, const unsigned* d_maps, int maps, i
  * queues */
 MGX_API int mgx_dbfs2_status(mgx_dbfs2_t h, int next_level, int64_t* out6);
 MGX_API int mgx_dbfs2_labels(mgx_dbfs2_t h, int* host_labels_local);
+
+/* ---- the partitioned traversal driven from C++ over RCCL (include/mgx/comm.hpp, bfs_dist2.hpp: d2_run) ----
+ * A communicator of the library's own: rank 0 calls mgx_comm_unique_id, the 128 bytes travel to the other ranks by any
+ * means (the Python layer broadcasts them over torch.distributed), every rank calls mgx_comm_create (collective:
+ * ncclCommInitRank).  RCCL is resolved at run time from the copy already in the process (PyTorch's librccl.so.1) or the
+ * system's; mgx_comm_library says which.  mgx_dbfs2_run then runs a WHOLE traversal: reset, and per level push -> the
+ * exchange of the new-bit maps (0: one ncclAllGather; 1: grouped ncclSend/ncclRecv of slices + OR + ncclAllGather of the
+ * merged slices) -> merge, enqueued for a batch of levels at a time on the context's stream, one synchronisation per
+ * batch; no host code runs between levels.  exchange_words: length of the exchanged map, >= mgx_dbfs2_words(n) and a
+ * multiple of 4 * ranks -- the d_newbits buffer given to mgx_dbfs2_create must be that long.  comm may be NULL for
+ * ranks == 1.  out6 as mgx_dbfs2_status. */
+MGX_API int mgx_comm_unique_id(unsigned char* out128);
+MGX_API int mgx_comm_create(mgx_ctx_t ctx, int ranks, int rank, const unsigned char* id128, mgx_comm_t* out);
+MGX_API int mgx_comm_free(mgx_comm_t comm);
+MGX_API const char* mgx_comm_library(void);
+MGX_API int mgx_dbfs2_run(mgx_dbfs2_t h, mgx_comm_t comm, int src_global, int exchange, int64_t exchange_words, int64_t* out6);
 
 /* ---- SSSP: sssp_problem_t / sssp_functor_t / sssp_enactor_t (gunrock/src/sssp/) ---- */
 MGX_API int mgx_sssp_create(mgx_graph_t g, int src, mgx_sssp_t* out);     /* sssp_problem.hxx:40-52 */

@@ -20,6 +20,7 @@
 #include <memory>
 
 #include "bfs_fused_run.hpp"
+#include "comm.hpp"
 
 namespace mgx {
 
@@ -191,6 +192,63 @@ inline void d2_status(d2_state_t& st, int next_level, standard_context_t& ctx, l
   out[3] = (long long)hc->merged_new;
   out[4] = (long long)((cur >> BFS_VSHIFT) + (lcur >> BFS_VSHIFT));
   out[5] = (long long)((cur & BFS_EMASK) + hc->ledges[next_level % 3]);
+}
+
+// ---- the whole traversal from C++: push -> RCCL exchange -> merge for a batch of levels, one synchronisation per batch ----
+// exchange 0 ("gather"): ncclAllGather of the ranks' new-bit maps, every rank ORs them (k_d2_or inside d2_merge);
+// exchange 1 ("reduce"): slice r of every map goes to rank r (grouped ncclSend / ncclRecv over the xGMI full mesh: all
+// seven links of a GPU busy at once), the owner ORs the slices, ncclAllGather of the merged slices: 2 (R - 1) / R bitmaps
+// per rank and level instead of R - 1.  xwords: length of the exchanged map (the bitmap padded to a multiple of 4 * ranks
+// words; st.newbits is that long).  Returns the status of d2_status.
+struct d2_run_bufs_t {
+  mem_t<u32> gathered;     // ranks * xwords (gather) / xwords (reduce: the merged map)
+  mem_t<u32> recv;         // reduce: the ranks' versions of this rank's slice
+  long long xwords = 0;
+  int levels_hint = 8;
+};
+
+inline void d2_run(d2_state_t& st, comm_t& cm, d2_run_bufs_t& bufs, int src, int exchange, long long xwords,
+                   standard_context_t& ctx, long long* out6) {
+  const rccl_api_t& api = rccl_api_t::get();
+  hipStream_t s = ctx.stream();
+  const int R = st.ranks;
+  if (bufs.xwords != xwords || !bufs.gathered.size()) {
+    ctx.synchronize();
+    bufs.gathered = mem_t<u32>((size_t)R * (size_t)xwords + 4, ctx);
+    bufs.recv = mem_t<u32>((size_t)xwords + 4, ctx);
+    bufs.xwords = xwords;
+  }
+  const long long S = xwords / R;                 // words per slice (xwords is a multiple of 4 * R)
+  d2_reset(st, src, ctx);
+  int level = 0;
+  int batch = bufs.levels_hint;
+  for (;;) {
+    for (int i = 0; i < batch; ++i, ++level) {
+      d2_push(st, level, ctx);
+      if (R == 1 && !cm.comm) {
+        d2_merge(st, level, st.newbits, 1, xwords, ctx);
+      } else if (exchange == 0) {
+        MGX_RCCL(api.AllGather(st.newbits, bufs.gathered.data(), (size_t)xwords, ncclUint32, cm.comm, s));
+        d2_merge(st, level, bufs.gathered.data(), R, xwords, ctx);
+      } else {
+        MGX_RCCL(api.GroupStart());
+        for (int r = 0; r < R; ++r) {
+          MGX_RCCL(api.Send(st.newbits + (size_t)r * S, (size_t)S, ncclUint32, r, cm.comm, s));
+          MGX_RCCL(api.Recv(bufs.recv.data() + (size_t)r * S, (size_t)S, ncclUint32, r, cm.comm, s));
+        }
+        MGX_RCCL(api.GroupEnd());
+        hipLaunchKernelGGL(k_d2_or_maps, dim3(grid_for(S / 4, BLOCK, 1024)), dim3(BLOCK), 0, s, (const uint4*)bufs.recv.data(), R,
+                           S / 4, S / 4, (uint4*)bufs.recv.data());
+        MGX_RCCL(api.AllGather(bufs.recv.data(), bufs.gathered.data(), (size_t)S, ncclUint32, cm.comm, s));
+        d2_merge(st, level, bufs.gathered.data(), 1, xwords, ctx);
+      }
+    }
+    MGX_CHECK_LAUNCH("partitioned BFS: kernel launch");
+    d2_status(st, level, ctx, out6);
+    if (out6[0]) break;
+    batch = 2;
+  }
+  bufs.levels_hint = (int)(out6[1] > 0 ? out6[1] + 1 : 1);      // + the level that finds nothing
 }
 
 }  // namespace mgx

@@ -1,0 +1,83 @@
+// mgx/comm.hpp -- RCCL from C++, without a link-time dependency.
+//
+// The partitioned traversal's per-level loop (bfs_dist2.hpp: push -> exchange -> merge) used to be driven from Python:
+// a torch.distributed collective between two ctypes calls per level, ~0.1 ms of interpreter per level.  With a
+// communicator of its own the library enqueues push, the RCCL collective and the merge of a whole BATCH of levels on
+// the context's stream back to back and synchronises once per batch.
+// RCCL is taken from the process: PyTorch ships its own librccl.so.1 and has loaded it by the time a process group
+// exists; dlopen finds that copy by soname (a second copy of the runtime in one process would see no peers), and falls
+// back to the system's /opt/rocm/lib/librccl.so.1 for hosts without torch.  Only the handful of entry points below.
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+#include <string>
+
+#include "runtime.hpp"
+
+namespace mgx {
+
+struct rccl_api_t {
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  void* handle = nullptr;
+  std::string where;
+
+  static rccl_api_t& get() {
+    static rccl_api_t api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+      const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+      for (int pass = 0; pass < 2 && !api.handle; ++pass)
+        for (const char* nm : names) {
+          // pass 0: only a copy that is already in the process (torch's); pass 1: load one
+          api.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+          if (api.handle) { api.where = std::string(nm) + (pass == 0 ? " (already loaded)" : ""); break; }
+        }
+      if (!api.handle) return;
+#define MGX_RCCL_SYM(field, sym) api.field = (decltype(api.field))dlsym(api.handle, sym)
+      MGX_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+      MGX_RCCL_SYM(CommInitRank, "ncclCommInitRank");
+      MGX_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+      MGX_RCCL_SYM(AllGather, "ncclAllGather");
+      MGX_RCCL_SYM(Send, "ncclSend");
+      MGX_RCCL_SYM(Recv, "ncclRecv");
+      MGX_RCCL_SYM(GroupStart, "ncclGroupStart");
+      MGX_RCCL_SYM(GroupEnd, "ncclGroupEnd");
+      MGX_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef MGX_RCCL_SYM
+    });
+    return api;
+  }
+  bool ok() const {
+    return handle && GetUniqueId && CommInitRank && CommDestroy && AllGather && Send && Recv && GroupStart && GroupEnd;
+  }
+};
+
+#define MGX_RCCL(expr)                                                                                         \
+  do {                                                                                                         \
+    ncclResult_t _r = (expr);                                                                                  \
+    if (_r != ncclSuccess) {                                                                                   \
+      const rccl_api_t& _a = ::mgx::rccl_api_t::get();                                                         \
+      throw ::mgx::mgx_error(MGX_E_HIP, std::string(#expr) + ": " + (_a.GetErrorString ? _a.GetErrorString(_r) : "RCCL error")); \
+    }                                                                                                          \
+  } while (0)
+
+struct comm_t {
+  ncclComm_t comm = nullptr;
+  int ranks = 1, rank = 0;
+  comm_t() {}
+  comm_t(const comm_t&) = delete;
+  comm_t& operator=(const comm_t&) = delete;
+  ~comm_t() { if (comm) (void)rccl_api_t::get().CommDestroy(comm); }
+};
+
+}  // namespace mgx

@@ -125,6 +125,19 @@ SIGNATURES = {
     "mgx_dbfs_receive": [_vp, _vp, _i64, _i],
     "mgx_dbfs_swap": [_vp, _pi64],
     "mgx_dbfs_labels": [_vp, _vp],
+    "mgx_comm_unique_id": [_vp],
+    "mgx_comm_create": [_vp, _i, _i, _vp, _pvp],
+    "mgx_comm_free": [_vp],
+    "mgx_comm_library": [],
+    "mgx_dbfs2_run": [_vp, _vp, _i, _i, _i64, _pi64],
+    "mgx_dsssp_create": [_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _pvp],
+    "mgx_dsssp_free": [_vp],
+    "mgx_dsssp_reset": [_vp, _i],
+    "mgx_dsssp_expand": [_vp, _pi64, _pi64],
+    "mgx_dsssp_bins": [_vp, _pvp, _pi64],
+    "mgx_dsssp_receive": [_vp, _vp, _i64],
+    "mgx_dsssp_swap": [_vp, _pi64],
+    "mgx_dsssp_distances": [_vp, _vp],
     "mgx_dbfs2_create": [_vp, _i, _i, _i, _vp, _vp, _vp, _pvp],
     "mgx_dbfs2_free": [_vp],
     "mgx_dbfs2_reset": [_vp, _i],
@@ -151,7 +164,7 @@ SIGNATURES = {
     "mgx_pr_ranks": [_vp, _vp],
     "mgx_rmat_edges": [_vp, _i, _i64, _i64, _u64, _i, _vp, _vp, _vp],
 }
-_RESTYPES = {"mgx_strerror": C.c_char_p, "mgx_last_error": C.c_char_p, "mgx_host_free": None}
+_RESTYPES = {"mgx_comm_library": C.c_char_p, "mgx_strerror": C.c_char_p, "mgx_last_error": C.c_char_p, "mgx_host_free": None}
 
 for _name, _args in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here == header/library drift

@@ -13,6 +13,7 @@
 #include "gunrock/sssp/sssp_enactor.hxx"
 #include "mgx/bfs_dist.hpp"
 #include "mgx/bfs_dist2.hpp"
+#include "mgx/sssp_dist.hpp"
 #include "mgx/sssp_fused.hpp"
 #include "mgx.h"
 
@@ -62,9 +63,19 @@ struct mgx_dbfs_s {
   mgx::dbfs_state_t st;
 };
 
+struct mgx_dsssp_s {
+  mgx_ctx_s* c;
+  mgx::dsssp_state_t st;
+};
+
 struct mgx_dbfs2_s {
   mgx_ctx_s* c;
   mgx::d2_state_t st;
+  mgx::d2_run_bufs_t run_bufs;
+};
+struct mgx_comm_s {
+  mgx_ctx_s* c;
+  mgx::comm_t cm;
 };
 
 static thread_local std::string g_last_error;
@@ -1009,6 +1020,78 @@ int mgx_dbfs_labels(mgx_dbfs_t h, int* host_labels) {
   MGX_CATCH
 }
 
+// ---- vertex-range partitioned SSSP (per-rank pieces; mgx/sssp_dist.hpp) -----------------------------------------
+int mgx_dsssp_create(mgx_ctx_t c, int n_global, int ranks, int rank, int64_t m_local, const int* d_row_offsets,
+                     const int* d_col_indices, const float* d_weights, mgx_dsssp_t* out) {
+  MGX_TRY
+  MGX_REQUIRE(c && out && d_row_offsets && ((d_col_indices && d_weights) || m_local == 0), "mgx_dsssp_create: NULL argument");
+  MGX_REQUIRE(n_global > 0 && ranks >= 1 && ranks <= mgx::DBFS_MAX_RANKS && rank >= 0 && rank < ranks, "mgx_dsssp_create: bad partition");
+  use_device(c);
+  const int chunk = (n_global + ranks - 1) / ranks;
+  const int lo = rank * chunk < n_global ? rank * chunk : n_global;
+  const int hi = (rank + 1) * chunk < n_global ? (rank + 1) * chunk : n_global;
+  auto* h = new mgx_dsssp_s();
+  h->c = c;
+  h->st.init(*c->ctx, n_global, lo, hi, ranks, rank, d_row_offsets, d_col_indices, d_weights, m_local);
+  *out = h;
+  MGX_CATCH
+}
+int mgx_dsssp_free(mgx_dsssp_t h) {
+  MGX_TRY
+  if (h) { use_device(h->c); delete h; }
+  MGX_CATCH
+}
+int mgx_dsssp_reset(mgx_dsssp_t h, int src_global) {
+  MGX_TRY
+  MGX_REQUIRE(h && src_global >= 0 && src_global < h->st.n_global, "mgx_dsssp_reset: bad argument");
+  use_device(h->c);
+  mgx::dsssp_reset(h->st, src_global, *h->c->ctx);
+  MGX_CATCH
+}
+int mgx_dsssp_expand(mgx_dsssp_t h, int64_t* counts, int64_t* edges) {
+  MGX_TRY
+  MGX_REQUIRE(h && counts, "NULL argument");
+  use_device(h->c);
+  long long e = 0;
+  mgx::dsssp_expand(h->st, *h->c->ctx, &e);
+  for (int r = 0; r < h->st.ranks; ++r) {
+    counts[r] = (int64_t)h->st.host_counters[r];
+    if (counts[r] > h->st.bin_cap) throw mgx::mgx_error(MGX_E_FRONTIER_OVERFLOW, "mgx_dsssp_expand: send bin overflow");
+  }
+  if (edges) *edges = e;
+  MGX_CATCH
+}
+int mgx_dsssp_bins(mgx_dsssp_t h, uint64_t** d_bins, int64_t* bin_cap) {
+  MGX_TRY
+  MGX_REQUIRE(h && d_bins && bin_cap, "NULL argument");
+  *d_bins = (uint64_t*)h->st.bins.data();
+  *bin_cap = h->st.bin_cap;
+  MGX_CATCH
+}
+int mgx_dsssp_receive(mgx_dsssp_t h, const uint64_t* d_pairs, int64_t count) {
+  MGX_TRY
+  MGX_REQUIRE(h && (d_pairs || count == 0) && count >= 0, "bad argument");
+  use_device(h->c);
+  mgx::dsssp_receive(h->st, (const unsigned long long*)d_pairs, count, *h->c->ctx);
+  MGX_CATCH
+}
+int mgx_dsssp_swap(mgx_dsssp_t h, int64_t* frontier_size) {
+  MGX_TRY
+  MGX_REQUIRE(h, "NULL argument");
+  use_device(h->c);
+  const long long f = mgx::dsssp_swap(h->st, *h->c->ctx);
+  if (frontier_size) *frontier_size = f;
+  MGX_CATCH
+}
+int mgx_dsssp_distances(mgx_dsssp_t h, float* host_dist_local) {
+  MGX_TRY
+  MGX_REQUIRE(h && host_dist_local, "NULL argument");
+  use_device(h->c);
+  h->c->ctx->synchronize();
+  MGX_HIP(mgx::dtoh((unsigned*)host_dist_local, h->st.dist.data(), (size_t)h->st.n_local));
+  MGX_CATCH
+}
+
 // ---- partitioned BFS, generation 2: fused kernels per rank + bitmap exchange (mgx/bfs_dist2.hpp) ----
 int mgx_dbfs2_create(mgx_ctx_t c, int n_global, int ranks, int rank, const int* d_row_offsets_local,
                      const int* d_col_indices_global, unsigned* d_newbits, mgx_dbfs2_t* out) {
@@ -1077,6 +1160,58 @@ int mgx_dbfs2_status(mgx_dbfs2_t h, int next_level, int64_t* out6) {
   use_device(h->c);
   long long o[6];
   mgx::d2_status(h->st, next_level, *h->c->ctx, o);
+  for (int i = 0; i < 6; ++i) out6[i] = o[i];
+  MGX_CATCH
+}
+// ---- RCCL communicator of the library's own (mgx/comm.hpp) and the traversal driven from C++ ----
+int mgx_comm_unique_id(unsigned char* out128) {
+  MGX_TRY
+  MGX_REQUIRE(out128, "NULL argument");
+  mgx::rccl_api_t& api = mgx::rccl_api_t::get();
+  MGX_REQUIRE(api.ok(), "mgx_comm_unique_id: no RCCL in this process and none could be loaded (librccl.so.1)");
+  ncclUniqueId id;
+  MGX_RCCL(api.GetUniqueId(&id));
+  memcpy(out128, id.internal, NCCL_UNIQUE_ID_BYTES);
+  MGX_CATCH
+}
+int mgx_comm_create(mgx_ctx_t c, int ranks, int rank, const unsigned char* id128, mgx_comm_t* out) {
+  MGX_TRY
+  MGX_REQUIRE(c && id128 && out && ranks >= 1 && rank >= 0 && rank < ranks, "mgx_comm_create: bad argument");
+  mgx::rccl_api_t& api = mgx::rccl_api_t::get();
+  MGX_REQUIRE(api.ok(), "mgx_comm_create: no RCCL in this process and none could be loaded (librccl.so.1)");
+  use_device(c);
+  ncclUniqueId id;
+  memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+  auto* h = new mgx_comm_s();
+  h->c = c;
+  h->cm.ranks = ranks; h->cm.rank = rank;
+  ncclResult_t r = api.CommInitRank(&h->cm.comm, ranks, id, rank);
+  if (r != ncclSuccess) {
+    h->cm.comm = nullptr;
+    delete h;
+    throw mgx::mgx_error(MGX_E_HIP, std::string("ncclCommInitRank: ") + (api.GetErrorString ? api.GetErrorString(r) : "RCCL error"));
+  }
+  *out = h;
+  MGX_CATCH
+}
+int mgx_comm_free(mgx_comm_t h) {
+  MGX_TRY
+  if (h) { use_device(h->c); delete h; }
+  MGX_CATCH
+}
+const char* mgx_comm_library(void) { return mgx::rccl_api_t::get().where.c_str(); }
+int mgx_dbfs2_run(mgx_dbfs2_t h, mgx_comm_t comm, int src_global, int exchange, int64_t exchange_words, int64_t* out6) {
+  MGX_TRY
+  MGX_REQUIRE(h && out6 && src_global >= 0 && src_global < h->st.n_global, "mgx_dbfs2_run: bad argument");
+  MGX_REQUIRE(exchange == 0 || exchange == 1, "mgx_dbfs2_run: exchange is 0 (all-gather) or 1 (slices + all-gather)");
+  MGX_REQUIRE(comm || h->st.ranks == 1, "mgx_dbfs2_run: a communicator is needed for more than one rank");
+  MGX_REQUIRE(!comm || (comm->cm.ranks == h->st.ranks && comm->cm.rank == h->st.rank), "mgx_dbfs2_run: communicator and engine disagree on the partition");
+  MGX_REQUIRE(exchange_words >= h->st.nwords && exchange_words % (4 * h->st.ranks) == 0,
+              "mgx_dbfs2_run: exchange_words must cover the bitmap and be a multiple of 4 * ranks");
+  use_device(h->c);
+  mgx::comm_t none;
+  long long o[6];
+  mgx::d2_run(h->st, comm ? comm->cm : none, h->run_bufs, src_global, exchange, (long long)exchange_words, *h->c->ctx, o);
   for (int i = 0; i < 6; ++i) out6[i] = o[i];
   MGX_CATCH
 }

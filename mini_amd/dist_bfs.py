@@ -211,6 +211,14 @@ class HipRankEngine2:
         check(lib.mgx_dbfs2_status(self._h, int(next_level), o))
         return {"over": bool(o[0]), "levels": o[1], "edges_local": o[2], "new_global": o[3]}
 
+    def run_native(self, src, comm, exchange):
+        """a whole traversal inside the library (mgx_dbfs2_run): push -> RCCL exchange -> merge per level, enqueued in
+        batches from C++ on the context's stream -- no Python between levels.  comm: NativeComm or None (one rank)."""
+        o = (C.c_int64 * 6)()
+        check(lib.mgx_dbfs2_run(self._h, comm._h if comm is not None else None, int(src), 1 if exchange == "reduce" else 0,
+                                int(self.newbits.numel()), o))
+        return {"over": bool(o[0]), "levels": o[1], "edges_local": o[2], "new_global": o[3]}
+
     def labels(self):
         out = np.empty(self.n_local, dtype=np.int32)
         check(lib.mgx_dbfs2_labels(self._h, out.ctypes.data_as(C.c_void_p)))
@@ -219,6 +227,32 @@ class HipRankEngine2:
     def close(self):
         if self._h:
             lib.mgx_dbfs2_free(self._h)
+            self._h = None
+
+
+class NativeComm:
+    """An RCCL communicator owned by the library (include/mgx/comm.hpp): rank 0 makes the unique id, torch.distributed
+    carries its 128 bytes to the other ranks, every rank joins (ncclCommInitRank)."""
+
+    def __init__(self, ctx, rank, world, comm_device):
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_ubyte * 128)()
+            check(lib.mgx_comm_unique_id(buf))
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        if world > 1:
+            t = ident.to(comm_device)
+            dist.broadcast(t, 0)
+            ident = t.cpu()
+        raw = (C.c_ubyte * 128)(*ident.tolist())
+        h = C.c_void_p()
+        check(lib.mgx_comm_create(ctx._h, int(world), int(rank), raw, C.byref(h)))
+        self._h = h
+        self.library = (lib.mgx_comm_library() or b"").decode()
+
+    def close(self):
+        if self._h:
+            lib.mgx_comm_free(self._h)
             self._h = None
 
 
@@ -244,6 +278,14 @@ class DistBfs2:
         if mode not in ("gather", "reduce"):
             mode = "reduce" if world >= 4 else "gather"
         self.exchange = mode
+        # The per-level loop inside the library over a communicator of its own (mgx_dbfs2_run) whenever the engine is
+        # the HIP one and the collectives run on the GPUs (RCCL); the Python loop below serves the gloo tests, the
+        # one-GPU pre-flights and MGX_DIST_NATIVE=0.
+        self.native, self.comm = False, None
+        if hasattr(engine, "run_native") and self.comm_device.type == "cuda" and os.environ.get("MGX_DIST_NATIVE", "1") != "0":
+            if world > 1 or os.environ.get("MGX_DIST_FORCE_COLLECTIVES") == "1":
+                self.comm = NativeComm(engine.ctx, rank, world, self.comm_device)
+            self.native = True
 
     def _exchange(self, new):
         """-> (maps, nmaps): what merge() takes"""
@@ -280,6 +322,10 @@ class DistBfs2:
 
     def run(self, src):
         e = self.e
+        if self.native:
+            st = e.run_native(src, self.comm, self.exchange)
+            self.levels = st["levels"]
+            return {"levels": st["levels"], "edges_local": st["edges_local"]}
         e.reset(src)
         level = 0
         batch = self.levels_hint

@@ -120,3 +120,68 @@ class NumpyRankEngine2:
 
     def labels(self):
         return self.lab.copy()
+
+
+class NumpySsspRankEngine:
+    """numpy stand-in for mini_amd.dist_sssp.HipSsspRankEngine (range partition, (vertex, distance) pairs with
+    min-combining before send).  Same reset/expand/send_bin/receive/swap/distances contract."""
+    device = torch.device("cpu")
+
+    def __init__(self, n_global, ranks, rank, ro_local, ci_global, w_local):
+        self.n_global, self.ranks, self.rank = n_global, ranks, rank
+        self.lo, self.hi = range_of(n_global, ranks, rank)
+        self.cap = chunk_of(n_global, ranks)
+        self.ro = np.asarray(ro_local, dtype=np.int64)
+        self.ci = np.asarray(ci_global, dtype=np.int64)
+        self.w = np.asarray(w_local, dtype=np.float32)
+        self._bins = [np.zeros(0, dtype=np.int64)] * ranks
+
+    def reset(self, src):
+        inf = np.float32(np.finfo(np.float32).max)
+        self.dist = np.full(self.hi - self.lo, inf, dtype=np.float32)
+        self.best = np.full(self.n_global, inf, dtype=np.float32)
+        self.best[src] = 0.0
+        self.front, self.next = [], set()
+        if self.lo <= src < self.hi:
+            self.dist[src - self.lo] = 0.0
+            self.front = [src - self.lo]
+
+    def expand(self):
+        edges, touched = 0, set()
+        for u in self.front:
+            du = self.dist[u]
+            for e in range(self.ro[u], self.ro[u + 1]):
+                g, cand = int(self.ci[e]), np.float32(du + self.w[e])
+                edges += 1
+                if self.lo <= g < self.hi:
+                    if cand < self.dist[g - self.lo]:
+                        self.dist[g - self.lo] = cand
+                        self.next.add(g - self.lo)
+                elif cand < self.best[g]:
+                    self.best[g] = cand
+                    touched.add(g)
+        self._bins = []
+        for r in range(self.ranks):
+            ids = sorted(g for g in touched if g // self.cap == r)
+            bits = self.best[ids].view(np.uint32).astype(np.int64) if ids else np.zeros(0, dtype=np.int64)
+            self._bins.append((np.asarray(ids, dtype=np.int64) << 32) | bits)
+        return [len(b) for b in self._bins], edges
+
+    def send_bin(self, r):
+        return torch.from_numpy(self._bins[r].copy())
+
+    def receive(self, pairs):
+        p = pairs.numpy()
+        for x in p.tolist():
+            v = (x >> 32) - self.lo
+            d = np.array([x & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0]
+            if d < self.dist[v]:
+                self.dist[v] = d
+                self.next.add(v)
+
+    def swap(self):
+        self.front, self.next = sorted(self.next), set()
+        return len(self.front)
+
+    def distances(self):
+        return self.dist.copy()

@@ -182,6 +182,58 @@ def test_or_maps_kernel_matches_numpy(built):
     eng.close()
 
 
+def _worker_sssp(rank, world, port, use_gpu, scale, seed, sources, q):
+    """partitioned SSSP: range partition, (vertex, distance) pairs with min-combining before send"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mini_amd.dist_bfs import range_of
+    from mini_amd.dist_sssp import DistSssp
+    from tests.oracle_binding import Oracle
+    orc = Oracle()
+    n, ro, ci, w = orc.rmat_csr(scale, 16, seed)
+    lo, hi = range_of(n, world, rank)
+    ro_l, ci_l = _shard(ro, ci, lo, hi)
+    w_l = w[ro[lo]:ro[hi]].astype(np.float32)
+    if use_gpu:
+        import mini_amd
+        from mini_amd.dist_sssp import HipSsspRankEngine
+        torch.cuda.set_device(0)
+        ctx = mini_amd.Context(0, torch.cuda.current_stream().cuda_stream)
+        eng = HipSsspRankEngine(ctx, n, world, rank, torch.from_numpy(ro_l).cuda(), torch.from_numpy(ci_l).cuda(),
+                                torch.from_numpy(w_l).cuda())
+    else:
+        from tests.dist_cpu_engine import NumpySsspRankEngine
+        eng = NumpySsspRankEngine(n, world, rank, ro_l, ci_l, w_l)
+    sssp = DistSssp(eng, rank, world, "cpu")
+    ok = True
+    for src in sources:
+        st = sssp.run(src)
+        got = sssp.gather_distances()
+        want = orc.sssp_dijkstra_f32(ro, ci, w, src)          # (integer weights: every float32 path sum is exact)
+        ok = ok and np.array_equal(got, want) and st["iterations"] >= 1
+        # min-combining: a rank sends at most one pair per (target vertex, superstep)
+        ok = ok and st["pairs_sent"] <= st["iterations"] * n
+    if rank == 0:
+        q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_partitioned_sssp_gloo_cpu(built, world):
+    _run(world, False, 7, 21, _worker_sssp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,scale", [(1, 12), (2, 12), (3, 14)])
+def test_partitioned_sssp_hip_engine_ranks_share_one_gpu(built, world, scale):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _run(world, True, scale, 30 + scale, _worker_sssp)
+
+
 def _bench_preflight(world, extra_args, env_extra):
     """bench.py's N > 1 body (bench_dist.bench_main) under torch.distributed.run with `world` ranks sharing the
     one GPU of the test box over gloo (RCCL refuses two ranks on one device): the launch contract, the partition, the
@@ -193,7 +245,8 @@ def _bench_preflight(world, extra_args, env_extra):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, MGX_BENCH_ALL_ON_GPU0="1", MGX_BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    env = dict(os.environ, MGX_BENCH_ALL_ON_GPU0="1", MGX_BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1"] + extra_args
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -221,3 +274,18 @@ def test_bench_main_preflight_ranks_share_one_gpu(built, world, extra, env_extra
         assert "oracle" in j["parity_check"]
         if "--no-cpu-baseline" not in extra:
             assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange,collectives", [("gather", "1"), ("reduce", "1"), ("gather", "0")])
+def test_bench_main_native_rccl_loop_one_rank(built, exchange, collectives):
+    """the per-level loop INSIDE the library over a communicator of its own (mgx_comm_*, mgx_dbfs2_run): bench.py's N > 1
+    body under a one-rank RCCL group -- ncclCommInitRank, ncclAllGather and grouped ncclSend / ncclRecv issued from C++
+    between the push and merge launches of a batch of levels (collectives 1), or the same loop without a communicator
+    (0: what a single rank needs); parity against the oracle as in every bench line"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    j = _bench_preflight(1, ["--scale", "15"], {"MGX_BENCH_FORCE_DIST": "1", "MGX_BENCH_DIST_BACKEND": "nccl",
+                                                "MGX_DIST_FORCE_COLLECTIVES": collectives, "MGX_DIST_EXCHANGE": exchange})
+    assert j["n_gpus"] == 1 and j["parity_vs_oracle"] is True and j["value"] > 0
+    assert j["config"]["native_loop"] is True
