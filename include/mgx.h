@@ -346,6 +346,12 @@ MGX_API int mgx_sssp_filter(mgx_sssp_t p, mgx_frontier_t in, mgx_frontier_t out,
 MGX_API int mgx_sssp_enact(mgx_sssp_t p, float queue_sizing, int64_t* stats);
 /* fused device-resident SSSP (same fixed point): stats as above                          */
 MGX_API int mgx_sssp_run(mgx_sssp_t p, int src, int64_t* stats);
+/* the same with near / far buckets of width delta (the delta-stepping BASELINE config 3 names): improved vertices whose
+ * distance lies at or above the current threshold wait until the queue of nearer ones has run dry, then the threshold
+ * moves to the bucket of the smallest waiting distance.  Same fixed point, fewer relaxations, more (cheap) iterations.
+ * delta == 0: off (plain frontier Bellman-Ford, what mgx_sssp_run does); delta < 0: the default (off; the environment
+ * variable MGX_SSSP_DELTA overrides either).  stats as above ([0] counts the iterations incl. the bucket changes). */
+MGX_API int mgx_sssp_run_delta(mgx_sssp_t p, int src, float delta, int64_t* stats);
 
 /* ---- PR: pr_problem_t / pr_functor_t / pr_enactor_t (gunrock/src/pr/) ---- */
 MGX_API int mgx_pr_create(mgx_graph_t g, int max_iter, mgx_pr_t* out);    /* pr_problem.hxx:33-44   */

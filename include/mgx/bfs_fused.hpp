@@ -84,6 +84,11 @@ struct bfs_ctrl_t {
   // as a bitmap into flush buffer 0 .. count - 1 instead of storing marks; zeroed one slot ahead by the opener.
   u32 flush_count[2];
   int fb_slot;       // frontier_bits holds exactly the frontier of this slot (written by the k_bfs_build of the slot before)
+  // fused SSSP with near / far buckets (sssp_fused.hpp): the current threshold (float bits) and, per iteration parity,
+  // how many improved vertices the queue build left for a later bucket and the smallest of their distances
+  u32 sssp_thr;
+  u32 sssp_far_cnt[2];
+  u32 sssp_far_min[2];
   int dense_slots;   // slots whose long rows were read from the unit blocks (bfs_fused_dense.hpp)
   int pad_[2];
   u64 stamp[64];     // s_memrealtime (100 MHz) when each level was opened: per-level times without host syncs
@@ -141,6 +146,9 @@ __device__ __forceinline__ void bfs_ctrl_reset(bfs_ctrl_t* c) {
   c->flush_count[0] = c->flush_count[1] = 0;
   c->fb_slot = 0;                                  // k_bfs_fused_init seeds frontier_bits with the source
   c->dense_slots = 0;
+  c->sssp_thr = 0x7f7fffffu;
+  c->sssp_far_cnt[0] = c->sssp_far_cnt[1] = 0;
+  c->sssp_far_min[0] = c->sssp_far_min[1] = 0x7f7fffffu;
   for (int i = 0; i < 64; ++i) c->stamp[i] = 0;
 }
 
@@ -701,6 +709,19 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
   }
 }
 
+// End of a batch of launches: the control block's head goes to the host's pinned copy, then a sequence number the host
+// is spinning on.  Instead of a D2H copy (a blit kernel of its own, ~4.5 us) followed by hipStreamSynchronize (the
+// runtime's wake-up path): the words are stored straight into host memory by one wave, fenced at system scope, and the
+// host reads them the moment the number changes.
+__global__ void k_bfs_publish(const bfs_ctrl_t* __restrict__ c, bfs_ctrl_t* __restrict__ host, u64* host_seq, u64 seq, int words) {
+  const u32* const src = (const u32*)c;
+  u32* const dst = (u32*)host;
+  for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // per-BFS device state of the fused engine
 struct bfs_fused_state_t {
   mem_t<u32> visited;
@@ -714,6 +735,9 @@ struct bfs_fused_state_t {
   mem_t<u32> flush_buf;              // deferred hot marks: BFS_FLUSH_MAX bitmaps of BFS_FLUSH_WORDS words (allocated on demand)
   unsigned defer_min_marks = 2048;   // a push workgroup with more deferred discoveries flushes a bitmap (MGX_BFS_DEFER: 0 = never defer)
   bfs_ctrl_t* host_ctrl = nullptr;   // pinned copy for stats
+  u64* host_seq = nullptr;           // pinned: the batch number k_bfs_publish stores when the copy above is complete
+  u64 seq = 0;
+  bool spin = true;                  // wait for a batch by spinning on host_seq (MGX_BFS_SPIN=0: copy + hipStreamSynchronize)
   int n = 0;
   int levels_per_sync = 2;           // slots (bfs_fused_run.hpp) launched between two read-backs of the control block ...
   int slots_hint = 5;                // ... except for the first batch: as many slots as the previous traversal needed
@@ -761,6 +785,8 @@ struct bfs_fused_state_t {
     }
     ctrl = mem_t<bfs_ctrl_t>(1, ctx);
     MGX_HIP(hipHostMalloc((void**)&host_ctrl, sizeof(bfs_ctrl_t), hipHostMallocDefault));
+    MGX_HIP(hipHostMalloc((void**)&host_seq, 64, hipHostMallocDefault));
+    *host_seq = 0;
     MGX_HIP(hipEventCreate(&ev0));
     MGX_HIP(hipEventCreate(&ev1));
     for (int i = 0; i < EV_POOL; ++i) MGX_HIP(hipEventCreate(&wev[i]));
@@ -775,6 +801,7 @@ struct bfs_fused_state_t {
   bfs_fused_state_t& operator=(const bfs_fused_state_t&) = delete;
   ~bfs_fused_state_t() {
     if (host_ctrl) (void)hipHostFree(host_ctrl);
+    if (host_seq) (void)hipHostFree(host_seq);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     for (int i = 0; i < EV_POOL; ++i) if (wev[i]) (void)hipEventDestroy(wev[i]);

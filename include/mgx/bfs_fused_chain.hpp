@@ -137,15 +137,13 @@ __device__ __forceinline__ void bfs_chain_body(const bfs_fused_args_t& a, int sl
         int d[EPT];
 #pragma unroll
         for (int k = 0; k < EPT; ++k) d[k] = a.col_indices[act[k] ? s_row[sj[k]] + (r[k] - s_off[sj[k]]) : 0u];
-        u32 word[EPT];
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) word[k] = a.visited[(u32)d[k] >> 5];     // (a stale word only costs an atomic)
+        // (no look at the word first: at this size the few thousand atomics cost less than the extra dependent load --
+        //  a lone workgroup pays ~2 us for every round trip to memory, and a level is a chain of them)
         u32 old[EPT];
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
           const u32 bit = 1u << (d[k] & 31);
-          old[k] = 0xFFFFFFFFu;
-          if (act[k] && !(word[k] & bit)) old[k] = atomicOr(a.visited + ((u32)d[k] >> 5), bit);
+          old[k] = act[k] ? atomicOr(a.visited + ((u32)d[k] >> 5), bit) : 0xFFFFFFFFu;
         }
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {

@@ -1,7 +1,7 @@
 // mgx/bfs_fused_pull.hpp -- bottom-up level of direction-optimising runs.
 // One lane per vertex: an unvisited vertex walks its in-edges until it meets a member of the level's
 // frontier bitmap (early exit -- the reference's advance_backward_kernel inspects every in-edge,
-// advance.hxx:142-157).  Like the push kernels it only sets mark[v]; k_bfs_build turns the marks into bitmap
+// advance.hxx:142-157); what is left of a long list after a few fruitless probes is walked by the whole wave, 64 edges a step.  Like the push kernels it only sets mark[v]; k_bfs_build turns the marks into bitmap
 // bits, labels and the next level's sizes.
 #pragma once
 #include "bfs_fused.hpp"
@@ -26,16 +26,51 @@ __global__ __launch_bounds__(NT) void k_bfs_pull_level(bfs_fused_args_t a, int a
   for (long long base = v_begin; base < v_end; base += NT) {
     const long long v = base + threadIdx.x;
     const bool active = v < v_end;
+    bool unvisited = false;
+    u32 e0 = 0, e1 = 0;
     if (active) {
       const u32 word = a.visited[v >> 5];
-      if (!((word >> (v & 31)) & 1u)) {
-        const u32 e0 = a.in_offsets[v], e1 = a.in_offsets[v + 1];
-        for (u32 e = e0; e < e1; ++e) {
-          const u32 u = (u32)a.in_indices[e];
-          ++inspected;
-          if ((a.frontier_bits[u >> 5] >> (u & 31)) & 1u) { a.mark[v] = 1; break; }
-        }
+      unvisited = !((word >> (v & 31)) & 1u);
+      if (unvisited) { e0 = a.in_offsets[v]; e1 = a.in_offsets[v + 1]; }
+    }
+    // Every lane starts on its own list, serially, and is out at the first frontier member: in-edge lists are sorted by
+    // neighbour id and the hub-first layout puts the vertices most likely to be in the frontier first, so most lanes
+    // are done within a few probes.  A short list is walked to its end that way.  A LONG list whose first PULL_PROBES
+    // entries held no frontier member (a lane walking a 10 000-entry list alone would hold its wave for as long) is
+    // handed to the whole wave afterwards: 64 consecutive in-edges per step, coalesced, out at the first step in which
+    // any lane meets a frontier member.  (Taking every long list cooperatively from its first entry was measured 3.5 x
+    // slower on a level with many unvisited mid-degree vertices: 64 lists one after the other per wave, a dependent
+    // load each, where 64 lanes would have been done after a probe or two each.)
+    constexpr u32 PULL_PROBES = 8;
+    bool found = false;
+    u32 e = e0;
+    if (unvisited) {
+      const bool is_long = e1 - e0 >= (u32)WAVE;
+      const u32 stop = is_long ? e0 + PULL_PROBES : e1;
+      for (; e < stop; ++e) {
+        const u32 u = (u32)a.in_indices[e];
+        ++inspected;
+        if ((a.frontier_bits[u >> 5] >> (u & 31)) & 1u) { found = true; break; }
       }
+      if (found) a.mark[v] = 1;
+    }
+    u64 big = __ballot(unvisited && !found && e < e1);
+    while (big) {
+      const int leader = __ffsll((long long)big) - 1;
+      big &= big - 1ull;
+      const u32 s0 = (u32)__shfl((int)e, leader, WAVE), s1 = (u32)__shfl((int)e1, leader, WAVE);
+      bool hit_any = false;
+      for (u32 b = s0; b < s1 && !hit_any; b += WAVE) {
+        const u32 ee = b + (u32)lane;
+        bool hit = false;
+        if (ee < s1) {
+          const u32 u = (u32)a.in_indices[ee];
+          ++inspected;
+          hit = (a.frontier_bits[u >> 5] >> (u & 31)) & 1u;
+        }
+        hit_any = __ballot(hit) != 0ull;
+      }
+      if (hit_any && lane == leader) a.mark[v] = 1;
     }
   }
   const int insp = wave_sum(inspected);

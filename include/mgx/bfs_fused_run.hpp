@@ -153,6 +153,7 @@ struct bfs_run_opts_t {
   int dense = -1;          // MGX_BFS_DENSE: 0 never, N > 0 dense_div = N (default 16)
   long long chain = -1;    // MGX_BFS_CHAIN_MAX_EDGES: 0 never (default BFS_CHAIN_CAP)
   long long defer = -1;    // MGX_BFS_DEFER: 0 never defer hot marks, N: flush a bitmap above N deferred marks per workgroup
+  int spin = -1;           // MGX_BFS_SPIN: 0 read the control block back with a copy + hipStreamSynchronize, 1 publish kernel + spin
   int biglds = 0;          // MGX_BFS_BIGLDS (experiment, timed mode)
   int build_list = 0;      // MGX_BFS_BUILD_LIST=1: the list-based queue build (k_bfs_build) instead of k_bfs_build2
   int build_diag = 0;      // MGX_BFS_BUILD_DIAG: parts of k_bfs_build switched off (measurements only)
@@ -168,6 +169,7 @@ struct bfs_run_opts_t {
     if (const char* e = getenv("MGX_BFS_BUILD_DIAG")) o.build_diag = atoi(e);
     if (const char* e = getenv("MGX_BFS_BUILD_LIST")) o.build_list = atoi(e);
     if (const char* e = getenv("MGX_BFS_BIGLDS")) o.biglds = atoi(e);
+    if (const char* e = getenv("MGX_BFS_SPIN")) o.spin = atoi(e);
     if (const char* e = getenv("MGX_BFS_DEFER")) o.defer = atoll(e);
     return o;
   }
@@ -303,10 +305,25 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
         hipLaunchKernelGGL(k_bfs_build2<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, arg, labels, st.n);   // (2 workgroups per CU overlap their phases)
     }
     if (batch_events) MGX_HIP(hipEventRecord(st.ev1, s));
-    MGX_CHECK_LAUNCH("fused BFS: kernel launch");
     // one read-back per batch: the counters and the first 64 trace slots (the flag alone would cost the same trip)
-    MGX_HIP(hipMemcpyAsync(st.host_ctrl, st.ctrl.data(), offsetof(bfs_ctrl_t, trace) + 64 * sizeof(u64), hipMemcpyDeviceToHost, s));
-    MGX_HIP(hipStreamSynchronize(s));
+    constexpr size_t head_bytes = offsetof(bfs_ctrl_t, trace) + 64 * sizeof(u64);
+    if ((opt.spin >= 0 ? opt.spin != 0 : st.spin) && !batch_events) {
+      const u64 seq = ++st.seq;
+      hipLaunchKernelGGL(k_bfs_publish, dim3(1), dim3(256), 0, s, (const bfs_ctrl_t*)st.ctrl.data(), st.host_ctrl, st.host_seq, seq,
+                         (int)(head_bytes / 4));
+      MGX_CHECK_LAUNCH("fused BFS: kernel launch");
+      volatile u64* const flag = st.host_seq;
+      long long spins = 0;
+      while (*flag != seq) {
+        if (++spins > 20000000LL) { MGX_HIP(hipStreamSynchronize(s)); break; }     // (a failed launch: let the runtime report it)
+        __builtin_ia32_pause();
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    } else {
+      MGX_CHECK_LAUNCH("fused BFS: kernel launch");
+      MGX_HIP(hipMemcpyAsync(st.host_ctrl, st.ctrl.data(), head_bytes, hipMemcpyDeviceToHost, s));
+      MGX_HIP(hipStreamSynchronize(s));
+    }
     float ms = 0.f;
     if (batch_events) MGX_HIP(hipEventElapsedTime(&ms, st.ev0, st.ev1));
     st.level_kernel_ms += ms;

@@ -13,6 +13,11 @@
 //                  scan, current distance) appended in batches with ONE packed 64-bit cursor atomic (bfs_fused.hpp);
 //                  marks are cleared on the way.  A vertex improved several times in an iteration enters once: the
 //                  reference's filter (stamp dedup, sssp_functor.hxx cond_filter) comes for free.
+// Near / far buckets (delta > 0; the delta-stepping BASELINE config 3 names, in the near-far form): the queue build
+// only takes improved vertices whose distance lies below the current threshold T; the others KEEP their mark and wait.
+// When an iteration finds the near queue empty and marks left, T moves to the bucket of the smallest waiting distance
+// and the build sweeps again.  A vertex far from the source is then expanded once its distance has (nearly) settled
+// instead of once per improvement: plain Bellman-Ford relaxes 1.5-2.2 x the edges a settled-order run needs on RMAT-22.
 // The fixpoint of min-plus relaxation is unique whatever the order of the relaxations (float addition is
 // monotone), so the distances are bit-identical to the reference algorithm's.  Predecessors are not maintained
 // (the reference's are racy); the operator path keeps them.
@@ -39,6 +44,8 @@ struct sssp_args_t {
   bfs_ctrl_t* ctrl;      // cursor[3] (packed, rotating), sums, done, levels = iterations
   int n;
   u32 hot_min_edges;     // iterations with at least this many edges keep distance bounds of the hubs in LDS
+  float delta;           // near / far bucket width (delta-stepping; BASELINE config 3 names it): 0 = plain frontier
+                         // Bellman-Ford, every improved vertex is expanded in the next iteration
 };
 
 // layout (optional): hub-first relabelled CSR with its weights and the two id maps; distances are reported in
@@ -76,6 +83,7 @@ __global__ __launch_bounds__(BLOCK) void k_sssp_init(sssp_args_t a, int src, con
     a.q_off[0][0] = 0;
     a.q_du[0][0] = (u32)src;
     a.ctrl->cursor[0] = deg ? ((1ull << BFS_VSHIFT) | (u64)deg) : 0ull;
+    a.ctrl->sssp_thr = a.delta > 0.f ? __float_as_uint(a.delta) : SSSP_INF_BITS;     // bucket 0: [0, delta)
   }
 }
 
@@ -85,7 +93,18 @@ __device__ __forceinline__ void sssp_open(const sssp_args_t& a, int it) {
   const u64 cur = c->cursor[it % 3];
   c->cursor[(it + 2) % 3] = 0;
   if (it < 64) c->stamp[it] = __builtin_amdgcn_s_memrealtime();
+  // what the previous build left waiting behind the threshold; this iteration's build counts into the other pair
+  const u32 far_cnt = c->sssp_far_cnt[it & 1], far_min = c->sssp_far_min[it & 1];
+  c->sssp_far_cnt[(it + 1) & 1] = 0;
+  c->sssp_far_min[(it + 1) & 1] = SSSP_INF_BITS;
   if ((cur >> BFS_VSHIFT) == 0) {
+    if (far_cnt && a.delta > 0.f) {
+      // the near queue ran dry: next bucket = the one that holds the smallest waiting distance (this iteration's
+      // relax finds nothing to do, its build sweeps the marks again with the new threshold)
+      const float lo = floorf(__uint_as_float(far_min) / a.delta);
+      c->sssp_thr = __float_as_uint((lo + 1.0f) * a.delta);
+      return;
+    }
     if (!c->done) { c->done = 1; c->levels = it; }
     return;
   }
@@ -292,6 +311,7 @@ __global__ __launch_bounds__(NT) void k_sssp_build(sssp_args_t a, int it) {
   if (c->done) return;
   const long long i0 = (((long long)blockIdx.x + (long long)(threadIdx.x >> 6) * gridDim.x) * 64 + (threadIdx.x & 63)) * 16;
   u32 new16 = 0;
+  u32 far_n = 0, far_lo = SSSP_INF_BITS;
   if (i0 < a.n) {
     const u32 valid = (a.n - i0 >= 16) ? 0xFFFFu : ((1u << (int)(a.n - i0)) - 1u);
     uint4* mp = (uint4*)(a.mark + i0);
@@ -301,7 +321,35 @@ __global__ __launch_bounds__(NT) void k_sssp_build(sssp_args_t a, int it) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) new16 |= (((x[q] & 0x01010101u) * 0x10204080u) >> 28) << (4 * q);
       new16 &= valid;
-      *mp = make_uint4(0, 0, 0, 0);
+      uint4 keep = make_uint4(0, 0, 0, 0);
+      if (a.delta > 0.f) {
+        // near / far: only distances below the threshold enter the queue now; the others keep their mark
+        const u32 thr = c->sssp_thr;
+        u32 far16 = 0;
+        for (u32 rest = new16; rest;) {
+          const int q = __ffs((int)rest) - 1;
+          rest &= rest - 1;
+          const u32 d = a.dist[i0 + q];
+          if (d >= thr) { far16 |= 1u << q; far_lo = d < far_lo ? d : far_lo; }
+        }
+        new16 &= ~far16;
+        far_n = (u32)__popc(far16);
+        u32 kb[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) kb[q >> 2] |= ((far16 >> q) & 1u) << (8 * (q & 3));
+        keep = make_uint4(kb[0], kb[1], kb[2], kb[3]);
+      }
+      *mp = keep;
+    }
+  }
+  if (a.delta > 0.f) {               // (grid-uniform) what stays behind: count and smallest distance, one atomic pair per wave
+    const u32 wn = wave_sum(far_n);
+    u32 wl = far_lo;
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) { const u32 o = (u32)__shfl_xor((int)wl, d, WAVE); wl = o < wl ? o : wl; }
+    if ((threadIdx.x & (WAVE - 1)) == 0 && wn) {
+      atomicAdd(&c->sssp_far_cnt[(it + 1) & 1], wn);
+      atomicMin(&c->sssp_far_min[(it + 1) & 1], wl);
     }
   }
   u64 total64;
@@ -379,6 +427,7 @@ struct sssp_fused_state_t {
   bfs_ctrl_t* host_ctrl = nullptr;
   int n = 0;
   int iters_hint = 12;
+  float delta = 0.f;                 // near / far bucket width (0: off); MGX_SSSP_DELTA overrides
   sssp_fused_state_t(int num_nodes, standard_context_t& ctx) : n(num_nodes) {
     mark = mem_t<unsigned char>((size_t)num_nodes + 64, ctx);
     dist_layout = mem_t<u32>((size_t)num_nodes + 4, ctx);
@@ -409,6 +458,8 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   for (int i = 0; i < 2; ++i) { a.q_row[i] = st.q_row[i].data(); a.q_off[i] = st.q_off[i].data(); a.q_du[i] = st.q_du[i].data(); }
   a.ctrl = st.ctrl.data();
   a.n = st.n;
+  a.delta = st.delta;
+  if (const char* de = getenv("MGX_SSSP_DELTA")) a.delta = (float)atof(de);
   const char* const hme = getenv("MGX_SSSP_HOT_MIN_EDGES");        // (tests force the LDS bounds on small graphs)
   a.hot_min_edges = hme ? (u32)atoll(hme) : SSSP_HOT_MIN_EDGES;
   hipLaunchKernelGGL(k_sssp_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src,
@@ -430,7 +481,7 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
     if (st.host_ctrl->done) break;
     // every iteration launched so far has run: an empty next frontier ends the loop here, without the launch that
     // would find that out
-    if ((st.host_ctrl->cursor[it % 3] >> BFS_VSHIFT) == 0) {
+    if ((st.host_ctrl->cursor[it % 3] >> BFS_VSHIFT) == 0 && st.host_ctrl->sssp_far_cnt[it & 1] == 0) {
       st.host_ctrl->done = 1;
       st.host_ctrl->levels = it;
       break;

@@ -158,6 +158,7 @@ SIGNATURES = {
     "mgx_sssp_filter": [_vp, _vp, _vp, _i, _pi64],
     "mgx_sssp_enact": [_vp, _f, _pi64],
     "mgx_sssp_run": [_vp, _i, _pi64],
+    "mgx_sssp_run_delta": [_vp, _i, _f, _pi64],
     "mgx_pr_create": [_vp, _i, _pvp],
     "mgx_pr_free": [_vp],
     "mgx_pr_enact": [_vp, _pi64, _pi],

@@ -430,9 +430,13 @@ class SsspProblem:
         check(lib.mgx_sssp_enact(self._h, C.c_float(queue_sizing), st))
         return {"iterations": st[0], "relaxations": st[1], "frontier_total": st[2]}
 
-    def run(self, src):
+    def run(self, src, delta=None):
+        """fused device-resident loop; delta: near / far bucket width (None / 0: plain frontier Bellman-Ford)"""
         st = (C.c_int64 * 3)()
-        check(lib.mgx_sssp_run(self._h, int(src), st))
+        if delta is None:
+            check(lib.mgx_sssp_run(self._h, int(src), st))
+        else:
+            check(lib.mgx_sssp_run_delta(self._h, int(src), C.c_float(delta), st))
         return {"iterations": st[0], "relaxations": st[1], "frontier_total": st[2]}
 
     def close(self):

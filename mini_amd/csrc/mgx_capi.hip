@@ -1328,7 +1328,8 @@ int mgx_sssp_enact(mgx_sssp_t p, float queue_sizing, int64_t* stats) {
   }
   MGX_CATCH
 }
-int mgx_sssp_run(mgx_sssp_t p, int src, int64_t* stats) {
+int mgx_sssp_run(mgx_sssp_t p, int src, int64_t* stats) { return mgx_sssp_run_delta(p, src, -1.0f, stats); }
+int mgx_sssp_run_delta(mgx_sssp_t p, int src, float delta, int64_t* stats) {
   // device-resident loop (include/mgx/sssp_fused.hpp): distances identical to mgx_sssp_enact's; predecessors are
   // left at -1 (the reference's are racy, the operator path keeps them)
   int rc = mgx_sssp_reset(p, src);
@@ -1341,6 +1342,8 @@ int mgx_sssp_run(mgx_sssp_t p, int src, int64_t* stats) {
   check_weights(p->g);
   MGX_REQUIRE(p->g->weights_ok, "mgx_sssp_run: negative or NaN weight");
   if (!p->fused) p->fused.reset(new mgx::sssp_fused_state_t(G.num_nodes, ctx));
+  MGX_REQUIRE(!(delta != delta) && delta < 3e38f, "mgx_sssp_run_delta: delta must be a finite number (< 0: the default)");
+  p->fused->delta = delta < 0.f ? 0.f : delta;
   mgx::sssp_layout_t layout;
   if (G.has_layout && G.has_layout_weights) {
     layout.row_offsets = G.d_layout_row_offsets.data();

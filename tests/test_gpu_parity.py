@@ -758,3 +758,33 @@ def test_bfs_large_rmat_properties(gpu_ctx, torch_mod):
     st2 = bfs2.run(src)
     assert np.array_equal(bfs2.labels(), fused)
     assert st2["m_t"] == st["m_t"] and st2["reached"] == st["reached"]
+
+
+@pytest.mark.parametrize("layout", [False, True])
+def test_sssp_fused_near_far_buckets(gpu_ctx, oracle, layout):
+    """delta-stepping in its near / far form (mgx_sssp_run_delta): the same distances as the plain loop and the oracle
+    for every bucket width -- tiny (every improvement waits for its bucket), around the mean weight, huge (one bucket ==
+    plain Bellman-Ford) -- on integer and on real-valued weights, with and without the hub-first copy; and fewer edge
+    relaxations than the plain loop at a sensible width"""
+    import mini_amd
+    rng = np.random.default_rng(77)
+    fewer = 0
+    for trial in range(4):
+        n, ro, ci, w = oracle.rmat_csr(int(rng.integers(9, 15)), int(rng.integers(4, 20)), int(rng.integers(1, 1 << 20)))
+        if trial % 2:
+            w = (rng.random(len(ci)) * 10.0).astype(np.float32)
+        g = _graph(gpu_ctx, ro, ci, w)
+        if layout:
+            g.build_layout(weights=True)
+        deg = np.diff(ro)
+        sssp = mini_amd.SsspProblem(g, 0)
+        for src in (int(np.argmax(deg)), int(np.where(deg > 0)[0][3])):
+            want = oracle.sssp_dijkstra_f32(ro, ci, w, src)
+            base = sssp.run(src)
+            assert np.array_equal(sssp.distances(), want)
+            for delta in (0.0, 0.5, 4.0, 32.0, 1e9):
+                st = sssp.run(src, delta=delta)
+                assert np.array_equal(sssp.distances(), want), (trial, src, delta)
+                if delta == 4.0 and st["relaxations"] < base["relaxations"]:
+                    fewer += 1
+    assert fewer >= 4

@@ -41,10 +41,10 @@ for rnd in range(a.rounds):
             bfs.run(s, a.mode, a.alpha)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        m_t = 0
+        m_t, nb, nsl = 0, 0, 0
         for s in srcs[a.warmup:]:
             st = bfs.run(s, a.mode, a.alpha)
-            m_t += st["m_t"]
+            m_t += st["m_t"]; nb += len(bfs.batch_times_ms()); nsl += st["slots"]
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         lab = bfs.labels()
@@ -52,7 +52,7 @@ for rnd in range(a.rounds):
             ref = lab.copy()
         same = bool(np.array_equal(lab, ref))
         results[cfg].append(dt / a.steps * 1e3)
-        print("round %d  %-60s %.4f ms/BFS  %.1f GTEPS  slots %d dense %d small %d  labels_equal %s" % (
-            rnd, cfg or "(defaults)", dt / a.steps * 1e3, m_t / dt / 1e9, st["slots"], st["dense_slots"], st["small_levels"], same), flush=True)
+        print("round %d  %-60s %.4f ms/BFS  %.1f GTEPS  slots %.2f batches %.2f dense %d small %d  labels_equal %s" % (
+            rnd, cfg or "(defaults)", dt / a.steps * 1e3, m_t / dt / 1e9, nsl / a.steps, nb / a.steps, st["dense_slots"], st["small_levels"], same), flush=True)
 for cfg in configs:
     print("best  %-60s %.4f ms/BFS" % (cfg or "(defaults)", min(results[cfg])))

@@ -37,6 +37,16 @@ for s in srcs[1:]:
         s, st["iterations"], st["relaxations"], st["frontier_total"], dt * 1e3, st["relaxations"] / dt / 1e6))
 print("SSSP RMAT-%d fused loop: %.1f MTEPS (relaxations/s) over %d sources, %.3f ms per source; distances == operator path: %s" % (
     a.scale, tot_relax / tot_t / 1e6, a.runs, tot_t / a.runs * 1e3, bool(np.array_equal(sssp.distances(), op_dist))))
+# near / far buckets (delta-stepping): fewer relaxations, more iterations
+for delta in (4.0, 8.0, 16.0, 32.0, 64.0):
+    sssp.run(srcs[0], delta=delta)
+    tot_t, tot_relax, tot_it = 0.0, 0, 0
+    for s in srcs[1:]:
+        ctx.synchronize()
+        t0 = time.perf_counter(); st = sssp.run(s, delta=delta); ctx.synchronize(); dt = time.perf_counter() - t0
+        tot_t += dt; tot_relax += st["relaxations"]; tot_it += st["iterations"]
+    print("SSSP RMAT-%d fused loop, near/far delta %g: %.3f ms per source, %.1f M relaxations, %.1f iterations per source; distances == operator path: %s" % (
+        a.scale, delta, tot_t / a.runs * 1e3, tot_relax / a.runs / 1e6, tot_it / a.runs, bool(np.array_equal(sssp.distances(), op_dist))))
 if a.check:
     from tests.oracle_binding import Oracle
     orc = Oracle(); ci = g["col_indices"].cpu().numpy(); w = g["weights"].cpu().numpy()
