@@ -126,6 +126,7 @@ struct bfs_fused_args_t {
   u32 dense_div;           // a slot reads its long rows from the unit blocks when frontier units * dense_div >= ub_units (0: never)
   u32* flush_buf;          // BFS_FLUSH_MAX buffers of BFS_FLUSH_WORDS words (NULL: hot marks are never deferred)
   u32 defer_min_marks;     // a workgroup with more deferred discoveries than this flushes them as a bitmap (else: byte marks)
+  int interleave;          // merged push launch: even workgroups take the long rows, odd ones the short rows (instead of first half / second half)
   int build_diag;          // measurements only (MGX_BFS_BUILD_DIAG; results wrong): 1 no label stores, 2 no extent gathers, 4 no cursor atomics
   int dense_diag;          // measurements only (MGX_BFS_DENSE_DIAG): 1 the unit-block body stores no marks, 2 tests nothing
   u32 chain_max_edges;     // a level of at most this many edges (and BFS_CHAIN_CQ rows) runs inside block 0 of the push launch (0: never)
@@ -574,7 +575,12 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
   if (c->done || c->skip_build[slot & 3]) return;
   if (blockIdx.x == 0 && threadIdx.x == 0) c->fb_slot = slot + 1;     // frontier_bits: written in full below
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long i0 = (((long long)blockIdx.x + (long long)wave * gridDim.x) * 64 + lane) * 16;
+  // A workgroup owns NW runs of 1024 vertices, gridDim runs apart (under the hub-first layout a level's discoveries
+  // sit in a prefix of the ids: every workgroup gets its share of it).  Inside the workgroup a run is spread over ALL
+  // waves -- thread t takes group t / NW (16 vertices) of run t % NW -- so that the one or two runs that hold the
+  // workgroup's discoveries keep every wave busy instead of one; a wave still reads NW pieces of 128 contiguous bytes.
+  const int my_run = threadIdx.x % NW, my_group = threadIdx.x / NW;
+  const long long i0 = (((long long)blockIdx.x + (long long)my_run * gridDim.x) * 64 + my_group) * 16;
   const int new_label = level + 1;
   const u32 long_min = a.long_min > 0 ? (u32)a.long_min : 0xFFFFFFFFu;
 
@@ -592,9 +598,9 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
         for (u32 k = (u32)wave; k < F; k += NW) acc |= col[(size_t)k * (BFS_FLUSH_WORDS * 2)];
         s_or[wave][lane] = acc;
         __syncthreads();
-        if (wave == hr) {
+        if (my_run == hr) {
 #pragma unroll
-          for (int w = 0; w < NW; ++w) flushed16 |= s_or[w][lane];
+          for (int w = 0; w < NW; ++w) flushed16 |= s_or[w][my_group];
         }
         __syncthreads();
       }

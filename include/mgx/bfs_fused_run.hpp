@@ -87,13 +87,19 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
   }
   if ((PART == 0 || PART == 1) && blockIdx.x == 0 && threadIdx.x == 0) bfs_slot_open(a, p);
   if (p.empty || PART == 1) return;
-  if (PART == 2 || (PART == 0 && blockIdx.x < nstream)) {
+  // Which part this workgroup takes: the first nstream workgroups the long rows, the others the short rows.
+  // (interleave: even / odd instead, so that the two parts share every CU -- an experiment that lost, see bfs_run_opts_t)
+  const bool il = PART == 0 && a.interleave && gridDim.x == 2u * nstream;
+  const bool long_part = PART == 2 || (PART == 0 && (il ? !(blockIdx.x & 1u) : blockIdx.x < nstream));
+  if (long_part) {
     const u32 nb = PART == 0 ? nstream : gridDim.x;
-    if (!COLDT && p.dense) bfs_dense_body<1024, BFS_DENSE_HOTW>(a, p.slot, blockIdx.x, nb, p.level);
-    else bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, COLDT, false, true>(a, p.slot, blockIdx.x, nb, p.level);
+    const u32 bi = il ? blockIdx.x >> 1 : blockIdx.x;
+    if (!COLDT && p.dense) bfs_dense_body<1024, BFS_DENSE_HOTW>(a, p.slot, bi, nb, p.level);
+    else bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, COLDT, false, true>(a, p.slot, bi, nb, p.level);
   } else {
     const u32 first = PART == 0 ? nstream : 0u;
-    bfs_wave_body<1024, BFS_WAVE_HOTW, COLDT, false>(a, p.slot, blockIdx.x - first, gridDim.x - first, p.level);
+    const u32 bi = il ? blockIdx.x >> 1 : blockIdx.x - first;
+    bfs_wave_body<1024, BFS_WAVE_HOTW, COLDT, false>(a, p.slot, bi, gridDim.x - first, p.level);
   }
 }
 
@@ -153,6 +159,9 @@ struct bfs_run_opts_t {
   int dense = -1;          // MGX_BFS_DENSE: 0 never, N > 0 dense_div = N (default 16)
   long long chain = -1;    // MGX_BFS_CHAIN_MAX_EDGES: 0 never (default BFS_CHAIN_CAP)
   long long defer = -1;    // MGX_BFS_DEFER: 0 never defer hot marks, N: flush a bitmap above N deferred marks per workgroup
+  int interleave = 0;      // MGX_BFS_INTERLEAVE=1: long-row and short-row workgroups of the merged push launch alternate instead of
+                           // forming two halves -- measured 0.52 vs 0.41 ms per RMAT-22 traversal: the two bodies side by side
+                           // on a CU (both lean on LDS) are slower than one after the other; kept as a switch only
   int spin = -1;           // MGX_BFS_SPIN: 0 read the control block back with a copy + hipStreamSynchronize, 1 publish kernel + spin
   int biglds = 0;          // MGX_BFS_BIGLDS (experiment, timed mode)
   int build_list = 0;      // MGX_BFS_BUILD_LIST=1: the list-based queue build (k_bfs_build) instead of k_bfs_build2
@@ -170,6 +179,7 @@ struct bfs_run_opts_t {
     if (const char* e = getenv("MGX_BFS_BUILD_LIST")) o.build_list = atoi(e);
     if (const char* e = getenv("MGX_BFS_BIGLDS")) o.biglds = atoi(e);
     if (const char* e = getenv("MGX_BFS_SPIN")) o.spin = atoi(e);
+    if (const char* e = getenv("MGX_BFS_INTERLEAVE")) o.interleave = atoi(e);
     if (const char* e = getenv("MGX_BFS_DEFER")) o.defer = atoll(e);
     return o;
   }
@@ -244,6 +254,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.dense_div = !units ? 0u : (opt.dense >= 0 ? (u32)opt.dense : st.dense_div);
   a.dense_diag = opt.dense_diag;
   a.build_diag = opt.build_diag;
+  a.interleave = opt.interleave;
   // deferred hot marks (bfs_hot_epilogue): the flush buffers are allocated at the first traversal that may use them
   const long long defer = opt.defer >= 0 ? opt.defer : (long long)st.defer_min_marks;
   if (defer > 0 && !a.flags && !st.flush_buf.size()) st.flush_buf = mem_t<u32>((size_t)BFS_FLUSH_MAX * BFS_FLUSH_WORDS, ctx);
