@@ -151,6 +151,7 @@ struct bfs_run_stats_t {
   int small_levels = 0;              // levels run inside a push launch's block 0 (chains of small levels)
   int slots = 0;                     // launch slots the run used
   int dense_slots = 0;               // slots whose long rows were read from the unit blocks
+  int vshort_slots = 0;              // slots whose short rows were walked vertex by vertex
   long long claims_level[64] = {0};
 };
 
@@ -183,6 +184,8 @@ struct bfs_fused_enactor_t {
         layout.ub_units_pad = g.ub_units_pad;
         layout.ub_min_degree = g.ub_min_degree;
       }
+      for (int i = 0; i < 4; ++i) layout.vs_v[i] = g.vs_v[i];
+      layout.vs_edges = g.vs_edges; layout.vs_dummy = g.vs_dummy; layout.vs_long_min = g.vs_long_min;
     }
     // the hub-first layout carries no separate CSC: bottom-up levels can use it only on graphs whose
     // CSC slots alias the CSR (symmetric input, what the reference always has)
@@ -207,6 +210,7 @@ struct bfs_fused_enactor_t {
     last.small_levels = hc->small_levels;
     last.slots = fused->slots_used;
     last.dense_slots = hc->dense_slots;
+    last.vshort_slots = hc->vshort_slots;
     for (int i = 0; i < last.push_levels && i < (int)last.trace.size(); ++i) last.push_edges += last.trace[i].second;
     // the long-row queue only exists on push levels; the short-row queue gets the rest of the push edges
     last.stream.launches = fused->stream_kernel_launches;

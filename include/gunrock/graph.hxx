@@ -76,6 +76,11 @@ struct graph_device_t {
   mem_t<int> d_ub_owner;
   long long ub_units = 0, ub_units_pad = 0;
   int ub_min_degree = 0;
+  // Degree classes of the layout's short rows (mgx/bfs_fused_vshort.hpp): only for a layout the library built itself
+  // (sorted by degree, eight ints of -1 behind its neighbour array).
+  unsigned vs_v[4] = {0, 0, 0, 0};
+  unsigned vs_edges = 0, vs_dummy = 0;
+  int vs_long_min = 0;
 
   graph_device_t() : num_nodes(0), num_edges(0) {}
 

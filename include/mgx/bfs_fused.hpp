@@ -90,6 +90,7 @@ struct bfs_ctrl_t {
   u32 sssp_far_cnt[2];
   u32 sssp_far_min[2];
   int dense_slots;   // slots whose long rows were read from the unit blocks (bfs_fused_dense.hpp)
+  int vshort_slots;  // slots whose short rows were walked vertex by vertex (bfs_fused_vshort.hpp)
   int pad_[2];
   u64 stamp[64];     // s_memrealtime (100 MHz) when each level was opened: per-level times without host syncs
   u64 trace[BFS_MAX_TRACE];   // (vertices << 38 | edges) of each level, both queues (kept LAST: read back up to `levels`)
@@ -124,8 +125,14 @@ struct bfs_fused_args_t {
   u32 ub_units;            // real units
   u32 ub_units_pad;        // multiple of 16
   u32 dense_div;           // a slot reads its long rows from the unit blocks when frontier units * dense_div >= ub_units (0: never)
+  // short rows vertex by vertex (bfs_fused_vshort.hpp; needs a degree-sorted CSR with 8 readable ints behind col_indices)
+  u32 vs_v[4];             // class boundaries: [0]..[1] degrees 17..long_min-1, [1]..[2] 5..16, [2]..[3] 1..4
+  u32 vs_edges;            // edges of the rows in [vs_v[0], vs_v[3])
+  u32 vs_div;              // a slot takes its short rows this way when its short-row queue holds >= vs_edges / vs_div edges (0: never)
+  u32 vs_dummy;            // index (into col_indices) of four entries of -1
   u32* flush_buf;          // BFS_FLUSH_MAX buffers of BFS_FLUSH_WORDS words (NULL: hot marks are never deferred)
   u32 defer_min_marks;     // a workgroup with more deferred discoveries than this flushes them as a bitmap (else: byte marks)
+  int combine;             // merged push launch: a slot that takes both dense paths runs them in the same workgroups
   int interleave;          // merged push launch: even workgroups take the long rows, odd ones the short rows (instead of first half / second half)
   int build_diag;          // measurements only (MGX_BFS_BUILD_DIAG; results wrong): 1 no label stores, 2 no extent gathers, 4 no cursor atomics
   int dense_diag;          // measurements only (MGX_BFS_DENSE_DIAG): 1 the unit-block body stores no marks, 2 tests nothing
@@ -147,6 +154,7 @@ __device__ __forceinline__ void bfs_ctrl_reset(bfs_ctrl_t* c) {
   c->flush_count[0] = c->flush_count[1] = 0;
   c->fb_slot = 0;                                  // k_bfs_fused_init seeds frontier_bits with the source
   c->dense_slots = 0;
+  c->vshort_slots = 0;
   c->sssp_thr = 0x7f7fffffu;
   c->sssp_far_cnt[0] = c->sssp_far_cnt[1] = 0;
   c->sssp_far_min[0] = c->sssp_far_min[1] = 0x7f7fffffu;
@@ -751,6 +759,8 @@ struct bfs_fused_state_t {
   bool time_batches = false;         // HIP events around every batch of launches (-> level_kernel_ms; ~6 us each)
   unsigned chain_max_edges = 6144;   // levels up to this size (and BFS_CHAIN_CAP) run inside block 0 of the push launch,
                                      // chained with the small levels behind them (bfs_fused_chain.hpp; 0: never)
+  unsigned vshort_div = 8;           // short rows are walked vertex by vertex when the level holds at least 1 / vshort_div of
+                                     // all short-row edges (bfs_fused_vshort.hpp; 0: never)
   unsigned dense_div = 2;            // long rows are read from the unit blocks when the frontier holds at least
                                      // 1 / dense_div of the units (bfs_fused_dense.hpp; 0: never)
   int long_min = 64;                 // rows at least this long go to the long-row queue (0: no such queue)

@@ -43,34 +43,33 @@ __device__ __forceinline__ bool bfs_long_is_dense(const bfs_fused_args_t& a, con
   return units * (u64)a.dense_div >= (u64)a.ub_units;
 }
 
-// GPS: groups per step (1: four 16-byte loads in flight per lane while the previous four are tested; 2: eight -- for
-// launches with half the waves per CU)
-template <int NT, int HOTW, int GPS = 1>
-__device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int slot, u32 block, u32 nblocks, int stat_level) {
-  constexpr int NW = NT / WAVE;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // [0..3] word of ones at hot[-1] (index 3), hot[0..HOTW), hot[HOTW] = 0
+// The LDS prefix of the visited bitmap as the unit-block and vertex-by-vertex bodies use it: a word of ones in front
+// (hot[-1]: the -1 entries of inactive lanes read as visited), a word of zeros behind (hot[HOTW]: vertices outside the
+// prefix read as unvisited), so that one clamp replaces the range checks of the probe.  Returns hot; all threads.
+template <int NT, int HOTW>
+__device__ __forceinline__ u32* bfs_hot_setup(const bfs_fused_args_t& a, char* smem, int** s_int) {
   u32* const hot = (u32*)smem + 4;
-  int* const s_int = (int*)(hot + HOTW + 4);
+  *s_int = (int*)(hot + HOTW + 4);
+  const uint4* src = (const uint4*)a.visited;
+  uint4* dstp = (uint4*)hot;
+  for (int i = threadIdx.x; i < HOTW / 4; i += NT) dstp[i] = src[i];
+  if (threadIdx.x == 0) { hot[-1] = 0xFFFFFFFFu; hot[HOTW] = 0u; (*s_int)[0] = 0; }
+  __syncthreads();
+  return hot;
+}
+
+// the unit-block pass of one workgroup (block `block` of `nblocks`) over an LDS prefix that is already set up
+template <int NT, int HOTW, int GPS>
+__device__ __forceinline__ void bfs_dense_work(const bfs_fused_args_t& a, u32* const hot, u32 hot_n, u32 defer_n, u32 block,
+                                               u32 nblocks, int& marks) {
+  constexpr int NW = NT / WAVE;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
   const int lane = lane_id();
-  bfs_ctrl_t* const c = a.ctrl;
-
-  const u32* __restrict__ vis = a.visited;
   unsigned char* __restrict__ mark = a.mark;
   const int* __restrict__ ucol = a.ub_col;
   const int* __restrict__ owner = a.ub_owner;
   const u32* __restrict__ fbits = a.frontier_bits;
-
-  const u32 hot_n = ((u32)a.n < (u32)(HOTW * 32)) ? (u32)a.n : (u32)(HOTW * 32);
-  {
-    const uint4* src = (const uint4*)vis;
-    uint4* dstp = (uint4*)hot;
-    for (int i = threadIdx.x; i < HOTW / 4; i += NT) dstp[i] = src[i];
-    if (threadIdx.x == 0) { hot[-1] = 0xFFFFFFFFu; hot[HOTW] = 0u; s_int[0] = 0; }
-  }
-  __syncthreads();
-
+  const int diag = a.dense_diag;     // MGX_BFS_DENSE_DIAG (measurements; results are wrong by design): 1 no mark stores, 2 no test
   const u32 G = a.ub_units_pad / BFS_DENSE_GROUP;              // groups of 16 units
   const u32 W = nblocks * NW;                                  // waves of the grid
   const u32 w = block * NW + (u32)wave;
@@ -78,10 +77,6 @@ __device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int sl
   const u32 lane_unit = (u32)lane & 15u;                       // my unit inside its group, for the owner load ...
   const u32 lane_grp = (u32)lane >> 4;                         // ... and which of the batch's 4 groups
   const u32 lane_q = (u32)lane >> 4;                           // col loads: lane l reads entries 4l..4l+3 of a 256-entry chunk = unit l >> 4 of the chunk
-  int marks = 0;
-  // marks of the vertices in [0, defer_n) wait for the end of the workgroup (bfs_hot_epilogue)
-  const u32 defer_n = bfs_defer_limit(a, hot_n);
-  const int diag = a.dense_diag;     // MGX_BFS_DENSE_DIAG (measurements; results are wrong by design): 1 no mark stores, 2 no test
 
   // batch b of this wave: groups w + (4 b + k) W, k = 0..3
   const u32 nbatch = (w < G) ? ((G - w + W - 1) / W + 3) / 4 : 0u;
@@ -181,6 +176,21 @@ __device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int sl
       test();
     }
   }
+}
+
+// GPS: groups per step (1: four 16-byte loads in flight per lane while the previous four are tested; 2: eight -- for
+// launches with half the waves per CU)
+template <int NT, int HOTW, int GPS = 1>
+__device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int slot, u32 block, u32 nblocks, int stat_level) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* s_int;
+  u32* const hot = bfs_hot_setup<NT, HOTW>(a, smem, &s_int);
+  const int lane = lane_id();
+  bfs_ctrl_t* const c = a.ctrl;
+  const u32 hot_n = ((u32)a.n < (u32)(HOTW * 32)) ? (u32)a.n : (u32)(HOTW * 32);
+  const u32 defer_n = bfs_defer_limit(a, hot_n);      // marks of the vertices in [0, defer_n) wait for the end of the workgroup
+  int marks = 0;
+  bfs_dense_work<NT, HOTW, GPS>(a, hot, hot_n, defer_n, block, nblocks, marks);
   (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, slot, s_int + 4);
   if (a.count_marks) {
     marks = wave_sum(marks);

@@ -12,6 +12,7 @@
 #include "bfs_fused_dense.hpp"
 #include "bfs_fused_pull.hpp"
 #include "bfs_fused_stream.hpp"
+#include "bfs_fused_vshort.hpp"
 #include "bfs_fused_wave.hpp"
 
 namespace mgx {
@@ -27,6 +28,11 @@ struct bfs_layout_t {
   const int* ub_owner = nullptr;
   long long ub_units = 0, ub_units_pad = 0;
   int ub_min_degree = 0;            // the rows the unit blocks hold: degree >= this (must equal the long-row threshold)
+  // short rows vertex by vertex (bfs_fused_vshort.hpp): class boundaries of the degree-sorted CSR, edges of the range,
+  // the long-row threshold they were computed for, index of four -1 behind col_indices (0: not available)
+  unsigned vs_v[4] = {0, 0, 0, 0};
+  unsigned vs_edges = 0, vs_dummy = 0;
+  int vs_long_min = 0;
 };
 
 constexpr int BFS_STREAM_HOTW2 = 20400;   // two workgroups per CU: 80 KB of bitmap each
@@ -38,13 +44,14 @@ constexpr size_t bfs_push_lds_bytes() {
   if (bfs_wave_lds_bytes(1024, BFS_WAVE_HOTW) > m) m = bfs_wave_lds_bytes(1024, BFS_WAVE_HOTW);
   if (bfs_dense_lds_bytes(BFS_DENSE_HOTW) > m) m = bfs_dense_lds_bytes(BFS_DENSE_HOTW);
   if (bfs_chain_lds_bytes() > m) m = bfs_chain_lds_bytes();
+  if (bfs_vshort_lds_bytes(BFS_DENSE_HOTW) > m) m = bfs_vshort_lds_bytes(BFS_DENSE_HOTW);
   return m;
 }
 
 // what a slot's push launch does, derived by every workgroup from the same stable inputs
 struct bfs_slot_plan_t {
   int slot, level;
-  bool empty, chained, dense;
+  bool empty, chained, dense, vshort;
 };
 __device__ __forceinline__ bfs_slot_plan_t bfs_slot_plan(const bfs_fused_args_t& a, int arg) {
   const bfs_ctrl_t* const c = a.ctrl;
@@ -53,7 +60,9 @@ __device__ __forceinline__ bfs_slot_plan_t bfs_slot_plan(const bfs_fused_args_t&
   const u64 cur = c->cursor[p.slot % 3], lcur = c->lcursor[p.slot % 3], ledges = c->ledges[p.slot % 3];
   p.empty = ((cur | lcur) >> BFS_VSHIFT) == 0 || c->done;
   p.chained = !p.empty && bfs_level_is_chained(a, cur, lcur, ledges);
-  p.dense = !p.empty && !p.chained && bfs_long_is_dense(a, c, p.slot, lcur) && !bfs_level_pulls(a, c, p.slot);
+  const bool pulls = bfs_level_pulls(a, c, p.slot);
+  p.dense = !p.empty && !p.chained && !pulls && bfs_long_is_dense(a, c, p.slot, lcur);
+  p.vshort = !p.empty && !p.chained && !pulls && bfs_short_is_dense(a, c, p.slot, cur);
   return p;
 }
 
@@ -69,6 +78,7 @@ __device__ __forceinline__ void bfs_slot_open(const bfs_fused_args_t& a, const b
   c->slot_level[(p.slot + 1) & 3] = p.level + 1;
   c->skip_build[p.slot & 3] = 0;
   if (p.dense) c->dense_slots += 1;
+  if (p.vshort) c->vshort_slots += 1;
 }
 
 // Push of one slot, ONE launch: block 0 opens the level (or runs the chain of small levels and everybody else
@@ -89,6 +99,11 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
   if (p.empty || PART == 1) return;
   // Which part this workgroup takes: the first nstream workgroups the long rows, the others the short rows.
   // (interleave: even / odd instead, so that the two parts share every CU -- an experiment that lost, see bfs_run_opts_t)
+  if (PART == 0 && !COLDT && p.dense && p.vshort && a.combine) {
+    // both dense paths: the first nstream workgroups take their share of the long AND of the short rows
+    if (blockIdx.x < nstream) bfs_dense_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, blockIdx.x, nstream, p.level);
+    return;
+  }
   const bool il = PART == 0 && a.interleave && gridDim.x == 2u * nstream;
   const bool long_part = PART == 2 || (PART == 0 && (il ? !(blockIdx.x & 1u) : blockIdx.x < nstream));
   if (long_part) {
@@ -99,7 +114,8 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
   } else {
     const u32 first = PART == 0 ? nstream : 0u;
     const u32 bi = il ? blockIdx.x >> 1 : blockIdx.x - first;
-    bfs_wave_body<1024, BFS_WAVE_HOTW, COLDT, false>(a, p.slot, bi, gridDim.x - first, p.level);
+    if (!COLDT && p.vshort) bfs_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, bi, gridDim.x - first, p.level);
+    else bfs_wave_body<1024, BFS_WAVE_HOTW, COLDT, false>(a, p.slot, bi, gridDim.x - first, p.level);
   }
 }
 
@@ -156,9 +172,13 @@ struct bfs_run_opts_t {
   int cold_test = -1;      // MGX_BFS_COLD_TEST
   int merged = 1;          // MGX_BFS_MERGED_PUSH
   int flags = 0;           // MGX_BFS_FLAGS (instrumented stream kernel)
-  int dense = -1;          // MGX_BFS_DENSE: 0 never, N > 0 dense_div = N (default 16)
+  int dense = -1;          // MGX_BFS_DENSE: 0 never, N > 0 dense_div = N
+  int vshort = -1;         // MGX_BFS_VSHORT: 0 never, N > 0 vshort_div = N
   long long chain = -1;    // MGX_BFS_CHAIN_MAX_EDGES: 0 never (default BFS_CHAIN_CAP)
   long long defer = -1;    // MGX_BFS_DEFER: 0 never defer hot marks, N: flush a bitmap above N deferred marks per workgroup
+  int combine = 0;         // MGX_BFS_COMBINE=1: a level that takes both dense paths runs them in the SAME workgroups (one copy of the
+                           // bitmap prefix and one epilogue per workgroup instead of two) -- measured 0.4055 vs 0.4012 ms per RMAT-22
+                           // traversal: no gain, the two halves of the grid overlap their tails better; kept as a switch
   int interleave = 0;      // MGX_BFS_INTERLEAVE=1: long-row and short-row workgroups of the merged push launch alternate instead of
                            // forming two halves -- measured 0.52 vs 0.41 ms per RMAT-22 traversal: the two bodies side by side
                            // on a CU (both lean on LDS) are slower than one after the other; kept as a switch only
@@ -173,6 +193,7 @@ struct bfs_run_opts_t {
     if (const char* e = getenv("MGX_BFS_MERGED_PUSH")) o.merged = atoi(e);
     if (const char* e = getenv("MGX_BFS_FLAGS")) o.flags = atoi(e);
     if (const char* e = getenv("MGX_BFS_DENSE")) o.dense = atoi(e);
+    if (const char* e = getenv("MGX_BFS_VSHORT")) o.vshort = atoi(e);
     if (const char* e = getenv("MGX_BFS_CHAIN_MAX_EDGES")) o.chain = atoll(e);
     if (const char* e = getenv("MGX_BFS_DENSE_DIAG")) o.dense_diag = atoi(e);
     if (const char* e = getenv("MGX_BFS_BUILD_DIAG")) o.build_diag = atoi(e);
@@ -180,6 +201,7 @@ struct bfs_run_opts_t {
     if (const char* e = getenv("MGX_BFS_BIGLDS")) o.biglds = atoi(e);
     if (const char* e = getenv("MGX_BFS_SPIN")) o.spin = atoi(e);
     if (const char* e = getenv("MGX_BFS_INTERLEAVE")) o.interleave = atoi(e);
+    if (const char* e = getenv("MGX_BFS_COMBINE")) o.combine = atoi(e);
     if (const char* e = getenv("MGX_BFS_DEFER")) o.defer = atoll(e);
     return o;
   }
@@ -252,9 +274,17 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.ub_units = units ? (u32)layout->ub_units : 0u;
   a.ub_units_pad = units ? (u32)layout->ub_units_pad : 0u;
   a.dense_div = !units ? 0u : (opt.dense >= 0 ? (u32)opt.dense : st.dense_div);
+  // short rows vertex by vertex: the layout's own degree-sorted CSR with its padding, the threshold it was cut for
+  const bool vs = relabelled && layout->vs_dummy != 0 && layout->vs_long_min == st.long_min && st.long_min > 0 && !coldt && !opt.flags &&
+                  layout->vs_edges > 0;
+  for (int i = 0; i < 4; ++i) a.vs_v[i] = vs ? layout->vs_v[i] : 0u;
+  a.vs_edges = vs ? layout->vs_edges : 0u;
+  a.vs_dummy = vs ? layout->vs_dummy : 0u;
+  a.vs_div = !vs ? 0u : (opt.vshort >= 0 ? (u32)opt.vshort : st.vshort_div);
   a.dense_diag = opt.dense_diag;
   a.build_diag = opt.build_diag;
   a.interleave = opt.interleave;
+  a.combine = opt.combine;
   // deferred hot marks (bfs_hot_epilogue): the flush buffers are allocated at the first traversal that may use them
   const long long defer = opt.defer >= 0 ? opt.defer : (long long)st.defer_min_marks;
   if (defer > 0 && !a.flags && !st.flush_buf.size()) st.flush_buf = mem_t<u32>((size_t)BFS_FLUSH_MAX * BFS_FLUSH_WORDS, ctx);

@@ -314,6 +314,7 @@ int mgx_graph_attach_layout(mgx_graph_t g, const int* d_row_offsets, const int* 
   G.d_new_of_old = mem_t<int>::borrow((int*)d_new_of_old, (size_t)G.num_nodes);
   G.d_old_of_new = mem_t<int>::borrow((int*)d_old_of_new, (size_t)G.num_nodes);
   G.has_layout = true;
+  G.vs_edges = 0; G.vs_dummy = 0; G.vs_long_min = 0;      // (borrowed arrays: no padding behind them, sortedness not checked)
   use_device(g->c);
   g->c->ctx->synchronize();
   build_unit_blocks(g);
@@ -362,7 +363,8 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
   const size_t n = (size_t)G.num_nodes, m = (size_t)G.num_edges;
   MGX_REQUIRE(!with_weights || G.d_col_values.size() >= m, "mgx_graph_build_layout: the graph has no weights");
   ctx.synchronize();
-  mem_t<int> lro(n + 1, ctx), lci(m, ctx), n2o(n, ctx), o2n(n, ctx);
+  mem_t<int> lro(n + 1, ctx), lci(m + 8, ctx), n2o(n, ctx), o2n(n, ctx);     // (+8: slack and four -1 for bfs_fused_vshort.hpp)
+  MGX_HIP(hipMemsetAsync(lci.data() + m, 0xFF, 8 * sizeof(int), ctx.stream()));
   mem_t<float> lw;
   if (with_weights) lw = mem_t<float>(m, ctx);
   const int rc = mgx_layout_build_device(G.d_row_offsets.data(), G.d_col_indices.data(),
@@ -377,6 +379,27 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
   G.has_layout = true;
   if (with_weights) { G.d_layout_col_values = std::move(lw); G.has_layout_weights = true; }
   build_unit_blocks(g);
+  // degree classes of the short rows (the layout is sorted by degree): boundaries by binary search on a host copy
+  G.vs_edges = 0; G.vs_dummy = 0; G.vs_long_min = 0;
+  {
+    int long_min = 64;
+    if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
+    if (long_min > 0 && long_min <= 64 && n > 0 && m > 0) {
+      std::vector<int> h(n + 1);
+      MGX_HIP(mgx::dtoh(h.data(), G.d_layout_row_offsets.data(), n + 1));
+      auto first_below = [&](int d) {            // first vertex with degree < d (degrees are non-increasing)
+        size_t lo = 0, hi = n;
+        while (lo < hi) { const size_t mid = (lo + hi) / 2; if (h[mid + 1] - h[mid] >= d) lo = mid + 1; else hi = mid; }
+        return (unsigned)lo;
+      };
+      const unsigned b0 = first_below(long_min), b1 = std::max(b0, first_below(17)), b2 = std::max(b1, first_below(5)),
+                     b3 = std::max(b2, first_below(1));
+      G.vs_v[0] = b0; G.vs_v[1] = b1; G.vs_v[2] = b2; G.vs_v[3] = b3;
+      G.vs_edges = (unsigned)(h[b3] - h[b0]);
+      G.vs_dummy = (unsigned)m + 4u;
+      G.vs_long_min = long_min;
+    }
+  }
   MGX_CATCH
 }
 extern "C" int mgx_csc_build_device(const int* ro, const int* ci, const float* w, int n, long long m, int* co, int* ri, float* rv,
@@ -871,6 +894,7 @@ int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats) {
   p->last_stats[15] = L.small_levels;
   p->last_stats[16] = L.slots;
   p->last_stats[17] = L.dense_slots;
+  p->last_stats[18] = L.vshort_slots;
   if (stats) memcpy(stats, p->last_stats, sizeof(p->last_stats));
   MGX_CATCH
 }

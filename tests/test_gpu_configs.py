@@ -163,6 +163,7 @@ def test_config2_rmat22_bfs_full_size_vs_oracle(gpu_ctx, oracle, torch_mod):
     deg = np.diff(ro)
     assert st["reached"] == int((want >= 0).sum()) and st["m_t"] == int(deg[want >= 0].sum())
     assert st["dense_slots"] >= 1          # the big level read its long rows from the unit blocks
+    assert st["vshort_slots"] >= 1         # ... and walked its short rows vertex by vertex
     st = bfs.run(src, mode=mini_amd.MGX_BFS_DIRECTION_OPT, alpha=4.0)
     assert np.array_equal(bfs.labels(), want)
 
