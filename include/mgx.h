@@ -193,18 +193,20 @@ MGX_API int mgx_bfs_enact_pushpull(mgx_bfs_t p, float threshold, int64_t* stats)
 /* Whole traversal on the fused device-resident path (no per-level host round trip):
  * labels identical to enact_pushpull's.  mode: MGX_BFS_PUSH (config 2) or
  * MGX_BFS_DIRECTION_OPT (config 4; needs a genuine CSC for directed graphs).
- * The call is asynchronous on the context's stream except for one 8-byte read-back per
- * `MGX_BFS_LEVELS_PER_SYNC` levels.  stats (may be NULL):
+ * A traversal is enqueued as batches of launch slots (mgx/bfs_fused_run.hpp); the host waits once per batch
+ * (first batch: as many slots as the previous traversal of the graph needed, then MGX_BFS_LEVELS_PER_SYNC).
+ * stats (may be NULL):
  *   [0] levels run  [1] vertices reached (incl. source)  [2] m_t = sum of out-degrees of
  *   reached vertices (the TEPS numerator)  [3] edges inspected by push levels
  *   [4] edges inspected by pull levels [5] push levels [6] level-kernel launches (incl. the
  *   empty ones behind the last level) [7] device time of those launches in ns (HIP events on
  *   the context's stream) [8] frontier vertices expanded (sum of per-level frontier sizes)
  *   [9] visited-bit claims (atomicOr) issued.
- *   Dominant push kernel = the one of the two (mgx_bfs_kernel_times) with more device time in this run:
+ *   Timed push kernel (only with mgx_bfs_set_kernel_timing; mode 2: the merged k_bfs_push launch, mode 1: the part
+ *   with more device time in this run):
  *   [10] its launches (incl. the ones that find nothing to do) [11] their device time in ns (HIP events
  *   around every launch) [12] edges and [13] frontier vertices it processed
- *   [14] which one (1 = k_bfs_push_level_stream, 0 = k_bfs_push_level_wave)
+ *   [14] which one (1 = long-row part or the merged launch, 0 = short-row part)
  *   [15] levels run inside a push launch's block 0 (chains of small levels, bfs_fused_chain.hpp)
  *   [16] launch slots used [17] slots whose long rows were read from the unit blocks (bfs_fused_dense.hpp)
  *   [18] slots whose short rows were walked vertex by vertex (bfs_fused_vshort.hpp).
