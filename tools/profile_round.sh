@@ -10,16 +10,22 @@ echo "pytest rc=$?"; tail -4 $O/pytest_gpu.log
 timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1
 echo "smoke rc=$?"; tail -1 $O/smoke.log
 timeout 300 ./tools/microbench > $O/microbench.jsonl 2>&1
+# the PMC passes FIRST: the traffic figure they give (tied to the hash of the sources) is what the bench line of this
+# very run reports as roofline.traffic
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-check > $O/pmc_$c.log 2>&1
+  echo "pmc $c rc=$?"
+done
+cd $R
+python3 tools/summarize_profiles.py $O > /dev/null 2>&1
+[ -s $O/pmc_traffic.json ] && cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json
 timeout 900 python bench.py --steps 16 --warmup 2 > $O/bench.log 2>&1
 echo "bench rc=$?"; tail -1 $O/bench.log
 timeout 600 python tools/bfs_levels.py --scale 22 --runs 2 > $O/levels.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 16 --warmup 2 --no-cpu-baseline --no-check > $O/trace_bench.log 2>&1
 echo "trace rc=$?"
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-check > $O/pmc_$c.log 2>&1
-  echo "pmc $c rc=$?"
-done
 timeout 900 rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $O/pmc_TCC -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-check > $O/pmc_TCC.log 2>&1
 cd $R
 # auxiliary logs: operator path (reference loop, idempotent mode), SSSP (operator / fused / near-far), direction-optimising sweep
