@@ -152,6 +152,7 @@ struct bfs_run_stats_t {
   int slots = 0;                     // launch slots the run used
   int dense_slots = 0;               // slots whose long rows were read from the unit blocks
   int vshort_slots = 0;              // slots whose short rows were walked vertex by vertex
+  int lazy_slots = 0;                // slots that ran without queues (bfs_build_is_lazy)
   long long claims_level[64] = {0};
 };
 
@@ -211,6 +212,7 @@ struct bfs_fused_enactor_t {
     last.slots = fused->slots_used;
     last.dense_slots = hc->dense_slots;
     last.vshort_slots = hc->vshort_slots;
+    last.lazy_slots = hc->lazy_slots;
     for (int i = 0; i < last.push_levels && i < (int)last.trace.size(); ++i) last.push_edges += last.trace[i].second;
     // the long-row queue only exists on push levels; the short-row queue gets the rest of the push edges
     last.stream.launches = fused->stream_kernel_launches;

@@ -91,7 +91,8 @@ struct bfs_ctrl_t {
   u32 sssp_far_min[2];
   int dense_slots;   // slots whose long rows were read from the unit blocks (bfs_fused_dense.hpp)
   int vshort_slots;  // slots whose short rows were walked vertex by vertex (bfs_fused_vshort.hpp)
-  int pad_[2];
+  int lazy_slot;     // the slot whose queues were NOT written (bfs_build_is_lazy): it must take both queue-less bodies; -1: none
+  int lazy_slots;    // how many there were
   u64 stamp[64];     // s_memrealtime (100 MHz) when each level was opened: per-level times without host syncs
   u64 trace[BFS_MAX_TRACE];   // (vertices << 38 | edges) of each level, both queues (kept LAST: read back up to `levels`)
 };
@@ -137,7 +138,32 @@ struct bfs_fused_args_t {
   int build_diag;          // measurements only (MGX_BFS_BUILD_DIAG; results wrong): 1 no label stores, 2 no extent gathers, 4 no cursor atomics
   int dense_diag;          // measurements only (MGX_BFS_DENSE_DIAG): 1 the unit-block body stores no marks, 2 tests nothing
   u32 chain_max_edges;     // a level of at most this many edges (and BFS_CHAIN_CQ rows) runs inside block 0 of the push launch (0: never)
+  u32 lazy_div;            // the build behind a level with >= n / lazy_div mark stores writes no queues (bfs_build_is_lazy; 0: never)
+  u32* slot_marks;         // [2][BFS_MARK_CTRS] counters, 128 bytes apart: marks stored by the push workgroups of slot s in set s & 1 (NULL: not counted)
 };
+
+constexpr int BFS_MARK_CTRS = 8;               // the workgroups of a push launch spread their adds over this many lines
+constexpr int BFS_MARK_STRIDE = 32;            // u32 words between two counters
+
+// End of a push body (all threads of the workgroup): its mark count goes to the slot's counters -- what the queue build
+// bases its lazy decision on -- and, for the tools, to the statistics.  s_int[0] must be 0 on entry.
+__device__ __forceinline__ void bfs_body_finish(const bfs_fused_args_t& a, int marks, int slot, int stat_level, int* s_int) {
+  if (!a.slot_marks && !a.count_marks) return;
+  marks = wave_sum(marks);
+  if ((threadIdx.x & (WAVE - 1)) == 0 && marks) atomicAdd(&s_int[0], marks);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_int[0]) {
+    if (a.slot_marks) atomicAdd(&a.slot_marks[((slot & 1) * BFS_MARK_CTRS + (int)(blockIdx.x % BFS_MARK_CTRS)) * BFS_MARK_STRIDE], (u32)s_int[0]);
+    if (a.count_marks) {           // statistics for the tools: two device-scope atomics per workgroup on one line
+      atomicAdd(&a.ctrl->claims, (u64)s_int[0]);
+      if (stat_level < 64) atomicAdd(&a.ctrl->claims_level[stat_level], (u64)s_int[0]);
+    }
+  }
+}
+__device__ __forceinline__ void bfs_slot_marks_clear(const bfs_fused_args_t& a, int slot) {       // one thread
+  if (a.slot_marks)
+    for (int i = 0; i < BFS_MARK_CTRS; ++i) a.slot_marks[((slot & 1) * BFS_MARK_CTRS + i) * BFS_MARK_STRIDE] = 0u;
+}
 
 __device__ __forceinline__ void bfs_ctrl_reset(bfs_ctrl_t* c) {
   for (int i = 0; i < 3; ++i) { c->cursor[i] = 0; c->lcursor[i] = 0; c->ledges[i] = 0; }
@@ -155,6 +181,8 @@ __device__ __forceinline__ void bfs_ctrl_reset(bfs_ctrl_t* c) {
   c->fb_slot = 0;                                  // k_bfs_fused_init seeds frontier_bits with the source
   c->dense_slots = 0;
   c->vshort_slots = 0;
+  c->lazy_slot = -1;
+  c->lazy_slots = 0;
   c->sssp_thr = 0x7f7fffffu;
   c->sssp_far_cnt[0] = c->sssp_far_cnt[1] = 0;
   c->sssp_far_min[0] = c->sssp_far_min[1] = 0x7f7fffffu;
@@ -213,6 +241,8 @@ __global__ __launch_bounds__(BLOCK) void k_bfs_fused_init(bfs_fused_args_t a, in
   }
   if (tid == 0) {
     bfs_ctrl_reset(a.ctrl);
+    bfs_slot_marks_clear(a, 0);
+    bfs_slot_marks_clear(a, 1);
     bfs_seed_queue(a, (u32)src);
   }
 }
@@ -568,6 +598,27 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 4) void k_bfs_build(bfs_fused_a
 // gives the positions; a thread writes its own discoveries (consecutive queue slots per class) and labels.  No list, no
 // batches, no second distribution: three barriers' worth of scans instead of seven plus the list's.
 // (Measured, RMAT-22, the level with 2 M discoveries: 46 us for the list version, 12.5 of them the label scatter.)
+//
+// LAZY queues.  The two bodies that read the unit blocks and the degree-sorted CSR (bfs_fused_dense.hpp,
+// bfs_fused_vshort.hpp) take the frontier from frontier_bits: a slot that runs both never looks at its queues.  Which
+// body a slot takes depends on the size of its frontier, which is only known when the build is over -- but the build can
+// know how many marks the push stored (bfs_body_finish: one add per workgroup into the slot's counters): an upper bound
+// of the discoveries, a few times their number on a skewed graph.  Behind a push that stored at least n / lazy_div marks
+// (grid-uniform: the counters are complete when the build starts) the build writes NO queues: no positions, hence no
+// scans and no returning atomics on the two hot cursors (500 workgroups queue up there at 12 ns each), no queue stores
+// -- bits, labels and totals only (the cursors still receive the level's counts, with adds nobody waits for).
+// ctrl->lazy_slot tells the next slot's push launch that it MUST take the queue-less bodies, whatever its size turns out
+// to be (a sparse frontier then costs their sweeps and LDS copies: ~27 us instead of ~10 on RMAT-22, which is why the
+// rule looks at the marks and not at the level's edges: few marks guarantee a small frontier).
+// Measured, RMAT-22: the two big builds 41 -> 24 and 27 -> 20 us.
+__device__ __forceinline__ bool bfs_build_is_lazy(const bfs_fused_args_t& a, int slot) {
+  if (a.lazy_div == 0u || !a.slot_marks) return false;
+  u64 M = 0;
+#pragma unroll
+  for (int i = 0; i < BFS_MARK_CTRS; ++i) M += a.slot_marks[((slot & 1) * BFS_MARK_CTRS + i) * BFS_MARK_STRIDE];
+  return M * (u64)a.lazy_div >= (u64)(u32)a.n;
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int arg, int* __restrict__ labels, int n) {
   constexpr int NW = NT / WAVE;
@@ -581,7 +632,12 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
   int slot, level;
   bfs_resolve(c, arg, slot, level);
   if (c->done || c->skip_build[slot & 3]) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) c->fb_slot = slot + 1;     // frontier_bits: written in full below
+  const bool lazy = bfs_build_is_lazy(a, slot);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    c->fb_slot = slot + 1;                                             // frontier_bits: written in full below
+    c->lazy_slot = lazy ? slot + 1 : -1;
+    if (lazy) c->lazy_slots += 1;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // A workgroup owns NW runs of 1024 vertices, gridDim runs apart (under the hub-first layout a level's discoveries
   // sit in a prefix of the ids: every workgroup gets its share of it).  Inside the workgroup a run is spread over ALL
@@ -678,6 +734,28 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
     }
   }
 
+  if (lazy) {
+    // totals only: (count << 40 | edges) per queue, true long edges, discoveries -- wave sums, one add per wave into LDS,
+    // one add per workgroup and counter into the control block (no return value: nobody waits on the hot lines)
+    const u64 w_s = wave_sum(sum_s), w_l = wave_sum(sum_l);
+    const u32 w_t = wave_sum(long_true), w_n = wave_sum((u32)mine);
+    if (threadIdx.x < 4) s_scan[threadIdx.x] = 0;
+    __syncthreads();
+    if (lane == 0 && w_n) {
+      atomicAdd(&s_scan[0], w_s); atomicAdd(&s_scan[1], w_l); atomicAdd(&s_scan[2], (u64)w_t); atomicAdd(&s_scan[3], (u64)w_n);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_scan[3]) {
+      const u64 tot_s = s_scan[0], tot_l = s_scan[1];
+      atomicAdd(&c->reached, s_scan[3]);
+      if (tot_s >> 40) atomicAdd(&c->cursor[(slot + 1) % 3], ((tot_s >> 40) << BFS_VSHIFT) | (tot_s & DEGMASK));
+      if (tot_l >> 40) {
+        atomicAdd(&c->lcursor[(slot + 1) % 3], ((tot_l >> 40) << BFS_VSHIFT) | (tot_l & DEGMASK));
+        atomicAdd(&c->ledges[(slot + 1) % 3], s_scan[2]);
+      }
+    }
+    return;
+  }
   // ---- positions: one packed scan per queue; batches of a workgroup are appended with one atomic per queue -------------
   if (threadIdx.x == 0) s_long_edges = 0;
   u64 tot_n;
@@ -761,6 +839,8 @@ struct bfs_fused_state_t {
                                      // chained with the small levels behind them (bfs_fused_chain.hpp; 0: never)
   unsigned vshort_div = 8;           // short rows are walked vertex by vertex when the level holds at least 1 / vshort_div of
                                      // all short-row edges (bfs_fused_vshort.hpp; 0: never)
+  unsigned lazy_div = 4;             // the build behind a push with >= n / lazy_div mark stores writes no queues (bfs_build_is_lazy; 0: never)
+  mem_t<u32> slot_marks;             // the counters it looks at (bfs_fused_args_t::slot_marks)
   unsigned dense_div = 2;            // long rows are read from the unit blocks when the frontier holds at least
                                      // 1 / dense_div of the units (bfs_fused_dense.hpp; 0: never)
   int long_min = 64;                 // rows at least this long go to the long-row queue (0: no such queue)

@@ -259,6 +259,7 @@ __device__ __forceinline__ void bfs_chain_body(const bfs_fused_args_t& a, int sl
       c->slot_level[(slot + 1) & 3] = level + 1;
       c->skip_build[slot & 3] = 1;
       c->flush_count[(slot + 1) & 1] = 0;
+      bfs_slot_marks_clear(a, slot + 1);
       if (nf2 == 0 && !c->done) { c->done = 1; c->levels = level + 1; }
     }
     return;

@@ -192,15 +192,7 @@ __device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int sl
   int marks = 0;
   bfs_dense_work<NT, HOTW, GPS>(a, hot, hot_n, defer_n, block, nblocks, marks);
   (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, slot, s_int + 4);
-  if (a.count_marks) {
-    marks = wave_sum(marks);
-    if (lane == 0 && marks) atomicAdd(&s_int[0], marks);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_int[0]) {
-      atomicAdd(&c->claims, (u64)s_int[0]);
-      if (stat_level < 64) atomicAdd(&c->claims_level[stat_level], (u64)s_int[0]);
-    }
-  }
+  bfs_body_finish(a, marks, slot, stat_level, s_int);
 }
 
 }  // namespace mgx

@@ -63,6 +63,10 @@ __device__ __forceinline__ bfs_slot_plan_t bfs_slot_plan(const bfs_fused_args_t&
   const bool pulls = bfs_level_pulls(a, c, p.slot);
   p.dense = !p.empty && !p.chained && !pulls && bfs_long_is_dense(a, c, p.slot, lcur);
   p.vshort = !p.empty && !p.chained && !pulls && bfs_short_is_dense(a, c, p.slot, cur);
+  if (!p.empty && c->lazy_slot == p.slot) {       // the build before this slot wrote no queues (bfs_build_is_lazy)
+    p.chained = false;
+    p.dense = p.vshort = true;
+  }
   return p;
 }
 
@@ -75,6 +79,7 @@ __device__ __forceinline__ void bfs_slot_open(const bfs_fused_args_t& a, const b
   if (!bfs_open_level(a, p.level, p.slot)) return;  // (an empty frontier: done = 1, levels = level)
   c->slots += 1;
   c->flush_count[(p.slot + 1) & 1] = 0;
+  bfs_slot_marks_clear(a, p.slot + 1);
   c->slot_level[(p.slot + 1) & 3] = p.level + 1;
   c->skip_build[p.slot & 3] = 0;
   if (p.dense) c->dense_slots += 1;
@@ -175,6 +180,7 @@ struct bfs_run_opts_t {
   int dense = -1;          // MGX_BFS_DENSE: 0 never, N > 0 dense_div = N
   int vshort = -1;         // MGX_BFS_VSHORT: 0 never, N > 0 vshort_div = N
   long long chain = -1;    // MGX_BFS_CHAIN_MAX_EDGES: 0 never (default BFS_CHAIN_CAP)
+  int lazy = -1;           // MGX_BFS_LAZY: 0 the queue build always writes the queues, N: not behind a push that stored >= n / N marks
   long long defer = -1;    // MGX_BFS_DEFER: 0 never defer hot marks, N: flush a bitmap above N deferred marks per workgroup
   int combine = 0;         // MGX_BFS_COMBINE=1: a level that takes both dense paths runs them in the SAME workgroups (one copy of the
                            // bitmap prefix and one epilogue per workgroup instead of two) -- measured 0.4055 vs 0.4012 ms per RMAT-22
@@ -203,6 +209,7 @@ struct bfs_run_opts_t {
     if (const char* e = getenv("MGX_BFS_INTERLEAVE")) o.interleave = atoi(e);
     if (const char* e = getenv("MGX_BFS_COMBINE")) o.combine = atoi(e);
     if (const char* e = getenv("MGX_BFS_DEFER")) o.defer = atoll(e);
+    if (const char* e = getenv("MGX_BFS_LAZY")) { o.lazy = atoi(e); if (o.lazy > (1 << 20)) o.lazy = 1 << 20; }   // (edges < 2^38: no overflow)
     return o;
   }
 };
@@ -281,6 +288,8 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.vs_edges = vs ? layout->vs_edges : 0u;
   a.vs_dummy = vs ? layout->vs_dummy : 0u;
   a.vs_div = !vs ? 0u : (opt.vshort >= 0 ? (u32)opt.vshort : st.vshort_div);
+  if (!st.slot_marks.size()) st.slot_marks = mem_t<u32>((size_t)2 * BFS_MARK_CTRS * BFS_MARK_STRIDE, ctx);
+  a.slot_marks = st.slot_marks.data();
   a.dense_diag = opt.dense_diag;
   a.build_diag = opt.build_diag;
   a.interleave = opt.interleave;
@@ -302,6 +311,8 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   st.batches = 0;
   // k_bfs_build2 reads a thread's 17 row offsets and 16 layout ids with 16-byte loads: borrowed arrays must be aligned
   const bool build2_ok = ((uintptr_t)a.row_offsets % 16 == 0) && ((uintptr_t)a.old_of_new % 16 == 0);
+  // lazy queues (bfs_build_is_lazy): only k_bfs_build2 knows them, and only when both queue-less bodies are available
+  a.lazy_div = (a.dense_div && a.vs_div && mode == 0 && build2_ok && !opt.build_list) ? (opt.lazy >= 0 ? (u32)opt.lazy : st.lazy_div) : 0u;
   const bool batch_events = st.time_kernels != 0 || st.time_batches;    // (an event costs ~6 us of stream gap)
   const u32 nstream = a.long_min > 0 ? (u32)ctx.num_cus * 2 : 0u;
   const u32 nwave = (u32)ctx.num_cus * 2;

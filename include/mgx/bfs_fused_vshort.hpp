@@ -152,15 +152,7 @@ __device__ __forceinline__ void bfs_vshort_body(const bfs_fused_args_t& a, int s
   int marks = 0;
   bfs_vshort_work<NT, HOTW>(a, hot, hot_n, defer_n, block, nblocks, marks);
   (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, slot, s_int + 4);
-  if (a.count_marks) {
-    marks = wave_sum(marks);
-    if (lane == 0 && marks) atomicAdd(&s_int[0], marks);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_int[0]) {
-      atomicAdd(&c->claims, (u64)s_int[0]);
-      if (stat_level < 64) atomicAdd(&c->claims_level[stat_level], (u64)s_int[0]);
-    }
-  }
+  bfs_body_finish(a, marks, slot, stat_level, s_int);
 }
 
 // Long rows from the unit blocks AND short rows vertex by vertex in ONE workgroup, one after the other over the same LDS
@@ -180,15 +172,7 @@ __device__ __forceinline__ void bfs_dense_vshort_body(const bfs_fused_args_t& a,
   bfs_dense_work<NT, HOTW, 1>(a, hot, hot_n, defer_n, block, nblocks, marks);
   bfs_vshort_work<NT, HOTW>(a, hot, hot_n, defer_n, block, nblocks, marks);
   (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, slot, s_int + 4);
-  if (a.count_marks) {
-    marks = wave_sum(marks);
-    if (lane == 0 && marks) atomicAdd(&s_int[0], marks);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_int[0]) {
-      atomicAdd(&c->claims, (u64)s_int[0]);
-      if (stat_level < 64) atomicAdd(&c->claims_level[stat_level], (u64)s_int[0]);
-    }
-  }
+  bfs_body_finish(a, marks, slot, stat_level, s_int);
 }
 
 }  // namespace mgx

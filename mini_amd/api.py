@@ -341,7 +341,7 @@ class BfsProblem:
                 "claims": st[9], "dom_launches": st[10], "dom_ns": st[11], "dom_edges": st[12],
                 "dom_vertices": st[13],
                 "dom_kernel": "k_bfs_push_level_stream" if st[14] else "k_bfs_push_level_wave",
-                "small_levels": st[15], "slots": st[16], "dense_slots": st[17], "vshort_slots": st[18]}
+                "small_levels": st[15], "slots": st[16], "dense_slots": st[17], "vshort_slots": st[18], "lazy_slots": st[19]}
 
     def level_trace(self, cap=4096):
         nf, ne, lv = (C.c_int64 * cap)(), (C.c_int64 * cap)(), C.c_int()

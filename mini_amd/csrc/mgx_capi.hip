@@ -895,6 +895,7 @@ int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats) {
   p->last_stats[16] = L.slots;
   p->last_stats[17] = L.dense_slots;
   p->last_stats[18] = L.vshort_slots;
+  p->last_stats[19] = L.lazy_slots;
   if (stats) memcpy(stats, p->last_stats, sizeof(p->last_stats));
   MGX_CATCH
 }
