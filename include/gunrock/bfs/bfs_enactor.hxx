@@ -153,6 +153,7 @@ struct bfs_run_stats_t {
   int dense_slots = 0;               // slots whose long rows were read from the unit blocks
   int vshort_slots = 0;              // slots whose short rows were walked vertex by vertex
   int lazy_slots = 0;                // slots that ran without queues (bfs_build_is_lazy)
+  int cold_slots = 0;                // slots that ran the cold-edge pass (bfs_fused_cold.hpp)
   long long claims_level[64] = {0};
 };
 
@@ -187,6 +188,15 @@ struct bfs_fused_enactor_t {
       }
       for (int i = 0; i < 4; ++i) layout.vs_v[i] = g.vs_v[i];
       layout.vs_edges = g.vs_edges; layout.vs_dummy = g.vs_dummy; layout.vs_long_min = g.vs_long_min;
+      if (g.cold_slices > 0) {
+        layout.cold_owner = g.d_cold_owner.data();
+        layout.cold_dst = g.d_cold_dst.data();
+        layout.cold_slices = g.cold_slices;
+        for (int i = 0; i < 16; ++i) layout.cold_lo[i] = g.cold_lo[i];
+        for (int i = 0; i < 17; ++i) { layout.cold_off[i] = g.cold_off[i]; layout.cold_wgs[i] = g.cold_wgs[i]; }
+        layout.cold_hot_n = g.cold_hot_n;
+        layout.cold_long_min = g.cold_long_min;
+      }
     }
     // the hub-first layout carries no separate CSC: bottom-up levels can use it only on graphs whose
     // CSC slots alias the CSR (symmetric input, what the reference always has)
@@ -213,6 +223,7 @@ struct bfs_fused_enactor_t {
     last.dense_slots = hc->dense_slots;
     last.vshort_slots = hc->vshort_slots;
     last.lazy_slots = hc->lazy_slots;
+    last.cold_slots = hc->cold_slots;
     for (int i = 0; i < last.push_levels && i < (int)last.trace.size(); ++i) last.push_edges += last.trace[i].second;
     // the long-row queue only exists on push levels; the short-row queue gets the rest of the push edges
     last.stream.launches = fused->stream_kernel_launches;

@@ -81,6 +81,15 @@ struct graph_device_t {
   unsigned vs_v[4] = {0, 0, 0, 0};
   unsigned vs_edges = 0, vs_dummy = 0;
   int vs_long_min = 0;
+  // Cold-edge lists of the long rows (mgx/bfs_fused_cold.hpp): the unit blocks' entries behind the LDS prefix as
+  // (owner, dst) pairs grouped by slice of the id range; built with the layout when they are a small share of the entries.
+  mem_t<int> d_cold_owner;
+  mem_t<int> d_cold_dst;
+  long long cold_pairs = 0;
+  int cold_slices = 0;
+  unsigned cold_lo[16] = {0}, cold_off[17] = {0}, cold_wgs[17] = {0};
+  unsigned cold_hot_n = 0;
+  int cold_long_min = 0;
 
   graph_device_t() : num_nodes(0), num_edges(0) {}
 

@@ -210,8 +210,9 @@ MGX_API int mgx_bfs_enact_pushpull(mgx_bfs_t p, float threshold, int64_t* stats)
  *   [15] levels run inside a push launch's block 0 (chains of small levels, bfs_fused_chain.hpp)
  *   [16] launch slots used [17] slots whose long rows were read from the unit blocks (bfs_fused_dense.hpp)
  *   [18] slots whose short rows were walked vertex by vertex (bfs_fused_vshort.hpp)
- *   [19] slots that ran without queues (the build before them wrote none, bfs_build_is_lazy).
- *   stats must hold 20 entries.                                                                 */
+ *   [19] slots that ran without queues (the build before them wrote none, bfs_build_is_lazy)
+ *   [20] slots that ran the cold-edge pass (bfs_fused_cold.hpp).
+ *   stats must hold 24 entries.                                                                 */
 #define MGX_BFS_PUSH 0
 #define MGX_BFS_DIRECTION_OPT 1
 MGX_API int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats);

@@ -93,6 +93,8 @@ struct bfs_ctrl_t {
   int vshort_slots;  // slots whose short rows were walked vertex by vertex (bfs_fused_vshort.hpp)
   int lazy_slot;     // the slot whose queues were NOT written (bfs_build_is_lazy): it must take both queue-less bodies; -1: none
   int lazy_slots;    // how many there were
+  int cold_slot;     // the slot whose push ran the cold-edge pass (bfs_fused_cold.hpp): its build ORs the cold bitmaps; -1: none
+  int cold_slots;    // how many there were
   u64 stamp[64];     // s_memrealtime (100 MHz) when each level was opened: per-level times without host syncs
   u64 trace[BFS_MAX_TRACE];   // (vertices << 38 | edges) of each level, both queues (kept LAST: read back up to `levels`)
 };
@@ -140,7 +142,20 @@ struct bfs_fused_args_t {
   u32 chain_max_edges;     // a level of at most this many edges (and BFS_CHAIN_CQ rows) runs inside block 0 of the push launch (0: never)
   u32 lazy_div;            // the build behind a level with >= n / lazy_div mark stores writes no queues (bfs_build_is_lazy; 0: never)
   u32* slot_marks;         // [2][BFS_MARK_CTRS] counters, 128 bytes apart: marks stored by the push workgroups of slot s in set s & 1 (NULL: not counted)
+  // cold-edge lists of the long rows (bfs_fused_cold.hpp, mgx_layout.hip): (owner, dst) pairs of the unit blocks' entries
+  // that point behind the LDS prefix, grouped by slice of the id range; NULL: none (the unit-block body marks them)
+  const int* cold_owner;
+  const int* cold_dst;
+  int cold_slices;         // slices that hold pairs (<= BFS_COLD_MAX_SLICES)
+  u32 cold_lo[16];         // first vertex of slice i (a multiple of 1024; the slice is BFS_COLD_WORDS * 32 vertices)
+  u32 cold_off[17];        // its pairs: [cold_off[i], cold_off[i + 1])
+  u32 cold_wgs[17];        // the cold workgroups [cold_wgs[i], cold_wgs[i + 1]) of a push launch take slice i
+  u32* cold_flush;         // BFS_COLD_WGS bitmaps of BFS_COLD_WORDS words: what cold workgroup k discovered in its slice
 };
+
+constexpr int BFS_COLD_MAX_SLICES = 16;
+constexpr int BFS_COLD_WGS = 128;              // workgroups of a push launch that take the cold pairs
+constexpr int BFS_COLD_WORDS = 20384;          // bitmap words of a slice == the unit-block body's LDS prefix (BFS_DENSE_HOTW)
 
 constexpr int BFS_MARK_CTRS = 8;               // the workgroups of a push launch spread their adds over this many lines
 constexpr int BFS_MARK_STRIDE = 32;            // u32 words between two counters
@@ -183,6 +198,8 @@ __device__ __forceinline__ void bfs_ctrl_reset(bfs_ctrl_t* c) {
   c->vshort_slots = 0;
   c->lazy_slot = -1;
   c->lazy_slots = 0;
+  c->cold_slot = -1;
+  c->cold_slots = 0;
   c->sssp_thr = 0x7f7fffffu;
   c->sssp_far_cnt[0] = c->sssp_far_cnt[1] = 0;
   c->sssp_far_min[0] = c->sssp_far_min[1] = 0x7f7fffffu;
@@ -671,6 +688,38 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
     }
   }
 
+  // the same for the bitmaps of the slot's cold-edge pass (bfs_fused_cold.hpp): cold workgroup k of slice s wrote what it
+  // discovered in [cold_lo[s], + BFS_COLD_WORDS * 32) into buffer k.  Wave w takes the workgroup's run w: 16-byte loads,
+  // eight lanes per buffer (a run is 128 bytes of bitmap), eight buffers per instruction, everything in flight at once.
+  if (a.cold_dst && c->cold_slot == slot) {                          // (grid-uniform)
+    static_assert(NW == 8, "one wave per run");
+    u32* const s_run = &s_or[0][0];                                  // [NW][32] words
+    const long long run = (long long)blockIdx.x + (long long)wave * gridDim.x;
+    const long long v0 = run * 1024;
+    int sl = -1;
+    for (int q = 0; q < a.cold_slices; ++q)
+      if (v0 >= (long long)a.cold_lo[q] && v0 < (long long)a.cold_lo[q] + (long long)BFS_COLD_WORDS * 32) sl = q;
+    uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+    if (sl >= 0) {                                                   // (wave-uniform)
+      const u32 rel = (u32)((v0 - (long long)a.cold_lo[sl]) >> 10);
+      const uint4* const base = (const uint4*)(a.cold_flush + (size_t)rel * 32) + (lane & 7);
+      const u32 k1 = a.cold_wgs[sl + 1];
+      for (u32 k = a.cold_wgs[sl] + ((u32)lane >> 3); k < k1; k += 8u) {
+        const uint4 v = base[(size_t)k * (BFS_COLD_WORDS / 4)];
+        acc.x |= v.x; acc.y |= v.y; acc.z |= v.z; acc.w |= v.w;
+      }
+#pragma unroll
+      for (int sh = 8; sh < 64; sh <<= 1) {
+        acc.x |= __shfl_xor(acc.x, sh, WAVE); acc.y |= __shfl_xor(acc.y, sh, WAVE);
+        acc.z |= __shfl_xor(acc.z, sh, WAVE); acc.w |= __shfl_xor(acc.w, sh, WAVE);
+      }
+    }
+    if (lane < 8) *(uint4*)(s_run + wave * 32 + lane * 4) = acc;
+    __syncthreads();
+    flushed16 |= (u32)((const unsigned short*)(s_run + my_run * 32))[my_group];
+    __syncthreads();
+  }
+
   // ---- which of my 16 vertices are new -------------------------------------------------------------------------------
   u32 new16 = 0;
   if (i0 < n) {
@@ -841,6 +890,7 @@ struct bfs_fused_state_t {
                                      // all short-row edges (bfs_fused_vshort.hpp; 0: never)
   unsigned lazy_div = 4;             // the build behind a push with >= n / lazy_div mark stores writes no queues (bfs_build_is_lazy; 0: never)
   mem_t<u32> slot_marks;             // the counters it looks at (bfs_fused_args_t::slot_marks)
+  mem_t<u32> cold_flush;             // cold-edge pass: BFS_COLD_WGS bitmaps of BFS_COLD_WORDS words (allocated on demand)
   unsigned dense_div = 2;            // long rows are read from the unit blocks when the frontier holds at least
                                      // 1 / dense_div of the units (bfs_fused_dense.hpp; 0: never)
   int long_min = 64;                 // rows at least this long go to the long-row queue (0: no such queue)

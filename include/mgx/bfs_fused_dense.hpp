@@ -47,13 +47,15 @@ __device__ __forceinline__ bool bfs_long_is_dense(const bfs_fused_args_t& a, con
 // (hot[-1]: the -1 entries of inactive lanes read as visited), a word of zeros behind (hot[HOTW]: vertices outside the
 // prefix read as unvisited), so that one clamp replaces the range checks of the probe.  Returns hot; all threads.
 template <int NT, int HOTW>
-__device__ __forceinline__ u32* bfs_hot_setup(const bfs_fused_args_t& a, char* smem, int** s_int) {
+__device__ __forceinline__ u32* bfs_hot_setup(const bfs_fused_args_t& a, char* smem, int** s_int, u32 behind = 0u) {
   u32* const hot = (u32*)smem + 4;
   *s_int = (int*)(hot + HOTW + 4);
   const uint4* src = (const uint4*)a.visited;
   uint4* dstp = (uint4*)hot;
   for (int i = threadIdx.x; i < HOTW / 4; i += NT) dstp[i] = src[i];
-  if (threadIdx.x == 0) { hot[-1] = 0xFFFFFFFFu; hot[HOTW] = 0u; (*s_int)[0] = 0; }
+  // (behind: what a vertex outside the prefix reads as -- 0 "unvisited": marked untested; all ones when the slot's cold-edge
+  //  pass takes care of those entries, bfs_fused_cold.hpp)
+  if (threadIdx.x == 0) { hot[-1] = 0xFFFFFFFFu; hot[HOTW] = behind; (*s_int)[0] = 0; }
   __syncthreads();
   return hot;
 }
@@ -121,7 +123,7 @@ __device__ __forceinline__ void bfs_dense_work(const bfs_fused_args_t& a, u32* c
         const u32 bit = 1u << (d & 31u);
         bool is_new = true;
         if (d < hot_n) is_new = !(atomicOr(&hot[d >> 5], bit) & bit);
-        if (is_new) { if (!(diag & 1) && d >= defer_n) mark[d] = 1; ++marks; }
+        if (is_new) { if (!(diag & 1) && d >= defer_n && !((diag & 4) && d >= hot_n)) mark[d] = 1; ++marks; }   // (diag 4: no COLD marks)
       }
     };
     // four LDS probes in flight, then the four decisions (a probe that waits for its own result before the next one
@@ -181,10 +183,11 @@ __device__ __forceinline__ void bfs_dense_work(const bfs_fused_args_t& a, u32* c
 // GPS: groups per step (1: four 16-byte loads in flight per lane while the previous four are tested; 2: eight -- for
 // launches with half the waves per CU)
 template <int NT, int HOTW, int GPS = 1>
-__device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int slot, u32 block, u32 nblocks, int stat_level) {
+__device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int slot, u32 block, u32 nblocks, int stat_level,
+                                               bool cold = false) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* s_int;
-  u32* const hot = bfs_hot_setup<NT, HOTW>(a, smem, &s_int);
+  u32* const hot = bfs_hot_setup<NT, HOTW>(a, smem, &s_int, cold ? 0xFFFFFFFFu : 0u);    // cold: those entries are somebody else's
   const int lane = lane_id();
   bfs_ctrl_t* const c = a.ctrl;
   const u32 hot_n = ((u32)a.n < (u32)(HOTW * 32)) ? (u32)a.n : (u32)(HOTW * 32);

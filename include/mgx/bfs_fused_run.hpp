@@ -9,6 +9,7 @@
 #pragma once
 #include "bfs_fused.hpp"
 #include "bfs_fused_chain.hpp"
+#include "bfs_fused_cold.hpp"
 #include "bfs_fused_dense.hpp"
 #include "bfs_fused_pull.hpp"
 #include "bfs_fused_stream.hpp"
@@ -33,11 +34,19 @@ struct bfs_layout_t {
   unsigned vs_v[4] = {0, 0, 0, 0};
   unsigned vs_edges = 0, vs_dummy = 0;
   int vs_long_min = 0;
+  // cold-edge lists of the long rows (bfs_fused_cold.hpp): pairs grouped by slice; hot_n / long_min they were cut for
+  const int* cold_owner = nullptr;
+  const int* cold_dst = nullptr;
+  int cold_slices = 0;
+  unsigned cold_lo[16] = {0}, cold_off[17] = {0}, cold_wgs[17] = {0};
+  unsigned cold_hot_n = 0;
+  int cold_long_min = 0;
 };
 
 constexpr int BFS_STREAM_HOTW2 = 20400;   // two workgroups per CU: 80 KB of bitmap each
 constexpr int BFS_WAVE_HOTW = 18000;
 constexpr int BFS_DENSE_HOTW = BFS_STREAM_HOTW2 - 16;   // (the dense body's two sentinel words fit the same 81 664 bytes)
+static_assert(BFS_COLD_WORDS == BFS_DENSE_HOTW, "a cold slice is as long as the unit-block body's LDS prefix");
 
 constexpr size_t bfs_push_lds_bytes() {
   size_t m = bfs_stream_lds_bytes(BFS_STREAM_HOTW2);
@@ -45,13 +54,14 @@ constexpr size_t bfs_push_lds_bytes() {
   if (bfs_dense_lds_bytes(BFS_DENSE_HOTW) > m) m = bfs_dense_lds_bytes(BFS_DENSE_HOTW);
   if (bfs_chain_lds_bytes() > m) m = bfs_chain_lds_bytes();
   if (bfs_vshort_lds_bytes(BFS_DENSE_HOTW) > m) m = bfs_vshort_lds_bytes(BFS_DENSE_HOTW);
+  if (bfs_cold_lds_bytes() > m) m = bfs_cold_lds_bytes();
   return m;
 }
 
 // what a slot's push launch does, derived by every workgroup from the same stable inputs
 struct bfs_slot_plan_t {
   int slot, level;
-  bool empty, chained, dense, vshort;
+  bool empty, chained, dense, vshort, cold;
 };
 __device__ __forceinline__ bfs_slot_plan_t bfs_slot_plan(const bfs_fused_args_t& a, int arg) {
   const bfs_ctrl_t* const c = a.ctrl;
@@ -63,6 +73,10 @@ __device__ __forceinline__ bfs_slot_plan_t bfs_slot_plan(const bfs_fused_args_t&
   const bool pulls = bfs_level_pulls(a, c, p.slot);
   p.dense = !p.empty && !p.chained && !pulls && bfs_long_is_dense(a, c, p.slot, lcur);
   p.vshort = !p.empty && !p.chained && !pulls && bfs_short_is_dense(a, c, p.slot, cur);
+  // the long rows' cold entries go through the pair lists (bfs_fused_cold.hpp) when the frontier holds enough long rows to
+  // read the unit blocks by its own size (a sweep of all pairs does not pay for a sparse frontier that was only forced
+  // onto the unit blocks by a lazy build: the unit-block body marks the few cold entries it meets)
+  p.cold = p.dense && a.cold_dst != nullptr;
   if (!p.empty && c->lazy_slot == p.slot) {       // the build before this slot wrote no queues (bfs_build_is_lazy)
     p.chained = false;
     p.dense = p.vshort = true;
@@ -83,6 +97,7 @@ __device__ __forceinline__ void bfs_slot_open(const bfs_fused_args_t& a, const b
   c->slot_level[(p.slot + 1) & 3] = p.level + 1;
   c->skip_build[p.slot & 3] = 0;
   if (p.dense) c->dense_slots += 1;
+  if (p.cold) { c->cold_slot = p.slot; c->cold_slots += 1; }
   if (p.vshort) c->vshort_slots += 1;
 }
 
@@ -102,25 +117,30 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
   }
   if ((PART == 0 || PART == 1) && blockIdx.x == 0 && threadIdx.x == 0) bfs_slot_open(a, p);
   if (p.empty || PART == 1) return;
-  // Which part this workgroup takes: the first nstream workgroups the long rows, the others the short rows.
+  // Which part this workgroup takes: the first nstream workgroups the long rows, then (graphs with cold-edge lists) the
+  // BFS_COLD_WGS workgroups of the cold pass, the others the short rows.
   // (interleave: even / odd instead, so that the two parts share every CU -- an experiment that lost, see bfs_run_opts_t)
+  const u32 ncold = (!COLDT && a.cold_dst) ? (u32)BFS_COLD_WGS : 0u;
   if (PART == 0 && !COLDT && p.dense && p.vshort && a.combine) {
     // both dense paths: the first nstream workgroups take their share of the long AND of the short rows
-    if (blockIdx.x < nstream) bfs_dense_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, blockIdx.x, nstream, p.level);
+    if (blockIdx.x < nstream) bfs_dense_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, blockIdx.x, nstream, p.level, p.cold);
+    else if (blockIdx.x < nstream + ncold && p.cold) bfs_cold_body<1024>(a, p.slot, blockIdx.x - nstream, p.level);
     return;
   }
-  const bool il = PART == 0 && a.interleave && gridDim.x == 2u * nstream;
-  const bool long_part = PART == 2 || (PART == 0 && (il ? !(blockIdx.x & 1u) : blockIdx.x < nstream));
+  const bool il = PART == 0 && a.interleave && ncold == 0u && gridDim.x == 2u * nstream;
+  const bool long_part = PART == 2 ? blockIdx.x < nstream : (PART == 0 && (il ? !(blockIdx.x & 1u) : blockIdx.x < nstream));
   if (long_part) {
-    const u32 nb = PART == 0 ? nstream : gridDim.x;
     const u32 bi = il ? blockIdx.x >> 1 : blockIdx.x;
-    if (!COLDT && p.dense) bfs_dense_body<1024, BFS_DENSE_HOTW>(a, p.slot, bi, nb, p.level);
-    else bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, COLDT, false, true>(a, p.slot, bi, nb, p.level);
-  } else {
-    const u32 first = PART == 0 ? nstream : 0u;
+    if (!COLDT && p.dense) bfs_dense_body<1024, BFS_DENSE_HOTW>(a, p.slot, bi, nstream, p.level, p.cold);
+    else bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, COLDT, false, true>(a, p.slot, bi, nstream, p.level);
+  } else if (!il && (PART == 0 || PART == 2) && blockIdx.x < nstream + ncold) {
+    if (p.cold) bfs_cold_body<1024>(a, p.slot, blockIdx.x - nstream, p.level);
+  } else if (PART != 2) {
+    const u32 first = PART == 0 ? nstream + ncold : 0u;
     const u32 bi = il ? blockIdx.x >> 1 : blockIdx.x - first;
-    if (!COLDT && p.vshort) bfs_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, bi, gridDim.x - first, p.level);
-    else bfs_wave_body<1024, BFS_WAVE_HOTW, COLDT, false>(a, p.slot, bi, gridDim.x - first, p.level);
+    const u32 nb = il ? nstream : gridDim.x - first;
+    if (!COLDT && p.vshort) bfs_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, bi, nb, p.level);
+    else bfs_wave_body<1024, BFS_WAVE_HOTW, COLDT, false>(a, p.slot, bi, nb, p.level);
   }
 }
 
@@ -180,6 +200,7 @@ struct bfs_run_opts_t {
   int dense = -1;          // MGX_BFS_DENSE: 0 never, N > 0 dense_div = N
   int vshort = -1;         // MGX_BFS_VSHORT: 0 never, N > 0 vshort_div = N
   long long chain = -1;    // MGX_BFS_CHAIN_MAX_EDGES: 0 never (default BFS_CHAIN_CAP)
+  int cold = 1;            // MGX_BFS_COLD=0: the unit-block body marks its cold entries itself (no cold-edge pass)
   int lazy = -1;           // MGX_BFS_LAZY: 0 the queue build always writes the queues, N: not behind a push that stored >= n / N marks
   long long defer = -1;    // MGX_BFS_DEFER: 0 never defer hot marks, N: flush a bitmap above N deferred marks per workgroup
   int combine = 0;         // MGX_BFS_COMBINE=1: a level that takes both dense paths runs them in the SAME workgroups (one copy of the
@@ -209,6 +230,7 @@ struct bfs_run_opts_t {
     if (const char* e = getenv("MGX_BFS_INTERLEAVE")) o.interleave = atoi(e);
     if (const char* e = getenv("MGX_BFS_COMBINE")) o.combine = atoi(e);
     if (const char* e = getenv("MGX_BFS_DEFER")) o.defer = atoll(e);
+    if (const char* e = getenv("MGX_BFS_COLD")) o.cold = atoi(e);
     if (const char* e = getenv("MGX_BFS_LAZY")) { o.lazy = atoi(e); if (o.lazy > (1 << 20)) o.lazy = 1 << 20; }   // (edges < 2^38: no overflow)
     return o;
   }
@@ -311,11 +333,24 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   st.batches = 0;
   // k_bfs_build2 reads a thread's 17 row offsets and 16 layout ids with 16-byte loads: borrowed arrays must be aligned
   const bool build2_ok = ((uintptr_t)a.row_offsets % 16 == 0) && ((uintptr_t)a.old_of_new % 16 == 0);
+  // cold-edge lists (bfs_fused_cold.hpp): with the unit blocks they were cut from, the prefix they were cut behind, and a
+  // queue build that knows their bitmaps
+  const bool cold = units && a.dense_div && layout->cold_dst && layout->cold_slices > 0 && layout->cold_hot_n == (unsigned)(BFS_DENSE_HOTW * 32) &&
+                    layout->cold_long_min == st.long_min && build2_ok && !opt.build_list && !opt.interleave && opt.cold != 0 &&
+                    !opt.dense_diag && !(opt.biglds && st.time_kernels == 1);
+  a.cold_owner = cold ? layout->cold_owner : nullptr;
+  a.cold_dst = cold ? layout->cold_dst : nullptr;
+  a.cold_slices = cold ? layout->cold_slices : 0;
+  for (int i = 0; i < 16; ++i) a.cold_lo[i] = cold ? layout->cold_lo[i] : 0u;
+  for (int i = 0; i < 17; ++i) { a.cold_off[i] = cold ? layout->cold_off[i] : 0u; a.cold_wgs[i] = cold ? layout->cold_wgs[i] : 0u; }
+  if (cold && !st.cold_flush.size()) st.cold_flush = mem_t<u32>((size_t)BFS_COLD_WGS * BFS_COLD_WORDS, ctx);
+  a.cold_flush = cold ? st.cold_flush.data() : nullptr;
   // lazy queues (bfs_build_is_lazy): only k_bfs_build2 knows them, and only when both queue-less bodies are available
   a.lazy_div = (a.dense_div && a.vs_div && mode == 0 && build2_ok && !opt.build_list) ? (opt.lazy >= 0 ? (u32)opt.lazy : st.lazy_div) : 0u;
   const bool batch_events = st.time_kernels != 0 || st.time_batches;    // (an event costs ~6 us of stream gap)
   const u32 nstream = a.long_min > 0 ? (u32)ctx.num_cus * 2 : 0u;
   const u32 nwave = (u32)ctx.num_cus * 2;
+  const u32 ncold = (!coldt && a.cold_dst) ? (u32)BFS_COLD_WGS : 0u;
   int slot = 0;
   for (int batch = 0;; ++batch) {
     // first batch: what the previous traversal of this graph needed (sources differ, level structure hardly)
@@ -331,7 +366,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
         // the product launch itself between two events: its average duration is what rocprofv3 --stats reports for
         // k_bfs_push<., 0> too (launches of small or empty slots included on both sides)
         MGX_HIP(hipEventRecord(st.wev[3 * i], s));
-        bfs_launch_push_part<0>(a, arg, ctx, coldt, nstream + nwave, nstream);
+        bfs_launch_push_part<0>(a, arg, ctx, coldt, nstream + ncold + nwave, nstream);
         MGX_HIP(hipEventRecord(st.wev[3 * i + 1], s));
       } else if (timed || !opt.merged || a.flags) {
         // the parts as launches of their own: opener / chain, long rows, short rows
@@ -340,13 +375,13 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
         if (a.long_min > 0) {
           if (a.flags) hipLaunchKernelGGL(k_bfs_push_stream_diag, dim3(nstream), dim3(1024), bfs_push_lds_bytes(), s, a, arg);
           else if (opt.biglds && !coldt) hipLaunchKernelGGL(k_bfs_push_dense_big, dim3(ctx.num_cus), dim3(1024), bfs_dense_lds_bytes(BFS_DENSE_HOTW_BIG), s, a, arg);
-          else bfs_launch_push_part<2>(a, arg, ctx, coldt, nstream, 0);
+          else bfs_launch_push_part<2>(a, arg, ctx, coldt, nstream + ncold, nstream);
         }
         if (timed) MGX_HIP(hipEventRecord(st.wev[3 * i + 1], s));
         bfs_launch_push_part<3>(a, arg, ctx, coldt, nwave, 0);
         if (timed) MGX_HIP(hipEventRecord(st.wev[3 * i + 2], s));
       } else {
-        bfs_launch_push_part<0>(a, arg, ctx, coldt, nstream + nwave, nstream);
+        bfs_launch_push_part<0>(a, arg, ctx, coldt, nstream + ncold + nwave, nstream);
       }
       if (mode == 1)
         hipLaunchKernelGGL(k_bfs_pull_level<256>, dim3(ctx.num_cus * 8), dim3(256), 0, s, a, arg);

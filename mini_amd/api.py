@@ -334,14 +334,14 @@ class BfsProblem:
 
     def run(self, src, mode=_lib.MGX_BFS_PUSH, alpha=0.0):
         """Fused device-resident traversal."""
-        st = (C.c_int64 * 20)()
+        st = (C.c_int64 * 24)()
         check(lib.mgx_bfs_run(self._h, int(src), int(mode), C.c_float(alpha), st))
         return {"levels": st[0], "reached": st[1], "m_t": st[2], "push_edges": st[3], "pull_edges": st[4],
                 "push_levels": st[5], "kernel_launches": st[6], "kernel_ns": st[7], "frontier_vertices": st[8],
                 "claims": st[9], "dom_launches": st[10], "dom_ns": st[11], "dom_edges": st[12],
                 "dom_vertices": st[13],
                 "dom_kernel": "k_bfs_push_level_stream" if st[14] else "k_bfs_push_level_wave",
-                "small_levels": st[15], "slots": st[16], "dense_slots": st[17], "vshort_slots": st[18], "lazy_slots": st[19]}
+                "small_levels": st[15], "slots": st[16], "dense_slots": st[17], "vshort_slots": st[18], "lazy_slots": st[19], "cold_slots": st[20]}
 
     def level_trace(self, cap=4096):
         nf, ne, lv = (C.c_int64 * cap)(), (C.c_int64 * cap)(), C.c_int()

@@ -41,7 +41,7 @@ struct mgx_bfs_s {
   std::shared_ptr<bfs::bfs_problem_t> p;
   std::unique_ptr<bfs::bfs_enactor_t> e;              // lazily: holds two m-capacity buffers
   std::unique_ptr<bfs::bfs_fused_enactor_t> fe;       // lazily: O(n)
-  int64_t last_stats[20] = {0};
+  int64_t last_stats[24] = {0};
   mem_t<unsigned> visited_mask;                       // lazily: the idempotent mode's bitmask ((n + 31) / 32 words)
   int time_kernels = -1;                              // -1: environment default
 };
@@ -315,6 +315,7 @@ int mgx_graph_attach_layout(mgx_graph_t g, const int* d_row_offsets, const int* 
   G.d_old_of_new = mem_t<int>::borrow((int*)d_old_of_new, (size_t)G.num_nodes);
   G.has_layout = true;
   G.vs_edges = 0; G.vs_dummy = 0; G.vs_long_min = 0;      // (borrowed arrays: no padding behind them, sortedness not checked)
+  G.d_cold_owner = mem_t<int>(); G.d_cold_dst = mem_t<int>(); G.cold_pairs = 0; G.cold_slices = 0;
   use_device(g->c);
   g->c->ctx->synchronize();
   build_unit_blocks(g);
@@ -353,6 +354,58 @@ static void build_unit_blocks(mgx_graph_s* g) {
   G.d_ub_owner = mem_t<int>::adopt(owner, (size_t)units_pad);
   G.d_ub_col = mem_t<int>::adopt(ucol, ((size_t)units_pad << 6) + 4);
   G.ub_units = units; G.ub_units_pad = units_pad; G.ub_min_degree = long_min;
+}
+extern "C" int mgx_cold_build_device(const int* ro, const int* ci, int n, int rows, int min_deg, unsigned hot_n, unsigned slice_n,
+                                     int slices, int** owner, int** dst, long long* pairs, int* slice_off, hipStream_t stream);
+// Cold-edge lists of the layout's long rows (mgx/bfs_fused_cold.hpp); MGX_BFS_COLD_LISTS=0 skips them.  Needs the unit
+// blocks and the degree classes (a degree-sorted layout: the long rows are [0, vs_v[0])); built only when the cold entries
+// are a small share of the long rows' entries (a skewed graph under the hub-first order) and few slices hold any.
+static void build_cold_lists(mgx_graph_s* g) {
+  graph_device_t& G = *g->g;
+  G.d_cold_owner = mem_t<int>(); G.d_cold_dst = mem_t<int>(); G.cold_pairs = 0; G.cold_slices = 0; G.cold_hot_n = 0; G.cold_long_min = 0;
+  if (const char* e = getenv("MGX_BFS_COLD_LISTS")) if (atoi(e) == 0) return;
+  if (G.ub_units <= 0 || G.vs_long_min <= 0 || G.vs_long_min != G.ub_min_degree || G.vs_v[0] == 0) return;
+  const unsigned hot_n = (unsigned)mgx::BFS_COLD_WORDS * 32u, slice_n = hot_n;
+  const unsigned n = (unsigned)G.num_nodes;
+  if (n <= hot_n) return;                                          // everything is inside the prefix
+  const long long slices_ll = ((long long)n - hot_n + slice_n - 1) / slice_n;
+  if (slices_ll > 64) return;
+  const int slices = (int)slices_ll;
+  std::vector<int> off((size_t)slices + 1, 0);
+  int *owner = nullptr, *dst = nullptr;
+  long long pairs = 0;
+  const int rc = mgx_cold_build_device(G.d_layout_row_offsets.data(), G.d_layout_col_indices.data(), (int)n, (int)G.vs_v[0],
+                                       G.vs_long_min, hot_n, slice_n, slices, &owner, &dst, &pairs, off.data(), g->c->ctx->stream());
+  if (rc != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("cold-edge lists: ") + hipGetErrorString((hipError_t)rc));
+  if (pairs <= 0) return;
+  mem_t<int> d_owner = mem_t<int>::adopt(owner, (size_t)pairs + 256), d_dst = mem_t<int>::adopt(dst, (size_t)pairs + 256);
+  // the non-empty slices; give up when there are too many of them or when the pairs are not a small share of the entries
+  int used = 0;
+  for (int k = 0; k < slices; ++k) if (off[k + 1] > off[k]) ++used;
+  const long long long_entries = (long long)G.ub_units * 64;       // (padded: an upper bound of the long rows' entries)
+  if (used > mgx::BFS_COLD_MAX_SLICES || pairs * 4 > long_entries) return;
+  int q = 0;
+  for (int k = 0; k < slices; ++k) {
+    if (off[k + 1] == off[k]) continue;
+    G.cold_lo[q] = hot_n + (unsigned)k * slice_n;
+    G.cold_off[q] = (unsigned)off[k];
+    G.cold_off[q + 1] = (unsigned)off[k + 1];
+    ++q;
+  }
+  // workgroups per slice: in proportion to its pairs, at least one each
+  unsigned left = (unsigned)mgx::BFS_COLD_WGS - (unsigned)used, acc = 0;
+  G.cold_wgs[0] = 0;
+  for (int i = 0; i < used; ++i) {
+    const long long cnt = (long long)G.cold_off[i + 1] - (long long)G.cold_off[i];
+    unsigned extra = (unsigned)((cnt * (long long)((unsigned)mgx::BFS_COLD_WGS - (unsigned)used)) / pairs);
+    if (extra > left) extra = left;
+    left -= extra;
+    acc += 1u + extra;
+    G.cold_wgs[i + 1] = acc;
+  }
+  for (int i = used + 1; i <= 16; ++i) { G.cold_wgs[i] = acc; G.cold_off[i] = G.cold_off[used]; }
+  G.d_cold_owner = std::move(d_owner); G.d_cold_dst = std::move(d_dst);
+  G.cold_pairs = pairs; G.cold_slices = used; G.cold_hot_n = hot_n; G.cold_long_min = G.vs_long_min;
 }
 int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
   MGX_TRY
@@ -400,6 +453,7 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
       G.vs_long_min = long_min;
     }
   }
+  build_cold_lists(g);
   MGX_CATCH
 }
 extern "C" int mgx_csc_build_device(const int* ro, const int* ci, const float* w, int n, long long m, int* co, int* ri, float* rv,
@@ -896,6 +950,7 @@ int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats) {
   p->last_stats[17] = L.dense_slots;
   p->last_stats[18] = L.vshort_slots;
   p->last_stats[19] = L.lazy_slots;
+  p->last_stats[20] = L.cold_slots;
   if (stats) memcpy(stats, p->last_stats, sizeof(p->last_stats));
   MGX_CATCH
 }

@@ -195,6 +195,104 @@ extern "C" int mgx_units_build_device(const int* ro, const int* ci, int n, int m
   return 0;
 }
 
+// ---- cold-edge lists of the long rows (mgx/bfs_fused_cold.hpp) --------------------------------------------------------
+// The unit-block body keeps the first `hot_n` vertices of the visited bitmap in LDS; an entry that points behind them is
+// "cold": it cannot be tested there, and marking it costs a scattered one-byte store -- which, for a 4 MB mark array under
+// a stream, costs the fabric as much as a whole cache line (tools/microbench4.hip).  Here the cold entries of the rows
+// [0, rows) are pulled out once, as (owner, dst) pairs grouped by the SLICE of the id range dst lies in (slice k =
+// [hot_n + k * slice_n, hot_n + (k + 1) * slice_n)): a workgroup that takes pairs of ONE slice can keep that slice of
+// the bitmap in LDS and needs no marks at all.  Inside a slice the pairs are ordered by owner, then dst (the rows are
+// sorted): neighbouring lanes ask for neighbouring frontier bits.
+namespace {
+
+// cnt[k * rows + r] = entries of row r in slice k (0 for rows of fewer than min_deg entries)
+__global__ void k_cold_counts(const int* __restrict__ ro, const int* __restrict__ ci, int rows, int min_deg, unsigned hot_n,
+                              unsigned slice_n, int slices, int* __restrict__ cnt) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const int r0 = ro[r], r1 = ro[r + 1];
+  const bool is_long = r1 - r0 >= min_deg;
+  int prev = r1;
+  if (is_long) {                                   // first entry >= hot_n
+    int lo = r0, hi = r1;
+    while (lo < hi) { const int mid = lo + (hi - lo) / 2; if ((unsigned)ci[mid] < hot_n) lo = mid + 1; else hi = mid; }
+    prev = lo;
+  }
+  for (int k = 0; k < slices; ++k) {
+    int next = r1;
+    if (is_long && k + 1 < slices) {
+      const unsigned long long bound = (unsigned long long)hot_n + (unsigned long long)(k + 1) * slice_n;
+      int lo = prev, hi = r1;
+      while (lo < hi) { const int mid = lo + (hi - lo) / 2; if ((unsigned long long)(unsigned)ci[mid] < bound) lo = mid + 1; else hi = mid; }
+      next = lo;
+    }
+    cnt[(long long)k * rows + r] = is_long ? next - prev : 0;
+    prev = next;
+  }
+}
+
+// one wave per row: its cold entries to their places (off[k * rows + r] = first pair of (slice k, row r))
+__global__ void k_cold_fill(const int* __restrict__ ro, const int* __restrict__ ci, int rows, const int* __restrict__ cnt,
+                            const int* __restrict__ off, int slices, int* __restrict__ owner, int* __restrict__ dst) {
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long r = wave0; r < rows; r += nwaves) {
+    int total = 0;
+    for (int k = 0; k < slices; ++k) total += cnt[(long long)k * rows + r];
+    if (total == 0) continue;
+    int src = ro[r + 1] - total;                   // the cold entries are the row's tail
+    for (int k = 0; k < slices; ++k) {
+      const int c = cnt[(long long)k * rows + r], o = off[(long long)k * rows + r];
+      for (int i = lane; i < c; i += 64) { owner[o + i] = (int)r; dst[o + i] = ci[src + i]; }
+      src += c;
+    }
+  }
+}
+
+__global__ void k_cold_pad(int pairs, int pad, int n, int* __restrict__ owner, int* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < pad) { owner[pairs + i] = n; dst[pairs + i] = -1; }
+}
+
+}  // namespace
+
+// rows: the long rows are [0, rows) (a degree-sorted CSR).  slice_off: slices + 1 ints (host).  Allocates *owner / *dst
+// (pairs + 256 ints each: the padding holds owner = n, dst = -1) with hipMalloc; nothing is allocated when there are no pairs.
+extern "C" int mgx_cold_build_device(const int* ro, const int* ci, int n, int rows, int min_deg, unsigned hot_n, unsigned slice_n,
+                                     int slices, int** owner, int** dst, long long* pairs, int* slice_off, hipStream_t stream) {
+  *owner = nullptr; *dst = nullptr; *pairs = 0;
+  for (int k = 0; k <= slices; ++k) slice_off[k] = 0;
+  if (rows <= 0 || slices <= 0) return 0;
+  const size_t cells = (size_t)rows * (size_t)slices;
+  tmp_t cnt, off, st;
+  LAY_TRY(cnt.alloc(cells * 4)); LAY_TRY(off.alloc(cells * 4));
+  hipLaunchKernelGGL(k_cold_counts, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, ro, ci, rows, min_deg, hot_n,
+                     slice_n, slices, cnt.as<int>());
+  size_t sb = 0;
+  LAY_TRY(rocprim::exclusive_scan(nullptr, sb, cnt.as<int>(), off.as<int>(), 0, cells, rocprim::plus<int>(), stream));
+  LAY_TRY(st.alloc(sb));
+  LAY_TRY(rocprim::exclusive_scan(st.p, sb, cnt.as<int>(), off.as<int>(), 0, cells, rocprim::plus<int>(), stream));
+  int last_off = 0, last_cnt = 0;
+  LAY_TRY(hipMemcpyAsync(&last_off, off.as<int>() + (cells - 1), 4, hipMemcpyDeviceToHost, stream));
+  LAY_TRY(hipMemcpyAsync(&last_cnt, cnt.as<int>() + (cells - 1), 4, hipMemcpyDeviceToHost, stream));
+  for (int k = 0; k < slices; ++k)
+    LAY_TRY(hipMemcpyAsync(slice_off + k, off.as<int>() + (size_t)k * rows, 4, hipMemcpyDeviceToHost, stream));
+  LAY_TRY(hipStreamSynchronize(stream));
+  const long long E = (long long)last_off + last_cnt;
+  slice_off[slices] = (int)E;
+  if (E <= 0) return 0;
+  LAY_TRY(hipMalloc((void**)owner, ((size_t)E + 256) * 4));
+  hipError_t e = hipMalloc((void**)dst, ((size_t)E + 256) * 4);
+  if (e != hipSuccess) { (void)hipFree(*owner); *owner = nullptr; return (int)e; }
+  hipLaunchKernelGGL(k_cold_fill, dim3(2048), dim3(256), 0, stream, ro, ci, rows, cnt.as<int>(), off.as<int>(), slices, *owner, *dst);
+  hipLaunchKernelGGL(k_cold_pad, dim3(1), dim3(256), 0, stream, (int)E, 256, n, *owner, *dst);
+  e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) { (void)hipFree(*owner); (void)hipFree(*dst); *owner = nullptr; *dst = nullptr; return (int)e; }
+  *pairs = E;
+  return 0;
+}
+
 // ---- genuine CSC (transpose) of a device CSR ------------------------------------------------------------------------
 // The reference's loader always ends up with csc == csr (its transposed copy goes into a shadowed local), which
 // is only right for symmetric inputs.  Bottom-up BFS levels on a DIRECTED graph need the in-edges: col_offsets[v] ..

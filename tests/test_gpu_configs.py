@@ -164,8 +164,43 @@ def test_config2_rmat22_bfs_full_size_vs_oracle(gpu_ctx, oracle, torch_mod):
     assert st["reached"] == int((want >= 0).sum()) and st["m_t"] == int(deg[want >= 0].sum())
     assert st["dense_slots"] >= 1          # the big level read its long rows from the unit blocks
     assert st["vshort_slots"] >= 1         # ... and walked its short rows vertex by vertex
+    assert st["cold_slots"] >= 1           # ... and its long rows' entries behind the LDS prefix went through the pair lists
+    assert st["lazy_slots"] >= 1           # the build behind a heavy push wrote no queues
     st = bfs.run(src, mode=mini_amd.MGX_BFS_DIRECTION_OPT, alpha=4.0)
     assert np.array_equal(bfs.labels(), want)
+
+
+@pytest.mark.parametrize("scale,undir,env", [
+    (20, True, {}), (21, True, {"MGX_BFS_DENSE": "1000000", "MGX_BFS_LAZY": "1048576"}), (20, False, {"MGX_BFS_DENSE": "1000000"}),
+    (21, True, {"MGX_BFS_DEFER": "0"}), (20, True, {"MGX_BFS_COLD": "0"}), (21, True, {"MGX_BFS_DENSE": "1000000", "MGX_BFS_MERGED_PUSH": "0"}),
+    (21, True, {"MGX_BFS_COMBINE": "1", "MGX_BFS_DENSE": "1000000", "MGX_BFS_VSHORT": "1000000"})])
+def test_cold_edge_pass_vs_oracle(gpu_ctx, oracle, torch_mod, monkeypatch, scale, undir, env):
+    """the cold-edge pass (bfs_fused_cold.hpp) needs a graph with vertices behind the LDS prefix (652 288): R-MAT 20 / 21,
+    symmetrised and directed (destinations without out-edges sit at the very end of the hub-first order), default
+    thresholds and the unit blocks forced onto every level, bitmaps and replayed marks, the parts launched separately;
+    labels against the oracle for hub, ordinary and isolated sources"""
+    import mini_amd
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n = 1 << scale
+    s, d, w = oracle.rmat_edges(scale, 0, 8 * n, 900 + scale, True)
+    ro, ci, _ = oracle.csr_from_tuples(n, s, d, None, undir=undir)
+    graph = mini_amd.Graph.from_host(gpu_ctx, ro, ci, None).build_layout()
+    deg = np.diff(ro)
+    rng = np.random.default_rng(scale)
+    srcs = [int(np.argmax(deg))] + [int(v) for v in rng.choice(np.where(deg > 0)[0], size=3, replace=False)] + [int(np.where(deg == 0)[0][0])]
+    bfs = mini_amd.BfsProblem(graph, srcs[0])
+    cold = 0
+    for src in srcs:
+        want = oracle.bfs_cpu(ro, ci, src)
+        st = bfs.run(src)
+        assert np.array_equal(bfs.labels(), want), (scale, undir, env, src)
+        assert st["m_t"] == int(deg[want >= 0].sum())
+        cold += st["cold_slots"]
+    if env.get("MGX_BFS_COLD") == "0":
+        assert cold == 0
+    elif undir and "MGX_BFS_DENSE" in env:
+        assert cold > 0
 
 
 def test_config3_rmat22_sssp_full_size_vs_oracle(gpu_ctx, oracle, torch_mod):

@@ -52,7 +52,7 @@ for rnd in range(a.rounds):
             ref = lab.copy()
         same = bool(np.array_equal(lab, ref))
         results[cfg].append(dt / a.steps * 1e3)
-        print("round %d  %-60s %.4f ms/BFS  %.1f GTEPS  slots %.2f batches %.2f dense %d vshort %d lazy %d small %d  labels_equal %s" % (
-            rnd, cfg or "(defaults)", dt / a.steps * 1e3, m_t / dt / 1e9, nsl / a.steps, nb / a.steps, st["dense_slots"], st["vshort_slots"], st.get("lazy_slots", 0), st["small_levels"], same), flush=True)
+        print("round %d  %-60s %.4f ms/BFS  %.1f GTEPS  slots %.2f batches %.2f dense %d vshort %d lazy %d cold %d small %d  labels_equal %s" % (
+            rnd, cfg or "(defaults)", dt / a.steps * 1e3, m_t / dt / 1e9, nsl / a.steps, nb / a.steps, st["dense_slots"], st["vshort_slots"], st.get("lazy_slots", 0), st.get("cold_slots", 0), st["small_levels"], same), flush=True)
 for cfg in configs:
     print("best  %-60s %.4f ms/BFS" % (cfg or "(defaults)", min(results[cfg])))
