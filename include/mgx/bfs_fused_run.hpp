@@ -117,28 +117,32 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
   }
   if ((PART == 0 || PART == 1) && blockIdx.x == 0 && threadIdx.x == 0) bfs_slot_open(a, p);
   if (p.empty || PART == 1) return;
-  // Which part this workgroup takes: the first nstream workgroups the long rows, then (graphs with cold-edge lists) the
-  // BFS_COLD_WGS workgroups of the cold pass, the others the short rows.
+  // Which part this workgroup takes: (graphs with cold-edge lists) BFS_COLD_WGS workgroups of the cold pass, then nstream
+  // workgroups for the long rows, the others the short rows.
   // (interleave: even / odd instead, so that the two parts share every CU -- an experiment that lost, see bfs_run_opts_t)
-  const u32 ncold = (!COLDT && a.cold_dst) ? (u32)BFS_COLD_WGS : 0u;
-  if (PART == 0 && !COLDT && p.dense && p.vshort && a.combine) {
-    // both dense paths: the first nstream workgroups take their share of the long AND of the short rows
-    if (blockIdx.x < nstream) bfs_dense_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, blockIdx.x, nstream, p.level, p.cold);
-    else if (blockIdx.x < nstream + ncold && p.cold) bfs_cold_body<1024>(a, p.slot, blockIdx.x - nstream, p.level);
+  const u32 ncold = (!COLDT && a.cold_dst && (PART == 0 || PART == 2)) ? (u32)BFS_COLD_WGS : 0u;
+  // grid: [cold pass][long rows][short rows] -- the cold workgroups first: they are few and short, and the launch does
+  // not end on them
+  if (blockIdx.x < ncold) {
+    if (p.cold) bfs_cold_body<1024>(a, p.slot, blockIdx.x, p.level);
     return;
   }
-  const bool il = PART == 0 && a.interleave && ncold == 0u && gridDim.x == 2u * nstream;
-  const bool long_part = PART == 2 ? blockIdx.x < nstream : (PART == 0 && (il ? !(blockIdx.x & 1u) : blockIdx.x < nstream));
+  const u32 blk = blockIdx.x - ncold, nblk = gridDim.x - ncold;
+  if (PART == 0 && !COLDT && p.dense && p.vshort && a.combine) {
+    // both dense paths: the first nstream workgroups take their share of the long AND of the short rows
+    if (blk < nstream) bfs_dense_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, blk, nstream, p.level, p.cold);
+    return;
+  }
+  const bool il = PART == 0 && a.interleave && nblk == 2u * nstream;
+  const bool long_part = PART == 2 || (PART == 0 && (il ? !(blk & 1u) : blk < nstream));
   if (long_part) {
-    const u32 bi = il ? blockIdx.x >> 1 : blockIdx.x;
+    const u32 bi = il ? blk >> 1 : blk;
     if (!COLDT && p.dense) bfs_dense_body<1024, BFS_DENSE_HOTW>(a, p.slot, bi, nstream, p.level, p.cold);
     else bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, COLDT, false, true>(a, p.slot, bi, nstream, p.level);
-  } else if (!il && (PART == 0 || PART == 2) && blockIdx.x < nstream + ncold) {
-    if (p.cold) bfs_cold_body<1024>(a, p.slot, blockIdx.x - nstream, p.level);
-  } else if (PART != 2) {
-    const u32 first = PART == 0 ? nstream + ncold : 0u;
-    const u32 bi = il ? blockIdx.x >> 1 : blockIdx.x - first;
-    const u32 nb = il ? nstream : gridDim.x - first;
+  } else {
+    const u32 first = PART == 0 ? nstream : 0u;
+    const u32 bi = il ? blk >> 1 : blk - first;
+    const u32 nb = il ? nstream : nblk - first;
     if (!COLDT && p.vshort) bfs_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, bi, nb, p.level);
     else bfs_wave_body<1024, BFS_WAVE_HOTW, COLDT, false>(a, p.slot, bi, nb, p.level);
   }
@@ -336,7 +340,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   // cold-edge lists (bfs_fused_cold.hpp): with the unit blocks they were cut from, the prefix they were cut behind, and a
   // queue build that knows their bitmaps
   const bool cold = units && a.dense_div && layout->cold_dst && layout->cold_slices > 0 && layout->cold_hot_n == (unsigned)(BFS_DENSE_HOTW * 32) &&
-                    layout->cold_long_min == st.long_min && build2_ok && !opt.build_list && !opt.interleave && opt.cold != 0 &&
+                    layout->cold_long_min == st.long_min && build2_ok && !opt.build_list && opt.cold != 0 &&
                     !opt.dense_diag && !(opt.biglds && st.time_kernels == 1);
   a.cold_owner = cold ? layout->cold_owner : nullptr;
   a.cold_dst = cold ? layout->cold_dst : nullptr;

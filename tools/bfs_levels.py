@@ -12,7 +12,7 @@ ctx = mini_amd.Context(0, torch.cuda.current_stream().cuda_stream)
 g = rmat.rmat_csr(ctx, a.scale, 16, seed=a.scale)
 graph = mini_amd.Graph.from_device(ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"])
 if a.layout:
-    graph.attach_layout(*rmat.degree_order(g["row_offsets"], g["col_indices"]))
+    graph.build_layout()          # the library's own layout (unit blocks, degree classes, cold-edge lists): what bench.py runs
 ro = g["row_offsets"].cpu().numpy()
 srcs = rmat.pick_sources(ro, a.runs + 1, a.scale)
 bfs = mini_amd.BfsProblem(graph, srcs[0])
