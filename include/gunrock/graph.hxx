@@ -85,9 +85,11 @@ struct graph_device_t {
   // (owner, dst) pairs grouped by slice of the id range; built with the layout when they are a small share of the entries.
   mem_t<int> d_cold_owner;
   mem_t<int> d_cold_dst;
-  long long cold_pairs = 0;
+  mem_t<int> d_colds_owner;           // the same for the SHORT rows' entries (the vertex-by-vertex body's cold entries)
+  mem_t<int> d_colds_dst;
+  long long cold_pairs = 0, colds_pairs = 0;
   int cold_slices = 0;
-  unsigned cold_lo[16] = {0}, cold_off[17] = {0}, cold_wgs[17] = {0};
+  unsigned cold_lo[16] = {0}, cold_off[17] = {0}, colds_off[17] = {0}, cold_wgs[17] = {0};
   unsigned cold_hot_n = 0;
   int cold_long_min = 0;
 

@@ -150,6 +150,9 @@ struct bfs_fused_args_t {
   u32 cold_lo[16];         // first vertex of slice i (a multiple of 1024; the slice is BFS_COLD_WORDS * 32 vertices)
   u32 cold_off[17];        // its pairs: [cold_off[i], cold_off[i + 1])
   u32 cold_wgs[17];        // the cold workgroups [cold_wgs[i], cold_wgs[i + 1]) of a push launch take slice i
+  const int* colds_owner;  // the same lists for the SHORT rows (the entries the vertex-by-vertex body would mark); NULL: none
+  const int* colds_dst;
+  u32 colds_off[17];
   u32* cold_flush;         // BFS_COLD_WGS bitmaps of BFS_COLD_WORDS words: what cold workgroup k discovered in its slice
 };
 

@@ -26,7 +26,7 @@ constexpr size_t bfs_cold_lds_bytes() { return (size_t)BFS_COLD_WORDS * 4 + 128;
 
 // cold workgroup `cw` (0 .. BFS_COLD_WGS - 1) of slot `slot`; all threads
 template <int NT>
-__device__ __forceinline__ void bfs_cold_body(const bfs_fused_args_t& a, int slot, u32 cw, int stat_level) {
+__device__ __forceinline__ void bfs_cold_body(const bfs_fused_args_t& a, int slot, u32 cw, int stat_level, bool do_long, bool do_short) {
   constexpr int HOTW = BFS_COLD_WORDS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u32* const hot = (u32*)smem + 4;
@@ -43,38 +43,42 @@ __device__ __forceinline__ void bfs_cold_body(const bfs_fused_args_t& a, int slo
   if (threadIdx.x == 0) { hot[-1] = 0xFFFFFFFFu; hot[HOTW] = 0xFFFFFFFFu; s_int[0] = 0; s_int[1] = 0; }
   __syncthreads();
 
-  const u32 p0 = a.cold_off[sl], p1 = a.cold_off[sl + 1];
-  const u32 chunk = (((p1 - p0) + parts - 1u) / parts + 255u) & ~255u;
-  const u32 b = p0 + part * chunk;
-  const u32 e = b + chunk < p1 ? b + chunk : p1;
-  const int* __restrict__ owner = a.cold_owner;
-  const int* __restrict__ dst = a.cold_dst;
   const u32* __restrict__ fbits = a.frontier_bits;
   int marks = 0;
   constexpr int K = 4;                               // pairs per thread and round: 8 loads in flight, then 4 gathers
-  for (u32 r0 = b; r0 < e; r0 += (u32)NT * K) {
-    const u32 base = r0 + threadIdx.x;
-    u32 ow[K], dd[K];
+  // the long rows' list of the slice, then the short rows' (whichever the slot's bodies leave to this pass)
+  for (int which = 0; which < 2; ++which) {
+    if (which == 0 ? !do_long : !do_short) continue;
+    const int* __restrict__ owner = which == 0 ? a.cold_owner : a.colds_owner;
+    const int* __restrict__ dst = which == 0 ? a.cold_dst : a.colds_dst;
+    const u32 p0 = which == 0 ? a.cold_off[sl] : a.colds_off[sl], p1 = which == 0 ? a.cold_off[sl + 1] : a.colds_off[sl + 1];
+    const u32 chunk = (((p1 - p0) + parts - 1u) / parts + 255u) & ~255u;
+    const u32 b = p0 + part * chunk < p1 ? p0 + part * chunk : p1;
+    const u32 e = b + chunk < p1 ? b + chunk : p1;
+    for (u32 r0 = b; r0 < e; r0 += (u32)NT * K) {
+      const u32 base = r0 + threadIdx.x;
+      u32 ow[K], dd[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const u32 i = base + (u32)k * NT;
-      const bool in = i < e;
-      const u32 j = in ? i : p1;                     // (p1 .. p1 + 255: the next slice's pairs or the padding: readable, ignored)
-      ow[k] = (u32)owner[j];
-      dd[k] = in ? (u32)dst[j] : 0xFFFFFFFFu;
-      if (!in) ow[k] = 0xFFFFFFFFu;
-    }
-    u32 fw[K];
+      for (int k = 0; k < K; ++k) {
+        const u32 i = base + (u32)k * NT;
+        const bool in = i < e;
+        const u32 j = in ? i : p1;                   // (p1 .. p1 + 255: the next slice's pairs or the padding: readable, ignored)
+        ow[k] = (u32)owner[j];
+        dd[k] = in ? (u32)dst[j] : 0xFFFFFFFFu;
+        if (!in) ow[k] = 0xFFFFFFFFu;
+      }
+      u32 fw[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) fw[k] = fbits[ow[k] != 0xFFFFFFFFu ? ow[k] >> 5 : 0u];
+      for (int k = 0; k < K; ++k) fw[k] = fbits[ow[k] != 0xFFFFFFFFu ? ow[k] >> 5 : 0u];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const bool act = ow[k] != 0xFFFFFFFFu && ((fw[k] >> (ow[k] & 31u)) & 1u);
-      if (act) {
-        const u32 r = dd[k] - lo;                    // < HOTW * 32 by construction
-        const u32 bit = 1u << (r & 31u);
-        if (r < (u32)HOTW * 32u && !(hot[r >> 5] & bit)) {
-          if (!(atomicOr(&hot[r >> 5], bit) & bit)) ++marks;
+      for (int k = 0; k < K; ++k) {
+        const bool act = ow[k] != 0xFFFFFFFFu && ((fw[k] >> (ow[k] & 31u)) & 1u);
+        if (act) {
+          const u32 r = dd[k] - lo;                  // < HOTW * 32 by construction
+          const u32 bit = 1u << (r & 31u);
+          if (r < (u32)HOTW * 32u && !(hot[r >> 5] & bit)) {
+            if (!(atomicOr(&hot[r >> 5], bit) & bit)) ++marks;
+          }
         }
       }
     }

@@ -37,8 +37,10 @@ struct bfs_layout_t {
   // cold-edge lists of the long rows (bfs_fused_cold.hpp): pairs grouped by slice; hot_n / long_min they were cut for
   const int* cold_owner = nullptr;
   const int* cold_dst = nullptr;
+  const int* colds_owner = nullptr;   // the short rows' cold entries (optional)
+  const int* colds_dst = nullptr;
   int cold_slices = 0;
-  unsigned cold_lo[16] = {0}, cold_off[17] = {0}, cold_wgs[17] = {0};
+  unsigned cold_lo[16] = {0}, cold_off[17] = {0}, colds_off[17] = {0}, cold_wgs[17] = {0};
   unsigned cold_hot_n = 0;
   int cold_long_min = 0;
 };
@@ -61,7 +63,7 @@ constexpr size_t bfs_push_lds_bytes() {
 // what a slot's push launch does, derived by every workgroup from the same stable inputs
 struct bfs_slot_plan_t {
   int slot, level;
-  bool empty, chained, dense, vshort, cold;
+  bool empty, chained, dense, vshort, cold, colds;
 };
 __device__ __forceinline__ bfs_slot_plan_t bfs_slot_plan(const bfs_fused_args_t& a, int arg) {
   const bfs_ctrl_t* const c = a.ctrl;
@@ -77,6 +79,7 @@ __device__ __forceinline__ bfs_slot_plan_t bfs_slot_plan(const bfs_fused_args_t&
   // read the unit blocks by its own size (a sweep of all pairs does not pay for a sparse frontier that was only forced
   // onto the unit blocks by a lazy build: the unit-block body marks the few cold entries it meets)
   p.cold = p.dense && a.cold_dst != nullptr;
+  p.colds = p.cold && p.vshort && a.colds_dst != nullptr;   // (with them, the short rows' cold entries of a level that walks those vertex by vertex)
   if (!p.empty && c->lazy_slot == p.slot) {       // the build before this slot wrote no queues (bfs_build_is_lazy)
     p.chained = false;
     p.dense = p.vshort = true;
@@ -97,7 +100,7 @@ __device__ __forceinline__ void bfs_slot_open(const bfs_fused_args_t& a, const b
   c->slot_level[(p.slot + 1) & 3] = p.level + 1;
   c->skip_build[p.slot & 3] = 0;
   if (p.dense) c->dense_slots += 1;
-  if (p.cold) { c->cold_slot = p.slot; c->cold_slots += 1; }
+  if (p.cold || p.colds) { c->cold_slot = p.slot; c->cold_slots += 1; }
   if (p.vshort) c->vshort_slots += 1;
 }
 
@@ -120,17 +123,17 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
   // Which part this workgroup takes: (graphs with cold-edge lists) BFS_COLD_WGS workgroups of the cold pass, then nstream
   // workgroups for the long rows, the others the short rows.
   // (interleave: even / odd instead, so that the two parts share every CU -- an experiment that lost, see bfs_run_opts_t)
-  const u32 ncold = (!COLDT && a.cold_dst && (PART == 0 || PART == 2)) ? (u32)BFS_COLD_WGS : 0u;
+  const u32 ncold = (!COLDT && a.cold_dst && (PART == 0 || PART == 2)) ? (u32)BFS_COLD_WGS : 0u;   // (PART 2: with the long rows)
   // grid: [cold pass][long rows][short rows] -- the cold workgroups first: they are few and short, and the launch does
   // not end on them
   if (blockIdx.x < ncold) {
-    if (p.cold) bfs_cold_body<1024>(a, p.slot, blockIdx.x, p.level);
+    if (p.cold || p.colds) bfs_cold_body<1024>(a, p.slot, blockIdx.x, p.level, p.cold, p.colds);
     return;
   }
   const u32 blk = blockIdx.x - ncold, nblk = gridDim.x - ncold;
   if (PART == 0 && !COLDT && p.dense && p.vshort && a.combine) {
     // both dense paths: the first nstream workgroups take their share of the long AND of the short rows
-    if (blk < nstream) bfs_dense_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, blk, nstream, p.level, p.cold);
+    if (blk < nstream) bfs_dense_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, blk, nstream, p.level, p.cold, p.colds);
     return;
   }
   const bool il = PART == 0 && a.interleave && nblk == 2u * nstream;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
     const u32 first = PART == 0 ? nstream : 0u;
     const u32 bi = il ? blk >> 1 : blk - first;
     const u32 nb = il ? nstream : nblk - first;
-    if (!COLDT && p.vshort) bfs_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, bi, nb, p.level);
+    if (!COLDT && p.vshort) bfs_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, bi, nb, p.level, p.colds);
     else bfs_wave_body<1024, BFS_WAVE_HOTW, COLDT, false>(a, p.slot, bi, nb, p.level);
   }
 }
@@ -204,7 +207,8 @@ struct bfs_run_opts_t {
   int dense = -1;          // MGX_BFS_DENSE: 0 never, N > 0 dense_div = N
   int vshort = -1;         // MGX_BFS_VSHORT: 0 never, N > 0 vshort_div = N
   long long chain = -1;    // MGX_BFS_CHAIN_MAX_EDGES: 0 never (default BFS_CHAIN_CAP)
-  int cold = 1;            // MGX_BFS_COLD=0: the unit-block body marks its cold entries itself (no cold-edge pass)
+  int cold = 2;            // MGX_BFS_COLD: 0 the unit-block body marks its cold entries itself (no cold-edge pass), 2 the long rows' lists
+                           // (default), 1 also the short rows' (built with MGX_BFS_COLD_LISTS=2; measured equal on RMAT-22: 0.3712 / 0.3708 ms)
   int lazy = -1;           // MGX_BFS_LAZY: 0 the queue build always writes the queues, N: not behind a push that stored >= n / N marks
   long long defer = -1;    // MGX_BFS_DEFER: 0 never defer hot marks, N: flush a bitmap above N deferred marks per workgroup
   int combine = 0;         // MGX_BFS_COMBINE=1: a level that takes both dense paths runs them in the SAME workgroups (one copy of the
@@ -347,6 +351,11 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.cold_slices = cold ? layout->cold_slices : 0;
   for (int i = 0; i < 16; ++i) a.cold_lo[i] = cold ? layout->cold_lo[i] : 0u;
   for (int i = 0; i < 17; ++i) { a.cold_off[i] = cold ? layout->cold_off[i] : 0u; a.cold_wgs[i] = cold ? layout->cold_wgs[i] : 0u; }
+  // ... and of the short rows, for the levels that walk them vertex by vertex
+  const bool colds = cold && a.vs_div && layout->colds_dst && opt.cold != 2;
+  a.colds_owner = colds ? layout->colds_owner : nullptr;
+  a.colds_dst = colds ? layout->colds_dst : nullptr;
+  for (int i = 0; i < 17; ++i) a.colds_off[i] = colds ? layout->colds_off[i] : 0u;
   if (cold && !st.cold_flush.size()) st.cold_flush = mem_t<u32>((size_t)BFS_COLD_WGS * BFS_COLD_WORDS, ctx);
   a.cold_flush = cold ? st.cold_flush.data() : nullptr;
   // lazy queues (bfs_build_is_lazy): only k_bfs_build2 knows them, and only when both queue-less bodies are available

@@ -141,10 +141,11 @@ __device__ __forceinline__ void bfs_vshort_work(const bfs_fused_args_t& a, u32* 
 }
 
 template <int NT, int HOTW>
-__device__ __forceinline__ void bfs_vshort_body(const bfs_fused_args_t& a, int slot, u32 block, u32 nblocks, int stat_level) {
+__device__ __forceinline__ void bfs_vshort_body(const bfs_fused_args_t& a, int slot, u32 block, u32 nblocks, int stat_level,
+                                                bool cold = false) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* s_int;
-  u32* const hot = bfs_hot_setup<NT, HOTW>(a, smem, &s_int);
+  u32* const hot = bfs_hot_setup<NT, HOTW>(a, smem, &s_int, cold ? 0xFFFFFFFFu : 0u);    // cold: the cold-edge pass has those entries
   const int lane = lane_id();
   bfs_ctrl_t* const c = a.ctrl;
   const u32 hot_n = ((u32)a.n < (u32)(HOTW * 32)) ? (u32)a.n : (u32)(HOTW * 32);
@@ -161,7 +162,7 @@ __device__ __forceinline__ void bfs_vshort_body(const bfs_fused_args_t& a, int s
 // short rows are tested.
 template <int NT, int HOTW>
 __device__ __forceinline__ void bfs_dense_vshort_body(const bfs_fused_args_t& a, int slot, u32 block, u32 nblocks, int stat_level,
-                                                      bool cold = false) {
+                                                      bool cold = false, bool colds = false) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* s_int;
   u32* const hot = bfs_hot_setup<NT, HOTW>(a, smem, &s_int, cold ? 0xFFFFFFFFu : 0u);
@@ -171,9 +172,9 @@ __device__ __forceinline__ void bfs_dense_vshort_body(const bfs_fused_args_t& a,
   const u32 defer_n = bfs_defer_limit(a, hot_n);
   int marks = 0;
   bfs_dense_work<NT, HOTW, 1>(a, hot, hot_n, defer_n, block, nblocks, marks);
-  if (cold) {                          // the short rows' cold entries are still marked here: back to "unvisited" behind the prefix
+  if (cold != colds) {                 // the sentinel behind the prefix as the short rows need it
     __syncthreads();
-    if (threadIdx.x == 0) hot[HOTW] = 0u;
+    if (threadIdx.x == 0) hot[HOTW] = colds ? 0xFFFFFFFFu : 0u;
     __syncthreads();
   }
   bfs_vshort_work<NT, HOTW>(a, hot, hot_n, defer_n, block, nblocks, marks);

@@ -315,7 +315,8 @@ int mgx_graph_attach_layout(mgx_graph_t g, const int* d_row_offsets, const int* 
   G.d_old_of_new = mem_t<int>::borrow((int*)d_old_of_new, (size_t)G.num_nodes);
   G.has_layout = true;
   G.vs_edges = 0; G.vs_dummy = 0; G.vs_long_min = 0;      // (borrowed arrays: no padding behind them, sortedness not checked)
-  G.d_cold_owner = mem_t<int>(); G.d_cold_dst = mem_t<int>(); G.cold_pairs = 0; G.cold_slices = 0;
+  G.d_cold_owner = mem_t<int>(); G.d_cold_dst = mem_t<int>(); G.d_colds_owner = mem_t<int>(); G.d_colds_dst = mem_t<int>();
+  G.cold_pairs = G.colds_pairs = 0; G.cold_slices = 0;
   use_device(g->c);
   g->c->ctx->synchronize();
   build_unit_blocks(g);
@@ -355,15 +356,18 @@ static void build_unit_blocks(mgx_graph_s* g) {
   G.d_ub_col = mem_t<int>::adopt(ucol, ((size_t)units_pad << 6) + 4);
   G.ub_units = units; G.ub_units_pad = units_pad; G.ub_min_degree = long_min;
 }
-extern "C" int mgx_cold_build_device(const int* ro, const int* ci, int n, int rows, int min_deg, unsigned hot_n, unsigned slice_n,
+extern "C" int mgx_cold_build_device(const int* ro, const int* ci, int n, int row0, int rows, int min_deg, unsigned hot_n, unsigned slice_n,
                                      int slices, int** owner, int** dst, long long* pairs, int* slice_off, hipStream_t stream);
-// Cold-edge lists of the layout's long rows (mgx/bfs_fused_cold.hpp); MGX_BFS_COLD_LISTS=0 skips them.  Needs the unit
-// blocks and the degree classes (a degree-sorted layout: the long rows are [0, vs_v[0])); built only when the cold entries
-// are a small share of the long rows' entries (a skewed graph under the hub-first order) and few slices hold any.
+// Cold-edge lists of the layout (mgx/bfs_fused_cold.hpp); MGX_BFS_COLD_LISTS=0 skips them.  Needs the unit blocks and the
+// degree classes (a degree-sorted layout: the long rows are [0, vs_v[0]), the short ones [vs_v[0], vs_v[3])); built only
+// when the cold entries are a small share of the long rows' entries (a skewed graph under the hub-first order) and few
+// slices hold any.  One list for the long rows, one for the short rows, the same slices.
 static void build_cold_lists(mgx_graph_s* g) {
   graph_device_t& G = *g->g;
-  G.d_cold_owner = mem_t<int>(); G.d_cold_dst = mem_t<int>(); G.cold_pairs = 0; G.cold_slices = 0; G.cold_hot_n = 0; G.cold_long_min = 0;
-  if (const char* e = getenv("MGX_BFS_COLD_LISTS")) if (atoi(e) == 0) return;
+  G.d_cold_owner = mem_t<int>(); G.d_cold_dst = mem_t<int>(); G.d_colds_owner = mem_t<int>(); G.d_colds_dst = mem_t<int>();
+  G.cold_pairs = G.colds_pairs = 0; G.cold_slices = 0; G.cold_hot_n = 0; G.cold_long_min = 0;
+  bool with_short = false;                                         // (MGX_BFS_COLD_LISTS=2: also the short rows' list -- measured equal)
+  if (const char* e = getenv("MGX_BFS_COLD_LISTS")) { if (atoi(e) == 0) return; with_short = atoi(e) == 2; }
   if (G.ub_units <= 0 || G.vs_long_min <= 0 || G.vs_long_min != G.ub_min_degree || G.vs_v[0] == 0) return;
   const unsigned hot_n = (unsigned)mgx::BFS_COLD_WORDS * 32u, slice_n = hot_n;
   const unsigned n = (unsigned)G.num_nodes;
@@ -371,41 +375,59 @@ static void build_cold_lists(mgx_graph_s* g) {
   const long long slices_ll = ((long long)n - hot_n + slice_n - 1) / slice_n;
   if (slices_ll > 64) return;
   const int slices = (int)slices_ll;
-  std::vector<int> off((size_t)slices + 1, 0);
+  std::vector<int> off_l((size_t)slices + 1, 0), off_s((size_t)slices + 1, 0);
   int *owner = nullptr, *dst = nullptr;
   long long pairs = 0;
-  const int rc = mgx_cold_build_device(G.d_layout_row_offsets.data(), G.d_layout_col_indices.data(), (int)n, (int)G.vs_v[0],
-                                       G.vs_long_min, hot_n, slice_n, slices, &owner, &dst, &pairs, off.data(), g->c->ctx->stream());
+  int rc = mgx_cold_build_device(G.d_layout_row_offsets.data(), G.d_layout_col_indices.data(), (int)n, 0, (int)G.vs_v[0],
+                                 G.vs_long_min, hot_n, slice_n, slices, &owner, &dst, &pairs, off_l.data(), g->c->ctx->stream());
   if (rc != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("cold-edge lists: ") + hipGetErrorString((hipError_t)rc));
   if (pairs <= 0) return;
   mem_t<int> d_owner = mem_t<int>::adopt(owner, (size_t)pairs + 256), d_dst = mem_t<int>::adopt(dst, (size_t)pairs + 256);
-  // the non-empty slices; give up when there are too many of them or when the pairs are not a small share of the entries
-  int used = 0;
-  for (int k = 0; k < slices; ++k) if (off[k + 1] > off[k]) ++used;
   const long long long_entries = (long long)G.ub_units * 64;       // (padded: an upper bound of the long rows' entries)
-  if (used > mgx::BFS_COLD_MAX_SLICES || pairs * 4 > long_entries) return;
+  if (pairs * 4 > long_entries) return;
+  // the short rows' cold entries
+  int *owner_s = nullptr, *dst_s = nullptr;
+  long long pairs_s = 0;
+  mem_t<int> d_owner_s, d_dst_s;
+  if (with_short && G.vs_v[3] > G.vs_v[0]) {
+    rc = mgx_cold_build_device(G.d_layout_row_offsets.data(), G.d_layout_col_indices.data(), (int)n, (int)G.vs_v[0],
+                               (int)(G.vs_v[3] - G.vs_v[0]), 1, hot_n, slice_n, slices, &owner_s, &dst_s, &pairs_s, off_s.data(),
+                               g->c->ctx->stream());
+    if (rc != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("cold-edge lists: ") + hipGetErrorString((hipError_t)rc));
+    if (pairs_s > 0) {
+      d_owner_s = mem_t<int>::adopt(owner_s, (size_t)pairs_s + 256); d_dst_s = mem_t<int>::adopt(dst_s, (size_t)pairs_s + 256);
+      if (pairs_s * 2 > (long long)G.vs_edges) { d_owner_s = mem_t<int>(); d_dst_s = mem_t<int>(); pairs_s = 0; }    // (mostly cold: leave them to the marks)
+    }
+  }
+  if (pairs_s <= 0) std::fill(off_s.begin(), off_s.end(), 0);
+  // the slices that hold pairs of either list; give up when there are too many of them
+  int used = 0;
+  for (int k = 0; k < slices; ++k) if (off_l[k + 1] > off_l[k] || off_s[k + 1] > off_s[k]) ++used;
+  if (used > mgx::BFS_COLD_MAX_SLICES) return;
   int q = 0;
   for (int k = 0; k < slices; ++k) {
-    if (off[k + 1] == off[k]) continue;
+    if (!(off_l[k + 1] > off_l[k] || off_s[k + 1] > off_s[k])) continue;
     G.cold_lo[q] = hot_n + (unsigned)k * slice_n;
-    G.cold_off[q] = (unsigned)off[k];
-    G.cold_off[q + 1] = (unsigned)off[k + 1];
+    G.cold_off[q] = (unsigned)off_l[k]; G.cold_off[q + 1] = (unsigned)off_l[k + 1];
+    G.colds_off[q] = (unsigned)off_s[k]; G.colds_off[q + 1] = (unsigned)off_s[k + 1];
     ++q;
   }
   // workgroups per slice: in proportion to its pairs, at least one each
+  const long long all = pairs + pairs_s;
   unsigned left = (unsigned)mgx::BFS_COLD_WGS - (unsigned)used, acc = 0;
   G.cold_wgs[0] = 0;
   for (int i = 0; i < used; ++i) {
-    const long long cnt = (long long)G.cold_off[i + 1] - (long long)G.cold_off[i];
-    unsigned extra = (unsigned)((cnt * (long long)((unsigned)mgx::BFS_COLD_WGS - (unsigned)used)) / pairs);
+    const long long cnt = ((long long)G.cold_off[i + 1] - (long long)G.cold_off[i]) + ((long long)G.colds_off[i + 1] - (long long)G.colds_off[i]);
+    unsigned extra = (unsigned)((cnt * (long long)((unsigned)mgx::BFS_COLD_WGS - (unsigned)used)) / all);
     if (extra > left) extra = left;
     left -= extra;
     acc += 1u + extra;
     G.cold_wgs[i + 1] = acc;
   }
-  for (int i = used + 1; i <= 16; ++i) { G.cold_wgs[i] = acc; G.cold_off[i] = G.cold_off[used]; }
+  for (int i = used + 1; i <= 16; ++i) { G.cold_wgs[i] = acc; G.cold_off[i] = G.cold_off[used]; G.colds_off[i] = G.colds_off[used]; }
   G.d_cold_owner = std::move(d_owner); G.d_cold_dst = std::move(d_dst);
-  G.cold_pairs = pairs; G.cold_slices = used; G.cold_hot_n = hot_n; G.cold_long_min = G.vs_long_min;
+  G.d_colds_owner = std::move(d_owner_s); G.d_colds_dst = std::move(d_dst_s);
+  G.cold_pairs = pairs; G.colds_pairs = pairs_s; G.cold_slices = used; G.cold_hot_n = hot_n; G.cold_long_min = G.vs_long_min;
 }
 int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
   MGX_TRY

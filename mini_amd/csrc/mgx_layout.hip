@@ -206,11 +206,11 @@ extern "C" int mgx_units_build_device(const int* ro, const int* ci, int n, int m
 namespace {
 
 // cnt[k * rows + r] = entries of row r in slice k (0 for rows of fewer than min_deg entries)
-__global__ void k_cold_counts(const int* __restrict__ ro, const int* __restrict__ ci, int rows, int min_deg, unsigned hot_n,
+__global__ void k_cold_counts(const int* __restrict__ ro, const int* __restrict__ ci, int row0, int rows, int min_deg, unsigned hot_n,
                               unsigned slice_n, int slices, int* __restrict__ cnt) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
-  const int r0 = ro[r], r1 = ro[r + 1];
+  const int r0 = ro[row0 + r], r1 = ro[row0 + r + 1];
   const bool is_long = r1 - r0 >= min_deg;
   int prev = r1;
   if (is_long) {                                   // first entry >= hot_n
@@ -232,7 +232,7 @@ __global__ void k_cold_counts(const int* __restrict__ ro, const int* __restrict_
 }
 
 // one wave per row: its cold entries to their places (off[k * rows + r] = first pair of (slice k, row r))
-__global__ void k_cold_fill(const int* __restrict__ ro, const int* __restrict__ ci, int rows, const int* __restrict__ cnt,
+__global__ void k_cold_fill(const int* __restrict__ ro, const int* __restrict__ ci, int row0, int rows, const int* __restrict__ cnt,
                             const int* __restrict__ off, int slices, int* __restrict__ owner, int* __restrict__ dst) {
   const int lane = threadIdx.x & 63;
   const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -241,10 +241,10 @@ __global__ void k_cold_fill(const int* __restrict__ ro, const int* __restrict__ 
     int total = 0;
     for (int k = 0; k < slices; ++k) total += cnt[(long long)k * rows + r];
     if (total == 0) continue;
-    int src = ro[r + 1] - total;                   // the cold entries are the row's tail
+    int src = ro[row0 + r + 1] - total;            // the cold entries are the row's tail
     for (int k = 0; k < slices; ++k) {
       const int c = cnt[(long long)k * rows + r], o = off[(long long)k * rows + r];
-      for (int i = lane; i < c; i += 64) { owner[o + i] = (int)r; dst[o + i] = ci[src + i]; }
+      for (int i = lane; i < c; i += 64) { owner[o + i] = row0 + (int)r; dst[o + i] = ci[src + i]; }
       src += c;
     }
   }
@@ -257,9 +257,9 @@ __global__ void k_cold_pad(int pairs, int pad, int n, int* __restrict__ owner, i
 
 }  // namespace
 
-// rows: the long rows are [0, rows) (a degree-sorted CSR).  slice_off: slices + 1 ints (host).  Allocates *owner / *dst
+// The rows [row0, row0 + rows) of at least min_deg entries.  slice_off: slices + 1 ints (host).  Allocates *owner / *dst
 // (pairs + 256 ints each: the padding holds owner = n, dst = -1) with hipMalloc; nothing is allocated when there are no pairs.
-extern "C" int mgx_cold_build_device(const int* ro, const int* ci, int n, int rows, int min_deg, unsigned hot_n, unsigned slice_n,
+extern "C" int mgx_cold_build_device(const int* ro, const int* ci, int n, int row0, int rows, int min_deg, unsigned hot_n, unsigned slice_n,
                                      int slices, int** owner, int** dst, long long* pairs, int* slice_off, hipStream_t stream) {
   *owner = nullptr; *dst = nullptr; *pairs = 0;
   for (int k = 0; k <= slices; ++k) slice_off[k] = 0;
@@ -267,7 +267,7 @@ extern "C" int mgx_cold_build_device(const int* ro, const int* ci, int n, int ro
   const size_t cells = (size_t)rows * (size_t)slices;
   tmp_t cnt, off, st;
   LAY_TRY(cnt.alloc(cells * 4)); LAY_TRY(off.alloc(cells * 4));
-  hipLaunchKernelGGL(k_cold_counts, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, ro, ci, rows, min_deg, hot_n,
+  hipLaunchKernelGGL(k_cold_counts, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, ro, ci, row0, rows, min_deg, hot_n,
                      slice_n, slices, cnt.as<int>());
   size_t sb = 0;
   LAY_TRY(rocprim::exclusive_scan(nullptr, sb, cnt.as<int>(), off.as<int>(), 0, cells, rocprim::plus<int>(), stream));
@@ -285,7 +285,7 @@ extern "C" int mgx_cold_build_device(const int* ro, const int* ci, int n, int ro
   LAY_TRY(hipMalloc((void**)owner, ((size_t)E + 256) * 4));
   hipError_t e = hipMalloc((void**)dst, ((size_t)E + 256) * 4);
   if (e != hipSuccess) { (void)hipFree(*owner); *owner = nullptr; return (int)e; }
-  hipLaunchKernelGGL(k_cold_fill, dim3(2048), dim3(256), 0, stream, ro, ci, rows, cnt.as<int>(), off.as<int>(), slices, *owner, *dst);
+  hipLaunchKernelGGL(k_cold_fill, dim3(2048), dim3(256), 0, stream, ro, ci, row0, rows, cnt.as<int>(), off.as<int>(), slices, *owner, *dst);
   hipLaunchKernelGGL(k_cold_pad, dim3(1), dim3(256), 0, stream, (int)E, 256, n, *owner, *dst);
   e = hipStreamSynchronize(stream);
   if (e != hipSuccess) { (void)hipFree(*owner); (void)hipFree(*dst); *owner = nullptr; *dst = nullptr; return (int)e; }
