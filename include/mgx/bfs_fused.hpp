@@ -668,7 +668,10 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
   const int new_label = level + 1;
   const u32 long_min = a.long_min > 0 ? (u32)a.long_min : 0xFFFFFFFFu;
 
-  // deferred hot marks of the slot (bfs_hot_epilogue): the flush buffers' bits for this workgroup's runs
+  // deferred hot marks of the slot (bfs_hot_epilogue): the flush buffers' bits for this workgroup's runs.  A run is 128
+  // bytes of every buffer: 16-byte loads, eight lanes per buffer, eight buffers per wave instruction, the F buffers
+  // spread over the workgroup's waves -- all loads of a wave in flight at once (2-byte loads, one buffer per instruction:
+  // the OR of a level that deferred in 512 workgroups took 10 us of its build).
   u32 flushed16 = 0;
   if (a.flush_buf) {
     const u32 F = c->flush_count[slot & 1];
@@ -676,15 +679,23 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
       for (int hr = 0; hr < NW; ++hr) {
         const long long run = (long long)blockIdx.x + (long long)hr * gridDim.x;
         if (run >= BFS_FLUSH_RUNS) break;
-        const unsigned short* const col = (const unsigned short*)a.flush_buf + run * 64 + lane;
-        u32 acc = 0;
-#pragma unroll 16
-        for (u32 k = (u32)wave; k < F; k += NW) acc |= col[(size_t)k * (BFS_FLUSH_WORDS * 2)];
-        s_or[wave][lane] = acc;
+        const uint4* const base = (const uint4*)(a.flush_buf + (size_t)run * 32) + (lane & 7);
+        uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll 8
+        for (u32 k = (u32)wave * 8u + ((u32)lane >> 3); k < F; k += 8u * NW) {
+          const uint4 v = base[(size_t)k * (BFS_FLUSH_WORDS / 4)];
+          acc.x |= v.x; acc.y |= v.y; acc.z |= v.z; acc.w |= v.w;
+        }
+#pragma unroll
+        for (int sh = 8; sh < 64; sh <<= 1) {
+          acc.x |= __shfl_xor(acc.x, sh, WAVE); acc.y |= __shfl_xor(acc.y, sh, WAVE);
+          acc.z |= __shfl_xor(acc.z, sh, WAVE); acc.w |= __shfl_xor(acc.w, sh, WAVE);
+        }
+        if (lane < 8) *(uint4*)(&s_or[wave][lane * 4]) = acc;
         __syncthreads();
         if (my_run == hr) {
 #pragma unroll
-          for (int w = 0; w < NW; ++w) flushed16 |= s_or[w][my_group];
+          for (int w = 0; w < NW; ++w) flushed16 |= (u32)((const unsigned short*)&s_or[w][0])[my_group];
         }
         __syncthreads();
       }

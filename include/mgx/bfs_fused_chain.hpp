@@ -42,7 +42,10 @@ __device__ __forceinline__ bool bfs_level_is_chained(const bfs_fused_args_t& a, 
 }
 
 // Runs level `level` of slot `slot` and the small levels behind it.  Whole workgroup (NT threads).
-template <int NT>
+// INPLACE: the chain is a launch of its own in FRONT of the slot (k_bfs_seed_chain, behind the init kernel): it takes the
+// slot's queues and leaves the first level that is not small in the SAME slot's queues and ring entry -- the slot's push
+// launch then opens that level; nothing is skipped and no slot is used up.
+template <int NT, bool INPLACE = false>
 __device__ __forceinline__ void bfs_chain_body(const bfs_fused_args_t& a, int slot, int level) {
   constexpr int NW = NT / WAVE;
   constexpr int CAP = BFS_CHAIN_CAP;
@@ -106,7 +109,7 @@ __device__ __forceinline__ void bfs_chain_body(const bfs_fused_args_t& a, int sl
       c->sum_frontier += (u64)nf;
       c->push_levels += 1;
       c->small_levels += 1;
-      if (chained == 0) c->slots += 1;
+      if (chained == 0 && !INPLACE) c->slots += 1;
       s_i[0] = 0;
     }
     __syncthreads();
@@ -209,11 +212,12 @@ __device__ __forceinline__ void bfs_chain_body(const bfs_fused_args_t& a, int sl
       continue;
     }
 
-    // ---- stage out: the next level's list -> the global queues of slot + 1 ----------------------------------------
-    u32* __restrict__ const out_row_s = a.fr_row[(slot + 1) & 1];
-    u32* __restrict__ const out_off_s = a.fr_off[(slot + 1) & 1];
-    u32* __restrict__ const out_row_l = a.lq_row[(slot + 1) & 1];
-    u32* __restrict__ const out_off_l = a.lq_off[(slot + 1) & 1];
+    // ---- stage out: the next level's list -> the global queues of slot + 1 (in place: of this slot) ----------------------------------------
+    const int out = INPLACE ? slot : slot + 1;      // (in place: the list is in LDS, the queues it came from are dead)
+    u32* __restrict__ const out_row_s = a.fr_row[out & 1];
+    u32* __restrict__ const out_off_s = a.fr_off[out & 1];
+    u32* __restrict__ const out_row_l = a.lq_row[out & 1];
+    u32* __restrict__ const out_off_l = a.lq_off[out & 1];
     u64 tot_s = 0, tot_l = 0, tot_true = 0;        // (count << 40 | edges) of the two queues so far; true edges of the long one
     for (int first = 0; first < nf2; first += NT) {
       const int i = first + threadIdx.x;
@@ -247,19 +251,23 @@ __device__ __forceinline__ void bfs_chain_body(const bfs_fused_args_t& a, int sl
         const u32 v = s_win[i];
         atomicOr(a.frontier_bits + (v >> 5), 1u << (v & 31u));
       }
-      if (threadIdx.x == 0) c->fb_slot = slot + 1;
+      if (threadIdx.x == 0) c->fb_slot = out;
+    } else if (INPLACE) {
+      if (threadIdx.x == 0) c->fb_slot = -1;       // (the init kernel's bitmap -- the source alone -- is not this slot's frontier any more)
     }
     if (threadIdx.x == 0) {
-      c->cursor[(slot + 1) % 3] = ((tot_s >> 40) << BFS_VSHIFT) | (tot_s & DEGMASK);
-      c->lcursor[(slot + 1) % 3] = ((tot_l >> 40) << BFS_VSHIFT) | (tot_l & DEGMASK);
-      c->ledges[(slot + 1) % 3] = tot_true;
-      c->cursor[(slot + 2) % 3] = 0;
-      c->lcursor[(slot + 2) % 3] = 0;
-      c->ledges[(slot + 2) % 3] = 0;
-      c->slot_level[(slot + 1) & 3] = level + 1;
-      c->skip_build[slot & 3] = 1;
-      c->flush_count[(slot + 1) & 1] = 0;
-      bfs_slot_marks_clear(a, slot + 1);
+      c->cursor[out % 3] = ((tot_s >> 40) << BFS_VSHIFT) | (tot_s & DEGMASK);
+      c->lcursor[out % 3] = ((tot_l >> 40) << BFS_VSHIFT) | (tot_l & DEGMASK);
+      c->ledges[out % 3] = tot_true;
+      c->slot_level[out & 3] = level + 1;
+      if (!INPLACE) {
+        c->cursor[(slot + 2) % 3] = 0;
+        c->lcursor[(slot + 2) % 3] = 0;
+        c->ledges[(slot + 2) % 3] = 0;
+        c->skip_build[slot & 3] = 1;
+        c->flush_count[(slot + 1) & 1] = 0;
+        bfs_slot_marks_clear(a, slot + 1);
+      }
       if (nf2 == 0 && !c->done) { c->done = 1; c->levels = level + 1; }
     }
     return;

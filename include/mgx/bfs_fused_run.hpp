@@ -151,6 +151,18 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
   }
 }
 
+// The chain of small levels at the START of a traversal as a launch of its own, one workgroup, between the init kernel
+// and slot 0: the source's level and whatever small levels follow it cost a 1-workgroup launch instead of a push launch
+// over the whole grid plus a queue build that finds nothing to do (~19 us -> ~10 on RMAT-22); the first level that is
+// not small is left in slot 0's queues (bfs_chain_body<., true>).  A source whose own level is not small: returns at once.
+__global__ __launch_bounds__(1024) void k_bfs_seed_chain(bfs_fused_args_t a) {
+  const bfs_ctrl_t* const c = a.ctrl;
+  const u64 cur = c->cursor[0], lcur = c->lcursor[0];
+  if (c->done || ((cur | lcur) >> BFS_VSHIFT) == 0) return;         // (a source without edges: slot 0's opener ends the traversal)
+  if (!bfs_level_is_chained(a, cur, lcur, c->ledges[0])) return;
+  bfs_chain_body<1024, true>(a, 0, c->slot_level[0]);
+}
+
 // Experiment (MGX_BFS_BIGLDS=1, timed mode only): the unit-block body with ONE workgroup per CU and twice the bitmap
 // prefix in LDS (fewer cold neighbours marked untested), 128 VGPRs.
 constexpr int BFS_DENSE_HOTW_BIG = 40800;
@@ -188,6 +200,7 @@ inline void bfs_set_kernel_attributes() {
   MGX_SET_LDS((k_bfs_push<false, 3>)); MGX_SET_LDS((k_bfs_push<true, 3>));
   MGX_SET_LDS(k_bfs_push_stream_diag);
   MGX_SET_LDS(k_bfs_push_dense_big);
+  MGX_SET_LDS(k_bfs_seed_chain);
   MGX_SET_LDS(k_bfs_push_level<false>);
   MGX_SET_LDS(k_bfs_push_level<true>);
 #undef MGX_SET_LDS
@@ -207,6 +220,7 @@ struct bfs_run_opts_t {
   int dense = -1;          // MGX_BFS_DENSE: 0 never, N > 0 dense_div = N
   int vshort = -1;         // MGX_BFS_VSHORT: 0 never, N > 0 vshort_div = N
   long long chain = -1;    // MGX_BFS_CHAIN_MAX_EDGES: 0 never (default BFS_CHAIN_CAP)
+  int seed_chain = 1;      // MGX_BFS_SEED_CHAIN=0: the small levels at the start run inside slot 0's push launch (no k_bfs_seed_chain)
   int cold = 2;            // MGX_BFS_COLD: 0 the unit-block body marks its cold entries itself (no cold-edge pass), 2 the long rows' lists
                            // (default), 1 also the short rows' (built with MGX_BFS_COLD_LISTS=2; measured equal on RMAT-22: 0.3712 / 0.3708 ms)
   int lazy = -1;           // MGX_BFS_LAZY: 0 the queue build always writes the queues, N: not behind a push that stored >= n / N marks
@@ -239,6 +253,7 @@ struct bfs_run_opts_t {
     if (const char* e = getenv("MGX_BFS_COMBINE")) o.combine = atoi(e);
     if (const char* e = getenv("MGX_BFS_DEFER")) o.defer = atoll(e);
     if (const char* e = getenv("MGX_BFS_COLD")) o.cold = atoi(e);
+    if (const char* e = getenv("MGX_BFS_SEED_CHAIN")) o.seed_chain = atoi(e);
     if (const char* e = getenv("MGX_BFS_LAZY")) { o.lazy = atoi(e); if (o.lazy > (1 << 20)) o.lazy = 1 << 20; }   // (edges < 2^38: no overflow)
     return o;
   }
@@ -332,6 +347,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.chain_max_edges = mode != 0 ? 0u : (opt.chain >= 0 ? (u32)(opt.chain > BFS_CHAIN_CAP ? BFS_CHAIN_CAP : opt.chain) : st.chain_max_edges);
   const long long nwords = ((long long)st.n + 31) / 32;
   hipLaunchKernelGGL(k_bfs_fused_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src, nwords);
+  if (a.chain_max_edges && opt.seed_chain) hipLaunchKernelGGL(k_bfs_seed_chain, dim3(1), dim3(1024), bfs_chain_lds_bytes(), s, a);
   st.level_kernel_ms = 0.0;
   st.level_kernel_launches = 0;
   st.wave_kernel_ms = 0.0;
