@@ -159,15 +159,20 @@ def main():
         bfs.run(s, mode, args.alpha)
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    stats = []
+    # the timed region: K whole traversals, one after the other (each call returns when its labels are complete); the
+    # counters go into buffers made beforehand, nothing is converted or allocated between two traversals
+    timed = [int(s) for s in sources[args.warmup:]]
+    bufs = [bfs.new_stats() for _ in timed]
+    alpha_f, run_into = float(args.alpha), bfs.run_into
     t0 = time.perf_counter()
     ev0.record(stream)
-    for s in sources[args.warmup:]:
-        stats.append(bfs.run(s, mode, args.alpha))
+    for s, st in zip(timed, bufs):
+        run_into(s, mode, alpha_f, st)
     ev1.record(stream)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
+    stats = [bfs.stats_dict(st) for st in bufs]
     # Roofline pass: the SAME K sources again, now with HIP events around every launch of the product kernel k_bfs_push
     # (on the launch stream).  A second pass because every event record between two kernels leaves a ~6 us gap on the
     # stream (rocprofv3 kernel trace, profiles/): inside the timed region they would cost several % of `value`.

@@ -7,6 +7,9 @@
 // (bfs_fused_chain.hpp; k_bfs_build then returns at once).  RMAT-22: init + 5 slots instead of init + 7 levels x 2.
 // The partitioned path (bfs_dist2.hpp) drives the same kernel bodies with explicit level numbers (k_bfs_push_level).
 #pragma once
+#include <cstring>
+#include <unistd.h>
+extern "C" char** environ;
 #include "bfs_fused.hpp"
 #include "bfs_fused_chain.hpp"
 #include "bfs_fused_cold.hpp"
@@ -236,25 +239,37 @@ struct bfs_run_opts_t {
   int build_list = 0;      // MGX_BFS_BUILD_LIST=1: the list-based queue build (k_bfs_build) instead of k_bfs_build2
   int build_diag = 0;      // MGX_BFS_BUILD_DIAG: parts of k_bfs_build switched off (measurements only)
   int dense_diag = 0;      // MGX_BFS_DENSE_DIAG: parts of the unit-block body switched off (measurements only)
+  // one pass over the environment (a traversal reads twenty switches: twenty getenv calls were ~3 us of its ~20 us of
+  // host time between two traversals)
   static bfs_run_opts_t from_env() {
     bfs_run_opts_t o;
-    if (const char* e = getenv("MGX_BFS_COLD_TEST")) o.cold_test = atoi(e);
-    if (const char* e = getenv("MGX_BFS_MERGED_PUSH")) o.merged = atoi(e);
-    if (const char* e = getenv("MGX_BFS_FLAGS")) o.flags = atoi(e);
-    if (const char* e = getenv("MGX_BFS_DENSE")) o.dense = atoi(e);
-    if (const char* e = getenv("MGX_BFS_VSHORT")) o.vshort = atoi(e);
-    if (const char* e = getenv("MGX_BFS_CHAIN_MAX_EDGES")) o.chain = atoll(e);
-    if (const char* e = getenv("MGX_BFS_DENSE_DIAG")) o.dense_diag = atoi(e);
-    if (const char* e = getenv("MGX_BFS_BUILD_DIAG")) o.build_diag = atoi(e);
-    if (const char* e = getenv("MGX_BFS_BUILD_LIST")) o.build_list = atoi(e);
-    if (const char* e = getenv("MGX_BFS_BIGLDS")) o.biglds = atoi(e);
-    if (const char* e = getenv("MGX_BFS_SPIN")) o.spin = atoi(e);
-    if (const char* e = getenv("MGX_BFS_INTERLEAVE")) o.interleave = atoi(e);
-    if (const char* e = getenv("MGX_BFS_COMBINE")) o.combine = atoi(e);
-    if (const char* e = getenv("MGX_BFS_DEFER")) o.defer = atoll(e);
-    if (const char* e = getenv("MGX_BFS_COLD")) o.cold = atoi(e);
-    if (const char* e = getenv("MGX_BFS_SEED_CHAIN")) o.seed_chain = atoi(e);
-    if (const char* e = getenv("MGX_BFS_LAZY")) { o.lazy = atoi(e); if (o.lazy > (1 << 20)) o.lazy = 1 << 20; }   // (edges < 2^38: no overflow)
+    for (char** ep = ::environ; ep && *ep; ++ep) {
+      const char* const kv = *ep;
+      if (strncmp(kv, "MGX_BFS_", 8) != 0) continue;
+      const char* const name = kv + 8;
+      const char* const eq = strchr(name, '=');
+      if (!eq) continue;
+      const size_t len = (size_t)(eq - name);
+      const char* const val = eq + 1;
+      auto is = [&](const char* n) { return strlen(n) == len && strncmp(name, n, len) == 0; };
+      if (is("COLD_TEST")) o.cold_test = atoi(val);
+      else if (is("MERGED_PUSH")) o.merged = atoi(val);
+      else if (is("FLAGS")) o.flags = atoi(val);
+      else if (is("DENSE")) o.dense = atoi(val);
+      else if (is("VSHORT")) o.vshort = atoi(val);
+      else if (is("CHAIN_MAX_EDGES")) o.chain = atoll(val);
+      else if (is("DENSE_DIAG")) o.dense_diag = atoi(val);
+      else if (is("BUILD_DIAG")) o.build_diag = atoi(val);
+      else if (is("BUILD_LIST")) o.build_list = atoi(val);
+      else if (is("BIGLDS")) o.biglds = atoi(val);
+      else if (is("SPIN")) o.spin = atoi(val);
+      else if (is("INTERLEAVE")) o.interleave = atoi(val);
+      else if (is("COMBINE")) o.combine = atoi(val);
+      else if (is("DEFER")) o.defer = atoll(val);
+      else if (is("COLD")) o.cold = atoi(val);
+      else if (is("SEED_CHAIN")) o.seed_chain = atoi(val);
+      else if (is("LAZY")) { o.lazy = atoi(val); if (o.lazy > (1 << 20)) o.lazy = 1 << 20; }   // (edges < 2^38: no overflow)
+    }
     return o;
   }
 };

@@ -332,16 +332,35 @@ class BfsProblem:
         check(lib.mgx_bfs_uniquify(self._h, fin._h, fout._h, int(iteration), C.byref(v)))
         return v.value
 
-    def run(self, src, mode=_lib.MGX_BFS_PUSH, alpha=0.0):
-        """Fused device-resident traversal."""
-        st = (C.c_int64 * 24)()
-        check(lib.mgx_bfs_run(self._h, int(src), int(mode), C.c_float(alpha), st))
+    STATS_LEN = 24
+
+    @staticmethod
+    def new_stats():
+        """a buffer for run_into()"""
+        return (C.c_int64 * BfsProblem.STATS_LEN)()
+
+    def run_into(self, src, mode, alpha, st):
+        """Fused device-resident traversal, counters into a caller-made buffer (new_stats()): the call a timing loop
+        makes -- nothing is allocated or converted between two traversals; stats_dict(st) reads the buffer afterwards."""
+        rc = lib.mgx_bfs_run(self._h, src, mode, alpha, st)
+        if rc:
+            check(rc)
+
+    @staticmethod
+    def stats_dict(st):
         return {"levels": st[0], "reached": st[1], "m_t": st[2], "push_edges": st[3], "pull_edges": st[4],
                 "push_levels": st[5], "kernel_launches": st[6], "kernel_ns": st[7], "frontier_vertices": st[8],
                 "claims": st[9], "dom_launches": st[10], "dom_ns": st[11], "dom_edges": st[12],
                 "dom_vertices": st[13],
-                "dom_kernel": "k_bfs_push_level_stream" if st[14] else "k_bfs_push_level_wave",
-                "small_levels": st[15], "slots": st[16], "dense_slots": st[17], "vshort_slots": st[18], "lazy_slots": st[19], "cold_slots": st[20]}
+                "dom_kernel": "k_bfs_push (long rows / merged launch)" if st[14] else "k_bfs_push (short rows)",
+                "small_levels": st[15], "slots": st[16], "dense_slots": st[17], "vshort_slots": st[18], "lazy_slots": st[19],
+                "cold_slots": st[20]}
+
+    def run(self, src, mode=_lib.MGX_BFS_PUSH, alpha=0.0):
+        """Fused device-resident traversal."""
+        st = self.new_stats()
+        self.run_into(int(src), int(mode), float(alpha), st)
+        return self.stats_dict(st)
 
     def level_trace(self, cap=4096):
         nf, ne, lv = (C.c_int64 * cap)(), (C.c_int64 * cap)(), C.c_int()

@@ -41,18 +41,22 @@ for rnd in range(a.rounds):
             bfs.run(s, a.mode, a.alpha)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        m_t, nb, nsl = 0, 0, 0
-        for s in srcs[a.warmup:]:
-            st = bfs.run(s, a.mode, a.alpha)
-            m_t += st["m_t"]; nb += len(bfs.batch_times_ms()); nsl += st["slots"]
+        timed = [int(s) for s in srcs[a.warmup:]]
+        bufs = [bfs.new_stats() for _ in timed]
+        t0 = time.perf_counter()
+        for s, b in zip(timed, bufs):
+            bfs.run_into(s, a.mode, a.alpha, b)          # (bench.py's timed loop)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        sts = [bfs.stats_dict(b) for b in bufs]
+        st = sts[-1]
+        m_t, nsl, nb = sum(x["m_t"] for x in sts), sum(x["slots"] for x in sts), 0
         lab = bfs.labels()
         if ref is None:
             ref = lab.copy()
         same = bool(np.array_equal(lab, ref))
         results[cfg].append(dt / a.steps * 1e3)
-        print("round %d  %-60s %.4f ms/BFS  %.1f GTEPS  slots %.2f batches %.2f dense %d vshort %d lazy %d cold %d small %d  labels_equal %s" % (
-            rnd, cfg or "(defaults)", dt / a.steps * 1e3, m_t / dt / 1e9, nsl / a.steps, nb / a.steps, st["dense_slots"], st["vshort_slots"], st.get("lazy_slots", 0), st.get("cold_slots", 0), st["small_levels"], same), flush=True)
+        print("round %d  %-60s %.4f ms/BFS  %.1f GTEPS  slots %.2f dense %d vshort %d lazy %d cold %d small %d  labels_equal %s" % (
+            rnd, cfg or "(defaults)", dt / a.steps * 1e3, m_t / dt / 1e9, nsl / a.steps, st["dense_slots"], st["vshort_slots"], st.get("lazy_slots", 0), st.get("cold_slots", 0), st["small_levels"], same), flush=True)
 for cfg in configs:
     print("best  %-60s %.4f ms/BFS" % (cfg or "(defaults)", min(results[cfg])))

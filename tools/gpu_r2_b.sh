@@ -1,9 +1,6 @@
 #!/bin/bash
-# where the unit-block body's time goes: marks off / test off
-ulimit -c 0
-O=gpurun_out/r2b; rm -rf $O; mkdir -p $O
-for cfg in "" "MGX_BFS_DENSE=1000000" "MGX_BFS_DENSE=1000000 MGX_BFS_DENSE_DIAG=1" "MGX_BFS_DENSE=1000000 MGX_BFS_DENSE_DIAG=2" "MGX_BFS_DENSE=0"; do
-  echo "=== $cfg" >> $O/levels.log
-  env $cfg timeout 300 python tools/bfs_levels.py --scale 22 --runs 2 2>&1 | grep -E "^src|level  [1234]|slots|stream" >> $O/levels.log
-done
-cat $O/levels.log
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2b; rm -rf $O; mkdir -p $O; cd $R
+timeout 1800 python -m pytest tests -q -x -m gpu --timeout 900 > $O/pytest_gpu.log 2>&1
+echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
+for i in 1 2; do timeout 600 python bench.py --steps 16 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-420; done | tee $O/bench.log
+timeout 300 python bench.py --mode do --alpha 64 --steps 16 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-300
