@@ -135,6 +135,7 @@ struct bfs_fused_args_t {
   u32 vs_dummy;            // index (into col_indices) of four entries of -1
   u32* flush_buf;          // BFS_FLUSH_MAX buffers of BFS_FLUSH_WORDS words (NULL: hot marks are never deferred)
   u32 defer_min_marks;     // a workgroup with more deferred discoveries than this flushes them as a bitmap (else: byte marks)
+  u32 defer_reach_mul, defer_reach_div;   // a level defers while reached * mul < deferred range * div (1 / 1; MGX_BFS_DEFER_REACH="mul/div")
   int combine;             // merged push launch: a slot that takes both dense paths runs them in the same workgroups
   int interleave;          // merged push launch: even workgroups take the long rows, odd ones the short rows (instead of first half / second half)
   int build_diag;          // measurements only (MGX_BFS_BUILD_DIAG; results wrong): 1 no label stores, 2 no extent gathers, 4 no cursor atomics
@@ -345,8 +346,9 @@ __host__ __device__ __forceinline__ int bfs_slot_arg(int slot) { return -1 - slo
 //     into its sweep (all waves of a workgroup share the reads of a run: a few coalesced loads each).
 // Vertices behind the deferred range, cold neighbours and small levels (no LDS copy) keep their immediate byte marks.
 // The epilogue costs every workgroup a second read of its 72 KB of bitmap (~4 us per level, measured), which only pays
-// while discoveries are dense: a level defers when less than a quarter of the deferred range has been reached before it
-// (bfs_defer_limit: grid-uniform, ctrl->reached is stable while a level runs) -- the hub levels at the start of a
+// while discoveries are dense: a level defers while fewer vertices have been reached than the deferred range holds
+// (bfs_defer_limit: grid-uniform, ctrl->reached is stable while a level runs; a quarter of the range was the rule while
+// the cold marks still dominated those levels) -- the hub levels at the start of a
 // traversal; later levels find most of the prefix visited and store the few marks they have at once.
 constexpr int BFS_FLUSH_WORDS = 17984;                 // 562 runs of 1024 vertices: inside every body's LDS prefix
 constexpr int BFS_FLUSH_MAX = 1024;                    // one buffer per push workgroup of a slot at most
@@ -356,7 +358,7 @@ constexpr int BFS_FLUSH_RUNS = BFS_FLUSH_WORDS / 32;
 __device__ __forceinline__ u32 bfs_defer_limit(const bfs_fused_args_t& a, u32 hot_n) {
   if (!a.flush_buf || hot_n == 0u) return 0u;
   const u32 range = hot_n < (u32)(BFS_FLUSH_WORDS * 32) ? hot_n : (u32)(BFS_FLUSH_WORDS * 32);
-  return a.ctrl->reached * 4ull < (u64)range ? range : 0u;
+  return a.ctrl->reached * (u64)a.defer_reach_mul < (u64)range * (u64)a.defer_reach_div ? range : 0u;
 }
 
 // End of a push workgroup (all threads; contains barriers).  hot: the LDS copy, deferred words = min(hot words in use,

@@ -223,6 +223,8 @@ struct bfs_run_opts_t {
   int dense = -1;          // MGX_BFS_DENSE: 0 never, N > 0 dense_div = N
   int vshort = -1;         // MGX_BFS_VSHORT: 0 never, N > 0 vshort_div = N
   long long chain = -1;    // MGX_BFS_CHAIN_MAX_EDGES: 0 never (default BFS_CHAIN_CAP)
+  int defer_mul = 1, defer_div = 1;   // MGX_BFS_DEFER_REACH="mul/div": a level defers its hot marks while reached * mul < range * div
+                                      // (RMAT-22, ms per traversal: 4/1 0.3627, 2/1 0.3600, 1/1 0.3521, 2/3 0.3511, 1/3 0.3530, 1/8 0.3625, always 0.3641)
   int seed_chain = 1;      // MGX_BFS_SEED_CHAIN=0: the small levels at the start run inside slot 0's push launch (no k_bfs_seed_chain)
   int cold = 2;            // MGX_BFS_COLD: 0 the unit-block body marks its cold entries itself (no cold-edge pass), 2 the long rows' lists
                            // (default), 1 also the short rows' (built with MGX_BFS_COLD_LISTS=2; measured equal on RMAT-22: 0.3712 / 0.3708 ms)
@@ -267,6 +269,7 @@ struct bfs_run_opts_t {
       else if (is("COMBINE")) o.combine = atoi(val);
       else if (is("DEFER")) o.defer = atoll(val);
       else if (is("COLD")) o.cold = atoi(val);
+      else if (is("DEFER_REACH")) { o.defer_mul = atoi(val); const char* sl = strchr(val, '/'); o.defer_div = sl ? atoi(sl + 1) : 1; if (o.defer_div < 1) o.defer_div = 1; }
       else if (is("SEED_CHAIN")) o.seed_chain = atoi(val);
       else if (is("LAZY")) { o.lazy = atoi(val); if (o.lazy > (1 << 20)) o.lazy = 1 << 20; }   // (edges < 2^38: no overflow)
     }
@@ -359,6 +362,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   if (defer > 0 && !a.flags && !st.flush_buf.size()) st.flush_buf = mem_t<u32>((size_t)BFS_FLUSH_MAX * BFS_FLUSH_WORDS, ctx);
   a.flush_buf = (defer > 0 && !a.flags) ? st.flush_buf.data() : nullptr;
   a.defer_min_marks = (u32)defer;
+  a.defer_reach_mul = (u32)opt.defer_mul; a.defer_reach_div = (u32)opt.defer_div;
   a.chain_max_edges = mode != 0 ? 0u : (opt.chain >= 0 ? (u32)(opt.chain > BFS_CHAIN_CAP ? BFS_CHAIN_CAP : opt.chain) : st.chain_max_edges);
   const long long nwords = ((long long)st.n + 31) / 32;
   hipLaunchKernelGGL(k_bfs_fused_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src, nwords);
