@@ -141,6 +141,7 @@ struct bfs_fused_args_t {
   int build_diag;          // measurements only (MGX_BFS_BUILD_DIAG; results wrong): 1 no label stores, 2 no extent gathers, 4 no cursor atomics
   int dense_diag;          // measurements only (MGX_BFS_DENSE_DIAG): 1 the unit-block body stores no marks, 2 tests nothing
   u32 chain_max_edges;     // a level of at most this many edges (and BFS_CHAIN_CQ rows) runs inside block 0 of the push launch (0: never)
+  u32 chain_big_edges;     // ... and of at most this many edges inside the in-place chain kernel (k_bfs_chain_inplace; 0: never)
   u32 lazy_div;            // the build behind a level with >= n / lazy_div mark stores writes no queues (bfs_build_is_lazy; 0: never)
   u32* slot_marks;         // [2][BFS_MARK_CTRS] counters, 128 bytes apart: marks stored by the push workgroups of slot s in set s & 1 (NULL: not counted)
   // cold-edge lists of the long rows (bfs_fused_cold.hpp, mgx_layout.hip): (owner, dst) pairs of the unit blocks' entries
@@ -904,6 +905,9 @@ struct bfs_fused_state_t {
                                      // chained with the small levels behind them (bfs_fused_chain.hpp; 0: never)
   unsigned vshort_div = 8;           // short rows are walked vertex by vertex when the level holds at least 1 / vshort_div of
                                      // all short-row edges (bfs_fused_vshort.hpp; 0: never)
+  unsigned chain_big_edges = 12288;  // largest level the in-place chain kernel runs (bfs_fused_run.hpp; <= BFS_CHAIN_CAP_BIG)
+  int recent_need[4] = {1, 1, 1, 1}, recent_at = 0;   // slots the last traversals needed
+  int tail_from = 1 << 30;           // slots from this one on get an in-place chain launch in front (learnt from the previous traversal)
   unsigned lazy_div = 4;             // the build behind a push with >= n / lazy_div mark stores writes no queues (bfs_build_is_lazy; 0: never)
   mem_t<u32> slot_marks;             // the counters it looks at (bfs_fused_args_t::slot_marks)
   mem_t<u32> cold_flush;             // cold-edge pass: BFS_COLD_WGS bitmaps of BFS_COLD_WORDS words (allocated on demand)

@@ -28,27 +28,30 @@ namespace mgx {
 constexpr int BFS_CHAIN_NT = 1024;
 constexpr int BFS_CHAIN_CAP = 6144;          // edges (>= winners >= rows of the next level) of a chained level
 constexpr int BFS_CHAIN_EPT = 4;             // edge ranks per thread in flight
-constexpr size_t bfs_chain_lds_bytes() {
-  return (size_t)(BFS_CHAIN_NT / 64 + 2) * 8 + (size_t)(3 * BFS_CHAIN_CAP + 4) * 4 + 64;
+constexpr int BFS_CHAIN_CAP_BIG = 12288;     // ... of a level run by the in-place chain kernel (a launch of its own: 148 KB of LDS)
+constexpr size_t bfs_chain_lds_bytes(int cap = BFS_CHAIN_CAP) {
+  return (size_t)(BFS_CHAIN_NT / 64 + 2) * 8 + (size_t)(3 * cap + 4) * 4 + 64;
 }
 
 // grid-uniform: sizes of ring entry slot % 3 (complete since the previous launch)
-__device__ __forceinline__ bool bfs_level_is_chained(const bfs_fused_args_t& a, u64 cur, u64 lcur, u64 ledges) {
-  if (a.mode != 0 || a.chain_max_edges == 0u) return false;
+__device__ __forceinline__ bool bfs_level_is_chained(const bfs_fused_args_t& a, u64 cur, u64 lcur, u64 ledges, u32 max_edges, int list_cap = BFS_CHAIN_CAP) {
+  if (a.mode != 0 || max_edges == 0u) return false;
   const u64 nf = (cur >> BFS_VSHIFT) + (lcur >> BFS_VSHIFT);
   const u64 E = (cur & BFS_EMASK) + ledges;
-  const u64 cap = a.chain_max_edges < (u32)BFS_CHAIN_CAP ? a.chain_max_edges : (u32)BFS_CHAIN_CAP;
-  return nf <= (u64)BFS_CHAIN_CAP && E <= cap;
+  const u64 cap = max_edges < (u32)list_cap ? max_edges : (u32)list_cap;
+  return nf <= (u64)list_cap && E <= cap;
+}
+__device__ __forceinline__ bool bfs_level_is_chained(const bfs_fused_args_t& a, u64 cur, u64 lcur, u64 ledges) {
+  return bfs_level_is_chained(a, cur, lcur, ledges, a.chain_max_edges);
 }
 
 // Runs level `level` of slot `slot` and the small levels behind it.  Whole workgroup (NT threads).
 // INPLACE: the chain is a launch of its own in FRONT of the slot (k_bfs_seed_chain, behind the init kernel): it takes the
 // slot's queues and leaves the first level that is not small in the SAME slot's queues and ring entry -- the slot's push
 // launch then opens that level; nothing is skipped and no slot is used up.
-template <int NT, bool INPLACE = false>
+template <int NT, bool INPLACE = false, int CAP = BFS_CHAIN_CAP>
 __device__ __forceinline__ void bfs_chain_body(const bfs_fused_args_t& a, int slot, int level) {
   constexpr int NW = NT / WAVE;
-  constexpr int CAP = BFS_CHAIN_CAP;
   constexpr int EPT = BFS_CHAIN_EPT;
   constexpr u64 CNT1 = 1ull << 40;
   constexpr u64 DEGMASK = CNT1 - 1ull;
@@ -62,7 +65,8 @@ __device__ __forceinline__ void bfs_chain_body(const bfs_fused_args_t& a, int sl
   bfs_ctrl_t* const c = a.ctrl;
   const int lane = lane_id();
   const u32 long_min = a.long_min > 0 ? (u32)a.long_min : 0xFFFFFFFFu;
-  const u32 max_e = a.chain_max_edges < (u32)CAP ? a.chain_max_edges : (u32)CAP;
+  const u32 lim_e = INPLACE ? a.chain_big_edges : a.chain_max_edges;
+  const u32 max_e = lim_e < (u32)CAP ? lim_e : (u32)CAP;
 
   // ---- stage in: the slot's two queues as one list (long rows first) ---------------------------------------------
   int nf;

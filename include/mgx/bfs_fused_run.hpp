@@ -154,16 +154,26 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
   }
 }
 
-// The chain of small levels at the START of a traversal as a launch of its own, one workgroup, between the init kernel
-// and slot 0: the source's level and whatever small levels follow it cost a 1-workgroup launch instead of a push launch
-// over the whole grid plus a queue build that finds nothing to do (~19 us -> ~10 on RMAT-22); the first level that is
-// not small is left in slot 0's queues (bfs_chain_body<., true>).  A source whose own level is not small: returns at once.
-__global__ __launch_bounds__(1024) void k_bfs_seed_chain(bfs_fused_args_t a) {
+// The chain of small levels as a launch of its own, ONE workgroup with (nearly) all of a CU's LDS, IN FRONT of a slot:
+//   * at the start of a traversal (slot 0, behind the init kernel): the source's level and whatever small levels follow
+//     it cost a 1-workgroup launch instead of a push launch over the whole grid plus a queue build that finds nothing to
+//     do (~19 us -> ~10 on RMAT-22);
+//   * at its end (slots >= tail_from, which the host learns from the previous traversal of the graph, and once more
+//     behind the last slot of a batch): the stragglers -- RMAT-22: 10 000 edges, then 1 300 -- used to take two slots,
+//     two push launches over 1024 workgroups and two sweeps of the queue build: 35 of 350 us.  With twice the list
+//     capacity of the chain inside a push launch (BFS_CHAIN_CAP_BIG: the LDS is this workgroup's alone) they run here,
+//     back to back, and the traversal ends without another slot.
+// The first level that is not small is left in the SAME slot's queues (bfs_chain_body<., true, .>): the slot's push
+// launch opens it.  Nothing to do (a big level, an empty or lazy slot, the traversal over): returns at once (~2.5 us).
+__global__ __launch_bounds__(1024) void k_bfs_chain_inplace(bfs_fused_args_t a, int arg) {
   const bfs_ctrl_t* const c = a.ctrl;
-  const u64 cur = c->cursor[0], lcur = c->lcursor[0];
-  if (c->done || ((cur | lcur) >> BFS_VSHIFT) == 0) return;         // (a source without edges: slot 0's opener ends the traversal)
-  if (!bfs_level_is_chained(a, cur, lcur, c->ledges[0])) return;
-  bfs_chain_body<1024, true>(a, 0, c->slot_level[0]);
+  int slot, level;
+  bfs_resolve(c, arg, slot, level);
+  const u64 cur = c->cursor[slot % 3], lcur = c->lcursor[slot % 3];
+  if (c->done || ((cur | lcur) >> BFS_VSHIFT) == 0) return;         // (an empty frontier: the slot's opener ends the traversal)
+  if (c->lazy_slot == slot) return;                                  // (the build before wrote no queues: nothing to stage in)
+  if (!bfs_level_is_chained(a, cur, lcur, c->ledges[slot % 3], a.chain_big_edges, BFS_CHAIN_CAP_BIG)) return;
+  bfs_chain_body<1024, true, BFS_CHAIN_CAP_BIG>(a, slot, level);
 }
 
 // Experiment (MGX_BFS_BIGLDS=1, timed mode only): the unit-block body with ONE workgroup per CU and twice the bitmap
@@ -203,7 +213,7 @@ inline void bfs_set_kernel_attributes() {
   MGX_SET_LDS((k_bfs_push<false, 3>)); MGX_SET_LDS((k_bfs_push<true, 3>));
   MGX_SET_LDS(k_bfs_push_stream_diag);
   MGX_SET_LDS(k_bfs_push_dense_big);
-  MGX_SET_LDS(k_bfs_seed_chain);
+  MGX_SET_LDS(k_bfs_chain_inplace);
   MGX_SET_LDS(k_bfs_push_level<false>);
   MGX_SET_LDS(k_bfs_push_level<true>);
 #undef MGX_SET_LDS
@@ -225,7 +235,9 @@ struct bfs_run_opts_t {
   long long chain = -1;    // MGX_BFS_CHAIN_MAX_EDGES: 0 never (default BFS_CHAIN_CAP)
   int defer_mul = 1, defer_div = 1;   // MGX_BFS_DEFER_REACH="mul/div": a level defers its hot marks while reached * mul < range * div
                                       // (RMAT-22, ms per traversal: 4/1 0.3627, 2/1 0.3600, 1/1 0.3521, 2/3 0.3511, 1/3 0.3530, 1/8 0.3625, always 0.3641)
-  int seed_chain = 1;      // MGX_BFS_SEED_CHAIN=0: the small levels at the start run inside slot 0's push launch (no k_bfs_seed_chain)
+  int seed_chain = 1;      // MGX_BFS_SEED_CHAIN=0: no in-place chain launches at all (small levels run inside the slots' push launches)
+  int tail_chain = 1;      // MGX_BFS_TAIL_CHAIN=0: ... only the one at the start
+  int chain_big = -1;      // MGX_BFS_CHAIN_BIG_EDGES: largest level of an in-place chain launch
   int cold = 2;            // MGX_BFS_COLD: 0 the unit-block body marks its cold entries itself (no cold-edge pass), 2 the long rows' lists
                            // (default), 1 also the short rows' (built with MGX_BFS_COLD_LISTS=2; measured equal on RMAT-22: 0.3712 / 0.3708 ms)
   int lazy = -1;           // MGX_BFS_LAZY: 0 the queue build always writes the queues, N: not behind a push that stored >= n / N marks
@@ -271,6 +283,8 @@ struct bfs_run_opts_t {
       else if (is("COLD")) o.cold = atoi(val);
       else if (is("DEFER_REACH")) { o.defer_mul = atoi(val); const char* sl = strchr(val, '/'); o.defer_div = sl ? atoi(sl + 1) : 1; if (o.defer_div < 1) o.defer_div = 1; }
       else if (is("SEED_CHAIN")) o.seed_chain = atoi(val);
+      else if (is("TAIL_CHAIN")) o.tail_chain = atoi(val);
+      else if (is("CHAIN_BIG_EDGES")) o.chain_big = atoi(val);
       else if (is("LAZY")) { o.lazy = atoi(val); if (o.lazy > (1 << 20)) o.lazy = 1 << 20; }   // (edges < 2^38: no overflow)
     }
     return o;
@@ -366,7 +380,12 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.chain_max_edges = mode != 0 ? 0u : (opt.chain >= 0 ? (u32)(opt.chain > BFS_CHAIN_CAP ? BFS_CHAIN_CAP : opt.chain) : st.chain_max_edges);
   const long long nwords = ((long long)st.n + 31) / 32;
   hipLaunchKernelGGL(k_bfs_fused_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src, nwords);
-  if (a.chain_max_edges && opt.seed_chain) hipLaunchKernelGGL(k_bfs_seed_chain, dim3(1), dim3(1024), bfs_chain_lds_bytes(), s, a);
+  // in-place chain launches (k_bfs_chain_inplace): in front of slot 0, of the slots from tail_from on, behind a batch
+  a.chain_big_edges = (a.chain_max_edges && opt.seed_chain) ? (opt.chain_big >= 0 ? (u32)(opt.chain_big > BFS_CHAIN_CAP_BIG ? BFS_CHAIN_CAP_BIG : opt.chain_big) : st.chain_big_edges) : 0u;
+  auto chain_inplace = [&](int sl) {
+    hipLaunchKernelGGL(k_bfs_chain_inplace, dim3(1), dim3(1024), bfs_chain_lds_bytes(BFS_CHAIN_CAP_BIG), s, a, bfs_slot_arg(sl));
+  };
+  if (a.chain_big_edges) chain_inplace(0);
   st.level_kernel_ms = 0.0;
   st.level_kernel_launches = 0;
   st.wave_kernel_ms = 0.0;
@@ -407,6 +426,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
     if (batch_events) MGX_HIP(hipEventRecord(st.ev0, s));
     for (int i = 0; i < nslots; ++i, ++slot) {
       const int arg = bfs_slot_arg(slot);
+      if (a.chain_big_edges && slot > 0 && slot >= st.tail_from && opt.tail_chain) chain_inplace(slot);
       const bool in_pool = 3 * i + 2 < bfs_fused_state_t::EV_POOL;
       const bool timed = st.time_kernels == 1 && in_pool;
       const bool timed_merged = st.time_kernels == 2 && in_pool && opt.merged && !a.flags;
@@ -439,6 +459,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
       else
         hipLaunchKernelGGL(k_bfs_build2<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, arg, labels, st.n);   // (2 workgroups per CU overlap their phases)
     }
+    if (a.chain_big_edges && slot >= st.tail_from && opt.tail_chain) chain_inplace(slot);    // (the stragglers: may end the traversal here)
     if (batch_events) MGX_HIP(hipEventRecord(st.ev1, s));
     // one read-back per batch: the counters and the first 64 trace slots (the flag alone would cost the same trip)
     constexpr size_t head_bytes = offsetof(bfs_ctrl_t, trace) + 64 * sizeof(u64);
@@ -498,10 +519,36 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   }
   st.slots_used = slot;
   st.slots_hint = st.host_ctrl->slots > 0 ? st.host_ctrl->slots : 1;    // slots that found work
+  st.tail_from = 1 << 30;
   const int lv = st.host_ctrl->levels < BFS_MAX_TRACE ? st.host_ctrl->levels : BFS_MAX_TRACE;
   if (lv > 64) {                // the rest of the per-level trace (deep traversals only)
     MGX_HIP(hipMemcpyAsync(st.host_ctrl->trace + 64, st.ctrl.data()->trace + 64, (size_t)(lv - 64) * sizeof(u64), hipMemcpyDeviceToHost, s));
     MGX_HIP(hipStreamSynchronize(s));
+  }
+  if (a.chain_big_edges && opt.tail_chain) {
+    // What the NEXT traversal of this graph should enqueue, from this one's level sizes: a slot for every level that is
+    // too big for the in-place chain, and chain launches from the first slot on that had a small level in front of it
+    // (sources differ, the level structure of a graph hardly does; a wrong guess costs an idle launch or a second batch).
+    int k = 0, tail = 1 << 30;
+    for (int l = 0; l < lv; ++l) {
+      const u64 t = st.host_ctrl->trace[l];
+      const bool small = (t >> BFS_VSHIFT) <= (u64)BFS_CHAIN_CAP_BIG && (t & BFS_EMASK) <= (u64)a.chain_big_edges;
+      if (small) { if (k >= 1 && k < tail) tail = k; }
+      else ++k;
+    }
+    // over the last few traversals: the most slots any of them needed (a slot too many is two idle launches, ~9 us; one too
+    // few a second batch, ~25 us).  In-place chain launches from the first slot behind them on, i.e. behind the batch: a
+    // chain launch that finds a big level costs 5 us (its reads of the control block miss behind the build's atomics),
+    // and on RMAT-22 the level behind the last big one is small for a minority of the sources only.
+    const int need = k > 0 ? k : 1;
+    (void)tail;
+    st.recent_need[st.recent_at & 3] = need;
+    st.recent_at += 1;
+    int hint = 1;
+    for (int i = 0; i < 4 && i < st.recent_at; ++i)
+      if (st.recent_need[i] > hint) hint = st.recent_need[i];
+    st.slots_hint = hint;
+    st.tail_from = hint;
   }
 }
 
