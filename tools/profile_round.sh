@@ -10,6 +10,7 @@ echo "pytest rc=$?"; tail -4 $O/pytest_gpu.log
 timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1
 echo "smoke rc=$?"; tail -1 $O/smoke.log
 timeout 300 ./tools/microbench > $O/microbench.jsonl 2>&1
+timeout 300 ./tools/microbench4 > $O/microbench4.jsonl 2>&1
 # the PMC passes FIRST: the traffic figure they give (tied to the hash of the sources) is what the bench line of this
 # very run reports as roofline.traffic
 cd /tmp && export TMPDIR=/tmp
@@ -41,6 +42,6 @@ python3 tools/summarize_profiles.py $O > $O/summary.txt 2>&1
 cat $O/summary.txt
 # what goes under profiles/ (the caller copies gpurun_out/round/keep/* to profiles/rNN/ and pmc_traffic.json to profiles/)
 mkdir -p $O/keep
-cp $O/summary.txt $O/summary.json $O/kernel_stats_mgx.csv $O/levels.log $O/microbench.jsonl $O/keep/ 2>/dev/null
+cp $O/summary.txt $O/summary.json $O/kernel_stats_mgx.csv $O/levels.log $O/microbench.jsonl $O/microbench4.jsonl $O/keep/ 2>/dev/null
 cp $O/pmc_traffic.json $O/bfs_operator_s22.log $O/sssp_s22.log $O/dobfs_alpha_sweep.txt $O/keep/ 2>/dev/null
 grep '^{' $O/bench.log | tail -1 > $O/keep/bench_line.json

@@ -11,7 +11,7 @@ for f in glob.glob(os.path.join(O, "trace", "**", "*kernel_stats.csv"), recursiv
         for r in keep:
             r = dict(r); r["Name"] = r["Name"][:120]; w.writerow(r)
     for r in rows:
-        for kn in ("k_bfs_push<false, 0>", "k_bfs_push<false, 1>", "k_bfs_push<false, 2>", "k_bfs_push<false, 3>", "k_bfs_build", "k_bfs_fused_init", "k_bfs_pull_level"):
+        for kn in ("k_bfs_push<false, 0>", "k_bfs_push<false, 1>", "k_bfs_push<false, 2>", "k_bfs_push<false, 3>", "k_bfs_build", "k_bfs_fused_init", "k_bfs_pull_level", "k_bfs_chain_inplace", "k_bfs_publish"):
             if kn in r["Name"]:
                 out[kn] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "total_ns": int(r["TotalDurationNs"])}
                 print("kernel-trace: %s calls=%s avg=%.1f us total=%.3f ms" % (kn, r["Calls"], float(r["AverageNs"]) / 1e3, int(r["TotalDurationNs"]) / 1e6))
