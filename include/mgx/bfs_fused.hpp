@@ -901,11 +901,12 @@ struct bfs_fused_state_t {
   int slots_hint = 5;                // ... except for the first batch: as many slots as the previous traversal needed
   int slots_used = 0;                // slots the last run launched
   bool time_batches = false;         // HIP events around every batch of launches (-> level_kernel_ms; ~6 us each)
-  unsigned chain_max_edges = 6144;   // levels up to this size (and BFS_CHAIN_CAP) run inside block 0 of the push launch,
-                                     // chained with the small levels behind them (bfs_fused_chain.hpp; 0: never)
+  unsigned chain_max_edges = 4096;   // largest level block 0 of a push launch runs itself, chained with the small levels behind it
+                                     // (bfs_fused_chain.hpp; <= BFS_CHAIN_CAP; early in a traversal BFS_CHAIN_EARLY_EDGES; 0: never)
   unsigned vshort_div = 8;           // short rows are walked vertex by vertex when the level holds at least 1 / vshort_div of
                                      // all short-row edges (bfs_fused_vshort.hpp; 0: never)
-  unsigned chain_big_edges = 12288;  // largest level the in-place chain kernel runs (bfs_fused_run.hpp; <= BFS_CHAIN_CAP_BIG)
+  unsigned chain_big_edges = 4096;   // largest level the in-place chain kernel runs (bfs_fused_run.hpp; <= BFS_CHAIN_CAP_BIG): a lone workgroup
+                                     // needs ~5 + 4.3 us per 1000 edges (measured: 10 487 edges 49 us, 7 391 38 us, 1 281 17 us), a device-wide slot ~21 us
   int recent_need[4] = {1, 1, 1, 1}, recent_at = 0;   // slots the last traversals needed
   int tail_from = 1 << 30;           // slots from this one on get an in-place chain launch in front (learnt from the previous traversal)
   unsigned lazy_div = 4;             // the build behind a push with >= n / lazy_div mark stores writes no queues (bfs_build_is_lazy; 0: never)

@@ -34,11 +34,23 @@ constexpr size_t bfs_chain_lds_bytes(int cap = BFS_CHAIN_CAP) {
 }
 
 // grid-uniform: sizes of ring entry slot % 3 (complete since the previous launch)
+// What a chained level may cost.  The claims are device-scope atomics from ONE compute unit, which issues about 100 M of
+// them per second (tools/microbench.hip: 25 G/s over 256 CUs): a level that discovers 4 000 vertices takes 50 us here and
+// 20 us device-wide (measured: 335 edges 14 us, 1 937 26 us, 4 532 55 us, 7 440 74 us for the first two levels of a
+// traversal).  The claim is only issued for a neighbour whose bit reads unset, so what counts is the DISCOVERIES: early
+// in a traversal nearly every edge is one (limit BFS_CHAIN_EARLY_EDGES edges); once a quarter of the vertices is reached
+// the peak is over and the stragglers' edges mostly end at visited vertices (limit: max_edges).
+constexpr u32 BFS_CHAIN_EARLY_EDGES = 1536;
+__device__ __forceinline__ u32 bfs_chain_edge_limit(const bfs_fused_args_t& a, u64 reached, u32 max_edges) {
+  const bool late = reached * 4ull >= (u64)(u32)a.n;
+  return late || max_edges < BFS_CHAIN_EARLY_EDGES ? max_edges : BFS_CHAIN_EARLY_EDGES;
+}
 __device__ __forceinline__ bool bfs_level_is_chained(const bfs_fused_args_t& a, u64 cur, u64 lcur, u64 ledges, u32 max_edges, int list_cap = BFS_CHAIN_CAP) {
   if (a.mode != 0 || max_edges == 0u) return false;
   const u64 nf = (cur >> BFS_VSHIFT) + (lcur >> BFS_VSHIFT);
   const u64 E = (cur & BFS_EMASK) + ledges;
-  const u64 cap = max_edges < (u32)list_cap ? max_edges : (u32)list_cap;
+  const u32 lim = bfs_chain_edge_limit(a, a.ctrl->reached, max_edges);
+  const u64 cap = lim < (u32)list_cap ? lim : (u32)list_cap;
   return nf <= (u64)list_cap && E <= cap;
 }
 __device__ __forceinline__ bool bfs_level_is_chained(const bfs_fused_args_t& a, u64 cur, u64 lcur, u64 ledges) {
@@ -66,7 +78,6 @@ __device__ __forceinline__ void bfs_chain_body(const bfs_fused_args_t& a, int sl
   const int lane = lane_id();
   const u32 long_min = a.long_min > 0 ? (u32)a.long_min : 0xFFFFFFFFu;
   const u32 lim_e = INPLACE ? a.chain_big_edges : a.chain_max_edges;
-  const u32 max_e = lim_e < (u32)CAP ? lim_e : (u32)CAP;
 
   // ---- stage in: the slot's two queues as one list (long rows first) ---------------------------------------------
   int nf;
@@ -144,13 +155,16 @@ __device__ __forceinline__ void bfs_chain_body(const bfs_fused_args_t& a, int sl
         int d[EPT];
 #pragma unroll
         for (int k = 0; k < EPT; ++k) d[k] = a.col_indices[act[k] ? s_row[sj[k]] + (r[k] - s_off[sj[k]]) : 0u];
-        // (no look at the word first: at this size the few thousand atomics cost less than the extra dependent load --
-        //  a lone workgroup pays ~2 us for every round trip to memory, and a level is a chain of them)
+        // a look at the word first (possibly stale, i.e. with fewer bits: then the claim below decides): one compute unit
+        // issues ~100 M device-scope atomics per second, and the stragglers' edges mostly end at visited vertices
+        u32 seen[EPT];
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) seen[k] = act[k] ? a.visited[(u32)d[k] >> 5] : 0xFFFFFFFFu;
         u32 old[EPT];
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
           const u32 bit = 1u << (d[k] & 31);
-          old[k] = act[k] ? atomicOr(a.visited + ((u32)d[k] >> 5), bit) : 0xFFFFFFFFu;
+          old[k] = (seen[k] & bit) ? 0xFFFFFFFFu : atomicOr(a.visited + ((u32)d[k] >> 5), bit);
         }
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
@@ -204,11 +218,15 @@ __device__ __forceinline__ void bfs_chain_body(const bfs_fused_args_t& a, int sl
     const u32 E2 = (u32)(run & DEGMASK);          // (a level reached from <= CAP edges: far below 2^32)
     if (threadIdx.x == 0) {
       s_off[nf2] = E2;
-      c->reached += (u64)W;
+      const u64 reached_now = c->reached + (u64)W;
+      c->reached = reached_now;
+      s_i[1] = (int)bfs_chain_edge_limit(a, reached_now, lim_e);      // what the next level may hold to be chained too
       if (a.count_marks) { c->claims += (u64)W; if (level < 64) c->claims_level[level] += (u64)W; }
     }
     __syncthreads();
 
+    const u32 max_l = (u32)s_i[1];
+    const u32 max_e = max_l < (u32)CAP ? max_l : (u32)CAP;
     if (nf2 != 0 && (run & DEGMASK) <= (u64)max_e) {     // the next level is small too: keep going
       nf = nf2;
       E = E2;

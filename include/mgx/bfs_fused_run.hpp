@@ -160,9 +160,9 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
 //     do (~19 us -> ~10 on RMAT-22);
 //   * at its end (slots >= tail_from, which the host learns from the previous traversal of the graph, and once more
 //     behind the last slot of a batch): the stragglers -- RMAT-22: 10 000 edges, then 1 300 -- used to take two slots,
-//     two push launches over 1024 workgroups and two sweeps of the queue build: 35 of 350 us.  With twice the list
-//     capacity of the chain inside a push launch (BFS_CHAIN_CAP_BIG: the LDS is this workgroup's alone) they run here,
-//     back to back, and the traversal ends without another slot.
+//     their own push launches over 1024 workgroups and sweeps of the queue build.  With twice the list capacity of the
+//     chain inside a push launch (BFS_CHAIN_CAP_BIG: the LDS is this workgroup's alone) the levels of up to
+//     chain_big_edges edges run here, back to back, and the traversal ends without another slot.
 // The first level that is not small is left in the SAME slot's queues (bfs_chain_body<., true, .>): the slot's push
 // launch opens it.  Nothing to do (a big level, an empty or lazy slot, the traversal over): returns at once (~2.5 us).
 __global__ __launch_bounds__(1024) void k_bfs_chain_inplace(bfs_fused_args_t a, int arg) {
@@ -530,9 +530,13 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
     // too big for the in-place chain, and chain launches from the first slot on that had a small level in front of it
     // (sources differ, the level structure of a graph hardly does; a wrong guess costs an idle launch or a second batch).
     int k = 0, tail = 1 << 30;
+    u64 reached = 1;                         // (vertices with edges reached before level l runs: what bfs_chain_edge_limit looks at, nearly)
     for (int l = 0; l < lv; ++l) {
       const u64 t = st.host_ctrl->trace[l];
-      const bool small = (t >> BFS_VSHIFT) <= (u64)BFS_CHAIN_CAP_BIG && (t & BFS_EMASK) <= (u64)a.chain_big_edges;
+      if (l > 0) reached += t >> BFS_VSHIFT;
+      const bool late = reached * 4ull >= (u64)(u32)a.n;
+      const u64 lim = late || a.chain_big_edges < BFS_CHAIN_EARLY_EDGES ? a.chain_big_edges : BFS_CHAIN_EARLY_EDGES;
+      const bool small = (t >> BFS_VSHIFT) <= (u64)BFS_CHAIN_CAP_BIG && (t & BFS_EMASK) <= lim;
       if (small) { if (k >= 1 && k < tail) tail = k; }
       else ++k;
     }
