@@ -19,6 +19,11 @@ def graphs():
     k = 0
     while True:
         k += 1
+        if k % 7 == 6:      # big enough for vertices behind the LDS prefix (cold-edge pass): R-MAT 20 / 21, few edges per vertex
+            s = int(rng.integers(20, 22))
+            n, ro, ci, w = orc.rmat_csr(s, int(rng.integers(2, 7)), int(rng.integers(1, 1 << 30)))
+            yield "rmat-%d" % s, n, ro, ci, w
+            continue
         kind = k % 5
         if kind == 0:
             s = int(rng.integers(8, 19))
@@ -101,7 +106,7 @@ for name, n, ro, ci, w in graphs():
     d_ro, d_ci, d_w = torch.from_numpy(ro).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(w).cuda()
     g = mini_amd.Graph.from_device(ctx, n, len(ci), d_ro, d_ci, d_w)
     symmetric = "directed" not in name
-    layout = bool(rng.integers(0, 2))
+    layout = bool(rng.integers(0, 2)) or n > 600000
     if layout:
         g.build_layout(weights=True)
     bfs, sssp = mini_amd.BfsProblem(g, 0), mini_amd.SsspProblem(g, 0)
@@ -112,16 +117,27 @@ for name, n, ro, ci, w in graphs():
         # whenever the frontier bitmap allows)
         for direct in ("1", "0"):
             os.environ["MGX_BFS_CHAIN_MAX_EDGES"] = str(int(rng.choice([0, 1, 64, 6144]))) if direct == "0" else "6144"
-            os.environ["MGX_BFS_DENSE"] = "1000000" if direct == "0" else str(int(rng.choice([0, 16])))
+            os.environ["MGX_BFS_DENSE"] = "1000000" if direct == "0" else str(int(rng.choice([0, 2, 16])))
+            # ... and this round's: lazy queues, vertex-by-vertex short rows, deferred marks, in-place chain launches, cold pass
+            knobs = {"MGX_BFS_LAZY": rng.choice(["", "0", "4", "1048576"]), "MGX_BFS_VSHORT": rng.choice(["", "0", "1000000"]),
+                     "MGX_BFS_DEFER": rng.choice(["", "0", "1", "2048"]), "MGX_BFS_SEED_CHAIN": rng.choice(["", "0"]),
+                     "MGX_BFS_TAIL_CHAIN": rng.choice(["", "0"]), "MGX_BFS_CHAIN_BIG_EDGES": rng.choice(["", "100", "12288"]),
+                     "MGX_BFS_COLD": rng.choice(["", "0", "2"]), "MGX_BFS_DEFER_REACH": rng.choice(["", "0/1", "4/1"])}
+            for kk, vv in knobs.items():
+                if vv == "":
+                    os.environ.pop(kk, None)
+                else:
+                    os.environ[kk] = str(vv)
             st = bfs.run(src)
-            assert np.array_equal(bfs.labels(), want), (name, n, src, "push", direct, layout)
+            assert np.array_equal(bfs.labels(), want), (name, n, src, "push", direct, layout, knobs)
             assert st["m_t"] == int(deg[want >= 0].sum()), (name, n, src, "m_t", direct, layout)
             if symmetric:
                 alpha = float(10.0 ** rng.uniform(-2, 4))
                 bfs.run(src, mode=mini_amd.MGX_BFS_DIRECTION_OPT, alpha=alpha)
                 assert np.array_equal(bfs.labels(), want), (name, n, src, "do", alpha, direct, layout)
-        os.environ.pop("MGX_BFS_CHAIN_MAX_EDGES", None)
-        os.environ.pop("MGX_BFS_DENSE", None)
+        for kk in ("MGX_BFS_CHAIN_MAX_EDGES", "MGX_BFS_DENSE", "MGX_BFS_LAZY", "MGX_BFS_VSHORT", "MGX_BFS_DEFER", "MGX_BFS_SEED_CHAIN",
+                   "MGX_BFS_TAIL_CHAIN", "MGX_BFS_CHAIN_BIG_EDGES", "MGX_BFS_COLD", "MGX_BFS_DEFER_REACH"):
+            os.environ.pop(kk, None)
         if src == srcs[0] and n <= 150000:
             G = int(rng.choice([2, 3, 5, 8]))
             mode = str(rng.choice(["gather", "reduce"]))
