@@ -136,6 +136,8 @@ struct bfs_fused_args_t {
   u32* flush_buf;          // BFS_FLUSH_MAX buffers of BFS_FLUSH_WORDS words (NULL: hot marks are never deferred)
   u32 defer_min_marks;     // a workgroup with more deferred discoveries than this flushes them as a bitmap (else: byte marks)
   u32 defer_reach_mul, defer_reach_div;   // a level defers while reached * mul < deferred range * div (1 / 1; MGX_BFS_DEFER_REACH="mul/div")
+  int lazy_pull;           // direction-optimising runs: the builds behind bottom-up levels write no queues
+  int merged_pull;         // direction-optimising runs: the bottom-up sweep runs inside the push launch (no k_bfs_pull_level launch)
   int combine;             // merged push launch: a slot that takes both dense paths runs them in the same workgroups
   int interleave;          // merged push launch: even workgroups take the long rows, odd ones the short rows (instead of first half / second half)
   int build_diag;          // measurements only (MGX_BFS_BUILD_DIAG; results wrong): 1 no label stores, 2 no extent gathers, 4 no cursor atomics
@@ -655,7 +657,9 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
   int slot, level;
   bfs_resolve(c, arg, slot, level);
   if (c->done || c->skip_build[slot & 3]) return;
-  const bool lazy = bfs_build_is_lazy(a, slot);
+  // (direction-optimising runs: once the traversal has switched to bottom-up levels it stays there, and those read the
+  //  frontier bitmap: no queue is ever needed again)
+  const bool lazy = bfs_build_is_lazy(a, slot) || (a.lazy_pull && c->pull);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     c->fb_slot = slot + 1;                                             // frontier_bits: written in full below
     c->lazy_slot = lazy ? slot + 1 : -1;

@@ -41,14 +41,21 @@ constexpr size_t bfs_chain_lds_bytes(int cap = BFS_CHAIN_CAP) {
 // in a traversal nearly every edge is one (limit BFS_CHAIN_EARLY_EDGES edges); once a quarter of the vertices is reached
 // the peak is over and the stragglers' edges mostly end at visited vertices (limit: max_edges).
 constexpr u32 BFS_CHAIN_EARLY_EDGES = 1536;
+// the direction rule of bfs_level_pulls for a frontier of nf vertices with `reached` vertices labelled
+__device__ __forceinline__ bool bfs_rule_pulls(const bfs_fused_args_t& a, u64 reached, u64 nf) {
+  const float unvisited = (float)((long long)a.n - (long long)reached);
+  return unvisited < (float)(long long)nf * a.alpha;
+}
 __device__ __forceinline__ u32 bfs_chain_edge_limit(const bfs_fused_args_t& a, u64 reached, u32 max_edges) {
   const bool late = reached * 4ull >= (u64)(u32)a.n;
   return late || max_edges < BFS_CHAIN_EARLY_EDGES ? max_edges : BFS_CHAIN_EARLY_EDGES;
 }
 __device__ __forceinline__ bool bfs_level_is_chained(const bfs_fused_args_t& a, u64 cur, u64 lcur, u64 ledges, u32 max_edges, int list_cap = BFS_CHAIN_CAP) {
-  if (a.mode != 0 || max_edges == 0u) return false;
+  if (max_edges == 0u) return false;
   const u64 nf = (cur >> BFS_VSHIFT) + (lcur >> BFS_VSHIFT);
   const u64 E = (cur & BFS_EMASK) + ledges;
+  // direction-optimising runs: only top-down levels are chained (the rule of bfs_level_pulls, same inputs)
+  if (a.mode == 1 && (a.ctrl->pull || bfs_rule_pulls(a, a.ctrl->reached, nf))) return false;
   const u32 lim = bfs_chain_edge_limit(a, a.ctrl->reached, max_edges);
   const u64 cap = lim < (u32)list_cap ? lim : (u32)list_cap;
   return nf <= (u64)list_cap && E <= cap;
@@ -221,13 +228,15 @@ __device__ __forceinline__ void bfs_chain_body(const bfs_fused_args_t& a, int sl
       const u64 reached_now = c->reached + (u64)W;
       c->reached = reached_now;
       s_i[1] = (int)bfs_chain_edge_limit(a, reached_now, lim_e);      // what the next level may hold to be chained too
+      s_i[2] = (a.mode == 1 && bfs_rule_pulls(a, reached_now, (u64)nf2)) ? 1 : 0;   // direction-optimising: the next level is a bottom-up one
       if (a.count_marks) { c->claims += (u64)W; if (level < 64) c->claims_level[level] += (u64)W; }
     }
     __syncthreads();
 
     const u32 max_l = (u32)s_i[1];
     const u32 max_e = max_l < (u32)CAP ? max_l : (u32)CAP;
-    if (nf2 != 0 && (run & DEGMASK) <= (u64)max_e) {     // the next level is small too: keep going
+    const bool next_pulls = s_i[2] != 0;
+    if (nf2 != 0 && (run & DEGMASK) <= (u64)max_e && !next_pulls) {     // the next level is small too (and top-down): keep going
       nf = nf2;
       E = E2;
       level += 1;
@@ -263,7 +272,7 @@ __device__ __forceinline__ void bfs_chain_body(const bfs_fused_args_t& a, int sl
     }
     // ... and, when that level will read its long rows from the unit blocks (bfs_long_is_dense's rule), its frontier as
     // a bitmap -- what k_bfs_build leaves behind a device-wide level: s_win still holds the vertices this level discovered.
-    if (nf2 != 0 && a.ub_col && a.dense_div && ((tot_l & DEGMASK) >> 6) * (u64)a.dense_div >= (u64)a.ub_units) {
+    if (nf2 != 0 && (next_pulls || (a.ub_col && a.dense_div && ((tot_l & DEGMASK) >> 6) * (u64)a.dense_div >= (u64)a.ub_units))) {
       uint4* const fb4 = (uint4*)a.frontier_bits;
       const int quads = (a.n + 127) / 128;
       for (int i = threadIdx.x; i < quads; i += NT) fb4[i] = make_uint4(0u, 0u, 0u, 0u);

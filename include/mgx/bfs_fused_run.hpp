@@ -66,7 +66,7 @@ constexpr size_t bfs_push_lds_bytes() {
 // what a slot's push launch does, derived by every workgroup from the same stable inputs
 struct bfs_slot_plan_t {
   int slot, level;
-  bool empty, chained, dense, vshort, cold, colds;
+  bool empty, chained, dense, vshort, cold, colds, pulls;
 };
 __device__ __forceinline__ bfs_slot_plan_t bfs_slot_plan(const bfs_fused_args_t& a, int arg) {
   const bfs_ctrl_t* const c = a.ctrl;
@@ -76,6 +76,7 @@ __device__ __forceinline__ bfs_slot_plan_t bfs_slot_plan(const bfs_fused_args_t&
   p.empty = ((cur | lcur) >> BFS_VSHIFT) == 0 || c->done;
   p.chained = !p.empty && bfs_level_is_chained(a, cur, lcur, ledges);
   const bool pulls = bfs_level_pulls(a, c, p.slot);
+  p.pulls = !p.empty && pulls;
   p.dense = !p.empty && !p.chained && !pulls && bfs_long_is_dense(a, c, p.slot, lcur);
   p.vshort = !p.empty && !p.chained && !pulls && bfs_short_is_dense(a, c, p.slot, cur);
   // the long rows' cold entries go through the pair lists (bfs_fused_cold.hpp) when the frontier holds enough long rows to
@@ -123,6 +124,15 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
   }
   if ((PART == 0 || PART == 1) && blockIdx.x == 0 && threadIdx.x == 0) bfs_slot_open(a, p);
   if (p.empty || PART == 1) return;
+  if (p.pulls) {
+    // a bottom-up level of a direction-optimising run: the whole grid sweeps the vertices (bfs_fused_pull.hpp) -- inside this
+    // launch unless the host asked for the sweep as a launch of its own (a.merged_pull == 0)
+    if (a.merged_pull && PART != 3) {
+      extern __shared__ __attribute__((aligned(16))) char smem_pull[];
+      bfs_pull_body<1024>(a, blockIdx.x, gridDim.x, (unsigned long long*)smem_pull);
+    }
+    return;
+  }
   // Which part this workgroup takes: (graphs with cold-edge lists) BFS_COLD_WGS workgroups of the cold pass, then nstream
   // workgroups for the long rows, the others the short rows.
   // (interleave: even / odd instead, so that the two parts share every CU -- an experiment that lost, see bfs_run_opts_t)
@@ -235,6 +245,8 @@ struct bfs_run_opts_t {
   long long chain = -1;    // MGX_BFS_CHAIN_MAX_EDGES: 0 never (default BFS_CHAIN_CAP)
   int defer_mul = 1, defer_div = 1;   // MGX_BFS_DEFER_REACH="mul/div": a level defers its hot marks while reached * mul < range * div
                                       // (RMAT-22, ms per traversal: 4/1 0.3627, 2/1 0.3600, 1/1 0.3521, 2/3 0.3511, 1/3 0.3530, 1/8 0.3625, always 0.3641)
+  int do_chain = 1;        // MGX_BFS_DO_CHAIN=0: direction-optimising runs keep every level device-wide (no chains of small top-down levels)
+  int merged_pull = 1;     // MGX_BFS_MERGED_PULL=0: the bottom-up sweep as a launch of its own behind every push launch
   int seed_chain = 1;      // MGX_BFS_SEED_CHAIN=0: no in-place chain launches at all (small levels run inside the slots' push launches)
   int tail_chain = 1;      // MGX_BFS_TAIL_CHAIN=0: ... only the one at the start
   int chain_big = -1;      // MGX_BFS_CHAIN_BIG_EDGES: largest level of an in-place chain launch
@@ -283,6 +295,8 @@ struct bfs_run_opts_t {
       else if (is("COLD")) o.cold = atoi(val);
       else if (is("DEFER_REACH")) { o.defer_mul = atoi(val); const char* sl = strchr(val, '/'); o.defer_div = sl ? atoi(sl + 1) : 1; if (o.defer_div < 1) o.defer_div = 1; }
       else if (is("SEED_CHAIN")) o.seed_chain = atoi(val);
+      else if (is("MERGED_PULL")) o.merged_pull = atoi(val);
+      else if (is("DO_CHAIN")) o.do_chain = atoi(val);
       else if (is("TAIL_CHAIN")) o.tail_chain = atoi(val);
       else if (is("CHAIN_BIG_EDGES")) o.chain_big = atoi(val);
       else if (is("LAZY")) { o.lazy = atoi(val); if (o.lazy > (1 << 20)) o.lazy = 1 << 20; }   // (edges < 2^38: no overflow)
@@ -367,6 +381,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.vs_div = !vs ? 0u : (opt.vshort >= 0 ? (u32)opt.vshort : st.vshort_div);
   if (!st.slot_marks.size()) st.slot_marks = mem_t<u32>((size_t)2 * BFS_MARK_CTRS * BFS_MARK_STRIDE, ctx);
   a.slot_marks = st.slot_marks.data();
+  a.merged_pull = (mode == 1 && opt.merged_pull && opt.merged && !a.flags) ? 1 : 0;
   a.dense_diag = opt.dense_diag;
   a.build_diag = opt.build_diag;
   a.interleave = opt.interleave;
@@ -377,7 +392,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.flush_buf = (defer > 0 && !a.flags) ? st.flush_buf.data() : nullptr;
   a.defer_min_marks = (u32)defer;
   a.defer_reach_mul = (u32)opt.defer_mul; a.defer_reach_div = (u32)opt.defer_div;
-  a.chain_max_edges = mode != 0 ? 0u : (opt.chain >= 0 ? (u32)(opt.chain > BFS_CHAIN_CAP ? BFS_CHAIN_CAP : opt.chain) : st.chain_max_edges);
+  a.chain_max_edges = (mode != 0 && !opt.do_chain) ? 0u : (opt.chain >= 0 ? (u32)(opt.chain > BFS_CHAIN_CAP ? BFS_CHAIN_CAP : opt.chain) : st.chain_max_edges);
   const long long nwords = ((long long)st.n + 31) / 32;
   hipLaunchKernelGGL(k_bfs_fused_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src, nwords);
   // in-place chain launches (k_bfs_chain_inplace): in front of slot 0, of the slots from tail_from on, behind a batch
@@ -413,6 +428,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   if (cold && !st.cold_flush.size()) st.cold_flush = mem_t<u32>((size_t)BFS_COLD_WGS * BFS_COLD_WORDS, ctx);
   a.cold_flush = cold ? st.cold_flush.data() : nullptr;
   // lazy queues (bfs_build_is_lazy): only k_bfs_build2 knows them, and only when both queue-less bodies are available
+  a.lazy_pull = (mode == 1 && build2_ok && !opt.build_list && opt.lazy != 0) ? 1 : 0;
   a.lazy_div = (a.dense_div && a.vs_div && mode == 0 && build2_ok && !opt.build_list) ? (opt.lazy >= 0 ? (u32)opt.lazy : st.lazy_div) : 0u;
   const bool batch_events = st.time_kernels != 0 || st.time_batches;    // (an event costs ~6 us of stream gap)
   const u32 nstream = a.long_min > 0 ? (u32)ctx.num_cus * 2 : 0u;
@@ -451,7 +467,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
       } else {
         bfs_launch_push_part<0>(a, arg, ctx, coldt, nstream + ncold + nwave, nstream);
       }
-      if (mode == 1)
+      if (mode == 1 && !a.merged_pull)
         hipLaunchKernelGGL(k_bfs_pull_level<256>, dim3(ctx.num_cus * 8), dim3(256), 0, s, a, arg);
       if (opt.build_list || !build2_ok)
         hipLaunchKernelGGL((k_bfs_build<512, true>), dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, arg,
@@ -530,13 +546,19 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
     // too big for the in-place chain, and chain launches from the first slot on that had a small level in front of it
     // (sources differ, the level structure of a graph hardly does; a wrong guess costs an idle launch or a second batch).
     int k = 0, tail = 1 << 30;
+    bool pulled = false;
     u64 reached = 1;                         // (vertices with edges reached before level l runs: what bfs_chain_edge_limit looks at, nearly)
     for (int l = 0; l < lv; ++l) {
       const u64 t = st.host_ctrl->trace[l];
       if (l > 0) reached += t >> BFS_VSHIFT;
       const bool late = reached * 4ull >= (u64)(u32)a.n;
       const u64 lim = late || a.chain_big_edges < BFS_CHAIN_EARLY_EDGES ? a.chain_big_edges : BFS_CHAIN_EARLY_EDGES;
-      const bool small = (t >> BFS_VSHIFT) <= (u64)BFS_CHAIN_CAP_BIG && (t & BFS_EMASK) <= lim;
+      bool small = (t >> BFS_VSHIFT) <= (u64)BFS_CHAIN_CAP_BIG && (t & BFS_EMASK) <= lim;
+      if (mode == 1) {                       // direction-optimising: bottom-up levels (and everything behind the first) are device-wide
+        const float unvisited = (float)((long long)a.n - (long long)reached);
+        if (unvisited < (float)(long long)(t >> BFS_VSHIFT) * a.alpha) pulled = true;
+        if (pulled) small = false;
+      }
       if (small) { if (k >= 1 && k < tail) tail = k; }
       else ++k;
     }
