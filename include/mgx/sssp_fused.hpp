@@ -412,6 +412,106 @@ __global__ __launch_bounds__(NT) void k_sssp_build(sssp_args_t a, int it) {
   }
 }
 
+// The same without the detour through a list (k_bfs_build2's shape): a thread's 16 vertices are consecutive, so their row
+// extents are ONE contiguous piece (17 offsets, 16-byte loads) read by every thread that found a mark; one packed
+// workgroup scan gives the positions, a thread writes its own queue entries.  Three barriers instead of the list's
+// redistribution and its two scans per batch: 28 -> ~10 us for the light iterations at the end of an RMAT-22 run.
+// Needs row_offsets 16-byte aligned (the host checks).
+template <int NT>
+__global__ __launch_bounds__(NT, 4) void k_sssp_build2(sssp_args_t a, int it) {
+  constexpr int NW = NT / WAVE;
+  constexpr u64 CNT1 = 1ull << 40;
+  constexpr u64 DEGMASK = CNT1 - 1ull;
+  __shared__ u64 s_scan[NW + 1];
+  __shared__ u64 s_base;
+  bfs_ctrl_t* const c = a.ctrl;
+  if (c->done) return;
+  const long long i0 = (((long long)blockIdx.x + (long long)(threadIdx.x >> 6) * gridDim.x) * 64 + (threadIdx.x & 63)) * 16;
+  u32 new16 = 0;
+  u32 far_n = 0, far_lo = SSSP_INF_BITS;
+  if (i0 < a.n) {
+    const u32 valid = (a.n - i0 >= 16) ? 0xFFFFu : ((1u << (int)(a.n - i0)) - 1u);
+    uint4* mp = (uint4*)(a.mark + i0);
+    const uint4 m = *mp;
+    if (m.x | m.y | m.z | m.w) {
+      const u32 x[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) new16 |= (((x[q] & 0x01010101u) * 0x10204080u) >> 28) << (4 * q);
+      new16 &= valid;
+      uint4 keep = make_uint4(0, 0, 0, 0);
+      if (a.delta > 0.f) {
+        // near / far: only distances below the threshold enter the queue now; the others keep their mark
+        const u32 thr = c->sssp_thr;
+        u32 far16 = 0;
+        for (u32 rest = new16; rest;) {
+          const int q = __ffs((int)rest) - 1;
+          rest &= rest - 1;
+          const u32 d = a.dist[i0 + q];
+          if (d >= thr) { far16 |= 1u << q; far_lo = d < far_lo ? d : far_lo; }
+        }
+        new16 &= ~far16;
+        far_n = (u32)__popc(far16);
+        u32 kb[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) kb[q >> 2] |= ((far16 >> q) & 1u) << (8 * (q & 3));
+        keep = make_uint4(kb[0], kb[1], kb[2], kb[3]);
+      }
+      *mp = keep;
+    }
+  }
+  if (a.delta > 0.f) {               // (grid-uniform) what stays behind: count and smallest distance, one atomic pair per wave
+    const u32 wn = wave_sum(far_n);
+    u32 wl = far_lo;
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) { const u32 o = (u32)__shfl_xor((int)wl, d, WAVE); wl = o < wl ? o : wl; }
+    if ((threadIdx.x & (WAVE - 1)) == 0 && wn) {
+      atomicAdd(&c->sssp_far_cnt[(it + 1) & 1], wn);
+      atomicMin(&c->sssp_far_min[(it + 1) & 1], wl);
+    }
+  }
+  // my vertices' row extents: contiguous
+  u32 ro[17];
+  u64 sum = 0;
+  if (new16) {
+    if (i0 + 16 < (long long)a.n) {
+      const u32* const p = a.row_offsets + i0;
+      const uint4 r0 = *(const uint4*)p, r1 = *(const uint4*)(p + 4), r2 = *(const uint4*)(p + 8), r3 = *(const uint4*)(p + 12);
+      ro[0] = r0.x; ro[1] = r0.y; ro[2] = r0.z; ro[3] = r0.w; ro[4] = r1.x; ro[5] = r1.y; ro[6] = r1.z; ro[7] = r1.w;
+      ro[8] = r2.x; ro[9] = r2.y; ro[10] = r2.z; ro[11] = r2.w; ro[12] = r3.x; ro[13] = r3.y; ro[14] = r3.z; ro[15] = r3.w;
+      ro[16] = p[16];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 17; ++q) ro[q] = a.row_offsets[(i0 + q <= (long long)a.n) ? i0 + q : (long long)a.n];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const u32 deg = ro[q + 1] - ro[q];
+      if (((new16 >> q) & 1u) && deg) sum += CNT1 | (u64)deg;
+    }
+  }
+  u64 tot;
+  u64 ex = block_exclusive_sum_lean<NW>(sum, s_scan, &tot);
+  if ((tot >> 40) == 0) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(&c->cursor[(it + 1) % 3], ((tot >> 40) << BFS_VSHIFT) | (tot & DEGMASK));
+  __syncthreads();
+  if (!new16) return;
+  const u64 base = s_base;
+  u32* __restrict__ const out_row = a.q_row[(it + 1) & 1];
+  u32* __restrict__ const out_off = a.q_off[(it + 1) & 1];
+  u32* __restrict__ const out_du = a.q_du[(it + 1) & 1];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const u32 deg = ro[q + 1] - ro[q];
+    if (((new16 >> q) & 1u) && deg) {
+      const u64 slot = (base >> BFS_VSHIFT) + (ex >> 40);
+      out_row[slot] = ro[q];
+      out_off[slot] = (u32)((base & BFS_EMASK) + (ex & DEGMASK));
+      out_du[slot] = (u32)(i0 + q);
+      ex += CNT1 | (u64)deg;
+    }
+  }
+}
+
 // dist_out[old_of_new[v]] = dist_layout[v]
 __global__ __launch_bounds__(BLOCK) void k_sssp_unpermute(const u32* __restrict__ dist_layout, const int* __restrict__ old_of_new,
                                                          u32* __restrict__ dist_out, long long n) {
@@ -460,6 +560,8 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   a.n = st.n;
   a.delta = st.delta;
   if (const char* de = getenv("MGX_SSSP_DELTA")) a.delta = (float)atof(de);
+  const char* const bl = getenv("MGX_SSSP_BUILD_LIST");            // (=1: the list-based queue build, k_sssp_build)
+  const bool build2 = !(bl && atoi(bl) != 0) && ((uintptr_t)a.row_offsets % 16 == 0);
   const char* const hme = getenv("MGX_SSSP_HOT_MIN_EDGES");        // (tests force the LDS bounds on small graphs)
   a.hot_min_edges = hme ? (u32)atoll(hme) : SSSP_HOT_MIN_EDGES;
   hipLaunchKernelGGL(k_sssp_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src,
@@ -473,7 +575,8 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
     const int nit = batch == 0 ? st.iters_hint : 2;
     for (int i = 0; i < nit; ++i, ++it) {
       hipLaunchKernelGGL(k_sssp_relax<1024>, dim3(ctx.num_cus * 2), dim3(1024), SSSP_HOTN * 2, s, a, it);
-      hipLaunchKernelGGL(k_sssp_build<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, it);
+      if (build2) hipLaunchKernelGGL(k_sssp_build2<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, it);
+      else hipLaunchKernelGGL(k_sssp_build<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, it);
     }
     MGX_CHECK_LAUNCH("fused SSSP: kernel launch");
     MGX_HIP(hipMemcpyAsync(st.host_ctrl, st.ctrl.data(), offsetof(bfs_ctrl_t, trace) + 64 * sizeof(u64), hipMemcpyDeviceToHost, s));
