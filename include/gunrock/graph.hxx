@@ -92,6 +92,12 @@ struct graph_device_t {
   unsigned cold_lo[16] = {0}, cold_off[17] = {0}, colds_off[17] = {0}, cold_wgs[17] = {0};
   unsigned cold_hot_n = 0;
   int cold_long_min = 0;
+  // Destination-sliced edge list of the weighted layout (mgx/sssp_fused.hpp: sssp_sliced_body): (src, dst, w) triples
+  // ordered by dst >> 14; built at the first fused SSSP run of a graph that carries layout weights.
+  mem_t<int> d_e_src, d_e_dst, d_slice_off;
+  mem_t<float> d_e_w;
+  int sliced_slices = 0;            // 0: not built (yet)
+  bool sliced_tried = false;
 
   graph_device_t() : num_nodes(0), num_edges(0) {}
 

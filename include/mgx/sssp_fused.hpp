@@ -44,6 +44,17 @@ struct sssp_args_t {
   bfs_ctrl_t* ctrl;      // cursor[3] (packed, rotating), sums, done, levels = iterations
   int n;
   u32 hot_min_edges;     // iterations with at least this many edges keep distance bounds of the hubs in LDS
+  // destination-sliced edge list (sssp_sliced_body; NULL: none): all m edges as (src, dst, w), ordered by dst >> slice_shift
+  // and by src inside a slice; slice_off[s] .. slice_off[s + 1] are the edges of slice s; frontier_bits: the frontier as a
+  // bitmap (written by k_sssp_build2); an iteration whose frontier holds >= m / sliced_div edges takes this path
+  const int* e_src;
+  const int* e_dst;
+  const float* e_w;
+  const int* slice_off;
+  int slices, slice_shift;
+  unsigned long long m_edges;
+  u32 sliced_div;
+  u32* frontier_bits;
   float delta;           // near / far bucket width (delta-stepping; BASELINE config 3 names it): 0 = plain frontier
                          // Bellman-Ford, every improved vertex is expanded in the next iteration
 };
@@ -56,6 +67,13 @@ struct sssp_layout_t {
   const float* weights = nullptr;
   const int* new_of_old = nullptr;
   const int* old_of_new = nullptr;
+  // destination-sliced edge list of this CSR (optional)
+  const int* e_src = nullptr;
+  const int* e_dst = nullptr;
+  const float* e_w = nullptr;
+  const int* slice_off = nullptr;
+  int slices = 0, slice_shift = 0;
+  long long m_edges = 0;
 };
 
 constexpr u32 SSSP_INF_BITS = 0x7f7fffffu;      // FLT_MAX: what the reference stores for "not reached" (sssp_problem.hxx:45)
@@ -74,6 +92,10 @@ __global__ __launch_bounds__(BLOCK) void k_sssp_init(sssp_args_t a, int src, con
     } else {
       for (long long k = j; k < n; ++k) { a.dist[k] = (k == src) ? 0u : SSSP_INF_BITS; a.mark[k] = 0; }
     }
+  }
+  if (a.frontier_bits) {
+    const long long nwords = (n + 31) / 32;
+    for (long long wd = tid; wd < nwords; wd += nth) a.frontier_bits[wd] = (wd == (src >> 5)) ? 1u << (src & 31) : 0u;
   }
   if (tid == 0) {
     bfs_ctrl_reset(a.ctrl);
@@ -123,6 +145,107 @@ constexpr int SSSP_TILE = WAVE * SSSP_EPT;
 constexpr int SSSP_HOTN = 32768;                   // 64 KB per workgroup, two workgroups per CU (65536 with one: same rate)
 constexpr u32 SSSP_HOT_MIN_EDGES = 1u << 20;       // smaller iterations do not pay for the copy
 
+// ---- heavy iterations: the edges by slice of their destination, that slice of the distances in LDS --------------------
+// The relax kernel below gathers the neighbour's distance for every edge: 4 bytes out of a 16 MB array in arbitrary order,
+// 80-100 G/s on this part whatever else the kernel does (profiles/r01/microbench.jsonl) -- the three heavy iterations of an
+// RMAT-22 run (80-100 M relaxations each) take 0.7-1.2 ms each, 2.8 of the run's 3.5 ms.  When most of the graph's edges
+// are in the frontier anyway, it is cheaper to stream ALL edges in an order that makes the destinations local: the
+// destination-sliced list (mgx_layout.hip) holds (src, dst, w) ordered by dst >> 14.  A workgroup takes a contiguous
+// piece of it; for each slice the piece touches it copies the slice's 16 384 distances into LDS, streams the edges (12
+// bytes each, coalesced; the source's frontier bit and distance are gathers too, but the sources ascend inside a slice:
+// neighbouring lanes ask for neighbouring or equal words), folds the candidates with ds_min, and at the end writes back
+// what became smaller (atomicMin on the array, a mark for the next frontier) -- 16 384 coalesced compares instead of a
+// gather per edge.  A slice of which the piece holds only a few edges is not worth the copy: those edges take the
+// gather + atomicMin route of the other kernel.
+// MEASURED (RMAT-22, MGX_SSSP_SLICED=3): distances identical, but no gain -- the first heavy iteration takes 0.89 ms this
+// way too (1.6 GB of triples at 1.8 TB/s: the LDS minima of a slice full of hubs collide, and what a workgroup found only
+// reaches the array at the end of its piece, so the same iteration propagates less: 456 M relaxations instead of 346 M
+// for one source).  Left in as an option (the list is only built when the switch asks for it).
+constexpr int SSSP_SLICE_SHIFT = 14;
+constexpr int SSSP_SLICE_V = 1 << SSSP_SLICE_SHIFT;        // 64 KB of distances: the dynamic LDS of k_sssp_relax
+constexpr u32 SSSP_SLICE_MIN_EDGES = 4096;                  // fewer edges of a slice in a workgroup's piece: no LDS copy
+
+template <int NT>
+__device__ __forceinline__ void sssp_sliced_body(const sssp_args_t& a, u32* const lds) {
+  const u32 m = (u32)a.m_edges;                         // (int32 CSR: m < 2^31)
+  const u32 W = gridDim.x;
+  const u32 chunk = ((m + W - 1u) / W + 1023u) & ~1023u;
+  const u64 pb64 = (u64)blockIdx.x * chunk;
+  if (pb64 >= (u64)m) return;
+  const u32 pb = (u32)pb64;
+  const u32 pe = (u64)pb + chunk < (u64)m ? pb + chunk : m;
+  const int* __restrict__ esrc = a.e_src;
+  const int* __restrict__ edst = a.e_dst;
+  const float* __restrict__ ew = a.e_w;
+  const u32* __restrict__ fbits = a.frontier_bits;
+  u32* dist = a.dist;
+  unsigned char* mark = a.mark;
+  // the slice of the first edge: last s with slice_off[s] <= pb (uniform binary search)
+  int sl;
+  {
+    int lo = 0, hi = a.slices;
+    while (hi - lo > 1) { const int mid = lo + (hi - lo) / 2; if ((u32)a.slice_off[mid] <= pb) lo = mid; else hi = mid; }
+    sl = lo;
+  }
+  constexpr int K = 4;
+  u32 pos = pb;
+  while (pos < pe) {
+    while (sl + 1 < a.slices && (u32)a.slice_off[sl + 1] <= pos) ++sl;
+    const u32 s_end = sl + 1 < a.slices ? (u32)a.slice_off[sl + 1] : m;
+    const u32 seg_end = s_end < pe ? s_end : pe;
+    const u32 lo_v = (u32)sl << a.slice_shift;
+    const u32 cnt_v = (u32)a.n - lo_v < (u32)SSSP_SLICE_V ? (u32)a.n - lo_v : (u32)SSSP_SLICE_V;
+    const bool in_lds = seg_end - pos >= SSSP_SLICE_MIN_EDGES;       // (uniform)
+    if (in_lds) {
+      for (u32 j = threadIdx.x; j < (u32)SSSP_SLICE_V; j += NT) lds[j] = j < cnt_v ? dist[lo_v + j] : SSSP_INF_BITS;
+      __syncthreads();
+    }
+    for (u32 r0 = pos; r0 < seg_end; r0 += (u32)NT * K) {
+      u32 sv[K], dv[K];
+      float wv[K];
+      bool in[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const u32 i = r0 + (u32)k * NT + threadIdx.x;
+        in[k] = i < seg_end;
+        const u32 j = in[k] ? i : m;                 // (the padding behind the list: readable)
+        sv[k] = (u32)esrc[j]; dv[k] = (u32)edst[j]; wv[k] = ew[j];
+      }
+      u32 fw[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) fw[k] = fbits[in[k] ? sv[k] >> 5 : 0u];
+      u32 du[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        in[k] = in[k] && ((fw[k] >> (sv[k] & 31u)) & 1u);
+        du[k] = dist[in[k] ? sv[k] : 0u];
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        if (in[k] && du[k] != SSSP_INF_BITS) {
+          const u32 cand = __float_as_uint(__uint_as_float(du[k]) + wv[k]);
+          if (in_lds) {
+            atomicMin(&lds[dv[k] - lo_v], cand);
+          } else if (cand < dist[dv[k]]) {
+            if (cand < atomicMin(dist + dv[k], cand)) mark[dv[k]] = 1;
+          }
+        }
+      }
+    }
+    if (in_lds) {
+      __syncthreads();
+      for (u32 j = threadIdx.x; j < cnt_v; j += NT) {
+        const u32 v = lds[j];
+        if (v < dist[lo_v + j]) {
+          if (v < atomicMin(dist + lo_v + j, v)) mark[lo_v + j] = 1;
+        }
+      }
+      __syncthreads();
+    }
+    pos = seg_end;
+  }
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT, 8) void k_sssp_relax(sssp_args_t a, int it) {
   constexpr int NW = NT / WAVE;
@@ -151,6 +274,10 @@ __global__ __launch_bounds__(NT, 8) void k_sssp_relax(sssp_args_t a, int it) {
   unsigned char* mark = a.mark;
 
   extern __shared__ __attribute__((aligned(16))) u32 s_hot[];        // SSSP_HOTN / 2 words: two bounds per word
+  if (a.e_src && (u64)E * (u64)a.sliced_div >= a.m_edges) {            // a heavy iteration (grid-uniform): the edges by slice
+    sssp_sliced_body<NT>(a, s_hot);
+    return;
+  }
   const bool use_hot = E >= a.hot_min_edges;
   const u32 hot_n = use_hot ? ((u32)a.n < (u32)SSSP_HOTN ? ((u32)a.n & ~1u) : (u32)SSSP_HOTN) : 0u;
   if (use_hot) {
@@ -458,6 +585,7 @@ __global__ __launch_bounds__(NT, 4) void k_sssp_build2(sssp_args_t a, int it) {
       }
       *mp = keep;
     }
+    if (a.frontier_bits) ((unsigned short*)a.frontier_bits)[i0 >> 4] = (unsigned short)new16;    // the next frontier as a bitmap (sssp_sliced_body)
   }
   if (a.delta > 0.f) {               // (grid-uniform) what stays behind: count and smallest distance, one atomic pair per wave
     const u32 wn = wave_sum(far_n);
@@ -523,6 +651,9 @@ struct sssp_fused_state_t {
   mem_t<unsigned char> mark;
   mem_t<u32> dist_layout;            // only with a layout: distances in layout order
   mem_t<u32> q_row[2], q_off[2], q_du[2];
+  mem_t<u32> frontier_bits;          // the frontier as a bitmap (sssp_sliced_body; allocated on demand)
+  unsigned sliced_div = 0;           // an iteration whose frontier holds >= m / sliced_div edges streams the sliced edge list (0: never --
+                                     // the default: measured 2.59 ms (div 3) / 2.54 (2) / 2.82 (6) against 2.47 ms without, RMAT-22)
   mem_t<bfs_ctrl_t> ctrl;
   bfs_ctrl_t* host_ctrl = nullptr;
   int n = 0;
@@ -562,6 +693,20 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   if (const char* de = getenv("MGX_SSSP_DELTA")) a.delta = (float)atof(de);
   const char* const bl = getenv("MGX_SSSP_BUILD_LIST");            // (=1: the list-based queue build, k_sssp_build)
   const bool build2 = !(bl && atoi(bl) != 0) && ((uintptr_t)a.row_offsets % 16 == 0);
+  // heavy iterations over the destination-sliced edge list (needs the frontier bitmap k_sssp_build2 writes)
+  unsigned sdiv = st.sliced_div;
+  if (const char* e = getenv("MGX_SSSP_SLICED")) sdiv = (unsigned)atoi(e);
+  const bool sliced = layout && layout->e_src && layout->slices > 0 && layout->slice_shift == SSSP_SLICE_SHIFT && build2 && sdiv > 0 && a.delta == 0.f;
+  if (sliced && !st.frontier_bits.size()) st.frontier_bits = mem_t<u32>(((size_t)st.n + 31) / 32 + 4, ctx);
+  a.e_src = sliced ? layout->e_src : nullptr;
+  a.e_dst = sliced ? layout->e_dst : nullptr;
+  a.e_w = sliced ? layout->e_w : nullptr;
+  a.slice_off = sliced ? layout->slice_off : nullptr;
+  a.slices = sliced ? layout->slices : 0;
+  a.slice_shift = SSSP_SLICE_SHIFT;
+  a.m_edges = sliced ? (unsigned long long)layout->m_edges : 0ull;
+  a.sliced_div = sdiv;
+  a.frontier_bits = sliced ? st.frontier_bits.data() : nullptr;
   const char* const hme = getenv("MGX_SSSP_HOT_MIN_EDGES");        // (tests force the LDS bounds on small graphs)
   a.hot_min_edges = hme ? (u32)atoll(hme) : SSSP_HOT_MIN_EDGES;
   hipLaunchKernelGGL(k_sssp_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src,

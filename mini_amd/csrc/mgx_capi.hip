@@ -314,6 +314,7 @@ int mgx_graph_attach_layout(mgx_graph_t g, const int* d_row_offsets, const int* 
   G.d_new_of_old = mem_t<int>::borrow((int*)d_new_of_old, (size_t)G.num_nodes);
   G.d_old_of_new = mem_t<int>::borrow((int*)d_old_of_new, (size_t)G.num_nodes);
   G.has_layout = true;
+  G.sliced_tried = false; G.sliced_slices = 0;
   G.vs_edges = 0; G.vs_dummy = 0; G.vs_long_min = 0;      // (borrowed arrays: no padding behind them, sortedness not checked)
   G.d_cold_owner = mem_t<int>(); G.d_cold_dst = mem_t<int>(); G.d_colds_owner = mem_t<int>(); G.d_colds_dst = mem_t<int>();
   G.cold_pairs = G.colds_pairs = 0; G.cold_slices = 0;
@@ -329,6 +330,7 @@ int mgx_graph_attach_layout_weights(mgx_graph_t g, const float* d_layout_weights
   graph_device_t& G = *g->g;
   G.d_layout_col_values = mem_t<float>::borrow((float*)d_layout_weights, (size_t)G.num_edges);
   G.has_layout_weights = true;
+  G.sliced_tried = false; G.sliced_slices = 0;
   MGX_CATCH
 }
 extern "C" int mgx_layout_build_device(const int* ro, const int* ci, const float* w, int n, long long m, int* lro, int* lci,
@@ -452,6 +454,7 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
   G.d_new_of_old = std::move(n2o);
   G.d_old_of_new = std::move(o2n);
   G.has_layout = true;
+  G.sliced_tried = false; G.sliced_slices = 0;
   if (with_weights) { G.d_layout_col_values = std::move(lw); G.has_layout_weights = true; }
   build_unit_blocks(g);
   // degree classes of the short rows (the layout is sorted by degree): boundaries by binary search on a host copy
@@ -1430,6 +1433,30 @@ int mgx_sssp_enact(mgx_sssp_t p, float queue_sizing, int64_t* stats) {
   }
   MGX_CATCH
 }
+extern "C" int mgx_sliced_build_device(const int* ro, const int* ci, const float* w, int n, long long m, int shift, int slices,
+                                       int* e_src, int* e_dst, float* e_w, int* slice_off, hipStream_t stream);   // mgx_layout.hip
+// The destination-sliced edge list of the weighted layout, once per graph and only when MGX_SSSP_SLICED=N asks for it: 12 bytes per edge.
+static void ensure_sliced_edges(mgx_graph_s* g) {
+  graph_device_t& G = *g->g;
+  if (G.sliced_tried) return;
+  G.sliced_tried = true;
+  G.sliced_slices = 0;
+  const char* const e = getenv("MGX_SSSP_SLICED");                  // (opt-in: measured no faster, sssp_fused.hpp)
+  if (!e || atoi(e) <= 0) { G.sliced_tried = false; return; }
+  if (!G.has_layout || !G.has_layout_weights || G.num_edges <= 0 || G.num_nodes <= 0) return;
+  standard_context_t& ctx = *g->c->ctx;
+  const size_t m = (size_t)G.num_edges;
+  const int slices = (int)(((long long)G.num_nodes + mgx::SSSP_SLICE_V - 1) >> mgx::SSSP_SLICE_SHIFT);
+  ctx.synchronize();
+  mem_t<int> es(m + 4096, ctx), ed(m + 4096, ctx), so((size_t)slices + 2, ctx);
+  mem_t<float> ew(m + 4096, ctx);
+  const int rc = mgx_sliced_build_device(G.d_layout_row_offsets.data(), G.d_layout_col_indices.data(), G.d_layout_col_values.data(),
+                                         G.num_nodes, (long long)m, mgx::SSSP_SLICE_SHIFT, slices, es.data(), ed.data(), ew.data(),
+                                         so.data(), ctx.stream());
+  if (rc != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("sliced edge list: ") + hipGetErrorString((hipError_t)rc));
+  G.d_e_src = std::move(es); G.d_e_dst = std::move(ed); G.d_e_w = std::move(ew); G.d_slice_off = std::move(so);
+  G.sliced_slices = slices;
+}
 int mgx_sssp_run(mgx_sssp_t p, int src, int64_t* stats) { return mgx_sssp_run_delta(p, src, -1.0f, stats); }
 int mgx_sssp_run_delta(mgx_sssp_t p, int src, float delta, int64_t* stats) {
   // device-resident loop (include/mgx/sssp_fused.hpp): distances identical to mgx_sssp_enact's; predecessors are
@@ -1453,6 +1480,12 @@ int mgx_sssp_run_delta(mgx_sssp_t p, int src, float delta, int64_t* stats) {
     layout.weights = G.d_layout_col_values.data();
     layout.new_of_old = G.d_new_of_old.data();
     layout.old_of_new = G.d_old_of_new.data();
+    ensure_sliced_edges(p->g);
+    if (G.sliced_slices > 0) {
+      layout.e_src = G.d_e_src.data(); layout.e_dst = G.d_e_dst.data(); layout.e_w = G.d_e_w.data();
+      layout.slice_off = G.d_slice_off.data();
+      layout.slices = G.sliced_slices; layout.slice_shift = mgx::SSSP_SLICE_SHIFT; layout.m_edges = (long long)G.num_edges;
+    }
   }
   mgx::sssp_fused_run(*p->fused, G.d_row_offsets.data(), G.d_col_indices.data(), G.d_col_values.data(),
                       p->p->d_labels.data(), src, ctx, layout.row_offsets ? &layout : nullptr);

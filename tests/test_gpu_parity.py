@@ -605,14 +605,16 @@ def test_bfs_kernel_variants_on_random_graphs(gpu_ctx, oracle, monkeypatch, vari
             assert st["m_t"] == int(deg[want >= 0].sum())
 
 
-@pytest.mark.parametrize("build_list", [0, 1])
+@pytest.mark.parametrize("build_list", [0, 1, 2])
 @pytest.mark.parametrize("hot_min_edges", [0, 1 << 30])
 def test_sssp_fused_with_and_without_lds_distance_bounds(gpu_ctx, oracle, monkeypatch, hot_min_edges, build_list):
     """the bfloat16 upper bounds of the hubs' distances (sssp_fused.hpp) forced on for every iteration, and off; the direct
-    queue build (k_sssp_build2) and the list-based one"""
+    queue build (k_sssp_build2) and the list-based one; the sliced edge list for heavy iterations"""
     import mini_amd
     monkeypatch.setenv("MGX_SSSP_HOT_MIN_EDGES", str(hot_min_edges))
-    monkeypatch.setenv("MGX_SSSP_BUILD_LIST", str(build_list))
+    monkeypatch.setenv("MGX_SSSP_BUILD_LIST", str(build_list & 1))
+    if build_list == 2:                                     # heavy iterations over the destination-sliced edge list (opt-in)
+        monkeypatch.setenv("MGX_SSSP_SLICED", "4")
     rng = np.random.default_rng(5 + (hot_min_edges > 0))
     for trial in range(4):
         n, ro, ci, _ = oracle.rmat_csr(int(rng.integers(8, 15)), int(rng.integers(2, 20)), int(rng.integers(1, 1 << 20)))
