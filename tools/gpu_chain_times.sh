@@ -1,4 +1,5 @@
 #!/bin/bash
+# durations of the in-place chain launches per traversal (tools/chain_debug.py under a rocprofv3 kernel trace)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/cd; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 $R/tools/chain_debug.py 22 > $O/run.log 2>&1

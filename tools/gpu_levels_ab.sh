@@ -1,4 +1,5 @@
 #!/bin/bash
+# tools/bfs_levels.py (per-level / per-part timing) with and without a switch
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/lv; rm -rf $O; mkdir -p $O; cd $R
 for cfg in "" "MGX_BFS_COLD=0"; do
   for kv in $cfg; do export "$kv"; done

@@ -1,4 +1,6 @@
 #!/bin/bash
+# parity subset (tests/test_gpu_parity.py, test_gpu_configs.py), then tools/bfs_ab.py on RMAT-22 over the switch settings in $1
+#   gpurun -- bash tools/gpu_parity_ab.sh ";MGX_BFS_COLD=0" [noparity]
 ulimit -c 0
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r2l; rm -rf $O; mkdir -p $O

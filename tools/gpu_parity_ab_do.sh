@@ -1,4 +1,5 @@
 #!/bin/bash
+# parity subset, then tools/bfs_ab.py in direction-optimising mode at alpha 16 / 64 / 256 over the switch settings in $1
 ulimit -c 0
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r2do; rm -rf $O; mkdir -p $O

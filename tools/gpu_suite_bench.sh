@@ -1,4 +1,5 @@
 #!/bin/bash
+# the whole GPU suite, two bench.py runs and a direction-optimising one
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2b; rm -rf $O; mkdir -p $O; cd $R
 timeout 1800 python -m pytest tests -q -x -m gpu --timeout 900 > $O/pytest_gpu.log 2>&1
 echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log

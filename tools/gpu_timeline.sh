@@ -1,6 +1,6 @@
 #!/bin/bash
 # timeline of single traversals on the product path: rocprofv3 kernel trace of a short bench run, windows printed
-# usage: gpu_r2_tl.sh "<ENV=val ENV=val>" ...   (one run per argument; "" = defaults)
+# usage: gpu_timeline.sh "<ENV=val ENV=val>" ...   (one run per argument; "" = defaults)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/tl; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 i=0

@@ -1,5 +1,5 @@
 #!/bin/bash
-# timeline of single traversals, any bench.py arguments: gpu_r2_tl2.sh "<bench args>" [occurrences...]
+# timeline of single traversals, any bench.py arguments: gpu_timeline_bench.sh "<bench args>" [occurrences...]
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/tl2; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-check $1 > $O/run.log 2>&1

@@ -1,4 +1,5 @@
 #!/bin/bash
+# kernel sequence of the fused SSSP loop (tools/sssp_bench.py under a rocprofv3 kernel trace)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ss; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 $R/tools/sssp_bench.py --scale 22 --runs 2 --check 0 > $O/run.log 2>&1
