@@ -206,6 +206,37 @@ def test_cold_edge_pass_vs_oracle(gpu_ctx, oracle, torch_mod, monkeypatch, scale
         assert cold > 0
 
 
+@pytest.mark.parametrize("env", [{}, {"MGX_BFS_DENSE": "1000000", "MGX_BFS_LAZY": "1048576"}, {"MGX_BFS_DENSE": "1000000", "MGX_BFS_DEFER": "1"}])
+def test_cold_edge_pass_ragged_last_slice(gpu_ctx, oracle, monkeypatch, env):
+    """a vertex count that is no multiple of anything (800 003): the last cold slice ends in the middle of a bitmap word and
+    of a 1024-vertex run of the queue build; hubs whose neighbours are spread over the whole id range, so that about a
+    fifth of the long rows' entries lie behind the LDS prefix"""
+    import mini_amd
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(800003)
+    n, h = 800003, 1500
+    deg = rng.integers(500, 4000, size=h)
+    t0 = np.repeat(np.arange(h), deg).astype(np.int32)
+    t1 = rng.integers(h, n, size=int(deg.sum())).astype(np.int32)
+    e2 = 600000                                                           # ... and a sparse random background
+    t0 = np.concatenate([t0, rng.integers(0, n, size=e2).astype(np.int32)])
+    t1 = np.concatenate([t1, rng.integers(0, n, size=e2).astype(np.int32)])
+    ro, ci, _ = oracle.csr_from_tuples(n, t0, t1, None, undir=True)
+    graph = mini_amd.Graph.from_host(gpu_ctx, ro, ci, None).build_layout()
+    d = np.diff(ro)
+    bfs = mini_amd.BfsProblem(graph, 0)
+    cold = 0
+    for src in [0, int(h + 5), int(n - 1), int(np.argmax(d))]:
+        want = oracle.bfs_cpu(ro, ci, src)
+        st = bfs.run(src)
+        assert np.array_equal(bfs.labels(), want), (env, src)
+        assert st["m_t"] == int(d[want >= 0].sum())
+        cold += st["cold_slots"]
+    if env:
+        assert cold > 0
+
+
 def test_config3_rmat22_sssp_full_size_vs_oracle(gpu_ctx, oracle, torch_mod):
     """config 3 at the benchmarked size: the same topology with integer weights in [0, 63] (every float32 path sum is
     exact, so the north star's 1e-6 relative tolerance is met with equality): fused SSSP distances against the oracle's
