@@ -188,6 +188,7 @@ struct bfs_fused_enactor_t {
       }
       for (int i = 0; i < 4; ++i) layout.vs_v[i] = g.vs_v[i];
       layout.vs_edges = g.vs_edges; layout.vs_dummy = g.vs_dummy; layout.vs_long_min = g.vs_long_min;
+      if (g.d_ss_tab.size() && g.vs_long_min > 0) layout.ss_tab = g.d_ss_tab.data();
       if (g.cold_slices > 0) {
         layout.cold_owner = g.d_cold_owner.data();
         layout.cold_dst = g.d_cold_dst.data();

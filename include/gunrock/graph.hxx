@@ -81,6 +81,7 @@ struct graph_device_t {
   unsigned vs_v[4] = {0, 0, 0, 0};
   unsigned vs_edges = 0, vs_dummy = 0;
   int vs_long_min = 0;
+  mem_t<unsigned> d_ss_tab;          // region table of the short rows (mgx/bfs_fused_sshort.hpp); with the degree classes
   // Cold-edge lists of the long rows (mgx/bfs_fused_cold.hpp): the unit blocks' entries behind the LDS prefix as
   // (owner, dst) pairs grouped by slice of the id range; built with the layout when they are a small share of the entries.
   mem_t<int> d_cold_owner;

@@ -133,6 +133,8 @@ struct bfs_fused_args_t {
   u32 vs_edges;            // edges of the rows in [vs_v[0], vs_v[3])
   u32 vs_div;              // a slot takes its short rows this way when its short-row queue holds >= vs_edges / vs_div edges (0: never)
   u32 vs_dummy;            // index (into col_indices) of four entries of -1
+  const u32* ss_tab;       // short rows as one stream (bfs_fused_sshort.hpp): first entry / first row of every degree's region; NULL: none
+  int ss_dmax;             // the largest short degree (long_min - 1)
   u32* flush_buf;          // BFS_FLUSH_MAX buffers of BFS_FLUSH_WORDS words (NULL: hot marks are never deferred)
   u32 defer_min_marks;     // a workgroup with more deferred discoveries than this flushes them as a bitmap (else: byte marks)
   u32 defer_reach_mul, defer_reach_div;   // a level defers while reached * mul < deferred range * div (1 / 1; MGX_BFS_DEFER_REACH="mul/div")
@@ -159,6 +161,30 @@ struct bfs_fused_args_t {
   u32 colds_off[17];
   u32* cold_flush;         // BFS_COLD_WGS bitmaps of BFS_COLD_WORDS words: what cold workgroup k discovered in its slice
 };
+
+// Copy `words` words (a multiple of 4; src 16-byte aligned, readable up to the next multiple of 4 * NT words... clamped)
+// of the bitmap into LDS: ALL of a thread's 16-byte loads are issued before the first one is stored.  (The plain loop
+// `for (i = tid; i < q; i += NT) dst[i] = src[i]` compiles to load - wait - store per trip: five dependent round trips
+// to L2 at the start of every workgroup of every level.)
+template <int NT, int WORDS>
+__device__ __forceinline__ void bfs_copy_prefix(u32* __restrict__ dst, const u32* __restrict__ src) {
+  static_assert(WORDS % 4 == 0, "whole 16-byte pieces");
+  constexpr int Q = WORDS / 4;
+  constexpr int IT = (Q + NT - 1) / NT;
+  const uint4* const s4 = (const uint4*)src;
+  uint4* const d4 = (uint4*)dst;
+  uint4 v[IT];
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int i = k * NT + (int)threadIdx.x;
+    v[k] = s4[i < Q ? i : Q - 1];
+  }
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int i = k * NT + (int)threadIdx.x;
+    if (i < Q) d4[i] = v[k];
+  }
+}
 
 constexpr int BFS_COLD_MAX_SLICES = 16;
 constexpr int BFS_COLD_WGS = 128;              // workgroups of a push launch that take the cold pairs

@@ -39,7 +39,31 @@ __device__ __forceinline__ void bfs_cold_body(const bfs_fused_args_t& a, int slo
   const u32 w0 = lo >> 5;
   const u32 nwords = ((u32)a.n + 31u) >> 5;
   const u32 have = w0 < nwords ? (nwords - w0 < (u32)HOTW ? nwords - w0 : (u32)HOTW) : 0u;   // words of the slice that exist
-  for (u32 i = threadIdx.x; i < (u32)HOTW; i += NT) hot[i] = i < have ? a.visited[w0 + i] : 0xFFFFFFFFu;
+  {
+    // all loads first (bfs_copy_prefix's reason), 16 bytes each (w0 is a multiple of 32 words); words behind the bitmap's end
+    // read as "visited"
+    constexpr int Q = HOTW / 4, IT = (Q + NT - 1) / NT;
+    const uint4* const s4 = (const uint4*)(a.visited + w0);
+    const u32 q_have = (have + 3u) / 4u;                     // 16-byte pieces that hold existing words (the bitmap is padded to whole pieces)
+    uint4 v[IT];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      const u32 i = (u32)k * NT + threadIdx.x;
+      v[k] = s4[i < q_have ? i : 0u];
+    }
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      const u32 i = (u32)k * NT + threadIdx.x;
+      if (i < (u32)Q) {
+        uint4 x = v[k];
+        if (i * 4u + 0u >= have) x.x = 0xFFFFFFFFu;
+        if (i * 4u + 1u >= have) x.y = 0xFFFFFFFFu;
+        if (i * 4u + 2u >= have) x.z = 0xFFFFFFFFu;
+        if (i * 4u + 3u >= have) x.w = 0xFFFFFFFFu;
+        ((uint4*)hot)[i] = x;
+      }
+    }
+  }
   if (threadIdx.x == 0) { hot[-1] = 0xFFFFFFFFu; hot[HOTW] = 0xFFFFFFFFu; s_int[0] = 0; s_int[1] = 0; }
   __syncthreads();
 

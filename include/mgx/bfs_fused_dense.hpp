@@ -50,9 +50,7 @@ template <int NT, int HOTW>
 __device__ __forceinline__ u32* bfs_hot_setup(const bfs_fused_args_t& a, char* smem, int** s_int, u32 behind = 0u) {
   u32* const hot = (u32*)smem + 4;
   *s_int = (int*)(hot + HOTW + 4);
-  const uint4* src = (const uint4*)a.visited;
-  uint4* dstp = (uint4*)hot;
-  for (int i = threadIdx.x; i < HOTW / 4; i += NT) dstp[i] = src[i];
+  bfs_copy_prefix<NT, HOTW>(hot, a.visited);
   // (behind: what a vertex outside the prefix reads as -- 0 "unvisited": marked untested; all ones when the slot's cold-edge
   //  pass takes care of those entries, bfs_fused_cold.hpp)
   if (threadIdx.x == 0) { hot[-1] = 0xFFFFFFFFu; hot[HOTW] = behind; (*s_int)[0] = 0; }

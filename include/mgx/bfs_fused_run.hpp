@@ -15,6 +15,7 @@ extern "C" char** environ;
 #include "bfs_fused_cold.hpp"
 #include "bfs_fused_dense.hpp"
 #include "bfs_fused_pull.hpp"
+#include "bfs_fused_sshort.hpp"
 #include "bfs_fused_stream.hpp"
 #include "bfs_fused_vshort.hpp"
 #include "bfs_fused_wave.hpp"
@@ -37,6 +38,7 @@ struct bfs_layout_t {
   unsigned vs_v[4] = {0, 0, 0, 0};
   unsigned vs_edges = 0, vs_dummy = 0;
   int vs_long_min = 0;
+  const unsigned* ss_tab = nullptr;   // region table of the short rows (bfs_fused_sshort.hpp; device, BFS_SS_TAB_WORDS words)
   // cold-edge lists of the long rows (bfs_fused_cold.hpp): pairs grouped by slice; hot_n / long_min they were cut for
   const int* cold_owner = nullptr;
   const int* cold_dst = nullptr;
@@ -83,7 +85,7 @@ __device__ __forceinline__ bfs_slot_plan_t bfs_slot_plan(const bfs_fused_args_t&
   // read the unit blocks by its own size (a sweep of all pairs does not pay for a sparse frontier that was only forced
   // onto the unit blocks by a lazy build: the unit-block body marks the few cold entries it meets)
   p.cold = p.dense && a.cold_dst != nullptr;
-  p.colds = p.cold && p.vshort && a.colds_dst != nullptr;   // (with them, the short rows' cold entries of a level that walks those vertex by vertex)
+  p.colds = p.cold && p.vshort && a.colds_dst != nullptr && !a.ss_tab;   // (with them, the short rows' cold entries of a level that walks those vertex by vertex)
   if (!p.empty && c->lazy_slot == p.slot) {       // the build before this slot wrote no queues (bfs_build_is_lazy)
     p.chained = false;
     p.dense = p.vshort = true;
@@ -159,7 +161,8 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
     const u32 first = PART == 0 ? nstream : 0u;
     const u32 bi = il ? blk >> 1 : blk - first;
     const u32 nb = il ? nstream : nblk - first;
-    if (!COLDT && p.vshort) bfs_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, bi, nb, p.level, p.colds);
+    if (!COLDT && p.vshort && a.ss_tab) bfs_sstream_body<1024, BFS_DENSE_HOTW - BFS_SS_TAB_PAD>(a, p.slot, bi, nb, p.level, false);
+    else if (!COLDT && p.vshort) bfs_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, bi, nb, p.level, p.colds);
     else bfs_wave_body<1024, BFS_WAVE_HOTW, COLDT, false>(a, p.slot, bi, nb, p.level);
   }
 }
@@ -246,6 +249,8 @@ struct bfs_run_opts_t {
   int defer_mul = 1, defer_div = 1;   // MGX_BFS_DEFER_REACH="mul/div": a level defers its hot marks while reached * mul < range * div
                                       // (RMAT-22, ms per traversal: 4/1 0.3627, 2/1 0.3600, 1/1 0.3521, 2/3 0.3511, 1/3 0.3530, 1/8 0.3625, always 0.3641)
   int do_chain = 1;        // MGX_BFS_DO_CHAIN=0: direction-optimising runs keep every level device-wide (no chains of small top-down levels)
+  int sstream = 0;         // MGX_BFS_SSTREAM=1: dense short rows as one stream of entries (bfs_fused_sshort.hpp) instead of vertex by
+                           // vertex -- measured 6 us slower per RMAT-22 traversal (0.3578 / 0.3519 ms): off
   int merged_pull = 1;     // MGX_BFS_MERGED_PULL=0: the bottom-up sweep as a launch of its own behind every push launch
   int seed_chain = 1;      // MGX_BFS_SEED_CHAIN=0: no in-place chain launches at all (small levels run inside the slots' push launches)
   int tail_chain = 1;      // MGX_BFS_TAIL_CHAIN=0: ... only the one at the start
@@ -296,6 +301,7 @@ struct bfs_run_opts_t {
       else if (is("DEFER_REACH")) { o.defer_mul = atoi(val); const char* sl = strchr(val, '/'); o.defer_div = sl ? atoi(sl + 1) : 1; if (o.defer_div < 1) o.defer_div = 1; }
       else if (is("SEED_CHAIN")) o.seed_chain = atoi(val);
       else if (is("MERGED_PULL")) o.merged_pull = atoi(val);
+      else if (is("SSTREAM")) o.sstream = atoi(val);
       else if (is("DO_CHAIN")) o.do_chain = atoi(val);
       else if (is("TAIL_CHAIN")) o.tail_chain = atoi(val);
       else if (is("CHAIN_BIG_EDGES")) o.chain_big = atoi(val);
@@ -379,6 +385,8 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.vs_edges = vs ? layout->vs_edges : 0u;
   a.vs_dummy = vs ? layout->vs_dummy : 0u;
   a.vs_div = !vs ? 0u : (opt.vshort >= 0 ? (u32)opt.vshort : st.vshort_div);
+  a.ss_tab = (vs && layout->ss_tab && opt.sstream && st.long_min <= BFS_SS_MAXDEG) ? layout->ss_tab : nullptr;
+  a.ss_dmax = st.long_min - 1;
   if (!st.slot_marks.size()) st.slot_marks = mem_t<u32>((size_t)2 * BFS_MARK_CTRS * BFS_MARK_STRIDE, ctx);
   a.slot_marks = st.slot_marks.data();
   a.merged_pull = (mode == 1 && opt.merged_pull && opt.merged && !a.flags) ? 1 : 0;

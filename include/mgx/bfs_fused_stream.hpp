@@ -85,9 +85,7 @@ __device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int l
   const bool use_hot = E >= a.hot_min_edges;
   const u32 hot_n = use_hot ? (((u32)a.n < (u32)(HOTW * 32)) ? (u32)a.n : (u32)(HOTW * 32)) : 0u;
   if (use_hot) {
-    const uint4* src = (const uint4*)vis;
-    uint4* dstp = (uint4*)hot;
-    for (int i = threadIdx.x; i < HOTW / 4; i += NT) dstp[i] = src[i];
+    bfs_copy_prefix<NT, HOTW>(hot, vis);
   }
   if (threadIdx.x == 0) s_int[0] = 0;
   __syncthreads();

@@ -458,7 +458,7 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
   if (with_weights) { G.d_layout_col_values = std::move(lw); G.has_layout_weights = true; }
   build_unit_blocks(g);
   // degree classes of the short rows (the layout is sorted by degree): boundaries by binary search on a host copy
-  G.vs_edges = 0; G.vs_dummy = 0; G.vs_long_min = 0;
+  G.vs_edges = 0; G.vs_dummy = 0; G.vs_long_min = 0; G.d_ss_tab = mem_t<unsigned>();
   {
     int long_min = 64;
     if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
@@ -476,6 +476,16 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
       G.vs_edges = (unsigned)(h[b3] - h[b0]);
       G.vs_dummy = (unsigned)m + 4u;
       G.vs_long_min = long_min;
+      // the short rows as one stream (mgx/bfs_fused_sshort.hpp): first entry and first row of every degree's region
+      std::vector<unsigned> tab((size_t)mgx::BFS_SS_TAB_WORDS, 0u);
+      for (int d = 0; d <= mgx::BFS_SS_MAXDEG; ++d) {
+        const unsigned fr = first_below(d + 1);          // first row of degree <= d, i.e. of the region of degree d
+        const unsigned row = d >= long_min ? b0 : std::max(b0, fr);
+        tab[(size_t)d] = (unsigned)h[row];
+        tab[(size_t)(mgx::BFS_SS_MAXDEG + 1 + d)] = row;
+      }
+      G.d_ss_tab = mem_t<unsigned>(tab.size(), ctx);
+      MGX_HIP(mgx::htod(G.d_ss_tab.data(), tab.data(), tab.size()));
     }
   }
   build_cold_lists(g);

@@ -566,6 +566,10 @@ VARIANTS = [{}, {"MGX_BFS_COLD_TEST": "1"}, {"MGX_BFS_COLD_TEST": "1", "MGX_BFS_
             {"MGX_BFS_LAZY": "1048576", "MGX_BFS_MERGED_PUSH": "0"},
             # the chain of small levels at the start: inside slot 0's push launch instead of a launch of its own
             {"MGX_BFS_SEED_CHAIN": "0"}, {"MGX_BFS_SEED_CHAIN": "0", "MGX_BFS_DENSE": "1000000", "MGX_BFS_LAZY": "1048576"},
+            # dense short rows as one stream of entries (bfs_fused_sshort.hpp) / vertex by vertex
+            {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_SSTREAM": "1"}, {"MGX_BFS_SSTREAM": "1"},
+            {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_LONG_MIN": "8", "MGX_BFS_DENSE": "1000000", "MGX_BFS_SSTREAM": "1"},
+            {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_LONG_MIN": "1", "MGX_BFS_SSTREAM": "1"},
             {"MGX_BFS_TAIL_CHAIN": "0"}, {"MGX_BFS_CHAIN_BIG_EDGES": "100"}, {"MGX_BFS_CHAIN_MAX_EDGES": "64", "MGX_BFS_CHAIN_BIG_EDGES": "12288", "MGX_BFS_LAZY": "1048576"}]
 
 

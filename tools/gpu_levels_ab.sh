@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/bfs_levels.py (per-level / per-part timing) with and without a switch
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/lv; rm -rf $O; mkdir -p $O; cd $R
-for cfg in "" "MGX_BFS_COLD=0"; do
+for cfg in "" "$1"; do
   for kv in $cfg; do export "$kv"; done
   echo "=== [$cfg]"; timeout 300 python tools/bfs_levels.py --scale 22 --runs 2 2>&1 | grep -v amdgpu.ids
   for kv in $cfg; do unset "${kv%%=*}"; done
