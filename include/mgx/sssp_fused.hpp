@@ -281,9 +281,19 @@ __global__ __launch_bounds__(NT, 8) void k_sssp_relax(sssp_args_t a, int it) {
   const bool use_hot = E >= a.hot_min_edges;
   const u32 hot_n = use_hot ? ((u32)a.n < (u32)SSSP_HOTN ? ((u32)a.n & ~1u) : (u32)SSSP_HOTN) : 0u;
   if (use_hot) {
-    for (u32 i = threadIdx.x; i < hot_n / 2; i += NT) {
-      const uint2 d = *(const uint2*)(dist + 2 * i);
-      s_hot[i] = ((d.x + 0xFFFFu) >> 16) | (((d.y + 0xFFFFu) >> 16) << 16);
+    // all loads first, then the stores (the plain loop compiles to load - wait - store per trip: sixteen dependent round
+    // trips at the start of every workgroup; bfs_copy_prefix in bfs_fused.hpp tells the same story)
+    constexpr int IT = (SSSP_HOTN / 2 + NT - 1) / NT;
+    uint2 dv[IT];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      const u32 i = (u32)k * NT + threadIdx.x;
+      dv[k] = *(const uint2*)(dist + 2 * (i < hot_n / 2 ? i : 0u));
+    }
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+      const u32 i = (u32)k * NT + threadIdx.x;
+      if (i < hot_n / 2) s_hot[i] = ((dv[k].x + 0xFFFFu) >> 16) | (((dv[k].y + 0xFFFFu) >> 16) << 16);
     }
     __syncthreads();
   }
