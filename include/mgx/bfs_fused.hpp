@@ -862,13 +862,17 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
   u64 tot_s, tot_l;
   u64 ex_s = block_exclusive_sum_lean<NW>(sum_s, s_scan, &tot_s);
   u64 ex_l = block_exclusive_sum_lean<NW>(sum_l, s_scan, &tot_l);
+  // the two returning atomics from two different waves: one thread would wait for the first before it issues the second
   if (threadIdx.x == 0) {
     atomicAdd(&c->reached, tot_n);
-    if (a.build_diag & 4) { s_base[0] = s_base[1] = ((u64)blockIdx.x * 8192) << BFS_VSHIFT; }
+    if (a.build_diag & 4) s_base[0] = ((u64)blockIdx.x * 8192) << BFS_VSHIFT;
+    else s_base[0] = (tot_s >> 40) ? atomicAdd(&c->cursor[(slot + 1) % 3], ((tot_s >> 40) << BFS_VSHIFT) | (tot_s & DEGMASK)) : 0ull;
+  }
+  if (threadIdx.x == WAVE) {
+    if (a.build_diag & 4) s_base[1] = ((u64)blockIdx.x * 8192) << BFS_VSHIFT;
     else {
-    s_base[0] = (tot_s >> 40) ? atomicAdd(&c->cursor[(slot + 1) % 3], ((tot_s >> 40) << BFS_VSHIFT) | (tot_s & DEGMASK)) : 0ull;
-    s_base[1] = (tot_l >> 40) ? atomicAdd(&c->lcursor[(slot + 1) % 3], ((tot_l >> 40) << BFS_VSHIFT) | (tot_l & DEGMASK)) : 0ull;
-    if (tot_l >> 40) atomicAdd(&c->ledges[(slot + 1) % 3], (u64)s_long_edges);
+      s_base[1] = (tot_l >> 40) ? atomicAdd(&c->lcursor[(slot + 1) % 3], ((tot_l >> 40) << BFS_VSHIFT) | (tot_l & DEGMASK)) : 0ull;
+      if (tot_l >> 40) atomicAdd(&c->ledges[(slot + 1) % 3], (u64)s_long_edges);
     }
   }
   __syncthreads();
