@@ -53,33 +53,37 @@ __device__ __forceinline__ void bfs_vshort_work(const bfs_fused_args_t& a, u32* 
   const u32 dummy = a.vs_dummy;                                 // index into col of four readable entries behind the CSR
 
   constexpr int K = 2;                                          // wave steps per pipeline stage
-  struct raw_t { u32 lo, hi, fw, v_sub; };                      // what a step's planning loads return: row ends, frontier word
+  struct raw_t { u32 lo, hi, fw, v_sub; };                      // what a step's planning loads return: row ends, frontier WORD (raw), bit | sub-position
   struct step_t { u32 e0, cnt; };                               // first entry of the lane's four (dummy if none), how many are real
-  // stage A: the planning loads of step s (nothing is looked at yet)
+  // stage A: the planning loads of step s.  NOTHING is looked at yet and no load sits under a condition: a value that is
+  // shifted or masked here would have to land here (the compiler waits where the ALU op stands), and a conditional load
+  // makes it drain everything in flight (bfs_fused.hpp, "countable loads") -- either way the entry loads issued a moment
+  // ago would be waited for before the previous step is tested.  Lanes without a vertex read vertex 0 and carry sub = ~0.
   auto plan_load = [&](u32 s) -> raw_t {
-    raw_t r; r.lo = 0; r.hi = 0; r.fw = 0; r.v_sub = 0;
-    if (s >= T) return r;
+    raw_t r;
     u32 lpr_shift, vbase, vend;
     if (s < s16) { lpr_shift = 4; vbase = b0 + s * 4u; vend = b1; }
     else if (s < s16 + s4) { lpr_shift = 2; vbase = b1 + (s - s16) * 16u; vend = b2; }
     else { lpr_shift = 0; vbase = b2 + (s - s16 - s4) * 64u; vend = b3; }
     const u32 v = vbase + ((u32)lane >> lpr_shift);
     const u32 sub = (u32)lane & ((1u << lpr_shift) - 1u);
-    if (v < vend) {
-      const bfs_u32x2 ext = *(const bfs_u32x2*)(ro + v);
-      r.lo = ext.x; r.hi = ext.y;
-      r.fw = (fbits[v >> 5] >> (v & 31u)) & 1u;
-      r.v_sub = sub;
-    }
+    const bool in = s < T && v < vend;
+    const u32 vc = in ? v : 0u;
+    const bfs_u32x2 ext = *(const bfs_u32x2*)(ro + vc);
+    r.lo = ext.x; r.hi = ext.y;
+    r.fw = fbits[vc >> 5];
+    r.v_sub = in ? (sub | ((vc & 31u) << 8)) : 0xFFFFFFFFu;
     return r;
   };
   // stage B: from the landed planning loads to the lane's entry range
   auto resolve = [&](const raw_t& r) -> step_t {
     step_t p; p.e0 = dummy; p.cnt = 0;
     const u32 deg = r.hi - r.lo;
-    if (r.fw && r.v_sub * 4u < deg) {
-      p.e0 = r.lo + r.v_sub * 4u;
-      const u32 left = deg - r.v_sub * 4u;
+    const u32 sub = r.v_sub & 0xFFu;
+    const bool in_frontier = r.v_sub != 0xFFFFFFFFu && ((r.fw >> ((r.v_sub >> 8) & 31u)) & 1u);
+    if (in_frontier && sub * 4u < deg) {
+      p.e0 = r.lo + sub * 4u;
+      const u32 left = deg - sub * 4u;
       p.cnt = left < 4u ? left : 4u;
     }
     return p;
