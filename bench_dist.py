@@ -176,7 +176,7 @@ def bench_main(args, rank, world, local_rank):
                                                              world, exch, args.steps),
                           "scale": gscale, "edgefactor": args.edgefactor, "seed": seed,
                           "parallelism": "vertex-cyclic x%d" % world,
-                          "native_loop": bool(getattr(bfs, "native", False)),
+                          "native_loop": bool(getattr(bfs, "native", False)), "native_error": getattr(bfs, "native_error", None),
                           "rccl": getattr(getattr(bfs, "comm", None), "library", None)},
                "roofline": {"bound": "hbm", "kernel": "k_bfs_push_level (per rank)",
                             "achieved": round(8.0 * m_t / world / elapsed / 1e9, 2), "peak": 8000.0, "unit": "GB/s",

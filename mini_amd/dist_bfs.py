@@ -281,11 +281,24 @@ class DistBfs2:
         # The per-level loop inside the library over a communicator of its own (mgx_dbfs2_run) whenever the engine is
         # the HIP one and the collectives run on the GPUs (RCCL); the Python loop below serves the gloo tests, the
         # one-GPU pre-flights and MGX_DIST_NATIVE=0.
-        self.native, self.comm = False, None
+        self.native, self.comm, self.native_error = False, None, None
         if hasattr(engine, "run_native") and self.comm_device.type == "cuda" and os.environ.get("MGX_DIST_NATIVE", "1") != "0":
+            ok = 1
             if world > 1 or os.environ.get("MGX_DIST_FORCE_COLLECTIVES") == "1":
-                self.comm = NativeComm(engine.ctx, rank, world, self.comm_device)
-            self.native = True
+                try:
+                    self.comm = NativeComm(engine.ctx, rank, world, self.comm_device)
+                except Exception as ex:                      # (librccl not loadable, symbol missing, init refused ...)
+                    self.comm, ok, self.native_error = None, 0, repr(ex)
+                if world > 1:
+                    # every rank must take the same path: the Python loop below issues torch.distributed collectives, the
+                    # native one RCCL calls of its own -- one rank without a communicator sends everybody to the Python loop
+                    flag = torch.tensor([ok], dtype=torch.int32, device=self.comm_device)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    ok = int(flag.item())
+                    if not ok and self.comm is not None:
+                        self.comm.close()
+                        self.comm = None
+            self.native = bool(ok)
 
     def _exchange(self, new):
         """-> (maps, nmaps): what merge() takes"""
