@@ -122,7 +122,10 @@ for name, n, ro, ci, w in graphs():
             knobs = {"MGX_BFS_LAZY": rng.choice(["", "0", "4", "1048576"]), "MGX_BFS_VSHORT": rng.choice(["", "0", "1000000"]),
                      "MGX_BFS_DEFER": rng.choice(["", "0", "1", "2048"]), "MGX_BFS_SEED_CHAIN": rng.choice(["", "0"]),
                      "MGX_BFS_TAIL_CHAIN": rng.choice(["", "0"]), "MGX_BFS_CHAIN_BIG_EDGES": rng.choice(["", "100", "12288"]),
-                     "MGX_BFS_COLD": rng.choice(["", "0", "2"]), "MGX_BFS_DEFER_REACH": rng.choice(["", "0/1", "4/1"])}
+                     "MGX_BFS_COLD": rng.choice(["", "0", "2"]), "MGX_BFS_DEFER_REACH": rng.choice(["", "0/1", "4/1"]),
+                     "MGX_BFS_MERGED_PULL": rng.choice(["", "0"]), "MGX_BFS_DO_CHAIN": rng.choice(["", "0"]),
+                     "MGX_BFS_SSTREAM": rng.choice(["", "1"]), "MGX_SSSP_BUILD_LIST": rng.choice(["", "1"]),
+                     "MGX_SSSP_SLICED": rng.choice(["", "", "3"])}
             for kk, vv in knobs.items():
                 if vv == "":
                     os.environ.pop(kk, None)
@@ -136,7 +139,8 @@ for name, n, ro, ci, w in graphs():
                 bfs.run(src, mode=mini_amd.MGX_BFS_DIRECTION_OPT, alpha=alpha)
                 assert np.array_equal(bfs.labels(), want), (name, n, src, "do", alpha, direct, layout)
         for kk in ("MGX_BFS_CHAIN_MAX_EDGES", "MGX_BFS_DENSE", "MGX_BFS_LAZY", "MGX_BFS_VSHORT", "MGX_BFS_DEFER", "MGX_BFS_SEED_CHAIN",
-                   "MGX_BFS_TAIL_CHAIN", "MGX_BFS_CHAIN_BIG_EDGES", "MGX_BFS_COLD", "MGX_BFS_DEFER_REACH"):
+                   "MGX_BFS_TAIL_CHAIN", "MGX_BFS_CHAIN_BIG_EDGES", "MGX_BFS_COLD", "MGX_BFS_DEFER_REACH", "MGX_BFS_MERGED_PULL",
+                   "MGX_BFS_DO_CHAIN", "MGX_BFS_SSTREAM"):
             os.environ.pop(kk, None)
         if src == srcs[0] and n <= 150000:
             G = int(rng.choice([2, 3, 5, 8]))
@@ -144,8 +148,9 @@ for name, n, ro, ci, w in graphs():
             got = partitioned_labels(n, ro, ci, src, G, mode)
             assert np.array_equal(got, want), (name, n, src, "partitioned", G, mode)
         dist, _, _ = orc.sssp_enact(ro, ci, w, src, 8.0)
-        sssp.run(src)
-        assert np.array_equal(sssp.distances(), dist), (name, n, src, "sssp", layout)
+        sssp.run(src)                                  # (MGX_SSSP_BUILD_LIST / MGX_SSSP_SLICED: whatever the last draw left)
+        assert np.array_equal(sssp.distances(), dist), (name, n, src, "sssp", layout, os.environ.get("MGX_SSSP_BUILD_LIST"), os.environ.get("MGX_SSSP_SLICED"))
+        os.environ.pop("MGX_SSSP_BUILD_LIST", None); os.environ.pop("MGX_SSSP_SLICED", None)
     ran += 1
     print("ok %-18s n=%-7d m=%-9d layout=%d" % (name, n, len(ci), layout), flush=True)
 print("fuzz: %d graphs, all equal to the oracle" % ran)
