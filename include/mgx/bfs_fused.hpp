@@ -99,6 +99,8 @@ struct bfs_ctrl_t {
   u64 trace[BFS_MAX_TRACE];   // (vertices << 38 | edges) of each level, both queues (kept LAST: read back up to `levels`)
 };
 
+constexpr int BFS_COLD_MAX_SLICES = 32;           // slices of the id range that may hold cold-edge pairs (bfs_fused_cold.hpp)
+
 struct bfs_fused_args_t {
   const u32* row_offsets;
   const int* col_indices;
@@ -153,12 +155,12 @@ struct bfs_fused_args_t {
   const int* cold_owner;
   const int* cold_dst;
   int cold_slices;         // slices that hold pairs (<= BFS_COLD_MAX_SLICES)
-  u32 cold_lo[16];         // first vertex of slice i (a multiple of 1024; the slice is BFS_COLD_WORDS * 32 vertices)
-  u32 cold_off[17];        // its pairs: [cold_off[i], cold_off[i + 1])
-  u32 cold_wgs[17];        // the cold workgroups [cold_wgs[i], cold_wgs[i + 1]) of a push launch take slice i
+  u32 cold_lo[BFS_COLD_MAX_SLICES];         // first vertex of slice i (a multiple of 1024; the slice is BFS_COLD_WORDS * 32 vertices)
+  u32 cold_off[BFS_COLD_MAX_SLICES + 1];        // its pairs: [cold_off[i], cold_off[i + 1])
+  u32 cold_wgs[BFS_COLD_MAX_SLICES + 1];        // the cold workgroups [cold_wgs[i], cold_wgs[i + 1]) of a push launch take slice i
   const int* colds_owner;  // the same lists for the SHORT rows (the entries the vertex-by-vertex body would mark); NULL: none
   const int* colds_dst;
-  u32 colds_off[17];
+  u32 colds_off[BFS_COLD_MAX_SLICES + 1];
   u32* cold_flush;         // BFS_COLD_WGS bitmaps of BFS_COLD_WORDS words: what cold workgroup k discovered in its slice
 };
 
@@ -186,7 +188,6 @@ __device__ __forceinline__ void bfs_copy_prefix(u32* __restrict__ dst, const u32
   }
 }
 
-constexpr int BFS_COLD_MAX_SLICES = 16;
 constexpr int BFS_COLD_WGS = 128;              // workgroups of a push launch that take the cold pairs
 constexpr int BFS_COLD_WORDS = 20384;          // bitmap words of a slice == the unit-block body's LDS prefix (BFS_DENSE_HOTW)
 

@@ -45,7 +45,8 @@ struct bfs_layout_t {
   const int* colds_owner = nullptr;   // the short rows' cold entries (optional)
   const int* colds_dst = nullptr;
   int cold_slices = 0;
-  unsigned cold_lo[16] = {0}, cold_off[17] = {0}, colds_off[17] = {0}, cold_wgs[17] = {0};
+  unsigned cold_lo[BFS_COLD_MAX_SLICES] = {0}, cold_off[BFS_COLD_MAX_SLICES + 1] = {0}, colds_off[BFS_COLD_MAX_SLICES + 1] = {0},
+           cold_wgs[BFS_COLD_MAX_SLICES + 1] = {0};
   unsigned cold_hot_n = 0;
   int cold_long_min = 0;
 };
@@ -368,11 +369,14 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.n = st.n;
   a.flags = opt.flags;
   a.count_marks = (st.count_marks || st.time_kernels == 1) ? 1 : 0;
-  const bool coldt = bfs_cold_test(a.n, opt.cold_test);
-  // unit blocks: only for the CSR they were built from, with the long-row threshold they were built for, and not on
-  // graphs whose cold neighbours are probed (the dense body marks them untested)
-  const bool units = relabelled && layout->ub_col && layout->ub_units > 0 && layout->ub_min_degree == st.long_min &&
-                     st.long_min > 0 && !coldt && !opt.flags;
+  // unit blocks: only for the CSR they were built from, with the long-row threshold they were built for
+  const bool units_avail = relabelled && layout->ub_col && layout->ub_units > 0 && layout->ub_min_degree == st.long_min &&
+                           st.long_min > 0 && !opt.flags;
+  // Probing the bitmap word of cold neighbours (instead of marking them untested) pays on big graphs WITHOUT the unit
+  // blocks -- the partitioned ranks, a caller-made layout.  With them the unit-block body, the cold-edge pass and the
+  // lazy builds win at every size measured: RMAT-23 391 against 272 GTEPS, RMAT-24 386 / 253, RMAT-25 187 / 179.
+  const bool coldt = opt.cold_test >= 0 ? opt.cold_test != 0 : (bfs_cold_test(a.n, -1) && !units_avail);
+  const bool units = units_avail && !coldt;
   a.ub_col = units ? layout->ub_col : nullptr;
   a.ub_owner = units ? layout->ub_owner : nullptr;
   a.ub_units = units ? (u32)layout->ub_units : 0u;
@@ -426,13 +430,13 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.cold_owner = cold ? layout->cold_owner : nullptr;
   a.cold_dst = cold ? layout->cold_dst : nullptr;
   a.cold_slices = cold ? layout->cold_slices : 0;
-  for (int i = 0; i < 16; ++i) a.cold_lo[i] = cold ? layout->cold_lo[i] : 0u;
-  for (int i = 0; i < 17; ++i) { a.cold_off[i] = cold ? layout->cold_off[i] : 0u; a.cold_wgs[i] = cold ? layout->cold_wgs[i] : 0u; }
+  for (int i = 0; i < BFS_COLD_MAX_SLICES; ++i) a.cold_lo[i] = cold ? layout->cold_lo[i] : 0u;
+  for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) { a.cold_off[i] = cold ? layout->cold_off[i] : 0u; a.cold_wgs[i] = cold ? layout->cold_wgs[i] : 0u; }
   // ... and of the short rows, for the levels that walk them vertex by vertex
   const bool colds = cold && a.vs_div && layout->colds_dst && opt.cold != 2;
   a.colds_owner = colds ? layout->colds_owner : nullptr;
   a.colds_dst = colds ? layout->colds_dst : nullptr;
-  for (int i = 0; i < 17; ++i) a.colds_off[i] = colds ? layout->colds_off[i] : 0u;
+  for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) a.colds_off[i] = colds ? layout->colds_off[i] : 0u;
   if (cold && !st.cold_flush.size()) st.cold_flush = mem_t<u32>((size_t)BFS_COLD_WGS * BFS_COLD_WORDS, ctx);
   a.cold_flush = cold ? st.cold_flush.data() : nullptr;
   // lazy queues (bfs_build_is_lazy): only k_bfs_build2 knows them, and only when both queue-less bodies are available

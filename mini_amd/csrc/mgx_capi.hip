@@ -426,7 +426,7 @@ static void build_cold_lists(mgx_graph_s* g) {
     acc += 1u + extra;
     G.cold_wgs[i + 1] = acc;
   }
-  for (int i = used + 1; i <= 16; ++i) { G.cold_wgs[i] = acc; G.cold_off[i] = G.cold_off[used]; G.colds_off[i] = G.colds_off[used]; }
+  for (int i = used + 1; i <= mgx::BFS_COLD_MAX_SLICES; ++i) { G.cold_wgs[i] = acc; G.cold_off[i] = G.cold_off[used]; G.colds_off[i] = G.colds_off[used]; }
   G.d_cold_owner = std::move(d_owner); G.d_cold_dst = std::move(d_dst);
   G.d_colds_owner = std::move(d_owner_s); G.d_colds_dst = std::move(d_dst_s);
   G.cold_pairs = pairs; G.colds_pairs = pairs_s; G.cold_slices = used; G.cold_hot_n = hot_n; G.cold_long_min = G.vs_long_min;

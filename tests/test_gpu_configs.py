@@ -237,6 +237,25 @@ def test_cold_edge_pass_ragged_last_slice(gpu_ctx, oracle, monkeypatch, env):
         assert cold > 0
 
 
+def test_rmat23_unit_blocks_and_cold_pass_on_a_big_graph(gpu_ctx, oracle, torch_mod):
+    """one size up (n = 8 388 608, m = 268 435 456): the traversal keeps the unit blocks, the cold-edge pass (seven slices
+    behind the prefix) and the lazy builds on graphs of this size too -- the bitmap probe of cold neighbours is for
+    graphs without unit blocks; labels against the oracle"""
+    import mini_amd
+    from mini_amd import rmat
+    g = rmat.rmat_csr(gpu_ctx, 23, 16, seed=23)
+    graph = mini_amd.Graph.from_device(gpu_ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"]).build_layout()
+    ro, ci = g["row_offsets"].cpu().numpy(), g["col_indices"].cpu().numpy()
+    src = rmat.pick_sources(ro, 2, 23)[1]
+    want = oracle.bfs_cpu(ro, ci, src)
+    bfs = mini_amd.BfsProblem(graph, src)
+    st = bfs.run(src)
+    assert np.array_equal(bfs.labels(), want)
+    deg = np.diff(ro)
+    assert st["m_t"] == int(deg[want >= 0].sum())
+    assert st["dense_slots"] >= 1 and st["cold_slots"] >= 1 and st["lazy_slots"] >= 1
+
+
 def test_config3_rmat22_sssp_full_size_vs_oracle(gpu_ctx, oracle, torch_mod):
     """config 3 at the benchmarked size: the same topology with integer weights in [0, 63] (every float32 path sum is
     exact, so the north star's 1e-6 relative tolerance is met with equality): fused SSSP distances against the oracle's
