@@ -161,7 +161,7 @@ struct bfs_fused_args_t {
   const int* colds_owner;  // the same lists for the SHORT rows (the entries the vertex-by-vertex body would mark); NULL: none
   const int* colds_dst;
   u32 colds_off[BFS_COLD_MAX_SLICES + 1];
-  u32* cold_flush;         // BFS_COLD_WGS bitmaps of BFS_COLD_WORDS words: what cold workgroup k discovered in its slice
+  u32* cold_flush;         // cold_wgs[cold_slices] bitmaps of BFS_COLD_WORDS words: what cold workgroup k discovered in its slice
 };
 
 // Copy `words` words (a multiple of 4; src 16-byte aligned, readable up to the next multiple of 4 * NT words... clamped)
@@ -188,7 +188,8 @@ __device__ __forceinline__ void bfs_copy_prefix(u32* __restrict__ dst, const u32
   }
 }
 
-constexpr int BFS_COLD_WGS = 128;              // workgroups of a push launch that take the cold pairs
+constexpr int BFS_COLD_WGS = 128;              // workgroups of a push launch that take the cold pairs: at least this many ...
+constexpr int BFS_COLD_WGS_MAX = 1024;         // ... one per 65 536 pairs, at most this many (cold_wgs[cold_slices] says how many)
 constexpr int BFS_COLD_WORDS = 20384;          // bitmap words of a slice == the unit-block body's LDS prefix (BFS_DENSE_HOTW)
 
 constexpr int BFS_MARK_CTRS = 8;               // the workgroups of a push launch spread their adds over this many lines

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
   // Which part this workgroup takes: (graphs with cold-edge lists) BFS_COLD_WGS workgroups of the cold pass, then nstream
   // workgroups for the long rows, the others the short rows.
   // (interleave: even / odd instead, so that the two parts share every CU -- an experiment that lost, see bfs_run_opts_t)
-  const u32 ncold = (!COLDT && a.cold_dst && (PART == 0 || PART == 2)) ? (u32)BFS_COLD_WGS : 0u;   // (PART 2: with the long rows)
+  const u32 ncold = (!COLDT && a.cold_dst && (PART == 0 || PART == 2)) ? a.cold_wgs[a.cold_slices] : 0u;   // (PART 2: with the long rows)
   // grid: [cold pass][long rows][short rows] -- the cold workgroups first: they are few and short, and the launch does
   // not end on them
   if (blockIdx.x < ncold) {
@@ -437,7 +437,8 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.colds_owner = colds ? layout->colds_owner : nullptr;
   a.colds_dst = colds ? layout->colds_dst : nullptr;
   for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) a.colds_off[i] = colds ? layout->colds_off[i] : 0u;
-  if (cold && !st.cold_flush.size()) st.cold_flush = mem_t<u32>((size_t)BFS_COLD_WGS * BFS_COLD_WORDS, ctx);
+  const size_t cold_words = cold ? (size_t)layout->cold_wgs[layout->cold_slices] * BFS_COLD_WORDS : 0;
+  if (cold && st.cold_flush.size() < cold_words) { ctx.synchronize(); st.cold_flush = mem_t<u32>(cold_words, ctx); }
   a.cold_flush = cold ? st.cold_flush.data() : nullptr;
   // lazy queues (bfs_build_is_lazy): only k_bfs_build2 knows them, and only when both queue-less bodies are available
   a.lazy_pull = (mode == 1 && build2_ok && !opt.build_list && opt.lazy != 0) ? 1 : 0;
@@ -446,7 +447,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   const bool batch_events = st.time_kernels != 0 || st.time_batches;    // (an event costs ~6 us of stream gap)
   const u32 nstream = a.long_min > 0 ? (u32)ctx.num_cus * 2 : 0u;
   const u32 nwave = (u32)ctx.num_cus * 2;
-  const u32 ncold = (!coldt && a.cold_dst) ? (u32)BFS_COLD_WGS : 0u;
+  const u32 ncold = (!coldt && a.cold_dst) ? a.cold_wgs[a.cold_slices] : 0u;
   int slot = 0;
   for (int batch = 0;; ++batch) {
     // first batch: what the previous traversal of this graph needed (sources differ, level structure hardly)

@@ -414,13 +414,16 @@ static void build_cold_lists(mgx_graph_s* g) {
     G.colds_off[q] = (unsigned)off_s[k]; G.colds_off[q + 1] = (unsigned)off_s[k + 1];
     ++q;
   }
-  // workgroups per slice: in proportion to its pairs, at least one each
+  // workgroups per slice: in proportion to its pairs, at least one each; in all one per 65 536 pairs, 128 .. 1024
   const long long all = pairs + pairs_s;
-  unsigned left = (unsigned)mgx::BFS_COLD_WGS - (unsigned)used, acc = 0;
+  long long nwg = (all + 65535) / 65536;
+  nwg = std::max<long long>(nwg, mgx::BFS_COLD_WGS);
+  nwg = std::min<long long>(nwg, mgx::BFS_COLD_WGS_MAX);
+  unsigned left = (unsigned)nwg - (unsigned)used, acc = 0;
   G.cold_wgs[0] = 0;
   for (int i = 0; i < used; ++i) {
     const long long cnt = ((long long)G.cold_off[i + 1] - (long long)G.cold_off[i]) + ((long long)G.colds_off[i + 1] - (long long)G.colds_off[i]);
-    unsigned extra = (unsigned)((cnt * (long long)((unsigned)mgx::BFS_COLD_WGS - (unsigned)used)) / all);
+    unsigned extra = (unsigned)((cnt * (long long)((unsigned)nwg - (unsigned)used)) / all);
     if (extra > left) extra = left;
     left -= extra;
     acc += 1u + extra;
