@@ -230,14 +230,14 @@ MGX_API int mgx_bfs_level_trace(mgx_bfs_t p, int cap, int64_t* level_nf, int64_t
 MGX_API int mgx_bfs_set_kernel_timing(mgx_bfs_t p, int on);
 /* the two push kernels of the last mgx_bfs_run, timed per launch with HIP events on the context's stream:
  * out8 = { stream launches, ns, edges, frontier vertices,  wave launches, ns, edges, frontier vertices }
- * (k_bfs_push_level_stream: rows of >= MGX_BFS_LONG_MIN edges, read row-wise;
- *  k_bfs_push_level_wave: the shorter rows, load-balanced search per edge rank)                 */
+ * ("stream": the long-row part of k_bfs_push -- rows of >= MGX_BFS_LONG_MIN edges, unit blocks or queue walk, with the
+ *  cold-edge pass -- or, in timing mode 2, the whole merged launch; "wave": the short-row part)               */
 MGX_API int mgx_bfs_kernel_times(mgx_bfs_t p, int64_t* out8);
 /* duration of each level of the last run (ms), from device-side timestamps taken when a level is opened: no host
  * synchronisation involved; first min(cap, 63) levels */
 MGX_API int mgx_bfs_level_times(mgx_bfs_t p, int cap, float* ms, int* levels);
-/* the same per launch slot (ms), first min(cap, 64) slots of the last run; a slot = the small-level kernel plus one
- * round of the device-wide kernels (include/mgx/bfs_fused_run.hpp) */
+/* the same per launch slot (ms), first min(cap, 64) slots of the last run; a slot = one k_bfs_push launch
+ * and its queue build (include/mgx/bfs_fused_run.hpp) */
 MGX_API int mgx_bfs_level_kernel_times(mgx_bfs_t p, int cap, float* stream_ms, float* wave_ms);
 /* atomicOr claims issued per level of the last run (first 64 levels) */
 MGX_API int mgx_bfs_level_claims(mgx_bfs_t p, int cap, int64_t* claims);

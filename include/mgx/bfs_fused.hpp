@@ -1,28 +1,36 @@
 // mgx/bfs_fused.hpp -- device-resident BFS: advance + filter fused per level, no host round trip per
-// level.  This header holds the shared pieces: control block, level bookkeeping, the claim helper and the
-// kernel that builds the next level's queues; the traversal kernels are in bfs_fused_stream.hpp (long rows),
-// bfs_fused_wave.hpp (short rows) and bfs_fused_pull.hpp (bottom-up); bfs_fused_run.hpp drives them.
+// level.  This header holds the shared pieces: control block, level bookkeeping, the deferred-mark epilogue, the
+// kernels that build the next level's queues, the per-BFS state.  The bodies that expand a level live in
+//   bfs_fused_stream.hpp  long rows, queue walk            bfs_fused_dense.hpp   long rows from the unit blocks
+//   bfs_fused_wave.hpp    short rows, search per edge rank  bfs_fused_vshort.hpp  short rows vertex by vertex
+//   bfs_fused_cold.hpp    the long rows' entries behind the LDS prefix, as pairs by slice of the id range
+//   bfs_fused_chain.hpp   small levels, one workgroup       bfs_fused_pull.hpp    bottom-up levels
+//   bfs_fused_sshort.hpp  (option) short rows as one stream of entries
+// and bfs_fused_run.hpp launches them, slot by slot (k_bfs_push: all bodies in ONE grid; k_bfs_chain_inplace).
 //
 // What the reference does per level: degree scan (K1) -> 4-byte D2H (K2) ->
 // load-balanced expand writing one int per EDGE, mostly -1 (K3) -> compaction upsweep + D2H (K4)
 // -> downsweep (K5); ~10 launches, 2 host syncs, 4-5 cudaMalloc/cudaFree pairs, and
 // 16 B/edge + 40 B/vertex of traffic.  Here a level is
 //
-//   bfs_open_level      bookkeeping (sizes, termination flag, TEPS numerator, direction): one thread -- of the push
-//                       grid (direct scheme), of k_bfs_small_levels (slot scheme) or of k_bfs_level_begin.
-//   push kernels        MARK ONLY: a neighbour that is not in the visited bitmap gets mark[v] = 1, a plain byte
-//                       store.  No atomics anywhere: measured on MI355X, device-scope atomics execute at the
+//   bfs_open_level      bookkeeping (sizes, termination flag, TEPS numerator, direction): one thread -- of the slot's
+//                       push grid, of a chain of small levels, or of k_bfs_level_begin (partitioned runs).
+//   push bodies         MARK ONLY: a neighbour that is not in the visited bitmap gets mark[v] = 1, a plain byte
+//                       store.  No atomics on the hot path: measured on MI355X, device-scope atomics execute at the
 //                       memory side (the per-XCD L2s are not coherent with each other), drop their L2 line,
 //                       and together with the re-reads of the lines they dropped ran at ~5 G/s in a level with
 //                       1.7 M claims -- 0.34 ms of a 0.40 ms kernel.  Byte stores are idempotent (every writer
 //                       writes the same value), merge in the write-back L2s by byte mask, and are visible to
 //                       the next kernel; nobody reads them while the level runs.  The visited bitmap itself is
-//                       read-only during a level, so its hot prefix can sit in LDS and the rest in L2.
-//   k_bfs_build         one sweep over mark[] and the bitmap: marked and not yet visited = the level's
-//                       discoveries.  Sets their bits (a wave owns the words of its 64 vertices: plain
-//                       stores), writes their labels and appends them to the next level's queues in batches
-//                       of thousands per workgroup (two cursor atomics per batch: ONE hot 64-bit cursor
-//                       takes only ~83 M returning atomics/s).
+//                       read-only during a level, so its hot prefix can sit in LDS and the rest in L2.  (Marks are
+//                       not free either -- a scattered store costs the fabric a cache line, tools/microbench4.hip:
+//                       hence the deferred hot marks below and the cold-edge pass.)
+//   k_bfs_build2        one sweep over mark[] and the bitmap (+ the bitmaps the push workgroups flushed): marked and
+//                       not yet visited = the level's discoveries.  Sets their bits (a thread owns the half-word of
+//                       its 16 vertices: plain stores), writes their labels, the frontier bitmap and -- unless the
+//                       next slot will not read them (bfs_build_is_lazy) -- the next level's two queues: one packed
+//                       scan per queue, ONE cursor atomic per workgroup and queue (a hot 64-bit cursor takes only
+//                       ~83 M returning atomics/s).  k_bfs_build is the list-based variant (partitioned runs).
 //
 // Queues: a frontier is stored as (row_start, scanned_edge_offset) pairs: a batch is appended with ONE 64-bit
 // atomicAdd on a packed (vertex_count << 38 | edge_count) cursor, so the slot it gets back is at once the
@@ -947,7 +955,7 @@ struct bfs_fused_state_t {
   int tail_from = 1 << 30;           // slots from this one on get an in-place chain launch in front (learnt from the previous traversal)
   unsigned lazy_div = 4;             // the build behind a push with >= n / lazy_div mark stores writes no queues (bfs_build_is_lazy; 0: never)
   mem_t<u32> slot_marks;             // the counters it looks at (bfs_fused_args_t::slot_marks)
-  mem_t<u32> cold_flush;             // cold-edge pass: BFS_COLD_WGS bitmaps of BFS_COLD_WORDS words (allocated on demand)
+  mem_t<u32> cold_flush;             // cold-edge pass: one bitmap of BFS_COLD_WORDS words per cold workgroup (allocated on demand)
   unsigned dense_div = 2;            // long rows are read from the unit blocks when the frontier holds at least
                                      // 1 / dense_div of the units (bfs_fused_dense.hpp; 0: never)
   int long_min = 64;                 // rows at least this long go to the long-row queue (0: no such queue)
@@ -965,9 +973,9 @@ struct bfs_fused_state_t {
   // per-launch timing of the two push kernels of a level: events [3i] stream [3i+1] wave [3i+2]
   static constexpr int EV_POOL = 96;
   hipEvent_t wev[EV_POOL] = {};
-  double wave_kernel_ms = 0.0;       // k_bfs_push_level_wave: per-edge search over the short-row queue
+  double wave_kernel_ms = 0.0;       // the short-row part of k_bfs_push (timing mode 1)
   long long wave_kernel_launches = 0;
-  double stream_kernel_ms = 0.0;     // k_bfs_push_level_stream: row-wise streaming of the long-row queue
+  double stream_kernel_ms = 0.0;     // the long-row part of k_bfs_push (timing mode 1) or the whole merged launch (mode 2)
   long long stream_kernel_launches = 0;
   float level_stream_ms[64] = {};    // the same per slot (first 64 slots)
   float level_wave_ms[64] = {};

@@ -65,7 +65,7 @@ __device__ __forceinline__ bool bfs_level_is_chained(const bfs_fused_args_t& a, 
 }
 
 // Runs level `level` of slot `slot` and the small levels behind it.  Whole workgroup (NT threads).
-// INPLACE: the chain is a launch of its own in FRONT of the slot (k_bfs_seed_chain, behind the init kernel): it takes the
+// INPLACE: the chain is a launch of its own in FRONT of the slot (k_bfs_chain_inplace, bfs_fused_run.hpp): it takes the
 // slot's queues and leaves the first level that is not small in the SAME slot's queues and ring entry -- the slot's push
 // launch then opens that level; nothing is skipped and no slot is used up.
 template <int NT, bool INPLACE = false, int CAP = BFS_CHAIN_CAP>

@@ -9,7 +9,7 @@
 //
 // So the cold entries are pulled out of the rows when the layout is built (mgx_layout.hip: mgx_cold_build_device): pairs
 // (owner, dst), grouped by the SLICE of the id range dst lies in -- a slice is as many vertices as the LDS prefix holds --
-// and ordered by owner inside a slice.  On a level that reads the unit blocks, BFS_COLD_WGS workgroups of the same push
+// and ordered by owner inside a slice.  On a level that reads the unit blocks, a few hundred workgroups of the same push
 // launch take the pairs instead (the unit-block body then skips cold entries: its sentinel word behind the prefix reads
 // "visited"): a workgroup copies ITS slice of the bitmap into LDS, streams its share of the slice's pairs -- 8 bytes per
 // pair, coalesced -- asks the frontier bitmap for the owner (neighbouring lanes, neighbouring or equal owners), tests and
@@ -24,7 +24,7 @@ namespace mgx {
 
 constexpr size_t bfs_cold_lds_bytes() { return (size_t)BFS_COLD_WORDS * 4 + 128; }
 
-// cold workgroup `cw` (0 .. BFS_COLD_WGS - 1) of slot `slot`; all threads
+// cold workgroup `cw` (0 .. cold_wgs[cold_slices] - 1) of slot `slot`; all threads
 template <int NT>
 __device__ __forceinline__ void bfs_cold_body(const bfs_fused_args_t& a, int slot, u32 cw, int stat_level, bool do_long, bool do_short) {
   constexpr int HOTW = BFS_COLD_WORDS;
@@ -33,7 +33,7 @@ __device__ __forceinline__ void bfs_cold_body(const bfs_fused_args_t& a, int slo
   int* const s_int = (int*)(hot + HOTW + 4);
   int sl = 0;
   while (sl + 1 < a.cold_slices && cw >= a.cold_wgs[sl + 1]) ++sl;             // (uniform)
-  if (cw >= a.cold_wgs[a.cold_slices]) return;            // (cannot happen: the slices share all BFS_COLD_WGS workgroups)
+  if (cw >= a.cold_wgs[a.cold_slices]) return;            // (cannot happen: the slices share all cold workgroups)
   const u32 part = cw - a.cold_wgs[sl], parts = a.cold_wgs[sl + 1] - a.cold_wgs[sl];
   const u32 lo = a.cold_lo[sl];                      // first vertex of the slice: a multiple of 1024
   const u32 w0 = lo >> 5;

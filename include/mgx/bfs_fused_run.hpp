@@ -1,11 +1,12 @@
-// mgx/bfs_fused_run.hpp -- host driver of the fused BFS.  One init kernel, then per launch SLOT
-//   k_bfs_push (long rows: unit blocks or queue walk | short rows searched | or: block 0 runs a chain of small levels)
-//   [-> k_bfs_pull_level]  -> k_bfs_build
-// enqueued back to back for as many slots as the previous traversal of the graph needed; the host reads the control
-// block back once per batch.  A slot works on the level ctrl->slot_level[slot & 3]: one device-wide level, or -- when
-// the level is small -- that level and every small level behind it, inside block 0 of the push launch
-// (bfs_fused_chain.hpp; k_bfs_build then returns at once).  RMAT-22: init + 5 slots instead of init + 7 levels x 2.
-// The partitioned path (bfs_dist2.hpp) drives the same kernel bodies with explicit level numbers (k_bfs_push_level).
+// mgx/bfs_fused_run.hpp -- host driver of the fused BFS.  One init kernel, an in-place chain launch for the small levels
+// at the start (k_bfs_chain_inplace: one workgroup), then per launch SLOT
+//   k_bfs_push   ONE grid: [cold-edge pass | long rows: unit blocks or queue walk | short rows: vertex by vertex or searched]
+//                -- or the bottom-up sweep of a direction-optimising run, or block 0 running a chain of small levels
+//   k_bfs_build2 marks (+ flushed bitmaps) -> bitmap bits, labels, frontier bitmap, the next slot's queues (or none: lazy)
+// enqueued back to back for as many slots as the last traversals of the graph needed, another in-place chain launch for
+// the stragglers, and k_bfs_publish, on which the host spins: one host wait per batch.  A slot works on the level
+// ctrl->slot_level[slot & 3].  RMAT-22: init + chain + 4 slots + chain + publish = 12 launches for 7 levels.
+// The partitioned path (bfs_dist2.hpp) drives the queue-walk bodies with explicit level numbers (k_bfs_push_level).
 #pragma once
 #include <cstring>
 #include <unistd.h>
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
     }
     return;
   }
-  // Which part this workgroup takes: (graphs with cold-edge lists) BFS_COLD_WGS workgroups of the cold pass, then nstream
+  // Which part this workgroup takes: (graphs with cold-edge lists) the workgroups of the cold pass, then nstream
   // workgroups for the long rows, the others the short rows.
   // (interleave: even / odd instead, so that the two parts share every CU -- an experiment that lost, see bfs_run_opts_t)
   const u32 ncold = (!COLDT && a.cold_dst && (PART == 0 || PART == 2)) ? a.cold_wgs[a.cold_slices] : 0u;   // (PART 2: with the long rows)

@@ -32,8 +32,8 @@ constexpr int BFS_STREAM_HOTW = 40896;     // words of the bitmap kept in LDS: 1
 constexpr size_t bfs_stream_lds_bytes(int hotw) { return (size_t)hotw * 4 + 64; }
 
 // DIAG: honour MGX_BFS_FLAGS (switch parts of the kernel off for measurements; results are then wrong by design).
-// The kernel body as a device function: block `block` of `nblocks` (k_bfs_push_level_stream launches it for a grid
-// of its own, k_bfs_push_level in bfs_fused_run.hpp gives it the first part of a grid shared with the wave body).
+// The kernel body as a device function: block `block` of `nblocks` (k_bfs_push / k_bfs_push_level in bfs_fused_run.hpp
+// give it a part of a grid it shares with the other bodies).
 //
 // What bounds it (RMAT-22's big level, 98 M long edges: 151 us alone, 2.6 TB/s of col_indices): the latency of the
 // memory pipeline under load.  8192 waves x 8 loads x 256 B = 16.8 MB in flight, returned in ~4 us -- the same ~4 TB/s
