@@ -418,7 +418,9 @@ static void build_cold_lists(mgx_graph_s* g) {
   const long long all = pairs + pairs_s;
   long long nwg = (all + 65535) / 65536;
   nwg = std::max<long long>(nwg, mgx::BFS_COLD_WGS);
+  if (const char* e = getenv("MGX_BFS_COLD_WGS")) if (atoi(e) > 0) nwg = atoi(e);      // (measurements)
   nwg = std::min<long long>(nwg, mgx::BFS_COLD_WGS_MAX);
+  nwg = std::max<long long>(nwg, used);
   unsigned left = (unsigned)nwg - (unsigned)used, acc = 0;
   G.cold_wgs[0] = 0;
   for (int i = 0; i < used; ++i) {
