@@ -73,8 +73,30 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) WITHOUT a launcher: start the N ranks as fresh child processes -- before this
+    process has imported torch or touched the GPU -- through torch.distributed.run on 127.0.0.1, relay their output (rank
+    0 prints the one JSON line) and return the launcher's exit code.  Never falls through to the 1-GPU body."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
+    if os.environ.get("MGX_BENCH_LAUNCH_ONLY") == "1":      # (CPU test of the launch contract: who was started, nothing else)
+        print("launched rank %s of %s (--gpus %d)" % (os.environ.get("RANK"), os.environ.get("WORLD_SIZE"), args.gpus), flush=True)
+        return
     import numpy as np
     import torch
     import torch.distributed as dist

@@ -110,6 +110,11 @@ def bench_main(args, rank, world, local_rank):
     e = torch.tensor([edges_local], dtype=torch.int64, device=device if comm_dev == "cuda" else "cpu")
     dist.all_reduce(e)
     m_t = int(e.item())
+    # how many ranks really took part in the collectives (a launcher that started fewer processes than --gpus must not
+    # pass for an N-GPU run): every rank adds one
+    ones = torch.tensor([1], dtype=torch.int64, device=device if comm_dev == "cuda" else "cpu")
+    dist.all_reduce(ones)
+    ranks_seen = int(ones.item())
 
     # ---- parity of the first timed source (untimed) ---------------------------------------------------------------
     parity, parity_how, cpu = None, None, None
@@ -183,6 +188,7 @@ def bench_main(args, rank, world, local_rank):
                             "frac": round(8.0 * m_t / world / elapsed / 1e9 / 8000.0, 5), "traffic": None,
                             "note": "per-GPU algorithmic bytes (8 B/edge) over the whole superstep loop incl. exchange"},
                "cpu_baseline": cpu, "parity_vs_oracle": parity, "parity_check": parity_how,
+               "rccl_ranks": ranks_seen, "collective_backend": dist.get_backend(),
                "avg_levels": round(levels / max(args.steps, 1), 2),
                "graph_build_s": round(t_build, 2)}
         print(json.dumps(out), flush=True)
@@ -191,4 +197,7 @@ def bench_main(args, rank, world, local_rank):
     dist.barrier()
     dist.destroy_process_group()
     if parity is False:
+        sys.exit(1)
+    if ranks_seen != args.gpus:
+        print("bench.py: %d ranks took part, --gpus says %d" % (ranks_seen, args.gpus), file=sys.stderr)
         sys.exit(1)

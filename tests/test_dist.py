@@ -234,6 +234,42 @@ def test_partitioned_sssp_hip_engine_ranks_share_one_gpu(built, world, scale):
     _run(world, True, scale, 30 + scale, _worker_sssp)
 
 
+def test_bench_self_launch_starts_one_rank_per_gpu():
+    """`python bench.py --gpus N` without a launcher starts N fresh ranks (torch.distributed.run on 127.0.0.1) before
+    anything touches the GPU, instead of falling through to the 1-GPU body.  CPU: the ranks
+    only report who they are (MGX_BENCH_LAUNCH_ONLY)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["MGX_BENCH_LAUNCH_ONLY"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    import re
+    seen = sorted(re.findall(r"launched rank (\d) of 3 \(--gpus 3\)", p.stdout + p.stderr))     # (ranks share the pipe: lines may interleave)
+    assert seen == ["0", "1", "2"], p.stdout + p.stderr
+
+
+@pytest.mark.gpu
+def test_bench_plain_command_runs_n_ranks(built):
+    """the same on the GPU box, end to end: `python bench.py --gpus 2` (no torchrun) prints ONE line with n_gpus = 2 and
+    rccl_ranks = 2 (two ranks on the one GPU over gloo: the pre-flight switches)"""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(MGX_BENCH_ALL_ON_GPU0="1", MGX_BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--scale", "14"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["parity_vs_oracle"] is True
+
+
 def _bench_preflight(world, extra_args, env_extra):
     """bench.py's N > 1 body (bench_dist.bench_main) under torch.distributed.run with `world` ranks sharing the
     one GPU of the test box over gloo (RCCL refuses two ranks on one device): the launch contract, the partition, the
