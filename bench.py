@@ -140,14 +140,24 @@ def main():
     if args.file:
         # a MatrixMarket file is parsed and sorted once; its binary CSR cache (mgx_graph_save_csr) is used from then on
         cache = args.file if args.file.endswith(".mgxcsr") else args.file + (".undir" if args.undirected else "") + ".mgxcsr"
-        if os.path.exists(cache):
-            c = mini_amd.load_csr_cache(cache)
-            n, ro_host, ci_host, w_host = c["n"], c["row_offsets"], c["col_indices"], c["weights"]
+        loaded = None
+        # the cache is used only while it is at least as new as the text file; a truncated or corrupt one (an interrupted
+        # run) is re-made from the text instead of ending the run
+        if os.path.exists(cache) and (cache == args.file or os.path.getmtime(cache) >= os.path.getmtime(args.file)):
+            try:
+                loaded = mini_amd.load_csr_cache(cache)
+            except mini_amd.MgxError:
+                if cache == args.file:
+                    raise
+        if loaded is not None:
+            n, ro_host, ci_host, w_host = loaded["n"], loaded["row_offsets"], loaded["col_indices"], loaded["weights"]
         else:
             n, ro_host, ci_host, w_host = mini_amd.load_mtx(args.file, undir=args.undirected)
             try:
-                mini_amd.save_csr_cache(cache, ro_host, ci_host, w_host, undirected=args.undirected)
-            except mini_amd.MgxError:
+                tmp = "%s.tmp.%d" % (cache, os.getpid())
+                mini_amd.save_csr_cache(tmp, ro_host, ci_host, w_host, undirected=args.undirected)
+                os.replace(tmp, cache)              # (never a half-written cache under the final name)
+            except (mini_amd.MgxError, OSError):
                 pass                    # (a read-only directory: no cache, nothing else changes)
         graph = mini_amd.Graph.from_host(ctx, ro_host, ci_host, w_host)
         if args.mode == "do" and not args.undirected:

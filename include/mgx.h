@@ -212,10 +212,13 @@ MGX_API int mgx_bfs_enact_pushpull(mgx_bfs_t p, float threshold, int64_t* stats)
  *   [18] slots whose short rows were walked vertex by vertex (bfs_fused_vshort.hpp)
  *   [19] slots that ran without queues (the build before them wrote none, bfs_build_is_lazy)
  *   [20] slots that ran the cold-edge pass (bfs_fused_cold.hpp).
- *   stats must hold 24 entries.                                                                 */
+ *   mgx_bfs_run writes entries [0] .. [15] (stats must hold 16: the contract of the first release, kept so that a
+ *   caller built against it is not overrun); mgx_bfs_run_stats is the same call with an explicit capacity and writes
+ *   min(cap, 24) entries.                                                                       */
 #define MGX_BFS_PUSH 0
 #define MGX_BFS_DIRECTION_OPT 1
 MGX_API int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats);
+MGX_API int mgx_bfs_run_stats(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats, int cap);
 /* per-level trace of the last mgx_bfs_run: level_nf[i], level_edges[i] for i < *levels  */
 MGX_API int mgx_bfs_level_trace(mgx_bfs_t p, int cap, int64_t* level_nf, int64_t* level_edges, int* levels);
 
@@ -333,6 +336,7 @@ MGX_API int mgx_comm_unique_id(unsigned char* out128);
 MGX_API int mgx_comm_create(mgx_ctx_t ctx, int ranks, int rank, const unsigned char* id128, mgx_comm_t* out);
 MGX_API int mgx_comm_free(mgx_comm_t comm);
 MGX_API const char* mgx_comm_library(void);
+MGX_API int mgx_comm_available(void); /* 1: RCCL is in the process or could be loaded with every entry point the library needs */
 MGX_API int mgx_dbfs2_run(mgx_dbfs2_t h, mgx_comm_t comm, int src_global, int exchange, int64_t exchange_words, int64_t* out6);
 
 /* ---- SSSP: sssp_problem_t / sssp_functor_t / sssp_enactor_t (gunrock/src/sssp/) ---- */

@@ -235,12 +235,14 @@ inline void d2_run(d2_state_t& st, comm_t& cm, d2_run_bufs_t& bufs, int src, int
         MGX_RCCL(api.AllGather(st.newbits, bufs.gathered.data(), (size_t)xwords, ncclUint32, cm.comm, s));
         d2_merge(st, level, bufs.gathered.data(), R, xwords, ctx);
       } else {
-        MGX_RCCL(api.GroupStart());
-        for (int r = 0; r < R; ++r) {
-          MGX_RCCL(api.Send(st.newbits + (size_t)r * S, (size_t)S, ncclUint32, r, cm.comm, s));
-          MGX_RCCL(api.Recv(bufs.recv.data() + (size_t)r * S, (size_t)S, ncclUint32, r, cm.comm, s));
+        {
+          rccl_group_t group(api);                  // (GroupEnd on every way out: a throw inside must not leave the thread's group open)
+          for (int r = 0; r < R; ++r) {
+            MGX_RCCL(api.Send(st.newbits + (size_t)r * S, (size_t)S, ncclUint32, r, cm.comm, s));
+            MGX_RCCL(api.Recv(bufs.recv.data() + (size_t)r * S, (size_t)S, ncclUint32, r, cm.comm, s));
+          }
+          group.end();
         }
-        MGX_RCCL(api.GroupEnd());
         hipLaunchKernelGGL(k_d2_or_maps, dim3(grid_for(S / 4, BLOCK, 1024)), dim3(BLOCK), 0, s, (const uint4*)bufs.recv.data(), R,
                            S / 4, S / 4, (uint4*)bufs.recv.data());
         MGX_RCCL(api.AllGather(bufs.recv.data(), bufs.gathered.data(), (size_t)S, ncclUint32, cm.comm, s));

@@ -71,6 +71,18 @@ struct rccl_api_t {
     }                                                                                                          \
   } while (0)
 
+// ncclGroupStart ... ncclGroupEnd as a scope: end() closes the group and reports its status; if the scope is left by an
+// exception before that, the destructor still closes the group (its status is dropped: the first error is on its way up)
+struct rccl_group_t {
+  const rccl_api_t& api;
+  bool open = false;
+  explicit rccl_group_t(const rccl_api_t& a) : api(a) { MGX_RCCL(api.GroupStart()); open = true; }
+  rccl_group_t(const rccl_group_t&) = delete;
+  rccl_group_t& operator=(const rccl_group_t&) = delete;
+  void end() { open = false; MGX_RCCL(api.GroupEnd()); }
+  ~rccl_group_t() { if (open) (void)api.GroupEnd(); }
+};
+
 struct comm_t {
   ncclComm_t comm = nullptr;
   int ranks = 1, rank = 0;

@@ -119,7 +119,13 @@ struct standard_context_t : context_t {
     if (mailbox) (void)hipHostFree(mailbox);
   }
   hipStream_t stream() const override { return _stream; }
-  void set_stream(hipStream_t s) { _stream = s; set_current_stream(s); }
+  // Work already enqueued by this context is finished first: the scans' look-back tickets and epochs (scan.hpp), the
+  // scratch arena and the mailbox assume that all launches of a context are serialised on ONE stream.
+  void set_stream(hipStream_t s) {
+    if (s != _stream) (void)hipStreamSynchronize(_stream);
+    _stream = s;
+    set_current_stream(s);
+  }
   void make_current() const { set_current_stream(_stream); }
   void synchronize() { MGX_HIP(hipStreamSynchronize(_stream)); }
 

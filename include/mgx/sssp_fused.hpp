@@ -124,7 +124,13 @@ __device__ __forceinline__ void sssp_open(const sssp_args_t& a, int it) {
       // the near queue ran dry: next bucket = the one that holds the smallest waiting distance (this iteration's
       // relax finds nothing to do, its build sweeps the marks again with the new threshold)
       const float lo = floorf(__uint_as_float(far_min) / a.delta);
-      c->sssp_thr = __float_as_uint((lo + 1.0f) * a.delta);
+      u32 thr = __float_as_uint((lo + 1.0f) * a.delta);
+      // progress guarantee: in float32 (lo + 1) * delta can round to <= far_min once far_min / delta nears 2^23 (far_min
+      // 1000, delta 1e-5: thr == 1000) -- the build tests d >= thr, nothing would become near and the same threshold
+      // would be computed forever.  Non-negative floats order like their bit patterns: the next float above far_min
+      // always admits the smallest waiting vertex.
+      if (thr <= far_min) thr = far_min + 1u;
+      c->sssp_thr = thr;
       return;
     }
     if (!c->done) { c->done = 1; c->levels = it; }

@@ -109,6 +109,7 @@ SIGNATURES = {
     "mgx_bfs_uniquify": [_vp, _vp, _vp, _i, _pi64],
     "mgx_bfs_enact_idempotent": [_vp, _pi64],
     "mgx_bfs_run": [_vp, _i, _i, _f, _pi64],
+    "mgx_bfs_run_stats": [_vp, _i, _i, _f, _pi64, _i],
     "mgx_bfs_level_trace": [_vp, _i, _pi64, _pi64, _pi],
     "mgx_bfs_set_kernel_timing": [_vp, _i],
     "mgx_bfs_kernel_times": [_vp, _pi64],
@@ -129,6 +130,7 @@ SIGNATURES = {
     "mgx_comm_create": [_vp, _i, _i, _vp, _pvp],
     "mgx_comm_free": [_vp],
     "mgx_comm_library": [],
+    "mgx_comm_available": [],
     "mgx_dbfs2_run": [_vp, _vp, _i, _i, _i64, _pi64],
     "mgx_dsssp_create": [_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _pvp],
     "mgx_dsssp_free": [_vp],

@@ -342,7 +342,7 @@ class BfsProblem:
     def run_into(self, src, mode, alpha, st):
         """Fused device-resident traversal, counters into a caller-made buffer (new_stats()): the call a timing loop
         makes -- nothing is allocated or converted between two traversals; stats_dict(st) reads the buffer afterwards."""
-        rc = lib.mgx_bfs_run(self._h, src, mode, alpha, st)
+        rc = lib.mgx_bfs_run_stats(self._h, src, mode, alpha, st, BfsProblem.STATS_LEN)
         if rc:
             check(rc)
 

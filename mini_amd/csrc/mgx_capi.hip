@@ -957,9 +957,11 @@ int mgx_bfs_enact_idempotent(mgx_bfs_t p, int64_t* stats) {
   MGX_CATCH
 }
 
-int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats) {
+int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats) { return mgx_bfs_run_stats(p, src, mode, alpha, stats, 16); }
+int mgx_bfs_run_stats(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats, int cap) {
   MGX_TRY
   MGX_REQUIRE(p, "NULL argument");
+  MGX_REQUIRE(cap >= 0, "mgx_bfs_run_stats: negative capacity");
   MGX_REQUIRE(src >= 0 && src < p->g->g->num_nodes, "mgx_bfs_run: src out of range");
   MGX_REQUIRE(mode == MGX_BFS_PUSH || mode == MGX_BFS_DIRECTION_OPT, "mgx_bfs_run: unknown mode");
   use_device(p->g->c);
@@ -991,7 +993,8 @@ int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats) {
   p->last_stats[18] = L.vshort_slots;
   p->last_stats[19] = L.lazy_slots;
   p->last_stats[20] = L.cold_slots;
-  if (stats) memcpy(stats, p->last_stats, sizeof(p->last_stats));
+  constexpr int have = (int)(sizeof(p->last_stats) / sizeof(p->last_stats[0]));
+  if (stats) memcpy(stats, p->last_stats, sizeof(int64_t) * (size_t)(cap < have ? cap : have));
   MGX_CATCH
 }
 int mgx_bfs_level_trace(mgx_bfs_t p, int cap, int64_t* level_nf, int64_t* level_edges, int* levels) {
@@ -1320,6 +1323,7 @@ int mgx_comm_free(mgx_comm_t h) {
   MGX_CATCH
 }
 const char* mgx_comm_library(void) { return mgx::rccl_api_t::get().where.c_str(); }
+int mgx_comm_available(void) { return mgx::rccl_api_t::get().ok() ? 1 : 0; }
 int mgx_dbfs2_run(mgx_dbfs2_t h, mgx_comm_t comm, int src_global, int exchange, int64_t exchange_words, int64_t* out6) {
   MGX_TRY
   MGX_REQUIRE(h && out6 && src_global >= 0 && src_global < h->st.n_global, "mgx_dbfs2_run: bad argument");

@@ -23,7 +23,7 @@ import torch
 import torch.distributed as dist
 
 from . import api
-from ._lib import check, lib
+from ._lib import MgxError, check, lib
 
 
 def chunk_of(n_global, ranks):
@@ -230,21 +230,44 @@ class HipRankEngine2:
             self._h = None
 
 
+def _lib_status_invalid():
+    from ._lib import MGX_E_INVALID
+    return MGX_E_INVALID
+
+
 class NativeComm:
     """An RCCL communicator owned by the library (include/mgx/comm.hpp): rank 0 makes the unique id, torch.distributed
     carries its 128 bytes to the other ranks, every rank joins (ncclCommInitRank)."""
 
     def __init__(self, ctx, rank, world, comm_device):
-        ident = torch.zeros(128, dtype=torch.uint8)
+        # The collective sequence is the same on every rank whatever fails where (ADVICE round 2): rank 0 ALWAYS
+        # broadcasts 129 bytes -- the id and an ok flag; if it could not make an id (librccl not loadable, a symbol
+        # missing) the flag is 0 and every rank raises the same error after the broadcast, instead of rank 0 skipping the
+        # broadcast and the others waiting in it.
+        self._h = None
+        # (ncclCommInitRank is itself a collective: a rank that cannot load RCCL must not leave the others waiting in it)
+        avail = torch.tensor([int(lib.mgx_comm_available())], dtype=torch.int32, device=comm_device)
+        if world > 1:
+            dist.all_reduce(avail, op=dist.ReduceOp.MIN)
+        if int(avail.item()) != 1:
+            raise MgxError(_lib_status_invalid(), "RCCL is not loadable on every rank (mgx_comm_available)")
+        ident = torch.zeros(129, dtype=torch.uint8)
+        err = None
         if rank == 0:
             buf = (C.c_ubyte * 128)()
-            check(lib.mgx_comm_unique_id(buf))
-            ident = torch.tensor(list(buf), dtype=torch.uint8)
+            try:
+                check(lib.mgx_comm_unique_id(buf))
+                ident[:128] = torch.tensor(list(buf), dtype=torch.uint8)
+                ident[128] = 1
+            except Exception as ex:
+                err = ex
         if world > 1:
             t = ident.to(comm_device)
             dist.broadcast(t, 0)
             ident = t.cpu()
-        raw = (C.c_ubyte * 128)(*ident.tolist())
+        if int(ident[128]) != 1:
+            raise err if err is not None else MgxError(_lib_status_invalid(), "rank 0 could not create an RCCL unique id")
+        raw = (C.c_ubyte * 128)(*ident[:128].tolist())
         h = C.c_void_p()
         check(lib.mgx_comm_create(ctx._h, int(world), int(rank), raw, C.byref(h)))
         self._h = h

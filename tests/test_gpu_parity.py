@@ -807,3 +807,22 @@ def test_sssp_fused_near_far_buckets(gpu_ctx, oracle, layout):
                 if delta == 4.0 and st["relaxations"] < base["relaxations"]:
                     fewer += 1
     assert fewer >= 4
+
+
+def test_sssp_near_far_tiny_delta_terminates(gpu_ctx, oracle):
+    """with far_min / delta near 2^23 the next threshold (floor(far_min / delta) + 1) * delta can round to
+    <= far_min in float32; nothing became near and the loop never ended.  The threshold now always admits the smallest
+    waiting distance: weights scaled so that distances are ~1000, delta 1e-4 and 1e-5 (ratios 1e7 .. 1e8), on a graph
+    small enough that one bucket per distinct distance still finishes quickly; distances equal float32 Dijkstra's."""
+    import mini_amd
+    rng = np.random.default_rng(5)
+    n, ro, ci, w = oracle.rmat_csr(8, 6, 99)
+    w = (rng.random(len(ci)) * 300.0 + 200.0).astype(np.float32)
+    g = _graph(gpu_ctx, ro, ci, w)
+    deg = np.diff(ro)
+    src = int(np.argmax(deg))
+    want = oracle.sssp_dijkstra_f32(ro, ci, w, src)
+    sssp = mini_amd.SsspProblem(g, src)
+    for delta in (1e-4, 1e-5):
+        sssp.run(src, delta=delta)
+        assert np.array_equal(sssp.distances(), want), delta
