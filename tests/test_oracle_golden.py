@@ -6,45 +6,49 @@ import os
 import numpy as np
 import pytest
 
+from tests.golden_inputs import case_path, matches
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 CASES = json.load(open(os.path.join(GOLD, "reference_goldens.json")))["cases"]
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
-def test_loader_and_cpu_validators_match_reference_goldens(oracle, case):
-    n, ro, ci, w, srcs = oracle.load_mtx(os.path.join(GOLD, case["file"]), undir=case["undir"])
+def test_loader_and_cpu_validators_match_reference_goldens(oracle, case, tmp_path):
+    """the oracle against what the reference's OWN load_graph / cpu() produced (tools/regen_goldens.sh): its fixtures with
+    src 0, and simple R-MAT graphs of 1 K .. 16 K vertices from the busiest row"""
+    n, ro, ci, w, srcs = oracle.load_mtx(case_path(case, oracle, tmp_path, GOLD), undir=case["undir"])
+    src = case["src"]
     assert n == case["n"] and len(ci) == case["m"]
-    if "offsets" in case:
-        assert ro.tolist() == case["offsets"]
-        assert ci.tolist() == case["indices"]
-    if "weights" in case:
-        assert w.tolist() == case["weights"]
+    assert matches(case, "offsets", ro, np.int32)
+    assert matches(case, "indices", ci, np.int32)
+    assert matches(case, "weights", w, np.float32)
     # csr.sources = row id per entry (graph.hxx:169)
     assert srcs.tolist() == np.repeat(np.arange(n), np.diff(ro)).tolist()
-    assert oracle.bfs_cpu(ro, ci, 0).tolist() == case["bfs_labels"]          # bfs_problem.hxx:52-72
-    preds, dist = oracle.sssp_cpu(ro, ci, w, 0)                              # sssp_problem.hxx:59-88
-    assert preds.tolist() == case["sssp_preds"]
-    if "sssp_dist" in case:
-        assert dist.tolist() == case["sssp_dist"]
+    assert matches(case, "bfs_labels", oracle.bfs_cpu(ro, ci, src), np.int32)          # bfs_problem.hxx:52-72
+    preds, dist = oracle.sssp_cpu(ro, ci, w, src)                                      # sssp_problem.hxx:59-88
+    assert matches(case, "sssp_preds", preds, np.int32)
+    assert matches(case, "sssp_dist", dist, np.int32)
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
-def test_enactor_restatements_agree_with_cpu_validators(oracle, case):
-    n, ro, ci, w, _ = oracle.load_mtx(os.path.join(GOLD, case["file"]), undir=case["undir"])
-    want = np.array(case["bfs_labels"], dtype=np.int32)
+def test_enactor_restatements_agree_with_cpu_validators(oracle, case, tmp_path):
+    n, ro, ci, w, _ = oracle.load_mtx(case_path(case, oracle, tmp_path, GOLD), undir=case["undir"])
+    src = case["src"]
+    want = oracle.bfs_cpu(ro, ci, src)
+    assert matches(case, "bfs_labels", want, np.int32)
     # push only (alpha = 1/n, test_bfs.cu:30)
-    rc, labels, stats = oracle.bfs_enact_pushpull(ro, ci, 0, 1.0 / n)
+    rc, labels, stats = oracle.bfs_enact_pushpull(ro, ci, src, 1.0 / n)
     assert rc == 0 and labels.tolist() == want.tolist()
     if case["undir"] and len(ci) >= n:
         # the reference's pull phase walks the CSR copy (F8): right only on symmetric graphs
         for alpha in (0.05, 0.5, 1.0, 4.0):
-            rc, labels, _ = oracle.bfs_enact_pushpull(ro, ci, 0, alpha)
+            rc, labels, _ = oracle.bfs_enact_pushpull(ro, ci, src, alpha)
             assert rc == 0 and labels.tolist() == want.tolist(), alpha
     # SSSP: frontier Bellman-Ford fixed point == float Dijkstra == the reference's int distances
-    dist, preds, st = oracle.sssp_enact(ro, ci, w, 0, 1.5)
-    dj = oracle.sssp_dijkstra_f32(ro, ci, w, 0)
+    dist, preds, st = oracle.sssp_enact(ro, ci, w, src, 1.5)
+    dj = oracle.sssp_dijkstra_f32(ro, ci, w, src)
     assert np.array_equal(dist, dj)
-    _, idist = oracle.sssp_cpu(ro, ci, w, 0)
+    _, idist = oracle.sssp_cpu(ro, ci, w, src)
     reach = idist < np.iinfo(np.int32).max
     assert np.array_equal(dist[reach], idist[reach].astype(np.float32))
     assert np.all(dist[~reach] == np.finfo(np.float32).max)
