@@ -37,7 +37,7 @@ HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 T
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scale", type=int, default=22)
     ap.add_argument("--edgefactor", type=int, default=16)
@@ -48,8 +48,13 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--mode", choices=["push", "do"], default="push",
-                    help="push = BASELINE config 2 (headline); do = direction-optimising (config 4)")
+    ap.add_argument("--mode", choices=["push", "do", "sssp", "pr"], default="push",
+                    help="push = BASELINE config 2 (headline); do = direction-optimising (config 4); sssp = config 3 (fused "
+                         "frontier Bellman-Ford on weighted RMAT, value = edge relaxations/s); pr = the segmented "
+                         "neighbour-reduce over the full frontier (value = reduced edges/s)")
+    ap.add_argument("--per-call", action="store_true",
+                    help="BFS: time one library call per source instead of submitting the K sources as one batch "
+                         "(mgx_bfs_run_many); the per-call figure is on the line either way (per_call)")
     ap.add_argument("--alpha", type=float, default=4.0, help="bottom-up switch: unvisited < frontier*alpha")
     ap.add_argument("--no-layout", action="store_true", help="keep generator vertex ids (no hub-first relabelling)")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
@@ -135,6 +140,36 @@ def main():
 
     stream = torch.cuda.current_stream()
     ctx = mini_amd.Context(local_rank, stream.cuda_stream)
+    if args.mode == "sssp":
+        return bench_sssp(args, ctx, stream)
+    if args.mode == "pr":
+        return bench_pr(args, ctx, stream)
+    return bench_bfs(args, ctx, stream)
+
+
+def _pmc_traffic(args, kname, sha):
+    """roofline.traffic from the committed PMC passes -- only when they were taken on exactly these sources"""
+    traffic, note = None, "no PMC measurement for these sources (profiles/pmc_traffic.json)"
+    if os.path.exists(args.pmc_json) and not args.file:
+        try:
+            pj = json.load(open(args.pmc_json))
+            entries = pj.get("entries", [pj])
+            for e in entries:
+                if e.get("scale") == args.scale and e.get("kernel") == kname and e.get("source_sha") == sha and e.get("mode") == args.mode:
+                    return e.get("hbm_bytes_per_launch"), ("2 x FETCH_SIZE + WRITE_SIZE per dispatch of this kernel, separate --pmc "
+                                                           "passes of this command (profiles/)")
+            note = "profiles/pmc_traffic.json was measured on other sources/kernels (%s vs %s): not reported" % (
+                entries[0].get("source_sha") if entries else None, sha)
+        except Exception:
+            pass
+    return traffic, note
+
+
+def bench_bfs(args, ctx, stream):
+    import numpy as np
+    import torch
+    import mini_amd
+    from mini_amd import rmat
     seed = args.scale if args.seed is None else args.seed
     t_build = time.time()
     if args.file:
@@ -187,36 +222,70 @@ def main():
     bfs = mini_amd.BfsProblem(graph, sources[0])
 
     mode = mini_amd.MGX_BFS_DIRECTION_OPT if args.mode == "do" else mini_amd.MGX_BFS_PUSH
+    timed = [int(s) for s in sources[args.warmup:]]
+    alpha_f = float(args.alpha)
+    # warm-up: the W warm-up sources one call each, then (batched submission) the timed batch shape once, so that the
+    # slot hint the batch is sized by has seen this graph's level structure
     for s in sources[:args.warmup]:
         bfs.run(s, mode, args.alpha)
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    # the timed region: K whole traversals, one after the other (each call returns when its labels are complete); the
-    # counters go into buffers made beforehand, nothing is converted or allocated between two traversals
-    timed = [int(s) for s in sources[args.warmup:]]
-    bufs = [bfs.new_stats() for _ in timed]
-    alpha_f, run_into = float(args.alpha), bfs.run_into
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for s, st in zip(timed, bufs):
-        run_into(s, mode, alpha_f, st)
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    reruns = 0
+    if args.per_call:
+        # K whole traversals, one library call each (each call returns when its labels are complete); the counters go into
+        # buffers made beforehand, nothing is converted or allocated between two traversals
+        bufs = [bfs.new_stats() for _ in timed]
+        run_into = bfs.run_into
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for s, st in zip(timed, bufs):
+            run_into(s, mode, alpha_f, st)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        stats = [bfs.stats_dict(st) for st in bufs]
+    else:
+        # the timed region: the K traversals handed to the library as ONE batch (mgx_bfs_run_many): each traversal is
+        # complete (labels re-initialised, every level run, counters taken) before the next one starts on the device, but
+        # the host waits once, at the end -- no host round trip between two traversals
+        prepared = bfs.prepare_many(timed)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        raw, reruns = bfs.run_many(timed, mode, alpha_f, prepared=prepared)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        L = bfs.STATS_LEN
+        stats = [bfs.stats_dict(raw[i * L:(i + 1) * L]) for i in range(len(timed))]
     dev_ms = ev0.elapsed_time(ev1)
-    stats = [bfs.stats_dict(st) for st in bufs]
+    # Per-call pass (always): the same K sources, one call each, each timed on the host -> the per-call mean beside the
+    # batched figure, and the per-source median SURVEY 8d asks for
+    per_src_s = []
+    for s in timed:
+        st1 = bfs.new_stats()
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        bfs.run_into(s, mode, alpha_f, st1)
+        per_src_s.append(time.perf_counter() - tc)
+    per_src_mt = [st["m_t"] for st in stats]
     # Roofline pass: the SAME K sources again, now with HIP events around every launch of the product kernel k_bfs_push
-    # (on the launch stream).  A second pass because every event record between two kernels leaves a ~6 us gap on the
-    # stream (rocprofv3 kernel trace, profiles/): inside the timed region they would cost several % of `value`.
+    # and of the queue build behind it (on the launch stream).  A pass of its own because every event record between two
+    # kernels leaves a ~6 us gap on the stream (rocprofv3 kernel trace, profiles/): inside the timed region they would cost
+    # several % of `value`.
     bfs.set_kernel_timing(2)
     stats_timed, kernel_times = [], []
-    for s in sources[args.warmup:]:
+    build_launches, build_ns = 0, 0
+    for s in timed:
         stats_timed.append(bfs.run(s, mode, args.alpha))
-        kernel_times.append(bfs.kernel_times()["stream"])
+        kt = bfs.kernel_times()
+        kernel_times.append(kt["stream"])
+        build_launches += kt["wave"]["launches"]
+        build_ns += kt["wave"]["ns"]
     # ... and once more with the launch split into its parts (long rows / short rows), for the breakdown only
     bfs.set_kernel_timing(1)
     parts = {"stream": {"launches": 0, "ns": 0, "edges": 0, "vertices": 0}, "wave": {"launches": 0, "ns": 0, "edges": 0, "vertices": 0}}
-    for s in sources[args.warmup:]:
+    for s in timed:
         bfs.run(s, mode, args.alpha)
         k = bfs.kernel_times()
         for name in parts:
@@ -236,45 +305,47 @@ def main():
     alg_bytes = 8.0 * push_edges + 4.125 * pull_edges + 20.0 * nf_total
     value = m_t / elapsed / 1e6
 
-    # Dominant kernel: k_bfs_push, ONE launch per slot.  achieved = algorithmic bytes of the edges / frontier vertices
-    # the push levels expanded / device time of ALL its launches (the ones that run a chain of small levels or find
-    # nothing to do included, as rocprofv3 --stats averages over them too).
+    # Dominant kernel: k_bfs_push, ONE launch per slot.  achieved = algorithmic bytes of what the kernel itself moves --
+    # 8 B per edge (column index + visited probe) + 12 B per frontier vertex (id, two row offsets); the other 8 B per
+    # vertex of SURVEY 8d's 20 (label write, next-frontier write) are moved by the queue build and credited to the slot
+    # (push + build) below -- / device time of ALL its launches (the ones that run a chain of small levels or find nothing
+    # to do included, as rocprofv3 --stats averages over them too).
     dom = {f: sum(k[f] for k in kernel_times) for f in ("launches", "ns", "edges", "vertices")}
     kname = "k_bfs_push<false, 0>"
+    slot_frac = None
     if dom["launches"] and dom["ns"] and dom["edges"]:
-        dom_bytes = 8.0 * dom["edges"] + 20.0 * dom["vertices"]
+        dom_bytes = 8.0 * dom["edges"] + 12.0 * dom["vertices"]
         avg_launch_s = (dom["ns"] / 1e9) / dom["launches"]
         bytes_per_launch = dom_bytes / dom["launches"]
+        if build_ns:
+            slot_frac = (8.0 * dom["edges"] + 20.0 * dom["vertices"]) / ((dom["ns"] + build_ns) / 1e9) / 1e9 / HBM_PEAK_GBPS
     else:
         avg_launch_s = (kernel_ns / 1e9) / max(launches, 1)
         bytes_per_launch = alg_bytes / max(launches, 1)
         kname = "bfs level kernels (all)"
     achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
     sha = source_sha()
-    traffic, traffic_note = None, "no PMC measurement for these sources (profiles/pmc_traffic.json)"
-    if os.path.exists(args.pmc_json) and not args.file:
-        try:
-            pj = json.load(open(args.pmc_json))
-            if pj.get("scale") == args.scale and pj.get("kernel") == kname and pj.get("source_sha") == sha and pj.get("mode") == args.mode:
-                traffic = pj.get("hbm_bytes_per_launch")
-                traffic_note = "2 x FETCH_SIZE + WRITE_SIZE per dispatch of this kernel, separate --pmc passes of this command (profiles/)"
-            else:
-                traffic_note = "profiles/pmc_traffic.json was measured on other sources/kernels (%s vs %s): not reported" % (pj.get("source_sha"), sha)
-        except Exception:
-            traffic = None
+    traffic, traffic_note = _pmc_traffic(args, kname, sha)
     long_ns, short_ns = parts["stream"]["ns"], parts["wave"]["ns"]
+    K = max(len(stats), 1)
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": traffic, "traffic_note": traffic_note, "launches": dom["launches"] if dom["launches"] else launches,
+                "alg_bytes": "8 B per traversed edge + 12 B per frontier vertex (this kernel's share of SURVEY 8d's 8 + 20; the "
+                             "label and next-frontier writes, 8 B per vertex, belong to the queue build: slot_frac)",
                 "timing": "HIP events around every launch of this kernel on the launch stream, second pass over the same %d "
                           "sources (events kept out of the timed region: each leaves a ~6 us gap on the stream)" % len(stats),
                 "avg_launch_us": round(avg_launch_s * 1e6, 3),
                 "alg_bytes_per_launch": round(bytes_per_launch, 1),
                 "share_of_edges": round(dom["edges"] / max(m_t, 1), 4) if dom["launches"] else 1.0,
-                "parts": {"long_rows": {"alg_GBps": round((8.0 * parts["stream"]["edges"] + 20.0 * parts["stream"]["vertices"]) / max(long_ns, 1), 2),
-                                        "us_per_traversal": round(long_ns / 1e3 / max(len(stats), 1), 2), "edges_share": round(parts["stream"]["edges"] / max(m_t, 1), 4)},
-                          "short_rows": {"alg_GBps": round((8.0 * parts["wave"]["edges"] + 20.0 * parts["wave"]["vertices"]) / max(short_ns, 1), 2),
-                                         "us_per_traversal": round(short_ns / 1e3 / max(len(stats), 1), 2), "edges_share": round(parts["wave"]["edges"] / max(m_t, 1), 4)},
+                "slot_frac": round(slot_frac, 5) if slot_frac is not None else None,
+                "slot_note": "advance + filter: (8 B/edge + 20 B/vertex) / (device time of k_bfs_push + k_bfs_build2 of every slot) / peak",
+                "build_us_per_traversal": round(build_ns / 1e3 / K, 2), "build_launches_per_traversal": round(build_launches / K, 2),
+                "push_us_per_traversal": round(dom["ns"] / 1e3 / K, 2),
+                "parts": {"long_rows": {"alg_GBps": round((8.0 * parts["stream"]["edges"] + 12.0 * parts["stream"]["vertices"]) / max(long_ns, 1), 2),
+                                        "us_per_traversal": round(long_ns / 1e3 / K, 2), "edges_share": round(parts["stream"]["edges"] / max(m_t, 1), 4)},
+                          "short_rows": {"alg_GBps": round((8.0 * parts["wave"]["edges"] + 12.0 * parts["wave"]["vertices"]) / max(short_ns, 1), 2),
+                                         "us_per_traversal": round(short_ns / 1e3 / K, 2), "edges_share": round(parts["wave"]["edges"] / max(m_t, 1), 4)},
                           "note": "third pass, the launch split into its parts (k_bfs_push<false, 2> / <false, 3>) with events around each"},
                 "all_level_kernels_alg_GBps": round(alg_bytes / max(kernel_ns / 1e9, 1e-12) / 1e9, 2),
                 "whole_bfs_alg_GBps": round(alg_bytes / (dev_ms / 1e3) / 1e9, 2),
@@ -289,7 +360,7 @@ def main():
             ci_host = g["col_indices"].cpu().numpy()
         deg = np.diff(ro_host)
         cpu_edges, cpu_time, used = 0, 0.0, 0
-        for s in sources[args.warmup:]:
+        for s in timed:
             tc = time.perf_counter()
             want = orc.bfs_cpu(ro_host, ci_host, s)
             cpu_time += time.perf_counter() - tc
@@ -298,6 +369,10 @@ def main():
             if (used == 1 or args.validate) and not args.no_check:
                 bfs.run(s, mode, args.alpha)
                 ok = bool(np.array_equal(bfs.labels(), want))
+                if used == 1 and not args.per_call:
+                    # ... and the batched call itself: the labels it leaves are the LAST source's -- run [first, this] as a batch
+                    bfs.run_many([timed[-1], s], mode, alpha_f)
+                    ok = ok and bool(np.array_equal(bfs.labels(), want))
                 parity = ok if parity is None else (parity and ok)
             if (cpu_time > args.cpu_seconds or args.no_cpu_baseline) and not args.validate:
                 break
@@ -307,26 +382,248 @@ def main():
                    "sample": "oracle orc_bfs_cpu (restated bfs_problem_t::cpu) on %d of the %d timed sources, "
                              "same in-memory CSR, 1 thread, %.1f s" % (used, len(stats), cpu_time)}
 
+    per_call_ms = sorted(x * 1e3 for x in per_src_s)
+    med = per_call_ms[len(per_call_ms) // 2] if per_call_ms else 0.0
+    per_src_rate = sorted(mt / max(t, 1e-12) / 1e6 for mt, t in zip(per_src_mt, per_src_s))
+    submission = "one library call per source" if args.per_call else \
+        "the %d sources submitted as ONE batch (mgx_bfs_run_many: traversals back to back on the device, one host wait)" % len(timed)
     out = {"metric": "MTEPS (million traversed edges/sec) BFS advance+filter, %s" % ("RMAT-%d" % args.scale if not args.file else os.path.basename(args.file)),
            "value": round(value, 2), "unit": "MTEPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 4), "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic" if not args.file else "file",
-           "config": {"workload": "BFS %s (fused LB advance + idempotent-visited filter) on %s, n=%d m=%d, %d %s; "
+           "config": {"workload": "BFS %s (fused LB advance + idempotent-visited filter) on %s, n=%d m=%d, %d %s, %s; "
                                   "untimed one-time preprocessing per graph: hub-first copy + unit blocks (layout_build_s)"
                                   % ("push" if args.mode == "push" else "direction-optimising alpha=%g" % args.alpha,
-                                     what, n, m, args.steps, "seeded sources" if args.src is None and not args.file else "runs from source %d" % sources[0]),
+                                     what, n, m, args.steps, "seeded sources" if args.src is None and not args.file else "runs from source %d" % sources[0],
+                                     submission),
                       "scale": args.scale if not args.file else None, "edgefactor": args.edgefactor if not args.file else None,
-                      "seed": seed, "parallelism": "1 GPU",
+                      "seed": seed, "parallelism": "1 GPU", "submission": "per_call" if args.per_call else "batch",
                       "layout": "hub-first (degree-sorted) copy + unit blocks for the fused kernel" if use_layout else "generator ids"},
            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity,
+           "per_call": {"ms_per_step": round(sum(per_src_s) * 1e3 / K, 4), "value": round(m_t / max(sum(per_src_s), 1e-12) / 1e6, 2),
+                        "ms_per_step_median": round(med, 4),
+                        "value_median_source": round(per_src_rate[len(per_src_rate) // 2], 2) if per_src_rate else None,
+                        "note": "the same %d sources, one mgx_bfs_run call each, each timed on the host (call to return); the median is "
+                                "over sources (SURVEY 8d)" % len(timed)},
+           "graph500_MTEPS": round(m_t / 2.0 / elapsed / 1e6, 2),
+           "graph500_note": "Graph500 convention: undirected input edges inside the reached component / time = m_t / 2 on the symmetrised CSR (SURVEY 8d)",
+           "batch_reruns": reruns,
            "device_ms_per_step": round(dev_ms / max(args.steps, 1), 4),
-           "avg_levels": round(sum(st["levels"] for st in stats) / max(len(stats), 1), 2),
-           "avg_slots": round(sum(st["slots"] for st in stats) / max(len(stats), 1), 2),
-           "avg_reached": reached // max(len(stats), 1), "graph_build_s": round(t_build, 2), "layout_build_s": round(t_layout, 2),
+           "avg_levels": round(sum(st["levels"] for st in stats) / K, 2),
+           "avg_slots": round(sum(st["slots"] for st in stats) / K, 2),
+           "avg_reached": reached // K, "graph_build_s": round(t_build, 2), "layout_build_s": round(t_layout, 2),
            "source_sha": sha}
     print(json.dumps(out), flush=True)
     if parity is False:
         print("bench.py: labels differ from the oracle's -- the line above is NOT a valid measurement", file=sys.stderr)
+        sys.exit(1)
+
+
+
+def bench_sssp(args, ctx, stream):
+    """BASELINE config 3: SSSP on the weighted RMAT (integer weights in [0, 63]).  step = one whole run from a seeded source
+    (mgx_sssp_run: the fused frontier Bellman-Ford of sssp_enactor.hxx:40-72, advance = relax every edge of the frontier,
+    filter = one entry per improved vertex); value = edge relaxations / s."""
+    import numpy as np
+    import torch
+    import mini_amd
+    from mini_amd import rmat
+    seed = args.scale if args.seed is None else args.seed
+    t_build = time.time()
+    g = rmat.rmat_csr(ctx, args.scale, args.edgefactor, seed=seed, weighted=True)
+    graph = mini_amd.Graph.from_device(ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"], g["weights"])
+    ro_host = g["row_offsets"].cpu().numpy()
+    n, m = g["n"], g["m"]
+    t_build = time.time() - t_build
+    t_layout = time.time()
+    if not args.no_layout:
+        graph.build_layout(weights=True)
+        torch.cuda.synchronize()
+    t_layout = time.time() - t_layout
+    sources = [args.src] * (args.steps + args.warmup) if args.src is not None else rmat.pick_sources(ro_host, args.steps + args.warmup, seed)
+    sssp = mini_amd.SsspProblem(graph, sources[0])
+    for s in sources[:args.warmup]:
+        sssp.run(s)
+    timed = [int(s) for s in sources[args.warmup:]]
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    stats = []
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for s in timed:
+        stats.append(sssp.run(s))
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    relax = sum(st["relaxations"] for st in stats)
+    ftot = sum(st["frontier_total"] for st in stats)
+    iters = sum(st["iterations"] for st in stats)
+    # roofline pass: the same sources with HIP events around every k_sssp_relax launch (on the launch stream)
+    sssp.set_kernel_timing(True)
+    k_launch, k_ns, relax2, ftot2 = 0, 0, 0, 0
+    for s in timed:
+        st = sssp.run(s)
+        kt = sssp.kernel_times()
+        k_launch += kt["launches"]; k_ns += kt["ns"]
+        relax2 += st["relaxations"]; ftot2 += st["frontier_total"]
+    sssp.set_kernel_timing(False)
+    # algorithmic bytes (SURVEY 8d): 12 B per relaxation (column index, weight, dist[dst]) + 24 B per frontier vertex
+    # (id, two offsets, dist[src], next-frontier entry, mark); the relax kernel's share: 12 B + 16 B
+    alg_bytes = 12.0 * relax + 24.0 * ftot
+    k_bytes = 12.0 * relax2 + 16.0 * ftot2
+    avg_launch_s = (k_ns / 1e9) / max(k_launch, 1)
+    achieved = (k_bytes / max(k_launch, 1)) / max(avg_launch_s, 1e-12) / 1e9
+    sha = source_sha()
+    traffic, traffic_note = _pmc_traffic(args, "k_sssp_relax<1024>", sha)
+    K = max(len(timed), 1)
+    roofline = {"bound": "hbm", "kernel": "k_sssp_relax<1024>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_note": traffic_note,
+                "launches": k_launch, "avg_launch_us": round(avg_launch_s * 1e6, 3),
+                "alg_bytes_per_launch": round(k_bytes / max(k_launch, 1), 1),
+                "alg_bytes": "12 B per edge relaxation + 16 B per frontier vertex (this kernel's share of SURVEY 8d's 12 + 24; the "
+                             "queue build moves the other 8 B per vertex)",
+                "timing": "HIP events around every launch of this kernel on the launch stream, second pass over the same %d sources" % len(timed),
+                "whole_run_alg_GBps": round(alg_bytes / (dev_ms / 1e3) / 1e9, 2),
+                "whole_run_frac": round(alg_bytes / (dev_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 5)}
+    cpu, parity = None, None
+    if not args.no_cpu_baseline or not args.no_check:
+        from tests.oracle_binding import Oracle
+        orc = Oracle()
+        ci_host, w_host = g["col_indices"].cpu().numpy(), g["weights"].cpu().numpy()
+        deg = np.diff(ro_host)
+        if not args.no_check:
+            s = timed[0]
+            want = orc.sssp_dijkstra_f32(ro_host, ci_host, w_host, s)       # float32 Dijkstra: the unique min-plus fixed point
+            sssp.run(s)
+            parity = bool(np.array_equal(sssp.distances(), want))
+        if not args.no_cpu_baseline:
+            cpu_time, cpu_edges, used = 0.0, 0, 0
+            for s in timed:
+                tc = time.perf_counter()
+                _, idist = orc.sssp_cpu(ro_host, ci_host, w_host, s)        # restated sssp_problem_t::cpu (sssp_problem.hxx:59-88)
+                cpu_time += time.perf_counter() - tc
+                cpu_edges += int(deg[idist < np.iinfo(np.int32).max].sum())
+                used += 1
+                if cpu_time > args.cpu_seconds:
+                    break
+            cpu = {"value": round(cpu_edges / max(cpu_time, 1e-9) / 1e6, 2), "unit": "MTEPS (out-edges of reached vertices / s)", "cores": 1,
+                   "kind": "port", "host_cpus": os.cpu_count(), "seconds_per_source": round(cpu_time / max(used, 1), 3),
+                   "sample": "oracle orc_sssp_cpu (restated sssp_problem_t::cpu: label-correcting, priority queue) on %d of the %d timed "
+                             "sources, same in-memory CSR, 1 thread, %.1f s; it scans an edge once per improvement of its source, "
+                             "so its rate is quoted on the traversed edges m_t, next to traversed_MTEPS of the GPU run" % (used, len(timed), cpu_time)}
+    out = {"metric": "MTEPS (million edge relaxations/sec) SSSP advance+filter, RMAT-%d weighted" % args.scale,
+           "value": round(relax / elapsed / 1e6, 2), "unit": "MTEPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 4), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "SSSP (fused frontier Bellman-Ford: relax every edge of the frontier with atomicMin, one queue entry per "
+                                  "improved vertex) on RMAT scale %d ef %d symmetrised, integer weights in [0, 63] as float32, n=%d m=%d, "
+                                  "%d seeded sources, one library call per source; untimed one-time preprocessing per graph: hub-first "
+                                  "copy with weights (layout_build_s)" % (args.scale, args.edgefactor, n, m, args.steps),
+                      "scale": args.scale, "edgefactor": args.edgefactor, "seed": seed, "parallelism": "1 GPU",
+                      "layout": "generator ids" if args.no_layout else "hub-first (degree-sorted) copy with weights"},
+           "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity,
+           "traversed_MTEPS": None,
+           "relaxations_per_source": relax // K, "frontier_total_per_source": ftot // K, "iterations_per_source": round(iters / K, 2),
+           "device_ms_per_step": round(dev_ms / max(args.steps, 1), 4), "graph_build_s": round(t_build, 2), "layout_build_s": round(t_layout, 2),
+           "source_sha": sha}
+    # traversed edges of the reached component (Gunrock's m_t), for the comparison with the CPU validator's rate
+    if cpu is not None or parity is not None:
+        reached_deg = None
+        try:
+            d0 = sssp.distances()
+            reached_deg = int(np.diff(ro_host)[d0 < np.finfo(np.float32).max].sum())
+        except Exception:
+            pass
+        if reached_deg is not None:
+            out["traversed_MTEPS"] = round(reached_deg / (elapsed / K) / 1e6, 2)
+    print(json.dumps(out), flush=True)
+    if parity is False:
+        print("bench.py: distances differ from the oracle's -- the line above is NOT a valid measurement", file=sys.stderr)
+        sys.exit(1)
+
+
+def bench_pr(args, ctx, stream):
+    """The segmented neighbour-reduce (neighborhood.hxx:12-70, the operator PR is built on): step = one reduce over the full
+    frontier (every vertex), reduced[v] = sum of value[u] over the row of v; value = reduced edges / s."""
+    import numpy as np
+    import torch
+    import mini_amd
+    from mini_amd import rmat
+    seed = args.scale if args.seed is None else args.seed
+    t_build = time.time()
+    g = rmat.rmat_csr(ctx, args.scale, args.edgefactor, seed=seed, weighted=False)
+    graph = mini_amd.Graph.from_device(ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"])
+    n, m = g["n"], g["m"]
+    t_build = time.time() - t_build
+    t_layout = 0.0
+    f = mini_amd.Frontier(ctx, n).fill_iota(n)
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    vals = torch.rand(n, device="cuda", generator=gen)
+    red = torch.empty(n, device="cuda")
+    for _ in range(max(args.warmup, 1)):
+        mini_amd.segreduce(graph, f, vals, 0.0, red, "f32_plus")
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    nz = 0
+    for _ in range(args.steps):
+        nz = mini_amd.segreduce(graph, f, vals, 0.0, red, "f32_plus")
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    # roofline pass: events around each operator call (all its kernels run on this stream; the count read-back included)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for a, b in evs:
+        a.record(stream)
+        mini_amd.segreduce(graph, f, vals, 0.0, red, "f32_plus")
+        b.record(stream)
+    torch.cuda.synchronize()
+    op_ms = sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1)
+    alg = 8.0 * nz + 16.0 * n
+    achieved = alg / (op_ms / 1e3) / 1e9
+    sha = source_sha()
+    traffic, traffic_note = _pmc_traffic(args, "neighbour-reduce operator", sha)
+    roofline = {"bound": "hbm", "kernel": "neighbour-reduce operator (degree scan + segmented reduce + fix-ups: every kernel of one "
+                                          "mgx_segreduce_f32_plus call)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_note": traffic_note, "launches": len(evs),
+                "avg_launch_us": round(op_ms * 1e3, 3), "alg_bytes_per_launch": alg,
+                "alg_bytes": "8 B per edge (column index + value gather) + 16 B per frontier vertex (SURVEY 8d)",
+                "timing": "HIP events around every operator call on the launch stream, second pass"}
+    cpu, parity = None, None
+    if not args.no_cpu_baseline or not args.no_check:
+        from tests.oracle_binding import Oracle
+        orc = Oracle()
+        ro_h, ci_h = g["row_offsets"].cpu().numpy(), g["col_indices"].cpu().numpy()
+        fin = np.arange(n, dtype=np.int32)
+        v_h = vals.cpu().numpy()
+        tc = time.perf_counter()
+        want, onz = orc.neighbor_reduce_f32_plus(ro_h, ci_h, fin, v_h, 0.0)
+        cpu_time = time.perf_counter() - tc
+        if not args.no_check:
+            got = red.cpu().numpy()
+            # float sum order differs (the reference's own order is moderngpu's, unpinned): 2e-5 relative, as tests/ do
+            parity = bool(onz == nz and np.allclose(got, want, rtol=2e-5, atol=1e-6))
+        if not args.no_cpu_baseline:
+            cpu = {"value": round(onz / max(cpu_time, 1e-9) / 1e6, 2), "unit": "MTEPS", "cores": 1, "kind": "port", "host_cpus": os.cpu_count(),
+                   "sample": "oracle orc_neighbor_reduce_f32_plus (serial restatement of neighborhood.hxx:12-70) once over the same "
+                             "%d edges, 1 thread, %.1f s" % (onz, cpu_time)}
+    out = {"metric": "MTEPS (million reduced edges/sec) segmented neighbour-reduce, RMAT-%d" % args.scale,
+           "value": round(nz * args.steps / elapsed / 1e6, 2), "unit": "MTEPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 4), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "neighbour-reduce (float plus) over the full frontier of RMAT scale %d ef %d symmetrised, n=%d m=%d: "
+                                  "one operator call per step" % (args.scale, args.edgefactor, n, m),
+                      "scale": args.scale, "edgefactor": args.edgefactor, "seed": seed, "parallelism": "1 GPU",
+                      "layout": "generator ids"},
+           "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "parity_tolerance": "rtol 2e-5 (float sum order)",
+           "device_ms_per_step": round(dev_ms / max(args.steps, 1), 4), "graph_build_s": round(t_build, 2), "layout_build_s": round(t_layout, 2),
+           "source_sha": sha}
+    print(json.dumps(out), flush=True)
+    if parity is False:
+        print("bench.py: reduced values differ from the oracle's -- the line above is NOT a valid measurement", file=sys.stderr)
         sys.exit(1)
 
 

@@ -167,13 +167,9 @@ struct bfs_fused_enactor_t {
   bfs_fused_enactor_t(const bfs_fused_enactor_t&) = delete;
   bfs_fused_enactor_t& operator=(const bfs_fused_enactor_t&) = delete;
 
-  // labels are (re)initialised by the run itself; bfs_problem->src is the source.
-  // direction_optimizing: bottom-up levels once num_unvisited < frontier_length * alpha
-  // (the reference's rule, bfs_enactor.hxx:68); in-edges come from the graph's CSC slots.
-  void enact(std::shared_ptr<bfs_problem_t> bfs_problem, standard_context_t& context,
-             bool direction_optimizing = false, float alpha = 0.f) {
+  // the graph's hub-first layout (if it has one) as the fused loop takes it
+  static mgx::bfs_layout_t layout_of(graph_device_t& g) {
     mgx::bfs_layout_t layout;
-    auto& g = *bfs_problem->gslice;
     if (g.has_layout) {
       layout.row_offsets = g.d_layout_row_offsets.data();
       layout.col_indices = g.d_layout_col_indices.data();
@@ -202,22 +198,17 @@ struct bfs_fused_enactor_t {
         layout.cold_long_min = g.cold_long_min;
       }
     }
-    // the hub-first layout carries no separate CSC: bottom-up levels can use it only on graphs whose
-    // CSC slots alias the CSR (symmetric input, what the reference always has)
-    const bool use_layout = g.has_layout && (!direction_optimizing || g.csc_is_csr);
-    last = bfs_run_stats_t();
-    mgx::bfs_fused_run(*fused, g.d_row_offsets.data(), g.d_col_indices.data(), bfs_problem->d_labels.data(),
-                       bfs_problem->src, context, use_layout ? &layout : nullptr, direction_optimizing ? 1 : 0, alpha,
-                       g.d_col_offsets.data(), g.d_row_indices.data());
-    const mgx::bfs_ctrl_t* hc = fused->host_ctrl;
+    return layout;
+  }
+
+  // counters of a traversal from the (head of the) control block it left on the host
+  void fill_stats(bfs_run_stats_t& last, const mgx::bfs_ctrl_t* hc, bool direction_optimizing, bool with_timing) const {
     last.levels = hc->levels; last.push_levels = hc->push_levels;
     last.reached = (long long)hc->reached; last.m_t = (long long)hc->sum_edges;
     last.pull_edges = (long long)hc->pull_edges; last.frontier_vertices = (long long)hc->sum_frontier;
     last.claims = (long long)hc->claims;
-    last.kernel_launches = fused->level_kernel_launches; last.kernel_ns = (long long)(fused->level_kernel_ms * 1e6);
-    for (int i = 0; i < hc->levels && i < mgx::BFS_MAX_TRACE; ++i)
+    for (int i = 0; i < hc->levels && i < (with_timing ? mgx::BFS_MAX_TRACE : 64); ++i)
       last.trace.emplace_back((long long)(hc->trace[i] >> mgx::BFS_VSHIFT), (long long)(hc->trace[i] & mgx::BFS_EMASK));
-    for (int i = 0; i < fused->batches; ++i) last.batch_ms.push_back(fused->batch_ms[i]);
     // (a level's duration needs the stamp of the NEXT level's opening: the direct scheme ends a traversal from the
     //  read-back cursors without opening the level behind the last one -- no time for that last level then)
     for (int i = 0; i < hc->levels && i < 63 && hc->stamp[i + 1] >= hc->stamp[i] && hc->stamp[i + 1] != 0; ++i)
@@ -229,15 +220,20 @@ struct bfs_fused_enactor_t {
     last.lazy_slots = hc->lazy_slots;
     last.cold_slots = hc->cold_slots;
     for (int i = 0; i < last.push_levels && i < (int)last.trace.size(); ++i) last.push_edges += last.trace[i].second;
-    // the long-row queue only exists on push levels; the short-row queue gets the rest of the push edges
-    last.stream.launches = fused->stream_kernel_launches;
-    last.stream.ns = (long long)(fused->stream_kernel_ms * 1e6);
-    last.wave.launches = fused->wave_kernel_launches;
-    last.wave.ns = (long long)(fused->wave_kernel_ms * 1e6);
+    if (hc->levels > (int)last.trace.size() && !direction_optimizing) last.push_edges = last.m_t;   // (a deep traversal whose trace tail stayed on the device)
     long long push_vertices = 0;
     for (int i = 0; i < last.push_levels && i < (int)last.trace.size(); ++i) push_vertices += last.trace[i].first;
-    if (fused->time_kernels == 2) {            // the merged push launch: everything the push levels expanded
-      last.stream.edges = last.push_edges;
+    if (with_timing) {
+      last.kernel_launches = fused->level_kernel_launches; last.kernel_ns = (long long)(fused->level_kernel_ms * 1e6);
+      for (int i = 0; i < fused->batches; ++i) last.batch_ms.push_back(fused->batch_ms[i]);
+      // the long-row queue only exists on push levels; the short-row queue gets the rest of the push edges
+      last.stream.launches = fused->stream_kernel_launches;
+      last.stream.ns = (long long)(fused->stream_kernel_ms * 1e6);
+      last.wave.launches = fused->wave_kernel_launches;
+      last.wave.ns = (long long)(fused->wave_kernel_ms * 1e6);
+    }
+    if (with_timing && fused->time_kernels == 2) {            // the merged push launch: everything the push levels expanded
+      last.stream.edges = last.push_edges;                    // (the "wave" half then holds the queue builds: launches and ns only)
       last.stream.vertices = push_vertices;
     } else if (!direction_optimizing) {
       last.stream.edges = (long long)hc->sum_long_edges;
@@ -245,9 +241,52 @@ struct bfs_fused_enactor_t {
       last.wave.edges = last.push_edges - last.stream.edges;
       last.wave.vertices = push_vertices - last.stream.vertices;
     }
-    last.dominant = last.stream.ns > last.wave.ns ? 1 : 0;
+    last.dominant = (last.stream.ns > last.wave.ns || (with_timing && fused->time_kernels == 2)) ? 1 : 0;
     for (int i = 0; i < 64; ++i) last.claims_level[i] = (long long)hc->claims_level[i];
   }
+
+  // labels are (re)initialised by the run itself; bfs_problem->src is the source.
+  // direction_optimizing: bottom-up levels once num_unvisited < frontier_length * alpha
+  // (the reference's rule, bfs_enactor.hxx:68); in-edges come from the graph's CSC slots.
+  void enact(std::shared_ptr<bfs_problem_t> bfs_problem, standard_context_t& context,
+             bool direction_optimizing = false, float alpha = 0.f) {
+    auto& g = *bfs_problem->gslice;
+    mgx::bfs_layout_t layout = layout_of(g);
+    // the hub-first layout carries no separate CSC: bottom-up levels can use it only on graphs whose
+    // CSC slots alias the CSR (symmetric input, what the reference always has)
+    const bool use_layout = g.has_layout && (!direction_optimizing || g.csc_is_csr);
+    last = bfs_run_stats_t();
+    mgx::bfs_fused_run(*fused, g.d_row_offsets.data(), g.d_col_indices.data(), bfs_problem->d_labels.data(),
+                       bfs_problem->src, context, use_layout ? &layout : nullptr, direction_optimizing ? 1 : 0, alpha,
+                       g.d_col_offsets.data(), g.d_row_indices.data());
+    fill_stats(last, fused->host_ctrl, direction_optimizing, true);
+  }
+
+  // `count` traversals enqueued back to back, one host wait (mgx::bfs_fused_run_many): out[i] = the counters of source
+  // srcs[i]; the labels are those of the LAST source when the call returns.  Returns how many traversals had to be run
+  // again on their own (they did not finish within the slots the batch gave them).
+  char* many_heads = nullptr;       // pinned
+  int many_cap = 0;
+  int enact_many(std::shared_ptr<bfs_problem_t> bfs_problem, standard_context_t& context, const int* srcs, int count,
+                 std::vector<bfs_run_stats_t>& out, bool direction_optimizing = false, float alpha = 0.f) {
+    auto& g = *bfs_problem->gslice;
+    mgx::bfs_layout_t layout = layout_of(g);
+    const bool use_layout = g.has_layout && (!direction_optimizing || g.csc_is_csr);
+    if (count > many_cap) {
+      if (many_heads) (void)hipHostFree(many_heads);
+      many_heads = nullptr;
+      MGX_HIP(hipHostMalloc((void**)&many_heads, (size_t)count * mgx::bfs_many_head_bytes(), hipHostMallocDefault));
+      many_cap = count;
+    }
+    const int reruns = mgx::bfs_fused_run_many(*fused, g.d_row_offsets.data(), g.d_col_indices.data(), bfs_problem->d_labels.data(), srcs,
+                                               count, context, many_heads, use_layout ? &layout : nullptr, direction_optimizing ? 1 : 0,
+                                               alpha, g.d_col_offsets.data(), g.d_row_indices.data());
+    out.assign((size_t)count, bfs_run_stats_t());
+    for (int i = 0; i < count; ++i) fill_stats(out[(size_t)i], mgx::bfs_many_head(many_heads, i), direction_optimizing, false);
+    if (count > 0) { last = out.back(); bfs_problem->src = srcs[count - 1]; }
+    return reruns;
+  }
+  ~bfs_fused_enactor_t() { if (many_heads) (void)hipHostFree(many_heads); }
 };
 
 }  // namespace bfs

@@ -47,6 +47,7 @@ typedef struct mgx_dsssp_s* mgx_dsssp_t;
 typedef struct mgx_comm_s* mgx_comm_t;
 
 MGX_API int mgx_version(void);
+MGX_API int mgx_build_is_lab(void); /* 1: built with -DMGX_LAB (experiment shapes and instrumented kernels compiled in: never the product) */
 MGX_API const char* mgx_strerror(int status);
 MGX_API const char* mgx_last_error(void); /* thread-local detail of the last failure */
 
@@ -219,6 +220,13 @@ MGX_API int mgx_bfs_enact_pushpull(mgx_bfs_t p, float threshold, int64_t* stats)
 #define MGX_BFS_DIRECTION_OPT 1
 MGX_API int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats);
 MGX_API int mgx_bfs_run_stats(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats, int cap);
+/* A batch of sources: `count` complete traversals (each as mgx_bfs_run: labels re-initialised, every level run, counters
+ * taken) enqueued back to back on the context's stream with ONE host wait at the end -- the reference's one-call-per-
+ * source driver (test_bfs.cu:32-42) pays a host round trip per traversal, ~18 us of a 0.35 ms RMAT-22 traversal here.
+ * stats: count x cap entries, row i = the counters of sources[i] (the layout of mgx_bfs_run_stats; timing entries are 0);
+ * the labels (mgx_bfs_labels) are those of the LAST source.  *reruns (optional): traversals that did not finish inside the
+ * batch and were run again on their own (a source whose level structure needed more launch slots than its predecessors). */
+MGX_API int mgx_bfs_run_many(mgx_bfs_t p, const int* sources, int count, int mode, float alpha, int64_t* stats, int cap, int* reruns);
 /* per-level trace of the last mgx_bfs_run: level_nf[i], level_edges[i] for i < *levels  */
 MGX_API int mgx_bfs_level_trace(mgx_bfs_t p, int cap, int64_t* level_nf, int64_t* level_edges, int* levels);
 
@@ -229,7 +237,8 @@ MGX_API int mgx_bfs_level_trace(mgx_bfs_t p, int cap, int64_t* level_nf, int64_t
  * a slot's push (long rows, short rows) separately with events around each and fill mgx_bfs_kernel_times /
  * mgx_bfs_level_kernel_times; on == 2: events around the ONE merged push launch of every slot (k_bfs_push, the kernel a
  * traversal actually runs): its launches and time are reported in the "stream" half of mgx_bfs_kernel_times with ALL
- * push edges and frontier vertices, the "wave" half is zero. */
+ * push edges and frontier vertices; the "wave" half then holds the launches and time of the slots' queue builds
+ * (k_bfs_build2 -- the filter half of advance + filter), edges and vertices zero. */
 MGX_API int mgx_bfs_set_kernel_timing(mgx_bfs_t p, int on);
 /* the two push kernels of the last mgx_bfs_run, timed per launch with HIP events on the context's stream:
  * out8 = { stream launches, ns, edges, frontier vertices,  wave launches, ns, edges, frontier vertices }
@@ -361,6 +370,11 @@ MGX_API int mgx_sssp_run(mgx_sssp_t p, int src, int64_t* stats);
  * delta == 0: off (plain frontier Bellman-Ford, what mgx_sssp_run does); delta < 0: the default (off; the environment
  * variable MGX_SSSP_DELTA overrides either).  stats as above ([0] counts the iterations incl. the bucket changes). */
 MGX_API int mgx_sssp_run_delta(mgx_sssp_t p, int src, float delta, int64_t* stats);
+/* per-launch timing of the relax kernel of mgx_sssp_run (k_sssp_relax: sssp_functor.hxx:20-29 over every edge of the
+ * frontier): on != 0 brackets each launch with HIP events on the context's stream (each costs ~6 us of stream gap: measurement
+ * runs only); mgx_sssp_kernel_times: out2 = { launches, device ns } of the last run                                        */
+MGX_API int mgx_sssp_set_kernel_timing(mgx_sssp_t p, int on);
+MGX_API int mgx_sssp_kernel_times(mgx_sssp_t p, int64_t* out2);
 
 /* ---- PR: pr_problem_t / pr_functor_t / pr_enactor_t (gunrock/src/pr/) ---- */
 MGX_API int mgx_pr_create(mgx_graph_t g, int max_iter, mgx_pr_t* out);    /* pr_problem.hxx:33-44   */

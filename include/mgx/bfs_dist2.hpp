@@ -116,7 +116,7 @@ struct d2_state_t {
     merged = mem_t<u32>((size_t)nwords + 4, ctx);
   }
   bfs_fused_args_t args() const {
-    bfs_fused_args_t a;
+    bfs_fused_args_t a{};
     a.row_offsets = (const u32*)row_offsets;
     a.col_indices = col_indices;
     a.labels = nullptr;
@@ -134,13 +134,12 @@ struct d2_state_t {
     a.old_of_new = nullptr; a.new_of_old = nullptr;
     a.n = n_global;
     a.mode = 0; a.alpha = 0.f;
-    a.flags = 0;
     a.count_marks = 0;
-    a.ub_col = nullptr; a.ub_owner = nullptr; a.ub_units = 0; a.ub_units_pad = 0; a.dense_div = 0; a.dense_diag = 0; a.build_diag = 0; a.interleave = 0; a.combine = 0;
-    a.vs_v[0] = a.vs_v[1] = a.vs_v[2] = a.vs_v[3] = 0; a.vs_edges = 0; a.vs_div = 0; a.vs_dummy = 0; a.ss_tab = nullptr; a.ss_dmax = 0; a.lazy_div = 0; a.slot_marks = nullptr; a.merged_pull = 0; a.lazy_pull = 0; a.chain_big_edges = 0; a.defer_reach_mul = 1; a.defer_reach_div = 1;
-    a.cold_owner = nullptr; a.cold_dst = nullptr; a.colds_owner = nullptr; a.colds_dst = nullptr; a.cold_slices = 0; a.cold_flush = nullptr;
+    a.ub_col = nullptr; a.ub_owner = nullptr; a.ub_units = 0; a.ub_units_pad = 0; a.dense_div = 0;
+    a.vs_v[0] = a.vs_v[1] = a.vs_v[2] = a.vs_v[3] = 0; a.vs_edges = 0; a.vs_div = 0; a.vs_dummy = 0; a.lazy_div = 0; a.slot_marks = nullptr; a.merged_pull = 0; a.lazy_pull = 0; a.chain_big_edges = 0; a.defer_reach_mul = 1; a.defer_reach_div = 1;
+    a.cold_owner = nullptr; a.cold_dst = nullptr; a.cold_slices = 0; a.cold_flush = nullptr;
     for (int i = 0; i < BFS_COLD_MAX_SLICES; ++i) a.cold_lo[i] = 0;
-    for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) { a.cold_off[i] = 0; a.colds_off[i] = 0; a.cold_wgs[i] = 0; }
+    for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) { a.cold_off[i] = 0; a.cold_wgs[i] = 0; }
     a.flush_buf = nullptr; a.defer_min_marks = 0;     // (k_d2_newbits reads the marks: nothing is deferred)
     a.chain_max_edges = 0;               // (levels are counted by the host here: no chains of small levels)
     return a;

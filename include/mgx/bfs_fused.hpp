@@ -42,6 +42,9 @@
 // Algorithmic traffic: 8 B per traversed edge (col index + visited/label probe) and 20 B per
 // frontier vertex -- the figure BASELINE.md's roofline uses.
 #pragma once
+#include <cstdlib>
+#include <cstring>
+
 #include "runtime.hpp"
 #include "wave.hpp"
 
@@ -130,7 +133,6 @@ struct bfs_fused_args_t {
   int mode;                // MGX_BFS_PUSH / MGX_BFS_DIRECTION_OPT
   float alpha;             // switch to bottom-up when unvisited < frontier_vertices * alpha (bfs_enactor.hxx:68)
   int n;
-  int flags;               // diagnostics only
   int count_marks;         // the push kernels count their mark stores into ctrl->claims / claims_level (tools only)
   // unit blocks of the long rows (mgx_layout.hip: rows of >= long_min edges padded to 64-entry units; NULL: none)
   const int* ub_col;       // units_pad * 64 entries + 4 x (-1)
@@ -143,17 +145,11 @@ struct bfs_fused_args_t {
   u32 vs_edges;            // edges of the rows in [vs_v[0], vs_v[3])
   u32 vs_div;              // a slot takes its short rows this way when its short-row queue holds >= vs_edges / vs_div edges (0: never)
   u32 vs_dummy;            // index (into col_indices) of four entries of -1
-  const u32* ss_tab;       // short rows as one stream (bfs_fused_sshort.hpp): first entry / first row of every degree's region; NULL: none
-  int ss_dmax;             // the largest short degree (long_min - 1)
   u32* flush_buf;          // BFS_FLUSH_MAX buffers of BFS_FLUSH_WORDS words (NULL: hot marks are never deferred)
   u32 defer_min_marks;     // a workgroup with more deferred discoveries than this flushes them as a bitmap (else: byte marks)
   u32 defer_reach_mul, defer_reach_div;   // a level defers while reached * mul < deferred range * div (1 / 1; MGX_BFS_DEFER_REACH="mul/div")
   int lazy_pull;           // direction-optimising runs: the builds behind bottom-up levels write no queues
   int merged_pull;         // direction-optimising runs: the bottom-up sweep runs inside the push launch (no k_bfs_pull_level launch)
-  int combine;             // merged push launch: a slot that takes both dense paths runs them in the same workgroups
-  int interleave;          // merged push launch: even workgroups take the long rows, odd ones the short rows (instead of first half / second half)
-  int build_diag;          // measurements only (MGX_BFS_BUILD_DIAG; results wrong): 1 no label stores, 2 no extent gathers, 4 no cursor atomics
-  int dense_diag;          // measurements only (MGX_BFS_DENSE_DIAG): 1 the unit-block body stores no marks, 2 tests nothing
   u32 chain_max_edges;     // a level of at most this many edges (and BFS_CHAIN_CQ rows) runs inside block 0 of the push launch (0: never)
   u32 chain_big_edges;     // ... and of at most this many edges inside the in-place chain kernel (k_bfs_chain_inplace; 0: never)
   u32 lazy_div;            // the build behind a level with >= n / lazy_div mark stores writes no queues (bfs_build_is_lazy; 0: never)
@@ -166,11 +162,30 @@ struct bfs_fused_args_t {
   u32 cold_lo[BFS_COLD_MAX_SLICES];         // first vertex of slice i (a multiple of 1024; the slice is BFS_COLD_WORDS * 32 vertices)
   u32 cold_off[BFS_COLD_MAX_SLICES + 1];        // its pairs: [cold_off[i], cold_off[i + 1])
   u32 cold_wgs[BFS_COLD_MAX_SLICES + 1];        // the cold workgroups [cold_wgs[i], cold_wgs[i + 1]) of a push launch take slice i
-  const int* colds_owner;  // the same lists for the SHORT rows (the entries the vertex-by-vertex body would mark); NULL: none
+  u32* cold_flush;         // cold_wgs[cold_slices] bitmaps of BFS_COLD_WORDS words: what cold workgroup k discovered in its slice
+#ifdef MGX_LAB
+  // ---- lab build only (-DMGX_LAB, never set by __graft_entry__.build()): shapes that lost their A/B runs and the
+  // instrumented kernels of the measurement tools.  The product library carries none of this: MGX_LAB_GET reads a
+  // constant there and the compiler drops the code behind it.
+  int flags;               // MGX_BFS_FLAGS: instrumented stream kernel (results are wrong by design)
+  const u32* ss_tab;       // short rows as one stream (bfs_fused_sshort.hpp): first entry / first row of every degree's region; NULL: none
+  int ss_dmax;             // the largest short degree (long_min - 1)
+  int combine;             // merged push launch: a slot that takes both dense paths runs them in the same workgroups
+  int interleave;          // merged push launch: even workgroups take the long rows, odd ones the short rows (instead of first half / second half)
+  int build_diag;          // measurements only (MGX_BFS_BUILD_DIAG; results wrong): 1 no label stores, 2 no extent gathers, 4 no cursor atomics
+  int dense_diag;          // measurements only (MGX_BFS_DENSE_DIAG): 1 the unit-block body stores no marks, 2 tests nothing
+  const int* colds_owner;  // cold-edge lists of the SHORT rows (the entries the vertex-by-vertex body would mark; measured equal); NULL: none
   const int* colds_dst;
   u32 colds_off[BFS_COLD_MAX_SLICES + 1];
-  u32* cold_flush;         // cold_wgs[cold_slices] bitmaps of BFS_COLD_WORDS words: what cold workgroup k discovered in its slice
+#endif
 };
+
+// a lab-only field of the arguments / run options: the field in a lab build, a constant in the product
+#ifdef MGX_LAB
+#define MGX_LAB_GET(obj, field, product_value) ((obj).field)
+#else
+#define MGX_LAB_GET(obj, field, product_value) (product_value)
+#endif
 
 // Copy `words` words (a multiple of 4; src 16-byte aligned, readable up to the next multiple of 4 * NT words... clamped)
 // of the bitmap into LDS: ALL of a thread's 16-byte loads are issued before the first one is stored.  (The plain loop
@@ -276,7 +291,15 @@ __device__ __forceinline__ void bfs_seed_queue(const bfs_fused_args_t& a, u32 ro
 // Start of a traversal, one launch: clears labels (-1), bitmap(s) and marks, and seeds the source.  The thread that
 // clears the element holding the source's label / bit writes the seed value instead, so there is no ordering
 // between workgroups to worry about.
-__global__ __launch_bounds__(BLOCK) void k_bfs_fused_init(bfs_fused_args_t a, int src, long long nwords) {
+// prev_head (batches of sources, bfs_fused_run_many): the head of the control block as the PREVIOUS traversal left it goes to
+// (pinned) host memory first -- by the workgroup whose thread 0 then resets it; nobody else touches the block here.
+__global__ __launch_bounds__(BLOCK) void k_bfs_fused_init(bfs_fused_args_t a, int src, long long nwords, bfs_ctrl_t* prev_head, int head_words) {
+  if (prev_head && blockIdx.x == 0) {
+    const u32* const from = (const u32*)a.ctrl;
+    u32* const to = (u32*)prev_head;
+    for (int i = threadIdx.x; i < head_words; i += BLOCK) to[i] = from[i];
+    __syncthreads();
+  }
   const int src_old = src;
   if (a.new_of_old) src = a.new_of_old[src];           // labels live in ORIGINAL id space, everything else in layout space
   const long long tid = (long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -589,13 +612,13 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 4) void k_bfs_build(bfs_fused_a
       if (i < cnt) {
         const u32 v = st_v[i];
         bfs_u32x2 ext;
-        if (a.build_diag & 2) { ext.x = v * 8u; ext.y = v * 8u + 3u; }
+        if (MGX_LAB_GET(a, build_diag, 0) & 2) { ext.x = v * 8u; ext.y = v * 8u + 3u; }
         else ext = *(const bfs_u32x2*)(a.row_offsets + v);                  // both ends of the row in one 8-byte load
         // (non-temporal stores here were measured slower.  So was moving this scatter out of the build -- vertex ids in
         //  the queues, labels written by 64 workgroups of the launch that consumes the queue: the builds of the two big
         //  RMAT-22 levels went from 30 to 23-25 us, but the push launches grew by more, 0.44 -> 0.46 ms per traversal:
         //  a million random 4-byte stores cost their ~20 us wherever they run, and here they have the most threads)
-        if (!(a.build_diag & 1)) labels[old_of_new ? old_of_new[v] : (int)v] = new_label;
+        if (!(MGX_LAB_GET(a, build_diag, 0) & 1)) labels[old_of_new ? old_of_new[v] : (int)v] = new_label;
         st_v[i] = ext.x;
         st_d[i] = ext.y - ext.x;
       }
@@ -626,7 +649,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 4) void k_bfs_build(bfs_fused_a
     const u64 ex_s = block_exclusive_sum_lean<NW>(sum_s, s_scan, &tot_s);
     const u64 ex_l = block_exclusive_sum_lean<NW>(sum_l, s_scan, &tot_l);
     if (threadIdx.x == 0) {
-      if (a.build_diag & 4) { s_base[0] = ((u64)blockIdx.x * 4096) << BFS_VSHIFT; s_base[1] = ((u64)blockIdx.x * 4096) << BFS_VSHIFT; }
+      if (MGX_LAB_GET(a, build_diag, 0) & 4) { s_base[0] = ((u64)blockIdx.x * 4096) << BFS_VSHIFT; s_base[1] = ((u64)blockIdx.x * 4096) << BFS_VSHIFT; }
       else {
       s_base[0] = (tot_s >> 40) ? atomicAdd(cur_s, ((tot_s >> 40) << BFS_VSHIFT) | (tot_s & DEGMASK)) : 0ull;
       s_base[1] = (tot_l >> 40) ? atomicAdd(cur_l, ((tot_l >> 40) << BFS_VSHIFT) | (tot_l & DEGMASK)) : 0ull;
@@ -799,7 +822,8 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
   int target[16];
   u64 sum_s = 0, sum_l = 0;
   u32 long_true = 0;
-  if (new16 && (a.build_diag & 16)) {
+  const bool diag_extents = (MGX_LAB_GET(a, build_diag, 0) & 16) != 0;     // (lab builds: synthetic extents)
+  if (diag_extents && new16) {
 #pragma unroll
     for (int q = 0; q < 17; ++q) ro[q] = (u32)(i0 + q) * 3u;
 #pragma unroll
@@ -832,7 +856,7 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       if ((new16 >> q) & 1u) {
-        if (!(a.build_diag & 1)) labels[target[q]] = new_label;
+        if (!(MGX_LAB_GET(a, build_diag, 0) & 1)) labels[target[q]] = new_label;
         const u32 deg = ro[q + 1] - ro[q];
         if (deg >= long_min) { sum_l += CNT1 | (u64)bfs_lq_pad(deg); long_true += deg; }
         else if (deg) sum_s += CNT1 | (u64)deg;
@@ -875,18 +899,18 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
   // the two returning atomics from two different waves: one thread would wait for the first before it issues the second
   if (threadIdx.x == 0) {
     atomicAdd(&c->reached, tot_n);
-    if (a.build_diag & 4) s_base[0] = ((u64)blockIdx.x * 8192) << BFS_VSHIFT;
+    if (MGX_LAB_GET(a, build_diag, 0) & 4) s_base[0] = ((u64)blockIdx.x * 8192) << BFS_VSHIFT;
     else s_base[0] = (tot_s >> 40) ? atomicAdd(&c->cursor[(slot + 1) % 3], ((tot_s >> 40) << BFS_VSHIFT) | (tot_s & DEGMASK)) : 0ull;
   }
   if (threadIdx.x == WAVE) {
-    if (a.build_diag & 4) s_base[1] = ((u64)blockIdx.x * 8192) << BFS_VSHIFT;
+    if (MGX_LAB_GET(a, build_diag, 0) & 4) s_base[1] = ((u64)blockIdx.x * 8192) << BFS_VSHIFT;
     else {
       s_base[1] = (tot_l >> 40) ? atomicAdd(&c->lcursor[(slot + 1) % 3], ((tot_l >> 40) << BFS_VSHIFT) | (tot_l & DEGMASK)) : 0ull;
       if (tot_l >> 40) atomicAdd(&c->ledges[(slot + 1) % 3], (u64)s_long_edges);
     }
   }
   __syncthreads();
-  if (!new16 || (a.build_diag & 8)) return;
+  if (!new16 || (MGX_LAB_GET(a, build_diag, 0) & 8)) return;
   u32* __restrict__ const out_row_s = a.fr_row[(slot + 1) & 1];
   u32* __restrict__ const out_off_s = a.fr_off[(slot + 1) & 1];
   u32* __restrict__ const out_row_l = a.lq_row[(slot + 1) & 1];
@@ -924,8 +948,85 @@ __global__ void k_bfs_publish(const bfs_ctrl_t* __restrict__ c, bfs_ctrl_t* __re
   if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Tuning switches of the fused traversal, read from the environment ONCE per handle (when its state is made -- the
+// parity tests set them and then create the problem), never per traversal or per launch.  Every one of them selects
+// between product paths that the default thresholds pick by size; the shapes that lost their A/B runs and the
+// instrumented kernels exist in lab builds only (-DMGX_LAB).
+struct bfs_run_opts_t {
+  int cold_test = -1;      // MGX_BFS_COLD_TEST
+  int merged = 1;          // MGX_BFS_MERGED_PUSH
+  int dense = -1;          // MGX_BFS_DENSE: 0 never, N > 0 dense_div = N
+  int vshort = -1;         // MGX_BFS_VSHORT: 0 never, N > 0 vshort_div = N
+  long long chain = -1;    // MGX_BFS_CHAIN_MAX_EDGES: 0 never (default BFS_CHAIN_CAP)
+  int defer_mul = 1, defer_div = 1;   // MGX_BFS_DEFER_REACH="mul/div": a level defers its hot marks while reached * mul < range * div
+                                      // (RMAT-22, ms per traversal: 4/1 0.3627, 2/1 0.3600, 1/1 0.3521, 2/3 0.3511, 1/3 0.3530, 1/8 0.3625, always 0.3641)
+  int do_chain = 1;        // MGX_BFS_DO_CHAIN=0: direction-optimising runs keep every level device-wide (no chains of small top-down levels)
+  int merged_pull = 1;     // MGX_BFS_MERGED_PULL=0: the bottom-up sweep as a launch of its own behind every push launch
+  int seed_chain = 1;      // MGX_BFS_SEED_CHAIN=0: no in-place chain launches at all (small levels run inside the slots' push launches)
+  int tail_chain = 1;      // MGX_BFS_TAIL_CHAIN=0: ... only the one at the start
+  int chain_big = -1;      // MGX_BFS_CHAIN_BIG_EDGES: largest level of an in-place chain launch
+  int cold = 2;            // MGX_BFS_COLD: 0 the unit-block body marks its cold entries itself (no cold-edge pass), 2 the long rows' lists
+                           // (default); lab builds: 1 also the short rows' (measured equal on RMAT-22: 0.3712 / 0.3708 ms)
+  int lazy = -1;           // MGX_BFS_LAZY: 0 the queue build always writes the queues, N: not behind a push that stored >= n / N marks
+  long long defer = -1;    // MGX_BFS_DEFER: 0 never defer hot marks, N: flush a bitmap above N deferred marks per workgroup
+  int spin = -1;           // MGX_BFS_SPIN: 0 read the control block back with a copy + hipStreamSynchronize, 1 publish kernel + spin
+  int build_list = 0;      // MGX_BFS_BUILD_LIST=1: the list-based queue build (k_bfs_build) instead of k_bfs_build2
+#ifdef MGX_LAB
+  int flags = 0;           // MGX_BFS_FLAGS (instrumented stream kernel)
+  int sstream = 0;         // MGX_BFS_SSTREAM=1: dense short rows as one stream of entries (bfs_fused_sshort.hpp) instead of vertex by
+                           // vertex -- measured 6 us slower per RMAT-22 traversal (0.3578 / 0.3519 ms)
+  int combine = 0;         // MGX_BFS_COMBINE=1: a level that takes both dense paths runs them in the SAME workgroups -- measured 0.4055
+                           // vs 0.4012 ms per RMAT-22 traversal: the two halves of the grid overlap their tails better
+  int interleave = 0;      // MGX_BFS_INTERLEAVE=1: long-row and short-row workgroups alternate -- measured 0.52 vs 0.41 ms per RMAT-22
+                           // traversal: the two bodies side by side on a CU (both lean on LDS) are slower than one after the other
+  int biglds = 0;          // MGX_BFS_BIGLDS (timed mode): one 160 KB workgroup per CU -- slower
+  int build_diag = 0;      // MGX_BFS_BUILD_DIAG: parts of k_bfs_build switched off (measurements only)
+  int dense_diag = 0;      // MGX_BFS_DENSE_DIAG: parts of the unit-block body switched off (measurements only)
+#endif
+  static bfs_run_opts_t from_env() {
+    bfs_run_opts_t o;
+    auto geti = [](const char* name, int& out) { if (const char* e = getenv(name)) out = atoi(e); };
+    auto getll = [](const char* name, long long& out) { if (const char* e = getenv(name)) out = atoll(e); };
+    geti("MGX_BFS_COLD_TEST", o.cold_test);
+    geti("MGX_BFS_MERGED_PUSH", o.merged);
+    geti("MGX_BFS_DENSE", o.dense);
+    geti("MGX_BFS_VSHORT", o.vshort);
+    getll("MGX_BFS_CHAIN_MAX_EDGES", o.chain);
+    geti("MGX_BFS_BUILD_LIST", o.build_list);
+    geti("MGX_BFS_SPIN", o.spin);
+    getll("MGX_BFS_DEFER", o.defer);
+    geti("MGX_BFS_COLD", o.cold);
+    if (const char* e = getenv("MGX_BFS_DEFER_REACH")) {
+      o.defer_mul = atoi(e);
+      const char* sl = strchr(e, '/');
+      o.defer_div = sl ? atoi(sl + 1) : 1;
+      if (o.defer_div < 1) o.defer_div = 1;
+    }
+    geti("MGX_BFS_SEED_CHAIN", o.seed_chain);
+    geti("MGX_BFS_MERGED_PULL", o.merged_pull);
+    geti("MGX_BFS_DO_CHAIN", o.do_chain);
+    geti("MGX_BFS_TAIL_CHAIN", o.tail_chain);
+    geti("MGX_BFS_CHAIN_BIG_EDGES", o.chain_big);
+    geti("MGX_BFS_LAZY", o.lazy);
+    if (o.lazy > (1 << 20)) o.lazy = 1 << 20;     // (edges < 2^38: no overflow)
+#ifdef MGX_LAB
+    geti("MGX_BFS_FLAGS", o.flags);
+    geti("MGX_BFS_SSTREAM", o.sstream);
+    geti("MGX_BFS_COMBINE", o.combine);
+    geti("MGX_BFS_INTERLEAVE", o.interleave);
+    geti("MGX_BFS_BIGLDS", o.biglds);
+    geti("MGX_BFS_BUILD_DIAG", o.build_diag);
+    geti("MGX_BFS_DENSE_DIAG", o.dense_diag);
+#else
+    if (o.cold == 1) o.cold = 2;                  // (the short rows' cold lists are a lab shape)
+#endif
+    return o;
+  }
+};
+
 // per-BFS device state of the fused engine
 struct bfs_fused_state_t {
+  bfs_run_opts_t opts = bfs_run_opts_t::from_env();
   mem_t<u32> visited;
   mem_t<unsigned char> mark;
   mem_t<u32> frontier_bits;

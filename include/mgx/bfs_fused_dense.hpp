@@ -69,7 +69,7 @@ __device__ __forceinline__ void bfs_dense_work(const bfs_fused_args_t& a, u32* c
   const int* __restrict__ ucol = a.ub_col;
   const int* __restrict__ owner = a.ub_owner;
   const u32* __restrict__ fbits = a.frontier_bits;
-  const int diag = a.dense_diag;     // MGX_BFS_DENSE_DIAG (measurements; results are wrong by design): 1 no mark stores, 2 no test
+  const int diag = MGX_LAB_GET(a, dense_diag, 0);     // MGX_BFS_DENSE_DIAG (measurements; results are wrong by design): 1 no mark stores, 2 no test
   const u32 G = a.ub_units_pad / BFS_DENSE_GROUP;              // groups of 16 units
   const u32 W = nblocks * NW;                                  // waves of the grid
   const u32 w = block * NW + (u32)wave;

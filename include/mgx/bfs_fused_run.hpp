@@ -10,13 +10,14 @@
 #pragma once
 #include <cstring>
 #include <unistd.h>
-extern "C" char** environ;
 #include "bfs_fused.hpp"
 #include "bfs_fused_chain.hpp"
 #include "bfs_fused_cold.hpp"
 #include "bfs_fused_dense.hpp"
 #include "bfs_fused_pull.hpp"
+#ifdef MGX_LAB
 #include "bfs_fused_sshort.hpp"
+#endif
 #include "bfs_fused_stream.hpp"
 #include "bfs_fused_vshort.hpp"
 #include "bfs_fused_wave.hpp"
@@ -39,11 +40,11 @@ struct bfs_layout_t {
   unsigned vs_v[4] = {0, 0, 0, 0};
   unsigned vs_edges = 0, vs_dummy = 0;
   int vs_long_min = 0;
-  const unsigned* ss_tab = nullptr;   // region table of the short rows (bfs_fused_sshort.hpp; device, BFS_SS_TAB_WORDS words)
+  const unsigned* ss_tab = nullptr;   // (lab builds) region table of the short rows (bfs_fused_sshort.hpp; device, BFS_SS_TAB_WORDS words)
   // cold-edge lists of the long rows (bfs_fused_cold.hpp): pairs grouped by slice; hot_n / long_min they were cut for
   const int* cold_owner = nullptr;
   const int* cold_dst = nullptr;
-  const int* colds_owner = nullptr;   // the short rows' cold entries (optional)
+  const int* colds_owner = nullptr;   // (lab builds) the short rows' cold entries
   const int* colds_dst = nullptr;
   int cold_slices = 0;
   unsigned cold_lo[BFS_COLD_MAX_SLICES] = {0}, cold_off[BFS_COLD_MAX_SLICES + 1] = {0}, colds_off[BFS_COLD_MAX_SLICES + 1] = {0},
@@ -87,7 +88,8 @@ __device__ __forceinline__ bfs_slot_plan_t bfs_slot_plan(const bfs_fused_args_t&
   // read the unit blocks by its own size (a sweep of all pairs does not pay for a sparse frontier that was only forced
   // onto the unit blocks by a lazy build: the unit-block body marks the few cold entries it meets)
   p.cold = p.dense && a.cold_dst != nullptr;
-  p.colds = p.cold && p.vshort && a.colds_dst != nullptr && !a.ss_tab;   // (with them, the short rows' cold entries of a level that walks those vertex by vertex)
+  // (lab builds: with them, the short rows' cold entries of a level that walks those vertex by vertex)
+  p.colds = p.cold && p.vshort && MGX_LAB_GET(a, colds_dst, (const int*)nullptr) != nullptr && !MGX_LAB_GET(a, ss_tab, (const u32*)nullptr);
   if (!p.empty && c->lazy_slot == p.slot) {       // the build before this slot wrote no queues (bfs_build_is_lazy)
     p.chained = false;
     p.dense = p.vshort = true;
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
   }
   // Which part this workgroup takes: (graphs with cold-edge lists) the workgroups of the cold pass, then nstream
   // workgroups for the long rows, the others the short rows.
-  // (interleave: even / odd instead, so that the two parts share every CU -- an experiment that lost, see bfs_run_opts_t)
+  // (lab builds, interleave: even / odd instead, so that the two parts share every CU -- an experiment that lost)
   const u32 ncold = (!COLDT && a.cold_dst && (PART == 0 || PART == 2)) ? a.cold_wgs[a.cold_slices] : 0u;   // (PART 2: with the long rows)
   // grid: [cold pass][long rows][short rows] -- the cold workgroups first: they are few and short, and the launch does
   // not end on them
@@ -148,12 +150,14 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
     return;
   }
   const u32 blk = blockIdx.x - ncold, nblk = gridDim.x - ncold;
+#ifdef MGX_LAB
   if (PART == 0 && !COLDT && p.dense && p.vshort && a.combine) {
     // both dense paths: the first nstream workgroups take their share of the long AND of the short rows
     if (blk < nstream) bfs_dense_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, blk, nstream, p.level, p.cold, p.colds);
     return;
   }
-  const bool il = PART == 0 && a.interleave && nblk == 2u * nstream;
+#endif
+  const bool il = PART == 0 && MGX_LAB_GET(a, interleave, 0) && nblk == 2u * nstream;
   const bool long_part = PART == 2 || (PART == 0 && (il ? !(blk & 1u) : blk < nstream));
   if (long_part) {
     const u32 bi = il ? blk >> 1 : blk;
@@ -163,8 +167,10 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
     const u32 first = PART == 0 ? nstream : 0u;
     const u32 bi = il ? blk >> 1 : blk - first;
     const u32 nb = il ? nstream : nblk - first;
-    if (!COLDT && p.vshort && a.ss_tab) bfs_sstream_body<1024, BFS_DENSE_HOTW - BFS_SS_TAB_PAD>(a, p.slot, bi, nb, p.level, false);
-    else if (!COLDT && p.vshort) bfs_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, bi, nb, p.level, p.colds);
+#ifdef MGX_LAB
+    if (!COLDT && p.vshort && a.ss_tab) { bfs_sstream_body<1024, BFS_DENSE_HOTW - BFS_SS_TAB_PAD>(a, p.slot, bi, nb, p.level, false); return; }
+#endif
+    if (!COLDT && p.vshort) bfs_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, bi, nb, p.level, p.colds);
     else bfs_wave_body<1024, BFS_WAVE_HOTW, COLDT, false>(a, p.slot, bi, nb, p.level);
   }
 }
@@ -191,6 +197,7 @@ __global__ __launch_bounds__(1024) void k_bfs_chain_inplace(bfs_fused_args_t a, 
   bfs_chain_body<1024, true, BFS_CHAIN_CAP_BIG>(a, slot, level);
 }
 
+#ifdef MGX_LAB
 // Experiment (MGX_BFS_BIGLDS=1, timed mode only): the unit-block body with ONE workgroup per CU and twice the bitmap
 // prefix in LDS (fewer cold neighbours marked untested), 128 VGPRs.
 constexpr int BFS_DENSE_HOTW_BIG = 40800;
@@ -208,6 +215,7 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push_stream_diag(bfs_fused_args
   if (p.empty || p.chained) return;
   bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, false, true, true>(a, p.slot, blockIdx.x, gridDim.x, p.level);
 }
+#endif  // MGX_LAB
 
 // Explicit-level variant for the partitioned path (bfs_dist2.hpp): slot == level, the level's bookkeeping rides on
 // the launch (open_here == 2: a rank of a partitioned run), no chain, no unit blocks.
@@ -226,8 +234,10 @@ inline void bfs_set_kernel_attributes() {
   MGX_SET_LDS((k_bfs_push<false, 1>)); MGX_SET_LDS((k_bfs_push<true, 1>));
   MGX_SET_LDS((k_bfs_push<false, 2>)); MGX_SET_LDS((k_bfs_push<true, 2>));
   MGX_SET_LDS((k_bfs_push<false, 3>)); MGX_SET_LDS((k_bfs_push<true, 3>));
+#ifdef MGX_LAB
   MGX_SET_LDS(k_bfs_push_stream_diag);
   MGX_SET_LDS(k_bfs_push_dense_big);
+#endif
   MGX_SET_LDS(k_bfs_chain_inplace);
   MGX_SET_LDS(k_bfs_push_level<false>);
   MGX_SET_LDS(k_bfs_push_level<true>);
@@ -239,79 +249,6 @@ inline bool bfs_cold_test(int n, int forced) {
   if (forced >= 0) return forced != 0;
   return (long long)n >= 8ll * 32 * BFS_STREAM_HOTW;
 }
-
-// Environment switches of a run, read ONCE per traversal (the tests flip them between runs), never per launch.
-struct bfs_run_opts_t {
-  int cold_test = -1;      // MGX_BFS_COLD_TEST
-  int merged = 1;          // MGX_BFS_MERGED_PUSH
-  int flags = 0;           // MGX_BFS_FLAGS (instrumented stream kernel)
-  int dense = -1;          // MGX_BFS_DENSE: 0 never, N > 0 dense_div = N
-  int vshort = -1;         // MGX_BFS_VSHORT: 0 never, N > 0 vshort_div = N
-  long long chain = -1;    // MGX_BFS_CHAIN_MAX_EDGES: 0 never (default BFS_CHAIN_CAP)
-  int defer_mul = 1, defer_div = 1;   // MGX_BFS_DEFER_REACH="mul/div": a level defers its hot marks while reached * mul < range * div
-                                      // (RMAT-22, ms per traversal: 4/1 0.3627, 2/1 0.3600, 1/1 0.3521, 2/3 0.3511, 1/3 0.3530, 1/8 0.3625, always 0.3641)
-  int do_chain = 1;        // MGX_BFS_DO_CHAIN=0: direction-optimising runs keep every level device-wide (no chains of small top-down levels)
-  int sstream = 0;         // MGX_BFS_SSTREAM=1: dense short rows as one stream of entries (bfs_fused_sshort.hpp) instead of vertex by
-                           // vertex -- measured 6 us slower per RMAT-22 traversal (0.3578 / 0.3519 ms): off
-  int merged_pull = 1;     // MGX_BFS_MERGED_PULL=0: the bottom-up sweep as a launch of its own behind every push launch
-  int seed_chain = 1;      // MGX_BFS_SEED_CHAIN=0: no in-place chain launches at all (small levels run inside the slots' push launches)
-  int tail_chain = 1;      // MGX_BFS_TAIL_CHAIN=0: ... only the one at the start
-  int chain_big = -1;      // MGX_BFS_CHAIN_BIG_EDGES: largest level of an in-place chain launch
-  int cold = 2;            // MGX_BFS_COLD: 0 the unit-block body marks its cold entries itself (no cold-edge pass), 2 the long rows' lists
-                           // (default), 1 also the short rows' (built with MGX_BFS_COLD_LISTS=2; measured equal on RMAT-22: 0.3712 / 0.3708 ms)
-  int lazy = -1;           // MGX_BFS_LAZY: 0 the queue build always writes the queues, N: not behind a push that stored >= n / N marks
-  long long defer = -1;    // MGX_BFS_DEFER: 0 never defer hot marks, N: flush a bitmap above N deferred marks per workgroup
-  int combine = 0;         // MGX_BFS_COMBINE=1: a level that takes both dense paths runs them in the SAME workgroups (one copy of the
-                           // bitmap prefix and one epilogue per workgroup instead of two) -- measured 0.4055 vs 0.4012 ms per RMAT-22
-                           // traversal: no gain, the two halves of the grid overlap their tails better; kept as a switch
-  int interleave = 0;      // MGX_BFS_INTERLEAVE=1: long-row and short-row workgroups of the merged push launch alternate instead of
-                           // forming two halves -- measured 0.52 vs 0.41 ms per RMAT-22 traversal: the two bodies side by side
-                           // on a CU (both lean on LDS) are slower than one after the other; kept as a switch only
-  int spin = -1;           // MGX_BFS_SPIN: 0 read the control block back with a copy + hipStreamSynchronize, 1 publish kernel + spin
-  int biglds = 0;          // MGX_BFS_BIGLDS (experiment, timed mode)
-  int build_list = 0;      // MGX_BFS_BUILD_LIST=1: the list-based queue build (k_bfs_build) instead of k_bfs_build2
-  int build_diag = 0;      // MGX_BFS_BUILD_DIAG: parts of k_bfs_build switched off (measurements only)
-  int dense_diag = 0;      // MGX_BFS_DENSE_DIAG: parts of the unit-block body switched off (measurements only)
-  // one pass over the environment (a traversal reads twenty switches: twenty getenv calls were ~3 us of its ~20 us of
-  // host time between two traversals)
-  static bfs_run_opts_t from_env() {
-    bfs_run_opts_t o;
-    for (char** ep = ::environ; ep && *ep; ++ep) {
-      const char* const kv = *ep;
-      if (strncmp(kv, "MGX_BFS_", 8) != 0) continue;
-      const char* const name = kv + 8;
-      const char* const eq = strchr(name, '=');
-      if (!eq) continue;
-      const size_t len = (size_t)(eq - name);
-      const char* const val = eq + 1;
-      auto is = [&](const char* n) { return strlen(n) == len && strncmp(name, n, len) == 0; };
-      if (is("COLD_TEST")) o.cold_test = atoi(val);
-      else if (is("MERGED_PUSH")) o.merged = atoi(val);
-      else if (is("FLAGS")) o.flags = atoi(val);
-      else if (is("DENSE")) o.dense = atoi(val);
-      else if (is("VSHORT")) o.vshort = atoi(val);
-      else if (is("CHAIN_MAX_EDGES")) o.chain = atoll(val);
-      else if (is("DENSE_DIAG")) o.dense_diag = atoi(val);
-      else if (is("BUILD_DIAG")) o.build_diag = atoi(val);
-      else if (is("BUILD_LIST")) o.build_list = atoi(val);
-      else if (is("BIGLDS")) o.biglds = atoi(val);
-      else if (is("SPIN")) o.spin = atoi(val);
-      else if (is("INTERLEAVE")) o.interleave = atoi(val);
-      else if (is("COMBINE")) o.combine = atoi(val);
-      else if (is("DEFER")) o.defer = atoll(val);
-      else if (is("COLD")) o.cold = atoi(val);
-      else if (is("DEFER_REACH")) { o.defer_mul = atoi(val); const char* sl = strchr(val, '/'); o.defer_div = sl ? atoi(sl + 1) : 1; if (o.defer_div < 1) o.defer_div = 1; }
-      else if (is("SEED_CHAIN")) o.seed_chain = atoi(val);
-      else if (is("MERGED_PULL")) o.merged_pull = atoi(val);
-      else if (is("SSTREAM")) o.sstream = atoi(val);
-      else if (is("DO_CHAIN")) o.do_chain = atoi(val);
-      else if (is("TAIL_CHAIN")) o.tail_chain = atoi(val);
-      else if (is("CHAIN_BIG_EDGES")) o.chain_big = atoi(val);
-      else if (is("LAZY")) { o.lazy = atoi(val); if (o.lazy > (1 << 20)) o.lazy = 1 << 20; }   // (edges < 2^38: no overflow)
-    }
-    return o;
-  }
-};
 
 // Shapes that were measured and dropped, RMAT-22 (stream kernel of the big level / whole BFS at the time):
 //   stream  2 workgroups x 1024 threads per CU = 32 waves, 80 KB of bitmap each, 8 non-temporal loads per lane (kept):
@@ -335,17 +272,24 @@ inline void bfs_launch_push(const bfs_fused_args_t& a, int level, standard_conte
   else hipLaunchKernelGGL(k_bfs_push_level<false>, dim3(nstream + nwave), dim3(1024), bfs_push_lds_bytes(), ctx.stream(), a, level, nstream, open_here);
 }
 
-// Runs a whole BFS from `src` on the context's stream.  labels[] is (re)initialised here.  Returns with the
-// stream synchronised and host_ctrl holding the final counters.
-// mode/alpha: MGX_BFS_PUSH (0) or MGX_BFS_DIRECTION_OPT (1) with the reference's switch rule
-// num_unvisited < frontier_length * alpha (bfs_enactor.hxx:68).  in_offsets/in_indices: in-edges for the
-// bottom-up levels (pass the CSR for symmetric graphs, the reference's behaviour -- SURVEY F8).
-inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const int* col_indices, int* labels,
-                          int src, standard_context_t& ctx, const bfs_layout_t* layout = nullptr, int mode = 0,
-                          float alpha = 0.f, const int* in_offsets = nullptr, const int* in_indices = nullptr) {
-  hipStream_t s = ctx.stream();
-  const bfs_run_opts_t opt = bfs_run_opts_t::from_env();
+// Everything a traversal's launches need that does not depend on the source: the kernel arguments (which bodies are
+// available on this graph / layout, thresholds, buffers) and the grid shapes.  Made once per call (per batch of sources).
+struct bfs_launch_plan_t {
   bfs_fused_args_t a;
+  bool coldt = false, build2_ok = false;
+  u32 nstream = 0, nwave = 0, ncold = 0;
+  int lab_flags = 0;
+  long long nwords = 0;
+  int mode = 0;
+  int* labels = nullptr;
+};
+
+inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_offsets, const int* col_indices, int* labels,
+                                        standard_context_t& ctx, const bfs_layout_t* layout, int mode, float alpha,
+                                        const int* in_offsets, const int* in_indices) {
+  bfs_launch_plan_t plan;
+  bfs_fused_args_t& a = plan.a;
+  const bfs_run_opts_t& opt = st.opts;        // (environment switches: read once, when the handle's state was made)
   const bool relabelled = layout && layout->row_offsets;
   a.row_offsets = (const u32*)(relabelled ? layout->row_offsets : row_offsets);
   a.col_indices = relabelled ? layout->col_indices : col_indices;
@@ -368,11 +312,14 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.hot_min_edges = st.hot_min_edges;
   a.ctrl = st.ctrl.data();
   a.n = st.n;
-  a.flags = opt.flags;
+  const int lab_flags = MGX_LAB_GET(opt, flags, 0);      // (lab builds: the instrumented stream kernel)
+#ifdef MGX_LAB
+  a.flags = lab_flags;
+#endif
   a.count_marks = (st.count_marks || st.time_kernels == 1) ? 1 : 0;
   // unit blocks: only for the CSR they were built from, with the long-row threshold they were built for
   const bool units_avail = relabelled && layout->ub_col && layout->ub_units > 0 && layout->ub_min_degree == st.long_min &&
-                           st.long_min > 0 && !opt.flags;
+                           st.long_min > 0 && !lab_flags;
   // Probing the bitmap word of cold neighbours (instead of marking them untested) pays on big graphs WITHOUT the unit
   // blocks -- the partitioned ranks, a caller-made layout.  With them the unit-block body, the cold-edge pass and the
   // lazy builds win at every size measured: RMAT-23 391 against 272 GTEPS, RMAT-24 386 / 253, RMAT-25 187 / 179.
@@ -384,60 +331,52 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.ub_units_pad = units ? (u32)layout->ub_units_pad : 0u;
   a.dense_div = !units ? 0u : (opt.dense >= 0 ? (u32)opt.dense : st.dense_div);
   // short rows vertex by vertex: the layout's own degree-sorted CSR with its padding, the threshold it was cut for
-  const bool vs = relabelled && layout->vs_dummy != 0 && layout->vs_long_min == st.long_min && st.long_min > 0 && !coldt && !opt.flags &&
+  const bool vs = relabelled && layout->vs_dummy != 0 && layout->vs_long_min == st.long_min && st.long_min > 0 && !coldt && !lab_flags &&
                   layout->vs_edges > 0;
   for (int i = 0; i < 4; ++i) a.vs_v[i] = vs ? layout->vs_v[i] : 0u;
   a.vs_edges = vs ? layout->vs_edges : 0u;
   a.vs_dummy = vs ? layout->vs_dummy : 0u;
   a.vs_div = !vs ? 0u : (opt.vshort >= 0 ? (u32)opt.vshort : st.vshort_div);
+#ifdef MGX_LAB
   a.ss_tab = (vs && layout->ss_tab && opt.sstream && st.long_min <= BFS_SS_MAXDEG) ? layout->ss_tab : nullptr;
   a.ss_dmax = st.long_min - 1;
-  if (!st.slot_marks.size()) st.slot_marks = mem_t<u32>((size_t)2 * BFS_MARK_CTRS * BFS_MARK_STRIDE, ctx);
-  a.slot_marks = st.slot_marks.data();
-  a.merged_pull = (mode == 1 && opt.merged_pull && opt.merged && !a.flags) ? 1 : 0;
   a.dense_diag = opt.dense_diag;
   a.build_diag = opt.build_diag;
   a.interleave = opt.interleave;
   a.combine = opt.combine;
+#endif
+  if (!st.slot_marks.size()) st.slot_marks = mem_t<u32>((size_t)2 * BFS_MARK_CTRS * BFS_MARK_STRIDE, ctx);
+  a.slot_marks = st.slot_marks.data();
+  a.merged_pull = (mode == 1 && opt.merged_pull && opt.merged && !lab_flags) ? 1 : 0;
   // deferred hot marks (bfs_hot_epilogue): the flush buffers are allocated at the first traversal that may use them
   const long long defer = opt.defer >= 0 ? opt.defer : (long long)st.defer_min_marks;
-  if (defer > 0 && !a.flags && !st.flush_buf.size()) st.flush_buf = mem_t<u32>((size_t)BFS_FLUSH_MAX * BFS_FLUSH_WORDS, ctx);
-  a.flush_buf = (defer > 0 && !a.flags) ? st.flush_buf.data() : nullptr;
+  if (defer > 0 && !lab_flags && !st.flush_buf.size()) st.flush_buf = mem_t<u32>((size_t)BFS_FLUSH_MAX * BFS_FLUSH_WORDS, ctx);
+  a.flush_buf = (defer > 0 && !lab_flags) ? st.flush_buf.data() : nullptr;
   a.defer_min_marks = (u32)defer;
   a.defer_reach_mul = (u32)opt.defer_mul; a.defer_reach_div = (u32)opt.defer_div;
   a.chain_max_edges = (mode != 0 && !opt.do_chain) ? 0u : (opt.chain >= 0 ? (u32)(opt.chain > BFS_CHAIN_CAP ? BFS_CHAIN_CAP : opt.chain) : st.chain_max_edges);
   const long long nwords = ((long long)st.n + 31) / 32;
-  hipLaunchKernelGGL(k_bfs_fused_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src, nwords);
   // in-place chain launches (k_bfs_chain_inplace): in front of slot 0, of the slots from tail_from on, behind a batch
   a.chain_big_edges = (a.chain_max_edges && opt.seed_chain) ? (opt.chain_big >= 0 ? (u32)(opt.chain_big > BFS_CHAIN_CAP_BIG ? BFS_CHAIN_CAP_BIG : opt.chain_big) : st.chain_big_edges) : 0u;
-  auto chain_inplace = [&](int sl) {
-    hipLaunchKernelGGL(k_bfs_chain_inplace, dim3(1), dim3(1024), bfs_chain_lds_bytes(BFS_CHAIN_CAP_BIG), s, a, bfs_slot_arg(sl));
-  };
-  if (a.chain_big_edges) chain_inplace(0);
-  st.level_kernel_ms = 0.0;
-  st.level_kernel_launches = 0;
-  st.wave_kernel_ms = 0.0;
-  st.wave_kernel_launches = 0;
-  st.stream_kernel_ms = 0.0;
-  st.stream_kernel_launches = 0;
-  st.batches = 0;
   // k_bfs_build2 reads a thread's 17 row offsets and 16 layout ids with 16-byte loads: borrowed arrays must be aligned
   const bool build2_ok = ((uintptr_t)a.row_offsets % 16 == 0) && ((uintptr_t)a.old_of_new % 16 == 0);
   // cold-edge lists (bfs_fused_cold.hpp): with the unit blocks they were cut from, the prefix they were cut behind, and a
   // queue build that knows their bitmaps
   const bool cold = units && a.dense_div && layout->cold_dst && layout->cold_slices > 0 && layout->cold_hot_n == (unsigned)(BFS_DENSE_HOTW * 32) &&
                     layout->cold_long_min == st.long_min && build2_ok && !opt.build_list && opt.cold != 0 &&
-                    !opt.dense_diag && !(opt.biglds && st.time_kernels == 1);
+                    !MGX_LAB_GET(opt, dense_diag, 0) && !(MGX_LAB_GET(opt, biglds, 0) && st.time_kernels == 1);
   a.cold_owner = cold ? layout->cold_owner : nullptr;
   a.cold_dst = cold ? layout->cold_dst : nullptr;
   a.cold_slices = cold ? layout->cold_slices : 0;
   for (int i = 0; i < BFS_COLD_MAX_SLICES; ++i) a.cold_lo[i] = cold ? layout->cold_lo[i] : 0u;
   for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) { a.cold_off[i] = cold ? layout->cold_off[i] : 0u; a.cold_wgs[i] = cold ? layout->cold_wgs[i] : 0u; }
   // ... and of the short rows, for the levels that walk them vertex by vertex
+#ifdef MGX_LAB
   const bool colds = cold && a.vs_div && layout->colds_dst && opt.cold != 2;
   a.colds_owner = colds ? layout->colds_owner : nullptr;
   a.colds_dst = colds ? layout->colds_dst : nullptr;
   for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) a.colds_off[i] = colds ? layout->colds_off[i] : 0u;
+#endif
   const size_t cold_words = cold ? (size_t)layout->cold_wgs[layout->cold_slices] * BFS_COLD_WORDS : 0;
   if (cold && st.cold_flush.size() < cold_words) { ctx.synchronize(); st.cold_flush = mem_t<u32>(cold_words, ctx); }
   a.cold_flush = cold ? st.cold_flush.data() : nullptr;
@@ -445,10 +384,109 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   a.lazy_pull = (mode == 1 && build2_ok && !opt.build_list && opt.lazy != 0) ? 1 : 0;
   // (direction-optimising runs too: a level behind a lazy build either pulls -- no queue needed -- or takes the queue-less bodies)
   a.lazy_div = (a.dense_div && a.vs_div && build2_ok && !opt.build_list) ? (opt.lazy >= 0 ? (u32)opt.lazy : st.lazy_div) : 0u;
+  plan.coldt = coldt;
+  plan.build2_ok = build2_ok;
+  plan.nstream = a.long_min > 0 ? (u32)ctx.num_cus * 2 : 0u;
+  plan.nwave = (u32)ctx.num_cus * 2;
+  plan.ncold = (!coldt && a.cold_dst) ? a.cold_wgs[a.cold_slices] : 0u;
+  plan.lab_flags = lab_flags;
+  plan.nwords = nwords;
+  plan.mode = mode;
+  plan.labels = labels;
+  return plan;
+}
+
+// the launches of a traversal on the product path (no events, merged push): init + the chain of the small levels at the
+// start; one slot; the chain behind the last slot of a batch.  prev_head: see k_bfs_fused_init.
+inline void bfs_enqueue_chain_inplace(const bfs_launch_plan_t& plan, int slot, hipStream_t s) {
+  hipLaunchKernelGGL(k_bfs_chain_inplace, dim3(1), dim3(1024), bfs_chain_lds_bytes(BFS_CHAIN_CAP_BIG), s, plan.a, bfs_slot_arg(slot));
+}
+inline void bfs_enqueue_start(const bfs_fused_state_t& st, const bfs_launch_plan_t& plan, int src, standard_context_t& ctx,
+                              bfs_ctrl_t* prev_head = nullptr, int head_words = 0) {
+  hipStream_t s = ctx.stream();
+  hipLaunchKernelGGL(k_bfs_fused_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, plan.a, src,
+                     plan.nwords, prev_head, head_words);
+  if (plan.a.chain_big_edges) bfs_enqueue_chain_inplace(plan, 0, s);
+}
+inline void bfs_enqueue_build(const bfs_fused_state_t& st, const bfs_launch_plan_t& plan, int arg, hipStream_t s) {
+  if (st.opts.build_list || !plan.build2_ok)
+    hipLaunchKernelGGL((k_bfs_build<512, true>), dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, plan.a, arg,
+                       (const u32*)nullptr, plan.labels, st.n, 1, 0, 1);
+  else
+    hipLaunchKernelGGL(k_bfs_build2<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, plan.a, arg, plan.labels, st.n);   // (2 workgroups per CU overlap their phases)
+}
+inline void bfs_enqueue_slot(const bfs_fused_state_t& st, const bfs_launch_plan_t& plan, int slot, standard_context_t& ctx) {
+  hipStream_t s = ctx.stream();
+  const int arg = bfs_slot_arg(slot);
+  if (plan.a.chain_big_edges && slot > 0 && slot >= st.tail_from && st.opts.tail_chain) bfs_enqueue_chain_inplace(plan, slot, s);
+  bfs_launch_push_part<0>(plan.a, arg, ctx, plan.coldt, plan.nstream + plan.ncold + plan.nwave, plan.nstream);
+  if (plan.mode == 1 && !plan.a.merged_pull)
+    hipLaunchKernelGGL(k_bfs_pull_level<256>, dim3(ctx.num_cus * 8), dim3(256), 0, s, plan.a, arg);
+  bfs_enqueue_build(st, plan, arg, s);
+}
+
+// What the NEXT traversal of this graph should enqueue, from the level sizes of the one whose control block `hc` holds:
+// a slot for every level that is too big for the in-place chain (sources differ, the level structure of a graph hardly
+// does; a slot too many is two idle launches, ~9 us; one too few a second batch, ~25 us) -- the most any of the last four
+// traversals needed.  In-place chain launches from the first slot behind them on, i.e. behind the batch: a chain launch
+// that finds a big level costs 5 us (its reads of the control block miss behind the build's atomics), and on RMAT-22 the
+// level behind the last big one is small for a minority of the sources only.
+inline void bfs_learn_slots(bfs_fused_state_t& st, const bfs_fused_args_t& a, const bfs_ctrl_t* hc, int mode, int trace_avail) {
+  st.slots_hint = hc->slots > 0 ? hc->slots : 1;    // slots that found work
+  st.tail_from = 1 << 30;
+  if (!(a.chain_big_edges && st.opts.tail_chain)) return;
+  const int lv = hc->levels < trace_avail ? hc->levels : trace_avail;     // (levels behind the part of the trace the host holds count as small)
+  int k = 0;
+  bool pulled = false;
+  u64 reached = 1;                         // (vertices with edges reached before level l runs: what bfs_chain_edge_limit looks at, nearly)
+  for (int l = 0; l < lv; ++l) {
+    const u64 t = hc->trace[l];
+    if (l > 0) reached += t >> BFS_VSHIFT;
+    const bool late = reached * 4ull >= (u64)(u32)a.n;
+    const u64 lim = late || a.chain_big_edges < BFS_CHAIN_EARLY_EDGES ? a.chain_big_edges : BFS_CHAIN_EARLY_EDGES;
+    bool small = (t >> BFS_VSHIFT) <= (u64)BFS_CHAIN_CAP_BIG && (t & BFS_EMASK) <= lim;
+    if (mode == 1) {                       // direction-optimising: bottom-up levels (and everything behind the first) are device-wide
+      const float unvisited = (float)((long long)a.n - (long long)reached);
+      if (unvisited < (float)(long long)(t >> BFS_VSHIFT) * a.alpha) pulled = true;
+      if (pulled) small = false;
+    }
+    if (!small) ++k;
+  }
+  const int need = k > 0 ? k : 1;
+  st.recent_need[st.recent_at & 3] = need;
+  st.recent_at += 1;
+  int hint = 1;
+  for (int i = 0; i < 4 && i < st.recent_at; ++i)
+    if (st.recent_need[i] > hint) hint = st.recent_need[i];
+  st.slots_hint = hint;
+  st.tail_from = hint;
+}
+
+// Runs a whole BFS from `src` on the context's stream.  labels[] is (re)initialised here.  Returns with the
+// stream synchronised and host_ctrl holding the final counters.
+// mode/alpha: MGX_BFS_PUSH (0) or MGX_BFS_DIRECTION_OPT (1) with the reference's switch rule
+// num_unvisited < frontier_length * alpha (bfs_enactor.hxx:68).  in_offsets/in_indices: in-edges for the
+// bottom-up levels (pass the CSR for symmetric graphs, the reference's behaviour -- SURVEY F8).
+inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const int* col_indices, int* labels,
+                          int src, standard_context_t& ctx, const bfs_layout_t* layout = nullptr, int mode = 0,
+                          float alpha = 0.f, const int* in_offsets = nullptr, const int* in_indices = nullptr) {
+  hipStream_t s = ctx.stream();
+  const bfs_run_opts_t& opt = st.opts;
+  const bfs_launch_plan_t plan = bfs_fused_plan(st, row_offsets, col_indices, labels, ctx, layout, mode, alpha, in_offsets, in_indices);
+  const bfs_fused_args_t& a = plan.a;
+  const bool coldt = plan.coldt;
+  const int lab_flags = plan.lab_flags;
+  bfs_enqueue_start(st, plan, src, ctx);
+  auto chain_inplace = [&](int sl) { bfs_enqueue_chain_inplace(plan, sl, s); };
+  st.level_kernel_ms = 0.0;
+  st.level_kernel_launches = 0;
+  st.wave_kernel_ms = 0.0;
+  st.wave_kernel_launches = 0;
+  st.stream_kernel_ms = 0.0;
+  st.stream_kernel_launches = 0;
+  st.batches = 0;
   const bool batch_events = st.time_kernels != 0 || st.time_batches;    // (an event costs ~6 us of stream gap)
-  const u32 nstream = a.long_min > 0 ? (u32)ctx.num_cus * 2 : 0u;
-  const u32 nwave = (u32)ctx.num_cus * 2;
-  const u32 ncold = (!coldt && a.cold_dst) ? a.cold_wgs[a.cold_slices] : 0u;
+  const u32 nstream = plan.nstream, nwave = plan.nwave, ncold = plan.ncold;
   int slot = 0;
   for (int batch = 0;; ++batch) {
     // first batch: what the previous traversal of this graph needed (sources differ, level structure hardly)
@@ -460,21 +498,24 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
       if (a.chain_big_edges && slot > 0 && slot >= st.tail_from && opt.tail_chain) chain_inplace(slot);
       const bool in_pool = 3 * i + 2 < bfs_fused_state_t::EV_POOL;
       const bool timed = st.time_kernels == 1 && in_pool;
-      const bool timed_merged = st.time_kernels == 2 && in_pool && opt.merged && !a.flags;
+      const bool timed_merged = st.time_kernels == 2 && in_pool && opt.merged && !lab_flags;
       if (timed_merged) {
         // the product launch itself between two events: its average duration is what rocprofv3 --stats reports for
         // k_bfs_push<., 0> too (launches of small or empty slots included on both sides)
         MGX_HIP(hipEventRecord(st.wev[3 * i], s));
         bfs_launch_push_part<0>(a, arg, ctx, coldt, nstream + ncold + nwave, nstream);
         MGX_HIP(hipEventRecord(st.wev[3 * i + 1], s));
-      } else if (timed || !opt.merged || a.flags) {
+      } else if (timed || !opt.merged || lab_flags) {
         // the parts as launches of their own: opener / chain, long rows, short rows
         bfs_launch_push_part<1>(a, arg, ctx, coldt, 1, 0);
         if (timed) MGX_HIP(hipEventRecord(st.wev[3 * i], s));
         if (a.long_min > 0) {
+#ifdef MGX_LAB
           if (a.flags) hipLaunchKernelGGL(k_bfs_push_stream_diag, dim3(nstream), dim3(1024), bfs_push_lds_bytes(), s, a, arg);
           else if (opt.biglds && !coldt) hipLaunchKernelGGL(k_bfs_push_dense_big, dim3(ctx.num_cus), dim3(1024), bfs_dense_lds_bytes(BFS_DENSE_HOTW_BIG), s, a, arg);
-          else bfs_launch_push_part<2>(a, arg, ctx, coldt, nstream + ncold, nstream);
+          else
+#endif
+          bfs_launch_push_part<2>(a, arg, ctx, coldt, nstream + ncold, nstream);
         }
         if (timed) MGX_HIP(hipEventRecord(st.wev[3 * i + 1], s));
         bfs_launch_push_part<3>(a, arg, ctx, coldt, nwave, 0);
@@ -484,11 +525,8 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
       }
       if (mode == 1 && !a.merged_pull)
         hipLaunchKernelGGL(k_bfs_pull_level<256>, dim3(ctx.num_cus * 8), dim3(256), 0, s, a, arg);
-      if (opt.build_list || !build2_ok)
-        hipLaunchKernelGGL((k_bfs_build<512, true>), dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, arg,
-                           (const u32*)nullptr, labels, st.n, 1, 0, 1);
-      else
-        hipLaunchKernelGGL(k_bfs_build2<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, arg, labels, st.n);   // (2 workgroups per CU overlap their phases)
+      bfs_enqueue_build(st, plan, arg, s);
+      if (timed_merged) MGX_HIP(hipEventRecord(st.wev[3 * i + 2], s));    // (timing mode 2: the slot's queue build too)
     }
     if (a.chain_big_edges && slot >= st.tail_from && opt.tail_chain) chain_inplace(slot);    // (the stragglers: may end the traversal here)
     if (batch_events) MGX_HIP(hipEventRecord(st.ev1, s));
@@ -518,11 +556,15 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
       const int sl = slot - nslots + i;
       float wms = 0.f;
       if (st.time_kernels == 2) {
-        if (!(opt.merged && !a.flags)) break;
+        if (!(opt.merged && !lab_flags)) break;
         MGX_HIP(hipEventElapsedTime(&wms, st.wev[3 * i], st.wev[3 * i + 1]));
         st.stream_kernel_ms += wms;
         st.stream_kernel_launches += 1;
-        if (sl < 64) { st.level_stream_ms[sl] = wms; st.level_wave_ms[sl] = 0.f; }
+        float bms = 0.f;                                  // ... and the queue build behind it (reported in the "wave" half)
+        MGX_HIP(hipEventElapsedTime(&bms, st.wev[3 * i + 1], st.wev[3 * i + 2]));
+        st.wave_kernel_ms += bms;
+        st.wave_kernel_launches += 1;
+        if (sl < 64) { st.level_stream_ms[sl] = wms; st.level_wave_ms[sl] = bms; }
         continue;
       }
       MGX_HIP(hipEventElapsedTime(&wms, st.wev[3 * i + 1], st.wev[3 * i + 2]));
@@ -549,48 +591,75 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
     }
   }
   st.slots_used = slot;
-  st.slots_hint = st.host_ctrl->slots > 0 ? st.host_ctrl->slots : 1;    // slots that found work
-  st.tail_from = 1 << 30;
   const int lv = st.host_ctrl->levels < BFS_MAX_TRACE ? st.host_ctrl->levels : BFS_MAX_TRACE;
   if (lv > 64) {                // the rest of the per-level trace (deep traversals only)
     MGX_HIP(hipMemcpyAsync(st.host_ctrl->trace + 64, st.ctrl.data()->trace + 64, (size_t)(lv - 64) * sizeof(u64), hipMemcpyDeviceToHost, s));
     MGX_HIP(hipStreamSynchronize(s));
   }
-  if (a.chain_big_edges && opt.tail_chain) {
-    // What the NEXT traversal of this graph should enqueue, from this one's level sizes: a slot for every level that is
-    // too big for the in-place chain, and chain launches from the first slot on that had a small level in front of it
-    // (sources differ, the level structure of a graph hardly does; a wrong guess costs an idle launch or a second batch).
-    int k = 0, tail = 1 << 30;
-    bool pulled = false;
-    u64 reached = 1;                         // (vertices with edges reached before level l runs: what bfs_chain_edge_limit looks at, nearly)
-    for (int l = 0; l < lv; ++l) {
-      const u64 t = st.host_ctrl->trace[l];
-      if (l > 0) reached += t >> BFS_VSHIFT;
-      const bool late = reached * 4ull >= (u64)(u32)a.n;
-      const u64 lim = late || a.chain_big_edges < BFS_CHAIN_EARLY_EDGES ? a.chain_big_edges : BFS_CHAIN_EARLY_EDGES;
-      bool small = (t >> BFS_VSHIFT) <= (u64)BFS_CHAIN_CAP_BIG && (t & BFS_EMASK) <= lim;
-      if (mode == 1) {                       // direction-optimising: bottom-up levels (and everything behind the first) are device-wide
-        const float unvisited = (float)((long long)a.n - (long long)reached);
-        if (unvisited < (float)(long long)(t >> BFS_VSHIFT) * a.alpha) pulled = true;
-        if (pulled) small = false;
-      }
-      if (small) { if (k >= 1 && k < tail) tail = k; }
-      else ++k;
-    }
-    // over the last few traversals: the most slots any of them needed (a slot too many is two idle launches, ~9 us; one too
-    // few a second batch, ~25 us).  In-place chain launches from the first slot behind them on, i.e. behind the batch: a
-    // chain launch that finds a big level costs 5 us (its reads of the control block miss behind the build's atomics),
-    // and on RMAT-22 the level behind the last big one is small for a minority of the sources only.
-    const int need = k > 0 ? k : 1;
-    (void)tail;
-    st.recent_need[st.recent_at & 3] = need;
-    st.recent_at += 1;
-    int hint = 1;
-    for (int i = 0; i < 4 && i < st.recent_at; ++i)
-      if (st.recent_need[i] > hint) hint = st.recent_need[i];
-    st.slots_hint = hint;
-    st.tail_from = hint;
+  bfs_learn_slots(st, a, st.host_ctrl, mode, BFS_MAX_TRACE);
+}
+
+// COUNT traversals enqueued back to back with ONE host wait at the end (mgx_bfs_run_many): every traversal is complete --
+// its labels written, its counters taken -- before the next one's init kernel resets the state, but the host does not
+// look in between, so the ~18 us between the publish of one traversal and the first kernel of the next (the host's
+// wake-up, the call, the first launch) and the publish kernel itself disappear.  Each traversal gets the slots the last
+// traversals of the graph needed plus one; the head of its control block is copied to heads[i] by the NEXT traversal's
+// init kernel (the last one's by k_bfs_publish).  A traversal that did not finish within its slots (a source with an
+// unusual level structure) is run again on its own afterwards -- then the last source too, so that labels[] always holds
+// the LAST source's traversal when the call returns.  heads: pinned host memory, bfs_many_head_bytes() apart.
+constexpr size_t bfs_head_bytes() { return offsetof(bfs_ctrl_t, trace) + 64 * sizeof(u64); }
+constexpr size_t bfs_many_head_bytes() { return (bfs_head_bytes() + 63) & ~(size_t)63; }
+inline bfs_ctrl_t* bfs_many_head(char* heads, int i) { return (bfs_ctrl_t*)(heads + (size_t)i * bfs_many_head_bytes()); }
+
+inline int bfs_fused_run_many(bfs_fused_state_t& st, const int* row_offsets, const int* col_indices, int* labels,
+                              const int* srcs, int count, standard_context_t& ctx, char* heads, const bfs_layout_t* layout = nullptr,
+                              int mode = 0, float alpha = 0.f, const int* in_offsets = nullptr, const int* in_indices = nullptr) {
+  if (count <= 0) return 0;
+  hipStream_t s = ctx.stream();
+  const bfs_launch_plan_t plan = bfs_fused_plan(st, row_offsets, col_indices, labels, ctx, layout, mode, alpha, in_offsets, in_indices);
+  const bfs_fused_args_t& a = plan.a;
+  constexpr int head_words = (int)(bfs_head_bytes() / 4);
+  int nslots = st.slots_hint + 1;
+  if (nslots > 30) nslots = 30;
+  const int saved_tail = st.tail_from;
+  st.tail_from = nslots - 1;                       // (chain launches in front of the spare slot and behind the batch)
+  const bool tail = a.chain_big_edges && st.opts.tail_chain;
+  for (int i = 0; i < count; ++i) {
+    bfs_enqueue_start(st, plan, srcs[i], ctx, i > 0 ? bfs_many_head(heads, i - 1) : nullptr, head_words);
+    for (int sl = 0; sl < nslots; ++sl) bfs_enqueue_slot(st, plan, sl, ctx);
+    if (tail) bfs_enqueue_chain_inplace(plan, nslots, s);
   }
+  st.tail_from = saved_tail;
+  const u64 seq = ++st.seq;
+  hipLaunchKernelGGL(k_bfs_publish, dim3(1), dim3(256), 0, s, (const bfs_ctrl_t*)st.ctrl.data(), bfs_many_head(heads, count - 1), st.host_seq, seq, head_words);
+  MGX_CHECK_LAUNCH("fused BFS (batch of sources): kernel launch");
+  {
+    volatile u64* const flag = st.host_seq;
+    long long spins = 0;
+    while (*flag != seq) {
+      if (++spins > 20000000LL) { MGX_HIP(hipStreamSynchronize(s)); break; }
+      __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  }
+  // finished?  (as in bfs_fused_run: done, or the last slot left both queues of the next one empty)
+  int reruns = 0;
+  bool redo_last = false;
+  for (int i = 0; i < count; ++i) {
+    bfs_ctrl_t* const h = bfs_many_head(heads, i);
+    if (!h->done) {
+      const u64 next = h->cursor[nslots % 3] | h->lcursor[nslots % 3];
+      if ((next >> BFS_VSHIFT) == 0) { h->done = 1; h->levels = h->slot_level[nslots & 3]; }
+    }
+    if (h->done) { bfs_learn_slots(st, a, h, mode, 64); continue; }
+    bfs_fused_run(st, row_offsets, col_indices, labels, srcs[i], ctx, layout, mode, alpha, in_offsets, in_indices);
+    memcpy(h, st.host_ctrl, bfs_head_bytes());
+    ++reruns;
+    if (i != count - 1) redo_last = true;
+  }
+  if (redo_last) bfs_fused_run(st, row_offsets, col_indices, labels, srcs[count - 1], ctx, layout, mode, alpha, in_offsets, in_indices);
+  st.slots_used = nslots;
+  return reruns;
 }
 
 }  // namespace mgx

@@ -92,7 +92,7 @@ __device__ __forceinline__ void bfs_stream_body(const bfs_fused_args_t& a, int l
 
   // marks of the vertices in [0, defer_n) wait for the end of the workgroup (bfs_hot_epilogue)
   const u32 defer_n = DIAG ? 0u : bfs_defer_limit(a, hot_n);
-  const int diag = (DIAG && (a.flags >> 8) == stat_level) ? (a.flags & 255) : 0;   // MGX_BFS_FLAGS = level << 8 | bits
+  const int diag = (DIAG && (MGX_LAB_GET(a, flags, 0) >> 8) == stat_level) ? (MGX_LAB_GET(a, flags, 0) & 255) : 0;   // MGX_BFS_FLAGS = level << 8 | bits
   int marks = 0;                 // per lane
 
   if (has_work) {

@@ -160,6 +160,7 @@ __device__ __forceinline__ void bfs_vshort_body(const bfs_fused_args_t& a, int s
   bfs_body_finish(a, marks, slot, stat_level, s_int);
 }
 
+#ifdef MGX_LAB   // (MGX_BFS_COMBINE: measured no faster than the two halves of the grid -- lab builds only)
 // Long rows from the unit blocks AND short rows vertex by vertex in ONE workgroup, one after the other over the same LDS
 // prefix: a level that takes both dense paths (the big level of a skewed graph) then copies the bitmap prefix 512 times
 // instead of 1024, runs one epilogue per workgroup, and what the long rows claimed in LDS is already known when the
@@ -185,5 +186,6 @@ __device__ __forceinline__ void bfs_dense_vshort_body(const bfs_fused_args_t& a,
   (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, slot, s_int + 4);
   bfs_body_finish(a, marks, slot, stat_level, s_int);
 }
+#endif  // MGX_LAB
 
 }  // namespace mgx

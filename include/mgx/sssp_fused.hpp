@@ -25,6 +25,7 @@
 // The relaxation rate barely moved (86 vs 80 G/s: the kernel is bound by the distance gather and the atomics, not
 // by the row search) and processing the hubs in a kernel of their own cost 1.4 x the relaxations: 3.36 vs 2.81 ms.
 #pragma once
+#include <vector>
 #include "bfs_fused.hpp"
 
 namespace mgx {
@@ -171,6 +172,7 @@ constexpr int SSSP_SLICE_SHIFT = 14;
 constexpr int SSSP_SLICE_V = 1 << SSSP_SLICE_SHIFT;        // 64 KB of distances: the dynamic LDS of k_sssp_relax
 constexpr u32 SSSP_SLICE_MIN_EDGES = 4096;                  // fewer edges of a slice in a workgroup's piece: no LDS copy
 
+#ifdef MGX_LAB
 template <int NT>
 __device__ __forceinline__ void sssp_sliced_body(const sssp_args_t& a, u32* const lds) {
   const u32 m = (u32)a.m_edges;                         // (int32 CSR: m < 2^31)
@@ -251,6 +253,7 @@ __device__ __forceinline__ void sssp_sliced_body(const sssp_args_t& a, u32* cons
     pos = seg_end;
   }
 }
+#endif  // MGX_LAB
 
 template <int NT>
 __global__ __launch_bounds__(NT, 8) void k_sssp_relax(sssp_args_t a, int it) {
@@ -280,10 +283,12 @@ __global__ __launch_bounds__(NT, 8) void k_sssp_relax(sssp_args_t a, int it) {
   unsigned char* mark = a.mark;
 
   extern __shared__ __attribute__((aligned(16))) u32 s_hot[];        // SSSP_HOTN / 2 words: two bounds per word
+#ifdef MGX_LAB   // (MGX_SSSP_SLICED: distances identical, measured no faster -- lab builds only)
   if (a.e_src && (u64)E * (u64)a.sliced_div >= a.m_edges) {            // a heavy iteration (grid-uniform): the edges by slice
     sssp_sliced_body<NT>(a, s_hot);
     return;
   }
+#endif
   const bool use_hot = E >= a.hot_min_edges;
   const u32 hot_n = use_hot ? ((u32)a.n < (u32)SSSP_HOTN ? ((u32)a.n & ~1u) : (u32)SSSP_HOTN) : 0u;
   if (use_hot) {
@@ -675,6 +680,11 @@ struct sssp_fused_state_t {
   int n = 0;
   int iters_hint = 12;
   float delta = 0.f;                 // near / far bucket width (0: off); MGX_SSSP_DELTA overrides
+  // per-launch timing of k_sssp_relax (measurement runs: mgx_sssp_set_kernel_timing; an event costs ~6 us of stream gap)
+  bool time_kernels = false;
+  std::vector<hipEvent_t> ev;        // pairs around the relax launches of a batch, made on demand
+  double relax_ms = 0.0;             // of the last run
+  long long relax_launches = 0;
   sssp_fused_state_t(int num_nodes, standard_context_t& ctx) : n(num_nodes) {
     mark = mem_t<unsigned char>((size_t)num_nodes + 64, ctx);
     dist_layout = mem_t<u32>((size_t)num_nodes + 4, ctx);
@@ -688,7 +698,10 @@ struct sssp_fused_state_t {
   }
   sssp_fused_state_t(const sssp_fused_state_t&) = delete;
   sssp_fused_state_t& operator=(const sssp_fused_state_t&) = delete;
-  ~sssp_fused_state_t() { if (host_ctrl) (void)hipHostFree(host_ctrl); }
+  ~sssp_fused_state_t() {
+    if (host_ctrl) (void)hipHostFree(host_ctrl);
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  }
 };
 
 // Whole run from `src`; d_dist (n floats) holds the distances afterwards (+inf: unreachable is reported as the
@@ -711,7 +724,11 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   const bool build2 = !(bl && atoi(bl) != 0) && ((uintptr_t)a.row_offsets % 16 == 0);
   // heavy iterations over the destination-sliced edge list (needs the frontier bitmap k_sssp_build2 writes)
   unsigned sdiv = st.sliced_div;
+#ifdef MGX_LAB
   if (const char* e = getenv("MGX_SSSP_SLICED")) sdiv = (unsigned)atoi(e);
+#else
+  sdiv = 0;                                                        // (the sliced list is a lab shape: measured no faster)
+#endif
   const bool sliced = layout && layout->e_src && layout->slices > 0 && layout->slice_shift == SSSP_SLICE_SHIFT && build2 && sdiv > 0 && a.delta == 0.f;
   if (sliced && !st.frontier_bits.size()) st.frontier_bits = mem_t<u32>(((size_t)st.n + 31) / 32 + 4, ctx);
   a.e_src = sliced ? layout->e_src : nullptr;
@@ -732,16 +749,28 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
     MGX_HIP(hipFuncSetAttribute((const void*)k_sssp_relax<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SSSP_HOTN * 2));
   }
   int it = 0;
+  st.relax_ms = 0.0;
+  st.relax_launches = 0;
   for (int batch = 0;; ++batch) {
     const int nit = batch == 0 ? st.iters_hint : 2;
+    if (st.time_kernels)
+      while ((int)st.ev.size() < 2 * nit) { hipEvent_t e; MGX_HIP(hipEventCreate(&e)); st.ev.push_back(e); }
     for (int i = 0; i < nit; ++i, ++it) {
+      if (st.time_kernels) MGX_HIP(hipEventRecord(st.ev[2 * i], s));
       hipLaunchKernelGGL(k_sssp_relax<1024>, dim3(ctx.num_cus * 2), dim3(1024), SSSP_HOTN * 2, s, a, it);
+      if (st.time_kernels) MGX_HIP(hipEventRecord(st.ev[2 * i + 1], s));
       if (build2) hipLaunchKernelGGL(k_sssp_build2<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, it);
       else hipLaunchKernelGGL(k_sssp_build<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, it);
     }
     MGX_CHECK_LAUNCH("fused SSSP: kernel launch");
     MGX_HIP(hipMemcpyAsync(st.host_ctrl, st.ctrl.data(), offsetof(bfs_ctrl_t, trace) + 64 * sizeof(u64), hipMemcpyDeviceToHost, s));
     MGX_HIP(hipStreamSynchronize(s));
+    for (int i = 0; st.time_kernels && i < nit; ++i) {
+      float ms = 0.f;
+      MGX_HIP(hipEventElapsedTime(&ms, st.ev[2 * i], st.ev[2 * i + 1]));
+      st.relax_ms += ms;
+      st.relax_launches += 1;
+    }
     if (st.host_ctrl->done) break;
     // every iteration launched so far has run: an empty next frontier ends the loop here, without the launch that
     // would find that out

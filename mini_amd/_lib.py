@@ -51,6 +51,7 @@ _pi, _pi64, _pf, _pvp = C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_
 # name -> argtypes (restype is int unless listed in _RESTYPES)
 SIGNATURES = {
     "mgx_version": [],
+    "mgx_build_is_lab": [],
     "mgx_strerror": [_i],
     "mgx_last_error": [],
     "mgx_ctx_create": [_i, _vp, _pvp],
@@ -110,6 +111,7 @@ SIGNATURES = {
     "mgx_bfs_enact_idempotent": [_vp, _pi64],
     "mgx_bfs_run": [_vp, _i, _i, _f, _pi64],
     "mgx_bfs_run_stats": [_vp, _i, _i, _f, _pi64, _i],
+    "mgx_bfs_run_many": [_vp, _pi, _i, _i, _f, _pi64, _i, _pi],
     "mgx_bfs_level_trace": [_vp, _i, _pi64, _pi64, _pi],
     "mgx_bfs_set_kernel_timing": [_vp, _i],
     "mgx_bfs_kernel_times": [_vp, _pi64],
@@ -161,6 +163,8 @@ SIGNATURES = {
     "mgx_sssp_enact": [_vp, _f, _pi64],
     "mgx_sssp_run": [_vp, _i, _pi64],
     "mgx_sssp_run_delta": [_vp, _i, _f, _pi64],
+    "mgx_sssp_set_kernel_timing": [_vp, _i],
+    "mgx_sssp_kernel_times": [_vp, _pi64],
     "mgx_pr_create": [_vp, _i, _pvp],
     "mgx_pr_free": [_vp],
     "mgx_pr_enact": [_vp, _pi64, _pi],

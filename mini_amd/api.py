@@ -346,6 +346,27 @@ class BfsProblem:
         if rc:
             check(rc)
 
+    def run_many(self, sources, mode=_lib.MGX_BFS_PUSH, alpha=0.0, prepared=None):
+        """A batch of sources enqueued back to back, one host wait (mgx_bfs_run_many).  Returns (list of stats dicts,
+        reruns); labels() are the last source's.  prepared = prepare_many(sources): buffers made beforehand, for timing loops
+        (then only the ctypes call happens here and the raw buffer is returned instead of dicts)."""
+        if prepared is None:
+            srcs, st, rr = self.prepare_many(sources)
+        else:
+            srcs, st, rr = prepared
+        rc = lib.mgx_bfs_run_many(self._h, srcs, len(srcs), int(mode), float(alpha), st, BfsProblem.STATS_LEN, C.byref(rr))
+        if rc:
+            check(rc)
+        if prepared is not None:
+            return st, rr.value
+        L = BfsProblem.STATS_LEN
+        return [self.stats_dict(st[i * L:(i + 1) * L]) for i in range(len(srcs))], rr.value
+
+    @staticmethod
+    def prepare_many(sources):
+        n = len(sources)
+        return (C.c_int * max(n, 1))(*[int(s) for s in sources]), (C.c_int64 * (max(n, 1) * BfsProblem.STATS_LEN))(), C.c_int(0)
+
     @staticmethod
     def stats_dict(st):
         return {"levels": st[0], "reached": st[1], "m_t": st[2], "push_edges": st[3], "pull_edges": st[4],
@@ -448,6 +469,15 @@ class SsspProblem:
         st = (C.c_int64 * 3)()
         check(lib.mgx_sssp_enact(self._h, C.c_float(queue_sizing), st))
         return {"iterations": st[0], "relaxations": st[1], "frontier_total": st[2]}
+
+    def set_kernel_timing(self, on=True):
+        check(lib.mgx_sssp_set_kernel_timing(self._h, int(bool(on))))
+
+    def kernel_times(self):
+        """{launches, ns} of k_sssp_relax in the last run() (after set_kernel_timing)"""
+        c = (C.c_int64 * 2)()
+        check(lib.mgx_sssp_kernel_times(self._h, c))
+        return {"launches": c[0], "ns": c[1]}
 
     def run(self, src, delta=None):
         """fused device-resident loop; delta: near / far bucket width (None / 0: plain frontier Bellman-Ford)"""

@@ -368,8 +368,13 @@ static void build_cold_lists(mgx_graph_s* g) {
   graph_device_t& G = *g->g;
   G.d_cold_owner = mem_t<int>(); G.d_cold_dst = mem_t<int>(); G.d_colds_owner = mem_t<int>(); G.d_colds_dst = mem_t<int>();
   G.cold_pairs = G.colds_pairs = 0; G.cold_slices = 0; G.cold_hot_n = 0; G.cold_long_min = 0;
-  bool with_short = false;                                         // (MGX_BFS_COLD_LISTS=2: also the short rows' list -- measured equal)
-  if (const char* e = getenv("MGX_BFS_COLD_LISTS")) { if (atoi(e) == 0) return; with_short = atoi(e) == 2; }
+  bool with_short = false;                                         // (lab builds, MGX_BFS_COLD_LISTS=2: also the short rows' list -- measured equal)
+  if (const char* e = getenv("MGX_BFS_COLD_LISTS")) {
+    if (atoi(e) == 0) return;
+#ifdef MGX_LAB
+    with_short = atoi(e) == 2;
+#endif
+  }
   if (G.ub_units <= 0 || G.vs_long_min <= 0 || G.vs_long_min != G.ub_min_degree || G.vs_v[0] == 0) return;
   const unsigned hot_n = (unsigned)mgx::BFS_COLD_WORDS * 32u, slice_n = hot_n;
   const unsigned n = (unsigned)G.num_nodes;
@@ -481,6 +486,7 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
       G.vs_edges = (unsigned)(h[b3] - h[b0]);
       G.vs_dummy = (unsigned)m + 4u;
       G.vs_long_min = long_min;
+#ifdef MGX_LAB
       // the short rows as one stream (mgx/bfs_fused_sshort.hpp): first entry and first row of every degree's region
       std::vector<unsigned> tab((size_t)mgx::BFS_SS_TAB_WORDS, 0u);
       for (int d = 0; d <= mgx::BFS_SS_MAXDEG; ++d) {
@@ -491,6 +497,7 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
       }
       G.d_ss_tab = mem_t<unsigned>(tab.size(), ctx);
       MGX_HIP(mgx::htod(G.d_ss_tab.data(), tab.data(), tab.size()));
+#endif
     }
   }
   build_cold_lists(g);
@@ -957,6 +964,30 @@ int mgx_bfs_enact_idempotent(mgx_bfs_t p, int64_t* stats) {
   MGX_CATCH
 }
 
+static void fill_bfs_stats(int64_t* out24, const bfs::bfs_run_stats_t& L) {
+  out24[0] = L.levels;
+  out24[1] = L.reached;
+  out24[2] = L.m_t;
+  out24[3] = L.push_edges;
+  out24[4] = L.pull_edges;
+  out24[5] = L.push_levels;
+  out24[6] = L.kernel_launches;
+  out24[7] = L.kernel_ns;
+  out24[8] = L.frontier_vertices;
+  out24[9] = L.claims;
+  const bfs::bfs_kernel_stats_t& D = L.dominant ? L.stream : L.wave;
+  out24[10] = D.launches;
+  out24[11] = D.ns;
+  out24[12] = D.edges;
+  out24[13] = D.vertices;
+  out24[14] = L.dominant;
+  out24[15] = L.small_levels;
+  out24[16] = L.slots;
+  out24[17] = L.dense_slots;
+  out24[18] = L.vshort_slots;
+  out24[19] = L.lazy_slots;
+  out24[20] = L.cold_slots;
+}
 int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats) { return mgx_bfs_run_stats(p, src, mode, alpha, stats, 16); }
 int mgx_bfs_run_stats(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats, int cap) {
   MGX_TRY
@@ -970,31 +1001,33 @@ int mgx_bfs_run_stats(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stat
   if (p->time_kernels >= 0) p->fe->fused->time_kernels = p->time_kernels;
   p->p->src = src;
   p->fe->enact(p->p, ctx, mode == MGX_BFS_DIRECTION_OPT, alpha);
-  const bfs::bfs_run_stats_t& L = p->fe->last;
-  p->last_stats[0] = L.levels;
-  p->last_stats[1] = L.reached;
-  p->last_stats[2] = L.m_t;
-  p->last_stats[3] = L.push_edges;
-  p->last_stats[4] = L.pull_edges;
-  p->last_stats[5] = L.push_levels;
-  p->last_stats[6] = L.kernel_launches;
-  p->last_stats[7] = L.kernel_ns;
-  p->last_stats[8] = L.frontier_vertices;
-  p->last_stats[9] = L.claims;
-  const bfs::bfs_kernel_stats_t& D = L.dominant ? L.stream : L.wave;
-  p->last_stats[10] = D.launches;
-  p->last_stats[11] = D.ns;
-  p->last_stats[12] = D.edges;
-  p->last_stats[13] = D.vertices;
-  p->last_stats[14] = L.dominant;
-  p->last_stats[15] = L.small_levels;
-  p->last_stats[16] = L.slots;
-  p->last_stats[17] = L.dense_slots;
-  p->last_stats[18] = L.vshort_slots;
-  p->last_stats[19] = L.lazy_slots;
-  p->last_stats[20] = L.cold_slots;
+  fill_bfs_stats(p->last_stats, p->fe->last);
   constexpr int have = (int)(sizeof(p->last_stats) / sizeof(p->last_stats[0]));
   if (stats) memcpy(stats, p->last_stats, sizeof(int64_t) * (size_t)(cap < have ? cap : have));
+  MGX_CATCH
+}
+int mgx_bfs_run_many(mgx_bfs_t p, const int* sources, int count, int mode, float alpha, int64_t* stats, int cap, int* reruns) {
+  MGX_TRY
+  MGX_REQUIRE(p && (sources || count == 0), "NULL argument");
+  MGX_REQUIRE(count >= 0 && count <= (1 << 20), "mgx_bfs_run_many: count out of range");
+  MGX_REQUIRE(cap >= 0, "mgx_bfs_run_many: negative capacity");
+  MGX_REQUIRE(mode == MGX_BFS_PUSH || mode == MGX_BFS_DIRECTION_OPT, "mgx_bfs_run_many: unknown mode");
+  for (int i = 0; i < count; ++i) MGX_REQUIRE(sources[i] >= 0 && sources[i] < p->g->g->num_nodes, "mgx_bfs_run_many: src out of range");
+  if (reruns) *reruns = 0;
+  if (count == 0) return MGX_OK;
+  use_device(p->g->c);
+  standard_context_t& ctx = *p->g->c->ctx;
+  if (!p->fe) p->fe.reset(new bfs::bfs_fused_enactor_t(ctx, p->g->g->num_nodes));
+  p->fe->fused->time_kernels = 0;                       // (per-launch events belong to mgx_bfs_run)
+  std::vector<bfs::bfs_run_stats_t> all;
+  const int rr = p->fe->enact_many(p->p, ctx, sources, count, all, mode == MGX_BFS_DIRECTION_OPT, alpha);
+  if (reruns) *reruns = rr;
+  constexpr int have = (int)(sizeof(p->last_stats) / sizeof(p->last_stats[0]));
+  const int take = cap < have ? cap : have;
+  for (int i = 0; i < count; ++i) {
+    fill_bfs_stats(p->last_stats, all[(size_t)i]);
+    if (stats && take > 0) memcpy(stats + (size_t)i * (size_t)cap, p->last_stats, sizeof(int64_t) * (size_t)take);
+  }
   MGX_CATCH
 }
 int mgx_bfs_level_trace(mgx_bfs_t p, int cap, int64_t* level_nf, int64_t* level_edges, int* levels) {
@@ -1323,6 +1356,13 @@ int mgx_comm_free(mgx_comm_t h) {
   MGX_CATCH
 }
 const char* mgx_comm_library(void) { return mgx::rccl_api_t::get().where.c_str(); }
+int mgx_build_is_lab(void) {
+#ifdef MGX_LAB
+  return 1;
+#else
+  return 0;
+#endif
+}
 int mgx_comm_available(void) { return mgx::rccl_api_t::get().ok() ? 1 : 0; }
 int mgx_dbfs2_run(mgx_dbfs2_t h, mgx_comm_t comm, int src_global, int exchange, int64_t exchange_words, int64_t* out6) {
   MGX_TRY
@@ -1460,7 +1500,11 @@ static void ensure_sliced_edges(mgx_graph_s* g) {
   if (G.sliced_tried) return;
   G.sliced_tried = true;
   G.sliced_slices = 0;
-  const char* const e = getenv("MGX_SSSP_SLICED");                  // (opt-in: measured no faster, sssp_fused.hpp)
+#ifndef MGX_LAB
+  G.sliced_tried = false;                                           // (a lab shape: measured no faster, sssp_fused.hpp)
+  return;
+#endif
+  const char* const e = getenv("MGX_SSSP_SLICED");                  // (opt-in)
   if (!e || atoi(e) <= 0) { G.sliced_tried = false; return; }
   if (!G.has_layout || !G.has_layout_weights || G.num_edges <= 0 || G.num_nodes <= 0) return;
   standard_context_t& ctx = *g->c->ctx;
@@ -1513,6 +1557,22 @@ int mgx_sssp_run_delta(mgx_sssp_t p, int src, float delta, int64_t* stats) {
     stats[1] = (int64_t)p->fused->host_ctrl->sum_edges;
     stats[2] = (int64_t)p->fused->host_ctrl->sum_frontier;
   }
+  MGX_CATCH
+}
+int mgx_sssp_set_kernel_timing(mgx_sssp_t p, int on) {
+  MGX_TRY
+  MGX_REQUIRE(p, "NULL argument");
+  use_device(p->g->c);
+  if (!p->fused) p->fused.reset(new mgx::sssp_fused_state_t(p->g->g->num_nodes, *p->g->c->ctx));
+  p->fused->time_kernels = on != 0;
+  MGX_CATCH
+}
+int mgx_sssp_kernel_times(mgx_sssp_t p, int64_t* out2) {
+  MGX_TRY
+  MGX_REQUIRE(p && out2, "NULL argument");
+  MGX_REQUIRE(p->fused != nullptr, "mgx_sssp_kernel_times: no mgx_sssp_run yet");
+  out2[0] = p->fused->relax_launches;
+  out2[1] = (int64_t)(p->fused->relax_ms * 1e6);
   MGX_CATCH
 }
 

@@ -10,6 +10,23 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "lab: needs the lab library (MGX_LIB=mini_amd/libmgx_lab.so, built by "
+                                       "`python __graft_entry__.py --lab`): experiment shapes that are not in the product")
+
+
+LAB_ENV_KEYS = ("MGX_BFS_COMBINE", "MGX_BFS_INTERLEAVE", "MGX_BFS_SSTREAM", "MGX_BFS_BIGLDS", "MGX_BFS_FLAGS", "MGX_BFS_DENSE_DIAG",
+                "MGX_BFS_BUILD_DIAG", "MGX_SSSP_SLICED")
+
+
+def needs_lab(env):
+    """does this set of environment switches select a shape that only the lab library holds?"""
+    return any(k in env for k in LAB_ENV_KEYS) or env.get("MGX_BFS_COLD") == "1" or env.get("MGX_BFS_COLD_LISTS") == "2"
+
+
+def skip_unless_lab(env=None):
+    import mini_amd
+    if (env is None or needs_lab(env)) and not mini_amd.lib.mgx_build_is_lab():
+        pytest.skip("lab shape: run with MGX_LIB=mini_amd/libmgx_lab.so")
 
 
 @pytest.fixture(scope="session")

@@ -183,6 +183,8 @@ def test_cold_edge_pass_vs_oracle(gpu_ctx, oracle, torch_mod, monkeypatch, scale
     thresholds and the unit blocks forced onto every level, bitmaps and replayed marks, the parts launched separately;
     labels against the oracle for hub, ordinary and isolated sources"""
     import mini_amd
+    from tests.conftest import skip_unless_lab
+    skip_unless_lab(env)                    # (the short rows' cold lists and the combined bodies: lab library only)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     n = 1 << scale

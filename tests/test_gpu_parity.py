@@ -178,7 +178,9 @@ def test_reference_fixtures_bfs_and_sssp(gpu_ctx, oracle, case, tmp_path):
         sssp = mini_amd.SsspProblem(g, src)
         sssp.enact(1.5)
         dist = sssp.distances()
-        as_int = np.where(dist == FLT_MAX, np.iinfo(np.int32).max, dist).astype(np.int64).astype(np.int32)
+        unreached = dist == FLT_MAX
+        as_int = np.where(unreached, 0.0, dist).astype(np.int32)
+        as_int[unreached] = np.iinfo(np.int32).max
         assert matches(case, "sssp_dist", as_int, np.int32)
         sssp.run(src)                                                 # the fused device-resident loop: same fixed point
         assert np.array_equal(sssp.distances(), dist)
@@ -588,6 +590,8 @@ def test_bfs_kernel_variants_on_random_graphs(gpu_ctx, oracle, monkeypatch, vari
     no LDS prefix, unmerged launches, no chains of small levels / short ones, the unit blocks forced on for every level
     that may use them (also with every row in them) / off."""
     import mini_amd
+    from tests.conftest import skip_unless_lab
+    skip_unless_lab(VARIANTS[variant])      # (shapes that lost their A/B runs live in the lab library only)
     for k, v in VARIANTS[variant].items():
         monkeypatch.setenv(k, v)
     rng = np.random.default_rng(100 + variant)
@@ -625,7 +629,9 @@ def test_sssp_fused_with_and_without_lds_distance_bounds(gpu_ctx, oracle, monkey
     import mini_amd
     monkeypatch.setenv("MGX_SSSP_HOT_MIN_EDGES", str(hot_min_edges))
     monkeypatch.setenv("MGX_SSSP_BUILD_LIST", str(build_list & 1))
-    if build_list == 2:                                     # heavy iterations over the destination-sliced edge list (opt-in)
+    if build_list == 2:                                     # heavy iterations over the destination-sliced edge list (lab library)
+        from tests.conftest import skip_unless_lab
+        skip_unless_lab()
         monkeypatch.setenv("MGX_SSSP_SLICED", "4")
     rng = np.random.default_rng(5 + (hot_min_edges > 0))
     for trial in range(4):
@@ -834,3 +840,65 @@ def test_sssp_near_far_tiny_delta_terminates(gpu_ctx, oracle):
     for delta in (1e-4, 1e-5):
         sssp.run(src, delta=delta)
         assert np.array_equal(sssp.distances(), want), delta
+
+
+@pytest.mark.parametrize("layout", [False, True])
+def test_bfs_run_many_equals_one_call_per_source(gpu_ctx, oracle, layout):
+    """mgx_bfs_run_many: K traversals enqueued back to back with one host wait -- every traversal's counters equal those
+    of a call of its own, the labels left behind are the LAST source's (checked against the oracle for every position
+    of the batch by rotating it), direction-optimising batches too; hubs, ordinary and isolated sources mixed"""
+    import mini_amd
+    rng = np.random.default_rng(31)
+    for scale, ef in ((10, 8), (14, 16), (16, 8)):
+        n, ro, ci, w = oracle.rmat_csr(scale, ef, 40 + scale)
+        g = _graph(gpu_ctx, ro, ci)
+        if layout:
+            g.build_layout()
+        deg = np.diff(ro)
+        srcs = [int(np.argmax(deg))] + [int(v) for v in rng.choice(np.where(deg > 0)[0], size=5, replace=False)] + [int(np.where(deg == 0)[0][0])]
+        bfs = mini_amd.BfsProblem(g, srcs[0])
+        solo = [bfs.run(s) for s in srcs]
+        for mode, alpha in ((mini_amd.MGX_BFS_PUSH, 0.0), (mini_amd.MGX_BFS_DIRECTION_OPT, 4.0)):
+            for rot in range(len(srcs)):
+                batch = srcs[rot:] + srcs[:rot]
+                sts, reruns = bfs.run_many(batch, mode, alpha)
+                want = oracle.bfs_cpu(ro, ci, batch[-1])
+                assert np.array_equal(bfs.labels(), want), (scale, mode, rot)
+                for s, st in zip(batch, sts):
+                    ref = solo[srcs.index(s)]
+                    assert (st["m_t"], st["reached"], st["levels"]) == (ref["m_t"], ref["reached"], ref["levels"]), (scale, mode, rot, s)
+        sts, _ = bfs.run_many([], mini_amd.MGX_BFS_PUSH, 0.0)
+        assert sts == []
+
+
+def test_bfs_run_many_reruns_a_traversal_that_needs_more_slots(gpu_ctx, oracle, monkeypatch):
+    """a batch is sized by the launch slots the previous traversals needed: a source whose traversal has many more big
+    levels (here: a long chain of cliques behind a graph of diameter 2, chains of small levels switched off so that every
+    level takes a slot) does not finish inside the batch, is run again on its own and reported in `reruns` -- counters and
+    labels are right either way"""
+    import mini_amd
+    monkeypatch.setenv("MGX_BFS_CHAIN_MAX_EDGES", "0")
+    monkeypatch.setenv("MGX_BFS_SEED_CHAIN", "0")
+    t0, t1 = [], []
+    hub, nleaf = 0, 2000
+    for k in range(1, nleaf + 1):                       # a star: depth 1 from the hub, 2 from a leaf
+        t0.append(hub); t1.append(k)
+    base = nleaf + 1
+    length = 40                                         # a path of 40 more levels hanging off leaf 1
+    prev = 1
+    for k in range(length):
+        t0.append(prev); t1.append(base + k); prev = base + k
+    n = base + length
+    ro, ci, _ = oracle.csr_from_tuples(n, np.array(t0, dtype=np.int32), np.array(t1, dtype=np.int32), None, undir=True)
+    g = _graph(gpu_ctx, ro, ci)
+    bfs = mini_amd.BfsProblem(g, hub)
+    for _ in range(4):
+        bfs.run(5)                                      # a leaf far from the path: few levels ... wait, the path is reachable from everywhere
+    far = n - 1                                         # the end of the path: the deepest traversal of the graph
+    sts, reruns = bfs.run_many([hub, far, hub], mini_amd.MGX_BFS_PUSH, 0.0)
+    assert np.array_equal(bfs.labels(), oracle.bfs_cpu(ro, ci, hub))
+    for s, st in zip([hub, far, hub], sts):
+        want = oracle.bfs_cpu(ro, ci, s)
+        assert st["reached"] == int((want >= 0).sum()) and st["levels"] == int(want.max()) + 1, (s, st, reruns)
+    sts, reruns2 = bfs.run_many([far, far], mini_amd.MGX_BFS_PUSH, 0.0)
+    assert np.array_equal(bfs.labels(), oracle.bfs_cpu(ro, ci, far))
