@@ -269,6 +269,7 @@ def bench_bfs(args, ctx, stream):
         bfs.run_into(s, mode, alpha_f, st1)
         per_src_s.append(time.perf_counter() - tc)
     per_src_mt = [st["m_t"] for st in stats]
+    slots_hist = {}
     # Roofline pass: the SAME K sources again, now with HIP events around every launch of the product kernel k_bfs_push
     # and of the queue build behind it (on the launch stream).  A pass of its own because every event record between two
     # kernels leaves a ~6 us gap on the stream (rocprofv3 kernel trace, profiles/): inside the timed region they would cost
@@ -278,6 +279,7 @@ def bench_bfs(args, ctx, stream):
     build_launches, build_ns = 0, 0
     for s in timed:
         stats_timed.append(bfs.run(s, mode, args.alpha))
+        slots_hist[stats_timed[-1]["slots"]] = slots_hist.get(stats_timed[-1]["slots"], 0) + 1
         kt = bfs.kernel_times()
         kernel_times.append(kt["stream"])
         build_launches += kt["wave"]["launches"]
@@ -407,7 +409,7 @@ def bench_bfs(args, ctx, stream):
                                 "over sources (SURVEY 8d)" % len(timed)},
            "graph500_MTEPS": round(m_t / 2.0 / elapsed / 1e6, 2),
            "graph500_note": "Graph500 convention: undirected input edges inside the reached component / time = m_t / 2 on the symmetrised CSR (SURVEY 8d)",
-           "batch_reruns": reruns,
+           "batch_reruns": reruns, "slots_needed_hist": {str(k): v for k, v in sorted(slots_hist.items())},
            "device_ms_per_step": round(dev_ms / max(args.steps, 1), 4),
            "avg_levels": round(sum(st["levels"] for st in stats) / K, 2),
            "avg_slots": round(sum(st["slots"] for st in stats) / K, 2),
@@ -556,7 +558,11 @@ def bench_pr(args, ctx, stream):
     graph = mini_amd.Graph.from_device(ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"])
     n, m = g["n"], g["m"]
     t_build = time.time() - t_build
-    t_layout = 0.0
+    t_layout = time.time()
+    if not args.no_layout:
+        graph.build_layout()          # the operator's full-frontier path reads the graph's hub-first copy (mgx/nreduce.hpp)
+        torch.cuda.synchronize()
+    t_layout = time.time() - t_layout
     f = mini_amd.Frontier(ctx, n).fill_iota(n)
     gen = torch.Generator(device="cuda").manual_seed(seed)
     vals = torch.rand(n, device="cuda", generator=gen)
@@ -617,7 +623,8 @@ def bench_pr(args, ctx, stream):
            "config": {"workload": "neighbour-reduce (float plus) over the full frontier of RMAT scale %d ef %d symmetrised, n=%d m=%d: "
                                   "one operator call per step" % (args.scale, args.edgefactor, n, m),
                       "scale": args.scale, "edgefactor": args.edgefactor, "seed": seed, "parallelism": "1 GPU",
-                      "layout": "generator ids"},
+                      "layout": "generator ids" if args.no_layout else "the operator is called with generator ids; for a full frontier the library reads "
+                                "the graph's hub-first copy (unit blocks + degree classes, untimed one-time preprocessing: layout_build_s)"},
            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "parity_tolerance": "rtol 2e-5 (float sum order)",
            "device_ms_per_step": round(dev_ms / max(args.steps, 1), 4), "graph_build_s": round(t_build, 2), "layout_build_s": round(t_layout, 2),
            "source_sha": sha}

@@ -76,6 +76,9 @@ struct graph_device_t {
   mem_t<int> d_ub_owner;
   long long ub_units = 0, ub_units_pad = 0;
   int ub_min_degree = 0;
+  mem_t<unsigned char> d_ub_cnt;     // real entries of every unit (the rest is padding): what a reduction may count (mgx/nreduce.hpp)
+  mem_t<int> d_ub_first;             // n + 1: the units of layout row v are [ub_first[v], ub_first[v + 1])
+  unsigned nr_big_rows = 0;          // layout rows [0, nr_big_rows) hold more than mgx::NR_BIG_UNITS units (degree-sorted layouts)
   // Degree classes of the layout's short rows (mgx/bfs_fused_vshort.hpp): only for a layout the library built itself
   // (sorted by degree, eight ints of -1 behind its neighbour array).
   unsigned vs_v[4] = {0, 0, 0, 0};

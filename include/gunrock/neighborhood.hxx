@@ -6,7 +6,10 @@
 // number of edges visited.
 #pragma once
 
+#include <type_traits>
+
 #include "../mgx/lbs.hpp"
+#include "../mgx/nreduce.hpp"
 #include "../mgx/scan.hpp"
 #include "frontier.hxx"
 #include "intrinsics.hxx"
@@ -14,6 +17,15 @@
 namespace gunrock {
 namespace oprtr {
 namespace neighborhood {
+
+// A functor may declare `static constexpr bool mgx_pure_gather = true`: its cond_advance / apply_advance are trivially
+// true and get_value_to_reduce(v) is a pure read.  Only then may the operator skip the two calls and take a vertex's value
+// once instead of once per edge (the full-frontier path below); the reference's own functors declare nothing and always
+// get the per-edge contract of neighborhood.hxx:39-57.
+template <typename F, typename = void>
+struct is_pure_gather : std::false_type {};
+template <typename F>
+struct is_pure_gather<F, typename std::enable_if<F::mgx_pure_gather>::type> : std::true_type {};
 
 template <typename Problem, typename Functor, typename Value, typename reduce_op, bool has_output, bool push>
 int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<frontier_t<int>>& input,
@@ -26,6 +38,20 @@ int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fronti
   const int* const frontier = input->data()->data();
   const long long frontier_size = (long long)input->size();
 
+  // Full frontier (0, 1, ..., n - 1: PR's first iteration) on a graph that carries the hub-first layout with unit blocks and
+  // degree classes: mgx/nreduce.hpp.  Whether the frontier IS the iota is checked on the device; the answer rides on the
+  // host wait of the degree scan below.
+  bool try_full = false;
+  if (!has_output && is_pure_gather<Functor>::value && frontier_size == (long long)graph.num_nodes && frontier_size > 0 &&
+      graph.has_layout && (push || graph.csc_is_csr) && graph.ub_units > 0 && graph.ub_min_degree == 64 && graph.vs_long_min == 64 &&
+      graph.d_ub_cnt.size() && graph.d_ub_first.size() && graph.vs_dummy != 0 &&
+      context.scratch_bytes >= mgx::nr_scratch_bytes(graph.num_nodes, graph.ub_units_pad, sizeof(Value))) {
+    try_full = true;
+    context.mailbox[8] = 1;
+    hipLaunchKernelGGL(mgx::k_nr_check_iota, dim3(mgx::grid_for(frontier_size, mgx::BLOCK, context.num_cus * 4)), dim3(mgx::BLOCK), 0,
+                       context.stream(), frontier, frontier_size, context.mailbox + 8);
+  }
+
   // segment i = the neighbour list of frontier[i]: exclusive scan of the degrees into the graph's scratch scan
   graph.ensure_scanned(input->capacity(), context);
   int* const segment_start = graph.d_scanned_row_offsets.data();
@@ -33,13 +59,30 @@ int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fronti
   mgx::transform_scan([=] __device__(long long i) { return offsets[frontier[i] + 1] - offsets[frontier[i]]; },
                       frontier_size, segment_start, context, &edges);
   if (edges == 0) return 0;
+  typename Problem::data_slice_t* const data = problem->d_data_slice.data();
+  if (try_full && context.mailbox[8] == 1) {
+    mgx::nr_layout_t L;
+    L.row_offsets = (const mgx::u32*)graph.d_layout_row_offsets.data();
+    L.col_indices = graph.d_layout_col_indices.data();
+    L.old_of_new = graph.d_old_of_new.data();
+    L.ub_col = graph.d_ub_col.data();
+    L.ub_cnt = graph.d_ub_cnt.data();
+    L.ub_first = graph.d_ub_first.data();
+    L.ub_units = (mgx::u32)graph.ub_units; L.ub_units_pad = (mgx::u32)graph.ub_units_pad;
+    for (int i = 0; i < 4; ++i) L.vs_v[i] = graph.vs_v[i];
+    L.vs_dummy = graph.vs_dummy;
+    L.big_rows = graph.nr_big_rows;
+    L.n = graph.num_nodes;
+    mgx::nr_full_frontier<Value>(L, [=] __device__(int v) -> Value { return Functor::get_value_to_reduce(v, data, iteration); }, reduced,
+                                 identity, reduce_op(), context);
+    return (int)edges;
+  }
 
   int* out = nullptr;
   if (has_output) {
     output->resize((size_t)edges);
     out = output->data()->data();
   }
-  typename Problem::data_slice_t* const data = problem->d_data_slice.data();
 
   // per edge: the functor's contract (cond, then apply, both always), the optional output slot, and the value that
   // goes into the segment's reduction; reduced[i] belongs to frontier POSITION i (neighborhood.hxx:58)

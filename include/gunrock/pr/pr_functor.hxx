@@ -15,6 +15,9 @@ namespace pr {
 
 struct pr_functor_t {
   using slice_t = pr_problem_t::data_slice_t;
+  // cond_advance / apply_advance are trivially true and get_value_to_reduce is a pure read: the operator may take the
+  // value of a vertex once instead of once per edge and skip the two calls (include/gunrock/neighborhood.hxx)
+  static constexpr bool mgx_pure_gather = true;
 
   static __device__ __forceinline__ float finite_or_zero(float x) { return isfinite(x) ? x : 0.0f; }
 

@@ -971,6 +971,8 @@ struct bfs_run_opts_t {
   long long defer = -1;    // MGX_BFS_DEFER: 0 never defer hot marks, N: flush a bitmap above N deferred marks per workgroup
   int spin = -1;           // MGX_BFS_SPIN: 0 read the control block back with a copy + hipStreamSynchronize, 1 publish kernel + spin
   int build_list = 0;      // MGX_BFS_BUILD_LIST=1: the list-based queue build (k_bfs_build) instead of k_bfs_build2
+  int many_spare = 1;      // MGX_BFS_MANY_SPARE: launch slots a traversal of a batch (mgx_bfs_run_many) gets beyond what the last
+                           // traversals of the graph needed (one that does not finish is run again on its own)
 #ifdef MGX_LAB
   int flags = 0;           // MGX_BFS_FLAGS (instrumented stream kernel)
   int sstream = 0;         // MGX_BFS_SSTREAM=1: dense short rows as one stream of entries (bfs_fused_sshort.hpp) instead of vertex by
@@ -1007,6 +1009,8 @@ struct bfs_run_opts_t {
     geti("MGX_BFS_DO_CHAIN", o.do_chain);
     geti("MGX_BFS_TAIL_CHAIN", o.tail_chain);
     geti("MGX_BFS_CHAIN_BIG_EDGES", o.chain_big);
+    geti("MGX_BFS_MANY_SPARE", o.many_spare);
+    if (o.many_spare < 0) o.many_spare = 0;
     geti("MGX_BFS_LAZY", o.lazy);
     if (o.lazy > (1 << 20)) o.lazy = 1 << 20;     // (edges < 2^38: no overflow)
 #ifdef MGX_LAB

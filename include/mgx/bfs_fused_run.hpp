@@ -619,8 +619,9 @@ inline int bfs_fused_run_many(bfs_fused_state_t& st, const int* row_offsets, con
   const bfs_launch_plan_t plan = bfs_fused_plan(st, row_offsets, col_indices, labels, ctx, layout, mode, alpha, in_offsets, in_indices);
   const bfs_fused_args_t& a = plan.a;
   constexpr int head_words = (int)(bfs_head_bytes() / 4);
-  int nslots = st.slots_hint + 1;
+  int nslots = st.slots_hint + st.opts.many_spare;
   if (nslots > 30) nslots = 30;
+  if (nslots < 1) nslots = 1;
   const int saved_tail = st.tail_from;
   st.tail_from = nslots - 1;                       // (chain launches in front of the spare slot and behind the batch)
   const bool tail = a.chain_big_edges && st.opts.tail_chain;

@@ -1,0 +1,256 @@
+// mgx/nreduce.hpp -- segmented neighbour-reduce over the FULL frontier on the graph's hub-first layout.
+//
+// The operator (gunrock/neighborhood.hxx, reference neighborhood.hxx:12-70) computes reduced[i] = (+) over the neighbours u
+// of frontier[i] of value(u).  Its general kernel (lbs.hpp: k_lbs_segreduce2) addresses the edges by rank: a load-balanced
+// search per item and one 4-byte gather of value(u) per edge out of an n-float array in arbitrary order -- 77 G gathers/s
+// from 16 MB on this part (profiles/r01/microbench.jsonl), 1.4 ms for the 134 M edges of RMAT-22, 0.14 of the HBM roof.
+// When the frontier is every vertex in order (PR's first iteration, mgx_segreduce_* over an iota frontier) and the graph
+// carries the hub-first layout of the fused BFS, nothing needs a search and most gathers never leave the compute unit:
+//
+//   k_nr_values   vals[v] = value(old_of_new[v]) for every layout vertex v: ONE gather per vertex instead of one per
+//                 edge; from here on the values are addressed by layout id, where the hubs -- the targets of most edges --
+//                 are the first ids; reduced[] <- identity.
+//   k_nr_long     the long rows (>= 64 entries) from the unit blocks (mgx_layout.hip): 16 bytes per lane, a unit of 64
+//                 entries belongs to ONE row (ub_cnt[u] of them are real, the rest padding), so the segment id is free;
+//                 the values of the first NR_HOTV layout vertices sit in LDS (80 KB per workgroup, two workgroups per
+//                 CU), the others are gathered from L2 (the next 600 K vertices are 2.4 MB); 16 lanes fold a unit with
+//                 four shuffle steps in a fixed order -> partial[u].
+//   k_nr_rows     a long row's units are contiguous (ub_first[v] .. ub_first[v + 1]): one thread folds the partials of a
+//                 row of up to NR_BIG_UNITS units in order; the few rows above that (the first rows of the degree-sorted
+//                 layout) take a workgroup each.  Deterministic: the order of the fold never depends on timing.
+//   k_nr_short    rows of 1 .. 63 entries by degree class as in bfs_fused_vshort.hpp: 16 / 4 / 1 lanes per vertex, one
+//                 unaligned 16-byte load of four entries per lane, fold by shuffles.
+// Results go to reduced[old_of_new[v]] -- the frontier POSITION of vertex v in an iota frontier (neighborhood.hxx:58).
+// Float sums are folded in a different order than the general kernel's (both are deterministic; the reference's own
+// order is moderngpu's and unpinned): the tests compare with 2e-5 relative.
+#pragma once
+#include "runtime.hpp"
+#include "wave.hpp"
+
+namespace mgx {
+
+constexpr int NR_HOTV = 20000;            // values of the first NR_HOTV layout vertices in LDS (80 000 bytes per workgroup)
+constexpr int NR_BIG_UNITS = 64;          // rows of more units than this are folded by a workgroup of their own
+constexpr size_t nr_lds_bytes() { return (size_t)NR_HOTV * 4 + 64; }
+
+struct nr_layout_t {
+  const u32* row_offsets = nullptr;       // the layout's CSR
+  const int* col_indices = nullptr;
+  const int* old_of_new = nullptr;
+  const int* ub_col = nullptr;            // unit blocks of the rows of >= 64 entries
+  const unsigned char* ub_cnt = nullptr;  // real entries of every unit (1 .. 64; 0 for padding units)
+  const int* ub_first = nullptr;          // n + 1: units of row v = [ub_first[v], ub_first[v + 1])
+  u32 ub_units = 0, ub_units_pad = 0;
+  u32 vs_v[4] = {0, 0, 0, 0};             // degree classes of the short rows (bfs_fused_vshort.hpp)
+  u32 vs_dummy = 0;                       // index into col_indices of four entries of -1
+  u32 big_rows = 0;                       // rows [0, big_rows) hold more than NR_BIG_UNITS units each
+  int n = 0;
+};
+
+// is the frontier 0, 1, ..., n - 1?  *flag was set to 1 by the host before the launch
+__global__ __launch_bounds__(BLOCK) void k_nr_check_iota(const int* __restrict__ frontier, long long n, long long* flag) {
+  bool bad = false;
+  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) bad |= frontier[i] != (int)i;
+  if (__ballot(bad) && lane_id() == 0) *flag = 0;
+}
+
+template <typename V, typename GetValue>
+__global__ __launch_bounds__(BLOCK) void k_nr_values(GetValue get, const int* __restrict__ old_of_new, V* __restrict__ vals,
+                                                     V* __restrict__ reduced, V identity, long long n) {
+  for (long long v = (long long)blockIdx.x * BLOCK + threadIdx.x; v < n; v += (long long)gridDim.x * BLOCK) {
+    vals[v] = get(old_of_new[v]);
+    reduced[v] = identity;
+  }
+}
+
+// value of entry d: -1 (padding, lanes past a row's end) -> identity, a hub -> LDS, anything else -> L2 / HBM.  The global
+// load is unconditional (a load under a condition serialises the pipeline, bfs_fused.hpp "countable loads"): entries
+// served from LDS read vals[0] instead, one broadcast request per wave instruction.
+template <typename V>
+__device__ __forceinline__ V nr_fetch(u32 d, const V* __restrict__ vals, const V* hot, u32 hot_n, V identity) {
+  const bool is_hot = d < hot_n;
+  const bool none = (int)d < 0;
+  const V g = vals[(is_hot || none) ? 0u : d];
+  const V h = hot[is_hot ? d : 0u];
+  return none ? identity : (is_hot ? h : g);
+}
+
+template <typename V, int NT>
+__device__ __forceinline__ V* nr_hot_setup(char* smem, const V* __restrict__ vals, u32 hot_n) {
+  V* const hot = (V*)smem;
+  for (u32 i = threadIdx.x; i < hot_n; i += NT) hot[i] = vals[i];
+  __syncthreads();
+  return hot;
+}
+
+struct __attribute__((aligned(4))) nr_u32x4u { u32 x, y, z, w; };   // 16-byte load at 4-byte alignment
+typedef unsigned int nr_u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename V, typename Op, int NT>
+__global__ __launch_bounds__(NT, 2) void k_nr_long(nr_layout_t L, const V* __restrict__ vals, V* __restrict__ partial, V identity, Op op) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = NT / WAVE;
+  const u32 hot_n = (u32)L.n < (u32)NR_HOTV ? (u32)L.n : (u32)NR_HOTV;
+  const V* const hot = nr_hot_setup<V, NT>(smem, vals, hot_n);
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+  const u32 G = L.ub_units_pad / 16u;                 // groups of 16 units = 1024 entries
+  const u32 W = gridDim.x * NW, w = blockIdx.x * NW + (u32)wave;
+  const int* __restrict__ ucol = L.ub_col;
+  const unsigned char* __restrict__ ucnt = L.ub_cnt;
+  const u32 sub = (u32)lane & 15u, q = (u32)lane >> 4;                  // my four entries inside my unit; my unit inside a 4-unit load
+  if (w >= G) return;
+  // group g: four loads; load j covers units 16 g + 4 j .. + 3, lane (q, sub) reads entries 4 sub .. 4 sub + 3 of unit 4 j + q
+  nr_u32x4 cur[4], nxt[4];
+  u32 ccnt[4], ncnt[4];
+  auto issue = [&](u32 g, nr_u32x4* d, u32* c) {
+    const u32 gg = g < G ? g : G - 1u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32 u = gg * 16u + 4u * (u32)j + q;
+      d[j] = __builtin_nontemporal_load((const nr_u32x4*)(ucol + ((size_t)u << 6) + sub * 4u));
+      c[j] = ucnt[u];
+    }
+  };
+  issue(w, cur, ccnt);
+  for (u32 g = w; g < G; g += W) {
+    issue(g + W, nxt, ncnt);                          // (past the end: the last group again, ignored)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32 have = ccnt[j];                       // real entries of my unit
+      const u32 e0 = sub * 4u;
+      const u32 d0 = e0 + 0u < have ? cur[j].x : 0xFFFFFFFFu, d1 = e0 + 1u < have ? cur[j].y : 0xFFFFFFFFu;
+      const u32 d2 = e0 + 2u < have ? cur[j].z : 0xFFFFFFFFu, d3 = e0 + 3u < have ? cur[j].w : 0xFFFFFFFFu;
+      const V v0 = nr_fetch(d0, vals, hot, hot_n, identity), v1 = nr_fetch(d1, vals, hot, hot_n, identity);
+      const V v2 = nr_fetch(d2, vals, hot, hot_n, identity), v3 = nr_fetch(d3, vals, hot, hot_n, identity);
+      V s = op(op(v0, v1), op(v2, v3));
+#pragma unroll
+      for (int sh = 1; sh < 16; sh <<= 1) s = op(s, __shfl_xor(s, sh, WAVE));     // the 16 lanes of my unit
+      if (sub == 0u) partial[g * 16u + 4u * (u32)j + q] = s;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { cur[j] = nxt[j]; ccnt[j] = ncnt[j]; }
+  }
+}
+
+// rows [first_row, last_row) of the layout hold unit blocks; one thread per row folds the row's partials in order
+template <typename V, typename Op>
+__global__ __launch_bounds__(BLOCK) void k_nr_rows(nr_layout_t L, const V* __restrict__ partial, V* __restrict__ reduced, V identity, Op op,
+                                                   u32 first_row, u32 last_row) {
+  const u32 r = first_row + blockIdx.x * BLOCK + threadIdx.x;
+  if (r >= last_row) return;
+  const int u0 = L.ub_first[r], u1 = L.ub_first[r + 1];
+  if (u1 <= u0) return;
+  V acc = partial[u0];
+  for (int u = u0 + 1; u < u1; ++u) acc = op(acc, partial[u]);
+  reduced[L.old_of_new[r]] = acc;
+}
+// ... and the rows of more than NR_BIG_UNITS units: a workgroup each, a fixed strided fold
+template <typename V, typename Op>
+__global__ __launch_bounds__(BLOCK) void k_nr_big_rows(nr_layout_t L, const V* __restrict__ partial, V* __restrict__ reduced, V identity, Op op) {
+  __shared__ V s_part[BLOCK / WAVE];
+  const u32 r = blockIdx.x;
+  const int u0 = L.ub_first[r], u1 = L.ub_first[r + 1];
+  V acc = identity;
+  for (int u = u0 + (int)threadIdx.x; u < u1; u += BLOCK) acc = op(acc, partial[u]);
+#pragma unroll
+  for (int sh = 1; sh < WAVE; sh <<= 1) acc = op(acc, __shfl_xor(acc, sh, WAVE));
+  if (lane_id() == 0) s_part[threadIdx.x / WAVE] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    V t = s_part[0];
+#pragma unroll
+    for (int k = 1; k < BLOCK / WAVE; ++k) t = op(t, s_part[k]);
+    reduced[L.old_of_new[r]] = t;
+  }
+}
+
+// short rows by degree class: [vs_v[0], vs_v[1]) 16 lanes per vertex (17 .. 63 entries), [vs_v[1], vs_v[2]) 4 lanes (5 .. 16),
+// [vs_v[2], vs_v[3]) 1 lane (1 .. 4).  A lane reads four consecutive entries of its row with one 16-byte load.
+template <typename V, typename Op, int NT>
+__global__ __launch_bounds__(NT, 2) void k_nr_short(nr_layout_t L, const V* __restrict__ vals, V* __restrict__ reduced, V identity, Op op) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = NT / WAVE;
+  const u32 hot_n = (u32)L.n < (u32)NR_HOTV ? (u32)L.n : (u32)NR_HOTV;
+  const V* const hot = nr_hot_setup<V, NT>(smem, vals, hot_n);
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+  const u32 b0 = L.vs_v[0], b1 = L.vs_v[1], b2 = L.vs_v[2], b3 = L.vs_v[3];
+  const u32 s16 = (b1 - b0 + 3u) / 4u, s4 = (b2 - b1 + 15u) / 16u, s1 = (b3 - b2 + 63u) / 64u;
+  const u32 T = s16 + s4 + s1;
+  const u32 W = gridDim.x * NW, w = blockIdx.x * NW + (u32)wave;
+  const u32* __restrict__ ro = L.row_offsets;
+  const int* __restrict__ col = L.col_indices;
+  const int* __restrict__ o2n = L.old_of_new;
+  struct plan_t { u32 e0, cnt, v, lpr_shift; };
+  auto plan = [&](u32 s) -> plan_t {
+    plan_t p; p.e0 = L.vs_dummy; p.cnt = 0; p.v = 0xFFFFFFFFu; p.lpr_shift = 0;
+    u32 vbase, vend;
+    if (s < s16) { p.lpr_shift = 4; vbase = b0 + s * 4u; vend = b1; }
+    else if (s < s16 + s4) { p.lpr_shift = 2; vbase = b1 + (s - s16) * 16u; vend = b2; }
+    else { p.lpr_shift = 0; vbase = b2 + (s - s16 - s4) * 64u; vend = b3; }
+    const u32 v = vbase + ((u32)lane >> p.lpr_shift);
+    const u32 sub = (u32)lane & ((1u << p.lpr_shift) - 1u);
+    const bool in = s < T && v < vend;
+    const u32 vc = in ? v : 0u;
+    const u32 lo = ro[vc], hi = ro[vc + 1];
+    const u32 deg = hi - lo;
+    if (in) p.v = v;
+    if (in && sub * 4u < deg) { p.e0 = lo + sub * 4u; p.cnt = deg - sub * 4u < 4u ? deg - sub * 4u : 4u; }
+    return p;
+  };
+  plan_t pc = plan(w);
+  nr_u32x4u dc = *(const nr_u32x4u*)(col + pc.e0);
+  for (u32 s = w; s < T; s += W) {
+    const plan_t pn = plan(s + W);
+    const nr_u32x4u dn = *(const nr_u32x4u*)(col + pn.e0);
+    const u32 d0 = pc.cnt > 0u ? dc.x : 0xFFFFFFFFu, d1 = pc.cnt > 1u ? dc.y : 0xFFFFFFFFu;
+    const u32 d2 = pc.cnt > 2u ? dc.z : 0xFFFFFFFFu, d3 = pc.cnt > 3u ? dc.w : 0xFFFFFFFFu;
+    const V v0 = nr_fetch(d0, vals, hot, hot_n, identity), v1 = nr_fetch(d1, vals, hot, hot_n, identity);
+    const V v2 = nr_fetch(d2, vals, hot, hot_n, identity), v3 = nr_fetch(d3, vals, hot, hot_n, identity);
+    V acc = op(op(v0, v1), op(v2, v3));
+    // fold over the lanes of my vertex (wave-uniform class: the step decides it)
+    if (pc.lpr_shift == 4) {
+#pragma unroll
+      for (int sh = 1; sh < 16; sh <<= 1) acc = op(acc, __shfl_xor(acc, sh, WAVE));
+    } else if (pc.lpr_shift == 2) {
+#pragma unroll
+      for (int sh = 1; sh < 4; sh <<= 1) acc = op(acc, __shfl_xor(acc, sh, WAVE));
+    }
+    const u32 sub = (u32)lane & ((1u << pc.lpr_shift) - 1u);
+    if (pc.v != 0xFFFFFFFFu && sub == 0u) reduced[o2n[pc.v]] = acc;
+    pc = pn; dc = dn;
+  }
+}
+
+// scratch the fast path needs (vals + partials), in bytes
+inline size_t nr_scratch_bytes(long long n, long long units_pad, size_t value_size) {
+  return (((size_t)n + 64) * value_size + 255) / 256 * 256 + ((size_t)units_pad + 64) * value_size;
+}
+
+// The whole fast path.  get(old_id) -> V; reduced: n entries.  Everything is enqueued on the context's stream.
+template <typename V, typename Op, typename GetValue>
+inline void nr_full_frontier(const nr_layout_t& L, GetValue get, V* reduced, V identity, Op op, standard_context_t& ctx) {
+  hipStream_t s = ctx.stream();
+  V* const vals = (V*)ctx.scratch;
+  V* const partial = (V*)((char*)ctx.scratch + (((size_t)L.n + 64) * sizeof(V) + 255) / 256 * 256);
+  static unsigned char seen[64] = {};
+  if (first_use_on_device(seen)) {
+    MGX_HIP(hipFuncSetAttribute((const void*)(k_nr_long<V, Op, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGX_HIP(hipFuncSetAttribute((const void*)(k_nr_short<V, Op, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  }
+  hipLaunchKernelGGL((k_nr_values<V, GetValue>), dim3(grid_for(L.n, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, get, L.old_of_new, vals,
+                     reduced, identity, (long long)L.n);
+  const u32 long_rows = L.vs_v[0];
+  if (L.ub_units > 0 && long_rows > 0) {
+    hipLaunchKernelGGL((k_nr_long<V, Op, 1024>), dim3(ctx.num_cus * 2), dim3(1024), nr_lds_bytes(), s, L, (const V*)vals, partial, identity, op);
+    if (L.big_rows > 0) hipLaunchKernelGGL((k_nr_big_rows<V, Op>), dim3(L.big_rows), dim3(BLOCK), 0, s, L, (const V*)partial, reduced, identity, op);
+    if (long_rows > L.big_rows)
+      hipLaunchKernelGGL((k_nr_rows<V, Op>), dim3((long_rows - L.big_rows + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, L, (const V*)partial, reduced,
+                         identity, op, L.big_rows, long_rows);
+  }
+  if (L.vs_v[3] > L.vs_v[0])
+    hipLaunchKernelGGL((k_nr_short<V, Op, 1024>), dim3(ctx.num_cus * 2), dim3(1024), nr_lds_bytes(), s, L, (const V*)vals, reduced, identity, op);
+}
+
+}  // namespace mgx

@@ -351,21 +351,21 @@ class BfsProblem:
         reruns); labels() are the last source's.  prepared = prepare_many(sources): buffers made beforehand, for timing loops
         (then only the ctypes call happens here and the raw buffer is returned instead of dicts)."""
         if prepared is None:
-            srcs, st, rr = self.prepare_many(sources)
+            srcs, st, rr, count = self.prepare_many(sources)
         else:
-            srcs, st, rr = prepared
-        rc = lib.mgx_bfs_run_many(self._h, srcs, len(srcs), int(mode), float(alpha), st, BfsProblem.STATS_LEN, C.byref(rr))
+            srcs, st, rr, count = prepared
+        rc = lib.mgx_bfs_run_many(self._h, srcs, count, int(mode), float(alpha), st, BfsProblem.STATS_LEN, C.byref(rr))
         if rc:
             check(rc)
         if prepared is not None:
             return st, rr.value
         L = BfsProblem.STATS_LEN
-        return [self.stats_dict(st[i * L:(i + 1) * L]) for i in range(len(srcs))], rr.value
+        return [self.stats_dict(st[i * L:(i + 1) * L]) for i in range(count)], rr.value
 
     @staticmethod
     def prepare_many(sources):
         n = len(sources)
-        return (C.c_int * max(n, 1))(*[int(s) for s in sources]), (C.c_int64 * (max(n, 1) * BfsProblem.STATS_LEN))(), C.c_int(0)
+        return (C.c_int * max(n, 1))(*[int(s) for s in sources]), (C.c_int64 * (max(n, 1) * BfsProblem.STATS_LEN))(), C.c_int(0), n
 
     @staticmethod
     def stats_dict(st):

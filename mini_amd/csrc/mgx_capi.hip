@@ -120,6 +120,7 @@ struct gather_problem_t : problem_t {
 template <typename V>
 struct gather_functor_t {
   typedef typename gather_problem_t<V>::data_slice_t slice_t;
+  static constexpr bool mgx_pure_gather = true;      // cond / apply are trivially true, the value is a pure read (neighborhood.hxx)
   static __device__ __forceinline__ bool cond_advance(int, int, int, int, int, slice_t*, int) { return true; }
   static __device__ __forceinline__ bool apply_advance(int, int, int, int, int, slice_t*, int) { return true; }
   static __device__ __forceinline__ V get_value_to_reduce(int idx, slice_t* d, int) { return d->values[idx]; }
@@ -336,7 +337,8 @@ int mgx_graph_attach_layout_weights(mgx_graph_t g, const float* d_layout_weights
 extern "C" int mgx_layout_build_device(const int* ro, const int* ci, const float* w, int n, long long m, int* lro, int* lci,
                                        float* lw, int* new_of_old, int* old_of_new, hipStream_t stream);   // mgx_layout.hip
 extern "C" int mgx_units_build_device(const int* ro, const int* ci, int n, int min_deg, int max_deg, int ushift, int** owner,
-                                      int** ucol, long long* units, long long* units_pad, hipStream_t stream);
+                                      int** ucol, unsigned char** ucnt, int** ufirst, long long* units, long long* units_pad,
+                                      hipStream_t stream);
 
 // Unit blocks of the layout's long rows (mgx/bfs_fused_dense.hpp); MGX_BFS_UNITS=0 skips them.  The threshold is the
 // fused traversal's long-row threshold at build time (MGX_BFS_LONG_MIN, default 64; a unit is 64 entries whatever the
@@ -344,18 +346,24 @@ extern "C" int mgx_units_build_device(const int* ro, const int* ci, int n, int m
 static void build_unit_blocks(mgx_graph_s* g) {
   graph_device_t& G = *g->g;
   G.d_ub_col = mem_t<int>(); G.d_ub_owner = mem_t<int>(); G.ub_units = G.ub_units_pad = 0; G.ub_min_degree = 0;
+  G.d_ub_cnt = mem_t<unsigned char>(); G.d_ub_first = mem_t<int>(); G.nr_big_rows = 0;
   if (const char* e = getenv("MGX_BFS_UNITS")) if (atoi(e) == 0) return;
   int long_min = 64;
   if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
   if (long_min <= 0 || !G.has_layout || G.num_edges <= 0) return;
-  int *owner = nullptr, *ucol = nullptr;
+  int *owner = nullptr, *ucol = nullptr, *ufirst = nullptr;
+  unsigned char* ucnt = nullptr;
   long long units = 0, units_pad = 0;
   const int rc = mgx_units_build_device(G.d_layout_row_offsets.data(), G.d_layout_col_indices.data(), G.num_nodes, long_min,
-                                        0x7FFFFFFF, 6, &owner, &ucol, &units, &units_pad, g->c->ctx->stream());
+                                        0x7FFFFFFF, 6, &owner, &ucol, &ucnt, &ufirst, &units, &units_pad, g->c->ctx->stream());
   if (rc != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("unit blocks: ") + hipGetErrorString((hipError_t)rc));
   if (units <= 0) return;
   G.d_ub_owner = mem_t<int>::adopt(owner, (size_t)units_pad);
   G.d_ub_col = mem_t<int>::adopt(ucol, ((size_t)units_pad << 6) + 4);
+  G.d_ub_cnt = mem_t<unsigned char>::adopt(ucnt, (size_t)units_pad + 16);
+  G.d_ub_first = mem_t<int>::adopt(ufirst, (size_t)G.num_nodes + 1);
+  // the neighbour-reduce over the unit blocks (mgx/nreduce.hpp) keeps its values and per-unit partials in the context's arena
+  g->c->ctx->reserve_scratch(mgx::nr_scratch_bytes(G.num_nodes, units_pad, 8));
   G.ub_units = units; G.ub_units_pad = units_pad; G.ub_min_degree = long_min;
 }
 extern "C" int mgx_cold_build_device(const int* ro, const int* ci, int n, int row0, int rows, int min_deg, unsigned hot_n, unsigned slice_n,
@@ -483,6 +491,7 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
       const unsigned b0 = first_below(long_min), b1 = std::max(b0, first_below(17)), b2 = std::max(b1, first_below(5)),
                      b3 = std::max(b2, first_below(1));
       G.vs_v[0] = b0; G.vs_v[1] = b1; G.vs_v[2] = b2; G.vs_v[3] = b3;
+      G.nr_big_rows = first_below(64 * mgx::NR_BIG_UNITS + 1);       // rows of more than NR_BIG_UNITS units (mgx/nreduce.hpp)
       G.vs_edges = (unsigned)(h[b3] - h[b0]);
       G.vs_dummy = (unsigned)m + 4u;
       G.vs_long_min = long_min;

@@ -131,7 +131,7 @@ __global__ void k_unit_counts(const int* __restrict__ ro, int n, int min_deg, in
 
 // one wave per row of the class: owners and padded entries
 __global__ void k_unit_fill(const int* __restrict__ ro, const int* __restrict__ ci, int n, const int* __restrict__ uoff,
-                            int ushift, int* __restrict__ owner, int* __restrict__ ucol) {
+                            int ushift, int* __restrict__ owner, int* __restrict__ ucol, unsigned char* __restrict__ ucnt) {
   const int lane = threadIdx.x & 63;
   const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
@@ -140,7 +140,12 @@ __global__ void k_unit_fill(const int* __restrict__ ro, const int* __restrict__ 
     if (u1 == u0) continue;
     const int r0 = ro[v], deg = ro[v + 1] - r0;
     const int first = ci[r0];
-    for (int u = u0 + lane; u < u1; u += 64) owner[u] = (int)v;
+    for (int u = u0 + lane; u < u1; u += 64) {
+      owner[u] = (int)v;
+      // real entries of the unit (the rest repeats the row's first neighbour): what a REDUCTION over the unit may count (mgx/nreduce.hpp)
+      const long long left = (long long)deg - ((long long)(u - u0) << ushift);
+      ucnt[u] = (unsigned char)(left < (1 << ushift) ? left : (1 << ushift));
+    }
     const long long e0 = (long long)u0 << ushift, e1 = (long long)u1 << ushift;
     for (long long e = e0 + lane; e < e1; e += 64) {
       const long long k = e - e0;
@@ -149,20 +154,23 @@ __global__ void k_unit_fill(const int* __restrict__ ro, const int* __restrict__ 
   }
 }
 
-__global__ void k_unit_tail(int n, int units, int units_pad, int ushift, int* __restrict__ owner, int* __restrict__ ucol) {
+__global__ void k_unit_tail(int n, int units, int units_pad, int ushift, int* __restrict__ owner, int* __restrict__ ucol,
+                            unsigned char* __restrict__ ucnt) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long tail_entries = ((long long)(units_pad - units) << ushift) + 4;
-  if (i < units_pad - units) owner[units + i] = n;
+  if (i < units_pad - units) { owner[units + i] = n; ucnt[units + i] = 0; }
   if (i < tail_entries) ucol[((long long)units << ushift) + i] = -1;
 }
 
 }  // namespace
 
 // Allocates *owner (units_pad ints) and *ucol ((units_pad << ushift) + 4 ints) with hipMalloc; the caller owns them.
-// *units = real units, *units_pad = padded to a multiple of 16.  Returns 0 or the hipError_t that stopped it.
+// *units = real units, *units_pad = padded to a multiple of 16.  *ucnt (units_pad bytes): real entries of every unit (ushift
+// <= 7); *ufirst (n + 1 ints): the units of row v are [ufirst[v], ufirst[v + 1]).  Returns 0 or the hipError_t that stopped it.
 extern "C" int mgx_units_build_device(const int* ro, const int* ci, int n, int min_deg, int max_deg, int ushift, int** owner,
-                                      int** ucol, long long* units, long long* units_pad, hipStream_t stream) {
-  *owner = nullptr; *ucol = nullptr; *units = 0; *units_pad = 0;
+                                      int** ucol, unsigned char** ucnt, int** ufirst, long long* units, long long* units_pad,
+                                      hipStream_t stream) {
+  *owner = nullptr; *ucol = nullptr; *ucnt = nullptr; *ufirst = nullptr; *units = 0; *units_pad = 0;
   if (n <= 0) return 0;
   const int threads = 256;
   const unsigned nblocks = (unsigned)(((long long)n + threads - 1) / threads);
@@ -186,11 +194,23 @@ extern "C" int mgx_units_build_device(const int* ro, const int* ci, int n, int m
   LAY_TRY(hipMalloc((void**)owner, (size_t)Up * 4));
   hipError_t e = hipMalloc((void**)ucol, (((size_t)Up << ushift) + 4) * 4);
   if (e != hipSuccess) { (void)hipFree(*owner); *owner = nullptr; return (int)e; }
-  hipLaunchKernelGGL(k_unit_fill, dim3(4096), dim3(256), 0, stream, ro, ci, n, uoff.as<int>(), ushift, *owner, *ucol);
+  e = hipMalloc((void**)ucnt, (size_t)Up + 16);
+  if (e == hipSuccess) e = hipMalloc((void**)ufirst, ((size_t)n + 1) * 4);
+  if (e != hipSuccess) {
+    (void)hipFree(*owner); (void)hipFree(*ucol); if (*ucnt) (void)hipFree(*ucnt);
+    *owner = nullptr; *ucol = nullptr; *ucnt = nullptr; *ufirst = nullptr;
+    return (int)e;
+  }
+  hipLaunchKernelGGL(k_unit_fill, dim3(4096), dim3(256), 0, stream, ro, ci, n, uoff.as<int>(), ushift, *owner, *ucol, *ucnt);
   const long long tail = ((Up - U) << ushift) + 4;
-  hipLaunchKernelGGL(k_unit_tail, dim3((unsigned)((tail + 255) / 256)), dim3(256), 0, stream, n, (int)U, (int)Up, ushift, *owner, *ucol);
+  hipLaunchKernelGGL(k_unit_tail, dim3((unsigned)((tail + 255) / 256)), dim3(256), 0, stream, n, (int)U, (int)Up, ushift, *owner, *ucol, *ucnt);
+  (void)hipMemcpyAsync(*ufirst, uoff.as<int>(), ((size_t)n + 1) * 4, hipMemcpyDeviceToDevice, stream);
   e = hipStreamSynchronize(stream);                       // (tot lives on this frame)
-  if (e != hipSuccess) { (void)hipFree(*owner); (void)hipFree(*ucol); *owner = nullptr; *ucol = nullptr; return (int)e; }
+  if (e != hipSuccess) {
+    (void)hipFree(*owner); (void)hipFree(*ucol); (void)hipFree(*ucnt); (void)hipFree(*ufirst);
+    *owner = nullptr; *ucol = nullptr; *ucnt = nullptr; *ufirst = nullptr;
+    return (int)e;
+  }
   *units = U; *units_pad = Up;
   return 0;
 }

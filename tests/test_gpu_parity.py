@@ -139,6 +139,46 @@ def test_neighbour_reduce_matches_oracle(gpu_ctx, oracle, torch_mod, rmat_graphs
     assert np.array_equal(red.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("op", ["f32_plus", "i32_min", "i32_max"])
+@pytest.mark.parametrize("scale,ef", [(9, 4), (13, 16), (16, 16)])
+def test_neighbour_reduce_full_frontier_on_the_layout(gpu_ctx, oracle, torch_mod, op, scale, ef):
+    """the full-frontier path of the neighbour-reduce (mgx/nreduce.hpp: unit blocks for the long rows, degree classes for the
+    short ones, hub values in LDS) -- taken when the frontier is 0 .. n - 1 and the graph carries the library's hub-first
+    layout -- against the oracle's serial restatement: exact for int min / max and for float sums of small integers, 2e-5
+    relative for real-valued floats (the fold order differs); a permuted frontier of the same size takes the general
+    kernel and is compared the same way; R-MAT 16 has rows of more than 4096 entries (a workgroup per row)"""
+    import mini_amd
+    torch = torch_mod
+    n, ro, ci, w = oracle.rmat_csr(scale, ef, 60 + scale)
+    g = _graph(gpu_ctx, ro, ci).build_layout()
+    rng = np.random.default_rng(scale)
+    for frontier_kind in ("iota", "permuted"):
+        ids = np.arange(n, dtype=np.int32) if frontier_kind == "iota" else rng.permutation(n).astype(np.int32)
+        f = mini_amd.Frontier(gpu_ctx, n).load(ids)
+        if op == "f32_plus":
+            for real in (False, True):
+                vals = (rng.random(n) * 3.0).astype(np.float32) if real else rng.integers(0, 8, size=n).astype(np.float32)
+                dv = torch.from_numpy(vals).cuda()
+                red = torch.full((n,), -1, dtype=torch.float32, device="cuda")
+                nz = mini_amd.segreduce(g, f, dv, 0.0, red, op)
+                want, wnz = oracle.neighbor_reduce_f32_plus(ro, ci, ids, vals, 0.0)
+                assert nz == wnz == len(ci)
+                got = red.cpu().numpy()
+                if real:
+                    assert np.allclose(got, want, rtol=2e-5, atol=1e-6), (frontier_kind, np.abs(got - want).max())
+                else:
+                    assert np.array_equal(got, want), frontier_kind
+        else:
+            vals = rng.integers(-1000, 1000, size=n).astype(np.int32)
+            dv = torch.from_numpy(vals).cuda()
+            ident = 2**31 - 1 if op == "i32_min" else -2**31
+            red = torch.full((n,), 12345, dtype=torch.int32, device="cuda")
+            nz = mini_amd.segreduce(g, f, dv, ident, red, op)
+            want, wnz = oracle.neighbor_reduce_i32(ro, ci, ids, vals, ident, op == "i32_max")
+            assert nz == wnz
+            assert np.array_equal(red.cpu().numpy(), want), frontier_kind
+
+
 # ---- golden fixtures through the C-ABI -------------------------------------------------------
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_reference_fixtures_bfs_and_sssp(gpu_ctx, oracle, case, tmp_path):
@@ -892,13 +932,20 @@ def test_bfs_run_many_reruns_a_traversal_that_needs_more_slots(gpu_ctx, oracle, 
     ro, ci, _ = oracle.csr_from_tuples(n, np.array(t0, dtype=np.int32), np.array(t1, dtype=np.int32), None, undir=True)
     g = _graph(gpu_ctx, ro, ci)
     bfs = mini_amd.BfsProblem(g, hub)
-    for _ in range(4):
-        bfs.run(5)                                      # a leaf far from the path: few levels ... wait, the path is reachable from everywhere
     far = n - 1                                         # the end of the path: the deepest traversal of the graph
+    ref_far = bfs.run(far)
+    # make the handle forget it: four shallow traversals of ANOTHER graph shape are not available here, so size the hint by
+    # hand through a fresh handle that has only seen the hub
+    bfs = mini_amd.BfsProblem(g, hub)
+    ref_hub = None
+    for _ in range(4):
+        ref_hub = bfs.run(hub)
+    assert ref_far["levels"] > ref_hub["levels"] + 8
     sts, reruns = bfs.run_many([hub, far, hub], mini_amd.MGX_BFS_PUSH, 0.0)
+    assert reruns >= 1
     assert np.array_equal(bfs.labels(), oracle.bfs_cpu(ro, ci, hub))
-    for s, st in zip([hub, far, hub], sts):
-        want = oracle.bfs_cpu(ro, ci, s)
-        assert st["reached"] == int((want >= 0).sum()) and st["levels"] == int(want.max()) + 1, (s, st, reruns)
+    for st, ref in zip(sts, [ref_hub, ref_far, ref_hub]):
+        assert (st["m_t"], st["reached"], st["levels"]) == (ref["m_t"], ref["reached"], ref["levels"]), (st, ref, reruns)
     sts, reruns2 = bfs.run_many([far, far], mini_amd.MGX_BFS_PUSH, 0.0)
     assert np.array_equal(bfs.labels(), oracle.bfs_cpu(ro, ci, far))
+    assert (sts[1]["m_t"], sts[1]["levels"]) == (ref_far["m_t"], ref_far["levels"])
