@@ -39,17 +39,35 @@ int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fronti
   const long long frontier_size = (long long)input->size();
 
   // Full frontier (0, 1, ..., n - 1: PR's first iteration) on a graph that carries the hub-first layout with unit blocks and
-  // degree classes: mgx/nreduce.hpp.  Whether the frontier IS the iota is checked on the device; the answer rides on the
-  // host wait of the degree scan below.
-  bool try_full = false;
+  // degree classes: mgx/nreduce.hpp.  Whether the frontier IS the iota is checked on the device (one pass over it, one
+  // host wait); it then holds every edge of the graph: no degree scan, no search.
+  typename Problem::data_slice_t* const data = problem->d_data_slice.data();
   if (!has_output && is_pure_gather<Functor>::value && frontier_size == (long long)graph.num_nodes && frontier_size > 0 &&
       graph.has_layout && (push || graph.csc_is_csr) && graph.ub_units > 0 && graph.ub_min_degree == 64 && graph.vs_long_min == 64 &&
       graph.d_ub_cnt.size() && graph.d_ub_first.size() && graph.vs_dummy != 0 &&
       context.scratch_bytes >= mgx::nr_scratch_bytes(graph.num_nodes, graph.ub_units_pad, sizeof(Value))) {
-    try_full = true;
     context.mailbox[8] = 1;
     hipLaunchKernelGGL(mgx::k_nr_check_iota, dim3(mgx::grid_for(frontier_size, mgx::BLOCK, context.num_cus * 4)), dim3(mgx::BLOCK), 0,
                        context.stream(), frontier, frontier_size, context.mailbox + 8);
+    context.synchronize();
+    if (context.mailbox[8] == 1) {
+      if (graph.num_edges == 0) return 0;
+      mgx::nr_layout_t L;
+      L.row_offsets = (const mgx::u32*)graph.d_layout_row_offsets.data();
+      L.col_indices = graph.d_layout_col_indices.data();
+      L.old_of_new = graph.d_old_of_new.data();
+      L.ub_col = graph.d_ub_col.data();
+      L.ub_cnt = graph.d_ub_cnt.data();
+      L.ub_first = graph.d_ub_first.data();
+      L.ub_units = (mgx::u32)graph.ub_units; L.ub_units_pad = (mgx::u32)graph.ub_units_pad;
+      for (int i = 0; i < 4; ++i) L.vs_v[i] = graph.vs_v[i];
+      L.vs_dummy = graph.vs_dummy;
+      L.big_rows = graph.nr_big_rows;
+      L.n = graph.num_nodes;
+      mgx::nr_full_frontier<Value>(L, [=] __device__(int v) -> Value { return Functor::get_value_to_reduce(v, data, iteration); }, reduced,
+                                   identity, reduce_op(), context);
+      return (int)graph.num_edges;
+    }
   }
 
   // segment i = the neighbour list of frontier[i]: exclusive scan of the degrees into the graph's scratch scan
@@ -59,25 +77,6 @@ int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fronti
   mgx::transform_scan([=] __device__(long long i) { return offsets[frontier[i] + 1] - offsets[frontier[i]]; },
                       frontier_size, segment_start, context, &edges);
   if (edges == 0) return 0;
-  typename Problem::data_slice_t* const data = problem->d_data_slice.data();
-  if (try_full && context.mailbox[8] == 1) {
-    mgx::nr_layout_t L;
-    L.row_offsets = (const mgx::u32*)graph.d_layout_row_offsets.data();
-    L.col_indices = graph.d_layout_col_indices.data();
-    L.old_of_new = graph.d_old_of_new.data();
-    L.ub_col = graph.d_ub_col.data();
-    L.ub_cnt = graph.d_ub_cnt.data();
-    L.ub_first = graph.d_ub_first.data();
-    L.ub_units = (mgx::u32)graph.ub_units; L.ub_units_pad = (mgx::u32)graph.ub_units_pad;
-    for (int i = 0; i < 4; ++i) L.vs_v[i] = graph.vs_v[i];
-    L.vs_dummy = graph.vs_dummy;
-    L.big_rows = graph.nr_big_rows;
-    L.n = graph.num_nodes;
-    mgx::nr_full_frontier<Value>(L, [=] __device__(int v) -> Value { return Functor::get_value_to_reduce(v, data, iteration); }, reduced,
-                                 identity, reduce_op(), context);
-    return (int)edges;
-  }
-
   int* out = nullptr;
   if (has_output) {
     output->resize((size_t)edges);

@@ -328,6 +328,16 @@ MGX_API int mgx_dbfs2_or_maps(mgx_dbfs2_t h, const unsigned* d_maps, int maps, i
  * on ANY rank -- the same on every rank, no reduction needed) [1] levels that hold vertices [2] edges this rank has
  * expanded [3] vertices discovered by all ranks in the level merged last [4] size and [5] edges of this rank's next
  * queues */
+/* Sparse levels (lists on sparse levels, bitmaps on dense ones).  With a list set (mgx_dbfs2_set_list: a device
+ * buffer of mgx_dbfs2_list_words(n, ranks) words -- 4 header words, [0] = count, then ids), mgx_dbfs2_push also writes the
+ * rank's discoveries of the level there as vertex ids; a count above the capacity means "did not fit".  The caller all-gathers
+ * the lists and hands them to mgx_dbfs2_apply_lists, which answers out3 = { 1: some list overflowed, NOTHING was applied,
+ * exchange the bitmaps and call mgx_dbfs2_merge* as before | 0: the level is merged (every listed vertex decided once on
+ * every rank, the owner's labels and next queues written); sum of the counts (0: no rank discovered anything -- the
+ * traversal is over); 0 }.  It waits for that verdict only (a spin on pinned memory), not for the stream.             */
+MGX_API int mgx_dbfs2_list_words(int n_global, int ranks, int64_t* words);
+MGX_API int mgx_dbfs2_set_list(mgx_dbfs2_t h, unsigned* d_list, int64_t words);
+MGX_API int mgx_dbfs2_apply_lists(mgx_dbfs2_t h, int level, const unsigned* d_lists, int lists, int64_t stride_words, int64_t* out3);
 MGX_API int mgx_dbfs2_status(mgx_dbfs2_t h, int next_level, int64_t* out6);
 MGX_API int mgx_dbfs2_labels(mgx_dbfs2_t h, int* host_labels_local);
 

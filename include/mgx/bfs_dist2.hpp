@@ -14,6 +14,14 @@
 //   * merge: OR of the G bitmaps = the level's global discoveries; every rank ORs them into its bitmap (so
 //     all ranks agree before the next level) and k_bfs_build turns the bits it OWNS into labels and into its
 //     next local queues (row start, scanned degree; packed-cursor append as everywhere else).
+//   * SPARSE levels do not ship bitmaps ("switch representation per level by density").  The sweep that turns
+//     marks into new bits also compacts the new vertices into a short ID LIST (a header word with the count + up to
+//     list_cap ids, list_cap = n / (256 ranks)); the lists are all-gathered first -- n / 64 bytes per rank instead of n / 8 --
+//     and if every rank's discoveries fitted (the headers tell every rank the same), k_d2_lists_apply applies them:
+//     atomicOr on the bitmap decides a vertex once, its owner labels it and appends it to its next queue (block scan,
+//     one packed cursor atomic per workgroup).  Only when some rank overflowed does the level go through the bitmap
+//     exchange below.  The host learns the decision (and whether the level found anything at all: the sum of the counts)
+//     from three words in pinned memory it spins on -- the one host round trip of a level.
 // Labels are the global BFS depths, identical to the single-GPU result.
 #pragma once
 #include <cstddef>
@@ -24,22 +32,43 @@
 
 namespace mgx {
 
-// out[w] = the rank's discoveries of the level: vertices it marked that are not in the bitmap
+// out[w] = the rank's discoveries of the level: vertices it marked that are not in the bitmap.  list (optional): the same
+// vertices as ids -- list[0] counts ALL of them (the caller zeroed it), list[D2_LIST_HEAD + i] holds the first list_cap.
+constexpr int D2_LIST_HEAD = 4;          // header words of an id list: [0] count (may exceed the capacity: overflow), [1..3] unused
 __global__ __launch_bounds__(BLOCK) void k_d2_newbits(const u32* __restrict__ visited, const unsigned char* __restrict__ mark,
-                                                      u32* __restrict__ out, long long nwords, long long n, bfs_ctrl_t* c) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) c->merged_new = 0;     // k_d2_or of this level counts into it
-  for (long long w = (long long)blockIdx.x * BLOCK + threadIdx.x; w < nwords; w += (long long)gridDim.x * BLOCK) {
+                                                      u32* __restrict__ out, long long nwords, long long n, bfs_ctrl_t* c,
+                                                      u32* __restrict__ list, u32 list_cap) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) c->merged_new = 0;     // the merge of this level counts into it
+  const long long stride = (long long)gridDim.x * BLOCK;
+  for (long long w0 = (long long)blockIdx.x * BLOCK; w0 < nwords; w0 += stride) {      // (block-uniform trip count: the wave scan below)
+    const long long w = w0 + threadIdx.x;
     u32 bits = 0;
-    if (w * 32 + 32 <= n) {
-      const uint4* m = (const uint4*)(mark + w * 32);              // 32 marks (0/1 bytes) -> 32 bits
-      const uint4 lo = m[0], hi = m[1];
-      const u32 x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    if (w < nwords) {
+      if (w * 32 + 32 <= n) {
+        const uint4* m = (const uint4*)(mark + w * 32);              // 32 marks (0/1 bytes) -> 32 bits
+        const uint4 lo = m[0], hi = m[1];
+        const u32 x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-      for (int i = 0; i < 8; ++i) bits |= (((x[i] & 0x01010101u) * 0x10204080u) >> 28) << (4 * i);
-    } else {
-      for (int i = 0; i < 32 && w * 32 + i < n; ++i) bits |= (mark[w * 32 + i] ? 1u : 0u) << i;
+        for (int i = 0; i < 8; ++i) bits |= (((x[i] & 0x01010101u) * 0x10204080u) >> 28) << (4 * i);
+      } else {
+        for (int i = 0; i < 32 && w * 32 + i < n; ++i) bits |= (mark[w * 32 + i] ? 1u : 0u) << i;
+      }
+      bits &= ~visited[w];
+      out[w] = bits;
     }
-    out[w] = bits & ~visited[w];
+    if (list) {
+      const u32 cnt = (u32)__popc(bits);
+      const u32 inc = wave_inclusive_sum(cnt);
+      const u32 tot = (u32)__shfl((int)inc, WAVE - 1, WAVE);
+      if (tot) {                                                     // (wave-uniform)
+        u32 base = 0;
+        if (lane_id() == 0) base = atomicAdd(&list[0], tot);
+        base = (u32)__shfl((int)base, 0, WAVE);
+        u32 at = base + inc - cnt;
+        for (u32 rest = bits; rest; rest &= rest - 1u, ++at)
+          if (at < list_cap) list[D2_LIST_HEAD + at] = (u32)(w * 32) + (u32)(__ffs((int)rest) - 1);
+      }
+    }
   }
 }
 
@@ -83,6 +112,108 @@ __global__ __launch_bounds__(BLOCK) void k_d2_or_maps(const uint4* __restrict__ 
   }
 }
 
+// The sparse merge.  glists: `nlists` id lists, `stride` words apart (what the all-gather delivered).  If any list
+// overflowed its capacity nothing is applied (the level takes the bitmap exchange); otherwise every listed vertex is
+// decided once by atomicOr on the bitmap -- the same id may come from several ranks -- and, if this rank owns it
+// (v % ranks == rank), labelled and appended to the next level's queues: one block scan per queue and ONE packed cursor
+// atomic per workgroup and round, as in k_bfs_build.  host_flag (pinned): [1] overflow, [2] sum of the counts (0: the level
+// found nothing anywhere -- the traversal is over), then [0] = seq, which the host spins on.  *mylist_count <- 0 for the
+// next level's sweep.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_d2_lists_apply(bfs_fused_args_t a, int level, const u32* __restrict__ glists, int nlists, u32 stride,
+                                                       u32 cap, int* __restrict__ labels, int ranks, int rank, u32* mylist_count,
+                                                       u64* host_flag, u64 seq) {
+  constexpr int NW = NT / WAVE;
+  constexpr u64 CNT1 = 1ull << 40;
+  constexpr u64 DEGMASK = CNT1 - 1ull;
+  __shared__ u32 s_pre[66];
+  __shared__ int s_over;
+  __shared__ u64 s_scan[NW + 1];
+  __shared__ u64 s_base[2];
+  __shared__ u32 s_long_true;
+  bfs_ctrl_t* const c = a.ctrl;
+  if (threadIdx.x == 0) {
+    u32 run = 0;
+    int over = 0;
+    for (int r = 0; r < nlists; ++r) {
+      const u32 cnt = glists[(size_t)r * stride];
+      s_pre[r] = run;
+      if (cnt > cap) over = 1;
+      run += cnt > cap ? cap : cnt;
+    }
+    s_pre[nlists] = run;
+    s_over = over;
+  }
+  __syncthreads();
+  const u32 T = s_pre[nlists];
+  const bool over = s_over != 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (mylist_count) *mylist_count = 0;
+    if (host_flag) {
+      host_flag[1] = over ? 1ull : 0ull;
+      host_flag[2] = (u64)T;
+      __threadfence_system();
+      __hip_atomic_store(&host_flag[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if (over || T == 0u) return;
+  const u32 long_min = a.long_min > 0 ? (u32)a.long_min : 0xFFFFFFFFu;
+  u64* const cur_s = &c->cursor[(level + 1) % 3];
+  u64* const cur_l = &c->lcursor[(level + 1) % 3];
+  u32* __restrict__ const out_row_s = a.fr_row[(level + 1) & 1];
+  u32* __restrict__ const out_off_s = a.fr_off[(level + 1) & 1];
+  u32* __restrict__ const out_row_l = a.lq_row[(level + 1) & 1];
+  u32* __restrict__ const out_off_l = a.lq_off[(level + 1) & 1];
+  for (u32 base = blockIdx.x * NT; base < T; base += gridDim.x * NT) {        // (block-uniform)
+    const u32 idx = base + threadIdx.x;
+    bool fresh = false, mine = false;
+    u32 ro = 0, deg = 0;
+    if (idx < T) {
+      int r = 0;
+      while (r + 1 < nlists && s_pre[r + 1] <= idx) ++r;
+      const u32 v = glists[(size_t)r * stride + D2_LIST_HEAD + (idx - s_pre[r])];
+      const u32 bit = 1u << (v & 31u);
+      fresh = !(atomicOr(a.visited + (v >> 5), bit) & bit);
+      mine = fresh && (int)(v % (u32)ranks) == rank;
+      if (mine) {
+        const u32 local = v / (u32)ranks;
+        labels[local] = level + 1;
+        const bfs_u32x2 ext = *(const bfs_u32x2*)(a.row_offsets + local);
+        ro = ext.x; deg = ext.y - ext.x;
+      }
+    }
+    const u32 nfresh = wave_sum(fresh ? 1u : 0u), nmine = wave_sum(mine ? 1u : 0u);
+    if (lane_id() == 0) {
+      if (nfresh) atomicAdd(&c->merged_new, (u64)nfresh);
+      if (nmine) atomicAdd(&c->reached, (u64)nmine);
+    }
+    const bool is_long = mine && deg >= long_min;
+    const u64 add_s = (mine && !is_long && deg) ? (CNT1 | (u64)deg) : 0ull;
+    const u64 add_l = is_long ? (CNT1 | (u64)bfs_lq_pad(deg)) : 0ull;
+    if (threadIdx.x == 0) s_long_true = 0;
+    u64 tot_s, tot_l;
+    const u64 ex_s = block_exclusive_sum_lean<NW>(add_s, s_scan, &tot_s);    // (also orders s_long_true = 0 before the adds)
+    const u64 ex_l = block_exclusive_sum_lean<NW>(add_l, s_scan, &tot_l);
+    const u32 lt = wave_sum(is_long ? deg : 0u);
+    if (lane_id() == 0 && lt) atomicAdd(&s_long_true, lt);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      s_base[0] = (tot_s >> 40) ? atomicAdd(cur_s, ((tot_s >> 40) << BFS_VSHIFT) | (tot_s & DEGMASK)) : 0ull;
+      s_base[1] = (tot_l >> 40) ? atomicAdd(cur_l, ((tot_l >> 40) << BFS_VSHIFT) | (tot_l & DEGMASK)) : 0ull;
+      if (tot_l >> 40) atomicAdd(&c->ledges[(level + 1) % 3], (u64)s_long_true);
+    }
+    __syncthreads();
+    if (mine && deg) {
+      const u64 b = is_long ? s_base[1] : s_base[0];
+      const u64 at = is_long ? ex_l : ex_s;
+      const u64 slot = (b >> BFS_VSHIFT) + (at >> 40);
+      (is_long ? out_row_l : out_row_s)[slot] = ro;
+      (is_long ? out_off_l : out_off_s)[slot] = (u32)((b & BFS_EMASK) + (at & DEGMASK)) | (is_long ? (deg & 63u) : 0u);
+    }
+    __syncthreads();           // s_base / s_long_true are reused by the next round
+  }
+}
+
 __global__ void k_d2_init(bfs_fused_args_t a, int* labels_local, int src, int ranks, int rank) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   bfs_ctrl_reset(a.ctrl);
@@ -104,6 +235,12 @@ struct d2_state_t {
   long long nwords = 0;
   long long last_edges = 0;           // edges of the frontier the last push expanded
   int cold_forced = -1;               // MGX_BFS_COLD_TEST at creation (-1: by size)
+  // id lists of the sparse levels: the rank's own (caller-owned or ours), its capacity in ids; 0: bitmaps on every level
+  u32* mylist = nullptr;
+  u32 list_cap = 0;
+  mem_t<u32> own_list;
+  u64* host_flag = nullptr;           // pinned: what k_d2_lists_apply tells the host
+  u64 flag_seq = 0;
 
   void init(standard_context_t& ctx, int n_global_, int ranks_, int rank_, const int* ro, const int* ci, u32* newbits_) {
     n_global = n_global_; ranks = ranks_; rank = rank_;
@@ -114,7 +251,22 @@ struct d2_state_t {
     if (const char* e = getenv("MGX_BFS_COLD_TEST")) cold_forced = atoi(e);
     labels = mem_t<int>((size_t)n_local + 1, ctx);
     merged = mem_t<u32>((size_t)nwords + 4, ctx);
+    MGX_HIP(hipHostMalloc((void**)&host_flag, 64, hipHostMallocDefault));
+    host_flag[0] = host_flag[1] = host_flag[2] = 0;
   }
+  ~d2_state_t() { if (host_flag) (void)hipHostFree(host_flag); }
+  d2_state_t() {}
+  d2_state_t(const d2_state_t&) = delete;
+  d2_state_t& operator=(const d2_state_t&) = delete;
+  // capacity (ids) of a rank's list: n / (256 ranks), at least 252, so that head + ids is a multiple of 4 words
+  static u32 default_list_cap(int n_global, int ranks) {
+    long long c = (long long)n_global / (256ll * ranks);
+    if (c < 252) c = 252;
+    c = (c + D2_LIST_HEAD + 3) / 4 * 4 - D2_LIST_HEAD;
+    return (u32)c;
+  }
+  void set_list(u32* d_list, u32 cap) { mylist = d_list; list_cap = d_list ? cap : 0u; }
+  long long list_words() const { return (long long)D2_LIST_HEAD + list_cap; }
   bfs_fused_args_t args() const {
     bfs_fused_args_t a{};
     a.row_offsets = (const u32*)row_offsets;
@@ -152,6 +304,7 @@ inline void d2_reset(d2_state_t& st, int src, standard_context_t& ctx) {
   MGX_HIP(hipMemsetAsync(st.labels.data(), 0xFF, (size_t)st.n_local * sizeof(int), s));
   MGX_HIP(hipMemsetAsync(st.fs->visited.data(), 0, st.fs->visited.size() * sizeof(u32), s));
   MGX_HIP(hipMemsetAsync(st.fs->mark.data(), 0, st.fs->mark.size(), s));
+  if (st.mylist) MGX_HIP(hipMemsetAsync(st.mylist, 0, D2_LIST_HEAD * sizeof(u32), s));
   hipLaunchKernelGGL(k_d2_init, dim3(1), dim3(64), 0, s, st.args(), st.labels.data(), src, st.ranks, st.rank);
 }
 
@@ -162,7 +315,30 @@ inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx) {
   bfs_set_kernel_attributes();
   bfs_launch_push(a, level, ctx, 2, bfs_cold_test(a.n, st.cold_forced));   // (the level's bookkeeping rides on the push launch)
   hipLaunchKernelGGL(k_d2_newbits, dim3(grid_for(st.nwords, BLOCK, 256)), dim3(BLOCK), 0, s, st.fs->visited.data(),
-                     st.fs->mark.data(), st.newbits, st.nwords, (long long)st.n_global, a.ctrl);
+                     st.fs->mark.data(), st.newbits, st.nwords, (long long)st.n_global, a.ctrl, st.mylist, st.list_cap);
+}
+
+// The sparse merge of a level (k_d2_lists_apply) on `nlists` gathered lists, `stride_words` apart, and the host's wait for
+// its verdict: out3 = { 1 if some list overflowed (nothing was applied: exchange the bitmaps), sum of the counts (0: the
+// level found nothing on any rank), 0 }.  Synchronises with the kernel's first workgroup only (a spin on pinned memory).
+inline void d2_apply_lists(d2_state_t& st, int level, const u32* glists, int nlists, long long stride_words, standard_context_t& ctx,
+                           long long* out3) {
+  hipStream_t s = ctx.stream();
+  bfs_fused_args_t a = st.args();
+  const u64 seq = ++st.flag_seq;
+  hipLaunchKernelGGL(k_d2_lists_apply<BLOCK>, dim3(256), dim3(BLOCK), 0, s, a, level, glists, nlists, (u32)stride_words, st.list_cap,
+                     st.labels.data(), st.ranks, st.rank, st.mylist, st.host_flag, seq);
+  MGX_CHECK_LAUNCH("partitioned BFS: list merge launch");
+  volatile u64* const flag = st.host_flag;
+  long long spins = 0;
+  while (flag[0] != seq) {
+    if (++spins > 20000000LL) { MGX_HIP(hipStreamSynchronize(s)); break; }
+    __builtin_ia32_pause();
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  out3[0] = (long long)flag[1];
+  out3[1] = (long long)flag[2];
+  out3[2] = 0;
 }
 
 // gathered: `maps` new-bit maps, `stride_words` apart (a multiple of 4): every rank's map after an all-gather, or
@@ -206,9 +382,38 @@ inline void d2_status(d2_state_t& st, int next_level, standard_context_t& ctx, l
 struct d2_run_bufs_t {
   mem_t<u32> gathered;     // ranks * xwords (gather) / xwords (reduce: the merged map)
   mem_t<u32> recv;         // reduce: the ranks' versions of this rank's slice
+  mem_t<u32> glists;       // ranks id lists (sparse levels)
   long long xwords = 0;
   int levels_hint = 8;
 };
+
+// the bitmap exchange of one level + the dense merge (what every level did before the id lists)
+inline void d2_exchange_bitmaps(d2_state_t& st, comm_t& cm, d2_run_bufs_t& bufs, int level, int exchange, long long xwords,
+                                standard_context_t& ctx) {
+  const rccl_api_t& api = rccl_api_t::get();
+  hipStream_t s = ctx.stream();
+  const int R = st.ranks;
+  const long long S = xwords / R;                 // words per slice (xwords is a multiple of 4 * R)
+  if (R == 1 && !cm.comm) {
+    d2_merge(st, level, st.newbits, 1, xwords, ctx);
+  } else if (exchange == 0) {
+    MGX_RCCL(api.AllGather(st.newbits, bufs.gathered.data(), (size_t)xwords, ncclUint32, cm.comm, s));
+    d2_merge(st, level, bufs.gathered.data(), R, xwords, ctx);
+  } else {
+    {
+      rccl_group_t group(api);                  // (GroupEnd on every way out: a throw inside must not leave the thread's group open)
+      for (int r = 0; r < R; ++r) {
+        MGX_RCCL(api.Send(st.newbits + (size_t)r * S, (size_t)S, ncclUint32, r, cm.comm, s));
+        MGX_RCCL(api.Recv(bufs.recv.data() + (size_t)r * S, (size_t)S, ncclUint32, r, cm.comm, s));
+      }
+      group.end();
+    }
+    hipLaunchKernelGGL(k_d2_or_maps, dim3(grid_for(S / 4, BLOCK, 1024)), dim3(BLOCK), 0, s, (const uint4*)bufs.recv.data(), R,
+                       S / 4, S / 4, (uint4*)bufs.recv.data());
+    MGX_RCCL(api.AllGather(bufs.recv.data(), bufs.gathered.data(), (size_t)S, ncclUint32, cm.comm, s));
+    d2_merge(st, level, bufs.gathered.data(), 1, xwords, ctx);
+  }
+}
 
 inline void d2_run(d2_state_t& st, comm_t& cm, d2_run_bufs_t& bufs, int src, int exchange, long long xwords,
                    standard_context_t& ctx, long long* out6) {
@@ -221,32 +426,39 @@ inline void d2_run(d2_state_t& st, comm_t& cm, d2_run_bufs_t& bufs, int src, int
     bufs.recv = mem_t<u32>((size_t)xwords + 4, ctx);
     bufs.xwords = xwords;
   }
-  const long long S = xwords / R;                 // words per slice (xwords is a multiple of 4 * R)
+  if (st.mylist && bufs.glists.size() < (size_t)R * (size_t)st.list_words()) {
+    ctx.synchronize();
+    bufs.glists = mem_t<u32>((size_t)R * (size_t)st.list_words() + 4, ctx);
+  }
   d2_reset(st, src, ctx);
   int level = 0;
+  if (st.mylist) {
+    // One level per round: id lists first; the bitmaps only when some rank's discoveries did not fit its list.  The host
+    // looks at three words per level (d2_apply_lists) -- that is also how it learns that the traversal is over.
+    for (;;) {
+      d2_push(st, level, ctx);
+      const u32* lists = st.mylist;
+      int nl = 1;
+      if (R > 1 || cm.comm) {
+        MGX_RCCL(api.AllGather(st.mylist, bufs.glists.data(), (size_t)st.list_words(), ncclUint32, cm.comm, s));
+        lists = bufs.glists.data();
+        nl = R;
+      }
+      long long o3[3];
+      d2_apply_lists(st, level, lists, nl, st.list_words(), ctx, o3);
+      if (o3[1] == 0) { ++level; break; }                   // nothing discovered on any rank: over
+      if (o3[0]) d2_exchange_bitmaps(st, cm, bufs, level, exchange, xwords, ctx);
+      ++level;
+    }
+    MGX_CHECK_LAUNCH("partitioned BFS: kernel launch");
+    d2_status(st, level, ctx, out6);
+    return;
+  }
   int batch = bufs.levels_hint;
   for (;;) {
     for (int i = 0; i < batch; ++i, ++level) {
       d2_push(st, level, ctx);
-      if (R == 1 && !cm.comm) {
-        d2_merge(st, level, st.newbits, 1, xwords, ctx);
-      } else if (exchange == 0) {
-        MGX_RCCL(api.AllGather(st.newbits, bufs.gathered.data(), (size_t)xwords, ncclUint32, cm.comm, s));
-        d2_merge(st, level, bufs.gathered.data(), R, xwords, ctx);
-      } else {
-        {
-          rccl_group_t group(api);                  // (GroupEnd on every way out: a throw inside must not leave the thread's group open)
-          for (int r = 0; r < R; ++r) {
-            MGX_RCCL(api.Send(st.newbits + (size_t)r * S, (size_t)S, ncclUint32, r, cm.comm, s));
-            MGX_RCCL(api.Recv(bufs.recv.data() + (size_t)r * S, (size_t)S, ncclUint32, r, cm.comm, s));
-          }
-          group.end();
-        }
-        hipLaunchKernelGGL(k_d2_or_maps, dim3(grid_for(S / 4, BLOCK, 1024)), dim3(BLOCK), 0, s, (const uint4*)bufs.recv.data(), R,
-                           S / 4, S / 4, (uint4*)bufs.recv.data());
-        MGX_RCCL(api.AllGather(bufs.recv.data(), bufs.gathered.data(), (size_t)S, ncclUint32, cm.comm, s));
-        d2_merge(st, level, bufs.gathered.data(), 1, xwords, ctx);
-      }
+      d2_exchange_bitmaps(st, cm, bufs, level, exchange, xwords, ctx);
     }
     MGX_CHECK_LAUNCH("partitioned BFS: kernel launch");
     d2_status(st, level, ctx, out6);

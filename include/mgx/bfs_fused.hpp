@@ -424,27 +424,22 @@ __device__ __forceinline__ u32 bfs_defer_limit(const bfs_fused_args_t& a, u32 ho
 }
 
 // End of a push workgroup (all threads; contains barriers).  hot: the LDS copy, deferred words = min(hot words in use,
-// BFS_FLUSH_WORDS); s_red: 2 ints of LDS.  Returns the marks it stored or flushed (for the statistics).
+// BFS_FLUSH_WORDS); marks: this thread's count of claims (deferred and stored alike); s_red: 2 ints of LDS.
+// A workgroup with many claims writes its LDS words AS THEY ARE -- the bitmap it started from plus its own claims; the
+// queue build masks with the old bitmap anyway (new = (marks | flushed) & ~visited) -- so it never reads the global bitmap
+// again (that second read was ~4 us of every deferring level).  Only a workgroup with few claims looks at the difference,
+// to replay it as byte marks.
 template <int NT>
 __device__ __forceinline__ int bfs_hot_epilogue(const bfs_fused_args_t& a, const u32* hot, u32 defer_words, int slot,
-                                                int* s_red) {
+                                                int* s_red, int marks) {
   if (defer_words == 0u) return 0;
   constexpr int PERT = (BFS_FLUSH_WORDS + NT - 1) / NT;          // words per thread (18 at 1024 threads)
-  __syncthreads();                                                // every wave's claims are in
-  u32 diff[PERT];
-  int cnt = 0;
-#pragma unroll
-  for (int q = 0; q < PERT; ++q) {
-    const u32 i = (u32)q * NT + threadIdx.x;
-    diff[q] = i < defer_words ? (hot[i] & ~a.visited[i]) : 0u;
-    cnt += __popc(diff[q]);
-  }
   if (threadIdx.x == 0) { s_red[0] = 0; s_red[1] = -1; }
+  __syncthreads();                                                // every wave's claims are in
+  const int wm = wave_sum(marks);
+  if (lane_id() == 0 && wm) atomicAdd(&s_red[0], wm);
   __syncthreads();
-  cnt = wave_sum(cnt);
-  if (lane_id() == 0 && cnt) atomicAdd(&s_red[0], cnt);
-  __syncthreads();
-  const int total = s_red[0];
+  const int total = s_red[0];                                     // claims of the workgroup (>= the deferred ones)
   if (total == 0) return 0;
   if ((u32)total > a.defer_min_marks) {
     if (threadIdx.x == 0) {
@@ -458,7 +453,7 @@ __device__ __forceinline__ int bfs_hot_epilogue(const bfs_fused_args_t& a, const
 #pragma unroll
       for (int q = 0; q < PERT; ++q) {
         const u32 i = (u32)q * NT + threadIdx.x;
-        if (i < (u32)BFS_FLUSH_WORDS) out[i] = diff[q];          // (words behind defer_words: zeros)
+        if (i < (u32)BFS_FLUSH_WORDS) out[i] = i < defer_words ? hot[i] : 0u;
       }
       return total;
     }
@@ -466,8 +461,9 @@ __device__ __forceinline__ int bfs_hot_epilogue(const bfs_fused_args_t& a, const
   // few: the marks themselves
 #pragma unroll
   for (int q = 0; q < PERT; ++q) {
-    u32 w = diff[q];
-    const u32 base = ((u32)q * NT + threadIdx.x) * 32u;
+    const u32 i = (u32)q * NT + threadIdx.x;
+    u32 w = i < defer_words ? (hot[i] & ~a.visited[i]) : 0u;
+    const u32 base = i * 32u;
     while (w) {
       const int b = __ffs((int)w) - 1;
       w &= w - 1u;
@@ -971,8 +967,10 @@ struct bfs_run_opts_t {
   long long defer = -1;    // MGX_BFS_DEFER: 0 never defer hot marks, N: flush a bitmap above N deferred marks per workgroup
   int spin = -1;           // MGX_BFS_SPIN: 0 read the control block back with a copy + hipStreamSynchronize, 1 publish kernel + spin
   int build_list = 0;      // MGX_BFS_BUILD_LIST=1: the list-based queue build (k_bfs_build) instead of k_bfs_build2
-  int many_spare = 1;      // MGX_BFS_MANY_SPARE: launch slots a traversal of a batch (mgx_bfs_run_many) gets beyond what the last
-                           // traversals of the graph needed (one that does not finish is run again on its own)
+  int many_spare = 0;      // MGX_BFS_MANY_SPARE: launch slots a traversal of a batch (mgx_bfs_run_many) gets beyond what the last
+                           // traversals of the graph needed (0: measured 0.341 against 0.346 ms with one spare slot on RMAT-22 -- an idle
+                           // slot is two launches, ~9 us; the chain behind the batch takes stragglers of up to BFS_CHAIN_CAP_BIG edges,
+                           // and a traversal that still does not finish is run again on its own)
 #ifdef MGX_LAB
   int flags = 0;           // MGX_BFS_FLAGS (instrumented stream kernel)
   int sstream = 0;         // MGX_BFS_SSTREAM=1: dense short rows as one stream of entries (bfs_fused_sshort.hpp) instead of vertex by

@@ -625,10 +625,14 @@ inline int bfs_fused_run_many(bfs_fused_state_t& st, const int* row_offsets, con
   const int saved_tail = st.tail_from;
   st.tail_from = nslots - 1;                       // (chain launches in front of the spare slot and behind the batch)
   const bool tail = a.chain_big_edges && st.opts.tail_chain;
+  // the chain behind a traversal's last slot may run levels up to the list capacity here (a lone workgroup needs ~4.3 us per
+  // 1000 edges: slower than a slot above ~4000 edges, but far cheaper than running the whole traversal again)
+  bfs_launch_plan_t plan_tail = plan;
+  plan_tail.a.chain_big_edges = BFS_CHAIN_CAP_BIG;
   for (int i = 0; i < count; ++i) {
     bfs_enqueue_start(st, plan, srcs[i], ctx, i > 0 ? bfs_many_head(heads, i - 1) : nullptr, head_words);
     for (int sl = 0; sl < nslots; ++sl) bfs_enqueue_slot(st, plan, sl, ctx);
-    if (tail) bfs_enqueue_chain_inplace(plan, nslots, s);
+    if (tail) bfs_enqueue_chain_inplace(plan_tail, nslots, s);
   }
   st.tail_from = saved_tail;
   const u64 seq = ++st.seq;

@@ -154,7 +154,7 @@ __device__ __forceinline__ void bfs_sstream_body(const bfs_fused_args_t& a, int 
   const u32 defer_n = bfs_defer_limit(a, hot_n);
   int marks = 0;
   bfs_sstream_work<NT, HOTW>(a, hot, tab, hot_n, defer_n, block, nblocks, marks);
-  (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, slot, s_int + 4);
+  (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, slot, s_int + 4, marks);
   bfs_body_finish(a, marks, slot, stat_level, s_int);
 }
 

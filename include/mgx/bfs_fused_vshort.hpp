@@ -156,7 +156,7 @@ __device__ __forceinline__ void bfs_vshort_body(const bfs_fused_args_t& a, int s
   const u32 defer_n = bfs_defer_limit(a, hot_n);
   int marks = 0;
   bfs_vshort_work<NT, HOTW>(a, hot, hot_n, defer_n, block, nblocks, marks);
-  (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, slot, s_int + 4);
+  (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, slot, s_int + 4, marks);
   bfs_body_finish(a, marks, slot, stat_level, s_int);
 }
 
@@ -183,7 +183,7 @@ __device__ __forceinline__ void bfs_dense_vshort_body(const bfs_fused_args_t& a,
     __syncthreads();
   }
   bfs_vshort_work<NT, HOTW>(a, hot, hot_n, defer_n, block, nblocks, marks);
-  (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, slot, s_int + 4);
+  (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, slot, s_int + 4, marks);
   bfs_body_finish(a, marks, slot, stat_level, s_int);
 }
 #endif  // MGX_LAB

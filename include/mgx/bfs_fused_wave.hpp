@@ -201,7 +201,7 @@ __device__ __forceinline__ void bfs_wave_body(const bfs_fused_args_t& a, int lev
     }
   }
 
-  (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, level, s_int + 4);
+  (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, level, s_int + 4, marks);
   bfs_body_finish(a, marks, level, stat_level, s_int);
 }
 

@@ -10,7 +10,7 @@
 //   k_nr_values   vals[v] = value(old_of_new[v]) for every layout vertex v: ONE gather per vertex instead of one per
 //                 edge; from here on the values are addressed by layout id, where the hubs -- the targets of most edges --
 //                 are the first ids; reduced[] <- identity.
-//   k_nr_long     the long rows (>= 64 entries) from the unit blocks (mgx_layout.hip): 16 bytes per lane, a unit of 64
+//   k_nr_edges    ONE launch, two parts.  Long rows (>= 64 entries) from the unit blocks (mgx_layout.hip): 16 bytes per lane, a unit of 64
 //                 entries belongs to ONE row (ub_cnt[u] of them are real, the rest padding), so the segment id is free;
 //                 the values of the first NR_HOTV layout vertices sit in LDS (80 KB per workgroup, two workgroups per
 //                 CU), the others are gathered from L2 (the next 600 K vertices are 2.4 MB); 16 lanes fold a unit with
@@ -18,7 +18,7 @@
 //   k_nr_rows     a long row's units are contiguous (ub_first[v] .. ub_first[v + 1]): one thread folds the partials of a
 //                 row of up to NR_BIG_UNITS units in order; the few rows above that (the first rows of the degree-sorted
 //                 layout) take a workgroup each.  Deterministic: the order of the fold never depends on timing.
-//   k_nr_short    rows of 1 .. 63 entries by degree class as in bfs_fused_vshort.hpp: 16 / 4 / 1 lanes per vertex, one
+//                 Short rows: 1 .. 63 entries by degree class as in bfs_fused_vshort.hpp: 16 / 4 / 1 lanes per vertex, one
 //                 unaligned 16-byte load of four entries per lane, fold by shuffles.
 // Results go to reduced[old_of_new[v]] -- the frontier POSITION of vertex v in an iota frontier (neighborhood.hxx:58).
 // Float sums are folded in a different order than the general kernel's (both are deterministic; the reference's own
@@ -86,20 +86,19 @@ __device__ __forceinline__ V* nr_hot_setup(char* smem, const V* __restrict__ val
 struct __attribute__((aligned(4))) nr_u32x4u { u32 x, y, z, w; };   // 16-byte load at 4-byte alignment
 typedef unsigned int nr_u32x4 __attribute__((ext_vector_type(4)));
 
+// the long rows' part of one workgroup (block `block` of `nblocks`); hot: the LDS values, already set up
 template <typename V, typename Op, int NT>
-__global__ __launch_bounds__(NT, 2) void k_nr_long(nr_layout_t L, const V* __restrict__ vals, V* __restrict__ partial, V identity, Op op) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void nr_long_work(const nr_layout_t& L, const V* __restrict__ vals, const V* hot, u32 hot_n, V* __restrict__ partial,
+                                             V identity, Op op, u32 block, u32 nblocks) {
   constexpr int NW = NT / WAVE;
-  const u32 hot_n = (u32)L.n < (u32)NR_HOTV ? (u32)L.n : (u32)NR_HOTV;
-  const V* const hot = nr_hot_setup<V, NT>(smem, vals, hot_n);
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
   const u32 G = L.ub_units_pad / 16u;                 // groups of 16 units = 1024 entries
-  const u32 W = gridDim.x * NW, w = blockIdx.x * NW + (u32)wave;
+  const u32 W = nblocks * NW, w = block * NW + (u32)wave;
   const int* __restrict__ ucol = L.ub_col;
   const unsigned char* __restrict__ ucnt = L.ub_cnt;
   const u32 sub = (u32)lane & 15u, q = (u32)lane >> 4;                  // my four entries inside my unit; my unit inside a 4-unit load
-  if (w >= G) return;
+  if (w < G) {
   // group g: four loads; load j covers units 16 g + 4 j .. + 3, lane (q, sub) reads entries 4 sub .. 4 sub + 3 of unit 4 j + q
   nr_u32x4 cur[4], nxt[4];
   u32 ccnt[4], ncnt[4];
@@ -115,21 +114,27 @@ __global__ __launch_bounds__(NT, 2) void k_nr_long(nr_layout_t L, const V* __res
   issue(w, cur, ccnt);
   for (u32 g = w; g < G; g += W) {
     issue(g + W, nxt, ncnt);                          // (past the end: the last group again, ignored)
+    // all sixteen gathers of the group first, then the folds (a fold's shuffles between two gathers would order them)
+    V val[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const u32 have = ccnt[j];                       // real entries of my unit
       const u32 e0 = sub * 4u;
       const u32 d0 = e0 + 0u < have ? cur[j].x : 0xFFFFFFFFu, d1 = e0 + 1u < have ? cur[j].y : 0xFFFFFFFFu;
       const u32 d2 = e0 + 2u < have ? cur[j].z : 0xFFFFFFFFu, d3 = e0 + 3u < have ? cur[j].w : 0xFFFFFFFFu;
-      const V v0 = nr_fetch(d0, vals, hot, hot_n, identity), v1 = nr_fetch(d1, vals, hot, hot_n, identity);
-      const V v2 = nr_fetch(d2, vals, hot, hot_n, identity), v3 = nr_fetch(d3, vals, hot, hot_n, identity);
-      V s = op(op(v0, v1), op(v2, v3));
+      val[j][0] = nr_fetch(d0, vals, hot, hot_n, identity); val[j][1] = nr_fetch(d1, vals, hot, hot_n, identity);
+      val[j][2] = nr_fetch(d2, vals, hot, hot_n, identity); val[j][3] = nr_fetch(d3, vals, hot, hot_n, identity);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      V s = op(op(val[j][0], val[j][1]), op(val[j][2], val[j][3]));
 #pragma unroll
       for (int sh = 1; sh < 16; sh <<= 1) s = op(s, __shfl_xor(s, sh, WAVE));     // the 16 lanes of my unit
       if (sub == 0u) partial[g * 16u + 4u * (u32)j + q] = s;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { cur[j] = nxt[j]; ccnt[j] = ncnt[j]; }
+  }
   }
 }
 
@@ -168,17 +173,15 @@ __global__ __launch_bounds__(BLOCK) void k_nr_big_rows(nr_layout_t L, const V* _
 // short rows by degree class: [vs_v[0], vs_v[1]) 16 lanes per vertex (17 .. 63 entries), [vs_v[1], vs_v[2]) 4 lanes (5 .. 16),
 // [vs_v[2], vs_v[3]) 1 lane (1 .. 4).  A lane reads four consecutive entries of its row with one 16-byte load.
 template <typename V, typename Op, int NT>
-__global__ __launch_bounds__(NT, 2) void k_nr_short(nr_layout_t L, const V* __restrict__ vals, V* __restrict__ reduced, V identity, Op op) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void nr_short_work(const nr_layout_t& L, const V* __restrict__ vals, const V* hot, u32 hot_n, V* __restrict__ reduced,
+                                              V identity, Op op, u32 block, u32 nblocks) {
   constexpr int NW = NT / WAVE;
-  const u32 hot_n = (u32)L.n < (u32)NR_HOTV ? (u32)L.n : (u32)NR_HOTV;
-  const V* const hot = nr_hot_setup<V, NT>(smem, vals, hot_n);
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
   const u32 b0 = L.vs_v[0], b1 = L.vs_v[1], b2 = L.vs_v[2], b3 = L.vs_v[3];
   const u32 s16 = (b1 - b0 + 3u) / 4u, s4 = (b2 - b1 + 15u) / 16u, s1 = (b3 - b2 + 63u) / 64u;
   const u32 T = s16 + s4 + s1;
-  const u32 W = gridDim.x * NW, w = blockIdx.x * NW + (u32)wave;
+  const u32 W = nblocks * NW, w = block * NW + (u32)wave;
   const u32* __restrict__ ro = L.row_offsets;
   const int* __restrict__ col = L.col_indices;
   const int* __restrict__ o2n = L.old_of_new;
@@ -223,6 +226,20 @@ __global__ __launch_bounds__(NT, 2) void k_nr_short(nr_layout_t L, const V* __re
   }
 }
 
+// ONE launch for both parts.
+template <typename V, typename Op, int NT>
+__global__ __launch_bounds__(NT, 8) void k_nr_edges(nr_layout_t L, const V* __restrict__ vals, V* __restrict__ partial, V* __restrict__ reduced,
+                                                    V identity, Op op, u32 nlong) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const u32 hot_n = (u32)L.n < (u32)NR_HOTV ? (u32)L.n : (u32)NR_HOTV;
+  const V* const hot = nr_hot_setup<V, NT>(smem, vals, hot_n);
+  // every workgroup takes its share of BOTH parts, one after the other over the same LDS values: the parts differ in cost
+  // per entry (the short rows pay a planning load per vertex), so any fixed split of the grid leaves one half waiting
+  (void)nlong;
+  nr_long_work<V, Op, NT>(L, vals, hot, hot_n, partial, identity, op, blockIdx.x, gridDim.x);
+  nr_short_work<V, Op, NT>(L, vals, hot, hot_n, reduced, identity, op, blockIdx.x, gridDim.x);
+}
+
 // scratch the fast path needs (vals + partials), in bytes
 inline size_t nr_scratch_bytes(long long n, long long units_pad, size_t value_size) {
   return (((size_t)n + 64) * value_size + 255) / 256 * 256 + ((size_t)units_pad + 64) * value_size;
@@ -235,22 +252,21 @@ inline void nr_full_frontier(const nr_layout_t& L, GetValue get, V* reduced, V i
   V* const vals = (V*)ctx.scratch;
   V* const partial = (V*)((char*)ctx.scratch + (((size_t)L.n + 64) * sizeof(V) + 255) / 256 * 256);
   static unsigned char seen[64] = {};
-  if (first_use_on_device(seen)) {
-    MGX_HIP(hipFuncSetAttribute((const void*)(k_nr_long<V, Op, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MGX_HIP(hipFuncSetAttribute((const void*)(k_nr_short<V, Op, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  }
+  if (first_use_on_device(seen))
+    MGX_HIP(hipFuncSetAttribute((const void*)(k_nr_edges<V, Op, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL((k_nr_values<V, GetValue>), dim3(grid_for(L.n, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, get, L.old_of_new, vals,
                      reduced, identity, (long long)L.n);
   const u32 long_rows = L.vs_v[0];
-  if (L.ub_units > 0 && long_rows > 0) {
-    hipLaunchKernelGGL((k_nr_long<V, Op, 1024>), dim3(ctx.num_cus * 2), dim3(1024), nr_lds_bytes(), s, L, (const V*)vals, partial, identity, op);
+  const bool has_long = L.ub_units > 0 && long_rows > 0, has_short = L.vs_v[3] > L.vs_v[0];
+  if (has_long || has_short)
+    hipLaunchKernelGGL((k_nr_edges<V, Op, 1024>), dim3(ctx.num_cus * 2), dim3(1024), nr_lds_bytes(), s, L, (const V*)vals, partial, reduced,
+                       identity, op, 0u);
+  if (has_long) {
     if (L.big_rows > 0) hipLaunchKernelGGL((k_nr_big_rows<V, Op>), dim3(L.big_rows), dim3(BLOCK), 0, s, L, (const V*)partial, reduced, identity, op);
     if (long_rows > L.big_rows)
       hipLaunchKernelGGL((k_nr_rows<V, Op>), dim3((long_rows - L.big_rows + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, L, (const V*)partial, reduced,
                          identity, op, L.big_rows, long_rows);
   }
-  if (L.vs_v[3] > L.vs_v[0])
-    hipLaunchKernelGGL((k_nr_short<V, Op, 1024>), dim3(ctx.num_cus * 2), dim3(1024), nr_lds_bytes(), s, L, (const V*)vals, reduced, identity, op);
 }
 
 }  // namespace mgx

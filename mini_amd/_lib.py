@@ -147,6 +147,9 @@ SIGNATURES = {
     "mgx_dbfs2_reset": [_vp, _i],
     "mgx_dbfs2_words": [_i, _pi64],
     "mgx_dbfs2_status": [_vp, _i, _pi64],
+    "mgx_dbfs2_list_words": [_i, _i, _pi64],
+    "mgx_dbfs2_set_list": [_vp, _vp, _i64],
+    "mgx_dbfs2_apply_lists": [_vp, _i, _vp, _i, _i64, _pi64],
     "mgx_dbfs2_push": [_vp, _i],
     "mgx_dbfs2_merge": [_vp, _i, _vp],
     "mgx_dbfs2_merge_maps": [_vp, _i, _vp, _i, _i64],

@@ -1319,6 +1319,33 @@ int mgx_dbfs2_or_maps(mgx_dbfs2_t h, const unsigned* d_maps, int maps, int64_t s
                        (uint4*)d_out);
   MGX_CATCH
 }
+int mgx_dbfs2_list_words(int n_global, int ranks, int64_t* words) {
+  MGX_TRY
+  MGX_REQUIRE(words && n_global > 0 && ranks >= 1 && ranks <= 64, "mgx_dbfs2_list_words: bad argument");
+  *words = (int64_t)mgx::D2_LIST_HEAD + (int64_t)mgx::d2_state_t::default_list_cap(n_global, ranks);
+  MGX_CATCH
+}
+int mgx_dbfs2_set_list(mgx_dbfs2_t h, unsigned* d_list, int64_t words) {
+  MGX_TRY
+  MGX_REQUIRE(h, "NULL argument");
+  MGX_REQUIRE(!d_list || (words > mgx::D2_LIST_HEAD && words % 4 == 0 && words < (1ll << 31)),
+              "mgx_dbfs2_set_list: the list must hold its 4 header words and a multiple of 4 words in all");
+  use_device(h->c);
+  h->c->ctx->synchronize();
+  h->st.set_list(d_list, d_list ? (unsigned)(words - mgx::D2_LIST_HEAD) : 0u);
+  MGX_CATCH
+}
+int mgx_dbfs2_apply_lists(mgx_dbfs2_t h, int level, const unsigned* d_lists, int lists, int64_t stride_words, int64_t* out3) {
+  MGX_TRY
+  MGX_REQUIRE(h && d_lists && out3 && level >= 0, "bad argument");
+  MGX_REQUIRE(h->st.mylist != nullptr, "mgx_dbfs2_apply_lists: no list was set (mgx_dbfs2_set_list)");
+  MGX_REQUIRE(lists >= 1 && lists <= 64 && stride_words >= h->st.list_words(), "mgx_dbfs2_apply_lists: 1..64 lists, each at least a list long");
+  use_device(h->c);
+  long long o[3];
+  mgx::d2_apply_lists(h->st, level, d_lists, lists, (long long)stride_words, *h->c->ctx, o);
+  for (int i = 0; i < 3; ++i) out3[i] = o[i];
+  MGX_CATCH
+}
 int mgx_dbfs2_status(mgx_dbfs2_t h, int next_level, int64_t* out6) {
   MGX_TRY
   MGX_REQUIRE(h && out6 && next_level >= 0, "bad argument");

@@ -161,6 +161,13 @@ def bitmap_words(n_global):
     return ((n_global + 31) // 32 + 3) // 4 * 4
 
 
+def list_words(n_global, ranks):
+    """32-bit words of a rank's id list on sparse levels: 4 header words ([0] = count) + n / (256 ranks) ids, at least 252
+    (== mgx_dbfs2_list_words)"""
+    c = max(n_global // (256 * ranks), 252)
+    return (c + 4 + 3) // 4 * 4
+
+
 def exchange_words(n_global, ranks):
     """length of the buffer a rank's new-bit map is exchanged in: bitmap_words padded so that it splits into
     `ranks` slices of whole 16-byte units (the reduce-scatter exchange sends slice r to rank r)"""
@@ -187,13 +194,29 @@ class HipRankEngine2:
                                    C.c_void_p(row_offsets_local.data_ptr()), C.c_void_p(col_indices_global.data_ptr()),
                                    C.c_void_p(self.newbits.data_ptr()), C.byref(h)))
         self._h = h
+        # id lists of the sparse levels (MGX_DIST_LISTS=0: bitmaps on every level)
+        self.list = None
+        if os.environ.get("MGX_DIST_LISTS", "1") != "0":
+            w = C.c_int64()
+            check(lib.mgx_dbfs2_list_words(int(n_global), int(ranks), C.byref(w)))
+            assert w.value == list_words(n_global, ranks)
+            self.list = torch.zeros(w.value, dtype=torch.int32, device=row_offsets_local.device)
+            check(lib.mgx_dbfs2_set_list(self._h, C.c_void_p(self.list.data_ptr()), w.value))
 
     def reset(self, src):
         check(lib.mgx_dbfs2_reset(self._h, int(src)))
 
     def push(self, level):
+        """enqueues the level's push; returns the rank's new-bit map (and fills self.list, if lists are on)"""
         check(lib.mgx_dbfs2_push(self._h, int(level)))
         return self.newbits
+
+    def apply_lists(self, level, lists, nlists):
+        """lists: nlists gathered id lists -> (overflow: exchange the bitmaps, sum of the counts: 0 = traversal over)"""
+        o = (C.c_int64 * 3)()
+        check(lib.mgx_dbfs2_apply_lists(self._h, int(level), C.c_void_p(lists.data_ptr()), int(nlists),
+                                        int(lists.numel() // nlists), o))
+        return bool(o[0]), int(o[1])
 
     def merge(self, level, maps, nmaps):
         """maps: nmaps new-bit maps, each as long as the buffer push() returned"""
@@ -296,7 +319,9 @@ class DistBfs2:
         self.e, self.rank, self.world, self.comm_device = engine, rank, world, torch.device(comm_device)
         self.levels_hint = 8
         self._gathered = None
+        self._glists = None
         self._bufs = None
+        self.sparse_levels = self.dense_levels = 0
         mode = os.environ.get("MGX_DIST_EXCHANGE", "auto")
         if mode not in ("gather", "reduce"):
             mode = "reduce" if world >= 4 else "gather"
@@ -322,6 +347,18 @@ class DistBfs2:
                         self.comm.close()
                         self.comm = None
             self.native = bool(ok)
+
+    def _gather_lists(self, mine):
+        """-> (lists, nlists): every rank's id list of the level (what apply_lists takes)"""
+        W = self.world
+        if W == 1 and os.environ.get("MGX_DIST_FORCE_COLLECTIVES") != "1":
+            return mine, 1
+        src = mine if mine.device == self.comm_device else mine.to(self.comm_device)
+        if self._glists is None or self._glists.numel() != W * src.numel() or self._glists.device != self.comm_device:
+            self._glists = torch.empty(W * src.numel(), dtype=src.dtype, device=self.comm_device)
+        dist.all_gather_into_tensor(self._glists, src.contiguous())
+        out = self._glists
+        return (out if out.device == mine.device else out.to(mine.device)), W
 
     def _exchange(self, new):
         """-> (maps, nmaps): what merge() takes"""
@@ -364,6 +401,24 @@ class DistBfs2:
             return {"levels": st["levels"], "edges_local": st["edges_local"]}
         e.reset(src)
         level = 0
+        if getattr(e, "list", None) is not None:
+            # one level per round: the id lists first; the bitmaps only when some rank's discoveries did not fit its list
+            # (every rank reads the same headers, so all take the same branch); a level whose lists are all empty ends it
+            self.sparse_levels = self.dense_levels = 0
+            while True:
+                new = e.push(level)
+                overflow, total = e.apply_lists(level, *self._gather_lists(e.list))
+                level += 1
+                if total == 0:
+                    break
+                if overflow:
+                    e.merge(level - 1, *self._exchange(new))
+                    self.dense_levels += 1
+                else:
+                    self.sparse_levels += 1
+            st = e.status(level)
+            self.levels = st["levels"]
+            return {"levels": st["levels"], "edges_local": st["edges_local"]}
         batch = self.levels_hint
         while True:
             for _ in range(batch):

@@ -60,11 +60,13 @@ class NumpyRankEngine2:
     cyclic ownership, new-bit maps exchanged by all-gather).  Same reset/push/merge/status/labels contract,
     including "levels enqueued past the end are no-ops"."""
 
-    def __init__(self, n_global, ranks, rank, ro_local, ci_global):
-        from mini_amd.dist_bfs import bitmap_words
+    def __init__(self, n_global, ranks, rank, ro_local, ci_global, lists=True):
+        from mini_amd.dist_bfs import bitmap_words, list_words
         self.n_global, self.ranks, self.rank = n_global, ranks, rank
         self.n_local = (n_global - rank + ranks - 1) // ranks
         self.nwords = bitmap_words(n_global)
+        # id lists of the sparse levels: [count, 0, 0, 0, ids ...] (count may exceed the capacity: "did not fit")
+        self.list = torch.zeros(list_words(n_global, ranks), dtype=torch.int32) if lists else None
         self.ro = np.asarray(ro_local, dtype=np.int64)
         self.ci = np.asarray(ci_global, dtype=np.int64)
 
@@ -100,7 +102,34 @@ class NumpyRankEngine2:
         self.edges += len(g)
         new = np.zeros(self.n_global, dtype=bool)
         new[g[~self.visited[g]]] = True
+        if self.list is not None:
+            ids = np.nonzero(new)[0].astype(np.int32)
+            cap = self.list.numel() - 4
+            self.list.zero_()
+            self.list[0] = len(ids)
+            k = min(len(ids), cap)
+            self.list[4:4 + k] = torch.from_numpy(ids[:k].copy())
         return torch.from_numpy(self._bits_to_words(new.astype(np.uint8), self.nwords).copy())
+
+    def apply_lists(self, level, lists, nlists):
+        L = lists.numpy().reshape(nlists, -1)
+        cap = L.shape[1] - 4
+        counts = L[:, 0].astype(np.int64)
+        if (counts > cap).any():
+            return True, int(np.minimum(counts, cap).sum())
+        total = int(counts.sum())
+        if total == 0:
+            self.new_global = 0
+            return False, 0
+        ids = np.unique(np.concatenate([L[r, 4:4 + counts[r]] for r in range(nlists)]).astype(np.int64))
+        ids = ids[~self.visited[ids]]
+        self.visited[ids] = True
+        own = ids[ids % self.ranks == self.rank] // self.ranks
+        self.lab[own] = level + 1
+        deg = self.ro[own + 1] - self.ro[own]
+        self.front = own[deg > 0].tolist()
+        self.new_global = len(ids)
+        return False, total
 
     def merge(self, level, maps, nmaps):
         g = maps.numpy().reshape(nmaps, -1)[:, : self.nwords]

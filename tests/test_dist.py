@@ -85,12 +85,15 @@ def _worker2(rank, world, port, use_gpu, scale, seed, sources, q):
         eng = HipRankEngine2(ctx, n, world, rank, torch.from_numpy(ro_l).cuda(), torch.from_numpy(ci_l).cuda())
     else:
         from tests.dist_cpu_engine import NumpyRankEngine2
-        eng = NumpyRankEngine2(n, world, rank, ro_l, ci_l)
+        eng = NumpyRankEngine2(n, world, rank, ro_l, ci_l, lists=os.environ.get("MGX_DIST_LISTS", "1") != "0")
     bfs = DistBfs2(eng, rank, world, "cpu")
     ok = True
     deg = np.diff(ro)
+    sparse = dense = 0
     for src in sources:
         st = bfs.run(int(new_of_old[src]))
+        sparse += bfs.sparse_levels
+        dense += bfs.dense_levels
         got_new = bfs.gather_labels()
         got = np.empty(n, dtype=np.int32)
         got[old_of_new] = got_new
@@ -99,6 +102,12 @@ def _worker2(rank, world, port, use_gpu, scale, seed, sources, q):
         dist.all_reduce(e)
         ok = ok and np.array_equal(got, want) and int(e.item()) == int(deg[want >= 0].sum())
         ok = ok and st["levels"] == int(want.max()) + 1
+    if os.environ.get("MGX_DIST_LISTS", "1") != "0":
+        # id lists on the sparse levels, bitmaps where a rank's discoveries do not fit its list (252 ids on these graphs):
+        # every run has sparse levels; the hub's big level overflows from scale 11 on
+        ok = ok and sparse > 0 and (dense > 0 or scale < 11)
+    else:
+        ok = ok and sparse == 0
     if rank == 0:
         q.put(bool(ok))
     dist.barrier()
@@ -138,18 +147,33 @@ def test_partitioned_bfs_hip_engine_two_ranks_one_gpu(built):
 @pytest.mark.parametrize("world", [1, 2, 3])
 def test_bitmap_exchange_bfs_gloo_cpu(built, world, exchange, monkeypatch):
     """exchange: one all_gather of the ranks' maps, or all_to_all of slices + OR + all_gather of the merged slices
-    (DistBfs2; world 3 does not divide the bitmap: the slices are padded)"""
+    (DistBfs2; world 3 does not divide the bitmap: the slices are padded); bitmaps on every level (MGX_DIST_LISTS=0)"""
     monkeypatch.setenv("MGX_DIST_EXCHANGE", exchange)
+    monkeypatch.setenv("MGX_DIST_LISTS", "0")
     _run(world, False, 9, 9, _worker2)
+
+
+@pytest.mark.parametrize("world,scale,exchange", [(1, 9, "gather"), (2, 9, "gather"), (2, 12, "reduce"), (3, 12, "gather")])
+def test_density_switched_exchange_bfs_gloo_cpu(built, world, scale, exchange, monkeypatch):
+    """the default exchange: id lists all-gathered on sparse levels, the bitmap exchange only for a level on
+    which some rank's discoveries overflow its list; every rank takes the same branch (they read the same headers) and the
+    traversal ends on the level whose lists are all empty.  Labels == the oracle's, edges == m_t, levels == depth + 1."""
+    monkeypatch.setenv("MGX_DIST_EXCHANGE", exchange)
+    monkeypatch.setenv("MGX_DIST_LISTS", "1")
+    _run(world, False, scale, scale, _worker2)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,scale,exchange", [(1, 12, "gather"), (2, 12, "gather"), (2, 16, "reduce"),
                                                   (3, 14, "gather"), (3, 14, "reduce")])
-def test_bitmap_exchange_bfs_hip_engine_ranks_share_one_gpu(built, world, scale, exchange, monkeypatch):
+@pytest.mark.parametrize("lists", ["1", "0"])
+def test_bitmap_exchange_bfs_hip_engine_ranks_share_one_gpu(built, world, scale, exchange, lists, monkeypatch):
+    """the HIP rank engine, several ranks on the one GPU of the test box over gloo: id lists on sparse levels + bitmaps on
+    dense ones (k_d2_newbits' list, k_d2_lists_apply), and bitmaps on every level"""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     monkeypatch.setenv("MGX_DIST_EXCHANGE", exchange)
+    monkeypatch.setenv("MGX_DIST_LISTS", lists)
     _run(world, True, scale, scale, _worker2)
 
 

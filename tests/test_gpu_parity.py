@@ -913,7 +913,7 @@ def test_bfs_run_many_equals_one_call_per_source(gpu_ctx, oracle, layout):
 
 def test_bfs_run_many_reruns_a_traversal_that_needs_more_slots(gpu_ctx, oracle, monkeypatch):
     """a batch is sized by the launch slots the previous traversals needed: a source whose traversal has many more big
-    levels (here: a long chain of cliques behind a graph of diameter 2, chains of small levels switched off so that every
+    levels (here: the end of a 40-vertex path next to a star of diameter 2, chains of small levels switched off so that every
     level takes a slot) does not finish inside the batch, is run again on its own and reported in `reruns` -- counters and
     labels are right either way"""
     import mini_amd
@@ -924,10 +924,9 @@ def test_bfs_run_many_reruns_a_traversal_that_needs_more_slots(gpu_ctx, oracle, 
     for k in range(1, nleaf + 1):                       # a star: depth 1 from the hub, 2 from a leaf
         t0.append(hub); t1.append(k)
     base = nleaf + 1
-    length = 40                                         # a path of 40 more levels hanging off leaf 1
-    prev = 1
-    for k in range(length):
-        t0.append(prev); t1.append(base + k); prev = base + k
+    length = 40                                         # a path of 40 vertices, a component of its own
+    for k in range(length - 1):
+        t0.append(base + k); t1.append(base + k + 1)
     n = base + length
     ro, ci, _ = oracle.csr_from_tuples(n, np.array(t0, dtype=np.int32), np.array(t1, dtype=np.int32), None, undir=True)
     g = _graph(gpu_ctx, ro, ci)
