@@ -76,6 +76,8 @@ struct graph_device_t {
   mem_t<int> d_ub_owner;
   long long ub_units = 0, ub_units_pad = 0;
   int ub_min_degree = 0;
+  mem_t<float> d_ub_w;               // weights of the unit blocks' entries (fused SSSP's heavy iterations); built on first use
+  bool ub_w_tried = false;
   mem_t<unsigned char> d_ub_cnt;     // real entries of every unit (the rest is padding): what a reduction may count (mgx/nreduce.hpp)
   mem_t<int> d_ub_first;             // n + 1: the units of layout row v are [ub_first[v], ub_first[v + 1])
   unsigned nr_big_rows = 0;          // layout rows [0, nr_big_rows) hold more than mgx::NR_BIG_UNITS units (degree-sorted layouts)

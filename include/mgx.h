@@ -384,6 +384,9 @@ MGX_API int mgx_sssp_run_delta(mgx_sssp_t p, int src, float delta, int64_t* stat
  * frontier): on != 0 brackets each launch with HIP events on the context's stream (each costs ~6 us of stream gap: measurement
  * runs only); mgx_sssp_kernel_times: out2 = { launches, device ns } of the last run                                        */
 MGX_API int mgx_sssp_set_kernel_timing(mgx_sssp_t p, int on);
+/* per-iteration trace of the last mgx_sssp_run (first min(cap, 63) iterations): frontier vertices, edges relaxed, duration in
+ * ms from device-side timestamps taken when an iteration is opened (0 for the last one); *iterations = how many there were */
+MGX_API int mgx_sssp_iteration_trace(mgx_sssp_t p, int cap, int64_t* frontier, int64_t* edges, float* ms, int* iterations);
 MGX_API int mgx_sssp_kernel_times(mgx_sssp_t p, int64_t* out2);
 
 /* ---- PR: pr_problem_t / pr_functor_t / pr_enactor_t (gunrock/src/pr/) ---- */

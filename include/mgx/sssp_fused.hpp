@@ -56,6 +56,15 @@ struct sssp_args_t {
   unsigned long long m_edges;
   u32 sliced_div;
   u32* frontier_bits;
+  // heavy iterations over the layout's unit blocks and degree classes (sssp_dense_*; NULL: never): the long rows' entries
+  // and weights in 64-entry units of one row each, real entries per unit, the row of every unit; the short rows' classes
+  const int* ub_col;
+  const float* ub_w;
+  const unsigned char* ub_cnt;
+  const int* ub_owner;
+  u32 ub_units_pad;
+  u32 vs_v[4];
+  u32 dense_div;         // an iteration whose frontier holds >= m / dense_div edges takes the sweep (0: never)
   float delta;           // near / far bucket width (delta-stepping; BASELINE config 3 names it): 0 = plain frontier
                          // Bellman-Ford, every improved vertex is expanded in the next iteration
 };
@@ -75,6 +84,13 @@ struct sssp_layout_t {
   const int* slice_off = nullptr;
   int slices = 0, slice_shift = 0;
   long long m_edges = 0;
+  // unit blocks of this CSR with their weights, degree classes (optional: a layout the library built and sorted itself)
+  const int* ub_col = nullptr;
+  const float* ub_w = nullptr;
+  const unsigned char* ub_cnt = nullptr;
+  const int* ub_owner = nullptr;
+  unsigned ub_units_pad = 0;
+  unsigned vs_v[4] = {0, 0, 0, 0};
 };
 
 constexpr u32 SSSP_INF_BITS = 0x7f7fffffu;      // FLT_MAX: what the reference stores for "not reached" (sssp_problem.hxx:45)
@@ -151,6 +167,178 @@ constexpr int SSSP_TILE = WAVE * SSSP_EPT;
 // time the workgroup started, rounded UP to bfloat16: distances only decrease, so it stays a bound.
 constexpr int SSSP_HOTN = 32768;                   // 64 KB per workgroup, two workgroups per CU (65536 with one: same rate)
 constexpr u32 SSSP_HOT_MIN_EDGES = 1u << 20;       // smaller iterations do not pay for the copy
+
+// ---- heavy iterations: a sweep over the unit blocks and the degree classes instead of the queue ------------------------
+// The queue walk above resolves every edge rank to its row (a search per tile) and reads neighbours and weights 4 bytes per
+// lane.  An iteration whose frontier holds a large share of ALL edges (the three heavy iterations of an RMAT-22 run relax
+// 80-100 M of the 134 M edges each: 2.8 of the run's 3.5 ms) is cheaper as a sweep in the shape of the BFS's unit-block
+// body and of mgx/nreduce.hpp: the long rows' entries and weights are streamed from the unit blocks, 16 bytes per lane, a
+// unit of 64 entries belongs to ONE row -- its owner's frontier bit and current distance are one (broadcast) gather per
+// unit --, the short rows are walked by degree class; no queue, no search.  What stays random is dist[dst]: the hubs'
+// bounds sit in LDS as before.  Rows outside the frontier are read and masked: the price of the sweep.
+typedef unsigned int sssp_u32x4 __attribute__((ext_vector_type(4)));
+typedef float sssp_f32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((aligned(4))) sssp_u32x4u { u32 x, y, z, w; };
+struct __attribute__((aligned(4))) sssp_f32x4u { float x, y, z, w; };
+
+// one candidate: entry d (0xFFFFFFFF: none) reached with distance bits nd
+__device__ __forceinline__ u32 sssp_gather_index(u32 d, u32 nd, const unsigned short* hot16, u32 hot_n, bool& live) {
+  const bool none = d == 0xFFFFFFFFu;
+  const bool hotm = d < hot_n;
+  const u32 ub = hot16[hotm ? d : 0u];
+  const bool skip = hotm && nd >= (ub << 16);          // cannot beat the bound of a hub: no gather
+  live = !none && !skip;
+  return live ? d : 0u;
+}
+
+template <int NT>
+__device__ __forceinline__ void sssp_dense_long(const sssp_args_t& a, const unsigned short* hot16, u32 hot_n, u32 block, u32 nblocks) {
+  constexpr int NW = NT / WAVE;
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+  const u32 sub = (u32)lane & 15u, q = (u32)lane >> 4;
+  const u32 H = a.ub_units_pad / 8u;                   // half-groups: 8 units = 512 entries
+  const u32 W = nblocks * NW, w = block * NW + (u32)wave;
+  if (w >= H) return;
+  const int* __restrict__ ucol = a.ub_col;
+  const float* __restrict__ uw = a.ub_w;
+  const unsigned char* __restrict__ ucnt = a.ub_cnt;
+  const int* __restrict__ owner = a.ub_owner;
+  const u32* __restrict__ fbits = a.frontier_bits;
+  u32* dist = a.dist;
+  unsigned char* mark = a.mark;
+  sssp_u32x4 cC[2], cN[2];
+  sssp_f32x4 wC[2], wN[2];
+  u32 nC[2], nN[2], oC[2], oN[2];
+  auto issue = [&](u32 h, sssp_u32x4* c, sssp_f32x4* wt, u32* cnt, u32* own) {
+    const u32 hh = h < H ? h : H - 1u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const u32 u = hh * 8u + 4u * (u32)j + q;
+      const size_t e = ((size_t)u << 6) + sub * 4u;
+      c[j] = __builtin_nontemporal_load((const sssp_u32x4*)(ucol + e));
+      wt[j] = __builtin_nontemporal_load((const sssp_f32x4*)(uw + e));
+      cnt[j] = ucnt[u];
+      own[j] = (u32)owner[u];
+    }
+  };
+  issue(w, cC, wC, nC, oC);
+  for (u32 h = w; h < H; h += W) {
+    issue(h + W, cN, wN, nN, oN);                      // (past the end: the last half-group again, ignored)
+    u32 du[2];
+    bool act[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                      // my unit's row: in the frontier?  its distance NOW
+      const bool real = nC[j] != 0u;                   // (padding units: owner n)
+      const u32 o = real ? oC[j] : 0u;
+      const u32 fw = fbits[o >> 5];
+      du[j] = dist[o];
+      act[j] = real && ((fw >> (o & 31u)) & 1u);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                      // (one unit load at a time: 64 registers per lane)
+      const u32 have = act[j] ? nC[j] : 0u;
+      const u32 e0 = sub * 4u;
+      const float base = __uint_as_float(du[j]);
+      u32 dd[4], nd[4], gi[4], old[4];
+      bool live[4];
+      dd[0] = e0 + 0u < have ? cC[j].x : 0xFFFFFFFFu; dd[1] = e0 + 1u < have ? cC[j].y : 0xFFFFFFFFu;
+      dd[2] = e0 + 2u < have ? cC[j].z : 0xFFFFFFFFu; dd[3] = e0 + 3u < have ? cC[j].w : 0xFFFFFFFFu;
+      nd[0] = __float_as_uint(base + wC[j].x); nd[1] = __float_as_uint(base + wC[j].y);
+      nd[2] = __float_as_uint(base + wC[j].z); nd[3] = __float_as_uint(base + wC[j].w);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gi[k] = sssp_gather_index(dd[k], nd[k], hot16, hot_n, live[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) old[k] = dist[gi[k]];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (live[k] && nd[k] < old[k]) {
+          atomicMin(dist + dd[k], nd[k]);
+          mark[dd[k]] = 1;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { cC[j] = cN[j]; wC[j] = wN[j]; nC[j] = nN[j]; oC[j] = oN[j]; }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void sssp_dense_short(const sssp_args_t& a, const unsigned short* hot16, u32 hot_n, u32 block, u32 nblocks) {
+  constexpr int NW = NT / WAVE;
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+  const u32 b0 = a.vs_v[0], b1 = a.vs_v[1], b2 = a.vs_v[2], b3 = a.vs_v[3];
+  const u32 s16 = (b1 - b0 + 3u) / 4u, s4 = (b2 - b1 + 15u) / 16u, s1 = (b3 - b2 + 63u) / 64u;
+  const u32 T = s16 + s4 + s1;
+  const u32 W = nblocks * NW, w = block * NW + (u32)wave;
+  const u32* __restrict__ ro = a.row_offsets;
+  const int* __restrict__ col = a.col_indices;
+  const float* __restrict__ wts = a.weights;
+  const u32* __restrict__ fbits = a.frontier_bits;
+  u32* dist = a.dist;
+  unsigned char* mark = a.mark;
+  struct plan_t { u32 e0, cnt, du; };
+  auto plan = [&](u32 s) -> plan_t {
+    plan_t p; p.e0 = 0u; p.cnt = 0u; p.du = SSSP_INF_BITS;
+    u32 lpr_shift, vbase, vend;
+    if (s < s16) { lpr_shift = 4; vbase = b0 + s * 4u; vend = b1; }
+    else if (s < s16 + s4) { lpr_shift = 2; vbase = b1 + (s - s16) * 16u; vend = b2; }
+    else { lpr_shift = 0; vbase = b2 + (s - s16 - s4) * 64u; vend = b3; }
+    const u32 v = vbase + ((u32)lane >> lpr_shift);
+    const u32 sub = (u32)lane & ((1u << lpr_shift) - 1u);
+    const bool in = s < T && v < vend;
+    const u32 vc = in ? v : 0u;
+    const u32 lo = ro[vc], hi = ro[vc + 1];
+    const u32 fw = fbits[vc >> 5];
+    p.du = dist[vc];
+    const u32 deg = hi - lo;
+    if (in && ((fw >> (vc & 31u)) & 1u) && sub * 4u < deg) { p.e0 = lo + sub * 4u; p.cnt = deg - sub * 4u < 4u ? deg - sub * 4u : 4u; }
+    return p;
+  };
+  if (w >= T) return;
+  plan_t pc = plan(w);
+  sssp_u32x4u dc = *(const sssp_u32x4u*)(col + pc.e0);
+  sssp_f32x4u wc = *(const sssp_f32x4u*)(wts + pc.e0);
+  for (u32 s = w; s < T; s += W) {
+    const plan_t pn = plan(s + W);
+    const sssp_u32x4u dn = *(const sssp_u32x4u*)(col + pn.e0);
+    const sssp_f32x4u wn = *(const sssp_f32x4u*)(wts + pn.e0);
+    const float base = __uint_as_float(pc.du);
+    u32 dd[4], nd[4], gi[4], old[4];
+    bool live[4];
+    dd[0] = pc.cnt > 0u ? dc.x : 0xFFFFFFFFu; dd[1] = pc.cnt > 1u ? dc.y : 0xFFFFFFFFu;
+    dd[2] = pc.cnt > 2u ? dc.z : 0xFFFFFFFFu; dd[3] = pc.cnt > 3u ? dc.w : 0xFFFFFFFFu;
+    nd[0] = __float_as_uint(base + wc.x); nd[1] = __float_as_uint(base + wc.y);
+    nd[2] = __float_as_uint(base + wc.z); nd[3] = __float_as_uint(base + wc.w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gi[k] = sssp_gather_index(dd[k], nd[k], hot16, hot_n, live[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) old[k] = dist[gi[k]];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (live[k] && nd[k] < old[k]) {
+        atomicMin(dist + dd[k], nd[k]);
+        mark[dd[k]] = 1;
+      }
+    pc = pn; dc = dn; wc = wn;
+  }
+}
+
+// weights of the unit blocks: ub_w[(ub_first[v] << 6) + k] = weights[row_offsets[v] + k] for the rows that hold units
+__global__ __launch_bounds__(BLOCK) void k_sssp_unit_weights(const int* __restrict__ ro, const float* __restrict__ wts,
+                                                             const int* __restrict__ ub_first, int n, float* __restrict__ ub_w) {
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = ((long long)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * BLOCK) >> 6;
+  for (long long v = wave0; v < n; v += nwaves) {
+    const int u0 = ub_first[v], u1 = ub_first[v + 1];
+    if (u1 == u0) continue;
+    const int r0 = ro[v], deg = ro[v + 1] - r0;
+    const long long e0 = (long long)u0 << 6, e1 = (long long)u1 << 6;
+    for (long long e = e0 + lane; e < e1; e += 64) ub_w[e] = (e - e0) < deg ? wts[r0 + (e - e0)] : 0.0f;
+  }
+}
+
 
 // ---- heavy iterations: the edges by slice of their destination, that slice of the distances in LDS --------------------
 // The relax kernel below gathers the neighbour's distance for every edge: 4 bytes out of a 16 MB array in arbitrary order,
@@ -309,6 +497,13 @@ __global__ __launch_bounds__(NT, 8) void k_sssp_relax(sssp_args_t a, int it) {
     __syncthreads();
   }
   const unsigned short* const hot16 = (const unsigned short*)s_hot;
+
+  if (a.ub_w && (u64)E * (u64)a.dense_div >= a.m_edges) {
+    // a heavy iteration (grid-uniform): every workgroup takes its share of the unit blocks, then of the short rows' classes
+    sssp_dense_long<NT>(a, hot16, hot_n, blockIdx.x, gridDim.x);
+    sssp_dense_short<NT>(a, hot16, hot_n, blockIdx.x, gridDim.x);
+    return;
+  }
 
   const u32 total_waves = gridDim.x * NW;
   u32 per = (E + total_waves - 1) / total_waves;
@@ -673,6 +868,7 @@ struct sssp_fused_state_t {
   mem_t<u32> dist_layout;            // only with a layout: distances in layout order
   mem_t<u32> q_row[2], q_off[2], q_du[2];
   mem_t<u32> frontier_bits;          // the frontier as a bitmap (sssp_sliced_body; allocated on demand)
+  unsigned dense_div = 4;            // an iteration whose frontier holds >= m / dense_div edges sweeps the unit blocks (sssp_dense_*; 0: never)
   unsigned sliced_div = 0;           // an iteration whose frontier holds >= m / sliced_div edges streams the sliced edge list (0: never --
                                      // the default: measured 2.59 ms (div 3) / 2.54 (2) / 2.82 (6) against 2.47 ms without, RMAT-22)
   mem_t<bfs_ctrl_t> ctrl;
@@ -740,6 +936,21 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   a.m_edges = sliced ? (unsigned long long)layout->m_edges : 0ull;
   a.sliced_div = sdiv;
   a.frontier_bits = sliced ? st.frontier_bits.data() : nullptr;
+  // heavy iterations as a sweep over the layout's unit blocks and degree classes (sssp_dense_*): needs the frontier as a
+  // bitmap (k_sssp_build2 writes it) and the plain loop (near / far buckets park vertices outside the queue)
+  unsigned ddiv = st.dense_div;
+  if (const char* e = getenv("MGX_SSSP_DENSE")) ddiv = (unsigned)atoi(e);
+  const bool dense = layout && layout->ub_w && layout->ub_col && layout->ub_cnt && layout->ub_owner && layout->ub_units_pad >= 16 &&
+                     layout->vs_v[3] >= layout->vs_v[0] && layout->m_edges > 0 && build2 && ddiv > 0 && a.delta == 0.f;
+  if (dense && !st.frontier_bits.size()) st.frontier_bits = mem_t<u32>(((size_t)st.n + 31) / 32 + 4, ctx);
+  a.ub_col = dense ? layout->ub_col : nullptr;
+  a.ub_w = dense ? layout->ub_w : nullptr;
+  a.ub_cnt = dense ? layout->ub_cnt : nullptr;
+  a.ub_owner = dense ? layout->ub_owner : nullptr;
+  a.ub_units_pad = dense ? layout->ub_units_pad : 0u;
+  for (int i = 0; i < 4; ++i) a.vs_v[i] = dense ? layout->vs_v[i] : 0u;
+  a.dense_div = dense ? ddiv : 0u;
+  if (dense) { a.m_edges = (unsigned long long)layout->m_edges; a.frontier_bits = st.frontier_bits.data(); }
   const char* const hme = getenv("MGX_SSSP_HOT_MIN_EDGES");        // (tests force the LDS bounds on small graphs)
   a.hot_min_edges = hme ? (u32)atoll(hme) : SSSP_HOT_MIN_EDGES;
   hipLaunchKernelGGL(k_sssp_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src,

@@ -167,6 +167,7 @@ SIGNATURES = {
     "mgx_sssp_run": [_vp, _i, _pi64],
     "mgx_sssp_run_delta": [_vp, _i, _f, _pi64],
     "mgx_sssp_set_kernel_timing": [_vp, _i],
+    "mgx_sssp_iteration_trace": [_vp, _i, _pi64, _pi64, _pf, _pi],
     "mgx_sssp_kernel_times": [_vp, _pi64],
     "mgx_pr_create": [_vp, _i, _pvp],
     "mgx_pr_free": [_vp],

@@ -473,6 +473,12 @@ class SsspProblem:
     def set_kernel_timing(self, on=True):
         check(lib.mgx_sssp_set_kernel_timing(self._h, int(bool(on))))
 
+    def iteration_trace(self, cap=63):
+        """[(frontier vertices, edges relaxed, ms)] of the last run()'s iterations (device-side timestamps)"""
+        nf, ne, ms, it = (C.c_int64 * cap)(), (C.c_int64 * cap)(), (C.c_float * cap)(), C.c_int()
+        check(lib.mgx_sssp_iteration_trace(self._h, cap, nf, ne, ms, C.byref(it)))
+        return [(nf[i], ne[i], ms[i]) for i in range(min(it.value, cap))]
+
     def kernel_times(self):
         """{launches, ns} of k_sssp_relax in the last run() (after set_kernel_timing)"""
         c = (C.c_int64 * 2)()

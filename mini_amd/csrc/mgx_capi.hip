@@ -346,7 +346,7 @@ extern "C" int mgx_units_build_device(const int* ro, const int* ci, int n, int m
 static void build_unit_blocks(mgx_graph_s* g) {
   graph_device_t& G = *g->g;
   G.d_ub_col = mem_t<int>(); G.d_ub_owner = mem_t<int>(); G.ub_units = G.ub_units_pad = 0; G.ub_min_degree = 0;
-  G.d_ub_cnt = mem_t<unsigned char>(); G.d_ub_first = mem_t<int>(); G.nr_big_rows = 0;
+  G.d_ub_cnt = mem_t<unsigned char>(); G.d_ub_first = mem_t<int>(); G.nr_big_rows = 0; G.d_ub_w = mem_t<float>(); G.ub_w_tried = false;
   if (const char* e = getenv("MGX_BFS_UNITS")) if (atoi(e) == 0) return;
   int long_min = 64;
   if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
@@ -461,7 +461,7 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
   mem_t<int> lro(n + 1, ctx), lci(m + 8, ctx), n2o(n, ctx), o2n(n, ctx);     // (+8: slack and four -1 for bfs_fused_vshort.hpp)
   MGX_HIP(hipMemsetAsync(lci.data() + m, 0xFF, 8 * sizeof(int), ctx.stream()));
   mem_t<float> lw;
-  if (with_weights) lw = mem_t<float>(m, ctx);
+  if (with_weights) lw = mem_t<float>(m + 8, ctx);          // (+8: the short rows' 16-byte weight loads of sssp_dense_short may reach past the last entry)
   const int rc = mgx_layout_build_device(G.d_row_offsets.data(), G.d_col_indices.data(),
                                          with_weights ? G.d_col_values.data() : (const float*)nullptr, (int)n, (long long)m,
                                          lro.data(), lci.data(), with_weights ? lw.data() : (float*)nullptr, n2o.data(),
@@ -1556,6 +1556,24 @@ static void ensure_sliced_edges(mgx_graph_s* g) {
   G.d_e_src = std::move(es); G.d_e_dst = std::move(ed); G.d_e_w = std::move(ew); G.d_slice_off = std::move(so);
   G.sliced_slices = slices;
 }
+// Weights of the unit blocks' entries (mgx/sssp_fused.hpp: sssp_dense_long), once per graph at its first fused SSSP run:
+// 4 bytes per padded long-row entry; skipped (the queue walk serves every iteration) when the memory is not there.
+static void ensure_unit_weights(mgx_graph_s* g) {
+  graph_device_t& G = *g->g;
+  if (G.ub_w_tried) return;
+  G.ub_w_tried = true;
+  if (!G.has_layout || !G.has_layout_weights || G.ub_units <= 0 || !G.d_ub_first.size() || G.vs_long_min != 64 || G.ub_min_degree != 64) return;
+  if (const char* e = getenv("MGX_SSSP_DENSE")) if (atoi(e) == 0) return;
+  standard_context_t& ctx = *g->c->ctx;
+  float* w = nullptr;
+  const size_t entries = ((size_t)G.ub_units_pad << 6) + 4;
+  if (hipMalloc((void**)&w, entries * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return; }
+  G.d_ub_w = mem_t<float>::adopt(w, entries);
+  MGX_HIP(hipMemsetAsync(w, 0, entries * sizeof(float), ctx.stream()));
+  hipLaunchKernelGGL(mgx::k_sssp_unit_weights, dim3(4096), dim3(mgx::BLOCK), 0, ctx.stream(), G.d_layout_row_offsets.data(),
+                     G.d_layout_col_values.data(), G.d_ub_first.data(), G.num_nodes, w);
+  MGX_CHECK_LAUNCH("unit-block weights");
+}
 int mgx_sssp_run(mgx_sssp_t p, int src, int64_t* stats) { return mgx_sssp_run_delta(p, src, -1.0f, stats); }
 int mgx_sssp_run_delta(mgx_sssp_t p, int src, float delta, int64_t* stats) {
   // device-resident loop (include/mgx/sssp_fused.hpp): distances identical to mgx_sssp_enact's; predecessors are
@@ -1579,6 +1597,13 @@ int mgx_sssp_run_delta(mgx_sssp_t p, int src, float delta, int64_t* stats) {
     layout.weights = G.d_layout_col_values.data();
     layout.new_of_old = G.d_new_of_old.data();
     layout.old_of_new = G.d_old_of_new.data();
+    ensure_unit_weights(p->g);
+    if (G.d_ub_w.size()) {
+      layout.ub_col = G.d_ub_col.data(); layout.ub_w = G.d_ub_w.data(); layout.ub_cnt = G.d_ub_cnt.data(); layout.ub_owner = G.d_ub_owner.data();
+      layout.ub_units_pad = (unsigned)G.ub_units_pad;
+      for (int i = 0; i < 4; ++i) layout.vs_v[i] = G.vs_v[i];
+      layout.m_edges = (long long)G.num_edges;
+    }
     ensure_sliced_edges(p->g);
     if (G.sliced_slices > 0) {
       layout.e_src = G.d_e_src.data(); layout.e_dst = G.d_e_dst.data(); layout.e_w = G.d_e_w.data();
@@ -1592,6 +1617,20 @@ int mgx_sssp_run_delta(mgx_sssp_t p, int src, float delta, int64_t* stats) {
     stats[0] = p->fused->host_ctrl->levels;
     stats[1] = (int64_t)p->fused->host_ctrl->sum_edges;
     stats[2] = (int64_t)p->fused->host_ctrl->sum_frontier;
+  }
+  MGX_CATCH
+}
+int mgx_sssp_iteration_trace(mgx_sssp_t p, int cap, int64_t* frontier, int64_t* edges, float* ms, int* iterations) {
+  MGX_TRY
+  MGX_REQUIRE(p && iterations, "NULL argument");
+  MGX_REQUIRE(p->fused != nullptr, "mgx_sssp_iteration_trace: no mgx_sssp_run yet");
+  const mgx::bfs_ctrl_t* hc = p->fused->host_ctrl;
+  const int it = hc->levels < 63 ? hc->levels : 63;
+  *iterations = hc->levels;
+  for (int i = 0; i < it && i < cap; ++i) {
+    if (frontier) frontier[i] = (int64_t)(hc->trace[i] >> mgx::BFS_VSHIFT);
+    if (edges) edges[i] = (int64_t)(hc->trace[i] & mgx::BFS_EMASK);
+    if (ms) ms[i] = (hc->stamp[i + 1] >= hc->stamp[i] && hc->stamp[i + 1] != 0) ? (float)((double)(hc->stamp[i + 1] - hc->stamp[i]) / 1e5) : 0.f;
   }
   MGX_CATCH
 }
