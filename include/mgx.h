@@ -335,6 +335,14 @@ MGX_API int mgx_dbfs2_or_maps(mgx_dbfs2_t h, const unsigned* d_maps, int maps, i
  * exchange the bitmaps and call mgx_dbfs2_merge* as before | 0: the level is merged (every listed vertex decided once on
  * every rank, the owner's labels and next queues written); sum of the counts (0: no rank discovered anything -- the
  * traversal is over); 0 }.  It waits for that verdict only (a spin on pinned memory), not for the stream.             */
+/* A rank's shard of the symmetrised R-MAT graph (scale, edgefactor, seed) under this layout, built inside the library on
+ * the rank's GPU with no communication (every rank derives the same hub-first permutation from the same counter-based pair
+ * stream): mgx_dbfs2_shard_plan makes the permutation and says how many rows and entries the rank holds; the caller
+ * allocates; mgx_dbfs2_shard_fill writes local row offsets (n_local + 1), global neighbour ids (m_local) and, where not
+ * NULL, new_of_old / old_of_new / degree_of_new (n each); mgx_dbfs2_shard_free releases the plan.  Untimed setup.     */
+MGX_API int mgx_dbfs2_shard_plan(mgx_ctx_t ctx, int scale, int edgefactor, uint64_t seed, int ranks, int rank, void** plan, int* n_local, int64_t* m_local);
+MGX_API int mgx_dbfs2_shard_fill(mgx_ctx_t ctx, void* plan, int* d_row_offsets_local, int* d_col_indices, int* d_new_of_old, int* d_old_of_new, int* d_degree_of_new);
+MGX_API int mgx_dbfs2_shard_free(void* plan);
 MGX_API int mgx_dbfs2_list_words(int n_global, int ranks, int64_t* words);
 MGX_API int mgx_dbfs2_set_list(mgx_dbfs2_t h, unsigned* d_list, int64_t words);
 MGX_API int mgx_dbfs2_apply_lists(mgx_dbfs2_t h, int level, const unsigned* d_lists, int lists, int64_t stride_words, int64_t* out3);

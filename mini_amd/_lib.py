@@ -147,6 +147,9 @@ SIGNATURES = {
     "mgx_dbfs2_reset": [_vp, _i],
     "mgx_dbfs2_words": [_i, _pi64],
     "mgx_dbfs2_status": [_vp, _i, _pi64],
+    "mgx_dbfs2_shard_plan": [_vp, _i, _i, _u64, _i, _i, _pvp, _pi, _pi64],
+    "mgx_dbfs2_shard_fill": [_vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mgx_dbfs2_shard_free": [_vp],
     "mgx_dbfs2_list_words": [_i, _i, _pi64],
     "mgx_dbfs2_set_list": [_vp, _vp, _i64],
     "mgx_dbfs2_apply_lists": [_vp, _i, _vp, _i, _i64, _pi64],

@@ -14,6 +14,7 @@
 #include "mgx/bfs_dist.hpp"
 #include "mgx/bfs_dist2.hpp"
 #include "mgx/sssp_dist.hpp"
+#include "mgx/rmat.hpp"
 #include "mgx/sssp_fused.hpp"
 #include "mgx.h"
 
@@ -1319,6 +1320,38 @@ int mgx_dbfs2_or_maps(mgx_dbfs2_t h, const unsigned* d_maps, int maps, int64_t s
                        (uint4*)d_out);
   MGX_CATCH
 }
+extern "C" int mgx_shard_plan_device(int scale, int edgefactor, unsigned long long seed, int ranks, int rank, void** handle, int* n_local,
+                                     long long* m_local, hipStream_t stream);
+extern "C" int mgx_shard_fill_device(void* handle, int* row_offsets, int* col, int* new_of_old, int* old_of_new, int* deg_of_new,
+                                     hipStream_t stream);
+extern "C" void mgx_shard_free_device(void* handle);
+int mgx_dbfs2_shard_plan(mgx_ctx_t c, int scale, int edgefactor, uint64_t seed, int ranks, int rank, void** plan, int* n_local, int64_t* m_local) {
+  MGX_TRY
+  MGX_REQUIRE(c && plan && n_local && m_local, "NULL argument");
+  MGX_REQUIRE(scale >= 1 && scale <= 30 && edgefactor >= 1 && ranks >= 1 && ranks <= 64 && rank >= 0 && rank < ranks,
+              "mgx_dbfs2_shard_plan: bad argument");
+  use_device(c);
+  long long m = 0;
+  const int rc = mgx_shard_plan_device(scale, edgefactor, (unsigned long long)seed, ranks, rank, plan, n_local, &m, c->ctx->stream());
+  if (rc != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("mgx_dbfs2_shard_plan: ") + hipGetErrorString((hipError_t)rc));
+  MGX_REQUIRE(m < (1ll << 31), "mgx_dbfs2_shard_plan: more than 2^31 - 1 entries on one rank (int32 local offsets)");
+  *m_local = m;
+  MGX_CATCH
+}
+int mgx_dbfs2_shard_fill(mgx_ctx_t c, void* plan, int* d_row_offsets_local, int* d_col_indices, int* d_new_of_old, int* d_old_of_new,
+                         int* d_degree_of_new) {
+  MGX_TRY
+  MGX_REQUIRE(c && plan && d_row_offsets_local, "NULL argument");
+  use_device(c);
+  const int rc = mgx_shard_fill_device(plan, d_row_offsets_local, d_col_indices, d_new_of_old, d_old_of_new, d_degree_of_new, c->ctx->stream());
+  if (rc != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("mgx_dbfs2_shard_fill: ") + hipGetErrorString((hipError_t)rc));
+  MGX_CATCH
+}
+int mgx_dbfs2_shard_free(void* plan) {
+  MGX_TRY
+  mgx_shard_free_device(plan);
+  MGX_CATCH
+}
 int mgx_dbfs2_list_words(int n_global, int ranks, int64_t* words) {
   MGX_TRY
   MGX_REQUIRE(words && n_global > 0 && ranks >= 1 && ranks <= 64, "mgx_dbfs2_list_words: bad argument");
@@ -1693,40 +1726,17 @@ int mgx_pr_ranks(mgx_pr_t p, float* host) {
 
 // ---- R-MAT generator (spec: oracle/oracle.c orc_rmat_edges) -----------------------
 namespace {
-__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-__device__ __forceinline__ unsigned scramble(unsigned v, int scale, unsigned mask) {
-  v = (v * 0x9E3779B1u + 0x7F4A7C15u) & mask;
-  v = __brev(v) >> (32 - scale);
-  v = (v * 0x85EBCA6Bu + 0xC2B2AE35u) & mask;
-  return v;
-}
 __global__ void k_rmat_edges(int scale, long long first_edge, long long count, unsigned long long seed, int do_scramble,
                              int* __restrict__ src, int* __restrict__ dst, float* __restrict__ weight) {
-  const unsigned long long K0 = 0xD1B54A32D192ED03ull, K1 = 0x8CB92BA72F3D8DD7ull, K2 = 0xA24BAED4963EE407ull;
-  const unsigned A = 2448131358u, AB = 3264175144u, ABC = 4080218931u;
-  const unsigned mask = (scale >= 32) ? 0xFFFFFFFFu : ((1u << scale) - 1u);
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (; i < count; i += stride) {
     const unsigned long long e = (unsigned long long)(first_edge + i);
-    const unsigned long long x = mix64(seed * K0 + e);
-    unsigned s = 0, d = 0;
-    for (int l = 0; l < scale; ++l) {
-      const unsigned u = (unsigned)(mix64(x + (unsigned long long)(l + 1) * K1) >> 32);
-      const unsigned sb = (u >= AB) ? 1u : 0u;
-      const unsigned db = (u < A) ? 0u : (u < AB) ? 1u : (u < ABC) ? 0u : 1u;
-      s = (s << 1) | sb;
-      d = (d << 1) | db;
-    }
-    if (do_scramble) { s = scramble(s, scale, mask); d = scramble(d, scale, mask); }
+    unsigned s, d;
+    mgx::rmat_pair(scale, seed, e, do_scramble, s, d);
     src[i] = (int)s;
     dst[i] = (int)d;
-    if (weight) weight[i] = (float)(mix64(seed * K0 + e + K2) % 64ull);
+    if (weight) weight[i] = mgx::rmat_weight(seed, e);
   }
 }
 }  // namespace

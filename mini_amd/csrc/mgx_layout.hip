@@ -428,3 +428,166 @@ extern "C" int mgx_sliced_build_device(const int* ro, const int* ci, const float
   LAY_TRY(hipMemsetAsync(e_w + m, 0, 4096 * 4, stream));
   return (int)hipStreamSynchronize(stream);
 }
+
+// ---- a rank's shard of the partitioned R-MAT graph (mgx/bfs_dist2.hpp; mgx_dbfs2_shard_*) ------------------------------
+// What mini_amd.dist_bfs.rmat_cyclic_shard did with torch device ops, inside the library: the symmetrised R-MAT graph of
+// (scale, edgefactor, seed) under the generation-2 layout -- vertices renumbered hub-first by GLOBAL degree (every rank
+// derives the same permutation from the same counter-based pair stream: no communication), vertex v owned by rank
+// v % ranks, local row v / ranks, neighbour ids global.
+//   plan   one pass over the pair stream: global degrees (atomic adds), stable sort by descending degree -> old_of_new,
+//          new_of_old; the rank's rows and entries are then known (n_local, m_local)
+//   fill   a second pass: both directions of every pair whose (new) row this rank owns as keys (local row << 32 | neighbour)
+//          into a buffer of exactly m_local keys, one 64-bit radix sort, split into row offsets and neighbour ids
+// Every rank generates the WHOLE pair stream twice (RMAT-26: 2^30 pairs, ~40 hash rounds each: tens of milliseconds on one
+// MI355X) instead of generating a share and shuffling 17 GB of pairs between the ranks.
+#include "mgx/rmat.hpp"
+namespace {
+
+__global__ void k_shard_degrees(int scale, long long first, long long count, unsigned long long seed, int* __restrict__ deg) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+    unsigned s, d;
+    mgx::rmat_pair(scale, seed, (unsigned long long)(first + i), 1, s, d);
+    atomicAdd(deg + s, 1);                  // (the symmetrised CSR holds every pair in both directions)
+    atomicAdd(deg + d, 1);
+  }
+}
+__global__ void k_iota(int n, int* __restrict__ ids) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ids[i] = (int)i;
+}
+// local row i of the rank = new vertex i * ranks + rank: its degree
+__global__ void k_shard_local_degrees(const int* __restrict__ deg_sorted, int n, int ranks, int rank, int n_local, int* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_local) out[i] = deg_sorted[i * ranks + rank];
+}
+__global__ void k_shard_keys(int scale, long long first, long long count, unsigned long long seed, const int* __restrict__ new_of_old,
+                             int ranks, int rank, unsigned long long* __restrict__ keys, unsigned long long* cursor,
+                             unsigned long long cap) {
+  const int lane = (int)(threadIdx.x & 63);
+  for (long long i0 = (long long)blockIdx.x * blockDim.x; i0 < count; i0 += (long long)gridDim.x * blockDim.x) {   // (block-uniform trips)
+    const long long i = i0 + threadIdx.x;
+    unsigned long long k0 = 0, k1 = 0;
+    int have = 0;
+    if (i < count) {
+      unsigned s, d;
+      mgx::rmat_pair(scale, seed, (unsigned long long)(first + i), 1, s, d);
+      const unsigned ns = (unsigned)new_of_old[s], nd = (unsigned)new_of_old[d];
+      // pair (u, v): CSR row v holds u (graph.hxx F9 orientation), and the swapped copy: row u holds v
+      if ((int)(nd % (unsigned)ranks) == rank) { k0 = ((unsigned long long)(nd / (unsigned)ranks) << 32) | ns; have = 1; }
+      if ((int)(ns % (unsigned)ranks) == rank) { (have ? k1 : k0) = ((unsigned long long)(ns / (unsigned)ranks) << 32) | nd; have += 1; }
+    }
+    // wave-aggregated append
+    int inc = have;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) { const int y = __shfl_up(inc, dlt, 64); if (lane >= dlt) inc += y; }
+    const int tot = __shfl(inc, 63, 64);
+    unsigned long long base = 0;
+    if (lane == 63 && tot) base = atomicAdd(cursor, (unsigned long long)tot);
+    base = __shfl(base, 63, 64);
+    const unsigned long long at = base + (unsigned long long)(inc - have);
+    if (have >= 1 && at < cap) keys[at] = k0;
+    if (have == 2 && at + 1 < cap) keys[at + 1] = k1;
+  }
+}
+__global__ void k_shard_split(const unsigned long long* __restrict__ keys, long long m, int* __restrict__ col) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x)
+    col[i] = (int)(keys[i] & 0xFFFFFFFFull);
+}
+
+struct shard_plan_t {
+  int scale = 0, edgefactor = 0, ranks = 1, rank = 0, n = 0, n_local = 0;
+  unsigned long long seed = 0;
+  long long m_local = 0;
+  tmp_t deg_sorted, old_of_new, new_of_old, ro_local;
+};
+
+}  // namespace
+
+// plan: *handle owns device arrays until mgx_shard_free_device; n_local / m_local tell the caller what to allocate
+extern "C" int mgx_shard_plan_device(int scale, int edgefactor, unsigned long long seed, int ranks, int rank, void** handle, int* n_local,
+                                     long long* m_local, hipStream_t stream) {
+  *handle = nullptr;
+  shard_plan_t* P = new shard_plan_t();
+  P->scale = scale; P->edgefactor = edgefactor; P->seed = seed; P->ranks = ranks; P->rank = rank;
+  const int n = 1 << scale;
+  P->n = n;
+  P->n_local = (n - rank + ranks - 1) / ranks;
+  const long long total = (long long)edgefactor * n;
+  tmp_t deg, ids;
+  const int threads = 256;
+  const unsigned nb = (unsigned)(((long long)n + threads - 1) / threads);
+#define SHARD_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { delete P; return (int)e_; } } while (0)
+  SHARD_TRY(deg.alloc((size_t)n * 4)); SHARD_TRY(ids.alloc((size_t)n * 4));
+  SHARD_TRY(P->deg_sorted.alloc((size_t)n * 4)); SHARD_TRY(P->old_of_new.alloc((size_t)n * 4)); SHARD_TRY(P->new_of_old.alloc((size_t)n * 4));
+  SHARD_TRY(hipMemsetAsync(deg.p, 0, (size_t)n * 4, stream));
+  const long long chunk = 1ll << 28;
+  for (long long first = 0; first < total; first += chunk) {
+    const long long cnt = total - first < chunk ? total - first : chunk;
+    hipLaunchKernelGGL(k_shard_degrees, dim3(8192), dim3(threads), 0, stream, scale, first, cnt, seed, deg.as<int>());
+  }
+  hipLaunchKernelGGL(k_iota, dim3(nb), dim3(threads), 0, stream, n, ids.as<int>());
+  size_t bytes = 0;
+  tmp_t scratch;
+  SHARD_TRY(rocprim::radix_sort_pairs_desc(nullptr, bytes, deg.as<int>(), P->deg_sorted.as<int>(), ids.as<int>(), P->old_of_new.as<int>(),
+                                           (size_t)n, 0, 32, stream));
+  SHARD_TRY(scratch.alloc(bytes));
+  SHARD_TRY(rocprim::radix_sort_pairs_desc(scratch.p, bytes, deg.as<int>(), P->deg_sorted.as<int>(), ids.as<int>(), P->old_of_new.as<int>(),
+                                           (size_t)n, 0, 32, stream));
+  hipLaunchKernelGGL(k_invert, dim3(nb), dim3(threads), 0, stream, P->old_of_new.as<int>(), n, P->new_of_old.as<int>());
+  // local row offsets: exclusive scan of the owned vertices' degrees
+  tmp_t ldeg, st;
+  SHARD_TRY(ldeg.alloc(((size_t)P->n_local + 1) * 4)); SHARD_TRY(P->ro_local.alloc(((size_t)P->n_local + 1) * 4));
+  SHARD_TRY(hipMemsetAsync(ldeg.p, 0, ((size_t)P->n_local + 1) * 4, stream));
+  hipLaunchKernelGGL(k_shard_local_degrees, dim3((unsigned)(((long long)P->n_local + threads - 1) / threads)), dim3(threads), 0, stream,
+                     P->deg_sorted.as<int>(), n, ranks, rank, P->n_local, ldeg.as<int>());
+  size_t sb = 0;
+  SHARD_TRY(rocprim::exclusive_scan(nullptr, sb, ldeg.as<int>(), P->ro_local.as<int>(), 0, (size_t)P->n_local + 1, rocprim::plus<int>(), stream));
+  SHARD_TRY(st.alloc(sb));
+  SHARD_TRY(rocprim::exclusive_scan(st.p, sb, ldeg.as<int>(), P->ro_local.as<int>(), 0, (size_t)P->n_local + 1, rocprim::plus<int>(), stream));
+  int last = 0;
+  SHARD_TRY(hipMemcpyAsync(&last, P->ro_local.as<int>() + P->n_local, 4, hipMemcpyDeviceToHost, stream));
+  SHARD_TRY(hipStreamSynchronize(stream));
+  P->m_local = last;
+  *handle = P; *n_local = P->n_local; *m_local = P->m_local;
+  return 0;
+}
+
+// fill: row_offsets (n_local + 1), col (m_local), new_of_old / old_of_new / deg_of_new (n each; any may be NULL) -- device buffers
+extern "C" int mgx_shard_fill_device(void* handle, int* row_offsets, int* col, int* new_of_old, int* old_of_new, int* deg_of_new,
+                                     hipStream_t stream) {
+  shard_plan_t* P = (shard_plan_t*)handle;
+  if (!P) return (int)hipErrorInvalidValue;
+  const int n = P->n;
+  LAY_TRY(hipMemcpyAsync(row_offsets, P->ro_local.p, ((size_t)P->n_local + 1) * 4, hipMemcpyDeviceToDevice, stream));
+  if (new_of_old) LAY_TRY(hipMemcpyAsync(new_of_old, P->new_of_old.p, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+  if (old_of_new) LAY_TRY(hipMemcpyAsync(old_of_new, P->old_of_new.p, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+  if (deg_of_new) LAY_TRY(hipMemcpyAsync(deg_of_new, P->deg_sorted.p, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+  const long long m = P->m_local;
+  if (m <= 0) { LAY_TRY(hipStreamSynchronize(stream)); return 0; }
+  tmp_t keys, keys_sorted, cursor, scratch;
+  LAY_TRY(keys.alloc((size_t)m * 8)); LAY_TRY(keys_sorted.alloc((size_t)m * 8)); LAY_TRY(cursor.alloc(8));
+  LAY_TRY(hipMemsetAsync(cursor.p, 0, 8, stream));
+  const long long total = (long long)P->edgefactor * n;
+  const long long chunk = 1ll << 28;
+  for (long long first = 0; first < total; first += chunk) {
+    const long long cnt = total - first < chunk ? total - first : chunk;
+    hipLaunchKernelGGL(k_shard_keys, dim3(8192), dim3(256), 0, stream, P->scale, first, cnt, P->seed, P->new_of_old.as<int>(), P->ranks,
+                       P->rank, keys.as<unsigned long long>(), cursor.as<unsigned long long>(), (unsigned long long)m);
+  }
+  unsigned long long filled = 0;
+  LAY_TRY(hipMemcpyAsync(&filled, cursor.p, 8, hipMemcpyDeviceToHost, stream));
+  LAY_TRY(hipStreamSynchronize(stream));
+  if ((long long)filled != m) return (int)hipErrorUnknown;        // (the two passes must agree: same stream, same permutation)
+  int row_bits = 1;
+  while (row_bits < 31 && (1ll << row_bits) < (long long)P->n_local) ++row_bits;
+  size_t bytes = 0;
+  LAY_TRY(rocprim::radix_sort_keys(nullptr, bytes, keys.as<unsigned long long>(), keys_sorted.as<unsigned long long>(), (size_t)m, 0,
+                                   32 + row_bits, stream));
+  LAY_TRY(scratch.alloc(bytes));
+  LAY_TRY(rocprim::radix_sort_keys(scratch.p, bytes, keys.as<unsigned long long>(), keys_sorted.as<unsigned long long>(), (size_t)m, 0,
+                                   32 + row_bits, stream));
+  hipLaunchKernelGGL(k_shard_split, dim3(8192), dim3(256), 0, stream, keys_sorted.as<unsigned long long>(), m, col);
+  LAY_TRY(hipStreamSynchronize(stream));
+  return 0;
+}
+extern "C" void mgx_shard_free_device(void* handle) { delete (shard_plan_t*)handle; }

@@ -469,11 +469,33 @@ def cyclic_shard_from_csr(ro, ci, ranks, rank):
     return ro_l.astype(np.int32), ci_l, new_of_old.astype(np.int32), old_of_new.astype(np.int32)
 
 
-def rmat_cyclic_shard(ctx, scale, edgefactor, seed, ranks, rank, device, pairs_per_chunk=1 << 26):
+def rmat_cyclic_shard(ctx, scale, edgefactor, seed, ranks, rank, device):
     """Local CSR of the symmetrised R-MAT graph under the generation-2 layout: vertices renumbered
     hub-first by GLOBAL degree (every rank derives the same permutation from the same pair stream),
-    vertex v owned by rank v % ranks, local row v // ranks, neighbour ids global.
+    vertex v owned by rank v % ranks, local row v // ranks, neighbour ids global.  Built inside the library
+    (mgx_dbfs2_shard_plan / _fill: mgx_layout.hip); this function only allocates the result tensors.
     Returns (row_offsets_local, col_indices, new_of_old, old_of_new, degree_of_new) as device tensors."""
+    n = 1 << scale
+    plan, nl, ml = C.c_void_p(), C.c_int(), C.c_int64()
+    check(lib.mgx_dbfs2_shard_plan(ctx._h, int(scale), int(edgefactor), C.c_uint64(seed), int(ranks), int(rank), C.byref(plan),
+                                   C.byref(nl), C.byref(ml)))
+    try:
+        ro = torch.empty(nl.value + 1, dtype=torch.int32, device=device)
+        col = torch.empty(max(ml.value, 1), dtype=torch.int32, device=device)[: ml.value]
+        new_of_old = torch.empty(n, dtype=torch.int32, device=device)
+        old_of_new = torch.empty(n, dtype=torch.int32, device=device)
+        deg_new = torch.empty(n, dtype=torch.int32, device=device)
+        torch.cuda.synchronize(device)
+        check(lib.mgx_dbfs2_shard_fill(ctx._h, plan, C.c_void_p(ro.data_ptr()), C.c_void_p(col.data_ptr() if ml.value else 0),
+                                       C.c_void_p(new_of_old.data_ptr()), C.c_void_p(old_of_new.data_ptr()), C.c_void_p(deg_new.data_ptr())))
+    finally:
+        lib.mgx_dbfs2_shard_free(plan)
+    return ro, col, new_of_old, old_of_new, deg_new.to(torch.int64)
+
+
+def rmat_cyclic_shard_torch(ctx, scale, edgefactor, seed, ranks, rank, device, pairs_per_chunk=1 << 26):
+    """the same with torch device ops (the first implementation): kept as the cross-check of the library's builder
+    (tests/test_dist.py)"""
     n = 1 << scale
     total = edgefactor * n
     deg = torch.zeros(n, dtype=torch.int64, device=device)

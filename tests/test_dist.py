@@ -349,3 +349,32 @@ def test_bench_main_native_rccl_loop_one_rank(built, exchange, collectives):
                                                 "MGX_DIST_FORCE_COLLECTIVES": collectives, "MGX_DIST_EXCHANGE": exchange})
     assert j["n_gpus"] == 1 and j["parity_vs_oracle"] is True and j["value"] > 0
     assert j["config"]["native_loop"] is True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale,ranks", [(10, 1), (12, 3), (14, 8)])
+def test_library_shard_builder_equals_the_torch_one(built, scale, ranks):
+    """mgx_dbfs2_shard_plan / _fill (the rank's shard built inside the library: global degrees, hub-first permutation, the
+    rank's rows as sorted keys) against the torch-op construction it replaces: the same row offsets, neighbour ids, id maps
+    and degrees for every rank; and against the oracle's graph: relabelling the shard's rows back gives the CSR's rows"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import mini_amd
+    from mini_amd.dist_bfs import rmat_cyclic_shard, rmat_cyclic_shard_torch
+    from tests.oracle_binding import Oracle
+    ctx = mini_amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    dev = torch.device("cuda", 0)
+    n, ro, ci, _ = Oracle().rmat_csr(scale, 16, 77 + scale)
+    for rank in range(ranks):
+        a = rmat_cyclic_shard(ctx, scale, 16, 77 + scale, ranks, rank, dev)
+        b = rmat_cyclic_shard_torch(ctx, scale, 16, 77 + scale, ranks, rank, dev)
+        for x, y, what in zip(a, b, ("row offsets", "neighbours", "new_of_old", "old_of_new", "degrees")):
+            assert torch.equal(x.to(torch.int64), y.to(torch.int64)), (rank, what)
+        ro_l, col, new_of_old, old_of_new = (t.cpu().numpy() for t in a[:4])
+        assert ro_l[-1] == len(col)
+        for i in (0, 1, len(ro_l) // 2, len(ro_l) - 2):
+            if i < 0 or i >= len(ro_l) - 1:
+                continue
+            v_old = old_of_new[i * ranks + rank]
+            want = np.sort(new_of_old[ci[ro[v_old]:ro[v_old + 1]]])
+            assert np.array_equal(col[ro_l[i]:ro_l[i + 1]], want), (rank, i)
