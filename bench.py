@@ -477,9 +477,9 @@ def bench_sssp(args, ctx, stream):
     avg_launch_s = (k_ns / 1e9) / max(k_launch, 1)
     achieved = (k_bytes / max(k_launch, 1)) / max(avg_launch_s, 1e-12) / 1e9
     sha = source_sha()
-    traffic, traffic_note = _pmc_traffic(args, "k_sssp_relax<1024>", sha)
+    traffic, traffic_note = _pmc_traffic(args, "k_sssp_relax<1024> (+ k_sssp_relax_dense<1024> on heavy iterations)", sha)
     K = max(len(timed), 1)
-    roofline = {"bound": "hbm", "kernel": "k_sssp_relax<1024>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": "k_sssp_relax<1024> (+ k_sssp_relax_dense<1024> on heavy iterations)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_note": traffic_note,
                 "launches": k_launch, "avg_launch_us": round(avg_launch_s * 1e6, 3),
                 "alg_bytes_per_launch": round(k_bytes / max(k_launch, 1), 1),

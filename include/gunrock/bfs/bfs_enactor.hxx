@@ -154,6 +154,7 @@ struct bfs_run_stats_t {
   int vshort_slots = 0;              // slots whose short rows were walked vertex by vertex
   int lazy_slots = 0;                // slots that ran without queues (bfs_build_is_lazy)
   int cold_slots = 0;                // slots that ran the cold-edge pass (bfs_fused_cold.hpp)
+  int mini_slots = 0;                // levels expanded by M launches (bfs_fused_mini.hpp)
   long long claims_level[64] = {0};
 };
 
@@ -204,7 +205,7 @@ struct bfs_fused_enactor_t {
   // counters of a traversal from the (head of the) control block it left on the host
   void fill_stats(bfs_run_stats_t& last, const mgx::bfs_ctrl_t* hc, bool direction_optimizing, bool with_timing) const {
     last.levels = hc->levels; last.push_levels = hc->push_levels;
-    last.reached = (long long)hc->reached; last.m_t = (long long)hc->sum_edges;
+    last.reached = (long long)(hc->reached + hc->reached_mini); last.m_t = (long long)hc->sum_edges;
     last.pull_edges = (long long)hc->pull_edges; last.frontier_vertices = (long long)hc->sum_frontier;
     last.claims = (long long)hc->claims;
     for (int i = 0; i < hc->levels && i < (with_timing ? mgx::BFS_MAX_TRACE : 64); ++i)
@@ -219,6 +220,7 @@ struct bfs_fused_enactor_t {
     last.vshort_slots = hc->vshort_slots;
     last.lazy_slots = hc->lazy_slots;
     last.cold_slots = hc->cold_slots;
+    last.mini_slots = hc->mini_slots;
     for (int i = 0; i < last.push_levels && i < (int)last.trace.size(); ++i) last.push_edges += last.trace[i].second;
     if (hc->levels > (int)last.trace.size() && !direction_optimizing) last.push_edges = last.m_t;   // (a deep traversal whose trace tail stayed on the device)
     long long push_vertices = 0;

@@ -212,7 +212,7 @@ MGX_API int mgx_bfs_enact_pushpull(mgx_bfs_t p, float threshold, int64_t* stats)
  *   [16] launch slots used [17] slots whose long rows were read from the unit blocks (bfs_fused_dense.hpp)
  *   [18] slots whose short rows were walked vertex by vertex (bfs_fused_vshort.hpp)
  *   [19] slots that ran without queues (the build before them wrote none, bfs_build_is_lazy)
- *   [20] slots that ran the cold-edge pass (bfs_fused_cold.hpp).
+ *   [20] slots that ran the cold-edge pass (bfs_fused_cold.hpp) [21] mid-size levels expanded by M launches (bfs_fused_mini.hpp).
  *   mgx_bfs_run writes entries [0] .. [15] (stats must hold 16: the contract of the first release, kept so that a
  *   caller built against it is not overrun); mgx_bfs_run_stats is the same call with an explicit capacity and writes
  *   min(cap, 24) entries.                                                                       */

@@ -106,6 +106,9 @@ struct bfs_ctrl_t {
   int lazy_slots;    // how many there were
   int cold_slot;     // the slot whose push ran the cold-edge pass (bfs_fused_cold.hpp): its build ORs the cold bitmaps; -1: none
   int cold_slots;    // how many there were
+  int mini_slots;    // levels expanded by M launches (bfs_fused_mini.hpp)
+  u32 mini_blocks[4];   // workgroups of the M launch of slot s & 3 that are through (a forwarding launch's last one moves the flags)
+  u64 reached_mini;  // vertices labelled by M launches: NOT in `reached` (which must not change while such a launch decides)
   u64 stamp[64];     // s_memrealtime (100 MHz) when each level was opened: per-level times without host syncs
   u64 trace[BFS_MAX_TRACE];   // (vertices << 38 | edges) of each level, both queues (kept LAST: read back up to `levels`)
 };
@@ -258,6 +261,9 @@ __device__ __forceinline__ void bfs_ctrl_reset(bfs_ctrl_t* c) {
   c->lazy_slots = 0;
   c->cold_slot = -1;
   c->cold_slots = 0;
+  c->mini_slots = 0;
+  for (int i = 0; i < 4; ++i) c->mini_blocks[i] = 0u;
+  c->reached_mini = 0;
   c->sssp_thr = 0x7f7fffffu;
   c->sssp_far_cnt[0] = c->sssp_far_cnt[1] = 0;
   c->sssp_far_min[0] = c->sssp_far_min[1] = 0x7f7fffffu;
@@ -960,6 +966,7 @@ struct bfs_run_opts_t {
   int merged_pull = 1;     // MGX_BFS_MERGED_PULL=0: the bottom-up sweep as a launch of its own behind every push launch
   int seed_chain = 1;      // MGX_BFS_SEED_CHAIN=0: no in-place chain launches at all (small levels run inside the slots' push launches)
   int tail_chain = 1;      // MGX_BFS_TAIL_CHAIN=0: ... only the one at the start
+  int tail_front = 1;      // MGX_BFS_TAIL_FRONT=0: no chain launch in FRONT of the last slots of a batch (only behind it)
   int chain_big = -1;      // MGX_BFS_CHAIN_BIG_EDGES: largest level of an in-place chain launch
   int cold = 2;            // MGX_BFS_COLD: 0 the unit-block body marks its cold entries itself (no cold-edge pass), 2 the long rows' lists
                            // (default); lab builds: 1 also the short rows' (measured equal on RMAT-22: 0.3712 / 0.3708 ms)
@@ -967,6 +974,7 @@ struct bfs_run_opts_t {
   long long defer = -1;    // MGX_BFS_DEFER: 0 never defer hot marks, N: flush a bitmap above N deferred marks per workgroup
   int spin = -1;           // MGX_BFS_SPIN: 0 read the control block back with a copy + hipStreamSynchronize, 1 publish kernel + spin
   int build_list = 0;      // MGX_BFS_BUILD_LIST=1: the list-based queue build (k_bfs_build) instead of k_bfs_build2
+  int mini = 1;            // MGX_BFS_MINI=0: no M launches (mid-size levels take device-wide slots; bfs_fused_mini.hpp)
   int many_spare = 0;      // MGX_BFS_MANY_SPARE: launch slots a traversal of a batch (mgx_bfs_run_many) gets beyond what the last
                            // traversals of the graph needed (0: measured 0.341 against 0.346 ms with one spare slot on RMAT-22 -- an idle
                            // slot is two launches, ~9 us; the chain behind the batch takes stragglers of up to BFS_CHAIN_CAP_BIG edges,
@@ -1006,7 +1014,9 @@ struct bfs_run_opts_t {
     geti("MGX_BFS_MERGED_PULL", o.merged_pull);
     geti("MGX_BFS_DO_CHAIN", o.do_chain);
     geti("MGX_BFS_TAIL_CHAIN", o.tail_chain);
+    geti("MGX_BFS_TAIL_FRONT", o.tail_front);
     geti("MGX_BFS_CHAIN_BIG_EDGES", o.chain_big);
+    geti("MGX_BFS_MINI", o.mini);
     geti("MGX_BFS_MANY_SPARE", o.many_spare);
     if (o.many_spare < 0) o.many_spare = 0;
     geti("MGX_BFS_LAZY", o.lazy);

@@ -14,6 +14,7 @@
 #include "bfs_fused_chain.hpp"
 #include "bfs_fused_cold.hpp"
 #include "bfs_fused_dense.hpp"
+#include "bfs_fused_mini.hpp"
 #include "bfs_fused_pull.hpp"
 #ifdef MGX_LAB
 #include "bfs_fused_sshort.hpp"
@@ -239,6 +240,8 @@ inline void bfs_set_kernel_attributes() {
   MGX_SET_LDS(k_bfs_push_dense_big);
 #endif
   MGX_SET_LDS(k_bfs_chain_inplace);
+  // (k_bfs_mini has static LDS too: the attribute carries what it needs, not the whole 160 KB)
+  MGX_HIP(hipFuncSetAttribute((const void*)k_bfs_mini<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bfs_mini_lds_bytes()));
   MGX_SET_LDS(k_bfs_push_level<false>);
   MGX_SET_LDS(k_bfs_push_level<true>);
 #undef MGX_SET_LDS
@@ -277,6 +280,7 @@ inline void bfs_launch_push(const bfs_fused_args_t& a, int level, standard_conte
 struct bfs_launch_plan_t {
   bfs_fused_args_t a;
   bool coldt = false, build2_ok = false;
+  bool minis = false;       // M launches (bfs_fused_mini.hpp) in front of the first and behind the last device-wide slot of a traversal
   u32 nstream = 0, nwave = 0, ncold = 0;
   int lab_flags = 0;
   long long nwords = 0;
@@ -386,6 +390,7 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   a.lazy_div = (a.dense_div && a.vs_div && build2_ok && !opt.build_list) ? (opt.lazy >= 0 ? (u32)opt.lazy : st.lazy_div) : 0u;
   plan.coldt = coldt;
   plan.build2_ok = build2_ok;
+  plan.minis = mode == 0 && opt.mini != 0 && a.chain_big_edges != 0u && opt.merged && !lab_flags;
   plan.nstream = a.long_min > 0 ? (u32)ctx.num_cus * 2 : 0u;
   plan.nwave = (u32)ctx.num_cus * 2;
   plan.ncold = (!coldt && a.cold_dst) ? a.cold_wgs[a.cold_slices] : 0u;
@@ -401,12 +406,19 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
 inline void bfs_enqueue_chain_inplace(const bfs_launch_plan_t& plan, int slot, hipStream_t s) {
   hipLaunchKernelGGL(k_bfs_chain_inplace, dim3(1), dim3(1024), bfs_chain_lds_bytes(BFS_CHAIN_CAP_BIG), s, plan.a, bfs_slot_arg(slot));
 }
-inline void bfs_enqueue_start(const bfs_fused_state_t& st, const bfs_launch_plan_t& plan, int src, standard_context_t& ctx,
-                              bfs_ctrl_t* prev_head = nullptr, int head_words = 0) {
+inline void bfs_enqueue_mini(const bfs_launch_plan_t& plan, int slot, hipStream_t s) {
+  hipLaunchKernelGGL(k_bfs_mini<1024>, dim3(BFS_MINI_WGS), dim3(1024), bfs_mini_lds_bytes(), s, plan.a, bfs_slot_arg(slot));
+}
+// init, the chain of the tiny levels at the start, and (M launches on) the first mid-size level: returns the first slot
+// that is still to be launched
+inline int bfs_enqueue_start(const bfs_fused_state_t& st, const bfs_launch_plan_t& plan, int src, standard_context_t& ctx,
+                             bfs_ctrl_t* prev_head = nullptr, int head_words = 0) {
   hipStream_t s = ctx.stream();
   hipLaunchKernelGGL(k_bfs_fused_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, plan.a, src,
                      plan.nwords, prev_head, head_words);
   if (plan.a.chain_big_edges) bfs_enqueue_chain_inplace(plan, 0, s);
+  if (plan.minis) { bfs_enqueue_mini(plan, 0, s); return 1; }
+  return 0;
 }
 inline void bfs_enqueue_build(const bfs_fused_state_t& st, const bfs_launch_plan_t& plan, int arg, hipStream_t s) {
   if (st.opts.build_list || !plan.build2_ok)
@@ -418,7 +430,8 @@ inline void bfs_enqueue_build(const bfs_fused_state_t& st, const bfs_launch_plan
 inline void bfs_enqueue_slot(const bfs_fused_state_t& st, const bfs_launch_plan_t& plan, int slot, standard_context_t& ctx) {
   hipStream_t s = ctx.stream();
   const int arg = bfs_slot_arg(slot);
-  if (plan.a.chain_big_edges && slot > 0 && slot >= st.tail_from && st.opts.tail_chain) bfs_enqueue_chain_inplace(plan, slot, s);
+  if (plan.a.chain_big_edges && slot > 0 && slot >= st.tail_from && st.opts.tail_chain && st.opts.tail_front && !plan.minis)
+    bfs_enqueue_chain_inplace(plan, slot, s);
   bfs_launch_push_part<0>(plan.a, arg, ctx, plan.coldt, plan.nstream + plan.ncold + plan.nwave, plan.nstream);
   if (plan.mode == 1 && !plan.a.merged_pull)
     hipLaunchKernelGGL(k_bfs_pull_level<256>, dim3(ctx.num_cus * 8), dim3(256), 0, s, plan.a, arg);
@@ -431,27 +444,45 @@ inline void bfs_enqueue_slot(const bfs_fused_state_t& st, const bfs_launch_plan_
 // traversals needed.  In-place chain launches from the first slot behind them on, i.e. behind the batch: a chain launch
 // that finds a big level costs 5 us (its reads of the control block miss behind the build's atomics), and on RMAT-22 the
 // level behind the last big one is small for a minority of the sources only.
-inline void bfs_learn_slots(bfs_fused_state_t& st, const bfs_fused_args_t& a, const bfs_ctrl_t* hc, int mode, int trace_avail) {
+inline void bfs_learn_slots(bfs_fused_state_t& st, const bfs_fused_args_t& a, const bfs_ctrl_t* hc, int mode, int trace_avail, bool minis = false) {
   st.slots_hint = hc->slots > 0 ? hc->slots : 1;    // slots that found work
   st.tail_from = 1 << 30;
   if (!(a.chain_big_edges && st.opts.tail_chain)) return;
   const int lv = hc->levels < trace_avail ? hc->levels : trace_avail;     // (levels behind the part of the trace the host holds count as small)
-  int k = 0;
+  // 0 small (a chain launch runs it), 1 mid-size (an M launch, bfs_fused_mini.hpp), 2 a device-wide slot
+  int kind[64];
+  const int L = lv < 64 ? lv : 64;
   bool pulled = false;
   u64 reached = 1;                         // (vertices with edges reached before level l runs: what bfs_chain_edge_limit looks at, nearly)
-  for (int l = 0; l < lv; ++l) {
+  int extra_big = lv > 64 ? lv - 64 : 0;   // (deep traversals: their tails are chains of small levels)
+  (void)extra_big;
+  for (int l = 0; l < L; ++l) {
     const u64 t = hc->trace[l];
     if (l > 0) reached += t >> BFS_VSHIFT;
     const bool late = reached * 4ull >= (u64)(u32)a.n;
     const u64 lim = late || a.chain_big_edges < BFS_CHAIN_EARLY_EDGES ? a.chain_big_edges : BFS_CHAIN_EARLY_EDGES;
     bool small = (t >> BFS_VSHIFT) <= (u64)BFS_CHAIN_CAP_BIG && (t & BFS_EMASK) <= lim;
+    // (the trace holds the level's vertices in all; the device rule looks at its long and its short rows separately)
+    bool mid = (t >> BFS_VSHIFT) <= (u64)BFS_MINI_SHORT_ROWS && (t & BFS_EMASK) <= (u64)(late ? BFS_MINI_EDGES_LATE : BFS_MINI_EDGES_EARLY);
     if (mode == 1) {                       // direction-optimising: bottom-up levels (and everything behind the first) are device-wide
       const float unvisited = (float)((long long)a.n - (long long)reached);
       if (unvisited < (float)(long long)(t >> BFS_VSHIFT) * a.alpha) pulled = true;
       if (pulled) small = false;
+      mid = false;
     }
-    if (!small) ++k;
+    kind[l] = small ? 0 : (minis && mid ? 1 : 2);
   }
+  // the launch sequence [chain][M] slots [M][chain]: what the two ends absorb needs no slot
+  int lo = 0, hi = L;
+  while (lo < hi && kind[lo] == 0) ++lo;                    // the chain at the start
+  if (minis && lo < hi && kind[lo] == 1) ++lo;              // the M launch behind it
+  while (hi > lo && kind[hi - 1] == 0) --hi;                // the chain behind the batch
+  if (minis && hi > lo && kind[hi - 1] == 1) {              // the M launch in front of it ...
+    --hi;
+    while (hi > lo && kind[hi - 1] == 0) --hi;              // (... and small levels in front of THAT ride in a slot's push launch)
+  }
+  int k = 0;
+  for (int l = lo; l < hi; ++l) if (kind[l] != 0) ++k;
   const int need = k > 0 ? k : 1;
   st.recent_need[st.recent_at & 3] = need;
   st.recent_at += 1;
@@ -476,7 +507,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   const bfs_fused_args_t& a = plan.a;
   const bool coldt = plan.coldt;
   const int lab_flags = plan.lab_flags;
-  bfs_enqueue_start(st, plan, src, ctx);
+  int slot = bfs_enqueue_start(st, plan, src, ctx);          // (1 when an M launch took slot 0)
   auto chain_inplace = [&](int sl) { bfs_enqueue_chain_inplace(plan, sl, s); };
   st.level_kernel_ms = 0.0;
   st.level_kernel_launches = 0;
@@ -487,15 +518,15 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   st.batches = 0;
   const bool batch_events = st.time_kernels != 0 || st.time_batches;    // (an event costs ~6 us of stream gap)
   const u32 nstream = plan.nstream, nwave = plan.nwave, ncold = plan.ncold;
-  int slot = 0;
   for (int batch = 0;; ++batch) {
     // first batch: what the previous traversal of this graph needed (sources differ, level structure hardly)
     int nslots = batch == 0 ? st.slots_hint : st.levels_per_sync;
     if (nslots > bfs_fused_state_t::EV_POOL / 3) nslots = bfs_fused_state_t::EV_POOL / 3;
     if (batch_events) MGX_HIP(hipEventRecord(st.ev0, s));
+    const int first_slot = slot;
     for (int i = 0; i < nslots; ++i, ++slot) {
       const int arg = bfs_slot_arg(slot);
-      if (a.chain_big_edges && slot > 0 && slot >= st.tail_from && opt.tail_chain) chain_inplace(slot);
+      if (a.chain_big_edges && slot > 0 && slot >= st.tail_from && opt.tail_chain && opt.tail_front && !plan.minis) chain_inplace(slot);
       const bool in_pool = 3 * i + 2 < bfs_fused_state_t::EV_POOL;
       const bool timed = st.time_kernels == 1 && in_pool;
       const bool timed_merged = st.time_kernels == 2 && in_pool && opt.merged && !lab_flags;
@@ -528,7 +559,8 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
       bfs_enqueue_build(st, plan, arg, s);
       if (timed_merged) MGX_HIP(hipEventRecord(st.wev[3 * i + 2], s));    // (timing mode 2: the slot's queue build too)
     }
-    if (a.chain_big_edges && slot >= st.tail_from && opt.tail_chain) chain_inplace(slot);    // (the stragglers: may end the traversal here)
+    if (plan.minis && batch == 0) { bfs_enqueue_mini(plan, slot, s); ++slot; }                // (the mid-size level behind the peak)
+    if (a.chain_big_edges && (slot >= st.tail_from || plan.minis) && opt.tail_chain) chain_inplace(slot);    // (the stragglers: may end the traversal here)
     if (batch_events) MGX_HIP(hipEventRecord(st.ev1, s));
     // one read-back per batch: the counters and the first 64 trace slots (the flag alone would cost the same trip)
     constexpr size_t head_bytes = offsetof(bfs_ctrl_t, trace) + 64 * sizeof(u64);
@@ -553,7 +585,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
     if (batch_events) MGX_HIP(hipEventElapsedTime(&ms, st.ev0, st.ev1));
     st.level_kernel_ms += ms;
     for (int i = 0; st.time_kernels && i < nslots && 3 * i + 2 < bfs_fused_state_t::EV_POOL; ++i) {
-      const int sl = slot - nslots + i;
+      const int sl = first_slot + i;
       float wms = 0.f;
       if (st.time_kernels == 2) {
         if (!(opt.merged && !lab_flags)) break;
@@ -596,7 +628,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
     MGX_HIP(hipMemcpyAsync(st.host_ctrl->trace + 64, st.ctrl.data()->trace + 64, (size_t)(lv - 64) * sizeof(u64), hipMemcpyDeviceToHost, s));
     MGX_HIP(hipStreamSynchronize(s));
   }
-  bfs_learn_slots(st, a, st.host_ctrl, mode, BFS_MAX_TRACE);
+  bfs_learn_slots(st, a, st.host_ctrl, mode, BFS_MAX_TRACE, plan.minis);
 }
 
 // COUNT traversals enqueued back to back with ONE host wait at the end (mgx_bfs_run_many): every traversal is complete --
@@ -623,16 +655,19 @@ inline int bfs_fused_run_many(bfs_fused_state_t& st, const int* row_offsets, con
   if (nslots > 30) nslots = 30;
   if (nslots < 1) nslots = 1;
   const int saved_tail = st.tail_from;
-  st.tail_from = nslots - 1;                       // (chain launches in front of the spare slot and behind the batch)
+  st.tail_from = plan.minis ? (1 << 30) : nslots - 1;      // (no M launches: a chain launch in front of the last slot and behind the batch)
   const bool tail = a.chain_big_edges && st.opts.tail_chain;
+  int last_slot = nslots;                          // the slot the chain behind a traversal works in: where an unfinished one stands
   // the chain behind a traversal's last slot may run levels up to the list capacity here (a lone workgroup needs ~4.3 us per
   // 1000 edges: slower than a slot above ~4000 edges, but far cheaper than running the whole traversal again)
   bfs_launch_plan_t plan_tail = plan;
   plan_tail.a.chain_big_edges = BFS_CHAIN_CAP_BIG;
   for (int i = 0; i < count; ++i) {
-    bfs_enqueue_start(st, plan, srcs[i], ctx, i > 0 ? bfs_many_head(heads, i - 1) : nullptr, head_words);
-    for (int sl = 0; sl < nslots; ++sl) bfs_enqueue_slot(st, plan, sl, ctx);
-    if (tail) bfs_enqueue_chain_inplace(plan_tail, nslots, s);
+    int sl = bfs_enqueue_start(st, plan, srcs[i], ctx, i > 0 ? bfs_many_head(heads, i - 1) : nullptr, head_words);
+    for (int k = 0; k < nslots; ++k, ++sl) bfs_enqueue_slot(st, plan, sl, ctx);
+    if (plan.minis) { bfs_enqueue_mini(plan, sl, s); ++sl; }
+    if (tail) bfs_enqueue_chain_inplace(plan_tail, sl, s);
+    last_slot = sl;
   }
   st.tail_from = saved_tail;
   const u64 seq = ++st.seq;
@@ -653,17 +688,17 @@ inline int bfs_fused_run_many(bfs_fused_state_t& st, const int* row_offsets, con
   for (int i = 0; i < count; ++i) {
     bfs_ctrl_t* const h = bfs_many_head(heads, i);
     if (!h->done) {
-      const u64 next = h->cursor[nslots % 3] | h->lcursor[nslots % 3];
-      if ((next >> BFS_VSHIFT) == 0) { h->done = 1; h->levels = h->slot_level[nslots & 3]; }
+      const u64 next = h->cursor[last_slot % 3] | h->lcursor[last_slot % 3];
+      if ((next >> BFS_VSHIFT) == 0) { h->done = 1; h->levels = h->slot_level[last_slot & 3]; }
     }
-    if (h->done) { bfs_learn_slots(st, a, h, mode, 64); continue; }
+    if (h->done) { bfs_learn_slots(st, a, h, mode, 64, plan.minis); continue; }
     bfs_fused_run(st, row_offsets, col_indices, labels, srcs[i], ctx, layout, mode, alpha, in_offsets, in_indices);
     memcpy(h, st.host_ctrl, bfs_head_bytes());
     ++reruns;
     if (i != count - 1) redo_last = true;
   }
   if (redo_last) bfs_fused_run(st, row_offsets, col_indices, labels, srcs[count - 1], ctx, layout, mode, alpha, in_offsets, in_indices);
-  st.slots_used = nslots;
+  st.slots_used = last_slot;
   return reruns;
 }
 

@@ -12,8 +12,8 @@
 //                 are the first ids; reduced[] <- identity.
 //   k_nr_edges    ONE launch, two parts.  Long rows (>= 64 entries) from the unit blocks (mgx_layout.hip): 16 bytes per lane, a unit of 64
 //                 entries belongs to ONE row (ub_cnt[u] of them are real, the rest padding), so the segment id is free;
-//                 the values of the first NR_HOTV layout vertices sit in LDS (80 KB per workgroup, two workgroups per
-//                 CU), the others are gathered from L2 (the next 600 K vertices are 2.4 MB); 16 lanes fold a unit with
+//                 the values of the first NR_HOTV layout vertices sit in LDS (160 KB: one workgroup per CU), the others
+//                 are gathered from L2 (the next 600 K vertices are 2.4 MB); 16 lanes fold a unit with
 //                 four shuffle steps in a fixed order -> partial[u].
 //   k_nr_rows     a long row's units are contiguous (ub_first[v] .. ub_first[v + 1]): one thread folds the partials of a
 //                 row of up to NR_BIG_UNITS units in order; the few rows above that (the first rows of the degree-sorted
@@ -24,12 +24,17 @@
 // Float sums are folded in a different order than the general kernel's (both are deterministic; the reference's own
 // order is moderngpu's and unpinned): the tests compare with 2e-5 relative.
 #pragma once
+#include <cstdlib>
+
 #include "runtime.hpp"
 #include "wave.hpp"
 
 namespace mgx {
 
-constexpr int NR_HOTV = 20000;            // values of the first NR_HOTV layout vertices in LDS (80 000 bytes per workgroup)
+constexpr int NR_HOTV = 40000;            // values of the first NR_HOTV layout vertices in LDS: 160 000 bytes, ONE workgroup per CU.
+                                          // (Measured, RMAT-22: 0.539 ms per reduce against 0.609 with two workgroups of 20 000 values each --
+                                          //  unlike the BFS's bit probes, every entry here is a 4-byte gather: what counts is how many of them
+                                          //  stay in LDS -- 64 % of the endpoints at 40 000 values against 51 % -- and 128 registers per lane.)
 constexpr int NR_BIG_UNITS = 64;          // rows of more units than this are folded by a workgroup of their own
 constexpr size_t nr_lds_bytes() { return (size_t)NR_HOTV * 4 + 64; }
 
@@ -99,25 +104,31 @@ __device__ __forceinline__ void nr_long_work(const nr_layout_t& L, const V* __re
   const unsigned char* __restrict__ ucnt = L.ub_cnt;
   const u32 sub = (u32)lane & 15u, q = (u32)lane >> 4;                  // my four entries inside my unit; my unit inside a 4-unit load
   if (w < G) {
-  // group g: four loads; load j covers units 16 g + 4 j .. + 3, lane (q, sub) reads entries 4 sub .. 4 sub + 3 of unit 4 j + q
-  nr_u32x4 cur[4], nxt[4];
-  u32 ccnt[4], ncnt[4];
-  auto issue = [&](u32 g, nr_u32x4* d, u32* c) {
-    const u32 gg = g < G ? g : G - 1u;
+  // A step takes GPS groups (g, g + W, ...): four loads per group; load j covers units 16 g + 4 j .. + 3, lane (q, sub) reads
+  // entries 4 sub .. 4 sub + 3 of unit 4 j + q.  The next step's loads are in flight while this step's 16 GPS gathers are.
+  constexpr int GPS = 2, NL = 4 * GPS;
+  nr_u32x4 cur[NL], nxt[NL];
+  u32 ccnt[NL], ncnt[NL];
+  auto issue = [&](u32 g0, nr_u32x4* d, u32* c) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const u32 u = gg * 16u + 4u * (u32)j + q;
-      d[j] = __builtin_nontemporal_load((const nr_u32x4*)(ucol + ((size_t)u << 6) + sub * 4u));
-      c[j] = ucnt[u];
+    for (int k = 0; k < GPS; ++k) {
+      const u32 g = g0 + (u32)k * W;
+      const u32 gg = g < G ? g : G - 1u;                // (past the end: the last group again, ignored)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 u = gg * 16u + 4u * (u32)j + q;
+        d[4 * k + j] = __builtin_nontemporal_load((const nr_u32x4*)(ucol + ((size_t)u << 6) + sub * 4u));
+        c[4 * k + j] = g < G ? (u32)ucnt[u] : 0u;
+      }
     }
   };
   issue(w, cur, ccnt);
-  for (u32 g = w; g < G; g += W) {
-    issue(g + W, nxt, ncnt);                          // (past the end: the last group again, ignored)
-    // all sixteen gathers of the group first, then the folds (a fold's shuffles between two gathers would order them)
-    V val[4][4];
+  for (u32 g0 = w; g0 < G; g0 += (u32)GPS * W) {
+    issue(g0 + (u32)GPS * W, nxt, ncnt);
+    // all gathers of the step first, then the folds (a fold's shuffles between two gathers would order them)
+    V val[NL][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NL; ++j) {
       const u32 have = ccnt[j];                       // real entries of my unit
       const u32 e0 = sub * 4u;
       const u32 d0 = e0 + 0u < have ? cur[j].x : 0xFFFFFFFFu, d1 = e0 + 1u < have ? cur[j].y : 0xFFFFFFFFu;
@@ -126,14 +137,15 @@ __device__ __forceinline__ void nr_long_work(const nr_layout_t& L, const V* __re
       val[j][2] = nr_fetch(d2, vals, hot, hot_n, identity); val[j][3] = nr_fetch(d3, vals, hot, hot_n, identity);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NL; ++j) {
       V s = op(op(val[j][0], val[j][1]), op(val[j][2], val[j][3]));
 #pragma unroll
       for (int sh = 1; sh < 16; sh <<= 1) s = op(s, __shfl_xor(s, sh, WAVE));     // the 16 lanes of my unit
-      if (sub == 0u) partial[g * 16u + 4u * (u32)j + q] = s;
+      const u32 g = g0 + (u32)(j / 4) * W;
+      if (sub == 0u && g < G) partial[g * 16u + 4u * (u32)(j % 4) + q] = s;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { cur[j] = nxt[j]; ccnt[j] = ncnt[j]; }
+    for (int j = 0; j < NL; ++j) { cur[j] = nxt[j]; ccnt[j] = ncnt[j]; }
   }
   }
 }
@@ -227,11 +239,12 @@ __device__ __forceinline__ void nr_short_work(const nr_layout_t& L, const V* __r
 }
 
 // ONE launch for both parts.
-template <typename V, typename Op, int NT>
-__global__ __launch_bounds__(NT, 8) void k_nr_edges(nr_layout_t L, const V* __restrict__ vals, V* __restrict__ partial, V* __restrict__ reduced,
+// HOTV values in LDS, WPE waves per SIMD: one workgroup of 1024 threads per CU
+template <typename V, typename Op, int NT, int HOTV = NR_HOTV, int WPE = 4>
+__global__ __launch_bounds__(NT, WPE) void k_nr_edges(nr_layout_t L, const V* __restrict__ vals, V* __restrict__ partial, V* __restrict__ reduced,
                                                     V identity, Op op, u32 nlong) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const u32 hot_n = (u32)L.n < (u32)NR_HOTV ? (u32)L.n : (u32)NR_HOTV;
+  const u32 hot_n = (u32)L.n < (u32)HOTV ? (u32)L.n : (u32)HOTV;
   const V* const hot = nr_hot_setup<V, NT>(smem, vals, hot_n);
   // every workgroup takes its share of BOTH parts, one after the other over the same LDS values: the parts differ in cost
   // per entry (the short rows pay a planning load per vertex), so any fixed split of the grid leaves one half waiting
@@ -259,7 +272,7 @@ inline void nr_full_frontier(const nr_layout_t& L, GetValue get, V* reduced, V i
   const u32 long_rows = L.vs_v[0];
   const bool has_long = L.ub_units > 0 && long_rows > 0, has_short = L.vs_v[3] > L.vs_v[0];
   if (has_long || has_short)
-    hipLaunchKernelGGL((k_nr_edges<V, Op, 1024>), dim3(ctx.num_cus * 2), dim3(1024), nr_lds_bytes(), s, L, (const V*)vals, partial, reduced,
+    hipLaunchKernelGGL((k_nr_edges<V, Op, 1024>), dim3(ctx.num_cus), dim3(1024), nr_lds_bytes(), s, L, (const V*)vals, partial, reduced,
                        identity, op, 0u);
   if (has_long) {
     if (L.big_rows > 0) hipLaunchKernelGGL((k_nr_big_rows<V, Op>), dim3(L.big_rows), dim3(BLOCK), 0, s, L, (const V*)partial, reduced, identity, op);

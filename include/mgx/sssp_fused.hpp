@@ -443,6 +443,45 @@ __device__ __forceinline__ void sssp_sliced_body(const sssp_args_t& a, u32* cons
 }
 #endif  // MGX_LAB
 
+// bounds of the first HOTN distances into LDS (two per word); returns how many there are.  All loads first, then the stores
+// (the plain loop compiles to load - wait - store per trip: sixteen dependent round trips at the start of every workgroup;
+// bfs_copy_prefix in bfs_fused.hpp tells the same story)
+template <int NT, int HOTN>
+__device__ __forceinline__ u32 sssp_load_bounds(const u32* __restrict__ dist, int n, u32* s_hot) {
+  const u32 hot_n = (u32)n < (u32)HOTN ? ((u32)n & ~1u) : (u32)HOTN;
+  constexpr int IT = (HOTN / 2 + NT - 1) / NT;
+  uint2 dv[IT];
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const u32 i = (u32)k * NT + threadIdx.x;
+    dv[k] = *(const uint2*)(dist + 2 * (i < hot_n / 2 ? i : 0u));
+  }
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const u32 i = (u32)k * NT + threadIdx.x;
+    if (i < hot_n / 2) s_hot[i] = ((dv[k].x + 0xFFFFu) >> 16) | (((dv[k].y + 0xFFFFu) >> 16) << 16);
+  }
+  __syncthreads();
+  return hot_n;
+}
+
+// The heavy iterations' kernel (sssp_dense_*): launched behind every k_sssp_relax of the loop and returns at once unless the
+// iteration is heavy -- then k_sssp_relax did (the same grid-uniform test on the same stable sizes).  A launch of its own
+// for the shape that suits a sweep whose cost is its distance gathers (mgx/nreduce.hpp measured the same trade): ONE
+// workgroup per CU, 128 registers per lane, and the bounds of the first SSSP_HOTN_DENSE vertices in LDS.
+constexpr int SSSP_HOTN_DENSE = 73728;             // 144 KB of 16-bit bounds
+template <int NT>
+__global__ __launch_bounds__(NT, 4) void k_sssp_relax_dense(sssp_args_t a, int it) {
+  extern __shared__ __attribute__((aligned(16))) u32 s_hot_dense[];
+  const u64 cur = a.ctrl->cursor[it % 3];
+  const u32 E = (u32)(cur & BFS_EMASK);
+  if ((cur >> BFS_VSHIFT) == 0 || !a.ub_w || (u64)E * (u64)a.dense_div < a.m_edges) return;
+  const u32 hot_n = sssp_load_bounds<NT, SSSP_HOTN_DENSE>(a.dist, a.n, s_hot_dense);
+  const unsigned short* const hot16 = (const unsigned short*)s_hot_dense;
+  sssp_dense_long<NT>(a, hot16, hot_n, blockIdx.x, gridDim.x);
+  sssp_dense_short<NT>(a, hot16, hot_n, blockIdx.x, gridDim.x);
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT, 8) void k_sssp_relax(sssp_args_t a, int it) {
   constexpr int NW = NT / WAVE;
@@ -477,33 +516,10 @@ __global__ __launch_bounds__(NT, 8) void k_sssp_relax(sssp_args_t a, int it) {
     return;
   }
 #endif
+  if (a.ub_w && (u64)E * (u64)a.dense_div >= a.m_edges) return;     // a heavy iteration (grid-uniform): k_sssp_relax_dense's
   const bool use_hot = E >= a.hot_min_edges;
-  const u32 hot_n = use_hot ? ((u32)a.n < (u32)SSSP_HOTN ? ((u32)a.n & ~1u) : (u32)SSSP_HOTN) : 0u;
-  if (use_hot) {
-    // all loads first, then the stores (the plain loop compiles to load - wait - store per trip: sixteen dependent round
-    // trips at the start of every workgroup; bfs_copy_prefix in bfs_fused.hpp tells the same story)
-    constexpr int IT = (SSSP_HOTN / 2 + NT - 1) / NT;
-    uint2 dv[IT];
-#pragma unroll
-    for (int k = 0; k < IT; ++k) {
-      const u32 i = (u32)k * NT + threadIdx.x;
-      dv[k] = *(const uint2*)(dist + 2 * (i < hot_n / 2 ? i : 0u));
-    }
-#pragma unroll
-    for (int k = 0; k < IT; ++k) {
-      const u32 i = (u32)k * NT + threadIdx.x;
-      if (i < hot_n / 2) s_hot[i] = ((dv[k].x + 0xFFFFu) >> 16) | (((dv[k].y + 0xFFFFu) >> 16) << 16);
-    }
-    __syncthreads();
-  }
+  const u32 hot_n = use_hot ? sssp_load_bounds<NT, SSSP_HOTN>(dist, a.n, s_hot) : 0u;
   const unsigned short* const hot16 = (const unsigned short*)s_hot;
-
-  if (a.ub_w && (u64)E * (u64)a.dense_div >= a.m_edges) {
-    // a heavy iteration (grid-uniform): every workgroup takes its share of the unit blocks, then of the short rows' classes
-    sssp_dense_long<NT>(a, hot16, hot_n, blockIdx.x, gridDim.x);
-    sssp_dense_short<NT>(a, hot16, hot_n, blockIdx.x, gridDim.x);
-    return;
-  }
 
   const u32 total_waves = gridDim.x * NW;
   u32 per = (E + total_waves - 1) / total_waves;
@@ -958,6 +974,7 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   static unsigned char attr_seen[64] = {};
   if (first_use_on_device(attr_seen)) {
     MGX_HIP(hipFuncSetAttribute((const void*)k_sssp_relax<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SSSP_HOTN * 2));
+    MGX_HIP(hipFuncSetAttribute((const void*)k_sssp_relax_dense<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   int it = 0;
   st.relax_ms = 0.0;
@@ -969,6 +986,7 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
     for (int i = 0; i < nit; ++i, ++it) {
       if (st.time_kernels) MGX_HIP(hipEventRecord(st.ev[2 * i], s));
       hipLaunchKernelGGL(k_sssp_relax<1024>, dim3(ctx.num_cus * 2), dim3(1024), SSSP_HOTN * 2, s, a, it);
+      if (dense) hipLaunchKernelGGL(k_sssp_relax_dense<1024>, dim3(ctx.num_cus), dim3(1024), SSSP_HOTN_DENSE * 2, s, a, it);
       if (st.time_kernels) MGX_HIP(hipEventRecord(st.ev[2 * i + 1], s));
       if (build2) hipLaunchKernelGGL(k_sssp_build2<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, it);
       else hipLaunchKernelGGL(k_sssp_build<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, it);

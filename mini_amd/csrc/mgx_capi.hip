@@ -997,6 +997,7 @@ static void fill_bfs_stats(int64_t* out24, const bfs::bfs_run_stats_t& L) {
   out24[18] = L.vshort_slots;
   out24[19] = L.lazy_slots;
   out24[20] = L.cold_slots;
+  out24[21] = L.mini_slots;
 }
 int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats) { return mgx_bfs_run_stats(p, src, mode, alpha, stats, 16); }
 int mgx_bfs_run_stats(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats, int cap) {
