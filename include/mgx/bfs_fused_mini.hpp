@@ -30,9 +30,8 @@ constexpr int BFS_MINI_WGS = 64;               // workgroups of an M launch
 constexpr int BFS_MINI_LCAP = 4096;            // long rows of a level an M launch expands (their queue is staged in LDS)
 constexpr int BFS_MINI_WCAP = 8192;            // winners a workgroup collects before it flushes them
 constexpr u32 BFS_MINI_EDGES_LATE = 131072;    // largest level (true edges) behind the peak ...
-constexpr u32 BFS_MINI_EDGES_EARLY = 131072;   // ... and before it, where nearly every edge is a claim (64 CUs issue ~6 G claims/s: ~20 us at
-                                               // the limit, what a device-wide slot costs such a level too -- but then EVERY source of
-                                               // RMAT-22 needs three device-wide slots, and the batch is sized by the source that needs most)
+constexpr u32 BFS_MINI_EDGES_EARLY = 32768;    // ... and before it, where nearly every edge is a claim (64 CUs issue ~6 G claims/s; with 131072 here the
+                                               // launch took the 114 000 all-new edges of some RMAT-22 sources' second level: slower than a slot)
 constexpr u32 BFS_MINI_SHORT_ROWS = 65536;     // short rows of such a level
 constexpr size_t bfs_mini_lds_bytes() {
   return (size_t)(2 * BFS_MINI_LCAP + 4) * 4 + (size_t)BFS_MINI_WCAP * 4 + 64 * 8 + 256;

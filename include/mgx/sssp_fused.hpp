@@ -191,8 +191,39 @@ __device__ __forceinline__ u32 sssp_gather_index(u32 d, u32 nd, const unsigned s
   return live ? d : 0u;
 }
 
-template <int NT>
-__device__ __forceinline__ void sssp_dense_long(const sssp_args_t& a, const unsigned short* hot16, u32 hot_n, u32 block, u32 nblocks) {
+// four candidates of a lane.  LIVE: the table holds the first hot_n distances as 32-bit minima the WORKGROUP keeps current
+// (ds_min): a candidate for such a vertex is decided in LDS -- it goes to the global atomicMin only if it lowered the
+// workgroup's minimum (the global value is never above it once those atomics have landed), no gather.  Otherwise the table
+// holds 16-bit upper bounds taken when the workgroup started: a candidate below the bound gathers the distance.
+template <bool LIVE>
+__device__ __forceinline__ void sssp_relax4(const u32 (&dd)[4], const u32 (&nd)[4], void* table, u32 hot_n, u32* dist, unsigned char* mark) {
+  u32 gi[4], old[4];
+  bool live[4], won[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    won[k] = false;
+    if (LIVE) {
+      const bool none = dd[k] == 0xFFFFFFFFu;
+      const bool hotm = dd[k] < hot_n;
+      if (hotm) won[k] = nd[k] < atomicMin((u32*)table + dd[k], nd[k]);
+      live[k] = !none && !hotm;
+      gi[k] = live[k] ? dd[k] : 0u;
+    } else {
+      gi[k] = sssp_gather_index(dd[k], nd[k], (const unsigned short*)table, hot_n, live[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) old[k] = dist[gi[k]];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (won[k] || (live[k] && nd[k] < old[k])) {
+      atomicMin(dist + dd[k], nd[k]);
+      mark[dd[k]] = 1;
+    }
+}
+
+template <int NT, bool LIVE>
+__device__ __forceinline__ void sssp_dense_long(const sssp_args_t& a, void* table, u32 hot_n, u32 block, u32 nblocks) {
   constexpr int NW = NT / WAVE;
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
@@ -240,30 +271,20 @@ __device__ __forceinline__ void sssp_dense_long(const sssp_args_t& a, const unsi
       const u32 have = act[j] ? nC[j] : 0u;
       const u32 e0 = sub * 4u;
       const float base = __uint_as_float(du[j]);
-      u32 dd[4], nd[4], gi[4], old[4];
-      bool live[4];
+      u32 dd[4], nd[4];
       dd[0] = e0 + 0u < have ? cC[j].x : 0xFFFFFFFFu; dd[1] = e0 + 1u < have ? cC[j].y : 0xFFFFFFFFu;
       dd[2] = e0 + 2u < have ? cC[j].z : 0xFFFFFFFFu; dd[3] = e0 + 3u < have ? cC[j].w : 0xFFFFFFFFu;
       nd[0] = __float_as_uint(base + wC[j].x); nd[1] = __float_as_uint(base + wC[j].y);
       nd[2] = __float_as_uint(base + wC[j].z); nd[3] = __float_as_uint(base + wC[j].w);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) gi[k] = sssp_gather_index(dd[k], nd[k], hot16, hot_n, live[k]);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) old[k] = dist[gi[k]];
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (live[k] && nd[k] < old[k]) {
-          atomicMin(dist + dd[k], nd[k]);
-          mark[dd[k]] = 1;
-        }
+      sssp_relax4<LIVE>(dd, nd, table, hot_n, dist, mark);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) { cC[j] = cN[j]; wC[j] = wN[j]; nC[j] = nN[j]; oC[j] = oN[j]; }
   }
 }
 
-template <int NT>
-__device__ __forceinline__ void sssp_dense_short(const sssp_args_t& a, const unsigned short* hot16, u32 hot_n, u32 block, u32 nblocks) {
+template <int NT, bool LIVE>
+__device__ __forceinline__ void sssp_dense_short(const sssp_args_t& a, void* table, u32 hot_n, u32 block, u32 nblocks) {
   constexpr int NW = NT / WAVE;
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
@@ -304,22 +325,12 @@ __device__ __forceinline__ void sssp_dense_short(const sssp_args_t& a, const uns
     const sssp_u32x4u dn = *(const sssp_u32x4u*)(col + pn.e0);
     const sssp_f32x4u wn = *(const sssp_f32x4u*)(wts + pn.e0);
     const float base = __uint_as_float(pc.du);
-    u32 dd[4], nd[4], gi[4], old[4];
-    bool live[4];
+    u32 dd[4], nd[4];
     dd[0] = pc.cnt > 0u ? dc.x : 0xFFFFFFFFu; dd[1] = pc.cnt > 1u ? dc.y : 0xFFFFFFFFu;
     dd[2] = pc.cnt > 2u ? dc.z : 0xFFFFFFFFu; dd[3] = pc.cnt > 3u ? dc.w : 0xFFFFFFFFu;
     nd[0] = __float_as_uint(base + wc.x); nd[1] = __float_as_uint(base + wc.y);
     nd[2] = __float_as_uint(base + wc.z); nd[3] = __float_as_uint(base + wc.w);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) gi[k] = sssp_gather_index(dd[k], nd[k], hot16, hot_n, live[k]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) old[k] = dist[gi[k]];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (live[k] && nd[k] < old[k]) {
-        atomicMin(dist + dd[k], nd[k]);
-        mark[dd[k]] = 1;
-      }
+    sssp_relax4<LIVE>(dd, nd, table, hot_n, dist, mark);
     pc = pn; dc = dn; wc = wn;
   }
 }
@@ -469,17 +480,29 @@ __device__ __forceinline__ u32 sssp_load_bounds(const u32* __restrict__ dist, in
 // iteration is heavy -- then k_sssp_relax did (the same grid-uniform test on the same stable sizes).  A launch of its own
 // for the shape that suits a sweep whose cost is its distance gathers (mgx/nreduce.hpp measured the same trade): ONE
 // workgroup per CU, 128 registers per lane, and the bounds of the first SSSP_HOTN_DENSE vertices in LDS.
-constexpr int SSSP_HOTN_DENSE = 73728;             // 144 KB of 16-bit bounds
-template <int NT>
+constexpr int SSSP_HOTN_DENSE = 73728;             // 144 KB of 16-bit bounds ...
+constexpr int SSSP_HOTN_LIVE = 36864;              // ... or of 32-bit live minima (LIVE)
+template <int NT, bool LIVE>
 __global__ __launch_bounds__(NT, 4) void k_sssp_relax_dense(sssp_args_t a, int it) {
   extern __shared__ __attribute__((aligned(16))) u32 s_hot_dense[];
   const u64 cur = a.ctrl->cursor[it % 3];
   const u32 E = (u32)(cur & BFS_EMASK);
   if ((cur >> BFS_VSHIFT) == 0 || !a.ub_w || (u64)E * (u64)a.dense_div < a.m_edges) return;
-  const u32 hot_n = sssp_load_bounds<NT, SSSP_HOTN_DENSE>(a.dist, a.n, s_hot_dense);
-  const unsigned short* const hot16 = (const unsigned short*)s_hot_dense;
-  sssp_dense_long<NT>(a, hot16, hot_n, blockIdx.x, gridDim.x);
-  sssp_dense_short<NT>(a, hot16, hot_n, blockIdx.x, gridDim.x);
+  u32 hot_n;
+  if (LIVE) {
+    hot_n = (u32)a.n < (u32)SSSP_HOTN_LIVE ? (u32)a.n : (u32)SSSP_HOTN_LIVE;
+    constexpr int IT = (SSSP_HOTN_LIVE + NT - 1) / NT;
+    u32 dv[IT];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) { const u32 i = (u32)k * NT + threadIdx.x; dv[k] = a.dist[i < hot_n ? i : 0u]; }
+#pragma unroll
+    for (int k = 0; k < IT; ++k) { const u32 i = (u32)k * NT + threadIdx.x; if (i < hot_n) s_hot_dense[i] = dv[k]; }
+    __syncthreads();
+  } else {
+    hot_n = sssp_load_bounds<NT, SSSP_HOTN_DENSE>(a.dist, a.n, s_hot_dense);
+  }
+  sssp_dense_long<NT, LIVE>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);
+  sssp_dense_short<NT, LIVE>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);
 }
 
 template <int NT>
@@ -884,6 +907,7 @@ struct sssp_fused_state_t {
   mem_t<u32> dist_layout;            // only with a layout: distances in layout order
   mem_t<u32> q_row[2], q_off[2], q_du[2];
   mem_t<u32> frontier_bits;          // the frontier as a bitmap (sssp_sliced_body; allocated on demand)
+  bool dense_live = false;           // (lab builds, MGX_SSSP_LIVE=1) the heavy iterations' LDS table as 32-bit minima kept current by the workgroup
   unsigned dense_div = 4;            // an iteration whose frontier holds >= m / dense_div edges sweeps the unit blocks (sssp_dense_*; 0: never)
   unsigned sliced_div = 0;           // an iteration whose frontier holds >= m / sliced_div edges streams the sliced edge list (0: never --
                                      // the default: measured 2.59 ms (div 3) / 2.54 (2) / 2.82 (6) against 2.47 ms without, RMAT-22)
@@ -956,6 +980,10 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   // bitmap (k_sssp_build2 writes it) and the plain loop (near / far buckets park vertices outside the queue)
   unsigned ddiv = st.dense_div;
   if (const char* e = getenv("MGX_SSSP_DENSE")) ddiv = (unsigned)atoi(e);
+  bool live = st.dense_live;
+#ifdef MGX_LAB       // (32-bit minima the workgroup keeps current instead of 16-bit bounds: measured 2.56 against 1.88 ms per RMAT-22 source)
+  if (const char* e = getenv("MGX_SSSP_LIVE")) live = atoi(e) != 0;
+#endif
   const bool dense = layout && layout->ub_w && layout->ub_col && layout->ub_cnt && layout->ub_owner && layout->ub_units_pad >= 16 &&
                      layout->vs_v[3] >= layout->vs_v[0] && layout->m_edges > 0 && build2 && ddiv > 0 && a.delta == 0.f;
   if (dense && !st.frontier_bits.size()) st.frontier_bits = mem_t<u32>(((size_t)st.n + 31) / 32 + 4, ctx);
@@ -974,7 +1002,10 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   static unsigned char attr_seen[64] = {};
   if (first_use_on_device(attr_seen)) {
     MGX_HIP(hipFuncSetAttribute((const void*)k_sssp_relax<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SSSP_HOTN * 2));
-    MGX_HIP(hipFuncSetAttribute((const void*)k_sssp_relax_dense<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MGX_HIP(hipFuncSetAttribute((const void*)(k_sssp_relax_dense<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#ifdef MGX_LAB
+    MGX_HIP(hipFuncSetAttribute((const void*)(k_sssp_relax_dense<1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
   }
   int it = 0;
   st.relax_ms = 0.0;
@@ -986,7 +1017,11 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
     for (int i = 0; i < nit; ++i, ++it) {
       if (st.time_kernels) MGX_HIP(hipEventRecord(st.ev[2 * i], s));
       hipLaunchKernelGGL(k_sssp_relax<1024>, dim3(ctx.num_cus * 2), dim3(1024), SSSP_HOTN * 2, s, a, it);
-      if (dense) hipLaunchKernelGGL(k_sssp_relax_dense<1024>, dim3(ctx.num_cus), dim3(1024), SSSP_HOTN_DENSE * 2, s, a, it);
+#ifdef MGX_LAB
+      if (dense && live) hipLaunchKernelGGL((k_sssp_relax_dense<1024, true>), dim3(ctx.num_cus), dim3(1024), SSSP_HOTN_LIVE * 4, s, a, it);
+      else
+#endif
+      if (dense) hipLaunchKernelGGL((k_sssp_relax_dense<1024, false>), dim3(ctx.num_cus), dim3(1024), SSSP_HOTN_DENSE * 2, s, a, it);
       if (st.time_kernels) MGX_HIP(hipEventRecord(st.ev[2 * i + 1], s));
       if (build2) hipLaunchKernelGGL(k_sssp_build2<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, it);
       else hipLaunchKernelGGL(k_sssp_build<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, it);
