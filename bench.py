@@ -388,8 +388,8 @@ def bench_bfs(args, ctx, stream):
     med = per_call_ms[len(per_call_ms) // 2] if per_call_ms else 0.0
     per_src_rate = sorted(mt / max(t, 1e-12) / 1e6 for mt, t in zip(per_src_mt, per_src_s))
     submission = "one library call per source" if args.per_call else \
-        ("the %d sources submitted as ONE batch (mgx_bfs_run_many: the traversals one after the other on the device, no host round "
-         "trip in between; two states alternate, a traversal that needs another launch slot is continued behind the next one)" % len(timed))
+        ("the %d sources submitted as ONE batch (mgx_bfs_run_many: the traversals one after the other on the device, each complete before the "
+         "next one's init kernel resets the state; the host waits once, at the end)" % len(timed))
     out = {"metric": "MTEPS (million traversed edges/sec) BFS advance+filter, %s" % ("RMAT-%d" % args.scale if not args.file else os.path.basename(args.file)),
            "value": round(value, 2), "unit": "MTEPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 4), "higher_is_better": True,
@@ -410,7 +410,7 @@ def bench_bfs(args, ctx, stream):
                                 "over sources (SURVEY 8d)" % len(timed)},
            "graph500_MTEPS": round(m_t / 2.0 / elapsed / 1e6, 2),
            "graph500_note": "Graph500 convention: undirected input edges inside the reached component / time = m_t / 2 on the symmetrised CSR (SURVEY 8d)",
-           "batch_continued": reruns, "slots_needed_hist": {str(k): v for k, v in sorted(slots_hist.items())},
+           "batch_reruns": reruns, "slots_needed_hist": {str(k): v for k, v in sorted(slots_hist.items())},
            "device_ms_per_step": round(dev_ms / max(args.steps, 1), 4),
            "avg_levels": round(sum(st["levels"] for st in stats) / K, 2),
            "avg_slots": round(sum(st["slots"] for st in stats) / K, 2),

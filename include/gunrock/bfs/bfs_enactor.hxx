@@ -269,9 +269,6 @@ struct bfs_fused_enactor_t {
   // again on their own (they did not finish within the slots the batch gave them).
   char* many_heads = nullptr;       // pinned
   int many_cap = 0;
-  // the second state of a batch (mgx::bfs_lane_t): bitmaps, marks, queues, control block and a labels buffer of its own
-  std::unique_ptr<mgx::bfs_fused_state_t> fused2;
-  mem_t<int> labels2;
   int enact_many(std::shared_ptr<bfs_problem_t> bfs_problem, standard_context_t& context, const int* srcs, int count,
                  std::vector<bfs_run_stats_t>& out, bool direction_optimizing = false, float alpha = 0.f) {
     auto& g = *bfs_problem->gslice;
@@ -283,22 +280,9 @@ struct bfs_fused_enactor_t {
       MGX_HIP(hipHostMalloc((void**)&many_heads, (size_t)count * mgx::bfs_many_head_bytes(), hipHostMallocDefault));
       many_cap = count;
     }
-    mgx::bfs_lane_t lanes[2];
-    lanes[0].st = fused.get(); lanes[0].labels = bfs_problem->d_labels.data();
-    int nlanes = 1;
-    if (fused->opts.many_states >= 2 && count >= 2) {
-      if (!fused2) {                                   // the second state of a batch, made at the first one
-        context.synchronize();
-        fused2.reset(new mgx::bfs_fused_state_t(g.num_nodes, context));
-        labels2 = mem_t<int>((size_t)g.num_nodes + 4, context);
-        context.synchronize();
-      }
-      lanes[1].st = fused2.get(); lanes[1].labels = labels2.data();
-      nlanes = 2;
-    }
-    const int reruns = mgx::bfs_fused_run_many(lanes, nlanes, g.d_row_offsets.data(), g.d_col_indices.data(), srcs, count, context, many_heads,
-                                               use_layout ? &layout : nullptr, direction_optimizing ? 1 : 0, alpha,
-                                               g.d_col_offsets.data(), g.d_row_indices.data());
+    const int reruns = mgx::bfs_fused_run_many(*fused, g.d_row_offsets.data(), g.d_col_indices.data(), bfs_problem->d_labels.data(), srcs,
+                                               count, context, many_heads, use_layout ? &layout : nullptr, direction_optimizing ? 1 : 0,
+                                               alpha, g.d_col_offsets.data(), g.d_row_indices.data());
     out.assign((size_t)count, bfs_run_stats_t());
     for (int i = 0; i < count; ++i) fill_stats(out[(size_t)i], mgx::bfs_many_head(many_heads, i), direction_optimizing, false);
     if (count > 0) { last = out.back(); bfs_problem->src = srcs[count - 1]; }

@@ -224,9 +224,8 @@ MGX_API int mgx_bfs_run_stats(mgx_bfs_t p, int src, int mode, float alpha, int64
  * taken) enqueued back to back on the context's stream with ONE host wait at the end -- the reference's one-call-per-
  * source driver (test_bfs.cu:32-42) pays a host round trip per traversal, ~18 us of a 0.35 ms RMAT-22 traversal here.
  * stats: count x cap entries, row i = the counters of sources[i] (the layout of mgx_bfs_run_stats; timing entries are 0);
- * the labels (mgx_bfs_labels) are those of the LAST source.  The batch alternates between two states, so a traversal that
- * needs more launch slots than its predecessors did is continued behind the next one (they may complete out of order; all
- * are complete on return).  *reruns (optional): how many traversals were continued (or, MGX_BFS_MANY_STATES=1, run again). */
+ * the labels (mgx_bfs_labels) are those of the LAST source.  *reruns (optional): traversals that did not finish inside the
+ * batch and were run again on their own (a source whose level structure needed more launch slots than its predecessors). */
 MGX_API int mgx_bfs_run_many(mgx_bfs_t p, const int* sources, int count, int mode, float alpha, int64_t* stats, int cap, int* reruns);
 /* per-level trace of the last mgx_bfs_run: level_nf[i], level_edges[i] for i < *levels  */
 MGX_API int mgx_bfs_level_trace(mgx_bfs_t p, int cap, int64_t* level_nf, int64_t* level_edges, int* levels);

@@ -297,19 +297,16 @@ __device__ __forceinline__ void bfs_seed_queue(const bfs_fused_args_t& a, u32 ro
 // Start of a traversal, one launch: clears labels (-1), bitmap(s) and marks, and seeds the source.  The thread that
 // clears the element holding the source's label / bit writes the seed value instead, so there is no ordering
 // between workgroups to worry about.
-// prev_ctrl / prev_head (batches of sources, bfs_fused_run_many): the head of the control block the PREVIOUS traversal of the
-// batch left -- in the other state of the pair, prev_ctrl -- goes to (pinned) host memory first, then the sequence number the
-// host waits for (this launch starts when that traversal's last launch has ended: the host learns whether it is complete
-// while this one runs).  Written by workgroup 0 only; nobody touches that block here.
+// prev_ctrl / prev_head (batches of sources, bfs_fused_run_many): the head of the control block as the PREVIOUS traversal of
+// the batch left it goes to (pinned) host memory first -- by the workgroup whose thread 0 then resets it; nobody else
+// touches the block here.
 __global__ __launch_bounds__(BLOCK) void k_bfs_fused_init(bfs_fused_args_t a, int src, long long nwords, const bfs_ctrl_t* prev_ctrl,
-                                                          bfs_ctrl_t* prev_head, int head_words, u64* host_seq, u64 seq) {
+                                                          bfs_ctrl_t* prev_head, int head_words) {
   if (prev_head && blockIdx.x == 0) {
     const u32* const from = (const u32*)prev_ctrl;
     u32* const to = (u32*)prev_head;
     for (int i = threadIdx.x; i < head_words; i += BLOCK) to[i] = from[i];
-    __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0 && host_seq) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   const int src_old = src;
   if (a.new_of_old) src = a.new_of_old[src];           // labels live in ORIGINAL id space, everything else in layout space
@@ -980,10 +977,9 @@ struct bfs_run_opts_t {
   int spin = -1;           // MGX_BFS_SPIN: 0 read the control block back with a copy + hipStreamSynchronize, 1 publish kernel + spin
   int build_list = 0;      // MGX_BFS_BUILD_LIST=1: the list-based queue build (k_bfs_build) instead of k_bfs_build2
   int mini = 1;            // MGX_BFS_MINI=0: no M launches (mid-size levels take device-wide slots; bfs_fused_mini.hpp)
-  int many_states = 2;     // MGX_BFS_MANY_STATES=1: a batch (mgx_bfs_run_many) keeps ONE state: a traversal that does not finish in its slots runs
-                           // again; 2: two states alternate and an unfinished traversal is continued behind the next one (bfs_fused_run_many)
   int many_spare = 0;      // MGX_BFS_MANY_SPARE: launch slots a traversal of a batch (mgx_bfs_run_many) gets beyond what the last
-                           // traversals of the graph needed (a batch continues a traversal that did not finish: bfs_fused_run_many)
+                           // traversals of the graph needed (the most any of the last four needed: one that still does not finish is run
+                           // again on its own, and the chain behind a traversal's last slot takes stragglers of up to BFS_CHAIN_CAP_BIG edges)
 #ifdef MGX_LAB
   int flags = 0;           // MGX_BFS_FLAGS (instrumented stream kernel)
   int sstream = 0;         // MGX_BFS_SSTREAM=1: dense short rows as one stream of entries (bfs_fused_sshort.hpp) instead of vertex by
@@ -1022,7 +1018,6 @@ struct bfs_run_opts_t {
     geti("MGX_BFS_TAIL_FRONT", o.tail_front);
     geti("MGX_BFS_CHAIN_BIG_EDGES", o.chain_big);
     geti("MGX_BFS_MINI", o.mini);
-    geti("MGX_BFS_MANY_STATES", o.many_states);
     geti("MGX_BFS_MANY_SPARE", o.many_spare);
     if (o.many_spare < 0) o.many_spare = 0;
     geti("MGX_BFS_LAZY", o.lazy);

@@ -412,11 +412,10 @@ inline void bfs_enqueue_mini(const bfs_launch_plan_t& plan, int slot, hipStream_
 // init, the chain of the tiny levels at the start, and (M launches on) the first mid-size level: returns the first slot
 // that is still to be launched
 inline int bfs_enqueue_start(const bfs_fused_state_t& st, const bfs_launch_plan_t& plan, int src, standard_context_t& ctx,
-                             const bfs_ctrl_t* prev_ctrl = nullptr, bfs_ctrl_t* prev_head = nullptr, int head_words = 0,
-                             u64* host_seq = nullptr, u64 seq = 0) {
+                             const bfs_ctrl_t* prev_ctrl = nullptr, bfs_ctrl_t* prev_head = nullptr, int head_words = 0) {
   hipStream_t s = ctx.stream();
   hipLaunchKernelGGL(k_bfs_fused_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, plan.a, src,
-                     plan.nwords, prev_ctrl, prev_head, head_words, host_seq, seq);
+                     plan.nwords, prev_ctrl, prev_head, head_words);
   if (plan.a.chain_big_edges) bfs_enqueue_chain_inplace(plan, 0, s);
   if (plan.minis) { bfs_enqueue_mini(plan, 0, s); return 1; }
   return 0;
@@ -644,153 +643,72 @@ constexpr size_t bfs_head_bytes() { return offsetof(bfs_ctrl_t, trace) + 64 * si
 constexpr size_t bfs_many_head_bytes() { return (bfs_head_bytes() + 63) & ~(size_t)63; }
 inline bfs_ctrl_t* bfs_many_head(char* heads, int i) { return (bfs_ctrl_t*)(heads + (size_t)i * bfs_many_head_bytes()); }
 
-// A batch alternates between TWO states (bitmaps, marks, queues, control block, labels buffer) on the one stream: source i
-// runs on state i & 1.  A traversal gets the launch slots most traversals of the graph need -- no spare ones: an idle slot
-// is two launches, ~9 us -- and the init kernel of the NEXT traversal (the other state) hands its control block to the host.
-// The host is one traversal ahead of the device: while traversal i + 1 runs it looks at traversal i, and if that one did not
-// finish (a source next to a hub needs a device-wide slot more than the others) it enqueues the missing slots behind
-// traversal i + 1 -- the state of traversal i is untouched until traversal i + 2 -- instead of running it again.  The
-// traversals of a batch may therefore complete out of order; each is complete when the call returns.
-struct bfs_lane_t {
-  bfs_fused_state_t* st = nullptr;
-  int* labels = nullptr;
-};
-
-inline int bfs_fused_run_many(bfs_lane_t* lanes, int nlanes, const int* row_offsets, const int* col_indices,
+// Tried for the batch and dropped (each measured on RMAT-22, 64 sources; the code is in the history of this file):
+//   * two LANES -- state + HIP stream each -- with the sources alternating between them, so that the single-workgroup
+//     launches at the start and end of one traversal overlap the device-wide launches of the other: 0.446 ms per traversal
+//     against 0.349 (0.615 against 0.340 without M launches): two push launches that each want two 80 KB workgroups per CU
+//     and the L2 for their bitmaps take turns instead of overlapping;
+//   * two STATES on one stream with the host one traversal ahead, every traversal sized by the source that needs FEWEST slots
+//     and an unfinished one continued behind the next instead of run again: 0.366 against 0.343 ms -- 35 of the 64 sources
+//     needed the continuation, and each one drains the queue while the host looks at its control block.
+inline int bfs_fused_run_many(bfs_fused_state_t& st, const int* row_offsets, const int* col_indices, int* labels,
                               const int* srcs, int count, standard_context_t& ctx, char* heads, const bfs_layout_t* layout = nullptr,
                               int mode = 0, float alpha = 0.f, const int* in_offsets = nullptr, const int* in_indices = nullptr) {
   if (count <= 0) return 0;
-  if (nlanes > 2) nlanes = 2;
-  if (count < 2) nlanes = 1;
   hipStream_t s = ctx.stream();
-  bfs_fused_state_t& st0 = *lanes[0].st;
+  const bfs_launch_plan_t plan = bfs_fused_plan(st, row_offsets, col_indices, labels, ctx, layout, mode, alpha, in_offsets, in_indices);
+  const bfs_fused_args_t& a = plan.a;
   constexpr int head_words = (int)(bfs_head_bytes() / 4);
-  bfs_launch_plan_t plan[2], plan_tail[2];
-  for (int l = 0; l < nlanes; ++l) {
-    plan[l] = bfs_fused_plan(*lanes[l].st, row_offsets, col_indices, lanes[l].labels, ctx, layout, mode, alpha, in_offsets, in_indices);
-    // the chain behind a traversal's last slot may run levels up to the list capacity here (a lone workgroup needs ~4.3 us
-    // per 1000 edges: slower than a slot above ~4000 edges, but it may save the traversal a continuation)
-    plan_tail[l] = plan[l];
-    plan_tail[l].a.chain_big_edges = BFS_CHAIN_CAP_BIG;
-  }
-  const bfs_fused_args_t& a = plan[0].a;
-  const bool tail = a.chain_big_edges && st0.opts.tail_chain;
-  // slots per traversal: with two states what the FEWEST of the last traversals needed (the others are continued), with one
-  // what the most needed (a traversal that does not finish there is run again)
-  int nslots = st0.slots_hint;
-  if (nlanes == 2) {
-    nslots = 1 << 30;
-    for (int i = 0; i < 4 && i < st0.recent_at; ++i) if (st0.recent_need[i] < nslots) nslots = st0.recent_need[i];
-    if (nslots == (1 << 30)) nslots = st0.slots_hint;
-  }
-  nslots += st0.opts.many_spare;
+  int nslots = st.slots_hint + st.opts.many_spare;
   if (nslots > 30) nslots = 30;
   if (nslots < 1) nslots = 1;
-  int saved_tail[2] = {0, 0};
-  for (int l = 0; l < nlanes; ++l) {
-    saved_tail[l] = lanes[l].st->tail_from;
-    lanes[l].st->tail_from = plan[l].minis ? (1 << 30) : nslots - 1;   // (no M launches: a chain launch in front of the last slot and behind the batch)
+  const int saved_tail = st.tail_from;
+  st.tail_from = plan.minis ? (1 << 30) : nslots - 1;      // (no M launches: a chain launch in front of the last slot and behind the batch)
+  const bool tail = a.chain_big_edges && st.opts.tail_chain;
+  int last_slot = nslots;                          // the slot the chain behind a traversal works in: where an unfinished one stands
+  // the chain behind a traversal's last slot may run levels up to the list capacity here (a lone workgroup needs ~4.3 us per
+  // 1000 edges: slower than a slot above ~4000 edges, but far cheaper than running the whole traversal again)
+  bfs_launch_plan_t plan_tail = plan;
+  plan_tail.a.chain_big_edges = BFS_CHAIN_CAP_BIG;
+  for (int i = 0; i < count; ++i) {
+    // (the head of the control block as the previous traversal left it goes to the host before the init kernel resets it)
+    int sl = bfs_enqueue_start(st, plan, srcs[i], ctx, i > 0 ? st.ctrl.data() : (const bfs_ctrl_t*)nullptr,
+                               i > 0 ? bfs_many_head(heads, i - 1) : (bfs_ctrl_t*)nullptr, head_words);
+    for (int k = 0; k < nslots; ++k, ++sl) bfs_enqueue_slot(st, plan, sl, ctx);
+    if (plan.minis) { bfs_enqueue_mini(plan, sl, s); ++sl; }
+    if (tail) bfs_enqueue_chain_inplace(plan_tail, sl, s);
+    last_slot = sl;
   }
-  auto spin = [&](volatile u64* flag, u64 want) {
+  st.tail_from = saved_tail;
+  const u64 seq = ++st.seq;
+  hipLaunchKernelGGL(k_bfs_publish, dim3(1), dim3(256), 0, s, (const bfs_ctrl_t*)st.ctrl.data(), bfs_many_head(heads, count - 1), st.host_seq, seq, head_words);
+  MGX_CHECK_LAUNCH("fused BFS (batch of sources): kernel launch");
+  {
+    volatile u64* const flag = st.host_seq;
     long long spins = 0;
-    while (*flag != want) {
+    while (*flag != seq) {
       if (++spins > 20000000LL) { MGX_HIP(hipStreamSynchronize(s)); break; }
       __builtin_ia32_pause();
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  };
-  // is the traversal whose head is `h` over, `slot` launch slots into it?  (as in bfs_fused_run: done, or the last slot left
-  // both queues of the next one empty)
-  auto finished = [&](bfs_ctrl_t* h, int slot) {
-    if (!h->done) {
-      const u64 next = h->cursor[slot % 3] | h->lcursor[slot % 3];
-      if ((next >> BFS_VSHIFT) == 0) { h->done = 1; h->levels = h->slot_level[slot & 3]; }
-    }
-    return h->done != 0;
-  };
-  int continued = 0, reruns = 0;
-  int slots_of[2] = {0, 0};                         // launch slots enqueued so far for the traversal in each state
-  // make sure traversal j (state j & 1) is complete; the device is behind its last enqueued launch when this is called with
-  // `published` (its head is on the host), otherwise a publish launch is enqueued and waited for
-  auto settle = [&](int j, bool published) {
-    const int l = j % nlanes;
-    bfs_fused_state_t& st = *lanes[l].st;
-    bfs_ctrl_t* const h = bfs_many_head(heads, j);
-    for (int round = 0;; ++round) {
-      if (!published) {
-        const u64 q = ++st.seq;
-        hipLaunchKernelGGL(k_bfs_publish, dim3(1), dim3(256), 0, s, (const bfs_ctrl_t*)st.ctrl.data(), h, st.host_seq, q, head_words);
-        MGX_CHECK_LAUNCH("fused BFS (batch of sources): kernel launch");
-        spin(st.host_seq, q);
-      }
-      published = false;
-      if (finished(h, slots_of[l])) break;
-      // two more device-wide slots and the chain, in this traversal's own state
-      if (round == 0) ++continued;
-      for (int k = 0; k < 2; ++k, ++slots_of[l]) bfs_enqueue_slot(st, plan[l], slots_of[l], ctx);
-      if (tail) bfs_enqueue_chain_inplace(plan_tail[l], slots_of[l], s);
-    }
-    bfs_learn_slots(st0, a, h, mode, 64, plan[0].minis);
-  };
-  u64 pub_seq[2] = {0, 0};                          // what the init kernel of the following traversal stores for state l's traversal
-  for (int i = 0; i < count; ++i) {
-    const int l = i % nlanes;
-    bfs_fused_state_t& st = *lanes[l].st;
-    // state l is about to be reset: its previous traversal (i - 2) must be complete -- its head came with traversal i - 1's init
-    if (nlanes == 2 && i >= 2) {
-      spin(lanes[l].st->host_seq, pub_seq[l]);
-      settle(i - 2, true);
-    }
-    const bfs_ctrl_t* prev_ctrl = nullptr;
-    bfs_ctrl_t* prev_head = nullptr;
-    u64* seq_ptr = nullptr;
-    u64 q = 0;
-    if (i >= 1) {
-      const int pl = (i - 1) % nlanes;                // (one state: the previous traversal of the SAME state, copied before the reset)
-      prev_ctrl = lanes[pl].st->ctrl.data();
-      prev_head = bfs_many_head(heads, i - 1);
-      if (nlanes == 2) { q = ++lanes[pl].st->seq; seq_ptr = lanes[pl].st->host_seq; pub_seq[pl] = q; }
-    }
-    int sl = bfs_enqueue_start(st, plan[l], srcs[i], ctx, prev_ctrl, prev_head, head_words, seq_ptr, q);
-    for (int k = 0; k < nslots; ++k, ++sl) bfs_enqueue_slot(st, plan[l], sl, ctx);
-    if (plan[l].minis) { bfs_enqueue_mini(plan[l], sl, s); ++sl; }
-    if (tail) bfs_enqueue_chain_inplace(plan_tail[l], sl, s);
-    slots_of[l] = sl;
   }
-  for (int l = 0; l < nlanes; ++l) lanes[l].st->tail_from = saved_tail[l];
-  if (nlanes == 2) {
-    // the last two traversals: the one before the last was published by the last one's init
-    if (count >= 2) { spin(lanes[(count - 2) % 2].st->host_seq, pub_seq[(count - 2) % 2]); settle(count - 2, true); }
-    settle(count - 1, false);
-    // the labels of the LAST source belong in state 0's buffer (the caller's)
-    if ((count - 1) % 2 != 0) {
-      MGX_HIP(hipMemcpyAsync(lanes[0].labels, lanes[1].labels, (size_t)st0.n * sizeof(int), hipMemcpyDeviceToDevice, s));
-      MGX_HIP(hipStreamSynchronize(s));
-    }
-    st0.slots_used = slots_of[(count - 1) % 2];
-    (void)reruns;
-    return continued;
-  }
-  // ---- one state: the heads of all but the last came with the following init; unfinished traversals run again ------------
-  {
-    const u64 q = ++st0.seq;
-    hipLaunchKernelGGL(k_bfs_publish, dim3(1), dim3(256), 0, s, (const bfs_ctrl_t*)st0.ctrl.data(), bfs_many_head(heads, count - 1), st0.host_seq, q,
-                       head_words);
-    MGX_CHECK_LAUNCH("fused BFS (batch of sources): kernel launch");
-    spin(st0.host_seq, q);
-  }
-  const int last_slot = slots_of[0];
+  // finished?  (as in bfs_fused_run: done, or the last slot left both queues of the next one empty)
+  int reruns = 0;
   bool redo_last = false;
   for (int i = 0; i < count; ++i) {
     bfs_ctrl_t* const h = bfs_many_head(heads, i);
-    if (finished(h, last_slot)) { bfs_learn_slots(st0, a, h, mode, 64, plan[0].minis); continue; }
-    bfs_fused_run(st0, row_offsets, col_indices, lanes[0].labels, srcs[i], ctx, layout, mode, alpha, in_offsets, in_indices);
-    memcpy(h, st0.host_ctrl, bfs_head_bytes());
+    if (!h->done) {
+      const u64 next = h->cursor[last_slot % 3] | h->lcursor[last_slot % 3];
+      if ((next >> BFS_VSHIFT) == 0) { h->done = 1; h->levels = h->slot_level[last_slot & 3]; }
+    }
+    if (h->done) { bfs_learn_slots(st, a, h, mode, 64, plan.minis); continue; }
+    bfs_fused_run(st, row_offsets, col_indices, labels, srcs[i], ctx, layout, mode, alpha, in_offsets, in_indices);
+    memcpy(h, st.host_ctrl, bfs_head_bytes());
     ++reruns;
     if (i != count - 1) redo_last = true;
   }
-  if (redo_last) bfs_fused_run(st0, row_offsets, col_indices, lanes[0].labels, srcs[count - 1], ctx, layout, mode, alpha, in_offsets, in_indices);
-  st0.slots_used = last_slot;
+  if (redo_last) bfs_fused_run(st, row_offsets, col_indices, labels, srcs[count - 1], ctx, layout, mode, alpha, in_offsets, in_indices);
+  st.slots_used = last_slot;
   return reruns;
 }
 
