@@ -11,7 +11,7 @@ for f in glob.glob(os.path.join(O, "trace", "**", "*kernel_stats.csv"), recursiv
         for r in keep:
             r = dict(r); r["Name"] = r["Name"][:120]; w.writerow(r)
     for r in rows:
-        for kn in ("k_bfs_push<false, 0>", "k_bfs_push<false, 1>", "k_bfs_push<false, 2>", "k_bfs_push<false, 3>", "k_bfs_build", "k_bfs_fused_init", "k_bfs_pull_level", "k_bfs_chain_inplace", "k_bfs_publish"):
+        for kn in ("k_bfs_push<false, 0>", "k_bfs_push<false, 1>", "k_bfs_push<false, 2>", "k_bfs_push<false, 3>", "k_bfs_build", "k_bfs_fused_init", "k_bfs_pull_level", "k_bfs_chain_inplace", "k_bfs_mini", "k_bfs_publish"):
             if kn in r["Name"]:
                 out[kn] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "total_ns": int(r["TotalDurationNs"])}
                 print("kernel-trace: %s calls=%s avg=%.1f us total=%.3f ms" % (kn, r["Calls"], float(r["AverageNs"]) / 1e3, int(r["TotalDurationNs"]) / 1e6))
@@ -50,7 +50,36 @@ if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
                "correction": "2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md, HBM: gfx950 FETCH_SIZE counts 128-B read requests as 64 B)",
                "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-check; "
                           "average over every dispatch of the kernel (all slots of all traversals, as bench.py's alg_bytes_per_launch)"}
-    json.dump(traffic, open(os.path.join(O, "pmc_traffic.json"), "w"), indent=1)
+    entries = [traffic]
+    # the other modes' dominant kernels: the same two counters from passes over `bench.py --mode sssp` / `--mode pr`
+    # (kernels summed, the kernel whose dispatches count the "launches" bench.py divides by)
+    for mode, pat, unit_pat, kname in (("sssp", "k_sssp_relax", "k_sssp_relax<", "k_sssp_relax<1024> (+ k_sssp_relax_dense<1024> on heavy iterations)"),
+                                       ("pr", "k_nr_", "k_nr_edges", "neighbour-reduce operator")):
+        vals = {}
+        for cn in ("FETCH_SIZE", "WRITE_SIZE"):
+            agg, cnt = 0.0, 0
+            for f in glob.glob(os.path.join(O, "pmc_%s_%s" % (mode, cn), "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if pat in r["Kernel_Name"] and r["Counter_Name"] == cn:
+                        agg += float(r["Counter_Value"])
+                        if unit_pat in r["Kernel_Name"]:
+                            cnt += 1
+            if cnt:
+                vals[cn] = (agg, cnt)
+        if len(vals) == 2:
+            # per "launch" as bench.py counts them: sssp = one relax launch per iteration (the sweep kernel behind it rides on it),
+            # pr = one operator call (every kernel of it)
+            disp = vals["FETCH_SIZE"][1]
+            fr = vals["FETCH_SIZE"][0] * 1024.0 / disp
+            wr = vals["WRITE_SIZE"][0] * 1024.0 / vals["WRITE_SIZE"][1]
+            entries.append({"kernel": kname, "scale": scale, "mode": mode, "source_sha": bench.source_sha(), "dispatches": disp,
+                            "fetch_bytes_corrected": 2.0 * fr, "write_bytes": wr, "hbm_bytes_per_launch": 2.0 * fr + wr,
+                            "correction": traffic["correction"],
+                            "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --mode %s --steps 4 --warmup 1 --no-cpu-baseline --no-check; dispatches matching '%s'" % (mode, pat)})
+            print("pmc %s: HBM bytes per launch %.4g (read x2 %.4g, written %.4g)" % (mode, 2 * fr + wr, 2 * fr, wr))
+    out_json = dict(traffic)
+    out_json["entries"] = entries
+    json.dump(out_json, open(os.path.join(O, "pmc_traffic.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(O, "summary.json"), "w"), indent=1)
 for f in glob.glob(os.path.join(O, "bench.log")):
     line = [l for l in open(f) if l.startswith("{")]
