@@ -295,6 +295,11 @@ MGX_API int mgx_dsssp_bins(mgx_dsssp_t h, uint64_t** d_bins, int64_t* bin_capaci
 MGX_API int mgx_dsssp_receive(mgx_dsssp_t h, const uint64_t* d_pairs, int64_t count);
 MGX_API int mgx_dsssp_swap(mgx_dsssp_t h, int64_t* next_frontier_size);
 MGX_API int mgx_dsssp_distances(mgx_dsssp_t h, float* host_dist_local);
+/* The whole superstep loop from `src_global` with the library's communicator (mgx_comm_create; NULL for one rank): expand,
+ * bin counts by all-gather, the all-to-all-v of the pairs as one group of sends and receives, receive, swap, global
+ * frontier size -- until it is zero.  out4: supersteps, edges relaxed here, pairs sent from here, pairs received here.
+ * Every rank of the communicator must make the call.  No reference counterpart (README.md:4); SURVEY 8e. */
+MGX_API int mgx_dsssp_run(mgx_dsssp_t h, mgx_comm_t comm, int src_global, int64_t* out4);
 
 /* ---- partitioned BFS, generation 2 (include/mgx/bfs_dist2.hpp): every rank runs the FUSED level
  *      kernels on its rows and ranks exchange dense "newly visited" bitmaps (one all-gather of n/8 bytes

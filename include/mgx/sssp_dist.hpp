@@ -10,13 +10,18 @@
 //            the first one of a superstep puts v on the list of its owner's bin.  When the expansion is done a second
 //            kernel turns every listed v into ONE pair (v, best[v]): MIN-COMBINING BEFORE SEND -- per destination vertex
 //            and superstep a rank sends at most one pair, carrying the minimum over all its edges to v so far;
-//   exchange host side (torch.distributed): bin sizes, then all-to-all-v of the 8-byte pairs over RCCL/xGMI;
+//   exchange bin sizes, then all-to-all-v of the 8-byte pairs over RCCL/xGMI: by the library itself in dsssp_run below (one
+//            group of sends and receives on the context's stream), or by the caller between the per-step entry points
+//            (torch.distributed in mini_amd/dist_sssp.py: the gloo tests);
 //   receive  the owner takes the minimum of what arrives (atomicMin); a vertex whose distance dropped joins the next
 //            frontier once (flag + list);
 //   swap     next frontier becomes current; its global size (all-reduce of one int) ends the loop at zero.
 // Distances are non-negative floats compared through their integer view (IEEE order), as in the single-GPU engine
 // (gunrock/intrinsics.hxx); the result is the min-plus fixed point, the same bits as the single-GPU loop and the oracle.
 #pragma once
+#include <vector>
+
+#include "comm.hpp"
 #include "lbs.hpp"
 #include "runtime.hpp"
 #include "scan.hpp"
@@ -205,6 +210,93 @@ inline long long dsssp_swap(dsssp_state_t& st, standard_context_t& ctx) {
   st.frontier_size = (long long)st.host_counters[st.ranks];
   st.cur ^= 1;
   return st.frontier_size;
+}
+
+// ---- the superstep loop with the library's own communicator ----------------------------------------------------------------
+// What mini_amd/dist_sssp.py did with torch.distributed between ctypes calls, on the context's stream with direct RCCL
+// calls: expand -> the ranks' bin counts (one all-gather of R counters per rank: everybody learns the whole R x R matrix,
+// a rank reads its column) -> the all-to-all-v of the 8-byte pairs as ONE group of R - 1 sends and R - 1 receives (SURVEY
+// 8e: all seven links of a GPU busy at once) -> receive -> swap -> the global frontier size (an all-gather of one counter).
+// Three host waits per superstep (bin counts, matrix, frontier size): the message sizes have to be known on the host.
+struct dsssp_run_bufs_t {
+  mem_t<unsigned long long> matrix;     // R x R bin counts (row = sender), then R frontier sizes
+  mem_t<unsigned long long> recv;       // what the other ranks send in a superstep: at most bin_cap pairs each
+  mem_t<unsigned long long> mine;       // my row of counters / my frontier size, as the all-gathers' send buffer
+  unsigned long long* host_matrix = nullptr;
+  dsssp_run_bufs_t() {}
+  dsssp_run_bufs_t(const dsssp_run_bufs_t&) = delete;
+  dsssp_run_bufs_t& operator=(const dsssp_run_bufs_t&) = delete;
+  ~dsssp_run_bufs_t() { if (host_matrix) (void)hipHostFree(host_matrix); }
+  void ensure(const dsssp_state_t& st, standard_context_t& ctx) {
+    const size_t R = (size_t)st.ranks;
+    if (matrix.size() < R * R + R) {
+      matrix = mem_t<unsigned long long>(R * R + R, ctx);
+      mine = mem_t<unsigned long long>(R + 1, ctx);
+      if (host_matrix) (void)hipHostFree(host_matrix);
+      MGX_HIP(hipHostMalloc((void**)&host_matrix, (R * R + R) * sizeof(unsigned long long), hipHostMallocDefault));
+    }
+    const size_t want = R > 1 ? (R - 1) * (size_t)st.bin_cap + 1 : 1;
+    if (recv.size() < want) recv = mem_t<unsigned long long>(want, ctx);
+  }
+};
+
+// out4: supersteps, edges relaxed here, pairs sent from here, pairs received here
+inline void dsssp_run(dsssp_state_t& st, comm_t& cm, dsssp_run_bufs_t& bufs, int src_global, standard_context_t& ctx, long long* out4) {
+  const rccl_api_t& api = rccl_api_t::get();
+  const int R = st.ranks, me = st.rank;
+  if (R > 1 && !(api.ok() && cm.comm)) throw mgx_error(MGX_E_INVALID, "dsssp_run: more than one rank needs a communicator");
+  const bool coll = cm.comm != nullptr;          // (a one-rank communicator still runs the collectives: the tests' way to exercise them on one GPU)
+  hipStream_t s = ctx.stream();
+  bufs.ensure(st, ctx);
+  dsssp_reset(st, src_global, ctx);
+  long long supersteps = 0, relaxed = 0, sent = 0, received = 0;
+  for (;;) {
+    long long edges = 0;
+    dsssp_expand(st, ctx, &edges);                    // (waits: host_counters[0 .. R) = this rank's bin counts)
+    relaxed += edges;
+    if (coll) {
+      st.host_counters[me] = 0;                       // (a rank never bins its own vertices: expand relaxed them)
+      MGX_HIP(hipMemcpyAsync(bufs.mine.data(), st.host_counters, (size_t)R * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+      MGX_RCCL(api.AllGather(bufs.mine.data(), bufs.matrix.data(), (size_t)R, ncclUint64, cm.comm, s));
+      MGX_HIP(hipMemcpyAsync(bufs.host_matrix, bufs.matrix.data(), (size_t)R * R * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+      MGX_HIP(hipStreamSynchronize(s));
+      std::vector<long long> from(R, 0);
+      long long total = 0;
+      for (int r = 0; r < R; ++r) {
+        from[r] = r == me ? 0 : (long long)bufs.host_matrix[(size_t)r * R + me];
+        if (from[r] > st.bin_cap) throw mgx_error(MGX_E_INVALID, "dsssp_run: a rank announced more pairs than a bin holds");
+        total += from[r];
+      }
+      bool any = total > 0;
+      for (int r = 0; r < R; ++r) any |= r != me && st.host_counters[r] > 0;
+      if (any) {
+        rccl_group_t group(api);
+        long long at = 0;
+        for (int r = 0; r < R; ++r) {
+          if (r == me) continue;
+          const long long out = (long long)st.host_counters[r];
+          if (out > 0) { MGX_RCCL(api.Send(st.bins.data() + (size_t)r * st.bin_cap, (size_t)out, ncclUint64, r, cm.comm, s)); sent += out; }
+          if (from[r] > 0) { MGX_RCCL(api.Recv(bufs.recv.data() + at, (size_t)from[r], ncclUint64, r, cm.comm, s)); at += from[r]; }
+        }
+        group.end();
+      }
+      received += total;
+      dsssp_receive(st, bufs.recv.data(), total, ctx);
+    }
+    long long nf = dsssp_swap(st, ctx);                // (waits)
+    ++supersteps;
+    if (coll) {
+      bufs.host_matrix[(size_t)R * R] = (unsigned long long)nf;
+      MGX_HIP(hipMemcpyAsync(bufs.mine.data() + R, bufs.host_matrix + (size_t)R * R, sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+      MGX_RCCL(api.AllGather(bufs.mine.data() + R, bufs.matrix.data() + (size_t)R * R, 1, ncclUint64, cm.comm, s));
+      MGX_HIP(hipMemcpyAsync(bufs.host_matrix, bufs.matrix.data() + (size_t)R * R, (size_t)R * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+      MGX_HIP(hipStreamSynchronize(s));
+      nf = 0;
+      for (int r = 0; r < R; ++r) nf += (long long)bufs.host_matrix[r];
+    }
+    if (nf == 0) break;
+  }
+  out4[0] = supersteps; out4[1] = relaxed; out4[2] = sent; out4[3] = received;
 }
 
 }  // namespace mgx

@@ -142,6 +142,7 @@ SIGNATURES = {
     "mgx_dsssp_receive": [_vp, _vp, _i64],
     "mgx_dsssp_swap": [_vp, _pi64],
     "mgx_dsssp_distances": [_vp, _vp],
+    "mgx_dsssp_run": [_vp, _vp, _i, _pi64],
     "mgx_dbfs2_create": [_vp, _i, _i, _i, _vp, _vp, _vp, _pvp],
     "mgx_dbfs2_free": [_vp],
     "mgx_dbfs2_reset": [_vp, _i],

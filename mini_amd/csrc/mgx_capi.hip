@@ -67,6 +67,7 @@ struct mgx_dbfs_s {
 struct mgx_dsssp_s {
   mgx_ctx_s* c;
   mgx::dsssp_state_t st;
+  mgx::dsssp_run_bufs_t run_bufs;
 };
 
 struct mgx_dbfs2_s {
@@ -1256,6 +1257,19 @@ int mgx_dsssp_distances(mgx_dsssp_t h, float* host_dist_local) {
   use_device(h->c);
   h->c->ctx->synchronize();
   MGX_HIP(mgx::dtoh((unsigned*)host_dist_local, h->st.dist.data(), (size_t)h->st.n_local));
+  MGX_CATCH
+}
+
+int mgx_dsssp_run(mgx_dsssp_t h, mgx_comm_t comm, int src_global, int64_t* out4) {
+  MGX_TRY
+  MGX_REQUIRE(h && out4 && src_global >= 0 && src_global < h->st.n_global, "mgx_dsssp_run: bad argument");
+  MGX_REQUIRE(comm || h->st.ranks == 1, "mgx_dsssp_run: a communicator is needed for more than one rank");
+  MGX_REQUIRE(!comm || (comm->cm.ranks == h->st.ranks && comm->cm.rank == h->st.rank), "mgx_dsssp_run: communicator and engine disagree on the partition");
+  use_device(h->c);
+  mgx::comm_t none;
+  long long o[4];
+  mgx::dsssp_run(h->st, comm ? comm->cm : none, h->run_bufs, src_global, *h->c->ctx, o);
+  for (int i = 0; i < 4; ++i) out4[i] = o[i];
   MGX_CATCH
 }
 

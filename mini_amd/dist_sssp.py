@@ -15,13 +15,14 @@ DistSssp only needs an `engine` with reset/expand/send_bin/receive/swap/distance
 (C-ABI mgx_dsssp_*); the gloo CPU tests plug a small numpy engine to exercise this exchange/termination logic without a GPU.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
 from ._lib import check, lib
-from .dist_bfs import chunk_of, range_of
+from .dist_bfs import NativeComm, chunk_of, range_of
 
 
 class HipSsspRankEngine:
@@ -72,6 +73,13 @@ class HipSsspRankEngine:
         check(lib.mgx_dsssp_swap(self._h, C.byref(v)))
         return v.value
 
+    def run_native(self, src, comm):
+        """The whole superstep loop inside the library (mgx_dsssp_run) over its own RCCL communicator: no Python between
+        the supersteps.  comm: mini_amd.dist_bfs.NativeComm or None (one rank)."""
+        out = (C.c_int64 * 4)()
+        check(lib.mgx_dsssp_run(self._h, comm._h if comm is not None else None, int(src), out))
+        return {"iterations": out[0], "edges_local": out[1], "pairs_sent": out[2], "pairs_received": out[3]}
+
     def distances(self):
         out = np.empty(self.hi - self.lo, dtype=np.float32)
         check(lib.mgx_dsssp_distances(self._h, out.ctypes.data_as(C.c_void_p)))
@@ -88,12 +96,33 @@ class DistSssp:
 
     def __init__(self, engine, rank, world, comm_device):
         self.e, self.rank, self.world, self.comm_device = engine, rank, world, torch.device(comm_device)
+        # The loop inside the library (mgx_dsssp_run, direct RCCL calls on the context's stream) whenever the engine is the
+        # HIP one and the collectives run on the GPUs; the Python loop below serves the gloo tests and MGX_DIST_NATIVE=0.
+        # Same agreement protocol as DistBfs2: one rank without a communicator sends everybody to the Python loop.
+        self.native, self.comm, self.native_error = False, None, None
+        if hasattr(engine, "run_native") and self.comm_device.type == "cuda" and os.environ.get("MGX_DIST_NATIVE", "1") != "0":
+            ok = 1
+            if world > 1 or os.environ.get("MGX_DIST_FORCE_COLLECTIVES") == "1":
+                try:
+                    self.comm = NativeComm(engine.ctx, rank, world, self.comm_device)
+                except Exception as ex:
+                    self.comm, ok, self.native_error = None, 0, repr(ex)
+                if world > 1:
+                    flag = torch.tensor([ok], dtype=torch.int32, device=self.comm_device)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    ok = int(flag.item())
+                    if not ok and self.comm is not None:
+                        self.comm.close()
+                        self.comm = None
+            self.native = bool(ok)
 
     def _to_comm(self, t):
         return t if t.device == self.comm_device else t.to(self.comm_device)
 
     def run(self, src):
         e, W = self.e, self.world
+        if self.native:
+            return e.run_native(src, self.comm)
         e.reset(src)
         iterations, relaxed, sent = 0, 0, 0
         while True:

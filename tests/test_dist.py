@@ -258,6 +258,35 @@ def test_partitioned_sssp_hip_engine_ranks_share_one_gpu(built, world, scale):
     _run(world, True, scale, 30 + scale, _worker_sssp)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("collectives", ["1", "0"])
+def test_partitioned_sssp_native_loop_one_rank(built, collectives, monkeypatch):
+    """the superstep loop INSIDE the library (mgx_dsssp_run): with a one-rank RCCL communicator of the library's own the
+    count / frontier-size all-gathers are issued from C++ (collectives 1), without one the same loop runs bare (0);
+    distances bit-equal to the oracle's either way"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import mini_amd
+    from mini_amd.dist_sssp import DistSssp, HipSsspRankEngine
+    from tests.oracle_binding import Oracle
+    monkeypatch.setenv("MGX_DIST_FORCE_COLLECTIVES", collectives)
+    orc = Oracle()
+    n, ro, ci, w = orc.rmat_csr(13, 16, 77)
+    ctx = mini_amd.Context(0, torch.cuda.current_stream().cuda_stream)
+    eng = HipSsspRankEngine(ctx, n, 1, 0, torch.from_numpy(ro.astype(np.int32)).cuda(), torch.from_numpy(ci.astype(np.int32)).cuda(),
+                            torch.from_numpy(w.astype(np.float32)).cuda())
+    sssp = DistSssp(eng, 0, 1, "cuda")
+    assert sssp.native, sssp.native_error
+    assert (sssp.comm is not None) == (collectives == "1")
+    for src in (0, 5, 4097):
+        st = sssp.run(src)
+        assert st["iterations"] >= 1 and st["pairs_sent"] == 0
+        assert np.array_equal(sssp.gather_distances(), orc.sssp_dijkstra_f32(ro, ci, w, src))
+    if sssp.comm is not None:
+        sssp.comm.close()
+    eng.close()
+
+
 def test_bench_self_launch_starts_one_rank_per_gpu():
     """`python bench.py --gpus N` without a launcher starts N fresh ranks (torch.distributed.run on 127.0.0.1) before
     anything touches the GPU, instead of falling through to the 1-GPU body.  CPU: the ranks
