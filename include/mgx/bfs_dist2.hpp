@@ -78,7 +78,9 @@ __global__ __launch_bounds__(BLOCK) void k_d2_newbits(const u32* __restrict__ vi
 // stride4 x 16 bytes after map r - 1.
 __global__ __launch_bounds__(BLOCK) void k_d2_or(const uint4* __restrict__ gathered, int maps, long long stride4,
                                                  long long nwords4, uint4* __restrict__ merged,
-                                                 uint4* __restrict__ visited, bfs_ctrl_t* c) {
+                                                 uint4* __restrict__ visited, bfs_ctrl_t* c, int level) {
+  // merged = the frontier of level + 1 as a bitmap over all vertices: what the unit-block body of the next push reads
+  if (blockIdx.x == 0 && threadIdx.x == 0) c->fb_slot = level + 1;
   int found = 0;
   for (long long w = (long long)blockIdx.x * BLOCK + threadIdx.x; w < nwords4; w += (long long)gridDim.x * BLOCK) {
     uint4 g = make_uint4(0, 0, 0, 0);
@@ -214,9 +216,19 @@ __global__ __launch_bounds__(NT) void k_d2_lists_apply(bfs_fused_args_t a, int l
   }
 }
 
+// unit owners as the builder numbers them (local rows; n_local for padding units) -> global ids (n_global for padding)
+__global__ __launch_bounds__(BLOCK) void k_d2_owner_global(int* __restrict__ owner, long long units_pad, int ranks, int rank, int n_local,
+                                                           int n_global) {
+  const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= units_pad) return;
+  const int o = owner[i];
+  owner[i] = (o >= n_local) ? n_global : o * ranks + rank;
+}
+
 __global__ void k_d2_init(bfs_fused_args_t a, int* labels_local, int src, int ranks, int rank) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   bfs_ctrl_reset(a.ctrl);
+  a.ctrl->fb_slot = -1;                        // (the merged bitmap describes a level only once k_d2_or has written it)
   a.visited[src >> 5] = 1u << (src & 31);      // every rank knows the source is visited
   if (src % ranks == rank) {
     labels_local[src / ranks] = 0;
@@ -241,6 +253,12 @@ struct d2_state_t {
   mem_t<u32> own_list;
   u64* host_flag = nullptr;           // pinned: what k_d2_lists_apply tells the host
   u64 flag_seq = 0;
+  // unit blocks of the rank's long rows (mgx_layout.hip; owners in GLOBAL ids, padding units owned by vertex n_global):
+  // built on request (mgx_dbfs2_build_units), owned here
+  int* ub_col = nullptr;
+  int* ub_owner = nullptr;
+  long long ub_units = 0, ub_units_pad = 0;
+  u32 dense_div = 4;
 
   void init(standard_context_t& ctx, int n_global_, int ranks_, int rank_, const int* ro, const int* ci, u32* newbits_) {
     n_global = n_global_; ranks = ranks_; rank = rank_;
@@ -251,10 +269,15 @@ struct d2_state_t {
     if (const char* e = getenv("MGX_BFS_COLD_TEST")) cold_forced = atoi(e);
     labels = mem_t<int>((size_t)n_local + 1, ctx);
     merged = mem_t<u32>((size_t)nwords + 4, ctx);
+    MGX_HIP(hipMemsetAsync(merged.data(), 0, ((size_t)nwords + 4) * sizeof(u32), ctx.stream()));   // (the bit of vertex n_global stays 0)
     MGX_HIP(hipHostMalloc((void**)&host_flag, 64, hipHostMallocDefault));
     host_flag[0] = host_flag[1] = host_flag[2] = 0;
   }
-  ~d2_state_t() { if (host_flag) (void)hipHostFree(host_flag); }
+  ~d2_state_t() {
+    if (host_flag) (void)hipHostFree(host_flag);
+    if (ub_col) (void)hipFree(ub_col);
+    if (ub_owner) (void)hipFree(ub_owner);
+  }
   d2_state_t() {}
   d2_state_t(const d2_state_t&) = delete;
   d2_state_t& operator=(const d2_state_t&) = delete;
@@ -274,7 +297,8 @@ struct d2_state_t {
     a.labels = nullptr;
     a.visited = fs->visited.data();
     a.mark = fs->mark.data();
-    a.frontier_bits = fs->frontier_bits.data();
+    // (with unit blocks: the level's merged discoveries ARE the frontier bitmap their owners are looked up in)
+    a.frontier_bits = ub_col ? merged.data() : fs->frontier_bits.data();
     a.in_offsets = nullptr; a.in_indices = nullptr;
     for (int i = 0; i < 2; ++i) {
       a.fr_row[i] = fs->fr_row[i].data(); a.fr_off[i] = fs->fr_off[i].data();
@@ -287,7 +311,7 @@ struct d2_state_t {
     a.n = n_global;
     a.mode = 0; a.alpha = 0.f;
     a.count_marks = 0;
-    a.ub_col = nullptr; a.ub_owner = nullptr; a.ub_units = 0; a.ub_units_pad = 0; a.dense_div = 0;
+    a.ub_col = ub_col; a.ub_owner = ub_owner; a.ub_units = (u32)ub_units; a.ub_units_pad = (u32)ub_units_pad; a.dense_div = ub_col ? dense_div : 0u;
     a.vs_v[0] = a.vs_v[1] = a.vs_v[2] = a.vs_v[3] = 0; a.vs_edges = 0; a.vs_div = 0; a.vs_dummy = 0; a.lazy_div = 0; a.slot_marks = nullptr; a.merged_pull = 0; a.lazy_pull = 0; a.chain_big_edges = 0; a.defer_reach_mul = 1; a.defer_reach_div = 1;
     a.cold_owner = nullptr; a.cold_dst = nullptr; a.cold_slices = 0; a.cold_flush = nullptr;
     for (int i = 0; i < BFS_COLD_MAX_SLICES; ++i) a.cold_lo[i] = 0;
@@ -314,7 +338,7 @@ inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx) {
   bfs_fused_args_t a = st.args();
   bfs_set_kernel_attributes();
   bfs_launch_push(a, level, ctx, 2, bfs_cold_test(a.n, st.cold_forced));   // (the level's bookkeeping rides on the push launch)
-  hipLaunchKernelGGL(k_d2_newbits, dim3(grid_for(st.nwords, BLOCK, 256)), dim3(BLOCK), 0, s, st.fs->visited.data(),
+  hipLaunchKernelGGL(k_d2_newbits, dim3(grid_for(st.nwords, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, st.fs->visited.data(),
                      st.fs->mark.data(), st.newbits, st.nwords, (long long)st.n_global, a.ctrl, st.mylist, st.list_cap);
 }
 
@@ -349,7 +373,7 @@ inline void d2_merge(d2_state_t& st, int level, const u32* gathered, int maps, l
   hipStream_t s = ctx.stream();
   bfs_fused_args_t a = st.args();
   hipLaunchKernelGGL(k_d2_or, dim3(grid_for(st.nwords / 4, BLOCK, 1024)), dim3(BLOCK), 0, s, (const uint4*)gathered, maps,
-                     stride_words / 4, st.nwords / 4, (uint4*)st.merged.data(), (uint4*)st.fs->visited.data(), a.ctrl);
+                     stride_words / 4, st.nwords / 4, (uint4*)st.merged.data(), (uint4*)st.fs->visited.data(), a.ctrl, level);
   hipLaunchKernelGGL((k_bfs_build<512, false>), dim3(bfs_build_grid(st.n_local, 512)), dim3(512), 0, s, a, level,
                      (const u32*)st.merged.data(), st.labels.data(), st.n_local, st.ranks, st.rank, 0);
 }

@@ -219,12 +219,19 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push_stream_diag(bfs_fused_args
 #endif  // MGX_LAB
 
 // Explicit-level variant for the partitioned path (bfs_dist2.hpp): slot == level, the level's bookkeeping rides on
-// the launch (open_here == 2: a rank of a partitioned run), no chain, no unit blocks.
+// the launch (open_here == 2: a rank of a partitioned run), no chain; unit blocks when the rank built them.
 template <bool COLDT>
 __global__ __launch_bounds__(1024, 8) void k_bfs_push_level(bfs_fused_args_t a, int level, u32 nstream, int open_here) {
   if (open_here && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) bfs_begin_level(a, level, open_here == 2);
-  if (blockIdx.x < nstream) bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, COLDT, false, true>(a, level, blockIdx.x, nstream, level);
-  else bfs_wave_body<1024, BFS_WAVE_HOTW, COLDT, false>(a, level, blockIdx.x - nstream, gridDim.x - nstream, level);
+  if (blockIdx.x < nstream) {
+    // a rank that carries unit blocks of its rows (bfs_dist2.hpp: owners in GLOBAL ids, frontier_bits = the level's merged
+    // discoveries of all ranks) reads a level that holds a large share of its long rows from them -- the queue-less body of
+    // the single-GPU path; the long-row cursor of the level is stable while the level runs
+    if (bfs_long_is_dense(a, a.ctrl, level, a.ctrl->lcursor[level % 3])) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) a.ctrl->dense_slots += 1;
+      bfs_dense_body<1024, BFS_DENSE_HOTW, 1, COLDT>(a, level, blockIdx.x, nstream, level);
+    } else bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, COLDT, false, true>(a, level, blockIdx.x, nstream, level);
+  } else bfs_wave_body<1024, BFS_WAVE_HOTW, COLDT, false>(a, level, blockIdx.x - nstream, gridDim.x - nstream, level);
 }
 
 inline void bfs_set_kernel_attributes() {

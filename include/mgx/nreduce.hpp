@@ -15,9 +15,9 @@
 //                 the values of the first NR_HOTV layout vertices sit in LDS (160 KB: one workgroup per CU), the others
 //                 are gathered from L2 (the next 600 K vertices are 2.4 MB); 16 lanes fold a unit with
 //                 four shuffle steps in a fixed order -> partial[u].
-//   k_nr_rows     a long row's units are contiguous (ub_first[v] .. ub_first[v + 1]): one thread folds the partials of a
-//                 row of up to NR_BIG_UNITS units in order; the few rows above that (the first rows of the degree-sorted
-//                 layout) take a workgroup each.  Deterministic: the order of the fold never depends on timing.
+//   k_nr_fold     a long row's units are contiguous (ub_first[v] .. ub_first[v + 1]): one thread folds the partials of a
+//                 row of up to NR_BIG_UNITS units (four accumulators, a fixed order); the few rows above that (the first rows
+//                 of the degree-sorted layout) take a workgroup each.  Deterministic: the order of the fold never depends on timing.
 //                 Short rows: 1 .. 63 entries by degree class as in bfs_fused_vshort.hpp: 16 / 4 / 1 lanes per vertex, one
 //                 unaligned 16-byte load of four entries per lane, fold by shuffles.
 // Results go to reduced[old_of_new[v]] -- the frontier POSITION of vertex v in an iota frontier (neighborhood.hxx:58).
@@ -52,16 +52,21 @@ struct nr_layout_t {
   int n = 0;
 };
 
-// is the frontier 0, 1, ..., n - 1?  *flag was set to 1 by the host before the launch
-__global__ __launch_bounds__(BLOCK) void k_nr_check_iota(const int* __restrict__ frontier, long long n, long long* flag) {
+// is the frontier 0, 1, ..., n - 1?  *host_flag (pinned) was set to 1 by the host before the launch; *dev_flag <- epoch if it is
+// not: the kernels of the fast path are enqueued right behind this one and return at once when they find their epoch there
+// (no host wait between the check and the work; the host looks at host_flag when everything has run and takes the general
+// kernel if the answer was no).  Epochs only grow: nothing is ever reset.
+__global__ __launch_bounds__(BLOCK) void k_nr_check_iota(const int* __restrict__ frontier, long long n, long long* host_flag,
+                                                         u32* dev_flag, u32 epoch) {
   bool bad = false;
   for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) bad |= frontier[i] != (int)i;
-  if (__ballot(bad) && lane_id() == 0) *flag = 0;
+  if (__ballot(bad) && lane_id() == 0) { *host_flag = 0; *dev_flag = epoch; }
 }
 
 template <typename V, typename GetValue>
 __global__ __launch_bounds__(BLOCK) void k_nr_values(GetValue get, const int* __restrict__ old_of_new, V* __restrict__ vals,
-                                                     V* __restrict__ reduced, V identity, long long n) {
+                                                     V* __restrict__ reduced, V identity, long long n, const u32* dev_flag, u32 epoch) {
+  if (*dev_flag == epoch) return;                    // (not an iota frontier: the general kernel runs instead)
   for (long long v = (long long)blockIdx.x * BLOCK + threadIdx.x; v < n; v += (long long)gridDim.x * BLOCK) {
     vals[v] = get(old_of_new[v]);
     reduced[v] = identity;
@@ -150,36 +155,45 @@ __device__ __forceinline__ void nr_long_work(const nr_layout_t& L, const V* __re
   }
 }
 
-// rows [first_row, last_row) of the layout hold unit blocks; one thread per row folds the row's partials in order
+// A long row's partials -> its result, ONE launch: workgroups [0, big_rows) take a row of more than NR_BIG_UNITS units each (a
+// fixed strided fold), the others one row per thread of [big_rows, last_row): four accumulators over the units k % 4 (four
+// independent loads in flight instead of a chain of up to 64 dependent ones), combined in a fixed order.
 template <typename V, typename Op>
-__global__ __launch_bounds__(BLOCK) void k_nr_rows(nr_layout_t L, const V* __restrict__ partial, V* __restrict__ reduced, V identity, Op op,
-                                                   u32 first_row, u32 last_row) {
-  const u32 r = first_row + blockIdx.x * BLOCK + threadIdx.x;
+__global__ __launch_bounds__(BLOCK) void k_nr_fold(nr_layout_t L, const V* __restrict__ partial, V* __restrict__ reduced, V identity, Op op,
+                                                   u32 last_row, const u32* dev_flag, u32 epoch) {
+  __shared__ V s_part[BLOCK / WAVE];
+  if (*dev_flag == epoch) return;
+  if (blockIdx.x < L.big_rows) {
+    const u32 r = blockIdx.x;
+    const int u0 = L.ub_first[r], u1 = L.ub_first[r + 1];
+    V acc = identity;
+    for (int u = u0 + (int)threadIdx.x; u < u1; u += BLOCK) acc = op(acc, partial[u]);
+#pragma unroll
+    for (int sh = 1; sh < WAVE; sh <<= 1) acc = op(acc, __shfl_xor(acc, sh, WAVE));
+    if (lane_id() == 0) s_part[threadIdx.x / WAVE] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      V t = s_part[0];
+#pragma unroll
+      for (int k = 1; k < BLOCK / WAVE; ++k) t = op(t, s_part[k]);
+      reduced[L.old_of_new[r]] = t;
+    }
+    return;
+  }
+  const u32 r = L.big_rows + (blockIdx.x - L.big_rows) * BLOCK + threadIdx.x;
   if (r >= last_row) return;
   const int u0 = L.ub_first[r], u1 = L.ub_first[r + 1];
   if (u1 <= u0) return;
-  V acc = partial[u0];
-  for (int u = u0 + 1; u < u1; ++u) acc = op(acc, partial[u]);
-  reduced[L.old_of_new[r]] = acc;
-}
-// ... and the rows of more than NR_BIG_UNITS units: a workgroup each, a fixed strided fold
-template <typename V, typename Op>
-__global__ __launch_bounds__(BLOCK) void k_nr_big_rows(nr_layout_t L, const V* __restrict__ partial, V* __restrict__ reduced, V identity, Op op) {
-  __shared__ V s_part[BLOCK / WAVE];
-  const u32 r = blockIdx.x;
-  const int u0 = L.ub_first[r], u1 = L.ub_first[r + 1];
-  V acc = identity;
-  for (int u = u0 + (int)threadIdx.x; u < u1; u += BLOCK) acc = op(acc, partial[u]);
-#pragma unroll
-  for (int sh = 1; sh < WAVE; sh <<= 1) acc = op(acc, __shfl_xor(acc, sh, WAVE));
-  if (lane_id() == 0) s_part[threadIdx.x / WAVE] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    V t = s_part[0];
-#pragma unroll
-    for (int k = 1; k < BLOCK / WAVE; ++k) t = op(t, s_part[k]);
-    reduced[L.old_of_new[r]] = t;
+  V a0 = identity, a1 = identity, a2 = identity, a3 = identity;
+  int u = u0;
+  for (; u + 4 <= u1; u += 4) {
+    const V p0 = partial[u], p1 = partial[u + 1], p2 = partial[u + 2], p3 = partial[u + 3];
+    a0 = op(a0, p0); a1 = op(a1, p1); a2 = op(a2, p2); a3 = op(a3, p3);
   }
+  if (u < u1) a0 = op(a0, partial[u]);
+  if (u + 1 < u1) a1 = op(a1, partial[u + 1]);
+  if (u + 2 < u1) a2 = op(a2, partial[u + 2]);
+  reduced[L.old_of_new[r]] = op(op(a0, a1), op(a2, a3));
 }
 
 // short rows by degree class: [vs_v[0], vs_v[1]) 16 lanes per vertex (17 .. 63 entries), [vs_v[1], vs_v[2]) 4 lanes (5 .. 16),
@@ -242,13 +256,13 @@ __device__ __forceinline__ void nr_short_work(const nr_layout_t& L, const V* __r
 // HOTV values in LDS, WPE waves per SIMD: one workgroup of 1024 threads per CU
 template <typename V, typename Op, int NT, int HOTV = NR_HOTV, int WPE = 4>
 __global__ __launch_bounds__(NT, WPE) void k_nr_edges(nr_layout_t L, const V* __restrict__ vals, V* __restrict__ partial, V* __restrict__ reduced,
-                                                    V identity, Op op, u32 nlong) {
+                                                    V identity, Op op, const u32* dev_flag, u32 epoch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (*dev_flag == epoch) return;                    // (grid-uniform)
   const u32 hot_n = (u32)L.n < (u32)HOTV ? (u32)L.n : (u32)HOTV;
   const V* const hot = nr_hot_setup<V, NT>(smem, vals, hot_n);
   // every workgroup takes its share of BOTH parts, one after the other over the same LDS values: the parts differ in cost
   // per entry (the short rows pay a planning load per vertex), so any fixed split of the grid leaves one half waiting
-  (void)nlong;
   nr_long_work<V, Op, NT>(L, vals, hot, hot_n, partial, identity, op, blockIdx.x, gridDim.x);
   nr_short_work<V, Op, NT>(L, vals, hot, hot_n, reduced, identity, op, blockIdx.x, gridDim.x);
 }
@@ -258,9 +272,11 @@ inline size_t nr_scratch_bytes(long long n, long long units_pad, size_t value_si
   return (((size_t)n + 64) * value_size + 255) / 256 * 256 + ((size_t)units_pad + 64) * value_size;
 }
 
-// The whole fast path.  get(old_id) -> V; reduced: n entries.  Everything is enqueued on the context's stream.
+// The whole fast path.  get(old_id) -> V; reduced: n entries.  Everything is enqueued on the context's stream; every kernel
+// returns at once if *dev_flag == epoch (k_nr_check_iota's verdict, enqueued in front by the caller).
 template <typename V, typename Op, typename GetValue>
-inline void nr_full_frontier(const nr_layout_t& L, GetValue get, V* reduced, V identity, Op op, standard_context_t& ctx) {
+inline void nr_full_frontier(const nr_layout_t& L, GetValue get, V* reduced, V identity, Op op, standard_context_t& ctx, const u32* dev_flag,
+                             u32 epoch) {
   hipStream_t s = ctx.stream();
   V* const vals = (V*)ctx.scratch;
   V* const partial = (V*)((char*)ctx.scratch + (((size_t)L.n + 64) * sizeof(V) + 255) / 256 * 256);
@@ -268,17 +284,16 @@ inline void nr_full_frontier(const nr_layout_t& L, GetValue get, V* reduced, V i
   if (first_use_on_device(seen))
     MGX_HIP(hipFuncSetAttribute((const void*)(k_nr_edges<V, Op, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL((k_nr_values<V, GetValue>), dim3(grid_for(L.n, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, get, L.old_of_new, vals,
-                     reduced, identity, (long long)L.n);
+                     reduced, identity, (long long)L.n, dev_flag, epoch);
   const u32 long_rows = L.vs_v[0];
   const bool has_long = L.ub_units > 0 && long_rows > 0, has_short = L.vs_v[3] > L.vs_v[0];
   if (has_long || has_short)
     hipLaunchKernelGGL((k_nr_edges<V, Op, 1024>), dim3(ctx.num_cus), dim3(1024), nr_lds_bytes(), s, L, (const V*)vals, partial, reduced,
-                       identity, op, 0u);
+                       identity, op, dev_flag, epoch);
   if (has_long) {
-    if (L.big_rows > 0) hipLaunchKernelGGL((k_nr_big_rows<V, Op>), dim3(L.big_rows), dim3(BLOCK), 0, s, L, (const V*)partial, reduced, identity, op);
-    if (long_rows > L.big_rows)
-      hipLaunchKernelGGL((k_nr_rows<V, Op>), dim3((long_rows - L.big_rows + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, L, (const V*)partial, reduced,
-                         identity, op, L.big_rows, long_rows);
+    const u32 rest = long_rows > L.big_rows ? long_rows - L.big_rows : 0u;
+    const u32 grid = L.big_rows + (rest + BLOCK - 1) / BLOCK;
+    if (grid) hipLaunchKernelGGL((k_nr_fold<V, Op>), dim3(grid), dim3(BLOCK), 0, s, L, (const V*)partial, reduced, identity, op, long_rows, dev_flag, epoch);
   }
 }
 

@@ -99,6 +99,14 @@ struct standard_context_t : context_t {
   unsigned* lookback_ticket = nullptr;      // monotonically increasing across launches; a launch subtracts its base
   unsigned lookback_ticket_base = 0;        // (host mirror: tickets handed out by the launches enqueued so far)
   unsigned lookback_epoch = 0;
+  // the neighbour-reduce's verdict word (mgx/nreduce.hpp): lives behind the ticket counter in the same 64-byte allocation,
+  // holds the epoch of the last full-frontier call whose frontier was not the iota (0: none yet)
+  unsigned nr_epoch = 0;
+  unsigned* nr_flag() const { return lookback_ticket + 8; }
+  unsigned next_nr_epoch() {
+    if (++nr_epoch == 0u) nr_epoch = 1u;      // (2^32 calls: a stale word could only name the call 2^32 - 1 before this one)
+    return nr_epoch;
+  }
 
   explicit standard_context_t(bool print_prop = false, hipStream_t s = nullptr) : _stream(s) {
     set_current_stream(s);

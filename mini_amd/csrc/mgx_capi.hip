@@ -1287,6 +1287,39 @@ int mgx_dbfs2_create(mgx_ctx_t c, int n_global, int ranks, int rank, const int* 
   *out = h;
   MGX_CATCH
 }
+int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
+  MGX_TRY
+  MGX_REQUIRE(h, "NULL argument");
+  use_device(h->c);
+  mgx::d2_state_t& st = h->st;
+  if (units) *units = 0;
+  if (st.ub_col) { if (units) *units = st.ub_units; return MGX_OK; }
+  const int long_min = st.fs->long_min;
+  if (long_min != 64 || st.n_local <= 0) return MGX_OK;     // (a unit is 64 entries: only with the default long-row threshold)
+  h->c->ctx->synchronize();
+  int *owner = nullptr, *ucol = nullptr, *ufirst = nullptr;
+  unsigned char* ucnt = nullptr;
+  long long U = 0, Up = 0;
+  const int rc = mgx_units_build_device(st.row_offsets, st.col_indices, st.n_local, long_min, 0x7FFFFFFF, 6, &owner, &ucol, &ucnt, &ufirst, &U, &Up,
+                                        h->c->ctx->stream());
+  if (rc != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("partitioned BFS, unit blocks: ") + hipGetErrorString((hipError_t)rc));
+  if (ucnt) (void)hipFree(ucnt);
+  if (ufirst) (void)hipFree(ufirst);
+  if (U <= 0) return MGX_OK;
+  hipLaunchKernelGGL(mgx::k_d2_owner_global, dim3((unsigned)((Up + mgx::BLOCK - 1) / mgx::BLOCK)), dim3(mgx::BLOCK), 0, h->c->ctx->stream(), owner, Up,
+                     st.ranks, st.rank, st.n_local, st.n_global);
+  h->c->ctx->synchronize();
+  st.ub_owner = owner; st.ub_col = ucol; st.ub_units = U; st.ub_units_pad = Up;
+  if (const char* e = getenv("MGX_DIST_DENSE_DIV")) { const int d = atoi(e); if (d >= 0) st.dense_div = (unsigned)d; }
+  if (units) *units = U;
+  MGX_CATCH
+}
+int mgx_dbfs2_dense_levels(mgx_dbfs2_t h, int64_t* levels) {
+  MGX_TRY
+  MGX_REQUIRE(h && levels, "NULL argument");
+  *levels = (int64_t)h->st.fs->host_ctrl->dense_slots;     // (as of the last mgx_dbfs2_status / mgx_dbfs2_run)
+  MGX_CATCH
+}
 int mgx_dbfs2_free(mgx_dbfs2_t h) {
   MGX_TRY
   if (h) { use_device(h->c); delete h; }

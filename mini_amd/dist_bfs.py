@@ -194,6 +194,12 @@ class HipRankEngine2:
                                    C.c_void_p(row_offsets_local.data_ptr()), C.c_void_p(col_indices_global.data_ptr()),
                                    C.c_void_p(self.newbits.data_ptr()), C.byref(h)))
         self._h = h
+        # unit blocks of the rank's long rows: big levels read them instead of walking the long-row queue (MGX_DIST_UNITS=0: off)
+        self.units = 0
+        if os.environ.get("MGX_DIST_UNITS", "1") != "0":
+            u = C.c_int64()
+            check(lib.mgx_dbfs2_build_units(self._h, C.byref(u)))
+            self.units = u.value
         # id lists of the sparse levels (MGX_DIST_LISTS=0: bitmaps on every level)
         self.list = None
         if os.environ.get("MGX_DIST_LISTS", "1") != "0":
@@ -202,6 +208,12 @@ class HipRankEngine2:
             assert w.value == list_words(n_global, ranks)
             self.list = torch.zeros(w.value, dtype=torch.int32, device=row_offsets_local.device)
             check(lib.mgx_dbfs2_set_list(self._h, C.c_void_p(self.list.data_ptr()), w.value))
+
+    def dense_levels(self):
+        """levels of the last traversal that read the long rows from the unit blocks (valid after status() / run_native())"""
+        v = C.c_int64()
+        check(lib.mgx_dbfs2_dense_levels(self._h, C.byref(v)))
+        return v.value
 
     def reset(self, src):
         check(lib.mgx_dbfs2_reset(self._h, int(src)))

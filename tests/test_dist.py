@@ -89,11 +89,13 @@ def _worker2(rank, world, port, use_gpu, scale, seed, sources, q):
     bfs = DistBfs2(eng, rank, world, "cpu")
     ok = True
     deg = np.diff(ro)
-    sparse = dense = 0
+    sparse = dense = unit_levels = 0
     for src in sources:
         st = bfs.run(int(new_of_old[src]))
         sparse += bfs.sparse_levels
         dense += bfs.dense_levels
+        if use_gpu:
+            unit_levels += eng.dense_levels()
         got_new = bfs.gather_labels()
         got = np.empty(n, dtype=np.int32)
         got[old_of_new] = got_new
@@ -108,6 +110,9 @@ def _worker2(rank, world, port, use_gpu, scale, seed, sources, q):
         ok = ok and sparse > 0 and (dense > 0 or scale < 11)
     else:
         ok = ok and sparse == 0
+    if use_gpu and os.environ.get("MGX_TEST_EXPECT_UNIT_LEVELS") is not None:
+        # levels whose long rows were read from the rank's unit blocks (rank 0 answers for the job: it holds the first hub)
+        ok = ok and ((unit_levels > 0) == (os.environ["MGX_TEST_EXPECT_UNIT_LEVELS"] == "1")) and ((eng.units > 0) == (os.environ.get("MGX_DIST_UNITS", "1") != "0"))
     if rank == 0:
         q.put(bool(ok))
     dist.barrier()
@@ -175,6 +180,29 @@ def test_bitmap_exchange_bfs_hip_engine_ranks_share_one_gpu(built, world, scale,
     monkeypatch.setenv("MGX_DIST_EXCHANGE", exchange)
     monkeypatch.setenv("MGX_DIST_LISTS", lists)
     _run(world, True, scale, scale, _worker2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,scale,lists,units,dense_div,expect", [
+    (2, 14, "0", "1", "1000000", "1"),      # every level that has a long-row queue and a merged bitmap reads the unit blocks
+    (3, 15, "0", "1", "1000000", "1"),
+    (2, 15, "1", "1", None, None),          # the default rule (a quarter of the rank's units), lists on the sparse levels
+    (1, 14, "0", "1", "1000000", "1"),
+    (2, 14, "0", "0", None, "0")])          # no unit blocks: the queue walk on every level
+def test_partitioned_ranks_read_big_levels_from_unit_blocks(built, world, scale, lists, units, dense_div, expect, monkeypatch):
+    """mgx_dbfs2_build_units: the ranks' long rows as unit blocks with GLOBAL owners, the level's merged discoveries as the
+    frontier bitmap, cold neighbours tested against the bitmap word (k_bfs_push_level -> bfs_dense_body<., COLDT>); labels,
+    edge counts and depths equal the oracle's whichever body a level takes"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    monkeypatch.setenv("MGX_DIST_EXCHANGE", "gather")
+    monkeypatch.setenv("MGX_DIST_LISTS", lists)
+    monkeypatch.setenv("MGX_DIST_UNITS", units)
+    if dense_div is not None:
+        monkeypatch.setenv("MGX_DIST_DENSE_DIV", dense_div)
+    if expect is not None:
+        monkeypatch.setenv("MGX_TEST_EXPECT_UNIT_LEVELS", expect)
+    _run(world, True, scale, scale + 40, _worker2)
 
 
 @pytest.mark.gpu

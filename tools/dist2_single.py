@@ -68,5 +68,5 @@ for it, s in enumerate(srcs):
             same = bool(torch.equal(lab_new[n2o.cpu()], single))
             print("check vs the single-GPU traversal of the unpartitioned graph: labels equal = %s (reached %d)" % (same, int((single >= 0).sum())))
             assert same
-        print(mode + " src %d levels %d edges %d  total %.3f ms  per-rank %.3f ms  -> %.1f GTEPS aggregate (no exchange time)"
-              % (s, sts[0]["levels"], edges, dt * 1e3, dt * 1e3 / G, edges / (dt / G) / 1e9))
+        print(mode + " src %d levels %d edges %d  total %.3f ms  per-rank %.3f ms  -> %.1f GTEPS aggregate (no exchange time); levels read from unit blocks on rank 0: %d"
+              % (s, sts[0]["levels"], edges, dt * 1e3, dt * 1e3 / G, edges / (dt / G) / 1e9, engs[0].dense_levels()))
