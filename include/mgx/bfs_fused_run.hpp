@@ -657,7 +657,15 @@ inline bfs_ctrl_t* bfs_many_head(char* heads, int i) { return (bfs_ctrl_t*)(head
 //     and the L2 for their bitmaps take turns instead of overlapping;
 //   * two STATES on one stream with the host one traversal ahead, every traversal sized by the source that needs FEWEST slots
 //     and an unfinished one continued behind the next instead of run again: 0.366 against 0.343 ms -- 35 of the 64 sources
-//     needed the continuation, and each one drains the queue while the host looks at its control block.
+//     needed the continuation, and each one drains the queue while the host looks at its control block;
+//   * two lanes STAGGERED -- the device-wide slots of traversal i wait (hipStreamWaitEvent) for those of traversal i - 1, only
+//     the one-workgroup launches at the two ends of a traversal (~58 of its 339 us) may run beside the other lane's big ones:
+//     0.413 against 0.339 ms.  They do not run BESIDE a push launch -- it holds every CU's LDS and all 32 wave slots -- they
+//     wait for it (k_bfs_chain_inplace 121 us, k_bfs_fused_init 62 us, k_bfs_mini 103 us in the trace) and then hold up their
+//     own lane.  Reserving CUs for them with CU-masked streams works as such, but a grid sized for the masked device is dealt
+//     round-robin to XCDs and shader engines whatever the mask left of each: 14 of 496 workgroups start a whole workgroup run
+//     late (tools/cumask_probe2.hip), which doubles a launch of equal static shares; a symmetric reservation costs 32 CUs.
+//     (profiles/r03/lanes_and_cu_masks.txt)
 inline int bfs_fused_run_many(bfs_fused_state_t& st, const int* row_offsets, const int* col_indices, int* labels,
                               const int* srcs, int count, standard_context_t& ctx, char* heads, const bfs_layout_t* layout = nullptr,
                               int mode = 0, float alpha = 0.f, const int* in_offsets = nullptr, const int* in_indices = nullptr) {
