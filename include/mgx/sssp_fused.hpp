@@ -24,6 +24,12 @@
 // Tried and dropped: a second queue for rows of >= 64 edges with a row-wise streaming relax kernel (the BFS design).
 // The relaxation rate barely moved (86 vs 80 G/s: the kernel is bound by the distance gather and the atomics, not
 // by the row search) and processing the hubs in a kernel of their own cost 1.4 x the relaxations: 3.36 vs 2.81 ms.
+// Also dropped (round 3): relaxing WITHOUT the look at dist[dst] while few vertices have a distance (the first heavy iteration
+// of a run from the hubs: nearly every candidate is the first for its vertex, so the gather looked like a wasted random
+// access) -- atomicMin at once, the mark by its return value.  RMAT-22: 3.3-4.4 ms per source against 1.86; the iteration
+// it was meant for went from 0.39 to 1.94 ms (15 M edges) and from 0.89 to 3.3 ms (70 M).  A dozen edges lead to every new
+// vertex in that iteration: the look lets all but the first few skip the atomic (the line is in the L2 by then), and
+// atomics are what this part is slowest at -- 8-21 G/s when every edge issues one, an order below its gathers.
 #pragma once
 #include <vector>
 #include "bfs_fused.hpp"
