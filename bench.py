@@ -594,7 +594,7 @@ def bench_pr(args, ctx, stream):
     sha = source_sha()
     traffic, traffic_note = _pmc_traffic(args, "neighbour-reduce operator", sha)
     roofline = {"bound": "hbm", "kernel": "neighbour-reduce operator (every kernel of one mgx_segreduce_f32_plus call over the full frontier: "
-                                          "k_nr_check_iota, k_nr_values, k_nr_edges -- the dominant one --, k_nr_fold)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                          "k_nr_values (with the frontier check), k_nr_edges -- the dominant one --, k_nr_fold)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_note": traffic_note, "launches": len(evs),
                 "avg_launch_us": round(op_ms * 1e3, 3), "alg_bytes_per_launch": alg,
                 "alg_bytes": "8 B per edge (column index + value gather) + 16 B per frontier vertex (SURVEY 8d)",

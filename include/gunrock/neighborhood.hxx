@@ -46,12 +46,10 @@ int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fronti
       graph.has_layout && (push || graph.csc_is_csr) && graph.ub_units > 0 && graph.ub_min_degree == 64 && graph.vs_long_min == 64 &&
       graph.d_ub_cnt.size() && graph.d_ub_first.size() && graph.vs_dummy != 0 &&
       context.scratch_bytes >= mgx::nr_scratch_bytes(graph.num_nodes, graph.ub_units_pad, sizeof(Value))) {
-    // the check and the work go out back to back: the kernels of the fast path look at the check's verdict themselves (a device
+    // the check (inside the first kernel) and the work go out back to back: the kernels behind it look at its verdict themselves (a device
     // word that holds the epoch of the last call whose frontier was NOT the iota); one host wait, behind everything
     context.mailbox[8] = 1;
     const unsigned epoch = context.next_nr_epoch();
-    hipLaunchKernelGGL(mgx::k_nr_check_iota, dim3(mgx::grid_for(frontier_size, mgx::BLOCK, context.num_cus * 4)), dim3(mgx::BLOCK), 0,
-                       context.stream(), frontier, frontier_size, context.mailbox + 8, context.nr_flag(), epoch);
     if (graph.num_edges > 0) {
       mgx::nr_layout_t L;
       L.row_offsets = (const mgx::u32*)graph.d_layout_row_offsets.data();
@@ -66,10 +64,10 @@ int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fronti
       L.big_rows = graph.nr_big_rows;
       L.n = graph.num_nodes;
       mgx::nr_full_frontier<Value>(L, [=] __device__(int v) -> Value { return Functor::get_value_to_reduce(v, data, iteration); }, reduced,
-                                   identity, reduce_op(), context, context.nr_flag(), epoch);
+                                   identity, reduce_op(), context, frontier, context.mailbox + 8, context.nr_flag(), epoch);
+      context.synchronize();
+      if (context.mailbox[8] == 1) return (int)graph.num_edges;
     }
-    context.synchronize();
-    if (context.mailbox[8] == 1) return (int)graph.num_edges;
   }
 
   // segment i = the neighbour list of frontier[i]: exclusive scan of the degrees into the graph's scratch scan

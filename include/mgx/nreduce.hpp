@@ -7,7 +7,7 @@
 // When the frontier is every vertex in order (PR's first iteration, mgx_segreduce_* over an iota frontier) and the graph
 // carries the hub-first layout of the fused BFS, nothing needs a search and most gathers never leave the compute unit:
 //
-//   k_nr_values   vals[v] = value(old_of_new[v]) for every layout vertex v: ONE gather per vertex instead of one per
+//   k_nr_values   (also checks that the frontier is 0 .. n - 1) vals[v] = value(old_of_new[v]) for every layout vertex v: ONE gather per vertex instead of one per
 //                 edge; from here on the values are addressed by layout id, where the hubs -- the targets of most edges --
 //                 are the first ids; reduced[] <- identity.
 //   k_nr_edges    ONE launch, two parts.  Long rows (>= 64 entries) from the unit blocks (mgx_layout.hip): 16 bytes per lane, a unit of 64
@@ -52,25 +52,22 @@ struct nr_layout_t {
   int n = 0;
 };
 
-// is the frontier 0, 1, ..., n - 1?  *host_flag (pinned) was set to 1 by the host before the launch; *dev_flag <- epoch if it is
-// not: the kernels of the fast path are enqueued right behind this one and return at once when they find their epoch there
-// (no host wait between the check and the work; the host looks at host_flag when everything has run and takes the general
-// kernel if the answer was no).  Epochs only grow: nothing is ever reset.
-__global__ __launch_bounds__(BLOCK) void k_nr_check_iota(const int* __restrict__ frontier, long long n, long long* host_flag,
-                                                         u32* dev_flag, u32 epoch) {
-  bool bad = false;
-  for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * BLOCK) bad |= frontier[i] != (int)i;
-  if (__ballot(bad) && lane_id() == 0) { *host_flag = 0; *dev_flag = epoch; }
-}
-
+// k_nr_values also answers: is the frontier 0, 1, ..., n - 1?  *host_flag (pinned) was set to 1 by the host before the launch;
+// *dev_flag <- epoch if it is not: the kernels behind this one return at once when they find their epoch there (no host wait
+// between the check and the work; the host looks at host_flag when everything has run and takes the general kernel if the
+// answer was no -- vals[] is scratch and reduced[] is rewritten by that kernel, so what this one stored does no harm).
+// Epochs only grow: nothing is ever reset.
 template <typename V, typename GetValue>
 __global__ __launch_bounds__(BLOCK) void k_nr_values(GetValue get, const int* __restrict__ old_of_new, V* __restrict__ vals,
-                                                     V* __restrict__ reduced, V identity, long long n, const u32* dev_flag, u32 epoch) {
-  if (*dev_flag == epoch) return;                    // (not an iota frontier: the general kernel runs instead)
+                                                     V* __restrict__ reduced, V identity, long long n, const int* __restrict__ frontier,
+                                                     long long* host_flag, u32* dev_flag, u32 epoch) {
+  bool bad = false;
   for (long long v = (long long)blockIdx.x * BLOCK + threadIdx.x; v < n; v += (long long)gridDim.x * BLOCK) {
+    bad |= frontier[v] != (int)v;
     vals[v] = get(old_of_new[v]);
     reduced[v] = identity;
   }
+  if (__ballot(bad) && lane_id() == 0) { *host_flag = 0; *dev_flag = epoch; }
 }
 
 // value of entry d: -1 (padding, lanes past a row's end) -> identity, a hub -> LDS, anything else -> L2 / HBM.  The global
@@ -272,11 +269,11 @@ inline size_t nr_scratch_bytes(long long n, long long units_pad, size_t value_si
   return (((size_t)n + 64) * value_size + 255) / 256 * 256 + ((size_t)units_pad + 64) * value_size;
 }
 
-// The whole fast path.  get(old_id) -> V; reduced: n entries.  Everything is enqueued on the context's stream; every kernel
-// returns at once if *dev_flag == epoch (k_nr_check_iota's verdict, enqueued in front by the caller).
+// The whole fast path.  get(old_id) -> V; reduced: n entries; frontier: n ids (checked to be 0 .. n - 1 by the first kernel).
+// Everything is enqueued on the context's stream; the kernels behind the first return at once if *dev_flag == epoch.
 template <typename V, typename Op, typename GetValue>
-inline void nr_full_frontier(const nr_layout_t& L, GetValue get, V* reduced, V identity, Op op, standard_context_t& ctx, const u32* dev_flag,
-                             u32 epoch) {
+inline void nr_full_frontier(const nr_layout_t& L, GetValue get, V* reduced, V identity, Op op, standard_context_t& ctx, const int* frontier,
+                             long long* host_flag, u32* dev_flag, u32 epoch) {
   hipStream_t s = ctx.stream();
   V* const vals = (V*)ctx.scratch;
   V* const partial = (V*)((char*)ctx.scratch + (((size_t)L.n + 64) * sizeof(V) + 255) / 256 * 256);
@@ -284,7 +281,7 @@ inline void nr_full_frontier(const nr_layout_t& L, GetValue get, V* reduced, V i
   if (first_use_on_device(seen))
     MGX_HIP(hipFuncSetAttribute((const void*)(k_nr_edges<V, Op, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL((k_nr_values<V, GetValue>), dim3(grid_for(L.n, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, get, L.old_of_new, vals,
-                     reduced, identity, (long long)L.n, dev_flag, epoch);
+                     reduced, identity, (long long)L.n, frontier, host_flag, dev_flag, epoch);
   const u32 long_rows = L.vs_v[0];
   const bool has_long = L.ub_units > 0 && long_rows > 0, has_short = L.vs_v[3] > L.vs_v[0];
   if (has_long || has_short)
