@@ -142,9 +142,11 @@ __device__ __forceinline__ void bfs_dense_work(const bfs_fused_args_t& a, u32* c
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
         const u32 w0 = probe(dT[j].x), w1 = probe(dT[j].y), w2 = probe(dT[j].z), w3 = probe(dT[j].w);
-        if (COLDT) {
-          const u32 c0 = cold_word(dT[j].x), c1 = cold_word(dT[j].y), c2 = cold_word(dT[j].z), c3 = cold_word(dT[j].w);
-          decide(dT[j].x, w0, c0); decide(dT[j].y, w1, c1); decide(dT[j].z, w2, c2); decide(dT[j].w, w3, c3);
+        if (COLDT) {                   // (two words in flight at a time: four more live registers spilled under the 64 of this kernel)
+          const u32 c0 = cold_word(dT[j].x), c1 = cold_word(dT[j].y);
+          decide(dT[j].x, w0, c0); decide(dT[j].y, w1, c1);
+          const u32 c2 = cold_word(dT[j].z), c3 = cold_word(dT[j].w);
+          decide(dT[j].z, w2, c2); decide(dT[j].w, w3, c3);
         } else {
           decide(dT[j].x, w0); decide(dT[j].y, w1); decide(dT[j].z, w2); decide(dT[j].w, w3);
         }
