@@ -190,7 +190,7 @@ struct bfs_fused_enactor_t {
         layout.cold_owner = g.d_cold_owner.data();
         layout.cold_dst = g.d_cold_dst.data();
         layout.cold_slices = g.cold_slices;
-        static_assert(mgx::BFS_COLD_MAX_SLICES == 32, "graph_device_t::cold_* hold this many slices");
+        static_assert(mgx::BFS_COLD_MAX_SLICES == 64, "graph_device_t::cold_* hold this many slices");
         for (int i = 0; i < mgx::BFS_COLD_MAX_SLICES; ++i) layout.cold_lo[i] = g.cold_lo[i];
         for (int i = 0; i <= mgx::BFS_COLD_MAX_SLICES; ++i) { layout.cold_off[i] = g.cold_off[i]; layout.colds_off[i] = g.colds_off[i]; layout.cold_wgs[i] = g.cold_wgs[i]; }
         layout.colds_owner = g.colds_pairs > 0 ? g.d_colds_owner.data() : nullptr;

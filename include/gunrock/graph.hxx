@@ -95,7 +95,7 @@ struct graph_device_t {
   mem_t<int> d_colds_dst;
   long long cold_pairs = 0, colds_pairs = 0;
   int cold_slices = 0;
-  unsigned cold_lo[32] = {0}, cold_off[33] = {0}, colds_off[33] = {0}, cold_wgs[33] = {0};     // (mgx::BFS_COLD_MAX_SLICES)
+  unsigned cold_lo[64] = {0}, cold_off[65] = {0}, colds_off[65] = {0}, cold_wgs[65] = {0};     // (mgx::BFS_COLD_MAX_SLICES)
   unsigned cold_hot_n = 0;
   int cold_long_min = 0;
   // Destination-sliced edge list of the weighted layout (mgx/sssp_fused.hpp: sssp_sliced_body): (src, dst, w) triples

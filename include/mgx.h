@@ -312,12 +312,18 @@ MGX_API int mgx_dbfs2_create(mgx_ctx_t ctx, int n_global, int ranks, int rank, c
                              const int* d_col_indices_global, unsigned* d_newbits, mgx_dbfs2_t* out);
 /* Unit blocks of the rank's long rows (64-entry units, one owner each, as mgx_graph_build_layout makes them for the
  * single-GPU path): levels that hold a large share of the rank's long rows are then read from them, 16 bytes per lane,
- * with the level's merged discoveries as the frontier bitmap, instead of walking the long-row queue.  Once per engine,
- * optional; *units (may be NULL) <- units built (0: the rows are all short).  Needs row_offsets / col_indices to stay
- * valid and unchanged.  No reference counterpart. */
+ * with the level's merged discoveries as the frontier bitmap, instead of walking the long-row queue.  On a graph that
+ * outgrows the LDS prefix of the visited bitmap (652 288 vertices) the call also builds the rows' cold-edge lists -- the
+ * entries behind the prefix as (owner, destination) pairs by slice of the destination: workgroups of the push launch take
+ * them with THEIR slice of the bitmap in LDS and leave a bitmap, no byte marks (needs rows sorted by neighbour id, as the
+ * library's shard builder makes them).  Once per engine, optional; *units (may be NULL) <- units built (0: the rows are
+ * all short).  Needs row_offsets / col_indices to stay valid and unchanged.  No reference counterpart. */
 MGX_API int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units);
 /* levels of the traversal whose long rows were read from the unit blocks, as of the last mgx_dbfs2_status / mgx_dbfs2_run */
 MGX_API int mgx_dbfs2_dense_levels(mgx_dbfs2_t h, int64_t* levels);
+/* ... and how many of them ran the cold-edge pass (the long rows' entries behind the LDS prefix as (owner, destination) pairs by
+ * slice of the destination, built with the unit blocks when the graph is big enough to have any: *pairs, may be NULL) */
+MGX_API int mgx_dbfs2_cold_levels(mgx_dbfs2_t h, int64_t* levels, int64_t* pairs);
 MGX_API int mgx_dbfs2_free(mgx_dbfs2_t h);
 /* All of reset / push / merge are asynchronous on the context's stream: a level is
  *   push(level) -> all-gather of d_newbits into d_gathered (the caller's collective, stream-ordered) -> merge(level)

@@ -33,12 +33,22 @@
 namespace mgx {
 
 // out[w] = the rank's discoveries of the level: vertices it marked that are not in the bitmap.  list (optional): the same
-// vertices as ids -- list[0] counts ALL of them (the caller zeroed it), list[D2_LIST_HEAD + i] holds the first list_cap.
+// vertices as ids -- list[0] counts them (the caller zeroed it; exact up to list_cap, some value above it once the list has
+// overflowed), list[D2_LIST_HEAD + i] holds the first list_cap.
+// what k_d2_newbits needs of a rank's cold-edge pass (bfs_fused_cold.hpp): cold workgroup k of slice q left the vertices it
+// discovered in [lo[q], lo[q] + BFS_COLD_WORDS * 32) as a bitmap in flush + k * BFS_COLD_WORDS
+struct d2_cold_view_t {
+  const u32* flush = nullptr;
+  int slices = 0;
+  u32 lo[BFS_COLD_MAX_SLICES] = {};
+  u32 wgs[BFS_COLD_MAX_SLICES + 1] = {};
+};
 constexpr int D2_LIST_HEAD = 4;          // header words of an id list: [0] count (may exceed the capacity: overflow), [1..3] unused
 __global__ __launch_bounds__(BLOCK) void k_d2_newbits(const u32* __restrict__ visited, const unsigned char* __restrict__ mark,
                                                       u32* __restrict__ out, long long nwords, long long n, bfs_ctrl_t* c,
-                                                      u32* __restrict__ list, u32 list_cap) {
+                                                      u32* __restrict__ list, u32 list_cap, d2_cold_view_t cv, int level) {
   if (blockIdx.x == 0 && threadIdx.x == 0) c->merged_new = 0;     // the merge of this level counts into it
+  const bool with_cold = cv.flush && c->cold_slot == level;       // (grid-uniform) the level's push ran the cold-edge pass
   const long long stride = (long long)gridDim.x * BLOCK;
   for (long long w0 = (long long)blockIdx.x * BLOCK; w0 < nwords; w0 += stride) {      // (block-uniform trip count: the wave scan below)
     const long long w = w0 + threadIdx.x;
@@ -53,6 +63,17 @@ __global__ __launch_bounds__(BLOCK) void k_d2_newbits(const u32* __restrict__ vi
       } else {
         for (int i = 0; i < 32 && w * 32 + i < n; ++i) bits |= (mark[w * 32 + i] ? 1u : 0u) << i;
       }
+      if (with_cold) {
+        // the slice this word lies in (slices start on multiples of 1024 vertices: a word belongs to one slice): OR of its
+        // workgroups' bitmaps -- neighbouring lanes read neighbouring words of every buffer
+        const u32 v0 = (u32)(w * 32);
+        for (int q = 0; q < cv.slices; ++q) {
+          if (v0 >= cv.lo[q] && v0 - cv.lo[q] < (u32)BFS_COLD_WORDS * 32u) {
+            const u32* const base = cv.flush + ((v0 - cv.lo[q]) >> 5);
+            for (u32 k = cv.wgs[q]; k < cv.wgs[q + 1]; ++k) bits |= base[(size_t)k * BFS_COLD_WORDS];
+          }
+        }
+      }
       bits &= ~visited[w];
       out[w] = bits;
     }
@@ -60,7 +81,9 @@ __global__ __launch_bounds__(BLOCK) void k_d2_newbits(const u32* __restrict__ vi
       const u32 cnt = (u32)__popc(bits);
       const u32 inc = wave_inclusive_sum(cnt);
       const u32 tot = (u32)__shfl((int)inc, WAVE - 1, WAVE);
-      if (tot) {                                                     // (wave-uniform)
+      // (a list that has overflowed is not read: only "more than list_cap" matters from there on.  A plain look first keeps the
+      //  waves of a dense level -- tens of thousands of them -- off the one hot counter: 36 -> 12 us per level at n = 33.5 M)
+      if (tot && __builtin_nontemporal_load(&list[0]) <= list_cap) {   // (wave-uniform)
         u32 base = 0;
         if (lane_id() == 0) base = atomicAdd(&list[0], tot);
         base = (u32)__shfl((int)base, 0, WAVE);
@@ -225,6 +248,20 @@ __global__ __launch_bounds__(BLOCK) void k_d2_owner_global(int* __restrict__ own
   owner[i] = (o >= n_local) ? n_global : o * ranks + rank;
 }
 
+// rows of at least min_deg entries (a prefix of the rank's rows: they come by descending degree) and whether every row is
+// sorted by neighbour id (the cold-list builder finds a row's cold tail by bisection): *long_rows <- the count, *sorted <- 0 if not
+__global__ __launch_bounds__(BLOCK) void k_d2_row_facts(const int* __restrict__ ro, const int* __restrict__ ci, int n_local, int min_deg,
+                                                        int* long_rows, int* sorted) {
+  const long long nwaves = ((long long)gridDim.x * BLOCK) / WAVE;
+  bool bad = false;
+  for (long long r = ((long long)blockIdx.x * BLOCK + threadIdx.x) / WAVE; r < n_local; r += nwaves) {
+    const int r0 = ro[r], r1 = ro[r + 1];
+    if (lane_id() == 0 && r1 - r0 >= min_deg) atomicMax(long_rows, (int)r + 1);
+    for (int e = r0 + 1 + lane_id(); e < r1; e += WAVE) bad |= ci[e - 1] > ci[e];
+  }
+  if (__ballot(bad) && lane_id() == 0) *sorted = 0;
+}
+
 __global__ void k_d2_init(bfs_fused_args_t a, int* labels_local, int src, int ranks, int rank) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   bfs_ctrl_reset(a.ctrl);
@@ -259,6 +296,24 @@ struct d2_state_t {
   int* ub_owner = nullptr;
   long long ub_units = 0, ub_units_pad = 0;
   u32 dense_div = 4;
+  // cold-edge lists of those rows (mgx_layout.hip: mgx_cold_build_device; owners global): pairs by slice of the destination,
+  // the slices that hold any, the cold workgroups of a push launch per slice, their flush bitmaps
+  int* cold_owner = nullptr;
+  int* cold_dst = nullptr;
+  long long cold_pairs = 0;
+  int cold_slices = 0;
+  u32 cold_lo[BFS_COLD_MAX_SLICES] = {};
+  u32 cold_off[BFS_COLD_MAX_SLICES + 1] = {};
+  u32 cold_wgs[BFS_COLD_MAX_SLICES + 1] = {};
+  mem_t<u32> cold_flush;
+  d2_cold_view_t cold_view() const {
+    d2_cold_view_t v;
+    if (!cold_dst) return v;
+    v.flush = cold_flush.data(); v.slices = cold_slices;
+    for (int i = 0; i < BFS_COLD_MAX_SLICES; ++i) v.lo[i] = cold_lo[i];
+    for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) v.wgs[i] = cold_wgs[i];
+    return v;
+  }
 
   void init(standard_context_t& ctx, int n_global_, int ranks_, int rank_, const int* ro, const int* ci, u32* newbits_) {
     n_global = n_global_; ranks = ranks_; rank = rank_;
@@ -277,6 +332,8 @@ struct d2_state_t {
     if (host_flag) (void)hipHostFree(host_flag);
     if (ub_col) (void)hipFree(ub_col);
     if (ub_owner) (void)hipFree(ub_owner);
+    if (cold_owner) (void)hipFree(cold_owner);
+    if (cold_dst) (void)hipFree(cold_dst);
   }
   d2_state_t() {}
   d2_state_t(const d2_state_t&) = delete;
@@ -313,9 +370,11 @@ struct d2_state_t {
     a.count_marks = 0;
     a.ub_col = ub_col; a.ub_owner = ub_owner; a.ub_units = (u32)ub_units; a.ub_units_pad = (u32)ub_units_pad; a.dense_div = ub_col ? dense_div : 0u;
     a.vs_v[0] = a.vs_v[1] = a.vs_v[2] = a.vs_v[3] = 0; a.vs_edges = 0; a.vs_div = 0; a.vs_dummy = 0; a.lazy_div = 0; a.slot_marks = nullptr; a.merged_pull = 0; a.lazy_pull = 0; a.chain_big_edges = 0; a.defer_reach_mul = 1; a.defer_reach_div = 1;
-    a.cold_owner = nullptr; a.cold_dst = nullptr; a.cold_slices = 0; a.cold_flush = nullptr;
-    for (int i = 0; i < BFS_COLD_MAX_SLICES; ++i) a.cold_lo[i] = 0;
-    for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) { a.cold_off[i] = 0; a.cold_wgs[i] = 0; }
+    const bool cold = cold_dst != nullptr && ub_col != nullptr;
+    a.cold_owner = cold ? cold_owner : nullptr; a.cold_dst = cold ? cold_dst : nullptr; a.cold_slices = cold ? cold_slices : 0;
+    a.cold_flush = cold ? cold_flush.data() : nullptr;
+    for (int i = 0; i < BFS_COLD_MAX_SLICES; ++i) a.cold_lo[i] = cold ? cold_lo[i] : 0u;
+    for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) { a.cold_off[i] = cold ? cold_off[i] : 0u; a.cold_wgs[i] = cold ? cold_wgs[i] : 0u; }
     a.flush_buf = nullptr; a.defer_min_marks = 0;     // (k_d2_newbits reads the marks: nothing is deferred)
     a.chain_max_edges = 0;               // (levels are counted by the host here: no chains of small levels)
     return a;
@@ -339,7 +398,7 @@ inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx) {
   bfs_set_kernel_attributes();
   bfs_launch_push(a, level, ctx, 2, bfs_cold_test(a.n, st.cold_forced));   // (the level's bookkeeping rides on the push launch)
   hipLaunchKernelGGL(k_d2_newbits, dim3(grid_for(st.nwords, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, st.fs->visited.data(),
-                     st.fs->mark.data(), st.newbits, st.nwords, (long long)st.n_global, a.ctrl, st.mylist, st.list_cap);
+                     st.fs->mark.data(), st.newbits, st.nwords, (long long)st.n_global, a.ctrl, st.mylist, st.list_cap, st.cold_view(), level);
 }
 
 // The sparse merge of a level (k_d2_lists_apply) on `nlists` gathered lists, `stride_words` apart, and the host's wait for

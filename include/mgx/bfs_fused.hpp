@@ -113,7 +113,7 @@ struct bfs_ctrl_t {
   u64 trace[BFS_MAX_TRACE];   // (vertices << 38 | edges) of each level, both queues (kept LAST: read back up to `levels`)
 };
 
-constexpr int BFS_COLD_MAX_SLICES = 32;           // slices of the id range that may hold cold-edge pairs (bfs_fused_cold.hpp)
+constexpr int BFS_COLD_MAX_SLICES = 64;           // slices of the id range that may hold cold-edge pairs (bfs_fused_cold.hpp; 64: a rank of RMAT-26 / 8 uses 51)
 
 struct bfs_fused_args_t {
   const u32* row_offsets;

@@ -59,11 +59,7 @@ __device__ __forceinline__ u32* bfs_hot_setup(const bfs_fused_args_t& a, char* s
 }
 
 // the unit-block pass of one workgroup (block `block` of `nblocks`) over an LDS prefix that is already set up
-// COLDT: an entry outside the LDS prefix is tested against the L2-resident bitmap word before it is marked (big graphs
-// without a cold-edge pass -- the ranks of a partitioned run: most endpoints are cold, and an untested mark is a scattered
-// byte store into a mark array far bigger than the L2s); the words of a load's four entries are gathered with unconditional
-// loads (hot lanes read word 0) right before they are decided -- the other waves of the CU cover the round trip.
-template <int NT, int HOTW, int GPS, bool COLDT = false>
+template <int NT, int HOTW, int GPS>
 __device__ __forceinline__ void bfs_dense_work(const bfs_fused_args_t& a, u32* const hot, u32 hot_n, u32 defer_n, u32 block,
                                                u32 nblocks, int& marks) {
   constexpr int NW = NT / WAVE;
@@ -120,14 +116,11 @@ __device__ __forceinline__ void bfs_dense_work(const bfs_fused_args_t& a, u32* c
       idx = idx > HOTW ? HOTW : idx;
       return hot[idx];
     };
-    const u32* __restrict__ vis = a.visited;
-    auto cold_word = [&](u32 d) -> u32 { return vis[((int)d >= 0 && d >= hot_n) ? (d >> 5) : 0u]; };
-    auto decide = [&](u32 d, u32 wd, u32 cw = 0u) {
+    auto decide = [&](u32 d, u32 wd) {
       if (!((wd >> (d & 31u)) & 1u)) {
         const u32 bit = 1u << (d & 31u);
         bool is_new = true;
         if (d < hot_n) is_new = !(atomicOr(&hot[d >> 5], bit) & bit);
-        else if (COLDT) is_new = !(cw & bit);
         if (is_new) { if (!(diag & 1) && d >= defer_n && !((diag & 4) && d >= hot_n)) mark[d] = 1; ++marks; }   // (diag 4: no COLD marks)
       }
     };
@@ -142,14 +135,7 @@ __device__ __forceinline__ void bfs_dense_work(const bfs_fused_args_t& a, u32* c
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
         const u32 w0 = probe(dT[j].x), w1 = probe(dT[j].y), w2 = probe(dT[j].z), w3 = probe(dT[j].w);
-        if (COLDT) {                   // (two words in flight at a time: four more live registers spilled under the 64 of this kernel)
-          const u32 c0 = cold_word(dT[j].x), c1 = cold_word(dT[j].y);
-          decide(dT[j].x, w0, c0); decide(dT[j].y, w1, c1);
-          const u32 c2 = cold_word(dT[j].z), c3 = cold_word(dT[j].w);
-          decide(dT[j].z, w2, c2); decide(dT[j].w, w3, c3);
-        } else {
-          decide(dT[j].x, w0); decide(dT[j].y, w1); decide(dT[j].z, w2); decide(dT[j].w, w3);
-        }
+        decide(dT[j].x, w0); decide(dT[j].y, w1); decide(dT[j].z, w2); decide(dT[j].w, w3);
       }
     };
 
@@ -194,7 +180,7 @@ __device__ __forceinline__ void bfs_dense_work(const bfs_fused_args_t& a, u32* c
 
 // GPS: groups per step (1: four 16-byte loads in flight per lane while the previous four are tested; 2: eight -- for
 // launches with half the waves per CU)
-template <int NT, int HOTW, int GPS = 1, bool COLDT = false>
+template <int NT, int HOTW, int GPS = 1>
 __device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int slot, u32 block, u32 nblocks, int stat_level,
                                                bool cold = false) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -205,7 +191,7 @@ __device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int sl
   const u32 hot_n = ((u32)a.n < (u32)(HOTW * 32)) ? (u32)a.n : (u32)(HOTW * 32);
   const u32 defer_n = bfs_defer_limit(a, hot_n);      // marks of the vertices in [0, defer_n) wait for the end of the workgroup
   int marks = 0;
-  bfs_dense_work<NT, HOTW, GPS, COLDT>(a, hot, hot_n, defer_n, block, nblocks, marks);
+  bfs_dense_work<NT, HOTW, GPS>(a, hot, hot_n, defer_n, block, nblocks, marks);
   (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, slot, s_int + 4, marks);
   bfs_body_finish(a, marks, slot, stat_level, s_int);
 }

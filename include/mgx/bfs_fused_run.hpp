@@ -221,17 +221,31 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push_stream_diag(bfs_fused_args
 // Explicit-level variant for the partitioned path (bfs_dist2.hpp): slot == level, the level's bookkeeping rides on
 // the launch (open_here == 2: a rank of a partitioned run), no chain; unit blocks when the rank built them.
 template <bool COLDT>
-__global__ __launch_bounds__(1024, 8) void k_bfs_push_level(bfs_fused_args_t a, int level, u32 nstream, int open_here) {
+__global__ __launch_bounds__(1024, 8) void k_bfs_push_level(bfs_fused_args_t a, int level, u32 nstream, int open_here, u32 ncold) {
   if (open_here && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) bfs_begin_level(a, level, open_here == 2);
-  if (blockIdx.x < nstream) {
-    // a rank that carries unit blocks of its rows (bfs_dist2.hpp: owners in GLOBAL ids, frontier_bits = the level's merged
-    // discoveries of all ranks) reads a level that holds a large share of its long rows from them -- the queue-less body of
-    // the single-GPU path; the long-row cursor of the level is stable while the level runs
-    if (bfs_long_is_dense(a, a.ctrl, level, a.ctrl->lcursor[level % 3])) {
-      if (blockIdx.x == 0 && threadIdx.x == 0) a.ctrl->dense_slots += 1;
-      bfs_dense_body<1024, BFS_DENSE_HOTW, 1, COLDT>(a, level, blockIdx.x, nstream, level);
-    } else bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, COLDT, false, true>(a, level, blockIdx.x, nstream, level);
-  } else bfs_wave_body<1024, BFS_WAVE_HOTW, COLDT, false>(a, level, blockIdx.x - nstream, gridDim.x - nstream, level);
+  // a rank that carries unit blocks of its rows (bfs_dist2.hpp: owners in GLOBAL ids, frontier_bits = the level's merged
+  // discoveries of all ranks) reads a level that holds a large share of its long rows from them -- the queue-less body of
+  // the single-GPU path; with cold-edge lists the first ncold workgroups take the entries behind the LDS prefix by slice
+  // (bfs_fused_cold.hpp) and the unit-block body skips them.  Grid-uniform: the long-row cursor of the level is stable
+  // while the level runs.
+  // (a graph big enough for the cold TEST -- most endpoints behind the prefix -- reads the unit blocks only together with the
+  //  cold-edge lists: marking those entries untested is what the test is there to avoid)
+  const bool dense = bfs_long_is_dense(a, a.ctrl, level, a.ctrl->lcursor[level % 3]) && (!COLDT || a.cold_dst != nullptr);
+  const bool cold = dense && a.cold_dst != nullptr;
+  if (blockIdx.x < ncold) {
+    if (cold) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) { a.ctrl->cold_slot = level; a.ctrl->cold_slots += 1; }   // (k_d2_newbits: OR the slices' flush bitmaps in)
+      bfs_cold_body<1024>(a, level, blockIdx.x, level, true, false);
+    }
+    return;
+  }
+  const u32 blk = blockIdx.x - ncold, nblk = gridDim.x - ncold;
+  if (blk < nstream) {
+    if (dense) {
+      if (blk == 0 && threadIdx.x == 0) a.ctrl->dense_slots += 1;
+      bfs_dense_body<1024, BFS_DENSE_HOTW>(a, level, blk, nstream, level, cold);
+    } else bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, COLDT, false, true>(a, level, blk, nstream, level);
+  } else bfs_wave_body<1024, BFS_WAVE_HOTW, COLDT, false>(a, level, blk - nstream, nblk - nstream, level);
 }
 
 inline void bfs_set_kernel_attributes() {
@@ -278,8 +292,9 @@ inline void bfs_launch_push_part(const bfs_fused_args_t& a, int arg, standard_co
 inline void bfs_launch_push(const bfs_fused_args_t& a, int level, standard_context_t& ctx, int open_here, bool coldt) {
   const u32 nstream = a.long_min > 0 ? (u32)ctx.num_cus * 2 : 0u;
   const u32 nwave = (u32)ctx.num_cus * 2;
-  if (coldt) hipLaunchKernelGGL(k_bfs_push_level<true>, dim3(nstream + nwave), dim3(1024), bfs_push_lds_bytes(), ctx.stream(), a, level, nstream, open_here);
-  else hipLaunchKernelGGL(k_bfs_push_level<false>, dim3(nstream + nwave), dim3(1024), bfs_push_lds_bytes(), ctx.stream(), a, level, nstream, open_here);
+  const u32 ncold = a.cold_dst ? a.cold_wgs[a.cold_slices] : 0u;
+  if (coldt) hipLaunchKernelGGL(k_bfs_push_level<true>, dim3(ncold + nstream + nwave), dim3(1024), bfs_push_lds_bytes(), ctx.stream(), a, level, nstream, open_here, ncold);
+  else hipLaunchKernelGGL(k_bfs_push_level<false>, dim3(ncold + nstream + nwave), dim3(1024), bfs_push_lds_bytes(), ctx.stream(), a, level, nstream, open_here, ncold);
 }
 
 // Everything a traversal's launches need that does not depend on the source: the kernel arguments (which bodies are

@@ -1312,12 +1312,82 @@ int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
   st.ub_owner = owner; st.ub_col = ucol; st.ub_units = U; st.ub_units_pad = Up;
   if (const char* e = getenv("MGX_DIST_DENSE_DIV")) { const int d = atoi(e); if (d >= 0) st.dense_div = (unsigned)d; }
   if (units) *units = U;
+  // cold-edge lists of the same rows (bfs_fused_cold.hpp; MGX_DIST_COLD=0: none): as build_cold_lists does for a graph's layout --
+  // only when the destinations behind the LDS prefix span at most 128 slices of which at most BFS_COLD_MAX_SLICES hold pairs,
+  // and the cold entries are at most half of the long rows' entries
+  bool want_cold = true;
+  if (const char* e = getenv("MGX_DIST_COLD")) want_cold = atoi(e) != 0;
+  const unsigned hot_n = (unsigned)mgx::BFS_COLD_WORDS * 32u, slice_n = hot_n;
+  const long long slices_ll = (unsigned)st.n_global > hot_n ? ((long long)st.n_global - hot_n + slice_n - 1) / slice_n : 0;
+  if (want_cold && slices_ll >= 1 && slices_ll <= 128) {
+    standard_context_t& ctx = *h->c->ctx;
+    mem_t<int> d_long = mgx::fill<int>(0, 1, ctx), d_sorted = mgx::fill<int>(1, 1, ctx);
+    hipLaunchKernelGGL(mgx::k_d2_row_facts, dim3(ctx.num_cus * 8), dim3(mgx::BLOCK), 0, ctx.stream(), st.row_offsets, st.col_indices, st.n_local, long_min,
+                       d_long.data(), d_sorted.data());
+    ctx.synchronize();
+    const int long_rows = mgx::from_mem(d_long)[0];
+    const bool rows_sorted = mgx::from_mem(d_sorted)[0] == 1;
+    const int slices = (int)slices_ll;
+    if (rows_sorted && long_rows > 0) {
+      std::vector<int> off((size_t)slices + 1, 0);
+      int *cowner = nullptr, *cdst = nullptr;
+      long long pairs = 0;
+      const int rc2 = mgx_cold_build_device(st.row_offsets, st.col_indices, st.n_local, 0, long_rows, long_min, hot_n, slice_n, slices, &cowner, &cdst,
+                                            &pairs, off.data(), ctx.stream());
+      if (rc2 != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("partitioned BFS, cold-edge lists: ") + hipGetErrorString((hipError_t)rc2));
+      int used = 0;
+      for (int k = 0; k < slices; ++k) if (off[k + 1] > off[k]) ++used;
+      if (getenv("MGX_DIST_VERBOSE"))
+        fprintf(stderr, "[mgx] rank %d: %lld units, %d long rows, %d slices behind the prefix, %d hold pairs, %lld cold pairs (%.1f %% of the unit entries)\n",
+                st.rank, U, long_rows, slices, used, pairs, 100.0 * (double)pairs / (double)(U * 64));
+      if (pairs > 0 && pairs * 2 <= U * 64 && used <= mgx::BFS_COLD_MAX_SLICES) {      // (RMAT-25 / 8: a quarter of the entries, RMAT-26 / 8: a third)
+        hipLaunchKernelGGL(mgx::k_d2_owner_global, dim3((unsigned)((pairs + 256 + mgx::BLOCK - 1) / mgx::BLOCK)), dim3(mgx::BLOCK), 0, ctx.stream(), cowner,
+                           pairs + 256, st.ranks, st.rank, st.n_local, st.n_global);
+        int q = 0;
+        for (int k = 0; k < slices; ++k) {
+          if (off[k + 1] <= off[k]) continue;
+          st.cold_lo[q] = hot_n + (unsigned)k * slice_n;
+          st.cold_off[q] = (unsigned)off[k]; st.cold_off[q + 1] = (unsigned)off[k + 1];
+          ++q;
+        }
+        long long nwg = (pairs + 65535) / 65536;
+        nwg = std::max<long long>(nwg, mgx::BFS_COLD_WGS);
+        nwg = std::min<long long>(nwg, mgx::BFS_COLD_WGS_MAX);
+        nwg = std::max<long long>(nwg, used);
+        unsigned left = (unsigned)nwg - (unsigned)used, acc = 0;
+        st.cold_wgs[0] = 0;
+        for (int i = 0; i < used; ++i) {
+          const long long cnt = (long long)st.cold_off[i + 1] - (long long)st.cold_off[i];
+          unsigned extra = (unsigned)((cnt * (long long)((unsigned)nwg - (unsigned)used)) / pairs);
+          if (extra > left) extra = left;
+          left -= extra;
+          acc += 1u + extra;
+          st.cold_wgs[i + 1] = acc;
+        }
+        for (int i = used + 1; i <= mgx::BFS_COLD_MAX_SLICES; ++i) { st.cold_wgs[i] = acc; st.cold_off[i] = st.cold_off[used]; }
+        st.cold_flush = mem_t<u32>((size_t)acc * mgx::BFS_COLD_WORDS, ctx);
+        MGX_HIP(hipMemsetAsync(st.cold_flush.data(), 0, (size_t)acc * mgx::BFS_COLD_WORDS * sizeof(unsigned), ctx.stream()));
+        ctx.synchronize();
+        st.cold_owner = cowner; st.cold_dst = cdst; st.cold_pairs = pairs; st.cold_slices = used;
+      } else {
+        if (cowner) (void)hipFree(cowner);
+        if (cdst) (void)hipFree(cdst);
+      }
+    }
+  }
   MGX_CATCH
 }
 int mgx_dbfs2_dense_levels(mgx_dbfs2_t h, int64_t* levels) {
   MGX_TRY
   MGX_REQUIRE(h && levels, "NULL argument");
   *levels = (int64_t)h->st.fs->host_ctrl->dense_slots;     // (as of the last mgx_dbfs2_status / mgx_dbfs2_run)
+  MGX_CATCH
+}
+int mgx_dbfs2_cold_levels(mgx_dbfs2_t h, int64_t* levels, int64_t* pairs) {
+  MGX_TRY
+  MGX_REQUIRE(h && levels, "NULL argument");
+  *levels = (int64_t)h->st.fs->host_ctrl->cold_slots;
+  if (pairs) *pairs = (int64_t)h->st.cold_pairs;
   MGX_CATCH
 }
 int mgx_dbfs2_free(mgx_dbfs2_t h) {

@@ -215,6 +215,12 @@ class HipRankEngine2:
         check(lib.mgx_dbfs2_dense_levels(self._h, C.byref(v)))
         return v.value
 
+    def cold_levels(self):
+        """(levels of the last traversal that ran the cold-edge pass, pairs in the rank's cold lists)"""
+        v, p = C.c_int64(), C.c_int64()
+        check(lib.mgx_dbfs2_cold_levels(self._h, C.byref(v), C.byref(p)))
+        return v.value, p.value
+
     def reset(self, src):
         check(lib.mgx_dbfs2_reset(self._h, int(src)))
 

@@ -89,13 +89,14 @@ def _worker2(rank, world, port, use_gpu, scale, seed, sources, q):
     bfs = DistBfs2(eng, rank, world, "cpu")
     ok = True
     deg = np.diff(ro)
-    sparse = dense = unit_levels = 0
+    sparse = dense = unit_levels = cold_levels = 0
     for src in sources:
         st = bfs.run(int(new_of_old[src]))
         sparse += bfs.sparse_levels
         dense += bfs.dense_levels
         if use_gpu:
             unit_levels += eng.dense_levels()
+            cold_levels += eng.cold_levels()[0]
         got_new = bfs.gather_labels()
         got = np.empty(n, dtype=np.int32)
         got[old_of_new] = got_new
@@ -113,6 +114,8 @@ def _worker2(rank, world, port, use_gpu, scale, seed, sources, q):
     if use_gpu and os.environ.get("MGX_TEST_EXPECT_UNIT_LEVELS") is not None:
         # levels whose long rows were read from the rank's unit blocks (rank 0 answers for the job: it holds the first hub)
         ok = ok and ((unit_levels > 0) == (os.environ["MGX_TEST_EXPECT_UNIT_LEVELS"] == "1")) and ((eng.units > 0) == (os.environ.get("MGX_DIST_UNITS", "1") != "0"))
+    if use_gpu and os.environ.get("MGX_TEST_EXPECT_COLD_LEVELS") is not None:
+        ok = ok and ((cold_levels > 0) == (os.environ["MGX_TEST_EXPECT_COLD_LEVELS"] == "1")) and ((eng.cold_levels()[1] > 0) == (os.environ["MGX_TEST_EXPECT_COLD_LEVELS"] == "1"))
     if rank == 0:
         q.put(bool(ok))
     dist.barrier()
@@ -191,8 +194,8 @@ def test_bitmap_exchange_bfs_hip_engine_ranks_share_one_gpu(built, world, scale,
     (2, 14, "0", "0", None, "0")])          # no unit blocks: the queue walk on every level
 def test_partitioned_ranks_read_big_levels_from_unit_blocks(built, world, scale, lists, units, dense_div, expect, monkeypatch):
     """mgx_dbfs2_build_units: the ranks' long rows as unit blocks with GLOBAL owners, the level's merged discoveries as the
-    frontier bitmap, cold neighbours tested against the bitmap word (k_bfs_push_level -> bfs_dense_body<., COLDT>); labels,
-    edge counts and depths equal the oracle's whichever body a level takes"""
+    frontier bitmap (k_bfs_push_level -> bfs_dense_body); labels, edge counts and depths equal the oracle's whichever body
+    a level takes (graphs inside the LDS prefix here: the cold-edge pass has its own test below)"""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     monkeypatch.setenv("MGX_DIST_EXCHANGE", "gather")
@@ -203,6 +206,26 @@ def test_partitioned_ranks_read_big_levels_from_unit_blocks(built, world, scale,
     if expect is not None:
         monkeypatch.setenv("MGX_TEST_EXPECT_UNIT_LEVELS", expect)
     _run(world, True, scale, scale + 40, _worker2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,scale,dense_div,cold,expect_cold", [
+    (2, 21, "1000000", "1", "1"),            # three slices behind the LDS prefix: every level with a long-row queue runs the pass
+    (3, 20, None, "1", None),                # the default rule
+    (2, 21, "1000000", "0", "0")])           # MGX_DIST_COLD=0: the unit-block body tests the cold entries against the bitmap word
+def test_partitioned_ranks_cold_edge_pass(built, world, scale, dense_div, cold, expect_cold, monkeypatch):
+    """the ranks' cold-edge pass (bfs_fused_cold.hpp behind k_bfs_push_level; flush bitmaps ORed in by k_d2_newbits) on graphs
+    whose id range outgrows the LDS prefix (R-MAT 20 / 21): labels, edge counts and depths equal the oracle's"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    monkeypatch.setenv("MGX_DIST_EXCHANGE", "gather")
+    monkeypatch.setenv("MGX_DIST_LISTS", "0")
+    monkeypatch.setenv("MGX_DIST_COLD", cold)
+    if dense_div is not None:
+        monkeypatch.setenv("MGX_DIST_DENSE_DIV", dense_div)
+    if expect_cold is not None:
+        monkeypatch.setenv("MGX_TEST_EXPECT_COLD_LEVELS", expect_cold)
+    _run(world, True, scale, scale + 3, _worker2)
 
 
 @pytest.mark.gpu
