@@ -54,6 +54,14 @@ for r in rows:
 PY
 done
 bash tools/gpu_timeline.sh "" > $O/timeline.txt 2>&1
+# the partitioned engine on this one GPU: G rank engines in turn, no exchange time
+for cfg in "25 8" "26 8" "22 8" "22 1"; do
+  set -- $cfg
+  timeout 900 python tools/dist2_single.py $1 $2 2>/dev/null | grep -v amdgpu.ids | tail -4 > $O/dist2_single_$1_$2.log
+done
+DIST2_CHECK=1 timeout 900 python tools/dist2_single.py 23 4 2>/dev/null | grep -v amdgpu.ids | tail -5 > $O/dist2_single_23_4_check.log
+# the driver's own command line
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.log 2>&1
 # auxiliary logs: operator path (reference loop, idempotent mode), direction-optimising sweep
 timeout 600 python tools/bfs_operator_bench.py 22 > $O/bfs_operator_s22.log 2>&1
 for a in 0.01 1 4 16 64 256 1000; do
@@ -68,6 +76,8 @@ cat $O/summary.txt
 mkdir -p $O/keep
 cp $O/summary.txt $O/summary.json $O/kernel_stats_mgx.csv $O/kernel_stats_sssp.csv $O/kernel_stats_pr.csv $O/levels.log $O/sssp_iterations.log $O/timeline.txt $O/keep/ 2>/dev/null
 cp $O/pmc_traffic.json $O/bfs_operator_s22.log $O/dobfs_alpha_sweep.txt $O/keep/ 2>/dev/null
+cp $O/dist2_single_*.log $O/keep/ 2>/dev/null
+grep '^{' $O/bench_driver_cmd.log | tail -1 > $O/keep/bench_line_driver_cmd.json
 grep '^{' $O/bench.log | tail -1 > $O/keep/bench_line.json
 grep '^{' $O/bench_per_call.log | tail -1 > $O/keep/bench_line_per_call.json
 grep '^{' $O/bench_sssp.log | tail -1 > $O/keep/bench_line_sssp.json
