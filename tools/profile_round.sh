@@ -82,4 +82,5 @@ grep '^{' $O/bench.log | tail -1 > $O/keep/bench_line.json
 grep '^{' $O/bench_per_call.log | tail -1 > $O/keep/bench_line_per_call.json
 grep '^{' $O/bench_sssp.log | tail -1 > $O/keep/bench_line_sssp.json
 grep '^{' $O/bench_pr.log | tail -1 > $O/keep/bench_line_pr.json
-tail -3 $O/pytest_gpu.log > $O/keep/pytest_gpu_tail.txt; tail -2 $O/pytest_gpu_lab.log >> $O/keep/pytest_gpu_tail.txt
+(echo "product library (mini_amd/libmgx.so), python -m pytest tests -q -m gpu:"; grep -E "passed|failed" $O/pytest_gpu.log | tail -1
+ echo "lab library (MGX_LIB=mini_amd/libmgx_lab.so), the variant tests:"; grep -E "passed|failed" $O/pytest_gpu_lab.log | tail -1) > $O/keep/pytest_gpu_tail.txt
