@@ -103,8 +103,15 @@ def _worker2(rank, world, port, use_gpu, scale, seed, sources, q):
         want = orc.bfs_cpu(ro, ci, src)
         e = torch.tensor([st["edges_local"]], dtype=torch.int64)
         dist.all_reduce(e)
-        ok = ok and np.array_equal(got, want) and int(e.item()) == int(deg[want >= 0].sum())
-        ok = ok and st["levels"] == int(want.max()) + 1
+        good = np.array_equal(got, want) and int(e.item()) == int(deg[want >= 0].sum()) and st["levels"] == int(want.max()) + 1
+        if not good and rank == 0:
+            print("partitioned BFS differs: src %d labels equal %s (first difference at %s) edges %d want %d levels %d want %d; sparse %d dense %d"
+                  % (src, np.array_equal(got, want), np.flatnonzero(got != want)[:5], int(e.item()), int(deg[want >= 0].sum()), st["levels"],
+                     int(want.max()) + 1, bfs.sparse_levels, bfs.dense_levels), file=sys.stderr, flush=True)
+        ok = ok and good
+    if rank == 0 and use_gpu:
+        print("partitioned BFS: sparse levels %d, bitmap levels %d, unit-block levels %d, cold-pass levels %d" % (sparse, dense, unit_levels, cold_levels),
+              file=sys.stderr, flush=True)
     if os.environ.get("MGX_DIST_LISTS", "1") != "0":
         # id lists on the sparse levels, bitmaps where a rank's discoveries do not fit its list (252 ids on these graphs):
         # every run has sparse levels; the hub's big level overflows from scale 11 on
@@ -209,17 +216,18 @@ def test_partitioned_ranks_read_big_levels_from_unit_blocks(built, world, scale,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,scale,dense_div,cold,expect_cold", [
-    (2, 21, "1000000", "1", "1"),            # three slices behind the LDS prefix: every level with a long-row queue runs the pass
-    (3, 20, None, "1", None),                # the default rule
-    (2, 21, "1000000", "0", "0")])           # MGX_DIST_COLD=0: the unit-block body tests the cold entries against the bitmap word
-def test_partitioned_ranks_cold_edge_pass(built, world, scale, dense_div, cold, expect_cold, monkeypatch):
+@pytest.mark.parametrize("world,scale,dense_div,cold,expect_cold,lists", [
+    (2, 21, "1000000", "1", "1", "0"),       # three slices behind the LDS prefix: every level with a long-row queue runs the pass
+    (3, 20, None, "1", None, "0"),           # the default rule (R-MAT 20: every vertex with edges is inside the prefix -- no lists are built)
+    (3, 21, "1000000", "1", "1", "1"),       # with the density-switched exchange (id lists on the sparse levels)
+    (2, 21, "1000000", "0", "0", "0")])      # MGX_DIST_COLD=0: cold entries are marked untested
+def test_partitioned_ranks_cold_edge_pass(built, world, scale, dense_div, cold, expect_cold, lists, monkeypatch):
     """the ranks' cold-edge pass (bfs_fused_cold.hpp behind k_bfs_push_level; flush bitmaps ORed in by k_d2_newbits) on graphs
     whose id range outgrows the LDS prefix (R-MAT 20 / 21): labels, edge counts and depths equal the oracle's"""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     monkeypatch.setenv("MGX_DIST_EXCHANGE", "gather")
-    monkeypatch.setenv("MGX_DIST_LISTS", "0")
+    monkeypatch.setenv("MGX_DIST_LISTS", lists)
     monkeypatch.setenv("MGX_DIST_COLD", cold)
     if dense_div is not None:
         monkeypatch.setenv("MGX_DIST_DENSE_DIV", dense_div)

@@ -125,7 +125,8 @@ for name, n, ro, ci, w in graphs():
                      "MGX_BFS_COLD": rng.choice(["", "0", "2"]), "MGX_BFS_DEFER_REACH": rng.choice(["", "0/1", "4/1"]),
                      "MGX_BFS_MERGED_PULL": rng.choice(["", "0"]), "MGX_BFS_DO_CHAIN": rng.choice(["", "0"]),
                      "MGX_BFS_SSTREAM": rng.choice(["", "1"]), "MGX_SSSP_BUILD_LIST": rng.choice(["", "1"]),
-                     "MGX_SSSP_SLICED": rng.choice(["", "", "3"])}
+                     "MGX_SSSP_SLICED": rng.choice(["", "", "3"]), "MGX_BFS_MINI": rng.choice(["", "0"]),
+                     "MGX_SSSP_DENSE": rng.choice(["", "0", "1000000000"])}
             for kk, vv in knobs.items():
                 if vv == "":
                     os.environ.pop(kk, None)
@@ -140,17 +141,44 @@ for name, n, ro, ci, w in graphs():
                 assert np.array_equal(bfs.labels(), want), (name, n, src, "do", alpha, direct, layout)
         for kk in ("MGX_BFS_CHAIN_MAX_EDGES", "MGX_BFS_DENSE", "MGX_BFS_LAZY", "MGX_BFS_VSHORT", "MGX_BFS_DEFER", "MGX_BFS_SEED_CHAIN",
                    "MGX_BFS_TAIL_CHAIN", "MGX_BFS_CHAIN_BIG_EDGES", "MGX_BFS_COLD", "MGX_BFS_DEFER_REACH", "MGX_BFS_MERGED_PULL",
-                   "MGX_BFS_DO_CHAIN", "MGX_BFS_SSTREAM"):
+                   "MGX_BFS_DO_CHAIN", "MGX_BFS_SSTREAM", "MGX_BFS_MINI"):
             os.environ.pop(kk, None)
-        if src == srcs[0] and n <= 150000:
-            G = int(rng.choice([2, 3, 5, 8]))
+        if src == srcs[0] and (n <= 150000 or (n >= (1 << 20) and ran % 2 == 0)):
+            # the partitioned engine's rank engines in this process: small graphs, and R-MAT 20 / 21 (the ranks' cold-edge pass);
+            # unit blocks forced onto every eligible level or by the default rule
+            G = int(rng.choice([2, 3, 5, 8])) if n <= 150000 else 2
             mode = str(rng.choice(["gather", "reduce"]))
+            dd = str(rng.choice(["", "1000000"]))
+            if dd:
+                os.environ["MGX_DIST_DENSE_DIV"] = dd
+            os.environ["MGX_DIST_COLD"] = str(rng.choice(["1", "1", "0"]))
             got = partitioned_labels(n, ro, ci, src, G, mode)
-            assert np.array_equal(got, want), (name, n, src, "partitioned", G, mode)
+            os.environ.pop("MGX_DIST_DENSE_DIV", None); os.environ.pop("MGX_DIST_COLD", None)
+            assert np.array_equal(got, want), (name, n, src, "partitioned", G, mode, dd)
         dist, _, _ = orc.sssp_enact(ro, ci, w, src, 8.0)
         sssp.run(src)                                  # (MGX_SSSP_BUILD_LIST / MGX_SSSP_SLICED: whatever the last draw left)
         assert np.array_equal(sssp.distances(), dist), (name, n, src, "sssp", layout, os.environ.get("MGX_SSSP_BUILD_LIST"), os.environ.get("MGX_SSSP_SLICED"))
         os.environ.pop("MGX_SSSP_BUILD_LIST", None); os.environ.pop("MGX_SSSP_SLICED", None)
+    # a batch of sources (mgx_bfs_run_many): the counters of every traversal, the labels of the last one
+    sts, reruns = bfs.run_many(srcs)
+    for src, st in zip(srcs, sts):
+        w_ = orc.bfs_cpu(ro, ci, src)
+        assert st["m_t"] == int(deg[w_ >= 0].sum()) and st["reached"] == int((w_ >= 0).sum()), (name, n, src, "run_many", st, reruns)
+    assert np.array_equal(bfs.labels(), orc.bfs_cpu(ro, ci, srcs[-1])), (name, n, "run_many labels", reruns)
+    # the neighbour-reduce over the full frontier (mgx/nreduce.hpp on graphs with a layout, the general kernel otherwise)
+    if len(ci) > 0:
+        ids = np.arange(n, dtype=np.int32)
+        f = mini_amd.Frontier(ctx, n).load(ids)
+        vals = rng.integers(-1000, 1000, size=n).astype(np.int32)
+        red = torch.full((n,), 12345, dtype=torch.int32, device="cuda")
+        nz = mini_amd.segreduce(g, f, torch.from_numpy(vals).cuda(), 2**31 - 1, red, "i32_min")
+        want_r, wnz = orc.neighbor_reduce_i32(ro, ci, ids, vals, 2**31 - 1, False)
+        assert nz == wnz and np.array_equal(red.cpu().numpy(), want_r), (name, n, "neighbour-reduce", layout)
+        fv = rng.integers(0, 8, size=n).astype(np.float32)
+        redf = torch.full((n,), -1, dtype=torch.float32, device="cuda")
+        mini_amd.segreduce(g, f, torch.from_numpy(fv).cuda(), 0.0, redf, "f32_plus")
+        want_f, _ = orc.neighbor_reduce_f32_plus(ro, ci, ids, fv, 0.0)
+        assert np.array_equal(redf.cpu().numpy(), want_f), (name, n, "neighbour-reduce f32", layout)
     ran += 1
     print("ok %-18s n=%-7d m=%-9d layout=%d" % (name, n, len(ci), layout), flush=True)
 print("fuzz: %d graphs, all equal to the oracle" % ran)
