@@ -44,13 +44,18 @@ struct d2_cold_view_t {
   u32 wgs[BFS_COLD_MAX_SLICES + 1] = {};
 };
 constexpr int D2_LIST_HEAD = 4;          // header words of an id list: [0] count (may exceed the capacity: overflow), [1..3] unused
-__global__ __launch_bounds__(BLOCK) void k_d2_newbits(const u32* __restrict__ visited, const unsigned char* __restrict__ mark,
-                                                      u32* __restrict__ out, long long nwords, long long n, bfs_ctrl_t* c,
-                                                      u32* __restrict__ list, u32 list_cap, d2_cold_view_t cv, int level) {
+constexpr int D2_NEWBITS_NT = 1024;      // threads per workgroup of k_d2_newbits: ONE add to the list's counter per workgroup and trip
+__global__ __launch_bounds__(D2_NEWBITS_NT) void k_d2_newbits(const u32* __restrict__ visited, const unsigned char* __restrict__ mark,
+                                                              u32* __restrict__ out, long long nwords, long long n, bfs_ctrl_t* c,
+                                                              u32* __restrict__ list, u32 list_cap, d2_cold_view_t cv, int level) {
+  constexpr int NT = D2_NEWBITS_NT, NW = NT / WAVE;
+  __shared__ u32 s_wave[NW];
+  __shared__ u32 s_base;
   if (blockIdx.x == 0 && threadIdx.x == 0) c->merged_new = 0;     // the merge of this level counts into it
   const bool with_cold = cv.flush && c->cold_slot == level;       // (grid-uniform) the level's push ran the cold-edge pass
-  const long long stride = (long long)gridDim.x * BLOCK;
-  for (long long w0 = (long long)blockIdx.x * BLOCK; w0 < nwords; w0 += stride) {      // (block-uniform trip count: the wave scan below)
+  const int wave = threadIdx.x / WAVE;
+  const long long stride = (long long)gridDim.x * NT;
+  for (long long w0 = (long long)blockIdx.x * NT; w0 < nwords; w0 += stride) {      // (block-uniform trip count: the barriers below)
     const long long w = w0 + threadIdx.x;
     u32 bits = 0;
     if (w < nwords) {
@@ -78,19 +83,33 @@ __global__ __launch_bounds__(BLOCK) void k_d2_newbits(const u32* __restrict__ vi
       out[w] = bits;
     }
     if (list) {
+      // positions in the list: a scan over the wave, a scan of the waves' totals, ONE add to the list's counter per workgroup --
+      // on a level that discovers something everywhere every wave has a count, and they all look at the counter before any of
+      // them has made it overflow: per-wave adds to the one address cost this kernel 25 of its 40 us on such a level.  A list
+      // that has overflowed is not read (only "more than list_cap" matters from there on): the workgroup skips its add.
       const u32 cnt = (u32)__popc(bits);
       const u32 inc = wave_inclusive_sum(cnt);
-      const u32 tot = (u32)__shfl((int)inc, WAVE - 1, WAVE);
-      // (a list that has overflowed is not read: only "more than list_cap" matters from there on.  A plain look first keeps the
-      //  waves of a dense level -- tens of thousands of them -- off the one hot counter: 36 -> 12 us per level at n = 33.5 M)
-      if (tot && __builtin_nontemporal_load(&list[0]) <= list_cap) {   // (wave-uniform)
-        u32 base = 0;
-        if (lane_id() == 0) base = atomicAdd(&list[0], tot);
-        base = (u32)__shfl((int)base, 0, WAVE);
-        u32 at = base + inc - cnt;
+      if (lane_id() == WAVE - 1) s_wave[wave] = inc;
+      __syncthreads();
+      if (wave == 0) {
+        const u32 v = lane_id() < NW ? s_wave[lane_id()] : 0u;
+        const u32 incl = wave_inclusive_sum(v);
+        if (lane_id() < NW) s_wave[lane_id()] = incl - v;
+        const u32 btot = (u32)__shfl((int)incl, NW - 1, WAVE);
+        if (lane_id() == 0) {
+          u32 base = 0xFFFFFFFFu;                                      // (nothing to place, or the list is over already)
+          if (btot && __builtin_nontemporal_load(&list[0]) <= list_cap) base = atomicAdd(&list[0], btot);
+          s_base = base;
+        }
+      }
+      __syncthreads();
+      const u32 base = s_base;
+      if (base != 0xFFFFFFFFu && cnt) {
+        u32 at = base + s_wave[wave] + inc - cnt;
         for (u32 rest = bits; rest; rest &= rest - 1u, ++at)
           if (at < list_cap) list[D2_LIST_HEAD + at] = (u32)(w * 32) + (u32)(__ffs((int)rest) - 1);
       }
+      __syncthreads();           // s_wave / s_base are reused by the next trip
     }
   }
 }
@@ -119,8 +138,15 @@ __global__ __launch_bounds__(BLOCK) void k_d2_or(const uint4* __restrict__ gathe
     }
     found += __popc(g.x) + __popc(g.y) + __popc(g.z) + __popc(g.w);
   }
+  // one add per WORKGROUP: on a level that discovers something everywhere every wave has a count, and four thousand adds to
+  // one address cost the kernel 20 of its 32 us (they queue up at ~5 ns each)
+  __shared__ int s_found;
+  if (threadIdx.x == 0) s_found = 0;
+  __syncthreads();
   found = wave_sum(found);
-  if (lane_id() == 0 && found) atomicAdd(&c->merged_new, (u64)found);
+  if (lane_id() == 0 && found) atomicAdd(&s_found, found);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_found) atomicAdd(&c->merged_new, (u64)s_found);
 }
 
 // out[w] = OR over the maps of maps[r][w] (the reduce step of the slice exchange: the maps are the ranks' versions of
@@ -397,7 +423,7 @@ inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx) {
   bfs_fused_args_t a = st.args();
   bfs_set_kernel_attributes();
   bfs_launch_push(a, level, ctx, 2, bfs_cold_test(a.n, st.cold_forced));   // (the level's bookkeeping rides on the push launch)
-  hipLaunchKernelGGL(k_d2_newbits, dim3(grid_for(st.nwords, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, st.fs->visited.data(),
+  hipLaunchKernelGGL(k_d2_newbits, dim3(grid_for(st.nwords, D2_NEWBITS_NT, ctx.num_cus * 2)), dim3(D2_NEWBITS_NT), 0, s, st.fs->visited.data(),
                      st.fs->mark.data(), st.newbits, st.nwords, (long long)st.n_global, a.ctrl, st.mylist, st.list_cap, st.cold_view(), level);
 }
 
