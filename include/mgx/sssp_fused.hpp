@@ -38,6 +38,13 @@
 // passes an improvement on within the iteration (dist[u] is read when the row is staged, the atomicMin lands at once), a pull
 // iteration works from the distances the workgroup copied at its start: 13 iterations and 473 M relaxation-equivalents against
 // 10 and 297 M for the same source.
+// And a HYBRID of the two for the hubs' iteration only (the early iterations with >= 2 M frontier edges, symmetric weights): the
+// pushes -- queue walk and sweep -- skip destinations that are short rows (< 64 entries: four in five of that iteration's atomics
+// go there) and one pass over the short rows lets each fetch min(dist[u] + w) over its frontier neighbours itself (frontier bits
+// of the first 655 K vertices in LDS, a plain store per improved vertex).  Distances bit-equal; 1.90-1.93 ms per source against
+// 1.85-1.88: the iteration of a source whose hubs hold 70 M edges went from 0.85 to 0.73 ms, the one with 15 M edges from 0.38 to
+// 0.44 -- the pass over all 18 M short-row entries costs ~0.15 ms whatever the frontier (two dependent gathers per entry), more
+// than the atomics it replaces.
 #pragma once
 #include <vector>
 #include "bfs_fused.hpp"
