@@ -459,8 +459,15 @@ inline void d2_merge(d2_state_t& st, int level, const u32* gathered, int maps, l
   bfs_fused_args_t a = st.args();
   hipLaunchKernelGGL(k_d2_or, dim3(grid_for(st.nwords / 4, BLOCK, 1024)), dim3(BLOCK), 0, s, (const uint4*)gathered, maps,
                      stride_words / 4, st.nwords / 4, (uint4*)st.merged.data(), (uint4*)st.fs->visited.data(), a.ctrl, level);
-  hipLaunchKernelGGL((k_bfs_build<512, false>), dim3(bfs_build_grid(st.n_local, 512)), dim3(512), 0, s, a, level,
-                     (const u32*)st.merged.data(), st.labels.data(), st.n_local, st.ranks, st.rank, 0);
+  // the queue build without a list when the rank's row offsets allow its 16-byte loads (k_bfs_build2<., DIST>: labels and
+  // row extents of a thread's 16 local vertices are contiguous); MGX_DIST_BUILD_LIST=1: the list-based one
+  static const bool build_list = [] { const char* e = getenv("MGX_DIST_BUILD_LIST"); return e && atoi(e) != 0; }();
+  if (!build_list && ((uintptr_t)a.row_offsets % 16 == 0))
+    hipLaunchKernelGGL((k_bfs_build2<512, true>), dim3(bfs_build_grid(st.n_local, 512)), dim3(512), 0, s, a, level, st.labels.data(), st.n_local,
+                       (const u32*)st.merged.data(), st.ranks, st.rank);
+  else
+    hipLaunchKernelGGL((k_bfs_build<512, false>), dim3(bfs_build_grid(st.n_local, 512)), dim3(512), 0, s, a, level,
+                       (const u32*)st.merged.data(), st.labels.data(), st.n_local, st.ranks, st.rank, 0);
 }
 
 // Synchronises and reports: out[0] traversal over (a level discovered nothing on any rank), [1] levels that hold

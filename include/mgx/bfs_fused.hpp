@@ -707,8 +707,12 @@ __device__ __forceinline__ bool bfs_build_is_lazy(const bfs_fused_args_t& a, int
   return M * (u64)a.lazy_div >= (u64)(u32)a.n;
 }
 
-template <int NT>
-__global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int arg, int* __restrict__ labels, int n) {
+// DIST (a rank of the partitioned traversal, bfs_dist2.hpp): the new vertices are the bits this rank OWNS of the level's merged
+// discoveries (`bits`, over all vertices: local vertex i is global vertex i * ranks + rank) instead of marks; bitmap and
+// frontier are k_d2_or's business; labels and row extents are local and contiguous: no scatter at all.
+template <int NT, bool DIST = false>
+__global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int arg, int* __restrict__ labels, int n,
+                                                      const u32* __restrict__ bits = nullptr, int ranks = 1, int rank = 0) {
   constexpr int NW = NT / WAVE;
   constexpr u64 CNT1 = 1ull << 40;
   constexpr u64 DEGMASK = CNT1 - 1ull;
@@ -719,11 +723,11 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
   bfs_ctrl_t* const c = a.ctrl;
   int slot, level;
   bfs_resolve(c, arg, slot, level);
-  if (c->done || c->skip_build[slot & 3]) return;
+  if (!DIST && (c->done || c->skip_build[slot & 3])) return;      // (a rank of a partitioned run may be handed work behind an empty frontier of its own)
   // (direction-optimising runs: once the traversal has switched to bottom-up levels it stays there, and those read the
   //  frontier bitmap: no queue is ever needed again)
-  const bool lazy = bfs_build_is_lazy(a, slot) || (a.lazy_pull && c->pull);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  const bool lazy = !DIST && (bfs_build_is_lazy(a, slot) || (a.lazy_pull && c->pull));
+  if (!DIST && blockIdx.x == 0 && threadIdx.x == 0) {
     c->fb_slot = slot + 1;                                             // frontier_bits: written in full below
     c->lazy_slot = lazy ? slot + 1 : -1;
     if (lazy) c->lazy_slots += 1;
@@ -743,7 +747,7 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
   // spread over the workgroup's waves -- all loads of a wave in flight at once (2-byte loads, one buffer per instruction:
   // the OR of a level that deferred in 512 workgroups took 10 us of its build).
   u32 flushed16 = 0;
-  if (a.flush_buf) {
+  if (!DIST && a.flush_buf) {
     const u32 F = c->flush_count[slot & 1];
     if (F) {                                                     // (grid-uniform)
       for (int hr = 0; hr < NW; ++hr) {
@@ -775,7 +779,7 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
   // the same for the bitmaps of the slot's cold-edge pass (bfs_fused_cold.hpp): cold workgroup k of slice s wrote what it
   // discovered in [cold_lo[s], + BFS_COLD_WORDS * 32) into buffer k.  Wave w takes the workgroup's run w: 16-byte loads,
   // eight lanes per buffer (a run is 128 bytes of bitmap), eight buffers per instruction, everything in flight at once.
-  if (a.cold_dst && c->cold_slot == slot) {                          // (grid-uniform)
+  if (!DIST && a.cold_dst && c->cold_slot == slot) {                 // (grid-uniform)
     static_assert(NW == 8, "one wave per run");
     u32* const s_run = &s_or[0][0];                                  // [NW][32] words
     const long long run = (long long)blockIdx.x + (long long)wave * gridDim.x;
@@ -806,7 +810,16 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
 
   // ---- which of my 16 vertices are new -------------------------------------------------------------------------------
   u32 new16 = 0;
-  if (i0 < n) {
+  if (DIST) {
+    if (i0 < n) {
+      const u32 valid = (n - i0 >= 16) ? 0xFFFFu : ((1u << (int)(n - i0)) - 1u);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const long long v = (i0 + q) * (long long)ranks + rank;              // (past the rank's last row: masked by `valid`; the bitmap is padded)
+        if (((valid >> q) & 1u) && ((bits[v >> 5] >> (v & 31)) & 1u)) new16 |= 1u << q;
+      }
+    }
+  } else if (i0 < n) {
     const u32 valid = (n - i0 >= 16) ? 0xFFFFu : ((1u << (int)(n - i0)) - 1u);
     const uint4 m = *(const uint4*)(a.mark + i0);                            // mark[] is padded: always readable
     const u32 x[4] = {m.x, m.y, m.z, m.w};
