@@ -59,7 +59,7 @@ for cfg in "25 8" "26 8" "22 8" "22 1"; do
   set -- $cfg
   timeout 900 python tools/dist2_single.py $1 $2 2>/dev/null | grep -v amdgpu.ids | tail -4 > $O/dist2_single_$1_$2.log
 done
-DIST2_CHECK=1 timeout 900 python tools/dist2_single.py 23 4 2>/dev/null | grep -v amdgpu.ids | tail -5 > $O/dist2_single_23_4_check.log
+DIST2_CHECK=1 timeout 900 python tools/dist2_single.py 23 4 2>/dev/null | grep -v amdgpu.ids | tail -8 > $O/dist2_single_23_4_check.log
 # the driver's own command line
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.log 2>&1
 # auxiliary logs: operator path (reference loop, idempotent mode), direction-optimising sweep
