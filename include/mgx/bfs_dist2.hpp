@@ -334,7 +334,7 @@ struct d2_state_t {
   mem_t<u32> cold_flush;
   d2_cold_view_t cold_view() const {
     d2_cold_view_t v;
-    if (!cold_dst) return v;
+    if (!cold_dst || cold_slices <= 0 || !cold_flush.size()) return v;
     v.flush = cold_flush.data(); v.slices = cold_slices;
     for (int i = 0; i < BFS_COLD_MAX_SLICES; ++i) v.lo[i] = cold_lo[i];
     for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) v.wgs[i] = cold_wgs[i];
@@ -396,7 +396,7 @@ struct d2_state_t {
     a.count_marks = 0;
     a.ub_col = ub_col; a.ub_owner = ub_owner; a.ub_units = (u32)ub_units; a.ub_units_pad = (u32)ub_units_pad; a.dense_div = ub_col ? dense_div : 0u;
     a.vs_v[0] = a.vs_v[1] = a.vs_v[2] = a.vs_v[3] = 0; a.vs_edges = 0; a.vs_div = 0; a.vs_dummy = 0; a.lazy_div = 0; a.slot_marks = nullptr; a.merged_pull = 0; a.lazy_pull = 0; a.chain_big_edges = 0; a.defer_reach_mul = 1; a.defer_reach_div = 1;
-    const bool cold = cold_dst != nullptr && ub_col != nullptr;
+    const bool cold = cold_dst != nullptr && ub_col != nullptr && cold_slices > 0 && cold_flush.size() > 0;
     a.cold_owner = cold ? cold_owner : nullptr; a.cold_dst = cold ? cold_dst : nullptr; a.cold_slices = cold ? cold_slices : 0;
     a.cold_flush = cold ? cold_flush.data() : nullptr;
     for (int i = 0; i < BFS_COLD_MAX_SLICES; ++i) a.cold_lo[i] = cold ? cold_lo[i] : 0u;

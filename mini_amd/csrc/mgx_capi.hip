@@ -1335,6 +1335,8 @@ int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
       const int rc2 = mgx_cold_build_device(st.row_offsets, st.col_indices, st.n_local, 0, long_rows, long_min, hot_n, slice_n, slices, &cowner, &cdst,
                                             &pairs, off.data(), ctx.stream());
       if (rc2 != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("partitioned BFS, cold-edge lists: ") + hipGetErrorString((hipError_t)rc2));
+      // (owned by the state from here on: freed with it whatever happens below; the pass is enabled by its flush buffers)
+      st.cold_owner = cowner; st.cold_dst = cdst;
       int used = 0;
       for (int k = 0; k < slices; ++k) if (off[k + 1] > off[k]) ++used;
       if (getenv("MGX_DIST_VERBOSE"))
@@ -1368,10 +1370,11 @@ int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
         st.cold_flush = mem_t<u32>((size_t)acc * mgx::BFS_COLD_WORDS, ctx);
         MGX_HIP(hipMemsetAsync(st.cold_flush.data(), 0, (size_t)acc * mgx::BFS_COLD_WORDS * sizeof(unsigned), ctx.stream()));
         ctx.synchronize();
-        st.cold_owner = cowner; st.cold_dst = cdst; st.cold_pairs = pairs; st.cold_slices = used;
+        st.cold_pairs = pairs; st.cold_slices = used;
       } else {
         if (cowner) (void)hipFree(cowner);
         if (cdst) (void)hipFree(cdst);
+        st.cold_owner = nullptr; st.cold_dst = nullptr;
       }
     }
   }
