@@ -237,6 +237,19 @@ def test_partitioned_ranks_cold_edge_pass(built, world, scale, dense_div, cold, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,scale", [(2, 14), (3, 13)])
+def test_partitioned_ranks_list_based_queue_build(built, world, scale, monkeypatch):
+    """MGX_DIST_BUILD_LIST=1: the ranks' queue build through an LDS list (k_bfs_build<., false>, what a rank falls back to when
+    its row offsets are not 16-byte aligned) instead of k_bfs_build2<., DIST>: the same labels, edge counts and depths"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    monkeypatch.setenv("MGX_DIST_EXCHANGE", "gather")
+    monkeypatch.setenv("MGX_DIST_LISTS", "0")
+    monkeypatch.setenv("MGX_DIST_BUILD_LIST", "1")
+    _run(world, True, scale, scale + 90, _worker2)
+
+
+@pytest.mark.gpu
 def test_or_maps_kernel_matches_numpy(built):
     """mgx_dbfs2_or_maps (the reduce step of the slice exchange, used when the collectives run on the GPU)"""
     if not torch.cuda.is_available():
