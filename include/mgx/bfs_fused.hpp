@@ -989,7 +989,8 @@ struct bfs_run_opts_t {
   long long defer = -1;    // MGX_BFS_DEFER: 0 never defer hot marks, N: flush a bitmap above N deferred marks per workgroup
   int spin = -1;           // MGX_BFS_SPIN: 0 read the control block back with a copy + hipStreamSynchronize, 1 publish kernel + spin
   int build_list = 0;      // MGX_BFS_BUILD_LIST=1: the list-based queue build (k_bfs_build) instead of k_bfs_build2
-  int mini = 1;            // MGX_BFS_MINI=0: no M launches (mid-size levels take device-wide slots; bfs_fused_mini.hpp)
+  int mini = 1;            // MGX_BFS_MINI=0: no M launches (mid-size levels take device-wide slots; bfs_fused_mini.hpp); 1: on graphs of at
+                           // least 2^22 vertices; 2: always
   int many_spare = 0;      // MGX_BFS_MANY_SPARE: launch slots a traversal of a batch (mgx_bfs_run_many) gets beyond what the last
                            // traversals of the graph needed (the most any of the last four needed: one that still does not finish is run
                            // again on its own, and the chain behind a traversal's last slot takes stragglers of up to BFS_CHAIN_CAP_BIG edges)

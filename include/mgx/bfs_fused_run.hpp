@@ -412,7 +412,12 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   a.lazy_div = (a.dense_div && a.vs_div && build2_ok && !opt.build_list) ? (opt.lazy >= 0 ? (u32)opt.lazy : st.lazy_div) : 0u;
   plan.coldt = coldt;
   plan.build2_ok = build2_ok;
-  plan.minis = mode == 0 && opt.mini != 0 && a.chain_big_edges != 0u && opt.merged && !lab_flags;
+  // M launches from RMAT-22's size on: what one costs does not depend on the graph, what the device-wide slot it replaces costs
+  // does (its queue build sweeps all n marks).  Measured, batches of 32 sources: RMAT-23 0.703 against 0.720 ms per traversal
+  // without them, RMAT-22 equal to 1 % better; with them at every size RMAT-21 / 18 were 1.4 / 2.4 % worse and RMAT-20 0.236
+  // against 0.195 ms (levels of 30-130 K edges are a large share of such a graph; two of 16 sources re-run).  MGX_BFS_MINI=2
+  // forces them (the tests' graphs are small)
+  plan.minis = mode == 0 && opt.mini != 0 && a.chain_big_edges != 0u && opt.merged && !lab_flags && (st.n >= (1 << 22) || opt.mini == 2);
   plan.nstream = a.long_min > 0 ? (u32)ctx.num_cus * 2 : 0u;
   plan.nwave = (u32)ctx.num_cus * 2;
   plan.ncold = (!coldt && a.cold_dst) ? a.cold_wgs[a.cold_slices] : 0u;

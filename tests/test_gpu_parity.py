@@ -620,7 +620,7 @@ VARIANTS = [{}, {"MGX_BFS_COLD_TEST": "1"}, {"MGX_BFS_COLD_TEST": "1", "MGX_BFS_
             {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_SSTREAM": "1"}, {"MGX_BFS_SSTREAM": "1"},
             {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_LONG_MIN": "8", "MGX_BFS_DENSE": "1000000", "MGX_BFS_SSTREAM": "1"},
             {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_LONG_MIN": "1", "MGX_BFS_SSTREAM": "1"},
-            {"MGX_BFS_MINI": "0"}, {"MGX_BFS_MINI": "0", "MGX_BFS_TAIL_FRONT": "0"}, {"MGX_BFS_TAIL_CHAIN": "0"}, {"MGX_BFS_CHAIN_BIG_EDGES": "100"}, {"MGX_BFS_CHAIN_MAX_EDGES": "64", "MGX_BFS_CHAIN_BIG_EDGES": "12288", "MGX_BFS_LAZY": "1048576"}]
+            {"MGX_BFS_MINI": "2"}, {"MGX_BFS_MINI": "0", "MGX_BFS_TAIL_FRONT": "0"}, {"MGX_BFS_TAIL_CHAIN": "0"}, {"MGX_BFS_CHAIN_BIG_EDGES": "100"}, {"MGX_BFS_CHAIN_MAX_EDGES": "64", "MGX_BFS_CHAIN_BIG_EDGES": "12288", "MGX_BFS_LAZY": "1048576"}]
 
 
 @pytest.mark.parametrize("variant", range(len(VARIANTS)))
@@ -951,13 +951,14 @@ def test_bfs_run_many_reruns_a_traversal_that_needs_more_slots(gpu_ctx, oracle, 
 
 
 @pytest.mark.parametrize("layout", [False, True])
-def test_bfs_mid_size_levels_take_m_launches(gpu_ctx, oracle, layout):
+def test_bfs_mid_size_levels_take_m_launches(gpu_ctx, oracle, layout, monkeypatch):
     """M launches (bfs_fused_mini.hpp: a mid-size level as one launch of 64 workgroups, claims by atomicOr, no sweep):
     graphs whose levels sit between the one-workgroup chain (4096 edges, 1536 early) and the mid-size limits (131072 edges,
     32768 early) -- hubs of a few thousand edges (long rows staged in LDS, 64-edge units), tens of thousands of short rows,
     more winners than a workgroup's list holds (flushes) -- and levels ABOVE the limits behind an M launch (forwarded to
     the next slot); labels and counters against the oracle, with the launches switched off as the cross-check"""
     import mini_amd
+    monkeypatch.setenv("MGX_BFS_MINI", "2")         # (by default only graphs of 2^22 vertices and more get M launches)
     rng = np.random.default_rng(2024)
     used = 0
     for trial in range(6):

@@ -125,7 +125,7 @@ for name, n, ro, ci, w in graphs():
                      "MGX_BFS_COLD": rng.choice(["", "0", "2"]), "MGX_BFS_DEFER_REACH": rng.choice(["", "0/1", "4/1"]),
                      "MGX_BFS_MERGED_PULL": rng.choice(["", "0"]), "MGX_BFS_DO_CHAIN": rng.choice(["", "0"]),
                      "MGX_BFS_SSTREAM": rng.choice(["", "1"]), "MGX_SSSP_BUILD_LIST": rng.choice(["", "1"]),
-                     "MGX_SSSP_SLICED": rng.choice(["", "", "3"]), "MGX_BFS_MINI": rng.choice(["", "0"]),
+                     "MGX_SSSP_SLICED": rng.choice(["", "", "3"]), "MGX_BFS_MINI": rng.choice(["", "0", "2"]),
                      "MGX_SSSP_DENSE": rng.choice(["", "0", "1000000000"])}
             for kk, vv in knobs.items():
                 if vv == "":
