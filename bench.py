@@ -611,8 +611,16 @@ def bench_pr(args, ctx, stream):
         cpu_time = time.perf_counter() - tc
         if not args.no_check:
             got = red.cpu().numpy()
-            # float sum order differs (the reference's own order is moderngpu's, unpinned): 2e-5 relative, as tests/ do
+            # float sum order differs (the reference's own order is moderngpu's, unpinned): 2e-5 relative to the oracle, as tests/ do.
+            # The oracle accumulates serially in float32 like the reference's reduce: on a row of several hundred thousand entries
+            # ITS rounding error passes that (RMAT-24, 739 757 entries: 4.2e-5 off the float64 sum; the library's folds 2e-7) -- so a
+            # mismatch is settled against the float64 sum of the same float32 values: the library within 2e-6 of it, the oracle
+            # within 1e-3.
             parity = bool(onz == nz and np.allclose(got, want, rtol=2e-5, atol=1e-6))
+            if not parity and onz == nz:
+                rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ro_h))
+                want64 = np.bincount(rows, weights=v_h.astype(np.float64)[ci_h], minlength=n)
+                parity = bool(np.allclose(got, want64, rtol=2e-6, atol=1e-6) and np.allclose(want, want64, rtol=1e-3, atol=1e-6))
         if not args.no_cpu_baseline:
             cpu = {"value": round(onz / max(cpu_time, 1e-9) / 1e6, 2), "unit": "MTEPS", "cores": 1, "kind": "port", "host_cpus": os.cpu_count(),
                    "sample": "oracle orc_neighbor_reduce_f32_plus (serial restatement of neighborhood.hxx:12-70) once over the same "
@@ -626,7 +634,7 @@ def bench_pr(args, ctx, stream):
                       "scale": args.scale, "edgefactor": args.edgefactor, "seed": seed, "parallelism": "1 GPU",
                       "layout": "generator ids" if args.no_layout else "the operator is called with generator ids; for a full frontier the library reads "
                                 "the graph's hub-first copy (unit blocks + degree classes, untimed one-time preprocessing: layout_build_s)"},
-           "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "parity_tolerance": "rtol 2e-5 (float sum order)",
+           "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "parity_tolerance": "rtol 2e-5 against the serial float32 oracle (float sum order); where the oracle's own rounding exceeds that (rows of several 10^5 entries): rtol 2e-6 against the float64 sum of the same values, the oracle within 1e-3 of it",
            "device_ms_per_step": round(dev_ms / max(args.steps, 1), 4), "graph_build_s": round(t_build, 2), "layout_build_s": round(t_layout, 2),
            "source_sha": sha}
     print(json.dumps(out), flush=True)
