@@ -694,13 +694,15 @@ inline int bfs_fused_run_many(bfs_fused_state_t& st, const int* row_offsets, con
   const bfs_launch_plan_t plan = bfs_fused_plan(st, row_offsets, col_indices, labels, ctx, layout, mode, alpha, in_offsets, in_indices);
   const bfs_fused_args_t& a = plan.a;
   constexpr int head_words = (int)(bfs_head_bytes() / 4);
-  // slots per traversal: what the last traversals of the graph needed at most -- plus one in a direction-optimising run whose
-  // last traversals did not all need the same (where a source switches direction moves its level structure: 4 .. 7 slots by
-  // source at alpha = 1 on RMAT-22; a spare slot is two idle launches, ~5-9 us, a traversal that does not finish is run again:
-  // 0.385 -> 0.344 ms per traversal, 7 of 64 -> 0 re-runs.  Top-down runs never needed it: 0.3405 -> 0.3445 with it)
+  // slots per traversal: what the last traversals of the graph needed at most.  A direction-optimising run gets one more, and
+  // another one when its last traversals did not all need the same: where a source switches direction moves its level
+  // structure (4 .. 7 slots by source at alpha = 1 on RMAT-22), a spare slot is two idle launches, ~5-9 us, and a traversal that
+  // does not finish is run again.  Measured at alpha = 64, 16 sources: RMAT-24 9 re-runs and 1.28 ms per traversal -> 0 and
+  // 0.78 (one call per source: 0.79), RMAT-23 0.47 -> 0.41, RMAT-20 0.19 -> 0.15; alpha = 1 on RMAT-22 0.385 -> 0.344.  Top-down
+  // runs never needed it (0.3405 -> 0.3445 ms with it).
   bool uneven = false;
   for (int i = 1; i < 4 && i < st.recent_at; ++i) uneven |= st.recent_need[i] != st.recent_need[0];
-  int nslots = st.slots_hint + st.opts.many_spare + ((uneven && mode == 1) ? 1 : 0);
+  int nslots = st.slots_hint + st.opts.many_spare + (mode == 1 ? (uneven ? 2 : 1) : 0);
   if (nslots > 30) nslots = 30;
   if (nslots < 1) nslots = 1;
   const int saved_tail = st.tail_from;
