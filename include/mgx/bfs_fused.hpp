@@ -1080,6 +1080,7 @@ struct bfs_fused_state_t {
   unsigned chain_big_edges = 4096;   // largest level the in-place chain kernel runs (bfs_fused_run.hpp; <= BFS_CHAIN_CAP_BIG): a lone workgroup
                                      // needs ~5 + 4.3 us per 1000 edges (measured: 10 487 edges 49 us, 7 391 38 us, 1 281 17 us), a device-wide slot ~21 us
   int recent_need[4] = {1, 1, 1, 1}, recent_at = 0;   // slots the last traversals needed
+  int auto_spare = 0, clean_batches = 0;             // batches (bfs_fused_run_many): spare slots learnt from re-runs, batches without one since
   int tail_from = 1 << 30;           // slots from this one on get an in-place chain launch in front (learnt from the previous traversal)
   unsigned lazy_div = 4;             // the build behind a push with >= n / lazy_div mark stores writes no queues (bfs_build_is_lazy; 0: never)
   mem_t<u32> slot_marks;             // the counters it looks at (bfs_fused_args_t::slot_marks)

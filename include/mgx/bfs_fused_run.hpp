@@ -702,7 +702,9 @@ inline int bfs_fused_run_many(bfs_fused_state_t& st, const int* row_offsets, con
   // runs never needed it (0.3405 -> 0.3445 ms with it).
   bool uneven = false;
   for (int i = 1; i < 4 && i < st.recent_at; ++i) uneven |= st.recent_need[i] != st.recent_need[0];
-  int nslots = st.slots_hint + st.opts.many_spare + (mode == 1 ? (uneven ? 2 : 1) : 0);
+  // ... and whatever mode: a batch that had to run a traversal again earns the handle's next batches a spare slot (at most 4),
+  // taken back after eight batches in a row without a re-run (graphs whose sources differ in depth: R-MAT 16, 3 of 32 sources)
+  int nslots = st.slots_hint + st.opts.many_spare + (mode == 1 ? (uneven ? 2 : 1) : 0) + st.auto_spare;
   if (nslots > 30) nslots = 30;
   if (nslots < 1) nslots = 1;
   const int saved_tail = st.tail_from;
@@ -752,6 +754,8 @@ inline int bfs_fused_run_many(bfs_fused_state_t& st, const int* row_offsets, con
   }
   if (redo_last) bfs_fused_run(st, row_offsets, col_indices, labels, srcs[count - 1], ctx, layout, mode, alpha, in_offsets, in_indices);
   st.slots_used = last_slot;
+  if (reruns > 0) { if (st.auto_spare < 4) ++st.auto_spare; st.clean_batches = 0; }
+  else if (st.auto_spare > 0 && ++st.clean_batches >= 8) { --st.auto_spare; st.clean_batches = 0; }
   return reruns;
 }
 
