@@ -60,6 +60,19 @@ for cfg in "25 8" "26 8" "22 8" "22 1"; do
   timeout 900 python tools/dist2_single.py $1 $2 2>/dev/null | grep -v amdgpu.ids | tail -4 > $O/dist2_single_$1_$2.log
 done
 DIST2_CHECK=1 timeout 900 python tools/dist2_single.py 23 4 2>/dev/null | grep -v amdgpu.ids | tail -8 > $O/dist2_single_23_4_check.log
+# ... and its kernels under rocprofv3
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_dist2 -- python3 $R/tools/dist2_single.py 25 8 > $O/trace_dist2.log 2>&1
+cd $R
+f=$(ls $O/trace_dist2/*/*kernel_stats.csv 2>/dev/null | head -1)
+[ -n "$f" ] && python3 - "$f" > $O/kernel_stats_dist2_25_8.csv <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+w = csv.DictWriter(sys.stdout, fieldnames=rows[0].keys()); w.writeheader()
+for r in rows:
+    if "mgx" in r["Name"]:
+        r = dict(r); r["Name"] = r["Name"][:120]; w.writerow(r)
+PY
 # the driver's own command line
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.log 2>&1
 # auxiliary logs: operator path (reference loop, idempotent mode), direction-optimising sweep
@@ -76,7 +89,7 @@ cat $O/summary.txt
 mkdir -p $O/keep
 cp $O/summary.txt $O/summary.json $O/kernel_stats_mgx.csv $O/kernel_stats_sssp.csv $O/kernel_stats_pr.csv $O/levels.log $O/sssp_iterations.log $O/timeline.txt $O/keep/ 2>/dev/null
 cp $O/pmc_traffic.json $O/bfs_operator_s22.log $O/dobfs_alpha_sweep.txt $O/keep/ 2>/dev/null
-cp $O/dist2_single_*.log $O/keep/ 2>/dev/null
+cp $O/dist2_single_*.log $O/kernel_stats_dist2_25_8.csv $O/keep/ 2>/dev/null
 grep '^{' $O/bench_driver_cmd.log | tail -1 > $O/keep/bench_line_driver_cmd.json
 grep '^{' $O/bench.log | tail -1 > $O/keep/bench_line.json
 grep '^{' $O/bench_per_call.log | tail -1 > $O/keep/bench_line_per_call.json
