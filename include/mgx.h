@@ -41,6 +41,7 @@ typedef struct mgx_frontier_s* mgx_frontier_t;
 typedef struct mgx_bfs_s* mgx_bfs_t;
 typedef struct mgx_sssp_s* mgx_sssp_t;
 typedef struct mgx_pr_s* mgx_pr_t;
+typedef struct mgx_kcore_s* mgx_kcore_t;
 typedef struct mgx_dbfs_s* mgx_dbfs_t;
 typedef struct mgx_dbfs2_s* mgx_dbfs2_t;
 typedef struct mgx_dsssp_s* mgx_dsssp_t;
@@ -421,6 +422,18 @@ MGX_API int mgx_pr_create(mgx_graph_t g, int max_iter, mgx_pr_t* out);    /* pr_
 MGX_API int mgx_pr_free(mgx_pr_t p);
 MGX_API int mgx_pr_enact(mgx_pr_t p, int64_t* frontier_len_per_iter, int* iterations); /* pr_enactor.hxx:41-79 */
 MGX_API int mgx_pr_ranks(mgx_pr_t p, float* host_ranks);
+
+/* ---- k-core: kcore_problem_t / kcore_functor.hxx / kcore_enactor_t (gunrock/src/kcore/) ---- */
+MGX_API int mgx_kcore_create(mgx_graph_t g, mgx_kcore_t* out);             /* kcore_problem.hxx:37-49 */
+MGX_API int mgx_kcore_reset(mgx_kcore_t p);                                /* core numbers 0, degrees = row lengths */
+MGX_API int mgx_kcore_free(mgx_kcore_t p);
+/* kcore_enactor_t::enact (kcore_enactor.hxx:40-86): peeling on filter<deg_less_than_k> / advance<update_deg, false, false> /
+ * filter<deg_atleast_k>.  *largest_k_core: what the enactor found (-1 if no k <= n ended the run: only a graph without
+ * entries, an upstream quirk that is kept).  stats[0] = k values tried, [1] = passes, [2] = entries expanded,
+ * [3] = vertices removed (stats may be NULL).  The run consumes the working degrees: mgx_kcore_reset before another one. */
+MGX_API int mgx_kcore_enact(mgx_kcore_t p, int* largest_k_core, int64_t* stats);
+MGX_API int mgx_kcore_num_cores(mgx_kcore_t p, int* host_num_cores);       /* extract() :51-53        */
+MGX_API int mgx_kcore_degrees(mgx_kcore_t p, int* host_degrees);           /* the working degrees (<= 0 once a run is over) */
 
 /* ---- synthetic input: counter-based R-MAT (the reference ships none, F4) ----
  * Writes edges [first_edge, first_edge+count) of the (scale, seed) stream to device arrays. */

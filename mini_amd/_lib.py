@@ -180,6 +180,12 @@ SIGNATURES = {
     "mgx_pr_free": [_vp],
     "mgx_pr_enact": [_vp, _pi64, _pi],
     "mgx_pr_ranks": [_vp, _vp],
+    "mgx_kcore_create": [_vp, _pvp],
+    "mgx_kcore_reset": [_vp],
+    "mgx_kcore_free": [_vp],
+    "mgx_kcore_enact": [_vp, _pi, _pi64],
+    "mgx_kcore_num_cores": [_vp, _vp],
+    "mgx_kcore_degrees": [_vp, _vp],
     "mgx_rmat_edges": [_vp, _i, _i64, _i64, _u64, _i, _vp, _vp, _vp],
 }
 _RESTYPES = {"mgx_comm_library": C.c_char_p, "mgx_strerror": C.c_char_p, "mgx_last_error": C.c_char_p, "mgx_host_free": None}

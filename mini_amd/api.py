@@ -2,7 +2,7 @@
 
 Names follow the reference (gunrock/src/*.hxx): Graph ~ graph_device_t, Frontier ~ frontier_t<int>,
 BfsProblem ~ bfs_problem_t + bfs_enactor_t, SsspProblem ~ sssp_problem_t + sssp_enactor_t,
-PrProblem ~ pr_problem_t + pr_enactor_t.  Every method is one C-ABI call; nothing is computed here.
+PrProblem ~ pr_problem_t + pr_enactor_t, KcoreProblem ~ kcore_problem_t + kcore_enactor_t.  Every method is one C-ABI call; nothing is computed here.
 """
 import ctypes as C
 
@@ -522,6 +522,40 @@ class PrProblem:
     def close(self):
         if self._h:
             lib.mgx_pr_free(self._h)
+            self._h = None
+
+
+class KcoreProblem:
+    """kcore_problem_t + kcore_enactor_t (gunrock/src/kcore/)."""
+
+    def __init__(self, graph):
+        h = C.c_void_p()
+        check(lib.mgx_kcore_create(graph._h, C.byref(h)))
+        self.graph, self._h = graph, h
+
+    def reset(self):
+        check(lib.mgx_kcore_reset(self._h))
+
+    def enact(self):
+        """-> (largest_k_core, {"rounds", "passes", "expanded", "removed"})"""
+        largest = C.c_int()
+        st = (C.c_int64 * 4)()
+        check(lib.mgx_kcore_enact(self._h, C.byref(largest), st))
+        return largest.value, {"rounds": st[0], "passes": st[1], "expanded": st[2], "removed": st[3]}
+
+    def num_cores(self):
+        out = np.empty(self.graph.num_nodes, dtype=np.int32)
+        check(lib.mgx_kcore_num_cores(self._h, _ptr(out)))
+        return out
+
+    def degrees(self):
+        out = np.empty(self.graph.num_nodes, dtype=np.int32)
+        check(lib.mgx_kcore_degrees(self._h, _ptr(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            lib.mgx_kcore_free(self._h)
             self._h = None
 
 

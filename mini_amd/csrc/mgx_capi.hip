@@ -10,6 +10,7 @@
 
 #include "gunrock/bfs/bfs_enactor.hxx"
 #include "gunrock/pr/pr_enactor.hxx"
+#include "gunrock/kcore/kcore_enactor.hxx"
 #include "gunrock/sssp/sssp_enactor.hxx"
 #include "mgx/bfs_dist.hpp"
 #include "mgx/bfs_dist2.hpp"
@@ -57,6 +58,11 @@ struct mgx_pr_s {
   mgx_graph_s* g;
   std::shared_ptr<pr::pr_problem_t> p;
   std::unique_ptr<pr::pr_enactor_t> e;
+};
+struct mgx_kcore_s {
+  mgx_graph_t g = nullptr;
+  std::shared_ptr<kcore::kcore_problem_t> p;
+  std::unique_ptr<kcore::kcore_enactor_t> e;
 };
 
 struct mgx_dbfs_s {
@@ -1840,6 +1846,64 @@ int mgx_pr_ranks(mgx_pr_t p, float* host) {
   use_device(p->g->c);
   p->g->c->ctx->synchronize();
   MGX_HIP(mgx::dtoh(host, p->p->d_current_ranks.data(), (size_t)p->g->g->num_nodes));
+  MGX_CATCH
+}
+
+
+// ---- k-core ----------------------------------------------------------------------------------
+int mgx_kcore_create(mgx_graph_t g, mgx_kcore_t* out) {
+  MGX_TRY
+  MGX_REQUIRE(g && out, "bad argument");
+  use_device(g->c);
+  auto* h = new mgx_kcore_s();
+  h->g = g;
+  h->p = std::make_shared<kcore::kcore_problem_t>(g->g, *g->c->ctx);
+  *out = h;
+  MGX_CATCH
+}
+int mgx_kcore_reset(mgx_kcore_t p) {
+  MGX_TRY
+  MGX_REQUIRE(p, "NULL argument");
+  use_device(p->g->c);
+  p->p->reset(*p->g->c->ctx);
+  MGX_CATCH
+}
+int mgx_kcore_free(mgx_kcore_t p) {
+  MGX_TRY
+  if (p) { use_device(p->g->c); delete p; }
+  MGX_CATCH
+}
+int mgx_kcore_enact(mgx_kcore_t p, int* largest_k_core, int64_t* stats) {
+  MGX_TRY
+  MGX_REQUIRE(p && largest_k_core, "NULL argument");
+  use_device(p->g->c);
+  standard_context_t& ctx = *p->g->c->ctx;
+  if (!p->e) p->e.reset(new kcore::kcore_enactor_t(ctx, p->g->g->num_nodes, p->g->g->num_edges));
+  p->e->enact(p->p, ctx);
+  ctx.synchronize();
+  *largest_k_core = p->p->largest_k_core;
+  if (stats) {
+    stats[0] = p->e->rounds;
+    stats[1] = p->e->passes;
+    stats[2] = p->e->expanded;
+    stats[3] = p->e->removed;
+  }
+  MGX_CATCH
+}
+int mgx_kcore_num_cores(mgx_kcore_t p, int* host) {
+  MGX_TRY
+  MGX_REQUIRE(p && host, "NULL argument");
+  use_device(p->g->c);
+  p->g->c->ctx->synchronize();
+  MGX_HIP(mgx::dtoh(host, p->p->d_num_cores.data(), (size_t)p->g->g->num_nodes));
+  MGX_CATCH
+}
+int mgx_kcore_degrees(mgx_kcore_t p, int* host) {
+  MGX_TRY
+  MGX_REQUIRE(p && host, "NULL argument");
+  use_device(p->g->c);
+  p->g->c->ctx->synchronize();
+  MGX_HIP(mgx::dtoh(host, p->p->d_degrees.data(), (size_t)p->g->g->num_nodes));
   MGX_CATCH
 }
 

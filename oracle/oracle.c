@@ -18,6 +18,9 @@
  *   - enactor loops                       gunrock/src/bfs/bfs_enactor.hxx:41-117,
  *                                         gunrock/src/sssp/sssp_enactor.hxx:40-72,
  *                                         gunrock/src/pr/pr_enactor.hxx:41-79
+ *   - k-core CPU validation + enactor     gunrock/src/kcore/kcore_problem.hxx:54-105,
+ *                                         gunrock/src/kcore/kcore_enactor.hxx:40-86,
+ *                                         gunrock/src/kcore/kcore_functor.hxx:10-36
  *
  * The scan / load-balanced-search / compaction / segmented-reduce arithmetic of the
  * reference lives in moderngpu (https://github.com/yzhwang/moderngpu.git, .gitmodules:1-3,
@@ -566,6 +569,98 @@ ORC_API int orc_pr_enact(int n, const int *offsets, const int *indices, int max_
     }
     free(reduced); free(degrees); free(gathered); free(buf[0]); free(buf[1]);
     return it;
+}
+
+/* ------------------------------------------------------------------------- */
+/* k-core decomposition: the reference's CPU validator and a      */
+/* serial restatement of its enactor loop over the operators                    */
+/* ------------------------------------------------------------------------- */
+
+/* kcore_problem_t::cpu (kcore_problem.hxx:54-105).  degrees start as the CSR row      */
+/* lengths (kcore_problem.hxx:43-45 via problem.hxx:23-30: multi-edges and self-loops  */
+/* count), num_cores as zeros (test_kcore.cu:36).  For k = 1, 2, ...: repeat { every    */
+/* vertex with 0 < degree < k that is still marked to_remain gets core k-1, degree 0;   */
+/* to_remain = degree >= k; the removed vertices' neighbours lose one degree per entry  */
+/* (degrees go negative: a removed vertex keeps being decremented) } until nothing was  */
+/* removed; the first k that leaves nobody with degree >= k ends the run.  Returns      */
+/* largest_k_core (-1 if no k <= n ended it).  Vertices without entries keep core 0.    */
+ORC_API int orc_kcore_cpu(int n, const int *row_offsets, const int *col_indices, int *num_cores)
+{
+    int *degrees = (int *)malloc((size_t)(n ? n : 1) * sizeof(int));
+    unsigned char *to_remove = (unsigned char *)malloc((size_t)(n ? n : 1));
+    unsigned char *to_remain = (unsigned char *)malloc((size_t)(n ? n : 1));
+    int largest = -1;
+    for (int v = 0; v < n; ++v) { degrees[v] = row_offsets[v + 1] - row_offsets[v]; num_cores[v] = 0; }
+    for (int k = 1; k <= n; ++k) {
+        int num_to_remain = 0;
+        memset(to_remove, 0, (size_t)n);
+        memset(to_remain, 1, (size_t)n);
+        for (;;) {
+            int num_to_remove = 0;
+            for (int v = 0; v < n; ++v) {
+                if (degrees[v] < k && degrees[v] > 0 && to_remain[v]) {
+                    num_cores[v] = k - 1; degrees[v] = 0; to_remove[v] = 1; ++num_to_remove;
+                } else to_remove[v] = 0;
+            }
+            num_to_remain = 0;
+            for (int v = 0; v < n; ++v) {
+                to_remain[v] = degrees[v] >= k;
+                num_to_remain += to_remain[v];
+            }
+            if (!num_to_remove) break;
+            for (int v = 0; v < n; ++v) {
+                if (!to_remove[v]) continue;
+                for (int e = row_offsets[v]; e < row_offsets[v + 1]; ++e) degrees[col_indices[e]]--;
+                to_remove[v] = 0;
+            }
+        }
+        if (num_to_remain == 0) { largest = k - 1; break; }
+    }
+    free(degrees); free(to_remove); free(to_remain);
+    return largest;
+}
+
+/* kcore_enactor_t::enact (kcore_enactor.hxx:40-86) over the serial operators, functors */
+/* inlined (kcore_functor.hxx:10-36):                                                   */
+/*   filter<deg_less_than_k>  keeps v with 0 < degree < k, side effect core = k-1,      */
+/*                            degree = 0                                    (:11-19)    */
+/*   advance<update_deg, idempotent=false, has_output=false>: one atomicAdd(-1) on the  */
+/*                            neighbour's degree per expanded entry, no output, returns */
+/*                            0 (advance.hxx:66)                            (:28-35)    */
+/*   filter<deg_atleast_k>    counts degree >= k                            (:22-26)    */
+/* `selector` never flips and the advance writes no output, so buffers[0] is the iota   */
+/* of init_frontier in every pass: each filter looks at ALL vertices.  Quirk kept:      */
+/* frontier_length is only refreshed in a pass that removed something, so a k whose     */
+/* first pass removes nothing is judged by the previous k's count (n before any) -- on  */
+/* a graph without entries the loop runs to k = n and largest_k_core stays -1, where    */
+/* cpu() answers 0.  stats[0] = k values tried, [1] = passes, [2] = entries expanded,   */
+/* [3] = vertices removed.                                                              */
+ORC_API int orc_kcore_enact(int n, const int *row_offsets, const int *col_indices, int *num_cores, int64_t *stats)
+{
+    int *degrees = (int *)malloc((size_t)(n ? n : 1) * sizeof(int));
+    int *removed = (int *)malloc((size_t)(n ? n : 1) * sizeof(int));
+    int largest = -1;
+    int64_t frontier_length = n, st[4] = {0, 0, 0, 0};
+    for (int v = 0; v < n; ++v) { degrees[v] = row_offsets[v + 1] - row_offsets[v]; num_cores[v] = 0; }
+    for (int k = 1; k <= n; ++k) {
+        ++st[0];
+        for (;;) {
+            int64_t num_to_remove = 0;
+            ++st[1];
+            for (int v = 0; v < n; ++v)
+                if (degrees[v] < k && degrees[v] > 0) { num_cores[v] = k - 1; degrees[v] = 0; removed[num_to_remove++] = v; }
+            if (!num_to_remove) break;
+            st[3] += num_to_remove;
+            for (int64_t i = 0; i < num_to_remove; ++i)
+                for (int e = row_offsets[removed[i]]; e < row_offsets[removed[i] + 1]; ++e, ++st[2]) degrees[col_indices[e]]--;
+            frontier_length = 0;
+            for (int v = 0; v < n; ++v) frontier_length += degrees[v] >= k;
+        }
+        if (frontier_length == 0) { largest = k - 1; break; }
+    }
+    if (stats) memcpy(stats, st, sizeof(st));
+    free(degrees); free(removed);
+    return largest;
 }
 
 /* ------------------------------------------------------------------------- */

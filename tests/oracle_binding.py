@@ -31,6 +31,8 @@ class Oracle:
         L.orc_scan_degrees.restype = C.c_int64
         L.orc_bfs_advance.restype = C.c_int64
         L.orc_bfs_filter.restype = C.c_int64
+        L.orc_bfs_gen_unvisited.restype = C.c_int64
+        L.orc_bfs_advance_backward.restype = C.c_int64
         L.orc_sssp_advance.restype = C.c_int64
         L.orc_sssp_filter.restype = C.c_int64
         L.orc_neighbor_reduce_f32_plus.restype = C.c_int64
@@ -116,6 +118,28 @@ class Oracle:
         k = self.lib.orc_bfs_filter(_p(fin), C.c_int64(len(fin)), _p(out))
         return out[:k]
 
+    # the pull-direction operators (advance.hxx:69-160), one call each
+    def bfs_gen_unvisited(self, labels, indices):
+        labels, indices = _i32(labels), _i32(indices)
+        out = np.zeros(max(len(indices), 1), dtype=np.int32)
+        k = self.lib.orc_bfs_gen_unvisited(_p(labels), _p(indices), C.c_int64(len(indices)), _p(out))
+        return out[:k]
+
+    def bfs_sparse_to_dense(self, labels, sparse, dense, iteration):
+        """writes dense[v] for the listed vertices only, in place (what the operator does)"""
+        labels, sparse = _i32(labels), _i32(sparse)
+        assert dense.dtype == np.int32 and dense.flags.c_contiguous
+        self.lib.orc_bfs_sparse_to_dense(_p(labels), _p(sparse), C.c_int64(len(sparse)), _p(dense), int(iteration))
+
+    def bfs_advance_backward(self, co, ri, labels, unvisited, bitmap, bitmap_out, iteration):
+        """one bottom-up step, in place on labels / unvisited (claimed slots become -1) / bitmap_out; returns the
+        in-edges inspected"""
+        co, ri, bitmap = _i32(co), _i32(ri), _i32(bitmap)
+        for a in (labels, unvisited, bitmap_out):
+            assert a.dtype == np.int32 and a.flags.c_contiguous
+        return self.lib.orc_bfs_advance_backward(_p(co), _p(ri), _p(labels), _p(unvisited), C.c_int64(len(unvisited)),
+                                                 _p(bitmap), _p(bitmap_out), int(iteration))
+
     def bfs_enact_pushpull(self, ro, ci, src, threshold, co=None, ri=None):
         ro, ci = _i32(ro), _i32(ci)
         co = ro if co is None else _i32(co)
@@ -169,6 +193,24 @@ class Oracle:
         lens = np.zeros(max(max_iter, 1), dtype=np.int64)
         it = self.lib.orc_pr_enact(n, _p(off), _p(idx), int(max_iter), _p(ranks, C.c_float), _p(lens, C.c_int64))
         return ranks, lens[:it]
+
+    # ---- k-core ----
+    def kcore_cpu(self, off, idx):
+        """kcore_problem_t::cpu: (core numbers, largest_k_core)"""
+        off, idx = _i32(off), _i32(idx)
+        n = len(off) - 1
+        cores = np.zeros(max(n, 1), dtype=np.int32)
+        largest = self.lib.orc_kcore_cpu(n, _p(off), _p(idx), _p(cores))
+        return cores[:n], largest
+
+    def kcore_enact(self, off, idx):
+        """kcore_enactor_t::enact over serial operators: (core numbers, largest_k_core, stats[4])"""
+        off, idx = _i32(off), _i32(idx)
+        n = len(off) - 1
+        cores = np.zeros(max(n, 1), dtype=np.int32)
+        stats = np.zeros(4, dtype=np.int64)
+        largest = self.lib.orc_kcore_enact(n, _p(off), _p(idx), _p(cores), _p(stats, C.c_int64))
+        return cores[:n], largest, stats
 
     # ---- RMAT spec ----
     def rmat_edges(self, scale, first, count, seed, scramble=True, weighted=True):

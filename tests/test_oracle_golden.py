@@ -28,6 +28,10 @@ def test_loader_and_cpu_validators_match_reference_goldens(oracle, case, tmp_pat
     preds, dist = oracle.sssp_cpu(ro, ci, w, src)                                      # sssp_problem.hxx:59-88
     assert matches(case, "sssp_preds", preds, np.int32)
     assert matches(case, "sssp_dist", dist, np.int32)
+    if "kcore_largest" in case:                                                        # kcore_problem.hxx:54-105
+        cores, largest = oracle.kcore_cpu(ro, ci)
+        assert largest == case["kcore_largest"]
+        assert matches(case, "kcore_num_cores", cores, np.int32)
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
@@ -114,3 +118,48 @@ def test_pr_restatement_first_iteration_is_a_pagerank_step(oracle):
     want = np.float32(0.15) + np.float32(0.85) * (np.float32(0.15) * deg) / deg
     assert np.allclose(ranks, want, rtol=1e-6)
     assert len(lens) == 1
+
+
+def _peel(ro, ci):
+    """textbook peeling on the multigraph the CSR holds (every entry counts, a self-loop once): core numbers"""
+    n = len(ro) - 1
+    deg = np.diff(ro).astype(np.int64)
+    core = np.zeros(n, dtype=np.int32)
+    alive = deg > 0
+    k = 1
+    while alive.any():
+        while True:
+            rm = np.where(alive & (deg < k))[0]
+            if len(rm) == 0:
+                break
+            core[rm] = k - 1
+            alive[rm] = False
+            for v in rm:
+                np.subtract.at(deg, ci[ro[v]:ro[v + 1]], 1)
+        k += 1
+    return core
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if "kcore_largest" in c], ids=lambda c: c["name"])
+def test_kcore_restatements_agree(oracle, case, tmp_path):
+    """the enactor loop over serial operators (kcore_enactor.hxx:40-86) ends with the validator's core numbers
+    (kcore_problem.hxx:54-105), and both are the textbook peeling of the loaded multigraph"""
+    n, ro, ci, w, _ = oracle.load_mtx(case_path(case, oracle, tmp_path, GOLD), undir=True)
+    cores, largest = oracle.kcore_cpu(ro, ci)
+    ecores, elargest, st = oracle.kcore_enact(ro, ci)
+    assert elargest == largest == case["kcore_largest"]
+    assert np.array_equal(ecores, cores)
+    assert st[0] == largest + 1 and st[3] == int((np.diff(ro) > 0).sum())   # every vertex with entries is removed once
+    assert st[2] == len(ci)                                                # ... and expands its row once
+    assert np.array_equal(cores, _peel(ro, ci))
+
+
+def test_kcore_quirk_on_a_graph_without_entries(oracle):
+    """cpu() answers 0 at k = 1 (nobody has degree >= 1); the enactor judges k = 1 by the count it started with (n) and
+    never finds a pass that removes something: it runs to k = n and leaves largest_k_core at -1 (kcore_enactor.hxx:77-81)"""
+    ro = np.zeros(6, dtype=np.int32)
+    ci = np.zeros(0, dtype=np.int32)
+    cores, largest = oracle.kcore_cpu(ro, ci)
+    assert largest == 0 and not cores.any()
+    ecores, elargest, st = oracle.kcore_enact(ro, ci)
+    assert elargest == -1 and not ecores.any() and st[0] == 5

@@ -4,6 +4,7 @@
 //   load_graph                 graph.hxx:96-223
 //   bfs_problem_t::cpu         bfs/bfs_problem.hxx:52-72
 //   sssp_problem_t::cpu        sssp/sssp_problem.hxx:59-88
+//   kcore_problem_t::cpu       kcore/kcore_problem.hxx:54-105   (undirected loads only: test_kcore.cu:24)
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -11,6 +12,7 @@
 
 #include "bfs/bfs_problem.hxx"
 #include "sssp/sssp_problem.hxx"
+#include "kcore/kcore_problem.hxx"
 
 using namespace gunrock;
 using namespace mgpu;
@@ -43,6 +45,14 @@ int main(int argc, char** argv) {
     sssp::sssp_problem_t sp(dg, src, ctx);
     sp.cpu(preds, g->csr->offsets, g->csr->indices, g->csr->edge_weights);
   }
+  std::vector<int> cores(g->num_nodes, 0);   // test_kcore.cu:36
+  int largest_k_core = -1;
+  {
+    kcore::kcore_problem_t kp(dg, ctx);
+    // degrees = CSR row lengths, what GetDegrees computes (problem.hxx:23-30); see the note in moderngpu/memory.hxx
+    for (int v = 0; v < g->num_nodes; ++v) kp.degrees[v] = g->csr->offsets[v + 1] - g->csr->offsets[v];
+    largest_k_core = kp.cpu(cores, g->csr->offsets, g->csr->indices);
+  }
   printf("{\"n\": %d, \"m\": %d, \"src\": %d, \"graph_t_undirected\": %d,\n", g->num_nodes, g->num_edges, src, (int)g->undirected);
   dump("offsets", g->csr->offsets, "%d");
   dump("indices", g->csr->indices, "%d");
@@ -51,6 +61,8 @@ int main(int argc, char** argv) {
   dump("csc_offsets", g->csc->offsets, "%d");
   dump("csc_indices", g->csc->indices, "%d");
   dump("bfs_labels", labels, "%d");
+  dump("kcore_num_cores", cores, "%d");
+  printf("\"kcore_largest\": %d,\n", largest_k_core);
   dump("sssp_preds", preds, "%d", true);
   printf("}\n");
   return 0;

@@ -11,6 +11,14 @@ struct mem_t {
   const T* data() const { return v.data(); }
   size_t size() const { return v.size(); }
   void swap(mem_t& r) { v.swap(r.v); }
+  // kcore_problem.hxx:44 hands a mem_t<int> to problem_t::GetDegrees(mem_t<float>&) (problem.hxx:23): upstream that only
+  // compiles against a moderngpu we do not have.  Here the call is let through as a view of the same 4-byte cells; what it
+  // writes (floats into int cells) is discarded -- the driver refills kcore_problem_t::degrees before it calls cpu().
+  template <class U>
+  operator mem_t<U>&() {
+    static_assert(sizeof(U) == sizeof(T), "view of equal-sized cells only");
+    return *reinterpret_cast<mem_t<U>*>(this);
+  }
 };
 template <class T>
 mem_t<T> to_mem(const std::vector<T>& h, context_t& c) {

@@ -67,6 +67,8 @@ def main():
              "graph_t_undirected": r["graph_t_undirected"], "offsets": r["offsets"], "indices": r["indices"],
              "weights": r["weights"], "csc_equals_csr": r["csc_offsets"] == r["offsets"] and r["csc_indices"] == r["indices"],
              "bfs_labels": r["bfs_labels"], "sssp_preds": r["sssp_preds"], "sssp_dist": dist_from_preds(r)}
+        if undir:                        # test_kcore.cu:24 loads undirected only
+            c["kcore_num_cores"], c["kcore_largest"] = r["kcore_num_cores"], r["kcore_largest"]
         cases.append(c)
     for name, scale, ef, seed, directed in GEN:
         text = rmat_simple_mtx_text(orc, scale, ef, seed, directed)
@@ -89,9 +91,14 @@ def main():
              "sssp_dist_sha256": sha(np.array(dist_from_preds(r), dtype=np.int32)),
              "bfs_reached": int((lab >= 0).sum()), "bfs_depth": int(lab.max()),
              "bfs_labels_head": r["bfs_labels"][:16], "sssp_preds_head": r["sssp_preds"][:16]}
+        if not directed:
+            c["kcore_num_cores_sha256"] = sha(np.array(r["kcore_num_cores"], dtype=np.int32))
+            c["kcore_largest"] = r["kcore_largest"]
+            c["kcore_num_cores_head"] = r["kcore_num_cores"][:16]
         cases.append(c)
-    prov = ("Outputs of the reference's OWN load_graph / bfs_problem_t::cpu / sssp_problem_t::cpu (gunrock/src/graph.hxx:96-223, "
-            "bfs/bfs_problem.hxx:52-72, sssp/sssp_problem.hxx:59-88), compiled from /root/reference where they lie by "
+    prov = ("Outputs of the reference's OWN load_graph / bfs_problem_t::cpu / sssp_problem_t::cpu / kcore_problem_t::cpu "
+            "(gunrock/src/graph.hxx:96-223, bfs/bfs_problem.hxx:52-72, sssp/sssp_problem.hxx:59-88, kcore/kcore_problem.hxx:54-105; "
+            "k-core on the undirected loads only, as test_kcore.cu:24 does), compiled from /root/reference where they lie by "
             "tools/regen_goldens.sh (g++; the three moderngpu includes are served by host stand-ins under tools/golden_ref/, "
             "own code) and run on (a) the reference's own test fixtures -- tests/golden/*.mtx are byte copies of "
             "gunrock/tests/{bfs,sssp,pr}/test.mtx and gunrock/tests/kcore/test_kcore.mtx; synthetic_dup.mtx is the "
