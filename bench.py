@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = the SAME RMAT-<scale> over N GPUs (the metric's RMAT-22 @1/2/4/8; --scale 26 "
                          "--gpus 8 is config 5); weak = RMAT-(scale + log2 N)")
+    ap.add_argument("--dist-timeout", type=float, default=900.0,
+                    help="N > 1: seconds the whole multi-rank run may take.  The self-launcher kills its child process group when "
+                         "they are up and exits 124 with a one-line reason; every rank also arms a watchdog of its own (a launch by "
+                         "torch.distributed.run has no parent of ours): a collective that never returns must not eat the caller's clock")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
@@ -92,23 +96,71 @@ def self_launch(args):
     env.setdefault("OMP_NUM_THREADS", "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    # fresh children in a process group (session) of their own: on expiry the GROUP is ended -- launcher and ranks --
+    # and nothing that has touched the GPU is ever re-executed
+    import signal
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return child.wait(timeout=args.dist_timeout if args.dist_timeout > 0 else None)
+    except subprocess.TimeoutExpired:
+        print("bench.py: the %d-rank run did not finish within --dist-timeout %.0f s (a collective or a rank hangs): "
+              "ending the child process group" % (args.gpus, args.dist_timeout), file=sys.stderr, flush=True)
+        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 10.0)):
+            try:
+                os.killpg(child.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return 124
+    except KeyboardInterrupt:
+        try:
+            os.killpg(child.pid, signal.SIGTERM)
+        except ProcessLookupError:
+            pass
+        raise
+
+
+def arm_watchdog(seconds, what):
+    """a rank's own deadline (daemon timer thread; library calls release the GIL): one line on stderr, then the process
+    ends with status 124 -- it does not try to unwind a collective that never returns"""
+    import threading
+
+    def expire():
+        print("bench.py: %s did not finish within %.0f s (--dist-timeout): exiting 124" % (what, seconds), file=sys.stderr, flush=True)
+        os._exit(124)
+    if seconds and seconds > 0:
+        t = threading.Timer(seconds, expire)
+        t.daemon = True
+        t.start()
+        return t
+    return None
 
 
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args))
-    if os.environ.get("MGX_BENCH_LAUNCH_ONLY") == "1":      # (CPU test of the launch contract: who was started, nothing else)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and os.environ.get("MGX_BENCH_WATCHDOG_OFF") != "1":
+        # (a little under the self-launcher's limit, so that a rank's own one-line reason is what the caller reads)
+        arm_watchdog(max(args.dist_timeout - 15.0, 0.9 * args.dist_timeout), "rank %d of %d" % (rank, world))
+    launch_only = os.environ.get("MGX_BENCH_LAUNCH_ONLY")
+    if launch_only:      # (CPU tests of the launch contract: who was started, nothing else; "hang": a rank that never returns)
         print("launched rank %s of %s (--gpus %d)" % (os.environ.get("RANK"), os.environ.get("WORLD_SIZE"), args.gpus), flush=True)
+        if launch_only == "hang" and (rank == 1 or os.environ.get("MGX_BENCH_HANG_ALL") == "1"):
+            while True:
+                time.sleep(3600)
         return
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         args.gpus = world
     # Pre-flight switches for a one-GPU box (never a reported number): MGX_BENCH_ALL_ON_GPU0=1 puts every rank on

@@ -267,24 +267,35 @@ struct bfs_fused_enactor_t {
   // `count` traversals enqueued back to back, one host wait (mgx::bfs_fused_run_many): out[i] = the counters of source
   // srcs[i]; the labels are those of the LAST source when the call returns.  Returns how many traversals had to be run
   // again on their own (they did not finish within the slots the batch gave them).
-  char* many_heads = nullptr;       // pinned
+  // A batch is submitted in chunks of at most MANY_CHUNK sources -- one enqueue, one host wait and one pinned block of heads
+  // per chunk, reused -- so that a long source list neither pins count x ~1 KB of host memory nor queues millions of launches
+  // behind one wait (a traversal is ~2 * slots + 4 launches).  A chunk of 512 traversals is ~170 ms of device work on
+  // RMAT-22: the extra host wait per chunk (~10 us) does not show.
+  static constexpr int MANY_CHUNK = 512;
+  char* many_heads = nullptr;       // pinned, MANY_CHUNK heads at most
   int many_cap = 0;
   int enact_many(std::shared_ptr<bfs_problem_t> bfs_problem, standard_context_t& context, const int* srcs, int count,
                  std::vector<bfs_run_stats_t>& out, bool direction_optimizing = false, float alpha = 0.f) {
     auto& g = *bfs_problem->gslice;
     mgx::bfs_layout_t layout = layout_of(g);
     const bool use_layout = g.has_layout && (!direction_optimizing || g.csc_is_csr);
-    if (count > many_cap) {
+    const int want = count < MANY_CHUNK ? count : MANY_CHUNK;
+    if (want > many_cap) {
       if (many_heads) (void)hipHostFree(many_heads);
       many_heads = nullptr;
-      MGX_HIP(hipHostMalloc((void**)&many_heads, (size_t)count * mgx::bfs_many_head_bytes(), hipHostMallocDefault));
-      many_cap = count;
+      many_cap = 0;
+      MGX_HIP(hipHostMalloc((void**)&many_heads, (size_t)want * mgx::bfs_many_head_bytes(), hipHostMallocDefault));
+      many_cap = want;
     }
-    const int reruns = mgx::bfs_fused_run_many(*fused, g.d_row_offsets.data(), g.d_col_indices.data(), bfs_problem->d_labels.data(), srcs,
-                                               count, context, many_heads, use_layout ? &layout : nullptr, direction_optimizing ? 1 : 0,
-                                               alpha, g.d_col_offsets.data(), g.d_row_indices.data());
-    out.assign((size_t)count, bfs_run_stats_t());
-    for (int i = 0; i < count; ++i) fill_stats(out[(size_t)i], mgx::bfs_many_head(many_heads, i), direction_optimizing, false);
+    out.assign((size_t)(count > 0 ? count : 0), bfs_run_stats_t());
+    int reruns = 0;
+    for (int first = 0; first < count; first += MANY_CHUNK) {
+      const int part = count - first < MANY_CHUNK ? count - first : MANY_CHUNK;
+      reruns += mgx::bfs_fused_run_many(*fused, g.d_row_offsets.data(), g.d_col_indices.data(), bfs_problem->d_labels.data(), srcs + first,
+                                        part, context, many_heads, use_layout ? &layout : nullptr, direction_optimizing ? 1 : 0,
+                                        alpha, g.d_col_offsets.data(), g.d_row_indices.data());
+      for (int i = 0; i < part; ++i) fill_stats(out[(size_t)(first + i)], mgx::bfs_many_head(many_heads, i), direction_optimizing, false);
+    }
     if (count > 0) { last = out.back(); bfs_problem->src = srcs[count - 1]; }
     return reruns;
   }

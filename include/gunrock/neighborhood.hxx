@@ -42,6 +42,7 @@ int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fronti
   // degree classes: mgx/nreduce.hpp.  Whether the frontier IS the iota is checked on the device (one pass over it);
   // it then holds every edge of the graph: no degree scan, no search.
   typename Problem::data_slice_t* const data = problem->d_data_slice.data();
+  if constexpr (sizeof(Value) == 4)     // (the kernel keeps 40 000 4-byte values in the 160 KB of LDS: wider values take the general path)
   if (!has_output && is_pure_gather<Functor>::value && frontier_size == (long long)graph.num_nodes && frontier_size > 0 &&
       graph.has_layout && (push || graph.csc_is_csr) && graph.ub_units > 0 && graph.ub_min_degree == 64 && graph.vs_long_min == 64 &&
       graph.d_ub_cnt.size() && graph.d_ub_first.size() && graph.vs_dummy != 0 &&

@@ -368,6 +368,9 @@ MGX_API int mgx_dbfs2_set_list(mgx_dbfs2_t h, unsigned* d_list, int64_t words);
 MGX_API int mgx_dbfs2_apply_lists(mgx_dbfs2_t h, int level, const unsigned* d_lists, int lists, int64_t stride_words, int64_t* out3);
 MGX_API int mgx_dbfs2_status(mgx_dbfs2_t h, int next_level, int64_t* out6);
 MGX_API int mgx_dbfs2_labels(mgx_dbfs2_t h, int* host_labels_local);
+/* this rank's copy of the visited bitmap over ALL vertices (mgx_dbfs2_words words, bit v = vertex v in hub-first global ids):
+ * after a traversal every rank holds the same one -- what the tests check */
+MGX_API int mgx_dbfs2_visited(mgx_dbfs2_t h, unsigned* host_words);
 
 /* ---- the partitioned traversal driven from C++ over RCCL (include/mgx/comm.hpp, bfs_dist2.hpp: d2_run) ----
  * A communicator of the library's own: rank 0 calls mgx_comm_unique_id, the 128 bytes travel to the other ranks by any

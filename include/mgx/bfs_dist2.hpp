@@ -168,12 +168,13 @@ __global__ __launch_bounds__(BLOCK) void k_d2_or_maps(const uint4* __restrict__ 
 // decided once by atomicOr on the bitmap -- the same id may come from several ranks -- and, if this rank owns it
 // (v % ranks == rank), labelled and appended to the next level's queues: one block scan per queue and ONE packed cursor
 // atomic per workgroup and round, as in k_bfs_build.  host_flag (pinned): [1] overflow, [2] sum of the counts (0: the level
-// found nothing anywhere -- the traversal is over), then [0] = seq, which the host spins on.  *mylist_count <- 0 for the
-// next level's sweep.
+// found nothing anywhere -- the traversal is over), then [0] = seq, which the host spins on.  The kernel does NOT reset the
+// header of this rank's own list for the next level's sweep: on a one-rank run `glists` IS that list, and a workgroup that
+// starts after the reset would read a count of 0 and drop its share of the ids (there is no grid-wide barrier between the
+// reads and such a store) -- d2_apply_lists clears it behind the kernel instead.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_d2_lists_apply(bfs_fused_args_t a, int level, const u32* __restrict__ glists, int nlists, u32 stride,
-                                                       u32 cap, int* __restrict__ labels, int ranks, int rank, u32* mylist_count,
-                                                       u64* host_flag, u64 seq) {
+                                                       u32 cap, int* __restrict__ labels, int ranks, int rank, u64* host_flag, u64 seq) {
   constexpr int NW = NT / WAVE;
   constexpr u64 CNT1 = 1ull << 40;
   constexpr u64 DEGMASK = CNT1 - 1ull;
@@ -199,7 +200,6 @@ __global__ __launch_bounds__(NT) void k_d2_lists_apply(bfs_fused_args_t a, int l
   const u32 T = s_pre[nlists];
   const bool over = s_over != 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (mylist_count) *mylist_count = 0;
     if (host_flag) {
       host_flag[1] = over ? 1ull : 0ull;
       host_flag[2] = (u64)T;
@@ -436,8 +436,10 @@ inline void d2_apply_lists(d2_state_t& st, int level, const u32* glists, int nli
   bfs_fused_args_t a = st.args();
   const u64 seq = ++st.flag_seq;
   hipLaunchKernelGGL(k_d2_lists_apply<BLOCK>, dim3(256), dim3(BLOCK), 0, s, a, level, glists, nlists, (u32)stride_words, st.list_cap,
-                     st.labels.data(), st.ranks, st.rank, st.mylist, st.host_flag, seq);
+                     st.labels.data(), st.ranks, st.rank, st.host_flag, seq);
   MGX_CHECK_LAUNCH("partitioned BFS: list merge launch");
+  // the count of this rank's own list, for the next level's sweep: behind the kernel, never inside it (see the kernel's header)
+  if (st.mylist) MGX_HIP(hipMemsetAsync(st.mylist, 0, sizeof(u32), s));
   volatile u64* const flag = st.host_flag;
   long long spins = 0;
   while (flag[0] != seq) {

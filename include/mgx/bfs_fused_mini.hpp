@@ -221,7 +221,12 @@ __global__ __launch_bounds__(NT) void k_bfs_mini(bfs_fused_args_t a, int arg) {
       }
       visit(act, d);
       __syncthreads();
-      if (s_cnt > BFS_MINI_WCAP - NT) flush();             // (block-uniform: s_cnt is stable between the barriers)
+      // ONE snapshot of the count decides for the whole workgroup: without the second barrier a fast wave could pass the test,
+      // run into the next visit() and push s_cnt over the limit before a slow wave has looked -- the waves would then disagree
+      // about entering flush(), whose barriers and block scans must pair
+      const int cnt_now = s_cnt;
+      __syncthreads();
+      if (cnt_now > BFS_MINI_WCAP - NT) flush();
     }
   }
   // ---- short rows: one row per thread, edge k of every row in step k -----------------------------------------------------
@@ -248,7 +253,9 @@ __global__ __launch_bounds__(NT) void k_bfs_mini(bfs_fused_args_t a, int arg) {
         const u32 d = act ? (u32)a.col_indices[row + k] : 0u;
         visit(act, d);
         __syncthreads();
-        if (s_cnt > BFS_MINI_WCAP - NT) flush();
+        const int cnt_now = s_cnt;                          // (one snapshot, as above)
+        __syncthreads();
+        if (cnt_now > BFS_MINI_WCAP - NT) flush();
       }
       __syncthreads();
       if (threadIdx.x == 0) s_maxdeg = 0;

@@ -254,6 +254,7 @@ __device__ __forceinline__ void nr_short_work(const nr_layout_t& L, const V* __r
 template <typename V, typename Op, int NT, int HOTV = NR_HOTV, int WPE = 4>
 __global__ __launch_bounds__(NT, WPE) void k_nr_edges(nr_layout_t L, const V* __restrict__ vals, V* __restrict__ partial, V* __restrict__ reduced,
                                                     V identity, Op op, const u32* dev_flag, u32 epoch) {
+  static_assert(sizeof(V) == 4, "k_nr_edges keeps HOTV 4-byte values in LDS (nr_lds_bytes): size both by sizeof(V) before adding an 8-byte value type");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (*dev_flag == epoch) return;                    // (grid-uniform)
   const u32 hot_n = (u32)L.n < (u32)HOTV ? (u32)L.n : (u32)HOTV;
@@ -274,6 +275,7 @@ inline size_t nr_scratch_bytes(long long n, long long units_pad, size_t value_si
 template <typename V, typename Op, typename GetValue>
 inline void nr_full_frontier(const nr_layout_t& L, GetValue get, V* reduced, V identity, Op op, standard_context_t& ctx, const int* frontier,
                              long long* host_flag, u32* dev_flag, u32 epoch) {
+  static_assert(sizeof(V) == 4, "the full-frontier neighbour-reduce is instantiated for 4-byte values only (neighborhood.hxx gates on it)");
   hipStream_t s = ctx.stream();
   V* const vals = (V*)ctx.scratch;
   V* const partial = (V*)((char*)ctx.scratch + (((size_t)L.n + 64) * sizeof(V) + 255) / 256 * 256);

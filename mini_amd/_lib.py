@@ -162,6 +162,7 @@ SIGNATURES = {
     "mgx_dbfs2_merge_maps": [_vp, _i, _vp, _i, _i64],
     "mgx_dbfs2_or_maps": [_vp, _vp, _i, _i64, _i64, _vp],
     "mgx_dbfs2_labels": [_vp, _vp],
+    "mgx_dbfs2_visited": [_vp, _vp],
     "mgx_sssp_create": [_vp, _i, _pvp],
     "mgx_sssp_reset": [_vp, _i],
     "mgx_sssp_free": [_vp],

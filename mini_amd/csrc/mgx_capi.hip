@@ -1589,6 +1589,14 @@ int mgx_dbfs2_labels(mgx_dbfs2_t h, int* host_labels_local) {
   MGX_HIP(mgx::dtoh(host_labels_local, h->st.labels.data(), (size_t)h->st.n_local));
   MGX_CATCH
 }
+int mgx_dbfs2_visited(mgx_dbfs2_t h, unsigned* host_words) {
+  MGX_TRY
+  MGX_REQUIRE(h && host_words, "NULL argument");
+  use_device(h->c);
+  h->c->ctx->synchronize();
+  MGX_HIP(mgx::dtoh(host_words, h->st.fs->visited.data(), (size_t)h->st.nwords));
+  MGX_CATCH
+}
 
 // ---- SSSP ----------------------------------------------------------------------------------
 static void check_weights(mgx_graph_t g) {

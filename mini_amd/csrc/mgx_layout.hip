@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_reduce.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
 
@@ -544,8 +545,16 @@ extern "C" int mgx_shard_plan_device(int scale, int edgefactor, unsigned long lo
   SHARD_TRY(rocprim::exclusive_scan(nullptr, sb, ldeg.as<int>(), P->ro_local.as<int>(), 0, (size_t)P->n_local + 1, rocprim::plus<int>(), stream));
   SHARD_TRY(st.alloc(sb));
   SHARD_TRY(rocprim::exclusive_scan(st.p, sb, ldeg.as<int>(), P->ro_local.as<int>(), 0, (size_t)P->n_local + 1, rocprim::plus<int>(), stream));
-  int last = 0;
-  SHARD_TRY(hipMemcpyAsync(&last, P->ro_local.as<int>() + P->n_local, 4, hipMemcpyDeviceToHost, stream));
+  // the shard's entry count in 64 bits: the int32 scan above wraps for a shard of 2^31 entries or more, and a wrapped (negative
+  // or small) total would pass the caller's range check and come back as an empty or truncated shard
+  tmp_t total64, rt;
+  SHARD_TRY(total64.alloc(8));
+  size_t rb = 0;
+  SHARD_TRY(rocprim::reduce(nullptr, rb, ldeg.as<int>(), total64.as<long long>(), 0ll, (size_t)P->n_local, rocprim::plus<long long>(), stream));
+  SHARD_TRY(rt.alloc(rb));
+  SHARD_TRY(rocprim::reduce(rt.p, rb, ldeg.as<int>(), total64.as<long long>(), 0ll, (size_t)P->n_local, rocprim::plus<long long>(), stream));
+  long long last = 0;
+  SHARD_TRY(hipMemcpyAsync(&last, total64.p, 8, hipMemcpyDeviceToHost, stream));
   SHARD_TRY(hipStreamSynchronize(stream));
   P->m_local = last;
   *handle = P; *n_local = P->n_local; *m_local = P->m_local;

@@ -265,6 +265,12 @@ class HipRankEngine2:
         check(lib.mgx_dbfs2_labels(self._h, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def visited(self):
+        """this rank's copy of the visited bitmap over all vertices (uint32 words; bit v = vertex v, hub-first global ids)"""
+        out = np.empty(self.nwords, dtype=np.uint32)
+        check(lib.mgx_dbfs2_visited(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def close(self):
         if self._h:
             lib.mgx_dbfs2_free(self._h)
@@ -422,7 +428,7 @@ class DistBfs2:
         if getattr(e, "list", None) is not None:
             # one level per round: the id lists first; the bitmaps only when some rank's discoveries did not fit its list
             # (every rank reads the same headers, so all take the same branch); a level whose lists are all empty ends it
-            self.sparse_levels = self.dense_levels = 0
+            self.sparse_levels = self.dense_levels = self.max_sparse_total = 0
             while True:
                 new = e.push(level)
                 overflow, total = e.apply_lists(level, *self._gather_lists(e.list))
@@ -434,6 +440,7 @@ class DistBfs2:
                     self.dense_levels += 1
                 else:
                     self.sparse_levels += 1
+                    self.max_sparse_total = max(self.max_sparse_total, int(total))
             st = e.status(level)
             self.levels = st["levels"]
             return {"levels": st["levels"], "edges_local": st["edges_local"]}

@@ -89,10 +89,11 @@ def _worker2(rank, world, port, use_gpu, scale, seed, sources, q):
     bfs = DistBfs2(eng, rank, world, "cpu")
     ok = True
     deg = np.diff(ro)
-    sparse = dense = unit_levels = cold_levels = 0
+    sparse = dense = unit_levels = cold_levels = big_sparse = 0
     for src in sources:
         st = bfs.run(int(new_of_old[src]))
         sparse += bfs.sparse_levels
+        big_sparse = max(big_sparse, getattr(bfs, "max_sparse_total", 0))
         dense += bfs.dense_levels
         if use_gpu:
             unit_levels += eng.dense_levels()
@@ -118,6 +119,9 @@ def _worker2(rank, world, port, use_gpu, scale, seed, sources, q):
         ok = ok and sparse > 0 and (dense > 0 or scale < 11)
     else:
         ok = ok and sparse == 0
+    if os.environ.get("MGX_TEST_EXPECT_BIG_SPARSE") is not None:
+        # a sparse level whose ids need more than one workgroup round of k_d2_lists_apply (256 threads x 256 workgroups walk them)
+        ok = ok and big_sparse > int(os.environ["MGX_TEST_EXPECT_BIG_SPARSE"])
     if use_gpu and os.environ.get("MGX_TEST_EXPECT_UNIT_LEVELS") is not None:
         # levels whose long rows were read from the rank's unit blocks (rank 0 answers for the job: it holds the first hub)
         ok = ok and ((unit_levels > 0) == (os.environ["MGX_TEST_EXPECT_UNIT_LEVELS"] == "1")) and ((eng.units > 0) == (os.environ.get("MGX_DIST_UNITS", "1") != "0"))
@@ -129,11 +133,13 @@ def _worker2(rank, world, port, use_gpu, scale, seed, sources, q):
     dist.destroy_process_group()
 
 
-def _run(world, use_gpu, scale, seed, worker=None):
+def _run(world, use_gpu, scale, seed, worker=None, pick_sources=None):
     from tests.oracle_binding import Oracle
     n, ro, ci, _ = Oracle().rmat_csr(scale, 16, seed)
     deg = np.diff(ro)
     sources = [int(np.argmax(deg)), int(np.where(deg > 0)[0][-1]), int(np.where(deg == 0)[0][0])]
+    if pick_sources is not None:
+        sources = pick_sources(deg)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -234,6 +240,27 @@ def test_partitioned_ranks_cold_edge_pass(built, world, scale, dense_div, cold, 
     if expect_cold is not None:
         monkeypatch.setenv("MGX_TEST_EXPECT_COLD_LEVELS", expect_cold)
     _run(world, True, scale, scale + 3, _worker2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_sparse_level_with_more_ids_than_one_workgroup_round(built, world, monkeypatch):
+    """on a one-rank run the gathered lists ARE the rank's own list; k_d2_lists_apply used to reset that
+    list's count from workgroup 0 while later workgroups still had to read it -- a sparse level of more than 256 ids could lose
+    vertices.  Sources of a few hundred neighbours on R-MAT 18 (list capacity 1024 / ranks): their first level is such a level."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    monkeypatch.setenv("MGX_DIST_EXCHANGE", "gather")
+    monkeypatch.setenv("MGX_DIST_LISTS", "1")
+    monkeypatch.setenv("MGX_TEST_EXPECT_BIG_SPARSE", "256")
+
+    def pick(deg):
+        lo, hi = 400, 900               # ~380-850 distinct neighbours: fits a rank's list (1024 / world ids), > 256 in all
+        ids = np.where((deg >= lo) & (deg <= hi))[0]
+        assert len(ids) >= 4
+        return [int(v) for v in ids[:: max(1, len(ids) // 6)][:6]]
+    for _ in range(2):                                   # (a scheduling race: more than one go)
+        _run(world, True, 18, 58, _worker2, pick_sources=pick)
 
 
 @pytest.mark.gpu
@@ -375,6 +402,36 @@ def test_bench_self_launch_starts_one_rank_per_gpu():
     assert seen == ["0", "1", "2"], p.stdout + p.stderr
 
 
+def _bench_hang(extra_env, dist_timeout):
+    import subprocess
+    import sys
+    import time as _t
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["MGX_BENCH_LAUNCH_ONLY"] = "hang"
+    env.update(extra_env)
+    t0 = _t.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--dist-timeout", str(dist_timeout)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    return p, _t.time() - t0
+
+
+def test_bench_rank_watchdog_ends_a_hung_rank():
+    """first contact with 8 GPUs must not eat the caller's clock: a rank that never returns is
+    ended by its OWN watchdog a little before --dist-timeout -- one line of reason, status 124 -- and the launcher, seeing
+    a failed rank, takes the others down; the self-launcher passes the failure on"""
+    p, took = _bench_hang({}, 40)
+    assert p.returncode != 0 and took < 150, (p.returncode, took)
+    assert "did not finish within" in p.stderr and "rank 1 of 2" in p.stderr, p.stderr[-3000:]
+
+
+def test_bench_self_launch_ends_the_child_group_on_timeout():
+    """... and when even the watchdogs do not fire in time (here: every rank hangs and the limit is shorter than the
+    ranks' own margin), the self-launcher ends the whole child process group and exits 124 with its own one-line reason"""
+    p, took = _bench_hang({"MGX_BENCH_HANG_ALL": "1", "MGX_BENCH_WATCHDOG_OFF": "1"}, 12)
+    assert p.returncode == 124 and took < 90, (p.returncode, took, p.stderr[-2000:])
+    assert "ending the child process group" in p.stderr
+
+
 @pytest.mark.gpu
 def test_bench_plain_command_runs_n_ranks(built):
     """the same on the GPU box, end to end: `python bench.py --gpus 2` (no torchrun) prints ONE line with n_gpus = 2 and
@@ -435,6 +492,20 @@ def test_bench_main_preflight_ranks_share_one_gpu(built, world, extra, env_extra
         assert "oracle" in j["parity_check"]
         if "--no-cpu-baseline" not in extra:
             assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_main_carries_config5_next_to_the_strong_line(built):
+    """at N = 8 the default line (strong RMAT-22) also carries `config5`: the same measurement on RMAT-26.  Pre-flight with
+    two ranks on the one GPU over gloo and the branch forced (MGX_BENCH_CONFIG5=1), the second graph big enough (scale 24)
+    to take the BFS-tree check of the sizes the oracle does not see"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    j = _bench_preflight(2, ["--scale", "15", "--no-cpu-baseline"], {"MGX_BENCH_CONFIG5": "1", "MGX_BENCH_CONFIG5_SCALE": "24"})
+    assert j["n_gpus"] == 2 and j["config"]["scale"] == 15 and j["parity_vs_oracle"] is True
+    c5 = j["config5"]
+    assert c5["parity"] is True and "BFS-tree" in c5["parity_check"] and c5["value"] > 0 and c5["steps"] == 3
+    assert "scale 24" in c5["workload"]
 
 
 @pytest.mark.gpu

@@ -6,7 +6,10 @@
             names for soc-LiveJournal: R-MAT without symmetrisation), alpha in {1/n, .01, .05, .1, 1}: oracle at scale
             16, size-independent BFS-tree properties at scale 20 and 22; the real file through mgx_load_mtx when
             MGX_DATA_DIR holds it
-  config 5  (8 GPUs) is covered by tests/test_dist.py (gloo, CPU) and the bench's own parity check.
+  config 5  BFS on RMAT-26 ef 16 partitioned over 8 ranks: the 8 shards built by the library (mgx_dbfs2_shard_*), the 8
+            rank engines run in turn on the ONE GPU of the test box (the exchange a concatenation): BFS-tree properties on
+            every rank's rows, every rank's bitmap equal; RMAT-23 over 4 ranks the same way with labels equal to the
+            single-GPU traversal and the oracle.  The message passing itself: tests/test_dist.py (gloo worlds).
 """
 import os
 
@@ -296,3 +299,108 @@ def test_real_dataset_if_supplied(gpu_ctx, oracle, torch_mod):
     for a in ALPHAS:
         bfs.run(src, mode=mini_amd.MGX_BFS_DIRECTION_OPT, alpha=_alpha(a, n))
         assert np.array_equal(bfs.labels(), want), a
+
+
+# ---- config 5: the partitioned engine at its named size, G rank engines in turn on one GPU ---------------------------
+def _rank_engines(ctx, torch, scale, ranks, seed):
+    from mini_amd.dist_bfs import HipRankEngine2, rmat_cyclic_shard
+    dev = torch.device("cuda", 0)
+    engs, shards = [], []
+    for r in range(ranks):
+        ro, col, new_of_old, old_of_new, deg_new = rmat_cyclic_shard(ctx, scale, 16, seed, ranks, r, dev)
+        engs.append(HipRankEngine2(ctx, 1 << scale, ranks, r, ro, col))
+        shards.append((ro, col))
+    return engs, shards, new_of_old, old_of_new, deg_new
+
+
+def _run_rank_engines(torch, engs, src, hint=8):
+    """what tools/dist2_single.py does: every level's push on every rank, the all-gather of the new-bit maps as a
+    concatenation, every rank merges all maps; the host looks after `hint` levels, then every two"""
+    G = len(engs)
+    for e in engs:
+        e.reset(src)
+    level, batch = 0, hint
+    while True:
+        for _ in range(batch):
+            gathered = torch.cat([e.push(level) for e in engs]) if G > 1 else engs[0].push(level)
+            for e in engs:
+                e.merge(level, gathered, G)
+            level += 1
+        sts = [e.status(level) for e in engs]
+        if sts[0]["over"]:
+            return sts
+        batch = 2
+
+
+def _gathered_labels(engs, n):
+    G = len(engs)
+    lab = np.empty(n, dtype=np.int32)
+    for r, e in enumerate(engs):
+        lab[r::G] = e.labels()                        # vertex v = local row * G + rank
+    return lab
+
+
+def _check_partitioned_traversal(torch, engs, shards, deg_new, src, sts):
+    from bench_dist import _tree_check_local
+    G, n = len(engs), engs[0].n_global
+    assert all(st["over"] for st in sts) and len({st["levels"] for st in sts}) == 1
+    lab = _gathered_labels(engs, n)
+    reached = lab >= 0
+    assert lab[src] == 0 and int(lab.max()) + 1 == sts[0]["levels"]
+    # the edges the ranks expanded: every entry of every reached vertex's row, once
+    assert sum(st["edges_local"] for st in sts) == int(deg_new.cpu().numpy()[reached].sum())
+    # every rank ends with the same visited bitmap, and it is the reached set
+    want_bits = np.packbits(reached, bitorder="little")
+    want_words = np.zeros(engs[0].nwords, dtype=np.uint32)
+    want_words.view(np.uint8)[: len(want_bits)] = want_bits
+    for e in engs:
+        assert np.array_equal(e.visited(), want_words), "rank %d's bitmap differs from the reached set" % e.rank
+    # BFS-tree properties over every rank's own rows (the graph is symmetric: a row lists all neighbours)
+    lab_dev = torch.from_numpy(lab).cuda()
+    for r, (ro, col) in enumerate(shards):
+        assert _tree_check_local(lab_dev, ro, col, G, r, src), "rank %d: BFS-tree properties violated" % r
+    return lab
+
+
+def test_config5_rmat26_eight_rank_engines(gpu_ctx, torch_mod):
+    """BASELINE config 5's workload: RMAT-26 ef 16 (n = 67 108 864, 2 147 483 648 entries), cyclic partition over 8 ranks"""
+    torch = torch_mod
+    scale, G = 26, 8
+    engs, shards, new_of_old, old_of_new, deg_new = _rank_engines(gpu_ctx, torch, scale, G, scale)
+    assert sum(int(ro[-1]) for ro, _ in shards) == 2 * 16 * (1 << scale)          # 64-bit global count, int32 per rank
+    assert all(e.units > 0 for e in engs) and all(e.cold_levels()[1] > 0 for e in engs)   # unit blocks + cold-edge lists per rank
+    cand = torch.nonzero(deg_new > 0)[:, 0]
+    srcs = [int(cand[0]), int(cand[len(cand) // 3]), int(cand[-1])]       # the biggest hub, a middling vertex, a leaf
+    for src in srcs:
+        sts = _run_rank_engines(torch, engs, src)
+        lab = _check_partitioned_traversal(torch, engs, shards, deg_new, src, sts)
+        assert (lab >= 0).sum() > (1 << scale) // 3                       # the giant component
+    for e in engs:
+        e.close()
+
+
+def test_config5_shape_rmat23_four_rank_engines_vs_single_gpu_and_oracle(gpu_ctx, oracle, torch_mod):
+    """the same engine at a size the single-GPU path and the oracle can check vertex by vertex"""
+    import mini_amd
+    from mini_amd import rmat
+    torch = torch_mod
+    scale, G = 23, 4
+    engs, shards, new_of_old, old_of_new, deg_new = _rank_engines(gpu_ctx, torch, scale, G, scale)
+    g = rmat.rmat_csr(gpu_ctx, scale, 16, seed=scale)
+    graph = mini_amd.Graph.from_device(gpu_ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"]).build_layout()
+    o2n = old_of_new.cpu().numpy()
+    cand = torch.nonzero(deg_new > 0)[:, 0]
+    bfs = None
+    for i, src in enumerate((int(cand[1]), int(cand[len(cand) // 2]))):
+        sts = _run_rank_engines(torch, engs, src)
+        lab_new = _check_partitioned_traversal(torch, engs, shards, deg_new, src, sts)
+        src_old = int(o2n[src])
+        bfs = bfs or mini_amd.BfsProblem(graph, src_old)
+        bfs.run(src_old)
+        single = bfs.labels()
+        assert np.array_equal(lab_new[new_of_old.cpu().numpy()], single)
+        if i == 0:
+            want = oracle.bfs_cpu(g["row_offsets"].cpu().numpy(), g["col_indices"].cpu().numpy(), src_old)
+            assert np.array_equal(single, want)
+    for e in engs:
+        e.close()

@@ -911,6 +911,25 @@ def test_bfs_run_many_equals_one_call_per_source(gpu_ctx, oracle, layout):
         assert sts == []
 
 
+def test_bfs_run_many_longer_than_one_chunk(gpu_ctx, oracle):
+    """a long source list is submitted in chunks of 512 traversals (one pinned block of heads, one host wait
+    each): 1100 sources = three chunks; every traversal's counters and the last source's labels as with one call per source"""
+    import mini_amd
+    n, ro, ci, w = oracle.rmat_csr(11, 8, 77)
+    g = _graph(gpu_ctx, ro, ci)
+    g.build_layout()
+    rng = np.random.default_rng(3)
+    uniq = [int(v) for v in rng.choice(n, size=40, replace=False)]
+    bfs = mini_amd.BfsProblem(g, uniq[0])
+    solo = {s: bfs.run(s) for s in uniq}
+    batch = [uniq[int(i)] for i in rng.integers(0, len(uniq), size=1100)]
+    sts, _ = bfs.run_many(batch, mini_amd.MGX_BFS_PUSH, 0.0)
+    assert len(sts) == len(batch)
+    for s, st in zip(batch, sts):
+        assert (st["m_t"], st["reached"], st["levels"]) == (solo[s]["m_t"], solo[s]["reached"], solo[s]["levels"]), s
+    assert np.array_equal(bfs.labels(), oracle.bfs_cpu(ro, ci, batch[-1]))
+
+
 def test_bfs_run_many_reruns_a_traversal_that_needs_more_slots(gpu_ctx, oracle, monkeypatch):
     """a batch is sized by the launch slots the previous traversals needed: a source whose traversal has many more big
     levels (here: the end of a 40-vertex path next to a star of diameter 2, chains of small levels switched off so that every
