@@ -175,7 +175,7 @@ struct bfs_fused_args_t {
   int ss_dmax;             // the largest short degree (long_min - 1)
   int combine;             // merged push launch: a slot that takes both dense paths runs them in the same workgroups
   int interleave;          // merged push launch: even workgroups take the long rows, odd ones the short rows (instead of first half / second half)
-  int build_diag;          // measurements only (MGX_BFS_BUILD_DIAG; results wrong): 1 no label stores, 2 no extent gathers, 4 no cursor atomics
+  int build_diag;          // measurements only (MGX_BFS_BUILD_DIAG; results wrong): 1 no label stores, 2 no extent gathers, 4 no cursor atomics, 8 no queue stores, 16 synthetic extents, 32 / 64 no OR of the deferred / the cold pass's bitmaps
   int dense_diag;          // measurements only (MGX_BFS_DENSE_DIAG): 1 the unit-block body stores no marks, 2 tests nothing
   const int* colds_owner;  // cold-edge lists of the SHORT rows (the entries the vertex-by-vertex body would mark; measured equal); NULL: none
   const int* colds_dst;
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 4) void k_bfs_build(bfs_fused_a
   // ---- deferred hot marks of the slot: the flush buffers' bits for this workgroup's runs (see bfs_hot_epilogue) -------
   u32 flushed16 = 0;
   if (FROM_MARKS && a.flush_buf) {
-    const u32 F = c->flush_count[slot & 1];
+    const u32 F = (MGX_LAB_GET(a, build_diag, 0) & 32) ? 0u : c->flush_count[slot & 1];     // (lab builds, 32: the OR of the flushed bitmaps skipped)
     if (F) {                                                     // (grid-uniform)
       __shared__ u32 s_or[NW][WAVE];
       const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
   // the OR of a level that deferred in 512 workgroups took 10 us of its build).
   u32 flushed16 = 0;
   if (!DIST && a.flush_buf) {
-    const u32 F = c->flush_count[slot & 1];
+    const u32 F = (MGX_LAB_GET(a, build_diag, 0) & 32) ? 0u : c->flush_count[slot & 1];     // (lab builds, 32: the OR of the flushed bitmaps skipped)
     if (F) {                                                     // (grid-uniform)
       for (int hr = 0; hr < NW; ++hr) {
         const long long run = (long long)blockIdx.x + (long long)hr * gridDim.x;
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
   // the same for the bitmaps of the slot's cold-edge pass (bfs_fused_cold.hpp): cold workgroup k of slice s wrote what it
   // discovered in [cold_lo[s], + BFS_COLD_WORDS * 32) into buffer k.  Wave w takes the workgroup's run w: 16-byte loads,
   // eight lanes per buffer (a run is 128 bytes of bitmap), eight buffers per instruction, everything in flight at once.
-  if (!DIST && a.cold_dst && c->cold_slot == slot) {                 // (grid-uniform)
+  if (!DIST && a.cold_dst && c->cold_slot == slot && !(MGX_LAB_GET(a, build_diag, 0) & 64)) {                 // (grid-uniform; lab builds, 64: skipped)
     static_assert(NW == 8, "one wave per run");
     u32* const s_run = &s_or[0][0];                                  // [NW][32] words
     const long long run = (long long)blockIdx.x + (long long)wave * gridDim.x;

@@ -116,12 +116,19 @@ __device__ __forceinline__ void bfs_dense_work(const bfs_fused_args_t& a, u32* c
       idx = idx > HOTW ? HOTW : idx;
       return hot[idx];
     };
+    // A miss (bit not set in the workgroup's LDS copy): set it there -- a NON-returning LDS OR: nobody waits for the old
+    // word -- and, outside the deferred range, store the mark.  The claim used to be a returning atomicOr whose old value
+    // decided whether the mark was stored (exact dedup inside the workgroup): per entry a dependent LDS round trip, five
+    // more vector instructions and two more divergent regions, executed by nearly every wave (3 % of a big level's entries
+    // miss, i.e. 86 % of its 64-lane instructions hold one) -- the kernel was issue-bound on them (PMC, round 4: 18 vector
+    // instructions per entry, VALU busy 45 % of a launch that streams at 60 % of the load rate).  Marks are idempotent byte
+    // stores, so the only thing lost is the dedup of the few probes that are in flight between another lane's probe and
+    // its OR: `marks` now counts misses (still an upper bound of the discoveries, which is all its readers ask of it).
     auto decide = [&](u32 d, u32 wd) {
       if (!((wd >> (d & 31u)) & 1u)) {
-        const u32 bit = 1u << (d & 31u);
-        bool is_new = true;
-        if (d < hot_n) is_new = !(atomicOr(&hot[d >> 5], bit) & bit);
-        if (is_new) { if (!(diag & 1) && d >= defer_n && !((diag & 4) && d >= hot_n)) mark[d] = 1; ++marks; }   // (diag 4: no COLD marks)
+        if (d < hot_n) (void)__hip_atomic_fetch_or(&hot[d >> 5], 1u << (d & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!(diag & 1) && d >= defer_n && !((diag & 4) && d >= hot_n)) mark[d] = 1;       // (diag 4: no COLD marks)
+        ++marks;
       }
     };
     // four LDS probes in flight, then the four decisions (a probe that waits for its own result before the next one
