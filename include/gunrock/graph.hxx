@@ -80,6 +80,13 @@ struct graph_device_t {
   bool ub_w_tried = false;
   mem_t<unsigned char> d_ub_cnt;     // real entries of every unit (the rest is padding): what a reduction may count (mgx/nreduce.hpp)
   mem_t<int> d_ub_first;             // n + 1: the units of layout row v are [ub_first[v], ub_first[v + 1])
+  // What a traversal FROM vertex v starts with, by original id, on the host (mgx::bfs_src_shape_t, bfs_fused_run.hpp): the
+  // source's own row and the level behind it -- its distinct neighbours other than itself that have entries: true edges,
+  // rows below and from the long-row threshold.  The fused BFS sizes a traversal's launch sequence from it before the
+  // first kernel is enqueued (which of the two small-level launches in front of the device-wide slots will find work).
+  // Built by mgx_graph_build_layout (rows sorted by neighbour: duplicates are adjacent); empty: not available.
+  std::vector<unsigned> src_shapes;  // 4 words per vertex: degree, level-1 edges, level-1 short rows, level-1 long rows
+  int src_shapes_long_min = 0;       // the long-row threshold the rows were split by
   unsigned nr_big_rows = 0;          // layout rows [0, nr_big_rows) hold more than mgx::NR_BIG_UNITS units (degree-sorted layouts)
   // Degree classes of the layout's short rows (mgx/bfs_fused_vshort.hpp): only for a layout the library built itself
   // (sorted by degree, eight ints of -1 behind its neighbour array).

@@ -150,6 +150,7 @@ struct bfs_fused_args_t {
   u32 vs_dummy;            // index (into col_indices) of four entries of -1
   u32* flush_buf;          // BFS_FLUSH_MAX buffers of BFS_FLUSH_WORDS words (NULL: hot marks are never deferred)
   u32 defer_min_marks;     // a workgroup with more deferred discoveries than this flushes them as a bitmap (else: byte marks)
+  u32 defer_words;         // words of the LDS prefix whose marks are deferred (a multiple of 32, <= BFS_FLUSH_WORDS: the flush buffers' stride)
   u32 defer_reach_mul, defer_reach_div;   // a level defers while reached * mul < deferred range * div (1 / 1; MGX_BFS_DEFER_REACH="mul/div")
   int lazy_pull;           // direction-optimising runs: the builds behind bottom-up levels write no queues
   int merged_pull;         // direction-optimising runs: the bottom-up sweep runs inside the push launch (no k_bfs_pull_level launch)
@@ -427,7 +428,7 @@ constexpr int BFS_FLUSH_RUNS = BFS_FLUSH_WORDS / 32;
 // vertices [0, limit) defer their marks in this level (0: nothing is deferred)
 __device__ __forceinline__ u32 bfs_defer_limit(const bfs_fused_args_t& a, u32 hot_n) {
   if (!a.flush_buf || hot_n == 0u) return 0u;
-  const u32 range = hot_n < (u32)(BFS_FLUSH_WORDS * 32) ? hot_n : (u32)(BFS_FLUSH_WORDS * 32);
+  const u32 range = hot_n < a.defer_words * 32u ? hot_n : a.defer_words * 32u;
   return a.ctrl->reached * (u64)a.defer_reach_mul < (u64)range * (u64)a.defer_reach_div ? range : 0u;
 }
 
@@ -461,7 +462,7 @@ __device__ __forceinline__ int bfs_hot_epilogue(const bfs_fused_args_t& a, const
 #pragma unroll
       for (int q = 0; q < PERT; ++q) {
         const u32 i = (u32)q * NT + threadIdx.x;
-        if (i < (u32)BFS_FLUSH_WORDS) out[i] = i < defer_words ? hot[i] : 0u;
+        if (i < defer_words) out[i] = hot[i];      // (the queue build reads the runs below the deferred range only)
       }
       return total;
     }
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 4) void k_bfs_build(bfs_fused_a
       const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
       for (int hr = 0; hr < NW; ++hr) {
         const long long run = (long long)blockIdx.x + (long long)hr * gridDim.x;       // the run wave `hr` owns
-        if (run >= BFS_FLUSH_RUNS) break;
+        if (run >= (long long)(a.defer_words / 32u)) break;
         // all waves share the reads: wave w takes buffers w, w + NW, ...; a lane's halfword = its 16 vertices of the run
         const unsigned short* const col = (const unsigned short*)a.flush_buf + run * 64 + lane;
         u32 acc = 0;
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
     if (F) {                                                     // (grid-uniform)
       for (int hr = 0; hr < NW; ++hr) {
         const long long run = (long long)blockIdx.x + (long long)hr * gridDim.x;
-        if (run >= BFS_FLUSH_RUNS) break;
+        if (run >= (long long)(a.defer_words / 32u)) break;
         const uint4* const base = (const uint4*)(a.flush_buf + (size_t)run * 32) + (lane & 7);
         uint4 acc = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll 8
@@ -975,6 +976,8 @@ struct bfs_run_opts_t {
   int dense = -1;          // MGX_BFS_DENSE: 0 never, N > 0 dense_div = N
   int vshort = -1;         // MGX_BFS_VSHORT: 0 never, N > 0 vshort_div = N
   long long chain = -1;    // MGX_BFS_CHAIN_MAX_EDGES: 0 never (default BFS_CHAIN_CAP)
+  int src_plan = 1;                   // MGX_BFS_SRC_PLAN=0: every traversal gets the same launch sequence (no per-source classes)
+  int defer_words = -1;               // MGX_BFS_DEFER_WORDS: words of the bitmap prefix whose marks are deferred (default: all BFS_FLUSH_WORDS)
   int defer_mul = 1, defer_div = 1;   // MGX_BFS_DEFER_REACH="mul/div": a level defers its hot marks while reached * mul < range * div
                                       // (RMAT-22, ms per traversal: 4/1 0.3627, 2/1 0.3600, 1/1 0.3521, 2/3 0.3511, 1/3 0.3530, 1/8 0.3625, always 0.3641)
   int do_chain = 1;        // MGX_BFS_DO_CHAIN=0: direction-optimising runs keep every level device-wide (no chains of small top-down levels)
@@ -1018,6 +1021,8 @@ struct bfs_run_opts_t {
     geti("MGX_BFS_BUILD_LIST", o.build_list);
     geti("MGX_BFS_SPIN", o.spin);
     getll("MGX_BFS_DEFER", o.defer);
+    geti("MGX_BFS_DEFER_WORDS", o.defer_words);
+    geti("MGX_BFS_SRC_PLAN", o.src_plan);
     geti("MGX_BFS_COLD", o.cold);
     if (const char* e = getenv("MGX_BFS_DEFER_REACH")) {
       o.defer_mul = atoi(e);
@@ -1080,6 +1085,10 @@ struct bfs_fused_state_t {
   unsigned chain_big_edges = 4096;   // largest level the in-place chain kernel runs (bfs_fused_run.hpp; <= BFS_CHAIN_CAP_BIG): a lone workgroup
                                      // needs ~5 + 4.3 us per 1000 edges (measured: 10 487 edges 49 us, 7 391 38 us, 1 281 17 us), a device-wide slot ~21 us
   int recent_need[4] = {1, 1, 1, 1}, recent_at = 0;   // slots the last traversals needed
+  // ... and per source class (bfs_classify_source, bfs_fused_run.hpp: 1 = the M launch in front absorbs the first level the
+  // chain leaves, 2 = that level is too big for it and the launch is not enqueued): the slots the last four traversals of
+  // the class needed under ITS launch sequence; a class without history takes the graph's hint
+  int cls_need[3][4] = {{1, 1, 1, 1}, {1, 1, 1, 1}, {1, 1, 1, 1}}, cls_at[3] = {0, 0, 0};
   int auto_spare = 0, clean_batches = 0;             // batches (bfs_fused_run_many): spare slots learnt from re-runs, batches without one since
   int tail_from = 1 << 30;           // slots from this one on get an in-place chain launch in front (learnt from the previous traversal)
   unsigned lazy_div = 4;             // the build behind a push with >= n / lazy_div mark stores writes no queues (bfs_build_is_lazy; 0: never)

@@ -9,6 +9,7 @@
 // The partitioned path (bfs_dist2.hpp) drives the queue-walk bodies with explicit level numbers (k_bfs_push_level).
 #pragma once
 #include <cstring>
+#include <vector>
 #include <unistd.h>
 #include "bfs_fused.hpp"
 #include "bfs_fused_chain.hpp"
@@ -52,7 +53,26 @@ struct bfs_layout_t {
            cold_wgs[BFS_COLD_MAX_SLICES + 1] = {0};
   unsigned cold_hot_n = 0;
   int cold_long_min = 0;
+  // HOST table, by ORIGINAL vertex id, 4 words per vertex (graph_device_t::src_shapes): what a traversal from v starts with
+  const unsigned* src_shapes = nullptr;
+  int src_shapes_long_min = 0;
 };
+
+// A traversal's first levels, known before anything is enqueued (bfs_layout_t::src_shapes): level 0 is the source's row,
+// level 1 its distinct neighbours.  The launch sequence of a traversal is [init][chain][M] slots ... [M][chain]; whether
+// the M launch in FRONT finds work is decided by the first level the in-place chain leaves behind -- and for most sources
+// that is level 0 or 1:
+//   BFS_SRC_ABSORB  that level is mid-size: the M launch expands it, the device-wide slots start one level later;
+//   BFS_SRC_SKIP    it is too big for an M launch, which would only forward it (a queue copy of 5-14 us on RMAT-22): the
+//                   launch is not enqueued, slot 0 is the first device-wide slot;
+//   BFS_SRC_UNKNOWN levels 0 and 1 are both small enough for the chain (or there is no table): the graph-wide sequence.
+// Each class learns its own number of device-wide slots (bfs_fused_state_t::cls_need).  RMAT-22, 64 bench sources: 45 %
+// ABSORB -- three slots instead of the four the other 55 % need, so their stragglers go to the M launch behind the slots
+// instead of a device-wide slot with a queue build behind it -- and 55 % SKIP.  The rules mirror the device's own
+// (bfs_level_is_chained with the in-place limits, bfs_level_is_mini) on exact numbers; a graph whose rows are not sorted
+// by neighbour overestimates level 1 (duplicates count twice), which can only turn ABSORB into SKIP or UNKNOWN -- a slot
+// more than needed, never one too few.
+constexpr int BFS_SRC_UNKNOWN = 0, BFS_SRC_ABSORB = 1, BFS_SRC_SKIP = 2;
 
 constexpr int BFS_STREAM_HOTW2 = 20400;   // two workgroups per CU: 80 KB of bitmap each
 constexpr int BFS_WAVE_HOTW = 18000;
@@ -379,6 +399,12 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   if (defer > 0 && !lab_flags && !st.flush_buf.size()) st.flush_buf = mem_t<u32>((size_t)BFS_FLUSH_MAX * BFS_FLUSH_WORDS, ctx);
   a.flush_buf = (defer > 0 && !lab_flags) ? st.flush_buf.data() : nullptr;
   a.defer_min_marks = (u32)defer;
+  {
+    // the deferred range: whole runs of 1024 vertices (the queue build ORs the flush buffers run by run), at most the buffers' stride
+    int dw = opt.defer_words >= 0 ? opt.defer_words : BFS_FLUSH_WORDS;
+    if (dw > BFS_FLUSH_WORDS) dw = BFS_FLUSH_WORDS;
+    a.defer_words = (u32)(dw / 32 * 32);
+  }
   a.defer_reach_mul = (u32)opt.defer_mul; a.defer_reach_div = (u32)opt.defer_div;
   a.chain_max_edges = (mode != 0 && !opt.do_chain) ? 0u : (opt.chain >= 0 ? (u32)(opt.chain > BFS_CHAIN_CAP ? BFS_CHAIN_CAP : opt.chain) : st.chain_max_edges);
   const long long nwords = ((long long)st.n + 31) / 32;
@@ -428,6 +454,49 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   return plan;
 }
 
+inline int bfs_classify_source(const bfs_fused_state_t& st, const bfs_launch_plan_t& plan, const bfs_layout_t* layout, int src) {
+  if (!layout || !layout->src_shapes || !plan.minis || plan.mode != 0 || !st.opts.src_plan || !st.opts.tail_chain) return BFS_SRC_UNKNOWN;
+  const bfs_fused_args_t& a = plan.a;
+  if (layout->src_shapes_long_min != a.long_min || src < 0 || src >= a.n) return BFS_SRC_UNKNOWN;
+  const unsigned* const sh = layout->src_shapes + (size_t)src * 4;
+  const u64 deg = sh[0], e1 = sh[1], s1 = sh[2], l1 = sh[3];
+  if (deg == 0 || e1 == 0xFFFFFFFFull) return BFS_SRC_UNKNOWN;
+  // both levels run before a quarter of the vertices is reached (the chain's and the M launch's EARLY limits apply)
+  if ((1ull + s1 + l1) * 4ull >= (u64)(u32)a.n) return BFS_SRC_UNKNOWN;
+  const u64 lim = a.chain_big_edges < BFS_CHAIN_EARLY_EDGES ? a.chain_big_edges : BFS_CHAIN_EARLY_EDGES;
+  const u64 chain_cap = lim < (u64)BFS_CHAIN_CAP_BIG ? lim : (u64)BFS_CHAIN_CAP_BIG;
+  u64 E, rs, rl;
+  if (deg > chain_cap) {                       // the source's own row is more than the in-place chain takes
+    const bool is_long = a.long_min > 0 && deg >= (u64)a.long_min;
+    E = deg; rs = is_long ? 0 : 1; rl = is_long ? 1 : 0;
+  } else if (e1 > chain_cap) {                 // level 0 is chained, level 1 is what the chain leaves
+    E = e1; rs = s1; rl = l1;
+  } else {
+    return BFS_SRC_UNKNOWN;
+  }
+  const bool mini = rl <= (u64)BFS_MINI_LCAP && rs <= (u64)BFS_MINI_SHORT_ROWS && E <= (u64)BFS_MINI_EDGES_EARLY;
+  return mini ? BFS_SRC_ABSORB : BFS_SRC_SKIP;
+}
+// device-wide slots a traversal of class `cls` gets: what the last traversals of the class needed, else the graph's hint
+inline int bfs_class_slots(const bfs_fused_state_t& st, int cls) {
+  auto known = [&](int c) {
+    int h = 0;
+    for (int i = 0; i < 4 && i < st.cls_at[c]; ++i) h = st.cls_need[c][i] > h ? st.cls_need[c][i] : h;
+    return h;
+  };
+  if (cls == BFS_SRC_UNKNOWN) return st.slots_hint;
+  if (st.cls_at[cls] > 0) return known(cls);
+  // no traversal of this class yet: the other class's need, one slot apart -- the level the M launch absorbs for an ABSORB
+  // source is the one that takes a SKIP source's first device-wide slot (a guess: a traversal that does not finish in its
+  // slots is run again and then IS the class's history)
+  const int other = cls == BFS_SRC_ABSORB ? BFS_SRC_SKIP : BFS_SRC_ABSORB;
+  if (st.cls_at[other] > 0) {
+    const int h = known(other) + (cls == BFS_SRC_SKIP ? 1 : -1);
+    return h > 1 ? h : 1;
+  }
+  return st.slots_hint;
+}
+
 // the launches of a traversal on the product path (no events, merged push): init + the chain of the small levels at the
 // start; one slot; the chain behind the last slot of a batch.  prev_head: see k_bfs_fused_init.
 inline void bfs_enqueue_chain_inplace(const bfs_launch_plan_t& plan, int slot, hipStream_t s) {
@@ -439,12 +508,13 @@ inline void bfs_enqueue_mini(const bfs_launch_plan_t& plan, int slot, hipStream_
 // init, the chain of the tiny levels at the start, and (M launches on) the first mid-size level: returns the first slot
 // that is still to be launched
 inline int bfs_enqueue_start(const bfs_fused_state_t& st, const bfs_launch_plan_t& plan, int src, standard_context_t& ctx,
-                             const bfs_ctrl_t* prev_ctrl = nullptr, bfs_ctrl_t* prev_head = nullptr, int head_words = 0) {
+                             const bfs_ctrl_t* prev_ctrl = nullptr, bfs_ctrl_t* prev_head = nullptr, int head_words = 0,
+                             bool front_mini = true) {
   hipStream_t s = ctx.stream();
   hipLaunchKernelGGL(k_bfs_fused_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, plan.a, src,
                      plan.nwords, prev_ctrl, prev_head, head_words);
   if (plan.a.chain_big_edges) bfs_enqueue_chain_inplace(plan, 0, s);
-  if (plan.minis) { bfs_enqueue_mini(plan, 0, s); return 1; }
+  if (plan.minis && front_mini) { bfs_enqueue_mini(plan, 0, s); return 1; }
   return 0;
 }
 inline void bfs_enqueue_build(const bfs_fused_state_t& st, const bfs_launch_plan_t& plan, int arg, hipStream_t s) {
@@ -471,7 +541,8 @@ inline void bfs_enqueue_slot(const bfs_fused_state_t& st, const bfs_launch_plan_
 // traversals needed.  In-place chain launches from the first slot behind them on, i.e. behind the batch: a chain launch
 // that finds a big level costs 5 us (its reads of the control block miss behind the build's atomics), and on RMAT-22 the
 // level behind the last big one is small for a minority of the sources only.
-inline void bfs_learn_slots(bfs_fused_state_t& st, const bfs_fused_args_t& a, const bfs_ctrl_t* hc, int mode, int trace_avail, bool minis = false) {
+inline void bfs_learn_slots(bfs_fused_state_t& st, const bfs_fused_args_t& a, const bfs_ctrl_t* hc, int mode, int trace_avail, bool minis = false,
+                            int cls = BFS_SRC_UNKNOWN) {
   st.slots_hint = hc->slots > 0 ? hc->slots : 1;    // slots that found work
   st.tail_from = 1 << 30;
   if (!(a.chain_big_edges && st.opts.tail_chain)) return;
@@ -500,17 +571,24 @@ inline void bfs_learn_slots(bfs_fused_state_t& st, const bfs_fused_args_t& a, co
     kind[l] = small ? 0 : (minis && mid ? 1 : 2);
   }
   // the launch sequence [chain][M] slots [M][chain]: what the two ends absorb needs no slot
-  int lo = 0, hi = L;
-  while (lo < hi && kind[lo] == 0) ++lo;                    // the chain at the start
-  if (minis && lo < hi && kind[lo] == 1) ++lo;              // the M launch behind it
-  while (hi > lo && kind[hi - 1] == 0) --hi;                // the chain behind the batch
-  if (minis && hi > lo && kind[hi - 1] == 1) {              // the M launch in front of it ...
-    --hi;
-    while (hi > lo && kind[hi - 1] == 0) --hi;              // (... and small levels in front of THAT ride in a slot's push launch)
+  auto slots_needed = [&](bool front_mini) {
+    int lo = 0, hi = L;
+    while (lo < hi && kind[lo] == 0) ++lo;                    // the chain at the start
+    if (minis && front_mini && lo < hi && kind[lo] == 1) ++lo;   // the M launch behind it
+    while (hi > lo && kind[hi - 1] == 0) --hi;                // the chain behind the batch
+    if (minis && hi > lo && kind[hi - 1] == 1) {              // the M launch in front of it ...
+      --hi;
+      while (hi > lo && kind[hi - 1] == 0) --hi;              // (... and small levels in front of THAT ride in a slot's push launch)
+    }
+    int k = 0;
+    for (int l = lo; l < hi; ++l) if (kind[l] != 0) ++k;
+    return k > 0 ? k : 1;
+  };
+  if (cls != BFS_SRC_UNKNOWN) {                               // what this class needs under ITS sequence (SKIP: no M launch in front)
+    st.cls_need[cls][st.cls_at[cls] & 3] = slots_needed(cls != BFS_SRC_SKIP);
+    st.cls_at[cls] += 1;
   }
-  int k = 0;
-  for (int l = lo; l < hi; ++l) if (kind[l] != 0) ++k;
-  const int need = k > 0 ? k : 1;
+  const int need = slots_needed(true);                        // ... and the graph-wide sequence, whoever ran
   st.recent_need[st.recent_at & 3] = need;
   st.recent_at += 1;
   int hint = 1;
@@ -534,7 +612,8 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   const bfs_fused_args_t& a = plan.a;
   const bool coldt = plan.coldt;
   const int lab_flags = plan.lab_flags;
-  int slot = bfs_enqueue_start(st, plan, src, ctx);          // (1 when an M launch took slot 0)
+  const int cls = bfs_classify_source(st, plan, layout, src);
+  int slot = bfs_enqueue_start(st, plan, src, ctx, nullptr, nullptr, 0, cls != BFS_SRC_SKIP);          // (1 when an M launch took slot 0)
   auto chain_inplace = [&](int sl) { bfs_enqueue_chain_inplace(plan, sl, s); };
   st.level_kernel_ms = 0.0;
   st.level_kernel_launches = 0;
@@ -547,7 +626,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   const u32 nstream = plan.nstream, nwave = plan.nwave, ncold = plan.ncold;
   for (int batch = 0;; ++batch) {
     // first batch: what the previous traversal of this graph needed (sources differ, level structure hardly)
-    int nslots = batch == 0 ? st.slots_hint : st.levels_per_sync;
+    int nslots = batch == 0 ? bfs_class_slots(st, cls) : st.levels_per_sync;
     if (nslots > bfs_fused_state_t::EV_POOL / 3) nslots = bfs_fused_state_t::EV_POOL / 3;
     if (batch_events) MGX_HIP(hipEventRecord(st.ev0, s));
     const int first_slot = slot;
@@ -655,7 +734,7 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
     MGX_HIP(hipMemcpyAsync(st.host_ctrl->trace + 64, st.ctrl.data()->trace + 64, (size_t)(lv - 64) * sizeof(u64), hipMemcpyDeviceToHost, s));
     MGX_HIP(hipStreamSynchronize(s));
   }
-  bfs_learn_slots(st, a, st.host_ctrl, mode, BFS_MAX_TRACE, plan.minis);
+  bfs_learn_slots(st, a, st.host_ctrl, mode, BFS_MAX_TRACE, plan.minis, cls);
 }
 
 // COUNT traversals enqueued back to back with ONE host wait at the end (mgx_bfs_run_many): every traversal is complete --
@@ -710,19 +789,25 @@ inline int bfs_fused_run_many(bfs_fused_state_t& st, const int* row_offsets, con
   const int saved_tail = st.tail_from;
   st.tail_from = plan.minis ? (1 << 30) : nslots - 1;      // (no M launches: a chain launch in front of the last slot and behind the batch)
   const bool tail = a.chain_big_edges && st.opts.tail_chain;
-  int last_slot = nslots;                          // the slot the chain behind a traversal works in: where an unfinished one stands
+  std::vector<int> last_slots((size_t)count, nslots), classes((size_t)count, BFS_SRC_UNKNOWN);   // per traversal: the slot the chain behind it works in (where an unfinished one stands), its class
   // the chain behind a traversal's last slot may run levels up to the list capacity here (a lone workgroup needs ~4.3 us per
   // 1000 edges: slower than a slot above ~4000 edges, but far cheaper than running the whole traversal again)
   bfs_launch_plan_t plan_tail = plan;
   plan_tail.a.chain_big_edges = BFS_CHAIN_CAP_BIG;
   for (int i = 0; i < count; ++i) {
     // (the head of the control block as the previous traversal left it goes to the host before the init kernel resets it)
+    // (per source: which of the launches in front of the device-wide slots will find work, and how many slots its class needs)
+    const int cls = bfs_classify_source(st, plan, layout, srcs[i]);
+    int my_slots = cls == BFS_SRC_UNKNOWN ? nslots : bfs_class_slots(st, cls) + st.opts.many_spare + st.auto_spare;
+    if (my_slots > 30) my_slots = 30;
+    if (my_slots < 1) my_slots = 1;
     int sl = bfs_enqueue_start(st, plan, srcs[i], ctx, i > 0 ? st.ctrl.data() : (const bfs_ctrl_t*)nullptr,
-                               i > 0 ? bfs_many_head(heads, i - 1) : (bfs_ctrl_t*)nullptr, head_words);
-    for (int k = 0; k < nslots; ++k, ++sl) bfs_enqueue_slot(st, plan, sl, ctx);
+                               i > 0 ? bfs_many_head(heads, i - 1) : (bfs_ctrl_t*)nullptr, head_words, cls != BFS_SRC_SKIP);
+    for (int k = 0; k < my_slots; ++k, ++sl) bfs_enqueue_slot(st, plan, sl, ctx);
     if (plan.minis) { bfs_enqueue_mini(plan, sl, s); ++sl; }
     if (tail) bfs_enqueue_chain_inplace(plan_tail, sl, s);
-    last_slot = sl;
+    last_slots[(size_t)i] = sl;
+    classes[(size_t)i] = cls;
   }
   st.tail_from = saved_tail;
   const u64 seq = ++st.seq;
@@ -742,18 +827,25 @@ inline int bfs_fused_run_many(bfs_fused_state_t& st, const int* row_offsets, con
   bool redo_last = false;
   for (int i = 0; i < count; ++i) {
     bfs_ctrl_t* const h = bfs_many_head(heads, i);
+    const int last_slot = last_slots[(size_t)i];
     if (!h->done) {
       const u64 next = h->cursor[last_slot % 3] | h->lcursor[last_slot % 3];
       if ((next >> BFS_VSHIFT) == 0) { h->done = 1; h->levels = h->slot_level[last_slot & 3]; }
     }
-    if (h->done) { bfs_learn_slots(st, a, h, mode, 64, plan.minis); continue; }
+    if (h->done) { bfs_learn_slots(st, a, h, mode, 64, plan.minis, classes[(size_t)i]); continue; }
     bfs_fused_run(st, row_offsets, col_indices, labels, srcs[i], ctx, layout, mode, alpha, in_offsets, in_indices);
     memcpy(h, st.host_ctrl, bfs_head_bytes());
     ++reruns;
     if (i != count - 1) redo_last = true;
   }
   if (redo_last) bfs_fused_run(st, row_offsets, col_indices, labels, srcs[count - 1], ctx, layout, mode, alpha, in_offsets, in_indices);
-  st.slots_used = last_slot;
+  st.slots_used = last_slots[(size_t)count - 1];
+  if (getenv("MGX_BFS_PLAN_VERBOSE")) {
+    int cc[3] = {0, 0, 0};
+    for (int i = 0; i < count; ++i) cc[classes[(size_t)i]]++;
+    fprintf(stderr, "[mgx] batch of %d: classes unknown %d absorb %d skip %d; slots graph %d absorb %d skip %d; reruns %d\n", count, cc[0], cc[1], cc[2],
+            st.slots_hint, bfs_class_slots(st, BFS_SRC_ABSORB), bfs_class_slots(st, BFS_SRC_SKIP), reruns);
+  }
   if (reruns > 0) { if (st.auto_spare < 4) ++st.auto_spare; st.clean_batches = 0; }
   else if (st.auto_spare > 0 && ++st.clean_batches >= 8) { --st.auto_spare; st.clean_batches = 0; }
   return reruns;

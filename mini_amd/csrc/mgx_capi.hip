@@ -457,6 +457,49 @@ static void build_cold_lists(mgx_graph_s* g) {
   G.d_colds_owner = std::move(d_owner_s); G.d_colds_dst = std::move(d_dst_s);
   G.cold_pairs = pairs; G.colds_pairs = pairs_s; G.cold_slices = used; G.cold_hot_n = hot_n; G.cold_long_min = G.vs_long_min;
 }
+// graph_device_t::src_shapes: per vertex (original ids) its degree and the shape of the level behind it as a traversal from
+// that vertex would meet it -- one wave per vertex, lanes over the row; a neighbour counts once (rows are sorted: a duplicate
+// sits next to its twin), the vertex itself and neighbours without entries do not
+namespace {
+__global__ __launch_bounds__(256) void k_src_shapes(const int* __restrict__ ro, const int* __restrict__ ci, int n, int long_min,
+                                                    uint4* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long v = wave0; v < n; v += nwaves) {
+    const int r0 = ro[v], r1 = ro[v + 1];
+    unsigned long long edges = 0;
+    unsigned rs = 0, rl = 0;
+    for (int e = r0 + lane; e < r1; e += 64) {
+      const int u = ci[e];
+      if (u == (int)v || (e > r0 && ci[e - 1] == u)) continue;
+      const unsigned d = (unsigned)(ro[u + 1] - ro[u]);
+      if (d == 0u) continue;
+      edges += d;
+      if (long_min > 0 && d >= (unsigned)long_min) ++rl; else ++rs;
+    }
+    edges = mgx::wave_sum(edges);
+    rs = mgx::wave_sum(rs);
+    rl = mgx::wave_sum(rl);
+    if (lane == 0) out[v] = make_uint4((unsigned)(r1 - r0), edges > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)edges, rs, rl);
+  }
+}
+}  // namespace
+static void build_src_shapes(mgx_graph_t g, int long_min) {
+  graph_device_t& G = *g->g;
+  standard_context_t& ctx = *g->c->ctx;
+  G.src_shapes.clear();
+  G.src_shapes_long_min = 0;
+  if (getenv("MGX_BFS_SRC_SHAPES") && atoi(getenv("MGX_BFS_SRC_SHAPES")) == 0) return;
+  const size_t n = (size_t)G.num_nodes;
+  if (n == 0 || G.num_edges <= 0) return;
+  mem_t<unsigned> d((n + 1) * 4, ctx);
+  hipLaunchKernelGGL(k_src_shapes, dim3(mgx::grid_for((long long)n * 64, 256, 16384)), dim3(256), 0, ctx.stream(), G.d_row_offsets.data(),
+                     G.d_col_indices.data(), (int)n, long_min, (uint4*)d.data());
+  G.src_shapes.resize(n * 4);
+  MGX_HIP(mgx::dtoh(G.src_shapes.data(), d.data(), n * 4));
+  G.src_shapes_long_min = long_min;
+}
 int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
   MGX_TRY
   MGX_REQUIRE(g, "graph is NULL");
@@ -517,7 +560,12 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
 #endif
     }
   }
-  build_cold_lists(g);
+build_cold_lists(g);
+  {
+    int long_min = 64;
+    if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
+    build_src_shapes(g, long_min);
+  }
   MGX_CATCH
 }
 extern "C" int mgx_csc_build_device(const int* ro, const int* ci, const float* w, int n, long long m, int* co, int* ri, float* rv,
