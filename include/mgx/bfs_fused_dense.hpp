@@ -6,7 +6,7 @@
 // their edges), mid-degree ones, a few sub-rounds each, so the walk never amortises.  Here nothing is walked:
 //
 //   * the long rows live a second time as unit blocks (mgx_layout.hip): every row padded to a multiple of 64 entries
-//     (padding repeats the row's first neighbour), so a UNIT of 64 consecutive entries belongs to exactly one row,
+//     (padding entries are -1: they read as visited, see the sentinel words below), so a UNIT of 64 consecutive entries belongs to exactly one row,
 //     owner[u] says which;
 //   * a wave takes groups of 16 consecutive units (4 KB of entries), interleaved over all waves of the grid -- equal
 //     shares whatever the frontier looks like (a level of a few thousand hubs activates one contiguous stretch of units);

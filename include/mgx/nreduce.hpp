@@ -11,7 +11,7 @@
 //                 edge; from here on the values are addressed by layout id, where the hubs -- the targets of most edges --
 //                 are the first ids; reduced[] <- identity.
 //   k_nr_edges    ONE launch, two parts.  Long rows (>= 64 entries) from the unit blocks (mgx_layout.hip): 16 bytes per lane, a unit of 64
-//                 entries belongs to ONE row (ub_cnt[u] of them are real, the rest padding), so the segment id is free;
+//                 entries belongs to ONE row (its padding entries are -1: the identity), so the segment id is free;
 //                 the values of the first NR_HOTV layout vertices sit in LDS (160 KB: one workgroup per CU), the others
 //                 are gathered from L2 (the next 600 K vertices are 2.4 MB); 16 lanes fold a unit with
 //                 four shuffle steps in a fixed order -> partial[u].
@@ -103,38 +103,36 @@ __device__ __forceinline__ void nr_long_work(const nr_layout_t& L, const V* __re
   const u32 G = L.ub_units_pad / 16u;                 // groups of 16 units = 1024 entries
   const u32 W = nblocks * NW, w = block * NW + (u32)wave;
   const int* __restrict__ ucol = L.ub_col;
-  const unsigned char* __restrict__ ucnt = L.ub_cnt;
   const u32 sub = (u32)lane & 15u, q = (u32)lane >> 4;                  // my four entries inside my unit; my unit inside a 4-unit load
   if (w < G) {
   // A step takes GPS groups (g, g + W, ...): four loads per group; load j covers units 16 g + 4 j .. + 3, lane (q, sub) reads
   // entries 4 sub .. 4 sub + 3 of unit 4 j + q.  The next step's loads are in flight while this step's 16 GPS gathers are.
   constexpr int GPS = 2, NL = 4 * GPS;
+  // (a unit's padding entries are -1 -- the identity to nr_fetch -- so nothing has to say how many of its 64 entries are real:
+  //  the per-unit counts this loop used to load, one byte per lane and 16-byte load, doubled its memory instructions)
   nr_u32x4 cur[NL], nxt[NL];
-  u32 ccnt[NL], ncnt[NL];
-  auto issue = [&](u32 g0, nr_u32x4* d, u32* c) {
+  auto issue = [&](u32 g0, nr_u32x4* d) {
 #pragma unroll
     for (int k = 0; k < GPS; ++k) {
       const u32 g = g0 + (u32)k * W;
-      const u32 gg = g < G ? g : G - 1u;                // (past the end: the last group again, ignored)
+      const u32 gg = g < G ? g : G - 1u;                // (past the end: the last group again, masked below)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const u32 u = gg * 16u + 4u * (u32)j + q;
         d[4 * k + j] = __builtin_nontemporal_load((const nr_u32x4*)(ucol + ((size_t)u << 6) + sub * 4u));
-        c[4 * k + j] = g < G ? (u32)ucnt[u] : 0u;
       }
     }
   };
-  issue(w, cur, ccnt);
+  issue(w, cur);
   for (u32 g0 = w; g0 < G; g0 += (u32)GPS * W) {
-    issue(g0 + (u32)GPS * W, nxt, ncnt);
+    issue(g0 + (u32)GPS * W, nxt);
     // all gathers of the step first, then the folds (a fold's shuffles between two gathers would order them)
     V val[NL][4];
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-      const u32 have = ccnt[j];                       // real entries of my unit
-      const u32 e0 = sub * 4u;
-      const u32 d0 = e0 + 0u < have ? cur[j].x : 0xFFFFFFFFu, d1 = e0 + 1u < have ? cur[j].y : 0xFFFFFFFFu;
-      const u32 d2 = e0 + 2u < have ? cur[j].z : 0xFFFFFFFFu, d3 = e0 + 3u < have ? cur[j].w : 0xFFFFFFFFu;
+      const bool real = g0 + (u32)(j / 4) * W < G;    // (wave-uniform)
+      const u32 d0 = real ? cur[j].x : 0xFFFFFFFFu, d1 = real ? cur[j].y : 0xFFFFFFFFu;
+      const u32 d2 = real ? cur[j].z : 0xFFFFFFFFu, d3 = real ? cur[j].w : 0xFFFFFFFFu;
       val[j][0] = nr_fetch(d0, vals, hot, hot_n, identity); val[j][1] = nr_fetch(d1, vals, hot, hot_n, identity);
       val[j][2] = nr_fetch(d2, vals, hot, hot_n, identity); val[j][3] = nr_fetch(d3, vals, hot, hot_n, identity);
     }
@@ -147,7 +145,7 @@ __device__ __forceinline__ void nr_long_work(const nr_layout_t& L, const V* __re
       if (sub == 0u && g < G) partial[g * 16u + 4u * (u32)(j % 4) + q] = s;
     }
 #pragma unroll
-    for (int j = 0; j < NL; ++j) { cur[j] = nxt[j]; ccnt[j] = ncnt[j]; }
+    for (int j = 0; j < NL; ++j) cur[j] = nxt[j];
   }
   }
 }

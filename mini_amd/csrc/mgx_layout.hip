@@ -114,8 +114,8 @@ extern "C" int mgx_layout_build_device(const int* ro, const int* ci, const float
 
 // ---- unit-blocked copy of a degree class ("unit blocks") -------------------------------------------------
 // The rows of a CSR whose degree lies in [min_deg, max_deg) copied so that every row starts on a multiple of
-// U = 1 << ushift entries and is padded to a multiple of U (padding repeats the row's first neighbour: testing an edge
-// twice is harmless for a traversal), plus owner[u] = the row unit u belongs to.  A unit is U consecutive entries of ONE
+// U = 1 << ushift entries and is padded to a multiple of U (padding is -1: the traversal kernels' LDS bitmap has a word of
+// ones in front, so a -1 reads as visited; a reduction takes it for the identity), plus owner[u] = the row unit u belongs to.  A unit is U consecutive entries of ONE
 // row: a kernel can stream the copy in fixed-size pieces (bfs_fused_dense.hpp) and decide per unit whether its row is in
 // the frontier, with no row walk and no search.  The number of units is padded to a multiple of 16 (owner = n for the
 // padding: a vertex that is never in a frontier) and the copy ends with four entries of -1 (where lanes of inactive
@@ -140,17 +140,16 @@ __global__ void k_unit_fill(const int* __restrict__ ro, const int* __restrict__ 
     const int u0 = uoff[v], u1 = uoff[v + 1];
     if (u1 == u0) continue;
     const int r0 = ro[v], deg = ro[v + 1] - r0;
-    const int first = ci[r0];
     for (int u = u0 + lane; u < u1; u += 64) {
       owner[u] = (int)v;
-      // real entries of the unit (the rest repeats the row's first neighbour): what a REDUCTION over the unit may count (mgx/nreduce.hpp)
+      // real entries of the unit (the rest is padding, -1): the fused SSSP's sweep masks by it (mgx/sssp_fused.hpp)
       const long long left = (long long)deg - ((long long)(u - u0) << ushift);
       ucnt[u] = (unsigned char)(left < (1 << ushift) ? left : (1 << ushift));
     }
     const long long e0 = (long long)u0 << ushift, e1 = (long long)u1 << ushift;
     for (long long e = e0 + lane; e < e1; e += 64) {
       const long long k = e - e0;
-      ucol[e] = k < deg ? ci[r0 + k] : first;
+      ucol[e] = k < deg ? ci[r0 + k] : -1;        // -1: "visited" to a traversal (the sentinel word in front of the LDS bitmap), the identity to a reduction
     }
   }
 }
