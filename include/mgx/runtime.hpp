@@ -9,6 +9,7 @@
 //     allocates 4-5 temporaries per superstep);
 //   * errors are status codes / exceptions, never exit() (frontier.hxx:53-59).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -90,6 +91,11 @@ struct standard_context_t : context_t {
   // pinned mailbox for the 8-byte count read-backs (advance.hxx:43, filter.hxx:21).  Device-visible: the kernel that
   // produces a count stores it here itself (a hipMemcpyAsync D2H of 8 bytes is a blit kernel of its own: ~20 us)
   long long* mailbox = nullptr;
+  // mailbox[1]: the sequence number of the last count a kernel delivered (scan.hpp).  The host used to wait for the stream
+  // (hipStreamSynchronize: ~10-20 us of runtime wake-up per operator call, two calls per superstep of an enactor) -- now it
+  // spins on this word, which the producing kernel stores at system scope behind the count (MGX_OP_SPIN=0: the old wait)
+  long long mailbox_seq = 0;
+  bool mailbox_spin = true;
   int num_cus = 256;
   // single-pass scans (scan.hpp): one 64-bit status word per tile, tagged with the launch's epoch so that the array never
   // needs clearing, and the dynamic tile counter.  Private to those kernels (nothing else writes here: a stale word
@@ -116,6 +122,8 @@ struct standard_context_t : context_t {
     num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (print_prop) std::printf("%s : %d CUs\n", prop.name, num_cus);
     MGX_HIP(hipHostMalloc((void**)&mailbox, 64 * sizeof(long long), hipHostMallocDefault));
+    for (int i = 0; i < 64; ++i) mailbox[i] = 0;
+    if (const char* e = std::getenv("MGX_OP_SPIN")) mailbox_spin = std::atoi(e) != 0;
     reserve_scratch(1 << 20);
   }
   standard_context_t(const standard_context_t&) = delete;
@@ -136,6 +144,20 @@ struct standard_context_t : context_t {
   }
   void make_current() const { set_current_stream(_stream); }
   void synchronize() { MGX_HIP(hipStreamSynchronize(_stream)); }
+  // wait for the count a kernel of this context's stream delivers under sequence number `seq` (mailbox[0] then holds it)
+  void mailbox_wait(long long seq) {
+    if (mailbox_spin) {
+      volatile long long* const flag = mailbox + 1;
+      long long spins = 0;
+      while (*flag != seq) {
+        if (++spins > 20000000LL) { MGX_HIP(hipStreamSynchronize(_stream)); break; }      // (a failed launch: let the runtime report it)
+        __builtin_ia32_pause();
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    } else {
+      MGX_HIP(hipStreamSynchronize(_stream));
+    }
+  }
 
   // Make sure the arena holds `bytes`.  Called from constructors of graphs,
   // frontiers and problems -- never from an operator in steady state.

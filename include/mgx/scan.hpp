@@ -48,11 +48,18 @@ __global__ __launch_bounds__(BLOCK) void k_scan_tile_sums(F f, long long n, long
   }
 }
 
+// a count for the host: the value into the pinned mailbox, then -- system scope, release -- the sequence number the host spins on
+__device__ __forceinline__ void deliver_count(long long* mailbox, long long value, long long seq) {
+  mailbox[0] = value;
+  __threadfence_system();
+  __hip_atomic_store(mailbox + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- pass 2: one workgroup turns the partials into exclusive prefixes --------------------
 // partials[ntiles] receives the grand total.
 // total_out: device-visible (the pinned mailbox: the host reads it after the stream, no read-back copy) or NULL.
 __global__ __launch_bounds__(BLOCK) void k_scan_partials(long long* __restrict__ partials, long long ntiles,
-                                                          long long* __restrict__ total_out) {
+                                                          long long* __restrict__ total_out, long long seq = 0) {
   __shared__ long long sm[WAVES_PER_BLOCK + 1];
   long long carry = 0;
   for (long long base = 0; base < ntiles; base += BLOCK * SCAN_ITEMS) {     // 8 consecutive partials per thread
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_partials(long long* __restrict__
   }
   if (threadIdx.x == 0) {
     partials[ntiles] = carry;
-    if (total_out) *total_out = carry;
+    if (total_out) deliver_count(total_out, carry, seq);
   }
 }
 
@@ -142,7 +149,7 @@ __device__ __forceinline__ unsigned lb_look_back(const unsigned long long* statu
 template <typename F>
 __global__ __launch_bounds__(BLOCK) void k_scan_lookback(F f, long long n, int* __restrict__ out, unsigned long long* status,
                                                          unsigned* ticket, unsigned ticket_base, unsigned epoch,
-                                                         long long* total_dev, long long* total_host) {
+                                                         long long* total_dev, long long* total_host, long long seq) {
   __shared__ unsigned sm[WAVES_PER_BLOCK + 1];
   __shared__ unsigned s_tile, s_prefix;
   if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_lookback(F f, long long n, int* 
       s_prefix = prefix;
       if (tile == scan_num_tiles_dev(n) - 1) {
         if (total_dev) *total_dev = (long long)(prefix + tot);
-        if (total_host) *total_host = (long long)(prefix + tot);
+        if (total_host) deliver_count(total_host, (long long)(prefix + tot), seq);
       }
     }
   }
@@ -194,6 +201,7 @@ inline long long* transform_scan(F f, long long n, int* out, standard_context_t&
     throw mgx_error(MGX_E_INVALID, "scan: scratch arena too small (reserve_scratch was not called for this size)");
   hipStream_t st = ctx.stream();
   long long* const host_slot = host_total ? ctx.mailbox : (long long*)nullptr;
+  const long long seq = host_total ? ++ctx.mailbox_seq : 0;
   if (n > 0 && ntiles <= SCAN_LOOKBACK_MAX_TILES) {
     // every tile resident at once: a tile looks back over aggregates that are published as soon as their tiles have
     // summed up -- a handful of polls.  (With tens of thousands of tiles the look-back of each one crosses the ~2000
@@ -201,18 +209,21 @@ inline long long* transform_scan(F f, long long n, int* out, standard_context_t&
     // went from 2.5 to 2.9 ms with the single pass everywhere.)
     const unsigned epoch = ctx.next_lookback_epoch();
     hipLaunchKernelGGL(k_scan_lookback<F>, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, f, n, out, ctx.lookback_status,
-                       ctx.lookback_ticket, ctx.lookback_ticket_base, epoch, d_total, host_slot);
+                       ctx.lookback_ticket, ctx.lookback_ticket_base, epoch, d_total, host_slot, seq);
     ctx.lookback_ticket_base += (unsigned)ntiles;
   } else if (n > 0) {
     hipLaunchKernelGGL(k_scan_tile_sums<F>, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, f, n, partials);
-    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(BLOCK), 0, st, partials, ntiles, host_slot);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(BLOCK), 0, st, partials, ntiles, host_slot, seq);
     hipLaunchKernelGGL(k_scan_downsweep<F>, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, f, n, partials, out);
   } else {
     MGX_HIP(hipMemsetAsync(d_total, 0, sizeof(long long), st));
     ctx.mailbox[0] = 0;
   }
   if (host_total) {
-    MGX_HIP(hipStreamSynchronize(st));
+    if (n > 0) {
+      MGX_CHECK_LAUNCH("scan: kernel launch");
+      ctx.mailbox_wait(seq);        // (the rescan of the three-launch shape may still be running: the total does not wait for it)
+    }
     *host_total = n > 0 ? ctx.mailbox[0] : 0;
   }
   return d_total;
@@ -227,7 +238,7 @@ template <typename P>
 __global__ __launch_bounds__(BLOCK) void k_compact_upsweep(P pred, long long n, u64* __restrict__ bits,
                                                             long long* __restrict__ partials, unsigned long long* status,
                                                             unsigned* ticket, unsigned ticket_base, unsigned epoch,
-                                                            long long* total_host) {
+                                                            long long* total_host, long long seq) {
   __shared__ int sm[WAVES_PER_BLOCK + 1];
   __shared__ unsigned s_tile;
   // (tickets only where tiles wait for each other: ONE hot counter serves ~83 M returning adds a second, 57 000 tiles
@@ -269,7 +280,7 @@ __global__ __launch_bounds__(BLOCK) void k_compact_upsweep(P pred, long long n, 
       partials[tile] = (long long)prefix;
       if (tile == scan_num_tiles_dev(n) - 1) {
         partials[tile + 1] = (long long)(prefix + t);
-        if (total_host) *total_host = (long long)(prefix + t);
+        if (total_host) deliver_count(total_host, (long long)(prefix + t), seq);
       }
     }
   }
@@ -328,12 +339,14 @@ struct compact_t {
     if ((size_t)ntiles > ctx.lookback_tiles) throw mgx_error(MGX_E_INVALID, "compact: scratch arena too small");
     const bool single = ntiles <= SCAN_LOOKBACK_MAX_TILES;       // (see transform_scan)
     const unsigned epoch = single ? ctx.next_lookback_epoch() : 0u;
+    const long long seq = ++ctx.mailbox_seq;
     hipLaunchKernelGGL(k_compact_upsweep<P>, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, pred, n, bits, partials,
                        single ? ctx.lookback_status : (unsigned long long*)nullptr, ctx.lookback_ticket, ctx.lookback_ticket_base,
-                       epoch, ctx.mailbox);
+                       epoch, ctx.mailbox, seq);
     if (single) ctx.lookback_ticket_base += (unsigned)ntiles;
-    if (!single) hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(BLOCK), 0, st, partials, ntiles, ctx.mailbox);
-    MGX_HIP(hipStreamSynchronize(st));
+    if (!single) hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(BLOCK), 0, st, partials, ntiles, ctx.mailbox, seq);
+    MGX_CHECK_LAUNCH("compact: kernel launch");
+    ctx.mailbox_wait(seq);
     return ctx.mailbox[0];
   }
   template <typename E>
