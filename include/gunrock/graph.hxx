@@ -214,7 +214,9 @@ inline std::shared_ptr<graph_t> load_graph(const char* _name, bool _undir = fals
     return nullptr;
   }
   std::vector<std::tuple<int, int, float>> tuples;
-  tuples.reserve((size_t)nnz * (_undir ? 2 : 1));
+  // (room for what the size line promises -- up to a point: the line is not believed before the entries have been read; a
+  //  file that claims 2 G entries and holds two must not cost a 24 GB reservation first)
+  tuples.reserve(std::min((size_t)nnz * (_undir ? 2 : 1), (size_t)1 << 24));
   for (int e = 0; e < nnz; ++e) {
     int a, b, items;
     float w;
@@ -254,7 +256,8 @@ inline std::shared_ptr<graph_t> load_graph(const char* _name, bool _undir = fals
 // load_graph parses MatrixMarket TEXT and sorts the tuples on every run: minutes for a 69 M-edge file.  save_graph_cache
 // writes what it produced -- CSR (and the CSC when it is a genuine one) -- as raw arrays behind a small header;
 // load_graph_cache maps it back into a graph_t without parsing or sorting.  Layout (little endian, as the host):
-//   char magic[8] = "MGXCSR1\0"; int32 num_nodes, num_edges, undirected, has_csc; uint64 checksum (FNV-1a over the arrays)
+//   char magic[8] = "MGXCSR2\0"; int32 num_nodes, num_edges, undirected, has_csc; uint64 checksum (FNV-1a over the four header
+//   words and the arrays: a flipped `undirected` flag is a corrupt file too -- version 1 hashed the arrays only)
 //   int32 offsets[n + 1]; int32 indices[m]; float weights[m];  [ int32 col_offsets[n + 1]; int32 row_indices[m]; float row_weights[m] ]
 // A file that is truncated, has another magic or fails the checksum is rejected (nullptr / false): a cache is never trusted.
 namespace detail {
@@ -277,10 +280,11 @@ inline bool save_graph_cache(const char* path, const graph_t& g) {
   const bool has_csc = g.csc && g.csc != g.csr;
   FILE* f = fopen(path, "wb");
   if (!f) return false;
-  unsigned long long sum = detail::csr_checksum(*g.csr, 1469598103934665603ull);
-  if (has_csc) sum = detail::csr_checksum(*g.csc, sum);
-  const char magic[8] = {'M', 'G', 'X', 'C', 'S', 'R', '1', 0};
+  const char magic[8] = {'M', 'G', 'X', 'C', 'S', 'R', '2', 0};
   const int head[4] = {g.num_nodes, g.num_edges, g.undirected ? 1 : 0, has_csc ? 1 : 0};
+  unsigned long long sum = detail::fnv1a(head, sizeof(head), 1469598103934665603ull);
+  sum = detail::csr_checksum(*g.csr, sum);
+  if (has_csc) sum = detail::csr_checksum(*g.csc, sum);
   bool ok = fwrite(magic, 1, 8, f) == 8 && fwrite(head, sizeof(int), 4, f) == 4 && fwrite(&sum, sizeof(sum), 1, f) == 1;
   auto put = [&](const csr_t& c) {
     ok = ok && fwrite(c.offsets.data(), sizeof(int), c.offsets.size(), f) == c.offsets.size();
@@ -299,13 +303,28 @@ inline std::shared_ptr<graph_t> load_graph_cache(const char* path) {
   char magic[8];
   int head[4];
   unsigned long long sum = 0;
-  const char want[8] = {'M', 'G', 'X', 'C', 'S', 'R', '1', 0};
+  const char want[8] = {'M', 'G', 'X', 'C', 'S', 'R', '2', 0};
   if (fread(magic, 1, 8, f) != 8 || memcmp(magic, want, 8) != 0 || fread(head, sizeof(int), 4, f) != 4 ||
       fread(&sum, sizeof(sum), 1, f) != 1 || head[0] < 0 || head[1] < 0) {
     fclose(f);
     return nullptr;
   }
   const size_t n = (size_t)head[0], m = (size_t)head[1];
+  {
+    // the header is not believed before the file's LENGTH agrees with it: nothing is allocated by numbers a truncated or
+    // corrupt file merely claims (a flipped bit in num_nodes used to cost a multi-gigabyte allocation before the short read
+    // was noticed)
+    const unsigned long long per_csr = (unsigned long long)(n + 1) * sizeof(int) + (unsigned long long)m * (sizeof(int) + sizeof(float));
+    const unsigned long long expect = 8ull + 4ull * sizeof(int) + sizeof(sum) + per_csr * (head[3] ? 2ull : 1ull);
+    const long at = ftell(f);
+    bool size_ok = at >= 0 && fseek(f, 0, SEEK_END) == 0;
+    const long end = size_ok ? ftell(f) : -1;
+    size_ok = size_ok && end >= 0 && (unsigned long long)end == expect && (head[3] == 0 || head[3] == 1) && fseek(f, at, SEEK_SET) == 0;
+    if (!size_ok) {
+      fclose(f);
+      return nullptr;
+    }
+  }
   auto get = [&](std::shared_ptr<csr_t>& c) -> bool {
     c = std::make_shared<csr_t>();
     c->num_nodes = (int)n; c->num_edges = (int)m;
@@ -329,7 +348,8 @@ inline std::shared_ptr<graph_t> load_graph_cache(const char* path) {
   ok = ok && fread(&extra, 1, 1, f) == 0;                 // nothing behind the arrays
   fclose(f);
   if (!ok) return nullptr;
-  unsigned long long have = detail::csr_checksum(*g->csr, 1469598103934665603ull);
+  unsigned long long have = detail::fnv1a(head, sizeof(head), 1469598103934665603ull);
+  have = detail::csr_checksum(*g->csr, have);
   if (g->csc != g->csr) have = detail::csr_checksum(*g->csc, have);
   return have == sum ? g : nullptr;
 }
