@@ -178,6 +178,7 @@ struct bfs_fused_enactor_t {
       layout.old_of_new = g.d_old_of_new.data();
       if (g.ub_units > 0) {
         layout.ub_col = g.d_ub_col.data();
+        layout.ub_col24 = g.d_ub_col24.size() ? g.d_ub_col24.data() : nullptr;
         layout.ub_owner = g.d_ub_owner.data();
         layout.ub_units = g.ub_units;
         layout.ub_units_pad = g.ub_units_pad;

@@ -73,6 +73,10 @@ struct graph_device_t {
   // Unit blocks of the layout's long rows (mgx_layout.hip, mgx/bfs_fused_dense.hpp): rows of >= ub_min_degree edges
   // padded to 64-entry units, owner[u] = the row of unit u.  Built with the layout; optional.
   mem_t<int> d_ub_col;
+  // the unit blocks' entries once more, 24 bits each (3 bytes: 4 entries = 12 bytes, -1 = 0xFFFFFF), for graphs of at most
+  // 2^23 vertices: the fused BFS's unit-block body streams these -- a quarter less HBM traffic on the level that carries
+  // a traversal's edges (mgx/bfs_fused_dense.hpp).  Empty: not built (bigger graphs, MGX_BFS_PACK24=0).
+  mem_t<unsigned> d_ub_col24;
   mem_t<int> d_ub_owner;
   long long ub_units = 0, ub_units_pad = 0;
   int ub_min_degree = 0;

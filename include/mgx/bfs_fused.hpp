@@ -139,6 +139,7 @@ struct bfs_fused_args_t {
   int count_marks;         // the push kernels count their mark stores into ctrl->claims / claims_level (tools only)
   // unit blocks of the long rows (mgx_layout.hip: rows of >= long_min edges padded to 64-entry units; NULL: none)
   const int* ub_col;       // units_pad * 64 entries + 4 x (-1)
+  const u32* ub_col24;     // the same, 24 bits per entry (12 bytes per four entries); NULL: not available
   const int* ub_owner;     // units_pad owners (vertex id in the space of row_offsets; n for padding units)
   u32 ub_units;            // real units
   u32 ub_units_pad;        // multiple of 16
@@ -976,6 +977,7 @@ struct bfs_run_opts_t {
   int dense = -1;          // MGX_BFS_DENSE: 0 never, N > 0 dense_div = N
   int vshort = -1;         // MGX_BFS_VSHORT: 0 never, N > 0 vshort_div = N
   long long chain = -1;    // MGX_BFS_CHAIN_MAX_EDGES: 0 never (default BFS_CHAIN_CAP)
+  int pack24 = 1;                     // MGX_BFS_PACK24=0: the unit-block body reads the 32-bit entries even when the graph carries the 24-bit copy
   int src_plan = 1;                   // MGX_BFS_SRC_PLAN=0: every traversal gets the same launch sequence (no per-source classes)
   int defer_words = -1;               // MGX_BFS_DEFER_WORDS: words of the bitmap prefix whose marks are deferred (default: all BFS_FLUSH_WORDS)
   int defer_mul = 1, defer_div = 1;   // MGX_BFS_DEFER_REACH="mul/div": a level defers its hot marks while reached * mul < range * div
@@ -1023,6 +1025,7 @@ struct bfs_run_opts_t {
     getll("MGX_BFS_DEFER", o.defer);
     geti("MGX_BFS_DEFER_WORDS", o.defer_words);
     geti("MGX_BFS_SRC_PLAN", o.src_plan);
+    geti("MGX_BFS_PACK24", o.pack24);
     geti("MGX_BFS_COLD", o.cold);
     if (const char* e = getenv("MGX_BFS_DEFER_REACH")) {
       o.defer_mul = atoi(e);

@@ -27,11 +27,24 @@
 // bfs_fused_stream.hpp runs.  Labels are the same either way: both mark exactly the unvisited neighbours of the
 // frontier's long rows.
 #pragma once
+#include <type_traits>
 #include "bfs_fused.hpp"
 
 namespace mgx {
 
 typedef unsigned int bfs_u32x4 __attribute__((ext_vector_type(4)));   // (a builtin vector: __builtin_nontemporal_load wants one)
+typedef unsigned int bfs_u32x3 __attribute__((ext_vector_type(3)));   // four 24-bit entries (global_load_dwordx3: 4-byte alignment is all the hardware asks)
+
+// four 24-bit entries out of three words, sign-extended (0xFFFFFF -> -1: padding and the lanes of inactive units): 6 vector
+// instructions per four entries -- against a quarter of the level's HBM bytes
+__device__ __forceinline__ bfs_u32x4 bfs_unpack24(bfs_u32x3 w) {
+  bfs_u32x4 d;
+  d.x = (u32)__builtin_amdgcn_sbfe((int)w.x, 0, 24);
+  d.y = (u32)__builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(w.y, w.x, 24), 0, 24);
+  d.z = (u32)__builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(w.z, w.y, 16), 0, 24);
+  d.w = (u32)((int)w.z >> 8);
+  return d;
+}
 
 constexpr int BFS_DENSE_GROUP = 16;                 // units per group (the unit of interleaving)
 constexpr size_t bfs_dense_lds_bytes(int hotw) { return (size_t)hotw * 4 + 128; }
@@ -59,7 +72,9 @@ __device__ __forceinline__ u32* bfs_hot_setup(const bfs_fused_args_t& a, char* s
 }
 
 // the unit-block pass of one workgroup (block `block` of `nblocks`) over an LDS prefix that is already set up
-template <int NT, int HOTW, int GPS>
+// P24: the entries come from the 24-bit copy of the unit blocks (a.ub_col24; graphs of at most 2^23 vertices): 12 bytes per
+// lane and load instead of 16, unpacked when they are tested
+template <int NT, int HOTW, int GPS, bool P24 = false>
 __device__ __forceinline__ void bfs_dense_work(const bfs_fused_args_t& a, u32* const hot, u32 hot_n, u32 defer_n, u32 block,
                                                u32 nblocks, int& marks) {
   constexpr int NW = NT / WAVE;
@@ -95,7 +110,9 @@ __device__ __forceinline__ void bfs_dense_work(const bfs_fused_args_t& a, u32* c
     };
 
     constexpr int NL = 4 * GPS;               // loads per step
-    bfs_u32x4 dL[NL], dT[NL];
+    typedef typename std::conditional<P24, bfs_u32x3, bfs_u32x4>::type raw_t;     // what a lane's load returns
+    raw_t dL[NL], dT[NL];
+    const u32* __restrict__ ucol24 = a.ub_col24;
     // issue the 16-byte loads of groups k .. k + GPS - 1 of a batch whose activity bits are `act`
     auto issue = [&](u32 b, u32 k, u64 act) {
 #pragma unroll
@@ -106,7 +123,8 @@ __device__ __forceinline__ void bfs_dense_work(const bfs_fused_args_t& a, u32* c
         for (int j = 0; j < 4; ++j) {
           const bool on = (bits16 >> (4u * j + lane_q)) & 1u;
           const u32 e = on ? base + (u32)j * 256u + (u32)lane * 4u : dummy;
-          dL[4 * g + j] = __builtin_nontemporal_load((const bfs_u32x4*)(ucol + e));
+          if constexpr (P24) dL[4 * g + j] = __builtin_nontemporal_load((const bfs_u32x3*)(ucol24 + (size_t)(e >> 2) * 3u));   // (e is a multiple of 4)
+          else dL[4 * g + j] = __builtin_nontemporal_load((const bfs_u32x4*)(ucol + e));
         }
       }
     };
@@ -136,13 +154,18 @@ __device__ __forceinline__ void bfs_dense_work(const bfs_fused_args_t& a, u32* c
     auto test = [&]() {
       if (diag & 2) {                  // measurement only: consume the loads, test nothing
 #pragma unroll
-        for (int j = 0; j < NL; ++j) marks += (int)((dT[j].x ^ dT[j].y ^ dT[j].z ^ dT[j].w) == 0x12345678u);
+        for (int j = 0; j < NL; ++j) {
+          if constexpr (P24) marks += (int)((dT[j].x ^ dT[j].y ^ dT[j].z) == 0x12345678u);
+          else marks += (int)((dT[j].x ^ dT[j].y ^ dT[j].z ^ dT[j].w) == 0x12345678u);
+        }
         return;
       }
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
-        const u32 w0 = probe(dT[j].x), w1 = probe(dT[j].y), w2 = probe(dT[j].z), w3 = probe(dT[j].w);
-        decide(dT[j].x, w0); decide(dT[j].y, w1); decide(dT[j].z, w2); decide(dT[j].w, w3);
+        bfs_u32x4 d;
+        if constexpr (P24) d = bfs_unpack24(dT[j]); else d = dT[j];
+        const u32 w0 = probe(d.x), w1 = probe(d.y), w2 = probe(d.z), w3 = probe(d.w);
+        decide(d.x, w0); decide(d.y, w1); decide(d.z, w2); decide(d.w, w3);
       }
     };
 
@@ -198,7 +221,8 @@ __device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int sl
   const u32 hot_n = ((u32)a.n < (u32)(HOTW * 32)) ? (u32)a.n : (u32)(HOTW * 32);
   const u32 defer_n = bfs_defer_limit(a, hot_n);      // marks of the vertices in [0, defer_n) wait for the end of the workgroup
   int marks = 0;
-  bfs_dense_work<NT, HOTW, GPS>(a, hot, hot_n, defer_n, block, nblocks, marks);
+  if (a.ub_col24) bfs_dense_work<NT, HOTW, GPS, true>(a, hot, hot_n, defer_n, block, nblocks, marks);      // (grid-uniform)
+  else bfs_dense_work<NT, HOTW, GPS, false>(a, hot, hot_n, defer_n, block, nblocks, marks);
   (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, slot, s_int + 4, marks);
   bfs_body_finish(a, marks, slot, stat_level, s_int);
 }

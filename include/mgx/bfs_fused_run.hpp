@@ -34,6 +34,7 @@ struct bfs_layout_t {
   const int* new_of_old = nullptr;
   const int* old_of_new = nullptr;
   const int* ub_col = nullptr;
+  const unsigned* ub_col24 = nullptr;   // the same entries, 24 bits each (graphs of at most 2^23 vertices; NULL: none)
   const int* ub_owner = nullptr;
   long long ub_units = 0, ub_units_pad = 0;
   int ub_min_degree = 0;            // the rows the unit blocks hold: degree >= this (must equal the long-row threshold)
@@ -372,6 +373,7 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   const bool coldt = opt.cold_test >= 0 ? opt.cold_test != 0 : (bfs_cold_test(a.n, -1) && !units_avail);
   const bool units = units_avail && !coldt;
   a.ub_col = units ? layout->ub_col : nullptr;
+  a.ub_col24 = (units && st.opts.pack24) ? layout->ub_col24 : nullptr;
   a.ub_owner = units ? layout->ub_owner : nullptr;
   a.ub_units = units ? (u32)layout->ub_units : 0u;
   a.ub_units_pad = units ? (u32)layout->ub_units_pad : 0u;

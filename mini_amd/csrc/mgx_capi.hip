@@ -351,9 +351,22 @@ extern "C" int mgx_units_build_device(const int* ro, const int* ci, int n, int m
 // Unit blocks of the layout's long rows (mgx/bfs_fused_dense.hpp); MGX_BFS_UNITS=0 skips them.  The threshold is the
 // fused traversal's long-row threshold at build time (MGX_BFS_LONG_MIN, default 64; a unit is 64 entries whatever the
 // threshold); a run with another threshold ignores the blocks.
+namespace {
+// four 32-bit entries -> three words of 24-bit entries (little endian: entry k occupies bits [24 k, 24 k + 24) of the 96)
+__global__ __launch_bounds__(256) void k_pack24(const int4* __restrict__ in, long long quads, unsigned* __restrict__ out) {
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (long long)gridDim.x * blockDim.x) {
+    const int4 e = in[q];
+    const unsigned a = (unsigned)e.x & 0xFFFFFFu, b = (unsigned)e.y & 0xFFFFFFu, c = (unsigned)e.z & 0xFFFFFFu, d = (unsigned)e.w & 0xFFFFFFu;
+    out[3 * q + 0] = a | (b << 24);
+    out[3 * q + 1] = (b >> 8) | (c << 16);
+    out[3 * q + 2] = (c >> 16) | (d << 8);
+  }
+}
+}  // namespace
 static void build_unit_blocks(mgx_graph_s* g) {
   graph_device_t& G = *g->g;
   G.d_ub_col = mem_t<int>(); G.d_ub_owner = mem_t<int>(); G.ub_units = G.ub_units_pad = 0; G.ub_min_degree = 0;
+  G.d_ub_col24 = mem_t<unsigned>();
   G.d_ub_cnt = mem_t<unsigned char>(); G.d_ub_first = mem_t<int>(); G.nr_big_rows = 0; G.d_ub_w = mem_t<float>(); G.ub_w_tried = false;
   if (const char* e = getenv("MGX_BFS_UNITS")) if (atoi(e) == 0) return;
   int long_min = 64;
@@ -373,6 +386,16 @@ static void build_unit_blocks(mgx_graph_s* g) {
   // the neighbour-reduce over the unit blocks (mgx/nreduce.hpp) keeps its values and per-unit partials in the context's arena
   g->c->ctx->reserve_scratch(mgx::nr_scratch_bytes(G.num_nodes, units_pad, 8));
   G.ub_units = units; G.ub_units_pad = units_pad; G.ub_min_degree = long_min;
+  // 24-bit copy for the fused BFS (ids below 2^23: bit 23 of an entry is free, so a sign-extending unpack turns 0xFFFFFF
+  // back into -1); (units_pad * 64 + 4) entries -- the four -1 behind the blocks included -- are whole quads
+  bool pack = (long long)G.num_nodes <= (1ll << 23);
+  if (const char* e = getenv("MGX_BFS_PACK24")) pack = pack && atoi(e) != 0;
+  if (pack) {
+    const long long quads = ((long long)units_pad << 4) + 1;
+    G.d_ub_col24 = mem_t<unsigned>((size_t)quads * 3 + 4, *g->c->ctx);
+    hipLaunchKernelGGL(k_pack24, dim3(mgx::grid_for(quads, 256, 16384)), dim3(256), 0, g->c->ctx->stream(), (const int4*)G.d_ub_col.data(), quads,
+                       G.d_ub_col24.data());
+  }
 }
 extern "C" int mgx_cold_build_device(const int* ro, const int* ci, int n, int row0, int rows, int min_deg, unsigned hot_n, unsigned slice_n,
                                      int slices, int** owner, int** dst, long long* pairs, int* slice_off, hipStream_t stream);
