@@ -377,7 +377,10 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   a.ub_owner = units ? layout->ub_owner : nullptr;
   a.ub_units = units ? (u32)layout->ub_units : 0u;
   a.ub_units_pad = units ? (u32)layout->ub_units_pad : 0u;
-  a.dense_div = !units ? 0u : (opt.dense >= 0 ? (u32)opt.dense : st.dense_div);
+  // (with the 24-bit copy a unit costs three quarters of the bytes: the unit-block body wins from an eighth of the units on
+  //  -- RMAT-22, per call: 1/2 0.3282, 1/4 0.3262, 1/8 0.3215, 1/16 0.3250 ms; with 32-bit entries 1/2 was best)
+  const bool packed = units && st.opts.pack24 && layout->ub_col24 != nullptr;
+  a.dense_div = !units ? 0u : (opt.dense >= 0 ? (u32)opt.dense : (packed ? 8u : st.dense_div));
   // short rows vertex by vertex: the layout's own degree-sorted CSR with its padding, the threshold it was cut for
   const bool vs = relabelled && layout->vs_dummy != 0 && layout->vs_long_min == st.long_min && st.long_min > 0 && !coldt && !lab_flags &&
                   layout->vs_edges > 0;
