@@ -13,18 +13,16 @@ namespace filter {
 template <typename Problem, typename Functor>
 int filter_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<frontier_t<int>>& input,
                   std::shared_ptr<frontier_t<int>>& output, int iteration, standard_context_t& context) {
-  auto compact = mgx::transform_compact((long long)input->size(), context);
-  const int* input_data = input->data()->data();
-  typename Problem::data_slice_t* data = problem->d_data_slice.data();
-  const long long stream_count = compact.upsweep([=] __device__(long long idx) {
-    const int item = input_data[idx];
-    return Functor::cond_filter(item, data, iteration);
-  });
-  output->resize((size_t)stream_count);
-  int* output_data = output->data()->data();
-  compact.downsweep(
-      [=] __device__(long long dest_idx, long long source_idx) { output_data[dest_idx] = input_data[source_idx]; });
-  return (int)stream_count;
+  // two launches over the same ballots: the first evaluates the functor once per element and counts (the count is the
+  // operator's return value: it has to reach the host anyway), the second scatters the survivors -- it reads only them
+  const int* const candidates = input->data()->data();
+  typename Problem::data_slice_t* const slice = problem->d_data_slice.data();
+  auto pass = mgx::transform_compact((long long)input->size(), context);
+  const long long kept = pass.upsweep([=] __device__(long long i) { return Functor::cond_filter(candidates[i], slice, iteration); });
+  output->resize((size_t)kept);
+  int* const survivors = output->data()->data();
+  pass.downsweep([=] __device__(long long to, long long from) { survivors[to] = candidates[from]; });
+  return (int)kept;
 }
 
 // uniquify_kernel (filter.hxx:95-119): the filter of the IDEMPOTENT traversal mode -- advance<idempotence = true>
@@ -44,24 +42,22 @@ template <typename Problem, typename ProblemFunctor>
 void uniquify_kernel(std::shared_ptr<Problem> problem, unsigned char* d_visited_mask,
                      std::shared_ptr<frontier_t<int>>& input, std::shared_ptr<frontier_t<int>>& output,
                      int iteration, standard_context_t& context) {
-  auto compact = mgx::transform_compact((long long)input->size(), context);
-  const int* input_data = input->data()->data();
-  typename Problem::data_slice_t* data = problem->d_data_slice.data();
-  unsigned* mask_words = (unsigned*)d_visited_mask;   // caller allocates (n+31)/32 words
-  const long long stream_count = compact.upsweep([=] __device__(long long idx) {
-    const int item = input_data[idx];
-    if (item < 0) return false;
-    const unsigned bit = 1u << (item & 31);
-    if (mask_words[item >> 5] & bit) return false;     // seen in an earlier call (or earlier in this one)
-    if (!mgx::wave_first_of_equal(item)) return false;  // another lane of this wave carries it on
-    const unsigned old = atomicOr(mask_words + (item >> 5), bit);
-    if (old & bit) return false;   // seen it
-    return ProblemFunctor::cond_uniq(item, data, iteration);
+  const int* const candidates = input->data()->data();
+  typename Problem::data_slice_t* const slice = problem->d_data_slice.data();
+  unsigned* const seen = (unsigned*)d_visited_mask;   // caller allocates (n+31)/32 words
+  auto pass = mgx::transform_compact((long long)input->size(), context);
+  const long long kept = pass.upsweep([=] __device__(long long i) {
+    const int v = candidates[i];
+    if (v < 0) return false;
+    const unsigned bit = 1u << (v & 31);
+    if (seen[v >> 5] & bit) return false;               // in an earlier call (or earlier in this one)
+    if (!mgx::wave_first_of_equal(v)) return false;     // another lane of this wave carries it on
+    if (atomicOr(seen + (v >> 5), bit) & bit) return false;   // somebody else got there first
+    return ProblemFunctor::cond_uniq(v, slice, iteration);
   });
-  output->resize((size_t)stream_count);
-  int* output_data = output->data()->data();
-  compact.downsweep(
-      [=] __device__(long long dest_idx, long long source_idx) { output_data[dest_idx] = input_data[source_idx]; });
+  output->resize((size_t)kept);
+  int* const survivors = output->data()->data();
+  pass.downsweep([=] __device__(long long to, long long from) { survivors[to] = candidates[from]; });
 }
 
 }  // namespace filter

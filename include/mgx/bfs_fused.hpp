@@ -1091,7 +1091,8 @@ struct bfs_fused_state_t {
   // ... and per source class (bfs_classify_source, bfs_fused_run.hpp: 1 = the M launch in front absorbs the first level the
   // chain leaves, 2 = that level is too big for it and the launch is not enqueued): the slots the last four traversals of
   // the class needed under ITS launch sequence; a class without history takes the graph's hint
-  int cls_need[3][4] = {{1, 1, 1, 1}, {1, 1, 1, 1}, {1, 1, 1, 1}}, cls_at[3] = {0, 0, 0};
+  int cls_max[3] = {0, 0, 0}, cls_at[3] = {0, 0, 0};   // the most any traversal of the class has needed on this handle (never shrinks: a
+                                                        // class whose members differ -- RMAT-24: 3 or 4 slots -- must not oscillate into re-runs)
   int auto_spare = 0, clean_batches = 0;             // batches (bfs_fused_run_many): spare slots learnt from re-runs, batches without one since
   int tail_from = 1 << 30;           // slots from this one on get an in-place chain launch in front (learnt from the previous traversal)
   unsigned lazy_div = 4;             // the build behind a push with >= n / lazy_div mark stores writes no queues (bfs_build_is_lazy; 0: never)

@@ -484,21 +484,11 @@ inline int bfs_classify_source(const bfs_fused_state_t& st, const bfs_launch_pla
 }
 // device-wide slots a traversal of class `cls` gets: what the last traversals of the class needed, else the graph's hint
 inline int bfs_class_slots(const bfs_fused_state_t& st, int cls) {
-  auto known = [&](int c) {
-    int h = 0;
-    for (int i = 0; i < 4 && i < st.cls_at[c]; ++i) h = st.cls_need[c][i] > h ? st.cls_need[c][i] : h;
-    return h;
-  };
   if (cls == BFS_SRC_UNKNOWN) return st.slots_hint;
-  if (st.cls_at[cls] > 0) return known(cls);
-  // no traversal of this class yet: the other class's need, one slot apart -- the level the M launch absorbs for an ABSORB
-  // source is the one that takes a SKIP source's first device-wide slot (a guess: a traversal that does not finish in its
-  // slots is run again and then IS the class's history)
-  const int other = cls == BFS_SRC_ABSORB ? BFS_SRC_SKIP : BFS_SRC_ABSORB;
-  if (st.cls_at[other] > 0) {
-    const int h = known(other) + (cls == BFS_SRC_SKIP ? 1 : -1);
-    return h > 1 ? h : 1;
-  }
+  if (st.cls_at[cls] > 0) return st.cls_max[cls];
+  // no traversal of this class yet: a SKIP source needs the slot an ABSORB source's M launch saves; an ABSORB source
+  // without history gets the graph's (conservative) number
+  if (cls == BFS_SRC_SKIP && st.cls_at[BFS_SRC_ABSORB] > 0) return st.cls_max[BFS_SRC_ABSORB] + 1 > st.slots_hint ? st.cls_max[BFS_SRC_ABSORB] + 1 : st.slots_hint;
   return st.slots_hint;
 }
 
@@ -590,7 +580,8 @@ inline void bfs_learn_slots(bfs_fused_state_t& st, const bfs_fused_args_t& a, co
     return k > 0 ? k : 1;
   };
   if (cls != BFS_SRC_UNKNOWN) {                               // what this class needs under ITS sequence (SKIP: no M launch in front)
-    st.cls_need[cls][st.cls_at[cls] & 3] = slots_needed(cls != BFS_SRC_SKIP);
+    const int need_cls = slots_needed(cls != BFS_SRC_SKIP);
+    if (need_cls > st.cls_max[cls]) st.cls_max[cls] = need_cls;
     st.cls_at[cls] += 1;
   }
   const int need = slots_needed(true);                        // ... and the graph-wide sequence, whoever ran
