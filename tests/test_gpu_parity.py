@@ -620,7 +620,12 @@ VARIANTS = [{}, {"MGX_BFS_COLD_TEST": "1"}, {"MGX_BFS_COLD_TEST": "1", "MGX_BFS_
             {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_SSTREAM": "1"}, {"MGX_BFS_SSTREAM": "1"},
             {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_LONG_MIN": "8", "MGX_BFS_DENSE": "1000000", "MGX_BFS_SSTREAM": "1"},
             {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_LONG_MIN": "1", "MGX_BFS_SSTREAM": "1"},
-            {"MGX_BFS_MINI": "2"}, {"MGX_BFS_MINI": "0", "MGX_BFS_TAIL_FRONT": "0"}, {"MGX_BFS_TAIL_CHAIN": "0"}, {"MGX_BFS_CHAIN_BIG_EDGES": "100"}, {"MGX_BFS_CHAIN_MAX_EDGES": "64", "MGX_BFS_CHAIN_BIG_EDGES": "12288", "MGX_BFS_LAZY": "1048576"}]
+            {"MGX_BFS_MINI": "2"}, {"MGX_BFS_MINI": "0", "MGX_BFS_TAIL_FRONT": "0"}, {"MGX_BFS_TAIL_CHAIN": "0"}, {"MGX_BFS_CHAIN_BIG_EDGES": "100"}, {"MGX_BFS_CHAIN_MAX_EDGES": "64", "MGX_BFS_CHAIN_BIG_EDGES": "12288", "MGX_BFS_LAZY": "1048576"},
+            # round 4: the unit blocks' 32-bit entries instead of the 24-bit copy (every level on them / by the default rule), the deferred
+            # range shortened to one run and to a third, the per-source launch plan off / on with M launches forced on small graphs
+            {"MGX_BFS_PACK24": "0", "MGX_BFS_DENSE": "1000000"}, {"MGX_BFS_PACK24": "0"}, {"MGX_BFS_DENSE": "1000000", "MGX_BFS_DEFER": "1", "MGX_BFS_DEFER_WORDS": "32"},
+            {"MGX_BFS_DEFER_WORDS": "6016", "MGX_BFS_DEFER": "1", "MGX_BFS_HOT_MIN_EDGES": "0"}, {"MGX_BFS_DEFER_WORDS": "0"},
+            {"MGX_BFS_MINI": "2", "MGX_BFS_SRC_PLAN": "0"}, {"MGX_BFS_MINI": "2", "MGX_BFS_SRC_PLAN": "1", "MGX_BFS_CHAIN_BIG_EDGES": "64"}]
 
 
 @pytest.mark.parametrize("variant", range(len(VARIANTS)))
@@ -967,6 +972,49 @@ def test_bfs_run_many_reruns_a_traversal_that_needs_more_slots(gpu_ctx, oracle, 
     sts, reruns2 = bfs.run_many([far, far], mini_amd.MGX_BFS_PUSH, 0.0)
     assert np.array_equal(bfs.labels(), oracle.bfs_cpu(ro, ci, far))
     assert (sts[1]["m_t"], sts[1]["levels"]) == (ref_far["m_t"], ref_far["levels"])
+
+
+def test_bfs_per_source_launch_plan(gpu_ctx, oracle, monkeypatch):
+    """round 4: the launch sequence of a traversal is chosen per source from graph_device_t::src_shapes (exact shapes of levels
+    0 and 1): sources whose first non-chained level is mid-size (the M launch in front absorbs it), sources whose level 1 is too
+    big for it (that launch is not enqueued), sources whose levels 0 and 1 both run in the chain -- single calls and batches,
+    every order, labels and counters against the oracle and against the plan switched off; no traversal is run twice once
+    every class has been seen"""
+    import mini_amd
+    monkeypatch.setenv("MGX_BFS_MINI", "2")          # (small graphs get no M launches by default)
+    rng = np.random.default_rng(77)
+    # hubs of 3 000 .. 5 000 entries (their neighbours' level is far above an M launch's 32 768 early edges for some sources,
+    # below it for others), a long tail of leaves, isolated vertices
+    h, n = 40, 90000
+    deg = rng.integers(3000, 5000, size=h)
+    t0 = np.concatenate([np.repeat(np.arange(h), deg), rng.integers(h, n - 500, size=60000)]).astype(np.int32)
+    t1 = np.concatenate([rng.integers(h, n - 500, size=int(deg.sum())), rng.integers(h, n - 500, size=60000)]).astype(np.int32)
+    ro, ci, _ = oracle.csr_from_tuples(n, t0, t1, None, undir=True)
+    d = np.diff(ro)
+    leaves = np.where((d > 0) & (d <= 3))[0]
+    mids = np.where((d >= 20) & (d < 64))[0]
+    srcs = [0, 7, int(leaves[0]), int(leaves[len(leaves) // 2]), int(leaves[-1])] + [int(v) for v in mids[:3]] + [n - 1]
+    results = {}
+    for plan in ("1", "0"):
+        monkeypatch.setenv("MGX_BFS_SRC_PLAN", plan)
+        g = _graph(gpu_ctx, ro, ci)
+        g.build_layout()
+        bfs = mini_amd.BfsProblem(g, srcs[0])
+        for rep in range(2):
+            for s in srcs:
+                st = bfs.run(s)
+                want = oracle.bfs_cpu(ro, ci, s)
+                assert np.array_equal(bfs.labels(), want), (plan, rep, s)
+                assert st["m_t"] == int(d[want >= 0].sum()) and (d[s] == 0 or st["levels"] == int(want.max()) + 1), (plan, rep, s, st)
+        for rot in range(len(srcs)):
+            batch = srcs[rot:] + srcs[:rot]
+            sts, reruns = bfs.run_many(batch, mini_amd.MGX_BFS_PUSH, 0.0)
+            assert np.array_equal(bfs.labels(), oracle.bfs_cpu(ro, ci, batch[-1])), (plan, rot)
+            results[(plan, rot)] = [(x["m_t"], x["reached"], x["levels"]) for x in sts]
+            if rot >= 2:
+                assert reruns == 0, (plan, rot, reruns)
+    for rot in range(len(srcs)):
+        assert results[("1", rot)] == results[("0", rot)], rot
 
 
 @pytest.mark.parametrize("layout", [False, True])
