@@ -16,9 +16,16 @@ dev = torch.device("cuda", 0)
 ctx = mini_amd.Context(0, torch.cuda.current_stream().cuda_stream)
 n = 1 << scale
 engs = []
+t_shard = t_eng = 0.0
 for r in range(G):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
     ro, col, new_of_old, old_of_new, deg_new = rmat_cyclic_shard(ctx, scale, 16, scale, G, r, dev)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
     engs.append(HipRankEngine2(ctx, n, G, r, ro, col))
+    torch.cuda.synchronize(); t_shard += t1 - t0; t_eng += time.perf_counter() - t1
+# what ONE rank spends before its first traversal: its shard out of the whole pair stream (every rank hashes all edgefactor * n
+# pairs twice -- degrees, then its own rows' keys -- and sorts its keys), then unit blocks + cold-edge lists of its rows
+print("setup per rank: shard (mgx_dbfs2_shard_plan + _fill) %.3f s, engine (unit blocks, cold-edge lists) %.3f s" % (t_shard / G, t_eng / G))
 srcs = [int(v) for v in torch.nonzero(deg_new > 0)[:: max(1, n // 64)][:6, 0].tolist()]
 hint = 8
 for it, s in enumerate(srcs):

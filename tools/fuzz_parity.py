@@ -126,7 +126,10 @@ for name, n, ro, ci, w in graphs():
                      "MGX_BFS_MERGED_PULL": rng.choice(["", "0"]), "MGX_BFS_DO_CHAIN": rng.choice(["", "0"]),
                      "MGX_BFS_SSTREAM": rng.choice(["", "1"]), "MGX_SSSP_BUILD_LIST": rng.choice(["", "1"]),
                      "MGX_SSSP_SLICED": rng.choice(["", "", "3"]), "MGX_BFS_MINI": rng.choice(["", "0", "2"]),
-                     "MGX_SSSP_DENSE": rng.choice(["", "0", "1000000000"])}
+                     "MGX_SSSP_DENSE": rng.choice(["", "0", "1000000000"]),
+                     # round 4: 24-bit unit blocks on / off, the deferred range, the per-source launch plan
+                     "MGX_BFS_PACK24": rng.choice(["", "0"]), "MGX_BFS_DEFER_WORDS": rng.choice(["", "32", "4096", "0"]),
+                     "MGX_BFS_SRC_PLAN": rng.choice(["", "0"])}
             for kk, vv in knobs.items():
                 if vv == "":
                     os.environ.pop(kk, None)
@@ -141,7 +144,7 @@ for name, n, ro, ci, w in graphs():
                 assert np.array_equal(bfs.labels(), want), (name, n, src, "do", alpha, direct, layout)
         for kk in ("MGX_BFS_CHAIN_MAX_EDGES", "MGX_BFS_DENSE", "MGX_BFS_LAZY", "MGX_BFS_VSHORT", "MGX_BFS_DEFER", "MGX_BFS_SEED_CHAIN",
                    "MGX_BFS_TAIL_CHAIN", "MGX_BFS_CHAIN_BIG_EDGES", "MGX_BFS_COLD", "MGX_BFS_DEFER_REACH", "MGX_BFS_MERGED_PULL",
-                   "MGX_BFS_DO_CHAIN", "MGX_BFS_SSTREAM", "MGX_BFS_MINI"):
+                   "MGX_BFS_DO_CHAIN", "MGX_BFS_SSTREAM", "MGX_BFS_MINI", "MGX_BFS_PACK24", "MGX_BFS_DEFER_WORDS", "MGX_BFS_SRC_PLAN"):
             os.environ.pop(kk, None)
         if src == srcs[0] and (n <= 150000 or (n >= (1 << 20) and ran % 2 == 0)):
             # the partitioned engine's rank engines in this process: small graphs, and R-MAT 20 / 21 (the ranks' cold-edge pass);
@@ -179,6 +182,13 @@ for name, n, ro, ci, w in graphs():
         mini_amd.segreduce(g, f, torch.from_numpy(fv).cuda(), 0.0, redf, "f32_plus")
         want_f, _ = orc.neighbor_reduce_f32_plus(ro, ci, ids, fv, 0.0)
         assert np.array_equal(redf.cpu().numpy(), want_f), (name, n, "neighbour-reduce f32", layout)
+    # k-core decomposition (round 4): the enactor on filter / advance<has_output=false> / filter against the validator's restatement
+    if symmetric and n <= 300000 and len(ci) > 0 and ran % 3 == 0:
+        kc = mini_amd.KcoreProblem(g)
+        largest, kst = kc.enact()
+        wc, wl = orc.kcore_cpu(ro, ci)
+        assert largest == wl and np.array_equal(kc.num_cores(), wc), (name, n, "k-core", largest, wl)
+        kc.close()
     ran += 1
     print("ok %-18s n=%-7d m=%-9d layout=%d" % (name, n, len(ci), layout), flush=True)
 print("fuzz: %d graphs, all equal to the oracle" % ran)
