@@ -80,7 +80,6 @@ timeout 600 python tools/bfs_operator_bench.py 22 > $O/bfs_operator_s22.log 2>&1
 timeout 600 python tools/sssp_bench.py > $O/sssp_s22.log 2>&1
 timeout 600 python tools/pr_bench.py > $O/pr_s22.log 2>&1
 timeout 600 python tools/kcore_bench.py 20 > $O/kcore_s20.log 2>&1
-timeout 900 bash tools/host_asan/run.sh > $O/host_asan.log 2>&1; echo "host asan rc=$?" >> $O/host_asan.log
 for a in 0.01 1 4 16 64 256 1000; do
   timeout 300 python bench.py --mode do --alpha $a --steps 16 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "
 import sys, json
@@ -92,7 +91,7 @@ cat $O/summary.txt
 # what goes under profiles/ (the caller copies gpurun_out/round/keep/* to profiles/rNN/ and pmc_traffic.json to profiles/)
 mkdir -p $O/keep
 cp $O/summary.txt $O/summary.json $O/kernel_stats_mgx.csv $O/kernel_stats_sssp.csv $O/kernel_stats_pr.csv $O/levels.log $O/sssp_iterations.log $O/timeline.txt $O/keep/ 2>/dev/null
-cp $O/pmc_traffic.json $O/bfs_operator_s22.log $O/dobfs_alpha_sweep.txt $O/sssp_s22.log $O/pr_s22.log $O/kcore_s20.log $O/host_asan.log $O/keep/ 2>/dev/null
+cp $O/pmc_traffic.json $O/bfs_operator_s22.log $O/dobfs_alpha_sweep.txt $O/sssp_s22.log $O/pr_s22.log $O/kcore_s20.log $O/keep/ 2>/dev/null
 cp $O/dist2_single_*.log $O/kernel_stats_dist2_25_8.csv $O/keep/ 2>/dev/null
 grep '^{' $O/bench_driver_cmd.log | tail -1 > $O/keep/bench_line_driver_cmd.json
 grep '^{' $O/bench.log | tail -1 > $O/keep/bench_line.json
