@@ -81,6 +81,7 @@ struct graph_device_t {
   long long ub_units = 0, ub_units_pad = 0;
   int ub_min_degree = 0;
   mem_t<float> d_ub_w;               // weights of the unit blocks' entries (fused SSSP's heavy iterations); built on first use
+  mem_t<unsigned short> d_ub_w16;    // the same weights as IEEE halves, kept only when every one of them is exact that way (fused SSSP's sweep, 24-bit entries)
   bool ub_w_tried = false;
   mem_t<unsigned char> d_ub_cnt;     // real entries of every unit (the rest is padding): what a reduction may count (mgx/nreduce.hpp)
   mem_t<int> d_ub_first;             // n + 1: the units of layout row v are [ub_first[v], ub_first[v + 1])

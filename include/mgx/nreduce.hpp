@@ -25,6 +25,7 @@
 // order is moderngpu's and unpinned): the tests compare with 2e-5 relative.
 #pragma once
 #include <cstdlib>
+#include <type_traits>
 
 #include "runtime.hpp"
 #include "wave.hpp"
@@ -43,6 +44,7 @@ struct nr_layout_t {
   const int* col_indices = nullptr;
   const int* old_of_new = nullptr;
   const int* ub_col = nullptr;            // unit blocks of the rows of >= 64 entries
+  const u32* ub_col24 = nullptr;          // the same entries, 24 bits each (graphs of at most 2^23 vertices; NULL: none): 12 instead of 16 bytes per lane and load
   const unsigned char* ub_cnt = nullptr;  // real entries of every unit (1 .. 64; 0 for padding units)
   const int* ub_first = nullptr;          // n + 1: units of row v = [ub_first[v], ub_first[v + 1])
   u32 ub_units = 0, ub_units_pad = 0;
@@ -94,7 +96,8 @@ struct __attribute__((aligned(4))) nr_u32x4u { u32 x, y, z, w; };   // 16-byte l
 typedef unsigned int nr_u32x4 __attribute__((ext_vector_type(4)));
 
 // the long rows' part of one workgroup (block `block` of `nblocks`); hot: the LDS values, already set up
-template <typename V, typename Op, int NT>
+typedef unsigned int nr_u32x3 __attribute__((ext_vector_type(3)));
+template <typename V, typename Op, int NT, bool P24 = false>
 __device__ __forceinline__ void nr_long_work(const nr_layout_t& L, const V* __restrict__ vals, const V* hot, u32 hot_n, V* __restrict__ partial,
                                              V identity, Op op, u32 block, u32 nblocks) {
   constexpr int NW = NT / WAVE;
@@ -110,8 +113,10 @@ __device__ __forceinline__ void nr_long_work(const nr_layout_t& L, const V* __re
   constexpr int GPS = 2, NL = 4 * GPS;
   // (a unit's padding entries are -1 -- the identity to nr_fetch -- so nothing has to say how many of its 64 entries are real:
   //  the per-unit counts this loop used to load, one byte per lane and 16-byte load, doubled its memory instructions)
-  nr_u32x4 cur[NL], nxt[NL];
-  auto issue = [&](u32 g0, nr_u32x4* d) {
+  typedef typename std::conditional<P24, nr_u32x3, nr_u32x4>::type raw_t;
+  const u32* __restrict__ ucol24 = L.ub_col24;
+  raw_t cur[NL], nxt[NL];
+  auto issue = [&](u32 g0, raw_t* d) {
 #pragma unroll
     for (int k = 0; k < GPS; ++k) {
       const u32 g = g0 + (u32)k * W;
@@ -119,7 +124,8 @@ __device__ __forceinline__ void nr_long_work(const nr_layout_t& L, const V* __re
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const u32 u = gg * 16u + 4u * (u32)j + q;
-        d[4 * k + j] = __builtin_nontemporal_load((const nr_u32x4*)(ucol + ((size_t)u << 6) + sub * 4u));
+        if constexpr (P24) d[4 * k + j] = __builtin_nontemporal_load((const nr_u32x3*)(ucol24 + (((size_t)u << 4) + sub) * 3u));
+        else d[4 * k + j] = __builtin_nontemporal_load((const nr_u32x4*)(ucol + ((size_t)u << 6) + sub * 4u));
       }
     }
   };
@@ -131,8 +137,15 @@ __device__ __forceinline__ void nr_long_work(const nr_layout_t& L, const V* __re
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       const bool real = g0 + (u32)(j / 4) * W < G;    // (wave-uniform)
-      const u32 d0 = real ? cur[j].x : 0xFFFFFFFFu, d1 = real ? cur[j].y : 0xFFFFFFFFu;
-      const u32 d2 = real ? cur[j].z : 0xFFFFFFFFu, d3 = real ? cur[j].w : 0xFFFFFFFFu;
+      u32 e0, e1, e2, e3;
+      if constexpr (P24) {                            // (sign-extending: 0xFFFFFF comes back as -1)
+        e0 = (u32)__builtin_amdgcn_sbfe((int)cur[j].x, 0, 24);
+        e1 = (u32)__builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(cur[j].y, cur[j].x, 24), 0, 24);
+        e2 = (u32)__builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(cur[j].z, cur[j].y, 16), 0, 24);
+        e3 = (u32)((int)cur[j].z >> 8);
+      } else { e0 = cur[j].x; e1 = cur[j].y; e2 = cur[j].z; e3 = cur[j].w; }
+      const u32 d0 = real ? e0 : 0xFFFFFFFFu, d1 = real ? e1 : 0xFFFFFFFFu;
+      const u32 d2 = real ? e2 : 0xFFFFFFFFu, d3 = real ? e3 : 0xFFFFFFFFu;
       val[j][0] = nr_fetch(d0, vals, hot, hot_n, identity); val[j][1] = nr_fetch(d1, vals, hot, hot_n, identity);
       val[j][2] = nr_fetch(d2, vals, hot, hot_n, identity); val[j][3] = nr_fetch(d3, vals, hot, hot_n, identity);
     }
@@ -259,7 +272,8 @@ __global__ __launch_bounds__(NT, WPE) void k_nr_edges(nr_layout_t L, const V* __
   const V* const hot = nr_hot_setup<V, NT>(smem, vals, hot_n);
   // every workgroup takes its share of BOTH parts, one after the other over the same LDS values: the parts differ in cost
   // per entry (the short rows pay a planning load per vertex), so any fixed split of the grid leaves one half waiting
-  nr_long_work<V, Op, NT>(L, vals, hot, hot_n, partial, identity, op, blockIdx.x, gridDim.x);
+  if (L.ub_col24) nr_long_work<V, Op, NT, true>(L, vals, hot, hot_n, partial, identity, op, blockIdx.x, gridDim.x);      // (grid-uniform)
+  else nr_long_work<V, Op, NT, false>(L, vals, hot, hot_n, partial, identity, op, blockIdx.x, gridDim.x);
   nr_short_work<V, Op, NT>(L, vals, hot, hot_n, reduced, identity, op, blockIdx.x, gridDim.x);
 }
 

@@ -46,6 +46,8 @@
 // 0.44 -- the pass over all 18 M short-row entries costs ~0.15 ms whatever the frontier (two dependent gathers per entry), more
 // than the atomics it replaces.
 #pragma once
+#include <hip/hip_fp16.h>
+#include <type_traits>
 #include <vector>
 #include "bfs_fused.hpp"
 
@@ -83,6 +85,11 @@ struct sssp_args_t {
   const float* ub_w;
   const unsigned char* ub_cnt;
   const int* ub_owner;
+  // the same entries as 24-bit ids and the same weights as IEEE halves (round 4; both or neither: graphs of at most 2^23
+  // vertices whose weights are ALL exactly representable in 16 bits -- small integers, for one): 5 instead of 8 bytes per
+  // entry of the sweep's stream, the arithmetic unchanged (a half converts to the float it was made from)
+  const u32* ub_col24;
+  const unsigned short* ub_w16;
   u32 ub_units_pad;
   u32 vs_v[4];
   u32 dense_div;         // an iteration whose frontier holds >= m / dense_div edges takes the sweep (0: never)
@@ -110,6 +117,8 @@ struct sssp_layout_t {
   const float* ub_w = nullptr;
   const unsigned char* ub_cnt = nullptr;
   const int* ub_owner = nullptr;
+  const unsigned* ub_col24 = nullptr;            // 24-bit entries / half weights (see sssp_args_t); NULL: not available
+  const unsigned short* ub_w16 = nullptr;
   unsigned ub_units_pad = 0;
   unsigned vs_v[4] = {0, 0, 0, 0};
 };
@@ -243,7 +252,13 @@ __device__ __forceinline__ void sssp_relax4(const u32 (&dd)[4], const u32 (&nd)[
     }
 }
 
-template <int NT, bool LIVE>
+typedef unsigned int sssp_u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned int sssp_u32x2 __attribute__((ext_vector_type(2)));
+
+// PACKED: the entries as 24-bit ids (12 bytes per lane and load) and the weights as halves (8 bytes) -- a.ub_col24 / a.ub_w16.
+// A unit's padding entries are -1 (no candidate: sssp_gather_index), a padding unit belongs to vertex n: nothing has to say
+// how many entries of a unit are real.
+template <int NT, bool LIVE, bool PACKED>
 __device__ __forceinline__ void sssp_dense_long(const sssp_args_t& a, void* table, u32 hot_n, u32 block, u32 nblocks) {
   constexpr int NW = NT / WAVE;
   const int lane = lane_id();
@@ -254,34 +269,41 @@ __device__ __forceinline__ void sssp_dense_long(const sssp_args_t& a, void* tabl
   if (w >= H) return;
   const int* __restrict__ ucol = a.ub_col;
   const float* __restrict__ uw = a.ub_w;
-  const unsigned char* __restrict__ ucnt = a.ub_cnt;
+  const u32* __restrict__ ucol24 = a.ub_col24;
+  const unsigned short* __restrict__ uw16 = a.ub_w16;
   const int* __restrict__ owner = a.ub_owner;
   const u32* __restrict__ fbits = a.frontier_bits;
   u32* dist = a.dist;
   unsigned char* mark = a.mark;
-  sssp_u32x4 cC[2], cN[2];
-  sssp_f32x4 wC[2], wN[2];
-  u32 nC[2], nN[2], oC[2], oN[2];
-  auto issue = [&](u32 h, sssp_u32x4* c, sssp_f32x4* wt, u32* cnt, u32* own) {
+  typedef typename std::conditional<PACKED, sssp_u32x3, sssp_u32x4>::type craw_t;
+  typedef typename std::conditional<PACKED, sssp_u32x2, sssp_f32x4>::type wraw_t;
+  craw_t cC[2], cN[2];
+  wraw_t wC[2], wN[2];
+  u32 oC[2], oN[2];
+  auto issue = [&](u32 h, craw_t* c, wraw_t* wt, u32* own) {
     const u32 hh = h < H ? h : H - 1u;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const u32 u = hh * 8u + 4u * (u32)j + q;
       const size_t e = ((size_t)u << 6) + sub * 4u;
-      c[j] = __builtin_nontemporal_load((const sssp_u32x4*)(ucol + e));
-      wt[j] = __builtin_nontemporal_load((const sssp_f32x4*)(uw + e));
-      cnt[j] = ucnt[u];
-      own[j] = (u32)owner[u];
+      if constexpr (PACKED) {
+        c[j] = __builtin_nontemporal_load((const sssp_u32x3*)(ucol24 + (e >> 2) * 3u));
+        wt[j] = __builtin_nontemporal_load((const sssp_u32x2*)(uw16 + e));
+      } else {
+        c[j] = __builtin_nontemporal_load((const sssp_u32x4*)(ucol + e));
+        wt[j] = __builtin_nontemporal_load((const sssp_f32x4*)(uw + e));
+      }
+      own[j] = h < H ? (u32)owner[u] : (u32)a.n;       // (past the end: the last half-group again, masked as a padding unit)
     }
   };
-  issue(w, cC, wC, nC, oC);
+  issue(w, cC, wC, oC);
   for (u32 h = w; h < H; h += W) {
-    issue(h + W, cN, wN, nN, oN);                      // (past the end: the last half-group again, ignored)
+    issue(h + W, cN, wN, oN);
     u32 du[2];
     bool act[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {                      // my unit's row: in the frontier?  its distance NOW
-      const bool real = nC[j] != 0u;                   // (padding units: owner n)
+      const bool real = oC[j] < (u32)a.n;              // (padding units: owner n)
       const u32 o = real ? oC[j] : 0u;
       const u32 fw = fbits[o >> 5];
       du[j] = dist[o];
@@ -289,18 +311,30 @@ __device__ __forceinline__ void sssp_dense_long(const sssp_args_t& a, void* tabl
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {                      // (one unit load at a time: 64 registers per lane)
-      const u32 have = act[j] ? nC[j] : 0u;
-      const u32 e0 = sub * 4u;
       const float base = __uint_as_float(du[j]);
+      u32 e4[4];
+      float w4[4];
+      if constexpr (PACKED) {
+        e4[0] = (u32)__builtin_amdgcn_sbfe((int)cC[j].x, 0, 24);
+        e4[1] = (u32)__builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(cC[j].y, cC[j].x, 24), 0, 24);
+        e4[2] = (u32)__builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(cC[j].z, cC[j].y, 16), 0, 24);
+        e4[3] = (u32)((int)cC[j].z >> 8);
+        w4[0] = __half2float(__ushort_as_half((unsigned short)(wC[j].x & 0xFFFFu))); w4[1] = __half2float(__ushort_as_half((unsigned short)(wC[j].x >> 16)));
+        w4[2] = __half2float(__ushort_as_half((unsigned short)(wC[j].y & 0xFFFFu))); w4[3] = __half2float(__ushort_as_half((unsigned short)(wC[j].y >> 16)));
+      } else {
+        e4[0] = cC[j].x; e4[1] = cC[j].y; e4[2] = cC[j].z; e4[3] = cC[j].w;
+        w4[0] = wC[j].x; w4[1] = wC[j].y; w4[2] = wC[j].z; w4[3] = wC[j].w;
+      }
       u32 dd[4], nd[4];
-      dd[0] = e0 + 0u < have ? cC[j].x : 0xFFFFFFFFu; dd[1] = e0 + 1u < have ? cC[j].y : 0xFFFFFFFFu;
-      dd[2] = e0 + 2u < have ? cC[j].z : 0xFFFFFFFFu; dd[3] = e0 + 3u < have ? cC[j].w : 0xFFFFFFFFu;
-      nd[0] = __float_as_uint(base + wC[j].x); nd[1] = __float_as_uint(base + wC[j].y);
-      nd[2] = __float_as_uint(base + wC[j].z); nd[3] = __float_as_uint(base + wC[j].w);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        dd[k] = act[j] ? e4[k] : 0xFFFFFFFFu;          // (-1 padding entries stay -1)
+        nd[k] = __float_as_uint(base + w4[k]);
+      }
       sssp_relax4<LIVE>(dd, nd, table, hot_n, dist, mark);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { cC[j] = cN[j]; wC[j] = wN[j]; nC[j] = nN[j]; oC[j] = oN[j]; }
+    for (int j = 0; j < 2; ++j) { cC[j] = cN[j]; wC[j] = wN[j]; oC[j] = oN[j]; }
   }
 }
 
@@ -371,6 +405,19 @@ __global__ __launch_bounds__(BLOCK) void k_sssp_unit_weights(const int* __restri
   }
 }
 
+
+// the unit blocks' weights as halves -- *exact = 0 if any weight is not the float its half converts back to
+__global__ __launch_bounds__(BLOCK) void k_sssp_unit_weights16(const float* __restrict__ ub_w, long long entries, unsigned short* __restrict__ ub_w16,
+                                                               int* exact) {
+  bool bad = false;
+  for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < entries; e += (long long)gridDim.x * BLOCK) {
+    const float w = ub_w[e];
+    const __half h = __float2half(w);
+    bad |= __half2float(h) != w;
+    ub_w16[e] = __half_as_ushort(h);
+  }
+  if (__ballot(bad) && lane_id() == 0) *exact = 0;
+}
 
 // ---- heavy iterations: the edges by slice of their destination, that slice of the distances in LDS --------------------
 // The relax kernel below gathers the neighbour's distance for every edge: 4 bytes out of a 16 MB array in arbitrary order,
@@ -522,7 +569,8 @@ __global__ __launch_bounds__(NT, 4) void k_sssp_relax_dense(sssp_args_t a, int i
   } else {
     hot_n = sssp_load_bounds<NT, SSSP_HOTN_DENSE>(a.dist, a.n, s_hot_dense);
   }
-  sssp_dense_long<NT, LIVE>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);
+  if (a.ub_col24 && a.ub_w16) sssp_dense_long<NT, LIVE, true>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);      // (grid-uniform)
+  else sssp_dense_long<NT, LIVE, false>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);
   sssp_dense_short<NT, LIVE>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);
 }
 
@@ -1012,6 +1060,12 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   a.ub_w = dense ? layout->ub_w : nullptr;
   a.ub_cnt = dense ? layout->ub_cnt : nullptr;
   a.ub_owner = dense ? layout->ub_owner : nullptr;
+  {
+    bool pack = dense && layout->ub_col24 && layout->ub_w16;
+    if (const char* e = getenv("MGX_SSSP_PACK")) pack = pack && atoi(e) != 0;
+    a.ub_col24 = pack ? layout->ub_col24 : nullptr;
+    a.ub_w16 = pack ? layout->ub_w16 : nullptr;
+  }
   a.ub_units_pad = dense ? layout->ub_units_pad : 0u;
   for (int i = 0; i < 4; ++i) a.vs_v[i] = dense ? layout->vs_v[i] : 0u;
   a.dense_div = dense ? ddiv : 0u;

@@ -367,7 +367,7 @@ static void build_unit_blocks(mgx_graph_s* g) {
   graph_device_t& G = *g->g;
   G.d_ub_col = mem_t<int>(); G.d_ub_owner = mem_t<int>(); G.ub_units = G.ub_units_pad = 0; G.ub_min_degree = 0;
   G.d_ub_col24 = mem_t<unsigned>();
-  G.d_ub_cnt = mem_t<unsigned char>(); G.d_ub_first = mem_t<int>(); G.nr_big_rows = 0; G.d_ub_w = mem_t<float>(); G.ub_w_tried = false;
+  G.d_ub_cnt = mem_t<unsigned char>(); G.d_ub_first = mem_t<int>(); G.nr_big_rows = 0; G.d_ub_w = mem_t<float>(); G.d_ub_w16 = mem_t<unsigned short>(); G.ub_w_tried = false;
   if (const char* e = getenv("MGX_BFS_UNITS")) if (atoi(e) == 0) return;
   int long_min = 64;
   if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
@@ -1812,6 +1812,16 @@ static void ensure_unit_weights(mgx_graph_s* g) {
   hipLaunchKernelGGL(mgx::k_sssp_unit_weights, dim3(4096), dim3(mgx::BLOCK), 0, ctx.stream(), G.d_layout_row_offsets.data(),
                      G.d_layout_col_values.data(), G.d_ub_first.data(), G.num_nodes, w);
   MGX_CHECK_LAUNCH("unit-block weights");
+  // ... and as halves, for the sweep's packed stream: only with the 24-bit entries, only when every weight survives the round trip
+  G.d_ub_w16 = mem_t<unsigned short>();
+  if (G.d_ub_col24.size()) {
+    mem_t<unsigned short> w16(entries + 8, ctx);
+    mem_t<int> exact = mgx::fill<int>(1, 1, ctx);
+    hipLaunchKernelGGL(mgx::k_sssp_unit_weights16, dim3(4096), dim3(mgx::BLOCK), 0, ctx.stream(), (const float*)w, (long long)entries, w16.data(), exact.data());
+    int ok = 0;
+    MGX_HIP(mgx::dtoh(&ok, exact.data(), 1));
+    if (ok) G.d_ub_w16 = std::move(w16);
+  }
 }
 int mgx_sssp_run(mgx_sssp_t p, int src, int64_t* stats) { return mgx_sssp_run_delta(p, src, -1.0f, stats); }
 int mgx_sssp_run_delta(mgx_sssp_t p, int src, float delta, int64_t* stats) {
@@ -1839,6 +1849,7 @@ int mgx_sssp_run_delta(mgx_sssp_t p, int src, float delta, int64_t* stats) {
     ensure_unit_weights(p->g);
     if (G.d_ub_w.size()) {
       layout.ub_col = G.d_ub_col.data(); layout.ub_w = G.d_ub_w.data(); layout.ub_cnt = G.d_ub_cnt.data(); layout.ub_owner = G.d_ub_owner.data();
+      if (G.d_ub_col24.size() && G.d_ub_w16.size()) { layout.ub_col24 = G.d_ub_col24.data(); layout.ub_w16 = G.d_ub_w16.data(); }
       layout.ub_units_pad = (unsigned)G.ub_units_pad;
       for (int i = 0; i < 4; ++i) layout.vs_v[i] = G.vs_v[i];
       layout.m_edges = (long long)G.num_edges;
