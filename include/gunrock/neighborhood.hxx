@@ -44,7 +44,7 @@ int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fronti
   typename Problem::data_slice_t* const data = problem->d_data_slice.data();
   if constexpr (sizeof(Value) == 4)     // (the kernel keeps 40 000 4-byte values in the 160 KB of LDS: wider values take the general path)
   if (!has_output && is_pure_gather<Functor>::value && frontier_size == (long long)graph.num_nodes && frontier_size > 0 &&
-      graph.has_layout && (push || graph.csc_is_csr) && graph.ub_units > 0 && graph.ub_min_degree == 64 && graph.vs_long_min == 64 &&
+      graph.has_layout && (push || graph.csc_is_csr) && graph.ub_units > 0 && graph.ub_min_degree == graph.vs_long_min && graph.vs_long_min >= 17 && graph.vs_long_min <= 64 &&
       graph.d_ub_cnt.size() && graph.d_ub_first.size() && graph.vs_dummy != 0 &&
       context.scratch_bytes >= mgx::nr_scratch_bytes(graph.num_nodes, graph.ub_units_pad, sizeof(Value))) {
     // the check (inside the first kernel) and the work go out back to back: the kernels behind it look at its verdict themselves (a device

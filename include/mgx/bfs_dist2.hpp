@@ -347,6 +347,9 @@ struct d2_state_t {
     row_offsets = ro; col_indices = ci; newbits = newbits_;
     nwords = (((long long)n_global + 31) / 32 + 3) / 4 * 4;     // padded to 16 bytes: the OR-merge reads uint4
     fs.reset(new bfs_fused_state_t(n_global, ctx));
+    // (a rank's short rows take the queue search, not the vertex-by-vertex walk the single-GPU threshold was re-tuned for in
+    //  round 4: the ranks keep 64 unless the switch says otherwise)
+    if (!getenv("MGX_BFS_LONG_MIN")) fs->long_min = 64;
     if (const char* e = getenv("MGX_BFS_COLD_TEST")) cold_forced = atoi(e);
     labels = mem_t<int>((size_t)n_local + 1, ctx);
     merged = mem_t<u32>((size_t)nwords + 4, ctx);

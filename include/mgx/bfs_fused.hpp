@@ -1100,7 +1100,7 @@ struct bfs_fused_state_t {
   mem_t<u32> cold_flush;             // cold-edge pass: one bitmap of BFS_COLD_WORDS words per cold workgroup (allocated on demand)
   unsigned dense_div = 2;            // long rows are read from the unit blocks when the frontier holds at least
                                      // 1 / dense_div of the units (bfs_fused_dense.hpp; 0: never)
-  int long_min = 64;                 // rows at least this long go to the long-row queue (0: no such queue)
+  int long_min = LONG_MIN_DEFAULT;   // rows at least this long go to the long-row queue (0: no such queue)
   bool count_marks = false;          // see bfs_fused_args_t::count_marks (MGX_BFS_COUNT_MARKS; on with time_kernels)
   int time_kernels = 0;              // 1: the push parts as separate launches, HIP events around each; 2: events around the
                                      // ONE merged push launch of every slot (the product kernel; -> stream_kernel_ms) (each event

@@ -23,6 +23,12 @@
 
 namespace mgx {
 
+// Rows of at least this many entries are "long": they live a second time as unit blocks (64-entry units of one row each)
+// and are streamed; shorter rows are walked vertex by vertex by degree class.  32 since round 4 (64 before): with 3-byte
+// entries a half-empty unit still costs less than the short-row walk's latency -- RMAT-22, ms per traversal at 64 / 48 / 32 /
+// 24 / 16: 0.3171 / 0.3185 / 0.3087 / 0.3081 / 0.3098 (MGX_BFS_LONG_MIN overrides; at most 64: a unit is 64 entries).
+constexpr int LONG_MIN_DEFAULT = 32;
+
 struct hip_error : std::runtime_error {
   hipError_t code;
   hip_error(hipError_t c, const char* what_, const char* file, int line)

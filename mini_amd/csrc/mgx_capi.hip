@@ -349,7 +349,7 @@ extern "C" int mgx_units_build_device(const int* ro, const int* ci, int n, int m
                                       hipStream_t stream);
 
 // Unit blocks of the layout's long rows (mgx/bfs_fused_dense.hpp); MGX_BFS_UNITS=0 skips them.  The threshold is the
-// fused traversal's long-row threshold at build time (MGX_BFS_LONG_MIN, default 64; a unit is 64 entries whatever the
+// fused traversal's long-row threshold at build time (MGX_BFS_LONG_MIN, default mgx::LONG_MIN_DEFAULT; a unit is 64 entries whatever the
 // threshold); a run with another threshold ignores the blocks.
 namespace {
 // four 32-bit entries -> three words of 24-bit entries (little endian: entry k occupies bits [24 k, 24 k + 24) of the 96)
@@ -369,7 +369,7 @@ static void build_unit_blocks(mgx_graph_s* g) {
   G.d_ub_col24 = mem_t<unsigned>();
   G.d_ub_cnt = mem_t<unsigned char>(); G.d_ub_first = mem_t<int>(); G.nr_big_rows = 0; G.d_ub_w = mem_t<float>(); G.d_ub_w16 = mem_t<unsigned short>(); G.ub_w_tried = false;
   if (const char* e = getenv("MGX_BFS_UNITS")) if (atoi(e) == 0) return;
-  int long_min = 64;
+  int long_min = mgx::LONG_MIN_DEFAULT;
   if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
   if (long_min <= 0 || !G.has_layout || G.num_edges <= 0) return;
   int *owner = nullptr, *ucol = nullptr, *ufirst = nullptr;
@@ -552,7 +552,7 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
   // degree classes of the short rows (the layout is sorted by degree): boundaries by binary search on a host copy
   G.vs_edges = 0; G.vs_dummy = 0; G.vs_long_min = 0; G.d_ss_tab = mem_t<unsigned>();
   {
-    int long_min = 64;
+    int long_min = mgx::LONG_MIN_DEFAULT;
     if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
     if (long_min > 0 && long_min <= 64 && n > 0 && m > 0) {
       std::vector<int> h(n + 1);
@@ -585,7 +585,7 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
   }
 build_cold_lists(g);
   {
-    int long_min = 64;
+    int long_min = mgx::LONG_MIN_DEFAULT;
     if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
     build_src_shapes(g, long_min);
   }
@@ -1801,7 +1801,8 @@ static void ensure_unit_weights(mgx_graph_s* g) {
   graph_device_t& G = *g->g;
   if (G.ub_w_tried) return;
   G.ub_w_tried = true;
-  if (!G.has_layout || !G.has_layout_weights || G.ub_units <= 0 || !G.d_ub_first.size() || G.vs_long_min != 64 || G.ub_min_degree != 64) return;
+  // (the sweep reads the long rows from the unit blocks and walks the short ones by degree class: any threshold the two were cut by together)
+  if (!G.has_layout || !G.has_layout_weights || G.ub_units <= 0 || !G.d_ub_first.size() || G.vs_long_min != G.ub_min_degree || G.vs_long_min < 17 || G.vs_long_min > 64) return;
   if (const char* e = getenv("MGX_SSSP_DENSE")) if (atoi(e) == 0) return;
   standard_context_t& ctx = *g->c->ctx;
   float* w = nullptr;
