@@ -422,7 +422,7 @@ __host__ __device__ __forceinline__ int bfs_slot_arg(int slot) { return -1 - slo
 // (bfs_defer_limit: grid-uniform, ctrl->reached is stable while a level runs; a quarter of the range was the rule while
 // the cold marks still dominated those levels) -- the hub levels at the start of a
 // traversal; later levels find most of the prefix visited and store the few marks they have at once.
-constexpr int BFS_FLUSH_WORDS = 17984;                 // 562 runs of 1024 vertices: inside every body's LDS prefix
+constexpr int BFS_FLUSH_WORDS = 20352;                 // 636 runs of 1024 vertices: (nearly) all of the unit-block body's LDS prefix; a body with a shorter prefix defers what it has
 constexpr int BFS_FLUSH_MAX = 1024;                    // one buffer per push workgroup of a slot at most
 constexpr int BFS_FLUSH_RUNS = BFS_FLUSH_WORDS / 32;
 
@@ -463,7 +463,7 @@ __device__ __forceinline__ int bfs_hot_epilogue(const bfs_fused_args_t& a, const
 #pragma unroll
       for (int q = 0; q < PERT; ++q) {
         const u32 i = (u32)q * NT + threadIdx.x;
-        if (i < defer_words) out[i] = hot[i];      // (the queue build reads the runs below the deferred range only)
+        if (i < a.defer_words) out[i] = i < defer_words ? hot[i] : 0u;      // (the queue build reads the runs below the launch's deferred range: a body whose own range is shorter leaves zeros, never what an earlier level wrote)
       }
       return total;
     }
