@@ -47,7 +47,11 @@ __device__ __forceinline__ void bfs_vshort_work(const bfs_fused_args_t& a, u32* 
   const u32* __restrict__ fbits = a.frontier_bits;
   // classes: [vs_v[0], vs_v[1]) 16 lanes per vertex, [vs_v[1], vs_v[2]) 4, [vs_v[2], vs_v[3]) 1
   const u32 b0 = a.vs_v[0], b1 = a.vs_v[1], b2 = a.vs_v[2], b3 = a.vs_v[3];
-  const u32 s16 = (b1 - b0 + 3u) / 4u, s4 = (b2 - b1 + 15u) / 16u, s1 = (b3 - b2 + 63u) / 64u;
+  // the widest class: 16 lanes per vertex cover 64 entries; with a long-row threshold of 32 or less its rows have at most 31
+  // entries and 8 lanes (32 entries) do -- twice the vertices per wave step
+  const u32 shift0 = (a.long_min > 0 && a.long_min <= 32) ? 3u : 4u;
+  const u32 vps0 = 64u >> shift0;
+  const u32 s16 = (b1 - b0 + vps0 - 1u) / vps0, s4 = (b2 - b1 + 15u) / 16u, s1 = (b3 - b2 + 63u) / 64u;
   const u32 T = s16 + s4 + s1;                                  // wave steps in all
   const u32 W = nblocks * NW, w = block * NW + (u32)wave;
   const u32 dummy = a.vs_dummy;                                 // index into col of four readable entries behind the CSR
@@ -62,7 +66,7 @@ __device__ __forceinline__ void bfs_vshort_work(const bfs_fused_args_t& a, u32* 
   auto plan_load = [&](u32 s) -> raw_t {
     raw_t r;
     u32 lpr_shift, vbase, vend;
-    if (s < s16) { lpr_shift = 4; vbase = b0 + s * 4u; vend = b1; }
+    if (s < s16) { lpr_shift = shift0; vbase = b0 + s * vps0; vend = b1; }
     else if (s < s16 + s4) { lpr_shift = 2; vbase = b1 + (s - s16) * 16u; vend = b2; }
     else { lpr_shift = 0; vbase = b2 + (s - s16 - s4) * 64u; vend = b3; }
     const u32 v = vbase + ((u32)lane >> lpr_shift);
