@@ -185,6 +185,7 @@ struct bfs_fused_enactor_t {
         layout.ub_min_degree = g.ub_min_degree;
       }
       for (int i = 0; i < 4; ++i) layout.vs_v[i] = g.vs_v[i];
+      layout.vs_v9 = g.vs_v9;
       layout.vs_edges = g.vs_edges; layout.vs_dummy = g.vs_dummy; layout.vs_long_min = g.vs_long_min;
       if (g.d_ss_tab.size() && g.vs_long_min > 0) layout.ss_tab = g.d_ss_tab.data();
       if (g.cold_slices > 0) {

@@ -96,6 +96,7 @@ struct graph_device_t {
   // Degree classes of the layout's short rows (mgx/bfs_fused_vshort.hpp): only for a layout the library built itself
   // (sorted by degree, eight ints of -1 behind its neighbour array).
   unsigned vs_v[4] = {0, 0, 0, 0};
+  unsigned vs_v9 = 0;                // first layout vertex of degree < 9 (inside [vs_v[1], vs_v[2]]): the fused BFS walks degrees 5 .. 8 with two lanes per vertex
   unsigned vs_edges = 0, vs_dummy = 0;
   int vs_long_min = 0;
   mem_t<unsigned> d_ss_tab;          // region table of the short rows (mgx/bfs_fused_sshort.hpp); with the degree classes

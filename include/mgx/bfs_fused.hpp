@@ -146,6 +146,7 @@ struct bfs_fused_args_t {
   u32 dense_div;           // a slot reads its long rows from the unit blocks when frontier units * dense_div >= ub_units (0: never)
   // short rows vertex by vertex (bfs_fused_vshort.hpp; needs a degree-sorted CSR with 8 readable ints behind col_indices)
   u32 vs_v[4];             // class boundaries: [0]..[1] degrees 17..long_min-1, [1]..[2] 5..16, [2]..[3] 1..4
+  u32 vs_v9;               // inside [1]..[2]: where the degrees drop below 9 (== vs_v[2]: not known, 5..16 is one class of four lanes per vertex)
   u32 vs_edges;            // edges of the rows in [vs_v[0], vs_v[3])
   u32 vs_div;              // a slot takes its short rows this way when its short-row queue holds >= vs_edges / vs_div edges (0: never)
   u32 vs_dummy;            // index (into col_indices) of four entries of -1

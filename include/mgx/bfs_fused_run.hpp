@@ -41,6 +41,7 @@ struct bfs_layout_t {
   // short rows vertex by vertex (bfs_fused_vshort.hpp): class boundaries of the degree-sorted CSR, edges of the range,
   // the long-row threshold they were computed for, index of four -1 behind col_indices (0: not available)
   unsigned vs_v[4] = {0, 0, 0, 0};
+  unsigned vs_v9 = 0;               // first vertex of degree < 9 (0: unknown -- degrees 5 .. 16 are one class)
   unsigned vs_edges = 0, vs_dummy = 0;
   int vs_long_min = 0;
   const unsigned* ss_tab = nullptr;   // (lab builds) region table of the short rows (bfs_fused_sshort.hpp; device, BFS_SS_TAB_WORDS words)
@@ -385,6 +386,7 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   const bool vs = relabelled && layout->vs_dummy != 0 && layout->vs_long_min == st.long_min && st.long_min > 0 && !coldt && !lab_flags &&
                   layout->vs_edges > 0;
   for (int i = 0; i < 4; ++i) a.vs_v[i] = vs ? layout->vs_v[i] : 0u;
+  a.vs_v9 = (vs && layout->vs_v9 >= layout->vs_v[1] && layout->vs_v9 <= layout->vs_v[2]) ? layout->vs_v9 : (vs ? layout->vs_v[2] : 0u);   // (unknown: nobody in the two-lane class)
   a.vs_edges = vs ? layout->vs_edges : 0u;
   a.vs_dummy = vs ? layout->vs_dummy : 0u;
   a.vs_div = !vs ? 0u : (opt.vshort >= 0 ? (u32)opt.vshort : st.vshort_div);

@@ -51,8 +51,10 @@ __device__ __forceinline__ void bfs_vshort_work(const bfs_fused_args_t& a, u32* 
   // entries and 8 lanes (32 entries) do -- twice the vertices per wave step
   const u32 shift0 = (a.long_min > 0 && a.long_min <= 32) ? 3u : 4u;
   const u32 vps0 = 64u >> shift0;
-  const u32 s16 = (b1 - b0 + vps0 - 1u) / vps0, s4 = (b2 - b1 + 15u) / 16u, s1 = (b3 - b2 + 63u) / 64u;
-  const u32 T = s16 + s4 + s1;                                  // wave steps in all
+  // ... and the class of degrees 5 .. 16 is split where the degrees drop below 9 (a.vs_v9): four lanes per vertex above, two below
+  const u32 b9 = a.vs_v9 >= b1 && a.vs_v9 <= b2 ? a.vs_v9 : b2;
+  const u32 s16 = (b1 - b0 + vps0 - 1u) / vps0, s4 = (b9 - b1 + 15u) / 16u, s2 = (b2 - b9 + 31u) / 32u, s1 = (b3 - b2 + 63u) / 64u;
+  const u32 T = s16 + s4 + s2 + s1;                             // wave steps in all
   const u32 W = nblocks * NW, w = block * NW + (u32)wave;
   const u32 dummy = a.vs_dummy;                                 // index into col of four readable entries behind the CSR
 
@@ -67,8 +69,9 @@ __device__ __forceinline__ void bfs_vshort_work(const bfs_fused_args_t& a, u32* 
     raw_t r;
     u32 lpr_shift, vbase, vend;
     if (s < s16) { lpr_shift = shift0; vbase = b0 + s * vps0; vend = b1; }
-    else if (s < s16 + s4) { lpr_shift = 2; vbase = b1 + (s - s16) * 16u; vend = b2; }
-    else { lpr_shift = 0; vbase = b2 + (s - s16 - s4) * 64u; vend = b3; }
+    else if (s < s16 + s4) { lpr_shift = 2; vbase = b1 + (s - s16) * 16u; vend = b9; }
+    else if (s < s16 + s4 + s2) { lpr_shift = 1; vbase = b9 + (s - s16 - s4) * 32u; vend = b2; }
+    else { lpr_shift = 0; vbase = b2 + (s - s16 - s4 - s2) * 64u; vend = b3; }
     const u32 v = vbase + ((u32)lane >> lpr_shift);
     const u32 sub = (u32)lane & ((1u << lpr_shift) - 1u);
     const bool in = s < T && v < vend;

@@ -565,6 +565,7 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
       const unsigned b0 = first_below(long_min), b1 = std::max(b0, first_below(17)), b2 = std::max(b1, first_below(5)),
                      b3 = std::max(b2, first_below(1));
       G.vs_v[0] = b0; G.vs_v[1] = b1; G.vs_v[2] = b2; G.vs_v[3] = b3;
+      G.vs_v9 = std::min(b2, std::max(b1, first_below(9)));
       G.nr_big_rows = first_below(64 * mgx::NR_BIG_UNITS + 1);       // rows of more than NR_BIG_UNITS units (mgx/nreduce.hpp)
       G.vs_edges = (unsigned)(h[b3] - h[b0]);
       G.vs_dummy = (unsigned)m + 4u;
