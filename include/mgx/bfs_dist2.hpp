@@ -40,18 +40,70 @@ namespace mgx {
 struct d2_cold_view_t {
   const u32* flush = nullptr;
   int slices = 0;
+  int reduced = 0;                     // the first buffer of a slice holds the OR of all of them (k_d2_cold_reduce ran in front)
+  u32 slice_n = 0;                     // vertices of a slice; slice number (v - lo[0]) / slice_n -> index into lo / wgs, 255: holds no pairs
+  unsigned char qof[128] = {};
   u32 lo[BFS_COLD_MAX_SLICES] = {};
   u32 wgs[BFS_COLD_MAX_SLICES + 1] = {};
 };
-constexpr int D2_LIST_HEAD = 4;          // header words of an id list: [0] count (may exceed the capacity: overflow), [1..3] unused
+// The bitmaps the cold workgroups of a slice left behind (bfs_fused_cold.hpp), ORed into the slice's first one: 16 bytes per
+// lane, eight buffers in flight -- a stream (a thousand buffers of 80 KB on RMAT-26 / 8: 83 MB).  Returns at once on a level
+// whose push did not run the cold pass.  (Inside the push launch -- the last workgroup of a slice to finish does it -- the
+// fences that make the other workgroups' stores visible across the XCDs' L2s tripled the launch: 368 -> 1 230 us.)
+__global__ __launch_bounds__(BLOCK) void k_d2_cold_reduce(d2_cold_view_t cv, const bfs_ctrl_t* c, int level, u32* flush) {
+  if (!cv.flush || c->cold_slot != level || c->d2_append_level == level) return;
+  constexpr u32 Q = BFS_COLD_WORDS / 4;
+  const u32 t = blockIdx.x * BLOCK + threadIdx.x;
+  const u32 q = t / Q, i = t % Q;
+  if ((int)q >= cv.slices) return;
+  const u32 parts = cv.wgs[q + 1] - cv.wgs[q];
+  if (parts < 2u) return;
+  uint4* const first = (uint4*)(flush + (size_t)cv.wgs[q] * BFS_COLD_WORDS);
+  uint4 acc = first[i];
+  u32 k = 1;
+  for (; k + 8u <= parts; k += 8u) {
+    uint4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = first[(size_t)(k + (u32)j) * Q + i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { acc.x |= v[j].x; acc.y |= v[j].y; acc.z |= v[j].z; acc.w |= v[j].w; }
+  }
+  for (; k < parts; ++k) {
+    const uint4 v = first[(size_t)k * Q + i];
+    acc.x |= v.x; acc.y |= v.y; acc.z |= v.z; acc.w |= v.w;
+  }
+  first[i] = acc;
+}
+
 constexpr int D2_NEWBITS_NT = 1024;      // threads per workgroup of k_d2_newbits: ONE add to the list's counter per workgroup and trip
+// Three shapes, chosen grid-uniformly from what the level's push left behind:
+//   * the push appended its discoveries to the list itself (a sparse level, bfs_fused_sparse.hpp): nothing to do;
+//   * the push stored more than declare_mul x list_cap marks (slot_marks: one add per push workgroup): the list is DECLARED
+//     overflowed (count = list_cap + 1: the level takes the bitmap exchange, which is always right) and the sweep is a plain
+//     stream -- no barriers, no counter;
+//   * otherwise: the sweep that also compacts the ids.
+// The bitmaps of the cold-edge pass: ONE per slice -- k_d2_cold_reduce has ORed the slice's buffers into the first.  (This
+// kernel used to OR them itself: a
+// thousand 80 KB buffers on RMAT-26 / 8, one 4-byte load per lane, buffer and trip -- 75 of the sweep's 105 us on the big levels;
+// eight loads in flight: 57 of 74; 16-byte loads by lane groups with a run of 1024 vertices per wave: slower, 109.)
 __global__ __launch_bounds__(D2_NEWBITS_NT) void k_d2_newbits(const u32* __restrict__ visited, const unsigned char* __restrict__ mark,
                                                               u32* __restrict__ out, long long nwords, long long n, bfs_ctrl_t* c,
-                                                              u32* __restrict__ list, u32 list_cap, d2_cold_view_t cv, int level) {
+                                                              u32* __restrict__ list, u32 list_cap, d2_cold_view_t cv, int level,
+                                                              const u32* __restrict__ slot_marks, u32 declare_mul) {
   constexpr int NT = D2_NEWBITS_NT, NW = NT / WAVE;
   __shared__ u32 s_wave[NW];
   __shared__ u32 s_base;
   if (blockIdx.x == 0 && threadIdx.x == 0) c->merged_new = 0;     // the merge of this level counts into it
+  if (c->d2_append_level == level) return;                        // (grid-uniform: written by the level's push launch)
+  if (list && slot_marks && declare_mul) {
+    u64 M = 0;
+#pragma unroll
+    for (int i = 0; i < BFS_MARK_CTRS; ++i) M += slot_marks[((level & 1) * BFS_MARK_CTRS + i) * BFS_MARK_STRIDE];
+    if (M > (u64)list_cap * (u64)declare_mul) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) { list[0] = list_cap + 1u; c->d2_declared_level = level; }
+      list = nullptr;
+    }
+  }
   const bool with_cold = cv.flush && c->cold_slot == level;       // (grid-uniform) the level's push ran the cold-edge pass
   const int wave = threadIdx.x / WAVE;
   const long long stride = (long long)gridDim.x * NT;
@@ -69,12 +121,23 @@ __global__ __launch_bounds__(D2_NEWBITS_NT) void k_d2_newbits(const u32* __restr
         for (int i = 0; i < 32 && w * 32 + i < n; ++i) bits |= (mark[w * 32 + i] ? 1u : 0u) << i;
       }
       if (with_cold) {
-        // the slice this word lies in (slices start on multiples of 1024 vertices: a word belongs to one slice): OR of its
-        // workgroups' bitmaps -- neighbouring lanes read neighbouring words of every buffer
+        // the slice this word lies in (slices start on multiples of 1024 vertices: a word belongs to one slice)
         const u32 v0 = (u32)(w * 32);
-        for (int q = 0; q < cv.slices; ++q) {
-          if (v0 >= cv.lo[q] && v0 - cv.lo[q] < (u32)BFS_COLD_WORDS * 32u) {
-            const u32* const base = cv.flush + ((v0 - cv.lo[q]) >> 5);
+        int q = -1;
+        if (cv.slice_n) {
+          if (v0 >= cv.lo[0]) {
+            const u32 k = (v0 - cv.lo[0]) / cv.slice_n;
+            if (k < 128u && cv.qof[k] != 255) q = (int)cv.qof[k];
+          }
+        } else {
+          for (int j = 0; j < cv.slices; ++j)
+            if (v0 >= cv.lo[j] && v0 - cv.lo[j] < (u32)BFS_COLD_WORDS * 32u) q = j;
+        }
+        if (q >= 0) {
+          const u32* const base = cv.flush + ((v0 - cv.lo[q]) >> 5);
+          if (cv.reduced) {
+            bits |= base[(size_t)cv.wgs[q] * BFS_COLD_WORDS];
+          } else {
             for (u32 k = cv.wgs[q]; k < cv.wgs[q + 1]; ++k) bits |= base[(size_t)k * BFS_COLD_WORDS];
           }
         }
@@ -82,7 +145,7 @@ __global__ __launch_bounds__(D2_NEWBITS_NT) void k_d2_newbits(const u32* __restr
       bits &= ~visited[w];
       out[w] = bits;
     }
-    if (list) {
+    if (list) {                                                        // (grid-uniform)
       // positions in the list: a scan over the wave, a scan of the waves' totals, ONE add to the list's counter per workgroup --
       // on a level that discovers something everywhere every wave has a count, and they all look at the counter before any of
       // them has made it overflow: per-wave adds to the one address cost this kernel 25 of its 40 us on such a level.  A list
@@ -114,13 +177,13 @@ __global__ __launch_bounds__(D2_NEWBITS_NT) void k_d2_newbits(const u32* __restr
   }
 }
 
-// merged[w] = OR over the maps of gathered[r][w]; visited |= merged; ctrl->merged_new += popcount(merged).
+// merged[w] = OR over the maps of gathered[r][w]; visited |= merged; ctrl->merged_new += popcount(merged); clear[w] = 0.
 // Every rank computes the same count, so the traversal ends on all ranks together without a reduction.
 // 16 bytes per lane (nwords4 = words / 4; the buffers are padded to a multiple of 4 words); map r starts
 // stride4 x 16 bytes after map r - 1.
 __global__ __launch_bounds__(BLOCK) void k_d2_or(const uint4* __restrict__ gathered, int maps, long long stride4,
                                                  long long nwords4, uint4* __restrict__ merged,
-                                                 uint4* __restrict__ visited, bfs_ctrl_t* c, int level) {
+                                                 uint4* __restrict__ visited, bfs_ctrl_t* c, int level, uint4* clear) {
   // merged = the frontier of level + 1 as a bitmap over all vertices: what the unit-block body of the next push reads
   if (blockIdx.x == 0 && threadIdx.x == 0) c->fb_slot = level + 1;
   int found = 0;
@@ -131,6 +194,9 @@ __global__ __launch_bounds__(BLOCK) void k_d2_or(const uint4* __restrict__ gathe
       g.x |= x.x; g.y |= x.y; g.z |= x.z; g.w |= x.w;
     }
     merged[w] = g;
+    // the rank's own new-bit map is consumed: all zero again for the next level (a sparse level ORs single bits into it).  On a
+    // one-rank run `gathered` IS that map: this thread has read the word it clears.
+    if (clear) clear[w] = make_uint4(0u, 0u, 0u, 0u);
     if (g.x | g.y | g.z | g.w) {
       uint4 v = visited[w];
       v.x |= g.x; v.y |= g.y; v.z |= g.z; v.w |= g.w;
@@ -174,7 +240,8 @@ __global__ __launch_bounds__(BLOCK) void k_d2_or_maps(const uint4* __restrict__ 
 // reads and such a store) -- d2_apply_lists clears it behind the kernel instead.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_d2_lists_apply(bfs_fused_args_t a, int level, const u32* __restrict__ glists, int nlists, u32 stride,
-                                                       u32 cap, int* __restrict__ labels, int ranks, int rank, u64* host_flag, u64 seq) {
+                                                       u32 cap, int* __restrict__ labels, int ranks, int rank, u64* host_flag, u64 seq,
+                                                       u32* own_bits, int own_list) {
   constexpr int NW = NT / WAVE;
   constexpr u64 CNT1 = 1ull << 40;
   constexpr u64 DEGMASK = CNT1 - 1ull;
@@ -224,6 +291,9 @@ __global__ __launch_bounds__(NT) void k_d2_lists_apply(bfs_fused_args_t a, int l
       while (r + 1 < nlists && s_pre[r + 1] <= idx) ++r;
       const u32 v = glists[(size_t)r * stride + D2_LIST_HEAD + (idx - s_pre[r])];
       const u32 bit = 1u << (v & 31u);
+      // the level is merged from the lists: this rank's new-bit map is not shipped -- its words go back to zero (every bit in it
+      // is one of the rank's own list: stores of 0 from several threads to one word are the same store)
+      if (r == own_list && own_bits) own_bits[v >> 5] = 0u;
       fresh = !(atomicOr(a.visited + (v >> 5), bit) & bit);
       mine = fresh && (int)(v % (u32)ranks) == rank;
       if (mine) {
@@ -291,6 +361,8 @@ __global__ __launch_bounds__(BLOCK) void k_d2_row_facts(const int* __restrict__ 
 __global__ void k_d2_init(bfs_fused_args_t a, int* labels_local, int src, int ranks, int rank) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   bfs_ctrl_reset(a.ctrl);
+  bfs_slot_marks_clear(a, 0);
+  bfs_slot_marks_clear(a, 1);
   a.ctrl->fb_slot = -1;                        // (the merged bitmap describes a level only once k_d2_or has written it)
   a.visited[src >> 5] = 1u << (src & 31);      // every rank knows the source is visited
   if (src % ranks == rank) {
@@ -314,12 +386,16 @@ struct d2_state_t {
   u32* mylist = nullptr;
   u32 list_cap = 0;
   mem_t<u32> own_list;
+  mem_t<u32> slot_marks;              // marks stored by the push workgroups of a level (bfs_body_finish): what k_d2_newbits bases its shape on
+  u32 declare_mul = 16;               // a level whose push stored more than this x list_cap marks does not fill its list (MGX_DIST_DECLARE_MUL; 0: always fill)
+  int sparse_push = 1;                // levels of at most list_cap edges append to the list themselves (MGX_DIST_SPARSE_PUSH=0: every level sweeps)
   u64* host_flag = nullptr;           // pinned: what k_d2_lists_apply tells the host
   u64 flag_seq = 0;
   // unit blocks of the rank's long rows (mgx_layout.hip; owners in GLOBAL ids, padding units owned by vertex n_global):
   // built on request (mgx_dbfs2_build_units), owned here
   int* ub_col = nullptr;
   int* ub_owner = nullptr;
+  mem_t<u32> ub_col24;                // the same, 24 bits per entry: only when the blocks hold the rows' HOT entries alone (the others are in the cold-edge lists)
   long long ub_units = 0, ub_units_pad = 0;
   u32 dense_div = 4;
   // cold-edge lists of those rows (mgx_layout.hip: mgx_cold_build_device; owners global): pairs by slice of the destination,
@@ -332,10 +408,22 @@ struct d2_state_t {
   u32 cold_off[BFS_COLD_MAX_SLICES + 1] = {};
   u32 cold_wgs[BFS_COLD_MAX_SLICES + 1] = {};
   mem_t<u32> cold_flush;
+  int cold_reduce = 1;                // k_d2_cold_reduce in front of the sweep (MGX_DIST_COLD_REDUCE)
   d2_cold_view_t cold_view() const {
     d2_cold_view_t v;
     if (!cold_dst || cold_slices <= 0 || !cold_flush.size()) return v;
     v.flush = cold_flush.data(); v.slices = cold_slices;
+    // (the table covers 128 slices behind the first one in use -- 83 M vertices; a bigger range keeps the search over lo[])
+    v.slice_n = (u32)BFS_COLD_WORDS * 32u;
+    bool table = true;
+    for (int k = 0; k < 128; ++k) v.qof[k] = 255;
+    for (int q = 0; q < cold_slices; ++q) {
+      const u32 k = (cold_lo[q] - cold_lo[0]) / v.slice_n;
+      if (k >= 128u || (cold_lo[q] - cold_lo[0]) % v.slice_n) { table = false; break; }
+      v.qof[k] = (unsigned char)q;
+    }
+    if (!table) v.slice_n = 0;
+    v.reduced = cold_reduce ? 1 : 0;
     for (int i = 0; i < BFS_COLD_MAX_SLICES; ++i) v.lo[i] = cold_lo[i];
     for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) v.wgs[i] = cold_wgs[i];
     return v;
@@ -351,6 +439,10 @@ struct d2_state_t {
     //  round 4: the ranks keep 64 unless the switch says otherwise)
     if (!getenv("MGX_BFS_LONG_MIN")) fs->long_min = 64;
     if (const char* e = getenv("MGX_BFS_COLD_TEST")) cold_forced = atoi(e);
+    if (const char* e = getenv("MGX_DIST_DECLARE_MUL")) declare_mul = (u32)atoi(e);
+    if (const char* e = getenv("MGX_DIST_SPARSE_PUSH")) sparse_push = atoi(e);
+    slot_marks = mem_t<u32>((size_t)2 * BFS_MARK_CTRS * BFS_MARK_STRIDE, ctx);
+    MGX_HIP(hipMemsetAsync(slot_marks.data(), 0, slot_marks.size() * sizeof(u32), ctx.stream()));
     labels = mem_t<int>((size_t)n_local + 1, ctx);
     merged = mem_t<u32>((size_t)nwords + 4, ctx);
     MGX_HIP(hipMemsetAsync(merged.data(), 0, ((size_t)nwords + 4) * sizeof(u32), ctx.stream()));   // (the bit of vertex n_global stays 0)
@@ -397,15 +489,17 @@ struct d2_state_t {
     a.n = n_global;
     a.mode = 0; a.alpha = 0.f;
     a.count_marks = 0;
-    a.ub_col = ub_col; a.ub_owner = ub_owner; a.ub_units = (u32)ub_units; a.ub_units_pad = (u32)ub_units_pad; a.dense_div = ub_col ? dense_div : 0u;
-    a.vs_v[0] = a.vs_v[1] = a.vs_v[2] = a.vs_v[3] = 0; a.vs_v9 = 0; a.vs_edges = 0; a.vs_div = 0; a.vs_dummy = 0; a.lazy_div = 0; a.slot_marks = nullptr; a.merged_pull = 0; a.lazy_pull = 0; a.chain_big_edges = 0; a.defer_reach_mul = 1; a.defer_reach_div = 1;
+    a.ub_col = ub_col; a.ub_col24 = ub_col24.size() ? ub_col24.data() : nullptr; a.ub_owner = ub_owner; a.ub_units = (u32)ub_units; a.ub_units_pad = (u32)ub_units_pad; a.dense_div = ub_col ? dense_div : 0u;
+    a.vs_v[0] = a.vs_v[1] = a.vs_v[2] = a.vs_v[3] = 0; a.vs_v9 = 0; a.vs_edges = 0; a.vs_div = 0; a.vs_dummy = 0; a.lazy_div = 0; a.slot_marks = const_cast<u32*>(slot_marks.data()); a.merged_pull = 0; a.lazy_pull = 0; a.chain_big_edges = 0; a.defer_reach_mul = 1; a.defer_reach_div = 1;
     const bool cold = cold_dst != nullptr && ub_col != nullptr && cold_slices > 0 && cold_flush.size() > 0;
     a.cold_owner = cold ? cold_owner : nullptr; a.cold_dst = cold ? cold_dst : nullptr; a.cold_slices = cold ? cold_slices : 0;
-    a.cold_flush = cold ? cold_flush.data() : nullptr;
+    a.cold_flush = cold ? const_cast<u32*>(cold_flush.data()) : nullptr;
     for (int i = 0; i < BFS_COLD_MAX_SLICES; ++i) a.cold_lo[i] = cold ? cold_lo[i] : 0u;
     for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) { a.cold_off[i] = cold ? cold_off[i] : 0u; a.cold_wgs[i] = cold ? cold_wgs[i] : 0u; }
     a.flush_buf = nullptr; a.defer_min_marks = 0;     // (k_d2_newbits reads the marks: nothing is deferred)
     a.chain_max_edges = 0;               // (levels are counted by the host here: no chains of small levels)
+    const bool sparse = sparse_push && mylist && list_cap > 0u;
+    a.d2_list = sparse ? mylist : nullptr; a.d2_list_cap = sparse ? list_cap : 0u; a.d2_newbits = sparse ? newbits : nullptr;
     return a;
   }
 };
@@ -417,6 +511,8 @@ inline void d2_reset(d2_state_t& st, int src, standard_context_t& ctx) {
   MGX_HIP(hipMemsetAsync(st.fs->visited.data(), 0, st.fs->visited.size() * sizeof(u32), s));
   MGX_HIP(hipMemsetAsync(st.fs->mark.data(), 0, st.fs->mark.size(), s));
   if (st.mylist) MGX_HIP(hipMemsetAsync(st.mylist, 0, D2_LIST_HEAD * sizeof(u32), s));
+  // (the new-bit map is all zero between the levels of a traversal that ran to its end; one that was abandoned may have left bits)
+  if (st.mylist && st.sparse_push) MGX_HIP(hipMemsetAsync(st.newbits, 0, (size_t)st.nwords * sizeof(u32), s));
   hipLaunchKernelGGL(k_d2_init, dim3(1), dim3(64), 0, s, st.args(), st.labels.data(), src, st.ranks, st.rank);
 }
 
@@ -426,8 +522,13 @@ inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx) {
   bfs_fused_args_t a = st.args();
   bfs_set_kernel_attributes();
   bfs_launch_push(a, level, ctx, 2, bfs_cold_test(a.n, st.cold_forced));   // (the level's bookkeeping rides on the push launch)
+  const d2_cold_view_t cv = st.cold_view();
+  if (cv.flush && cv.reduced)
+    hipLaunchKernelGGL(k_d2_cold_reduce, dim3((unsigned)(((size_t)cv.slices * (BFS_COLD_WORDS / 4) + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, cv,
+                       (const bfs_ctrl_t*)a.ctrl, level, const_cast<u32*>(st.cold_flush.data()));
   hipLaunchKernelGGL(k_d2_newbits, dim3(grid_for(st.nwords, D2_NEWBITS_NT, ctx.num_cus * 2)), dim3(D2_NEWBITS_NT), 0, s, st.fs->visited.data(),
-                     st.fs->mark.data(), st.newbits, st.nwords, (long long)st.n_global, a.ctrl, st.mylist, st.list_cap, st.cold_view(), level);
+                     st.fs->mark.data(), st.newbits, st.nwords, (long long)st.n_global, a.ctrl, st.mylist, st.list_cap, cv, level,
+                     (const u32*)st.slot_marks.data(), st.declare_mul);
 }
 
 // The sparse merge of a level (k_d2_lists_apply) on `nlists` gathered lists, `stride_words` apart, and the host's wait for
@@ -439,7 +540,7 @@ inline void d2_apply_lists(d2_state_t& st, int level, const u32* glists, int nli
   bfs_fused_args_t a = st.args();
   const u64 seq = ++st.flag_seq;
   hipLaunchKernelGGL(k_d2_lists_apply<BLOCK>, dim3(256), dim3(BLOCK), 0, s, a, level, glists, nlists, (u32)stride_words, st.list_cap,
-                     st.labels.data(), st.ranks, st.rank, st.host_flag, seq);
+                     st.labels.data(), st.ranks, st.rank, st.host_flag, seq, st.newbits, nlists == 1 ? 0 : st.rank);
   MGX_CHECK_LAUNCH("partitioned BFS: list merge launch");
   // the count of this rank's own list, for the next level's sweep: behind the kernel, never inside it (see the kernel's header)
   if (st.mylist) MGX_HIP(hipMemsetAsync(st.mylist, 0, sizeof(u32), s));
@@ -462,11 +563,30 @@ inline void d2_merge(d2_state_t& st, int level, const u32* gathered, int maps, l
                      standard_context_t& ctx) {
   hipStream_t s = ctx.stream();
   bfs_fused_args_t a = st.args();
+  static const bool build_list = [] { const char* e = getenv("MGX_DIST_BUILD_LIST"); return e && atoi(e) != 0; }();
+  // OR-merge and queue build in ONE launch (k_bfs_build2<., 2, RANKS>) when the ranks are a power of two (MGX_DIST_FUSED_MERGE=0:
+  // the two launches below)
+  static const bool fused = [] { const char* e = getenv("MGX_DIST_FUSED_MERGE"); return !e || atoi(e) != 0; }();
+  const int R = st.ranks;
+  if (fused && !build_list && (R == 2 || R == 4 || R == 8 || R == 16) && (uintptr_t)a.row_offsets % 16 == 0 &&
+      (uintptr_t)gathered % 16 == 0 && stride_words % 4 == 0) {
+    bfs_d2_fuse_t fz;
+    fz.maps = gathered; fz.nmaps = maps; fz.stride = stride_words; fz.nwords = st.nwords;
+    fz.merged = st.merged.data(); fz.clear = st.newbits;
+    const long long rw = R / 2;
+    long long groups = ((long long)st.n_local + 15) / 16;
+    if ((st.nwords + rw - 1) / rw > groups) groups = (st.nwords + rw - 1) / rw;      // (the grid covers the bitmap's words, not only the rank's rows)
+    const dim3 grid(bfs_build_grid(groups * 16, 512));
+#define MGX_D2_FUSED(R_) hipLaunchKernelGGL((k_bfs_build2<512, 2, R_>), grid, dim3(512), 0, s, a, level, st.labels.data(), st.n_local, \
+                                            (const u32*)nullptr, st.ranks, st.rank, fz)
+    if (R == 2) MGX_D2_FUSED(2); else if (R == 4) MGX_D2_FUSED(4); else if (R == 8) MGX_D2_FUSED(8); else MGX_D2_FUSED(16);
+#undef MGX_D2_FUSED
+    return;
+  }
   hipLaunchKernelGGL(k_d2_or, dim3(grid_for(st.nwords / 4, BLOCK, 1024)), dim3(BLOCK), 0, s, (const uint4*)gathered, maps,
-                     stride_words / 4, st.nwords / 4, (uint4*)st.merged.data(), (uint4*)st.fs->visited.data(), a.ctrl, level);
+                     stride_words / 4, st.nwords / 4, (uint4*)st.merged.data(), (uint4*)st.fs->visited.data(), a.ctrl, level, (uint4*)st.newbits);
   // the queue build without a list when the rank's row offsets allow its 16-byte loads (k_bfs_build2<., DIST>: labels and
   // row extents of a thread's 16 local vertices are contiguous); MGX_DIST_BUILD_LIST=1: the list-based one
-  static const bool build_list = [] { const char* e = getenv("MGX_DIST_BUILD_LIST"); return e && atoi(e) != 0; }();
   if (!build_list && ((uintptr_t)a.row_offsets % 16 == 0))
     hipLaunchKernelGGL((k_bfs_build2<512, true>), dim3(bfs_build_grid(st.n_local, 512)), dim3(512), 0, s, a, level, st.labels.data(), st.n_local,
                        (const u32*)st.merged.data(), st.ranks, st.rank);

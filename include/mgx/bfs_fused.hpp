@@ -79,8 +79,8 @@ struct bfs_ctrl_t {
   int levels;        // number of levels that expanded at least one edge
   int pull;          // direction of the level about to run (set by k_bfs_level_begin; sticky once 1)
   int push_levels;   // levels run top-down
-  int level;         // (unused)
-  int big;           // (unused)
+  int d2_append_level;     // partitioned runs: the level whose push appended its discoveries to the rank's id list itself (bfs_fused_sparse.hpp: k_d2_newbits has nothing to sweep); -1: none
+  int d2_declared_level;   // partitioned runs: the level whose sweep declared its list overflowed without filling it (k_d2_newbits); -1: none
   int small_levels;  // levels run by the chains of small levels (bfs_fused_chain.hpp)
   int slots;         // launch slots that found work (their opener / chain counts them)
   int dist_done;     // partitioned runs: a level ended with no discovery on any rank ...
@@ -169,6 +169,12 @@ struct bfs_fused_args_t {
   u32 cold_off[BFS_COLD_MAX_SLICES + 1];        // its pairs: [cold_off[i], cold_off[i + 1])
   u32 cold_wgs[BFS_COLD_MAX_SLICES + 1];        // the cold workgroups [cold_wgs[i], cold_wgs[i + 1]) of a push launch take slice i
   u32* cold_flush;         // cold_wgs[cold_slices] bitmaps of BFS_COLD_WORDS words: what cold workgroup k discovered in its slice
+  // a rank of the partitioned traversal (bfs_dist2.hpp; all NULL / 0 on the single-GPU path): its id list of the level
+  // ([0] count, ids from D2_LIST_HEAD on), the list's capacity in ids, the rank's new-bit map (bfs_fused_sparse.hpp), and the
+  // frontier as a bitmap over the rank's LOCAL rows (written by the merge; NULL: none)
+  u32* d2_list = nullptr;
+  u32 d2_list_cap = 0;
+  u32* d2_newbits = nullptr;
 #ifdef MGX_LAB
   // ---- lab build only (-DMGX_LAB, never set by __graft_entry__.build()): shapes that lost their A/B runs and the
   // instrumented kernels of the measurement tools.  The product library carries none of this: MGX_LAB_GET reads a
@@ -253,7 +259,8 @@ __device__ __forceinline__ void bfs_ctrl_reset(bfs_ctrl_t* c) {
   for (int i = 0; i < 64; ++i) c->claims_level[i] = 0;
   c->pull_edges = 0;
   c->done = c->levels = c->pull = c->push_levels = 0;
-  c->level = c->big = c->small_levels = c->slots = 0;
+  c->d2_append_level = c->d2_declared_level = -1;
+  c->small_levels = c->slots = 0;
   c->dist_done = c->dist_levels = 0;
   for (int i = 0; i < 4; ++i) { c->slot_level[i] = 0; c->skip_build[i] = 0; }
   c->flush_count[0] = c->flush_count[1] = 0;
@@ -713,9 +720,23 @@ __device__ __forceinline__ bool bfs_build_is_lazy(const bfs_fused_args_t& a, int
 // DIST (a rank of the partitioned traversal, bfs_dist2.hpp): the new vertices are the bits this rank OWNS of the level's merged
 // discoveries (`bits`, over all vertices: local vertex i is global vertex i * ranks + rank) instead of marks; bitmap and
 // frontier are k_d2_or's business; labels and row extents are local and contiguous: no scatter at all.
-template <int NT, bool DIST = false>
+// DIST == 2: the same with the OR-merge of the ranks' new-bit maps INSIDE (what k_d2_or did in a launch of its own in front:
+// ~12 us of launch and sweep per dense level).  With RANKS a power of two a thread's 16 local vertices are bits
+// rank, rank + RANKS, ... of RANKS / 2 consecutive words of the global bitmap -- exactly the words no other thread looks at: the
+// thread ORs those words of all maps, stores them as the level's frontier bitmap (`merged`), ORs them into its visited bitmap,
+// clears them in the rank's own map (bfs_fused_sparse.hpp) and picks its 16 bits.  The grid covers the words, not only the rows.
+struct bfs_d2_fuse_t {
+  const u32* maps = nullptr;   // nmaps new-bit maps, stride words apart
+  int nmaps = 0;
+  long long stride = 0;
+  long long nwords = 0;        // words of a map (a multiple of 4)
+  u32* merged = nullptr;
+  u32* clear = nullptr;        // the rank's own map (may be one of `maps`: a thread clears what it has read); NULL: none
+};
+template <int NT, int DIST = 0, int RANKS = 1>
 __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int arg, int* __restrict__ labels, int n,
-                                                      const u32* __restrict__ bits = nullptr, int ranks = 1, int rank = 0) {
+                                                      const u32* __restrict__ bits = nullptr, int ranks = 1, int rank = 0,
+                                                      bfs_d2_fuse_t fz = bfs_d2_fuse_t()) {
   constexpr int NW = NT / WAVE;
   constexpr u64 CNT1 = 1ull << 40;
   constexpr u64 DEGMASK = CNT1 - 1ull;
@@ -813,7 +834,60 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
 
   // ---- which of my 16 vertices are new -------------------------------------------------------------------------------
   u32 new16 = 0;
-  if (DIST) {
+  if constexpr (DIST == 2) {
+    static_assert(RANKS >= 2 && RANKS <= 16 && (RANKS & (RANKS - 1)) == 0, "ranks: 2, 4, 8 or 16");
+    constexpr int RW = RANKS / 2;                                            // words of the bitmap per thread
+    __shared__ u32 s_found;
+    if (threadIdx.x == 0) s_found = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) c->fb_slot = level + 1;         // merged = the frontier of level + 1 as a bitmap
+    const long long w0 = (i0 >> 4) * RW;
+    u32 g[RW];
+#pragma unroll
+    for (int k = 0; k < RW; ++k) g[k] = 0u;
+    const bool in = w0 < fz.nwords;                                          // (RW <= 4: then all RW words are; RW == 8: see below)
+    u32 found = 0;
+    if (in) {
+#pragma unroll 8
+      for (int r = 0; r < fz.nmaps; ++r) {
+        const u32* const mp = fz.maps + (size_t)r * (size_t)fz.stride + w0;
+        if constexpr (RW >= 4) {
+#pragma unroll
+          for (int q4 = 0; q4 < RW / 4; ++q4) {
+            if (q4 == 0 || w0 + 4 * q4 < fz.nwords) {
+              const uint4 v = ((const uint4*)mp)[q4];
+              g[4 * q4] |= v.x; g[4 * q4 + 1] |= v.y; g[4 * q4 + 2] |= v.z; g[4 * q4 + 3] |= v.w;
+            }
+          }
+        } else if constexpr (RW == 2) {
+          const uint2 v = *(const uint2*)mp;
+          g[0] |= v.x; g[1] |= v.y;
+        } else {
+          g[0] |= mp[0];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < RW; ++k) {
+        if (k < 4 || w0 + k < fz.nwords) {
+          fz.merged[w0 + k] = g[k];
+          if (fz.clear) fz.clear[w0 + k] = 0u;
+          if (g[k]) a.visited[w0 + k] |= g[k];                               // (this thread is the word's only writer)
+          found += (u32)__popc(g[k]);
+        }
+      }
+    }
+    // every rank counts the level's discoveries itself (ctrl->merged_new): one add per workgroup
+    found = wave_sum(found);
+    __syncthreads();                                                         // (s_found = 0 is in)
+    if (lane == 0 && found) atomicAdd(&s_found, found);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_found) atomicAdd(&c->merged_new, (u64)s_found);
+    if (i0 < n) {
+      const u32 valid = (n - i0 >= 16) ? 0xFFFFu : ((1u << (int)(n - i0)) - 1u);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) new16 |= ((g[(q * RANKS) >> 5] >> (((q * RANKS) & 31) + rank)) & 1u) << q;
+      new16 &= valid;
+    }
+  } else if (DIST) {
     if (i0 < n) {
       const u32 valid = (n - i0 >= 16) ? 0xFFFFu : ((1u << (int)(n - i0)) - 1u);
 #pragma unroll

@@ -22,6 +22,7 @@
 #endif
 #include "bfs_fused_stream.hpp"
 #include "bfs_fused_vshort.hpp"
+#include "bfs_fused_sparse.hpp"
 #include "bfs_fused_wave.hpp"
 
 namespace mgx {
@@ -244,7 +245,19 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push_stream_diag(bfs_fused_args
 // the launch (open_here == 2: a rank of a partitioned run), no chain; unit blocks when the rank built them.
 template <bool COLDT>
 __global__ __launch_bounds__(1024, 8) void k_bfs_push_level(bfs_fused_args_t a, int level, u32 nstream, int open_here, u32 ncold) {
-  if (open_here && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) bfs_begin_level(a, level, open_here == 2);
+  // a level with no more edges than the rank's id list has room for writes its discoveries there itself (bfs_fused_sparse.hpp):
+  // no marks for k_d2_newbits to sweep.  Grid-uniform: read from the ring entry of the level BEFORE the opener touches anything
+  // (it clears the entry two levels ahead only).
+  const bool appends = bfs_d2_level_appends(a, level);
+  if (open_here && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    bfs_begin_level(a, level, open_here == 2);
+    bfs_slot_marks_clear(a, level + 1);
+    a.ctrl->d2_append_level = appends ? level : -1;
+  }
+  if (appends) {
+    bfs_d2_sparse_body<1024>(a, level, blockIdx.x, gridDim.x);
+    return;
+  }
   // a rank that carries unit blocks of its rows (bfs_dist2.hpp: owners in GLOBAL ids, frontier_bits = the level's merged
   // discoveries of all ranks) reads a level that holds a large share of its long rows from them -- the queue-less body of
   // the single-GPU path; with cold-edge lists the first ncold workgroups take the entries behind the LDS prefix by slice

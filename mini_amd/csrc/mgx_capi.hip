@@ -344,8 +344,8 @@ int mgx_graph_attach_layout_weights(mgx_graph_t g, const float* d_layout_weights
 }
 extern "C" int mgx_layout_build_device(const int* ro, const int* ci, const float* w, int n, long long m, int* lro, int* lci,
                                        float* lw, int* new_of_old, int* old_of_new, hipStream_t stream);   // mgx_layout.hip
-extern "C" int mgx_units_build_device(const int* ro, const int* ci, int n, int min_deg, int max_deg, int ushift, int** owner,
-                                      int** ucol, unsigned char** ucnt, int** ufirst, long long* units, long long* units_pad,
+extern "C" int mgx_units_build_device(const int* ro, const int* ci, int n, int min_deg, int max_deg, int ushift, unsigned hot_limit,
+                                      int** owner, int** ucol, unsigned char** ucnt, int** ufirst, long long* units, long long* units_pad,
                                       hipStream_t stream);
 
 // Unit blocks of the layout's long rows (mgx/bfs_fused_dense.hpp); MGX_BFS_UNITS=0 skips them.  The threshold is the
@@ -376,7 +376,7 @@ static void build_unit_blocks(mgx_graph_s* g) {
   unsigned char* ucnt = nullptr;
   long long units = 0, units_pad = 0;
   const int rc = mgx_units_build_device(G.d_layout_row_offsets.data(), G.d_layout_col_indices.data(), G.num_nodes, long_min,
-                                        0x7FFFFFFF, 6, &owner, &ucol, &ucnt, &ufirst, &units, &units_pad, g->c->ctx->stream());
+                                        0x7FFFFFFF, 6, 0u, &owner, &ucol, &ucnt, &ufirst, &units, &units_pad, g->c->ctx->stream());
   if (rc != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("unit blocks: ") + hipGetErrorString((hipError_t)rc));
   if (units <= 0) return;
   G.d_ub_owner = mem_t<int>::adopt(owner, (size_t)units_pad);
@@ -1378,7 +1378,7 @@ int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
   int *owner = nullptr, *ucol = nullptr, *ufirst = nullptr;
   unsigned char* ucnt = nullptr;
   long long U = 0, Up = 0;
-  const int rc = mgx_units_build_device(st.row_offsets, st.col_indices, st.n_local, long_min, 0x7FFFFFFF, 6, &owner, &ucol, &ucnt, &ufirst, &U, &Up,
+  const int rc = mgx_units_build_device(st.row_offsets, st.col_indices, st.n_local, long_min, 0x7FFFFFFF, 6, 0u, &owner, &ucol, &ucnt, &ufirst, &U, &Up,
                                         h->c->ctx->stream());
   if (rc != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("partitioned BFS, unit blocks: ") + hipGetErrorString((hipError_t)rc));
   if (ucnt) (void)hipFree(ucnt);
@@ -1447,8 +1447,42 @@ int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
         for (int i = used + 1; i <= mgx::BFS_COLD_MAX_SLICES; ++i) { st.cold_wgs[i] = acc; st.cold_off[i] = st.cold_off[used]; }
         st.cold_flush = mem_t<u32>((size_t)acc * mgx::BFS_COLD_WORDS, ctx);
         MGX_HIP(hipMemsetAsync(st.cold_flush.data(), 0, (size_t)acc * mgx::BFS_COLD_WORDS * sizeof(unsigned), ctx.stream()));
+        // a launch of its own ORs a slice's bitmaps together in front of the sweep (MGX_DIST_COLD_REDUCE=0: k_d2_newbits reads them all)
+        if (const char* e = getenv("MGX_DIST_COLD_REDUCE")) st.cold_reduce = atoi(e);
         ctx.synchronize();
         st.cold_pairs = pairs; st.cold_slices = used;
+        // The unit blocks again, WITHOUT the entries that now live in the pair lists (the unit-block body read them only to skip
+        // them: a third of its stream on RMAT-26 / 8) -- and what is left points into the LDS prefix, ids below 2^20: three bytes
+        // per entry do (bfs_fused_dense.hpp: ub_col24).  MGX_DIST_HOT_UNITS=0: the full blocks stay.
+        bool hot_units = true;
+        if (const char* e = getenv("MGX_DIST_HOT_UNITS")) hot_units = atoi(e) != 0;
+        if (hot_units) {
+          int *owner2 = nullptr, *ucol2 = nullptr, *ufirst2 = nullptr;
+          unsigned char* ucnt2 = nullptr;
+          long long U2 = 0, Up2 = 0;
+          const int rc3 = mgx_units_build_device(st.row_offsets, st.col_indices, st.n_local, long_min, 0x7FFFFFFF, 6, hot_n, &owner2, &ucol2, &ucnt2,
+                                                 &ufirst2, &U2, &Up2, ctx.stream());
+          if (rc3 != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("partitioned BFS, unit blocks of the hot entries: ") + hipGetErrorString((hipError_t)rc3));
+          if (ucnt2) (void)hipFree(ucnt2);
+          if (ufirst2) (void)hipFree(ufirst2);
+          if (U2 > 0) {
+            hipLaunchKernelGGL(mgx::k_d2_owner_global, dim3((unsigned)((Up2 + mgx::BLOCK - 1) / mgx::BLOCK)), dim3(mgx::BLOCK), 0, ctx.stream(), owner2, Up2,
+                               st.ranks, st.rank, st.n_local, st.n_global);
+            ctx.synchronize();
+            (void)hipFree(st.ub_owner); (void)hipFree(st.ub_col);
+            st.ub_owner = owner2; st.ub_col = ucol2; st.ub_units = U2; st.ub_units_pad = Up2;
+            if (units) *units = U2;
+            bool pack = true;
+            if (const char* e = getenv("MGX_BFS_PACK24")) pack = atoi(e) != 0;
+            if (pack) {
+              const long long quads = ((long long)Up2 << 4) + 1;
+              st.ub_col24 = mem_t<unsigned>((size_t)quads * 3 + 4, ctx);
+              hipLaunchKernelGGL(k_pack24, dim3(mgx::grid_for(quads, 256, 16384)), dim3(256), 0, ctx.stream(), (const int4*)st.ub_col, quads,
+                                 st.ub_col24.data());
+              ctx.synchronize();
+            }
+          }
+        }
       } else {
         if (cowner) (void)hipFree(cowner);
         if (cdst) (void)hipFree(cdst);

@@ -122,24 +122,37 @@ extern "C" int mgx_layout_build_device(const int* ro, const int* ci, const float
 // units read from).
 namespace {
 
-__global__ void k_unit_counts(const int* __restrict__ ro, int n, int min_deg, int max_deg, int ushift, int* __restrict__ cnt) {
+// entries of the sorted row [r0, r1) that are below `limit` (0: all of them)
+__device__ __forceinline__ int entries_below(const int* __restrict__ ci, int r0, int r1, unsigned limit) {
+  if (limit == 0u) return r1 - r0;
+  int lo = r0, hi = r1;
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if ((unsigned)ci[mid] < limit) lo = mid + 1; else hi = mid;
+  }
+  return lo - r0;
+}
+
+__global__ void k_unit_counts(const int* __restrict__ ro, const int* __restrict__ ci, int n, int min_deg, int max_deg, int ushift,
+                              unsigned hot_limit, int* __restrict__ cnt) {
   const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= n) return;
   const int deg = ro[v + 1] - ro[v];
   const int U = 1 << ushift;
-  cnt[v] = (deg >= min_deg && deg < max_deg) ? (deg + U - 1) >> ushift : 0;
+  const int kept = (deg >= min_deg && deg < max_deg) ? entries_below(ci, ro[v], ro[v + 1], hot_limit) : 0;
+  cnt[v] = (kept + U - 1) >> ushift;
 }
 
 // one wave per row of the class: owners and padded entries
 __global__ void k_unit_fill(const int* __restrict__ ro, const int* __restrict__ ci, int n, const int* __restrict__ uoff,
-                            int ushift, int* __restrict__ owner, int* __restrict__ ucol, unsigned char* __restrict__ ucnt) {
+                            int ushift, unsigned hot_limit, int* __restrict__ owner, int* __restrict__ ucol, unsigned char* __restrict__ ucnt) {
   const int lane = threadIdx.x & 63;
   const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
   for (long long v = wave0; v < n; v += nwaves) {
     const int u0 = uoff[v], u1 = uoff[v + 1];
     if (u1 == u0) continue;
-    const int r0 = ro[v], deg = ro[v + 1] - r0;
+    const int r0 = ro[v], deg = entries_below(ci, r0, ro[v + 1], hot_limit);      // (hot_limit: the row's entries below it only -- a prefix: rows are sorted)
     for (int u = u0 + lane; u < u1; u += 64) {
       owner[u] = (int)v;
       // real entries of the unit (the rest is padding, -1): the fused SSSP's sweep masks by it (mgx/sssp_fused.hpp)
@@ -167,8 +180,10 @@ __global__ void k_unit_tail(int n, int units, int units_pad, int ushift, int* __
 // Allocates *owner (units_pad ints) and *ucol ((units_pad << ushift) + 4 ints) with hipMalloc; the caller owns them.
 // *units = real units, *units_pad = padded to a multiple of 16.  *ucnt (units_pad bytes): real entries of every unit (ushift
 // <= 7); *ufirst (n + 1 ints): the units of row v are [ufirst[v], ufirst[v + 1]).  Returns 0 or the hipError_t that stopped it.
-extern "C" int mgx_units_build_device(const int* ro, const int* ci, int n, int min_deg, int max_deg, int ushift, int** owner,
-                                      int** ucol, unsigned char** ucnt, int** ufirst, long long* units, long long* units_pad,
+// hot_limit != 0 (rows SORTED by neighbour id): only the entries below it are copied -- a rank of the partitioned traversal whose
+// other entries live in the cold-edge lists (bfs_fused_cold.hpp): its unit-block body would read them only to skip them.
+extern "C" int mgx_units_build_device(const int* ro, const int* ci, int n, int min_deg, int max_deg, int ushift, unsigned hot_limit,
+                                      int** owner, int** ucol, unsigned char** ucnt, int** ufirst, long long* units, long long* units_pad,
                                       hipStream_t stream) {
   *owner = nullptr; *ucol = nullptr; *ucnt = nullptr; *ufirst = nullptr; *units = 0; *units_pad = 0;
   if (n <= 0) return 0;
@@ -176,7 +191,7 @@ extern "C" int mgx_units_build_device(const int* ro, const int* ci, int n, int m
   const unsigned nblocks = (unsigned)(((long long)n + threads - 1) / threads);
   tmp_t cnt, uoff, st;
   LAY_TRY(cnt.alloc((size_t)n * 4)); LAY_TRY(uoff.alloc(((size_t)n + 1) * 4));
-  hipLaunchKernelGGL(k_unit_counts, dim3(nblocks), dim3(threads), 0, stream, ro, n, min_deg, max_deg, ushift, cnt.as<int>());
+  hipLaunchKernelGGL(k_unit_counts, dim3(nblocks), dim3(threads), 0, stream, ro, ci, n, min_deg, max_deg, ushift, hot_limit, cnt.as<int>());
   size_t sb = 0;
   LAY_TRY(rocprim::exclusive_scan(nullptr, sb, cnt.as<int>(), uoff.as<int>(), 0, (size_t)n, rocprim::plus<int>(), stream));
   LAY_TRY(st.alloc(sb));
@@ -201,7 +216,7 @@ extern "C" int mgx_units_build_device(const int* ro, const int* ci, int n, int m
     *owner = nullptr; *ucol = nullptr; *ucnt = nullptr; *ufirst = nullptr;
     return (int)e;
   }
-  hipLaunchKernelGGL(k_unit_fill, dim3(4096), dim3(256), 0, stream, ro, ci, n, uoff.as<int>(), ushift, *owner, *ucol, *ucnt);
+  hipLaunchKernelGGL(k_unit_fill, dim3(4096), dim3(256), 0, stream, ro, ci, n, uoff.as<int>(), ushift, hot_limit, *owner, *ucol, *ucnt);
   const long long tail = ((Up - U) << ushift) + 4;
   hipLaunchKernelGGL(k_unit_tail, dim3((unsigned)((tail + 255) / 256)), dim3(256), 0, stream, n, (int)U, (int)Up, ushift, *owner, *ucol, *ucnt);
   (void)hipMemcpyAsync(*ufirst, uoff.as<int>(), ((size_t)n + 1) * 4, hipMemcpyDeviceToDevice, stream);

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Generation-2 partitioned BFS on ONE GPU: G rank engines share the device and run one after another
 (the all-gather becomes a concatenation), so the time per rank = total / G is what each GPU of a G-GPU
-job would spend in kernels per BFS (no xGMI time).  usage: dist2_single.py [scale] [G] [gather|reduce]
-reduce: the slice exchange of DistBfs2 (all-to-all of slices -> OR -> all-gather of merged slices), the two
-collectives again as copies."""
+job would spend in kernels per BFS (no xGMI time).  usage: dist2_single.py [scale] [G] [lists|gather|reduce]
+lists (default): the level protocol of mgx_dbfs2_run / DistBfs2.run -- id lists first (the all-gather a concatenation, every
+engine's list merge with its host round trip), the bitmaps only when some rank's list overflowed;
+gather: bitmaps on every level; reduce: the slice exchange of DistBfs2 (all-to-all of slices -> OR -> all-gather of merged
+slices), the two collectives again as copies."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,7 +13,7 @@ import mini_amd
 from mini_amd.dist_bfs import HipRankEngine2, rmat_cyclic_shard
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-mode = sys.argv[3] if len(sys.argv) > 3 else "gather"
+mode = sys.argv[3] if len(sys.argv) > 3 else "lists"
 dev = torch.device("cuda", 0)
 ctx = mini_amd.Context(0, torch.cuda.current_stream().cuda_stream)
 n = 1 << scale
@@ -33,7 +35,22 @@ for it, s in enumerate(srcs):
     for e in engs:
         e.reset(s)
     level, batch = 0, hint
-    while True:
+    sparse = dense = 0
+    while mode == "lists":
+        maps = [e.push(level) for e in engs]
+        glists = torch.cat([e.list for e in engs]) if G > 1 else engs[0].list
+        res = [e.apply_lists(level, glists, G) for e in engs]
+        level += 1
+        if res[0][1] == 0:
+            break
+        if res[0][0]:
+            gathered = torch.cat(maps) if G > 1 else maps[0]
+            for e in engs:
+                e.merge(level - 1, gathered, G)
+            dense += 1
+        else:
+            sparse += 1
+    while mode != "lists":
         for _ in range(batch):
             if mode == "reduce" and G > 1:
                 maps = [e.push(level) for e in engs]
@@ -55,6 +72,8 @@ for it, s in enumerate(srcs):
         if sts[0]["over"]:
             break
         batch = 2
+    if mode == "lists":
+        sts = [e.status(level) for e in engs]
     hint = sts[0]["levels"] + 1
     edges = sum(st["edges_local"] for st in sts)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
@@ -76,4 +95,5 @@ for it, s in enumerate(srcs):
             print("check vs the single-GPU traversal of the unpartitioned graph: labels equal = %s (reached %d)" % (same, int((single >= 0).sum())))
             assert same
         print(mode + " src %d levels %d edges %d  total %.3f ms  per-rank %.3f ms  -> %.1f GTEPS aggregate (no exchange time); levels read from unit blocks on rank 0: %d"
-              % (s, sts[0]["levels"], edges, dt * 1e3, dt * 1e3 / G, edges / (dt / G) / 1e9, engs[0].dense_levels()))
+              % (s, sts[0]["levels"], edges, dt * 1e3, dt * 1e3 / G, edges / (dt / G) / 1e9, engs[0].dense_levels())
+              + (" (levels merged from lists %d, from bitmaps %d)" % (sparse, dense) if mode == "lists" else ""))
