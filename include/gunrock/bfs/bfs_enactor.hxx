@@ -192,6 +192,10 @@ struct bfs_fused_enactor_t {
         layout.cold_owner = g.d_cold_owner.data();
         layout.cold_dst = g.d_cold_dst.data();
         layout.cold_slices = g.cold_slices;
+        if (g.d_cold_pk.size() && g.d_cold_cbase.size()) {
+          layout.cold_pk = g.d_cold_pk.data(); layout.cold_cbase = g.d_cold_cbase.data(); layout.cold_pk_mask = g.cold_pk_mask;
+          for (int i = 0; i <= mgx::BFS_COLD_MAX_SLICES; ++i) layout.cold_cb[i] = g.cold_cb[i];
+        }
         static_assert(mgx::BFS_COLD_MAX_SLICES == 64, "graph_device_t::cold_* hold this many slices");
         for (int i = 0; i < mgx::BFS_COLD_MAX_SLICES; ++i) layout.cold_lo[i] = g.cold_lo[i];
         for (int i = 0; i <= mgx::BFS_COLD_MAX_SLICES; ++i) { layout.cold_off[i] = g.cold_off[i]; layout.colds_off[i] = g.colds_off[i]; layout.cold_wgs[i] = g.cold_wgs[i]; }

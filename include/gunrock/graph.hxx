@@ -104,6 +104,10 @@ struct graph_device_t {
   // (owner, dst) pairs grouped by slice of the id range; built with the layout when they are a small share of the entries.
   mem_t<int> d_cold_owner;
   mem_t<int> d_cold_dst;
+  mem_t<unsigned> d_cold_pk;          // the long rows' pairs at four bytes each + the owners of their 64-chunks (mgx_layout.hip: mgx_cold_pack_device)
+  mem_t<unsigned> d_cold_cbase;
+  unsigned cold_cb[65] = {0};
+  unsigned long long cold_pk_mask = 0;
   mem_t<int> d_colds_owner;           // the same for the SHORT rows' entries (the vertex-by-vertex body's cold entries)
   mem_t<int> d_colds_dst;
   long long cold_pairs = 0, colds_pairs = 0;

@@ -402,6 +402,10 @@ struct d2_state_t {
   // the slices that hold any, the cold workgroups of a push launch per slice, their flush bitmaps
   int* cold_owner = nullptr;
   int* cold_dst = nullptr;
+  u32* cold_pk = nullptr;             // the same pairs at four bytes each (mgx_layout.hip: mgx_cold_pack_device), their 64-chunks' owners
+  u32* cold_cbase = nullptr;
+  u32 cold_cb[BFS_COLD_MAX_SLICES + 1] = {};
+  u64 cold_pk_mask = 0;
   long long cold_pairs = 0;
   int cold_slices = 0;
   u32 cold_lo[BFS_COLD_MAX_SLICES] = {};
@@ -455,6 +459,8 @@ struct d2_state_t {
     if (ub_owner) (void)hipFree(ub_owner);
     if (cold_owner) (void)hipFree(cold_owner);
     if (cold_dst) (void)hipFree(cold_dst);
+    if (cold_pk) (void)hipFree(cold_pk);
+    if (cold_cbase) (void)hipFree(cold_cbase);
   }
   d2_state_t() {}
   d2_state_t(const d2_state_t&) = delete;
@@ -494,6 +500,9 @@ struct d2_state_t {
     const bool cold = cold_dst != nullptr && ub_col != nullptr && cold_slices > 0 && cold_flush.size() > 0;
     a.cold_owner = cold ? cold_owner : nullptr; a.cold_dst = cold ? cold_dst : nullptr; a.cold_slices = cold ? cold_slices : 0;
     a.cold_flush = cold ? const_cast<u32*>(cold_flush.data()) : nullptr;
+    const bool pk = cold && cold_pk && cold_cbase;
+    a.cold_pk = pk ? cold_pk : nullptr; a.cold_cbase = pk ? cold_cbase : nullptr; a.cold_pk_mask = pk ? cold_pk_mask : 0ull; a.cold_ranks = (u32)ranks;
+    for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) a.cold_cb[i] = pk ? cold_cb[i] : 0u;
     for (int i = 0; i < BFS_COLD_MAX_SLICES; ++i) a.cold_lo[i] = cold ? cold_lo[i] : 0u;
     for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) { a.cold_off[i] = cold ? cold_off[i] : 0u; a.cold_wgs[i] = cold ? cold_wgs[i] : 0u; }
     a.flush_buf = nullptr; a.defer_min_marks = 0;     // (k_d2_newbits reads the marks: nothing is deferred)
@@ -521,6 +530,12 @@ inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx) {
   hipStream_t s = ctx.stream();
   bfs_fused_args_t a = st.args();
   bfs_set_kernel_attributes();
+  static const bool split = [] { const char* e = getenv("MGX_DIST_PUSH_SPLIT"); return e && atoi(e) != 0; }();
+  if (split) {     // measurements: cold pass, long rows, short rows as three launches
+    bfs_launch_push(a, level, ctx, 2 | ((2 | 4) << 4), bfs_cold_test(a.n, st.cold_forced));
+    bfs_launch_push(a, level, ctx, 0 | ((1 | 4) << 4), bfs_cold_test(a.n, st.cold_forced));
+    bfs_launch_push(a, level, ctx, 0 | ((1 | 2) << 4), bfs_cold_test(a.n, st.cold_forced));
+  } else
   bfs_launch_push(a, level, ctx, 2, bfs_cold_test(a.n, st.cold_forced));   // (the level's bookkeeping rides on the push launch)
   const d2_cold_view_t cv = st.cold_view();
   if (cv.flush && cv.reduced)

@@ -169,6 +169,14 @@ struct bfs_fused_args_t {
   u32 cold_off[BFS_COLD_MAX_SLICES + 1];        // its pairs: [cold_off[i], cold_off[i + 1])
   u32 cold_wgs[BFS_COLD_MAX_SLICES + 1];        // the cold workgroups [cold_wgs[i], cold_wgs[i + 1]) of a push launch take slice i
   u32* cold_flush;         // cold_wgs[cold_slices] bitmaps of BFS_COLD_WORDS words: what cold workgroup k discovered in its slice
+  // the same pairs at four bytes each (mgx_layout.hip: mgx_cold_pack_device): bits 0..19 dst - cold_lo[slice], bits 20..31
+  // (owner - the owner of the first pair of the pair's 64-chunk) / cold_ranks; NULL: none.  Slice q is packed when bit q of
+  // cold_pk_mask is set; its chunks' owners are cold_cbase[cold_cb[q] ..)
+  const u32* cold_pk = nullptr;
+  const u32* cold_cbase = nullptr;
+  u64 cold_pk_mask = 0;
+  u32 cold_ranks = 1;
+  u32 cold_cb[BFS_COLD_MAX_SLICES + 1] = {};
   // a rank of the partitioned traversal (bfs_dist2.hpp; all NULL / 0 on the single-GPU path): its id list of the level
   // ([0] count, ids from D2_LIST_HEAD on), the list's capacity in ids, the rank's new-bit map (bfs_fused_sparse.hpp), and the
   // frontier as a bitmap over the rank's LOCAL rows (written by the merge; NULL: none)
@@ -1052,7 +1060,8 @@ struct bfs_run_opts_t {
   int dense = -1;          // MGX_BFS_DENSE: 0 never, N > 0 dense_div = N
   int vshort = -1;         // MGX_BFS_VSHORT: 0 never, N > 0 vshort_div = N
   long long chain = -1;    // MGX_BFS_CHAIN_MAX_EDGES: 0 never (default BFS_CHAIN_CAP)
-  int pack24 = 1;                     // MGX_BFS_PACK24=0: the unit-block body reads the 32-bit entries even when the graph carries the 24-bit copy
+  int pack24 = 1;                     // MGX_BFS_PACK24=0
+  int cold_pack = 1;                  // MGX_BFS_COLD_PACK=0: the cold-edge pass reads its pairs at eight bytes each: the unit-block body reads the 32-bit entries even when the graph carries the 24-bit copy
   int src_plan = 1;                   // MGX_BFS_SRC_PLAN=0: every traversal gets the same launch sequence (no per-source classes)
   int defer_words = -1;               // MGX_BFS_DEFER_WORDS: words of the bitmap prefix whose marks are deferred (default: all BFS_FLUSH_WORDS)
   int defer_mul = 1, defer_div = 1;   // MGX_BFS_DEFER_REACH="mul/div": a level defers its hot marks while reached * mul < range * div
@@ -1101,6 +1110,7 @@ struct bfs_run_opts_t {
     geti("MGX_BFS_DEFER_WORDS", o.defer_words);
     geti("MGX_BFS_SRC_PLAN", o.src_plan);
     geti("MGX_BFS_PACK24", o.pack24);
+    geti("MGX_BFS_COLD_PACK", o.cold_pack);
     geti("MGX_BFS_COLD", o.cold);
     if (const char* e = getenv("MGX_BFS_DEFER_REACH")) {
       o.defer_mul = atoi(e);

@@ -80,9 +80,30 @@ __device__ __forceinline__ void bfs_cold_body(const bfs_fused_args_t& a, int slo
     const u32 chunk = (((p1 - p0) + parts - 1u) / parts + 255u) & ~255u;
     const u32 b = p0 + part * chunk < p1 ? p0 + part * chunk : p1;
     const u32 e = b + chunk < p1 ? b + chunk : p1;
+    // four bytes per pair where the slice has them (args.cold_pk): the pair's word and the owner of its 64-chunk -- one address
+    // per wave (b is a multiple of 256 pairs behind p0: a wave's 64 pairs are one chunk)
+    const bool packed = which == 0 && a.cold_pk != nullptr && ((a.cold_pk_mask >> sl) & 1ull);
+    const u32* __restrict__ pk = a.cold_pk;
+    const u32* __restrict__ cbase = a.cold_cbase + a.cold_cb[sl];
     for (u32 r0 = b; r0 < e; r0 += (u32)NT * K) {
       const u32 base = r0 + threadIdx.x;
       u32 ow[K], dd[K];
+      if (packed) {
+        u32 pw[K], cb[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const u32 i = base + (u32)k * NT;
+          const u32 j = i < e ? i : b;               // (a pair of this workgroup's range: readable, ignored)
+          pw[k] = pk[j];
+          cb[k] = cbase[(j - p0) >> 6];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const bool in = base + (u32)k * NT < e;
+          ow[k] = in ? cb[k] + (pw[k] >> 20) * a.cold_ranks : 0xFFFFFFFFu;
+          dd[k] = in ? lo + (pw[k] & 0xFFFFFu) : 0xFFFFFFFFu;
+        }
+      } else {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const u32 i = base + (u32)k * NT;
@@ -91,6 +112,7 @@ __device__ __forceinline__ void bfs_cold_body(const bfs_fused_args_t& a, int slo
         ow[k] = (u32)owner[j];
         dd[k] = in ? (u32)dst[j] : 0xFFFFFFFFu;
         if (!in) ow[k] = 0xFFFFFFFFu;
+      }
       }
       u32 fw[K];
 #pragma unroll

@@ -49,6 +49,10 @@ struct bfs_layout_t {
   // cold-edge lists of the long rows (bfs_fused_cold.hpp): pairs grouped by slice; hot_n / long_min they were cut for
   const int* cold_owner = nullptr;
   const int* cold_dst = nullptr;
+  const unsigned* cold_pk = nullptr;    // the same pairs, four bytes each (bfs_fused_args_t::cold_pk); NULL: none
+  const unsigned* cold_cbase = nullptr;
+  unsigned cold_cb[BFS_COLD_MAX_SLICES + 1] = {0};
+  unsigned long long cold_pk_mask = 0;
   const int* colds_owner = nullptr;   // (lab builds) the short rows' cold entries
   const int* colds_dst = nullptr;
   int cold_slices = 0;
@@ -248,6 +252,10 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push_level(bfs_fused_args_t a, 
   // a level with no more edges than the rank's id list has room for writes its discoveries there itself (bfs_fused_sparse.hpp):
   // no marks for k_d2_newbits to sweep.  Grid-uniform: read from the ring entry of the level BEFORE the opener touches anything
   // (it clears the entry two levels ahead only).
+  // (measurements, MGX_DIST_PUSH_SPLIT=1: the three parts of the grid as three launches -- bits 4 / 5 / 6 of open_here switch the
+  //  cold pass / the long rows / the short rows of THIS launch off; the level's bookkeeping rides on the first)
+  const int skip = open_here >> 4;
+  open_here &= 15;
   const bool appends = bfs_d2_level_appends(a, level);
   if (open_here && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
     bfs_begin_level(a, level, open_here == 2);
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push_level(bfs_fused_args_t a, 
     a.ctrl->d2_append_level = appends ? level : -1;
   }
   if (appends) {
-    bfs_d2_sparse_body<1024>(a, level, blockIdx.x, gridDim.x);
+    if (!(skip & 1)) bfs_d2_sparse_body<1024>(a, level, blockIdx.x, gridDim.x);     // (a split push: with its first launch)
     return;
   }
   // a rank that carries unit blocks of its rows (bfs_dist2.hpp: owners in GLOBAL ids, frontier_bits = the level's merged
@@ -268,13 +276,14 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push_level(bfs_fused_args_t a, 
   const bool dense = bfs_long_is_dense(a, a.ctrl, level, a.ctrl->lcursor[level % 3]) && (!COLDT || a.cold_dst != nullptr);
   const bool cold = dense && a.cold_dst != nullptr;
   if (blockIdx.x < ncold) {
-    if (cold) {
+    if (cold && !(skip & 1)) {
       if (blockIdx.x == 0 && threadIdx.x == 0) { a.ctrl->cold_slot = level; a.ctrl->cold_slots += 1; }   // (k_d2_newbits: OR the slices' flush bitmaps in)
       bfs_cold_body<1024>(a, level, blockIdx.x, level, true, false);
     }
     return;
   }
   const u32 blk = blockIdx.x - ncold, nblk = gridDim.x - ncold;
+  if (blk < nstream ? (skip & 2) != 0 : (skip & 4) != 0) return;
   if (blk < nstream) {
     if (dense) {
       if (blk == 0 && threadIdx.x == 0) a.ctrl->dense_slots += 1;
@@ -440,6 +449,10 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   a.cold_owner = cold ? layout->cold_owner : nullptr;
   a.cold_dst = cold ? layout->cold_dst : nullptr;
   a.cold_slices = cold ? layout->cold_slices : 0;
+  const bool cold_pk = cold && layout->cold_pk && layout->cold_cbase && opt.cold_pack;
+  a.cold_pk = cold_pk ? layout->cold_pk : nullptr; a.cold_cbase = cold_pk ? layout->cold_cbase : nullptr;
+  a.cold_pk_mask = cold_pk ? layout->cold_pk_mask : 0ull; a.cold_ranks = 1;
+  for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) a.cold_cb[i] = cold_pk ? layout->cold_cb[i] : 0u;
   for (int i = 0; i < BFS_COLD_MAX_SLICES; ++i) a.cold_lo[i] = cold ? layout->cold_lo[i] : 0u;
   for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) { a.cold_off[i] = cold ? layout->cold_off[i] : 0u; a.cold_wgs[i] = cold ? layout->cold_wgs[i] : 0u; }
   // ... and of the short rows, for the levels that walk them vertex by vertex

@@ -326,6 +326,7 @@ int mgx_graph_attach_layout(mgx_graph_t g, const int* d_row_offsets, const int* 
   G.sliced_tried = false; G.sliced_slices = 0;
   G.vs_edges = 0; G.vs_dummy = 0; G.vs_long_min = 0;      // (borrowed arrays: no padding behind them, sortedness not checked)
   G.d_cold_owner = mem_t<int>(); G.d_cold_dst = mem_t<int>(); G.d_colds_owner = mem_t<int>(); G.d_colds_dst = mem_t<int>();
+  G.d_cold_pk = mem_t<unsigned>(); G.d_cold_cbase = mem_t<unsigned>(); G.cold_pk_mask = 0;
   G.cold_pairs = G.colds_pairs = 0; G.cold_slices = 0;
   use_device(g->c);
   g->c->ctx->synchronize();
@@ -399,6 +400,8 @@ static void build_unit_blocks(mgx_graph_s* g) {
 }
 extern "C" int mgx_cold_build_device(const int* ro, const int* ci, int n, int row0, int rows, int min_deg, unsigned hot_n, unsigned slice_n,
                                      int slices, int** owner, int** dst, long long* pairs, int* slice_off, hipStream_t stream);
+extern "C" int mgx_cold_pack_device(const int* owner, const int* dst, int used, const unsigned* off, const unsigned* lo, int ranks,
+                                    unsigned** pk, unsigned** cbase, unsigned* cb_off, unsigned long long* mask, hipStream_t stream);
 // Cold-edge lists of the layout (mgx/bfs_fused_cold.hpp); MGX_BFS_COLD_LISTS=0 skips them.  Needs the unit blocks and the
 // degree classes (a degree-sorted layout: the long rows are [0, vs_v[0]), the short ones [vs_v[0], vs_v[3])); built only
 // when the cold entries are a small share of the long rows' entries (a skewed graph under the hub-first order) and few
@@ -478,6 +481,19 @@ static void build_cold_lists(mgx_graph_s* g) {
   for (int i = used + 1; i <= mgx::BFS_COLD_MAX_SLICES; ++i) { G.cold_wgs[i] = acc; G.cold_off[i] = G.cold_off[used]; G.colds_off[i] = G.colds_off[used]; }
   G.d_cold_owner = std::move(d_owner); G.d_cold_dst = std::move(d_dst);
   G.d_colds_owner = std::move(d_owner_s); G.d_colds_dst = std::move(d_dst_s);
+  {
+    // the long rows' pairs once more, four bytes each
+    unsigned *pk = nullptr, *cbase = nullptr;
+    unsigned long long mask = 0;
+    const int rcp = mgx_cold_pack_device(G.d_cold_owner.data(), G.d_cold_dst.data(), used, G.cold_off, G.cold_lo, 1, &pk, &cbase, G.cold_cb, &mask,
+                                         g->c->ctx->stream());
+    if (rcp != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("cold-edge lists, packed copy: ") + hipGetErrorString((hipError_t)rcp));
+    if (pk && cbase) {
+      G.d_cold_pk = mem_t<unsigned>::adopt(pk, (size_t)pairs + 256);
+      G.d_cold_cbase = mem_t<unsigned>::adopt(cbase, (size_t)G.cold_cb[used] + 64);
+      G.cold_pk_mask = mask;
+    }
+  }
   G.cold_pairs = pairs; G.colds_pairs = pairs_s; G.cold_slices = used; G.cold_hot_n = hot_n; G.cold_long_min = G.vs_long_min;
 }
 // graph_device_t::src_shapes: per vertex (original ids) its degree and the shape of the level behind it as a traversal from
@@ -1451,6 +1467,19 @@ int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
         if (const char* e = getenv("MGX_DIST_COLD_REDUCE")) st.cold_reduce = atoi(e);
         ctx.synchronize();
         st.cold_pairs = pairs; st.cold_slices = used;
+        // the pairs once more, four bytes each (owners are global ids by now: `ranks` apart inside a list)
+        {
+          bool pack_pairs = true;
+          if (const char* e = getenv("MGX_BFS_COLD_PACK")) pack_pairs = atoi(e) != 0;
+          if (pack_pairs) {
+            unsigned *pk = nullptr, *cbase = nullptr;
+            unsigned long long mask = 0;
+            const int rcp = mgx_cold_pack_device(st.cold_owner, st.cold_dst, used, st.cold_off, st.cold_lo, st.ranks, &pk, &cbase, st.cold_cb, &mask, ctx.stream());
+            if (rcp != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("partitioned BFS, packed cold-edge lists: ") + hipGetErrorString((hipError_t)rcp));
+            st.cold_pk = pk; st.cold_cbase = cbase; st.cold_pk_mask = mask;
+            if (getenv("MGX_DIST_VERBOSE")) fprintf(stderr, "[mgx] rank %d: packed pair lists, slice mask %016llx of %d slices\n", st.rank, mask, used);
+          }
+        }
         // The unit blocks again, WITHOUT the entries that now live in the pair lists (the unit-block body read them only to skip
         // them: a third of its stream on RMAT-26 / 8) -- and what is left points into the LDS prefix, ids below 2^20: three bytes
         // per entry do (bfs_fused_dense.hpp: ub_col24).  MGX_DIST_HOT_UNITS=0: the full blocks stay.

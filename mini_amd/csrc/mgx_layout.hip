@@ -328,6 +328,75 @@ extern "C" int mgx_cold_build_device(const int* ro, const int* ci, int n, int ro
   return 0;
 }
 
+// ---- the pair lists, four bytes per pair ------------------------------------------------------------------------------
+// A level that reads the unit blocks streams ALL pairs of every slice (bfs_fused_cold.hpp), eight bytes each: on a rank of
+// RMAT-26 / 8 that is 712 MB per dense level -- 168 us, as much as its whole unit-block stream.  Inside a slice the pairs are
+// ordered by owner, so 64 consecutive pairs (what a wave loads at once) span few owners: the copy made here keeps, per chunk of
+// 64 pairs of a slice, the owner of its first pair (cbase) and per pair
+//     bits 0..19  dst - first vertex of the slice      (a slice is 652 288 vertices)
+//     bits 20..31 (owner - cbase of the chunk) / ranks (owners of a rank's list are global ids of ITS rows: multiples apart)
+// A slice with a chunk that spans 4 096 owners or more keeps the 8-byte pairs (its bit in *mask stays 0).
+namespace {
+struct cold_pack_t {
+  unsigned off[65];      // pairs of slice q: [off[q], off[q + 1])
+  unsigned lo[64];       // its first vertex
+  unsigned cb[65];       // its chunks' owners: cbase[cb[q] ..)
+  int used;
+  int ranks;
+};
+__global__ void k_cold_pack(const int* __restrict__ owner, const int* __restrict__ dst, cold_pack_t P, unsigned* __restrict__ pk,
+                            unsigned* __restrict__ cbase, unsigned* __restrict__ bad) {
+  const unsigned total = P.off[P.used];
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total + 256u; i += gridDim.x * blockDim.x) {
+    if (i >= total) { pk[i] = 0u; continue; }
+    int q = 0;
+    while (q + 1 < P.used && i >= P.off[q + 1]) ++q;
+    const unsigned p0 = P.off[q], c = (i - p0) >> 6;
+    const unsigned base = (unsigned)owner[p0 + (c << 6)];
+    const unsigned own = (unsigned)owner[i];
+    const unsigned delta = (own - base) / (unsigned)P.ranks;
+    const unsigned rel = (unsigned)dst[i] - P.lo[q];
+    if (own < base || delta >= 4096u || rel >= (1u << 20) || (own - base) % (unsigned)P.ranks) atomicOr(&bad[q >> 5], 1u << (q & 31));
+    pk[i] = (rel & 0xFFFFFu) | (delta << 20);
+    if (((i - p0) & 63u) == 0u) cbase[P.cb[q] + c] = base;
+  }
+}
+}  // namespace
+
+// owner / dst: the lists of mgx_cold_build_device AFTER the caller has put the owners into the id space the kernels look them
+// up in; used <= 64 slices, off (used + 1) / lo (used) as the kernels get them.  Allocates *pk (pairs + 256 words) and *cbase;
+// cb_off (used + 1, host): where a slice's chunk owners start; *mask: bit q set = slice q is packed.
+extern "C" int mgx_cold_pack_device(const int* owner, const int* dst, int used, const unsigned* off, const unsigned* lo, int ranks,
+                                    unsigned** pk, unsigned** cbase, unsigned* cb_off, unsigned long long* mask, hipStream_t stream) {
+  *pk = nullptr; *cbase = nullptr; *mask = 0ull;
+  if (used <= 0 || used > 64 || ranks <= 0) return 0;
+  cold_pack_t P;
+  P.used = used; P.ranks = ranks;
+  unsigned acc = 0;
+  for (int q = 0; q < used; ++q) { P.off[q] = off[q]; P.lo[q] = lo[q]; P.cb[q] = acc; cb_off[q] = acc; acc += (off[q + 1] - off[q] + 63u) / 64u; }
+  P.off[used] = off[used]; P.cb[used] = acc; cb_off[used] = acc;
+  for (int q = used + 1; q <= 64; ++q) { P.off[q] = off[used]; P.cb[q] = acc; }
+  for (int q = used; q < 64; ++q) P.lo[q] = 0;
+  const unsigned total = off[used];
+  if (total == 0u) return 0;
+  tmp_t bad;
+  LAY_TRY(bad.alloc(8));
+  LAY_TRY(hipMemsetAsync(bad.p, 0, 8, stream));
+  LAY_TRY(hipMalloc((void**)pk, ((size_t)total + 256) * 4));
+  hipError_t e = hipMalloc((void**)cbase, ((size_t)acc + 64) * 4);
+  if (e != hipSuccess) { (void)hipFree(*pk); *pk = nullptr; return (int)e; }
+  (void)hipMemsetAsync(*cbase, 0, ((size_t)acc + 64) * 4, stream);
+  hipLaunchKernelGGL(k_cold_pack, dim3(4096), dim3(256), 0, stream, owner, dst, P, *pk, *cbase, bad.as<unsigned>());
+  unsigned hb[2] = {0, 0};
+  e = hipMemcpyAsync(hb, bad.p, 8, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) { (void)hipFree(*pk); (void)hipFree(*cbase); *pk = nullptr; *cbase = nullptr; return (int)e; }
+  const unsigned long long badmask = (unsigned long long)hb[0] | ((unsigned long long)hb[1] << 32);
+  const unsigned long long all = used == 64 ? ~0ull : ((1ull << used) - 1ull);
+  *mask = all & ~badmask;
+  return 0;
+}
+
 // ---- genuine CSC (transpose) of a device CSR ------------------------------------------------------------------------
 // The reference's loader always ends up with csc == csr (its transposed copy goes into a shadowed local), which
 // is only right for symmetric inputs.  Bottom-up BFS levels on a DIRECTED graph need the in-edges: col_offsets[v] ..

@@ -42,6 +42,12 @@ for key in ("k_bfs_push_level", "k_d2_newbits", "k_d2_lists_apply", "k_d2_or", "
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in last if key in r["Kernel_Name"]]
     if d:
         print("  last traversal, %-18s per level (mean over ranks): %s" % (key, " ".join("%6.1f" % (sum(d[i:i + G]) / len(d[i:i + G])) for i in range(0, len(d), G))))
+nb = len([r for r in last if "k_d2_newbits" in r["Kernel_Name"]])
+d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in last if "k_bfs_push_level" in r["Kernel_Name"]]
+if nb and len(d) == 3 * nb:      # MGX_DIST_PUSH_SPLIT=1: three launches per rank and level
+    for part, name in enumerate(("cold pass", "long rows", "short rows")):
+        dd = d[part::3]
+        print("  split push, %-10s per level (mean over ranks): %s" % (name, " ".join("%6.1f" % (sum(dd[i:i + G]) / len(dd[i:i + G])) for i in range(0, len(dd), G))))
 PY
   rm -rf $O/tr$i
 done
