@@ -50,26 +50,50 @@ struct d2_cold_view_t {
 // lane, eight buffers in flight -- a stream (a thousand buffers of 80 KB on RMAT-26 / 8: 83 MB).  Returns at once on a level
 // whose push did not run the cold pass.  (Inside the push launch -- the last workgroup of a slice to finish does it -- the
 // fences that make the other workgroups' stores visible across the XCDs' L2s tripled the launch: 368 -> 1 230 us.)
-__global__ __launch_bounds__(BLOCK) void k_d2_cold_reduce(d2_cold_view_t cv, const bfs_ctrl_t* c, int level, u32* flush) {
-  if (!cv.flush || c->cold_slot != level || c->d2_append_level == level) return;
+// The same for the bitmaps of the level's deferred hot marks (bfs_hot_epilogue: ctrl->flush_count[level & 1] buffers of
+// BFS_FLUSH_WORDS words in defer_buf): the threads behind the slices'.
+__global__ __launch_bounds__(BLOCK) void k_d2_cold_reduce(d2_cold_view_t cv, const bfs_ctrl_t* c, int level, u32* flush, u32* defer_buf) {
+  if (c->d2_append_level == level) return;
   constexpr u32 Q = BFS_COLD_WORDS / 4;
   const u32 t = blockIdx.x * BLOCK + threadIdx.x;
-  const u32 q = t / Q, i = t % Q;
-  if ((int)q >= cv.slices) return;
-  const u32 parts = cv.wgs[q + 1] - cv.wgs[q];
+  const u32 cold_threads = (u32)cv.slices * Q;
+  u32 parts, i, stride4;
+  uint4* first;
+  if (t < cold_threads) {
+    if (!cv.flush || c->cold_slot != level) return;
+    const u32 q = t / Q;
+    i = t % Q;
+    parts = cv.wgs[q + 1] - cv.wgs[q];
+    first = (uint4*)(flush + (size_t)cv.wgs[q] * BFS_COLD_WORDS);
+    stride4 = Q;
+  } else {
+    i = t - cold_threads;
+    if (!defer_buf || i >= (u32)BFS_FLUSH_WORDS / 4u) return;
+    parts = c->flush_count[level & 1];
+    if (parts > (u32)BFS_FLUSH_MAX) parts = (u32)BFS_FLUSH_MAX;
+    first = (uint4*)defer_buf;
+    stride4 = (u32)BFS_FLUSH_WORDS / 4u;
+  }
   if (parts < 2u) return;
-  uint4* const first = (uint4*)(flush + (size_t)cv.wgs[q] * BFS_COLD_WORDS);
+  const u32 Qs = stride4;
   uint4 acc = first[i];
   u32 k = 1;
-  for (; k + 8u <= parts; k += 8u) {
-    uint4 v[8];
+  for (; k + 16u <= parts; k += 16u) {
+    uint4 v[16];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = first[(size_t)(k + (u32)j) * Q + i];
+    for (int j = 0; j < 16; ++j) v[j] = first[(size_t)(k + (u32)j) * Qs + i];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { acc.x |= v[j].x; acc.y |= v[j].y; acc.z |= v[j].z; acc.w |= v[j].w; }
+    for (int j = 0; j < 16; ++j) { acc.x |= v[j].x; acc.y |= v[j].y; acc.z |= v[j].z; acc.w |= v[j].w; }
+  }
+  for (; k + 4u <= parts; k += 4u) {
+    uint4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = first[(size_t)(k + (u32)j) * Qs + i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc.x |= v[j].x; acc.y |= v[j].y; acc.z |= v[j].z; acc.w |= v[j].w; }
   }
   for (; k < parts; ++k) {
-    const uint4 v = first[(size_t)k * Q + i];
+    const uint4 v = first[(size_t)k * Qs + i];
     acc.x |= v.x; acc.y |= v.y; acc.z |= v.z; acc.w |= v.w;
   }
   first[i] = acc;
@@ -89,7 +113,8 @@ constexpr int D2_NEWBITS_NT = 1024;      // threads per workgroup of k_d2_newbit
 __global__ __launch_bounds__(D2_NEWBITS_NT) void k_d2_newbits(const u32* __restrict__ visited, const unsigned char* __restrict__ mark,
                                                               u32* __restrict__ out, long long nwords, long long n, bfs_ctrl_t* c,
                                                               u32* __restrict__ list, u32 list_cap, d2_cold_view_t cv, int level,
-                                                              const u32* __restrict__ slot_marks, u32 declare_mul) {
+                                                              const u32* __restrict__ slot_marks, u32 declare_mul,
+                                                              const u32* __restrict__ defer_buf, u32 defer_words) {
   constexpr int NT = D2_NEWBITS_NT, NW = NT / WAVE;
   __shared__ u32 s_wave[NW];
   __shared__ u32 s_base;
@@ -105,6 +130,8 @@ __global__ __launch_bounds__(D2_NEWBITS_NT) void k_d2_newbits(const u32* __restr
     }
   }
   const bool with_cold = cv.flush && c->cold_slot == level;       // (grid-uniform) the level's push ran the cold-edge pass
+  // (grid-uniform) push workgroups of the level left their hot marks as bitmaps (bfs_hot_epilogue): ORed into the first by k_d2_cold_reduce
+  const bool with_defer = defer_buf && c->flush_count[level & 1] > 0u;
   const int wave = threadIdx.x / WAVE;
   const long long stride = (long long)gridDim.x * NT;
   for (long long w0 = (long long)blockIdx.x * NT; w0 < nwords; w0 += stride) {      // (block-uniform trip count: the barriers below)
@@ -120,6 +147,7 @@ __global__ __launch_bounds__(D2_NEWBITS_NT) void k_d2_newbits(const u32* __restr
       } else {
         for (int i = 0; i < 32 && w * 32 + i < n; ++i) bits |= (mark[w * 32 + i] ? 1u : 0u) << i;
       }
+      if (with_defer && w < (long long)defer_words) bits |= defer_buf[w];
       if (with_cold) {
         // the slice this word lies in (slices start on multiples of 1024 vertices: a word belongs to one slice)
         const u32 v0 = (u32)(w * 32);
@@ -413,6 +441,7 @@ struct d2_state_t {
   u32 cold_wgs[BFS_COLD_MAX_SLICES + 1] = {};
   mem_t<u32> cold_flush;
   int cold_reduce = 1;                // k_d2_cold_reduce in front of the sweep (MGX_DIST_COLD_REDUCE)
+  mem_t<u32> defer_buf;               // deferred hot marks of the push workgroups (bfs_hot_epilogue): BFS_FLUSH_MAX bitmaps; empty: nothing is deferred (MGX_DIST_DEFER=0)
   d2_cold_view_t cold_view() const {
     d2_cold_view_t v;
     if (!cold_dst || cold_slices <= 0 || !cold_flush.size()) return v;
@@ -445,6 +474,11 @@ struct d2_state_t {
     if (const char* e = getenv("MGX_BFS_COLD_TEST")) cold_forced = atoi(e);
     if (const char* e = getenv("MGX_DIST_DECLARE_MUL")) declare_mul = (u32)atoi(e);
     if (const char* e = getenv("MGX_DIST_SPARSE_PUSH")) sparse_push = atoi(e);
+    {
+      int defer = 1;
+      if (const char* e = getenv("MGX_DIST_DEFER")) defer = atoi(e);
+      if (defer) defer_buf = mem_t<u32>((size_t)BFS_FLUSH_MAX * BFS_FLUSH_WORDS, ctx);
+    }
     slot_marks = mem_t<u32>((size_t)2 * BFS_MARK_CTRS * BFS_MARK_STRIDE, ctx);
     MGX_HIP(hipMemsetAsync(slot_marks.data(), 0, slot_marks.size() * sizeof(u32), ctx.stream()));
     labels = mem_t<int>((size_t)n_local + 1, ctx);
@@ -505,7 +539,11 @@ struct d2_state_t {
     for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) a.cold_cb[i] = pk ? cold_cb[i] : 0u;
     for (int i = 0; i < BFS_COLD_MAX_SLICES; ++i) a.cold_lo[i] = cold ? cold_lo[i] : 0u;
     for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) { a.cold_off[i] = cold ? cold_off[i] : 0u; a.cold_wgs[i] = cold ? cold_wgs[i] : 0u; }
-    a.flush_buf = nullptr; a.defer_min_marks = 0;     // (k_d2_newbits reads the marks: nothing is deferred)
+    // deferred hot marks: while the ranks together have reached fewer vertices than the deferred range holds (reached counts this
+    // rank's: x ranks); k_d2_cold_reduce + k_d2_newbits read the bitmaps
+    const bool defer = defer_buf.size() != 0 && cold_reduce;
+    a.flush_buf = defer ? const_cast<u32*>(defer_buf.data()) : nullptr; a.defer_min_marks = defer ? fs->defer_min_marks : 0u;
+    a.defer_words = defer ? (u32)BFS_FLUSH_WORDS : 0u; a.defer_reach_mul = (u32)ranks; a.defer_reach_div = 1;
     a.chain_max_edges = 0;               // (levels are counted by the host here: no chains of small levels)
     const bool sparse = sparse_push && mylist && list_cap > 0u;
     a.d2_list = sparse ? mylist : nullptr; a.d2_list_cap = sparse ? list_cap : 0u; a.d2_newbits = sparse ? newbits : nullptr;
@@ -538,12 +576,17 @@ inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx) {
   } else
   bfs_launch_push(a, level, ctx, 2, bfs_cold_test(a.n, st.cold_forced));   // (the level's bookkeeping rides on the push launch)
   const d2_cold_view_t cv = st.cold_view();
-  if (cv.flush && cv.reduced)
-    hipLaunchKernelGGL(k_d2_cold_reduce, dim3((unsigned)(((size_t)cv.slices * (BFS_COLD_WORDS / 4) + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, cv,
-                       (const bfs_ctrl_t*)a.ctrl, level, const_cast<u32*>(st.cold_flush.data()));
+  u32* const dbuf = a.flush_buf;
+  if ((cv.flush && cv.reduced) || dbuf) {
+    d2_cold_view_t rv = cv;
+    if (!(cv.flush && cv.reduced)) { rv.flush = nullptr; rv.slices = 0; }
+    const size_t threads = (size_t)rv.slices * (BFS_COLD_WORDS / 4) + (dbuf ? (size_t)BFS_FLUSH_WORDS / 4 : 0);
+    hipLaunchKernelGGL(k_d2_cold_reduce, dim3((unsigned)((threads + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, rv,
+                       (const bfs_ctrl_t*)a.ctrl, level, rv.flush ? const_cast<u32*>(st.cold_flush.data()) : nullptr, dbuf);
+  }
   hipLaunchKernelGGL(k_d2_newbits, dim3(grid_for(st.nwords, D2_NEWBITS_NT, ctx.num_cus * 2)), dim3(D2_NEWBITS_NT), 0, s, st.fs->visited.data(),
                      st.fs->mark.data(), st.newbits, st.nwords, (long long)st.n_global, a.ctrl, st.mylist, st.list_cap, cv, level,
-                     (const u32*)st.slot_marks.data(), st.declare_mul);
+                     (const u32*)st.slot_marks.data(), st.declare_mul, (const u32*)dbuf, a.defer_words);
 }
 
 // The sparse merge of a level (k_d2_lists_apply) on `nlists` gathered lists, `stride_words` apart, and the host's wait for

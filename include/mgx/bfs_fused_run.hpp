@@ -260,6 +260,7 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push_level(bfs_fused_args_t a, 
   if (open_here && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
     bfs_begin_level(a, level, open_here == 2);
     bfs_slot_marks_clear(a, level + 1);
+    a.ctrl->flush_count[(level + 1) & 1] = 0;
     a.ctrl->d2_append_level = appends ? level : -1;
   }
   if (appends) {

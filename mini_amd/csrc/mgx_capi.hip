@@ -1448,7 +1448,10 @@ int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
         }
         long long nwg = (pairs + 65535) / 65536;
         nwg = std::max<long long>(nwg, mgx::BFS_COLD_WGS);
-        nwg = std::min<long long>(nwg, mgx::BFS_COLD_WGS_MAX);
+        // (at most 512 on a rank: every cold workgroup costs a copy of its slice into LDS and an 80 KB bitmap to write and to reduce --
+        //  RMAT-26 / 8 with 1 024 of them: push 584 us and reduce 87 us per traversal, with 512: 552 and 57, with 256: 575 and 46)
+        nwg = std::min<long long>(nwg, 512);
+        if (const char* e = getenv("MGX_DIST_COLD_WGS")) if (atoi(e) > 0) nwg = std::min<long long>(atoi(e), mgx::BFS_COLD_WGS_MAX);      // (measurements)
         nwg = std::max<long long>(nwg, used);
         unsigned left = (unsigned)nwg - (unsigned)used, acc = 0;
         st.cold_wgs[0] = 0;
