@@ -423,6 +423,13 @@ struct d2_state_t {
   // built on request (mgx_dbfs2_build_units), owned here
   int* ub_col = nullptr;
   int* ub_owner = nullptr;
+  // the short rows vertex by vertex (bfs_fused_vshort.hpp; mgx_dbfs2_build_units sets it up when the rank's rows come by
+  // non-increasing degree): class boundaries over the LOCAL rows, the edges of those rows, a copy of col_indices with readable
+  // entries behind it, the frontier over the local rows (written by k_bfs_build2)
+  u32 vs_v[4] = {0, 0, 0, 0};
+  u32 vs_v9 = 0, vs_edges = 0, vs_div = 0;
+  mem_t<int> col_pad;
+  mem_t<u32> front_local;
   mem_t<u32> ub_col24;                // the same, 24 bits per entry: only when the blocks hold the rows' HOT entries alone (the others are in the cold-edge lists)
   long long ub_units = 0, ub_units_pad = 0;
   u32 dense_div = 4;
@@ -530,7 +537,14 @@ struct d2_state_t {
     a.mode = 0; a.alpha = 0.f;
     a.count_marks = 0;
     a.ub_col = ub_col; a.ub_col24 = ub_col24.size() ? ub_col24.data() : nullptr; a.ub_owner = ub_owner; a.ub_units = (u32)ub_units; a.ub_units_pad = (u32)ub_units_pad; a.dense_div = ub_col ? dense_div : 0u;
-    a.vs_v[0] = a.vs_v[1] = a.vs_v[2] = a.vs_v[3] = 0; a.vs_v9 = 0; a.vs_edges = 0; a.vs_div = 0; a.vs_dummy = 0; a.lazy_div = 0; a.slot_marks = const_cast<u32*>(slot_marks.data()); a.merged_pull = 0; a.lazy_pull = 0; a.chain_big_edges = 0; a.defer_reach_mul = 1; a.defer_reach_div = 1;
+    {
+      static const bool build_list = [] { const char* e = getenv("MGX_DIST_BUILD_LIST"); return e && atoi(e) != 0; }();   // (that build writes no local frontier)
+      const bool vs = vs_div != 0u && col_pad.size() && front_local.size() && !build_list;
+      for (int i = 0; i < 4; ++i) a.vs_v[i] = vs ? vs_v[i] : 0u;
+      a.vs_v9 = vs ? vs_v9 : 0u; a.vs_edges = vs ? vs_edges : 0u; a.vs_div = vs ? vs_div : 0u; a.vs_dummy = 0;     // (entry 0: readable, and a lane without entries looks at none of the four)
+      a.vs_col = vs ? col_pad.data() : nullptr; a.d2_front = vs ? const_cast<u32*>(front_local.data()) : nullptr;
+    }
+    a.lazy_div = 0; a.slot_marks = const_cast<u32*>(slot_marks.data()); a.merged_pull = 0; a.lazy_pull = 0; a.chain_big_edges = 0; a.defer_reach_mul = 1; a.defer_reach_div = 1;
     const bool cold = cold_dst != nullptr && ub_col != nullptr && cold_slices > 0 && cold_flush.size() > 0;
     a.cold_owner = cold ? cold_owner : nullptr; a.cold_dst = cold ? cold_dst : nullptr; a.cold_slices = cold ? cold_slices : 0;
     a.cold_flush = cold ? const_cast<u32*>(cold_flush.data()) : nullptr;

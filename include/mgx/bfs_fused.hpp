@@ -178,11 +178,12 @@ struct bfs_fused_args_t {
   u32 cold_ranks = 1;
   u32 cold_cb[BFS_COLD_MAX_SLICES + 1] = {};
   // a rank of the partitioned traversal (bfs_dist2.hpp; all NULL / 0 on the single-GPU path): its id list of the level
-  // ([0] count, ids from D2_LIST_HEAD on), the list's capacity in ids, the rank's new-bit map (bfs_fused_sparse.hpp), and the
-  // frontier as a bitmap over the rank's LOCAL rows (written by the merge; NULL: none)
+  // ([0] count, ids from D2_LIST_HEAD on), the list's capacity in ids, the rank's new-bit map (bfs_fused_sparse.hpp)
   u32* d2_list = nullptr;
   u32 d2_list_cap = 0;
   u32* d2_newbits = nullptr;
+  u32* d2_front = nullptr;         // the level's frontier over the rank's LOCAL rows (k_bfs_build2 writes it, the vertex-by-vertex body reads it)
+  const int* vs_col = nullptr;     // the vertex-by-vertex body's copy of col_indices with readable entries behind it (NULL: col_indices has them)
 #ifdef MGX_LAB
   // ---- lab build only (-DMGX_LAB, never set by __graft_entry__.build()): shapes that lost their A/B runs and the
   // instrumented kernels of the measurement tools.  The product library carries none of this: MGX_LAB_GET reads a
@@ -917,6 +918,7 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
     if (new16) *vis16 = (unsigned short)(old16 | new16);                     // this thread is the half-word's only writer
     ((unsigned short*)a.frontier_bits)[i0 >> 4] = (unsigned short)new16;     // bottom-up levels, unit blocks
   }
+  if (DIST && a.d2_front && i0 < n) ((unsigned short*)a.d2_front)[i0 >> 4] = (unsigned short)new16;     // (the rank's short rows, vertex by vertex)
   const int mine = __popc(new16);
 
   // ---- my discoveries' row extents and label targets: contiguous, no gathers ----------------------------------------

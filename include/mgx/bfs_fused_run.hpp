@@ -290,6 +290,11 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push_level(bfs_fused_args_t a, 
       if (blk == 0 && threadIdx.x == 0) a.ctrl->dense_slots += 1;
       bfs_dense_body<1024, BFS_DENSE_HOTW>(a, level, blk, nstream, level, cold);
     } else bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, COLDT, false, true>(a, level, blk, nstream, level);
+  } else if (a.d2_front && bfs_short_is_dense(a, a.ctrl, level, a.ctrl->cursor[level % 3])) {
+    // (grid-uniform) a level that holds a large share of the rank's short rows walks them vertex by vertex, by the frontier over
+    // its LOCAL rows the merge left behind (bfs_fused_vshort.hpp; the queue is not looked at)
+    if (blk == nstream && threadIdx.x == 0) a.ctrl->vshort_slots += 1;
+    bfs_vshort_body<1024, BFS_DENSE_HOTW, COLDT>(a, level, blk - nstream, nblk - nstream, level);
   } else bfs_wave_body<1024, BFS_WAVE_HOTW, COLDT, false>(a, level, blk - nstream, nblk - nstream, level);
 }
 

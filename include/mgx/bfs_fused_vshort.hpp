@@ -42,9 +42,9 @@ __device__ __forceinline__ void bfs_vshort_work(const bfs_fused_args_t& a, u32* 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
   const int lane = lane_id();
   unsigned char* __restrict__ mark = a.mark;
-  const int* __restrict__ col = a.col_indices;
+  const int* __restrict__ col = a.vs_col ? a.vs_col : a.col_indices;
   const u32* __restrict__ ro = a.row_offsets;
-  const u32* __restrict__ fbits = a.frontier_bits;
+  const u32* __restrict__ fbits = a.d2_front ? a.d2_front : a.frontier_bits;
   // classes: [vs_v[0], vs_v[1]) 16 lanes per vertex, [vs_v[1], vs_v[2]) 4, [vs_v[2], vs_v[3]) 1
   const u32 b0 = a.vs_v[0], b1 = a.vs_v[1], b2 = a.vs_v[2], b3 = a.vs_v[3];
   // the widest class: 16 lanes per vertex cover 64 entries; with a long-row threshold of 32 or less its rows have at most 31
@@ -151,7 +151,100 @@ __device__ __forceinline__ void bfs_vshort_work(const bfs_fused_args_t& a, u32* 
   }
 }
 
+// The same with the COLD TEST of a big graph (most endpoints behind the LDS prefix: a rank of a partitioned RMAT-26): a neighbour
+// behind the prefix is looked up in the global bitmap before it is marked -- the words of a step's cold entries are requested
+// when the entries land and looked at one step later, so three steps are in flight: entries (s + 1), bitmap words (s), test
+// (s - 1).  One wave step per iteration (the words cost the registers the second step had).
 template <int NT, int HOTW>
+__device__ __forceinline__ void bfs_vshort_work_coldtest(const bfs_fused_args_t& a, u32* const hot, u32 hot_n, u32 defer_n, u32 block,
+                                                         u32 nblocks, int& marks) {
+  constexpr int NW = NT / WAVE;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+  const int lane = lane_id();
+  unsigned char* __restrict__ mark = a.mark;
+  const int* __restrict__ col = a.vs_col ? a.vs_col : a.col_indices;
+  const u32* __restrict__ ro = a.row_offsets;
+  const u32* __restrict__ fbits = a.d2_front ? a.d2_front : a.frontier_bits;
+  const u32* __restrict__ vis = a.visited;
+  const u32 b0 = a.vs_v[0], b1 = a.vs_v[1], b2 = a.vs_v[2], b3 = a.vs_v[3];
+  const u32 shift0 = (a.long_min > 0 && a.long_min <= 32) ? 3u : 4u;
+  const u32 vps0 = 64u >> shift0;
+  const u32 b9 = a.vs_v9 >= b1 && a.vs_v9 <= b2 ? a.vs_v9 : b2;
+  const u32 s16 = (b1 - b0 + vps0 - 1u) / vps0, s4 = (b9 - b1 + 15u) / 16u, s2 = (b2 - b9 + 31u) / 32u, s1 = (b3 - b2 + 63u) / 64u;
+  const u32 T = s16 + s4 + s2 + s1;
+  const u32 W = nblocks * NW, w = block * NW + (u32)wave;
+  const u32 dummy = a.vs_dummy;
+  struct raw_t { u32 lo, hi, fw, v_sub; };
+  struct step_t { u32 e0, cnt; };
+  auto plan_load = [&](u32 s) -> raw_t {
+    raw_t r;
+    u32 lpr_shift, vbase, vend;
+    if (s < s16) { lpr_shift = shift0; vbase = b0 + s * vps0; vend = b1; }
+    else if (s < s16 + s4) { lpr_shift = 2; vbase = b1 + (s - s16) * 16u; vend = b9; }
+    else if (s < s16 + s4 + s2) { lpr_shift = 1; vbase = b9 + (s - s16 - s4) * 32u; vend = b2; }
+    else { lpr_shift = 0; vbase = b2 + (s - s16 - s4 - s2) * 64u; vend = b3; }
+    const u32 v = vbase + ((u32)lane >> lpr_shift);
+    const u32 sub = (u32)lane & ((1u << lpr_shift) - 1u);
+    const bool in = s < T && v < vend;
+    const u32 vc = in ? v : 0u;
+    const bfs_u32x2 ext = *(const bfs_u32x2*)(ro + vc);
+    r.lo = ext.x; r.hi = ext.y;
+    r.fw = fbits[vc >> 5];
+    r.v_sub = in ? (sub | ((vc & 31u) << 8)) : 0xFFFFFFFFu;
+    return r;
+  };
+  auto resolve = [&](const raw_t& r) -> step_t {
+    step_t p; p.e0 = dummy; p.cnt = 0;
+    const u32 deg = r.hi - r.lo;
+    const u32 sub = r.v_sub & 0xFFu;
+    const bool in_frontier = r.v_sub != 0xFFFFFFFFu && ((r.fw >> ((r.v_sub >> 8) & 31u)) & 1u);
+    if (in_frontier && sub * 4u < deg) {
+      p.e0 = r.lo + sub * 4u;
+      const u32 left = deg - sub * 4u;
+      p.cnt = left < 4u ? left : 4u;
+    }
+    return p;
+  };
+  // (unconditional: entries inside the prefix and lanes without an entry ask for word 0)
+  auto cold_word = [&](u32 d) -> u32 { return vis[(d >= hot_n && d != 0xFFFFFFFFu) ? (d >> 5) : 0u]; };
+  auto decide = [&](u32 d, u32 wcold) {
+    if (d == 0xFFFFFFFFu) return;
+    const u32 bit = 1u << (d & 31u);
+    bool is_new;
+    if (d < hot_n) is_new = !(hot[d >> 5] & bit) && !(atomicOr(&hot[d >> 5], bit) & bit);
+    else is_new = !(wcold & bit);
+    if (is_new) { if (d >= defer_n) mark[d] = 1; ++marks; }
+  };
+  if (w < T) {
+    raw_t rA = plan_load(w);
+    step_t p = resolve(rA);
+    bfs_u32x4u dL = *(const bfs_u32x4u*)(col + p.e0);
+    u32 cL = p.cnt;
+    rA = plan_load(w + W);
+    u32 dP[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, wP[4] = {0u, 0u, 0u, 0u};
+    for (u32 s = w; s < T; s += W) {
+      const bfs_u32x4u dT = dL;
+      const u32 cT = cL;
+      p = resolve(rA);
+      dL = *(const bfs_u32x4u*)(col + p.e0);                    // (past the last step: the dummy)
+      cL = p.cnt;
+      rA = plan_load(s + 2u * W);
+      // entries past the lane's count (the next row's) do not exist
+      const u32 dN[4] = {cT > 0u ? dT.x : 0xFFFFFFFFu, cT > 1u ? dT.y : 0xFFFFFFFFu, cT > 2u ? dT.z : 0xFFFFFFFFu, cT > 3u ? dT.w : 0xFFFFFFFFu};
+      u32 wN[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wN[j] = cold_word(dN[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) decide(dP[j], wP[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { dP[j] = dN[j]; wP[j] = wN[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) decide(dP[j], wP[j]);
+  }
+}
+
+template <int NT, int HOTW, bool COLDT = false>
 __device__ __forceinline__ void bfs_vshort_body(const bfs_fused_args_t& a, int slot, u32 block, u32 nblocks, int stat_level,
                                                 bool cold = false) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -162,7 +255,8 @@ __device__ __forceinline__ void bfs_vshort_body(const bfs_fused_args_t& a, int s
   const u32 hot_n = ((u32)a.n < (u32)(HOTW * 32)) ? (u32)a.n : (u32)(HOTW * 32);
   const u32 defer_n = bfs_defer_limit(a, hot_n);
   int marks = 0;
-  bfs_vshort_work<NT, HOTW>(a, hot, hot_n, defer_n, block, nblocks, marks);
+  if constexpr (COLDT) bfs_vshort_work_coldtest<NT, HOTW>(a, hot, hot_n, defer_n, block, nblocks, marks);
+  else bfs_vshort_work<NT, HOTW>(a, hot, hot_n, defer_n, block, nblocks, marks);
   (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, slot, s_int + 4, marks);
   bfs_body_finish(a, marks, slot, stat_level, s_int);
 }

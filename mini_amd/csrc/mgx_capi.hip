@@ -1405,6 +1405,39 @@ int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
   h->c->ctx->synchronize();
   st.ub_owner = owner; st.ub_col = ucol; st.ub_units = U; st.ub_units_pad = Up;
   if (const char* e = getenv("MGX_DIST_DENSE_DIV")) { const int d = atoi(e); if (d >= 0) st.dense_div = (unsigned)d; }
+  // the short rows vertex by vertex (MGX_DIST_VSHORT=0: never; N: when a level holds 1 / N of their edges): needs rows by
+  // non-increasing degree (hub-first global ids, cyclic ownership: they are) -- checked here, on the host
+  {
+    int vdiv = 8;
+    if (const char* e = getenv("MGX_DIST_VSHORT")) vdiv = atoi(e);
+    standard_context_t& ctx = *h->c->ctx;
+    const int n = st.n_local;
+    if (vdiv > 0 && n > 0) {
+      std::vector<int> hro((size_t)n + 1);
+      MGX_HIP(mgx::dtoh(hro.data(), st.row_offsets, (size_t)n + 1));
+      bool sorted = true;
+      for (int i = 1; i < n && sorted; ++i) sorted = hro[i + 1] - hro[i] <= hro[i] - hro[i - 1];
+      const long long m_local = hro[n];
+      if (sorted && m_local > 0) {
+        auto first_below = [&](int d) {            // first row with degree < d
+          size_t lo = 0, hi = (size_t)n;
+          while (lo < hi) { const size_t mid = (lo + hi) / 2; if (hro[mid + 1] - hro[mid] >= d) lo = mid + 1; else hi = mid; }
+          return (unsigned)lo;
+        };
+        const unsigned b0 = first_below(long_min), b1 = std::max(b0, first_below(17)), b2 = std::max(b1, first_below(5)), b3 = std::max(b2, first_below(1));
+        st.vs_v[0] = b0; st.vs_v[1] = b1; st.vs_v[2] = b2; st.vs_v[3] = b3;
+        st.vs_v9 = std::min(b2, std::max(b1, first_below(9)));
+        st.vs_edges = (unsigned)(hro[b3] - hro[b0]);
+        st.col_pad = mem_t<int>((size_t)m_local + 8, ctx);
+        MGX_HIP(hipMemcpyAsync(st.col_pad.data(), st.col_indices, (size_t)m_local * sizeof(int), hipMemcpyDeviceToDevice, ctx.stream()));
+        MGX_HIP(hipMemsetAsync(st.col_pad.data() + m_local, 0xFF, 8 * sizeof(int), ctx.stream()));
+        st.front_local = mem_t<unsigned>((size_t)n / 32 + 64, ctx);
+        MGX_HIP(hipMemsetAsync(st.front_local.data(), 0, st.front_local.size() * sizeof(unsigned), ctx.stream()));
+        ctx.synchronize();
+        st.vs_div = st.vs_edges ? (unsigned)vdiv : 0u;
+      }
+    }
+  }
   if (units) *units = U;
   // cold-edge lists of the same rows (bfs_fused_cold.hpp; MGX_DIST_COLD=0: none): as build_cold_lists does for a graph's layout --
   // only when the destinations behind the LDS prefix span at most 128 slices of which at most BFS_COLD_MAX_SLICES hold pairs,
