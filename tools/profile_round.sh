@@ -55,10 +55,15 @@ PY
 done
 bash tools/gpu_timeline.sh "" > $O/timeline.txt 2>&1
 # the partitioned engine on this one GPU: G rank engines in turn, no exchange time
+# (lists: the level protocol of mgx_dbfs2_run, the default; gather: bitmaps on every level -- what rounds 2 and 3 measured)
 for cfg in "25 8" "26 8" "22 8" "22 1"; do
   set -- $cfg
-  timeout 900 python tools/dist2_single.py $1 $2 2>/dev/null | grep -v amdgpu.ids | tail -4 > $O/dist2_single_$1_$2.log
+  timeout 900 python tools/dist2_single.py $1 $2 2>/dev/null | grep -v amdgpu.ids | tail -6 > $O/dist2_single_$1_$2.log
 done
+timeout 900 python tools/dist2_single.py 26 8 gather 2>/dev/null | grep -v amdgpu.ids | tail -6 > $O/dist2_single_26_8_gather.log
+# the rank engines' kernels per rank and traversal, per level, and the three parts of the push grid
+bash tools/gpu_d2_stats.sh 26 8 "" "MGX_DIST_PUSH_SPLIT=1" > /dev/null 2>&1
+cp $R/gpurun_out/d2stats/summary.txt $O/dist2_kernels_26_8.txt 2>/dev/null
 DIST2_CHECK=1 timeout 900 python tools/dist2_single.py 23 4 2>/dev/null | grep -v amdgpu.ids | tail -8 > $O/dist2_single_23_4_check.log
 # ... and its kernels under rocprofv3
 cd /tmp && export TMPDIR=/tmp
@@ -92,7 +97,7 @@ cat $O/summary.txt
 mkdir -p $O/keep
 cp $O/summary.txt $O/summary.json $O/kernel_stats_mgx.csv $O/kernel_stats_sssp.csv $O/kernel_stats_pr.csv $O/levels.log $O/sssp_iterations.log $O/timeline.txt $O/keep/ 2>/dev/null
 cp $O/pmc_traffic.json $O/bfs_operator_s22.log $O/dobfs_alpha_sweep.txt $O/sssp_s22.log $O/pr_s22.log $O/kcore_s20.log $O/keep/ 2>/dev/null
-cp $O/dist2_single_*.log $O/kernel_stats_dist2_25_8.csv $O/keep/ 2>/dev/null
+cp $O/dist2_single_*.log $O/kernel_stats_dist2_25_8.csv $O/dist2_kernels_26_8.txt $O/keep/ 2>/dev/null
 grep '^{' $O/bench_driver_cmd.log | tail -1 > $O/keep/bench_line_driver_cmd.json
 grep '^{' $O/bench.log | tail -1 > $O/keep/bench_line.json
 grep '^{' $O/bench_per_call.log | tail -1 > $O/keep/bench_line_per_call.json
