@@ -325,6 +325,11 @@ MGX_API int mgx_dbfs2_dense_levels(mgx_dbfs2_t h, int64_t* levels);
 /* ... and how many of them ran the cold-edge pass (the long rows' entries behind the LDS prefix as (owner, destination) pairs by
  * slice of the destination, built with the unit blocks when the graph is big enough to have any: *pairs, may be NULL) */
 MGX_API int mgx_dbfs2_cold_levels(mgx_dbfs2_t h, int64_t* levels, int64_t* pairs);
+/* which of round 4's paths the last traversal took on this rank (as of the last mgx_dbfs2_status / mgx_dbfs2_run): out4 = { levels
+ * whose push appended its discoveries to the id list itself (no sweep over the marks), levels whose short rows were walked vertex
+ * by vertex, 1 if a sweep declared its list overflowed from the push's mark count, slices of the cold-edge lists stored at four
+ * bytes per pair }.  Tests and tools. */
+MGX_API int mgx_dbfs2_path_levels(mgx_dbfs2_t h, int64_t* out4);
 MGX_API int mgx_dbfs2_free(mgx_dbfs2_t h);
 /* All of reset / push / merge are asynchronous on the context's stream: a level is
  *   push(level) -> all-gather of d_newbits into d_gathered (the caller's collective, stream-ordered) -> merge(level)

@@ -448,6 +448,9 @@ struct d2_state_t {
   u32 cold_wgs[BFS_COLD_MAX_SLICES + 1] = {};
   mem_t<u32> cold_flush;
   int cold_reduce = 1;                // k_d2_cold_reduce in front of the sweep (MGX_DIST_COLD_REDUCE)
+  int fused_merge = 1;                // OR-merge inside the queue build (MGX_DIST_FUSED_MERGE)
+  int build_list = 0;                 // the list-based queue build (MGX_DIST_BUILD_LIST)
+  int push_split = 0;                 // measurements: the push grid's three parts as three launches (MGX_DIST_PUSH_SPLIT)
   mem_t<u32> defer_buf;               // deferred hot marks of the push workgroups (bfs_hot_epilogue): BFS_FLUSH_MAX bitmaps; empty: nothing is deferred (MGX_DIST_DEFER=0)
   d2_cold_view_t cold_view() const {
     d2_cold_view_t v;
@@ -481,6 +484,9 @@ struct d2_state_t {
     if (const char* e = getenv("MGX_BFS_COLD_TEST")) cold_forced = atoi(e);
     if (const char* e = getenv("MGX_DIST_DECLARE_MUL")) declare_mul = (u32)atoi(e);
     if (const char* e = getenv("MGX_DIST_SPARSE_PUSH")) sparse_push = atoi(e);
+    if (const char* e = getenv("MGX_DIST_FUSED_MERGE")) fused_merge = atoi(e);
+    if (const char* e = getenv("MGX_DIST_BUILD_LIST")) build_list = atoi(e);
+    if (const char* e = getenv("MGX_DIST_PUSH_SPLIT")) push_split = atoi(e);
     {
       int defer = 1;
       if (const char* e = getenv("MGX_DIST_DEFER")) defer = atoi(e);
@@ -538,8 +544,7 @@ struct d2_state_t {
     a.count_marks = 0;
     a.ub_col = ub_col; a.ub_col24 = ub_col24.size() ? ub_col24.data() : nullptr; a.ub_owner = ub_owner; a.ub_units = (u32)ub_units; a.ub_units_pad = (u32)ub_units_pad; a.dense_div = ub_col ? dense_div : 0u;
     {
-      static const bool build_list = [] { const char* e = getenv("MGX_DIST_BUILD_LIST"); return e && atoi(e) != 0; }();   // (that build writes no local frontier)
-      const bool vs = vs_div != 0u && col_pad.size() && front_local.size() && !build_list;
+      const bool vs = vs_div != 0u && col_pad.size() && front_local.size() && !build_list;      // (the list-based build writes no local frontier)
       for (int i = 0; i < 4; ++i) a.vs_v[i] = vs ? vs_v[i] : 0u;
       a.vs_v9 = vs ? vs_v9 : 0u; a.vs_edges = vs ? vs_edges : 0u; a.vs_div = vs ? vs_div : 0u; a.vs_dummy = 0;     // (entry 0: readable, and a lane without entries looks at none of the four)
       a.vs_col = vs ? col_pad.data() : nullptr; a.d2_front = vs ? const_cast<u32*>(front_local.data()) : nullptr;
@@ -582,8 +587,7 @@ inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx) {
   hipStream_t s = ctx.stream();
   bfs_fused_args_t a = st.args();
   bfs_set_kernel_attributes();
-  static const bool split = [] { const char* e = getenv("MGX_DIST_PUSH_SPLIT"); return e && atoi(e) != 0; }();
-  if (split) {     // measurements: cold pass, long rows, short rows as three launches
+  if (st.push_split) {     // measurements: cold pass, long rows, short rows as three launches
     bfs_launch_push(a, level, ctx, 2 | ((2 | 4) << 4), bfs_cold_test(a.n, st.cold_forced));
     bfs_launch_push(a, level, ctx, 0 | ((1 | 4) << 4), bfs_cold_test(a.n, st.cold_forced));
     bfs_launch_push(a, level, ctx, 0 | ((1 | 2) << 4), bfs_cold_test(a.n, st.cold_forced));
@@ -635,10 +639,9 @@ inline void d2_merge(d2_state_t& st, int level, const u32* gathered, int maps, l
                      standard_context_t& ctx) {
   hipStream_t s = ctx.stream();
   bfs_fused_args_t a = st.args();
-  static const bool build_list = [] { const char* e = getenv("MGX_DIST_BUILD_LIST"); return e && atoi(e) != 0; }();
   // OR-merge and queue build in ONE launch (k_bfs_build2<., 2, RANKS>) when the ranks are a power of two (MGX_DIST_FUSED_MERGE=0:
   // the two launches below)
-  static const bool fused = [] { const char* e = getenv("MGX_DIST_FUSED_MERGE"); return !e || atoi(e) != 0; }();
+  const bool build_list = st.build_list != 0, fused = st.fused_merge != 0;
   const int R = st.ranks;
   if (fused && !build_list && (R == 2 || R == 4 || R == 8 || R == 16) && (uintptr_t)a.row_offsets % 16 == 0 &&
       (uintptr_t)gathered % 16 == 0 && stride_words % 4 == 0) {

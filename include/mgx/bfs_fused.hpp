@@ -232,8 +232,8 @@ __device__ __forceinline__ void bfs_copy_prefix(u32* __restrict__ dst, const u32
   }
 }
 
-constexpr int BFS_COLD_WGS = 128;              // workgroups of a push launch that take the cold pairs: at least this many ...
-constexpr int BFS_COLD_WGS_MAX = 1024;         // ... one per 65 536 pairs, at most this many (cold_wgs[cold_slices] says how many)
+constexpr int BFS_COLD_WGS = 64;               // workgroups of a push launch that take the cold pairs: at least this many ...
+constexpr int BFS_COLD_WGS_MAX = 1024;         // ... one per 131 072 pairs, at most this many (cold_wgs[cold_slices] says how many).  Every one of them costs a copy of its slice into LDS, an 80 KB bitmap to write and to OR (RMAT-22, 9.4 M pairs: 143 workgroups 0.3017 ms per traversal, 64-96 0.2983-0.3006, 192 0.3055)
 constexpr int BFS_COLD_WORDS = 20384;          // bitmap words of a slice == the unit-block body's LDS prefix (BFS_DENSE_HOTW)
 
 constexpr int BFS_MARK_CTRS = 8;               // the workgroups of a push launch spread their adds over this many lines

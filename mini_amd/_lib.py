@@ -137,6 +137,7 @@ SIGNATURES = {
     "mgx_dbfs2_build_units": [_vp, _pi64],
     "mgx_dbfs2_dense_levels": [_vp, _pi64],
     "mgx_dbfs2_cold_levels": [_vp, _pi64, _pi64],
+    "mgx_dbfs2_path_levels": [_vp, _pi64],
     "mgx_dsssp_create": [_vp, _i, _i, _i, _i64, _vp, _vp, _vp, _pvp],
     "mgx_dsssp_free": [_vp],
     "mgx_dsssp_reset": [_vp, _i],

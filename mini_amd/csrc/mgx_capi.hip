@@ -461,9 +461,9 @@ static void build_cold_lists(mgx_graph_s* g) {
     G.colds_off[q] = (unsigned)off_s[k]; G.colds_off[q + 1] = (unsigned)off_s[k + 1];
     ++q;
   }
-  // workgroups per slice: in proportion to its pairs, at least one each; in all one per 65 536 pairs, 128 .. 1024
+  // workgroups per slice: in proportion to its pairs, at least one each; in all one per 131 072 pairs, 64 .. 1024
   const long long all = pairs + pairs_s;
-  long long nwg = (all + 65535) / 65536;
+  long long nwg = (all + 131071) / 131072;
   nwg = std::max<long long>(nwg, mgx::BFS_COLD_WGS);
   if (const char* e = getenv("MGX_BFS_COLD_WGS")) if (atoi(e) > 0) nwg = atoi(e);      // (measurements)
   nwg = std::min<long long>(nwg, mgx::BFS_COLD_WGS_MAX);
@@ -1479,7 +1479,7 @@ int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
           st.cold_off[q] = (unsigned)off[k]; st.cold_off[q + 1] = (unsigned)off[k + 1];
           ++q;
         }
-        long long nwg = (pairs + 65535) / 65536;
+        long long nwg = (pairs + 131071) / 131072;
         nwg = std::max<long long>(nwg, mgx::BFS_COLD_WGS);
         // (at most 512 on a rank: every cold workgroup costs a copy of its slice into LDS and an 80 KB bitmap to write and to reduce --
         //  RMAT-26 / 8 with 1 024 of them: push 584 us and reduce 87 us per traversal, with 512: 552 and 57, with 256: 575 and 46)
@@ -1568,6 +1568,16 @@ int mgx_dbfs2_cold_levels(mgx_dbfs2_t h, int64_t* levels, int64_t* pairs) {
   MGX_REQUIRE(h && levels, "NULL argument");
   *levels = (int64_t)h->st.fs->host_ctrl->cold_slots;
   if (pairs) *pairs = (int64_t)h->st.cold_pairs;
+  MGX_CATCH
+}
+int mgx_dbfs2_path_levels(mgx_dbfs2_t h, int64_t* out4) {
+  MGX_TRY
+  MGX_REQUIRE(h && out4, "NULL argument");
+  const mgx::bfs_ctrl_t* hc = h->st.fs->host_ctrl;          // (as of the last mgx_dbfs2_status / mgx_dbfs2_run)
+  out4[0] = (int64_t)hc->small_levels;                       // levels whose push appended its discoveries to the id list itself
+  out4[1] = (int64_t)hc->vshort_slots;                       // levels whose short rows were walked vertex by vertex
+  out4[2] = (int64_t)hc->d2_declared_level >= 0 ? 1 : 0;     // a sweep declared its list overflowed (the last such level is kept, not a count)
+  out4[3] = (int64_t)(h->st.cold_pk ? __builtin_popcountll(h->st.cold_pk_mask) : 0);   // slices whose pairs are packed to 4 bytes
   MGX_CATCH
 }
 int mgx_dbfs2_free(mgx_dbfs2_t h) {

@@ -221,6 +221,13 @@ class HipRankEngine2:
         check(lib.mgx_dbfs2_cold_levels(self._h, C.byref(v), C.byref(p)))
         return v.value, p.value
 
+    def path_levels(self):
+        """(levels appended by the push, levels with vertex-by-vertex short rows, 1 if a list was declared overflowed, packed
+        cold-edge slices) of the last traversal, valid after status() / run_native()"""
+        o = (C.c_int64 * 4)()
+        check(lib.mgx_dbfs2_path_levels(self._h, o))
+        return tuple(int(v) for v in o)
+
     def reset(self, src):
         check(lib.mgx_dbfs2_reset(self._h, int(src)))
 

@@ -362,6 +362,100 @@ def _check_partitioned_traversal(torch, engs, shards, deg_new, src, sts):
     return lab
 
 
+def _run_rank_engines_lists(torch, engs, src):
+    """the level protocol of mgx_dbfs2_run / DistBfs2.run: id lists first (the all-gather a concatenation, every engine's list
+    merge with its verdict), the bitmaps only when some rank's list overflowed; -> (statuses, levels merged from lists, from bitmaps)"""
+    G = len(engs)
+    for e in engs:
+        e.reset(src)
+    level = sparse = dense = 0
+    while True:
+        maps = [e.push(level) for e in engs]
+        glists = torch.cat([e.list for e in engs]) if G > 1 else engs[0].list
+        res = [e.apply_lists(level, glists, G) for e in engs]
+        assert len(set(res)) == 1, "the ranks disagree about the level's lists"
+        level += 1
+        if res[0][1] == 0:
+            break
+        if res[0][0]:
+            gathered = torch.cat(maps) if G > 1 else maps[0]
+            for e in engs:
+                e.merge(level - 1, gathered, G)
+            dense += 1
+        else:
+            sparse += 1
+    return [e.status(level) for e in engs], sparse, dense
+
+
+# round 4's rank engine (DESIGN 5): every new path against its switch, in ONE process (the engines read the switches when they
+# are made), on graphs whose id range outgrows the LDS prefix (R-MAT 21: cold-edge lists), with the unit-block and
+# vertex-by-vertex bodies forced onto every level that can take them
+_RANK_SWITCHES = [
+    {},                                                                  # the defaults
+    {"MGX_DIST_DENSE_DIV": "1000000", "MGX_DIST_VSHORT": "1000000"},     # dense bodies wherever the frontier bitmap is current
+    {"MGX_DIST_DENSE_DIV": "1000000", "MGX_DIST_VSHORT": "1000000", "MGX_DIST_DECLARE_MUL": "1"},   # lists declared overflowed early
+    {"MGX_DIST_DENSE_DIV": "1000000", "MGX_DIST_SPARSE_PUSH": "0", "MGX_DIST_FUSED_MERGE": "0"},
+    {"MGX_DIST_DENSE_DIV": "1000000", "MGX_DIST_COLD_REDUCE": "0", "MGX_DIST_HOT_UNITS": "0"},
+    {"MGX_DIST_DENSE_DIV": "1000000", "MGX_BFS_COLD_PACK": "0", "MGX_DIST_DEFER": "0", "MGX_DIST_VSHORT": "0"},
+    {"MGX_DIST_DENSE_DIV": "1000000", "MGX_DIST_VSHORT": "1000000", "MGX_BFS_PACK24": "0", "MGX_DIST_COLD_WGS": "700"},
+]
+
+
+@pytest.mark.parametrize("scale,G", [(21, 8), (21, 2), (19, 4)])
+def test_rank_engine_round4_paths_vs_single_gpu(gpu_ctx, torch_mod, monkeypatch, scale, G):
+    """sparse levels appended by the push, declared overflows, the OR-merge inside the queue build (2 / 4 / 8 ranks), the stream
+    reduce of the cold and deferred bitmaps, hot-only 24-bit unit blocks, 4-byte cold-edge pairs, deferred hot marks, short rows
+    vertex by vertex with the cold test: under both level protocols the ranks' labels equal the single-GPU traversal of the
+    unpartitioned graph, vertex by vertex, and every rank ends with the same bitmap"""
+    import mini_amd
+    from mini_amd import rmat
+    torch = torch_mod
+    g = rmat.rmat_csr(gpu_ctx, scale, 16, seed=scale)
+    graph = mini_amd.Graph.from_device(gpu_ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"]).build_layout()
+    single = {}
+    bfs = None
+    for env in _RANK_SWITCHES:
+        with monkeypatch.context() as mp:
+            for k, v in env.items():
+                mp.setenv(k, v)
+            engs, shards, new_of_old, old_of_new, deg_new = _rank_engines(gpu_ctx, torch, scale, G, scale)
+        o2n, n2o = old_of_new.cpu().numpy(), new_of_old.cpu().numpy()
+        cand = torch.nonzero(deg_new > 0)[:, 0]
+        srcs = [int(cand[0]), int(cand[len(cand) // 2]), int(cand[-1])]     # the biggest hub, a middling vertex, a leaf
+        for src in srcs:
+            if src not in single:
+                src_old = int(o2n[src])
+                bfs = bfs or mini_amd.BfsProblem(graph, src_old)
+                bfs.run(src_old)
+                single[src] = bfs.labels().copy()
+            for proto in ("lists", "bitmaps"):
+                if proto == "lists":
+                    sts, sparse, dense = _run_rank_engines_lists(torch, engs, src)
+                    assert sparse >= 1, "no level was merged from id lists: %r" % (env,)
+                else:
+                    sts = _run_rank_engines(torch, engs, src)
+                lab_new = _check_partitioned_traversal(torch, engs, shards, deg_new, src, sts)
+                assert np.array_equal(lab_new[n2o], single[src]), "labels differ from the single-GPU traversal: %r, %s, source %d" % (env, proto, src)
+                # ... and the paths the switches ask for were the ones that ran
+                paths = [e.path_levels() for e in engs]
+                if env.get("MGX_DIST_SPARSE_PUSH") == "0":
+                    assert all(p[0] == 0 for p in paths)
+                else:
+                    assert all(p[0] >= 1 for p in paths), "no level was appended by the push: %r" % (paths,)
+                forced = env.get("MGX_DIST_DENSE_DIV") == "1000000"
+                if forced and scale >= 21:
+                    assert all(e.dense_levels() >= 1 and e.cold_levels()[0] >= 1 for e in engs), "the cold-edge pass did not run"
+                    assert all((p[3] > 0) == (env.get("MGX_BFS_COLD_PACK") != "0") for p in paths), "packed pair lists: %r" % (paths,)
+                if env.get("MGX_DIST_VSHORT") == "1000000":
+                    assert any(p[1] >= 1 for p in paths), "no level walked its short rows vertex by vertex: %r" % (paths,)
+                if env.get("MGX_DIST_VSHORT") == "0":
+                    assert all(p[1] == 0 for p in paths)
+                if env.get("MGX_DIST_DECLARE_MUL") == "1" and proto == "lists":
+                    assert any(p[2] == 1 for p in paths), "no list was declared overflowed: %r" % (paths,)
+        for e in engs:
+            e.close()
+
+
 def test_config5_rmat26_eight_rank_engines(gpu_ctx, torch_mod):
     """BASELINE config 5's workload: RMAT-26 ef 16 (n = 67 108 864, 2 147 483 648 entries), cyclic partition over 8 ranks"""
     torch = torch_mod
