@@ -68,7 +68,22 @@ def partitioned_labels(n, ro, ci, src, G, mode):
     for e in engs:
         e.reset(s_new)
     level = 0
-    while True:
+    while mode == "lists":
+        # the level protocol of mgx_dbfs2_run: id lists first, the bitmaps only when some rank's list overflowed
+        bits = [e.push(level) for e in engs]
+        glists = torch.cat([e.list for e in engs]) if G > 1 else engs[0].list
+        res = [e.apply_lists(level, glists, G) for e in engs]
+        assert len(set(res)) == 1
+        level += 1
+        if res[0][1] == 0:
+            break
+        if res[0][0]:
+            gathered = torch.cat(bits) if G > 1 else bits[0]
+            for e in engs:
+                e.merge(level - 1, gathered, G)
+    if mode == "lists":
+        assert engs[0].status(level)["over"]
+    while mode != "lists":
         for _ in range(3):
             bits = [e.push(level) for e in engs]
             if mode == "reduce" and G > 1:
@@ -150,14 +165,27 @@ for name, n, ro, ci, w in graphs():
             # the partitioned engine's rank engines in this process: small graphs, and R-MAT 20 / 21 (the ranks' cold-edge pass);
             # unit blocks forced onto every eligible level or by the default rule
             G = int(rng.choice([2, 3, 5, 8])) if n <= 150000 else 2
-            mode = str(rng.choice(["gather", "reduce"]))
+            mode = str(rng.choice(["gather", "reduce", "lists"]))
             dd = str(rng.choice(["", "1000000"]))
             if dd:
                 os.environ["MGX_DIST_DENSE_DIV"] = dd
             os.environ["MGX_DIST_COLD"] = str(rng.choice(["1", "1", "0"]))
+            # round 4's rank-engine paths, each against its switch
+            dknobs = {"MGX_DIST_SPARSE_PUSH": rng.choice(["", "0"]), "MGX_DIST_DECLARE_MUL": rng.choice(["", "0", "1"]),
+                      "MGX_DIST_FUSED_MERGE": rng.choice(["", "0"]), "MGX_DIST_COLD_REDUCE": rng.choice(["", "0"]),
+                      "MGX_DIST_HOT_UNITS": rng.choice(["", "0"]), "MGX_BFS_COLD_PACK": rng.choice(["", "0"]),
+                      "MGX_DIST_DEFER": rng.choice(["", "0"]), "MGX_DIST_VSHORT": rng.choice(["", "0", "1000000"]),
+                      "MGX_DIST_COLD_WGS": rng.choice(["", "3", "700"])}
+            for kk, vv in dknobs.items():
+                if vv == "":
+                    os.environ.pop(kk, None)
+                else:
+                    os.environ[kk] = str(vv)
             got = partitioned_labels(n, ro, ci, src, G, mode)
             os.environ.pop("MGX_DIST_DENSE_DIV", None); os.environ.pop("MGX_DIST_COLD", None)
-            assert np.array_equal(got, want), (name, n, src, "partitioned", G, mode, dd)
+            for kk in dknobs:
+                os.environ.pop(kk, None)
+            assert np.array_equal(got, want), (name, n, src, "partitioned", G, mode, dd, dknobs)
         dist, _, _ = orc.sssp_enact(ro, ci, w, src, 8.0)
         sssp.run(src)                                  # (MGX_SSSP_BUILD_LIST / MGX_SSSP_SLICED: whatever the last draw left)
         assert np.array_equal(sssp.distances(), dist), (name, n, src, "sssp", layout, os.environ.get("MGX_SSSP_BUILD_LIST"), os.environ.get("MGX_SSSP_SLICED"))
