@@ -318,7 +318,11 @@ MGX_API int mgx_dbfs2_create(mgx_ctx_t ctx, int n_global, int ranks, int rank, c
  * entries behind the prefix as (owner, destination) pairs by slice of the destination: workgroups of the push launch take
  * them with THEIR slice of the bitmap in LDS and leave a bitmap, no byte marks (needs rows sorted by neighbour id, as the
  * library's shard builder makes them).  Once per engine, optional; *units (may be NULL) <- units built (0: the rows are
- * all short).  Needs row_offsets / col_indices to stay valid and unchanged.  No reference counterpart. */
+ * all short).  Needs row_offsets / col_indices to stay valid and unchanged.  No reference counterpart.
+ * Round 4: with cold-edge lists the unit blocks hold the rows' entries INSIDE the prefix only, three bytes each, and the pairs
+ * are kept a second time at four bytes each; when the rank's rows come by non-increasing degree (the shard builder's order) the
+ * call also prepares the vertex-by-vertex walk of its short rows -- a copy of col_indices with readable entries behind it
+ * (m_local + 8 ints of device memory) and a bitmap of the rank's local frontier.  mgx_dbfs2_path_levels says what a traversal used. */
 MGX_API int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units);
 /* levels of the traversal whose long rows were read from the unit blocks, as of the last mgx_dbfs2_status / mgx_dbfs2_run */
 MGX_API int mgx_dbfs2_dense_levels(mgx_dbfs2_t h, int64_t* levels);

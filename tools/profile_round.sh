@@ -61,6 +61,7 @@ for cfg in "25 8" "26 8" "22 8" "22 1"; do
   timeout 900 python tools/dist2_single.py $1 $2 2>/dev/null | grep -v amdgpu.ids | tail -6 > $O/dist2_single_$1_$2.log
 done
 timeout 900 python tools/dist2_single.py 26 8 gather 2>/dev/null | grep -v amdgpu.ids | tail -6 > $O/dist2_single_26_8_gather.log
+timeout 900 python tools/dist2_single.py 26 8 reduce 2>/dev/null | grep -v amdgpu.ids | tail -6 > $O/dist2_single_26_8_reduce.log
 # the rank engines' kernels per rank and traversal, per level, and the three parts of the push grid
 bash tools/gpu_d2_stats.sh 26 8 "" "MGX_DIST_PUSH_SPLIT=1" > /dev/null 2>&1
 cp $R/gpurun_out/d2stats/summary.txt $O/dist2_kernels_26_8.txt 2>/dev/null
