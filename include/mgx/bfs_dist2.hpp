@@ -269,7 +269,7 @@ __global__ __launch_bounds__(BLOCK) void k_d2_or_maps(const uint4* __restrict__ 
 template <int NT>
 __global__ __launch_bounds__(NT) void k_d2_lists_apply(bfs_fused_args_t a, int level, const u32* __restrict__ glists, int nlists, u32 stride,
                                                        u32 cap, int* __restrict__ labels, int ranks, int rank, u64* host_flag, u64 seq,
-                                                       u32* own_bits, int own_list) {
+                                                       u32* own_bits, int own_list, u32* own_count) {
   constexpr int NW = NT / WAVE;
   constexpr u64 CNT1 = 1ull << 40;
   constexpr u64 DEGMASK = CNT1 - 1ull;
@@ -302,6 +302,9 @@ __global__ __launch_bounds__(NT) void k_d2_lists_apply(bfs_fused_args_t a, int l
       __hip_atomic_store(&host_flag[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+  // the count of this rank's own list, for the next level: here when the gathered lists are a COPY (more than one rank: nobody in
+  // this launch reads the rank's own buffer); on a one-rank run d2_apply_lists clears it behind the kernel (see the header)
+  if (own_count && blockIdx.x == 0 && threadIdx.x == 0) own_count[0] = 0u;
   if (over || T == 0u) return;
   const u32 long_min = a.long_min > 0 ? (u32)a.long_min : 0xFFFFFFFFu;
   u64* const cur_s = &c->cursor[(level + 1) % 3];
@@ -384,6 +387,26 @@ __global__ __launch_bounds__(BLOCK) void k_d2_row_facts(const int* __restrict__ 
     for (int e = r0 + 1 + lane_id(); e < r1; e += WAVE) bad |= ci[e - 1] > ci[e];
   }
   if (__ballot(bad) && lane_id() == 0) *sorted = 0;
+}
+
+// Start of a traversal: the rank's labels (-1), visited bitmap, mark bytes, new-bit map and list header cleared by ONE launch (they
+// were five fills of 4 B .. 64 MB, each a launch of its own: ~45 us per traversal on a rank of RMAT-26 / 8).  Regions start on
+// 16-byte boundaries (device allocations); a region's last bytes, if it is not a multiple of 16 long, are written one by one.
+struct d2_fill_t { void* p; size_t bytes; u32 word; };
+__global__ __launch_bounds__(BLOCK) void k_d2_clear(d2_fill_t r0, d2_fill_t r1, d2_fill_t r2, d2_fill_t r3, d2_fill_t r4) {
+  const d2_fill_t regs[5] = {r0, r1, r2, r3, r4};
+  const size_t tid = (size_t)blockIdx.x * BLOCK + threadIdx.x, nth = (size_t)gridDim.x * BLOCK;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const d2_fill_t r = regs[k];
+    if (!r.p || !r.bytes) continue;
+    const uint4 v = make_uint4(r.word, r.word, r.word, r.word);
+    uint4* const q = (uint4*)r.p;
+    const size_t n16 = r.bytes / 16;
+    for (size_t i = tid; i < n16; i += nth) q[i] = v;
+    if (tid == 0)
+      for (size_t b = n16 * 16; b < r.bytes; ++b) ((unsigned char*)r.p)[b] = (unsigned char)(r.word & 0xFFu);
+  }
 }
 
 __global__ void k_d2_init(bfs_fused_args_t a, int* labels_local, int src, int ranks, int rank) {
@@ -573,12 +596,22 @@ struct d2_state_t {
 // Start of a traversal (asynchronous).
 inline void d2_reset(d2_state_t& st, int src, standard_context_t& ctx) {
   hipStream_t s = ctx.stream();
-  MGX_HIP(hipMemsetAsync(st.labels.data(), 0xFF, (size_t)st.n_local * sizeof(int), s));
-  MGX_HIP(hipMemsetAsync(st.fs->visited.data(), 0, st.fs->visited.size() * sizeof(u32), s));
-  MGX_HIP(hipMemsetAsync(st.fs->mark.data(), 0, st.fs->mark.size(), s));
-  if (st.mylist) MGX_HIP(hipMemsetAsync(st.mylist, 0, D2_LIST_HEAD * sizeof(u32), s));
   // (the new-bit map is all zero between the levels of a traversal that ran to its end; one that was abandoned may have left bits)
-  if (st.mylist && st.sparse_push) MGX_HIP(hipMemsetAsync(st.newbits, 0, (size_t)st.nwords * sizeof(u32), s));
+  const bool bits = st.mylist && st.sparse_push;
+  const d2_fill_t labels{st.labels.data(), (size_t)st.n_local * sizeof(int), 0xFFFFFFFFu};
+  const d2_fill_t visited{st.fs->visited.data(), st.fs->visited.size() * sizeof(u32), 0u};
+  const d2_fill_t marks{st.fs->mark.data(), st.fs->mark.size(), 0u};
+  const d2_fill_t head{st.mylist, st.mylist ? D2_LIST_HEAD * sizeof(u32) : 0, 0u};
+  const d2_fill_t newbits{bits ? st.newbits : nullptr, bits ? (size_t)st.nwords * sizeof(u32) : 0, 0u};
+  if (((uintptr_t)labels.p | (uintptr_t)visited.p | (uintptr_t)marks.p | (uintptr_t)head.p | (uintptr_t)newbits.p) % 16 == 0) {
+    hipLaunchKernelGGL(k_d2_clear, dim3(ctx.num_cus * 8), dim3(BLOCK), 0, s, labels, visited, marks, head, newbits);
+  } else {                                         // (a caller's buffer off the 16-byte grid: the fills one by one)
+    MGX_HIP(hipMemsetAsync(labels.p, 0xFF, labels.bytes, s));
+    MGX_HIP(hipMemsetAsync(visited.p, 0, visited.bytes, s));
+    MGX_HIP(hipMemsetAsync(marks.p, 0, marks.bytes, s));
+    if (head.p) MGX_HIP(hipMemsetAsync(head.p, 0, head.bytes, s));
+    if (newbits.p) MGX_HIP(hipMemsetAsync(newbits.p, 0, newbits.bytes, s));
+  }
   hipLaunchKernelGGL(k_d2_init, dim3(1), dim3(64), 0, s, st.args(), st.labels.data(), src, st.ranks, st.rank);
 }
 
@@ -615,11 +648,14 @@ inline void d2_apply_lists(d2_state_t& st, int level, const u32* glists, int nli
   hipStream_t s = ctx.stream();
   bfs_fused_args_t a = st.args();
   const u64 seq = ++st.flag_seq;
+  // (does the kernel read the rank's own buffer?  a one-rank run, or an in-place gather)
+  const bool own_is_read = st.mylist && glists < st.mylist + st.list_words() && st.mylist < glists + (size_t)nlists * (size_t)stride_words;
   hipLaunchKernelGGL(k_d2_lists_apply<BLOCK>, dim3(256), dim3(BLOCK), 0, s, a, level, glists, nlists, (u32)stride_words, st.list_cap,
-                     st.labels.data(), st.ranks, st.rank, st.host_flag, seq, st.newbits, nlists == 1 ? 0 : st.rank);
+                     st.labels.data(), st.ranks, st.rank, st.host_flag, seq, st.newbits, nlists == 1 ? 0 : st.rank,
+                     (st.mylist && !own_is_read) ? st.mylist : nullptr);
   MGX_CHECK_LAUNCH("partitioned BFS: list merge launch");
-  // the count of this rank's own list, for the next level's sweep: behind the kernel, never inside it (see the kernel's header)
-  if (st.mylist) MGX_HIP(hipMemsetAsync(st.mylist, 0, sizeof(u32), s));
+  // the count of this rank's own list, for the next level's sweep: behind the kernel when the kernel reads that very list (see its header)
+  if (st.mylist && own_is_read) MGX_HIP(hipMemsetAsync(st.mylist, 0, sizeof(u32), s));
   volatile u64* const flag = st.host_flag;
   long long spins = 0;
   while (flag[0] != seq) {
