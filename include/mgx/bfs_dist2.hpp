@@ -119,7 +119,12 @@ __global__ __launch_bounds__(D2_NEWBITS_NT) void k_d2_newbits(const u32* __restr
   __shared__ u32 s_wave[NW];
   __shared__ u32 s_base;
   if (blockIdx.x == 0 && threadIdx.x == 0) c->merged_new = 0;     // the merge of this level counts into it
-  if (c->d2_append_level == level) return;                        // (grid-uniform: written by the level's push launch)
+  if (c->d2_append_level == level) {                              // (grid-uniform: written by the level's push launch)
+    // (counted HERE for mgx_dbfs2_path_levels: the same add in the push launch's opener cost that kernel 17 % -- 534 -> 621 us per
+    //  traversal on a rank of RMAT-26 / 8, every level slower, for one read-modify-write by one thread; found by bisecting two builds)
+    if (blockIdx.x == 0 && threadIdx.x == 0) c->small_levels += 1;
+    return;
+  }
   if (list && slot_marks && declare_mul) {
     u64 M = 0;
 #pragma unroll

@@ -262,7 +262,6 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push_level(bfs_fused_args_t a, 
     bfs_slot_marks_clear(a, level + 1);
     a.ctrl->flush_count[(level + 1) & 1] = 0;
     a.ctrl->d2_append_level = appends ? level : -1;
-    if (appends) a.ctrl->small_levels += 1;               // (mgx_dbfs2_path_levels)
   }
   if (appends) {
     if (!(skip & 1)) bfs_d2_sparse_body<1024>(a, level, blockIdx.x, gridDim.x);     // (a split push: with its first launch)
