@@ -162,6 +162,16 @@ def _measure(args, rank, world, local_rank, ctx, device, gscale, steps, warmup, 
            "native": bool(getattr(bfs, "native", False)), "native_error": getattr(bfs, "native_error", None),
            "rccl": getattr(getattr(bfs, "comm", None), "library", None),
            "sparse_levels": getattr(bfs, "sparse_levels", None), "dense_levels": getattr(bfs, "dense_levels", None)}
+    # which paths of the rank engine the LAST traversal took on this rank: a first run on real GPUs should
+    # say more than a number
+    e = getattr(bfs, "e", None)
+    if e is not None and hasattr(e, "path_levels"):
+        try:
+            p = e.path_levels()
+            res["rank_paths"] = {"levels_appended_by_the_push": p[0], "levels_short_rows_vertex_by_vertex": p[1], "a_list_declared_overflowed": bool(p[2]),
+                                 "cold_edge_slices_packed": p[3], "levels_from_unit_blocks": e.dense_levels(), "levels_with_cold_edge_pass": e.cold_levels()[0]}
+        except Exception as ex:                      # (diagnostics only)
+            res["rank_paths"] = {"error": repr(ex)}
     return res
 
 
@@ -204,7 +214,8 @@ def bench_main(args, rank, world, local_rank):
                                                              world, r["exch"], args.steps),
                           "scale": gscale, "edgefactor": args.edgefactor, "seed": r["seed"],
                           "parallelism": "vertex-cyclic x%d" % world,
-                          "native_loop": r["native"], "native_error": r["native_error"], "rccl": r["rccl"]},
+                          "native_loop": r["native"], "native_error": r["native_error"], "rccl": r["rccl"],
+                          "rank0_paths_last_traversal": r.get("rank_paths")},
                "roofline": {"bound": "hbm", "kernel": "k_bfs_push_level (per rank)",
                             "achieved": round(8.0 * m_t / world / elapsed / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
                             "frac": round(8.0 * m_t / world / elapsed / 1e9 / 8000.0, 5), "traffic": None,
@@ -221,6 +232,7 @@ def bench_main(args, rank, world, local_rank):
                               "steps": c5["steps"], "avg_levels": round(c5["levels"] / max(c5["steps"], 1), 2),
                               "parity": c5["parity"], "parity_check": c5["parity_how"], "shard_build_s": round(c5["t_build"], 2),
                               "per_gpu_alg_GBps": round(8.0 * c5["m_t"] / world / c5["elapsed"] / 1e9, 2),
+                              "rank0_paths_last_traversal": c5.get("rank_paths"),
                               "note": "the 1-GPU figure the north star's >= 5x is quoted against cannot be RMAT-26 itself in this data model "
                                       "(2^31 CSR entries do not fit int32 row offsets on one GPU, SURVEY 8d): compare with the N = 1 line's "
                                       "RMAT-22 value (and DESIGN 5's single-GPU RMAT-25 figure)"}
