@@ -506,6 +506,9 @@ def test_bench_main_carries_config5_next_to_the_strong_line(built):
     c5 = j["config5"]
     assert c5["parity"] is True and "BFS-tree" in c5["parity_check"] and c5["value"] > 0 and c5["steps"] == 3
     assert "scale 24" in c5["workload"]
+    # the line says which paths of the rank engine ran (round 4): on RMAT-24 over 2 ranks the cold-edge pass and a sparse level
+    paths = c5["rank0_paths_last_traversal"]
+    assert paths and "error" not in paths and paths["levels_appended_by_the_push"] >= 1 and paths["levels_from_unit_blocks"] >= 1, paths
 
 
 @pytest.mark.gpu
