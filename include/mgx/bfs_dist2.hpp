@@ -23,6 +23,18 @@
 //     exchange below.  The host learns the decision (and whether the level found anything at all: the sum of the counts)
 //     from three words in pinned memory it spins on -- the one host round trip of a level.
 // Labels are the global BFS depths, identical to the single-GPU result.
+//
+// Round 4 ("the rank engine"; every item against a switch, MGX_DIST_* / MGX_BFS_COLD_PACK):
+//   * a level of no more edges than the id list holds ids appends its discoveries to the list from the push launch itself
+//     (bfs_fused_sparse.hpp) -- k_d2_newbits has nothing to sweep; a level whose push stored many marks declares its list
+//     overflowed without filling it;
+//   * the OR-merge of the ranks' maps runs inside the queue build (k_bfs_build2<., 2, RANKS>, 2 / 4 / 8 / 16 ranks), which also
+//     leaves the frontier over the rank's LOCAL rows for the vertex-by-vertex walk of its short rows (bfs_fused_vshort.hpp, with
+//     the cold test a bitmap of 2^26 vertices needs);
+//   * the cold-edge pass reads four bytes per pair, its bitmaps and those of the deferred hot marks are ORed together by a stream
+//     kernel in front of the sweep (k_d2_cold_reduce), and the unit blocks hold the rows' hot entries only, three bytes each;
+//   * the rank's new-bit map is all zero between levels: the sweep writes every word, a sparse level ORs single bits, whoever
+//     consumes the map (list merge: the words of the rank's own list; bitmap merge: all of it) clears what it read.
 #pragma once
 #include <cstddef>
 #include <memory>

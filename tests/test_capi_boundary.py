@@ -165,3 +165,26 @@ def test_pick_sources_is_deterministic_and_skips_isolated(built):
     a = rmat.pick_sources(ro, 8, 22)
     assert a == rmat.pick_sources(ro, 8, 22)
     assert set(a) <= {1, 3} and len(a) == 8
+
+
+def test_push_kernels_do_not_spill_vector_registers(built):
+    """the push kernels sit at their 64-VGPR budget (two 1024-thread workgroups per CU): one more live value tips the
+    allocator into scratch, and a kernel that streams at 6 TB/s then loses a sixth of its speed (end of round 4).
+    build() keeps the compiler's resource remarks: the hot kernels must report no scratch."""
+    import os, re
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mini_amd", "kernel_resources.txt")
+    if not os.path.exists(path):
+        pytest.skip("no resource remarks next to the library (built by hand)")
+    cur, scratch = None, {}
+    for line in open(path):
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            continue
+        m = re.search(r"ScratchSize[^:]*: (\d+)", line)
+        if m and cur:
+            scratch[cur] = int(m.group(1))
+    hot = [k for k in scratch if ("k_bfs_pushILb0ELi0" in k) or ("k_bfs_push_levelILb1" in k) or ("k_bfs_push_levelILb0" in k)]
+    assert len(hot) == 3, sorted(scratch)[:5]
+    for k in hot:
+        assert scratch[k] == 0, "%s spills: ScratchSize %d" % (k, scratch[k])
