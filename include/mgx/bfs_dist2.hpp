@@ -492,6 +492,11 @@ struct d2_state_t {
   int build_list = 0;                 // the list-based queue build (MGX_DIST_BUILD_LIST)
   int push_split = 0;                 // measurements: the push grid's three parts as three launches (MGX_DIST_PUSH_SPLIT)
   mem_t<u32> defer_buf;               // deferred hot marks of the push workgroups (bfs_hot_epilogue): BFS_FLUSH_MAX bitmaps; empty: nothing is deferred (MGX_DIST_DEFER=0)
+  // ... and only on a shard big enough to pay for the 80 KB bitmap every deferring workgroup writes and the reduce behind it:
+  // RMAT-25 / 8 (134 M entries per rank) 551 against 578 us of kernels per traversal with them, RMAT-22 / 8 (17 M) 264 against 225
+  // without.  mgx_dbfs2_build_units sets it from the rank's entry count (MGX_DIST_DEFER=2: always)
+  bool defer_pays = true;
+  static constexpr long long D2_DEFER_MIN_ENTRIES = 48ll << 20;
   d2_cold_view_t cold_view() const {
     d2_cold_view_t v;
     if (!cold_dst || cold_slices <= 0 || !cold_flush.size()) return v;
@@ -600,7 +605,7 @@ struct d2_state_t {
     for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) { a.cold_off[i] = cold ? cold_off[i] : 0u; a.cold_wgs[i] = cold ? cold_wgs[i] : 0u; }
     // deferred hot marks: while the ranks together have reached fewer vertices than the deferred range holds (reached counts this
     // rank's: x ranks); k_d2_cold_reduce + k_d2_newbits read the bitmaps
-    const bool defer = defer_buf.size() != 0 && cold_reduce;
+    const bool defer = defer_buf.size() != 0 && cold_reduce && defer_pays;
     a.flush_buf = defer ? const_cast<u32*>(defer_buf.data()) : nullptr; a.defer_min_marks = defer ? fs->defer_min_marks : 0u;
     a.defer_words = defer ? (u32)BFS_FLUSH_WORDS : 0u; a.defer_reach_mul = (u32)ranks; a.defer_reach_div = 1;
     a.chain_max_edges = 0;               // (levels are counted by the host here: no chains of small levels)

@@ -1412,6 +1412,14 @@ int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
     if (const char* e = getenv("MGX_DIST_VSHORT")) vdiv = atoi(e);
     standard_context_t& ctx = *h->c->ctx;
     const int n = st.n_local;
+    if (n > 0) {
+      // deferred hot marks only on a shard big enough to pay for their bitmaps (d2_state_t::defer_pays)
+      int m_last = 0;
+      MGX_HIP(mgx::dtoh(&m_last, st.row_offsets + n, 1));
+      int defer_mode = 1;
+      if (const char* e = getenv("MGX_DIST_DEFER")) defer_mode = atoi(e);
+      st.defer_pays = defer_mode == 2 || (long long)m_last >= mgx::d2_state_t::D2_DEFER_MIN_ENTRIES;
+    }
     if (vdiv > 0 && n > 0) {
       std::vector<int> hro((size_t)n + 1);
       MGX_HIP(mgx::dtoh(hro.data(), st.row_offsets, (size_t)n + 1));

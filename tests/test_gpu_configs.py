@@ -392,8 +392,8 @@ def _run_rank_engines_lists(torch, engs, src):
 # vertex-by-vertex bodies forced onto every level that can take them
 _RANK_SWITCHES = [
     {},                                                                  # the defaults
-    {"MGX_DIST_DENSE_DIV": "1000000", "MGX_DIST_VSHORT": "1000000"},     # dense bodies wherever the frontier bitmap is current
-    {"MGX_DIST_DENSE_DIV": "1000000", "MGX_DIST_VSHORT": "1000000", "MGX_DIST_DECLARE_MUL": "1"},   # lists declared overflowed early
+    {"MGX_DIST_DENSE_DIV": "1000000", "MGX_DIST_VSHORT": "1000000", "MGX_DIST_DEFER": "2"},     # dense bodies wherever the frontier bitmap is current; deferred hot marks whatever the shard's size
+    {"MGX_DIST_DENSE_DIV": "1000000", "MGX_DIST_VSHORT": "1000000", "MGX_DIST_DECLARE_MUL": "1", "MGX_DIST_DEFER": "2"},   # lists declared overflowed early
     {"MGX_DIST_DENSE_DIV": "1000000", "MGX_DIST_SPARSE_PUSH": "0", "MGX_DIST_FUSED_MERGE": "0"},
     {"MGX_DIST_DENSE_DIV": "1000000", "MGX_DIST_COLD_REDUCE": "0", "MGX_DIST_HOT_UNITS": "0"},
     {"MGX_DIST_DENSE_DIV": "1000000", "MGX_BFS_COLD_PACK": "0", "MGX_DIST_DEFER": "0", "MGX_DIST_VSHORT": "0"},

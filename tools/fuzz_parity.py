@@ -174,7 +174,7 @@ for name, n, ro, ci, w in graphs():
             dknobs = {"MGX_DIST_SPARSE_PUSH": rng.choice(["", "0"]), "MGX_DIST_DECLARE_MUL": rng.choice(["", "0", "1"]),
                       "MGX_DIST_FUSED_MERGE": rng.choice(["", "0"]), "MGX_DIST_COLD_REDUCE": rng.choice(["", "0"]),
                       "MGX_DIST_HOT_UNITS": rng.choice(["", "0"]), "MGX_BFS_COLD_PACK": rng.choice(["", "0"]),
-                      "MGX_DIST_DEFER": rng.choice(["", "0"]), "MGX_DIST_VSHORT": rng.choice(["", "0", "1000000"]),
+                      "MGX_DIST_DEFER": rng.choice(["", "0", "2", "2"]), "MGX_DIST_VSHORT": rng.choice(["", "0", "1000000"]),
                       "MGX_DIST_COLD_WGS": rng.choice(["", "3", "700"])}
             for kk, vv in dknobs.items():
                 if vv == "":
