@@ -396,6 +396,19 @@ MGX_API int mgx_comm_create(mgx_ctx_t ctx, int ranks, int rank, const unsigned c
 MGX_API int mgx_comm_free(mgx_comm_t comm);
 MGX_API const char* mgx_comm_library(void);
 MGX_API int mgx_comm_available(void); /* 1: RCCL is in the process or could be loaded with every entry point the library needs */
+/* The in-process stand-in for RCCL (include/mgx/comm_loopback.hpp): G host THREADS of one process as G ranks -- any devices, the
+ * tests use one GPU, where RCCL itself refuses a second rank -- so that mgx_dbfs2_run / mgx_dsssp_run themselves can be run and
+ * checked with 2 .. 64 ranks on a one-GPU box.  mgx_comm_loopback_id makes an id that names it (mgx_comm_unique_id does the same
+ * when MGX_COMM=loopback is set); mgx_comm_create on such an id blocks until `ranks` threads have joined (or
+ * MGX_LOOPBACK_TIMEOUT_S seconds, default 120, have passed: MGX_E_HIP, as every later call on that communicator).  Collectives
+ * are host-synchronous device copies with the group semantics of ncclGroupStart / End.  Test infrastructure for the multi-rank
+ * loops: nothing selects it by default.  mgx_comm_info: *is_loopback, and the collective rounds its world has completed. */
+MGX_API int mgx_comm_loopback_id(unsigned char* out128);
+MGX_API int mgx_comm_info(mgx_comm_t comm, int* is_loopback, int64_t* rounds);
+/* A communicator's pre-flight, through the very function table the loops use (collective: every rank calls it): all-gather of the
+ * first `words` words of d_send into d_gathered (ranks * words), then the slice exchange's pattern -- grouped send of slice r of
+ * d_send (ranks * words) to rank r / receive from rank r into slice r of d_alltoall -- and a wait for the stream. */
+MGX_API int mgx_comm_selftest(mgx_comm_t comm, const unsigned* d_send, unsigned* d_gathered, unsigned* d_alltoall, int64_t words);
 MGX_API int mgx_dbfs2_run(mgx_dbfs2_t h, mgx_comm_t comm, int src_global, int exchange, int64_t exchange_words, int64_t* out6);
 
 /* ---- SSSP: sssp_problem_t / sssp_functor_t / sssp_enactor_t (gunrock/src/sssp/) ---- */

@@ -764,7 +764,7 @@ struct d2_run_bufs_t {
 // the bitmap exchange of one level + the dense merge (what every level did before the id lists)
 inline void d2_exchange_bitmaps(d2_state_t& st, comm_t& cm, d2_run_bufs_t& bufs, int level, int exchange, long long xwords,
                                 standard_context_t& ctx) {
-  const rccl_api_t& api = rccl_api_t::get();
+  const rccl_api_t& api = cm.table();
   hipStream_t s = ctx.stream();
   const int R = st.ranks;
   const long long S = xwords / R;                 // words per slice (xwords is a multiple of 4 * R)
@@ -791,7 +791,7 @@ inline void d2_exchange_bitmaps(d2_state_t& st, comm_t& cm, d2_run_bufs_t& bufs,
 
 inline void d2_run(d2_state_t& st, comm_t& cm, d2_run_bufs_t& bufs, int src, int exchange, long long xwords,
                    standard_context_t& ctx, long long* out6) {
-  const rccl_api_t& api = rccl_api_t::get();
+  const rccl_api_t& api = cm.table();
   hipStream_t s = ctx.stream();
   const int R = st.ranks;
   if (bufs.xwords != xwords || !bufs.gathered.size()) {

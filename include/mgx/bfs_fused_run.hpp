@@ -300,7 +300,8 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push_level(bfs_fused_args_t a, 
 
 inline void bfs_set_kernel_attributes() {
   static unsigned char seen[64] = {};
-  if (!first_use_on_device(seen)) return;
+  device_once_t once(seen);
+  if (!once) return;
 #define MGX_SET_LDS(K_) MGX_HIP(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
   MGX_SET_LDS((k_bfs_push<false, 0>)); MGX_SET_LDS((k_bfs_push<true, 0>));
   MGX_SET_LDS((k_bfs_push<false, 1>)); MGX_SET_LDS((k_bfs_push<true, 1>));

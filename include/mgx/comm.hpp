@@ -14,6 +14,7 @@
 #include <mutex>
 #include <string>
 
+#include "comm_loopback.hpp"
 #include "runtime.hpp"
 
 namespace mgx {
@@ -60,15 +61,34 @@ struct rccl_api_t {
   bool ok() const {
     return handle && GetUniqueId && CommInitRank && CommDestroy && AllGather && Send && Recv && GroupStart && GroupEnd;
   }
+  // The in-process stand-in (comm_loopback.hpp): the same nine pointers, G host threads for G ranks.  Only a communicator made
+  // from a loopback id carries this table (comm_t::api); nothing selects it by default.
+  static const rccl_api_t& loopback() {
+    static const rccl_api_t api = [] {
+      rccl_api_t a;
+      a.GetUniqueId = loopback::GetUniqueId;
+      a.CommInitRank = loopback::CommInitRank;
+      a.CommDestroy = loopback::CommDestroy;
+      a.AllGather = loopback::AllGather;
+      a.Send = loopback::Send;
+      a.Recv = loopback::Recv;
+      a.GroupStart = loopback::GroupStart;
+      a.GroupEnd = loopback::GroupEnd;
+      a.GetErrorString = loopback::GetErrorString;
+      a.handle = (void*)&loopback::registry_t::get();
+      a.where = "loopback (in-process, include/mgx/comm_loopback.hpp)";
+      return a;
+    }();
+    return api;
+  }
 };
 
+// (expects `api`, the table the call went through, in scope)
 #define MGX_RCCL(expr)                                                                                         \
   do {                                                                                                         \
     ncclResult_t _r = (expr);                                                                                  \
-    if (_r != ncclSuccess) {                                                                                   \
-      const rccl_api_t& _a = ::mgx::rccl_api_t::get();                                                         \
-      throw ::mgx::mgx_error(MGX_E_HIP, std::string(#expr) + ": " + (_a.GetErrorString ? _a.GetErrorString(_r) : "RCCL error")); \
-    }                                                                                                          \
+    if (_r != ncclSuccess)                                                                                     \
+      throw ::mgx::mgx_error(MGX_E_HIP, std::string(#expr) + ": " + (api.GetErrorString ? api.GetErrorString(_r) : "RCCL error")); \
   } while (0)
 
 // ncclGroupStart ... ncclGroupEnd as a scope: end() closes the group and reports its status; if the scope is left by an
@@ -86,10 +106,12 @@ struct rccl_group_t {
 struct comm_t {
   ncclComm_t comm = nullptr;
   int ranks = 1, rank = 0;
+  const rccl_api_t* api = nullptr;        // the table this communicator was made through (RCCL's or the loopback's); nullptr: RCCL's
   comm_t() {}
   comm_t(const comm_t&) = delete;
   comm_t& operator=(const comm_t&) = delete;
-  ~comm_t() { if (comm) (void)rccl_api_t::get().CommDestroy(comm); }
+  const rccl_api_t& table() const { return api ? *api : rccl_api_t::get(); }
+  ~comm_t() { if (comm) (void)table().CommDestroy(comm); }
 };
 
 }  // namespace mgx

@@ -292,7 +292,7 @@ inline void nr_full_frontier(const nr_layout_t& L, GetValue get, V* reduced, V i
   V* const vals = (V*)ctx.scratch;
   V* const partial = (V*)((char*)ctx.scratch + (((size_t)L.n + 64) * sizeof(V) + 255) / 256 * 256);
   static unsigned char seen[64] = {};
-  if (first_use_on_device(seen))
+  if (device_once_t once{seen})
     MGX_HIP(hipFuncSetAttribute((const void*)(k_nr_edges<V, Op, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL((k_nr_values<V, GetValue>), dim3(grid_for(L.n, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, get, L.old_of_new, vals,
                      reduced, identity, (long long)L.n, frontier, host_flag, dev_flag, epoch);

@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
+#include <exception>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -57,15 +59,30 @@ struct mgx_error : std::runtime_error {
   } while (0)
 
 // Per-DEVICE one-time setup (hipFuncSetAttribute is per device: a second context on another GPU of the same process
-// needs it again).  Returns true the first time it is called for the current device with this tag.
-inline bool first_use_on_device(unsigned char (&seen)[64]) {
-  int dev = 0;
-  MGX_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64) return true;
-  if (seen[dev]) return false;
-  seen[dev] = 1;
-  return true;
-}
+// needs it again).  `device_once_t once(seen); if (once) { ...set the attributes... }` -- true for ONE caller per device and
+// tag; a second host thread that arrives while the first is still inside the block waits for it (the rank threads of a
+// loopback world launch the same kernels at the same moment: "somebody has started setting the attributes" is not enough
+// to launch on).  The tag is marked when the block is left without an exception.
+struct device_once_t {
+  unsigned char* slot = nullptr;
+  bool first = false;
+  std::unique_lock<std::mutex> lk;
+  static std::mutex& mu() { static std::mutex m; return m; }
+  explicit device_once_t(unsigned char (&seen)[64]) {
+    int dev = 0;
+    MGX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { first = true; return; }
+    if (__atomic_load_n(&seen[dev], __ATOMIC_ACQUIRE)) return;
+    lk = std::unique_lock<std::mutex>(mu());
+    if (__atomic_load_n(&seen[dev], __ATOMIC_ACQUIRE)) { lk.unlock(); return; }
+    slot = &seen[dev];
+    first = true;
+  }
+  device_once_t(const device_once_t&) = delete;
+  device_once_t& operator=(const device_once_t&) = delete;
+  ~device_once_t() { if (slot && !std::uncaught_exceptions()) __atomic_store_n(slot, (unsigned char)1, __ATOMIC_RELEASE); }
+  explicit operator bool() const { return first; }
+};
 
 // ---------------------------------------------------------------------------
 // context: one device, one stream, a scratch arena, a pinned mailbox

@@ -242,7 +242,7 @@ struct dsssp_run_bufs_t {
 
 // out4: supersteps, edges relaxed here, pairs sent from here, pairs received here
 inline void dsssp_run(dsssp_state_t& st, comm_t& cm, dsssp_run_bufs_t& bufs, int src_global, standard_context_t& ctx, long long* out4) {
-  const rccl_api_t& api = rccl_api_t::get();
+  const rccl_api_t& api = cm.table();
   const int R = st.ranks, me = st.rank;
   if (R > 1 && !(api.ok() && cm.comm)) throw mgx_error(MGX_E_INVALID, "dsssp_run: more than one rank needs a communicator");
   const bool coll = cm.comm != nullptr;          // (a one-rank communicator still runs the collectives: the tests' way to exercise them on one GPU)

@@ -1075,7 +1075,7 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   hipLaunchKernelGGL(k_sssp_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src,
                      layout ? layout->new_of_old : (const int*)nullptr);
   static unsigned char attr_seen[64] = {};
-  if (first_use_on_device(attr_seen)) {
+  if (device_once_t once{attr_seen}) {
     MGX_HIP(hipFuncSetAttribute((const void*)k_sssp_relax<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SSSP_HOTN * 2));
     MGX_HIP(hipFuncSetAttribute((const void*)(k_sssp_relax_dense<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #ifdef MGX_LAB

@@ -1705,11 +1705,25 @@ int mgx_dbfs2_status(mgx_dbfs2_t h, int next_level, int64_t* out6) {
   MGX_CATCH
 }
 // ---- RCCL communicator of the library's own (mgx/comm.hpp) and the traversal driven from C++ ----
+static bool comm_env_loopback() {
+  const char* e = getenv("MGX_COMM");
+  return e && std::string(e) == "loopback";
+}
 int mgx_comm_unique_id(unsigned char* out128) {
   MGX_TRY
   MGX_REQUIRE(out128, "NULL argument");
+  if (comm_env_loopback()) return mgx_comm_loopback_id(out128);
   mgx::rccl_api_t& api = mgx::rccl_api_t::get();
   MGX_REQUIRE(api.ok(), "mgx_comm_unique_id: no RCCL in this process and none could be loaded (librccl.so.1)");
+  ncclUniqueId id;
+  MGX_RCCL(api.GetUniqueId(&id));
+  memcpy(out128, id.internal, NCCL_UNIQUE_ID_BYTES);
+  MGX_CATCH
+}
+int mgx_comm_loopback_id(unsigned char* out128) {
+  MGX_TRY
+  MGX_REQUIRE(out128, "NULL argument");
+  const mgx::rccl_api_t& api = mgx::rccl_api_t::loopback();
   ncclUniqueId id;
   MGX_RCCL(api.GetUniqueId(&id));
   memcpy(out128, id.internal, NCCL_UNIQUE_ID_BYTES);
@@ -1718,14 +1732,16 @@ int mgx_comm_unique_id(unsigned char* out128) {
 int mgx_comm_create(mgx_ctx_t c, int ranks, int rank, const unsigned char* id128, mgx_comm_t* out) {
   MGX_TRY
   MGX_REQUIRE(c && id128 && out && ranks >= 1 && rank >= 0 && rank < ranks, "mgx_comm_create: bad argument");
-  mgx::rccl_api_t& api = mgx::rccl_api_t::get();
+  // (a loopback id -- mgx_comm_loopback_id, or mgx_comm_unique_id under MGX_COMM=loopback -- names the in-process stand-in)
+  const bool loop = mgx::loopback::is_loopback_id(id128);
+  const mgx::rccl_api_t& api = loop ? mgx::rccl_api_t::loopback() : mgx::rccl_api_t::get();
   MGX_REQUIRE(api.ok(), "mgx_comm_create: no RCCL in this process and none could be loaded (librccl.so.1)");
   use_device(c);
   ncclUniqueId id;
   memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
   auto* h = new mgx_comm_s();
   h->c = c;
-  h->cm.ranks = ranks; h->cm.rank = rank;
+  h->cm.ranks = ranks; h->cm.rank = rank; h->cm.api = &api;
   ncclResult_t r = api.CommInitRank(&h->cm.comm, ranks, id, rank);
   if (r != ncclSuccess) {
     h->cm.comm = nullptr;
@@ -1733,6 +1749,33 @@ int mgx_comm_create(mgx_ctx_t c, int ranks, int rank, const unsigned char* id128
     throw mgx::mgx_error(MGX_E_HIP, std::string("ncclCommInitRank: ") + (api.GetErrorString ? api.GetErrorString(r) : "RCCL error"));
   }
   *out = h;
+  MGX_CATCH
+}
+int mgx_comm_info(mgx_comm_t h, int* is_loopback, int64_t* rounds) {
+  MGX_TRY
+  MGX_REQUIRE(h, "NULL argument");
+  const bool loop = h->cm.api == &mgx::rccl_api_t::loopback();
+  if (is_loopback) *is_loopback = loop ? 1 : 0;
+  if (rounds) *rounds = loop ? (int64_t)mgx::loopback::rounds(h->cm.comm) : 0;
+  MGX_CATCH
+}
+int mgx_comm_selftest(mgx_comm_t h, const unsigned* d_send, unsigned* d_gathered, unsigned* d_alltoall, int64_t words) {
+  MGX_TRY
+  MGX_REQUIRE(h && d_send && d_gathered && d_alltoall && words > 0, "mgx_comm_selftest: bad argument");
+  use_device(h->c);
+  const mgx::rccl_api_t& api = h->cm.table();
+  hipStream_t s = h->c->ctx->stream();
+  const int R = h->cm.ranks;
+  MGX_RCCL(api.AllGather(d_send, d_gathered, (size_t)words, ncclUint32, h->cm.comm, s));
+  {
+    mgx::rccl_group_t group(api);
+    for (int r = 0; r < R; ++r) {
+      MGX_RCCL(api.Send(d_send + (size_t)r * words, (size_t)words, ncclUint32, r, h->cm.comm, s));
+      MGX_RCCL(api.Recv(d_alltoall + (size_t)r * words, (size_t)words, ncclUint32, r, h->cm.comm, s));
+    }
+    group.end();
+  }
+  MGX_HIP(hipStreamSynchronize(s));
   MGX_CATCH
 }
 int mgx_comm_free(mgx_comm_t h) {

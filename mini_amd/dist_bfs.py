@@ -333,6 +333,65 @@ class NativeComm:
             self._h = None
 
 
+class LoopbackComm:
+    """A communicator of the library's in-process stand-in for RCCL (include/mgx/comm_loopback.hpp): the ranks are host THREADS
+    of this process.  One thread makes the id (LoopbackComm.new_id()), every rank thread constructs its communicator from it --
+    the constructor blocks until all `world` threads have joined, as ncclCommInitRank does.  What the -m gpu tests run
+    mgx_dbfs2_run / mgx_dsssp_run over with 2 .. 8 ranks on one GPU; never selected by a product path."""
+
+    @staticmethod
+    def new_id():
+        buf = (C.c_ubyte * 128)()
+        check(lib.mgx_comm_loopback_id(buf))
+        return bytes(buf)
+
+    def __init__(self, ctx, rank, world, ident):
+        self._h = None
+        raw = (C.c_ubyte * 128)(*ident)
+        h = C.c_void_p()
+        check(lib.mgx_comm_create(ctx._h, int(world), int(rank), raw, C.byref(h)))
+        self._h = h
+        self.library = "loopback"
+
+    def rounds(self):
+        """collective rounds the world has completed (one per collective outside a group, one per group)"""
+        loop, rounds = C.c_int(), C.c_int64()
+        check(lib.mgx_comm_info(self._h, C.byref(loop), C.byref(rounds)))
+        assert loop.value == 1
+        return rounds.value
+
+    def close(self):
+        if self._h:
+            lib.mgx_comm_free(self._h)
+            self._h = None
+
+
+def run_rank_threads(world, fn, timeout_s=300.0):
+    """fn(rank) on `world` host threads at once (ctypes calls release the GIL: the ranks really run side by side); returns the
+    list of results by rank, re-raises the first rank's exception.  A rank that never returns is reported, not waited for."""
+    import threading
+    out, err = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            out[r] = fn(r)
+        except BaseException as ex:      # noqa: BLE001 -- handed to the caller
+            err[r] = ex
+
+    ts = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout_s)
+    hung = [r for r, t in enumerate(ts) if t.is_alive()]
+    if hung:
+        raise RuntimeError("rank threads %r did not return within %.0f s" % (hung, timeout_s))
+    for r, ex in enumerate(err):
+        if ex is not None:
+            raise ex
+    return out
+
+
 class DistBfs2:
     """Superstep driver of generation 2: push (device) -> exchange of the new-bit maps -> merge (device), all
     stream-ordered.  The exchange is an OR-all-reduce of bitmaps, which RCCL does not have as such:
