@@ -192,6 +192,13 @@ def main():
 
     stream = torch.cuda.current_stream()
     ctx = mini_amd.Context(local_rank, stream.cuda_stream)
+    if args.mode == "push" and not args.file and (2 * args.edgefactor << args.scale) >= (1 << 31):
+        # more CSR entries than int32 row offsets hold (RMAT-26): the graph as shards of < 2^31 entries, in turn on this GPU
+        import bench_dist
+        shards = 2
+        while (2 * args.edgefactor << args.scale) // shards >= (1 << 31):
+            shards *= 2
+        return bench_dist.bench_single_sharded(args, ctx, shards)
     if args.mode == "sssp":
         return bench_sssp(args, ctx, stream)
     if args.mode == "pr":

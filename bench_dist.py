@@ -175,6 +175,76 @@ def _measure(args, rank, world, local_rank, ctx, device, gscale, steps, warmup, 
     return res
 
 
+def bench_single_sharded(args, ctx, shards):
+    """ONE GPU, a graph whose CSR does not fit int32 row offsets (RMAT-26 ef 16: 2^31 entries; SURVEY F12,
+    /root/reference/gunrock/src/graph.hxx:19-26): the graph is cut into `shards` cyclic vertex shards of < 2^31 entries each,
+    every shard gets a rank engine on THIS device, and a traversal runs the engines in turn (mgx_dbfs2_run_group: the C++
+    loop of the partitioned traversal, its level plan, the "collectives" as device copies into one shared buffer).  All the
+    work of the traversal is done by the one GPU: this is the 1-GPU figure for RMAT-26 -- the denominator of the north
+    star's ">= 5x at 8 GPUs over 1 GPU on RMAT-26"."""
+    import json
+    device = torch.device("cuda", 0)
+    scale, ef = args.scale, args.edgefactor
+    seed = scale if args.seed is None else args.seed
+    n = 1 << scale
+    t0 = time.time()
+    engs, rows = [], []
+    for r in range(shards):
+        ro, col, new_of_old, old_of_new, deg_new = rmat_cyclic_shard(ctx, scale, ef, seed, shards, r, device)
+        engs.append(HipRankEngine2(ctx, n, shards, r, ro, col))
+        rows.append((ro, col))
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+    from mini_amd.rmat import _mix64_py
+    steps, warmup = args.steps, max(args.warmup, 1)          # (the first traversal of an engine leaves the level plan)
+    cand = [int(_mix64_py(seed + k) % n) for k in range(8 * (steps + warmup) + 64)]
+    cand_new = new_of_old[torch.tensor(cand, device=device)].cpu().tolist()
+    cand_deg = deg_new[torch.tensor(cand_new, device=device)].cpu().tolist()
+    sources = [v for v, dg in zip(cand_new, cand_deg) if dg > 0][: steps + warmup]
+    for s in sources[:warmup]:
+        HipRankEngine2.run_group(engs, s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m_t = levels = 0
+    for s in sources[warmup:]:
+        sts = HipRankEngine2.run_group(engs, s)
+        m_t += sum(st["edges_local"] for st in sts)
+        levels += sts[0]["levels"]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    parity = None
+    if not args.no_check and steps > 0:
+        src = sources[warmup]
+        HipRankEngine2.run_group(engs, src)
+        lab = torch.empty(n, dtype=torch.int32, device=device)
+        for r, e in enumerate(engs):
+            lab[r::shards] = torch.from_numpy(e.labels()).to(device)
+        parity = all(_tree_check_local(lab, ro, col, shards, r, src) for r, (ro, col) in enumerate(rows))
+    value = m_t / elapsed / 1e6
+    out = {"metric": "MTEPS (million traversed edges/sec) BFS advance+filter, RMAT-%d" % scale,
+           "value": round(value, 2), "unit": "MTEPS", "n_gpus": 1, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(elapsed * 1e3 / max(steps, 1), 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "int32", "data": "synthetic",
+           "config": {"workload": "BFS push on RMAT scale %d ef %d, symmetrised (n=%d, %d CSR entries: more than int32 row offsets hold), on ONE "
+                                  "GPU as %d cyclic vertex shards of < 2^31 entries, a rank engine each, run in turn by the partitioned "
+                                  "traversal's C++ loop (mgx_dbfs2_run_group; the exchanges are device copies), %d seeded sources"
+                                  % (scale, ef, n, 2 * ef * n, shards, steps),
+                      "scale": scale, "edgefactor": ef, "seed": seed, "parallelism": "1 GPU, %d shards in turn" % shards,
+                      "level_plan": dict(zip(("planned_ahead", "frozen", "longer_than_planned", "levels", "lists_mask"), engs[0].spec_stats()))},
+           "roofline": {"bound": "hbm", "kernel": "k_bfs_push_level (all shards)", "achieved": round(8.0 * m_t / elapsed / 1e9, 2), "peak": 8000.0,
+                        "unit": "GB/s", "frac": round(8.0 * m_t / elapsed / 1e9 / 8000.0, 5), "traffic": None,
+                        "note": "algorithmic bytes (8 B/edge) over the whole traversal loop of all shards"},
+           "cpu_baseline": None, "parity_vs_oracle": parity,
+           "parity_check": "BFS-tree properties of the first timed source's labels over every shard's rows (the oracle needs the whole CSR in int32)",
+           "avg_levels": round(levels / max(steps, 1), 2), "graph_build_s": round(t_build, 2)}
+    print(json.dumps(out), flush=True)
+    for e in engs:
+        e.close()
+    if parity is False:
+        print("bench.py: the sharded traversal's labels failed the check -- the line above is NOT a valid measurement", file=sys.stderr)
+        sys.exit(1)
+
+
 def bench_main(args, rank, world, local_rank):
     """bench.py body for N > 1 (one process per GPU, RCCL).  --scaling strong (default): the SAME RMAT-<scale> graph
     partitioned over the N GPUs (the metric's "RMAT-22 @1/2/4/8"; --scale 26 at N = 8 is BASELINE config 5);

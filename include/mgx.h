@@ -410,6 +410,16 @@ MGX_API int mgx_comm_info(mgx_comm_t comm, int* is_loopback, int64_t* rounds);
  * d_send (ranks * words) to rank r / receive from rank r into slice r of d_alltoall -- and a wait for the stream. */
 MGX_API int mgx_comm_selftest(mgx_comm_t comm, const unsigned* d_send, unsigned* d_gathered, unsigned* d_alltoall, int64_t words);
 MGX_API int mgx_dbfs2_run(mgx_dbfs2_t h, mgx_comm_t comm, int src_global, int exchange, int64_t exchange_words, int64_t* out6);
+/* With id lists, mgx_dbfs2_run enqueues a WHOLE traversal ahead -- per level the push and either the lists or the bitmaps, as the
+ * engine's last traversals went (the first one, and MGX_DIST_SPEC=0, look once per level) -- and waits once.  A list that overflows
+ * against the plan freezes the traversal at that level on every rank alike; the host then sends that level through the bitmaps
+ * and goes on level by level.  out5 = { traversals planned ahead, of those frozen, of those longer than planned, levels and
+ * lists-mask (bit L: level L from id lists) of the last plan }. */
+MGX_API int mgx_dbfs2_spec_stats(mgx_dbfs2_t h, int64_t* out5);
+/* The engines of ALL ranks of one partition, made on one context, driven in turn by the calling thread: the collectives are device
+ * copies into one shared buffer, the level plan is mgx_dbfs2_run's.  A measurement and test entry (wall time / ranks = what one
+ * rank's GPU spends per traversal, no exchange time); out6_each: ranks x 6, as mgx_dbfs2_status per engine. */
+MGX_API int mgx_dbfs2_run_group(mgx_dbfs2_t* engines, int count, int src_global, int64_t exchange_words, int64_t* out6_each);
 
 /* ---- SSSP: sssp_problem_t / sssp_functor_t / sssp_enactor_t (gunrock/src/sssp/) ---- */
 MGX_API int mgx_sssp_create(mgx_graph_t g, int src, mgx_sssp_t* out);     /* sssp_problem.hxx:40-52 */

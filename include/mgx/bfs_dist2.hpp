@@ -65,6 +65,7 @@ struct d2_cold_view_t {
 // The same for the bitmaps of the level's deferred hot marks (bfs_hot_epilogue: ctrl->flush_count[level & 1] buffers of
 // BFS_FLUSH_WORDS words in defer_buf): the threads behind the slices'.
 __global__ __launch_bounds__(BLOCK) void k_d2_cold_reduce(d2_cold_view_t cv, const bfs_ctrl_t* c, int level, u32* flush, u32* defer_buf) {
+  if (bfs_d2_frozen(c, level)) return;
   if (c->d2_append_level == level) return;
   constexpr u32 Q = BFS_COLD_WORDS / 4;
   const u32 t = blockIdx.x * BLOCK + threadIdx.x;
@@ -130,7 +131,12 @@ __global__ __launch_bounds__(D2_NEWBITS_NT) void k_d2_newbits(const u32* __restr
   constexpr int NT = D2_NEWBITS_NT, NW = NT / WAVE;
   __shared__ u32 s_wave[NW];
   __shared__ u32 s_base;
-  if (blockIdx.x == 0 && threadIdx.x == 0) c->merged_new = 0;     // the merge of this level counts into it
+  if (bfs_d2_frozen(c, level)) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // (what all ranks discovered in the level before: the next traversal's level plan is made from these, d2_run)
+    if (level > 0 && level <= 64) c->d2_level_new[level - 1] = c->merged_new > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)c->merged_new;
+    c->merged_new = 0;                                            // the merge of this level counts into it
+  }
   if (c->d2_append_level == level) {                              // (grid-uniform: written by the level's push launch)
     // (counted HERE for mgx_dbfs2_path_levels: the same add in the push launch's opener cost that kernel 17 % -- 534 -> 621 us per
     //  traversal on a rank of RMAT-26 / 8, every level slower, for one read-modify-write by one thread; found by bisecting two builds)
@@ -229,6 +235,7 @@ __global__ __launch_bounds__(D2_NEWBITS_NT) void k_d2_newbits(const u32* __restr
 __global__ __launch_bounds__(BLOCK) void k_d2_or(const uint4* __restrict__ gathered, int maps, long long stride4,
                                                  long long nwords4, uint4* __restrict__ merged,
                                                  uint4* __restrict__ visited, bfs_ctrl_t* c, int level, uint4* clear) {
+  if (bfs_d2_frozen(c, level)) return;
   // merged = the frontier of level + 1 as a bitmap over all vertices: what the unit-block body of the next push reads
   if (blockIdx.x == 0 && threadIdx.x == 0) c->fb_slot = level + 1;
   int found = 0;
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(BLOCK) void k_d2_or_maps(const uint4* __restrict__ 
 template <int NT>
 __global__ __launch_bounds__(NT) void k_d2_lists_apply(bfs_fused_args_t a, int level, const u32* __restrict__ glists, int nlists, u32 stride,
                                                        u32 cap, int* __restrict__ labels, int ranks, int rank, u64* host_flag, u64 seq,
-                                                       u32* own_bits, int own_list, u32* own_count) {
+                                                       u32* own_bits, int own_list, u32* own_count, int spec) {
   constexpr int NW = NT / WAVE;
   constexpr u64 CNT1 = 1ull << 40;
   constexpr u64 DEGMASK = CNT1 - 1ull;
@@ -296,6 +303,7 @@ __global__ __launch_bounds__(NT) void k_d2_lists_apply(bfs_fused_args_t a, int l
   __shared__ u64 s_base[2];
   __shared__ u32 s_long_true;
   bfs_ctrl_t* const c = a.ctrl;
+  if (bfs_d2_frozen(c, level)) return;
   if (threadIdx.x == 0) {
     u32 run = 0;
     int over = 0;
@@ -312,6 +320,11 @@ __global__ __launch_bounds__(NT) void k_d2_lists_apply(bfs_fused_args_t a, int l
   const u32 T = s_pre[nlists];
   const bool over = s_over != 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (level < 64) c->d2_level_kind[level] = over ? (unsigned char)2 : (unsigned char)1;
+    // a speculative plan (d2_run) sent this level through the lists and one overflowed: nothing of a later level may run until
+    // the host has sent this one through the bitmap exchange.  Every rank reads the same headers: all freeze at the same level.
+    // (The other workgroups of this launch pass bfs_d2_frozen either way: level > level is false.)
+    if (spec && over) c->d2_frozen_level = level;
     if (host_flag) {
       host_flag[1] = over ? 1ull : 0ull;
       host_flag[2] = (u64)T;
@@ -381,6 +394,11 @@ __global__ __launch_bounds__(NT) void k_d2_lists_apply(bfs_fused_args_t a, int l
     }
     __syncthreads();           // s_base / s_long_true are reused by the next round
   }
+}
+
+// end of a freeze (one thread; enqueued by the host in front of the frozen level's bitmap exchange)
+__global__ void k_d2_unfreeze(bfs_ctrl_t* c) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) c->d2_frozen_level = -1;
 }
 
 // unit owners as the builder numbers them (local rows; n_local for padding units) -> global ids (n_global for padding)
@@ -491,6 +509,7 @@ struct d2_state_t {
   int fused_merge = 1;                // OR-merge inside the queue build (MGX_DIST_FUSED_MERGE)
   int build_list = 0;                 // the list-based queue build (MGX_DIST_BUILD_LIST)
   int push_split = 0;                 // measurements: the push grid's three parts as three launches (MGX_DIST_PUSH_SPLIT)
+  bool skip_small_reduce = false;     // d2_run's plan: no k_d2_cold_reduce launch on the levels it expects to be merged from id lists
   mem_t<u32> defer_buf;               // deferred hot marks of the push workgroups (bfs_hot_epilogue): BFS_FLUSH_MAX bitmaps; empty: nothing is deferred (MGX_DIST_DEFER=0)
   // ... and only on a shard big enough to pay for the 80 KB bitmap every deferring workgroup writes and the reduce behind it:
   // RMAT-25 / 8 (134 M entries per rank) 551 against 578 us of kernels per traversal with them, RMAT-22 / 8 (17 M) 264 against 225
@@ -638,7 +657,7 @@ inline void d2_reset(d2_state_t& st, int src, standard_context_t& ctx) {
 }
 
 // level kernels on the local queues (marks), then new_bits = marks & ~bitmap
-inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx) {
+inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx, bool want_list = true) {
   hipStream_t s = ctx.stream();
   bfs_fused_args_t a = st.args();
   bfs_set_kernel_attributes();
@@ -648,9 +667,15 @@ inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx) {
     bfs_launch_push(a, level, ctx, 0 | ((1 | 2) << 4), bfs_cold_test(a.n, st.cold_forced));
   } else
   bfs_launch_push(a, level, ctx, 2, bfs_cold_test(a.n, st.cold_forced));   // (the level's bookkeeping rides on the push launch)
-  const d2_cold_view_t cv = st.cold_view();
+  d2_cold_view_t cv = st.cold_view();
   u32* const dbuf = a.flush_buf;
-  if ((cv.flush && cv.reduced) || dbuf) {
+  // The stream reduce of the cold pass's bitmaps in front of the sweep -- not on a level the plan expects to be sparse (want_list:
+  // its frontier is too small for the cold pass to run, and a launch that finds nothing to do still costs ~2.5 us; should the pass
+  // have run after all, the sweep ORs the slices' buffers itself, as it did before the reduce existed).  Deferred hot marks need
+  // the reduce whatever the level (the sweep reads their first buffer only).
+  const bool planned_small = want_list && st.skip_small_reduce && !dbuf;
+  if (planned_small) cv.reduced = 0;
+  if (((cv.flush && cv.reduced) || dbuf) && !planned_small) {
     d2_cold_view_t rv = cv;
     if (!(cv.flush && cv.reduced)) { rv.flush = nullptr; rv.slices = 0; }
     const size_t threads = (size_t)rv.slices * (BFS_COLD_WORDS / 4) + (dbuf ? (size_t)BFS_FLUSH_WORDS / 4 : 0);
@@ -658,26 +683,33 @@ inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx) {
                        (const bfs_ctrl_t*)a.ctrl, level, rv.flush ? const_cast<u32*>(st.cold_flush.data()) : nullptr, dbuf);
   }
   hipLaunchKernelGGL(k_d2_newbits, dim3(grid_for(st.nwords, D2_NEWBITS_NT, ctx.num_cus * 2)), dim3(D2_NEWBITS_NT), 0, s, st.fs->visited.data(),
-                     st.fs->mark.data(), st.newbits, st.nwords, (long long)st.n_global, a.ctrl, st.mylist, st.list_cap, cv, level,
+                     st.fs->mark.data(), st.newbits, st.nwords, (long long)st.n_global, a.ctrl, want_list ? st.mylist : (u32*)nullptr, st.list_cap, cv, level,
                      (const u32*)st.slot_marks.data(), st.declare_mul, (const u32*)dbuf, a.defer_words);
 }
 
 // The sparse merge of a level (k_d2_lists_apply) on `nlists` gathered lists, `stride_words` apart, and the host's wait for
 // its verdict: out3 = { 1 if some list overflowed (nothing was applied: exchange the bitmaps), sum of the counts (0: the
 // level found nothing on any rank), 0 }.  Synchronises with the kernel's first workgroup only (a spin on pinned memory).
-inline void d2_apply_lists(d2_state_t& st, int level, const u32* glists, int nlists, long long stride_words, standard_context_t& ctx,
-                           long long* out3) {
+// spec: the level is part of a speculative plan -- nobody waits for the verdict; an overflow freezes the traversal (k_d2_lists_apply)
+inline u64 d2_enqueue_apply_lists(d2_state_t& st, int level, const u32* glists, int nlists, long long stride_words, standard_context_t& ctx,
+                                  bool spec) {
   hipStream_t s = ctx.stream();
   bfs_fused_args_t a = st.args();
-  const u64 seq = ++st.flag_seq;
+  const u64 seq = spec ? 0ull : ++st.flag_seq;
   // (does the kernel read the rank's own buffer?  a one-rank run, or an in-place gather)
   const bool own_is_read = st.mylist && glists < st.mylist + st.list_words() && st.mylist < glists + (size_t)nlists * (size_t)stride_words;
   hipLaunchKernelGGL(k_d2_lists_apply<BLOCK>, dim3(256), dim3(BLOCK), 0, s, a, level, glists, nlists, (u32)stride_words, st.list_cap,
-                     st.labels.data(), st.ranks, st.rank, st.host_flag, seq, st.newbits, nlists == 1 ? 0 : st.rank,
-                     (st.mylist && !own_is_read) ? st.mylist : nullptr);
+                     st.labels.data(), st.ranks, st.rank, spec ? (u64*)nullptr : st.host_flag, seq, st.newbits, nlists == 1 ? 0 : st.rank,
+                     (st.mylist && !own_is_read) ? st.mylist : nullptr, spec ? 1 : 0);
   MGX_CHECK_LAUNCH("partitioned BFS: list merge launch");
   // the count of this rank's own list, for the next level's sweep: behind the kernel when the kernel reads that very list (see its header)
   if (st.mylist && own_is_read) MGX_HIP(hipMemsetAsync(st.mylist, 0, sizeof(u32), s));
+  return seq;
+}
+inline void d2_apply_lists(d2_state_t& st, int level, const u32* glists, int nlists, long long stride_words, standard_context_t& ctx,
+                           long long* out3) {
+  hipStream_t s = ctx.stream();
+  const u64 seq = d2_enqueue_apply_lists(st, level, glists, nlists, stride_words, ctx, false);
   volatile u64* const flag = st.host_flag;
   long long spins = 0;
   while (flag[0] != seq) {
@@ -705,7 +737,7 @@ inline void d2_merge(d2_state_t& st, int level, const u32* gathered, int maps, l
       (uintptr_t)gathered % 16 == 0 && stride_words % 4 == 0) {
     bfs_d2_fuse_t fz;
     fz.maps = gathered; fz.nmaps = maps; fz.stride = stride_words; fz.nwords = st.nwords;
-    fz.merged = st.merged.data(); fz.clear = st.newbits;
+    fz.merged = st.merged.data(); fz.clear = st.newbits; fz.list_head = st.mylist;
     const long long rw = R / 2;
     long long groups = ((long long)st.n_local + 15) / 16;
     if ((st.nwords + rw - 1) / rw > groups) groups = (st.nwords + rw - 1) / rw;      // (the grid covers the bitmap's words, not only the rank's rows)
@@ -716,6 +748,7 @@ inline void d2_merge(d2_state_t& st, int level, const u32* gathered, int maps, l
 #undef MGX_D2_FUSED
     return;
   }
+  if (st.mylist) MGX_HIP(hipMemsetAsync(st.mylist, 0, sizeof(u32), s));      // (the list's count, as the fused merge resets it)
   hipLaunchKernelGGL(k_d2_or, dim3(grid_for(st.nwords / 4, BLOCK, 1024)), dim3(BLOCK), 0, s, (const uint4*)gathered, maps,
                      stride_words / 4, st.nwords / 4, (uint4*)st.merged.data(), (uint4*)st.fs->visited.data(), a.ctrl, level, (uint4*)st.newbits);
   // the queue build without a list when the rank's row offsets allow its 16-byte loads (k_bfs_build2<., DIST>: labels and
@@ -759,6 +792,47 @@ struct d2_run_bufs_t {
   mem_t<u32> glists;       // ranks id lists (sparse levels)
   long long xwords = 0;
   int levels_hint = 8;
+  // The SPECULATIVE LEVEL PLAN of a traversal with id lists (d2_run): what the last traversals on this engine looked like, level
+  // by level -- how many levels, and which of them could have been merged from id lists (they were, or all ranks together
+  // discovered no more than ONE list holds).  Every rank derives the same history: the verdicts come from all-gathered headers
+  // and from counts every rank computes alike.
+  struct hist_t { int levels = 0; u64 sparse_ok = 0; };
+  hist_t hist[4];
+  int hist_n = 0;
+  int spec = 1;            // MGX_DIST_SPEC=0: one host look per level, as before round 5
+  // traversals of the engine (statistics): planned ahead, frozen by a list that overflowed against the plan, continued level by level
+  long long spec_runs = 0, spec_frozen = 0, spec_short = 0;
+  int last_plan_levels = 0;
+  u64 last_plan_sparse = 0;
+  d2_run_bufs_t() { if (const char* e = getenv("MGX_DIST_SPEC")) spec = atoi(e); }
+  void learn(const bfs_ctrl_t* hc, int levels, long long last_new, u32 list_cap) {
+    hist_t h;
+    h.levels = levels < 64 ? levels : 64;
+    for (int l = 0; l < h.levels; ++l) {
+      const int kind = hc->d2_level_kind[l];
+      // (the level merged last has no successor whose sweep recorded its count: the merge's own counter holds it)
+      const long long found = (l + 1 < levels || l >= 63) ? (long long)hc->d2_level_new[l] : last_new;
+      if (kind == 1 || (kind != 2 && found <= (long long)list_cap)) h.sparse_ok |= 1ull << l;
+    }
+    hist[hist_n & 3] = h;
+    ++hist_n;
+  }
+  // the plan: as many levels as the longest of the remembered traversals + the one that finds nothing; level l from id lists iff
+  // every remembered traversal that had a level l could have merged it from lists (levels nobody had: lists)
+  bool plan(int* levels, u64* sparse) const {
+    if (!spec || hist_n == 0) return false;
+    int L = 0;
+    u64 sp = ~0ull;
+    for (int i = 0; i < 4 && i < hist_n; ++i) {
+      const hist_t& h = hist[i];
+      if (h.levels > L) L = h.levels;
+      const u64 have = h.levels >= 64 ? ~0ull : ((1ull << h.levels) - 1ull);
+      sp &= ~have | h.sparse_ok;
+    }
+    *levels = L + 1;
+    *sparse = sp;
+    return true;
+  }
 };
 
 // the bitmap exchange of one level + the dense merge (what every level did before the id lists)
@@ -807,25 +881,71 @@ inline void d2_run(d2_state_t& st, comm_t& cm, d2_run_bufs_t& bufs, int src, int
   d2_reset(st, src, ctx);
   int level = 0;
   if (st.mylist) {
-    // One level per round: id lists first; the bitmaps only when some rank's discoveries did not fit its list.  The host
-    // looks at three words per level (d2_apply_lists) -- that is also how it learns that the traversal is over.
-    for (;;) {
-      d2_push(st, level, ctx);
-      const u32* lists = st.mylist;
-      int nl = 1;
+    // the lists of a level, all-gathered (a one-rank run without a communicator reads its own)
+    auto gather_lists = [&](const u32** lists, int* nl) {
+      *lists = st.mylist; *nl = 1;
       if (R > 1 || cm.comm) {
         MGX_RCCL(api.AllGather(st.mylist, bufs.glists.data(), (size_t)st.list_words(), ncclUint32, cm.comm, s));
-        lists = bufs.glists.data();
-        nl = R;
+        *lists = bufs.glists.data(); *nl = R;
       }
+    };
+    // ---- a whole traversal enqueued ahead, from what the last ones looked like (d2_run_bufs_t::plan): per level the push and
+    // EITHER the lists (all-gather + merge) OR the bitmaps (exchange + merge) -- no host look in between.  Right whatever the
+    // traversal does: bitmaps are always right; a list that overflows against the plan freezes the traversal at that level
+    // (k_d2_lists_apply) and everything enqueued behind it returns at once; levels past the end find nothing.
+    bool over = false;
+    int plan_levels = 0;
+    u64 plan_sparse = 0;
+    if (bufs.plan(&plan_levels, &plan_sparse)) {
+      bufs.spec_runs += 1;
+      bufs.last_plan_levels = plan_levels; bufs.last_plan_sparse = plan_sparse;
+      for (; level < plan_levels; ++level) {
+        const bool sparse = level >= 64 || ((plan_sparse >> level) & 1ull);
+        st.skip_small_reduce = sparse;
+        d2_push(st, level, ctx, sparse);
+        st.skip_small_reduce = false;
+        if (sparse) {
+          const u32* lists; int nl;
+          gather_lists(&lists, &nl);
+          (void)d2_enqueue_apply_lists(st, level, lists, nl, st.list_words(), ctx, true);
+        } else {
+          d2_exchange_bitmaps(st, cm, bufs, level, exchange, xwords, ctx);
+        }
+      }
+      MGX_CHECK_LAUNCH("partitioned BFS: kernel launch");
+      d2_status(st, level, ctx, out6);                    // (the one wait of a traversal that went as planned)
+      const int frozen = st.fs->host_ctrl->d2_frozen_level;
+      if (frozen >= 0) {
+        // level `frozen` did not fit its lists: nothing of it was applied and nothing behind it ran.  Its new-bit map is intact:
+        // the bitmaps now, then level by level with a look at each (the loop below)
+        bufs.spec_frozen += 1;
+        hipLaunchKernelGGL(k_d2_unfreeze, dim3(1), dim3(64), 0, s, st.args().ctrl);
+        d2_exchange_bitmaps(st, cm, bufs, frozen, exchange, xwords, ctx);
+        level = frozen + 1;
+      } else if (out6[0]) {
+        over = true;
+      } else {
+        bufs.spec_short += 1;                             // (a deeper traversal than any remembered: on, level by level)
+      }
+    }
+    // ---- one level per round: id lists first; the bitmaps only when some rank's discoveries did not fit its list.  The host
+    // looks at three words per level (d2_apply_lists) -- that is also how it learns that the traversal is over.  The first
+    // traversal of an engine, MGX_DIST_SPEC=0, and what a plan left undone.
+    while (!over) {
+      d2_push(st, level, ctx);
+      const u32* lists; int nl;
+      gather_lists(&lists, &nl);
       long long o3[3];
       d2_apply_lists(st, level, lists, nl, st.list_words(), ctx, o3);
       if (o3[1] == 0) { ++level; break; }                   // nothing discovered on any rank: over
       if (o3[0]) d2_exchange_bitmaps(st, cm, bufs, level, exchange, xwords, ctx);
       ++level;
     }
-    MGX_CHECK_LAUNCH("partitioned BFS: kernel launch");
-    d2_status(st, level, ctx, out6);
+    if (!over) {
+      MGX_CHECK_LAUNCH("partitioned BFS: kernel launch");
+      d2_status(st, level, ctx, out6);
+    }
+    bufs.learn(st.fs->host_ctrl, (int)out6[1], out6[3], st.list_cap);
     return;
   }
   int batch = bufs.levels_hint;
@@ -840,6 +960,93 @@ inline void d2_run(d2_state_t& st, comm_t& cm, d2_run_bufs_t& bufs, int src, int
     batch = 2;
   }
   bufs.levels_hint = (int)(out6[1] > 0 ? out6[1] + 1 : 1);      // + the level that finds nothing
+}
+
+// ---- G rank engines of ONE partition on one device, driven in turn by one host thread ("group run") -------------------------
+// What a rank's GPU does per traversal, measured without a second GPU: the engines share the stream, every collective is the G
+// device copies that put the ranks' buffers side by side (ONE gathered buffer serves all engines: they are on the same device),
+// and the level plan, the freeze and the level-by-level continuation are d2_run's.  Wall time / G = kernels + launch gaps of one
+// rank per traversal, with no exchange time and no time of the other ranks in it -- tools/dist2_single.py's number without the
+// interpreter between the launches.  Exchange 0 (all-gather) only; every engine needs an id list or none does.
+struct d2_group_bufs_t {
+  mem_t<u32> gathered, glists;
+  long long xwords = 0;
+};
+inline void d2_group_run(d2_state_t** sts, d2_run_bufs_t** bufs, d2_group_bufs_t& gb, int G, int src, long long xwords,
+                         standard_context_t& ctx, long long* out6 /* G x 6 */) {
+  hipStream_t s = ctx.stream();
+  d2_state_t& s0 = *sts[0];
+  const bool lists = s0.mylist != nullptr;
+  const long long lw = lists ? s0.list_words() : 0;
+  if (gb.xwords != xwords || !gb.gathered.size()) {
+    ctx.synchronize();
+    gb.gathered = mem_t<u32>((size_t)G * (size_t)xwords + 4, ctx);
+    gb.glists = mem_t<u32>((size_t)G * (size_t)(lw > 0 ? lw : 4) + 4, ctx);
+    gb.xwords = xwords;
+  }
+  for (int r = 0; r < G; ++r) d2_reset(*sts[r], src, ctx);
+  auto gather_lists = [&]() {
+    for (int r = 0; r < G; ++r)
+      MGX_HIP(hipMemcpyAsync(gb.glists.data() + (size_t)r * lw, sts[r]->mylist, (size_t)lw * sizeof(u32), hipMemcpyDeviceToDevice, s));
+  };
+  auto bitmaps = [&](int level) {
+    for (int r = 0; r < G; ++r)
+      MGX_HIP(hipMemcpyAsync(gb.gathered.data() + (size_t)r * xwords, sts[r]->newbits, (size_t)xwords * sizeof(u32), hipMemcpyDeviceToDevice, s));
+    for (int r = 0; r < G; ++r) d2_merge(*sts[r], level, gb.gathered.data(), G, xwords, ctx);
+  };
+  int level = 0;
+  bool over = false;
+  if (lists) {
+    int plan_levels = 0;
+    u64 plan_sparse = 0;
+    if (bufs[0]->plan(&plan_levels, &plan_sparse)) {
+      for (int r = 0; r < G; ++r) { bufs[r]->spec_runs += 1; bufs[r]->last_plan_levels = plan_levels; bufs[r]->last_plan_sparse = plan_sparse; }
+      for (; level < plan_levels; ++level) {
+        const bool sparse = level >= 64 || ((plan_sparse >> level) & 1ull);
+        for (int r = 0; r < G; ++r) { sts[r]->skip_small_reduce = sparse; d2_push(*sts[r], level, ctx, sparse); sts[r]->skip_small_reduce = false; }
+        if (sparse) {
+          gather_lists();
+          for (int r = 0; r < G; ++r) (void)d2_enqueue_apply_lists(*sts[r], level, gb.glists.data(), G, lw, ctx, true);
+        } else bitmaps(level);
+      }
+      MGX_CHECK_LAUNCH("partitioned BFS (group): kernel launch");
+      for (int r = 0; r < G; ++r) d2_status(*sts[r], level, ctx, out6 + 6 * r);
+      const int frozen = s0.fs->host_ctrl->d2_frozen_level;
+      if (frozen >= 0) {
+        for (int r = 0; r < G; ++r) { bufs[r]->spec_frozen += 1; hipLaunchKernelGGL(k_d2_unfreeze, dim3(1), dim3(64), 0, s, sts[r]->args().ctrl); }
+        bitmaps(frozen);
+        level = frozen + 1;
+      } else if (out6[0]) over = true;
+      else for (int r = 0; r < G; ++r) bufs[r]->spec_short += 1;
+    }
+    while (!over) {
+      for (int r = 0; r < G; ++r) d2_push(*sts[r], level, ctx);
+      gather_lists();
+      long long o3[3] = {0, 0, 0};
+      for (int r = 0; r < G; ++r) d2_apply_lists(*sts[r], level, gb.glists.data(), G, lw, ctx, o3);
+      if (o3[1] == 0) { ++level; break; }
+      if (o3[0]) bitmaps(level);
+      ++level;
+    }
+    if (!over) {
+      MGX_CHECK_LAUNCH("partitioned BFS (group): kernel launch");
+      for (int r = 0; r < G; ++r) d2_status(*sts[r], level, ctx, out6 + 6 * r);
+    }
+    for (int r = 0; r < G; ++r) bufs[r]->learn(sts[r]->fs->host_ctrl, (int)out6[6 * r + 1], out6[6 * r + 3], sts[r]->list_cap);
+    return;
+  }
+  int batch = bufs[0]->levels_hint;
+  for (;;) {
+    for (int i = 0; i < batch; ++i, ++level) {
+      for (int r = 0; r < G; ++r) d2_push(*sts[r], level, ctx);
+      bitmaps(level);
+    }
+    MGX_CHECK_LAUNCH("partitioned BFS (group): kernel launch");
+    for (int r = 0; r < G; ++r) d2_status(*sts[r], level, ctx, out6 + 6 * r);
+    if (out6[0]) break;
+    batch = 2;
+  }
+  for (int r = 0; r < G; ++r) bufs[r]->levels_hint = (int)(out6[1] > 0 ? out6[1] + 1 : 1);
 }
 
 }  // namespace mgx

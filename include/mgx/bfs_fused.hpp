@@ -109,6 +109,14 @@ struct bfs_ctrl_t {
   int mini_slots;    // levels expanded by M launches (bfs_fused_mini.hpp)
   u32 mini_blocks[4];   // workgroups of the M launch of slot s & 3 that are through (a forwarding launch's last one moves the flags)
   u64 reached_mini;  // vertices labelled by M launches: NOT in `reached` (which must not change while such a launch decides)
+  // Partitioned runs with a SPECULATIVE level plan (bfs_dist2.hpp: d2_run enqueues a whole traversal, lists or bitmaps per level
+  // as the last traversals went, and looks once): a level that was planned for id lists but overflowed one FREEZES the
+  // traversal -- every kernel of a later level returns at once (bfs_d2_frozen) -- until the host has sent the level through the
+  // bitmap exchange.  d2_level_kind[L]: 1 merged from id lists, 2 its lists overflowed, 0 bitmaps without asking (or not run);
+  // d2_level_new[L]: vertices all ranks discovered in level L (what the next plan is made from).
+  int d2_frozen_level;           // -1: not frozen
+  unsigned char d2_level_kind[64];
+  u32 d2_level_new[64];
   u64 stamp[64];     // s_memrealtime (100 MHz) when each level was opened: per-level times without host syncs
   u64 trace[BFS_MAX_TRACE];   // (vertices << 38 | edges) of each level, both queues (kept LAST: read back up to `levels`)
 };
@@ -283,6 +291,9 @@ __device__ __forceinline__ void bfs_ctrl_reset(bfs_ctrl_t* c) {
   c->mini_slots = 0;
   for (int i = 0; i < 4; ++i) c->mini_blocks[i] = 0u;
   c->reached_mini = 0;
+  c->d2_frozen_level = -1;
+  for (int i = 0; i < 16; ++i) ((u32*)c->d2_level_kind)[i] = 0u;
+  for (int i = 0; i < 64; ++i) c->d2_level_new[i] = 0u;
   c->sssp_thr = 0x7f7fffffu;
   c->sssp_far_cnt[0] = c->sssp_far_cnt[1] = 0;
   c->sssp_far_min[0] = c->sssp_far_min[1] = 0x7f7fffffu;
@@ -412,6 +423,12 @@ __global__ void k_bfs_level_begin(bfs_fused_args_t a, int level, int partitioned
   bfs_begin_level(a, level, partitioned);
 }
 
+// a rank's traversal is frozen below `level` (see bfs_ctrl_t::d2_frozen_level): grid-uniform, nothing of a later level may run
+__device__ __forceinline__ bool bfs_d2_frozen(const bfs_ctrl_t* c, int level) {
+  const int f = c->d2_frozen_level;
+  return f >= 0 && level > f;
+}
+
 // Kernel argument `arg` of the level kernels: >= 0 is an explicit level (the partitioned path: the host counts the
 // levels, slot == level); -1 - s is launch slot s of the slot scheme, whose level is ctrl->slot_level[s & 3].
 __device__ __forceinline__ void bfs_resolve(const bfs_ctrl_t* c, int arg, int& slot, int& level) {
@@ -539,6 +556,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 4) void k_bfs_build(bfs_fused_a
   int slot, level;
   bfs_resolve(c, arg, slot, level);
   if (stop_when_done && c->done) return;        // (a rank of a partitioned run may be handed work with an empty frontier)
+  if (!FROM_MARKS && bfs_d2_frozen(c, level)) return;
   if (arg < 0 && c->skip_build[slot & 3]) return;   // the push launch of this slot ran its level(s) itself
   if (FROM_MARKS && blockIdx.x == 0 && threadIdx.x == 0) c->fb_slot = slot + 1;   // frontier_bits: written in full below
   // first of this thread's 16 vertices: run (blockIdx + k * gridDim) of 1024 vertices, k = the thread's wave
@@ -741,6 +759,7 @@ struct bfs_d2_fuse_t {
   long long nwords = 0;        // words of a map (a multiple of 4)
   u32* merged = nullptr;
   u32* clear = nullptr;        // the rank's own map (may be one of `maps`: a thread clears what it has read); NULL: none
+  u32* list_head = nullptr;    // the rank's id list (its count is reset: nobody reads the list in a level merged from bitmaps); NULL: none
 };
 template <int NT, int DIST = 0, int RANKS = 1>
 __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int arg, int* __restrict__ labels, int n,
@@ -757,6 +776,9 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
   int slot, level;
   bfs_resolve(c, arg, slot, level);
   if (!DIST && (c->done || c->skip_build[slot & 3])) return;      // (a rank of a partitioned run may be handed work behind an empty frontier of its own)
+  if (DIST && bfs_d2_frozen(c, level)) return;
+  // (a level merged from bitmaps: the header of the rank's id list goes back to zero for the next level -- its push may append)
+  if (DIST == 2 && fz.list_head && blockIdx.x == 0 && threadIdx.x == 0) fz.list_head[0] = 0u;
   // (direction-optimising runs: once the traversal has switched to bottom-up levels it stays there, and those read the
   //  frontier bitmap: no queue is ever needed again)
   const bool lazy = !DIST && (bfs_build_is_lazy(a, slot) || (a.lazy_pull && c->pull));

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push_level(bfs_fused_args_t a, 
   // (it clears the entry two levels ahead only).
   // (measurements, MGX_DIST_PUSH_SPLIT=1: the three parts of the grid as three launches -- bits 4 / 5 / 6 of open_here switch the
   //  cold pass / the long rows / the short rows of THIS launch off; the level's bookkeeping rides on the first)
+  if (bfs_d2_frozen(a.ctrl, level)) return;        // (a speculative plan ran past a level that has to wait for the host: bfs_dist2.hpp)
   const int skip = open_here >> 4;
   open_here &= 15;
   const bool appends = bfs_d2_level_appends(a, level);

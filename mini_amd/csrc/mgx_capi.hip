@@ -80,6 +80,7 @@ struct mgx_dbfs2_s {
   mgx_ctx_s* c;
   mgx::d2_state_t st;
   mgx::d2_run_bufs_t run_bufs;
+  mgx::d2_group_bufs_t group_bufs;     // (rank 0's handle holds the group run's shared buffers: mgx_dbfs2_run_group)
 };
 struct mgx_comm_s {
   mgx_ctx_s* c;
@@ -1805,6 +1806,34 @@ int mgx_dbfs2_run(mgx_dbfs2_t h, mgx_comm_t comm, int src_global, int exchange, 
   long long o[6];
   mgx::d2_run(h->st, comm ? comm->cm : none, h->run_bufs, src_global, exchange, (long long)exchange_words, *h->c->ctx, o);
   for (int i = 0; i < 6; ++i) out6[i] = o[i];
+  MGX_CATCH
+}
+int mgx_dbfs2_spec_stats(mgx_dbfs2_t h, int64_t* out5) {
+  MGX_TRY
+  MGX_REQUIRE(h && out5, "NULL argument");
+  out5[0] = h->run_bufs.spec_runs; out5[1] = h->run_bufs.spec_frozen; out5[2] = h->run_bufs.spec_short;
+  out5[3] = h->run_bufs.last_plan_levels; out5[4] = (int64_t)h->run_bufs.last_plan_sparse;
+  MGX_CATCH
+}
+int mgx_dbfs2_run_group(mgx_dbfs2_t* hs, int count, int src_global, int64_t exchange_words, int64_t* out6_each) {
+  MGX_TRY
+  MGX_REQUIRE(hs && out6_each && count >= 1 && count <= 64, "mgx_dbfs2_run_group: 1..64 engines");
+  mgx_dbfs2_t h0 = hs[0];
+  MGX_REQUIRE(h0 && count == h0->st.ranks, "mgx_dbfs2_run_group: one engine per rank of the partition");
+  MGX_REQUIRE(src_global >= 0 && src_global < h0->st.n_global, "mgx_dbfs2_run_group: bad source");
+  MGX_REQUIRE(exchange_words >= h0->st.nwords && exchange_words % 4 == 0, "mgx_dbfs2_run_group: exchange_words must cover the bitmap");
+  std::vector<mgx::d2_state_t*> sts((size_t)count);
+  std::vector<mgx::d2_run_bufs_t*> bufs((size_t)count);
+  for (int r = 0; r < count; ++r) {
+    MGX_REQUIRE(hs[r] && hs[r]->c == h0->c && hs[r]->st.ranks == count && hs[r]->st.rank == r && hs[r]->st.n_global == h0->st.n_global &&
+                (hs[r]->st.mylist != nullptr) == (h0->st.mylist != nullptr),
+                "mgx_dbfs2_run_group: the engines must be ranks 0 .. count - 1 of one partition, on one context, all with or all without id lists");
+    sts[(size_t)r] = &hs[r]->st; bufs[(size_t)r] = &hs[r]->run_bufs;
+  }
+  use_device(h0->c);
+  std::vector<long long> o((size_t)count * 6, 0);
+  mgx::d2_group_run(sts.data(), bufs.data(), h0->group_bufs, count, src_global, (long long)exchange_words, *h0->c->ctx, o.data());
+  for (size_t i = 0; i < o.size(); ++i) out6_each[i] = o[i];
   MGX_CATCH
 }
 int mgx_dbfs2_words(int n_global, int64_t* words) {

@@ -267,6 +267,22 @@ class HipRankEngine2:
                                 int(self.newbits.numel()), o))
         return {"over": bool(o[0]), "levels": o[1], "edges_local": o[2], "new_global": o[3]}
 
+    def spec_stats(self):
+        """(traversals planned ahead, frozen by a list that overflowed against the plan, longer than planned, levels of the last
+        plan, its lists-mask) -- mgx_dbfs2_spec_stats"""
+        o = (C.c_int64 * 5)()
+        check(lib.mgx_dbfs2_spec_stats(self._h, o))
+        return tuple(int(v) for v in o)
+
+    @staticmethod
+    def run_group(engines, src):
+        """all ranks' engines (made on ONE context) in turn from this thread, collectives as device copies (mgx_dbfs2_run_group)"""
+        G = len(engines)
+        hs = (C.c_void_p * G)(*[e._h for e in engines])
+        o = (C.c_int64 * (6 * G))()
+        check(lib.mgx_dbfs2_run_group(hs, G, int(src), int(engines[0].newbits.numel()), o))
+        return [{"over": bool(o[6 * r]), "levels": o[6 * r + 1], "edges_local": o[6 * r + 2], "new_global": o[6 * r + 3]} for r in range(G)]
+
     def labels(self):
         out = np.empty(self.n_local, dtype=np.int32)
         check(lib.mgx_dbfs2_labels(self._h, out.ctypes.data_as(C.c_void_p)))

@@ -94,11 +94,14 @@ def test_native_bfs_loop_over_loopback_world(gpu_ctx, oracle, torch_gpu, scale, 
     cand = np.nonzero(deg > 0)[0]
     # the biggest hub (a list overflows at level 1), a middling vertex, a leaf (sparse levels at both ends), and a vertex of
     # degree 0 if there is one (a traversal of one level: every rank's frontier but the owner's is empty from the start)
-    srcs = [int(cand[0]), int(cand[len(cand) // 2]), int(cand[-1])]
+    # Order: the first traversal of an engine looks once per level and leaves the level plan; the leaf's plan (lists at the first
+    # levels) then meets the hub, whose neighbourhood overflows a list against it -- the traversal freezes and is continued --, and
+    # the hub's plan (bitmaps early) meets the leaf again.
+    srcs = [int(cand[-1]), int(cand[0]), int(cand[len(cand) // 2]), int(cand[-1]), int(cand[0])]
     iso = np.nonzero(deg == 0)[0]
     if len(iso):
         srcs.append(int(iso[0]))
-    g, single = _single_gpu_labels(gpu_ctx, scale, scale, [int(o2n[s]) for s in srcs])
+    g, single = _single_gpu_labels(gpu_ctx, scale, scale, sorted({int(o2n[s]) for s in srcs}))
     ro_h, ci_h = g["row_offsets"].cpu().numpy(), g["col_indices"].cpu().numpy()
     ident = LoopbackComm.new_id()
     comms = run_rank_threads(G, lambda r: LoopbackComm(ctxs[r], r, G, ident))
@@ -124,6 +127,10 @@ def test_native_bfs_loop_over_loopback_world(gpu_ctx, oracle, torch_gpu, scale, 
         # sparse levels were merged from id lists AND some level overflowed its list (the hub's neighbourhood): both protocols ran
         paths = [e.path_levels() for e in engs]
         assert all(p[0] >= 1 for p in paths), paths
+        # every traversal but the first was enqueued ahead from the level plan, on every rank alike; the hub behind the leaf froze
+        stats = [e.spec_stats() for e in engs]
+        assert len(set(stats)) == 1, stats
+        assert stats[0][0] == len(srcs) - 1 and stats[0][1] >= 1, stats
     for c in comms:
         c.close()
     for e in engs:
@@ -185,6 +192,48 @@ def test_loopback_collectives_move_the_right_bytes(gpu_ctx, torch_gpu):
         assert np.array_equal(a2a[r].cpu().numpy(), want)
     for c in comms:
         c.close()
+
+
+@pytest.mark.parametrize("scale,G,lists,spec", [(17, 4, True, "1"), (17, 4, True, "0"), (18, 8, True, "1"), (16, 2, False, "1"), (15, 3, True, "1")])
+def test_group_run_in_turn_equals_single_gpu(gpu_ctx, torch_gpu, scale, G, lists, spec):
+    """mgx_dbfs2_run_group: all ranks' engines on one context, one host thread, collectives as copies, the level plan of
+    mgx_dbfs2_run (the measurement entry of tools/dist2_single.py native): labels equal to the single-GPU traversal"""
+    torch = torch_gpu
+    from mini_amd.dist_bfs import HipRankEngine2, rmat_cyclic_shard
+    dev = torch.device("cuda", 0)
+    old = {k: os.environ.get(k) for k in ("MGX_DIST_LISTS", "MGX_DIST_SPEC")}
+    os.environ["MGX_DIST_LISTS"] = "1" if lists else "0"
+    os.environ["MGX_DIST_SPEC"] = spec
+    try:
+        engs = []
+        for r in range(G):
+            ro, col, new_of_old, old_of_new, deg_new = rmat_cyclic_shard(gpu_ctx, scale, 16, scale, G, r, dev)
+            engs.append(HipRankEngine2(gpu_ctx, 1 << scale, G, r, ro, col))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    n = 1 << scale
+    n2o, o2n = new_of_old.cpu().numpy(), old_of_new.cpu().numpy()
+    deg = deg_new.cpu().numpy()
+    cand = np.nonzero(deg > 0)[0]
+    srcs = [int(cand[-1]), int(cand[0]), int(cand[len(cand) // 3]), int(cand[-2]), int(cand[1])]
+    g, single = _single_gpu_labels(gpu_ctx, scale, scale, sorted({int(o2n[s]) for s in srcs}))
+    for src in srcs:
+        sts = HipRankEngine2.run_group(engs, src)
+        assert all(st["over"] for st in sts) and len({st["levels"] for st in sts}) == 1, sts
+        lab_new = _gathered(engs, n)
+        assert np.array_equal(lab_new[n2o], single[int(o2n[src])]), "labels differ from the single-GPU traversal (source %d)" % src
+        assert sum(st["edges_local"] for st in sts) == int(deg[lab_new >= 0].sum())
+    if lists:
+        stats = engs[0].spec_stats()
+        assert stats[0] == (len(srcs) - 1 if spec == "1" else 0), stats
+        if spec == "1":
+            assert stats[1] >= 1, stats               # the hub behind the leaf
+    for e in engs:
+        e.close()
 
 
 @pytest.mark.parametrize("scale,G", [(12, 2), (13, 4), (14, 8), (12, 3)])

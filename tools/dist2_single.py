@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Generation-2 partitioned BFS on ONE GPU: G rank engines share the device and run one after another
 (the all-gather becomes a concatenation), so the time per rank = total / G is what each GPU of a G-GPU
-job would spend in kernels per BFS (no xGMI time).  usage: dist2_single.py [scale] [G] [lists|gather|reduce]
+job would spend in kernels per BFS (no xGMI time).  usage: dist2_single.py [scale] [G] [native|lists|gather|reduce]
+native: the C++ loop itself (mgx_dbfs2_run_group: the engines in turn from one host thread, the collectives as device copies, the
+level plan of mgx_dbfs2_run -- a whole traversal enqueued ahead, one host wait): wall time / G = kernels and launch gaps of one
+rank per traversal, no interpreter between the launches;
 lists (default): the level protocol of mgx_dbfs2_run / DistBfs2.run -- id lists first (the all-gather a concatenation, every
 engine's list merge with its host round trip), the bitmaps only when some rank's list overflowed;
 gather: bitmaps on every level; reduce: the slice exchange of DistBfs2 (all-to-all of slices -> OR -> all-gather of merged
@@ -32,10 +35,14 @@ srcs = [int(v) for v in torch.nonzero(deg_new > 0)[:: max(1, n // 64)][:6, 0].to
 hint = 8
 for it, s in enumerate(srcs):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for e in engs:
-        e.reset(s)
+    if mode != "native":
+        for e in engs:
+            e.reset(s)
     level, batch = 0, hint
     sparse = dense = 0
+    if mode == "native":
+        sts = HipRankEngine2.run_group(engs, s)
+        level = sts[0]["levels"]
     while mode == "lists":
         maps = [e.push(level) for e in engs]
         glists = torch.cat([e.list for e in engs]) if G > 1 else engs[0].list
@@ -50,7 +57,7 @@ for it, s in enumerate(srcs):
             dense += 1
         else:
             sparse += 1
-    while mode != "lists":
+    while mode not in ("lists", "native"):
         for _ in range(batch):
             if mode == "reduce" and G > 1:
                 maps = [e.push(level) for e in engs]
@@ -96,4 +103,5 @@ for it, s in enumerate(srcs):
             assert same
         print(mode + " src %d levels %d edges %d  total %.3f ms  per-rank %.3f ms  -> %.1f GTEPS aggregate (no exchange time); levels read from unit blocks on rank 0: %d"
               % (s, sts[0]["levels"], edges, dt * 1e3, dt * 1e3 / G, edges / (dt / G) / 1e9, engs[0].dense_levels())
-              + (" (levels merged from lists %d, from bitmaps %d)" % (sparse, dense) if mode == "lists" else ""))
+              + (" (levels merged from lists %d, from bitmaps %d)" % (sparse, dense) if mode == "lists" else "")
+              + (" (plan: %r)" % (engs[0].spec_stats(),) if mode == "native" else ""))
