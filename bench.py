@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--no-layout", action="store_true", help="keep generator vertex ids (no hub-first relabelling)")
     ap.add_argument("--pmc-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     # the reference's driver flags (tests/bfs/test_bfs.cu:14-31)
+    ap.add_argument("--graph", choices=["rmat", "uniform", "grid2d"], default="rmat",
+                    help="synthetic input: rmat (BASELINE's), uniform = edgefactor * 2^scale uniformly random pairs, symmetrised (no hubs), "
+                         "grid2d = a 2^(scale/2) x 2^(scale/2) 4-neighbour grid (thousands of levels); built on the device, seeded")
     ap.add_argument("--file", default=None, help="MatrixMarket file instead of the synthetic R-MAT")
     ap.add_argument("--undirected", action="store_true", help="--file: append the swapped copy of every entry")
     ap.add_argument("--src", type=int, default=None, help="source vertex (default: seeded sources; --file: 0)")
@@ -259,12 +262,19 @@ def bench_bfs(args, ctx, stream):
         m = len(ci_host)
         what = "%s%s" % (os.path.basename(args.file), " (undirected)" if args.undirected else "")
     else:
-        g = rmat.rmat_csr(ctx, args.scale, args.edgefactor, seed=seed, weighted=False)
+        if args.graph == "uniform":
+            g = rmat.uniform_csr(ctx, args.scale, args.edgefactor, seed=seed)
+            what = "uniform random graph, scale %d ef %d (2^%d vertices, %d x 2^%d random pairs), symmetrised" % (args.scale, args.edgefactor, args.scale, args.edgefactor, args.scale)
+        elif args.graph == "grid2d":
+            g = rmat.grid2d_csr(ctx, args.scale)
+            what = "2-d grid %d x %d, 4 neighbours" % (1 << (args.scale // 2), 1 << (args.scale - args.scale // 2))
+        else:
+            g = rmat.rmat_csr(ctx, args.scale, args.edgefactor, seed=seed, weighted=False)
+            what = "RMAT scale %d ef %d, symmetrised" % (args.scale, args.edgefactor)
         graph = mini_amd.Graph.from_device(ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"])
         ro_host = g["row_offsets"].cpu().numpy()
         ci_host = None
         n, m = g["n"], g["m"]
-        what = "RMAT scale %d ef %d, symmetrised" % (args.scale, args.edgefactor)
     t_build = time.time() - t_build
     t_layout = time.time()
     use_layout = not args.no_layout and not (args.mode == "do" and args.file and not args.undirected)
@@ -449,7 +459,8 @@ def bench_bfs(args, ctx, stream):
     submission = "one library call per source" if args.per_call else \
         ("the %d sources submitted as ONE batch (mgx_bfs_run_many: the traversals one after the other on the device, each complete before the "
          "next one's init kernel resets the state; the host waits once, at the end)" % len(timed))
-    out = {"metric": "MTEPS (million traversed edges/sec) BFS advance+filter, %s" % ("RMAT-%d" % args.scale if not args.file else os.path.basename(args.file)),
+    gname = {"rmat": "RMAT-%d", "uniform": "uniform-%d", "grid2d": "grid2d-%d"}[args.graph] % args.scale
+    out = {"metric": "MTEPS (million traversed edges/sec) BFS advance+filter, %s" % (gname if not args.file else os.path.basename(args.file)),
            "value": round(value, 2), "unit": "MTEPS", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 4), "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic" if not args.file else "file",
@@ -459,6 +470,7 @@ def bench_bfs(args, ctx, stream):
                                      what, n, m, args.steps, "seeded sources" if args.src is None and not args.file else "runs from source %d" % sources[0],
                                      submission),
                       "scale": args.scale if not args.file else None, "edgefactor": args.edgefactor if not args.file else None,
+                      "graph": args.graph if not args.file else "file",
                       "seed": seed, "parallelism": "1 GPU", "submission": "per_call" if args.per_call else "batch",
                       "layout": "hub-first (degree-sorted) copy + unit blocks for the fused kernel" if use_layout else "generator ids"},
            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity,

@@ -426,7 +426,13 @@ MGX_API int mgx_sssp_create(mgx_graph_t g, int src, mgx_sssp_t* out);     /* sss
 MGX_API int mgx_sssp_reset(mgx_sssp_t p, int src);
 MGX_API int mgx_sssp_free(mgx_sssp_t p);
 MGX_API int mgx_sssp_distances(mgx_sssp_t p, float* host_dist);           /* extract() :54-57       */
+/* After mgx_sssp_enact: the functor's preds (sssp_functor.hxx:31-34; racy as the reference's).  After mgx_sssp_run (the fused loop
+ * keeps none): a shortest-path TREE built from the final distances the first time it is asked for (include/mgx/sssp_preds.hpp) --
+ * pred[v] = the largest u with a tight edge u -> v from a strictly nearer vertex; equal-distance ties (zero weights) are resolved in
+ * rounds so that no cycle can form; pred[source] = pred[unreached] = -1.  mgx_sssp_build_preds builds them without copying:
+ * stats2 = { equal-distance tight edges found, rounds }. */
 MGX_API int mgx_sssp_preds(mgx_sssp_t p, int* host_preds);
+MGX_API int mgx_sssp_build_preds(mgx_sssp_t p, int64_t* stats2);
 MGX_API int mgx_sssp_distances_device(mgx_sssp_t p, float** d_dist);
 /* advance_forward_kernel<sssp_problem_t,sssp_functor_t,false,true> (sssp_enactor.hxx:49-54) */
 MGX_API int mgx_sssp_advance(mgx_sssp_t p, mgx_frontier_t in, mgx_frontier_t out, int iteration, int64_t* front);

@@ -134,6 +134,7 @@ SIGNATURES = {
     "mgx_comm_library": [],
     "mgx_comm_available": [],
     "mgx_comm_loopback_id": [_vp],
+    "mgx_sssp_build_preds": [_vp, _pi64],
     "mgx_dbfs2_spec_stats": [_vp, _pi64],
     "mgx_dbfs2_run_group": [_vp, _i, _i, _i64, _pi64],
     "mgx_comm_info": [_vp, _vp, _vp],

@@ -445,9 +445,16 @@ class SsspProblem:
         return out
 
     def preds(self):
+        """after enact(): the functor's preds; after run(): a shortest-path tree built from the distances (mgx/sssp_preds.hpp)"""
         out = np.empty(self.graph.num_nodes, dtype=np.int32)
         check(lib.mgx_sssp_preds(self._h, _ptr(out)))
         return out
+
+    def build_preds(self):
+        """builds the predecessors of the last run()'s distances on the device (no copy) -> {ties, rounds}"""
+        st = (C.c_int64 * 2)()
+        check(lib.mgx_sssp_build_preds(self._h, st))
+        return {"ties": st[0], "rounds": st[1]}
 
     @property
     def distances_device_ptr(self):

@@ -17,6 +17,7 @@
 #include "mgx/sssp_dist.hpp"
 #include "mgx/rmat.hpp"
 #include "mgx/sssp_fused.hpp"
+#include "mgx/sssp_preds.hpp"
 #include "mgx.h"
 
 using namespace gunrock;
@@ -53,6 +54,10 @@ struct mgx_sssp_s {
   std::unique_ptr<sssp::sssp_enactor_t> e;
   float e_sizing = 0.f;
   std::unique_ptr<mgx::sssp_fused_state_t> fused;     // lazily: O(n)
+  // predecessors of the fused loop's distances (mgx/sssp_preds.hpp): built when somebody asks for them
+  mgx::sssp_pred_state_t pred_state;
+  bool preds_stale = false;
+  int preds_src = 0;
 };
 struct mgx_pr_s {
   mgx_graph_s* g;
@@ -1891,6 +1896,7 @@ int mgx_sssp_reset(mgx_sssp_t p, int src) {
   MGX_REQUIRE(src >= 0 && src < p->g->g->num_nodes, "mgx_sssp_reset: src out of range");
   use_device(p->g->c);
   p->p->reset((size_t)src, *p->g->c->ctx);
+  p->preds_stale = false;          // (-1 everywhere: what the operator path starts from)
   MGX_CATCH
 }
 int mgx_sssp_free(mgx_sssp_t p) {
@@ -1906,10 +1912,27 @@ int mgx_sssp_distances(mgx_sssp_t p, float* host) {
   MGX_HIP(mgx::dtoh(host, p->p->d_labels.data(), (size_t)p->g->g->num_nodes));
   MGX_CATCH
 }
+// the fused loop keeps no predecessors (sssp_fused.hpp); they are built from its distances the first time they are asked for
+static void sssp_preds_if_stale(mgx_sssp_t p) {
+  if (!p->preds_stale) return;
+  graph_device_t& G = *p->g->g;
+  mgx::sssp_build_preds(p->pred_state, G.d_row_offsets.data(), G.d_col_indices.data(), G.d_col_values.data(), p->p->d_labels.data(),
+                        p->p->d_preds.data(), G.num_nodes, (long long)G.num_edges, p->preds_src, 3.402823466e+38f, *p->g->c->ctx);
+  p->preds_stale = false;
+}
+int mgx_sssp_build_preds(mgx_sssp_t p, int64_t* stats2) {
+  MGX_TRY
+  MGX_REQUIRE(p, "NULL argument");
+  use_device(p->g->c);
+  sssp_preds_if_stale(p);
+  if (stats2) { stats2[0] = p->pred_state.last_ties; stats2[1] = p->pred_state.last_rounds; }
+  MGX_CATCH
+}
 int mgx_sssp_preds(mgx_sssp_t p, int* host) {
   MGX_TRY
   MGX_REQUIRE(p && host, "NULL argument");
   use_device(p->g->c);
+  sssp_preds_if_stale(p);
   p->g->c->ctx->synchronize();
   MGX_HIP(mgx::dtoh(host, p->p->d_preds.data(), (size_t)p->g->g->num_nodes));
   MGX_CATCH
@@ -2054,6 +2077,8 @@ int mgx_sssp_run_delta(mgx_sssp_t p, int src, float delta, int64_t* stats) {
   }
   mgx::sssp_fused_run(*p->fused, G.d_row_offsets.data(), G.d_col_indices.data(), G.d_col_values.data(),
                       p->p->d_labels.data(), src, ctx, layout.row_offsets ? &layout : nullptr);
+  p->preds_stale = true;           // (mgx_sssp_preds / mgx_sssp_build_preds: from these distances, mgx/sssp_preds.hpp)
+  p->preds_src = src;
   if (stats) {
     stats[0] = p->fused->host_ctrl->levels;
     stats[1] = (int64_t)p->fused->host_ctrl->sum_edges;

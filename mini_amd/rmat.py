@@ -68,6 +68,40 @@ def rmat_csr(ctx, scale, edgefactor=16, seed=None, weighted=False, scramble=True
     return {"n": n, "m": int(ci.numel()), "row_offsets": ro, "col_indices": ci, "weights": weights}
 
 
+def uniform_csr(ctx, scale, edgefactor=16, seed=None, device=None):
+    """edgefactor * 2^scale pairs with both ends uniformly random (a seeded device generator), symmetrised like the R-MAT
+    input (swapped copies appended, nothing de-duplicated): the same sizes as RMAT-<scale>, no hubs -- every row has about
+    2 * edgefactor entries.  Returns the dict rmat_csr returns."""
+    device = device or torch.device("cuda", ctx.device)
+    seed = scale if seed is None else seed
+    n = 1 << scale
+    gen = torch.Generator(device=device)
+    gen.manual_seed(0x5EED0000 + int(seed))
+    pairs = edgefactor * n
+    src = torch.randint(0, n, (pairs,), generator=gen, dtype=torch.int32, device=device)
+    dst = torch.randint(0, n, (pairs,), generator=gen, dtype=torch.int32, device=device)
+    ro, ci, _ = csr_from_pairs(src, dst, n, None, undirected=True)
+    torch.cuda.synchronize(device)
+    return {"n": n, "m": int(ci.numel()), "row_offsets": ro, "col_indices": ci, "weights": None}
+
+
+def grid2d_csr(ctx, scale, device=None):
+    """a 2^(scale // 2) x 2^(scale - scale // 2) grid, every vertex joined to its 4 neighbours (both directions stored):
+    degree <= 4 everywhere and a diameter of rows + cols -- thousands of small levels.  Returns the dict rmat_csr returns."""
+    device = device or torch.device("cuda", ctx.device)
+    rows, cols = 1 << (scale // 2), 1 << (scale - scale // 2)
+    n = rows * cols
+    v = torch.arange(n, dtype=torch.int64, device=device)
+    r, c = v // cols, v % cols
+    right = v[c + 1 < cols]
+    down = v[r + 1 < rows]
+    src = torch.cat([right, down]).to(torch.int32)
+    dst = torch.cat([right + 1, down + cols]).to(torch.int32)
+    ro, ci, _ = csr_from_pairs(src, dst, n, None, undirected=True)
+    torch.cuda.synchronize(device)
+    return {"n": n, "m": int(ci.numel()), "row_offsets": ro, "col_indices": ci, "weights": None}
+
+
 def degree_order(row_offsets, col_indices, weights=None):
     """Hub-first layout of a CSR (device tensors): vertex ids renumbered by descending degree (stable).
 

@@ -498,3 +498,21 @@ def test_config5_shape_rmat23_four_rank_engines_vs_single_gpu_and_oracle(gpu_ctx
             assert np.array_equal(single, want)
     for e in engs:
         e.close()
+
+
+def test_rmat26_on_one_gpu_as_two_shards(gpu_ctx):
+    """the 1-GPU figure for BASELINE config 5's graph (the denominator of the north star's ">= 5x at 8 GPUs over 1 GPU on
+    RMAT-26"): 2^31 CSR entries do not fit int32 row offsets, so `bench.py --scale 26 --gpus 1` cuts the graph into
+    two cyclic shards of 2^30 entries, a rank engine each, and runs them in turn through the partitioned traversal's C++ loop
+    (mgx_dbfs2_run_group).  The line is only printed with parity true: BFS-tree properties of the labels over every shard's rows."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--scale", "26", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["scale"] == 26 and line["parity_vs_oracle"] is True
+    assert line["config"]["parallelism"] == "1 GPU, 2 shards in turn"
+    assert line["value"] > 0 and line["avg_levels"] >= 5

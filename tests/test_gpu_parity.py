@@ -1061,3 +1061,78 @@ def test_bfs_mid_size_levels_take_m_launches(gpu_ctx, oracle, layout, monkeypatc
             want = oracle.bfs_cpu(ro, ci, s)
             assert st["reached"] == int((want >= 0).sum()) and st["levels"] == int(want.max()) + 1
     assert used > 0
+
+
+def _check_shortest_path_tree(ro, ci, w, dist, pred, src):
+    """pred is a shortest-path tree of dist: pred[src] = pred[unreached] = -1; every other reached v has an edge pred[v] -> v
+    with dist[pred[v]] + w == dist[v] (float32, as the loop adds); following preds from any reached vertex ends at src"""
+    n = len(ro) - 1
+    inf = np.float32(3.402823466e+38)
+    reached = dist < inf
+    assert pred[src] == -1 and dist[src] == 0
+    assert np.all(pred[~reached] == -1)
+    rest = reached.copy(); rest[src] = False
+    assert np.all(pred[rest] >= 0), "a reached vertex without a predecessor"
+    # tight edge pred[v] -> v: among the entries of row pred[v] that point to v, one with the right weight
+    srcs = np.repeat(np.arange(n, dtype=np.int64), np.diff(ro))
+    key = srcs * n + ci.astype(np.int64)
+    tight = (dist[srcs] + w.astype(np.float32)).astype(np.float32) == dist[ci]
+    tight &= reached[srcs]
+    tkeys = np.unique(key[tight])
+    vs = np.nonzero(rest)[0]
+    want = pred[vs].astype(np.int64) * n + vs
+    assert np.all(np.isin(want, tkeys)), "a predecessor edge that is not tight (or not an edge)"
+    # acyclic: pointer doubling -- after ceil(log2 n) + 1 rounds everybody reached stands at the source
+    p = pred.astype(np.int64).copy()
+    p[src] = src
+    p[~reached] = np.arange(n)[~reached]
+    for _ in range(int(np.ceil(np.log2(max(n, 2)))) + 1):
+        p = p[p]
+    assert np.all(p[reached] == src), "the predecessors contain a cycle"
+
+
+@pytest.mark.parametrize("layout", [False, True])
+def test_sssp_fused_preds_form_a_shortest_path_tree(gpu_ctx, oracle, layout):
+    """sssp_functor.hxx:31-34 keeps preds in the relaxation (racy; tests/sssp/test_sssp.cu:44-51 compares them exactly); the fused
+    loop builds them from its distances (mgx/sssp_preds.hpp): a tree of tight edges, the same on every call.  R-MAT graphs with
+    weights in [0, 64) (zeros: equal-distance ties), real-valued weights, a directed graph, and a graph of zero weights only"""
+    import mini_amd
+    rng = np.random.default_rng(11)
+    cases = []
+    for scale, ef, seed in ((10, 8, 3), (13, 16, 5), (15, 16, 9)):
+        n, ro, ci, w = oracle.rmat_csr(scale, ef, seed)
+        cases.append((ro, ci, w))
+    n, ro, ci, w = oracle.rmat_csr(12, 8, 21)
+    cases.append((ro, ci, (rng.random(len(ci)) * 5.0).astype(np.float32)))             # real weights (not symmetric: a directed weighting)
+    cases.append((ro, ci, (rng.integers(0, 2, len(ci))).astype(np.float32)))           # half the edges weigh nothing
+    cases.append((ro, ci, np.zeros(len(ci), dtype=np.float32)))                        # all ties: the rounds are a BFS
+    # a directed chain with zero-weight shortcuts back (tight edges in both directions between equal-distance vertices)
+    k = 300
+    rows = [[] for _ in range(k)]
+    for i in range(k - 1):
+        rows[i].append((i + 1, 0.0 if i % 3 else 2.0))
+        rows[i + 1].append((i, 0.0))
+    ro_c = np.zeros(k + 1, dtype=np.int32); ci_c, w_c = [], []
+    for i, r in enumerate(rows):
+        r.sort()
+        ro_c[i + 1] = ro_c[i] + len(r)
+        ci_c += [d for d, _ in r]; w_c += [x for _, x in r]
+    cases.append((ro_c, np.array(ci_c, dtype=np.int32), np.array(w_c, dtype=np.float32)))
+    for ci_case, (ro, ci, w) in enumerate(cases):
+        g = _graph(gpu_ctx, ro, ci, w)
+        if layout:
+            g.build_layout(weights=True)
+        deg = np.diff(ro)
+        sssp = mini_amd.SsspProblem(g, 0)
+        for src in (int(np.argmax(deg)), int(np.where(deg > 0)[0][-1]), 0):
+            sssp.run(src)
+            dist = sssp.distances()
+            assert np.array_equal(dist, oracle.sssp_dijkstra_f32(ro, ci, w, src))
+            st = sssp.build_preds()
+            pred = sssp.preds()
+            _check_shortest_path_tree(ro, ci, w, dist, pred, src)
+            if ci_case >= 4:
+                assert st["ties"] > 0 and st["rounds"] >= 2, st
+            sssp.run(src)
+            assert np.array_equal(sssp.preds(), pred), "the predecessors differ between two runs"
+        sssp.close()
