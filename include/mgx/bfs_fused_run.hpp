@@ -401,7 +401,12 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   // Probing the bitmap word of cold neighbours (instead of marking them untested) pays on big graphs WITHOUT the unit
   // blocks -- the partitioned ranks, a caller-made layout.  With them the unit-block body, the cold-edge pass and the
   // lazy builds win at every size measured: RMAT-23 391 against 272 GTEPS, RMAT-24 386 / 253, RMAT-25 187 / 179.
-  const bool coldt = opt.cold_test >= 0 ? opt.cold_test != 0 : (bfs_cold_test(a.n, -1) && !units_avail);
+  // A FLAT graph (round 5: a uniform random graph of 2^22 vertices, every row ~32 entries): the LDS prefix holds 652 K of its
+  // vertices and nearly every endpoint lies behind it -- the layout built no cold-edge lists (they would be most of the graph), so
+  // the unit-block body would mark six entries in seven untested, a byte store each.  Probing the bitmap (512 KB: it lives in the
+  // L2s) wins there: 1.35 against 2.02 ms per traversal.
+  const bool flat = units_avail && (u32)a.n > (u32)(BFS_DENSE_HOTW * 32) && !(layout->cold_dst && layout->cold_slices > 0);
+  const bool coldt = opt.cold_test >= 0 ? opt.cold_test != 0 : ((bfs_cold_test(a.n, -1) && !units_avail) || flat);
   const bool units = units_avail && !coldt;
   a.ub_col = units ? layout->ub_col : nullptr;
   a.ub_col24 = (units && st.opts.pack24) ? layout->ub_col24 : nullptr;
@@ -658,7 +663,9 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
   const u32 nstream = plan.nstream, nwave = plan.nwave, ncold = plan.ncold;
   for (int batch = 0;; ++batch) {
     // first batch: what the previous traversal of this graph needed (sources differ, level structure hardly)
-    int nslots = batch == 0 ? bfs_class_slots(st, cls) : st.levels_per_sync;
+    // (later batches: a traversal deeper than the graph's last ones -- twice the slots every time, up to 32: a host look costs
+    //  what a dozen idle launches do)
+    int nslots = batch == 0 ? bfs_class_slots(st, cls) : (st.levels_per_sync << (batch - 1 < 4 ? batch - 1 : 4));
     if (nslots > bfs_fused_state_t::EV_POOL / 3) nslots = bfs_fused_state_t::EV_POOL / 3;
     if (batch_events) MGX_HIP(hipEventRecord(st.ev0, s));
     const int first_slot = slot;
@@ -781,6 +788,12 @@ constexpr size_t bfs_head_bytes() { return offsetof(bfs_ctrl_t, trace) + 64 * si
 constexpr size_t bfs_many_head_bytes() { return (bfs_head_bytes() + 63) & ~(size_t)63; }
 inline bfs_ctrl_t* bfs_many_head(char* heads, int i) { return (bfs_ctrl_t*)(heads + (size_t)i * bfs_many_head_bytes()); }
 
+// Tried for deep graphs and dropped (round 5; a 2048 x 2048 grid, 3 690 levels of <= 8 192 edges): an M launch that GOES ON with the level
+// it produced while that one is mid-size too -- 64 co-resident workgroups, a grid barrier (device-scope release / acquire) between
+// two levels instead of a [push, build] pair of launches.  It ran the whole traversal in one launch (3 launch slots instead of
+// 2 249) and took 60.2 ms against 61.5: ~16 us per level either way.  A level's cost there is its own chain of ~10 dependent
+// memory round trips (cursor, queue entry, row, bitmap word, claim, row extent, cursor add, queue store), not the launches; on
+// RMAT-22 the barrier made the stragglers' levels 1.5 % slower than the chain launch behind the M launch (0.3132 / 0.3086 ms).
 // Tried for the batch and dropped (each measured on RMAT-22, 64 sources; the code is in the history of this file):
 //   * two LANES -- state + HIP stream each -- with the sources alternating between them, so that the single-workgroup
 //     launches at the start and end of one traversal overlap the device-wide launches of the other: 0.446 ms per traversal
@@ -816,7 +829,16 @@ inline int bfs_fused_run_many(bfs_fused_state_t& st, const int* row_offsets, con
   // ... and whatever mode: a batch that had to run a traversal again earns the handle's next batches a spare slot (at most 4),
   // taken back after eight batches in a row without a re-run (graphs whose sources differ in depth: R-MAT 16, 3 of 32 sources)
   int nslots = st.slots_hint + st.opts.many_spare + (mode == 1 ? (uneven ? 2 : 1) : 0) + st.auto_spare;
-  if (nslots > 30) nslots = 30;
+  if (nslots > 30) {
+    // a DEEP graph (its last traversals needed more device-wide slots than a batch entry gets -- a grid, a road network): every
+    // traversal would run out of slots and be run again on its own.  One call per source then, each with its own batches of
+    // slots (round 5: grid2d-22, 79.9 -> 61.7 ms per traversal); the heads are what those calls leave.
+    for (int i = 0; i < count; ++i) {
+      bfs_fused_run(st, row_offsets, col_indices, labels, srcs[i], ctx, layout, mode, alpha, in_offsets, in_indices);
+      memcpy(bfs_many_head(heads, i), st.host_ctrl, bfs_head_bytes());
+    }
+    return 0;
+  }
   if (nslots < 1) nslots = 1;
   const int saved_tail = st.tail_from;
   st.tail_from = plan.minis ? (1 << 30) : nslots - 1;      // (no M launches: a chain launch in front of the last slot and behind the batch)

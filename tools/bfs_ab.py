@@ -16,10 +16,12 @@ ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--rounds", type=int, default=2)
 ap.add_argument("--mode", type=int, default=0)
 ap.add_argument("--alpha", type=float, default=4.0)
+ap.add_argument("--graph", choices=["rmat", "uniform", "grid2d"], default="rmat")
 ap.add_argument("--configs", default=";MGX_BFS_DENSE=0;MGX_BFS_CHAIN_MAX_EDGES=0;MGX_BFS_DENSE=0,MGX_BFS_CHAIN_MAX_EDGES=0")
 a = ap.parse_args()
 ctx = mini_amd.Context(0, torch.cuda.current_stream().cuda_stream)
-g = rmat.rmat_csr(ctx, a.scale, 16, seed=a.scale)
+g = {"rmat": lambda: rmat.rmat_csr(ctx, a.scale, 16, seed=a.scale), "uniform": lambda: rmat.uniform_csr(ctx, a.scale, 16, seed=a.scale),
+     "grid2d": lambda: rmat.grid2d_csr(ctx, a.scale)}[a.graph]()
 graph = mini_amd.Graph.from_device(ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"])
 graph.build_layout()
 ro = g["row_offsets"].cpu().numpy()
