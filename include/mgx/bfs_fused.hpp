@@ -736,6 +736,10 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : 4) void k_bfs_build(bfs_fused_a
 // to be (a sparse frontier then costs their sweeps and LDS copies: ~27 us instead of ~10 on RMAT-22, which is why the
 // rule looks at the marks and not at the level's edges: few marks guarantee a small frontier).
 // Measured, RMAT-22: the two big builds 41 -> 24 and 27 -> 20 us.
+// (Round 5, tried and dropped: a lazy build that still writes the LONG-row queue -- the level behind the peak has a million short
+//  rows and a few thousand long ones, and without a queue its long-row half sweeps every unit owner and runs the cold-edge pass for
+//  them.  With the queue that half became a short walk, but the launch ends with its short-row half either way: push 183.4 -> 182.1
+//  us per traversal, builds 89.9 -> 93.5 (the scan and the returning atomic behind the hub level), 0.3012 -> 0.3031 ms.)
 __device__ __forceinline__ bool bfs_build_is_lazy(const bfs_fused_args_t& a, int slot) {
   if (a.lazy_div == 0u || !a.slot_marks) return false;
   u64 M = 0;

@@ -31,3 +31,7 @@ for t in bfs sssp pr kcore; do
       -I"$FARM/inc" "$REF/gunrock/tests/$t/test_$t.cu" -o "$OUT/ref_test_$t"
   echo "built $OUT/ref_test_$t"
 done
+# the repo's own timing driver around the reference's UNCHANGED BFS enactor / problem / functor (tools/dropin_cost.py)
+${HIPCC:-/opt/rocm/bin/hipcc} --offload-arch=gfx950 -O2 -std=c++17 -Wno-unused-value -x hip \
+    -I"$FARM/inc" "$ROOT/tests/dropin/ref_bench_bfs.cu" -o "$OUT/ref_bench_bfs"
+echo "built $OUT/ref_bench_bfs"
