@@ -303,9 +303,15 @@ def bench_main(args, rank, world, local_rank):
                               "parity": c5["parity"], "parity_check": c5["parity_how"], "shard_build_s": round(c5["t_build"], 2),
                               "per_gpu_alg_GBps": round(8.0 * c5["m_t"] / world / c5["elapsed"] / 1e9, 2),
                               "rank0_paths_last_traversal": c5.get("rank_paths"),
-                              "note": "the 1-GPU figure the north star's >= 5x is quoted against cannot be RMAT-26 itself in this data model "
-                                      "(2^31 CSR entries do not fit int32 row offsets on one GPU, SURVEY 8d): compare with the N = 1 line's "
-                                      "RMAT-22 value (and DESIGN 5's single-GPU RMAT-25 figure)"}
+                              "note": "vs_1gpu_rmat26: this value / the one-GPU RMAT-26 figure of profiles/rmat26_1gpu.json (bench.py --scale 26 "
+                                      "--gpus 1: the graph as two shards in turn on one MI355X, round 5) -- the ratio the north star's >= 5x names"}
+            try:
+                one = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "rmat26_1gpu.json")))
+                if c5["gscale"] == 26:
+                    out["config5"]["vs_1gpu_rmat26"] = round(v5 / float(one["value"]), 3)
+                    out["config5"]["one_gpu_rmat26_MTEPS"] = one["value"]
+            except Exception:                    # (the file is a committed measurement: without it the ratio is simply not quoted)
+                pass
         print(json.dumps(out), flush=True)
         if parity is False:
             print("bench.py: the partitioned traversal's labels failed the check -- the line above is NOT a valid measurement", file=sys.stderr)
