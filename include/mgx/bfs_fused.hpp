@@ -199,8 +199,6 @@ struct bfs_fused_args_t {
   int flags;               // MGX_BFS_FLAGS: instrumented stream kernel (results are wrong by design)
   const u32* ss_tab;       // short rows as one stream (bfs_fused_sshort.hpp): first entry / first row of every degree's region; NULL: none
   int ss_dmax;             // the largest short degree (long_min - 1)
-  int combine;             // merged push launch: a slot that takes both dense paths runs them in the same workgroups
-  int interleave;          // merged push launch: even workgroups take the long rows, odd ones the short rows (instead of first half / second half)
   int build_diag;          // measurements only (MGX_BFS_BUILD_DIAG; results wrong): 1 no label stores, 2 no extent gathers, 4 no cursor atomics, 8 no queue stores, 16 synthetic extents, 32 / 64 no OR of the deferred / the cold pass's bitmaps
   int dense_diag;          // measurements only (MGX_BFS_DENSE_DIAG): 1 the unit-block body stores no marks, 2 tests nothing
   const int* colds_owner;  // cold-edge lists of the SHORT rows (the entries the vertex-by-vertex body would mark; measured equal); NULL: none
@@ -1115,11 +1113,6 @@ struct bfs_run_opts_t {
   int flags = 0;           // MGX_BFS_FLAGS (instrumented stream kernel)
   int sstream = 0;         // MGX_BFS_SSTREAM=1: dense short rows as one stream of entries (bfs_fused_sshort.hpp) instead of vertex by
                            // vertex -- measured 6 us slower per RMAT-22 traversal (0.3578 / 0.3519 ms)
-  int combine = 0;         // MGX_BFS_COMBINE=1: a level that takes both dense paths runs them in the SAME workgroups -- measured 0.4055
-                           // vs 0.4012 ms per RMAT-22 traversal: the two halves of the grid overlap their tails better
-  int interleave = 0;      // MGX_BFS_INTERLEAVE=1: long-row and short-row workgroups alternate -- measured 0.52 vs 0.41 ms per RMAT-22
-                           // traversal: the two bodies side by side on a CU (both lean on LDS) are slower than one after the other
-  int biglds = 0;          // MGX_BFS_BIGLDS (timed mode): one 160 KB workgroup per CU -- slower
   int build_diag = 0;      // MGX_BFS_BUILD_DIAG: parts of k_bfs_build switched off (measurements only)
   int dense_diag = 0;      // MGX_BFS_DENSE_DIAG: parts of the unit-block body switched off (measurements only)
 #endif
@@ -1160,9 +1153,6 @@ struct bfs_run_opts_t {
 #ifdef MGX_LAB
     geti("MGX_BFS_FLAGS", o.flags);
     geti("MGX_BFS_SSTREAM", o.sstream);
-    geti("MGX_BFS_COMBINE", o.combine);
-    geti("MGX_BFS_INTERLEAVE", o.interleave);
-    geti("MGX_BFS_BIGLDS", o.biglds);
     geti("MGX_BFS_BUILD_DIAG", o.build_diag);
     geti("MGX_BFS_DENSE_DIAG", o.dense_diag);
 #else

@@ -149,6 +149,9 @@ __device__ __forceinline__ void bfs_slot_open(const bfs_fused_args_t& a, const b
 // the parts separately so that each can be bracketed by events.
 // COLDT: probe the bitmap word of neighbours outside the LDS prefix (big graphs: many cold endpoints) or mark them
 // untested (k_bfs_build tests the bitmap anyway).  PART: 0 all, 1 opener / chain only, 2 long rows only, 3 short rows only.
+// (The 18 spilled SGPRs of <false, 0> are the chain body of block 0, inlined.  Calling it instead -- __attribute__((noinline)), round 5
+//  -- takes the SGPR spills to 0 and brings 72 spilled VGPRs and 1 560 bytes of scratch: a call makes the kernel provide for the
+//  callee's registers under its own 64-VGPR budget.  SGPR spills go to VGPR lanes, not to memory; left as it is.)
 template <bool COLDT, int PART>
 __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int arg, u32 nstream) {
   const bfs_slot_plan_t p = bfs_slot_plan(a, arg);
@@ -169,7 +172,6 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
   }
   // Which part this workgroup takes: (graphs with cold-edge lists) the workgroups of the cold pass, then nstream
   // workgroups for the long rows, the others the short rows.
-  // (lab builds, interleave: even / odd instead, so that the two parts share every CU -- an experiment that lost)
   const u32 ncold = (!COLDT && a.cold_dst && (PART == 0 || PART == 2)) ? a.cold_wgs[a.cold_slices] : 0u;   // (PART 2: with the long rows)
   // grid: [cold pass][long rows][short rows] -- the cold workgroups first: they are few and short, and the launch does
   // not end on them
@@ -178,23 +180,18 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
     return;
   }
   const u32 blk = blockIdx.x - ncold, nblk = gridDim.x - ncold;
-#ifdef MGX_LAB
-  if (PART == 0 && !COLDT && p.dense && p.vshort && a.combine) {
-    // both dense paths: the first nstream workgroups take their share of the long AND of the short rows
-    if (blk < nstream) bfs_dense_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, blk, nstream, p.level, p.cold, p.colds);
-    return;
-  }
-#endif
-  const bool il = PART == 0 && MGX_LAB_GET(a, interleave, 0) && nblk == 2u * nstream;
-  const bool long_part = PART == 2 || (PART == 0 && (il ? !(blk & 1u) : blk < nstream));
+  // (two other ways to deal the two halves were lab shapes until round 5 and lost in rounds 3 and 4: long- and short-row
+  //  workgroups alternating, 0.52 against 0.41 ms per traversal -- the two bodies side by side on a CU are slower than one after
+  //  the other --, and both dense paths in the SAME workgroups, 0.4055 / 0.4012 and again 0.3582 / 0.3481; HISTORY.md 3.1)
+  const bool long_part = PART == 2 || (PART == 0 && blk < nstream);
   if (long_part) {
-    const u32 bi = il ? blk >> 1 : blk;
+    const u32 bi = blk;
     if (!COLDT && p.dense) bfs_dense_body<1024, BFS_DENSE_HOTW>(a, p.slot, bi, nstream, p.level, p.cold);
     else bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, COLDT, false, true>(a, p.slot, bi, nstream, p.level);
   } else {
     const u32 first = PART == 0 ? nstream : 0u;
-    const u32 bi = il ? blk >> 1 : blk - first;
-    const u32 nb = il ? nstream : nblk - first;
+    const u32 bi = blk - first;
+    const u32 nb = nblk - first;
 #ifdef MGX_LAB
     if (!COLDT && p.vshort && a.ss_tab) { bfs_sstream_body<1024, BFS_DENSE_HOTW - BFS_SS_TAB_PAD>(a, p.slot, bi, nb, p.level, false); return; }
 #endif
@@ -226,16 +223,6 @@ __global__ __launch_bounds__(1024) void k_bfs_chain_inplace(bfs_fused_args_t a, 
 }
 
 #ifdef MGX_LAB
-// Experiment (MGX_BFS_BIGLDS=1, timed mode only): the unit-block body with ONE workgroup per CU and twice the bitmap
-// prefix in LDS (fewer cold neighbours marked untested), 128 VGPRs.
-constexpr int BFS_DENSE_HOTW_BIG = 40800;
-__global__ __launch_bounds__(1024, 4) void k_bfs_push_dense_big(bfs_fused_args_t a, int arg) {
-  const bfs_slot_plan_t p = bfs_slot_plan(a, arg);
-  if (p.empty || p.chained) return;
-  if (p.dense) bfs_dense_body<1024, BFS_DENSE_HOTW_BIG, 2>(a, p.slot, blockIdx.x, gridDim.x, p.level);
-  else bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, false, false, true>(a, p.slot, blockIdx.x, gridDim.x, p.level);
-}
-
 // The instrumented stream kernel (MGX_BFS_FLAGS: parts of the body switched off for measurements; results are wrong
 // by design).  Queue walk only.
 __global__ __launch_bounds__(1024, 8) void k_bfs_push_stream_diag(bfs_fused_args_t a, int arg) {
@@ -310,7 +297,6 @@ inline void bfs_set_kernel_attributes() {
   MGX_SET_LDS((k_bfs_push<false, 3>)); MGX_SET_LDS((k_bfs_push<true, 3>));
 #ifdef MGX_LAB
   MGX_SET_LDS(k_bfs_push_stream_diag);
-  MGX_SET_LDS(k_bfs_push_dense_big);
 #endif
   MGX_SET_LDS(k_bfs_chain_inplace);
   // (k_bfs_mini has static LDS too: the attribute carries what it needs, not the whole 160 KB)
@@ -430,8 +416,6 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   a.ss_dmax = st.long_min - 1;
   a.dense_diag = opt.dense_diag;
   a.build_diag = opt.build_diag;
-  a.interleave = opt.interleave;
-  a.combine = opt.combine;
 #endif
   if (!st.slot_marks.size()) st.slot_marks = mem_t<u32>((size_t)2 * BFS_MARK_CTRS * BFS_MARK_STRIDE, ctx);
   a.slot_marks = st.slot_marks.data();
@@ -458,7 +442,7 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   // queue build that knows their bitmaps
   const bool cold = units && a.dense_div && layout->cold_dst && layout->cold_slices > 0 && layout->cold_hot_n == (unsigned)(BFS_DENSE_HOTW * 32) &&
                     layout->cold_long_min == st.long_min && build2_ok && !opt.build_list && opt.cold != 0 &&
-                    !MGX_LAB_GET(opt, dense_diag, 0) && !(MGX_LAB_GET(opt, biglds, 0) && st.time_kernels == 1);
+                    !MGX_LAB_GET(opt, dense_diag, 0);
   a.cold_owner = cold ? layout->cold_owner : nullptr;
   a.cold_dst = cold ? layout->cold_dst : nullptr;
   a.cold_slices = cold ? layout->cold_slices : 0;
@@ -688,7 +672,6 @@ inline void bfs_fused_run(bfs_fused_state_t& st, const int* row_offsets, const i
         if (a.long_min > 0) {
 #ifdef MGX_LAB
           if (a.flags) hipLaunchKernelGGL(k_bfs_push_stream_diag, dim3(nstream), dim3(1024), bfs_push_lds_bytes(), s, a, arg);
-          else if (opt.biglds && !coldt) hipLaunchKernelGGL(k_bfs_push_dense_big, dim3(ctx.num_cus), dim3(1024), bfs_dense_lds_bytes(BFS_DENSE_HOTW_BIG), s, a, arg);
           else
 #endif
           bfs_launch_push_part<2>(a, arg, ctx, coldt, nstream + ncold, nstream);

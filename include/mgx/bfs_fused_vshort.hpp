@@ -261,32 +261,5 @@ __device__ __forceinline__ void bfs_vshort_body(const bfs_fused_args_t& a, int s
   bfs_body_finish(a, marks, slot, stat_level, s_int);
 }
 
-#ifdef MGX_LAB   // (MGX_BFS_COMBINE: measured no faster than the two halves of the grid -- lab builds only)
-// Long rows from the unit blocks AND short rows vertex by vertex in ONE workgroup, one after the other over the same LDS
-// prefix: a level that takes both dense paths (the big level of a skewed graph) then copies the bitmap prefix 512 times
-// instead of 1024, runs one epilogue per workgroup, and what the long rows claimed in LDS is already known when the
-// short rows are tested.
-template <int NT, int HOTW>
-__device__ __forceinline__ void bfs_dense_vshort_body(const bfs_fused_args_t& a, int slot, u32 block, u32 nblocks, int stat_level,
-                                                      bool cold = false, bool colds = false) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* s_int;
-  u32* const hot = bfs_hot_setup<NT, HOTW>(a, smem, &s_int, cold ? 0xFFFFFFFFu : 0u);
-  const int lane = lane_id();
-  bfs_ctrl_t* const c = a.ctrl;
-  const u32 hot_n = ((u32)a.n < (u32)(HOTW * 32)) ? (u32)a.n : (u32)(HOTW * 32);
-  const u32 defer_n = bfs_defer_limit(a, hot_n);
-  int marks = 0;
-  bfs_dense_work<NT, HOTW, 1>(a, hot, hot_n, defer_n, block, nblocks, marks);
-  if (cold != colds) {                 // the sentinel behind the prefix as the short rows need it
-    __syncthreads();
-    if (threadIdx.x == 0) hot[HOTW] = colds ? 0xFFFFFFFFu : 0u;
-    __syncthreads();
-  }
-  bfs_vshort_work<NT, HOTW>(a, hot, hot_n, defer_n, block, nblocks, marks);
-  (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, slot, s_int + 4, marks);
-  bfs_body_finish(a, marks, slot, stat_level, s_int);
-}
-#endif  // MGX_LAB
 
 }  // namespace mgx

@@ -176,7 +176,6 @@ def test_config2_rmat22_bfs_full_size_vs_oracle(gpu_ctx, oracle, torch_mod):
 @pytest.mark.parametrize("scale,undir,env", [
     (20, True, {}), (21, True, {"MGX_BFS_DENSE": "1000000", "MGX_BFS_LAZY": "1048576"}), (20, False, {"MGX_BFS_DENSE": "1000000"}),
     (21, True, {"MGX_BFS_DEFER": "0"}), (20, True, {"MGX_BFS_COLD": "0"}), (21, True, {"MGX_BFS_DENSE": "1000000", "MGX_BFS_MERGED_PUSH": "0"}),
-    (21, True, {"MGX_BFS_COMBINE": "1", "MGX_BFS_DENSE": "1000000", "MGX_BFS_VSHORT": "1000000"}),
     (21, True, {"MGX_BFS_COLD": "1", "MGX_BFS_COLD_LISTS": "2", "MGX_BFS_DENSE": "1000000"}), (20, True, {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_DENSE": "0"}),
     (21, False, {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_DENSE": "1000000", "MGX_BFS_LAZY": "1048576", "MGX_BFS_COLD": "1", "MGX_BFS_COLD_LISTS": "2"}),
     (21, True, {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_DENSE": "1000000", "MGX_BFS_CHAIN_MAX_EDGES": "0", "MGX_BFS_COLD": "1", "MGX_BFS_COLD_LISTS": "2"})])
@@ -187,7 +186,7 @@ def test_cold_edge_pass_vs_oracle(gpu_ctx, oracle, torch_mod, monkeypatch, scale
     labels against the oracle for hub, ordinary and isolated sources"""
     import mini_amd
     from tests.conftest import skip_unless_lab
-    skip_unless_lab(env)                    # (the short rows' cold lists and the combined bodies: lab library only)
+    skip_unless_lab(env)                    # (the short rows' cold lists: lab library only)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     n = 1 << scale

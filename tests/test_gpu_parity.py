@@ -607,7 +607,7 @@ VARIANTS = [{}, {"MGX_BFS_COLD_TEST": "1"}, {"MGX_BFS_COLD_TEST": "1", "MGX_BFS_
             {"MGX_BFS_DENSE": "1000000", "MGX_BFS_LONG_MIN": "1"}, {"MGX_BFS_DENSE": "1000000", "MGX_BFS_MERGED_PUSH": "0"},
             {"MGX_BFS_VSHORT": "1000000"}, {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_LONG_MIN": "8", "MGX_BFS_HOT_MIN_EDGES": "0"},
             {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_DENSE": "1000000", "MGX_BFS_DEFER": "1", "MGX_BFS_CHAIN_MAX_EDGES": "0", "MGX_BFS_HOT_MIN_EDGES": "0"},
-            {"MGX_BFS_VSHORT": "0", "MGX_BFS_DENSE": "0"}, {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_DENSE": "1000000", "MGX_BFS_COMBINE": "1"},
+            {"MGX_BFS_VSHORT": "0", "MGX_BFS_DENSE": "0"},
             {"MGX_BFS_BUILD_LIST": "1"}, {"MGX_BFS_DEFER": "0"}, {"MGX_BFS_DEFER": "1", "MGX_BFS_HOT_MIN_EDGES": "0"},
             {"MGX_BFS_DEFER": "1", "MGX_BFS_HOT_MIN_EDGES": "0", "MGX_BFS_BUILD_LIST": "1", "MGX_BFS_DENSE": "1000000"},
             # lazy queues (bfs_build_is_lazy) behind EVERY device-wide level / never
