@@ -777,6 +777,10 @@ inline bfs_ctrl_t* bfs_many_head(char* heads, int i) { return (bfs_ctrl_t*)(head
 // 2 249) and took 60.2 ms against 61.5: ~16 us per level either way.  A level's cost there is its own chain of ~10 dependent
 // memory round trips (cursor, queue entry, row, bitmap word, claim, row extent, cursor add, queue store), not the launches; on
 // RMAT-22 the barrier made the stragglers' levels 1.5 % slower than the chain launch behind the M launch (0.3132 / 0.3086 ms).
+// Also round 5, for the same graphs and for R-MAT's stragglers: a device-wide slot that finds a MID-SIZE level runs it M-launch style in
+// the first 64 workgroups of its push launch (the build returns at once).  RMAT-22: 0.3098 against 0.3076 ms (the push kernel went from
+// 18 to 48 spilled SGPRs); the grid: 68.7 against 62.7 ms -- 64 workgroups claiming by device-scope atomics are no faster per level
+// than the [push, build] pair they replace.
 // Tried for the batch and dropped (each measured on RMAT-22, 64 sources; the code is in the history of this file):
 //   * two LANES -- state + HIP stream each -- with the sources alternating between them, so that the single-workgroup
 //     launches at the start and end of one traversal overlap the device-wide launches of the other: 0.446 ms per traversal

@@ -60,6 +60,27 @@ for cfg in "25 8" "26 8" "22 8" "22 1"; do
   set -- $cfg
   timeout 900 python tools/dist2_single.py $1 $2 2>/dev/null | grep -v amdgpu.ids | tail -6 > $O/dist2_single_$1_$2.log
 done
+# (round 5) the same engines driven in turn by the C++ loop itself: a whole traversal enqueued ahead from the level plan, one host wait
+for cfg in "22 1" "22 2" "22 4" "22 8" "25 8" "26 8"; do
+  set -- $cfg
+  timeout 900 python tools/dist2_single.py $1 $2 native 2>/dev/null | grep -v amdgpu.ids | tail -6 > $O/dist2_native_$1_$2.log
+done
+bash tools/gpu_d2_native_stats.sh 26 8 "" > /dev/null 2>&1
+cp $R/gpurun_out/d2native/summary.txt $O/dist2_native_kernels_26_8.txt 2>/dev/null
+bash tools/gpu_d2_native_stats.sh 22 8 "" > /dev/null 2>&1
+cp $R/gpurun_out/d2native/summary.txt $O/dist2_native_kernels_22_8.txt 2>/dev/null
+timeout 600 python tools/dist2_loopback.py 22 8 reduce 8 2>/dev/null | grep -v amdgpu.ids | tail -10 > $O/dist2_loopback_22_8.log
+# (round 5) RMAT-26 on one GPU, the graphs off RMAT-22, what the drop-in costs, the timed batch per kernel
+timeout 900 python bench.py --scale 26 --steps 8 --warmup 1 > $O/bench_rmat26_1gpu.log 2>&1
+for g in "uniform 22 16" "grid2d 22 4" "rmat 24 16" "rmat 20 32"; do
+  set -- $g
+  timeout 600 python bench.py --graph $1 --scale $2 --steps $3 --warmup 2 --cpu-seconds 5 > $O/bench_$1_$2.log 2>&1
+done
+timeout 600 python tools/dropin_cost.py 20 4 2>&1 | grep -v amdgpu.ids > $O/dropin_cost.log
+timeout 600 python tools/dropin_cost.py 22 4 2>&1 | grep -v amdgpu.ids >> $O/dropin_cost.log
+bash tools/gpu_trace_batch.sh "" 64 > /dev/null 2>&1
+cp $R/gpurun_out/trb/batch_stats.txt $O/batch_stats.txt 2>/dev/null
+python3 tools/pmc_by_kernel.py $O 5 > $O/pmc_by_kernel.txt 2>&1
 timeout 900 python tools/dist2_single.py 26 8 gather 2>/dev/null | grep -v amdgpu.ids | tail -6 > $O/dist2_single_26_8_gather.log
 timeout 900 python tools/dist2_single.py 26 8 reduce 2>/dev/null | grep -v amdgpu.ids | tail -6 > $O/dist2_single_26_8_reduce.log
 # the rank engines' kernels per rank and traversal, per level, and the three parts of the push grid
@@ -99,6 +120,9 @@ mkdir -p $O/keep
 cp $O/summary.txt $O/summary.json $O/kernel_stats_mgx.csv $O/kernel_stats_sssp.csv $O/kernel_stats_pr.csv $O/levels.log $O/sssp_iterations.log $O/timeline.txt $O/keep/ 2>/dev/null
 cp $O/pmc_traffic.json $O/bfs_operator_s22.log $O/dobfs_alpha_sweep.txt $O/sssp_s22.log $O/pr_s22.log $O/kcore_s20.log $O/keep/ 2>/dev/null
 cp $O/dist2_single_*.log $O/kernel_stats_dist2_25_8.csv $O/dist2_kernels_26_8.txt $O/keep/ 2>/dev/null
+cp $O/dist2_native_*.log $O/dist2_native_kernels_*.txt $O/dist2_loopback_22_8.log $O/dropin_cost.log $O/batch_stats.txt $O/pmc_by_kernel.txt $O/keep/ 2>/dev/null
+grep '^{' $O/bench_rmat26_1gpu.log | tail -1 > $O/keep/bench_line_rmat26_1gpu.json
+for g in uniform_22 grid2d_22 rmat_24 rmat_20; do grep '^{' $O/bench_$g.log | tail -1 > $O/keep/bench_line_$g.json; done
 grep '^{' $O/bench_driver_cmd.log | tail -1 > $O/keep/bench_line_driver_cmd.json
 grep '^{' $O/bench.log | tail -1 > $O/keep/bench_line.json
 grep '^{' $O/bench_per_call.log | tail -1 > $O/keep/bench_line_per_call.json
