@@ -8,6 +8,7 @@
 // and never materialises the mostly -1 intermediate frontier.
 #pragma once
 #include <climits>
+#include <type_traits>
 
 #include "../mgx/lbs.hpp"
 #include "../mgx/scan.hpp"
@@ -19,6 +20,15 @@ namespace oprtr {
 namespace advance {
 
 namespace detail {
+
+// A functor may say that its filter test looks at the slot's value alone (no state another edge of the same advance could still
+// change): `static constexpr bool cond_filter_of_slot_value_only = true;` (the repo's bfs_functor_t: value != -1).  The advance
+// then evaluates that test per output slot while the value is in a register and leaves the ballots for the filter behind it
+// (mgx::standard_context_t::keep).  The reference's unchanged functors say nothing and are filtered the reference's way.
+template <typename F, typename = void>
+struct filter_of_slot_value_only : std::false_type {};
+template <typename F>
+struct filter_of_slot_value_only<F, typename std::enable_if<F::cond_filter_of_slot_value_only>::type> : std::true_type {};
 
 // Segment i of an expansion = the adjacency list of ids[i] under `offsets` (CSR rows when pushing, CSC columns when
 // pulling).  Writes the exclusive scan of the list lengths into the graph's shared scan buffer (graph.hxx:49-52:
@@ -61,6 +71,27 @@ int advance_forward_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fro
   //  and the reference's bfs_functor_t does an atomicCAS on labels[dst] there -- 134 M device-scope atomics per
   //  RMAT-22 traversal at ~25 G/s: 16.5 ms.  Our restatement of the functor reads the label first
   //  (bfs/bfs_functor.hxx): 2.5 ms.)
+  context.keep.valid = false;
+  if constexpr (has_output && !idempotence && detail::filter_of_slot_value_only<Functor>::value) {
+    // the filter's test rides on the expansion: one ballot word per 64 slots into the compaction's bit array (scan.hpp: compact_t
+    // lays it out the same way for the same count), nothing else of the filter's upsweep is left but to count them
+    mgx::compact_t where(edges, context);
+    auto visit_keep = [=] __device__(int slot, int segment, int rank) -> bool {
+      const int v = frontier[segment];
+      const int edge = row_start[v] + rank;
+      const int u = neighbours[edge];
+      const bool cond = Functor::cond_advance(v, u, edge, rank, slot, data, iteration);
+      const bool applied = Functor::apply_advance(v, u, edge, rank, slot, data, iteration);
+      const int value = (cond && applied) ? u : -1;
+      out[slot] = value;
+      return Functor::cond_filter(value, data, iteration);
+    };
+    ++context.scratch_epoch;
+    mgx::transform_lbs_keep(visit_keep, edges, graph.d_scanned_row_offsets.data(), frontier_size, where.bits, context);
+    context.keep.data = out; context.keep.n = edges; context.keep.iteration = iteration;
+    context.keep.functor = &mgx::functor_tag_t<Functor>::id; context.keep.epoch = context.scratch_epoch; context.keep.valid = true;
+    return (int)edges;
+  }
   auto visit = [=] __device__(int slot, int segment, int rank) {
     const int v = frontier[segment];
     const int edge = row_start[v] + rank;
@@ -95,6 +126,7 @@ int advance_filter_fused_kernel(std::shared_ptr<Problem> problem, std::shared_pt
   // the append cursor lives in the scratch arena, behind the scan's partial sums
   unsigned long long* const cursor =
       (unsigned long long*)((char*)context.scratch + ((size_t)mgx::scan_num_tiles(frontier_size) + 2) * 8);
+  ++context.scratch_epoch;
   MGX_HIP(hipMemsetAsync(cursor, 0, sizeof(unsigned long long), context.stream()));
   auto visit_and_keep = [=] __device__(int slot, int segment, int rank) {
     const int v = frontier[segment];

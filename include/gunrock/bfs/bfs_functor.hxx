@@ -31,6 +31,8 @@ struct bfs_functor_t {
 
   // ---- filter: drop the slots of the edges that lost -------------------------------------------------------------
   static __device__ __forceinline__ bool cond_filter(int slot_value, slice_t*, int) { return slot_value != -1; }
+  // (the test looks at the slot's value alone: the advance that writes the slot may evaluate it, advance.hxx / filter.hxx)
+  static constexpr bool cond_filter_of_slot_value_only = true;
 
   // idempotent mode (the reference's uniquify path): relabel unless the vertex already carries a level of this or
   // an earlier superstep; vertex 0 is skipped there too (bfs_functor.hxx:13-24)

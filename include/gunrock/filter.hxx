@@ -18,7 +18,15 @@ int filter_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<frontier_t<i
   const int* const candidates = input->data()->data();
   typename Problem::data_slice_t* const slice = problem->d_data_slice.data();
   auto pass = mgx::transform_compact((long long)input->size(), context);
-  const long long kept = pass.upsweep([=] __device__(long long i) { return Functor::cond_filter(candidates[i], slice, iteration); });
+  // the advance that produced this very frontier may have evaluated cond_filter per slot already (advance.hxx: functors whose test
+  // looks at the slot's value alone) and left the ballots where this pass keeps its own: then the test is not run again
+  // ("exactly once per input element" holds either way) and the raw frontier is read only to copy the survivors
+  const mgx::standard_context_t::keep_record_t rec = context.keep;
+  context.keep.valid = false;
+  const bool ready = rec.valid && rec.data == (const void*)candidates && rec.n == (long long)input->size() && rec.iteration == iteration &&
+                     rec.functor == (const void*)&mgx::functor_tag_t<Functor>::id && rec.epoch == context.scratch_epoch;
+  const long long kept = ready ? pass.upsweep_from_bits()
+                               : pass.upsweep([=] __device__(long long i) { return Functor::cond_filter(candidates[i], slice, iteration); });
   output->resize((size_t)kept);
   int* const survivors = output->data()->data();
   pass.downsweep([=] __device__(long long to, long long from) { survivors[to] = candidates[from]; });

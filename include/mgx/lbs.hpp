@@ -98,6 +98,57 @@ __global__ __launch_bounds__(BLOCK) void k_transform_lbs(F f, long long count, c
   }
 }
 
+// The same enumeration with f returning a bool per work item: the answers of 64 consecutive items -- one wave instruction: item
+// idx sits in lane idx % 64 of the wave that handles items [idx & ~63, + 64) -- go to bits[idx / 64] as one ballot word, the
+// layout the stable compaction reads (scan.hpp: compact_t).  An advance whose functor says that its filter test depends on the
+// slot's value alone evaluates that test here, while the value is in a register: the filter behind it never reads the raw
+// frontier to decide, only to copy the survivors (gunrock/advance.hxx, filter.hxx).
+template <typename F>
+__global__ __launch_bounds__(BLOCK) void k_transform_lbs_keep(F f, long long count, const int* __restrict__ segments,
+                                                               long long num_segments, u64* __restrict__ bits) {
+  __shared__ int s_off[LBS_WINDOW];
+  __shared__ long long s_bounds[2];
+  for (long long tile = blockIdx.x; tile * LBS_TILE < count; tile += gridDim.x) {
+    const long long first = tile * LBS_TILE;
+    const long long last = (first + LBS_TILE < count ? first + LBS_TILE : count) - 1;
+    lbs_tile_t t = lbs_stage_tile(segments, num_segments, first, last, s_off, s_bounds);
+#pragma unroll
+    for (int k = 0; k < LBS_ITEMS; ++k) {
+      const long long idx = first + k * BLOCK + threadIdx.x;
+      bool keep = false;
+      if (idx <= last) {
+        long long seg;
+        int start;
+        if (t.nseg) {
+          const int j = upper_bound_small(s_off, t.nseg, (int)idx) - 1;
+          seg = t.seg_lo + j;
+          start = s_off[j];
+        } else {
+          const int* a = segments + t.seg_lo;
+          const int j = upper_bound_small(a, (int)(t.seg_hi - t.seg_lo + 1), (int)idx) - 1;
+          seg = t.seg_lo + j;
+          start = a[j];
+        }
+        keep = f((int)idx, (int)seg, (int)idx - start);
+      }
+      const u64 m = __ballot(keep);
+      const long long row_first = idx - lane_id();             // a multiple of 64 (tiles are 1024 items, rows 64)
+      if (lane_id() == 0 && row_first <= last) bits[row_first / 64] = m;
+    }
+    __syncthreads();   // s_off / s_bounds are reused by the next tile
+  }
+}
+
+template <typename F>
+inline void transform_lbs_keep(F f, long long count, const int* segments, long long num_segments, u64* bits,
+                               standard_context_t& ctx) {
+  if (count <= 0) return;
+  long long tiles = (count + LBS_TILE - 1) / LBS_TILE;
+  const long long cap = (long long)ctx.num_cus * 32;
+  hipLaunchKernelGGL(k_transform_lbs_keep<F>, dim3((unsigned)(tiles < cap ? tiles : cap)), dim3(BLOCK), 0, ctx.stream(), f,
+                     count, segments, num_segments, bits);
+}
+
 template <typename F>
 inline void transform_lbs(F f, long long count, const int* segments, long long num_segments,
                           standard_context_t& ctx) {
@@ -361,6 +412,7 @@ inline void lbs_segreduce(F f, long long count, const int* segments, long long n
   const long long tiles = (count + LBS_TILE - 1) / LBS_TILE;
   if (segreduce_scratch_bytes(count, sizeof(T)) > ctx.scratch_bytes)
     throw mgx_error(MGX_E_INVALID, "segreduce: scratch arena too small");
+  ++ctx.scratch_epoch;
   long long* carry_seg = (long long*)ctx.scratch;
   T* carry_val = (T*)(carry_seg + tiles * 2);
   MGX_HIP(hipMemsetAsync(carry_seg, 0xFF, (size_t)tiles * 2 * sizeof(long long), st));

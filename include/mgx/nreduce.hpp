@@ -289,6 +289,7 @@ inline void nr_full_frontier(const nr_layout_t& L, GetValue get, V* reduced, V i
                              long long* host_flag, u32* dev_flag, u32 epoch) {
   static_assert(sizeof(V) == 4, "the full-frontier neighbour-reduce is instantiated for 4-byte values only (neighborhood.hxx gates on it)");
   hipStream_t s = ctx.stream();
+  ++ctx.scratch_epoch;
   V* const vals = (V*)ctx.scratch;
   V* const partial = (V*)((char*)ctx.scratch + (((size_t)L.n + 64) * sizeof(V) + 255) / 256 * 256);
   static unsigned char seen[64] = {};

@@ -87,6 +87,12 @@ struct device_once_t {
 // ---------------------------------------------------------------------------
 // context: one device, one stream, a scratch arena, a pinned mailbox
 // ---------------------------------------------------------------------------
+// one address per functor type: how an operator names "the functor I was instantiated with" in a host-side record
+template <typename F>
+struct functor_tag_t { static const char id; };
+template <typename F>
+const char functor_tag_t<F>::id = 0;
+
 struct context_t {
   virtual ~context_t() {}
   virtual hipStream_t stream() const = 0;
@@ -118,6 +124,18 @@ struct standard_context_t : context_t {
   // (hipStreamSynchronize: ~10-20 us of runtime wake-up per operator call, two calls per superstep of an enactor) -- now it
   // spins on this word, which the producing kernel stores at system scope behind the count (MGX_OP_SPIN=0: the old wait)
   long long mailbox_seq = 0;
+  // The scratch arena is shared by every operator of the context; scratch_epoch counts who wrote it.  `keep` is what an advance
+  // left there for the filter behind it (gunrock/advance.hxx -> filter.hxx): the keep-ballots of its output slots, valid only for
+  // that very frontier, iteration and functor, and only while nobody else has touched the arena since.
+  unsigned long long scratch_epoch = 0;
+  struct keep_record_t {
+    const void* data = nullptr;
+    long long n = 0;
+    int iteration = 0;
+    const void* functor = nullptr;
+    unsigned long long epoch = 0;
+    bool valid = false;
+  } keep;
   bool mailbox_spin = true;
   int num_cus = 256;
   // single-pass scans (scan.hpp): one 64-bit status word per tile, tagged with the launch's epoch so that the array never

@@ -195,6 +195,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan_lookback(F f, long long n, int* 
 template <typename F>
 inline long long* transform_scan(F f, long long n, int* out, standard_context_t& ctx, long long* host_total) {
   const long long ntiles = scan_num_tiles(n);
+  ++ctx.scratch_epoch;
   long long* const partials = (long long*)ctx.scratch;
   long long* const d_total = partials + ntiles;
   if ((size_t)ntiles > ctx.lookback_tiles || (size_t)(ntiles + 2) * sizeof(long long) > ctx.scratch_bytes)
@@ -234,7 +235,8 @@ inline long long* transform_scan(F f, long long n, int* out, standard_context_t&
 // (element i <-> bit i%64 of word i/64), count per tile -- and, in the same launch, turn the tile counts into
 // exclusive prefixes by decoupled look-back (as k_scan_lookback: no one-workgroup pass over the partials, no
 // read-back copy: the last tile stores the kept count in the pinned mailbox).
-template <typename P>
+// FROM_BITS: the ballot words are there already (an advance left them: lbs.hpp, k_transform_lbs_keep) -- count them, pred is not called.
+template <typename P, bool FROM_BITS = false>
 __global__ __launch_bounds__(BLOCK) void k_compact_upsweep(P pred, long long n, u64* __restrict__ bits,
                                                             long long* __restrict__ partials, unsigned long long* status,
                                                             unsigned* ticket, unsigned ticket_base, unsigned epoch,
@@ -253,12 +255,16 @@ __global__ __launch_bounds__(BLOCK) void k_compact_upsweep(P pred, long long n, 
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; ++k) {
     const long long i = base + k * BLOCK + threadIdx.x;
-    bool keep = false;
-    if (i < n) keep = pred(i);
-    const u64 m = __ballot(keep);
-    if (lane_id() == 0 && (base + k * BLOCK + (threadIdx.x / WAVE) * WAVE) < n) {
-      bits[i / 64] = m;   // i is this wave-row's first element, a multiple of 64
-      cnt += __popcll(m);
+    if constexpr (FROM_BITS) {
+      if (lane_id() == 0 && i < n) cnt += __popcll(bits[i / 64]);      // (i: this wave-row's first element, a multiple of 64)
+    } else {
+      bool keep = false;
+      if (i < n) keep = pred(i);
+      const u64 m = __ballot(keep);
+      if (lane_id() == 0 && (base + k * BLOCK + (threadIdx.x / WAVE) * WAVE) < n) {
+        bits[i / 64] = m;   // i is this wave-row's first element, a multiple of 64
+        cnt += __popcll(m);
+      }
     }
   }
   if (lane_id() == 0) sm[threadIdx.x / WAVE] = cnt;
@@ -331,16 +337,22 @@ struct compact_t {
     partials = (long long*)ctx.scratch;
     bits = (u64*)(((uintptr_t)(partials + ntiles + 2) + 255) & ~(uintptr_t)255);
   }
+  struct no_pred_t { __device__ bool operator()(long long) const { return false; } };
+  // the ballots are in `bits` already (transform_lbs_keep): counts, prefixes and the kept total only
+  long long upsweep_from_bits() { return upsweep_impl<no_pred_t, true>(no_pred_t()); }
   // returns the kept count (blocking 8-byte read-back, as mgpu's upsweep does)
   template <typename P>
-  long long upsweep(P pred) {
+  long long upsweep(P pred) { return upsweep_impl<P, false>(pred); }
+  template <typename P, bool FROM_BITS>
+  long long upsweep_impl(P pred) {
     hipStream_t st = ctx.stream();
+    ++ctx.scratch_epoch;
     if (n <= 0) return 0;
     if ((size_t)ntiles > ctx.lookback_tiles) throw mgx_error(MGX_E_INVALID, "compact: scratch arena too small");
     const bool single = ntiles <= SCAN_LOOKBACK_MAX_TILES;       // (see transform_scan)
     const unsigned epoch = single ? ctx.next_lookback_epoch() : 0u;
     const long long seq = ++ctx.mailbox_seq;
-    hipLaunchKernelGGL(k_compact_upsweep<P>, dim3((unsigned)ntiles), dim3(BLOCK), 0, st, pred, n, bits, partials,
+    hipLaunchKernelGGL((k_compact_upsweep<P, FROM_BITS>), dim3((unsigned)ntiles), dim3(BLOCK), 0, st, pred, n, bits, partials,
                        single ? ctx.lookback_status : (unsigned long long*)nullptr, ctx.lookback_ticket, ctx.lookback_ticket_base,
                        epoch, ctx.mailbox, seq);
     if (single) ctx.lookback_ticket_base += (unsigned)ntiles;
