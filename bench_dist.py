@@ -245,6 +245,63 @@ def bench_single_sharded(args, ctx, shards):
         sys.exit(1)
 
 
+def _measure_replicas(args, rank, world, ctx, device, stream):
+    """The other way to use N GPUs for a graph that fits ONE (RMAT-22: 2 GB with its layout): every rank holds the whole graph and
+    takes its share of the K sources -- no data-path collective at all ("replicas").  Not what the line's `value` measures (that is
+    ONE traversal at a time over the partitioned graph, the north star's shape); reported beside it so that a scaling run shows
+    both.  Collective-safe: whatever happens locally, every rank reaches the same two reductions."""
+    import mini_amd
+    from mini_amd import rmat
+    ok, elapsed, m_t, parity = 1, 0.0, 0, 1
+    try:
+        seed = args.scale if args.seed is None else args.seed
+        g = rmat.rmat_csr(ctx, args.scale, args.edgefactor, seed=seed, weighted=False)
+        graph = mini_amd.Graph.from_device(ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"])
+        graph.build_layout()
+        ro_host = g["row_offsets"].cpu().numpy()
+        sources = rmat.pick_sources(ro_host, args.steps + args.warmup, seed)
+        mine = [int(s) for s in sources[args.warmup:][rank::world]]
+        bfs = mini_amd.BfsProblem(graph, sources[0])
+        for s in sources[:max(args.warmup, 1)]:
+            bfs.run(int(s))
+        if mine:
+            bfs.run_many(mine[:2])
+        torch.cuda.synchronize()
+    except Exception as ex:                                   # noqa: BLE001 -- reported through the reduction below
+        print("[rank %d] replicas: %r" % (rank, ex), file=sys.stderr, flush=True)
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int64, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) != 1:
+        return None
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    try:
+        if mine:
+            sts, _ = bfs.run_many(mine)
+            m_t = sum(st["m_t"] for st in sts)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if rank == 0 and mine and not args.no_check:
+            from tests.oracle_binding import Oracle
+            want = Oracle().bfs_cpu(ro_host, g["col_indices"].cpu().numpy(), mine[-1])
+            parity = int(np.array_equal(bfs.labels(), want))
+    except Exception as ex:                                   # noqa: BLE001
+        print("[rank %d] replicas: %r" % (rank, ex), file=sys.stderr, flush=True)
+        ok = 0
+    t = torch.tensor([elapsed if ok else 1e30, float(m_t), float(parity if ok else 0)], dtype=torch.float64, device=device)
+    tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    tmin = t.clone(); dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+    if float(tmax[0]) >= 1e29:
+        return None
+    return {"workload": "the same %d seeded sources dealt round-robin to the %d ranks, every rank traverses ITS sources on its own copy of the "
+                        "whole RMAT-%d graph (fused single-GPU engine, one batch per rank); no data-path collective" % (args.steps, world, args.scale),
+            "value": round(float(tsum[1]) / float(tmax[0]) / 1e6, 2), "unit": "MTEPS", "ms_per_step": round(float(tmax[0]) * 1e3 / max(args.steps, 1), 4),
+            "scaling": "weak in sources per GPU, none in graph size", "parity_vs_oracle": bool(int(tmin[2]) == 1) if not args.no_check else None}
+
+
 def bench_main(args, rank, world, local_rank):
     """bench.py body for N > 1 (one process per GPU, RCCL).  --scaling strong (default): the SAME RMAT-<scale> graph
     partitioned over the N GPUs (the metric's "RMAT-22 @1/2/4/8"; --scale 26 at N = 8 is BASELINE config 5);
@@ -266,6 +323,9 @@ def bench_main(args, rank, world, local_rank):
     if (want5 == "1" or (want5 == "auto" and world == 8 and gscale == 22)) and not weak and r["parity"] is not False:
         c5_scale = int(os.environ.get("MGX_BENCH_CONFIG5_SCALE", "26"))
         c5 = _measure(args, rank, world, local_rank, ctx, device, c5_scale, min(args.steps, 16), 1, False)
+    rep = None
+    if os.environ.get("MGX_BENCH_REPLICAS", "auto") != "0" and not weak and dist.get_backend() == "nccl" and gscale <= 24:
+        rep = _measure_replicas(args, rank, world, ctx, device, stream)
     m_t, elapsed, levels, parity, ranks_seen = r["m_t"], r["elapsed"], r["levels"], r["parity"], r["ranks_seen"]
     if c5 is not None and c5["parity"] is False:
         parity = False
@@ -294,6 +354,8 @@ def bench_main(args, rank, world, local_rank):
                "rccl_ranks": ranks_seen, "collective_backend": dist.get_backend(),
                "avg_levels": round(levels / max(args.steps, 1), 2),
                "graph_build_s": round(r["t_build"], 2)}
+        if rep is not None:
+            out["replicas"] = rep
         if c5 is not None:
             v5 = c5["m_t"] / c5["elapsed"] / 1e6
             out["config5"] = {"workload": "BASELINE config 5: BFS on RMAT scale %d ef %d, cyclic vertex partition over %d GPUs (%s), %d seeded "

@@ -509,6 +509,7 @@ struct d2_state_t {
   int fused_merge = 1;                // OR-merge inside the queue build (MGX_DIST_FUSED_MERGE)
   int build_list = 0;                 // the list-based queue build (MGX_DIST_BUILD_LIST)
   int push_split = 0;                 // measurements: the push grid's three parts as three launches (MGX_DIST_PUSH_SPLIT)
+  u32 grid_div = 1;                   // the push grid's long-row and short-row halves get 2 x CUs / grid_div workgroups each (MGX_DIST_GRID_DIV)
   bool skip_small_reduce = false;     // d2_run's plan: no k_d2_cold_reduce launch on the levels it expects to be merged from id lists
   mem_t<u32> defer_buf;               // deferred hot marks of the push workgroups (bfs_hot_epilogue): BFS_FLUSH_MAX bitmaps; empty: nothing is deferred (MGX_DIST_DEFER=0)
   // ... and only on a shard big enough to pay for the 80 KB bitmap every deferring workgroup writes and the reduce behind it:
@@ -551,6 +552,7 @@ struct d2_state_t {
     if (const char* e = getenv("MGX_DIST_FUSED_MERGE")) fused_merge = atoi(e);
     if (const char* e = getenv("MGX_DIST_BUILD_LIST")) build_list = atoi(e);
     if (const char* e = getenv("MGX_DIST_PUSH_SPLIT")) push_split = atoi(e);
+    if (const char* e = getenv("MGX_DIST_GRID_DIV")) grid_div = (u32)atoi(e);
     {
       int defer = 1;
       if (const char* e = getenv("MGX_DIST_DEFER")) defer = atoi(e);
@@ -666,7 +668,7 @@ inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx, bool wan
     bfs_launch_push(a, level, ctx, 0 | ((1 | 4) << 4), bfs_cold_test(a.n, st.cold_forced));
     bfs_launch_push(a, level, ctx, 0 | ((1 | 2) << 4), bfs_cold_test(a.n, st.cold_forced));
   } else
-  bfs_launch_push(a, level, ctx, 2, bfs_cold_test(a.n, st.cold_forced));   // (the level's bookkeeping rides on the push launch)
+  bfs_launch_push(a, level, ctx, 2, bfs_cold_test(a.n, st.cold_forced), st.grid_div);   // (the level's bookkeeping rides on the push launch)
   d2_cold_view_t cv = st.cold_view();
   u32* const dbuf = a.flush_buf;
   // The stream reduce of the cold pass's bitmaps in front of the sweep -- not on a level the plan expects to be sparse (want_list:

@@ -327,9 +327,13 @@ inline void bfs_launch_push_part(const bfs_fused_args_t& a, int arg, standard_co
 }
 
 // explicit-level push of the partitioned path
-inline void bfs_launch_push(const bfs_fused_args_t& a, int level, standard_context_t& ctx, int open_here, bool coldt) {
-  const u32 nstream = a.long_min > 0 ? (u32)ctx.num_cus * 2 : 0u;
-  const u32 nwave = (u32)ctx.num_cus * 2;
+inline void bfs_launch_push(const bfs_fused_args_t& a, int level, standard_context_t& ctx, int open_here, bool coldt, u32 grid_div = 1) {
+  // (grid_div: a rank with a small shard takes fewer, fatter workgroups -- every one of them copies 80 KB of bitmap into LDS first)
+  if (grid_div < 1u) grid_div = 1u;
+  u32 per = (u32)ctx.num_cus * 2 / grid_div;
+  if (per < 32u) per = 32u;
+  const u32 nstream = a.long_min > 0 ? per : 0u;
+  const u32 nwave = per;
   const u32 ncold = a.cold_dst ? a.cold_wgs[a.cold_slices] : 0u;
   if (coldt) hipLaunchKernelGGL(k_bfs_push_level<true>, dim3(ncold + nstream + nwave), dim3(1024), bfs_push_lds_bytes(), ctx.stream(), a, level, nstream, open_here, ncold);
   else hipLaunchKernelGGL(k_bfs_push_level<false>, dim3(ncold + nstream + nwave), dim3(1024), bfs_push_lds_bytes(), ctx.stream(), a, level, nstream, open_here, ncold);

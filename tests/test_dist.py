@@ -524,6 +524,8 @@ def test_bench_main_native_rccl_loop_one_rank(built, exchange, collectives):
                                                 "MGX_DIST_FORCE_COLLECTIVES": collectives, "MGX_DIST_EXCHANGE": exchange})
     assert j["n_gpus"] == 1 and j["parity_vs_oracle"] is True and j["value"] > 0
     assert j["config"]["native_loop"] is True
+    # ... and beside the partitioned figure the replicas mode (every rank its own copy of the graph and its share of the sources)
+    assert j["replicas"]["value"] > 0 and j["replicas"]["parity_vs_oracle"] is True
 
 
 @pytest.mark.gpu

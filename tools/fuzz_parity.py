@@ -59,12 +59,43 @@ def graphs():
 def partitioned_labels(n, ro, ci, src, G, mode):
     """generation-2 partitioned BFS with G rank engines in this process (the collectives as copies): global labels in
     original ids"""
-    from mini_amd.dist_bfs import HipRankEngine2, cyclic_shard_from_csr
+    from mini_amd.dist_bfs import HipRankEngine2, LoopbackComm, cyclic_shard_from_csr, run_rank_threads
     engs, maps = [], None
+    # (round 5) "native": the C++ loop itself over all engines in turn (mgx_dbfs2_run_group: level plan, freeze, continuation);
+    # "loopback": mgx_dbfs2_run on G rank THREADS over the in-process communicator, an engine and a stream each
+    ctxs = [mini_amd.Context(0, torch.cuda.Stream().cuda_stream) for _ in range(G)] if mode == "loopback" else [ctx] * G
     for r in range(G):
         ro_l, ci_l, new_of_old, old_of_new = cyclic_shard_from_csr(ro, ci, G, r)
-        engs.append(HipRankEngine2(ctx, n, G, r, torch.from_numpy(ro_l).cuda(), torch.from_numpy(ci_l).cuda()))
+        engs.append(HipRankEngine2(ctxs[r], n, G, r, torch.from_numpy(ro_l).cuda(), torch.from_numpy(ci_l).cuda()))
+    torch.cuda.synchronize()
     s_new = int(new_of_old[src])
+    if mode in ("native", "loopback"):
+        d = np.diff(ro)
+        # a leaf first (its plan expects sparse early levels), then the biggest hub (which overflows a list against that plan: a
+        # frozen traversal), then the source that is checked -- under the plan the two before it left
+        warm = [int(np.argmin(np.where(d > 0, d, 1 << 30))), int(np.argmax(d))]
+        comms = None
+        if mode == "loopback":
+            ident = LoopbackComm.new_id()
+            comms = run_rank_threads(G, lambda r: LoopbackComm(ctxs[r], r, G, ident))
+        exch = str(rng.choice(["gather", "reduce"]))
+        for s_old in warm + [src]:
+            s2 = int(new_of_old[s_old])
+            if mode == "native":
+                sts = HipRankEngine2.run_group(engs, s2)
+            else:
+                sts = run_rank_threads(G, lambda r: engs[r].run_native(s2, comms[r], exch))
+            assert all(st["over"] for st in sts) and len({st["levels"] for st in sts}) == 1, sts
+        if comms:
+            for c in comms:
+                c.close()
+        lab_new = np.empty(n, dtype=np.int32)
+        for r, e in enumerate(engs):
+            lab_new[r::G] = e.labels()
+            e.close()
+        out = np.empty(n, dtype=np.int32)
+        out[old_of_new] = lab_new
+        return out
     for e in engs:
         e.reset(s_new)
     level = 0
@@ -165,7 +196,7 @@ for name, n, ro, ci, w in graphs():
             # the partitioned engine's rank engines in this process: small graphs, and R-MAT 20 / 21 (the ranks' cold-edge pass);
             # unit blocks forced onto every eligible level or by the default rule
             G = int(rng.choice([2, 3, 5, 8])) if n <= 150000 else 2
-            mode = str(rng.choice(["gather", "reduce", "lists"]))
+            mode = str(rng.choice(["gather", "reduce", "lists", "native", "native", "loopback"]))
             dd = str(rng.choice(["", "1000000"]))
             if dd:
                 os.environ["MGX_DIST_DENSE_DIV"] = dd
