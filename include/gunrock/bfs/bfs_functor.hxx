@@ -25,6 +25,9 @@ struct bfs_functor_t {
     // The operators call this for EVERY edge (advance.hxx:57-58).  A label only ever goes from -1 to a level, so a
     // plain read that does not see -1 already is the answer the CAS would give; device-scope atomics run at the
     // memory side on MI355X (~25 G/s), and nine edges in ten of an R-MAT traversal point at labelled vertices.
+    // (Round 5, tried and dropped: a visited BITMAP beside the labels -- 512 KB, L2-resident -- probed before the label: 2.49 against
+    //  2.21 ms per RMAT-22 traversal on the operator path.  Within a level the bit of a vertex another XCD has just labelled is not
+    //  in this XCD's L2 yet, so the level that carries the edges pays both probes for two edges in five.)
     int* const label = d->d_labels + dst;
     return *label == -1 && atomicCAS(label, -1, iteration + 1) == -1;
   }
