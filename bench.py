@@ -212,7 +212,7 @@ def main():
 def _pmc_traffic(args, kname, sha):
     """roofline.traffic from the committed PMC passes -- only when they were taken on exactly these sources"""
     traffic, note = None, "no PMC measurement for these sources (profiles/pmc_traffic.json)"
-    if os.path.exists(args.pmc_json) and not args.file:
+    if os.path.exists(args.pmc_json) and not args.file and getattr(args, "graph", "rmat") == "rmat":
         try:
             pj = json.load(open(args.pmc_json))
             entries = pj.get("entries", [pj])

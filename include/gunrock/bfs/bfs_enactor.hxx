@@ -204,6 +204,7 @@ struct bfs_fused_enactor_t {
         layout.cold_hot_n = g.cold_hot_n;
         layout.cold_long_min = g.cold_long_min;
       }
+      layout.cold_majority = g.cold_majority;
       if (g.src_shapes.size() == (size_t)g.num_nodes * 4) {
         layout.src_shapes = g.src_shapes.data();
         layout.src_shapes_long_min = g.src_shapes_long_min;

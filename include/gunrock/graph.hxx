@@ -115,6 +115,7 @@ struct graph_device_t {
   unsigned cold_lo[64] = {0}, cold_off[65] = {0}, colds_off[65] = {0}, cold_wgs[65] = {0};     // (mgx::BFS_COLD_MAX_SLICES)
   unsigned cold_hot_n = 0;
   int cold_long_min = 0;
+  bool cold_majority = false;         // the long rows' entries behind the LDS prefix were too many for lists (more than a quarter of them): a FLAT graph
   // Destination-sliced edge list of the weighted layout (mgx/sssp_fused.hpp: sssp_sliced_body): (src, dst, w) triples
   // ordered by dst >> 14; built at the first fused SSSP run of a graph that carries layout weights.
   mem_t<int> d_e_src, d_e_dst, d_slice_off;

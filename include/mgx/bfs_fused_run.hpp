@@ -60,6 +60,7 @@ struct bfs_layout_t {
            cold_wgs[BFS_COLD_MAX_SLICES + 1] = {0};
   unsigned cold_hot_n = 0;
   int cold_long_min = 0;
+  bool cold_majority = false;         // more than a quarter of the long rows' entries point behind the LDS prefix (no lists were built): a flat graph
   // HOST table, by ORIGINAL vertex id, 4 words per vertex (graph_device_t::src_shapes): what a traversal from v starts with
   const unsigned* src_shapes = nullptr;
   int src_shapes_long_min = 0;
@@ -395,7 +396,9 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   // vertices and nearly every endpoint lies behind it -- the layout built no cold-edge lists (they would be most of the graph), so
   // the unit-block body would mark six entries in seven untested, a byte store each.  Probing the bitmap (512 KB: it lives in the
   // L2s) wins there: 1.35 against 2.02 ms per traversal.
-  const bool flat = units_avail && (u32)a.n > (u32)(BFS_DENSE_HOTW * 32) && !(layout->cold_dst && layout->cold_slices > 0);
+  // (the layout says so: it counted the long rows' cold entries and found more than a quarter of them cold.  NOT "no lists": RMAT-20
+  //  has none either -- a handful of cold entries -- and lost 19 % to this rule while it read "no lists": 0.1915 -> 0.2272 ms)
+  const bool flat = units_avail && layout->cold_majority;
   const bool coldt = opt.cold_test >= 0 ? opt.cold_test != 0 : ((bfs_cold_test(a.n, -1) && !units_avail) || flat);
   const bool units = units_avail && !coldt;
   a.ub_col = units ? layout->ub_col : nullptr;
@@ -613,7 +616,10 @@ inline void bfs_learn_slots(bfs_fused_state_t& st, const bfs_fused_args_t& a, co
     if (need_cls > st.cls_max[cls]) st.cls_max[cls] = need_cls;
     st.cls_at[cls] += 1;
   }
-  const int need = slots_needed(true);                        // ... and the graph-wide sequence, whoever ran
+  int need = slots_needed(true);                              // ... and the graph-wide sequence, whoever ran
+  // (a traversal deeper than the trace the host holds -- 64 levels: a grid, a road network -- needed what the device counted: its
+  //  first levels, all small, say nothing about the thousands behind them)
+  if (hc->levels > L && hc->slots > need) need = hc->slots;
   st.recent_need[st.recent_at & 3] = need;
   st.recent_at += 1;
   int hint = 1;

@@ -415,7 +415,7 @@ extern "C" int mgx_cold_pack_device(const int* owner, const int* dst, int used, 
 static void build_cold_lists(mgx_graph_s* g) {
   graph_device_t& G = *g->g;
   G.d_cold_owner = mem_t<int>(); G.d_cold_dst = mem_t<int>(); G.d_colds_owner = mem_t<int>(); G.d_colds_dst = mem_t<int>();
-  G.cold_pairs = G.colds_pairs = 0; G.cold_slices = 0; G.cold_hot_n = 0; G.cold_long_min = 0;
+  G.cold_pairs = G.colds_pairs = 0; G.cold_slices = 0; G.cold_hot_n = 0; G.cold_long_min = 0; G.cold_majority = false;
   bool with_short = false;                                         // (lab builds, MGX_BFS_COLD_LISTS=2: also the short rows' list -- measured equal)
   if (const char* e = getenv("MGX_BFS_COLD_LISTS")) {
     if (atoi(e) == 0) return;
@@ -439,7 +439,7 @@ static void build_cold_lists(mgx_graph_s* g) {
   if (pairs <= 0) return;
   mem_t<int> d_owner = mem_t<int>::adopt(owner, (size_t)pairs + 256), d_dst = mem_t<int>::adopt(dst, (size_t)pairs + 256);
   const long long long_entries = (long long)G.ub_units * 64;       // (padded: an upper bound of the long rows' entries)
-  if (pairs * 4 > long_entries) return;
+  if (pairs * 4 > long_entries) { G.cold_majority = true; return; }     // (a flat graph: the fused BFS probes the bitmap instead, bfs_fused_run.hpp)
   // the short rows' cold entries
   int *owner_s = nullptr, *dst_s = nullptr;
   long long pairs_s = 0;
