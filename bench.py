@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--graph", choices=["rmat", "uniform", "grid2d"], default="rmat",
                     help="synthetic input: rmat (BASELINE's), uniform = edgefactor * 2^scale uniformly random pairs, symmetrised (no hubs), "
                          "grid2d = a 2^(scale/2) x 2^(scale/2) 4-neighbour grid (thousands of levels); built on the device, seeded")
+    ap.add_argument("--shards", type=int, default=0,
+                    help="push, 1 GPU: run the graph as this many cyclic vertex shards in turn (the RMAT-26 path) whatever its size")
     ap.add_argument("--file", default=None, help="MatrixMarket file instead of the synthetic R-MAT")
     ap.add_argument("--undirected", action="store_true", help="--file: append the swapped copy of every entry")
     ap.add_argument("--src", type=int, default=None, help="source vertex (default: seeded sources; --file: 0)")
@@ -195,10 +197,10 @@ def main():
 
     stream = torch.cuda.current_stream()
     ctx = mini_amd.Context(local_rank, stream.cuda_stream)
-    if args.mode == "push" and not args.file and (2 * args.edgefactor << args.scale) >= (1 << 31):
+    if args.mode == "push" and not args.file and args.graph == "rmat" and ((2 * args.edgefactor << args.scale) >= (1 << 31) or args.shards > 1):
         # more CSR entries than int32 row offsets hold (RMAT-26): the graph as shards of < 2^31 entries, in turn on this GPU
         import bench_dist
-        shards = 2
+        shards = max(2, args.shards)
         while (2 * args.edgefactor << args.scale) // shards >= (1 << 31):
             shards *= 2
         return bench_dist.bench_single_sharded(args, ctx, shards)
@@ -486,6 +488,10 @@ def bench_bfs(args, ctx, stream):
            "avg_levels": round(sum(st["levels"] for st in stats) / K, 2),
            "avg_slots": round(sum(st["slots"] for st in stats) / K, 2),
            "avg_reached": reached // K, "graph_build_s": round(t_build, 2), "layout_build_s": round(t_layout, 2),
+           "layout": (dict(graph.layout_info(), csr_bytes=4 * (n + 1) + 4 * m,
+                           note="what the fast path keeps beside the CSR (mgx_graph_layout_info): hub-first copy, id maps, unit blocks and their "
+                                "24-bit copy, cold-edge lists, the unit blocks without the lists' entries; device_bytes sums them")
+                      if use_layout else None),
            "source_sha": sha}
     print(json.dumps(out), flush=True)
     if parity is False:

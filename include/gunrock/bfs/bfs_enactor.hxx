@@ -203,6 +203,10 @@ struct bfs_fused_enactor_t {
         layout.colds_dst = g.colds_pairs > 0 ? g.d_colds_dst.data() : nullptr;
         layout.cold_hot_n = g.cold_hot_n;
         layout.cold_long_min = g.cold_long_min;
+        if (g.ubh_units > 0 && g.d_ubh_col24.size() && g.d_ubh_owner.size()) {
+          layout.ubh_col24 = g.d_ubh_col24.data(); layout.ubh_owner = g.d_ubh_owner.data();
+          layout.ubh_units = g.ubh_units; layout.ubh_units_pad = g.ubh_units_pad;
+        }
       }
       layout.cold_majority = g.cold_majority;
       if (g.src_shapes.size() == (size_t)g.num_nodes * 4) {

@@ -79,6 +79,12 @@ struct graph_device_t {
   mem_t<unsigned> d_ub_col24;
   mem_t<int> d_ub_owner;
   long long ub_units = 0, ub_units_pad = 0;
+  // The unit blocks of the fused BFS when the graph carries cold-edge lists: the same rows WITHOUT the entries that live in the
+  // lists (the unit-block body would read them only to skip them), 24 bits per entry whatever the graph's size -- what is left
+  // points into the LDS prefix.  Owners of their own (fewer units per row).  Empty: not built.
+  mem_t<unsigned> d_ubh_col24;
+  mem_t<int> d_ubh_owner;
+  long long ubh_units = 0, ubh_units_pad = 0;
   int ub_min_degree = 0;
   mem_t<float> d_ub_w;               // weights of the unit blocks' entries (fused SSSP's heavy iterations); built on first use
   mem_t<unsigned short> d_ub_w16;    // the same weights as IEEE halves, kept only when every one of them is exact that way (fused SSSP's sweep, 24-bit entries)

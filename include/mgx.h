@@ -87,6 +87,11 @@ MGX_API int mgx_graph_attach_layout_weights(mgx_graph_t g, const float* d_layout
  * along for the fused SSSP loop.  mgx_graph_layout_read copies the pieces to host buffers (NULL: skip; sizes n + 1,
  * m, n, n, m) -- what the tests compare with the torch construction in mini_amd/rmat.py. */
 MGX_API int mgx_graph_build_layout(mgx_graph_t g, int with_weights);
+/* What the layout holds: out8 = { 1 if the graph has one, unit blocks (64-entry units of the long rows), 1 if their 24-bit copy
+ * exists, pairs of the cold-edge lists, slices that hold pairs, units of the blocks WITHOUT the lists' entries (the fused BFS reads
+ * those when it runs the cold-edge pass), 1 if the long rows' entries were mostly cold (no lists: a flat graph), bytes of device
+ * memory the library allocated for the layout and everything cut from it (arrays the caller attached are not counted) }. */
+MGX_API int mgx_graph_layout_info(mgx_graph_t g, int64_t* out8);
 MGX_API int mgx_graph_layout_read(mgx_graph_t g, int* h_row_offsets, int* h_col_indices, int* h_new_of_old,
                                   int* h_old_of_new, float* h_weights);
 /* Genuine CSC (the transpose) built by the library from the graph's own CSR, device-side (one stable radix sort of the

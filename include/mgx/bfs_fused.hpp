@@ -151,6 +151,12 @@ struct bfs_fused_args_t {
   const int* ub_owner;     // units_pad owners (vertex id in the space of row_offsets; n for padding units)
   u32 ub_units;            // real units
   u32 ub_units_pad;        // multiple of 16
+  u32 ub_hot_only;         // ub_col24 / ub_owner / ub_units_pad are the blocks WITHOUT the entries of the cold-edge lists: for the slots that run
+                           // the cold-edge pass.  A slot that reads unit blocks without the pass (a sparse level behind a lazy build) takes the
+                           // full blocks: ub_col (32 bits) or ubf_col24, ubf_owner, ubf_units_pad (bfs_dense_body)
+  const u32* ubf_col24;
+  const int* ubf_owner;
+  u32 ubf_units_pad;
   u32 dense_div;           // a slot reads its long rows from the unit blocks when frontier units * dense_div >= ub_units (0: never)
   // short rows vertex by vertex (bfs_fused_vshort.hpp; needs a degree-sorted CSR with 8 readable ints behind col_indices)
   u32 vs_v[4];             // class boundaries: [0]..[1] degrees 17..long_min-1, [1]..[2] 5..16, [2]..[3] 1..4
@@ -1087,6 +1093,7 @@ struct bfs_run_opts_t {
   int vshort = -1;         // MGX_BFS_VSHORT: 0 never, N > 0 vshort_div = N
   long long chain = -1;    // MGX_BFS_CHAIN_MAX_EDGES: 0 never (default BFS_CHAIN_CAP)
   int pack24 = 1;                     // MGX_BFS_PACK24=0
+  int hot_units = 1;                  // MGX_BFS_HOT_UNITS=0: the full unit blocks even when the layout carries the ones without the cold entries
   int cold_pack = 1;                  // MGX_BFS_COLD_PACK=0: the cold-edge pass reads its pairs at eight bytes each: the unit-block body reads the 32-bit entries even when the graph carries the 24-bit copy
   int src_plan = 1;                   // MGX_BFS_SRC_PLAN=0: every traversal gets the same launch sequence (no per-source classes)
   int defer_words = -1;               // MGX_BFS_DEFER_WORDS: words of the bitmap prefix whose marks are deferred (default: all BFS_FLUSH_WORDS)
@@ -1132,6 +1139,7 @@ struct bfs_run_opts_t {
     geti("MGX_BFS_SRC_PLAN", o.src_plan);
     geti("MGX_BFS_PACK24", o.pack24);
     geti("MGX_BFS_COLD_PACK", o.cold_pack);
+    geti("MGX_BFS_HOT_UNITS", o.hot_units);
     geti("MGX_BFS_COLD", o.cold);
     if (const char* e = getenv("MGX_BFS_DEFER_REACH")) {
       o.defer_mul = atoi(e);

@@ -71,24 +71,34 @@ __device__ __forceinline__ u32* bfs_hot_setup(const bfs_fused_args_t& a, char* s
   return hot;
 }
 
+// the blocks a pass reads: entries at 32 or at 24 bits, owners, units (padded to a multiple of 16)
+struct bfs_units_view_t {
+  const int* col;
+  const u32* col24;
+  const int* owner;
+  u32 units_pad;
+};
+
 // the unit-block pass of one workgroup (block `block` of `nblocks`) over an LDS prefix that is already set up
-// P24: the entries come from the 24-bit copy of the unit blocks (a.ub_col24; graphs of at most 2^23 vertices): 12 bytes per
-// lane and load instead of 16, unpacked when they are tested
+// P24: the entries come from a 24-bit copy of the unit blocks (ub.col24: the full blocks of a graph of at most 2^23 vertices, or the
+// blocks without the cold-edge lists' entries, whose ids lie inside the LDS prefix): 12 bytes per lane and load instead of 16,
+// unpacked when they are tested
+
 template <int NT, int HOTW, int GPS, bool P24 = false>
-__device__ __forceinline__ void bfs_dense_work(const bfs_fused_args_t& a, u32* const hot, u32 hot_n, u32 defer_n, u32 block,
+__device__ __forceinline__ void bfs_dense_work(const bfs_fused_args_t& a, const bfs_units_view_t ub, u32* const hot, u32 hot_n, u32 defer_n, u32 block,
                                                u32 nblocks, int& marks) {
   constexpr int NW = NT / WAVE;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
   const int lane = lane_id();
   unsigned char* __restrict__ mark = a.mark;
-  const int* __restrict__ ucol = a.ub_col;
-  const int* __restrict__ owner = a.ub_owner;
+  const int* __restrict__ ucol = ub.col;
+  const int* __restrict__ owner = ub.owner;
   const u32* __restrict__ fbits = a.frontier_bits;
   const int diag = MGX_LAB_GET(a, dense_diag, 0);     // MGX_BFS_DENSE_DIAG (measurements; results are wrong by design): 1 no mark stores, 2 no test
-  const u32 G = a.ub_units_pad / BFS_DENSE_GROUP;              // groups of 16 units
+  const u32 G = ub.units_pad / BFS_DENSE_GROUP;                // groups of 16 units
   const u32 W = nblocks * NW;                                  // waves of the grid
   const u32 w = block * NW + (u32)wave;
-  const u32 dummy = a.ub_units_pad << 6;                       // entry index of the four -1
+  const u32 dummy = ub.units_pad << 6;                         // entry index of the four -1
   const u32 lane_unit = (u32)lane & 15u;                       // my unit inside its group, for the owner load ...
   const u32 lane_grp = (u32)lane >> 4;                         // ... and which of the batch's 4 groups
   const u32 lane_q = (u32)lane >> 4;                           // col loads: lane l reads entries 4l..4l+3 of a 256-entry chunk = unit l >> 4 of the chunk
@@ -112,7 +122,7 @@ __device__ __forceinline__ void bfs_dense_work(const bfs_fused_args_t& a, u32* c
     constexpr int NL = 4 * GPS;               // loads per step
     typedef typename std::conditional<P24, bfs_u32x3, bfs_u32x4>::type raw_t;     // what a lane's load returns
     raw_t dL[NL], dT[NL];
-    const u32* __restrict__ ucol24 = a.ub_col24;
+    const u32* __restrict__ ucol24 = ub.col24;
     // issue the 16-byte loads of groups k .. k + GPS - 1 of a batch whose activity bits are `act`
     auto issue = [&](u32 b, u32 k, u64 act) {
 #pragma unroll
@@ -221,8 +231,11 @@ __device__ __forceinline__ void bfs_dense_body(const bfs_fused_args_t& a, int sl
   const u32 hot_n = ((u32)a.n < (u32)(HOTW * 32)) ? (u32)a.n : (u32)(HOTW * 32);
   const u32 defer_n = bfs_defer_limit(a, hot_n);      // marks of the vertices in [0, defer_n) wait for the end of the workgroup
   int marks = 0;
-  if (a.ub_col24) bfs_dense_work<NT, HOTW, GPS, true>(a, hot, hot_n, defer_n, block, nblocks, marks);      // (grid-uniform)
-  else bfs_dense_work<NT, HOTW, GPS, false>(a, hot, hot_n, defer_n, block, nblocks, marks);
+  // (grid-uniform) the blocks without the cold-edge lists' entries are for the slots that run the cold-edge pass
+  bfs_units_view_t ub{a.ub_col, a.ub_col24, a.ub_owner, a.ub_units_pad};
+  if (a.ub_hot_only && !cold) { ub.col24 = a.ubf_col24; ub.owner = a.ubf_owner; ub.units_pad = a.ubf_units_pad; }
+  if (ub.col24) bfs_dense_work<NT, HOTW, GPS, true>(a, ub, hot, hot_n, defer_n, block, nblocks, marks);
+  else bfs_dense_work<NT, HOTW, GPS, false>(a, ub, hot, hot_n, defer_n, block, nblocks, marks);
   (void)bfs_hot_epilogue<NT>(a, hot, (defer_n + 31u) >> 5, slot, s_int + 4, marks);
   bfs_body_finish(a, marks, slot, stat_level, s_int);
 }

@@ -39,6 +39,11 @@ struct bfs_layout_t {
   const int* ub_owner = nullptr;
   long long ub_units = 0, ub_units_pad = 0;
   int ub_min_degree = 0;            // the rows the unit blocks hold: degree >= this (must equal the long-row threshold)
+  // the same rows without the entries of the cold-edge lists, 24 bits per entry (any graph size), their own owners: read instead of the
+  // blocks above by a run that takes the cold-edge pass on every unit-block level (NULL: none)
+  const unsigned* ubh_col24 = nullptr;
+  const int* ubh_owner = nullptr;
+  long long ubh_units = 0, ubh_units_pad = 0;
   // short rows vertex by vertex (bfs_fused_vshort.hpp): class boundaries of the degree-sorted CSR, edges of the range,
   // the long-row threshold they were computed for, index of four -1 behind col_indices (0: not available)
   unsigned vs_v[4] = {0, 0, 0, 0};
@@ -115,7 +120,8 @@ __device__ __forceinline__ bfs_slot_plan_t bfs_slot_plan(const bfs_fused_args_t&
   p.vshort = !p.empty && !p.chained && !pulls && bfs_short_is_dense(a, c, p.slot, cur);
   // the long rows' cold entries go through the pair lists (bfs_fused_cold.hpp) when the frontier holds enough long rows to
   // read the unit blocks by its own size (a sweep of all pairs does not pay for a sparse frontier that was only forced
-  // onto the unit blocks by a lazy build: the unit-block body marks the few cold entries it meets)
+  // onto the unit blocks by a lazy build: the unit-block body marks the few cold entries it meets -- in the FULL blocks: the ones
+  // without the lists' entries, args.ub_hot_only, are for the levels that run the pass, bfs_dense_body)
   p.cold = p.dense && a.cold_dst != nullptr;
   // (lab builds: with them, the short rows' cold entries of a level that walks those vertex by vertex)
   p.colds = p.cold && p.vshort && MGX_LAB_GET(a, colds_dst, (const int*)nullptr) != nullptr && !MGX_LAB_GET(a, ss_tab, (const u32*)nullptr);
@@ -408,7 +414,26 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   a.ub_units_pad = units ? (u32)layout->ub_units_pad : 0u;
   // (with the 24-bit copy a unit costs three quarters of the bytes: the unit-block body wins from an eighth of the units on
   //  -- RMAT-22, per call: 1/2 0.3282, 1/4 0.3262, 1/8 0.3215, 1/16 0.3250 ms; with 32-bit entries 1/2 was best)
-  const bool packed = units && st.opts.pack24 && layout->ub_col24 != nullptr;
+  // k_bfs_build2 reads a thread's 17 row offsets and 16 layout ids with 16-byte loads: borrowed arrays must be aligned
+  const bool build2_ok = ((uintptr_t)a.row_offsets % 16 == 0) && ((uintptr_t)a.old_of_new % 16 == 0);
+  // cold-edge lists (bfs_fused_cold.hpp): with the unit blocks they were cut from, the prefix they were cut behind, and a
+  // queue build that knows their bitmaps
+  const bool cold_lists = units && layout->cold_dst && layout->cold_slices > 0 && layout->cold_hot_n == (unsigned)(BFS_DENSE_HOTW * 32) &&
+                          layout->cold_long_min == st.long_min && build2_ok && !opt.build_list && opt.cold != 0 &&
+                          !MGX_LAB_GET(opt, dense_diag, 0);
+  // ... and then the unit blocks WITHOUT the lists' entries (every level that reads unit blocks runs the cold-edge pass: the body
+  // reads those entries only to skip them), at 24 bits whatever the graph's size.  Round 5, as the partitioned ranks have had
+  // them since round 4 (mgx_capi.hip): see the note at the layout's builder for what they are worth.
+  const bool hot_units = cold_lists && st.opts.pack24 && st.opts.hot_units && layout->ubh_col24 && layout->ubh_owner && layout->ubh_units > 0 &&
+                         (opt.dense < 0 || opt.dense > 0);
+  if (hot_units) {
+    a.ub_col24 = layout->ubh_col24; a.ub_owner = layout->ubh_owner;     // (a.ub_col: the full blocks' -- not read by the 24-bit body)
+    a.ub_units = (u32)layout->ubh_units; a.ub_units_pad = (u32)layout->ubh_units_pad;
+  }
+  a.ub_hot_only = hot_units ? 1u : 0u;
+  a.ubf_col24 = hot_units ? layout->ub_col24 : nullptr; a.ubf_owner = hot_units ? layout->ub_owner : nullptr;
+  a.ubf_units_pad = hot_units ? (u32)layout->ub_units_pad : 0u;
+  const bool packed = units && st.opts.pack24 && (layout->ub_col24 != nullptr || hot_units);
   a.dense_div = !units ? 0u : (opt.dense >= 0 ? (u32)opt.dense : (packed ? 8u : st.dense_div));
   // short rows vertex by vertex: the layout's own degree-sorted CSR with its padding, the threshold it was cut for
   const bool vs = relabelled && layout->vs_dummy != 0 && layout->vs_long_min == st.long_min && st.long_min > 0 && !coldt && !lab_flags &&
@@ -443,13 +468,7 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   const long long nwords = ((long long)st.n + 31) / 32;
   // in-place chain launches (k_bfs_chain_inplace): in front of slot 0, of the slots from tail_from on, behind a batch
   a.chain_big_edges = (a.chain_max_edges && opt.seed_chain) ? (opt.chain_big >= 0 ? (u32)(opt.chain_big > BFS_CHAIN_CAP_BIG ? BFS_CHAIN_CAP_BIG : opt.chain_big) : st.chain_big_edges) : 0u;
-  // k_bfs_build2 reads a thread's 17 row offsets and 16 layout ids with 16-byte loads: borrowed arrays must be aligned
-  const bool build2_ok = ((uintptr_t)a.row_offsets % 16 == 0) && ((uintptr_t)a.old_of_new % 16 == 0);
-  // cold-edge lists (bfs_fused_cold.hpp): with the unit blocks they were cut from, the prefix they were cut behind, and a
-  // queue build that knows their bitmaps
-  const bool cold = units && a.dense_div && layout->cold_dst && layout->cold_slices > 0 && layout->cold_hot_n == (unsigned)(BFS_DENSE_HOTW * 32) &&
-                    layout->cold_long_min == st.long_min && build2_ok && !opt.build_list && opt.cold != 0 &&
-                    !MGX_LAB_GET(opt, dense_diag, 0);
+  const bool cold = cold_lists && a.dense_div;
   a.cold_owner = cold ? layout->cold_owner : nullptr;
   a.cold_dst = cold ? layout->cold_dst : nullptr;
   a.cold_slices = cold ? layout->cold_slices : 0;

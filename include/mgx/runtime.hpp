@@ -264,6 +264,7 @@ class mem_t {
   void swap(mem_t& r) noexcept { std::swap(_ptr, r._ptr); std::swap(_size, r._size); std::swap(_owned, r._owned); }
   T* data() const { return _ptr; }
   size_t size() const { return _size; }
+  bool owned() const { return _owned; }
 };
 
 // Copies are stream-ordered: issued on `s` (default: the calling thread's current context stream, see above).

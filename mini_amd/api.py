@@ -103,6 +103,13 @@ class Graph:
         check(lib.mgx_graph_build_layout(self._h, int(bool(weights))))
         return self
 
+    def layout_info(self):
+        """what the layout holds (mgx_graph_layout_info): unit blocks, cold-edge lists, device bytes"""
+        out = (C.c_int64 * 8)()
+        check(lib.mgx_graph_layout_info(self._h, out))
+        keys = ("has_layout", "units", "units_24bit", "cold_pairs", "cold_slices", "hot_units", "cold_majority", "device_bytes")
+        return dict(zip(keys, (int(x) for x in out)))
+
     def build_csc(self):
         """Genuine CSC (transpose) built by the library on the device (mgx_graph_build_csc): in-edges for the bottom-up
         levels on directed graphs."""

@@ -416,6 +416,7 @@ static void build_cold_lists(mgx_graph_s* g) {
   graph_device_t& G = *g->g;
   G.d_cold_owner = mem_t<int>(); G.d_cold_dst = mem_t<int>(); G.d_colds_owner = mem_t<int>(); G.d_colds_dst = mem_t<int>();
   G.cold_pairs = G.colds_pairs = 0; G.cold_slices = 0; G.cold_hot_n = 0; G.cold_long_min = 0; G.cold_majority = false;
+  G.d_ubh_col24 = mem_t<unsigned>(); G.d_ubh_owner = mem_t<int>(); G.ubh_units = G.ubh_units_pad = 0;
   bool with_short = false;                                         // (lab builds, MGX_BFS_COLD_LISTS=2: also the short rows' list -- measured equal)
   if (const char* e = getenv("MGX_BFS_COLD_LISTS")) {
     if (atoi(e) == 0) return;
@@ -501,6 +502,41 @@ static void build_cold_lists(mgx_graph_s* g) {
     }
   }
   G.cold_pairs = pairs; G.colds_pairs = pairs_s; G.cold_slices = used; G.cold_hot_n = hot_n; G.cold_long_min = G.vs_long_min;
+  // The unit blocks once more for the fused BFS, WITHOUT the entries that now live in the lists (its unit-block body reads them only to
+  // skip them) -- and what is left points into the LDS prefix, ids below 2^20: 24 bits per entry do at every graph size (the full
+  // blocks' 24-bit copy stops at 2^23 vertices).  MGX_BFS_HOT_UNITS=0: not built.  The full blocks stay: the neighbour-reduce and the
+  // fused SSSP read them, and so does a traversal that is told to run without the cold-edge pass.
+  bool hot_units = true;
+  if (const char* e = getenv("MGX_BFS_HOT_UNITS")) hot_units = atoi(e) != 0;
+  if (const char* e = getenv("MGX_BFS_PACK24")) hot_units = hot_units && atoi(e) != 0;
+  if (hot_units) {
+    int *owner2 = nullptr, *ucol2 = nullptr, *ufirst2 = nullptr;
+    unsigned char* ucnt2 = nullptr;
+    long long U2 = 0, Up2 = 0;
+    const int rc3 = mgx_units_build_device(G.d_layout_row_offsets.data(), G.d_layout_col_indices.data(), G.num_nodes, G.vs_long_min, 0x7FFFFFFF, 6,
+                                           hot_n, &owner2, &ucol2, &ucnt2, &ufirst2, &U2, &Up2, g->c->ctx->stream());
+    if (ucnt2) (void)hipFree(ucnt2);
+    if (ufirst2) (void)hipFree(ufirst2);
+    if (rc3 != 0) {
+      if (owner2) (void)hipFree(owner2);
+      if (ucol2) (void)hipFree(ucol2);
+      throw mgx::mgx_error(MGX_E_HIP, std::string("unit blocks of the hot entries: ") + hipGetErrorString((hipError_t)rc3));
+    }
+    if (U2 > 0) {
+      mem_t<int> d_owner2 = mem_t<int>::adopt(owner2, (size_t)Up2);
+      mem_t<int> d_col2 = mem_t<int>::adopt(ucol2, ((size_t)Up2 << 6) + 4);          // (freed below: only the 24-bit copy is kept)
+      const long long quads = ((long long)Up2 << 4) + 1;
+      G.d_ubh_col24 = mem_t<unsigned>((size_t)quads * 3 + 4, *g->c->ctx);
+      hipLaunchKernelGGL(k_pack24, dim3(mgx::grid_for(quads, 256, 16384)), dim3(256), 0, g->c->ctx->stream(), (const int4*)d_col2.data(), quads,
+                         G.d_ubh_col24.data());
+      g->c->ctx->synchronize();
+      G.d_ubh_owner = std::move(d_owner2);
+      G.ubh_units = U2; G.ubh_units_pad = Up2;
+    } else {
+      if (owner2) (void)hipFree(owner2);
+      if (ucol2) (void)hipFree(ucol2);
+    }
+  }
 }
 // graph_device_t::src_shapes: per vertex (original ids) its degree and the shape of the level behind it as a traversal from
 // that vertex would meet it -- one wave per vertex, lanes over the row; a neighbour counts once (rows are sorted: a duplicate
@@ -645,6 +681,26 @@ int mgx_graph_csc_read(mgx_graph_t g, int* h_col_offsets, int* h_row_indices, fl
   if (h_col_offsets) MGX_HIP(mgx::dtoh(h_col_offsets, G.d_col_offsets.data(), n + 1));
   if (h_row_indices && m) MGX_HIP(mgx::dtoh(h_row_indices, G.d_row_indices.data(), m));
   if (h_row_values && m) MGX_HIP(mgx::dtoh(h_row_values, G.d_row_values.data(), m));
+  MGX_CATCH
+}
+int mgx_graph_layout_info(mgx_graph_t g, int64_t* out8) {
+  MGX_TRY
+  MGX_REQUIRE(g && out8, "NULL argument");
+  const graph_device_t& G = *g->g;
+  for (int i = 0; i < 8; ++i) out8[i] = 0;
+  if (!G.has_layout) return MGX_OK;
+  out8[0] = 1;
+  out8[1] = (int64_t)G.ub_units;
+  out8[2] = G.d_ub_col24.size() ? 1 : 0;
+  out8[3] = (int64_t)G.cold_pairs;
+  out8[4] = (int64_t)G.cold_slices;
+  out8[5] = (int64_t)G.ubh_units;
+  out8[6] = G.cold_majority ? 1 : 0;
+  auto bytes = [](auto& m) -> int64_t { return m.owned() ? (int64_t)(m.size() * sizeof(*m.data())) : 0; };
+  out8[7] = bytes(G.d_layout_row_offsets) + bytes(G.d_layout_col_indices) + bytes(G.d_layout_col_values) + bytes(G.d_new_of_old) + bytes(G.d_old_of_new) +
+            bytes(G.d_ub_col) + bytes(G.d_ub_col24) + bytes(G.d_ub_owner) + bytes(G.d_ubh_col24) + bytes(G.d_ubh_owner) + bytes(G.d_ub_w) + bytes(G.d_ub_w16) +
+            bytes(G.d_ub_cnt) + bytes(G.d_ub_first) + bytes(G.d_ss_tab) + bytes(G.d_cold_owner) + bytes(G.d_cold_dst) + bytes(G.d_cold_pk) + bytes(G.d_cold_cbase) +
+            bytes(G.d_colds_owner) + bytes(G.d_colds_dst);
   MGX_CATCH
 }
 int mgx_graph_layout_read(mgx_graph_t g, int* h_row_offsets, int* h_col_indices, int* h_new_of_old, int* h_old_of_new,

@@ -176,6 +176,8 @@ def test_config2_rmat22_bfs_full_size_vs_oracle(gpu_ctx, oracle, torch_mod):
 @pytest.mark.parametrize("scale,undir,env", [
     (20, True, {}), (21, True, {"MGX_BFS_DENSE": "1000000", "MGX_BFS_LAZY": "1048576"}), (20, False, {"MGX_BFS_DENSE": "1000000"}),
     (21, True, {"MGX_BFS_DEFER": "0"}), (20, True, {"MGX_BFS_COLD": "0"}), (21, True, {"MGX_BFS_DENSE": "1000000", "MGX_BFS_MERGED_PUSH": "0"}),
+    (21, True, {"MGX_BFS_DENSE": "1000000", "MGX_BFS_HOT_UNITS": "0"}), (21, True, {"MGX_BFS_DENSE": "1000000", "MGX_BFS_COLD": "0"}),
+    (21, False, {"MGX_BFS_DENSE": "1000000", "MGX_BFS_PACK24": "0"}),
     (21, True, {"MGX_BFS_COLD": "1", "MGX_BFS_COLD_LISTS": "2", "MGX_BFS_DENSE": "1000000"}), (20, True, {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_DENSE": "0"}),
     (21, False, {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_DENSE": "1000000", "MGX_BFS_LAZY": "1048576", "MGX_BFS_COLD": "1", "MGX_BFS_COLD_LISTS": "2"}),
     (21, True, {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_DENSE": "1000000", "MGX_BFS_CHAIN_MAX_EDGES": "0", "MGX_BFS_COLD": "1", "MGX_BFS_COLD_LISTS": "2"})])
@@ -194,6 +196,14 @@ def test_cold_edge_pass_vs_oracle(gpu_ctx, oracle, torch_mod, monkeypatch, scale
     ro, ci, _ = oracle.csr_from_tuples(n, s, d, None, undir=undir)
     graph = mini_amd.Graph.from_host(gpu_ctx, ro, ci, None).build_layout()
     deg = np.diff(ro)
+    # the unit blocks without the lists' entries (what the unit-block body reads when the cold-edge pass runs): built with the lists,
+    # fewer units than the full blocks; a run without the pass (MGX_BFS_COLD=0) reads the full blocks and marks those entries itself
+    info = graph.layout_info()
+    if info["cold_pairs"] > 0 and env.get("MGX_BFS_HOT_UNITS") != "0" and env.get("MGX_BFS_PACK24") != "0":
+        assert 0 < info["hot_units"] <= info["units"], info
+        assert (info["units"] - info["hot_units"]) * 64 <= info["cold_pairs"], info      # (a unit goes only when 64 entries went)
+    else:
+        assert info["hot_units"] == 0, info
     rng = np.random.default_rng(scale)
     srcs = [int(np.argmax(deg))] + [int(v) for v in rng.choice(np.where(deg > 0)[0], size=3, replace=False)] + [int(np.where(deg == 0)[0][0])]
     bfs = mini_amd.BfsProblem(graph, srcs[0])
@@ -210,7 +220,8 @@ def test_cold_edge_pass_vs_oracle(gpu_ctx, oracle, torch_mod, monkeypatch, scale
         assert cold > 0
 
 
-@pytest.mark.parametrize("env", [{}, {"MGX_BFS_DENSE": "1000000", "MGX_BFS_LAZY": "1048576"}, {"MGX_BFS_DENSE": "1000000", "MGX_BFS_DEFER": "1"}])
+@pytest.mark.parametrize("env", [{}, {"MGX_BFS_DENSE": "1000000", "MGX_BFS_LAZY": "1048576"}, {"MGX_BFS_DENSE": "1000000", "MGX_BFS_DEFER": "1"},
+                                 {"MGX_BFS_DENSE": "1000000", "MGX_BFS_HOT_UNITS": "0"}])
 def test_cold_edge_pass_ragged_last_slice(gpu_ctx, oracle, monkeypatch, env):
     """a vertex count that is no multiple of anything (800 003): the last cold slice ends in the middle of a bitmap word and
     of a 1024-vertex run of the queue build; hubs whose neighbours are spread over the whole id range, so that about a
@@ -229,6 +240,8 @@ def test_cold_edge_pass_ragged_last_slice(gpu_ctx, oracle, monkeypatch, env):
     ro, ci, _ = oracle.csr_from_tuples(n, t0, t1, None, undir=True)
     graph = mini_amd.Graph.from_host(gpu_ctx, ro, ci, None).build_layout()
     d = np.diff(ro)
+    info = graph.layout_info()
+    assert info["cold_pairs"] > 0 and ((0 < info["hot_units"] < info["units"]) if env.get("MGX_BFS_HOT_UNITS") != "0" else info["hot_units"] == 0), info
     bfs = mini_amd.BfsProblem(graph, 0)
     cold = 0
     for src in [0, int(h + 5), int(n - 1), int(np.argmax(d))]:
@@ -258,6 +271,36 @@ def test_rmat23_unit_blocks_and_cold_pass_on_a_big_graph(gpu_ctx, oracle, torch_
     deg = np.diff(ro)
     assert st["m_t"] == int(deg[want >= 0].sum())
     assert st["dense_slots"] >= 1 and st["cold_slots"] >= 1 and st["lazy_slots"] >= 1
+
+
+@pytest.mark.parametrize("hot", ["1", "0"])
+def test_hot_unit_blocks_beyond_2_23_vertices(gpu_ctx, oracle, torch_mod, monkeypatch, hot):
+    """n = 2^24: the full unit blocks have no 24-bit copy at this size (their entries need 25 bits), the blocks WITHOUT the
+    cold-edge lists' entries do (what is left points into the LDS prefix) -- the unit-block body reads those, 3 bytes per entry,
+    whenever the cold-edge pass runs; MGX_BFS_HOT_UNITS=0: the full blocks at 4 bytes.  Labels against the oracle either way,
+    push and direction-optimising."""
+    import mini_amd
+    from mini_amd import rmat
+    monkeypatch.setenv("MGX_BFS_HOT_UNITS", hot)
+    monkeypatch.setenv("MGX_BFS_DENSE", "1000000")          # (the unit blocks on every level whose frontier is a bitmap)
+    g = rmat.rmat_csr(gpu_ctx, 24, 3, seed=124)
+    graph = mini_amd.Graph.from_device(gpu_ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"]).build_layout()
+    info = graph.layout_info()
+    assert info["units"] > 0 and info["units_24bit"] == 0 and info["cold_pairs"] > 0, info
+    assert (info["hot_units"] > 0) == (hot == "1"), info
+    ro, ci = g["row_offsets"].cpu().numpy(), g["col_indices"].cpu().numpy()
+    deg = np.diff(ro)
+    bfs = mini_amd.BfsProblem(graph, 0)
+    cold = 0
+    for src in rmat.pick_sources(ro, 2, 124) + [int(np.argmax(deg))]:
+        want = oracle.bfs_cpu(ro, ci, src)
+        st = bfs.run(src)
+        assert np.array_equal(bfs.labels(), want), (hot, src)
+        assert st["m_t"] == int(deg[want >= 0].sum())
+        cold += st["cold_slots"]
+        bfs.run(src, mode=mini_amd.MGX_BFS_DIRECTION_OPT, alpha=4.0)
+        assert np.array_equal(bfs.labels(), want), (hot, src, "direction-optimising")
+    assert cold > 0
 
 
 def test_config3_rmat22_sssp_full_size_vs_oracle(gpu_ctx, oracle, torch_mod):
