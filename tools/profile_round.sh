@@ -72,7 +72,7 @@ cp $R/gpurun_out/d2native/summary.txt $O/dist2_native_kernels_22_8.txt 2>/dev/nu
 timeout 600 python tools/dist2_loopback.py 22 8 reduce 8 2>/dev/null | grep -v amdgpu.ids | tail -10 > $O/dist2_loopback_22_8.log
 # (round 5) RMAT-26 on one GPU, the graphs off RMAT-22, what the drop-in costs, the timed batch per kernel
 timeout 900 python bench.py --scale 26 --steps 8 --warmup 1 > $O/bench_rmat26_1gpu.log 2>&1
-for g in "uniform 22 16" "grid2d 22 4" "rmat 24 16" "rmat 20 32"; do
+for g in "uniform 22 16" "grid2d 22 4" "rmat 23 32" "rmat 24 16" "rmat 25 16" "rmat 20 32"; do
   set -- $g
   timeout 600 python bench.py --graph $1 --scale $2 --steps $3 --warmup 2 --cpu-seconds 5 > $O/bench_$1_$2.log 2>&1
 done
@@ -122,7 +122,7 @@ cp $O/pmc_traffic.json $O/bfs_operator_s22.log $O/dobfs_alpha_sweep.txt $O/sssp_
 cp $O/dist2_single_*.log $O/kernel_stats_dist2_25_8.csv $O/dist2_kernels_26_8.txt $O/keep/ 2>/dev/null
 cp $O/dist2_native_*.log $O/dist2_native_kernels_*.txt $O/dist2_loopback_22_8.log $O/dropin_cost.log $O/batch_stats.txt $O/pmc_by_kernel.txt $O/keep/ 2>/dev/null
 grep '^{' $O/bench_rmat26_1gpu.log | tail -1 > $O/keep/bench_line_rmat26_1gpu.json
-for g in uniform_22 grid2d_22 rmat_24 rmat_20; do grep '^{' $O/bench_$g.log | tail -1 > $O/keep/bench_line_$g.json; done
+for g in uniform_22 grid2d_22 rmat_23 rmat_24 rmat_25 rmat_20; do grep '^{' $O/bench_$g.log | tail -1 > $O/keep/bench_line_$g.json; done
 grep '^{' $O/bench_driver_cmd.log | tail -1 > $O/keep/bench_line_driver_cmd.json
 grep '^{' $O/bench.log | tail -1 > $O/keep/bench_line.json
 grep '^{' $O/bench_per_call.log | tail -1 > $O/keep/bench_line_per_call.json
