@@ -198,6 +198,12 @@ struct bfs_fused_args_t {
   u32* d2_newbits = nullptr;
   u32* d2_front = nullptr;         // the level's frontier over the rank's LOCAL rows (k_bfs_build2 writes it, the vertex-by-vertex body reads it)
   const int* vs_col = nullptr;     // the vertex-by-vertex body's copy of col_indices with readable entries behind it (NULL: col_indices has them)
+  // cold-edge lists of the SHORT rows (the entries the vertex-by-vertex body would mark untested), the long rows' slices: the same pass
+  // takes them on a level that walks its short rows vertex by vertex.  Equal to marking on RMAT-22 (6 % of the entries), what the big
+  // graphs need: RMAT-25 2.31 -> 2.10 ms per traversal, RMAT-24 1.153 -> 1.127 (round 5; a lab shape until then).  NULL: none
+  const int* colds_owner = nullptr;
+  const int* colds_dst = nullptr;
+  u32 colds_off[BFS_COLD_MAX_SLICES + 1] = {};
 #ifdef MGX_LAB
   // ---- lab build only (-DMGX_LAB, never set by __graft_entry__.build()): shapes that lost their A/B runs and the
   // instrumented kernels of the measurement tools.  The product library carries none of this: MGX_LAB_GET reads a
@@ -207,9 +213,6 @@ struct bfs_fused_args_t {
   int ss_dmax;             // the largest short degree (long_min - 1)
   int build_diag;          // measurements only (MGX_BFS_BUILD_DIAG; results wrong): 1 no label stores, 2 no extent gathers, 4 no cursor atomics, 8 no queue stores, 16 synthetic extents, 32 / 64 no OR of the deferred / the cold pass's bitmaps
   int dense_diag;          // measurements only (MGX_BFS_DENSE_DIAG): 1 the unit-block body stores no marks, 2 tests nothing
-  const int* colds_owner;  // cold-edge lists of the SHORT rows (the entries the vertex-by-vertex body would mark; measured equal); NULL: none
-  const int* colds_dst;
-  u32 colds_off[BFS_COLD_MAX_SLICES + 1];
 #endif
 };
 
@@ -1105,8 +1108,9 @@ struct bfs_run_opts_t {
   int tail_chain = 1;      // MGX_BFS_TAIL_CHAIN=0: ... only the one at the start
   int tail_front = 1;      // MGX_BFS_TAIL_FRONT=0: no chain launch in FRONT of the last slots of a batch (only behind it)
   int chain_big = -1;      // MGX_BFS_CHAIN_BIG_EDGES: largest level of an in-place chain launch
-  int cold = 2;            // MGX_BFS_COLD: 0 the unit-block body marks its cold entries itself (no cold-edge pass), 2 the long rows' lists
-                           // (default); lab builds: 1 also the short rows' (measured equal on RMAT-22: 0.3712 / 0.3708 ms)
+  int cold = 1;            // MGX_BFS_COLD: 0 the unit-block body marks its cold entries itself (no cold-edge pass), 2 the long rows' lists only,
+                           // 1 (default) also the short rows' where the layout carries them (graphs of more than 2^23 vertices; equal on RMAT-22:
+                           // 0.3712 / 0.3708 ms in round 4)
   int lazy = -1;           // MGX_BFS_LAZY: 0 the queue build always writes the queues, N: not behind a push that stored >= n / N marks
   long long defer = -1;    // MGX_BFS_DEFER: 0 never defer hot marks, N: flush a bitmap above N deferred marks per workgroup
   int spin = -1;           // MGX_BFS_SPIN: 0 read the control block back with a copy + hipStreamSynchronize, 1 publish kernel + spin
@@ -1164,7 +1168,6 @@ struct bfs_run_opts_t {
     geti("MGX_BFS_BUILD_DIAG", o.build_diag);
     geti("MGX_BFS_DENSE_DIAG", o.dense_diag);
 #else
-    if (o.cold == 1) o.cold = 2;                  // (the short rows' cold lists are a lab shape)
 #endif
     return o;
   }

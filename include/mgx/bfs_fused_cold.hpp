@@ -73,10 +73,10 @@ __device__ __forceinline__ void bfs_cold_body(const bfs_fused_args_t& a, int slo
   // the long rows' list of the slice, then the short rows' (whichever the slot's bodies leave to this pass)
   for (int which = 0; which < 2; ++which) {
     if (which == 0 ? !do_long : !do_short) continue;
-    // (the short rows' lists exist in lab builds only: measured equal to marking those entries, MGX_BFS_COLD=1)
-    const int* __restrict__ owner = which == 0 ? a.cold_owner : MGX_LAB_GET(a, colds_owner, (const int*)nullptr);
-    const int* __restrict__ dst = which == 0 ? a.cold_dst : MGX_LAB_GET(a, colds_dst, (const int*)nullptr);
-    const u32 p0 = which == 0 ? a.cold_off[sl] : MGX_LAB_GET(a, colds_off[sl], 0u), p1 = which == 0 ? a.cold_off[sl + 1] : MGX_LAB_GET(a, colds_off[sl + 1], 0u);
+    // (the short rows' lists: graphs of more than 2^23 vertices, or MGX_BFS_COLD_LISTS=2 when the layout is built)
+    const int* __restrict__ owner = which == 0 ? a.cold_owner : a.colds_owner;
+    const int* __restrict__ dst = which == 0 ? a.cold_dst : a.colds_dst;
+    const u32 p0 = which == 0 ? a.cold_off[sl] : a.colds_off[sl], p1 = which == 0 ? a.cold_off[sl + 1] : a.colds_off[sl + 1];
     const u32 chunk = (((p1 - p0) + parts - 1u) / parts + 255u) & ~255u;
     const u32 b = p0 + part * chunk < p1 ? p0 + part * chunk : p1;
     const u32 e = b + chunk < p1 ? b + chunk : p1;

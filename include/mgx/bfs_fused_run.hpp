@@ -58,7 +58,7 @@ struct bfs_layout_t {
   const unsigned* cold_cbase = nullptr;
   unsigned cold_cb[BFS_COLD_MAX_SLICES + 1] = {0};
   unsigned long long cold_pk_mask = 0;
-  const int* colds_owner = nullptr;   // (lab builds) the short rows' cold entries
+  const int* colds_owner = nullptr;   // the short rows' cold entries (graphs of more than 2^23 vertices)
   const int* colds_dst = nullptr;
   int cold_slices = 0;
   unsigned cold_lo[BFS_COLD_MAX_SLICES] = {0}, cold_off[BFS_COLD_MAX_SLICES + 1] = {0}, colds_off[BFS_COLD_MAX_SLICES + 1] = {0},
@@ -124,7 +124,7 @@ __device__ __forceinline__ bfs_slot_plan_t bfs_slot_plan(const bfs_fused_args_t&
   // without the lists' entries, args.ub_hot_only, are for the levels that run the pass, bfs_dense_body)
   p.cold = p.dense && a.cold_dst != nullptr;
   // (lab builds: with them, the short rows' cold entries of a level that walks those vertex by vertex)
-  p.colds = p.cold && p.vshort && MGX_LAB_GET(a, colds_dst, (const int*)nullptr) != nullptr && !MGX_LAB_GET(a, ss_tab, (const u32*)nullptr);
+  p.colds = p.cold && p.vshort && a.colds_dst != nullptr && !MGX_LAB_GET(a, ss_tab, (const u32*)nullptr);
   if (!p.empty && c->lazy_slot == p.slot) {       // the build before this slot wrote no queues (bfs_build_is_lazy)
     p.chained = false;
     p.dense = p.vshort = true;
@@ -479,12 +479,10 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   for (int i = 0; i < BFS_COLD_MAX_SLICES; ++i) a.cold_lo[i] = cold ? layout->cold_lo[i] : 0u;
   for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) { a.cold_off[i] = cold ? layout->cold_off[i] : 0u; a.cold_wgs[i] = cold ? layout->cold_wgs[i] : 0u; }
   // ... and of the short rows, for the levels that walk them vertex by vertex
-#ifdef MGX_LAB
   const bool colds = cold && a.vs_div && layout->colds_dst && opt.cold != 2;
   a.colds_owner = colds ? layout->colds_owner : nullptr;
   a.colds_dst = colds ? layout->colds_dst : nullptr;
   for (int i = 0; i <= BFS_COLD_MAX_SLICES; ++i) a.colds_off[i] = colds ? layout->colds_off[i] : 0u;
-#endif
   const size_t cold_words = cold ? (size_t)layout->cold_wgs[layout->cold_slices] * BFS_COLD_WORDS : 0;
   if (cold && st.cold_flush.size() < cold_words) { ctx.synchronize(); st.cold_flush = mem_t<u32>(cold_words, ctx); }
   a.cold_flush = cold ? st.cold_flush.data() : nullptr;

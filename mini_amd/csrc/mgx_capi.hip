@@ -417,12 +417,12 @@ static void build_cold_lists(mgx_graph_s* g) {
   G.d_cold_owner = mem_t<int>(); G.d_cold_dst = mem_t<int>(); G.d_colds_owner = mem_t<int>(); G.d_colds_dst = mem_t<int>();
   G.cold_pairs = G.colds_pairs = 0; G.cold_slices = 0; G.cold_hot_n = 0; G.cold_long_min = 0; G.cold_majority = false;
   G.d_ubh_col24 = mem_t<unsigned>(); G.d_ubh_owner = mem_t<int>(); G.ubh_units = G.ubh_units_pad = 0;
-  bool with_short = false;                                         // (lab builds, MGX_BFS_COLD_LISTS=2: also the short rows' list -- measured equal)
+  // the short rows' list too on graphs of more than 2^23 vertices (equal to marking those entries on RMAT-22, where 6 % of the entries
+  // are cold; RMAT-24 -2 %, RMAT-25 -9 % of a traversal); MGX_BFS_COLD_LISTS: 0 no lists at all, 1 the long rows' only, 2 both
+  bool with_short = (long long)G.num_nodes > (1ll << 23);
   if (const char* e = getenv("MGX_BFS_COLD_LISTS")) {
     if (atoi(e) == 0) return;
-#ifdef MGX_LAB
     with_short = atoi(e) == 2;
-#endif
   }
   if (G.ub_units <= 0 || G.vs_long_min <= 0 || G.vs_long_min != G.ub_min_degree || G.vs_v[0] == 0) return;
   const unsigned hot_n = (unsigned)mgx::BFS_COLD_WORDS * 32u, slice_n = hot_n;

@@ -20,7 +20,7 @@ LAB_ENV_KEYS = ("MGX_BFS_SSTREAM", "MGX_BFS_FLAGS", "MGX_BFS_DENSE_DIAG",
 
 def needs_lab(env):
     """does this set of environment switches select a shape that only the lab library holds?"""
-    return any(k in env for k in LAB_ENV_KEYS) or env.get("MGX_BFS_COLD") == "1" or env.get("MGX_BFS_COLD_LISTS") == "2"
+    return any(k in env for k in LAB_ENV_KEYS)
 
 
 def skip_unless_lab(env=None):

@@ -190,11 +190,12 @@ def test_push_kernels_do_not_spill_vector_registers(built):
     for k in hot:
         assert scratch[k] == 0, "%s spills: ScratchSize %d" % (k, scratch[k])
         assert vspill.get(k, 0) == 0, "%s spills %d VGPRs" % (k, vspill[k])
-    # SGPR spills (to VGPR lanes, not to memory): the chain body of block 0 costs the single-GPU push kernel 18, the level's opener
-    # the partitioned one 26 -- a budget, so that a change that adds to them shows up here (round 5: calling the chain body instead of
-    # inlining it takes them to 0 at the price of 72 spilled VGPRs and scratch)
+    # SGPR spills (to VGPR lanes, not to memory): the chain body of block 0 costs the single-GPU push kernel 18 -- 26 with the short
+    # rows' cold-edge lists in the product (late in round 5: the cold body's second list; RMAT-22 0.2979-0.2999 -> 0.2993-0.3006 ms,
+    # RMAT-25 2.25 -> 2.05) --, the level's opener the partitioned one 26: a budget, so that a change that adds to them shows up here
+    # (round 5: calling the chain body instead of inlining it takes them to 0 at the price of 72 spilled VGPRs and scratch)
     for k in hot:
-        budget = 18 if "k_bfs_pushILb0ELi0" in k else 28
+        budget = 26 if "k_bfs_pushILb0ELi0" in k else 28
         assert sspill.get(k, 0) <= budget, "%s spills %d SGPRs (budget %d)" % (k, sspill.get(k, 0), budget)
     # the split launch's long-row and short-row kernels (bench.py's parts pass) spill nothing at all
     for k in scratch:

@@ -188,7 +188,7 @@ def test_cold_edge_pass_vs_oracle(gpu_ctx, oracle, torch_mod, monkeypatch, scale
     labels against the oracle for hub, ordinary and isolated sources"""
     import mini_amd
     from tests.conftest import skip_unless_lab
-    skip_unless_lab(env)                    # (the short rows' cold lists: lab library only)
+    skip_unless_lab(env)                    # (no lab-only switch in the list any more: the short rows' cold lists are in the product since round 5)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     n = 1 << scale
