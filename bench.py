@@ -645,6 +645,10 @@ def bench_pr(args, ctx, stream):
     gen = torch.Generator(device="cuda").manual_seed(seed)
     vals = torch.rand(n, device="cuda", generator=gen)
     red = torch.empty(n, device="cuda")
+    t_slices = time.time()
+    mini_amd.segreduce(graph, f, vals, 0.0, red, "f32_plus")     # (the graph's first full-frontier reduce: the library regroups the long rows by slice of their destinations, untimed one-time preprocessing)
+    torch.cuda.synchronize()
+    t_slices = time.time() - t_slices
     for _ in range(max(args.warmup, 1)):
         mini_amd.segreduce(graph, f, vals, 0.0, red, "f32_plus")
     torch.cuda.synchronize()
@@ -671,7 +675,7 @@ def bench_pr(args, ctx, stream):
     sha = source_sha()
     traffic, traffic_note = _pmc_traffic(args, "neighbour-reduce operator", sha)
     roofline = {"bound": "hbm", "kernel": "neighbour-reduce operator (every kernel of one mgx_segreduce_f32_plus call over the full frontier: "
-                                          "k_nr_values (with the frontier check), k_nr_edges -- the dominant one --, k_nr_fold)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                          "k_nr_values (with the frontier check), k_nrs_edges -- the long rows by slice of their destinations + the short rows, the dominant one --, k_nrs_fold; k_nr_edges / k_nr_fold under MGX_NR_SLICED=0)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_note": traffic_note, "launches": len(evs),
                 "avg_launch_us": round(op_ms * 1e3, 3), "alg_bytes_per_launch": alg,
                 "alg_bytes": "8 B per edge (column index + value gather) + 16 B per frontier vertex (SURVEY 8d)",
@@ -710,9 +714,11 @@ def bench_pr(args, ctx, stream):
                                   "one operator call per step" % (args.scale, args.edgefactor, n, m),
                       "scale": args.scale, "edgefactor": args.edgefactor, "seed": seed, "parallelism": "1 GPU",
                       "layout": "generator ids" if args.no_layout else "the operator is called with generator ids; for a full frontier the library reads "
-                                "the graph's hub-first copy (unit blocks + degree classes, untimed one-time preprocessing: layout_build_s)"},
+                                "the graph's hub-first copy (the long rows regrouped by slice of their destinations -- nr_slices --, degree classes "
+                                "for the short rows; untimed one-time preprocessing: layout_build_s + nr_slices_build_s)"},
            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "parity_tolerance": "rtol 2e-5 against the serial float32 oracle (float sum order); where the oracle's own rounding exceeds that (rows of several 10^5 entries): rtol 2e-6 against the float64 sum of the same values, the oracle within 1e-3 of it",
            "device_ms_per_step": round(dev_ms / max(args.steps, 1), 4), "graph_build_s": round(t_build, 2), "layout_build_s": round(t_layout, 2),
+           "nr_slices_build_s": round(t_slices, 2), "nr_slices": None if args.no_layout else graph.nr_slices_info(),
            "source_sha": sha}
     print(json.dumps(out), flush=True)
     if parity is False:

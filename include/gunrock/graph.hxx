@@ -99,6 +99,15 @@ struct graph_device_t {
   std::vector<unsigned> src_shapes;  // 4 words per vertex: degree, level-1 edges, level-1 short rows, level-1 long rows
   int src_shapes_long_min = 0;       // the long-row threshold the rows were split by
   unsigned nr_big_rows = 0;          // layout rows [0, nr_big_rows) hold more than mgx::NR_BIG_UNITS units (degree-sorted layouts)
+  // The long rows by slice of their destinations for the full-frontier neighbour-reduce (mgx/nreduce.hpp: k_nrs_edges; built by the
+  // library at the graph's first such reduce, mgx_layout.hip: mgx_nrs_build_device): 16-byte mini-units (4 words each), where a
+  // row's mini-units of a slice start, the slices' first mini-units.  Empty: not built (the unit blocks serve).
+  mem_t<unsigned> d_nrs_mu;
+  mem_t<unsigned> d_nrs_off;
+  unsigned nrs_first[18] = {0};      // (mgx::NRS_MAX_SLICES + 2)
+  unsigned nrs_slices = 0, nrs_rows = 0, nrs_big_rows = 0;
+  long long nrs_units = 0;
+  bool nrs_tried = false;
   // Degree classes of the layout's short rows (mgx/bfs_fused_vshort.hpp): only for a layout the library built itself
   // (sorted by degree, eight ints of -1 behind its neighbour array).
   unsigned vs_v[4] = {0, 0, 0, 0};

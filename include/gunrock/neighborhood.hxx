@@ -68,6 +68,18 @@ int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fronti
       L.vs_dummy = graph.vs_dummy;
       L.big_rows = graph.nr_big_rows;
       L.n = graph.num_nodes;
+      {
+        // the long rows by slice of their destinations (MGX_NR_SLICED=0: the unit blocks, as before round 5), when the graph carries
+        // them and the scratch arena holds a partial per mini-unit
+        static const bool sliced = [] { const char* e = std::getenv("MGX_NR_SLICED"); return !e || std::atoi(e) != 0; }();
+        if (sliced && graph.nrs_units > 0 && graph.nrs_slices > 0 && graph.nrs_rows == graph.vs_v[0] && graph.d_nrs_mu.size() && graph.d_nrs_off.size() &&
+            context.scratch_bytes >= mgx::nr_scratch_bytes(graph.num_nodes, graph.nrs_units, sizeof(Value))) {
+          L.nrs_mu = (const uint4*)graph.d_nrs_mu.data();
+          L.nrs_off = graph.d_nrs_off.data();
+          for (int i = 0; i < mgx::NRS_MAX_SLICES + 2; ++i) L.nrs_first[i] = graph.nrs_first[i];
+          L.nrs_slices = graph.nrs_slices; L.nrs_rows = graph.nrs_rows; L.nrs_big_rows = graph.nrs_big_rows;
+        }
+      }
       mgx::nr_full_frontier<Value>(L, [=] __device__(int v) -> Value { return Functor::get_value_to_reduce(v, data, iteration); }, reduced,
                                    identity, reduce_op(), context, frontier, context.mailbox + 8, context.nr_flag(), epoch);
       context.synchronize();

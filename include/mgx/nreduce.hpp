@@ -38,6 +38,8 @@ constexpr int NR_HOTV = 40000;            // values of the first NR_HOTV layout 
                                           //  stay in LDS -- 64 % of the endpoints at 40 000 values against 51 % -- and 128 registers per lane.)
 constexpr int NR_BIG_UNITS = 64;          // rows of more units than this are folded by a workgroup of their own
 constexpr size_t nr_lds_bytes() { return (size_t)NR_HOTV * 4 + 64; }
+constexpr int NRS_MAX_SLICES = 16;        // hot slices of the sliced long rows (k_nrs_edges): 16 x 40 000 vertices hold 94 % of RMAT-22's long-row endpoints
+constexpr int NRS_BIG_DEG = 1024;         // rows of more entries than this: their partials are folded by a workgroup each
 
 struct nr_layout_t {
   const u32* row_offsets = nullptr;       // the layout's CSR
@@ -52,6 +54,15 @@ struct nr_layout_t {
   u32 vs_dummy = 0;                       // index into col_indices of four entries of -1
   u32 big_rows = 0;                       // rows [0, big_rows) hold more than NR_BIG_UNITS units each
   int n = 0;
+  // the long rows by slice of their destinations (round 5, mgx_layout.hip: mgx_nrs_build_device; nrs_mu == NULL: not built):
+  // 16-byte mini-units, slice-major -- slices [0, nrs_slices) as 8 x 16-bit offsets into the slice (padding: NR_HOTV), slice
+  // nrs_slices (the tail: everything behind nrs_slices * NR_HOTV) as 4 x 32-bit layout ids (padding: -1)
+  const uint4* nrs_mu = nullptr;
+  const u32* nrs_off = nullptr;           // (nrs_slices + 1) * nrs_rows + 1: the mini-units of (slice k, row r) start at nrs_off[k * nrs_rows + r]
+  u32 nrs_first[NRS_MAX_SLICES + 2] = {}; // first mini-unit of slice k; [nrs_slices + 1] = all of them
+  u32 nrs_slices = 0;
+  u32 nrs_rows = 0;                       // the long rows: [0, nrs_rows) (= vs_v[0])
+  u32 nrs_big_rows = 0;                   // rows [0, nrs_big_rows) have more than NRS_BIG_DEG entries: a workgroup each folds their partials
 };
 
 // k_nr_values also answers: is the frontier 0, 1, ..., n - 1?  *host_flag (pinned) was set to 1 by the host before the launch;
@@ -75,12 +86,22 @@ __global__ __launch_bounds__(BLOCK) void k_nr_values(GetValue get, const int* __
 // value of entry d: -1 (padding, lanes past a row's end) -> identity, a hub -> LDS, anything else -> L2 / HBM.  The global
 // load is unconditional (a load under a condition serialises the pipeline, bfs_fused.hpp "countable loads"): entries
 // served from LDS read vals[0] instead, one broadcast request per wave instruction.
+// A load the compiler must leave where it stands.  A plain load whose only use is one arm of a select is SUNK under the select's
+// condition by the code generator (select -> branch around the load), and hipcc's s_waitcnt insertion then waits for vmcnt(0)
+// inside every such branch: every gather of a step became a full round trip of its own, with the prefetched entry loads drained
+// on top (found in the ISA in round 5: 70 "s_waitcnt vmcnt(0) lgkmcnt(0)" in k_nr_edges).  A relaxed atomic load of wavefront
+// scope is the same machine instruction without cache-policy bits, but not a candidate for that transformation.
+template <typename V>
+__device__ __forceinline__ V nr_load_pinned(const V* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
 template <typename V>
 __device__ __forceinline__ V nr_fetch(u32 d, const V* __restrict__ vals, const V* hot, u32 hot_n, V identity) {
   const bool is_hot = d < hot_n;
   const bool none = (int)d < 0;
-  const V g = vals[(is_hot || none) ? 0u : d];
-  const V h = hot[is_hot ? d : 0u];
+  const V g = nr_load_pinned(vals + ((is_hot || none) ? 0u : d));
+  const V h = nr_load_pinned(hot + (is_hot ? d : 0u));
   return none ? identity : (is_hot ? h : g);
 }
 
@@ -110,7 +131,7 @@ __device__ __forceinline__ void nr_long_work(const nr_layout_t& L, const V* __re
   if (w < G) {
   // A step takes GPS groups (g, g + W, ...): four loads per group; load j covers units 16 g + 4 j .. + 3, lane (q, sub) reads
   // entries 4 sub .. 4 sub + 3 of unit 4 j + q.  The next step's loads are in flight while this step's 16 GPS gathers are.
-  constexpr int GPS = 2, NL = 4 * GPS;
+  constexpr int GPS = 1, NL = 4 * GPS;      // (two groups per step until round 5: with the gathers pinned (nr_load_pinned) all 32 + 32 of a step are in flight at once and spill)
   // (a unit's padding entries are -1 -- the identity to nr_fetch -- so nothing has to say how many of its 64 entries are real:
   //  the per-unit counts this loop used to load, one byte per lane and 16-byte load, doubled its memory instructions)
   typedef typename std::conditional<P24, nr_u32x3, nr_u32x4>::type raw_t;
@@ -277,7 +298,167 @@ __global__ __launch_bounds__(NT, WPE) void k_nr_edges(nr_layout_t L, const V* __
   nr_short_work<V, Op, NT>(L, vals, hot, hot_n, reduced, identity, op, blockIdx.x, gridDim.x);
 }
 
-// scratch the fast path needs (vals + partials), in bytes
+
+// ---- the long rows by slice of their destinations (round 5) -------------------------------------------------------------
+// k_nr_edges keeps the values of the first NR_HOTV layout vertices in LDS; every other entry is a 4-byte gather through the L2
+// -- 40 % of RMAT-22's long-row entries, 0.9 GB of sector traffic for 366 MB of entries (profiles/r05/pmc_by_kernel.txt):
+// what bounded the operator.  With the entries regrouped by SLICE of their destination (nr_layout_t::nrs_*) a workgroup takes
+// mini-units of one slice at a time, that slice's values in LDS: a lane loads 16 bytes -- eight 16-bit offsets --, reads eight
+// values from LDS, folds them in a fixed order and stores ONE partial; no gather leaves the compute unit, no shuffle, no
+// owner is looked up (the fold kernel knows where a row's partials are).  Only the tail behind the last hot slice (6 % of the
+// entries) still gathers.  The workgroups split the mini-unit sequence into equal contiguous shares: a share touches one or
+// two slices (the first slice is 60 % of everything), so a workgroup loads one or two tables.  In front of its share every
+// workgroup takes its part of the SHORT rows (nr_short_work) over the table of slice 0 -- the same values k_nr_edges keeps.
+template <typename V, typename Op, int NT>
+__device__ __forceinline__ void nrs_hot_pass(const uint4* __restrict__ mu, const V* hot, V* __restrict__ partial, u32 lo, u32 hi, Op op) {
+  constexpr int U = 4;
+  nr_u32x4 cur[U], nxt[U];
+  auto issue = [&](u32 j0, nr_u32x4* d) {
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const u32 jj = j0 + (u32)q * NT;
+      d[q] = __builtin_nontemporal_load((const nr_u32x4*)mu + (jj < hi ? jj : hi - 1u));
+    }
+  };
+  u32 j0 = lo + threadIdx.x;
+  if (j0 >= hi) return;
+  issue(j0, cur);
+  for (; j0 < hi; j0 += (u32)U * NT) {
+    issue(j0 + (u32)U * NT, nxt);
+    V s[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const V v0 = hot[cur[q].x & 0xFFFFu], v1 = hot[cur[q].x >> 16], v2 = hot[cur[q].y & 0xFFFFu], v3 = hot[cur[q].y >> 16];
+      const V v4 = hot[cur[q].z & 0xFFFFu], v5 = hot[cur[q].z >> 16], v6 = hot[cur[q].w & 0xFFFFu], v7 = hot[cur[q].w >> 16];
+      s[q] = op(op(op(v0, v1), op(v2, v3)), op(op(v4, v5), op(v6, v7)));
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const u32 jj = j0 + (u32)q * NT;
+      if (jj < hi) partial[jj] = s[q];
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) cur[q] = nxt[q];
+  }
+}
+
+// the tail: four layout ids per mini-unit, values gathered from the array (unconditional loads: padding reads vals[0])
+template <typename V, typename Op, int NT>
+__device__ __forceinline__ void nrs_tail_pass(const uint4* __restrict__ mu, const V* __restrict__ vals, V* __restrict__ partial, u32 lo, u32 hi,
+                                              V identity, Op op) {
+  constexpr int U = 4;
+  nr_u32x4 cur[U], nxt[U];
+  auto issue = [&](u32 j0, nr_u32x4* d) {
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const u32 jj = j0 + (u32)q * NT;
+      d[q] = __builtin_nontemporal_load((const nr_u32x4*)mu + (jj < hi ? jj : hi - 1u));
+    }
+  };
+  u32 j0 = lo + threadIdx.x;
+  if (j0 >= hi) return;
+  issue(j0, cur);
+  for (; j0 < hi; j0 += (u32)U * NT) {
+    issue(j0 + (u32)U * NT, nxt);
+    V g[U][4];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      g[q][0] = nr_load_pinned(vals + ((int)cur[q].x < 0 ? 0u : cur[q].x)); g[q][1] = nr_load_pinned(vals + ((int)cur[q].y < 0 ? 0u : cur[q].y));
+      g[q][2] = nr_load_pinned(vals + ((int)cur[q].z < 0 ? 0u : cur[q].z)); g[q][3] = nr_load_pinned(vals + ((int)cur[q].w < 0 ? 0u : cur[q].w));
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const V v0 = (int)cur[q].x < 0 ? identity : g[q][0], v1 = (int)cur[q].y < 0 ? identity : g[q][1];
+      const V v2 = (int)cur[q].z < 0 ? identity : g[q][2], v3 = (int)cur[q].w < 0 ? identity : g[q][3];
+      const u32 jj = j0 + (u32)q * NT;
+      if (jj < hi) partial[jj] = op(op(v0, v1), op(v2, v3));
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) cur[q] = nxt[q];
+  }
+}
+
+template <typename V, typename Op, int NT, int WPE = 4>
+__global__ __launch_bounds__(NT, WPE) void k_nrs_edges(nr_layout_t L, const V* __restrict__ vals, V* __restrict__ partial, V* __restrict__ reduced,
+                                                     V identity, Op op, const u32* dev_flag, u32 epoch) {
+  static_assert(sizeof(V) == 4, "k_nrs_edges keeps NR_HOTV 4-byte values in LDS (nr_lds_bytes)");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (*dev_flag == epoch) return;                    // (grid-uniform)
+  constexpr u32 S = (u32)NR_HOTV;
+  const u32 n = (u32)L.n;
+  const u32 hot_n = n < S ? n : S;
+  if (threadIdx.x == 0) ((V*)smem)[S] = identity;    // what a padding offset reads (nr_lds_bytes has the room)
+  V* const hot = nr_hot_setup<V, NT>(smem, vals, hot_n);
+  nr_short_work<V, Op, NT>(L, vals, hot, hot_n, reduced, identity, op, blockIdx.x, gridDim.x);
+  const u32 K = L.nrs_slices, M = L.nrs_first[K + 1];
+  const u32 lo_b = (u32)((u64)M * blockIdx.x / gridDim.x), hi_b = (u32)((u64)M * (blockIdx.x + 1u) / gridDim.x);
+  u32 loaded = 0u;                                   // the slice whose values are in LDS
+  for (u32 k = 0; k <= K; ++k) {
+    const u32 f0 = L.nrs_first[k], f1 = L.nrs_first[k + 1];
+    const u32 lo = lo_b > f0 ? lo_b : f0, hi = hi_b < f1 ? hi_b : f1;
+    if (lo >= hi) continue;                          // (workgroup-uniform)
+    if (k < K) {
+      if (k != loaded) {
+        __syncthreads();                             // (every wave is done with the table in LDS)
+        const u32 base = k * S, cnt = n - base < S ? n - base : S;
+        for (u32 i = threadIdx.x; i < cnt; i += NT) hot[i] = vals[base + i];
+        __syncthreads();
+        loaded = k;
+      }
+      nrs_hot_pass<V, Op, NT>(L.nrs_mu, hot, partial, lo, hi, op);
+    } else {
+      nrs_tail_pass<V, Op, NT>(L.nrs_mu, vals, partial, lo, hi, identity, op);
+    }
+  }
+}
+
+// a long row's partials -> its result: the row's mini-units of slice k are [nrs_off[k * rows + r], nrs_off[k * rows + r + 1]), for
+// neighbouring rows neighbouring pieces of `partial`.  Rows [0, nrs_big_rows) take a workgroup each (a fixed strided fold), the
+// others a thread each, four accumulators combined in a fixed order: deterministic whatever the timing.
+template <typename V, typename Op>
+__global__ __launch_bounds__(BLOCK) void k_nrs_fold(nr_layout_t L, const V* __restrict__ partial, V* __restrict__ reduced, V identity, Op op,
+                                                    const u32* dev_flag, u32 epoch) {
+  __shared__ V s_part[BLOCK / WAVE];
+  if (*dev_flag == epoch) return;
+  const u32 K1 = L.nrs_slices + 1u, LR = L.nrs_rows;
+  const u32* __restrict__ off = L.nrs_off;
+  if (blockIdx.x < L.nrs_big_rows) {
+    const u32 r = blockIdx.x;
+    V acc = identity;
+    for (u32 k = 0; k < K1; ++k) {
+      const u32 a = off[(size_t)k * LR + r], b = off[(size_t)k * LR + r + 1u];
+      for (u32 j = a + threadIdx.x; j < b; j += BLOCK) acc = op(acc, partial[j]);
+    }
+#pragma unroll
+    for (int sh = 1; sh < WAVE; sh <<= 1) acc = op(acc, __shfl_xor(acc, sh, WAVE));
+    if (lane_id() == 0) s_part[threadIdx.x / WAVE] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      V t = s_part[0];
+#pragma unroll
+      for (int k = 1; k < BLOCK / WAVE; ++k) t = op(t, s_part[k]);
+      reduced[L.old_of_new[r]] = t;
+    }
+    return;
+  }
+  const u32 r = L.nrs_big_rows + (blockIdx.x - L.nrs_big_rows) * BLOCK + threadIdx.x;
+  if (r >= LR) return;
+  V a0 = identity, a1 = identity, a2 = identity, a3 = identity;
+  for (u32 k = 0; k < K1; ++k) {
+    const u32 a = off[(size_t)k * LR + r], b = off[(size_t)k * LR + r + 1u];
+    u32 j = a;
+    for (; j + 4u <= b; j += 4u) {
+      const V p0 = partial[j], p1 = partial[j + 1u], p2 = partial[j + 2u], p3 = partial[j + 3u];
+      a0 = op(a0, p0); a1 = op(a1, p1); a2 = op(a2, p2); a3 = op(a3, p3);
+    }
+    if (j < b) a0 = op(a0, partial[j]);
+    if (j + 1u < b) a1 = op(a1, partial[j + 1u]);
+    if (j + 2u < b) a2 = op(a2, partial[j + 2u]);
+  }
+  reduced[L.old_of_new[r]] = op(op(a0, a1), op(a2, a3));
+}
+
+// scratch the fast path needs (vals + partials: one per unit, or per mini-unit of the sliced long rows), in bytes
 inline size_t nr_scratch_bytes(long long n, long long units_pad, size_t value_size) {
   return (((size_t)n + 64) * value_size + 255) / 256 * 256 + ((size_t)units_pad + 64) * value_size;
 }
@@ -297,6 +478,18 @@ inline void nr_full_frontier(const nr_layout_t& L, GetValue get, V* reduced, V i
     MGX_HIP(hipFuncSetAttribute((const void*)(k_nr_edges<V, Op, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipLaunchKernelGGL((k_nr_values<V, GetValue>), dim3(grid_for(L.n, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, get, L.old_of_new, vals,
                      reduced, identity, (long long)L.n, frontier, host_flag, dev_flag, epoch);
+  if (L.nrs_mu) {
+    // the long rows by slice of their destinations + the short rows, one launch; then the fold
+    static unsigned char seen_s[64] = {};
+    if (device_once_t once{seen_s})
+      MGX_HIP(hipFuncSetAttribute((const void*)(k_nrs_edges<V, Op, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL((k_nrs_edges<V, Op, 1024>), dim3(ctx.num_cus), dim3(1024), nr_lds_bytes(), s, L, (const V*)vals, partial, reduced,
+                       identity, op, dev_flag, epoch);
+    const u32 rest = L.nrs_rows > L.nrs_big_rows ? L.nrs_rows - L.nrs_big_rows : 0u;
+    const u32 grid = L.nrs_big_rows + (rest + BLOCK - 1) / BLOCK;
+    if (grid) hipLaunchKernelGGL((k_nrs_fold<V, Op>), dim3(grid), dim3(BLOCK), 0, s, L, (const V*)partial, reduced, identity, op, dev_flag, epoch);
+    return;
+  }
   const u32 long_rows = L.vs_v[0];
   const bool has_long = L.ub_units > 0 && long_rows > 0, has_short = L.vs_v[3] > L.vs_v[0];
   if (has_long || has_short)

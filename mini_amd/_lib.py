@@ -68,6 +68,7 @@ SIGNATURES = {
     "mgx_graph_csc_read": [_vp, _vp, _vp, _vp],
     "mgx_graph_layout_read": [_vp, _vp, _vp, _vp, _vp, _vp],
     "mgx_graph_layout_info": [_vp, _pi64],
+    "mgx_graph_nr_slices_info": [_vp, _pi64],
     "mgx_graph_free": [_vp],
     "mgx_graph_dims": [_vp, _pi, _pi64],
     "mgx_load_mtx": [C.c_char_p, _i, _i, _pi, _pi64, C.POINTER(_pi), C.POINTER(_pi), C.POINTER(_pf)],

@@ -110,6 +110,13 @@ class Graph:
         keys = ("has_layout", "units", "units_24bit", "cold_pairs", "cold_slices", "hot_units", "cold_majority", "device_bytes")
         return dict(zip(keys, (int(x) for x in out)))
 
+    def nr_slices_info(self):
+        """the long rows by slice of their destinations (mgx_graph_nr_slices_info; built at the first full-frontier reduce)"""
+        out = (C.c_int64 * 5)()
+        check(lib.mgx_graph_nr_slices_info(self._h, out))
+        keys = ("mini_units", "hot_slices", "long_rows", "big_rows", "tail_mini_units")
+        return dict(zip(keys, (int(x) for x in out)))
+
     def build_csc(self):
         """Genuine CSC (transpose) built by the library on the device (mgx_graph_build_csc): in-edges for the bottom-up
         levels on directed graphs."""

@@ -140,12 +140,57 @@ struct gather_functor_t {
   static __device__ __forceinline__ V get_value_to_reduce(int idx, slice_t* d, int) { return d->values[idx]; }
 };
 
+extern "C" int mgx_nrs_build_device(const int* ro, const int* ci, int rows, unsigned slice_n, int slices, void** mu, unsigned** off,
+                                    unsigned* first, long long* total, hipStream_t stream);   // mgx_layout.hip
+// The long rows by slice of their destinations (mgx/nreduce.hpp: k_nrs_edges), once per graph at its first neighbour-reduce
+// through the library: needs the layout with its degree classes (the long rows are [0, vs_v[0])); MGX_NR_SLICED=0 skips it.
+// 16 bytes per mini-unit -- RMAT-22: 17.5 M of them, 280 MB -- and a partial per mini-unit in the context's arena; left out
+// (the unit blocks serve) when the memory is not there.
+static void ensure_nr_slices(mgx_graph_s* g) {
+  graph_device_t& G = *g->g;
+  if (G.nrs_tried) return;
+  G.nrs_tried = true;
+  if (const char* e = getenv("MGX_NR_SLICED")) if (atoi(e) == 0) return;
+  if (!G.has_layout || G.ub_units <= 0 || !G.d_ub_first.size() || G.vs_long_min != G.ub_min_degree || G.vs_long_min < 17 || G.vs_long_min > 64 ||
+      G.vs_v[0] == 0 || G.vs_dummy == 0) return;
+  standard_context_t& ctx = *g->c->ctx;
+  const unsigned S = (unsigned)mgx::NR_HOTV;
+  const long long n = G.num_nodes;
+  int slices = (int)((n + S - 1) / S);
+  if (slices > mgx::NRS_MAX_SLICES) slices = mgx::NRS_MAX_SLICES;
+  if (const char* e = getenv("MGX_NR_SLICES")) { const int v = atoi(e); if (v >= 1 && v < slices) slices = v; }     // (tests: a tail on small graphs)
+  const int rows = (int)G.vs_v[0];
+  void* mu = nullptr;
+  unsigned* off = nullptr;
+  unsigned first[mgx::NRS_MAX_SLICES + 2] = {0};
+  long long total = 0;
+  ctx.synchronize();
+  const int rc = mgx_nrs_build_device(G.d_layout_row_offsets.data(), G.d_layout_col_indices.data(), rows, S, slices, &mu, &off, first, &total,
+                                      ctx.stream());
+  if (rc != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("sliced long rows: ") + hipGetErrorString((hipError_t)rc));
+  if (total <= 0 || !mu || !off) return;
+  G.d_nrs_mu = mem_t<unsigned>::adopt((unsigned*)mu, ((size_t)total + 4) * 4);
+  G.d_nrs_off = mem_t<unsigned>::adopt(off, (size_t)(slices + 1) * (size_t)rows + 1);
+  // rows of more than NRS_BIG_DEG entries (the layout is sorted by degree: a prefix), from the first rows' offsets
+  {
+    std::vector<int> h((size_t)rows + 1);
+    MGX_HIP(mgx::dtoh(h.data(), G.d_layout_row_offsets.data(), (size_t)rows + 1));
+    size_t lo = 0, hi = (size_t)rows;
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (h[mid + 1] - h[mid] > mgx::NRS_BIG_DEG) lo = mid + 1; else hi = mid; }
+    G.nrs_big_rows = (unsigned)lo;
+  }
+  ctx.reserve_scratch(mgx::nr_scratch_bytes(G.num_nodes, total, 8));      // (a partial per mini-unit)
+  for (int k = 0; k < mgx::NRS_MAX_SLICES + 2; ++k) G.nrs_first[k] = k <= slices + 1 ? first[k] : first[slices + 1];
+  G.nrs_slices = (unsigned)slices; G.nrs_rows = (unsigned)rows; G.nrs_units = total;
+}
+
 template <typename V, typename Op>
 int segreduce_impl(mgx_graph_t g, mgx_frontier_t in, int push, const V* vals, V identity, V* reduced, int64_t* nz) {
   MGX_TRY
   MGX_REQUIRE(g && in && vals && reduced, "segreduce: NULL argument");
   use_device(g->c);
   standard_context_t& ctx = *g->c->ctx;
+  if (in->f && (long long)in->f->size() == (long long)g->g->num_nodes) ensure_nr_slices(g);     // (a full frontier may take mgx/nreduce.hpp)
   auto prob = std::make_shared<gather_problem_t<V>>(g->g, vals, ctx);
   std::shared_ptr<frontier_t<int>> dummy;
   int r;
@@ -375,6 +420,7 @@ static void build_unit_blocks(mgx_graph_s* g) {
   G.d_ub_col = mem_t<int>(); G.d_ub_owner = mem_t<int>(); G.ub_units = G.ub_units_pad = 0; G.ub_min_degree = 0;
   G.d_ub_col24 = mem_t<unsigned>();
   G.d_ub_cnt = mem_t<unsigned char>(); G.d_ub_first = mem_t<int>(); G.nr_big_rows = 0; G.d_ub_w = mem_t<float>(); G.d_ub_w16 = mem_t<unsigned short>(); G.ub_w_tried = false;
+  G.d_nrs_mu = mem_t<unsigned>(); G.d_nrs_off = mem_t<unsigned>(); G.nrs_units = 0; G.nrs_slices = G.nrs_rows = G.nrs_big_rows = 0; G.nrs_tried = false;
   if (const char* e = getenv("MGX_BFS_UNITS")) if (atoi(e) == 0) return;
   int long_min = mgx::LONG_MIN_DEFAULT;
   if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
@@ -700,7 +746,18 @@ int mgx_graph_layout_info(mgx_graph_t g, int64_t* out8) {
   out8[7] = bytes(G.d_layout_row_offsets) + bytes(G.d_layout_col_indices) + bytes(G.d_layout_col_values) + bytes(G.d_new_of_old) + bytes(G.d_old_of_new) +
             bytes(G.d_ub_col) + bytes(G.d_ub_col24) + bytes(G.d_ub_owner) + bytes(G.d_ubh_col24) + bytes(G.d_ubh_owner) + bytes(G.d_ub_w) + bytes(G.d_ub_w16) +
             bytes(G.d_ub_cnt) + bytes(G.d_ub_first) + bytes(G.d_ss_tab) + bytes(G.d_cold_owner) + bytes(G.d_cold_dst) + bytes(G.d_cold_pk) + bytes(G.d_cold_cbase) +
-            bytes(G.d_colds_owner) + bytes(G.d_colds_dst);
+            bytes(G.d_colds_owner) + bytes(G.d_colds_dst) + bytes(G.d_nrs_mu) + bytes(G.d_nrs_off);
+  MGX_CATCH
+}
+int mgx_graph_nr_slices_info(mgx_graph_t g, int64_t* out5) {
+  MGX_TRY
+  MGX_REQUIRE(g && out5, "NULL argument");
+  const graph_device_t& G = *g->g;
+  out5[0] = (int64_t)G.nrs_units;
+  out5[1] = (int64_t)G.nrs_slices;
+  out5[2] = (int64_t)G.nrs_rows;
+  out5[3] = (int64_t)G.nrs_big_rows;
+  out5[4] = G.nrs_units > 0 ? (int64_t)(G.nrs_first[G.nrs_slices + 1] - G.nrs_first[G.nrs_slices]) : 0;
   MGX_CATCH
 }
 int mgx_graph_layout_read(mgx_graph_t g, int* h_row_offsets, int* h_col_indices, int* h_new_of_old, int* h_old_of_new,
@@ -2195,6 +2252,7 @@ int mgx_pr_enact(mgx_pr_t p, int64_t* lens, int* iterations) {
   use_device(p->g->c);
   standard_context_t& ctx = *p->g->c->ctx;
   if (!p->e) p->e.reset(new pr::pr_enactor_t(ctx, p->g->g->num_nodes, p->g->g->num_edges));
+  ensure_nr_slices(p->g);
   p->e->enact(p->p, ctx);
   ctx.synchronize();
   if (iterations) *iterations = (int)p->e->frontier_lengths.size();

@@ -683,3 +683,104 @@ extern "C" int mgx_shard_fill_device(void* handle, int* row_offsets, int* col, i
   return 0;
 }
 extern "C" void mgx_shard_free_device(void* handle) { delete (shard_plan_t*)handle; }
+
+// ---- the long rows by SLICE of their destinations, for the neighbour-reduce (mgx/nreduce.hpp: k_nrs_edges) ----------------
+// The full-frontier reduce gathers value(dst) per entry; only slice_n values (160 KB) fit the LDS of a compute unit, and on
+// RMAT-22 the first 40 000 layout vertices are 60 % of the long rows' endpoints -- the other 40 % were 4-byte gathers through
+// the L2, what bounded the kernel.  Here the entries of the rows [0, rows) are regrouped slice-major: slice k < slices holds
+// the entries with dst in [k * slice_n, (k + 1) * slice_n), slice `slices` (the TAIL) everything behind.  Inside a slice the
+// rows follow each other, each row's entries (the rows are sorted: a contiguous piece of the row) cut into MINI-UNITS of 16
+// bytes -- 8 offsets into the slice at 16 bits each (padding: slice_n, where the kernel keeps the identity), in the tail 4
+// layout ids at 32 bits (padding: -1).  A workgroup that takes mini-units of ONE slice keeps that slice's values in LDS: no
+// gather leaves the compute unit, one lane folds one mini-unit, and off[k * rows + r] says where row r's partials of slice k
+// start.  RMAT-22: 16 slices cover 94 % of the long rows' entries; 17.5 M mini-units, 1.21 slots per entry.
+namespace {
+
+// the entries of row [r0, r1) below `bound` (rows are sorted by neighbour)
+__device__ __forceinline__ int nrs_lower(const int* __restrict__ ci, int r0, int r1, unsigned long long bound) {
+  int lo = r0, hi = r1;
+  while (lo < hi) { const int mid = lo + (hi - lo) / 2; if ((unsigned long long)(unsigned)ci[mid] < bound) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+// cnt[k * rows + r] = mini-units of (slice k, row r); cnt[(slices + 1) * rows] = 0 (so that the scan's last entry is the total)
+__global__ void k_nrs_counts(const int* __restrict__ ro, const int* __restrict__ ci, int rows, unsigned slice_n, int slices,
+                             unsigned* __restrict__ cnt) {
+  const long long cells = (long long)(slices + 1) * rows;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == cells) cnt[i] = 0u;
+  if (i >= cells) return;
+  const int k = (int)(i / rows), r = (int)(i % rows);
+  const int r0 = ro[r], r1 = ro[r + 1];
+  const int a = k == 0 ? r0 : nrs_lower(ci, r0, r1, (unsigned long long)k * slice_n);
+  const int b = k == slices ? r1 : nrs_lower(ci, r0, r1, (unsigned long long)(k + 1) * slice_n);
+  const unsigned c = (unsigned)(b - a);
+  cnt[i] = k < slices ? (c + 7u) / 8u : (c + 3u) / 4u;
+}
+
+// mini-unit j: its cell by a search in the scanned counts (setup code), its entries from the row
+__global__ void k_nrs_fill(const int* __restrict__ ro, const int* __restrict__ ci, int rows, unsigned slice_n, int slices,
+                           const unsigned* __restrict__ off, unsigned total, uint4* __restrict__ mu) {
+  const long long cells = (long long)(slices + 1) * rows;
+  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+    long long lo = 0, hi = cells;                   // last cell with off[cell] <= j (it is not empty: off[cell + 1] > j)
+    while (hi - lo > 1) { const long long mid = lo + (hi - lo) / 2; if (off[mid] <= j) lo = mid; else hi = mid; }
+    const int k = (int)(lo / rows), r = (int)(lo % rows);
+    const unsigned t = j - off[lo];
+    const int r0 = ro[r], r1 = ro[r + 1];
+    const int a = k == 0 ? r0 : nrs_lower(ci, r0, r1, (unsigned long long)k * slice_n);
+    const int b = k == slices ? r1 : nrs_lower(ci, r0, r1, (unsigned long long)(k + 1) * slice_n);
+    unsigned w[4];
+    if (k < slices) {
+      const unsigned base = (unsigned)k * slice_n;
+      unsigned e[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const int at = a + (int)(t * 8u) + q; e[q] = at < b ? (unsigned)ci[at] - base : slice_n; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = e[2 * q] | (e[2 * q + 1] << 16);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int at = a + (int)(t * 4u) + q; w[q] = at < b ? (unsigned)ci[at] : 0xFFFFFFFFu; }
+    }
+    mu[j] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+}  // namespace
+
+// The rows [0, rows) of the layout (ro / ci: device, rows sorted by neighbour), slice_n <= 65535 values per slice, `slices` hot
+// slices + the tail.  Allocates *mu (16 bytes per mini-unit, + 64 of slack) and *off ((slices + 1) * rows + 1 words) with hipMalloc;
+// first[k] (host, slices + 2 words) = first mini-unit of slice k, first[slices + 1] = *total.  Nothing is allocated when
+// there are no mini-units or more than 2^31 of them.  Returns with `stream` synchronised.
+extern "C" int mgx_nrs_build_device(const int* ro, const int* ci, int rows, unsigned slice_n, int slices, void** mu, unsigned** off,
+                                    unsigned* first, long long* total, hipStream_t stream) {
+  *mu = nullptr; *off = nullptr; *total = 0;
+  for (int k = 0; k <= slices + 1; ++k) first[k] = 0u;
+  if (rows <= 0 || slices <= 0 || slice_n == 0u || slice_n > 65535u) return 0;
+  const size_t cells = (size_t)(slices + 1) * (size_t)rows;
+  tmp_t cnt, st;
+  unsigned* offs = nullptr;
+  LAY_TRY(cnt.alloc((cells + 1) * 4));
+  LAY_TRY(hipMalloc((void**)&offs, (cells + 1) * 4));
+  hipLaunchKernelGGL(k_nrs_counts, dim3((unsigned)((cells + 1 + 255) / 256)), dim3(256), 0, stream, ro, ci, rows, slice_n, slices,
+                     cnt.as<unsigned>());
+  // (64-bit sums would be needed past 2^32 mini-units: the entries are fewer than 2^31, a mini-unit holds at least one)
+  size_t sb = 0;
+  hipError_t e = rocprim::exclusive_scan(nullptr, sb, cnt.as<unsigned>(), offs, 0u, cells + 1, rocprim::plus<unsigned>(), stream);
+  if (e == hipSuccess) e = st.alloc(sb);
+  if (e == hipSuccess) e = rocprim::exclusive_scan(st.p, sb, cnt.as<unsigned>(), offs, 0u, cells + 1, rocprim::plus<unsigned>(), stream);
+  for (int k = 0; k <= slices + 1 && e == hipSuccess; ++k)
+    e = hipMemcpyAsync(first + k, offs + (size_t)k * rows, 4, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  const unsigned M = first[slices + 1];
+  if (e != hipSuccess || M == 0u || M >= (1u << 31)) { (void)hipFree(offs); for (int k = 0; k <= slices + 1; ++k) first[k] = 0u; return (int)e; }
+  void* units = nullptr;
+  e = hipMalloc(&units, ((size_t)M + 4) * 16);
+  if (e != hipSuccess) { (void)hipFree(offs); for (int k = 0; k <= slices + 1; ++k) first[k] = 0u; (void)hipGetLastError(); return 0; }   // (no memory: no slices)
+  hipLaunchKernelGGL(k_nrs_fill, dim3(8192), dim3(256), 0, stream, ro, ci, rows, slice_n, slices, (const unsigned*)offs, M, (uint4*)units);
+  e = hipMemsetAsync((char*)units + (size_t)M * 16, 0xFF, 64, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) { (void)hipFree(offs); (void)hipFree(units); for (int k = 0; k <= slices + 1; ++k) first[k] = 0u; return (int)e; }
+  *mu = units; *off = offs; *total = (long long)M;
+  return 0;
+}

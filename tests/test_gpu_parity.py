@@ -1147,3 +1147,49 @@ def test_sssp_fused_preds_form_a_shortest_path_tree(gpu_ctx, oracle, layout):
             sssp.run(src)
             assert np.array_equal(sssp.preds(), pred), "the predecessors differ between two runs"
         sssp.close()
+
+
+@pytest.mark.parametrize("op", ["f32_plus", "i32_min", "i32_max"])
+@pytest.mark.parametrize("slices", [0, 1, 2])
+def test_neighbour_reduce_sliced_long_rows(gpu_ctx, oracle, torch_mod, monkeypatch, op, slices):
+    """the long rows by slice of their destinations (mgx/nreduce.hpp: k_nrs_edges / k_nrs_fold, round 5) on R-MAT 17 (131 072
+    vertices: four hot slices of 40 000): the default cut, and with one / two hot slices only, so that the TAIL (32-bit ids, values
+    gathered) carries most of the entries; every cut against the oracle's serial reduce -- exact for ints and for float sums of
+    small integers, 2e-5 relative for real-valued floats -- and the library says that the slices were built and used"""
+    import mini_amd
+    torch = torch_mod
+    if slices:
+        monkeypatch.setenv("MGX_NR_SLICES", str(slices))
+    n, ro, ci, w = oracle.rmat_csr(17, 16, 77)
+    g = _graph(gpu_ctx, ro, ci).build_layout()
+    rng = np.random.default_rng(17 + slices)
+    ids = np.arange(n, dtype=np.int32)
+    f = mini_amd.Frontier(gpu_ctx, n).load(ids)
+    for rep in range(2):
+        if op == "f32_plus":
+            for real in (False, True):
+                vals = (rng.random(n) * 3.0).astype(np.float32) if real else rng.integers(0, 8, size=n).astype(np.float32)
+                dv = torch.from_numpy(vals).cuda()
+                red = torch.full((n,), -1, dtype=torch.float32, device="cuda")
+                nz = mini_amd.segreduce(g, f, dv, 0.0, red, op)
+                want, wnz = oracle.neighbor_reduce_f32_plus(ro, ci, ids, vals, 0.0)
+                assert nz == wnz == len(ci)
+                got = red.cpu().numpy()
+                if real:
+                    assert np.allclose(got, want, rtol=2e-5, atol=1e-6), np.abs(got - want).max()
+                else:
+                    assert np.array_equal(got, want)
+        else:
+            vals = rng.integers(-1000, 1000, size=n).astype(np.int32)
+            dv = torch.from_numpy(vals).cuda()
+            ident = 2**31 - 1 if op == "i32_min" else -2**31
+            red = torch.full((n,), 12345, dtype=torch.int32, device="cuda")
+            nz = mini_amd.segreduce(g, f, dv, ident, red, op)
+            want, wnz = oracle.neighbor_reduce_i32(ro, ci, ids, vals, ident, op == "i32_max")
+            assert nz == wnz
+            assert np.array_equal(red.cpu().numpy(), want)
+    info = g.nr_slices_info()
+    if os.environ.get("MGX_NR_SLICED", "1") != "0":
+        assert info["mini_units"] > 0 and info["long_rows"] > 0
+        assert info["hot_slices"] == (slices if slices else 4)
+        assert (info["tail_mini_units"] > 0) == (slices in (1, 2))

@@ -54,7 +54,7 @@ if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
     # the other modes' dominant kernels: the same two counters from passes over `bench.py --mode sssp` / `--mode pr`
     # (kernels summed, the kernel whose dispatches count the "launches" bench.py divides by)
     for mode, pat, unit_pat, kname in (("sssp", "k_sssp_relax", "k_sssp_relax<", "k_sssp_relax<1024> (+ k_sssp_relax_dense<1024> on heavy iterations)"),
-                                       ("pr", "k_nr_", "k_nr_edges", "neighbour-reduce operator")):
+                                       ("pr", "k_nr", "k_nr_values", "neighbour-reduce operator")):
         vals = {}
         for cn in ("FETCH_SIZE", "WRITE_SIZE"):
             agg, cnt = 0.0, 0
