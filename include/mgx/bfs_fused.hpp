@@ -512,21 +512,26 @@ __device__ __forceinline__ int bfs_hot_epilogue(const bfs_fused_args_t& a, const
   // few: the marks themselves.  All of this thread's words of the bitmap first, every load unconditional (round 5: with the load under
   // `i < defer_words` the code generator put each one in a branch of its own with an s_waitcnt vmcnt(0) behind it -- PERT dependent
   // round trips to the L2 at the end of the workgroup; a relaxed atomic load of wavefront scope is the same instruction, but stays put)
-  u32 vis[PERT];
+  constexpr int CH = 5;                                            // loads in flight per thread (all PERT at once cost the push kernels SGPR spills)
 #pragma unroll
-  for (int q = 0; q < PERT; ++q) {
-    const u32 i = (u32)q * NT + threadIdx.x;
-    vis[q] = __hip_atomic_load(a.visited + (i < defer_words ? i : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  }
+  for (int q0 = 0; q0 < PERT; q0 += CH) {
+    u32 vis[CH];
 #pragma unroll
-  for (int q = 0; q < PERT; ++q) {
-    const u32 i = (u32)q * NT + threadIdx.x;
-    u32 w = i < defer_words ? (hot[i] & ~vis[q]) : 0u;
-    const u32 base = i * 32u;
-    while (w) {
-      const int b = __ffs((int)w) - 1;
-      w &= w - 1u;
-      a.mark[base + (u32)b] = 1;
+    for (int k = 0; k < CH; ++k) {
+      const u32 i = (u32)(q0 + k) * NT + threadIdx.x;
+      vis[k] = __hip_atomic_load(a.visited + (i < defer_words ? i : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      if (q0 + k >= PERT) break;
+      const u32 i = (u32)(q0 + k) * NT + threadIdx.x;
+      u32 w = i < defer_words ? (hot[i] & ~vis[k]) : 0u;
+      const u32 base = i * 32u;
+      while (w) {
+        const int b = __ffs((int)w) - 1;
+        w &= w - 1u;
+        a.mark[base + (u32)b] = 1;
+      }
     }
   }
   return total;
