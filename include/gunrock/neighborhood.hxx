@@ -69,6 +69,10 @@ int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fronti
       L.big_rows = graph.nr_big_rows;
       L.n = graph.num_nodes;
       {
+        static const unsigned parts = [] { const char* e = std::getenv("MGX_NR_PARTS"); return e ? (unsigned)std::atoi(e) & 3u : 3u; }();
+        L.parts = parts ? parts : 3u;
+      }
+      {
         // the long rows by slice of their destinations (MGX_NR_SLICED=0: the unit blocks, as before round 5), when the graph carries
         // them and the scratch arena holds a partial per mini-unit
         static const bool sliced = [] { const char* e = std::getenv("MGX_NR_SLICED"); return !e || std::atoi(e) != 0; }();
@@ -77,7 +81,7 @@ int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fronti
           L.nrs_mu = (const uint4*)graph.d_nrs_mu.data();
           L.nrs_off = graph.d_nrs_off.data();
           for (int i = 0; i < mgx::NRS_MAX_SLICES + 2; ++i) L.nrs_first[i] = graph.nrs_first[i];
-          L.nrs_slices = graph.nrs_slices; L.nrs_rows = graph.nrs_rows; L.nrs_big_rows = graph.nrs_big_rows;
+          L.nrs_slices = graph.nrs_slices; L.nrs_rows = graph.nrs_rows; L.nrs_big_rows = graph.nrs_big_rows; L.nrs_mid_rows = graph.nrs_mid_rows;
         }
       }
       mgx::nr_full_frontier<Value>(L, [=] __device__(int v) -> Value { return Functor::get_value_to_reduce(v, data, iteration); }, reduced,

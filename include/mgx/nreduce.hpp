@@ -39,7 +39,8 @@ constexpr int NR_HOTV = 40000;            // values of the first NR_HOTV layout 
 constexpr int NR_BIG_UNITS = 64;          // rows of more units than this are folded by a workgroup of their own
 constexpr size_t nr_lds_bytes() { return (size_t)NR_HOTV * 4 + 64; }
 constexpr int NRS_MAX_SLICES = 16;        // hot slices of the sliced long rows (k_nrs_edges): 16 x 40 000 vertices hold 94 % of RMAT-22's long-row endpoints
-constexpr int NRS_BIG_DEG = 1024;         // rows of more entries than this: their partials are folded by a workgroup each
+constexpr int NRS_BIG_DEG = 16384;        // rows of more entries than this: their partials are folded by a workgroup each,
+constexpr int NRS_MID_DEG = 1024;         // ... of more than this by a wave each, the others by a thread each (k_nrs_fold)
 
 struct nr_layout_t {
   const u32* row_offsets = nullptr;       // the layout's CSR
@@ -62,7 +63,9 @@ struct nr_layout_t {
   u32 nrs_first[NRS_MAX_SLICES + 2] = {}; // first mini-unit of slice k; [nrs_slices + 1] = all of them
   u32 nrs_slices = 0;
   u32 nrs_rows = 0;                       // the long rows: [0, nrs_rows) (= vs_v[0])
-  u32 nrs_big_rows = 0;                   // rows [0, nrs_big_rows) have more than NRS_BIG_DEG entries: a workgroup each folds their partials
+  u32 nrs_big_rows = 0;                   // rows [0, nrs_big_rows) have more than NRS_BIG_DEG entries: a workgroup each folds their partials,
+  u32 nrs_mid_rows = 0;                   // rows [nrs_big_rows, nrs_mid_rows) more than NRS_MID_DEG: a wave each
+  u32 parts = 3u;                         // (timing runs, MGX_NR_PARTS: 1 the short rows only, 2 the long rows only -- the results are then incomplete)
 };
 
 // k_nr_values also answers: is the frontier 0, 1, ..., n - 1?  *host_flag (pinned) was set to 1 by the host before the launch;
@@ -293,9 +296,11 @@ __global__ __launch_bounds__(NT, WPE) void k_nr_edges(nr_layout_t L, const V* __
   const V* const hot = nr_hot_setup<V, NT>(smem, vals, hot_n);
   // every workgroup takes its share of BOTH parts, one after the other over the same LDS values: the parts differ in cost
   // per entry (the short rows pay a planning load per vertex), so any fixed split of the grid leaves one half waiting
-  if (L.ub_col24) nr_long_work<V, Op, NT, true>(L, vals, hot, hot_n, partial, identity, op, blockIdx.x, gridDim.x);      // (grid-uniform)
-  else nr_long_work<V, Op, NT, false>(L, vals, hot, hot_n, partial, identity, op, blockIdx.x, gridDim.x);
-  nr_short_work<V, Op, NT>(L, vals, hot, hot_n, reduced, identity, op, blockIdx.x, gridDim.x);
+  if (L.parts & 2u) {
+    if (L.ub_col24) nr_long_work<V, Op, NT, true>(L, vals, hot, hot_n, partial, identity, op, blockIdx.x, gridDim.x);      // (grid-uniform)
+    else nr_long_work<V, Op, NT, false>(L, vals, hot, hot_n, partial, identity, op, blockIdx.x, gridDim.x);
+  }
+  if (L.parts & 1u) nr_short_work<V, Op, NT>(L, vals, hot, hot_n, reduced, identity, op, blockIdx.x, gridDim.x);
 }
 
 
@@ -389,46 +394,89 @@ __global__ __launch_bounds__(NT, WPE) void k_nrs_edges(nr_layout_t L, const V* _
   const u32 hot_n = n < S ? n : S;
   if (threadIdx.x == 0) ((V*)smem)[S] = identity;    // what a padding offset reads (nr_lds_bytes has the room)
   V* const hot = nr_hot_setup<V, NT>(smem, vals, hot_n);
-  nr_short_work<V, Op, NT>(L, vals, hot, hot_n, reduced, identity, op, blockIdx.x, gridDim.x);
-  const u32 K = L.nrs_slices, M = L.nrs_first[K + 1];
-  const u32 lo_b = (u32)((u64)M * blockIdx.x / gridDim.x), hi_b = (u32)((u64)M * (blockIdx.x + 1u) / gridDim.x);
+  if (L.parts & 1u) nr_short_work<V, Op, NT>(L, vals, hot, hot_n, reduced, identity, op, blockIdx.x, gridDim.x);
+  if (!(L.parts & 2u)) return;
+  // every workgroup takes an equal contiguous share of the HOT mini-units (one or two slices: one or two tables) and an equal share
+  // of the TAIL's: a tail mini-unit costs four gathers through the compute unit's vector memory path, and with the tail at the end
+  // of one sequence the last 25 workgroups did all 7.5 M of them (433 us for the long rows' part against 60 for everybody else)
+  const u32 K = L.nrs_slices, H = L.nrs_first[K], M = L.nrs_first[K + 1];
+  const u32 lo_b = (u32)((u64)H * blockIdx.x / gridDim.x), hi_b = (u32)((u64)H * (blockIdx.x + 1u) / gridDim.x);
   u32 loaded = 0u;                                   // the slice whose values are in LDS
-  for (u32 k = 0; k <= K; ++k) {
+  for (u32 k = 0; k < K; ++k) {
     const u32 f0 = L.nrs_first[k], f1 = L.nrs_first[k + 1];
     const u32 lo = lo_b > f0 ? lo_b : f0, hi = hi_b < f1 ? hi_b : f1;
     if (lo >= hi) continue;                          // (workgroup-uniform)
-    if (k < K) {
-      if (k != loaded) {
-        __syncthreads();                             // (every wave is done with the table in LDS)
-        const u32 base = k * S, cnt = n - base < S ? n - base : S;
-        for (u32 i = threadIdx.x; i < cnt; i += NT) hot[i] = vals[base + i];
-        __syncthreads();
-        loaded = k;
-      }
-      nrs_hot_pass<V, Op, NT>(L.nrs_mu, hot, partial, lo, hi, op);
-    } else {
-      nrs_tail_pass<V, Op, NT>(L.nrs_mu, vals, partial, lo, hi, identity, op);
+    if (k != loaded) {
+      __syncthreads();                               // (every wave is done with the table in LDS)
+      const u32 base = k * S, cnt = n - base < S ? n - base : S;
+      for (u32 i = threadIdx.x; i < cnt; i += NT) hot[i] = vals[base + i];
+      __syncthreads();
+      loaded = k;
     }
+    nrs_hot_pass<V, Op, NT>(L.nrs_mu, hot, partial, lo, hi, op);
+  }
+  if (M > H) {
+    const u32 T = M - H;
+    const u32 lo = H + (u32)((u64)T * blockIdx.x / gridDim.x), hi = H + (u32)((u64)T * (blockIdx.x + 1u) / gridDim.x);
+    if (lo < hi) nrs_tail_pass<V, Op, NT>(L.nrs_mu, vals, partial, lo, hi, identity, op);
   }
 }
 
 // a long row's partials -> its result: the row's mini-units of slice k are [nrs_off[k * rows + r], nrs_off[k * rows + r + 1]), for
-// neighbouring rows neighbouring pieces of `partial`.  Rows [0, nrs_big_rows) take a workgroup each (a fixed strided fold), the
-// others a thread each, four accumulators combined in a fixed order: deterministic whatever the timing.
+// neighbouring rows neighbouring pieces of `partial`.  LANES lanes fold ONE row: all of its ranges' ends first (independent loads),
+// then every range's first LANES partials (again all in flight at once: for most rows that is everything), then what is left of
+// the long ranges.  The first version walked the slices one after the other -- a dependent pair of round trips per slice, 17 in a
+// row, a workgroup each for 16 515 rows: 93 us.  Fixed strides, fixed order: deterministic.
+template <typename V, typename Op, int LANES>
+__device__ __forceinline__ V nrs_fold_row(const u32* __restrict__ off, const V* __restrict__ partial, u32 K1, u32 LR, u32 r, u32 lane, V identity, Op op) {
+  constexpr int KM = NRS_MAX_SLICES + 1;
+  u32 a[KM], b[KM];
+#pragma unroll
+  for (int k = 0; k < KM; ++k) {
+    const size_t at = (size_t)((u32)k < K1 ? (u32)k : 0u) * LR + r;
+    a[k] = nr_load_pinned(off + at);
+    b[k] = nr_load_pinned(off + at + 1u);
+  }
+  V first[KM];
+#pragma unroll
+  for (int k = 0; k < KM; ++k) {
+    const u32 j = a[k] + lane;
+    const bool ok = (u32)k < K1 && j < b[k];
+    first[k] = nr_load_pinned(partial + (ok ? j : 0u));
+    if (!ok) first[k] = identity;
+  }
+  V acc = identity;
+#pragma unroll
+  for (int k = 0; k < KM; ++k) acc = op(acc, first[k]);
+#pragma unroll
+  for (int k = 0; k < KM; ++k) {
+    if ((u32)k < K1) {
+      V a0 = identity, a1 = identity;
+      u32 j = a[k] + lane + (u32)LANES;
+      for (; j + (u32)LANES < b[k]; j += 2u * LANES) {
+        const V p0 = partial[j], p1 = partial[j + (u32)LANES];
+        a0 = op(a0, p0); a1 = op(a1, p1);
+      }
+      if (j < b[k]) a0 = op(a0, partial[j]);
+      acc = op(acc, op(a0, a1));
+    }
+  }
+  return acc;
+}
+
 template <typename V, typename Op>
 __global__ __launch_bounds__(BLOCK) void k_nrs_fold(nr_layout_t L, const V* __restrict__ partial, V* __restrict__ reduced, V identity, Op op,
                                                     const u32* dev_flag, u32 epoch) {
-  __shared__ V s_part[BLOCK / WAVE];
+  constexpr int NW = BLOCK / WAVE;
+  __shared__ V s_part[NW];
   if (*dev_flag == epoch) return;
   const u32 K1 = L.nrs_slices + 1u, LR = L.nrs_rows;
   const u32* __restrict__ off = L.nrs_off;
-  if (blockIdx.x < L.nrs_big_rows) {
+  const u32 big = L.nrs_big_rows, mid = L.nrs_mid_rows;          // big <= mid <= LR
+  const u32 mid_blocks = (mid - big + NW - 1u) / NW;
+  if (blockIdx.x < big) {                                          // a workgroup per row
     const u32 r = blockIdx.x;
-    V acc = identity;
-    for (u32 k = 0; k < K1; ++k) {
-      const u32 a = off[(size_t)k * LR + r], b = off[(size_t)k * LR + r + 1u];
-      for (u32 j = a + threadIdx.x; j < b; j += BLOCK) acc = op(acc, partial[j]);
-    }
+    V acc = nrs_fold_row<V, Op, BLOCK>(off, partial, K1, LR, r, threadIdx.x, identity, op);
 #pragma unroll
     for (int sh = 1; sh < WAVE; sh <<= 1) acc = op(acc, __shfl_xor(acc, sh, WAVE));
     if (lane_id() == 0) s_part[threadIdx.x / WAVE] = acc;
@@ -436,26 +484,23 @@ __global__ __launch_bounds__(BLOCK) void k_nrs_fold(nr_layout_t L, const V* __re
     if (threadIdx.x == 0) {
       V t = s_part[0];
 #pragma unroll
-      for (int k = 1; k < BLOCK / WAVE; ++k) t = op(t, s_part[k]);
+      for (int k = 1; k < NW; ++k) t = op(t, s_part[k]);
       reduced[L.old_of_new[r]] = t;
     }
     return;
   }
-  const u32 r = L.nrs_big_rows + (blockIdx.x - L.nrs_big_rows) * BLOCK + threadIdx.x;
-  if (r >= LR) return;
-  V a0 = identity, a1 = identity, a2 = identity, a3 = identity;
-  for (u32 k = 0; k < K1; ++k) {
-    const u32 a = off[(size_t)k * LR + r], b = off[(size_t)k * LR + r + 1u];
-    u32 j = a;
-    for (; j + 4u <= b; j += 4u) {
-      const V p0 = partial[j], p1 = partial[j + 1u], p2 = partial[j + 2u], p3 = partial[j + 3u];
-      a0 = op(a0, p0); a1 = op(a1, p1); a2 = op(a2, p2); a3 = op(a3, p3);
-    }
-    if (j < b) a0 = op(a0, partial[j]);
-    if (j + 1u < b) a1 = op(a1, partial[j + 1u]);
-    if (j + 2u < b) a2 = op(a2, partial[j + 2u]);
+  if (blockIdx.x < big + mid_blocks) {                             // a wave per row
+    const u32 r = big + (blockIdx.x - big) * NW + (u32)__builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+    if (r >= mid) return;
+    V acc = nrs_fold_row<V, Op, WAVE>(off, partial, K1, LR, r, (u32)lane_id(), identity, op);
+#pragma unroll
+    for (int sh = 1; sh < WAVE; sh <<= 1) acc = op(acc, __shfl_xor(acc, sh, WAVE));
+    if (lane_id() == 0) reduced[L.old_of_new[r]] = acc;
+    return;
   }
-  reduced[L.old_of_new[r]] = op(op(a0, a1), op(a2, a3));
+  const u32 r = mid + (blockIdx.x - big - mid_blocks) * BLOCK + threadIdx.x;      // a thread per row
+  if (r >= LR) return;
+  reduced[L.old_of_new[r]] = nrs_fold_row<V, Op, 1>(off, partial, K1, LR, r, 0u, identity, op);
 }
 
 // scratch the fast path needs (vals + partials: one per unit, or per mini-unit of the sliced long rows), in bytes
@@ -485,8 +530,7 @@ inline void nr_full_frontier(const nr_layout_t& L, GetValue get, V* reduced, V i
       MGX_HIP(hipFuncSetAttribute((const void*)(k_nrs_edges<V, Op, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL((k_nrs_edges<V, Op, 1024>), dim3(ctx.num_cus), dim3(1024), nr_lds_bytes(), s, L, (const V*)vals, partial, reduced,
                        identity, op, dev_flag, epoch);
-    const u32 rest = L.nrs_rows > L.nrs_big_rows ? L.nrs_rows - L.nrs_big_rows : 0u;
-    const u32 grid = L.nrs_big_rows + (rest + BLOCK - 1) / BLOCK;
+    const u32 grid = L.nrs_big_rows + (L.nrs_mid_rows - L.nrs_big_rows + BLOCK / WAVE - 1) / (BLOCK / WAVE) + (L.nrs_rows - L.nrs_mid_rows + BLOCK - 1) / BLOCK;
     if (grid) hipLaunchKernelGGL((k_nrs_fold<V, Op>), dim3(grid), dim3(BLOCK), 0, s, L, (const V*)partial, reduced, identity, op, dev_flag, epoch);
     return;
   }

@@ -175,9 +175,15 @@ static void ensure_nr_slices(mgx_graph_s* g) {
   {
     std::vector<int> h((size_t)rows + 1);
     MGX_HIP(mgx::dtoh(h.data(), G.d_layout_row_offsets.data(), (size_t)rows + 1));
-    size_t lo = 0, hi = (size_t)rows;
-    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (h[mid + 1] - h[mid] > mgx::NRS_BIG_DEG) lo = mid + 1; else hi = mid; }
-    G.nrs_big_rows = (unsigned)lo;
+    auto first_at_most = [&](int d) {            // first row of at most d entries (degrees are non-increasing)
+      size_t lo = 0, hi = (size_t)rows;
+      while (lo < hi) { const size_t mid = (lo + hi) / 2; if (h[mid + 1] - h[mid] > d) lo = mid + 1; else hi = mid; }
+      return (unsigned)lo;
+    };
+    int big_deg = mgx::NRS_BIG_DEG, mid_deg = mgx::NRS_MID_DEG;
+    if (const char* e = getenv("MGX_NR_FOLD_DEGS")) { int b2 = 0, m2 = 0; if (sscanf(e, "%d/%d", &b2, &m2) == 2 && b2 >= m2 && m2 >= 0) { big_deg = b2; mid_deg = m2; } }   // (tests: every tier on small graphs)
+    G.nrs_big_rows = first_at_most(big_deg);
+    G.nrs_mid_rows = std::max(G.nrs_big_rows, first_at_most(mid_deg));
   }
   ctx.reserve_scratch(mgx::nr_scratch_bytes(G.num_nodes, total, 8));      // (a partial per mini-unit)
   for (int k = 0; k < mgx::NRS_MAX_SLICES + 2; ++k) G.nrs_first[k] = k <= slices + 1 ? first[k] : first[slices + 1];
@@ -420,7 +426,7 @@ static void build_unit_blocks(mgx_graph_s* g) {
   G.d_ub_col = mem_t<int>(); G.d_ub_owner = mem_t<int>(); G.ub_units = G.ub_units_pad = 0; G.ub_min_degree = 0;
   G.d_ub_col24 = mem_t<unsigned>();
   G.d_ub_cnt = mem_t<unsigned char>(); G.d_ub_first = mem_t<int>(); G.nr_big_rows = 0; G.d_ub_w = mem_t<float>(); G.d_ub_w16 = mem_t<unsigned short>(); G.ub_w_tried = false;
-  G.d_nrs_mu = mem_t<unsigned>(); G.d_nrs_off = mem_t<unsigned>(); G.nrs_units = 0; G.nrs_slices = G.nrs_rows = G.nrs_big_rows = 0; G.nrs_tried = false;
+  G.d_nrs_mu = mem_t<unsigned>(); G.d_nrs_off = mem_t<unsigned>(); G.nrs_units = 0; G.nrs_slices = G.nrs_rows = G.nrs_big_rows = G.nrs_mid_rows = 0; G.nrs_tried = false;
   if (const char* e = getenv("MGX_BFS_UNITS")) if (atoi(e) == 0) return;
   int long_min = mgx::LONG_MIN_DEFAULT;
   if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
