@@ -105,7 +105,8 @@ struct graph_device_t {
   mem_t<unsigned> d_nrs_mu;
   mem_t<unsigned> d_nrs_off;
   unsigned nrs_first[18] = {0};      // (mgx::NRS_MAX_SLICES + 2)
-  unsigned nrs_slices = 0, nrs_rows = 0, nrs_big_rows = 0, nrs_mid_rows = 0;
+  unsigned nrs_slices = 0, nrs_rows = 0;
+  unsigned nrs_tier[3] = {0, 0, 0};  // k_nrs_fold: rows [0, t0) a workgroup each, [t0, t1) a wave, [t1, t2) eight lanes, the others a thread
   long long nrs_units = 0;
   bool nrs_tried = false;
   // Degree classes of the layout's short rows (mgx/bfs_fused_vshort.hpp): only for a layout the library built itself

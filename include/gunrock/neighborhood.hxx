@@ -81,7 +81,7 @@ int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fronti
           L.nrs_mu = (const uint4*)graph.d_nrs_mu.data();
           L.nrs_off = graph.d_nrs_off.data();
           for (int i = 0; i < mgx::NRS_MAX_SLICES + 2; ++i) L.nrs_first[i] = graph.nrs_first[i];
-          L.nrs_slices = graph.nrs_slices; L.nrs_rows = graph.nrs_rows; L.nrs_big_rows = graph.nrs_big_rows; L.nrs_mid_rows = graph.nrs_mid_rows;
+          L.nrs_slices = graph.nrs_slices; L.nrs_rows = graph.nrs_rows; for (int i = 0; i < 3; ++i) L.nrs_tier[i] = graph.nrs_tier[i];
         }
       }
       mgx::nr_full_frontier<Value>(L, [=] __device__(int v) -> Value { return Functor::get_value_to_reduce(v, data, iteration); }, reduced,

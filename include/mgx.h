@@ -95,7 +95,7 @@ MGX_API int mgx_graph_layout_info(mgx_graph_t g, int64_t* out8);
 /* The long rows regrouped by slice of their destinations for the full-frontier neighbour-reduce (mgx/nreduce.hpp: k_nrs_edges; replaces
  * the gather of value(u) per edge of the reference's neighborhood_kernel, neighborhood.hxx:39-58, by LDS reads): built by the library
  * at the graph's first full-frontier reduce (mgx_segreduce_*, mgx_pr_enact) on a graph with the library's layout.  out5 = { 16-byte
- * mini-units (0: not built), hot slices of 40 000 vertices, long rows, rows folded by a workgroup each, mini-units of the tail }. */
+ * mini-units (0: not built), hot slices of 40 000 vertices, long rows, rows whose partials more than one lane folds, mini-units of the tail }. */
 MGX_API int mgx_graph_nr_slices_info(mgx_graph_t g, int64_t* out5);
 MGX_API int mgx_graph_layout_read(mgx_graph_t g, int* h_row_offsets, int* h_col_indices, int* h_new_of_old,
                                   int* h_old_of_new, float* h_weights);

@@ -39,8 +39,9 @@ constexpr int NR_HOTV = 40000;            // values of the first NR_HOTV layout 
 constexpr int NR_BIG_UNITS = 64;          // rows of more units than this are folded by a workgroup of their own
 constexpr size_t nr_lds_bytes() { return (size_t)NR_HOTV * 4 + 64; }
 constexpr int NRS_MAX_SLICES = 16;        // hot slices of the sliced long rows (k_nrs_edges): 16 x 40 000 vertices hold 94 % of RMAT-22's long-row endpoints
-constexpr int NRS_BIG_DEG = 16384;        // rows of more entries than this: their partials are folded by a workgroup each,
-constexpr int NRS_MID_DEG = 1024;         // ... of more than this by a wave each, the others by a thread each (k_nrs_fold)
+// k_nrs_fold: rows of more than NRS_FOLD_DEG[0] entries are folded by a workgroup each, of more than [1] by a wave, of more than [2] by
+// eight lanes, the others by a thread each (the layout is sorted by degree: the tiers are row ranges)
+constexpr int NRS_FOLD_DEG[3] = {65536, 4096, 256};
 
 struct nr_layout_t {
   const u32* row_offsets = nullptr;       // the layout's CSR
@@ -63,8 +64,7 @@ struct nr_layout_t {
   u32 nrs_first[NRS_MAX_SLICES + 2] = {}; // first mini-unit of slice k; [nrs_slices + 1] = all of them
   u32 nrs_slices = 0;
   u32 nrs_rows = 0;                       // the long rows: [0, nrs_rows) (= vs_v[0])
-  u32 nrs_big_rows = 0;                   // rows [0, nrs_big_rows) have more than NRS_BIG_DEG entries: a workgroup each folds their partials,
-  u32 nrs_mid_rows = 0;                   // rows [nrs_big_rows, nrs_mid_rows) more than NRS_MID_DEG: a wave each
+  u32 nrs_tier[3] = {0, 0, 0};            // the fold's tiers: rows [0, t0) a workgroup each, [t0, t1) a wave, [t1, t2) eight lanes, [t2, nrs_rows) a thread
   u32 parts = 3u;                         // (timing runs, MGX_NR_PARTS: 1 the short rows only, 2 the long rows only -- the results are then incomplete)
 };
 
@@ -314,9 +314,8 @@ __global__ __launch_bounds__(NT, WPE) void k_nr_edges(nr_layout_t L, const V* __
 // entries) still gathers.  The workgroups split the mini-unit sequence into equal contiguous shares: a share touches one or
 // two slices (the first slice is 60 % of everything), so a workgroup loads one or two tables.  In front of its share every
 // workgroup takes its part of the SHORT rows (nr_short_work) over the table of slice 0 -- the same values k_nr_edges keeps.
-template <typename V, typename Op, int NT>
+template <typename V, typename Op, int NT, int U>
 __device__ __forceinline__ void nrs_hot_pass(const uint4* __restrict__ mu, const V* hot, V* __restrict__ partial, u32 lo, u32 hi, Op op) {
-  constexpr int U = 4;
   nr_u32x4 cur[U], nxt[U];
   auto issue = [&](u32 j0, nr_u32x4* d) {
 #pragma unroll
@@ -383,7 +382,7 @@ __device__ __forceinline__ void nrs_tail_pass(const uint4* __restrict__ mu, cons
   }
 }
 
-template <typename V, typename Op, int NT, int WPE = 4>
+template <typename V, typename Op, int NT, int U = 4, int WPE = 4>
 __global__ __launch_bounds__(NT, WPE) void k_nrs_edges(nr_layout_t L, const V* __restrict__ vals, V* __restrict__ partial, V* __restrict__ reduced,
                                                      V identity, Op op, const u32* dev_flag, u32 epoch) {
   static_assert(sizeof(V) == 4, "k_nrs_edges keeps NR_HOTV 4-byte values in LDS (nr_lds_bytes)");
@@ -413,7 +412,7 @@ __global__ __launch_bounds__(NT, WPE) void k_nrs_edges(nr_layout_t L, const V* _
       __syncthreads();
       loaded = k;
     }
-    nrs_hot_pass<V, Op, NT>(L.nrs_mu, hot, partial, lo, hi, op);
+    nrs_hot_pass<V, Op, NT, U>(L.nrs_mu, hot, partial, lo, hi, op);
   }
   if (M > H) {
     const u32 T = M - H;
@@ -472,10 +471,11 @@ __global__ __launch_bounds__(BLOCK) void k_nrs_fold(nr_layout_t L, const V* __re
   if (*dev_flag == epoch) return;
   const u32 K1 = L.nrs_slices + 1u, LR = L.nrs_rows;
   const u32* __restrict__ off = L.nrs_off;
-  const u32 big = L.nrs_big_rows, mid = L.nrs_mid_rows;          // big <= mid <= LR
-  const u32 mid_blocks = (mid - big + NW - 1u) / NW;
-  if (blockIdx.x < big) {                                          // a workgroup per row
-    const u32 r = blockIdx.x;
+  const u32 t0 = L.nrs_tier[0], t1 = L.nrs_tier[1], t2 = L.nrs_tier[2];          // t0 <= t1 <= t2 <= LR
+  const u32 b1 = (t1 - t0 + NW - 1u) / NW, b2 = (t2 - t1 + BLOCK / 8 - 1u) / (BLOCK / 8);
+  u32 blk = blockIdx.x;
+  if (blk < t0) {                                                  // a workgroup per row
+    const u32 r = blk;
     V acc = nrs_fold_row<V, Op, BLOCK>(off, partial, K1, LR, r, threadIdx.x, identity, op);
 #pragma unroll
     for (int sh = 1; sh < WAVE; sh <<= 1) acc = op(acc, __shfl_xor(acc, sh, WAVE));
@@ -489,16 +489,28 @@ __global__ __launch_bounds__(BLOCK) void k_nrs_fold(nr_layout_t L, const V* __re
     }
     return;
   }
-  if (blockIdx.x < big + mid_blocks) {                             // a wave per row
-    const u32 r = big + (blockIdx.x - big) * NW + (u32)__builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
-    if (r >= mid) return;
+  blk -= t0;
+  if (blk < b1) {                                                  // a wave per row
+    const u32 r = t0 + blk * NW + (u32)__builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+    if (r >= t1) return;
     V acc = nrs_fold_row<V, Op, WAVE>(off, partial, K1, LR, r, (u32)lane_id(), identity, op);
 #pragma unroll
     for (int sh = 1; sh < WAVE; sh <<= 1) acc = op(acc, __shfl_xor(acc, sh, WAVE));
     if (lane_id() == 0) reduced[L.old_of_new[r]] = acc;
     return;
   }
-  const u32 r = mid + (blockIdx.x - big - mid_blocks) * BLOCK + threadIdx.x;      // a thread per row
+  blk -= b1;
+  if (blk < b2) {                                                  // eight lanes per row
+    const u32 r = t1 + blk * (BLOCK / 8) + threadIdx.x / 8u, sub = threadIdx.x & 7u;
+    const bool in = r < t2;
+    V acc = nrs_fold_row<V, Op, 8>(off, partial, K1, LR, in ? r : t1, sub, identity, op);
+#pragma unroll
+    for (int sh = 1; sh < 8; sh <<= 1) acc = op(acc, __shfl_xor(acc, sh, WAVE));
+    if (in && sub == 0u) reduced[L.old_of_new[r]] = acc;
+    return;
+  }
+  blk -= b2;
+  const u32 r = t2 + blk * BLOCK + threadIdx.x;                    // a thread per row
   if (r >= LR) return;
   reduced[L.old_of_new[r]] = nrs_fold_row<V, Op, 1>(off, partial, K1, LR, r, 0u, identity, op);
 }
@@ -526,11 +538,13 @@ inline void nr_full_frontier(const nr_layout_t& L, GetValue get, V* reduced, V i
   if (L.nrs_mu) {
     // the long rows by slice of their destinations + the short rows, one launch; then the fold
     static unsigned char seen_s[64] = {};
+    // (U = 8 mini-units in flight per lane measured equal to 4: 116.0 against 116.1 us for the long rows' part)
     if (device_once_t once{seen_s})
       MGX_HIP(hipFuncSetAttribute((const void*)(k_nrs_edges<V, Op, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL((k_nrs_edges<V, Op, 1024>), dim3(ctx.num_cus), dim3(1024), nr_lds_bytes(), s, L, (const V*)vals, partial, reduced,
                        identity, op, dev_flag, epoch);
-    const u32 grid = L.nrs_big_rows + (L.nrs_mid_rows - L.nrs_big_rows + BLOCK / WAVE - 1) / (BLOCK / WAVE) + (L.nrs_rows - L.nrs_mid_rows + BLOCK - 1) / BLOCK;
+    const u32 grid = L.nrs_tier[0] + (L.nrs_tier[1] - L.nrs_tier[0] + BLOCK / WAVE - 1) / (BLOCK / WAVE) + (L.nrs_tier[2] - L.nrs_tier[1] + BLOCK / 8 - 1) / (BLOCK / 8) +
+                     (L.nrs_rows - L.nrs_tier[2] + BLOCK - 1) / BLOCK;
     if (grid) hipLaunchKernelGGL((k_nrs_fold<V, Op>), dim3(grid), dim3(BLOCK), 0, s, L, (const V*)partial, reduced, identity, op, dev_flag, epoch);
     return;
   }

@@ -114,7 +114,7 @@ class Graph:
         """the long rows by slice of their destinations (mgx_graph_nr_slices_info; built at the first full-frontier reduce)"""
         out = (C.c_int64 * 5)()
         check(lib.mgx_graph_nr_slices_info(self._h, out))
-        keys = ("mini_units", "hot_slices", "long_rows", "big_rows", "tail_mini_units")
+        keys = ("mini_units", "hot_slices", "long_rows", "multi_lane_fold_rows", "tail_mini_units")
         return dict(zip(keys, (int(x) for x in out)))
 
     def build_csc(self):

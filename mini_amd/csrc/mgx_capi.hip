@@ -180,10 +180,13 @@ static void ensure_nr_slices(mgx_graph_s* g) {
       while (lo < hi) { const size_t mid = (lo + hi) / 2; if (h[mid + 1] - h[mid] > d) lo = mid + 1; else hi = mid; }
       return (unsigned)lo;
     };
-    int big_deg = mgx::NRS_BIG_DEG, mid_deg = mgx::NRS_MID_DEG;
-    if (const char* e = getenv("MGX_NR_FOLD_DEGS")) { int b2 = 0, m2 = 0; if (sscanf(e, "%d/%d", &b2, &m2) == 2 && b2 >= m2 && m2 >= 0) { big_deg = b2; mid_deg = m2; } }   // (tests: every tier on small graphs)
-    G.nrs_big_rows = first_at_most(big_deg);
-    G.nrs_mid_rows = std::max(G.nrs_big_rows, first_at_most(mid_deg));
+    int degs[3] = {mgx::NRS_FOLD_DEG[0], mgx::NRS_FOLD_DEG[1], mgx::NRS_FOLD_DEG[2]};
+    if (const char* e = getenv("MGX_NR_FOLD_DEGS")) {            // (tests: every tier on small graphs)
+      int d0 = 0, d1 = 0, d2 = 0;
+      if (sscanf(e, "%d/%d/%d", &d0, &d1, &d2) == 3 && d0 >= d1 && d1 >= d2 && d2 >= 0) { degs[0] = d0; degs[1] = d1; degs[2] = d2; }
+    }
+    unsigned prev = 0;
+    for (int i = 0; i < 3; ++i) { G.nrs_tier[i] = std::max(prev, first_at_most(degs[i])); prev = G.nrs_tier[i]; }
   }
   ctx.reserve_scratch(mgx::nr_scratch_bytes(G.num_nodes, total, 8));      // (a partial per mini-unit)
   for (int k = 0; k < mgx::NRS_MAX_SLICES + 2; ++k) G.nrs_first[k] = k <= slices + 1 ? first[k] : first[slices + 1];
@@ -426,7 +429,7 @@ static void build_unit_blocks(mgx_graph_s* g) {
   G.d_ub_col = mem_t<int>(); G.d_ub_owner = mem_t<int>(); G.ub_units = G.ub_units_pad = 0; G.ub_min_degree = 0;
   G.d_ub_col24 = mem_t<unsigned>();
   G.d_ub_cnt = mem_t<unsigned char>(); G.d_ub_first = mem_t<int>(); G.nr_big_rows = 0; G.d_ub_w = mem_t<float>(); G.d_ub_w16 = mem_t<unsigned short>(); G.ub_w_tried = false;
-  G.d_nrs_mu = mem_t<unsigned>(); G.d_nrs_off = mem_t<unsigned>(); G.nrs_units = 0; G.nrs_slices = G.nrs_rows = G.nrs_big_rows = G.nrs_mid_rows = 0; G.nrs_tried = false;
+  G.d_nrs_mu = mem_t<unsigned>(); G.d_nrs_off = mem_t<unsigned>(); G.nrs_units = 0; G.nrs_slices = G.nrs_rows = 0; G.nrs_tier[0] = G.nrs_tier[1] = G.nrs_tier[2] = 0; G.nrs_tried = false;
   if (const char* e = getenv("MGX_BFS_UNITS")) if (atoi(e) == 0) return;
   int long_min = mgx::LONG_MIN_DEFAULT;
   if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
@@ -762,7 +765,7 @@ int mgx_graph_nr_slices_info(mgx_graph_t g, int64_t* out5) {
   out5[0] = (int64_t)G.nrs_units;
   out5[1] = (int64_t)G.nrs_slices;
   out5[2] = (int64_t)G.nrs_rows;
-  out5[3] = (int64_t)G.nrs_big_rows;
+  out5[3] = (int64_t)G.nrs_tier[2];
   out5[4] = G.nrs_units > 0 ? (int64_t)(G.nrs_first[G.nrs_slices + 1] - G.nrs_first[G.nrs_slices]) : 0;
   MGX_CATCH
 }

@@ -1161,7 +1161,7 @@ def test_neighbour_reduce_sliced_long_rows(gpu_ctx, oracle, torch_mod, monkeypat
     if slices:
         monkeypatch.setenv("MGX_NR_SLICES", str(slices))
         # ... and the fold's three tiers (a workgroup / a wave / a thread per row) moved down to where this graph has rows
-        monkeypatch.setenv("MGX_NR_FOLD_DEGS", "64/40" if slices == 1 else "2000/200")
+        monkeypatch.setenv("MGX_NR_FOLD_DEGS", "64/48/40" if slices == 1 else "2000/500/100")
     n, ro, ci, w = oracle.rmat_csr(17, 16, 77)
     g = _graph(gpu_ctx, ro, ci).build_layout()
     rng = np.random.default_rng(17 + slices)
