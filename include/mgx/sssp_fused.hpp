@@ -100,6 +100,7 @@ struct sssp_args_t {
   const u32* nrs_owner;
   u32 nrs_first[18];
   u32 nrs_slices;
+  u32 nrs_min_edges;     // ... only on an iteration whose frontier holds at least this many edges (a sweep that reads every mini-unit; improvements are seen by other workgroups only when a slice is written back)
   u32 dense_div;         // an iteration whose frontier holds >= m / dense_div edges takes the sweep (0: never)
   float delta;           // near / far bucket width (delta-stepping; BASELINE config 3 names it): 0 = plain frontier
                          // Bellman-Ford, every improved vertex is expanded in the next iteration
@@ -608,7 +609,7 @@ __global__ __launch_bounds__(NT, 4) void k_sssp_relax_dense(sssp_args_t a, int i
   } else {
     hot_n = sssp_load_bounds<NT, SSSP_HOTN_DENSE>(a.dist, a.n, s_hot_dense);
   }
-  if (a.nrs_mu) sssp_sliced_tail<NT, LIVE>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);                        // (the hot slices: k_sssp_relax_sliced, behind this launch)
+  if (a.nrs_mu && E >= a.nrs_min_edges) sssp_sliced_tail<NT, LIVE>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);   // (grid-uniform; the hot slices: k_sssp_relax_sliced, behind this launch)
   else if (a.ub_col24 && a.ub_w16) sssp_dense_long<NT, LIVE, true>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);      // (grid-uniform)
   else sssp_dense_long<NT, LIVE, false>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);
   sssp_dense_short<NT, LIVE>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);
@@ -634,7 +635,7 @@ __global__ __launch_bounds__(NT, 4) void k_sssp_relax_sliced(sssp_args_t a, int 
   extern __shared__ __attribute__((aligned(16))) u32 s_min[];      // SSSP_SLICE_N minima + one word that no candidate beats (padding offsets)
   const u64 cur = a.ctrl->cursor[it % 3];
   const u32 E = (u32)(cur & BFS_EMASK);
-  if ((cur >> BFS_VSHIFT) == 0 || !a.nrs_mu || !a.ub_w || (u64)E * (u64)a.dense_div < a.m_edges) return;      // (the test of k_sssp_relax_dense)
+  if ((cur >> BFS_VSHIFT) == 0 || !a.nrs_mu || !a.ub_w || (u64)E * (u64)a.dense_div < a.m_edges || E < a.nrs_min_edges) return;      // (the tests of k_sssp_relax_dense)
   constexpr u32 S = SSSP_SLICE_N;
   const u32 n = (u32)a.n;
   const u32 K = a.nrs_slices, H = a.nrs_first[K];
@@ -658,37 +659,44 @@ __global__ __launch_bounds__(NT, 4) void k_sssp_relax_sliced(sssp_args_t a, int 
     }
     if (threadIdx.x == 0) s_min[S] = 0u;
     __syncthreads();
-    // one mini-unit per lane and step, the next step's loads in flight
+    // one mini-unit per lane and step: the row of step t + 2, the frontier word and the distance of the row of step t + 1 and its entries
+    // and weights are in flight while step t is decided (all loads unconditional: indices past the share read its last mini-unit)
+    auto row_of = [&](u32 jj) -> u32 { return owner[jj < hi ? jj : hi - 1u]; };
     u32 j = lo + threadIdx.x;
-    sssp_u32x4 eC = {0u, 0u, 0u, 0u};
-    sssp_f32x4 wC0 = {0.f, 0.f, 0.f, 0.f}, wC1 = wC0;
-    u32 oC = 0u;
-    auto issue = [&](u32 jj, sssp_u32x4& e, sssp_f32x4& w0, sssp_f32x4& w1, u32& o) {
-      const u32 jc = jj < hi ? jj : hi - 1u;
-      e = __builtin_nontemporal_load((const sssp_u32x4*)a.nrs_mu + jc);
-      w0 = __builtin_nontemporal_load((const sssp_f32x4*)a.nrs_w + 2 * (size_t)jc);
-      w1 = __builtin_nontemporal_load((const sssp_f32x4*)a.nrs_w + 2 * (size_t)jc + 1);
-      o = owner[jc];
-    };
-    if (j < hi) issue(j, eC, wC0, wC1, oC);
-    for (; j < hi; j += NT) {
-      sssp_u32x4 eN; sssp_f32x4 wN0, wN1; u32 oN;
-      issue(j + NT, eN, wN0, wN1, oN);
-      const u32 fw = fbits[oC >> 5];
-      const float du = __uint_as_float(dist[oC]);
-      if ((fw >> (oC & 31u)) & 1u) {
-        const u32 off[8] = {eC.x & 0xFFFFu, eC.x >> 16, eC.y & 0xFFFFu, eC.y >> 16, eC.z & 0xFFFFu, eC.z >> 16, eC.w & 0xFFFFu, eC.w >> 16};
-        const float wt[8] = {wC0.x, wC0.y, wC0.z, wC0.w, wC1.x, wC1.y, wC1.z, wC1.w};
-        u32 have[8];
+    if (j < hi) {
+      sssp_u32x4 eC, eN;
+      sssp_f32x4 wC0, wC1, wN0, wN1;
+      u32 fwC, duC, fwN, duN, oC, oN, oNN;
+      auto issue = [&](u32 jj, sssp_u32x4& e, sssp_f32x4& w0, sssp_f32x4& w1) {
+        const u32 jc = jj < hi ? jj : hi - 1u;
+        e = __builtin_nontemporal_load((const sssp_u32x4*)a.nrs_mu + jc);
+        w0 = __builtin_nontemporal_load((const sssp_f32x4*)a.nrs_w + 2 * (size_t)jc);
+        w1 = __builtin_nontemporal_load((const sssp_f32x4*)a.nrs_w + 2 * (size_t)jc + 1);
+      };
+      oC = row_of(j); oN = row_of(j + NT);
+      issue(j, eC, wC0, wC1);
+      fwC = __hip_atomic_load(fbits + (oC >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      duC = __hip_atomic_load(dist + oC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      for (; j < hi; j += NT) {
+        oNN = row_of(j + 2u * NT);
+        issue(j + NT, eN, wN0, wN1);
+        fwN = __hip_atomic_load(fbits + (oN >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        duN = __hip_atomic_load(dist + oN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if ((fwC >> (oC & 31u)) & 1u) {
+          const float du = __uint_as_float(duC);
+          const u32 off[8] = {eC.x & 0xFFFFu, eC.x >> 16, eC.y & 0xFFFFu, eC.y >> 16, eC.z & 0xFFFFu, eC.z >> 16, eC.w & 0xFFFFu, eC.w >> 16};
+          const float wt[8] = {wC0.x, wC0.y, wC0.z, wC0.w, wC1.x, wC1.y, wC1.z, wC1.w};
+          u32 have[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) have[q] = s_min[off[q]];
+          for (int q = 0; q < 8; ++q) have[q] = s_min[off[q]];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const u32 nd = __float_as_uint(du + wt[q]);
-          if (nd < have[q]) atomicMin(&s_min[off[q]], nd);
+          for (int q = 0; q < 8; ++q) {
+            const u32 nd = __float_as_uint(du + wt[q]);
+            if (nd < have[q]) atomicMin(&s_min[off[q]], nd);
+          }
         }
+        eC = eN; wC0 = wN0; wC1 = wN1; fwC = fwN; duC = duN; oC = oN; oN = oNN;
       }
-      eC = eN; wC0 = wN0; wC1 = wN1; oC = oN;
     }
     __syncthreads();                                 // every wave's minima are in
     for (u32 i = threadIdx.x; i < cnt; i += NT) {
@@ -1138,6 +1146,7 @@ struct sssp_fused_state_t {
 
 // Whole run from `src`; d_dist (n floats) holds the distances afterwards (+inf: unreachable is reported as the
 // reference does, see the caller).  Returns with the stream synchronised and host_ctrl filled.
+inline long long layout_m_edges(const sssp_layout_t* layout) { return layout ? layout->m_edges : 0; }
 inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const int* col_indices, const float* weights,
                            float* d_dist, int src, standard_context_t& ctx, const sssp_layout_t* layout = nullptr) {
   hipStream_t s = ctx.stream();
@@ -1201,6 +1210,10 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
     a.nrs_owner = sl ? layout->nrs_owner : nullptr;
     a.nrs_slices = sl ? layout->nrs_slices : 0u;
     for (int i = 0; i < 18; ++i) a.nrs_first[i] = sl ? layout->nrs_first[i] : 0u;
+    double share = 0.75;                              // of all edges in the frontier
+    if (const char* e = getenv("MGX_SSSP_SLICED2_SHARE")) share = atof(e);
+    const double me = (double)layout_m_edges(layout) * share;
+    a.nrs_min_edges = sl ? (me >= 4294967295.0 ? 0xFFFFFFFFu : (u32)me) : 0xFFFFFFFFu;
   }
   a.ub_units_pad = dense ? layout->ub_units_pad : 0u;
   for (int i = 0; i < 4; ++i) a.vs_v[i] = dense ? layout->vs_v[i] : 0u;

@@ -1207,6 +1207,7 @@ def test_sssp_fused_sliced_long_rows(gpu_ctx, oracle, monkeypatch, slices):
     if slices:
         monkeypatch.setenv("MGX_NR_SLICES", str(slices))
     monkeypatch.setenv("MGX_SSSP_DENSE", "1000000" if slices != 2 else "4")
+    monkeypatch.setenv("MGX_SSSP_SLICED2_SHARE", "0" if slices != 2 else "0.3")     # (the default: only iterations that hold 3/4 of all edges)
     n, ro, ci, _ = oracle.rmat_csr(17, 16, 78)
     rng = np.random.default_rng(170 + slices)
     deg = np.diff(ro)
