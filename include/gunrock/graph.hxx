@@ -109,9 +109,6 @@ struct graph_device_t {
   unsigned nrs_tier[3] = {0, 0, 0};  // k_nrs_fold: rows [0, t0) a workgroup each, [t0, t1) a wave, [t1, t2) eight lanes, the others a thread
   long long nrs_units = 0;
   bool nrs_tried = false;
-  mem_t<float> d_nrs_w;              // the mini-units' weights (8 floats each) and rows, for the fused SSSP's heavy iterations (mgx/sssp_fused.hpp:
-  mem_t<unsigned> d_nrs_owner;       // k_sssp_relax_sliced); built at the graph's first fused SSSP run on a weighted layout
-  bool nrs_w_tried = false;
   // Degree classes of the layout's short rows (mgx/bfs_fused_vshort.hpp): only for a layout the library built itself
   // (sorted by degree, eight ints of -1 behind its neighbour array).
   unsigned vs_v[4] = {0, 0, 0, 0};

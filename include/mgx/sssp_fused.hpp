@@ -45,6 +45,17 @@
 // 1.85-1.88: the iteration of a source whose hubs hold 70 M edges went from 0.85 to 0.73 ms, the one with 15 M edges from 0.38 to
 // 0.44 -- the pass over all 18 M short-row entries costs ~0.15 ms whatever the frontier (two dependent gathers per entry), more
 // than the atomics it replaces.
+// And (round 5) the heavy iterations over the long rows regrouped BY SLICE OF THEIR DESTINATIONS -- the layout the neighbour-reduce
+// got in the same round (mgx/nreduce.hpp: 16-byte mini-units of eight 16-bit offsets, + eight weights and the row per mini-unit
+// here): a workgroup keeps one slice's 40 000 distances in LDS as minima it maintains itself (a read per candidate, ds_min only
+// when lower), and writes what became smaller back with ONE atomicMin per vertex when it leaves the slice; the tail behind the 16
+// hot slices and the short rows stayed with the sweep kernel.  Distances bit-equal in every test (R-MAT 17 with 1 / 2 / 4 hot
+// slices, integer and real weights).  RMAT-22: 2.03-2.23 ms per source against 1.77 whatever share of the edges an iteration had
+// to hold to take it (profiles/r05/sssp_sliced_ab.log): the iteration with nearly all edges went from 0.70-0.81 to 0.57-0.63 ms,
+// but a minimum that sits in a workgroup's LDS is invisible to the rows other workgroups stage in the same iteration, so the
+// improvements arrive an iteration later: 12 iterations instead of 10, the fourth with 84 M instead of 72 M edges, a fifth with 22 M
+// instead of 0.4 M.  The push loop lives on improvements landing AT ONCE (dist[u] is read when a row is staged).  The code is in
+// the history of this file (commits da33246, 3c75a75 of round 5).
 #pragma once
 #include <hip/hip_fp16.h>
 #include <type_traits>
@@ -92,15 +103,6 @@ struct sssp_args_t {
   const unsigned short* ub_w16;
   u32 ub_units_pad;
   u32 vs_v[4];
-  // the long rows by slice of their destinations (round 5; mgx_layout.hip: mgx_nrs_build_device / mgx_nrs_weights_device; nrs_mu == NULL:
-  // the unit blocks serve): 16-byte mini-units of 8 x 16-bit offsets into the slice (tail: 4 x 32-bit ids), their weights (8 floats per
-  // mini-unit), their rows; nrs_first[k]: first mini-unit of slice k, [nrs_slices + 1]: all of them.  sssp_sliced_hot / k_sssp_relax_sliced.
-  const uint4* nrs_mu;
-  const float* nrs_w;
-  const u32* nrs_owner;
-  u32 nrs_first[18];
-  u32 nrs_slices;
-  u32 nrs_min_edges;     // ... only on an iteration whose frontier holds at least this many edges (a sweep that reads every mini-unit; improvements are seen by other workgroups only when a slice is written back)
   u32 dense_div;         // an iteration whose frontier holds >= m / dense_div edges takes the sweep (0: never)
   float delta;           // near / far bucket width (delta-stepping; BASELINE config 3 names it): 0 = plain frontier
                          // Bellman-Ford, every improved vertex is expanded in the next iteration
@@ -130,12 +132,6 @@ struct sssp_layout_t {
   const unsigned short* ub_w16 = nullptr;
   unsigned ub_units_pad = 0;
   unsigned vs_v[4] = {0, 0, 0, 0};
-  // the long rows by slice of their destinations (see sssp_args_t; optional)
-  const void* nrs_mu = nullptr;
-  const float* nrs_w = nullptr;
-  const unsigned* nrs_owner = nullptr;
-  unsigned nrs_first[18] = {0};
-  unsigned nrs_slices = 0;
 };
 
 constexpr u32 SSSP_INF_BITS = 0x7f7fffffu;      // FLT_MAX: what the reference stores for "not reached" (sssp_problem.hxx:45)
@@ -559,31 +555,6 @@ __device__ __forceinline__ u32 sssp_load_bounds(const u32* __restrict__ dist, in
   return hot_n;
 }
 
-// the TAIL of the long rows by slice of their destinations (see k_sssp_relax_sliced below): 4 layout ids per mini-unit, decided like
-// the unit blocks' entries
-template <int NT, bool LIVE>
-__device__ __forceinline__ void sssp_sliced_tail(const sssp_args_t& a, void* table, u32 hot_n, u32 block, u32 nblocks) {
-  const u32 K = a.nrs_slices, H = a.nrs_first[K], M = a.nrs_first[K + 1];
-  if (M <= H) return;
-  const u32 T = M - H;
-  const u32 lo = H + (u32)((u64)T * block / nblocks), hi = H + (u32)((u64)T * (block + 1u) / nblocks);
-  const u32* __restrict__ fbits = a.frontier_bits;
-  u32* dist = a.dist;
-  unsigned char* mark = a.mark;
-  for (u32 j = lo + threadIdx.x; j < hi; j += NT) {
-    const sssp_u32x4 e = __builtin_nontemporal_load((const sssp_u32x4*)a.nrs_mu + j);
-    const sssp_f32x4 w = __builtin_nontemporal_load((const sssp_f32x4*)a.nrs_w + 2 * (size_t)j);
-    const u32 o = a.nrs_owner[j];
-    const u32 fw = fbits[o >> 5];
-    const float base = __uint_as_float(dist[o]);
-    const bool act = (fw >> (o & 31u)) & 1u;
-    u32 dd[4], nd[4];
-    dd[0] = act ? e.x : 0xFFFFFFFFu; dd[1] = act ? e.y : 0xFFFFFFFFu; dd[2] = act ? e.z : 0xFFFFFFFFu; dd[3] = act ? e.w : 0xFFFFFFFFu;
-    nd[0] = __float_as_uint(base + w.x); nd[1] = __float_as_uint(base + w.y); nd[2] = __float_as_uint(base + w.z); nd[3] = __float_as_uint(base + w.w);
-    sssp_relax4<LIVE>(dd, nd, table, hot_n, dist, mark);
-  }
-}
-
 // The heavy iterations' kernel (sssp_dense_*): launched behind every k_sssp_relax of the loop and returns at once unless the
 // iteration is heavy -- then k_sssp_relax did (the same grid-uniform test on the same stable sizes).  A launch of its own
 // for the shape that suits a sweep whose cost is its distance gathers (mgx/nreduce.hpp measured the same trade): ONE
@@ -609,104 +580,9 @@ __global__ __launch_bounds__(NT, 4) void k_sssp_relax_dense(sssp_args_t a, int i
   } else {
     hot_n = sssp_load_bounds<NT, SSSP_HOTN_DENSE>(a.dist, a.n, s_hot_dense);
   }
-  if (a.nrs_mu && E >= a.nrs_min_edges) sssp_sliced_tail<NT, LIVE>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);   // (grid-uniform; the hot slices: k_sssp_relax_sliced, behind this launch)
-  else if (a.ub_col24 && a.ub_w16) sssp_dense_long<NT, LIVE, true>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);      // (grid-uniform)
+  if (a.ub_col24 && a.ub_w16) sssp_dense_long<NT, LIVE, true>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);      // (grid-uniform)
   else sssp_dense_long<NT, LIVE, false>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);
   sssp_dense_short<NT, LIVE>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);
-}
-
-// ---- heavy iterations, the long rows by slice of their destinations (round 5) ---------------------------------------------
-// The sweep above decides every long-row entry against dist[dst]: a bound in LDS for the first 73 728 vertices, else a 4-byte gather
-// through the L2, and an atomicMin at the memory side for every improvement -- what the heavy iterations' time is (39-80 G
-// relaxations/s on the hubs' iteration, where nearly every edge improves something).  With the entries regrouped by slice of their
-// destination (mgx/nreduce.hpp has the layout: the neighbour-reduce reads the same mini-units) a workgroup takes mini-units of ONE
-// slice at a time and keeps that slice's 40 000 distances in LDS as 32-bit minima it maintains itself: a candidate is compared in
-// LDS (a read; ds_min only when it is lower) -- no gather, no global atomic per edge.  When the workgroup is done with the slice it
-// walks the 40 000 minima once: what is below the array's value goes out as ONE atomicMin per vertex and workgroup, with the mark.
-// A mini-unit's row, its frontier bit and its distance are one gather each per 8 entries, from neighbouring addresses in
-// neighbouring lanes (inside a slice the mini-units follow their rows).  The tail behind the last hot slice (6 % of RMAT-22's
-// long-row entries) and the short rows stay with k_sssp_relax_dense (sssp_sliced_tail, sssp_dense_short).  Distances bit-equal:
-// every candidate is still dist[u] + w for a frontier row u, every improvement still reaches dist[] and the marks before the
-// iteration's queue build -- the order of the minima changes, the fixed point does not.
-constexpr u32 SSSP_SLICE_N = 40000;                 // = NR_HOTV (mgx/nreduce.hpp): vertices per hot slice, 160 KB of 32-bit minima
-
-template <int NT>
-__global__ __launch_bounds__(NT, 4) void k_sssp_relax_sliced(sssp_args_t a, int it) {
-  extern __shared__ __attribute__((aligned(16))) u32 s_min[];      // SSSP_SLICE_N minima + one word that no candidate beats (padding offsets)
-  const u64 cur = a.ctrl->cursor[it % 3];
-  const u32 E = (u32)(cur & BFS_EMASK);
-  if ((cur >> BFS_VSHIFT) == 0 || !a.nrs_mu || !a.ub_w || (u64)E * (u64)a.dense_div < a.m_edges || E < a.nrs_min_edges) return;      // (the tests of k_sssp_relax_dense)
-  constexpr u32 S = SSSP_SLICE_N;
-  const u32 n = (u32)a.n;
-  const u32 K = a.nrs_slices, H = a.nrs_first[K];
-  const u32 lo_b = (u32)((u64)H * blockIdx.x / gridDim.x), hi_b = (u32)((u64)H * (blockIdx.x + 1u) / gridDim.x);
-  const u32* __restrict__ fbits = a.frontier_bits;
-  const u32* __restrict__ owner = a.nrs_owner;
-  u32* dist = a.dist;
-  unsigned char* mark = a.mark;
-  for (u32 k = 0; k < K; ++k) {
-    const u32 f0 = a.nrs_first[k], f1 = a.nrs_first[k + 1];
-    const u32 lo = lo_b > f0 ? lo_b : f0, hi = hi_b < f1 ? hi_b : f1;
-    if (lo >= hi) continue;                          // (workgroup-uniform)
-    const u32 base = k * S, cnt = n - base < S ? n - base : S;
-    {                                                // (all loads first, then the stores: see sssp_load_bounds)
-      constexpr int IT = (int)((S + NT - 1) / NT);
-      u32 dv[IT];
-#pragma unroll
-      for (int t = 0; t < IT; ++t) { const u32 i = (u32)t * NT + threadIdx.x; dv[t] = __hip_atomic_load(dist + base + (i < cnt ? i : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
-#pragma unroll
-      for (int t = 0; t < IT; ++t) { const u32 i = (u32)t * NT + threadIdx.x; if (i < cnt) s_min[i] = dv[t]; }
-    }
-    if (threadIdx.x == 0) s_min[S] = 0u;
-    __syncthreads();
-    // one mini-unit per lane and step: the row of step t + 2, the frontier word and the distance of the row of step t + 1 and its entries
-    // and weights are in flight while step t is decided (all loads unconditional: indices past the share read its last mini-unit)
-    auto row_of = [&](u32 jj) -> u32 { return owner[jj < hi ? jj : hi - 1u]; };
-    u32 j = lo + threadIdx.x;
-    if (j < hi) {
-      sssp_u32x4 eC, eN;
-      sssp_f32x4 wC0, wC1, wN0, wN1;
-      u32 fwC, duC, fwN, duN, oC, oN, oNN;
-      auto issue = [&](u32 jj, sssp_u32x4& e, sssp_f32x4& w0, sssp_f32x4& w1) {
-        const u32 jc = jj < hi ? jj : hi - 1u;
-        e = __builtin_nontemporal_load((const sssp_u32x4*)a.nrs_mu + jc);
-        w0 = __builtin_nontemporal_load((const sssp_f32x4*)a.nrs_w + 2 * (size_t)jc);
-        w1 = __builtin_nontemporal_load((const sssp_f32x4*)a.nrs_w + 2 * (size_t)jc + 1);
-      };
-      oC = row_of(j); oN = row_of(j + NT);
-      issue(j, eC, wC0, wC1);
-      fwC = __hip_atomic_load(fbits + (oC >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      duC = __hip_atomic_load(dist + oC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-      for (; j < hi; j += NT) {
-        oNN = row_of(j + 2u * NT);
-        issue(j + NT, eN, wN0, wN1);
-        fwN = __hip_atomic_load(fbits + (oN >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        duN = __hip_atomic_load(dist + oN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        if ((fwC >> (oC & 31u)) & 1u) {
-          const float du = __uint_as_float(duC);
-          const u32 off[8] = {eC.x & 0xFFFFu, eC.x >> 16, eC.y & 0xFFFFu, eC.y >> 16, eC.z & 0xFFFFu, eC.z >> 16, eC.w & 0xFFFFu, eC.w >> 16};
-          const float wt[8] = {wC0.x, wC0.y, wC0.z, wC0.w, wC1.x, wC1.y, wC1.z, wC1.w};
-          u32 have[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) have[q] = s_min[off[q]];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const u32 nd = __float_as_uint(du + wt[q]);
-            if (nd < have[q]) atomicMin(&s_min[off[q]], nd);
-          }
-        }
-        eC = eN; wC0 = wN0; wC1 = wN1; fwC = fwN; duC = duN; oC = oN; oN = oNN;
-      }
-    }
-    __syncthreads();                                 // every wave's minima are in
-    for (u32 i = threadIdx.x; i < cnt; i += NT) {
-      const u32 v = s_min[i];
-      if (v < dist[base + i]) {
-        if (v < atomicMin(dist + base + i, v)) mark[base + i] = 1;
-      }
-    }
-    __syncthreads();                                 // (the table is reused by the next slice)
-  }
 }
 
 template <int NT>
@@ -1146,7 +1022,6 @@ struct sssp_fused_state_t {
 
 // Whole run from `src`; d_dist (n floats) holds the distances afterwards (+inf: unreachable is reported as the
 // reference does, see the caller).  Returns with the stream synchronised and host_ctrl filled.
-inline long long layout_m_edges(const sssp_layout_t* layout) { return layout ? layout->m_edges : 0; }
 inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const int* col_indices, const float* weights,
                            float* d_dist, int src, standard_context_t& ctx, const sssp_layout_t* layout = nullptr) {
   hipStream_t s = ctx.stream();
@@ -1202,19 +1077,6 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
     a.ub_col24 = pack ? layout->ub_col24 : nullptr;
     a.ub_w16 = pack ? layout->ub_w16 : nullptr;
   }
-  {
-    bool sl = dense && layout->nrs_mu && layout->nrs_w && layout->nrs_owner && layout->nrs_slices > 0 && !live;
-    if (const char* e = getenv("MGX_SSSP_SLICED2")) sl = sl && atoi(e) != 0;
-    a.nrs_mu = sl ? (const uint4*)layout->nrs_mu : nullptr;
-    a.nrs_w = sl ? layout->nrs_w : nullptr;
-    a.nrs_owner = sl ? layout->nrs_owner : nullptr;
-    a.nrs_slices = sl ? layout->nrs_slices : 0u;
-    for (int i = 0; i < 18; ++i) a.nrs_first[i] = sl ? layout->nrs_first[i] : 0u;
-    double share = 0.75;                              // of all edges in the frontier
-    if (const char* e = getenv("MGX_SSSP_SLICED2_SHARE")) share = atof(e);
-    const double me = (double)layout_m_edges(layout) * share;
-    a.nrs_min_edges = sl ? (me >= 4294967295.0 ? 0xFFFFFFFFu : (u32)me) : 0xFFFFFFFFu;
-  }
   a.ub_units_pad = dense ? layout->ub_units_pad : 0u;
   for (int i = 0; i < 4; ++i) a.vs_v[i] = dense ? layout->vs_v[i] : 0u;
   a.dense_div = dense ? ddiv : 0u;
@@ -1227,7 +1089,6 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   if (device_once_t once{attr_seen}) {
     MGX_HIP(hipFuncSetAttribute((const void*)k_sssp_relax<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SSSP_HOTN * 2));
     MGX_HIP(hipFuncSetAttribute((const void*)(k_sssp_relax_dense<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MGX_HIP(hipFuncSetAttribute((const void*)(k_sssp_relax_sliced<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #ifdef MGX_LAB
     MGX_HIP(hipFuncSetAttribute((const void*)(k_sssp_relax_dense<1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #endif
@@ -1247,7 +1108,6 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
       else
 #endif
       if (dense) hipLaunchKernelGGL((k_sssp_relax_dense<1024, false>), dim3(ctx.num_cus), dim3(1024), SSSP_HOTN_DENSE * 2, s, a, it);
-      if (dense && a.nrs_mu) hipLaunchKernelGGL((k_sssp_relax_sliced<1024>), dim3(ctx.num_cus), dim3(1024), (SSSP_SLICE_N + 16) * 4, s, a, it);
       if (st.time_kernels) MGX_HIP(hipEventRecord(st.ev[2 * i + 1], s));
       if (build2) hipLaunchKernelGGL(k_sssp_build2<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, it);
       else hipLaunchKernelGGL(k_sssp_build<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, it);

@@ -429,7 +429,7 @@ static void build_unit_blocks(mgx_graph_s* g) {
   G.d_ub_col = mem_t<int>(); G.d_ub_owner = mem_t<int>(); G.ub_units = G.ub_units_pad = 0; G.ub_min_degree = 0;
   G.d_ub_col24 = mem_t<unsigned>();
   G.d_ub_cnt = mem_t<unsigned char>(); G.d_ub_first = mem_t<int>(); G.nr_big_rows = 0; G.d_ub_w = mem_t<float>(); G.d_ub_w16 = mem_t<unsigned short>(); G.ub_w_tried = false;
-  G.d_nrs_mu = mem_t<unsigned>(); G.d_nrs_off = mem_t<unsigned>(); G.d_nrs_w = mem_t<float>(); G.d_nrs_owner = mem_t<unsigned>(); G.nrs_w_tried = false; G.nrs_units = 0; G.nrs_slices = G.nrs_rows = 0; G.nrs_tier[0] = G.nrs_tier[1] = G.nrs_tier[2] = 0; G.nrs_tried = false;
+  G.d_nrs_mu = mem_t<unsigned>(); G.d_nrs_off = mem_t<unsigned>(); G.nrs_units = 0; G.nrs_slices = G.nrs_rows = 0; G.nrs_tier[0] = G.nrs_tier[1] = G.nrs_tier[2] = 0; G.nrs_tried = false;
   if (const char* e = getenv("MGX_BFS_UNITS")) if (atoi(e) == 0) return;
   int long_min = mgx::LONG_MIN_DEFAULT;
   if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
@@ -755,7 +755,7 @@ int mgx_graph_layout_info(mgx_graph_t g, int64_t* out8) {
   out8[7] = bytes(G.d_layout_row_offsets) + bytes(G.d_layout_col_indices) + bytes(G.d_layout_col_values) + bytes(G.d_new_of_old) + bytes(G.d_old_of_new) +
             bytes(G.d_ub_col) + bytes(G.d_ub_col24) + bytes(G.d_ub_owner) + bytes(G.d_ubh_col24) + bytes(G.d_ubh_owner) + bytes(G.d_ub_w) + bytes(G.d_ub_w16) +
             bytes(G.d_ub_cnt) + bytes(G.d_ub_first) + bytes(G.d_ss_tab) + bytes(G.d_cold_owner) + bytes(G.d_cold_dst) + bytes(G.d_cold_pk) + bytes(G.d_cold_cbase) +
-            bytes(G.d_colds_owner) + bytes(G.d_colds_dst) + bytes(G.d_nrs_mu) + bytes(G.d_nrs_off) + bytes(G.d_nrs_w) + bytes(G.d_nrs_owner);
+            bytes(G.d_colds_owner) + bytes(G.d_colds_dst) + bytes(G.d_nrs_mu) + bytes(G.d_nrs_off);
   MGX_CATCH
 }
 int mgx_graph_nr_slices_info(mgx_graph_t g, int64_t* out5) {
@@ -2159,29 +2159,6 @@ static void ensure_unit_weights(mgx_graph_s* g) {
     if (ok) G.d_ub_w16 = std::move(w16);
   }
 }
-extern "C" int mgx_nrs_weights_device(const int* ro, const int* ci, const float* lw, int rows, unsigned slice_n, int slices, const unsigned* off,
-                                      long long total, unsigned** owner, float** w, hipStream_t stream);   // mgx_layout.hip
-// The sliced long rows (ensure_nr_slices) with their weights and rows, once per graph at its first fused SSSP run on a weighted layout
-// (mgx/sssp_fused.hpp: k_sssp_relax_sliced); MGX_SSSP_SLICED2=0 skips it.  36 more bytes per mini-unit (RMAT-22: 0.7 GB).
-static void ensure_sssp_slices(mgx_graph_s* g) {
-  graph_device_t& G = *g->g;
-  if (G.nrs_w_tried) return;
-  G.nrs_w_tried = true;
-  if (const char* e = getenv("MGX_SSSP_SLICED2")) if (atoi(e) == 0) return;
-  if (!G.has_layout || !G.has_layout_weights || !G.d_ub_w.size()) return;
-  ensure_nr_slices(g);
-  if (G.nrs_units <= 0 || !G.d_nrs_off.size()) return;
-  standard_context_t& ctx = *g->c->ctx;
-  unsigned* owner = nullptr;
-  float* w = nullptr;
-  ctx.synchronize();
-  const int rc = mgx_nrs_weights_device(G.d_layout_row_offsets.data(), G.d_layout_col_indices.data(), G.d_layout_col_values.data(), (int)G.nrs_rows,
-                                        (unsigned)mgx::NR_HOTV, (int)G.nrs_slices, G.d_nrs_off.data(), G.nrs_units, &owner, &w, ctx.stream());
-  if (rc != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("sliced long rows, weights: ") + hipGetErrorString((hipError_t)rc));
-  if (!owner || !w) return;
-  G.d_nrs_owner = mem_t<unsigned>::adopt(owner, (size_t)G.nrs_units + 64);
-  G.d_nrs_w = mem_t<float>::adopt(w, ((size_t)G.nrs_units + 8) * 8);
-}
 int mgx_sssp_run(mgx_sssp_t p, int src, int64_t* stats) { return mgx_sssp_run_delta(p, src, -1.0f, stats); }
 int mgx_sssp_run_delta(mgx_sssp_t p, int src, float delta, int64_t* stats) {
   // device-resident loop (include/mgx/sssp_fused.hpp): distances identical to mgx_sssp_enact's; predecessors are
@@ -2212,12 +2189,6 @@ int mgx_sssp_run_delta(mgx_sssp_t p, int src, float delta, int64_t* stats) {
       layout.ub_units_pad = (unsigned)G.ub_units_pad;
       for (int i = 0; i < 4; ++i) layout.vs_v[i] = G.vs_v[i];
       layout.m_edges = (long long)G.num_edges;
-      ensure_sssp_slices(p->g);
-      if (G.d_nrs_w.size() && G.d_nrs_owner.size() && G.nrs_units > 0) {
-        layout.nrs_mu = G.d_nrs_mu.data(); layout.nrs_w = G.d_nrs_w.data(); layout.nrs_owner = G.d_nrs_owner.data();
-        for (int i = 0; i < 18; ++i) layout.nrs_first[i] = G.nrs_first[i];
-        layout.nrs_slices = G.nrs_slices;
-      }
     }
     ensure_sliced_edges(p->g);
     if (G.sliced_slices > 0) {

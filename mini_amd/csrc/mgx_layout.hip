@@ -784,46 +784,3 @@ extern "C" int mgx_nrs_build_device(const int* ro, const int* ci, int rows, unsi
   *mu = units; *off = offs; *total = (long long)M;
   return 0;
 }
-
-// ---- the same mini-units with their rows and weights, for the fused SSSP's heavy iterations (mgx/sssp_fused.hpp: k_sssp_relax_sliced) ----
-// owner[j] = the row of mini-unit j; w[8 j .. 8 j + 7] = the weights of its entries (a tail mini-unit has four; padding: 0), in the
-// order mgx_nrs_build_device wrote the entries.  off / total: what that call returned.
-namespace {
-__global__ void k_nrs_fill_w(const int* __restrict__ ro, const int* __restrict__ ci, const float* __restrict__ lw, int rows, unsigned slice_n,
-                             int slices, const unsigned* __restrict__ off, unsigned total, unsigned* __restrict__ owner, float* __restrict__ w) {
-  const long long cells = (long long)(slices + 1) * rows;
-  for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
-    long long lo = 0, hi = cells;
-    while (hi - lo > 1) { const long long mid = lo + (hi - lo) / 2; if (off[mid] <= j) lo = mid; else hi = mid; }
-    const int k = (int)(lo / rows), r = (int)(lo % rows);
-    const unsigned t = j - off[lo];
-    const int r0 = ro[r], r1 = ro[r + 1];
-    const int a = k == 0 ? r0 : nrs_lower(ci, r0, r1, (unsigned long long)k * slice_n);
-    const int b = k == slices ? r1 : nrs_lower(ci, r0, r1, (unsigned long long)(k + 1) * slice_n);
-    const int per = k < slices ? 8 : 4;
-    float v[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { const int at = a + (int)t * per + q; v[q] = (q < per && at < b) ? lw[at] : 0.f; }
-    owner[j] = (unsigned)r;
-    ((float4*)w)[2 * (size_t)j] = make_float4(v[0], v[1], v[2], v[3]);
-    ((float4*)w)[2 * (size_t)j + 1] = make_float4(v[4], v[5], v[6], v[7]);
-  }
-}
-}  // namespace
-
-extern "C" int mgx_nrs_weights_device(const int* ro, const int* ci, const float* lw, int rows, unsigned slice_n, int slices, const unsigned* off,
-                                      long long total, unsigned** owner, float** w, hipStream_t stream) {
-  *owner = nullptr; *w = nullptr;
-  if (total <= 0 || rows <= 0 || slices <= 0 || !lw) return 0;
-  unsigned* o = nullptr;
-  float* ww = nullptr;
-  if (hipMalloc((void**)&o, ((size_t)total + 64) * 4) != hipSuccess) { (void)hipGetLastError(); return 0; }           // (no memory: no sliced sweep)
-  if (hipMalloc((void**)&ww, ((size_t)total + 8) * 32) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(o); return 0; }
-  hipLaunchKernelGGL(k_nrs_fill_w, dim3(8192), dim3(256), 0, stream, ro, ci, lw, rows, slice_n, slices, off, (unsigned)total, o, ww);
-  hipError_t e = hipMemsetAsync(o + total, 0, 64 * 4, stream);
-  if (e == hipSuccess) e = hipMemsetAsync((char*)ww + (size_t)total * 32, 0, 8 * 32, stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(stream);
-  if (e != hipSuccess) { (void)hipFree(o); (void)hipFree(ww); return (int)e; }
-  *owner = o; *w = ww;
-  return 0;
-}

@@ -1195,32 +1195,3 @@ def test_neighbour_reduce_sliced_long_rows(gpu_ctx, oracle, torch_mod, monkeypat
         assert info["mini_units"] > 0 and info["long_rows"] > 0
         assert info["hot_slices"] == (slices if slices else 4)
         assert (info["tail_mini_units"] > 0) == (slices in (1, 2))
-
-
-@pytest.mark.parametrize("slices", [0, 1, 2])
-def test_sssp_fused_sliced_long_rows(gpu_ctx, oracle, monkeypatch, slices):
-    """the heavy iterations of the fused SSSP over the long rows by slice of their destinations (mgx/sssp_fused.hpp:
-    k_sssp_relax_sliced -- a slice's distances as minima in LDS, one atomicMin per improved vertex and workgroup -- + the tail in
-    k_sssp_relax_dense) on R-MAT 17 (four hot slices; with one / two only the tail carries most entries), integer and real-valued
-    weights, every iteration forced onto the sweep: distances bit-equal to the oracle's enactor loop"""
-    import mini_amd
-    if slices:
-        monkeypatch.setenv("MGX_NR_SLICES", str(slices))
-    monkeypatch.setenv("MGX_SSSP_DENSE", "1000000" if slices != 2 else "4")
-    monkeypatch.setenv("MGX_SSSP_SLICED2_SHARE", "0" if slices != 2 else "0.3")     # (the default: only iterations that hold 3/4 of all edges)
-    n, ro, ci, _ = oracle.rmat_csr(17, 16, 78)
-    rng = np.random.default_rng(170 + slices)
-    deg = np.diff(ro)
-    for real in (False, True):
-        w = (rng.random(len(ci)) * 8.0).astype(np.float32)
-        if not real:
-            w = np.floor(w * 8.0)
-        g = _graph(gpu_ctx, ro, ci, w).build_layout(weights=True)
-        sssp = mini_amd.SsspProblem(g, 0)
-        for src in [int(np.argmax(deg)), int(rng.integers(0, n))]:
-            want, _, _ = oracle.sssp_enact(ro, ci, w, src, 8.0)
-            sssp.run(src)
-            assert np.array_equal(sssp.distances(), want), (slices, real, src)
-        if os.environ.get("MGX_SSSP_SLICED2", "1") != "0":
-            info = g.nr_slices_info()
-            assert info["mini_units"] > 0 and info["hot_slices"] == (slices if slices else 4)
