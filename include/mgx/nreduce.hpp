@@ -314,6 +314,12 @@ __global__ __launch_bounds__(NT, WPE) void k_nr_edges(nr_layout_t L, const V* __
 // entries) still gathers.  The workgroups split the mini-unit sequence into equal contiguous shares: a share touches one or
 // two slices (the first slice is 60 % of everything), so a workgroup loads one or two tables.  In front of its share every
 // workgroup takes its part of the SHORT rows (nr_short_work) over the table of slice 0 -- the same values k_nr_edges keeps.
+// Measured on RMAT-22 (profiles/r05/nr_sliced_ab.log; one operator call 0.487 -> 0.265 ms): k_nr_edges 408 us = long rows 336 + short rows 58;
+// k_nrs_edges 164-168 us = mini-units 116 (17.5 M hot + 1.9 M tail) + short rows 53-57, k_nrs_fold 39-40, k_nr_values 36.  Tried and dropped
+// in the same round: eight mini-units in flight per lane instead of four (116.0 against 116.1 us); a few waves of the workgroups that
+// stay in slice 0 taking the short rows WHILE the others stream (2 / 4 / 6 / 8 waves: 607 / 360 / 297 / 249 us against 165 -- the short
+// rows' time is inversely proportional to the waves that work on them); the short rows as a four-stage pipeline (extents, entries,
+// values, fold one step apart each: 57.4 against 55.8 us -- not the exposed round trips either).
 template <typename V, typename Op, int NT, int U>
 __device__ __forceinline__ void nrs_hot_pass(const uint4* __restrict__ mu, const V* hot, V* __restrict__ partial, u32 lo, u32 hi, Op op) {
   nr_u32x4 cur[U], nxt[U];
