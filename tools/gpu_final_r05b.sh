@@ -5,7 +5,7 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; rm -rf $O; mkdir -p $O
 cd $R
 ulimit -c 0
-bash tools/profile_refresh.sh > $O/refresh.log 2>&1; tail -3 $O/refresh.log
+GRAPHS="rmat 23 32;rmat 24 16;rmat 20 32" bash tools/profile_refresh.sh > $O/refresh.log 2>&1; tail -3 $O/refresh.log
 timeout 1500 python -m pytest tests -q -m gpu --timeout 900 > $O/pytest_gpu.log 2>&1
 echo "pytest rc=$?"; tail -2 $O/pytest_gpu.log
 MGX_LIB=$R/mini_amd/libmgx_lab.so timeout 600 python -m pytest tests -q -m gpu --timeout 600 -k "variants or cold_edge_pass_vs or lds_distance" > $O/pytest_gpu_lab.log 2>&1

@@ -15,7 +15,8 @@ timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd
 timeout 900 python bench.py --per-call --steps 64 > $O/bench_per_call.log 2>&1
 timeout 900 python bench.py --mode sssp > $O/bench_sssp.log 2>&1
 timeout 900 python bench.py --mode pr > $O/bench_pr.log 2>&1
-for g in "uniform 22 16" "grid2d 22 4" "rmat 23 32" "rmat 24 16" "rmat 25 16" "rmat 20 32"; do
+IFS=';' read -ra GRAPH_LIST <<< "${GRAPHS:-uniform 22 16;grid2d 22 4;rmat 23 32;rmat 24 16;rmat 25 16;rmat 20 32}"
+for g in "${GRAPH_LIST[@]}"; do
   set -- $g
   timeout 600 python bench.py --graph $1 --scale $2 --steps $3 --warmup 2 --cpu-seconds 5 > $O/bench_$1_$2.log 2>&1
 done
@@ -27,6 +28,6 @@ grep '^{' $O/bench_driver_cmd.log | tail -1 > $O/keep/bench_line_driver_cmd.json
 grep '^{' $O/bench_per_call.log | tail -1 > $O/keep/bench_line_per_call.json
 grep '^{' $O/bench_sssp.log | tail -1 > $O/keep/bench_line_sssp.json
 grep '^{' $O/bench_pr.log | tail -1 > $O/keep/bench_line_pr.json
-for g in uniform_22 grid2d_22 rmat_23 rmat_24 rmat_25 rmat_20; do grep '^{' $O/bench_$g.log | tail -1 > $O/keep/bench_line_$g.json; done
+for g in uniform_22 grid2d_22 rmat_23 rmat_24 rmat_25 rmat_20; do [ -s $O/bench_$g.log ] && grep '^{' $O/bench_$g.log | tail -1 > $O/keep/bench_line_$g.json; done
 rm -rf $O/pmc_*
 ls $O/keep
