@@ -60,7 +60,7 @@ if "FETCH_SIZE" in pm and "WRITE_SIZE" in pm:
             agg, cnt = 0.0, 0
             for f in glob.glob(os.path.join(O, "pmc_%s_%s" % (mode, cn), "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if pat in r["Kernel_Name"] and r["Counter_Name"] == cn:
+                    if pat in r["Kernel_Name"] and r["Counter_Name"] == cn and "k_nrs_counts" not in r["Kernel_Name"] and "k_nrs_fill" not in r["Kernel_Name"]:   # (the one-time builders of the sliced long rows are not the operator)
                         agg += float(r["Counter_Value"])
                         if unit_pat in r["Kernel_Name"]:
                             cnt += 1
