@@ -201,3 +201,29 @@ def test_push_kernels_do_not_spill_vector_registers(built):
     for k in scratch:
         if "k_bfs_pushILb0ELi2" in k or "k_bfs_pushILb0ELi3" in k:
             assert scratch[k] == 0 and vspill.get(k, 0) == 0 and sspill.get(k, 0) == 0, k
+
+
+def test_gather_kernels_keep_their_loads_unconditional(built):
+    """`cond ? load : x` is turned into a branch around the load by the code generator when the load has no other use, and hipcc then
+    waits for vmcnt(0) inside the branch: every gather a round trip of its own, the prefetched stream drained with it.  Round 5 found 70
+    such sites in k_nr_edges and 97 in the BFS push kernel (tools/isa_sunk_loads.py) under sources that said "unconditional"; the
+    gathers are pinned now (mgx/nreduce.hpp: nr_load_pinned).  A budget per kernel family, so that a change that brings them back --
+    or a compiler that learns a new trick -- shows up here.  (Compiles the device code to assembly: ~20 s; skipped without hipcc.)"""
+    import os, shutil, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import isa_sunk_loads as isl
+    if not (os.path.exists(isl.HIPCC) or shutil.which(isl.HIPCC)):
+        pytest.skip("no hipcc")
+    res = isl.sunk_loads(isl.device_asm())
+    names = isl.demangle(list(res))
+    budgets = {"mgx::k_nr_edges<": 3, "mgx::k_nrs_edges<": 3, "mgx::k_sssp_relax<": 3, "mgx::k_sssp_relax_dense<": 3, "mgx::k_bfs_build2<512, 0, 1>": 2,
+               "mgx::k_bfs_push<false, 0>": 60}          # (the push kernel: the chain body of block 0, the epilogue's chunks, the cold probes)
+    seen = set()
+    for k, c in res.items():
+        d = names.get(k, k)
+        for pat, budget in budgets.items():
+            if pat in d:
+                seen.add(pat)
+                assert c <= budget, "%s: %d loads under a branch with a vmcnt(0) behind them (budget %d)" % (d[:100], c, budget)
+    assert seen == set(budgets), sorted(set(budgets) - seen)
