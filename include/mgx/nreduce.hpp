@@ -108,29 +108,10 @@ __device__ __forceinline__ V nr_fetch(u32 d, const V* __restrict__ vals, const V
   return none ? identity : (is_hot ? h : g);
 }
 
-// cnt <= NR_HOTV values into LDS: ALL of a thread's loads first, then its stores.  The plain loop (hot[i] = vals[i]) compiles to
-// load - s_waitcnt vmcnt(0) - ds_write per trip: 40 dependent round trips to the L2, ~35 us at the start of every workgroup and
-// again when it changes its slice (seen in the ISA late in round 5; sssp_load_bounds and bfs_copy_prefix tell the same story).
-template <typename V, int NT>
-__device__ __forceinline__ void nr_copy_to_lds(V* dst, const V* __restrict__ src, u32 cnt) {
-  constexpr int IT = (NR_HOTV + NT - 1) / NT;
-  V t[IT];
-#pragma unroll
-  for (int k = 0; k < IT; ++k) {
-    const u32 i = (u32)k * NT + threadIdx.x;
-    t[k] = nr_load_pinned(src + (i < cnt ? i : 0u));
-  }
-#pragma unroll
-  for (int k = 0; k < IT; ++k) {
-    const u32 i = (u32)k * NT + threadIdx.x;
-    if (i < cnt) dst[i] = t[k];
-  }
-}
-
 template <typename V, int NT>
 __device__ __forceinline__ V* nr_hot_setup(char* smem, const V* __restrict__ vals, u32 hot_n) {
   V* const hot = (V*)smem;
-  nr_copy_to_lds<V, NT>(hot, vals, hot_n);
+  for (u32 i = threadIdx.x; i < hot_n; i += NT) hot[i] = vals[i];
   __syncthreads();
   return hot;
 }
@@ -433,7 +414,7 @@ __global__ __launch_bounds__(NT, WPE) void k_nrs_edges(nr_layout_t L, const V* _
     if (k != loaded) {
       __syncthreads();                               // (every wave is done with the table in LDS)
       const u32 base = k * S, cnt = n - base < S ? n - base : S;
-      nr_copy_to_lds<V, NT>(hot, vals + base, cnt);
+      for (u32 i = threadIdx.x; i < cnt; i += NT) hot[i] = vals[base + i];
       __syncthreads();
       loaded = k;
     }
