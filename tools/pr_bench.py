@@ -36,3 +36,15 @@ print("hub-first copy: max rel err vs original order: %.3g" % float(((lred[new_o
 lpr = mini_amd.PrProblem(lgraph, a.iters)
 t0 = time.perf_counter(); lens = lpr.enact(); ctx.synchronize(); dt = time.perf_counter() - t0
 print("hub-first copy: pr enact %d iterations: %.3f ms (%s)" % (len(lens), dt * 1e3, lens))
+# ... and with the library's own layout on the graph (mgx_graph_build_layout): a full frontier takes mgx/nreduce.hpp -- since late round 5 the
+# long rows by slice of their destinations -- inside the operator, results in generator ids
+graph.build_layout()
+mini_amd.segreduce(graph, f, vals, 0.0, red, "f32_plus"); ctx.synchronize()
+for _ in range(3):
+    t0 = time.perf_counter(); nz = mini_amd.segreduce(graph, f, vals, 0.0, red, "f32_plus"); ctx.synchronize(); dt = time.perf_counter() - t0
+    print("library layout: segreduce f32_plus all vertices: %d edges %.3f ms  %.1f GTEPS  alg %.1f GB/s" % (nz, dt * 1e3, nz / dt / 1e9, (8.0 * nz + 16.0 * g["n"]) / dt / 1e9))
+print("library layout: max rel err vs torch index_add: %.3g; slices %s" % (float(((red - want).abs() / want.abs().clamp(min=1)).max()), graph.nr_slices_info()))
+mini_amd.PrProblem(graph, a.iters).enact(); ctx.synchronize()        # (warm-up on a problem of its own)
+ppr = mini_amd.PrProblem(graph, a.iters)
+t0 = time.perf_counter(); lens = ppr.enact(); ctx.synchronize(); dt = time.perf_counter() - t0
+print("library layout: pr enact %d iterations: %.3f ms (%s) -- PR's frontier is the vertices that have edges, a full frontier only on graphs without isolated vertices" % (len(lens), dt * 1e3, lens))
