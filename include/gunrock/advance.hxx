@@ -89,7 +89,7 @@ int advance_forward_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fro
     ++context.scratch_epoch;
     mgx::transform_lbs_keep(visit_keep, edges, graph.d_scanned_row_offsets.data(), frontier_size, where.bits, context);
     context.keep.data = out; context.keep.n = edges; context.keep.iteration = iteration;
-    context.keep.functor = &mgx::functor_tag_t<Functor>::id; context.keep.epoch = context.scratch_epoch; context.keep.valid = true;
+    context.keep.functor = &mgx::functor_tag_t<Functor>::id; context.keep.epoch = context.scratch_epoch; context.keep.generation = mgx::frontier_generation(); context.keep.valid = true;
     return (int)edges;
   }
   auto visit = [=] __device__(int slot, int segment, int rank) {

@@ -23,8 +23,9 @@ int filter_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<frontier_t<i
   // ("exactly once per input element" holds either way) and the raw frontier is read only to copy the survivors
   const mgx::standard_context_t::keep_record_t rec = context.keep;
   context.keep.valid = false;
-  const bool ready = rec.valid && rec.data == (const void*)candidates && rec.n == (long long)input->size() && rec.iteration == iteration &&
-                     rec.functor == (const void*)&mgx::functor_tag_t<Functor>::id && rec.epoch == context.scratch_epoch;
+  const bool ready = rec.valid && !input->exposed() && rec.data == (const void*)candidates && rec.n == (long long)input->size() && rec.iteration == iteration &&
+                     rec.functor == (const void*)&mgx::functor_tag_t<Functor>::id && rec.epoch == context.scratch_epoch &&
+                     rec.generation == mgx::frontier_generation();     // (nobody has written into a frontier from outside since)
   const long long kept = ready ? pass.upsweep_from_bits()
                                : pass.upsweep([=] __device__(long long i) { return Functor::cond_filter(candidates[i], slice, iteration); });
   output->resize((size_t)kept);

@@ -37,17 +37,20 @@ class frontier_t {
     std::swap(fill_, other.fill_);
     std::swap(room_, other.room_);
     std::swap(kind_, other.kind_);
+    std::swap(exposed_, other.exposed_);
   }
 
   // contents <- a device array / a host vector (the fill level follows)
   hipError_t load(mem_t<type_t>& source) {
     admit("loading", source.size(), store_->size());
     fill_ = source.size();
+    mgx::frontier_touched();
     return dtod(store_->data(), source.data(), source.size());
   }
   hipError_t load(const std::vector<type_t>& source) {
     admit("loading", source.size(), store_->size());
     fill_ = source.size();
+    mgx::frontier_touched();
     return htod(store_->data(), source);
   }
   // an operator has written `count` entries
@@ -60,6 +63,10 @@ class frontier_t {
   size_t capacity() const { return room_; }
   frontier_type_t type() const { return kind_; }
   storage_t data() const { return store_; }
+  // the buffer's address has been handed to code outside the operators (the C-ABI's mgx_frontier_device_ptr): its contents may
+  // change at any time from now on, so nothing an operator remembered about them is trusted again (filter.hxx)
+  void mark_exposed() { exposed_ = true; mgx::frontier_touched(); }
+  bool exposed() const { return exposed_; }
 
  private:
   static void admit(const char* doing, size_t want, size_t have) {
@@ -73,6 +80,7 @@ class frontier_t {
   size_t fill_ = 0;
   size_t room_ = 0;
   frontier_type_t kind_ = node_frontier;
+  bool exposed_ = false;
 };
 
 }  // namespace gunrock

@@ -492,6 +492,7 @@ __device__ __forceinline__ int bfs_hot_epilogue(const bfs_fused_args_t& a, const
   __syncthreads();
   const int total = s_red[0];                                     // claims of the workgroup (>= the deferred ones)
   if (total == 0) return 0;
+  if (MGX_LAB_GET(a, dense_diag, 0) & 8) return total;            // (lab builds, measurements only: the deferred marks are dropped -- what a level costs without its flush)
   if ((u32)total > a.defer_min_marks) {
     if (threadIdx.x == 0) {
       const u32 k = atomicAdd(&a.ctrl->flush_count[slot & 1], 1u);

@@ -110,6 +110,15 @@ inline hipStream_t& current_stream_ref() {
 inline hipStream_t current_stream() { return current_stream_ref(); }
 inline void set_current_stream(hipStream_t s) { current_stream_ref() = s; }
 
+// Every write into a frontier's buffer from OUTSIDE an operator (frontier_t::load, the C-ABI's load / fill / fill_iota, a device
+// pointer handed to the caller) moves this counter on: what an operator remembered about a frontier's contents (the advance's
+// keep-ballots for the filter behind it) is only good while it stands still.  Host-side, one per process.
+inline unsigned long long& frontier_generation() {
+  static unsigned long long g = 0;
+  return g;
+}
+inline void frontier_touched() { ++frontier_generation(); }
+
 struct standard_context_t : context_t {
   int device = 0;
   hipStream_t _stream = nullptr;   // nullptr == the legacy default stream, like the reference
@@ -135,6 +144,7 @@ struct standard_context_t : context_t {
     const void* functor = nullptr;
     unsigned long long epoch = 0;
     bool valid = false;
+    unsigned long long generation = 0;     // frontier_generation() when the ballots were left
   } keep;
   bool mailbox_spin = true;
   int num_cus = 256;
@@ -205,9 +215,21 @@ struct standard_context_t : context_t {
   void reserve_scratch(size_t bytes) {
     if (bytes <= scratch_bytes) return;
     bytes = (bytes + 4095) & ~size_t(4095);
-    if (scratch) { MGX_HIP(hipStreamSynchronize(_stream)); MGX_HIP(hipFree(scratch)); scratch = nullptr; }
-    MGX_HIP(hipMalloc(&scratch, bytes));
+    // the new arena first: a failed allocation leaves the old one (and its size) in place.  Whatever an operator left in the old
+    // arena for the next one (the advance's keep-ballots, `keep`) is gone with it: the epoch moves on.
+    void* fresh = nullptr;
+    if (scratch) MGX_HIP(hipStreamSynchronize(_stream));
+    if (hipMalloc(&fresh, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      if (scratch) { (void)hipFree(scratch); scratch = nullptr; scratch_bytes = 0; }     // (make room and try once more)
+      MGX_HIP(hipMalloc(&fresh, bytes));
+    } else if (scratch) {
+      MGX_HIP(hipFree(scratch));
+    }
+    scratch = fresh;
     scratch_bytes = bytes;
+    ++scratch_epoch;
+    keep.valid = false;
     // status words for a scan over as many items as this arena serves (scan_scratch_bytes: >= n / 8 bytes for n items,
     // 2048 items per tile)
     const size_t tiles = bytes / 256 + 64;

@@ -167,7 +167,12 @@ static void ensure_nr_slices(mgx_graph_s* g) {
   ctx.synchronize();
   const int rc = mgx_nrs_build_device(G.d_layout_row_offsets.data(), G.d_layout_col_indices.data(), rows, S, slices, &mu, &off, first, &total,
                                       ctx.stream());
-  if (rc != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("sliced long rows: ") + hipGetErrorString((hipError_t)rc));
+  if (rc != 0) {                       // (the memory is not there: the unit blocks serve -- the call that asked is not failed for it)
+    (void)hipGetLastError();
+    if (mu) (void)hipFree(mu);
+    if (off) (void)hipFree(off);
+    return;
+  }
   if (total <= 0 || !mu || !off) return;
   G.d_nrs_mu = mem_t<unsigned>::adopt((unsigned*)mu, ((size_t)total + 4) * 4);
   G.d_nrs_off = mem_t<unsigned>::adopt(off, (size_t)(slices + 1) * (size_t)rows + 1);
@@ -188,7 +193,14 @@ static void ensure_nr_slices(mgx_graph_s* g) {
     unsigned prev = 0;
     for (int i = 0; i < 3; ++i) { G.nrs_tier[i] = std::max(prev, first_at_most(degs[i])); prev = G.nrs_tier[i]; }
   }
-  ctx.reserve_scratch(mgx::nr_scratch_bytes(G.num_nodes, total, 8));      // (a partial per mini-unit)
+  try {
+    ctx.reserve_scratch(mgx::nr_scratch_bytes(G.num_nodes, total, 8));    // (a partial per mini-unit)
+  } catch (const mgx::mgx_error&) {                                       // no room for the partials: give the slices back, the unit blocks serve
+    (void)hipGetLastError();
+    G.d_nrs_mu = mem_t<unsigned>();
+    G.d_nrs_off = mem_t<unsigned>();
+    return;
+  }
   for (int k = 0; k < mgx::NRS_MAX_SLICES + 2; ++k) G.nrs_first[k] = k <= slices + 1 ? first[k] : first[slices + 1];
   G.nrs_slices = (unsigned)slices; G.nrs_rows = (unsigned)rows; G.nrs_units = total;
 }
@@ -894,6 +906,7 @@ int mgx_frontier_load(mgx_frontier_t f, const int* host, int64_t n) {
   MGX_REQUIRE(f && (host || n == 0) && n >= 0, "mgx_frontier_load: bad argument");
   use_device(f->c);
   f->f->resize((size_t)n);   // throws MGX_E_FRONTIER_OVERFLOW
+  mgx::frontier_touched();
   MGX_HIP(mgx::htod(f->f->data()->data(), host, (size_t)n));
   MGX_CATCH
 }
@@ -902,6 +915,7 @@ int mgx_frontier_fill_iota(mgx_frontier_t f, int64_t n) {
   MGX_REQUIRE(f && n >= 0, "mgx_frontier_fill_iota: bad argument");
   use_device(f->c);
   f->f->resize((size_t)n);
+  mgx::frontier_touched();
   int* p = f->f->data()->data();
   mgx::transform([=] __device__(int i) { p[i] = i; }, n, *f->c->ctx);
   MGX_CATCH
@@ -911,6 +925,7 @@ int mgx_frontier_fill(mgx_frontier_t f, int value, int64_t n) {
   MGX_REQUIRE(f && n >= 0, "mgx_frontier_fill: bad argument");
   use_device(f->c);
   f->f->resize((size_t)n);
+  mgx::frontier_touched();
   int* p = f->f->data()->data();
   mgx::transform([=] __device__(int i) { p[i] = value; }, n, *f->c->ctx);
   MGX_CATCH
@@ -949,6 +964,7 @@ int mgx_frontier_device_ptr(mgx_frontier_t f, int** p) {
   MGX_TRY
   MGX_REQUIRE(f && p, "NULL argument");
   *p = f->f->data()->data();
+  f->f->mark_exposed();
   MGX_CATCH
 }
 

@@ -263,6 +263,42 @@ def test_bfs_operators_superstep_by_superstep(gpu_ctx, oracle, rmat_graphs):
     assert np.array_equal(bfs.labels(), oracle.bfs_cpu(ro, ci, src))
 
 
+@pytest.mark.parametrize("disturb", ["grow_arena", "overwrite", "expose"])
+def test_filter_does_not_trust_stale_keep_ballots(gpu_ctx, oracle, rmat_graphs, disturb):
+    """the advance leaves its keep-ballots in the context's scratch arena for the filter behind it.  Whatever
+    happens in between -- the arena reallocated (a bigger frontier is created), the frontier overwritten through the C-ABI,
+    its device pointer handed out -- the filter must then evaluate cond_filter itself: the result equals the predicate on
+    what the frontier holds NOW."""
+    import mini_amd
+    n, ro, ci, w = rmat_graphs[13]
+    m = len(ci)
+    g = _graph(gpu_ctx, ro, ci)
+    src = int(np.argmax(np.diff(ro)))
+    bfs = mini_amd.BfsProblem(g, src)
+    fa, fb = mini_amd.Frontier(gpu_ctx, m), mini_amd.Frontier(gpu_ctx, m)
+    fa.load(np.array([src], dtype=np.int32))
+    front = bfs.advance(fa, fb, 0)
+    raw = fb.read()
+    assert front == len(raw) and front > 64
+    keepalive = None
+    if disturb == "grow_arena":
+        keepalive = mini_amd.Frontier(gpu_ctx, 40 * m)          # scan scratch for 40 m items: the arena is reallocated
+        now = raw
+    elif disturb == "overwrite":
+        now = raw.copy()
+        now[::2] = -1                                           # same pointer, same size, same iteration: other contents
+        now[1::2] = np.arange(len(now[1::2]), dtype=np.int32) % n
+        fb.load(now)
+    else:
+        assert fb.device_ptr                                     # from here on anybody may write into it
+        now = raw
+    kept = bfs.filter(fb, fa, 0)
+    out = fa.read()
+    assert kept == len(out)
+    assert np.array_equal(out, now[now != -1])
+    del keepalive
+
+
 def test_bfs_fused_operator_equals_advance_plus_filter(gpu_ctx, oracle, rmat_graphs):
     import mini_amd
     n, ro, ci, w = rmat_graphs[13]
