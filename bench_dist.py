@@ -372,6 +372,12 @@ def bench_main(args, rank, world, local_rank):
                 if c5["gscale"] == 26:
                     out["config5"]["vs_1gpu_rmat26"] = round(v5 / float(one["value"]), 3)
                     out["config5"]["one_gpu_rmat26_MTEPS"] = one["value"]
+                    # the denominator is a COMMITTED measurement of another run: say which sources and round it was taken on, and whether
+                    # the kernels have changed since -- a stale denominator is visible on the line, not silent
+                    from bench import source_sha
+                    out["config5"]["one_gpu_rmat26_from"] = {"file": "profiles/rmat26_1gpu.json", "round": one.get("round"), "steps": one.get("steps"),
+                                                             "source_sha": one.get("source_sha"), "current_source_sha": source_sha(),
+                                                             "stale": one.get("source_sha") != source_sha()}
             except Exception:                    # (the file is a committed measurement: without it the ratio is simply not quoted)
                 pass
         print(json.dumps(out), flush=True)

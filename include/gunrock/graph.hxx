@@ -86,6 +86,7 @@ struct graph_device_t {
   mem_t<int> d_ubh_owner;
   long long ubh_units = 0, ubh_units_pad = 0;
   int ub_min_degree = 0;
+  mem_t<unsigned long long> d_nr_pos;   // neighbour-reduce over a SUBSET frontier (mgx/nreduce.hpp): (epoch, frontier position) per layout vertex; allocated and zeroed at the first such call
   mem_t<float> d_ub_w;               // weights of the unit blocks' entries (fused SSSP's heavy iterations); built on first use
   mem_t<unsigned short> d_ub_w16;    // the same weights as IEEE halves, kept only when every one of them is exact that way (fused SSSP's sweep, 24-bit entries)
   bool ub_w_tried = false;

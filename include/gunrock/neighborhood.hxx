@@ -27,6 +27,12 @@ struct is_pure_gather : std::false_type {};
 template <typename F>
 struct is_pure_gather<F, typename std::enable_if<F::mgx_pure_gather>::type> : std::true_type {};
 
+// MGX_NR_SUBSET=0: frontiers that are not 0 .. n - 1 take the general kernel, as before round 6
+inline bool nr_subset_enabled() {
+  static const bool on = [] { const char* e = std::getenv("MGX_NR_SUBSET"); return !e || std::atoi(e) != 0; }();
+  return on;
+}
+
 template <typename Problem, typename Functor, typename Value, typename reduce_op, bool has_output, bool push>
 int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<frontier_t<int>>& input,
                         std::shared_ptr<frontier_t<int>>& output, Value* reduced, Value identity, int iteration,
@@ -42,17 +48,25 @@ int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fronti
   // degree classes: mgx/nreduce.hpp.  Whether the frontier IS the iota is checked on the device (one pass over it);
   // it then holds every edge of the graph: no degree scan, no search.
   typename Problem::data_slice_t* const data = problem->d_data_slice.data();
+  // (round 6) ... or a large SUBSET of the vertices in ascending order -- what PR's filter leaves for every iteration but the first
+  // (pr_enactor.hxx:53-66): the same kernels compute every row and keep the frontier's, results by frontier position.  A frontier of
+  // fewer than n / 8 vertices takes the general kernel, whose cost follows the frontier's edges (the fast path costs what a full
+  // frontier costs).
+  const bool full = frontier_size == (long long)graph.num_nodes;
+  const bool subset = !full && frontier_size < (long long)graph.num_nodes && frontier_size * 8 >= (long long)graph.num_nodes && nr_subset_enabled();
   if constexpr (sizeof(Value) == 4)     // (the kernel keeps 40 000 4-byte values in the 160 KB of LDS: wider values take the general path)
-  if (!has_output && is_pure_gather<Functor>::value && frontier_size == (long long)graph.num_nodes && frontier_size > 0 &&
+  if (!has_output && is_pure_gather<Functor>::value && (full || subset) && frontier_size > 0 &&
       graph.has_layout && (push || graph.csc_is_csr) && graph.ub_units > 0 && graph.ub_min_degree == graph.vs_long_min && graph.vs_long_min >= 17 && graph.vs_long_min <= 64 &&
       graph.d_ub_cnt.size() && graph.d_ub_first.size() && graph.vs_dummy != 0 &&
       context.scratch_bytes >= mgx::nr_scratch_bytes(graph.num_nodes, graph.ub_units_pad, sizeof(Value))) {
     // the check (inside the first kernel) and the work go out back to back: the kernels behind it look at its verdict themselves (a device
     // word that holds the epoch of the last call whose frontier was NOT the iota); one host wait, behind everything
     context.mailbox[8] = 1;
+    context.mailbox[9] = (long long)context.nr_edges_base;
     const unsigned epoch = context.next_nr_epoch();
     if (graph.num_edges > 0) {
       mgx::nr_layout_t L;
+      L.new_of_old = graph.d_new_of_old.data();
       L.row_offsets = (const mgx::u32*)graph.d_layout_row_offsets.data();
       L.col_indices = graph.d_layout_col_indices.data();
       L.old_of_new = graph.d_old_of_new.data();
@@ -84,10 +98,19 @@ int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fronti
           L.nrs_slices = graph.nrs_slices; L.nrs_rows = graph.nrs_rows; for (int i = 0; i < 3; ++i) L.nrs_tier[i] = graph.nrs_tier[i];
         }
       }
-      mgx::nr_full_frontier<Value>(L, [=] __device__(int v) -> Value { return Functor::get_value_to_reduce(v, data, iteration); }, reduced,
-                                   identity, reduce_op(), context, frontier, context.mailbox + 8, context.nr_flag(), epoch);
-      context.synchronize();
-      if (context.mailbox[8] == 1) return (int)graph.num_edges;
+      if (subset && graph.d_nr_pos.size() < (size_t)graph.num_nodes) {       // (first subset call on this graph: the one allocation of this path)
+        context.synchronize();
+        graph.d_nr_pos = mem_t<unsigned long long>((size_t)graph.num_nodes, context);
+        MGX_HIP(hipMemsetAsync(graph.d_nr_pos.data(), 0, (size_t)graph.num_nodes * sizeof(unsigned long long), context.stream()));
+      }
+      const long long seq = mgx::nr_full_frontier<Value>(L, [=] __device__(int v) -> Value { return Functor::get_value_to_reduce(v, data, iteration); }, reduced,
+                                   identity, reduce_op(), context, frontier, context.mailbox + 8, context.nr_flag(), epoch,
+                                   full ? -1 : frontier_size, offsets, subset ? (mgx::u64*)graph.d_nr_pos.data() : nullptr);
+      context.mailbox_wait(seq);
+      // (a subset call added its frontier's degrees to the context's counter whatever its verdict: the base follows)
+      const unsigned long long before = context.nr_edges_base;
+      if (subset) context.nr_edges_base = (unsigned long long)context.mailbox[9];
+      if (context.mailbox[8] == 1) return full ? (int)graph.num_edges : (int)(context.nr_edges_base - before);
     }
   }
 

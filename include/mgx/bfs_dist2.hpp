@@ -315,6 +315,15 @@ __global__ __launch_bounds__(NT) void k_d2_lists_apply(bfs_fused_args_t a, int l
     }
     s_pre[nlists] = run;
     s_over = over;
+    // header words 1 .. 3 of every list: the level plan its rank is about to enqueue (d2_run writes them in front of level 0).
+    // All equal: host_flag[3] = 1 -- every rank reads the same gathered headers, so every rank gets the same answer.
+    if (blockIdx.x == 0 && host_flag) {
+      int agree = 1;
+      for (int r = 1; r < nlists; ++r)
+        for (int k = 1; k < D2_LIST_HEAD; ++k)
+          if (glists[(size_t)r * stride + k] != glists[k]) agree = 0;
+      host_flag[3] = (u64)agree;
+    }
   }
   __syncthreads();
   const u32 T = s_pre[nlists];
@@ -394,6 +403,11 @@ __global__ __launch_bounds__(NT) void k_d2_lists_apply(bfs_fused_args_t a, int l
     }
     __syncthreads();           // s_base / s_long_true are reused by the next round
   }
+}
+
+// the level plan this rank is about to enqueue, into the header of its id list (words 1 .. 3; one thread, behind d2_reset)
+__global__ void k_d2_plan_tag(u32* list, u32 levels, u64 sparse) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) { list[1] = levels; list[2] = (u32)sparse; list[3] = (u32)(sparse >> 32); }
 }
 
 // end of a freeze (one thread; enqueued by the host in front of the frozen level's bitmap exchange)
@@ -721,7 +735,7 @@ inline void d2_apply_lists(d2_state_t& st, int level, const u32* glists, int nli
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   out3[0] = (long long)flag[1];
   out3[1] = (long long)flag[2];
-  out3[2] = 0;
+  out3[2] = (long long)flag[3];        // (level 0: every rank announced the same level plan)
 }
 
 // gathered: `maps` new-bit maps, `stride_words` apart (a multiple of 4): every rank's map after an all-gather, or
@@ -832,7 +846,7 @@ struct d2_run_bufs_t {
       sp &= ~have | h.sparse_ok;
     }
     *levels = L + 1;
-    *sparse = sp;
+    *sparse = sp | 1ull;          // (level 0 -- the source -- is merged from the lists in every protocol: d2_run's agreement rides on it)
     return true;
   }
 };
@@ -895,10 +909,34 @@ inline void d2_run(d2_state_t& st, comm_t& cm, d2_run_bufs_t& bufs, int src, int
     // EITHER the lists (all-gather + merge) OR the bitmaps (exchange + merge) -- no host look in between.  Right whatever the
     // traversal does: bitmaps are always right; a list that overflows against the plan freezes the traversal at that level
     // (k_d2_lists_apply) and everything enqueued behind it returns at once; levels past the end find nothing.
+    // AGREEMENT (round 6).  The plan decides which collective a rank issues per level, and every rank makes its own from its own
+    // history: ranks whose histories differ -- an engine handle recreated on one of them, MGX_DIST_SPEC set in one environment,
+    // a traversal that threw on some -- would enqueue different RCCL collectives: a hang, not an error.  So level 0 (the source:
+    // always merged from the lists) runs with a host look on every rank, and its all-gathered list headers carry every rank's
+    // plan: only when all are equal (k_d2_lists_apply -> host_flag[3], the same answer everywhere) is the rest enqueued ahead.
     bool over = false;
     int plan_levels = 0;
     u64 plan_sparse = 0;
-    if (bufs.plan(&plan_levels, &plan_sparse)) {
+    const bool have_plan = bufs.plan(&plan_levels, &plan_sparse);
+    hipLaunchKernelGGL(k_d2_plan_tag, dim3(1), dim3(1), 0, s, st.mylist, have_plan ? (u32)plan_levels : 0u, have_plan ? plan_sparse : 0ull);
+    bool agreed = false;
+    {
+      d2_push(st, 0, ctx);
+      const u32* lists; int nl;
+      gather_lists(&lists, &nl);
+      long long o3[3];
+      d2_apply_lists(st, 0, lists, nl, st.list_words(), ctx, o3);
+      agreed = o3[2] != 0;
+      level = 1;
+      if (o3[1] == 0) {                                     // a source without edges: over
+        MGX_CHECK_LAUNCH("partitioned BFS: kernel launch");
+        d2_status(st, level, ctx, out6);
+        bufs.learn(st.fs->host_ctrl, (int)out6[1], out6[3], st.list_cap);
+        return;
+      }
+      if (o3[0]) d2_exchange_bitmaps(st, cm, bufs, 0, exchange, xwords, ctx);
+    }
+    if (have_plan && agreed) {
       bufs.spec_runs += 1;
       bufs.last_plan_levels = plan_levels; bufs.last_plan_sparse = plan_sparse;
       for (; level < plan_levels; ++level) {
@@ -1001,7 +1039,29 @@ inline void d2_group_run(d2_state_t** sts, d2_run_bufs_t** bufs, d2_group_bufs_t
   if (lists) {
     int plan_levels = 0;
     u64 plan_sparse = 0;
-    if (bufs[0]->plan(&plan_levels, &plan_sparse)) {
+    const bool have_plan = bufs[0]->plan(&plan_levels, &plan_sparse);
+    // level 0 with a host look, as d2_run's agreement has it (the engines of a group share one history: the headers agree)
+    bool agreed = true;
+    {
+      for (int r = 0; r < G; ++r) {
+        bool hp; int pl = 0; u64 ps = 0;
+        hp = bufs[r]->plan(&pl, &ps);
+        hipLaunchKernelGGL(k_d2_plan_tag, dim3(1), dim3(1), 0, s, sts[r]->mylist, hp ? (u32)pl : 0u, hp ? ps : 0ull);
+        d2_push(*sts[r], 0, ctx);
+      }
+      gather_lists();
+      long long o3[3] = {0, 0, 0};
+      for (int r = 0; r < G; ++r) { d2_apply_lists(*sts[r], 0, gb.glists.data(), G, lw, ctx, o3); agreed = agreed && o3[2] != 0; }
+      level = 1;
+      if (o3[1] == 0) {
+        MGX_CHECK_LAUNCH("partitioned BFS (group): kernel launch");
+        for (int r = 0; r < G; ++r) d2_status(*sts[r], level, ctx, out6 + 6 * r);
+        for (int r = 0; r < G; ++r) bufs[r]->learn(sts[r]->fs->host_ctrl, (int)out6[6 * r + 1], out6[6 * r + 3], sts[r]->list_cap);
+        return;
+      }
+      if (o3[0]) bitmaps(0);
+    }
+    if (have_plan && agreed) {
       for (int r = 0; r < G; ++r) { bufs[r]->spec_runs += 1; bufs[r]->last_plan_levels = plan_levels; bufs[r]->last_plan_sparse = plan_sparse; }
       for (; level < plan_levels; ++level) {
         const bool sparse = level >= 64 || ((plan_sparse >> level) & 1ull);

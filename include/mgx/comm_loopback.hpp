@@ -60,6 +60,7 @@ struct world_t {
   std::mutex mu;
   std::condition_variable cv;
   int joined = 0;
+  std::vector<char> taken;          // rank r has joined (CommInitRank refuses a second thread with the same rank)
   int arrived = 0;
   unsigned long long generation = 0;
   bool broken = false;
@@ -274,13 +275,25 @@ inline ncclResult_t CommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, i
       reg.worlds[key] = w;
     } else w = it->second;
   }
+  bool failed = false, last = false;
   {
     std::unique_lock<std::mutex> lk(w->mu);
     if (w->nranks != nranks || w->broken || w->joined >= nranks) return ncclInvalidArgument;
+    if (w->taken.size() != (size_t)nranks) w->taken.assign((size_t)nranks, 0);
+    if (w->taken[(size_t)rank]) return ncclInvalidArgument;          // (two threads with one rank: their mailboxes would alias silently)
+    w->taken[(size_t)rank] = 1;
     ++w->joined; ++w->refs;
     if (w->joined == nranks) w->cv.notify_all();
     else if (!w->cv.wait_for(lk, timeout(), [&] { return w->joined == w->nranks || w->broken; })) { w->broken = true; w->cv.notify_all(); }
-    if (w->broken) { --w->refs; return ncclSystemError; }
+    if (w->broken) { failed = true; last = --w->refs == 0; }
+  }
+  if (failed) {
+    if (last) {                                                       // (a broken world leaves the registry with its last member)
+      registry_t& reg = registry_t::get();
+      std::lock_guard<std::mutex> g(reg.mu);
+      reg.worlds.erase(key);
+    }
+    return ncclSystemError;
   }
   lcomm_t* c = new lcomm_t();
   c->w = w; c->rank = rank;
@@ -290,6 +303,10 @@ inline ncclResult_t CommInitRank(ncclComm_t* out, int nranks, ncclUniqueId id, i
 inline ncclResult_t CommDestroy(ncclComm_t comm) {
   lcomm_t* c = (lcomm_t*)comm;
   if (!c || c->magic != LOOPBACK_MAGIC) return ncclInvalidArgument;
+  {                                    // (a group this thread left open on the communicator: its operations must not outlive it)
+    group_state_t& g = group_state();
+    if (g.comm == c) { g.comm = nullptr; g.ops.clear(); g.failed = true; }
+  }
   bool last = false;
   unsigned long long key = 0;
   if (c->w) {

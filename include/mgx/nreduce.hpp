@@ -66,7 +66,21 @@ struct nr_layout_t {
   u32 nrs_rows = 0;                       // the long rows: [0, nrs_rows) (= vs_v[0])
   u32 nrs_tier[3] = {0, 0, 0};            // the fold's tiers: rows [0, t0) a workgroup each, [t0, t1) a wave, [t1, t2) eight lanes, [t2, nrs_rows) a thread
   u32 parts = 3u;                         // (timing runs, MGX_NR_PARTS: 1 the short rows only, 2 the long rows only -- the results are then incomplete)
+  // a frontier that is a SUBSET of the vertices (round 6; pos == NULL: the full frontier 0 .. n - 1, results by original id): layout
+  // vertex v is at frontier position (u32)pos[v] iff pos[v] >> 32 == pos_epoch (k_nr_values_subset wrote it in THIS call: the
+  // array is never cleared); results go to reduced[position] (neighborhood.hxx:58), rows outside the frontier are computed and dropped
+  const int* new_of_old = nullptr;
+  const u64* pos = nullptr;
+  u32 pos_epoch = 0;
 };
+
+// where the result of layout vertex v goes
+template <typename V>
+__device__ __forceinline__ void nr_store(const nr_layout_t& L, V* __restrict__ reduced, u32 v, V x) {
+  if (!L.pos) { reduced[L.old_of_new[v]] = x; return; }
+  const u64 p = L.pos[v];
+  if ((u32)(p >> 32) == L.pos_epoch) reduced[(u32)p] = x;
+}
 
 // k_nr_values also answers: is the frontier 0, 1, ..., n - 1?  *host_flag (pinned) was set to 1 by the host before the launch;
 // *dev_flag <- epoch if it is not: the kernels behind this one return at once when they find their epoch there (no host wait
@@ -84,6 +98,50 @@ __global__ __launch_bounds__(BLOCK) void k_nr_values(GetValue get, const int* __
     reduced[v] = identity;
   }
   if (__ballot(bad) && lane_id() == 0) { *host_flag = 0; *dev_flag = epoch; }
+}
+
+// The same for a frontier that is a subset: f[0] < f[1] < ... < f[nf - 1], all in [0, n) -- what a stable filter leaves of an iota
+// (pr_enactor.hxx: every iteration but the first) -- checked here the same way (*host_flag <- 0, *dev_flag <- epoch otherwise: a
+// frontier with duplicates or out of order takes the general kernel).  vals[] as above for ALL vertices (any of them may be a
+// neighbour); pos[new_of_old[f[i]]] = (epoch, i); reduced[i] <- identity for the nf positions; the frontier's degrees are summed into
+// *edges (the operator's return value: monotonic, the host keeps the base).
+template <typename V, typename GetValue>
+__global__ __launch_bounds__(BLOCK) void k_nr_values_subset(GetValue get, const int* __restrict__ old_of_new, const int* __restrict__ new_of_old,
+                                                            V* __restrict__ vals, V* __restrict__ reduced, V identity, long long n,
+                                                            const int* __restrict__ frontier, long long nf, const int* __restrict__ offsets,
+                                                            u64* __restrict__ pos, u64* edges, long long* host_flag, u32* dev_flag, u32 epoch) {
+  const long long t0 = (long long)blockIdx.x * BLOCK + threadIdx.x, nt = (long long)gridDim.x * BLOCK;
+  for (long long v = t0; v < n; v += nt) vals[v] = get(old_of_new[v]);
+  bool bad = false;
+  u64 deg = 0;
+  for (long long i = t0; i < nf; i += nt) {
+    const int f = frontier[i];
+    const int prev = i ? frontier[i - 1] : -1;
+    const bool ok = f >= 0 && f > prev && (long long)f < n;
+    bad |= !ok;
+    if (ok) {
+      pos[new_of_old[f]] = ((u64)epoch << 32) | (u64)(u32)i;
+      deg += (u64)(u32)(offsets[f + 1] - offsets[f]);
+    }
+    reduced[i] = identity;
+  }
+  if (__ballot(bad) && lane_id() == 0) { *host_flag = 0; *dev_flag = epoch; }
+  // ONE add per workgroup (an add per wave -- 37 000 of them on one address for RMAT-22's 2.4 M frontier vertices -- made this kernel
+  // 130 us instead of 45: same-address atomics are served one after the other, ~5-11 ns each, tools/microbench5.hip)
+  __shared__ unsigned long long s_deg;
+  if (threadIdx.x == 0) s_deg = 0ull;
+  __syncthreads();
+  deg = wave_sum(deg);
+  if (lane_id() == 0 && deg) atomicAdd(&s_deg, (unsigned long long)deg);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_deg) atomicAdd((unsigned long long*)edges, s_deg);
+}
+// last kernel of a call: (subset calls) the degree sum to the host's mailbox, then the sequence number the host spins on
+// (standard_context_t::mailbox_wait: a hipStreamSynchronize wakes up 10-20 us later)
+__global__ void k_nr_publish(const u64* edges, long long* host_edges, long long* mailbox, long long seq) {
+  if (host_edges) *host_edges = (long long)*edges;
+  __threadfence_system();
+  __hip_atomic_store(mailbox + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // value of entry d: -1 (padding, lanes past a row's end) -> identity, a hub -> LDS, anything else -> L2 / HBM.  The global
@@ -208,7 +266,7 @@ __global__ __launch_bounds__(BLOCK) void k_nr_fold(nr_layout_t L, const V* __res
       V t = s_part[0];
 #pragma unroll
       for (int k = 1; k < BLOCK / WAVE; ++k) t = op(t, s_part[k]);
-      reduced[L.old_of_new[r]] = t;
+      nr_store(L, reduced, r, t);
     }
     return;
   }
@@ -225,7 +283,7 @@ __global__ __launch_bounds__(BLOCK) void k_nr_fold(nr_layout_t L, const V* __res
   if (u < u1) a0 = op(a0, partial[u]);
   if (u + 1 < u1) a1 = op(a1, partial[u + 1]);
   if (u + 2 < u1) a2 = op(a2, partial[u + 2]);
-  reduced[L.old_of_new[r]] = op(op(a0, a1), op(a2, a3));
+  nr_store(L, reduced, r, op(op(a0, a1), op(a2, a3)));
 }
 
 // short rows by degree class: [vs_v[0], vs_v[1]) 16 lanes per vertex (17 .. 63 entries), [vs_v[1], vs_v[2]) 4 lanes (5 .. 16),
@@ -242,7 +300,6 @@ __device__ __forceinline__ void nr_short_work(const nr_layout_t& L, const V* __r
   const u32 W = nblocks * NW, w = block * NW + (u32)wave;
   const u32* __restrict__ ro = L.row_offsets;
   const int* __restrict__ col = L.col_indices;
-  const int* __restrict__ o2n = L.old_of_new;
   struct plan_t { u32 e0, cnt, v, lpr_shift; };
   auto plan = [&](u32 s) -> plan_t {
     plan_t p; p.e0 = L.vs_dummy; p.cnt = 0; p.v = 0xFFFFFFFFu; p.lpr_shift = 0;
@@ -279,7 +336,7 @@ __device__ __forceinline__ void nr_short_work(const nr_layout_t& L, const V* __r
       for (int sh = 1; sh < 4; sh <<= 1) acc = op(acc, __shfl_xor(acc, sh, WAVE));
     }
     const u32 sub = (u32)lane & ((1u << pc.lpr_shift) - 1u);
-    if (pc.v != 0xFFFFFFFFu && sub == 0u) reduced[o2n[pc.v]] = acc;
+    if (pc.v != 0xFFFFFFFFu && sub == 0u) nr_store(L, reduced, pc.v, acc);
     pc = pn; dc = dn;
   }
 }
@@ -491,7 +548,7 @@ __global__ __launch_bounds__(BLOCK) void k_nrs_fold(nr_layout_t L, const V* __re
       V t = s_part[0];
 #pragma unroll
       for (int k = 1; k < NW; ++k) t = op(t, s_part[k]);
-      reduced[L.old_of_new[r]] = t;
+      nr_store(L, reduced, r, t);
     }
     return;
   }
@@ -502,7 +559,7 @@ __global__ __launch_bounds__(BLOCK) void k_nrs_fold(nr_layout_t L, const V* __re
     V acc = nrs_fold_row<V, Op, WAVE>(off, partial, K1, LR, r, (u32)lane_id(), identity, op);
 #pragma unroll
     for (int sh = 1; sh < WAVE; sh <<= 1) acc = op(acc, __shfl_xor(acc, sh, WAVE));
-    if (lane_id() == 0) reduced[L.old_of_new[r]] = acc;
+    if (lane_id() == 0) nr_store(L, reduced, r, acc);
     return;
   }
   blk -= b1;
@@ -512,13 +569,13 @@ __global__ __launch_bounds__(BLOCK) void k_nrs_fold(nr_layout_t L, const V* __re
     V acc = nrs_fold_row<V, Op, 8>(off, partial, K1, LR, in ? r : t1, sub, identity, op);
 #pragma unroll
     for (int sh = 1; sh < 8; sh <<= 1) acc = op(acc, __shfl_xor(acc, sh, WAVE));
-    if (in && sub == 0u) reduced[L.old_of_new[r]] = acc;
+    if (in && sub == 0u) nr_store(L, reduced, r, acc);
     return;
   }
   blk -= b2;
   const u32 r = t2 + blk * BLOCK + threadIdx.x;                    // a thread per row
   if (r >= LR) return;
-  reduced[L.old_of_new[r]] = nrs_fold_row<V, Op, 1>(off, partial, K1, LR, r, 0u, identity, op);
+  nr_store(L, reduced, r, nrs_fold_row<V, Op, 1>(off, partial, K1, LR, r, 0u, identity, op));
 }
 
 // scratch the fast path needs (vals + partials: one per unit, or per mini-unit of the sliced long rows), in bytes
@@ -528,19 +585,37 @@ inline size_t nr_scratch_bytes(long long n, long long units_pad, size_t value_si
 
 // The whole fast path.  get(old_id) -> V; reduced: n entries; frontier: n ids (checked to be 0 .. n - 1 by the first kernel).
 // Everything is enqueued on the context's stream; the kernels behind the first return at once if *dev_flag == epoch.
+// nf == n: the frontier must be 0 .. n - 1 (results by original id).  nf < n (round 6): a strictly ascending subset -- results by frontier
+// position; L_in.new_of_old, `offsets` (the ORIGINAL CSR's, for the degree sum -> host_flag[1]) and `pos` are needed.  pos: n words of 64
+// bits that ONLY these calls write (zeroed when allocated: an entry is 0 or (epoch of an earlier call, position) -- memory that held
+// anything else could show this call's epoch by accident; the epochs of a context never repeat).
+// Returns the sequence number to wait for (standard_context_t::mailbox_wait).
 template <typename V, typename Op, typename GetValue>
-inline void nr_full_frontier(const nr_layout_t& L, GetValue get, V* reduced, V identity, Op op, standard_context_t& ctx, const int* frontier,
-                             long long* host_flag, u32* dev_flag, u32 epoch) {
+inline long long nr_full_frontier(const nr_layout_t& L_in, GetValue get, V* reduced, V identity, Op op, standard_context_t& ctx, const int* frontier,
+                             long long* host_flag, u32* dev_flag, u32 epoch, long long nf = -1, const int* offsets = nullptr, u64* pos = nullptr) {
   static_assert(sizeof(V) == 4, "the full-frontier neighbour-reduce is instantiated for 4-byte values only (neighborhood.hxx gates on it)");
   hipStream_t s = ctx.stream();
   ++ctx.scratch_epoch;
+  nr_layout_t L = L_in;
   V* const vals = (V*)ctx.scratch;
   V* const partial = (V*)((char*)ctx.scratch + (((size_t)L.n + 64) * sizeof(V) + 255) / 256 * 256);
   static unsigned char seen[64] = {};
   if (device_once_t once{seen})
     MGX_HIP(hipFuncSetAttribute((const void*)(k_nr_edges<V, Op, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  hipLaunchKernelGGL((k_nr_values<V, GetValue>), dim3(grid_for(L.n, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, get, L.old_of_new, vals,
-                     reduced, identity, (long long)L.n, frontier, host_flag, dev_flag, epoch);
+  const bool subset = nf >= 0 && nf < (long long)L.n && pos != nullptr;
+  if (subset) {
+    L.pos = pos; L.pos_epoch = epoch;
+    hipLaunchKernelGGL((k_nr_values_subset<V, GetValue>), dim3(grid_for(L.n, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, get, L.old_of_new, L.new_of_old,
+                       vals, reduced, identity, (long long)L.n, frontier, nf, offsets, pos, ctx.nr_edges(), host_flag, dev_flag, epoch);
+  } else {
+    hipLaunchKernelGGL((k_nr_values<V, GetValue>), dim3(grid_for(L.n, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, get, L.old_of_new, vals,
+                       reduced, identity, (long long)L.n, frontier, host_flag, dev_flag, epoch);
+  }
+  const long long seq = ++ctx.mailbox_seq;
+  struct publish_t {            // (behind everything else, whichever way the function is left)
+    bool subset; hipStream_t s; const u64* e; long long* h; long long* mb; long long seq;
+    ~publish_t() { hipLaunchKernelGGL(k_nr_publish, dim3(1), dim3(1), 0, s, e, subset ? h : (long long*)nullptr, mb, seq); }
+  } publish{subset, s, ctx.nr_edges(), host_flag + 1, ctx.mailbox, seq};
   if (L.nrs_mu) {
     // the long rows by slice of their destinations + the short rows, one launch; then the fold
     static unsigned char seen_s[64] = {};
@@ -552,7 +627,7 @@ inline void nr_full_frontier(const nr_layout_t& L, GetValue get, V* reduced, V i
     const u32 grid = L.nrs_tier[0] + (L.nrs_tier[1] - L.nrs_tier[0] + BLOCK / WAVE - 1) / (BLOCK / WAVE) + (L.nrs_tier[2] - L.nrs_tier[1] + BLOCK / 8 - 1) / (BLOCK / 8) +
                      (L.nrs_rows - L.nrs_tier[2] + BLOCK - 1) / BLOCK;
     if (grid) hipLaunchKernelGGL((k_nrs_fold<V, Op>), dim3(grid), dim3(BLOCK), 0, s, L, (const V*)partial, reduced, identity, op, dev_flag, epoch);
-    return;
+    return seq;
   }
   const u32 long_rows = L.vs_v[0];
   const bool has_long = L.ub_units > 0 && long_rows > 0, has_short = L.vs_v[3] > L.vs_v[0];
@@ -564,6 +639,7 @@ inline void nr_full_frontier(const nr_layout_t& L, GetValue get, V* reduced, V i
     const u32 grid = L.big_rows + (rest + BLOCK - 1) / BLOCK;
     if (grid) hipLaunchKernelGGL((k_nr_fold<V, Op>), dim3(grid), dim3(BLOCK), 0, s, L, (const V*)partial, reduced, identity, op, long_rows, dev_flag, epoch);
   }
+  return seq;
 }
 
 }  // namespace mgx

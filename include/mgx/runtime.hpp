@@ -160,6 +160,10 @@ struct standard_context_t : context_t {
   // holds the epoch of the last full-frontier call whose frontier was not the iota (0: none yet)
   unsigned nr_epoch = 0;
   unsigned* nr_flag() const { return lookback_ticket + 8; }
+  // ... and behind that the degree sum of the subset frontiers (64 bits at byte 48; only ever added to: nr_edges_base is what it
+  // held before the call in flight)
+  unsigned long long* nr_edges() const { return (unsigned long long*)(lookback_ticket + 12); }
+  unsigned long long nr_edges_base = 0;
   unsigned next_nr_epoch() {
     if (++nr_epoch == 0u) nr_epoch = 1u;      // (2^32 calls: a stale word could only name the call 2^32 - 1 before this one)
     return nr_epoch;

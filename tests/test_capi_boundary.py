@@ -217,8 +217,10 @@ def test_gather_kernels_keep_their_loads_unconditional(built):
         pytest.skip("no hipcc")
     res = isl.sunk_loads(isl.device_asm())
     names = isl.demangle(list(res))
-    budgets = {"mgx::k_nr_edges<": 3, "mgx::k_nrs_edges<": 3, "mgx::k_sssp_relax<": 3, "mgx::k_sssp_relax_dense<": 3, "mgx::k_bfs_build2<512, 0, 1>": 2,
-               "mgx::k_bfs_push<false, 0>": 60}          # (the push kernel: the chain body of block 0, the epilogue's chunks, the cold probes)
+    budgets = {"mgx::k_nr_edges<": 3, "mgx::k_nrs_edges<": 3, "mgx::k_sssp_relax<": 3, "mgx::k_sssp_relax_dense<": 6, "mgx::k_bfs_build2<512, 0, 1>": 2,
+               "mgx::k_bfs_push<false, 0>": 60}          # (the push kernel: the chain body of block 0, the epilogue's chunks, the cold probes;
+                                                         #  k_sssp_relax_dense, round 6: the gated sweep's relaxations sit under a wave-uniform
+                                                         #  "any unit active" branch by design -- 5 sites, none on the stream's own loads)
     seen = set()
     for k, c in res.items():
         d = names.get(k, k)

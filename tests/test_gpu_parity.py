@@ -179,6 +179,70 @@ def test_neighbour_reduce_full_frontier_on_the_layout(gpu_ctx, oracle, torch_mod
             assert np.array_equal(red.cpu().numpy(), want), frontier_kind
 
 
+@pytest.mark.parametrize("op", ["f32_plus", "i32_min", "i32_max"])
+@pytest.mark.parametrize("scale,ef,slices", [(9, 4, 0), (13, 16, 0), (16, 16, 0), (17, 16, 2)])
+def test_neighbour_reduce_subset_frontier_on_the_layout(gpu_ctx, oracle, torch_mod, monkeypatch, op, scale, ef, slices):
+    """round 6: a frontier that is a large ASCENDING SUBSET of the vertices (what PR's filter leaves behind its first iteration,
+    pr_enactor.hxx:53-66) takes the layout's kernels too -- every row is computed, the frontier's are kept, reduced[] is indexed by
+    frontier POSITION (neighborhood.hxx:58) -- against the oracle's serial restatement, like the full frontier.  Also: a subset
+    below n / 8 (general kernel), ids out of order and an ascending list with a duplicate (both: the device-side check sends
+    them to the general kernel, same answers), a frontier that holds every vertex but one, vertices without edges inside the frontier (identity), and MGX_NR_SLICES=2 on R-MAT 17 so that the
+    tail behind the hot slices is used."""
+    import mini_amd
+    torch = torch_mod
+    if slices:
+        monkeypatch.setenv("MGX_NR_SLICES", str(slices))
+    n, ro, ci, w = oracle.rmat_csr(scale, ef, 160 + scale)
+    g = _graph(gpu_ctx, ro, ci).build_layout()
+    rng = np.random.default_rng(100 + scale)
+    deg = np.diff(ro)
+    kinds = {
+        "half": np.sort(rng.permutation(n)[: n // 2]),
+        "with_edges": np.nonzero(deg > 0)[0],                       # PR's second frontier, nearly
+        "all_but_one": np.delete(np.arange(n), n // 3),
+        "eighth": np.sort(rng.permutation(n)[: (n + 7) // 8]),      # exactly at the threshold
+        "sparse": np.sort(rng.permutation(n)[: n // 50]),           # below it: the general kernel
+        "shuffled": rng.permutation(n)[: n // 2],                   # not ascending: the general kernel
+    }
+    dup = np.sort(rng.permutation(n)[: n // 2]); dup[5] = dup[4]    # a duplicate: not STRICTLY ascending
+    kinds["duplicate"] = dup
+    for kind, ids in kinds.items():
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        f = mini_amd.Frontier(gpu_ctx, n).load(ids)
+        if op == "f32_plus":
+            for real in (False, True):
+                vals = (rng.random(n) * 3.0).astype(np.float32) if real else rng.integers(0, 8, size=n).astype(np.float32)
+                dv = torch.from_numpy(vals).cuda()
+                red = torch.full((len(ids),), -1, dtype=torch.float32, device="cuda")
+                nz = mini_amd.segreduce(g, f, dv, 0.0, red, op)
+                want, wnz = oracle.neighbor_reduce_f32_plus(ro, ci, ids, vals, 0.0)
+                assert nz == wnz, kind
+                got = red.cpu().numpy()
+                if real:
+                    assert np.allclose(got, want, rtol=2e-5, atol=1e-6), (kind, np.abs(got - want).max())
+                else:
+                    assert np.array_equal(got, want), kind
+        else:
+            vals = rng.integers(-1000, 1000, size=n).astype(np.int32)
+            dv = torch.from_numpy(vals).cuda()
+            ident = 2**31 - 1 if op == "i32_min" else -2**31
+            red = torch.full((len(ids),), 12345, dtype=torch.int32, device="cuda")
+            nz = mini_amd.segreduce(g, f, dv, ident, red, op)
+            want, wnz = oracle.neighbor_reduce_i32(ro, ci, ids, vals, ident, op == "i32_max")
+            assert nz == wnz, kind
+            assert np.array_equal(red.cpu().numpy(), want), kind
+    # two calls in a row on the same context: the second frontier's positions must not be mixed up with the first one's
+    a_ids, b_ids = np.ascontiguousarray(kinds["half"], dtype=np.int32), np.ascontiguousarray(kinds["with_edges"], dtype=np.int32)
+    vals = rng.integers(0, 8, size=n).astype(np.int32)
+    dv = torch.from_numpy(vals).cuda()
+    for ids in (a_ids, b_ids, a_ids):
+        f = mini_amd.Frontier(gpu_ctx, n).load(ids)
+        red = torch.full((len(ids),), 777, dtype=torch.int32, device="cuda")
+        mini_amd.segreduce(g, f, dv, 2**31 - 1, red, "i32_min")
+        want, _ = oracle.neighbor_reduce_i32(ro, ci, ids, vals, 2**31 - 1, False)
+        assert np.array_equal(red.cpu().numpy(), want)
+
+
 # ---- golden fixtures through the C-ABI -------------------------------------------------------
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
 def test_reference_fixtures_bfs_and_sssp(gpu_ctx, oracle, case, tmp_path):
