@@ -426,6 +426,11 @@ MGX_API int mgx_dbfs2_run(mgx_dbfs2_t h, mgx_comm_t comm, int src_global, int ex
  * and goes on level by level.  out5 = { traversals planned ahead, of those frozen, of those longer than planned, levels and
  * lists-mask (bit L: level L from id lists) of the last plan }. */
 MGX_API int mgx_dbfs2_spec_stats(mgx_dbfs2_t h, int64_t* out5);
+/* Level 0 of every traversal runs with a host look on every rank, and its all-gathered id-list headers carry each rank's plan: the
+ * rest is enqueued ahead only when ALL ranks announced the same plan (round 6) -- a rank whose history differs (its engine handle was
+ * recreated, MGX_DIST_SPEC is set in its environment only, a traversal threw there) makes every rank go level by level instead of
+ * issuing different RCCL collectives.  mgx_dbfs2_forget_plan drops this engine's history (what a recreated handle starts with). */
+MGX_API int mgx_dbfs2_forget_plan(mgx_dbfs2_t h);
 /* The engines of ALL ranks of one partition, made on one context, driven in turn by the calling thread: the collectives are device
  * copies into one shared buffer, the level plan is mgx_dbfs2_run's.  A measurement and test entry (wall time / ranks = what one
  * rank's GPU spends per traversal, no exchange time); out6_each: ranks x 6, as mgx_dbfs2_status per engine. */

@@ -138,6 +138,7 @@ SIGNATURES = {
     "mgx_comm_loopback_id": [_vp],
     "mgx_sssp_build_preds": [_vp, _pi64],
     "mgx_dbfs2_spec_stats": [_vp, _pi64],
+    "mgx_dbfs2_forget_plan": [_vp],
     "mgx_dbfs2_run_group": [_vp, _i, _i, _i64, _pi64],
     "mgx_comm_info": [_vp, _vp, _vp],
     "mgx_comm_selftest": [_vp, _vp, _vp, _vp, _i64],

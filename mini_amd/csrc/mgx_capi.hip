@@ -1958,6 +1958,12 @@ int mgx_dbfs2_spec_stats(mgx_dbfs2_t h, int64_t* out5) {
   out5[3] = h->run_bufs.last_plan_levels; out5[4] = (int64_t)h->run_bufs.last_plan_sparse;
   MGX_CATCH
 }
+int mgx_dbfs2_forget_plan(mgx_dbfs2_t h) {
+  MGX_TRY
+  MGX_REQUIRE(h, "NULL argument");
+  h->run_bufs.hist_n = 0;
+  MGX_CATCH
+}
 int mgx_dbfs2_run_group(mgx_dbfs2_t* hs, int count, int src_global, int64_t exchange_words, int64_t* out6_each) {
   MGX_TRY
   MGX_REQUIRE(hs && out6_each && count >= 1 && count <= 64, "mgx_dbfs2_run_group: 1..64 engines");

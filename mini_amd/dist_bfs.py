@@ -274,6 +274,10 @@ class HipRankEngine2:
         check(lib.mgx_dbfs2_spec_stats(self._h, o))
         return tuple(int(v) for v in o)
 
+    def forget_plan(self):
+        """drop this engine's traversal history: its next plan is "none", as a recreated handle's (mgx_dbfs2_forget_plan)"""
+        check(lib.mgx_dbfs2_forget_plan(self._h))
+
     @staticmethod
     def run_group(engines, src):
         """all ranks' engines (made on ONE context) in turn from this thread, collectives as device copies (mgx_dbfs2_run_group)"""

@@ -97,10 +97,13 @@ def test_native_bfs_loop_over_loopback_world(gpu_ctx, oracle, torch_gpu, scale, 
     # Order: the first traversal of an engine looks once per level and leaves the level plan; the leaf's plan (lists at the first
     # levels) then meets the hub, whose neighbourhood overflows a list against it -- the traversal freezes and is continued --, and
     # the hub's plan (bitmaps early) meets the leaf again.
-    srcs = [int(cand[-1]), int(cand[0]), int(cand[len(cand) // 2]), int(cand[-1]), int(cand[0])]
+    # (round 6: level 0 of every traversal runs with a host look -- the ranks agree on the level plan there, bfs_dist2.hpp -- so a list
+    #  that overflows against the plan must do so at level >= 1 to freeze a traversal: the vertex WITHOUT edges goes first -- its
+    #  traversal has no level 1, so the plan made from it sends every later level through the lists -- and the hub behind it freezes)
     iso = np.nonzero(deg == 0)[0]
+    srcs = ([int(iso[0])] if len(iso) else []) + [int(cand[0]), int(cand[-1]), int(cand[len(cand) // 2]), int(cand[-1]), int(cand[0])]
     if len(iso):
-        srcs.append(int(iso[0]))
+        srcs.append(int(iso[-1]))
     g, single = _single_gpu_labels(gpu_ctx, scale, scale, sorted({int(o2n[s]) for s in srcs}))
     ro_h, ci_h = g["row_offsets"].cpu().numpy(), g["col_indices"].cpu().numpy()
     ident = LoopbackComm.new_id()
@@ -123,14 +126,36 @@ def test_native_bfs_loop_over_loopback_world(gpu_ctx, oracle, torch_gpu, scale, 
         for e in engs:
             assert np.array_equal(e.visited(), want_words), "rank %d's bitmap differs from the reached set" % e.rank
     assert comms[0].rounds() > rounds_before            # the collectives went through the loopback world
+    if lists and G > 1:
+        # (round 6) ONE rank loses its history -- a recreated engine handle -- while the others hold a plan: level 0's
+        # agreement sends every rank level by level instead of letting them enqueue different collectives (which the loopback world
+        # would report as mismatched rounds, and real RCCL would answer with a hang); labels as ever, and nobody planned ahead
+        before = [e.spec_stats()[0] for e in engs]
+        engs[G - 1].forget_plan()
+        src = srcs[1]
+        sts = run_rank_threads(G, lambda r: engs[r].run_native(src, comms[r], exchange))
+        assert all(st["over"] for st in sts) and len({st["levels"] for st in sts}) == 1, sts
+        assert np.array_equal(_gathered(engs, n)[n2o], single[int(o2n[src])]), "labels differ after one rank forgot its plan"
+        assert [e.spec_stats()[0] for e in engs] == before, "a rank planned ahead although the ranks' plans differed"
+        # ... and the next traversal is planned again on every rank (the histories differ in length, the plans they yield need not)
+        sts = run_rank_threads(G, lambda r: engs[r].run_native(src, comms[r], exchange))
+        assert np.array_equal(_gathered(engs, n)[n2o], single[int(o2n[src])])
+        for e in engs:
+            e.forget_plan()                              # (the statistics below count the traversals above this block)
+        stats_now = [e.spec_stats() for e in engs]
+        assert len({s[0] - b for s, b in zip(stats_now, before)}) == 1, (stats_now, before)     # all planned, or none did
     if lists:
         # sparse levels were merged from id lists AND some level overflowed its list (the hub's neighbourhood): both protocols ran
         paths = [e.path_levels() for e in engs]
         assert all(p[0] >= 1 for p in paths), paths
-        # every traversal but the first was enqueued ahead from the level plan, on every rank alike; the hub behind the leaf froze
+        # every traversal but the first (and the one from a vertex without edges: over at level 0) was enqueued ahead from the level
+        # plan, on every rank alike; the hub behind the vertex without edges froze
         stats = [e.spec_stats() for e in engs]
         assert len(set(stats)) == 1, stats
-        assert stats[0][0] == len(srcs) - 1 and stats[0][1] >= 1, stats
+        extra = (stats_now[0][0] - before[0]) if G > 1 else 0        # (the second traversal of the block above, if it was planned)
+        assert stats[0][0] == len(srcs) - 1 - (1 if len(iso) else 0) + extra, stats
+        if len(iso):
+            assert stats[0][1] >= 1, stats
     for c in comms:
         c.close()
     for e in engs:
@@ -219,7 +244,8 @@ def test_group_run_in_turn_equals_single_gpu(gpu_ctx, torch_gpu, scale, G, lists
     n2o, o2n = new_of_old.cpu().numpy(), old_of_new.cpu().numpy()
     deg = deg_new.cpu().numpy()
     cand = np.nonzero(deg > 0)[0]
-    srcs = [int(cand[-1]), int(cand[0]), int(cand[len(cand) // 3]), int(cand[-2]), int(cand[1])]
+    iso = np.nonzero(deg == 0)[0]
+    srcs = ([int(iso[0])] if len(iso) else []) + [int(cand[0]), int(cand[-1]), int(cand[len(cand) // 3]), int(cand[-2]), int(cand[1])]
     g, single = _single_gpu_labels(gpu_ctx, scale, scale, sorted({int(o2n[s]) for s in srcs}))
     for src in srcs:
         sts = HipRankEngine2.run_group(engs, src)
@@ -230,8 +256,8 @@ def test_group_run_in_turn_equals_single_gpu(gpu_ctx, torch_gpu, scale, G, lists
     if lists:
         stats = engs[0].spec_stats()
         assert stats[0] == (len(srcs) - 1 if spec == "1" else 0), stats
-        if spec == "1":
-            assert stats[1] >= 1, stats               # the hub behind the leaf
+        if spec == "1" and len(iso):
+            assert stats[1] >= 1, stats               # the hub behind the vertex without edges (whose plan sends level 1 through the lists)
     for e in engs:
         e.close()
 
