@@ -177,7 +177,7 @@ struct bfs_fused_enactor_t {
       layout.new_of_old = g.d_new_of_old.data();
       layout.old_of_new = g.d_old_of_new.data();
       if (g.ub_units > 0) {
-        layout.ub_col = g.d_ub_col.data();
+        layout.ub_col = g.d_ub_col.size() ? g.d_ub_col.data() : nullptr;      // (round 6: gone when the 24-bit copy below exists)
         layout.ub_col24 = g.d_ub_col24.size() ? g.d_ub_col24.data() : nullptr;
         layout.ub_owner = g.d_ub_owner.data();
         layout.ub_units = g.ub_units;
@@ -189,8 +189,10 @@ struct bfs_fused_enactor_t {
       layout.vs_edges = g.vs_edges; layout.vs_dummy = g.vs_dummy; layout.vs_long_min = g.vs_long_min;
       if (g.d_ss_tab.size() && g.vs_long_min > 0) layout.ss_tab = g.d_ss_tab.data();
       if (g.cold_slices > 0) {
-        layout.cold_owner = g.d_cold_owner.data();
-        layout.cold_dst = g.d_cold_dst.data();
+        // (round 6: the 8-byte pairs are gone when every slice carries the packed words below -- cold_pairs8 says which)
+        layout.cold_pairs8 = g.d_cold_owner.size() != 0 && g.d_cold_dst.size() != 0;
+        layout.cold_owner = layout.cold_pairs8 ? g.d_cold_owner.data() : nullptr;
+        layout.cold_dst = layout.cold_pairs8 ? g.d_cold_dst.data() : nullptr;
         layout.cold_slices = g.cold_slices;
         if (g.d_cold_pk.size() && g.d_cold_cbase.size()) {
           layout.cold_pk = g.d_cold_pk.data(); layout.cold_cbase = g.d_cold_cbase.data(); layout.cold_pk_mask = g.cold_pk_mask;
@@ -209,12 +211,16 @@ struct bfs_fused_enactor_t {
         }
       }
       layout.cold_majority = g.cold_majority;
-      if (g.src_shapes.size() == (size_t)g.num_nodes * 4) {
-        layout.src_shapes = g.src_shapes.data();
-        layout.src_shapes_long_min = g.src_shapes_long_min;
-      }
     }
     return layout;
+  }
+  // the shapes of the sources of one call (mgx/src_shapes.hpp), resolved into `table` and hung into the layout: entry i is source i's
+  std::vector<unsigned> shape_table;
+  void resolve_shapes(graph_device_t& g, mgx::bfs_layout_t& layout, const int* srcs, int count, int mode, standard_context_t& context) {
+    if (!g.has_layout || !g.src_shapes_enabled || !mgx::bfs_wants_src_shapes(*fused, mode) || g.num_edges <= 0) return;
+    g.src_shape_cache.resolve(g.d_row_offsets.data(), g.d_col_indices.data(), g.num_nodes, fused->long_min, srcs, count, shape_table, context);
+    layout.src_shapes = shape_table.data();
+    layout.src_shapes_long_min = fused->long_min;
   }
 
   // counters of a traversal from the (head of the) control block it left on the host
@@ -273,6 +279,7 @@ struct bfs_fused_enactor_t {
     // CSC slots alias the CSR (symmetric input, what the reference always has)
     const bool use_layout = g.has_layout && (!direction_optimizing || g.csc_is_csr);
     last = bfs_run_stats_t();
+    if (use_layout) resolve_shapes(g, layout, &bfs_problem->src, 1, direction_optimizing ? 1 : 0, context);
     mgx::bfs_fused_run(*fused, g.d_row_offsets.data(), g.d_col_indices.data(), bfs_problem->d_labels.data(),
                        bfs_problem->src, context, use_layout ? &layout : nullptr, direction_optimizing ? 1 : 0, alpha,
                        g.d_col_offsets.data(), g.d_row_indices.data());
@@ -306,6 +313,7 @@ struct bfs_fused_enactor_t {
     int reruns = 0;
     for (int first = 0; first < count; first += MANY_CHUNK) {
       const int part = count - first < MANY_CHUNK ? count - first : MANY_CHUNK;
+      if (use_layout) resolve_shapes(g, layout, srcs + first, part, direction_optimizing ? 1 : 0, context);
       reruns += mgx::bfs_fused_run_many(*fused, g.d_row_offsets.data(), g.d_col_indices.data(), bfs_problem->d_labels.data(), srcs + first,
                                         part, context, many_heads, use_layout ? &layout : nullptr, direction_optimizing ? 1 : 0,
                                         alpha, g.d_col_offsets.data(), g.d_row_indices.data());

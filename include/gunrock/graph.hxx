@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../mgx/runtime.hpp"
+#include "../mgx/src_shapes.hpp"
 
 // The reference's sources say `using namespace mgpu;` and `mgpu::fill<...>` for the memory
 // layer (graph.hxx:15, bfs_enactor.hxx:83); mgx is that layer here.
@@ -97,8 +98,10 @@ struct graph_device_t {
   // rows below and from the long-row threshold.  The fused BFS sizes a traversal's launch sequence from it before the
   // first kernel is enqueued (which of the two small-level launches in front of the device-wide slots will find work).
   // Built by mgx_graph_build_layout (rows sorted by neighbour: duplicates are adjacent); empty: not available.
-  std::vector<unsigned> src_shapes;  // 4 words per vertex: degree, level-1 edges, level-1 short rows, level-1 long rows
-  int src_shapes_long_min = 0;       // the long-row threshold the rows were split by
+  // what a traversal from a source starts with (mgx/src_shapes.hpp): computed for the sources that are asked for and remembered --
+  // round 6; until then 16 bytes per VERTEX of host memory, filled by a kernel that read 9.8 GB on RMAT-22 when the layout was built
+  mgx::src_shape_cache_t src_shape_cache;
+  bool src_shapes_enabled = true;    // (MGX_BFS_SRC_SHAPES=0 when the layout is built: every traversal gets the graph-wide launch sequence)
   unsigned nr_big_rows = 0;          // layout rows [0, nr_big_rows) hold more than mgx::NR_BIG_UNITS units (degree-sorted layouts)
   // The long rows by slice of their destinations for the full-frontier neighbour-reduce (mgx/nreduce.hpp: k_nrs_edges; built by the
   // library at the graph's first such reduce, mgx_layout.hip: mgx_nrs_build_device): 16-byte mini-units (4 words each), where a

@@ -272,7 +272,7 @@ __device__ __forceinline__ void bfs_chain_body(const bfs_fused_args_t& a, int sl
     }
     // ... and, when that level will read its long rows from the unit blocks (bfs_long_is_dense's rule), its frontier as
     // a bitmap -- what k_bfs_build leaves behind a device-wide level: s_win still holds the vertices this level discovered.
-    if (nf2 != 0 && (next_pulls || (a.ub_col && a.dense_div && ((tot_l & DEGMASK) >> 6) * (u64)a.dense_div >= (u64)a.ub_units))) {
+    if (nf2 != 0 && (next_pulls || (a.ub_owner && a.dense_div && ((tot_l & DEGMASK) >> 6) * (u64)a.dense_div >= (u64)a.ub_units))) {
       uint4* const fb4 = (uint4*)a.frontier_bits;
       const int quads = (a.n + 127) / 128;
       for (int i = threadIdx.x; i < quads; i += NT) fb4[i] = make_uint4(0u, 0u, 0u, 0u);

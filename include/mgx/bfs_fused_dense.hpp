@@ -51,7 +51,7 @@ constexpr size_t bfs_dense_lds_bytes(int hotw) { return (size_t)hotw * 4 + 128; 
 
 // the slot's long rows are read from the unit blocks (grid-uniform: every workgroup sees the same stable inputs)
 __device__ __forceinline__ bool bfs_long_is_dense(const bfs_fused_args_t& a, const bfs_ctrl_t* c, int slot, u64 lcur) {
-  if (!a.ub_col || a.dense_div == 0u || c->fb_slot != slot) return false;
+  if (!a.ub_owner || a.dense_div == 0u || c->fb_slot != slot) return false;      // (ub_col may be NULL: a layout that carries the 24-bit copy only)
   const u64 units = (lcur & BFS_EMASK) >> 6;        // the long-row queue's offsets count padded edges: 64 per unit
   return units * (u64)a.dense_div >= (u64)a.ub_units;
 }

@@ -54,6 +54,7 @@ struct bfs_layout_t {
   // cold-edge lists of the long rows (bfs_fused_cold.hpp): pairs grouped by slice; hot_n / long_min they were cut for
   const int* cold_owner = nullptr;
   const int* cold_dst = nullptr;
+  bool cold_pairs8 = false;             // the two arrays above exist (round 6: a layout whose slices are ALL packed drops them)
   const unsigned* cold_pk = nullptr;    // the same pairs, four bytes each (bfs_fused_args_t::cold_pk); NULL: none
   const unsigned* cold_cbase = nullptr;
   unsigned cold_cb[BFS_COLD_MAX_SLICES + 1] = {0};
@@ -66,7 +67,8 @@ struct bfs_layout_t {
   unsigned cold_hot_n = 0;
   int cold_long_min = 0;
   bool cold_majority = false;         // more than a quarter of the long rows' entries point behind the LDS prefix (no lists were built): a flat graph
-  // HOST table, by ORIGINAL vertex id, 4 words per vertex (graph_device_t::src_shapes): what a traversal from v starts with
+  // HOST table, 4 words per SOURCE OF THE CALL (entry i belongs to the i-th source handed to bfs_fused_run / _run_many; round 6: resolved
+  // on demand, mgx/src_shapes.hpp): what a traversal from it starts with
   const unsigned* src_shapes = nullptr;
   int src_shapes_long_min = 0;
 };
@@ -393,8 +395,9 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
 #endif
   a.count_marks = (st.count_marks || st.time_kernels == 1) ? 1 : 0;
   // unit blocks: only for the CSR they were built from, with the long-row threshold they were built for
-  const bool units_avail = relabelled && layout->ub_col && layout->ub_units > 0 && layout->ub_min_degree == st.long_min &&
-                           st.long_min > 0 && !lab_flags;
+  // (the entries at 32 bits, or their 24-bit copy when the run may read it: a layout that carries the copy has dropped the former)
+  const bool units_avail = relabelled && (layout->ub_col || (layout->ub_col24 && st.opts.pack24)) && layout->ub_owner && layout->ub_units > 0 &&
+                           layout->ub_min_degree == st.long_min && st.long_min > 0 && !lab_flags;
   // Probing the bitmap word of cold neighbours (instead of marking them untested) pays on big graphs WITHOUT the unit
   // blocks -- the partitioned ranks, a caller-made layout.  With them the unit-block body, the cold-edge pass and the
   // lazy builds win at every size measured: RMAT-23 391 against 272 GTEPS, RMAT-24 386 / 253, RMAT-25 187 / 179.
@@ -418,7 +421,12 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   const bool build2_ok = ((uintptr_t)a.row_offsets % 16 == 0) && ((uintptr_t)a.old_of_new % 16 == 0);
   // cold-edge lists (bfs_fused_cold.hpp): with the unit blocks they were cut from, the prefix they were cut behind, and a
   // queue build that knows their bitmaps
-  const bool cold_lists = units && layout->cold_dst && layout->cold_slices > 0 && layout->cold_hot_n == (unsigned)(BFS_DENSE_HOTW * 32) &&
+  // (the pairs at 8 bytes, or every slice packed at 4 and a run that may read those)
+  const bool cold_all_packed = layout && layout->cold_pk && layout->cold_cbase && layout->cold_slices > 0 &&
+                               (layout->cold_pk_mask & (layout->cold_slices >= 64 ? ~0ull : ((1ull << layout->cold_slices) - 1ull))) ==
+                                   (layout->cold_slices >= 64 ? ~0ull : ((1ull << layout->cold_slices) - 1ull));
+  const bool cold_pairs_ok = layout && ((layout->cold_pairs8 && layout->cold_dst) || (cold_all_packed && opt.cold_pack));
+  const bool cold_lists = units && cold_pairs_ok && layout->cold_slices > 0 && layout->cold_hot_n == (unsigned)(BFS_DENSE_HOTW * 32) &&
                           layout->cold_long_min == st.long_min && build2_ok && !opt.build_list && opt.cold != 0 &&
                           !MGX_LAB_GET(opt, dense_diag, 0);
   // ... and then the unit blocks WITHOUT the lists' entries (every level that reads unit blocks runs the cold-edge pass: the body
@@ -469,8 +477,10 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   // in-place chain launches (k_bfs_chain_inplace): in front of slot 0, of the slots from tail_from on, behind a batch
   a.chain_big_edges = (a.chain_max_edges && opt.seed_chain) ? (opt.chain_big >= 0 ? (u32)(opt.chain_big > BFS_CHAIN_CAP_BIG ? BFS_CHAIN_CAP_BIG : opt.chain_big) : st.chain_big_edges) : 0u;
   const bool cold = cold_lists && a.dense_div;
-  a.cold_owner = cold ? layout->cold_owner : nullptr;
-  a.cold_dst = cold ? layout->cold_dst : nullptr;
+  // (cold_dst != NULL is what "this run has cold-edge lists" reads as everywhere: a layout without the 8-byte pairs -- every slice
+  //  packed, bfs_cold_body never dereferences them -- hands the packed words' address instead)
+  a.cold_owner = cold ? (layout->cold_pairs8 ? layout->cold_owner : (const int*)layout->cold_pk) : nullptr;
+  a.cold_dst = cold ? (layout->cold_pairs8 ? layout->cold_dst : (const int*)layout->cold_pk) : nullptr;
   a.cold_slices = cold ? layout->cold_slices : 0;
   const bool cold_pk = cold && layout->cold_pk && layout->cold_cbase && opt.cold_pack;
   a.cold_pk = cold_pk ? layout->cold_pk : nullptr; a.cold_cbase = cold_pk ? layout->cold_cbase : nullptr;
@@ -508,11 +518,18 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   return plan;
 }
 
-inline int bfs_classify_source(const bfs_fused_state_t& st, const bfs_launch_plan_t& plan, const bfs_layout_t* layout, int src) {
+// does a run on this handle look at the sources' shapes at all?  (the callers resolve them only then: a launch and a wait per batch of
+// sources the cache has not seen)
+inline bool bfs_wants_src_shapes(const bfs_fused_state_t& st, int mode) {
+  return mode == 0 && st.opts.src_plan && st.opts.tail_chain && st.opts.mini != 0 && st.opts.merged && st.opts.seed_chain &&
+         (st.n >= (1 << 22) || st.opts.mini == 2);
+}
+// idx: the source's position in the call's source list (the row of layout->src_shapes that is its)
+inline int bfs_classify_source(const bfs_fused_state_t& st, const bfs_launch_plan_t& plan, const bfs_layout_t* layout, int src, int idx = 0) {
   if (!layout || !layout->src_shapes || !plan.minis || plan.mode != 0 || !st.opts.src_plan || !st.opts.tail_chain) return BFS_SRC_UNKNOWN;
   const bfs_fused_args_t& a = plan.a;
   if (layout->src_shapes_long_min != a.long_min || src < 0 || src >= a.n) return BFS_SRC_UNKNOWN;
-  const unsigned* const sh = layout->src_shapes + (size_t)src * 4;
+  const unsigned* const sh = layout->src_shapes + (size_t)idx * 4;
   const u64 deg = sh[0], e1 = sh[1], s1 = sh[2], l1 = sh[3];
   if (deg == 0 || e1 == 0xFFFFFFFFull) return BFS_SRC_UNKNOWN;
   // both levels run before a quarter of the vertices is reached (the chain's and the M launch's EARLY limits apply)
@@ -829,6 +846,12 @@ inline int bfs_fused_run_many(bfs_fused_state_t& st, const int* row_offsets, con
                               int mode = 0, float alpha = 0.f, const int* in_offsets = nullptr, const int* in_indices = nullptr) {
   if (count <= 0) return 0;
   hipStream_t s = ctx.stream();
+  // a traversal of the batch run on its own (a deep graph, a re-run): its row of the sources' shapes becomes row 0 of that call's
+  auto run_one = [&](int i) {
+    bfs_layout_t one;
+    if (layout) { one = *layout; if (one.src_shapes) one.src_shapes += (size_t)i * 4; }
+    bfs_fused_run(st, row_offsets, col_indices, labels, srcs[i], ctx, layout ? &one : nullptr, mode, alpha, in_offsets, in_indices);
+  };
   const bfs_launch_plan_t plan = bfs_fused_plan(st, row_offsets, col_indices, labels, ctx, layout, mode, alpha, in_offsets, in_indices);
   const bfs_fused_args_t& a = plan.a;
   constexpr int head_words = (int)(bfs_head_bytes() / 4);
@@ -848,7 +871,7 @@ inline int bfs_fused_run_many(bfs_fused_state_t& st, const int* row_offsets, con
     // traversal would run out of slots and be run again on its own.  One call per source then, each with its own batches of
     // slots (round 5: grid2d-22, 79.9 -> 61.7 ms per traversal); the heads are what those calls leave.
     for (int i = 0; i < count; ++i) {
-      bfs_fused_run(st, row_offsets, col_indices, labels, srcs[i], ctx, layout, mode, alpha, in_offsets, in_indices);
+      run_one(i);
       memcpy(bfs_many_head(heads, i), st.host_ctrl, bfs_head_bytes());
     }
     return 0;
@@ -865,7 +888,7 @@ inline int bfs_fused_run_many(bfs_fused_state_t& st, const int* row_offsets, con
   for (int i = 0; i < count; ++i) {
     // (the head of the control block as the previous traversal left it goes to the host before the init kernel resets it)
     // (per source: which of the launches in front of the device-wide slots will find work, and how many slots its class needs)
-    const int cls = bfs_classify_source(st, plan, layout, srcs[i]);
+    const int cls = bfs_classify_source(st, plan, layout, srcs[i], i);
     int my_slots = cls == BFS_SRC_UNKNOWN ? nslots : bfs_class_slots(st, cls) + st.opts.many_spare + st.auto_spare;
     if (my_slots > 30) my_slots = 30;
     if (my_slots < 1) my_slots = 1;
@@ -901,12 +924,12 @@ inline int bfs_fused_run_many(bfs_fused_state_t& st, const int* row_offsets, con
       if ((next >> BFS_VSHIFT) == 0) { h->done = 1; h->levels = h->slot_level[last_slot & 3]; }
     }
     if (h->done) { bfs_learn_slots(st, a, h, mode, 64, plan.minis, classes[(size_t)i]); continue; }
-    bfs_fused_run(st, row_offsets, col_indices, labels, srcs[i], ctx, layout, mode, alpha, in_offsets, in_indices);
+    run_one(i);
     memcpy(h, st.host_ctrl, bfs_head_bytes());
     ++reruns;
     if (i != count - 1) redo_last = true;
   }
-  if (redo_last) bfs_fused_run(st, row_offsets, col_indices, labels, srcs[count - 1], ctx, layout, mode, alpha, in_offsets, in_indices);
+  if (redo_last) run_one(count - 1);
   st.slots_used = last_slots[(size_t)count - 1];
   if (getenv("MGX_BFS_PLAN_VERBOSE")) {
     int cc[3] = {0, 0, 0};

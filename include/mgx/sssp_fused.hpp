@@ -269,7 +269,9 @@ typedef unsigned int sssp_u32x2 __attribute__((ext_vector_type(2)));
 // PACKED: the entries as 24-bit ids (12 bytes per lane and load) and the weights as halves (8 bytes) -- a.ub_col24 / a.ub_w16.
 // A unit's padding entries are -1 (no candidate: sssp_gather_index), a padding unit belongs to vertex n: nothing has to say
 // how many entries of a unit are real.
-template <int NT, bool LIVE, bool PACKED>
+// PIDS / PW separately (round 6): a layout that carries the 24-bit copy has dropped the 32-bit entries, whatever the weights are -- real
+// weights then ride as floats beside 24-bit ids (7 bytes per entry).
+template <int NT, bool LIVE, bool PIDS, bool PW>
 __device__ __forceinline__ void sssp_dense_long(const sssp_args_t& a, void* table, u32 hot_n, u32 block, u32 nblocks) {
   constexpr int NW = NT / WAVE;
   const int lane = lane_id();
@@ -286,8 +288,8 @@ __device__ __forceinline__ void sssp_dense_long(const sssp_args_t& a, void* tabl
   const u32* __restrict__ fbits = a.frontier_bits;
   u32* dist = a.dist;
   unsigned char* mark = a.mark;
-  typedef typename std::conditional<PACKED, sssp_u32x3, sssp_u32x4>::type craw_t;
-  typedef typename std::conditional<PACKED, sssp_u32x2, sssp_f32x4>::type wraw_t;
+  typedef typename std::conditional<PIDS, sssp_u32x3, sssp_u32x4>::type craw_t;
+  typedef typename std::conditional<PW, sssp_u32x2, sssp_f32x4>::type wraw_t;
   // GATED (round 6): a unit whose row is not in the frontier is never streamed.  The sweep used to read every long-row entry and
   // weight -- 5 bytes packed, 610 MB of unit blocks on RMAT-22 -- and mask the inactive ones afterwards: 456 MB per dispatch (PMC)
   // whatever the frontier held.  Now, as the BFS's unit-block body does it (bfs_fused_dense.hpp), the owners run ahead of the stream:
@@ -322,13 +324,10 @@ __device__ __forceinline__ void sssp_dense_long(const sssp_args_t& a, void* tabl
       act[j] = own[j] < (u32)a.n && ((fw[j] >> (own[j] & 31u)) & 1u);
       const u32 u = hh * 8u + 4u * (u32)j + q;
       const size_t e = act[j] ? ((size_t)u << 6) + sub * 4u : (size_t)dummy;
-      if constexpr (PACKED) {
-        c[j] = __builtin_nontemporal_load((const sssp_u32x3*)(ucol24 + (e >> 2) * 3u));
-        wt[j] = __builtin_nontemporal_load((const sssp_u32x2*)(uw16 + e));
-      } else {
-        c[j] = __builtin_nontemporal_load((const sssp_u32x4*)(ucol + e));
-        wt[j] = __builtin_nontemporal_load((const sssp_f32x4*)(uw + e));
-      }
+      if constexpr (PIDS) c[j] = __builtin_nontemporal_load((const sssp_u32x3*)(ucol24 + (e >> 2) * 3u));
+      else c[j] = __builtin_nontemporal_load((const sssp_u32x4*)(ucol + e));
+      if constexpr (PW) wt[j] = __builtin_nontemporal_load((const sssp_u32x2*)(uw16 + e));
+      else wt[j] = __builtin_nontemporal_load((const sssp_f32x4*)(uw + e));
       du[j] = dist[act[j] ? own[j] : 0u];
     }
   };
@@ -348,15 +347,18 @@ __device__ __forceinline__ void sssp_dense_long(const sssp_args_t& a, void* tabl
         const float base = __uint_as_float(duC[j]);
         u32 e4[4];
         float w4[4];
-        if constexpr (PACKED) {
+        if constexpr (PIDS) {
           e4[0] = (u32)__builtin_amdgcn_sbfe((int)cC[j].x, 0, 24);
           e4[1] = (u32)__builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(cC[j].y, cC[j].x, 24), 0, 24);
           e4[2] = (u32)__builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(cC[j].z, cC[j].y, 16), 0, 24);
           e4[3] = (u32)((int)cC[j].z >> 8);
+        } else {
+          e4[0] = cC[j].x; e4[1] = cC[j].y; e4[2] = cC[j].z; e4[3] = cC[j].w;
+        }
+        if constexpr (PW) {
           w4[0] = __half2float(__ushort_as_half((unsigned short)(wC[j].x & 0xFFFFu))); w4[1] = __half2float(__ushort_as_half((unsigned short)(wC[j].x >> 16)));
           w4[2] = __half2float(__ushort_as_half((unsigned short)(wC[j].y & 0xFFFFu))); w4[3] = __half2float(__ushort_as_half((unsigned short)(wC[j].y >> 16)));
         } else {
-          e4[0] = cC[j].x; e4[1] = cC[j].y; e4[2] = cC[j].z; e4[3] = cC[j].w;
           w4[0] = wC[j].x; w4[1] = wC[j].y; w4[2] = wC[j].z; w4[3] = wC[j].w;
         }
         u32 dd[4], nd[4];
@@ -607,8 +609,9 @@ __global__ __launch_bounds__(NT, 4) void k_sssp_relax_dense(sssp_args_t a, int i
   } else {
     hot_n = sssp_load_bounds<NT, SSSP_HOTN_DENSE>(a.dist, a.n, s_hot_dense);
   }
-  if (a.ub_col24 && a.ub_w16) sssp_dense_long<NT, LIVE, true>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);      // (grid-uniform)
-  else sssp_dense_long<NT, LIVE, false>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);
+  if (a.ub_col24 && a.ub_w16) sssp_dense_long<NT, LIVE, true, true>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);      // (grid-uniform)
+  else if (a.ub_col24) sssp_dense_long<NT, LIVE, true, false>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);
+  else sssp_dense_long<NT, LIVE, false, false>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);
   sssp_dense_short<NT, LIVE>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);
 }
 
@@ -1091,7 +1094,7 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
 #ifdef MGX_LAB       // (32-bit minima the workgroup keeps current instead of 16-bit bounds: measured 2.56 against 1.88 ms per RMAT-22 source)
   if (const char* e = getenv("MGX_SSSP_LIVE")) live = atoi(e) != 0;
 #endif
-  const bool dense = layout && layout->ub_w && layout->ub_col && layout->ub_cnt && layout->ub_owner && layout->ub_units_pad >= 16 &&
+  const bool dense = layout && layout->ub_w && (layout->ub_col || layout->ub_col24) && layout->ub_cnt && layout->ub_owner && layout->ub_units_pad >= 16 &&
                      layout->vs_v[3] >= layout->vs_v[0] && layout->m_edges > 0 && build2 && ddiv > 0 && a.delta == 0.f;
   if (dense && !st.frontier_bits.size()) st.frontier_bits = mem_t<u32>(((size_t)st.n + 31) / 32 + 4, ctx);
   a.ub_col = dense ? layout->ub_col : nullptr;
@@ -1099,10 +1102,11 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   a.ub_cnt = dense ? layout->ub_cnt : nullptr;
   a.ub_owner = dense ? layout->ub_owner : nullptr;
   {
-    bool pack = dense && layout->ub_col24 && layout->ub_w16;
-    if (const char* e = getenv("MGX_SSSP_PACK")) pack = pack && atoi(e) != 0;
+    // 24-bit ids whenever the layout has them (it has then dropped the 32-bit ones); half weights with them when every weight is
+    // exact that way.  (MGX_SSSP_PACK, the round-4 A/B switch, is gone: 1.864 -> 1.790 ms per source, HISTORY.md 3.2b.)
+    const bool pack = dense && layout->ub_col24;
     a.ub_col24 = pack ? layout->ub_col24 : nullptr;
-    a.ub_w16 = pack ? layout->ub_w16 : nullptr;
+    a.ub_w16 = (pack && layout->ub_w16) ? layout->ub_w16 : nullptr;
   }
   a.ub_units_pad = dense ? layout->ub_units_pad : 0u;
   for (int i = 0; i < 4; ++i) a.vs_v[i] = dense ? layout->vs_v[i] : 0u;

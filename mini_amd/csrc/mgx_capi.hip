@@ -469,6 +469,11 @@ static void build_unit_blocks(mgx_graph_s* g) {
     G.d_ub_col24 = mem_t<unsigned>((size_t)quads * 3 + 4, *g->c->ctx);
     hipLaunchKernelGGL(k_pack24, dim3(mgx::grid_for(quads, 256, 16384)), dim3(256), 0, g->c->ctx->stream(), (const int4*)G.d_ub_col.data(), quads,
                        G.d_ub_col24.data());
+    // Round 6 (memory): every reader of the unit blocks takes the 24-bit copy when there is one -- the fused BFS, the neighbour-reduce,
+    // the fused SSSP's sweep (with half or float weights) -- so the 32-bit entries go: 493 MB of RMAT-22's 2.03 GB of layout.
+    // (MGX_BFS_PACK24=0 at layout time keeps them and builds no copy.)
+    g->c->ctx->synchronize();
+    G.d_ub_col = mem_t<int>();
   }
 }
 extern "C" int mgx_cold_build_device(const int* ro, const int* ci, int n, int row0, int rows, int min_deg, unsigned hot_n, unsigned slice_n,
@@ -566,6 +571,13 @@ static void build_cold_lists(mgx_graph_s* g) {
       G.d_cold_pk = mem_t<unsigned>::adopt(pk, (size_t)pairs + 256);
       G.d_cold_cbase = mem_t<unsigned>::adopt(cbase, (size_t)G.cold_cb[used] + 64);
       G.cold_pk_mask = mask;
+      // Round 6 (memory): with EVERY slice packed nobody reads the 8-byte pairs of the long rows again (bfs_cold_body takes the
+      // packed words slice by slice): they go -- 53 MB on RMAT-22.  (MGX_BFS_COLD_PACK=0 at layout time keeps them and packs nothing.)
+      const unsigned long long every = used >= 64 ? ~0ull : ((1ull << used) - 1ull);
+      if ((mask & every) == every) {
+        g->c->ctx->synchronize();
+        G.d_cold_owner = mem_t<int>(); G.d_cold_dst = mem_t<int>();
+      }
     }
   }
   G.cold_pairs = pairs; G.colds_pairs = pairs_s; G.cold_slices = used; G.cold_hot_n = hot_n; G.cold_long_min = G.vs_long_min;
@@ -604,49 +616,6 @@ static void build_cold_lists(mgx_graph_s* g) {
       if (ucol2) (void)hipFree(ucol2);
     }
   }
-}
-// graph_device_t::src_shapes: per vertex (original ids) its degree and the shape of the level behind it as a traversal from
-// that vertex would meet it -- one wave per vertex, lanes over the row; a neighbour counts once (rows are sorted: a duplicate
-// sits next to its twin), the vertex itself and neighbours without entries do not
-namespace {
-__global__ __launch_bounds__(256) void k_src_shapes(const int* __restrict__ ro, const int* __restrict__ ci, int n, int long_min,
-                                                    uint4* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
-  for (long long v = wave0; v < n; v += nwaves) {
-    const int r0 = ro[v], r1 = ro[v + 1];
-    unsigned long long edges = 0;
-    unsigned rs = 0, rl = 0;
-    for (int e = r0 + lane; e < r1; e += 64) {
-      const int u = ci[e];
-      if (u == (int)v || (e > r0 && ci[e - 1] == u)) continue;
-      const unsigned d = (unsigned)(ro[u + 1] - ro[u]);
-      if (d == 0u) continue;
-      edges += d;
-      if (long_min > 0 && d >= (unsigned)long_min) ++rl; else ++rs;
-    }
-    edges = mgx::wave_sum(edges);
-    rs = mgx::wave_sum(rs);
-    rl = mgx::wave_sum(rl);
-    if (lane == 0) out[v] = make_uint4((unsigned)(r1 - r0), edges > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)edges, rs, rl);
-  }
-}
-}  // namespace
-static void build_src_shapes(mgx_graph_t g, int long_min) {
-  graph_device_t& G = *g->g;
-  standard_context_t& ctx = *g->c->ctx;
-  G.src_shapes.clear();
-  G.src_shapes_long_min = 0;
-  if (getenv("MGX_BFS_SRC_SHAPES") && atoi(getenv("MGX_BFS_SRC_SHAPES")) == 0) return;
-  const size_t n = (size_t)G.num_nodes;
-  if (n == 0 || G.num_edges <= 0) return;
-  mem_t<unsigned> d((n + 1) * 4, ctx);
-  hipLaunchKernelGGL(k_src_shapes, dim3(mgx::grid_for((long long)n * 64, 256, 16384)), dim3(256), 0, ctx.stream(), G.d_row_offsets.data(),
-                     G.d_col_indices.data(), (int)n, long_min, (uint4*)d.data());
-  G.src_shapes.resize(n * 4);
-  MGX_HIP(mgx::dtoh(G.src_shapes.data(), d.data(), n * 4));
-  G.src_shapes_long_min = long_min;
 }
 int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
   MGX_TRY
@@ -710,11 +679,9 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
     }
   }
 build_cold_lists(g);
-  {
-    int long_min = mgx::LONG_MIN_DEFAULT;
-    if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
-    build_src_shapes(g, long_min);
-  }
+  // (the sources' shapes -- mgx/src_shapes.hpp -- are resolved per call since round 6; what the cache held belongs to the old layout's threshold)
+  G.src_shape_cache.clear();
+  G.src_shapes_enabled = !(getenv("MGX_BFS_SRC_SHAPES") && atoi(getenv("MGX_BFS_SRC_SHAPES")) == 0);
   MGX_CATCH
 }
 extern "C" int mgx_csc_build_device(const int* ro, const int* ci, const float* w, int n, long long m, int* co, int* ri, float* rv,
@@ -767,7 +734,7 @@ int mgx_graph_layout_info(mgx_graph_t g, int64_t* out8) {
   out8[7] = bytes(G.d_layout_row_offsets) + bytes(G.d_layout_col_indices) + bytes(G.d_layout_col_values) + bytes(G.d_new_of_old) + bytes(G.d_old_of_new) +
             bytes(G.d_ub_col) + bytes(G.d_ub_col24) + bytes(G.d_ub_owner) + bytes(G.d_ubh_col24) + bytes(G.d_ubh_owner) + bytes(G.d_ub_w) + bytes(G.d_ub_w16) +
             bytes(G.d_ub_cnt) + bytes(G.d_ub_first) + bytes(G.d_ss_tab) + bytes(G.d_cold_owner) + bytes(G.d_cold_dst) + bytes(G.d_cold_pk) + bytes(G.d_cold_cbase) +
-            bytes(G.d_colds_owner) + bytes(G.d_colds_dst) + bytes(G.d_nrs_mu) + bytes(G.d_nrs_off);
+            bytes(G.d_colds_owner) + bytes(G.d_colds_dst) + bytes(G.d_nrs_mu) + bytes(G.d_nrs_off) + bytes(G.d_nr_pos);
   MGX_CATCH
 }
 int mgx_graph_nr_slices_info(mgx_graph_t g, int64_t* out5) {
@@ -2206,8 +2173,9 @@ int mgx_sssp_run_delta(mgx_sssp_t p, int src, float delta, int64_t* stats) {
     layout.old_of_new = G.d_old_of_new.data();
     ensure_unit_weights(p->g);
     if (G.d_ub_w.size()) {
-      layout.ub_col = G.d_ub_col.data(); layout.ub_w = G.d_ub_w.data(); layout.ub_cnt = G.d_ub_cnt.data(); layout.ub_owner = G.d_ub_owner.data();
-      if (G.d_ub_col24.size() && G.d_ub_w16.size()) { layout.ub_col24 = G.d_ub_col24.data(); layout.ub_w16 = G.d_ub_w16.data(); }
+      layout.ub_col = G.d_ub_col.size() ? G.d_ub_col.data() : nullptr; layout.ub_w = G.d_ub_w.data(); layout.ub_cnt = G.d_ub_cnt.data(); layout.ub_owner = G.d_ub_owner.data();
+      if (G.d_ub_col24.size()) layout.ub_col24 = G.d_ub_col24.data();
+      if (G.d_ub_col24.size() && G.d_ub_w16.size()) layout.ub_w16 = G.d_ub_w16.data();
       layout.ub_units_pad = (unsigned)G.ub_units_pad;
       for (int i = 0; i < 4; ++i) layout.vs_v[i] = G.vs_v[i];
       layout.m_edges = (long long)G.num_edges;
