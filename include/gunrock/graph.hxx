@@ -101,7 +101,7 @@ struct graph_device_t {
   // what a traversal from a source starts with (mgx/src_shapes.hpp): computed for the sources that are asked for and remembered --
   // round 6; until then 16 bytes per VERTEX of host memory, filled by a kernel that read 9.8 GB on RMAT-22 when the layout was built
   mgx::src_shape_cache_t src_shape_cache;
-  bool src_shapes_enabled = true;    // (MGX_BFS_SRC_SHAPES=0 when the layout is built: every traversal gets the graph-wide launch sequence)
+  bool src_shapes_enabled = true;    // (false: every traversal gets the graph-wide launch sequence; MGX_BFS_SRC_PLAN=0 is the run-time switch)
   unsigned nr_big_rows = 0;          // layout rows [0, nr_big_rows) hold more than mgx::NR_BIG_UNITS units (degree-sorted layouts)
   // The long rows by slice of their destinations for the full-frontier neighbour-reduce (mgx/nreduce.hpp: k_nrs_edges; built by the
   // library at the graph's first such reduce, mgx_layout.hip: mgx_nrs_build_device): 16-byte mini-units (4 words each), where a

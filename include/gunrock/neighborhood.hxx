@@ -71,10 +71,7 @@ int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fronti
       L.col_indices = graph.d_layout_col_indices.data();
       L.old_of_new = graph.d_old_of_new.data();
       L.ub_col = graph.d_ub_col.size() ? graph.d_ub_col.data() : nullptr;      // (round 6: gone when the layout carries the 24-bit copy)
-      {
-        static const bool pack = [] { const char* e = std::getenv("MGX_NR_PACK24"); return !e || std::atoi(e) != 0; }();
-        L.ub_col24 = ((pack || !L.ub_col) && graph.d_ub_col24.size()) ? graph.d_ub_col24.data() : nullptr;
-      }
+      L.ub_col24 = graph.d_ub_col24.size() ? graph.d_ub_col24.data() : nullptr;     // (the 24-bit copy whenever the layout has one: 0.492 -> 0.477 ms in round 4)
       L.ub_cnt = graph.d_ub_cnt.data();
       L.ub_first = graph.d_ub_first.data();
       L.ub_units = (mgx::u32)graph.ub_units; L.ub_units_pad = (mgx::u32)graph.ub_units_pad;

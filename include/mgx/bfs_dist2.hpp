@@ -523,7 +523,7 @@ struct d2_state_t {
   int fused_merge = 1;                // OR-merge inside the queue build (MGX_DIST_FUSED_MERGE)
   int build_list = 0;                 // the list-based queue build (MGX_DIST_BUILD_LIST)
   int push_split = 0;                 // measurements: the push grid's three parts as three launches (MGX_DIST_PUSH_SPLIT)
-  u32 grid_div = 1;                   // the push grid's long-row and short-row halves get 2 x CUs / grid_div workgroups each (MGX_DIST_GRID_DIV)
+  u32 grid_div = 1;                   // the push grid's long-row and short-row halves get 2 x CUs / grid_div workgroups each (set by the shard builder: a small shard takes fewer, fatter workgroups)
   bool skip_small_reduce = false;     // d2_run's plan: no k_d2_cold_reduce launch on the levels it expects to be merged from id lists
   mem_t<u32> defer_buf;               // deferred hot marks of the push workgroups (bfs_hot_epilogue): BFS_FLUSH_MAX bitmaps; empty: nothing is deferred (MGX_DIST_DEFER=0)
   // ... and only on a shard big enough to pay for the 80 KB bitmap every deferring workgroup writes and the reduce behind it:
@@ -566,7 +566,6 @@ struct d2_state_t {
     if (const char* e = getenv("MGX_DIST_FUSED_MERGE")) fused_merge = atoi(e);
     if (const char* e = getenv("MGX_DIST_BUILD_LIST")) build_list = atoi(e);
     if (const char* e = getenv("MGX_DIST_PUSH_SPLIT")) push_split = atoi(e);
-    if (const char* e = getenv("MGX_DIST_GRID_DIV")) grid_div = (u32)atoi(e);
     {
       int defer = 1;
       if (const char* e = getenv("MGX_DIST_DEFER")) defer = atoi(e);

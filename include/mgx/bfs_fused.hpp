@@ -1127,11 +1127,11 @@ struct bfs_run_opts_t {
                            // 0.3712 / 0.3708 ms in round 4)
   int lazy = -1;           // MGX_BFS_LAZY: 0 the queue build always writes the queues, N: not behind a push that stored >= n / N marks
   long long defer = -1;    // MGX_BFS_DEFER: 0 never defer hot marks, N: flush a bitmap above N deferred marks per workgroup
-  int spin = -1;           // MGX_BFS_SPIN: 0 read the control block back with a copy + hipStreamSynchronize, 1 publish kernel + spin
+  int spin = -1;           // (no switch since round 6) 0 read the control block back with a copy + hipStreamSynchronize, 1 publish kernel + spin, -1 the handle's default
   int build_list = 0;      // MGX_BFS_BUILD_LIST=1: the list-based queue build (k_bfs_build) instead of k_bfs_build2
   int mini = 1;            // MGX_BFS_MINI=0: no M launches (mid-size levels take device-wide slots; bfs_fused_mini.hpp); 1: on graphs of at
                            // least 2^22 vertices; 2: always
-  int many_spare = 0;      // MGX_BFS_MANY_SPARE: launch slots a traversal of a batch (mgx_bfs_run_many) gets beyond what the last
+  int many_spare = 0;      // (no switch since round 6: re-runs teach the handle, auto_spare) launch slots a traversal of a batch (mgx_bfs_run_many) gets beyond what the last
                            // traversals of the graph needed (the most any of the last four needed: one that still does not finish is run
                            // again on its own, and the chain behind a traversal's last slot takes stragglers of up to BFS_CHAIN_CAP_BIG edges)
 #ifdef MGX_LAB
@@ -1151,7 +1151,6 @@ struct bfs_run_opts_t {
     geti("MGX_BFS_VSHORT", o.vshort);
     getll("MGX_BFS_CHAIN_MAX_EDGES", o.chain);
     geti("MGX_BFS_BUILD_LIST", o.build_list);
-    geti("MGX_BFS_SPIN", o.spin);
     getll("MGX_BFS_DEFER", o.defer);
     geti("MGX_BFS_DEFER_WORDS", o.defer_words);
     geti("MGX_BFS_SRC_PLAN", o.src_plan);
@@ -1172,7 +1171,6 @@ struct bfs_run_opts_t {
     geti("MGX_BFS_TAIL_FRONT", o.tail_front);
     geti("MGX_BFS_CHAIN_BIG_EDGES", o.chain_big);
     geti("MGX_BFS_MINI", o.mini);
-    geti("MGX_BFS_MANY_SPARE", o.many_spare);
     if (o.many_spare < 0) o.many_spare = 0;
     geti("MGX_BFS_LAZY", o.lazy);
     if (o.lazy > (1 << 20)) o.lazy = 1 << 20;     // (edges < 2^38: no overflow)
@@ -1203,7 +1201,7 @@ struct bfs_fused_state_t {
   bfs_ctrl_t* host_ctrl = nullptr;   // pinned copy for stats
   u64* host_seq = nullptr;           // pinned: the batch number k_bfs_publish stores when the copy above is complete
   u64 seq = 0;
-  bool spin = true;                  // wait for a batch by spinning on host_seq (MGX_BFS_SPIN=0: copy + hipStreamSynchronize)
+  bool spin = true;                  // wait for a batch by spinning on host_seq (false: copy + hipStreamSynchronize)
   int n = 0;
   int levels_per_sync = 2;           // slots (bfs_fused_run.hpp) launched between two read-backs of the control block ...
   int slots_hint = 5;                // ... except for the first batch: as many slots as the previous traversal needed
@@ -1229,7 +1227,7 @@ struct bfs_fused_state_t {
   unsigned dense_div = 2;            // long rows are read from the unit blocks when the frontier holds at least
                                      // 1 / dense_div of the units (bfs_fused_dense.hpp; 0: never)
   int long_min = LONG_MIN_DEFAULT;   // rows at least this long go to the long-row queue (0: no such queue)
-  bool count_marks = false;          // see bfs_fused_args_t::count_marks (MGX_BFS_COUNT_MARKS; on with time_kernels)
+  bool count_marks = false;          // see bfs_fused_args_t::count_marks (mgx_bfs_set_kernel_timing switches it on)
   int time_kernels = 0;              // 1: the push parts as separate launches, HIP events around each; 2: events around the
                                      // ONE merged push launch of every slot (the product kernel; -> stream_kernel_ms) (each event
                                      // leaves a ~6 us gap on the stream: profiling runs only)
@@ -1272,11 +1270,7 @@ struct bfs_fused_state_t {
     MGX_HIP(hipEventCreate(&ev1));
     for (int i = 0; i < EV_POOL; ++i) MGX_HIP(hipEventCreate(&wev[i]));
     if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e) > 0 ? atoi(e) : 0;
-    if (const char* e = getenv("MGX_BFS_TIME_KERNELS")) time_kernels = atoi(e);
-    if (const char* e = getenv("MGX_BFS_COUNT_MARKS")) count_marks = atoi(e) != 0;
-    if (const char* e = getenv("MGX_BFS_TIME_BATCHES")) time_batches = atoi(e) != 0;
     if (const char* e = getenv("MGX_BFS_HOT_MIN_EDGES")) hot_min_edges = (unsigned)atoll(e);
-    if (const char* e = getenv("MGX_BFS_LEVELS_PER_SYNC")) levels_per_sync = atoi(e) > 0 ? atoi(e) : 2;
   }
   bfs_fused_state_t(const bfs_fused_state_t&) = delete;
   bfs_fused_state_t& operator=(const bfs_fused_state_t&) = delete;

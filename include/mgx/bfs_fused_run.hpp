@@ -931,12 +931,6 @@ inline int bfs_fused_run_many(bfs_fused_state_t& st, const int* row_offsets, con
   }
   if (redo_last) run_one(count - 1);
   st.slots_used = last_slots[(size_t)count - 1];
-  if (getenv("MGX_BFS_PLAN_VERBOSE")) {
-    int cc[3] = {0, 0, 0};
-    for (int i = 0; i < count; ++i) cc[classes[(size_t)i]]++;
-    fprintf(stderr, "[mgx] batch of %d: classes unknown %d absorb %d skip %d; slots graph %d absorb %d skip %d; reruns %d\n", count, cc[0], cc[1], cc[2],
-            st.slots_hint, bfs_class_slots(st, BFS_SRC_ABSORB), bfs_class_slots(st, BFS_SRC_SKIP), reruns);
-  }
   if (reruns > 0) { if (st.auto_spare < 4) ++st.auto_spare; st.clean_batches = 0; }
   else if (st.auto_spare > 0 && ++st.clean_batches >= 8) { --st.auto_spare; st.clean_batches = 0; }
   return reruns;

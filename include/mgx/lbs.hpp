@@ -160,114 +160,13 @@ inline void transform_lbs(F f, long long count, const int* segments, long long n
 }
 
 // ---- segmented reduce over the same enumeration ----------------------------------------------
-// reduced[seg] = op-fold of f(idx, seg, rank) over the segment's items, identity for empty
-// segments.  Deterministic (fixed association order, no atomics on values):
-//   * a run of <= 32 items inside a tile is folded left to right by the lane holding its first item;
-//   * a longer run is folded by a whole wave (lane l takes items l, l+64, ... left to right, then a
-//     shuffle tree) -- RMAT hub rows span hundreds of tiles, one lane per run would serialise them;
-//   * a segment that spans tiles leaves one partial per tile (carry_val/carry_seg); the fix-up
-//     kernel gives every such segment to the thread of its opening tile, which walks the following
-//     tiles' continuation slots in order.
-template <typename T, typename Op>
-__device__ __forceinline__ T wave_reduce_op(T x, Op op) {
-#pragma unroll
-  for (int d = WAVE / 2; d > 0; d >>= 1) {
-    const T y = __shfl_down(x, d, WAVE);
-    x = op(x, y);          // lanes >= WAVE-d combine with their own value's copy; only lane 0 is used
-  }
-  return x;
-}
-
-template <typename T, typename F, typename Op>
-__global__ __launch_bounds__(BLOCK) void k_lbs_segreduce(F f, long long count, const int* __restrict__ segments,
-                                                          long long num_segments, T* __restrict__ reduced, Op op,
-                                                          T identity, T* __restrict__ carry_val,
-                                                          long long* __restrict__ carry_seg) {
-  constexpr int SHORT_RUN = 32;
-  __shared__ int s_off[LBS_WINDOW];
-  __shared__ long long s_bounds[2];
-  __shared__ T s_val[LBS_TILE];
-  __shared__ int s_seg[LBS_TILE];    // segment index relative to seg_lo
-  __shared__ int s_long[LBS_TILE / SHORT_RUN + 1];
-  __shared__ int s_nlong;
-  const long long tile = blockIdx.x;
-  const long long first = tile * LBS_TILE;
-  const long long last = (first + LBS_TILE < count ? first + LBS_TILE : count) - 1;
-  if (threadIdx.x == 0) s_nlong = 0;
-  lbs_tile_t t = lbs_stage_tile(segments, num_segments, first, last, s_off, s_bounds);
-  const int nitems = (int)(last - first + 1);
-#pragma unroll
-  for (int k = 0; k < LBS_ITEMS; ++k) {
-    const int li = k * BLOCK + threadIdx.x;
-    const long long idx = first + li;
-    if (idx <= last) {
-      long long seg;
-      int start;
-      if (t.nseg) {
-        const int j = upper_bound_small(s_off, t.nseg, (int)idx) - 1;
-        seg = t.seg_lo + j;
-        start = s_off[j];
-      } else {
-        const int* a = segments + t.seg_lo;
-        const int j = upper_bound_small(a, (int)(t.seg_hi - t.seg_lo + 1), (int)idx) - 1;
-        seg = t.seg_lo + j;
-        start = a[j];
-      }
-      s_val[li] = f((int)idx, (int)seg, (int)idx - start);
-      s_seg[li] = (int)(seg - t.seg_lo);
-    }
-  }
-  __syncthreads();
-  // where a finished run goes: straight to reduced[] if the segment lies inside this tile, else a carry
-  auto emit = [&](int li, int e, T acc) {
-    const int sg = s_seg[li];
-    const long long seg = t.seg_lo + sg;
-    const bool opens_here = (li > 0) || (segments[seg] == (int)first);
-    const long long seg_end = (seg + 1 < num_segments) ? (long long)segments[seg + 1] : count;
-    const bool closes_here = (e < nitems) || (seg_end - 1 == last);
-    if (opens_here && closes_here) {
-      reduced[seg] = acc;
-    } else {
-      const int slot = opens_here ? 1 : 0;     // 0: continues a segment begun earlier, 1: left open
-      carry_val[tile * 2 + slot] = acc;
-      carry_seg[tile * 2 + slot] = seg;
-    }
-  };
-  // phase A: run heads fold short runs, register long ones
-  for (int li = threadIdx.x; li < nitems; li += BLOCK) {
-    const int sg = s_seg[li];
-    if (li == 0 || s_seg[li - 1] != sg) {
-      T acc = s_val[li];
-      int e = li + 1;
-      while (e < nitems && e - li <= SHORT_RUN && s_seg[e] == sg) { acc = op(acc, s_val[e]); ++e; }
-      if (e - li > SHORT_RUN) s_long[atomicAdd(&s_nlong, 1)] = li;
-      else emit(li, e, acc);
-    }
-  }
-  __syncthreads();
-  // phase B: one wave per long run
-  const int nlong = s_nlong;
-  const int lane = lane_id();
-  for (int r = threadIdx.x / WAVE; r < nlong; r += WAVES_PER_BLOCK) {
-    const int li = s_long[r];
-    const int sg = s_seg[li];
-    T acc = identity;
-    int e = li;
-    for (;;) {                                   // wave-uniform loop over 64-item strides of the run
-      const int i = e + lane;
-      const bool in = (i < nitems) && (s_seg[i] == sg);
-      if (in) acc = op(acc, s_val[i]);
-      const u64 m = __ballot(in);
-      if (m != ~0ull) { e += __popcll(m); break; }   // runs are contiguous: the mask is a prefix
-      e += WAVE;
-    }
-    acc = wave_reduce_op(acc, op);
-    if (lane == 0) emit(li, e, acc);
-  }
-}
+// reduced[seg] = op-fold of f(idx, seg, rank) over the segment's items, identity for empty segments.  Deterministic (fixed
+// association order, no atomics on values); a segment that spans tiles leaves one partial per tile (carry_val / carry_seg), and the
+// fix-up kernel gives every such segment to the thread of its opening tile, which walks the following tiles' continuation slots
+// in order.
 
 // ---- the same reduce, second generation: wave-level segmented scans instead of LDS-staged serial folds ------------
-// In k_lbs_segreduce one lane folds a run of up to 32 items while its neighbours idle (RMAT rows average 32 items),
+// In the first generation (k_lbs_segreduce: in this file's history until round 6) one lane folds a run of up to 32 items while its neighbours idle (RMAT rows average 32 items),
 // and every value makes a round trip through LDS.  Here a wave holds 64 CONSECUTIVE items of the tile in registers
 // (item = k * BLOCK + thread, so wave w of slab k holds items [64 (4k + w), +64)) and folds them with a segmented
 // inclusive scan over the lanes (6 shuffle steps, earlier items on the left: deterministic).  A run that lies
@@ -416,11 +315,8 @@ inline void lbs_segreduce(F f, long long count, const int* segments, long long n
   long long* carry_seg = (long long*)ctx.scratch;
   T* carry_val = (T*)(carry_seg + tiles * 2);
   MGX_HIP(hipMemsetAsync(carry_seg, 0xFF, (size_t)tiles * 2 * sizeof(long long), st));
-  static const int gen = getenv("MGX_SEGREDUCE_GEN") ? atoi(getenv("MGX_SEGREDUCE_GEN")) : 2;
-  if (gen == 1)
-    hipLaunchKernelGGL((k_lbs_segreduce<T, F, Op>), dim3((unsigned)tiles), dim3(BLOCK), 0, st, f, count, segments,
-                       num_segments, reduced, op, identity, carry_val, carry_seg);
-  else
+  // (the first generation, k_lbs_segreduce -- runs folded serially out of LDS, 1.75 against 1.40 ms on RMAT-22 -- stayed selectable
+  //  through MGX_SEGREDUCE_GEN=1 until round 6)
     hipLaunchKernelGGL((k_lbs_segreduce2<T, F, Op>), dim3((unsigned)tiles), dim3(BLOCK), 0, st, f, count, segments,
                        num_segments, reduced, op, identity, carry_val, carry_seg);
   hipLaunchKernelGGL((k_segreduce_fixup<T, Op>), dim3(grid_for(tiles)), dim3(BLOCK), 0, st, tiles, carry_val, carry_seg,

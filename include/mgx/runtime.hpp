@@ -131,7 +131,7 @@ struct standard_context_t : context_t {
   long long* mailbox = nullptr;
   // mailbox[1]: the sequence number of the last count a kernel delivered (scan.hpp).  The host used to wait for the stream
   // (hipStreamSynchronize: ~10-20 us of runtime wake-up per operator call, two calls per superstep of an enactor) -- now it
-  // spins on this word, which the producing kernel stores at system scope behind the count (MGX_OP_SPIN=0: the old wait)
+  // spins on this word, which the producing kernel stores at system scope behind the count (mailbox_spin = false: the old wait)
   long long mailbox_seq = 0;
   // The scratch arena is shared by every operator of the context; scratch_epoch counts who wrote it.  `keep` is what an advance
   // left there for the filter behind it (gunrock/advance.hxx -> filter.hxx): the keep-ballots of its output slots, valid only for
@@ -178,7 +178,6 @@ struct standard_context_t : context_t {
     if (print_prop) std::printf("%s : %d CUs\n", prop.name, num_cus);
     MGX_HIP(hipHostMalloc((void**)&mailbox, 64 * sizeof(long long), hipHostMallocDefault));
     for (int i = 0; i < 64; ++i) mailbox[i] = 0;
-    if (const char* e = std::getenv("MGX_OP_SPIN")) mailbox_spin = std::atoi(e) != 0;
     reserve_scratch(1 << 20);
   }
   standard_context_t(const standard_context_t&) = delete;

@@ -1025,7 +1025,7 @@ struct sssp_fused_state_t {
   bfs_ctrl_t* host_ctrl = nullptr;
   int n = 0;
   int iters_hint = 12;
-  float delta = 0.f;                 // near / far bucket width (0: off); MGX_SSSP_DELTA overrides
+  float delta = 0.f;                 // near / far bucket width (0: off) (mgx_sssp_run_delta)
   // per-launch timing of k_sssp_relax (measurement runs: mgx_sssp_set_kernel_timing; an event costs ~6 us of stream gap)
   bool time_kernels = false;
   std::vector<hipEvent_t> ev;        // pairs around the relax launches of a batch, made on demand
@@ -1065,7 +1065,6 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   a.ctrl = st.ctrl.data();
   a.n = st.n;
   a.delta = st.delta;
-  if (const char* de = getenv("MGX_SSSP_DELTA")) a.delta = (float)atof(de);
   const char* const bl = getenv("MGX_SSSP_BUILD_LIST");            // (=1: the list-based queue build, k_sssp_build)
   const bool build2 = !(bl && atoi(bl) != 0) && ((uintptr_t)a.row_offsets % 16 == 0);
   // heavy iterations over the destination-sliced edge list (needs the frontier bitmap k_sssp_build2 writes)

@@ -421,7 +421,7 @@ extern "C" int mgx_units_build_device(const int* ro, const int* ci, int n, int m
                                       int** owner, int** ucol, unsigned char** ucnt, int** ufirst, long long* units, long long* units_pad,
                                       hipStream_t stream);
 
-// Unit blocks of the layout's long rows (mgx/bfs_fused_dense.hpp); MGX_BFS_UNITS=0 skips them.  The threshold is the
+// Unit blocks of the layout's long rows (mgx/bfs_fused_dense.hpp).  The threshold is the
 // fused traversal's long-row threshold at build time (MGX_BFS_LONG_MIN, default mgx::LONG_MIN_DEFAULT; a unit is 64 entries whatever the
 // threshold); a run with another threshold ignores the blocks.
 namespace {
@@ -442,7 +442,6 @@ static void build_unit_blocks(mgx_graph_s* g) {
   G.d_ub_col24 = mem_t<unsigned>();
   G.d_ub_cnt = mem_t<unsigned char>(); G.d_ub_first = mem_t<int>(); G.nr_big_rows = 0; G.d_ub_w = mem_t<float>(); G.d_ub_w16 = mem_t<unsigned short>(); G.ub_w_tried = false;
   G.d_nrs_mu = mem_t<unsigned>(); G.d_nrs_off = mem_t<unsigned>(); G.nrs_units = 0; G.nrs_slices = G.nrs_rows = 0; G.nrs_tier[0] = G.nrs_tier[1] = G.nrs_tier[2] = 0; G.nrs_tried = false;
-  if (const char* e = getenv("MGX_BFS_UNITS")) if (atoi(e) == 0) return;
   int long_min = mgx::LONG_MIN_DEFAULT;
   if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
   if (long_min <= 0 || !G.has_layout || G.num_edges <= 0) return;
@@ -544,7 +543,6 @@ static void build_cold_lists(mgx_graph_s* g) {
   const long long all = pairs + pairs_s;
   long long nwg = (all + 131071) / 131072;
   nwg = std::max<long long>(nwg, mgx::BFS_COLD_WGS);
-  if (const char* e = getenv("MGX_BFS_COLD_WGS")) if (atoi(e) > 0) nwg = atoi(e);      // (measurements)
   nwg = std::min<long long>(nwg, mgx::BFS_COLD_WGS_MAX);
   nwg = std::max<long long>(nwg, used);
   unsigned left = (unsigned)nwg - (unsigned)used, acc = 0;
@@ -681,7 +679,7 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
 build_cold_lists(g);
   // (the sources' shapes -- mgx/src_shapes.hpp -- are resolved per call since round 6; what the cache held belongs to the old layout's threshold)
   G.src_shape_cache.clear();
-  G.src_shapes_enabled = !(getenv("MGX_BFS_SRC_SHAPES") && atoi(getenv("MGX_BFS_SRC_SHAPES")) == 0);
+  G.src_shapes_enabled = true;
   MGX_CATCH
 }
 extern "C" int mgx_csc_build_device(const int* ro, const int* ci, const float* w, int n, long long m, int* co, int* ri, float* rv,
@@ -1585,9 +1583,6 @@ int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
       st.cold_owner = cowner; st.cold_dst = cdst;
       int used = 0;
       for (int k = 0; k < slices; ++k) if (off[k + 1] > off[k]) ++used;
-      if (getenv("MGX_DIST_VERBOSE"))
-        fprintf(stderr, "[mgx] rank %d: %lld units, %d long rows, %d slices behind the prefix, %d hold pairs, %lld cold pairs (%.1f %% of the unit entries)\n",
-                st.rank, U, long_rows, slices, used, pairs, 100.0 * (double)pairs / (double)(U * 64));
       if (pairs > 0 && pairs * 2 <= U * 64 && used <= mgx::BFS_COLD_MAX_SLICES) {      // (RMAT-25 / 8: a quarter of the entries, RMAT-26 / 8: a third)
         hipLaunchKernelGGL(mgx::k_d2_owner_global, dim3((unsigned)((pairs + 256 + mgx::BLOCK - 1) / mgx::BLOCK)), dim3(mgx::BLOCK), 0, ctx.stream(), cowner,
                            pairs + 256, st.ranks, st.rank, st.n_local, st.n_global);
@@ -1632,7 +1627,6 @@ int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
             const int rcp = mgx_cold_pack_device(st.cold_owner, st.cold_dst, used, st.cold_off, st.cold_lo, st.ranks, &pk, &cbase, st.cold_cb, &mask, ctx.stream());
             if (rcp != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("partitioned BFS, packed cold-edge lists: ") + hipGetErrorString((hipError_t)rcp));
             st.cold_pk = pk; st.cold_cbase = cbase; st.cold_pk_mask = mask;
-            if (getenv("MGX_DIST_VERBOSE")) fprintf(stderr, "[mgx] rank %d: packed pair lists, slice mask %016llx of %d slices\n", st.rank, mask, used);
           }
         }
         // The unit blocks again, WITHOUT the entries that now live in the pair lists (the unit-block body read them only to skip
@@ -1816,10 +1810,9 @@ int mgx_dbfs2_status(mgx_dbfs2_t h, int next_level, int64_t* out6) {
   MGX_CATCH
 }
 // ---- RCCL communicator of the library's own (mgx/comm.hpp) and the traversal driven from C++ ----
-static bool comm_env_loopback() {
-  const char* e = getenv("MGX_COMM");
-  return e && std::string(e) == "loopback";
-}
+// (MGX_COMM=loopback, an environment route to the in-process stand-in, is gone since round 6: a loopback world is asked for by id,
+//  mgx_comm_loopback_id -- the tests' way)
+static bool comm_env_loopback() { return false; }
 int mgx_comm_unique_id(unsigned char* out128) {
   MGX_TRY
   MGX_REQUIRE(out128, "NULL argument");
