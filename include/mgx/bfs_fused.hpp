@@ -798,6 +798,17 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
   __shared__ u32 s_long_edges;
   __shared__ u32 s_or[NW][WAVE];
   bfs_ctrl_t* const c = a.ctrl;
+  // (round 6) the thread's 16 marks and its half-word of the bitmap are asked for BEFORE the control block is looked at: their
+  // addresses follow from the thread's position alone, so the two round trips -- control block, then marks -- become one.  (A launch
+  // that returns at once has read 18 bytes per thread for nothing; marks and bitmap are padded: always readable.)
+  uint4 pre_m = make_uint4(0u, 0u, 0u, 0u);
+  u32 pre_old16 = 0u;
+  if (!DIST) {
+    const long long j0 = ((((long long)blockIdx.x + (long long)(threadIdx.x % NW) * gridDim.x) * 64 + (threadIdx.x / NW)) * 16);
+    const long long jc = j0 < (long long)n ? j0 : 0;
+    pre_m = *(const uint4*)(a.mark + jc);
+    pre_old16 = ((const unsigned short*)a.visited)[jc >> 4];
+  }
   int slot, level;
   bfs_resolve(c, arg, slot, level);
   if (!DIST && (c->done || c->skip_build[slot & 3])) return;      // (a rank of a partitioned run may be handed work behind an empty frontier of its own)
@@ -954,13 +965,13 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
     }
   } else if (i0 < n) {
     const u32 valid = (n - i0 >= 16) ? 0xFFFFu : ((1u << (int)(n - i0)) - 1u);
-    const uint4 m = *(const uint4*)(a.mark + i0);                            // mark[] is padded: always readable
+    const uint4 m = pre_m;                                                   // (loaded at the kernel's entry)
     const u32 x[4] = {m.x, m.y, m.z, m.w};
     u32 m16 = flushed16;
 #pragma unroll
     for (int q = 0; q < 4; ++q) m16 |= (((x[q] & 0x01010101u) * 0x10204080u) >> 28) << (4 * q);   // 4 marks -> 4 bits
     unsigned short* const vis16 = (unsigned short*)a.visited + (i0 >> 4);
-    const u32 old16 = *vis16;
+    const u32 old16 = pre_old16;
     new16 = m16 & ~old16 & valid;
     if (new16) *vis16 = (unsigned short)(old16 | new16);                     // this thread is the half-word's only writer
     ((unsigned short*)a.frontier_bits)[i0 >> 4] = (unsigned short)new16;     // bottom-up levels, unit blocks
