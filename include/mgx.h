@@ -408,8 +408,9 @@ MGX_API const char* mgx_comm_library(void);
 MGX_API int mgx_comm_available(void); /* 1: RCCL is in the process or could be loaded with every entry point the library needs */
 /* The in-process stand-in for RCCL (include/mgx/comm_loopback.hpp): G host THREADS of one process as G ranks -- any devices, the
  * tests use one GPU, where RCCL itself refuses a second rank -- so that mgx_dbfs2_run / mgx_dsssp_run themselves can be run and
- * checked with 2 .. 64 ranks on a one-GPU box.  mgx_comm_loopback_id makes an id that names it (mgx_comm_unique_id does the same
- * when MGX_COMM=loopback is set); mgx_comm_create on such an id blocks until `ranks` threads have joined (or
+ * checked with 2 .. 64 ranks on a one-GPU box.  Since round 6 it is a library of its own, mini_amd/libmgx_loopback.so (built by
+ * __graft_entry__.build()): libmgx.so only recognises an id that names it and loads the stand-in from next to itself then; without
+ * that file both calls below return MGX_E_INVALID.  mgx_comm_loopback_id makes such an id; mgx_comm_create on it blocks until `ranks` threads have joined (or
  * MGX_LOOPBACK_TIMEOUT_S seconds, default 120, have passed: MGX_E_HIP, as every later call on that communicator).  Collectives
  * are host-synchronous device copies with the group semantics of ncclGroupStart / End.  Test infrastructure for the multi-rank
  * loops: nothing selects it by default.  mgx_comm_info: *is_loopback, and the collective rounds its world has completed. */

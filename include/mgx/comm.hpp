@@ -14,10 +14,20 @@
 #include <mutex>
 #include <string>
 
-#include "comm_loopback.hpp"
 #include "runtime.hpp"
 
 namespace mgx {
+
+// An id whose first eight bytes are this word names a world of the in-process stand-in for RCCL (comm_loopback.hpp: test
+// infrastructure, mini_amd/libmgx_loopback.so) -- not how an RCCL id starts.
+namespace loopback {
+constexpr unsigned long long LOOPBACK_MAGIC = 0x42504F4F4C58474Dull;       // "MGXLOOPB"
+inline bool is_loopback_id(const unsigned char* id128) {
+  unsigned long long magic = 0;
+  __builtin_memcpy(&magic, id128, 8);
+  return magic == LOOPBACK_MAGIC;
+}
+}  // namespace loopback
 
 struct rccl_api_t {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
@@ -63,20 +73,38 @@ struct rccl_api_t {
   }
   // The in-process stand-in (comm_loopback.hpp): the same nine pointers, G host threads for G ranks.  Only a communicator made
   // from a loopback id carries this table (comm_t::api); nothing selects it by default.
+  // (round 6: the stand-in is a library of its own, mini_amd/libmgx_loopback.so -- the product carries none of it.  It is looked for
+  //  next to the library this code is in; a build without it has an empty table here: ok() is false, a loopback id is refused.)
+  unsigned long long (*rounds)(ncclComm_t) = nullptr;     // loopback only: collective rounds the communicator's world has completed
   static const rccl_api_t& loopback() {
     static const rccl_api_t api = [] {
       rccl_api_t a;
-      a.GetUniqueId = loopback::GetUniqueId;
-      a.CommInitRank = loopback::CommInitRank;
-      a.CommDestroy = loopback::CommDestroy;
-      a.AllGather = loopback::AllGather;
-      a.Send = loopback::Send;
-      a.Recv = loopback::Recv;
-      a.GroupStart = loopback::GroupStart;
-      a.GroupEnd = loopback::GroupEnd;
-      a.GetErrorString = loopback::GetErrorString;
-      a.handle = (void*)&loopback::registry_t::get();
-      a.where = "loopback (in-process, include/mgx/comm_loopback.hpp)";
+      Dl_info self;
+      std::string dir;
+      if (dladdr((const void*)&rccl_api_t::loopback, &self) && self.dli_fname) {
+        dir = self.dli_fname;
+        const size_t slash = dir.rfind('/');
+        dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+      }
+      const std::string path = dir + "libmgx_loopback.so";
+      void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (!h) return a;
+      typedef int (*table_fn)(void**, int);
+      table_fn fn = (table_fn)dlsym(h, "mgx_loopback_table");
+      void* t[10] = {};
+      if (!fn || fn(t, 10) < 10) return a;
+      a.GetUniqueId = (decltype(a.GetUniqueId))t[0];
+      a.CommInitRank = (decltype(a.CommInitRank))t[1];
+      a.CommDestroy = (decltype(a.CommDestroy))t[2];
+      a.AllGather = (decltype(a.AllGather))t[3];
+      a.Send = (decltype(a.Send))t[4];
+      a.Recv = (decltype(a.Recv))t[5];
+      a.GroupStart = (decltype(a.GroupStart))t[6];
+      a.GroupEnd = (decltype(a.GroupEnd))t[7];
+      a.GetErrorString = (decltype(a.GetErrorString))t[8];
+      a.rounds = (decltype(a.rounds))t[9];
+      a.handle = h;
+      a.where = "loopback (in-process stand-in: " + path + ")";
       return a;
     }();
     return api;

@@ -39,7 +39,7 @@
 namespace mgx {
 namespace loopback {
 
-constexpr unsigned long long LOOPBACK_MAGIC = 0x42504F4F4C58474Dull;       // "MGXLOOPB" as the id's first eight bytes: not how an RCCL id starts
+constexpr unsigned long long LOOPBACK_MAGIC = 0x42504F4F4C58474Dull;       // "MGXLOOPB" as the id's first eight bytes: not how an RCCL id starts (comm.hpp -- never in one translation unit with this file -- knows the same word)
 
 enum op_kind_t : int { OP_SEND = 0, OP_RECV = 1, OP_ALLGATHER = 2 };
 struct op_t {

@@ -1812,11 +1812,9 @@ int mgx_dbfs2_status(mgx_dbfs2_t h, int next_level, int64_t* out6) {
 // ---- RCCL communicator of the library's own (mgx/comm.hpp) and the traversal driven from C++ ----
 // (MGX_COMM=loopback, an environment route to the in-process stand-in, is gone since round 6: a loopback world is asked for by id,
 //  mgx_comm_loopback_id -- the tests' way)
-static bool comm_env_loopback() { return false; }
 int mgx_comm_unique_id(unsigned char* out128) {
   MGX_TRY
   MGX_REQUIRE(out128, "NULL argument");
-  if (comm_env_loopback()) return mgx_comm_loopback_id(out128);
   mgx::rccl_api_t& api = mgx::rccl_api_t::get();
   MGX_REQUIRE(api.ok(), "mgx_comm_unique_id: no RCCL in this process and none could be loaded (librccl.so.1)");
   ncclUniqueId id;
@@ -1828,6 +1826,7 @@ int mgx_comm_loopback_id(unsigned char* out128) {
   MGX_TRY
   MGX_REQUIRE(out128, "NULL argument");
   const mgx::rccl_api_t& api = mgx::rccl_api_t::loopback();
+  MGX_REQUIRE(api.ok(), "mgx_comm_loopback_id: the in-process stand-in for RCCL is a test library of its own (mini_amd/libmgx_loopback.so, built by __graft_entry__.build()): not found next to this library");
   ncclUniqueId id;
   MGX_RCCL(api.GetUniqueId(&id));
   memcpy(out128, id.internal, NCCL_UNIQUE_ID_BYTES);
@@ -1836,10 +1835,11 @@ int mgx_comm_loopback_id(unsigned char* out128) {
 int mgx_comm_create(mgx_ctx_t c, int ranks, int rank, const unsigned char* id128, mgx_comm_t* out) {
   MGX_TRY
   MGX_REQUIRE(c && id128 && out && ranks >= 1 && rank >= 0 && rank < ranks, "mgx_comm_create: bad argument");
-  // (a loopback id -- mgx_comm_loopback_id, or mgx_comm_unique_id under MGX_COMM=loopback -- names the in-process stand-in)
+  // (a loopback id -- mgx_comm_loopback_id -- names the in-process stand-in: a test library of its own since round 6)
   const bool loop = mgx::loopback::is_loopback_id(id128);
   const mgx::rccl_api_t& api = loop ? mgx::rccl_api_t::loopback() : mgx::rccl_api_t::get();
-  MGX_REQUIRE(api.ok(), "mgx_comm_create: no RCCL in this process and none could be loaded (librccl.so.1)");
+  MGX_REQUIRE(api.ok(), loop ? "mgx_comm_create: a loopback id, but mini_amd/libmgx_loopback.so (the test double) is not next to this library"
+                             : "mgx_comm_create: no RCCL in this process and none could be loaded (librccl.so.1)");
   use_device(c);
   ncclUniqueId id;
   memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
@@ -1860,7 +1860,7 @@ int mgx_comm_info(mgx_comm_t h, int* is_loopback, int64_t* rounds) {
   MGX_REQUIRE(h, "NULL argument");
   const bool loop = h->cm.api == &mgx::rccl_api_t::loopback();
   if (is_loopback) *is_loopback = loop ? 1 : 0;
-  if (rounds) *rounds = loop ? (int64_t)mgx::loopback::rounds(h->cm.comm) : 0;
+  if (rounds) *rounds = (loop && h->cm.api->rounds) ? (int64_t)h->cm.api->rounds(h->cm.comm) : 0;
   MGX_CATCH
 }
 int mgx_comm_selftest(mgx_comm_t h, const unsigned* d_send, unsigned* d_gathered, unsigned* d_alltoall, int64_t words) {
