@@ -154,7 +154,6 @@ struct bfs_run_stats_t {
   int vshort_slots = 0;              // slots whose short rows were walked vertex by vertex
   int lazy_slots = 0;                // slots that ran without queues (bfs_build_is_lazy)
   int cold_slots = 0;                // slots that ran the cold-edge pass (bfs_fused_cold.hpp)
-  int sliced_slots = 0;              // slots whose long rows were read by slice of their destinations (bfs_fused_sliced.hpp)
   int mini_slots = 0;                // levels expanded by M launches (bfs_fused_mini.hpp)
   long long claims_level[64] = {0};
 };
@@ -212,13 +211,6 @@ struct bfs_fused_enactor_t {
         }
       }
       layout.cold_majority = g.cold_majority;
-      // the long rows by slice of their destinations, when the graph carries them (the C-ABI builds them with the first fused run or
-      // neighbour-reduce; a header-only caller without them simply keeps the queue walk on hub levels)
-      if (g.nrs_units > 0 && g.nrs_slices > 0 && g.nrs_rows == g.vs_v[0] && g.d_nrs_mu.size() && g.d_nrs_off.size() && g.d_nrs_vid_of.size()) {
-        layout.nrs_mu = g.d_nrs_mu.data(); layout.nrs_off = g.d_nrs_off.data(); layout.nrs_vid_of = g.d_nrs_vid_of.data();
-        for (int i = 0; i < mgx::NRS_MAX_SLICES + 2; ++i) layout.nrs_first[i] = g.nrs_first[i];
-        layout.nrs_rows = g.nrs_rows; layout.nrs_slices = g.nrs_slices; layout.nrs_long_min = g.vs_long_min;
-      }
     }
     return layout;
   }
@@ -249,7 +241,6 @@ struct bfs_fused_enactor_t {
     last.vshort_slots = hc->vshort_slots;
     last.lazy_slots = hc->lazy_slots;
     last.cold_slots = hc->cold_slots;
-    last.sliced_slots = hc->sliced_slots;
     last.mini_slots = hc->mini_slots;
     for (int i = 0; i < last.push_levels && i < (int)last.trace.size(); ++i) last.push_edges += last.trace[i].second;
     if (hc->levels > (int)last.trace.size() && !direction_optimizing) last.push_edges = last.m_t;   // (a deep traversal whose trace tail stayed on the device)

@@ -106,8 +106,6 @@ struct graph_device_t {
   // The long rows by slice of their destinations for the full-frontier neighbour-reduce (mgx/nreduce.hpp: k_nrs_edges; built by the
   // library at the graph's first such reduce, mgx_layout.hip: mgx_nrs_build_device): 16-byte mini-units (4 words each), where a
   // row's mini-units of a slice start, the slices' first mini-units.  Empty: not built (the unit blocks serve).
-  bool bfs_slices_tried = false;
-  mem_t<unsigned> d_nrs_vid_of;      // (round 6, fused BFS: bfs_fused_sliced.hpp) layout row start >> 5 -> row, for the rows the slices hold
   mem_t<unsigned> d_nrs_mu;
   mem_t<unsigned> d_nrs_off;
   unsigned nrs_first[18] = {0};      // (mgx::NRS_MAX_SLICES + 2)

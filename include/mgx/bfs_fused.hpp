@@ -104,8 +104,6 @@ struct bfs_ctrl_t {
   int vshort_slots;  // slots whose short rows were walked vertex by vertex (bfs_fused_vshort.hpp)
   int lazy_slot;     // the slot whose queues were NOT written (bfs_build_is_lazy): it must take both queue-less bodies; -1: none
   int lazy_slots;    // how many there were
-  int sliced_slot;   // the slot whose long rows went through bfs_fused_sliced.hpp: its build ORs the slices' bitmaps; -1: none
-  int sliced_slots;  // how many there were
   int cold_slot;     // the slot whose push ran the cold-edge pass (bfs_fused_cold.hpp): its build ORs the cold bitmaps; -1: none
   int cold_slots;    // how many there were
   int mini_slots;    // levels expanded by M launches (bfs_fused_mini.hpp)
@@ -206,16 +204,6 @@ struct bfs_fused_args_t {
   const int* colds_owner = nullptr;
   const int* colds_dst = nullptr;
   u32 colds_off[BFS_COLD_MAX_SLICES + 1] = {};
-  // the long rows by slice of their destinations (bfs_fused_sliced.hpp; the neighbour-reduce's layout, mgx_layout.hip): what a HUB
-  // level reads instead of the queue walk / the unit blocks.  NULL: never
-  const u32* nrs_mu = nullptr;             // 16-byte mini-units, slice-major
-  const u32* nrs_off = nullptr;            // (nrs_slices + 1) * nrs_rows + 1
-  const u32* nrs_vid_of = nullptr;         // row start >> 5 -> row (long rows are >= 32 entries apart)
-  u32 nrs_rows = 0, nrs_slices = 0;
-  unsigned short sl_base[18] = {};         // workgroup j of the long-row part takes slice k iff sl_base[k] <= j < sl_base[k + 1] (k = nrs_slices: the tail)
-  u32* slice_flush = nullptr;              // one bitmap of NR_HOTV / 32 words per workgroup of the long-row part
-  u32 sliced_min_edges = 0;                // a level whose long rows hold fewer edges takes the queue walk
-  u32 sliced_cold_from = 0;                // tail entries from this vertex on are the cold-edge pass's when the slot runs it
 #ifdef MGX_LAB
   // ---- lab build only (-DMGX_LAB, never set by __graft_entry__.build()): shapes that lost their A/B runs and the
   // instrumented kernels of the measurement tools.  The product library carries none of this: MGX_LAB_GET reads a
@@ -307,8 +295,6 @@ __device__ __forceinline__ void bfs_ctrl_reset(bfs_ctrl_t* c) {
   c->lazy_slots = 0;
   c->cold_slot = -1;
   c->cold_slots = 0;
-  c->sliced_slot = -1;
-  c->sliced_slots = 0;
   c->mini_slots = 0;
   for (int i = 0; i < 4; ++i) c->mini_blocks[i] = 0u;
   c->reached_mini = 0;
@@ -881,37 +867,6 @@ __global__ __launch_bounds__(NT, 4) void k_bfs_build2(bfs_fused_args_t a, int ar
     }
   }
 
-  // the same for the bitmaps of a sliced hub level (bfs_fused_sliced.hpp): workgroup j of the long-row part took slice k iff
-  // sl_base[k] <= j < sl_base[k + 1] and left that slice's 39 runs in slice_flush[j]; run r belongs to slice r / 39
-  if (!DIST && a.slice_flush && c->sliced_slot == slot) {              // (grid-uniform)
-    constexpr u32 SLW = 39936u / 32u, SLR = 39936u / 1024u;            // (NR_HOTV: nreduce.hpp; checked where the push body is compiled)
-    for (int hr = 0; hr < NW; ++hr) {
-      const long long run = (long long)blockIdx.x + (long long)hr * gridDim.x;
-      const u32 k = (u32)(run / SLR);
-      if (run >= (long long)a.nrs_slices * SLR) break;                 // (runs ascend with hr)
-      const u32 rel = (u32)(run % SLR), j0 = a.sl_base[k], j1 = a.sl_base[k + 1];
-      const uint4* const base = (const uint4*)(a.slice_flush + (size_t)rel * 32) + (lane & 7);
-      uint4 acc = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll 4
-      for (u32 j = j0 + (u32)wave * 8u + ((u32)lane >> 3); j < j1; j += 8u * NW) {
-        const uint4 v = base[(size_t)j * (SLW / 4)];
-        acc.x |= v.x; acc.y |= v.y; acc.z |= v.z; acc.w |= v.w;
-      }
-#pragma unroll
-      for (int sh = 8; sh < 64; sh <<= 1) {
-        acc.x |= __shfl_xor(acc.x, sh, WAVE); acc.y |= __shfl_xor(acc.y, sh, WAVE);
-        acc.z |= __shfl_xor(acc.z, sh, WAVE); acc.w |= __shfl_xor(acc.w, sh, WAVE);
-      }
-      if (lane < 8) *(uint4*)(&s_or[wave][lane * 4]) = acc;
-      __syncthreads();
-      if (my_run == hr) {
-#pragma unroll
-        for (int w = 0; w < NW; ++w) flushed16 |= (u32)((const unsigned short*)&s_or[w][0])[my_group];
-      }
-      __syncthreads();
-    }
-  }
-
   // the same for the bitmaps of the slot's cold-edge pass (bfs_fused_cold.hpp): cold workgroup k of slice s wrote what it
   // discovered in [cold_lo[s], + BFS_COLD_WORDS * 32) into buffer k.  Wave w takes the workgroup's run w: 16-byte loads,
   // eight lanes per buffer (a run is 128 bytes of bitmap), eight buffers per instruction, everything in flight at once.
@@ -1172,8 +1127,6 @@ struct bfs_run_opts_t {
   int defer_words = -1;               // MGX_BFS_DEFER_WORDS: words of the bitmap prefix whose marks are deferred (default: all BFS_FLUSH_WORDS)
   int defer_mul = 1, defer_div = 1;   // MGX_BFS_DEFER_REACH="mul/div": a level defers its hot marks while reached * mul < range * div
                                       // (RMAT-22, ms per traversal: 4/1 0.3627, 2/1 0.3600, 1/1 0.3521, 2/3 0.3511, 1/3 0.3530, 1/8 0.3625, always 0.3641)
-  int sliced = 1;          // MGX_BFS_SLICED=0: hub levels take the queue walk / the unit blocks (no bfs_fused_sliced.hpp)
-  long long sliced_min_edges = 1 << 20;   // MGX_BFS_SLICED_MIN_EDGES
   int do_chain = 1;        // MGX_BFS_DO_CHAIN=0: direction-optimising runs keep every level device-wide (no chains of small top-down levels)
   int merged_pull = 1;     // MGX_BFS_MERGED_PULL=0: the bottom-up sweep as a launch of its own behind every push launch
   int seed_chain = 1;      // MGX_BFS_SEED_CHAIN=0: no in-place chain launches at all (small levels run inside the slots' push launches)
@@ -1222,10 +1175,6 @@ struct bfs_run_opts_t {
       o.defer_div = sl ? atoi(sl + 1) : 1;
       if (o.defer_div < 1) o.defer_div = 1;
     }
-    geti("MGX_BFS_SLICED", o.sliced);
-    getll("MGX_BFS_SLICED_MIN_EDGES", o.sliced_min_edges);
-    if (o.sliced_min_edges < 0) o.sliced_min_edges = 0;
-    if (o.sliced_min_edges > 0xFFFFFFFFll) o.sliced_min_edges = 0xFFFFFFFFll;
     geti("MGX_BFS_SEED_CHAIN", o.seed_chain);
     geti("MGX_BFS_MERGED_PULL", o.merged_pull);
     geti("MGX_BFS_DO_CHAIN", o.do_chain);
@@ -1286,7 +1235,6 @@ struct bfs_fused_state_t {
   unsigned lazy_div = 4;             // the build behind a push with >= n / lazy_div mark stores writes no queues (bfs_build_is_lazy; 0: never)
   mem_t<u32> slot_marks;             // the counters it looks at (bfs_fused_args_t::slot_marks)
   mem_t<u32> cold_flush;             // cold-edge pass: one bitmap of BFS_COLD_WORDS words per cold workgroup (allocated on demand)
-  mem_t<u32> slice_flush;            // sliced hub levels: one bitmap of NR_HOTV / 32 words per long-row workgroup (allocated on demand)
   unsigned dense_div = 2;            // long rows are read from the unit blocks when the frontier holds at least
                                      // 1 / dense_div of the units (bfs_fused_dense.hpp; 0: never)
   int long_min = LONG_MIN_DEFAULT;   // rows at least this long go to the long-row queue (0: no such queue)

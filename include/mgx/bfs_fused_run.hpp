@@ -23,7 +23,6 @@
 #include "bfs_fused_stream.hpp"
 #include "bfs_fused_vshort.hpp"
 #include "bfs_fused_sparse.hpp"
-#include "bfs_fused_sliced.hpp"
 #include "bfs_fused_wave.hpp"
 
 namespace mgx {
@@ -68,13 +67,6 @@ struct bfs_layout_t {
   unsigned cold_hot_n = 0;
   int cold_long_min = 0;
   bool cold_majority = false;         // more than a quarter of the long rows' entries point behind the LDS prefix (no lists were built): a flat graph
-  // the long rows by slice of their destinations (bfs_fused_sliced.hpp; graph_device_t::d_nrs_*): hub levels read them.  NULL: none
-  const unsigned* nrs_mu = nullptr;
-  const unsigned* nrs_off = nullptr;
-  const unsigned* nrs_vid_of = nullptr;
-  unsigned nrs_first[NRS_MAX_SLICES + 2] = {0};
-  unsigned nrs_rows = 0, nrs_slices = 0;
-  int nrs_long_min = 0;                 // the long-row threshold the rows were cut by (>= 32: a row's start >> 5 names it)
   // HOST table, 4 words per SOURCE OF THE CALL (entry i belongs to the i-th source handed to bfs_fused_run / _run_many; round 6: resolved
   // on demand, mgx/src_shapes.hpp): what a traversal from it starts with
   const unsigned* src_shapes = nullptr;
@@ -105,7 +97,6 @@ static_assert(BFS_COLD_WORDS == BFS_DENSE_HOTW, "a cold slice is as long as the 
 constexpr size_t bfs_push_lds_bytes() {
   size_t m = bfs_stream_lds_bytes(BFS_STREAM_HOTW2);
   if (bfs_wave_lds_bytes(1024, BFS_WAVE_HOTW) > m) m = bfs_wave_lds_bytes(1024, BFS_WAVE_HOTW);
-  if (bfs_sliced_lds_bytes() > m) m = bfs_sliced_lds_bytes();
   if (bfs_dense_lds_bytes(BFS_DENSE_HOTW) > m) m = bfs_dense_lds_bytes(BFS_DENSE_HOTW);
   if (bfs_chain_lds_bytes() > m) m = bfs_chain_lds_bytes();
   if (bfs_vshort_lds_bytes(BFS_DENSE_HOTW) > m) m = bfs_vshort_lds_bytes(BFS_DENSE_HOTW);
@@ -116,7 +107,7 @@ constexpr size_t bfs_push_lds_bytes() {
 // what a slot's push launch does, derived by every workgroup from the same stable inputs
 struct bfs_slot_plan_t {
   int slot, level;
-  bool empty, chained, dense, vshort, cold, colds, pulls, sliced;
+  bool empty, chained, dense, vshort, cold, colds, pulls;
 };
 __device__ __forceinline__ bfs_slot_plan_t bfs_slot_plan(const bfs_fused_args_t& a, int arg) {
   const bfs_ctrl_t* const c = a.ctrl;
@@ -140,8 +131,6 @@ __device__ __forceinline__ bfs_slot_plan_t bfs_slot_plan(const bfs_fused_args_t&
     p.chained = false;
     p.dense = p.vshort = true;
   }
-  // a hub level (it defers its hot marks: few vertices reached yet) reads its long rows by slice of their destinations
-  p.sliced = !p.empty && !p.chained && !pulls && bfs_level_is_sliced(a, c, p.slot, lcur);
   return p;
 }
 
@@ -159,7 +148,6 @@ __device__ __forceinline__ void bfs_slot_open(const bfs_fused_args_t& a, const b
   c->skip_build[p.slot & 3] = 0;
   if (p.dense) c->dense_slots += 1;
   if (p.cold || p.colds) { c->cold_slot = p.slot; c->cold_slots += 1; }
-  if (p.sliced) { c->sliced_slot = p.slot; c->sliced_slots += 1; }
   if (p.vshort) c->vshort_slots += 1;
 }
 
@@ -207,8 +195,7 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
   const bool long_part = PART == 2 || (PART == 0 && blk < nstream);
   if (long_part) {
     const u32 bi = blk;
-    if (!COLDT && p.sliced) bfs_sliced_body<1024>(a, p.slot, bi, nstream, p.level, p.cold);
-    else if (!COLDT && p.dense) bfs_dense_body<1024, BFS_DENSE_HOTW>(a, p.slot, bi, nstream, p.level, p.cold);
+    if (!COLDT && p.dense) bfs_dense_body<1024, BFS_DENSE_HOTW>(a, p.slot, bi, nstream, p.level, p.cold);
     else bfs_stream_body<1024, BFS_STREAM_HOTW2, 8, COLDT, false, true>(a, p.slot, bi, nstream, p.level);
   } else {
     const u32 first = PART == 0 ? nstream : 0u;
@@ -374,7 +361,6 @@ struct bfs_launch_plan_t {
   int* labels = nullptr;
 };
 
-inline bool plan_nstream_ok(const standard_context_t& ctx) { return ctx.num_cus * 2 >= 2 * (NRS_MAX_SLICES + 1) && ctx.num_cus * 2 < 65535; }   // (every slice gets a workgroup; the table holds 16 bits)
 inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_offsets, const int* col_indices, int* labels,
                                         standard_context_t& ctx, const bfs_layout_t* layout, int mode, float alpha,
                                         const int* in_offsets, const int* in_indices) {
@@ -514,46 +500,6 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   a.lazy_pull = (mode == 1 && build2_ok && !opt.build_list && opt.lazy != 0) ? 1 : 0;
   // (direction-optimising runs too: a level behind a lazy build either pulls -- no queue needed -- or takes the queue-less bodies)
   a.lazy_div = (a.dense_div && a.vs_div && build2_ok && !opt.build_list) ? (opt.lazy >= 0 ? (u32)opt.lazy : st.lazy_div) : 0u;
-  // hub levels by slice of the destinations (bfs_fused_sliced.hpp): the layout's sliced long rows, cut by the run's threshold (>= 32:
-  // a row's start >> 5 names it), a queue build that knows the slices' buffers, no cold TEST (the tail marks untested), top-down runs
-  // (mode 0: a direction-optimising run's hub levels are the ones it pulls)
-  const bool sliced = units && opt.sliced && mode == 0 && layout->nrs_mu && layout->nrs_off && layout->nrs_vid_of && layout->nrs_rows > 0 &&
-                      layout->nrs_slices > 0 && layout->nrs_slices <= (unsigned)NRS_MAX_SLICES && layout->nrs_long_min == st.long_min && st.long_min >= 32 &&
-                      build2_ok && !opt.build_list && a.flush_buf != nullptr && opt.merged && !lab_flags && plan_nstream_ok(ctx);
-  a.nrs_mu = sliced ? layout->nrs_mu : nullptr;
-  a.nrs_off = sliced ? layout->nrs_off : nullptr;
-  a.nrs_vid_of = sliced ? layout->nrs_vid_of : nullptr;
-  a.nrs_rows = sliced ? layout->nrs_rows : 0u; a.nrs_slices = sliced ? layout->nrs_slices : 0u;
-  a.sliced_min_edges = (u32)opt.sliced_min_edges;
-  a.sliced_cold_from = (u32)(BFS_DENSE_HOTW * 32);
-  for (int i = 0; i < 18; ++i) a.sl_base[i] = 0;
-  a.slice_flush = nullptr;
-  if (sliced) {
-    // the long-row part's workgroups dealt to the slices in proportion to their mini-units (a mini-unit of the tail -- four 32-bit
-    // ids, a byte store each -- counts twice), at least one each
-    const u32 NS = (u32)ctx.num_cus * 2;
-    const int K1 = (int)layout->nrs_slices + 1;
-    double wsum = 0.0;
-    double wk[NRS_MAX_SLICES + 1];
-    for (int k = 0; k < K1; ++k) {
-      wk[k] = (double)(layout->nrs_first[k + 1] - layout->nrs_first[k]) * (k == K1 - 1 ? 2.0 : 1.0);
-      wsum += wk[k];
-    }
-    u32 left = NS > (u32)K1 ? NS - (u32)K1 : 0u, acc = 0;
-    a.sl_base[0] = 0;
-    for (int k = 0; k < K1; ++k) {
-      u32 extra = wsum > 0.0 ? (u32)((double)(NS - (u32)K1) * wk[k] / wsum) : 0u;
-      if (extra > left) extra = left;
-      left -= extra;
-      acc += 1u + extra;
-      a.sl_base[k + 1] = (unsigned short)acc;
-    }
-    // (what rounding left over goes to the biggest slice: the first)
-    if (left) for (int k = 1; k <= K1; ++k) a.sl_base[k] = (unsigned short)(a.sl_base[k] + left);
-    const size_t words = (size_t)NS * BFS_SL_WORDS;
-    if (st.slice_flush.size() < words) { ctx.synchronize(); st.slice_flush = mem_t<u32>(words, ctx); }
-    a.slice_flush = st.slice_flush.data();
-  }
   plan.coldt = coldt;
   plan.build2_ok = build2_ok;
   // M launches from RMAT-22's size on: what one costs does not depend on the graph, what the device-wide slot it replaces costs

@@ -32,9 +32,7 @@
 
 namespace mgx {
 
-constexpr int NR_HOTV = 39936;            // values of the first NR_HOTV layout vertices in LDS: 159 744 bytes, ONE workgroup per CU (39 runs of 1 024
-                                          // vertices -- 40 000 until round 6: the fused BFS reads the sliced long rows too, bfs_fused_sliced.hpp, and its
-                                          // queue build ORs a slice's bitmaps run by run).
+constexpr int NR_HOTV = 40000;            // values of the first NR_HOTV layout vertices in LDS: 160 000 bytes, ONE workgroup per CU.
                                           // (Measured, RMAT-22: 0.539 ms per reduce against 0.609 with two workgroups of 20 000 values each --
                                           //  unlike the BFS's bit probes, every entry here is a 4-byte gather: what counts is how many of them
                                           //  stay in LDS -- 64 % of the endpoints at 40 000 values against 51 % -- and 128 registers per lane.)

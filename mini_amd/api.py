@@ -389,7 +389,7 @@ class BfsProblem:
                 "dom_vertices": st[13],
                 "dom_kernel": "k_bfs_push (long rows / merged launch)" if st[14] else "k_bfs_push (short rows)",
                 "small_levels": st[15], "slots": st[16], "dense_slots": st[17], "vshort_slots": st[18], "lazy_slots": st[19],
-                "cold_slots": st[20], "mini_slots": st[21], "sliced_slots": st[22]}
+                "cold_slots": st[20], "mini_slots": st[21]}
 
     def run(self, src, mode=_lib.MGX_BFS_PUSH, alpha=0.0):
         """Fused device-resident traversal."""

@@ -205,35 +205,6 @@ static void ensure_nr_slices(mgx_graph_s* g) {
   G.nrs_slices = (unsigned)slices; G.nrs_rows = (unsigned)rows; G.nrs_units = total;
 }
 
-// ... and for the fused BFS's hub levels (mgx/bfs_fused_sliced.hpp), with the table that names a long row by its start: rows of at
-// least 32 entries are at least 32 entries apart in the layout's CSR, so start >> 5 is the row's own
-namespace {
-__global__ void k_nrs_vid_of(const int* __restrict__ ro, int rows, unsigned* __restrict__ vid_of) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < rows) vid_of[(unsigned)ro[r] >> 5] = (unsigned)r;
-}
-}  // namespace
-static void ensure_bfs_slices(mgx_graph_s* g) {
-  graph_device_t& G = *g->g;
-  if (G.d_nrs_vid_of.size() || G.bfs_slices_tried) return;
-  if (const char* e = getenv("MGX_BFS_SLICED")) if (atoi(e) == 0) return;      // (not remembered: a later handle may ask)
-  G.bfs_slices_tried = true;
-  if (!G.has_layout || G.vs_long_min < 32 || (long long)G.num_nodes < 4ll * mgx::NR_HOTV) return;      // (a graph of a few slices: nothing to win)
-  ensure_nr_slices(g);
-  if (!G.d_nrs_mu.size() || G.nrs_rows == 0) return;
-  standard_context_t& ctx = *g->c->ctx;
-  int end = 0;
-  MGX_HIP(mgx::dtoh(&end, G.d_layout_row_offsets.data() + G.nrs_rows, 1));
-  const size_t words = ((size_t)(unsigned)end >> 5) + 2;
-  unsigned* t = nullptr;
-  if (hipMalloc((void**)&t, words * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return; }
-  G.d_nrs_vid_of = mem_t<unsigned>::adopt(t, words);
-  MGX_HIP(hipMemsetAsync(t, 0, words * sizeof(unsigned), ctx.stream()));
-  hipLaunchKernelGGL(k_nrs_vid_of, dim3((G.nrs_rows + 255) / 256), dim3(256), 0, ctx.stream(), G.d_layout_row_offsets.data(), (int)G.nrs_rows, t);
-  MGX_CHECK_LAUNCH("row table of the sliced long rows");
-  ctx.synchronize();
-}
-
 template <typename V, typename Op>
 int segreduce_impl(mgx_graph_t g, mgx_frontier_t in, int push, const V* vals, V identity, V* reduced, int64_t* nz) {
   MGX_TRY
@@ -471,7 +442,6 @@ static void build_unit_blocks(mgx_graph_s* g) {
   G.d_ub_col24 = mem_t<unsigned>();
   G.d_ub_cnt = mem_t<unsigned char>(); G.d_ub_first = mem_t<int>(); G.nr_big_rows = 0; G.d_ub_w = mem_t<float>(); G.d_ub_w16 = mem_t<unsigned short>(); G.ub_w_tried = false;
   G.d_nrs_mu = mem_t<unsigned>(); G.d_nrs_off = mem_t<unsigned>(); G.nrs_units = 0; G.nrs_slices = G.nrs_rows = 0; G.nrs_tier[0] = G.nrs_tier[1] = G.nrs_tier[2] = 0; G.nrs_tried = false;
-  G.d_nrs_vid_of = mem_t<unsigned>(); G.bfs_slices_tried = false;
   int long_min = mgx::LONG_MIN_DEFAULT;
   if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
   if (long_min <= 0 || !G.has_layout || G.num_edges <= 0) return;
@@ -762,7 +732,7 @@ int mgx_graph_layout_info(mgx_graph_t g, int64_t* out8) {
   out8[7] = bytes(G.d_layout_row_offsets) + bytes(G.d_layout_col_indices) + bytes(G.d_layout_col_values) + bytes(G.d_new_of_old) + bytes(G.d_old_of_new) +
             bytes(G.d_ub_col) + bytes(G.d_ub_col24) + bytes(G.d_ub_owner) + bytes(G.d_ubh_col24) + bytes(G.d_ubh_owner) + bytes(G.d_ub_w) + bytes(G.d_ub_w16) +
             bytes(G.d_ub_cnt) + bytes(G.d_ub_first) + bytes(G.d_ss_tab) + bytes(G.d_cold_owner) + bytes(G.d_cold_dst) + bytes(G.d_cold_pk) + bytes(G.d_cold_cbase) +
-            bytes(G.d_colds_owner) + bytes(G.d_colds_dst) + bytes(G.d_nrs_mu) + bytes(G.d_nrs_off) + bytes(G.d_nr_pos) + bytes(G.d_nrs_vid_of);
+            bytes(G.d_colds_owner) + bytes(G.d_colds_dst) + bytes(G.d_nrs_mu) + bytes(G.d_nrs_off) + bytes(G.d_nr_pos);
   MGX_CATCH
 }
 int mgx_graph_nr_slices_info(mgx_graph_t g, int64_t* out5) {
@@ -1232,7 +1202,6 @@ static void fill_bfs_stats(int64_t* out24, const bfs::bfs_run_stats_t& L) {
   out24[19] = L.lazy_slots;
   out24[20] = L.cold_slots;
   out24[21] = L.mini_slots;
-  out24[22] = L.sliced_slots;
 }
 int mgx_bfs_run(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats) { return mgx_bfs_run_stats(p, src, mode, alpha, stats, 16); }
 int mgx_bfs_run_stats(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stats, int cap) {
@@ -1246,7 +1215,6 @@ int mgx_bfs_run_stats(mgx_bfs_t p, int src, int mode, float alpha, int64_t* stat
   if (!p->fe) p->fe.reset(new bfs::bfs_fused_enactor_t(ctx, p->g->g->num_nodes));
   if (p->time_kernels >= 0) p->fe->fused->time_kernels = p->time_kernels;
   p->p->src = src;
-  ensure_bfs_slices(p->g);
   p->fe->enact(p->p, ctx, mode == MGX_BFS_DIRECTION_OPT, alpha);
   fill_bfs_stats(p->last_stats, p->fe->last);
   constexpr int have = (int)(sizeof(p->last_stats) / sizeof(p->last_stats[0]));
@@ -1267,7 +1235,6 @@ int mgx_bfs_run_many(mgx_bfs_t p, const int* sources, int count, int mode, float
   if (!p->fe) p->fe.reset(new bfs::bfs_fused_enactor_t(ctx, p->g->g->num_nodes));
   p->fe->fused->time_kernels = 0;                       // (per-launch events belong to mgx_bfs_run)
   std::vector<bfs::bfs_run_stats_t> all;
-  ensure_bfs_slices(p->g);
   const int rr = p->fe->enact_many(p->p, ctx, sources, count, all, mode == MGX_BFS_DIRECTION_OPT, alpha);
   if (reruns) *reruns = rr;
   constexpr int have = (int)(sizeof(p->last_stats) / sizeof(p->last_stats[0]));

@@ -1128,46 +1128,6 @@ def test_bfs_per_source_launch_plan(gpu_ctx, oracle, monkeypatch):
         assert results[("1", rot)] == results[("0", rot)], rot
 
 
-@pytest.mark.parametrize("slices", [0, 3])
-@pytest.mark.parametrize("scale,ef", [(18, 16), (19, 8)])
-def test_bfs_hub_levels_by_slice_of_the_destinations(gpu_ctx, oracle, monkeypatch, scale, ef, slices):
-    """round 6, mgx/bfs_fused_sliced.hpp: a level that defers its hot marks reads its long rows from the layout's long rows BY SLICE OF
-    THEIR DESTINATIONS -- a workgroup per slice with that slice's 5 KB of bitmap in LDS, the slices' bitmaps ORed by the queue build --
-    instead of the queue walk / the unit blocks with their 80 KB flush buffers.  On a graph below 651 264 vertices EVERY level defers,
-    so with the edge threshold at 0 every device-wide level with long rows goes that way (rows cut between waves and workgroups, rows
-    without entries in a slice, the tail behind the hot slices when MGX_NR_SLICES caps them at 3): labels and counters against the
-    oracle and against the same traversals with the path switched off, one call per source and as a batch."""
-    import mini_amd
-    monkeypatch.setenv("MGX_BFS_SLICED_MIN_EDGES", "0")
-    if slices:
-        monkeypatch.setenv("MGX_NR_SLICES", str(slices))
-    n, ro, ci, w = oracle.rmat_csr(scale, ef, 300 + scale)
-    d = np.diff(ro)
-    order = np.argsort(-d, kind="stable")
-    with_edges = order[d[order] > 0]
-    srcs = [int(with_edges[0]), int(with_edges[len(with_edges) // 2]), int(with_edges[-1]), int(with_edges[7]), int(with_edges[len(with_edges) // 5])]
-    results = {}
-    for on in ("1", "0"):
-        monkeypatch.setenv("MGX_BFS_SLICED", on)
-        g = _graph(gpu_ctx, ro, ci).build_layout()
-        bfs = mini_amd.BfsProblem(g, srcs[0])
-        sliced = 0
-        for rep in range(2):
-            for s_ in srcs:
-                st = bfs.run(s_)
-                want = oracle.bfs_cpu(ro, ci, s_)
-                assert np.array_equal(bfs.labels(), want), (on, rep, s_)
-                assert st["m_t"] == int(d[want >= 0].sum()) and st["levels"] == int(want.max()) + 1, (on, rep, s_, st)
-                sliced += st["sliced_slots"]
-        sts, reruns = bfs.run_many(srcs, mini_amd.MGX_BFS_PUSH, 0.0)
-        assert np.array_equal(bfs.labels(), oracle.bfs_cpu(ro, ci, srcs[-1])), on
-        results[on] = [(x["m_t"], x["reached"], x["levels"]) for x in sts]
-        sliced += sum(x["sliced_slots"] for x in sts)
-        assert (sliced > 0) == (on == "1"), (on, sliced)
-        bfs.close()
-    assert results["1"] == results["0"]
-
-
 @pytest.mark.parametrize("layout", [False, True])
 def test_bfs_mid_size_levels_take_m_launches(gpu_ctx, oracle, layout, monkeypatch):
     """M launches (bfs_fused_mini.hpp: a mid-size level as one launch of 64 workgroups, claims by atomicOr, no sweep):
