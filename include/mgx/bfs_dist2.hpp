@@ -127,7 +127,7 @@ __global__ __launch_bounds__(D2_NEWBITS_NT) void k_d2_newbits(const u32* __restr
                                                               u32* __restrict__ out, long long nwords, long long n, bfs_ctrl_t* c,
                                                               u32* __restrict__ list, u32 list_cap, d2_cold_view_t cv, int level,
                                                               const u32* __restrict__ slot_marks, u32 declare_mul,
-                                                              const u32* __restrict__ defer_buf, u32 defer_words) {
+                                                              const u32* __restrict__ defer_buf, u32 defer_words, int defer_reduced = 1) {
   constexpr int NT = D2_NEWBITS_NT, NW = NT / WAVE;
   __shared__ u32 s_wave[NW];
   __shared__ u32 s_base;
@@ -170,7 +170,15 @@ __global__ __launch_bounds__(D2_NEWBITS_NT) void k_d2_newbits(const u32* __restr
       } else {
         for (int i = 0; i < 32 && w * 32 + i < n; ++i) bits |= (mark[w * 32 + i] ? 1u : 0u) << i;
       }
-      if (with_defer && w < (long long)defer_words) bits |= defer_buf[w];
+      if (with_defer && w < (long long)defer_words) {
+        bits |= defer_buf[w];
+        // (the reduce in front did not run -- a level the plan expected to be sparse, d2_push: the few buffers there are, one by one)
+        if (!defer_reduced) {
+          u32 F = c->flush_count[level & 1];
+          if (F > (u32)BFS_FLUSH_MAX) F = (u32)BFS_FLUSH_MAX;
+          for (u32 k = 1; k < F; ++k) bits |= defer_buf[(size_t)k * BFS_FLUSH_WORDS + w];
+        }
+      }
       if (with_cold) {
         // the slice this word lies in (slices start on multiples of 1024 vertices: a word belongs to one slice)
         const u32 v0 = (u32)(w * 32);
@@ -405,11 +413,6 @@ __global__ __launch_bounds__(NT) void k_d2_lists_apply(bfs_fused_args_t a, int l
   }
 }
 
-// the level plan this rank is about to enqueue, into the header of its id list (words 1 .. 3; one thread, behind d2_reset)
-__global__ void k_d2_plan_tag(u32* list, u32 levels, u64 sparse) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) { list[1] = levels; list[2] = (u32)sparse; list[3] = (u32)(sparse >> 32); }
-}
-
 // end of a freeze (one thread; enqueued by the host in front of the frozen level's bitmap exchange)
 __global__ void k_d2_unfreeze(bfs_ctrl_t* c) {
   if (blockIdx.x == 0 && threadIdx.x == 0) c->d2_frozen_level = -1;
@@ -458,8 +461,12 @@ __global__ __launch_bounds__(BLOCK) void k_d2_clear(d2_fill_t r0, d2_fill_t r1, 
   }
 }
 
-__global__ void k_d2_init(bfs_fused_args_t a, int* labels_local, int src, int ranks, int rank) {
+// list / plan_levels / plan_sparse: the level plan this rank is about to enqueue goes into header words 1 .. 3 of its id list (d2_run's
+// agreement; NULL: no list)
+__global__ void k_d2_init(bfs_fused_args_t a, int* labels_local, int src, int ranks, int rank, u32* list = nullptr, u32 plan_levels = 0,
+                          u64 plan_sparse = 0) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  if (list) { list[1] = plan_levels; list[2] = (u32)plan_sparse; list[3] = (u32)(plan_sparse >> 32); }
   bfs_ctrl_reset(a.ctrl);
   bfs_slot_marks_clear(a, 0);
   bfs_slot_marks_clear(a, 1);
@@ -650,7 +657,7 @@ struct d2_state_t {
 };
 
 // Start of a traversal (asynchronous).
-inline void d2_reset(d2_state_t& st, int src, standard_context_t& ctx) {
+inline void d2_reset(d2_state_t& st, int src, standard_context_t& ctx, u32 plan_levels = 0, u64 plan_sparse = 0) {
   hipStream_t s = ctx.stream();
   // (the new-bit map is all zero between the levels of a traversal that ran to its end; one that was abandoned may have left bits)
   const bool bits = st.mylist && st.sparse_push;
@@ -668,7 +675,7 @@ inline void d2_reset(d2_state_t& st, int src, standard_context_t& ctx) {
     if (head.p) MGX_HIP(hipMemsetAsync(head.p, 0, head.bytes, s));
     if (newbits.p) MGX_HIP(hipMemsetAsync(newbits.p, 0, newbits.bytes, s));
   }
-  hipLaunchKernelGGL(k_d2_init, dim3(1), dim3(64), 0, s, st.args(), st.labels.data(), src, st.ranks, st.rank);
+  hipLaunchKernelGGL(k_d2_init, dim3(1), dim3(64), 0, s, st.args(), st.labels.data(), src, st.ranks, st.rank, st.mylist, plan_levels, plan_sparse);
 }
 
 // level kernels on the local queues (marks), then new_bits = marks & ~bitmap
@@ -688,7 +695,9 @@ inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx, bool wan
   // its frontier is too small for the cold pass to run, and a launch that finds nothing to do still costs ~2.5 us; should the pass
   // have run after all, the sweep ORs the slices' buffers itself, as it did before the reduce existed).  Deferred hot marks need
   // the reduce whatever the level (the sweep reads their first buffer only).
-  const bool planned_small = want_list && st.skip_small_reduce && !dbuf;
+  // (round 6: with deferred hot marks too -- the sweep then ORs the level's flush buffers itself, a handful on a level that is sparse;
+  //  an empty launch is ~4.5 us, five sparse levels per traversal)
+  const bool planned_small = want_list && st.skip_small_reduce;
   if (planned_small) cv.reduced = 0;
   if (((cv.flush && cv.reduced) || dbuf) && !planned_small) {
     d2_cold_view_t rv = cv;
@@ -699,7 +708,7 @@ inline void d2_push(d2_state_t& st, int level, standard_context_t& ctx, bool wan
   }
   hipLaunchKernelGGL(k_d2_newbits, dim3(grid_for(st.nwords, D2_NEWBITS_NT, ctx.num_cus * 2)), dim3(D2_NEWBITS_NT), 0, s, st.fs->visited.data(),
                      st.fs->mark.data(), st.newbits, st.nwords, (long long)st.n_global, a.ctrl, want_list ? st.mylist : (u32*)nullptr, st.list_cap, cv, level,
-                     (const u32*)st.slot_marks.data(), st.declare_mul, (const u32*)dbuf, a.defer_words);
+                     (const u32*)st.slot_marks.data(), st.declare_mul, (const u32*)dbuf, a.defer_words, planned_small ? 0 : 1);
 }
 
 // The sparse merge of a level (k_d2_lists_apply) on `nlists` gathered lists, `stride_words` apart, and the host's wait for
@@ -893,7 +902,11 @@ inline void d2_run(d2_state_t& st, comm_t& cm, d2_run_bufs_t& bufs, int src, int
     ctx.synchronize();
     bufs.glists = mem_t<u32>((size_t)R * (size_t)st.list_words() + 4, ctx);
   }
-  d2_reset(st, src, ctx);
+  // (the level plan: made BEFORE the reset, whose last launch writes it into the header of the rank's id list)
+  int plan_levels = 0;
+  u64 plan_sparse = 0;
+  const bool have_plan = st.mylist && bufs.plan(&plan_levels, &plan_sparse);
+  d2_reset(st, src, ctx, have_plan ? (u32)plan_levels : 0u, have_plan ? plan_sparse : 0ull);
   int level = 0;
   if (st.mylist) {
     // the lists of a level, all-gathered (a one-rank run without a communicator reads its own)
@@ -914,10 +927,6 @@ inline void d2_run(d2_state_t& st, comm_t& cm, d2_run_bufs_t& bufs, int src, int
     // always merged from the lists) runs with a host look on every rank, and its all-gathered list headers carry every rank's
     // plan: only when all are equal (k_d2_lists_apply -> host_flag[3], the same answer everywhere) is the rest enqueued ahead.
     bool over = false;
-    int plan_levels = 0;
-    u64 plan_sparse = 0;
-    const bool have_plan = bufs.plan(&plan_levels, &plan_sparse);
-    hipLaunchKernelGGL(k_d2_plan_tag, dim3(1), dim3(1), 0, s, st.mylist, have_plan ? (u32)plan_levels : 0u, have_plan ? plan_sparse : 0ull);
     bool agreed = false;
     {
       d2_push(st, 0, ctx);
@@ -1023,7 +1032,11 @@ inline void d2_group_run(d2_state_t** sts, d2_run_bufs_t** bufs, d2_group_bufs_t
     gb.glists = mem_t<u32>((size_t)G * (size_t)(lw > 0 ? lw : 4) + 4, ctx);
     gb.xwords = xwords;
   }
-  for (int r = 0; r < G; ++r) d2_reset(*sts[r], src, ctx);
+  for (int r = 0; r < G; ++r) {
+    int pl = 0; u64 ps = 0;
+    const bool hp = lists && bufs[r]->plan(&pl, &ps);
+    d2_reset(*sts[r], src, ctx, hp ? (u32)pl : 0u, hp ? ps : 0ull);
+  }
   auto gather_lists = [&]() {
     for (int r = 0; r < G; ++r)
       MGX_HIP(hipMemcpyAsync(gb.glists.data() + (size_t)r * lw, sts[r]->mylist, (size_t)lw * sizeof(u32), hipMemcpyDeviceToDevice, s));
@@ -1042,12 +1055,7 @@ inline void d2_group_run(d2_state_t** sts, d2_run_bufs_t** bufs, d2_group_bufs_t
     // level 0 with a host look, as d2_run's agreement has it (the engines of a group share one history: the headers agree)
     bool agreed = true;
     {
-      for (int r = 0; r < G; ++r) {
-        bool hp; int pl = 0; u64 ps = 0;
-        hp = bufs[r]->plan(&pl, &ps);
-        hipLaunchKernelGGL(k_d2_plan_tag, dim3(1), dim3(1), 0, s, sts[r]->mylist, hp ? (u32)pl : 0u, hp ? ps : 0ull);
-        d2_push(*sts[r], 0, ctx);
-      }
+      for (int r = 0; r < G; ++r) d2_push(*sts[r], 0, ctx);
       gather_lists();
       long long o3[3] = {0, 0, 0};
       for (int r = 0; r < G; ++r) { d2_apply_lists(*sts[r], 0, gb.glists.data(), G, lw, ctx, o3); agreed = agreed && o3[2] != 0; }
