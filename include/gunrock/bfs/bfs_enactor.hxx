@@ -211,6 +211,8 @@ struct bfs_fused_enactor_t {
         }
       }
       layout.cold_majority = g.cold_majority;
+      layout.cold_all = g.cold_all;
+      layout.cold_pairs_total = g.cold_all ? (unsigned long long)g.cold_pairs : 0ull;
     }
     return layout;
   }
@@ -279,10 +281,18 @@ struct bfs_fused_enactor_t {
     // CSC slots alias the CSR (symmetric input, what the reference always has)
     const bool use_layout = g.has_layout && (!direction_optimizing || g.csc_is_csr);
     last = bfs_run_stats_t();
-    if (use_layout) resolve_shapes(g, layout, &bfs_problem->src, 1, direction_optimizing ? 1 : 0, context);
+    // (one source: no wait for its shape -- known: used; not known: asked for in front of the traversal, collected behind it)
+    bool asked = false;
+    if (use_layout && g.src_shapes_enabled && mgx::bfs_wants_src_shapes(*fused, direction_optimizing ? 1 : 0) && g.num_edges > 0) {
+      if (g.src_shape_cache.lookup_or_request(g.d_row_offsets.data(), g.d_col_indices.data(), g.num_nodes, fused->long_min, bfs_problem->src, shape_table, context)) {
+        layout.src_shapes = shape_table.data();
+        layout.src_shapes_long_min = fused->long_min;
+      } else asked = true;
+    }
     mgx::bfs_fused_run(*fused, g.d_row_offsets.data(), g.d_col_indices.data(), bfs_problem->d_labels.data(),
                        bfs_problem->src, context, use_layout ? &layout : nullptr, direction_optimizing ? 1 : 0, alpha,
                        g.d_col_offsets.data(), g.d_row_indices.data());
+    if (asked) g.src_shape_cache.collect();            // (bfs_fused_run returns behind its last launch: the copy in front of the first has landed)
     fill_stats(last, fused->host_ctrl, direction_optimizing, true);
   }
 

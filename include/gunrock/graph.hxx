@@ -136,6 +136,7 @@ struct graph_device_t {
   unsigned cold_hot_n = 0;
   int cold_long_min = 0;
   bool cold_majority = false;         // the long rows' entries behind the LDS prefix were too many for lists (more than a quarter of them): a FLAT graph
+  bool cold_all = false;             // (round 6) a FLAT graph: the lists hold EVERY entry of every row, slices from vertex 0 on (cold_hot_n == 0)
   // Destination-sliced edge list of the weighted layout (mgx/sssp_fused.hpp: sssp_sliced_body): (src, dst, w) triples
   // ordered by dst >> 14; built at the first fused SSSP run of a graph that carries layout weights.
   mem_t<int> d_e_src, d_e_dst, d_slice_off;

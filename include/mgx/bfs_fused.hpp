@@ -183,6 +183,11 @@ struct bfs_fused_args_t {
   u32 cold_off[BFS_COLD_MAX_SLICES + 1];        // its pairs: [cold_off[i], cold_off[i + 1])
   u32 cold_wgs[BFS_COLD_MAX_SLICES + 1];        // the cold workgroups [cold_wgs[i], cold_wgs[i + 1]) of a push launch take slice i
   u32* cold_flush;         // cold_wgs[cold_slices] bitmaps of BFS_COLD_WORDS words: what cold workgroup k discovered in its slice
+  // (round 6) a FLAT graph: the lists hold EVERY entry of every row (slices from vertex 0 on).  A level that holds at least an eighth
+  // of them (cold_all_pairs) is one sweep of the lists by the cold workgroups -- nothing else of the push grid works --, the other
+  // levels walk their queues and mark what they find untested.  0: the lists are the long rows' entries behind the LDS prefix
+  u32 cold_all = 0;
+  u64 cold_all_pairs = 0;
   // the same pairs at four bytes each (mgx_layout.hip: mgx_cold_pack_device): bits 0..19 dst - cold_lo[slice], bits 20..31
   // (owner - the owner of the first pair of the pair's 64-chunk) / cold_ranks; NULL: none.  Slice q is packed when bit q of
   // cold_pk_mask is set; its chunks' owners are cold_cbase[cold_cb[q] ..)

@@ -67,6 +67,8 @@ struct bfs_layout_t {
   unsigned cold_hot_n = 0;
   int cold_long_min = 0;
   bool cold_majority = false;         // more than a quarter of the long rows' entries point behind the LDS prefix (no lists were built): a flat graph
+  bool cold_all = false;              // (round 6) a flat graph WITH lists: every entry of every row, slices from vertex 0 on (cold_hot_n == 0); cold_pairs_total of them
+  unsigned long long cold_pairs_total = 0;
   // HOST table, 4 words per SOURCE OF THE CALL (entry i belongs to the i-th source handed to bfs_fused_run / _run_many; round 6: resolved
   // on demand, mgx/src_shapes.hpp): what a traversal from it starts with
   const unsigned* src_shapes = nullptr;
@@ -131,6 +133,14 @@ __device__ __forceinline__ bfs_slot_plan_t bfs_slot_plan(const bfs_fused_args_t&
     p.chained = false;
     p.dense = p.vshort = true;
   }
+  if (a.cold_all) {
+    // a flat graph: a level that holds an eighth of all entries (and whose frontier the build left as a bitmap) is ONE sweep of the
+    // all-entries lists by the cold workgroups; any other level walks its queues (no unit blocks, no vertex-by-vertex walk: their
+    // entries live in the lists)
+    const u64 E = (cur & BFS_EMASK) + ledges;
+    p.dense = p.vshort = p.colds = false;
+    p.cold = !p.empty && !p.chained && !pulls && c->fb_slot == p.slot && E * 8ull >= a.cold_all_pairs;
+  }
   return p;
 }
 
@@ -188,6 +198,7 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
     if (p.cold || p.colds) bfs_cold_body<1024>(a, p.slot, blockIdx.x, p.level, p.cold, p.colds);
     return;
   }
+  if (a.cold_all && p.cold) return;               // (a flat graph's sweep level: the lists hold every entry)
   const u32 blk = blockIdx.x - ncold, nblk = gridDim.x - ncold;
   // (two other ways to deal the two halves were lab shapes until round 5 and lost in rounds 3 and 4: long- and short-row
   //  workgroups alternating, 0.52 against 0.41 ms per traversal -- the two bodies side by side on a CU are slower than one after
@@ -426,7 +437,9 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
                                (layout->cold_pk_mask & (layout->cold_slices >= 64 ? ~0ull : ((1ull << layout->cold_slices) - 1ull))) ==
                                    (layout->cold_slices >= 64 ? ~0ull : ((1ull << layout->cold_slices) - 1ull));
   const bool cold_pairs_ok = layout && ((layout->cold_pairs8 && layout->cold_dst) || (cold_all_packed && opt.cold_pack));
-  const bool cold_lists = units && cold_pairs_ok && layout->cold_slices > 0 && layout->cold_hot_n == (unsigned)(BFS_DENSE_HOTW * 32) &&
+  const bool flat_lists = layout && layout->cold_all && layout->cold_hot_n == 0u && cold_all_packed && opt.cold_pack && layout->cold_pairs_total > 0;
+  const bool cold_lists = units && cold_pairs_ok && layout->cold_slices > 0 &&
+                          (layout->cold_hot_n == (unsigned)(BFS_DENSE_HOTW * 32) || flat_lists) && (!layout->cold_all || flat_lists) &&
                           layout->cold_long_min == st.long_min && build2_ok && !opt.build_list && opt.cold != 0 &&
                           !MGX_LAB_GET(opt, dense_diag, 0);
   // ... and then the unit blocks WITHOUT the lists' entries (every level that reads unit blocks runs the cold-edge pass: the body
@@ -482,6 +495,8 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   a.cold_owner = cold ? (layout->cold_pairs8 ? layout->cold_owner : (const int*)layout->cold_pk) : nullptr;
   a.cold_dst = cold ? (layout->cold_pairs8 ? layout->cold_dst : (const int*)layout->cold_pk) : nullptr;
   a.cold_slices = cold ? layout->cold_slices : 0;
+  a.cold_all = (cold && flat_lists) ? 1u : 0u;
+  a.cold_all_pairs = a.cold_all ? layout->cold_pairs_total : 0ull;
   const bool cold_pk = cold && layout->cold_pk && layout->cold_cbase && opt.cold_pack;
   a.cold_pk = cold_pk ? layout->cold_pk : nullptr; a.cold_cbase = cold_pk ? layout->cold_cbase : nullptr;
   a.cold_pk_mask = cold_pk ? layout->cold_pk_mask : 0ull; a.cold_ranks = 1;
@@ -499,7 +514,7 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   // lazy queues (bfs_build_is_lazy): only k_bfs_build2 knows them, and only when both queue-less bodies are available
   a.lazy_pull = (mode == 1 && build2_ok && !opt.build_list && opt.lazy != 0) ? 1 : 0;
   // (direction-optimising runs too: a level behind a lazy build either pulls -- no queue needed -- or takes the queue-less bodies)
-  a.lazy_div = (a.dense_div && a.vs_div && build2_ok && !opt.build_list) ? (opt.lazy >= 0 ? (u32)opt.lazy : st.lazy_div) : 0u;
+  a.lazy_div = (a.dense_div && a.vs_div && build2_ok && !opt.build_list && !a.cold_all) ? (opt.lazy >= 0 ? (u32)opt.lazy : st.lazy_div) : 0u;      // (a flat graph's levels keep their queues: what is not swept is walked)
   plan.coldt = coldt;
   plan.build2_ok = build2_ok;
   // M launches from RMAT-22's size on: what one costs does not depend on the graph, what the device-wide slot it replaces costs

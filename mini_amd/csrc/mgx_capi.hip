@@ -486,7 +486,7 @@ extern "C" int mgx_cold_pack_device(const int* owner, const int* dst, int used, 
 static void build_cold_lists(mgx_graph_s* g) {
   graph_device_t& G = *g->g;
   G.d_cold_owner = mem_t<int>(); G.d_cold_dst = mem_t<int>(); G.d_colds_owner = mem_t<int>(); G.d_colds_dst = mem_t<int>();
-  G.cold_pairs = G.colds_pairs = 0; G.cold_slices = 0; G.cold_hot_n = 0; G.cold_long_min = 0; G.cold_majority = false;
+  G.cold_pairs = G.colds_pairs = 0; G.cold_slices = 0; G.cold_hot_n = 0; G.cold_long_min = 0; G.cold_majority = false; G.cold_all = false;
   G.d_ubh_col24 = mem_t<unsigned>(); G.d_ubh_owner = mem_t<int>(); G.ubh_units = G.ubh_units_pad = 0;
   // the short rows' list too on graphs of more than 2^23 vertices (equal to marking those entries on RMAT-22, where 6 % of the entries
   // are cold; RMAT-24 -2 %, RMAT-25 -9 % of a traversal); MGX_BFS_COLD_LISTS: 0 no lists at all, 1 the long rows' only, 2 both
@@ -501,7 +501,9 @@ static void build_cold_lists(mgx_graph_s* g) {
   if (n <= hot_n) return;                                          // everything is inside the prefix
   const long long slices_ll = ((long long)n - hot_n + slice_n - 1) / slice_n;
   if (slices_ll > 64) return;
-  const int slices = (int)slices_ll;
+  int slices = (int)slices_ll;
+  unsigned list_hot_n = hot_n;          // first vertex the lists cover (0: a FLAT graph's lists hold every entry, below)
+  bool flat = false;
   std::vector<int> off_l((size_t)slices + 1, 0), off_s((size_t)slices + 1, 0);
   int *owner = nullptr, *dst = nullptr;
   long long pairs = 0;
@@ -511,7 +513,29 @@ static void build_cold_lists(mgx_graph_s* g) {
   if (pairs <= 0) return;
   mem_t<int> d_owner = mem_t<int>::adopt(owner, (size_t)pairs + 256), d_dst = mem_t<int>::adopt(dst, (size_t)pairs + 256);
   const long long long_entries = (long long)G.ub_units * 64;       // (padded: an upper bound of the long rows' entries)
-  if (pairs * 4 > long_entries) { G.cold_majority = true; return; }     // (a flat graph: the fused BFS probes the bitmap instead, bfs_fused_run.hpp)
+  if (pairs * 4 > long_entries) {
+    // A FLAT graph (a uniform random graph: six entries in seven point behind the LDS prefix).  Round 5 left it to the bodies that PROBE
+    // the bitmap in L2 -- 134 M probes at what the L2s deliver, 1.34 ms per RMAT-22-sized traversal, whatever the kernel around them
+    // does.  Round 6: EVERY entry of every row as a pair by slice of its destination, slices from vertex 0 on (the first is the LDS
+    // prefix itself); a level that holds an eighth of the graph's entries is then ONE sweep of the packed pairs by the cold-edge
+    // pass's workgroups, each with its slice of the bitmap in LDS -- no probe leaves the compute unit, no mark is stored -- and the
+    // other levels walk their queues and mark untested (few entries: few marks).  MGX_BFS_FLAT_LISTS=0: the probes, as in round 5.
+    G.cold_majority = true;
+    bool want = (long long)G.num_edges < (1ll << 31) - 512 && (n + (long long)slice_n - 1) / slice_n <= 64;
+    if (const char* e = getenv("MGX_BFS_FLAT_LISTS")) want = want && atoi(e) != 0;
+    if (!want || G.vs_v[3] == 0) return;
+    d_owner = mem_t<int>(); d_dst = mem_t<int>();                    // (the long rows' cold entries: superseded)
+    slices = (int)((n + (long long)slice_n - 1) / slice_n);
+    off_l.assign((size_t)slices + 1, 0); off_s.assign((size_t)slices + 1, 0);
+    owner = nullptr; dst = nullptr; pairs = 0;
+    rc = mgx_cold_build_device(G.d_layout_row_offsets.data(), G.d_layout_col_indices.data(), (int)n, 0, (int)G.vs_v[3], 1, 0u, slice_n, slices,
+                               &owner, &dst, &pairs, off_l.data(), g->c->ctx->stream());
+    if (rc != 0) { (void)hipGetLastError(); return; }                // (no memory for 8 bytes per entry: the probes serve)
+    if (pairs <= 0) return;
+    d_owner = mem_t<int>::adopt(owner, (size_t)pairs + 256); d_dst = mem_t<int>::adopt(dst, (size_t)pairs + 256);
+    list_hot_n = 0u; flat = true; with_short = false;
+    G.cold_majority = false;
+  }
   // the short rows' cold entries
   int *owner_s = nullptr, *dst_s = nullptr;
   long long pairs_s = 0;
@@ -534,7 +558,7 @@ static void build_cold_lists(mgx_graph_s* g) {
   int q = 0;
   for (int k = 0; k < slices; ++k) {
     if (!(off_l[k + 1] > off_l[k] || off_s[k + 1] > off_s[k])) continue;
-    G.cold_lo[q] = hot_n + (unsigned)k * slice_n;
+    G.cold_lo[q] = list_hot_n + (unsigned)k * slice_n;
     G.cold_off[q] = (unsigned)off_l[k]; G.cold_off[q + 1] = (unsigned)off_l[k + 1];
     G.colds_off[q] = (unsigned)off_s[k]; G.colds_off[q + 1] = (unsigned)off_s[k + 1];
     ++q;
@@ -578,7 +602,14 @@ static void build_cold_lists(mgx_graph_s* g) {
       }
     }
   }
-  G.cold_pairs = pairs; G.colds_pairs = pairs_s; G.cold_slices = used; G.cold_hot_n = hot_n; G.cold_long_min = G.vs_long_min;
+  G.cold_pairs = pairs; G.colds_pairs = pairs_s; G.cold_slices = used; G.cold_hot_n = list_hot_n; G.cold_long_min = G.vs_long_min;
+  G.cold_all = flat;
+  if (flat && (!G.d_cold_pk.size() || G.d_cold_owner.size())) {        // (a flat graph's lists are only worth their bytes when EVERY slice is packed: 4 per entry, what the CSR costs)
+    G.d_cold_owner = mem_t<int>(); G.d_cold_dst = mem_t<int>(); G.d_cold_pk = mem_t<unsigned>(); G.d_cold_cbase = mem_t<unsigned>();
+    G.cold_pairs = 0; G.cold_slices = 0; G.cold_all = false; G.cold_majority = true;
+    return;
+  }
+  if (flat) return;                          // (no blocks "without the lists' entries": the lists hold everything)
   // The unit blocks once more for the fused BFS, WITHOUT the entries that now live in the lists (its unit-block body reads them only to
   // skip them) -- and what is left points into the LDS prefix, ids below 2^20: 24 bits per entry do at every graph size (the full
   // blocks' 24-bit copy stops at 2^23 vertices).  MGX_BFS_HOT_UNITS=0: not built.  The full blocks stay: the neighbour-reduce and the

@@ -273,6 +273,41 @@ def test_rmat23_unit_blocks_and_cold_pass_on_a_big_graph(gpu_ctx, oracle, torch_
     assert st["dense_slots"] >= 1 and st["cold_slots"] >= 1 and st["lazy_slots"] >= 1
 
 
+@pytest.mark.parametrize("flat_lists", ["1", "0"])
+def test_flat_graph_sweeps_all_entries_lists(gpu_ctx, oracle, torch_mod, monkeypatch, flat_lists):
+    """round 6: a FLAT graph (uniform random, every row ~32 entries: six endpoints in seven lie behind the 652 288-vertex LDS prefix).
+    Its layout carries EVERY entry of every row as a packed (owner, destination) pair by slice of the destination, slices from vertex 0
+    on; a level that holds an eighth of the entries is one sweep of those lists by the cold-edge pass's workgroups (nothing else of the
+    push grid works), the other levels walk their queues.  Labels and counters against the oracle, against the same traversals with
+    the lists switched off (MGX_BFS_FLAT_LISTS=0: the bitmap probes of round 5), one call per source and as a batch."""
+    import mini_amd
+    from mini_amd import rmat
+    monkeypatch.setenv("MGX_BFS_FLAT_LISTS", flat_lists)
+    scale = 21
+    g = rmat.uniform_csr(gpu_ctx, scale, 16, seed=scale)
+    graph = mini_amd.Graph.from_device(gpu_ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"]).build_layout()
+    info = graph.layout_info()
+    if flat_lists == "1":
+        assert info["cold_majority"] == 0 and info["cold_pairs"] == g["m"] and info["cold_slices"] == 4, info      # 2^21 vertices: four slices of 652 288
+    else:
+        assert info["cold_majority"] == 1 and info["cold_pairs"] == 0, info
+    ro, ci = g["row_offsets"].cpu().numpy(), g["col_indices"].cpu().numpy()
+    deg = np.diff(ro)
+    srcs = [int(s) for s in rmat.pick_sources(ro, 3, scale)]
+    bfs = mini_amd.BfsProblem(graph, srcs[0])
+    swept = 0
+    for s_ in srcs:
+        want = oracle.bfs_cpu(ro, ci, s_)
+        st = bfs.run(s_)
+        assert np.array_equal(bfs.labels(), want), s_
+        assert st["m_t"] == int(deg[want >= 0].sum()) and st["levels"] == int(want.max()) + 1, (s_, st)
+        swept += st["cold_slots"]
+    sts, reruns = bfs.run_many(srcs, mini_amd.MGX_BFS_PUSH, 0.0)
+    assert np.array_equal(bfs.labels(), oracle.bfs_cpu(ro, ci, srcs[-1]))
+    assert all(x["m_t"] == sts[0]["m_t"] for x in sts)             # one component holds every vertex with an edge
+    assert (swept > 0) == (flat_lists == "1"), swept
+
+
 @pytest.mark.parametrize("hot", ["1", "0"])
 def test_hot_unit_blocks_beyond_2_23_vertices(gpu_ctx, oracle, torch_mod, monkeypatch, hot):
     """n = 2^24: the full unit blocks have no 24-bit copy at this size (their entries need 25 bits), the blocks WITHOUT the

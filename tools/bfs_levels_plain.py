@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-level times of the PRODUCT launches (merged push, no events on the stream) from the device-side stamps a level's opener
 takes, for several configurations of run-time switches side by side: the median over --reps traversals of each source.
-  python tools/bfs_levels_plain.py --scale 22 --sources 3 --configs ";MGX_BFS_DEFER_FOLD=2"
+  python tools/bfs_levels_plain.py --scale 22 --sources 3 --configs ";MGX_BFS_DEFER=0" [--graph uniform]
 A level's time runs from its opener to the next level's opener: push + build (+ whatever sits between them)."""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,10 +13,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--scale", type=int, default=22)
 ap.add_argument("--sources", type=int, default=3)
 ap.add_argument("--reps", type=int, default=5)
-ap.add_argument("--configs", default=";MGX_BFS_DEFER_FOLD=2")
+ap.add_argument("--configs", default=";MGX_BFS_DEFER=0")
+ap.add_argument("--graph", choices=["rmat", "uniform", "grid2d"], default="rmat")
 a = ap.parse_args()
 ctx = mini_amd.Context(0, torch.cuda.current_stream().cuda_stream)
-g = rmat.rmat_csr(ctx, a.scale, 16, seed=a.scale)
+g = {"rmat": lambda: rmat.rmat_csr(ctx, a.scale, 16, seed=a.scale), "uniform": lambda: rmat.uniform_csr(ctx, a.scale, 16, seed=a.scale),
+     "grid2d": lambda: rmat.grid2d_csr(ctx, a.scale)}[a.graph]()
 graph = mini_amd.Graph.from_device(ctx, g["n"], g["m"], g["row_offsets"], g["col_indices"])
 graph.build_layout()
 ro = g["row_offsets"].cpu().numpy()
