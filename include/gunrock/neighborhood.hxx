@@ -103,7 +103,7 @@ int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fronti
       const long long seq = mgx::nr_full_frontier<Value>(L, [=] __device__(int v) -> Value { return Functor::get_value_to_reduce(v, data, iteration); }, reduced,
                                    identity, reduce_op(), context, frontier, context.mailbox + 8, context.nr_flag(), epoch,
                                    full ? -1 : frontier_size, offsets, subset ? (mgx::u64*)graph.d_nr_pos.data() : nullptr);
-      context.mailbox_wait(seq);
+      if (seq) context.mailbox_wait(seq); else context.synchronize();
       // (a subset call added its frontier's degrees to the context's counter whatever its verdict: the base follows)
       const unsigned long long before = context.nr_edges_base;
       if (subset) context.nr_edges_base = (unsigned long long)context.mailbox[9];

@@ -589,7 +589,7 @@ inline size_t nr_scratch_bytes(long long n, long long units_pad, size_t value_si
 // position; L_in.new_of_old, `offsets` (the ORIGINAL CSR's, for the degree sum -> host_flag[1]) and `pos` are needed.  pos: n words of 64
 // bits that ONLY these calls write (zeroed when allocated: an entry is 0 or (epoch of an earlier call, position) -- memory that held
 // anything else could show this call's epoch by accident; the epochs of a context never repeat).
-// Returns the sequence number to wait for (standard_context_t::mailbox_wait).
+// Returns the sequence number to wait for (standard_context_t::mailbox_wait), 0: wait for the stream.
 template <typename V, typename Op, typename GetValue>
 inline long long nr_full_frontier(const nr_layout_t& L_in, GetValue get, V* reduced, V identity, Op op, standard_context_t& ctx, const int* frontier,
                              long long* host_flag, u32* dev_flag, u32 epoch, long long nf = -1, const int* offsets = nullptr, u64* pos = nullptr) {
@@ -611,10 +611,13 @@ inline long long nr_full_frontier(const nr_layout_t& L_in, GetValue get, V* redu
     hipLaunchKernelGGL((k_nr_values<V, GetValue>), dim3(grid_for(L.n, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, get, L.old_of_new, vals,
                        reduced, identity, (long long)L.n, frontier, host_flag, dev_flag, epoch);
   }
-  const long long seq = ++ctx.mailbox_seq;
+  // (a SUBSET call ends with a one-thread publish kernel -- the degree sum has to reach the host -- and the host spins on its sequence
+  //  number; a full-frontier call has nothing to deliver and waits for the stream, as before round 6: with a publish launch behind it
+  //  too the call measured 0.277-0.280 ms against 0.266-0.269)
+  const long long seq = subset ? ++ctx.mailbox_seq : 0;
   struct publish_t {            // (behind everything else, whichever way the function is left)
     bool subset; hipStream_t s; const u64* e; long long* h; long long* mb; long long seq;
-    ~publish_t() { hipLaunchKernelGGL(k_nr_publish, dim3(1), dim3(1), 0, s, e, subset ? h : (long long*)nullptr, mb, seq); }
+    ~publish_t() { if (subset) hipLaunchKernelGGL(k_nr_publish, dim3(1), dim3(1), 0, s, e, h, mb, seq); }
   } publish{subset, s, ctx.nr_edges(), host_flag + 1, ctx.mailbox, seq};
   if (L.nrs_mu) {
     // the long rows by slice of their destinations + the short rows, one launch; then the fold
