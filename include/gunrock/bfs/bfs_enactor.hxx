@@ -187,7 +187,6 @@ struct bfs_fused_enactor_t {
       for (int i = 0; i < 4; ++i) layout.vs_v[i] = g.vs_v[i];
       layout.vs_v9 = g.vs_v9;
       layout.vs_edges = g.vs_edges; layout.vs_dummy = g.vs_dummy; layout.vs_long_min = g.vs_long_min;
-      if (g.d_ss_tab.size() && g.vs_long_min > 0) layout.ss_tab = g.d_ss_tab.data();
       if (g.cold_slices > 0) {
         // (round 6: the 8-byte pairs are gone when every slice carries the packed words below -- cold_pairs8 says which)
         layout.cold_pairs8 = g.d_cold_owner.size() != 0 && g.d_cold_dst.size() != 0;

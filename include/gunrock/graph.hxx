@@ -108,7 +108,7 @@ struct graph_device_t {
   // row's mini-units of a slice start, the slices' first mini-units.  Empty: not built (the unit blocks serve).
   mem_t<unsigned> d_nrs_mu;
   mem_t<unsigned> d_nrs_off;
-  unsigned nrs_first[18] = {0};      // (mgx::NRS_MAX_SLICES + 2)
+  unsigned nrs_first[98] = {0};      // (mgx::NRS_MAX_SLICES + 2)
   unsigned nrs_slices = 0, nrs_rows = 0;
   unsigned nrs_tier[3] = {0, 0, 0};  // k_nrs_fold: rows [0, t0) a workgroup each, [t0, t1) a wave, [t1, t2) eight lanes, the others a thread
   long long nrs_units = 0;
@@ -119,7 +119,6 @@ struct graph_device_t {
   unsigned vs_v9 = 0;                // first layout vertex of degree < 9 (inside [vs_v[1], vs_v[2]]): the fused BFS walks degrees 5 .. 8 with two lanes per vertex
   unsigned vs_edges = 0, vs_dummy = 0;
   int vs_long_min = 0;
-  mem_t<unsigned> d_ss_tab;          // region table of the short rows (mgx/bfs_fused_sshort.hpp); with the degree classes
   // Cold-edge lists of the long rows (mgx/bfs_fused_cold.hpp): the unit blocks' entries behind the LDS prefix as
   // (owner, dst) pairs grouped by slice of the id range; built with the layout when they are a small share of the entries.
   mem_t<int> d_cold_owner;
@@ -137,12 +136,6 @@ struct graph_device_t {
   int cold_long_min = 0;
   bool cold_majority = false;         // the long rows' entries behind the LDS prefix were too many for lists (more than a quarter of them): a FLAT graph
   bool cold_all = false;             // (round 6) a FLAT graph: the lists hold EVERY entry of every row, slices from vertex 0 on (cold_hot_n == 0)
-  // Destination-sliced edge list of the weighted layout (mgx/sssp_fused.hpp: sssp_sliced_body): (src, dst, w) triples
-  // ordered by dst >> 14; built at the first fused SSSP run of a graph that carries layout weights.
-  mem_t<int> d_e_src, d_e_dst, d_slice_off;
-  mem_t<float> d_e_w;
-  int sliced_slices = 0;            // 0: not built (yet)
-  bool sliced_tried = false;
 
   graph_device_t() : num_nodes(0), num_edges(0) {}
 

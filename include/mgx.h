@@ -462,8 +462,8 @@ MGX_API int mgx_sssp_run(mgx_sssp_t p, int src, int64_t* stats);
 /* the same with near / far buckets of width delta (the delta-stepping BASELINE config 3 names): improved vertices whose
  * distance lies at or above the current threshold wait until the queue of nearer ones has run dry, then the threshold
  * moves to the bucket of the smallest waiting distance.  Same fixed point, fewer relaxations, more (cheap) iterations.
- * delta == 0: off (plain frontier Bellman-Ford, what mgx_sssp_run does); delta < 0: the default (off; the environment
- * variable MGX_SSSP_DELTA overrides either).  stats as above ([0] counts the iterations incl. the bucket changes). */
+ * delta == 0: off (plain frontier Bellman-Ford, what mgx_sssp_run does); delta < 0: the default (off).  stats as above ([0] counts
+ * the iterations incl. the bucket changes). */
 MGX_API int mgx_sssp_run_delta(mgx_sssp_t p, int src, float delta, int64_t* stats);
 /* per-launch timing of the relax kernel of mgx_sssp_run (k_sssp_relax: sssp_functor.hxx:20-29 over every edge of the
  * frontier): on != 0 brackets each launch with HIP events on the context's stream (each costs ~6 us of stream gap: measurement

@@ -5,7 +5,6 @@
 //   bfs_fused_wave.hpp    short rows, search per edge rank  bfs_fused_vshort.hpp  short rows vertex by vertex
 //   bfs_fused_cold.hpp    the long rows' entries behind the LDS prefix, as pairs by slice of the id range
 //   bfs_fused_chain.hpp   small levels, one workgroup       bfs_fused_pull.hpp    bottom-up levels
-//   bfs_fused_sshort.hpp  (option) short rows as one stream of entries
 // and bfs_fused_run.hpp launches them, slot by slot (k_bfs_push: all bodies in ONE grid; k_bfs_chain_inplace).
 //
 // What the reference does per level: degree scan (K1) -> 4-byte D2H (K2) ->
@@ -214,8 +213,6 @@ struct bfs_fused_args_t {
   // instrumented kernels of the measurement tools.  The product library carries none of this: MGX_LAB_GET reads a
   // constant there and the compiler drops the code behind it.
   int flags;               // MGX_BFS_FLAGS: instrumented stream kernel (results are wrong by design)
-  const u32* ss_tab;       // short rows as one stream (bfs_fused_sshort.hpp): first entry / first row of every degree's region; NULL: none
-  int ss_dmax;             // the largest short degree (long_min - 1)
   int build_diag;          // measurements only (MGX_BFS_BUILD_DIAG; results wrong): 1 no label stores, 2 no extent gathers, 4 no cursor atomics, 8 no queue stores, 16 synthetic extents, 32 / 64 no OR of the deferred / the cold pass's bitmaps
   int dense_diag;          // measurements only (MGX_BFS_DENSE_DIAG): 1 the unit-block body stores no marks, 2 tests nothing
 #endif
@@ -1152,8 +1149,6 @@ struct bfs_run_opts_t {
                            // again on its own, and the chain behind a traversal's last slot takes stragglers of up to BFS_CHAIN_CAP_BIG edges)
 #ifdef MGX_LAB
   int flags = 0;           // MGX_BFS_FLAGS (instrumented stream kernel)
-  int sstream = 0;         // MGX_BFS_SSTREAM=1: dense short rows as one stream of entries (bfs_fused_sshort.hpp) instead of vertex by
-                           // vertex -- measured 6 us slower per RMAT-22 traversal (0.3578 / 0.3519 ms)
   int build_diag = 0;      // MGX_BFS_BUILD_DIAG: parts of k_bfs_build switched off (measurements only)
   int dense_diag = 0;      // MGX_BFS_DENSE_DIAG: parts of the unit-block body switched off (measurements only)
 #endif
@@ -1192,7 +1187,6 @@ struct bfs_run_opts_t {
     if (o.lazy > (1 << 20)) o.lazy = 1 << 20;     // (edges < 2^38: no overflow)
 #ifdef MGX_LAB
     geti("MGX_BFS_FLAGS", o.flags);
-    geti("MGX_BFS_SSTREAM", o.sstream);
     geti("MGX_BFS_BUILD_DIAG", o.build_diag);
     geti("MGX_BFS_DENSE_DIAG", o.dense_diag);
 #else

@@ -17,9 +17,6 @@
 #include "bfs_fused_dense.hpp"
 #include "bfs_fused_mini.hpp"
 #include "bfs_fused_pull.hpp"
-#ifdef MGX_LAB
-#include "bfs_fused_sshort.hpp"
-#endif
 #include "bfs_fused_stream.hpp"
 #include "bfs_fused_vshort.hpp"
 #include "bfs_fused_sparse.hpp"
@@ -50,7 +47,6 @@ struct bfs_layout_t {
   unsigned vs_v9 = 0;               // first vertex of degree < 9 (0: unknown -- degrees 5 .. 16 are one class)
   unsigned vs_edges = 0, vs_dummy = 0;
   int vs_long_min = 0;
-  const unsigned* ss_tab = nullptr;   // (lab builds) region table of the short rows (bfs_fused_sshort.hpp; device, BFS_SS_TAB_WORDS words)
   // cold-edge lists of the long rows (bfs_fused_cold.hpp): pairs grouped by slice; hot_n / long_min they were cut for
   const int* cold_owner = nullptr;
   const int* cold_dst = nullptr;
@@ -128,7 +124,7 @@ __device__ __forceinline__ bfs_slot_plan_t bfs_slot_plan(const bfs_fused_args_t&
   // without the lists' entries, args.ub_hot_only, are for the levels that run the pass, bfs_dense_body)
   p.cold = p.dense && a.cold_dst != nullptr;
   // (lab builds: with them, the short rows' cold entries of a level that walks those vertex by vertex)
-  p.colds = p.cold && p.vshort && a.colds_dst != nullptr && !MGX_LAB_GET(a, ss_tab, (const u32*)nullptr);
+  p.colds = p.cold && p.vshort && a.colds_dst != nullptr;
   if (!p.empty && c->lazy_slot == p.slot) {       // the build before this slot wrote no queues (bfs_build_is_lazy)
     p.chained = false;
     p.dense = p.vshort = true;
@@ -212,9 +208,6 @@ __global__ __launch_bounds__(1024, 8) void k_bfs_push(bfs_fused_args_t a, int ar
     const u32 first = PART == 0 ? nstream : 0u;
     const u32 bi = blk - first;
     const u32 nb = nblk - first;
-#ifdef MGX_LAB
-    if (!COLDT && p.vshort && a.ss_tab) { bfs_sstream_body<1024, BFS_DENSE_HOTW - BFS_SS_TAB_PAD>(a, p.slot, bi, nb, p.level, false); return; }
-#endif
     if (!COLDT && p.vshort) bfs_vshort_body<1024, BFS_DENSE_HOTW>(a, p.slot, bi, nb, p.level, p.colds);
     else bfs_wave_body<1024, BFS_WAVE_HOTW, COLDT, false>(a, p.slot, bi, nb, p.level);
   }
@@ -465,8 +458,6 @@ inline bfs_launch_plan_t bfs_fused_plan(bfs_fused_state_t& st, const int* row_of
   a.vs_dummy = vs ? layout->vs_dummy : 0u;
   a.vs_div = !vs ? 0u : (opt.vshort >= 0 ? (u32)opt.vshort : st.vshort_div);
 #ifdef MGX_LAB
-  a.ss_tab = (vs && layout->ss_tab && opt.sstream && st.long_min <= BFS_SS_MAXDEG) ? layout->ss_tab : nullptr;
-  a.ss_dmax = st.long_min - 1;
   a.dense_diag = opt.dense_diag;
   a.build_diag = opt.build_diag;
 #endif

@@ -18,7 +18,7 @@
 //   * a rank that does not show up (its thread died of an error, the loops disagree about the sequence of collectives) does not
 //     hang the others: every wait has a deadline (MGX_LOOPBACK_TIMEOUT_S, 120 s), after which the world is BROKEN and every call
 //     on it returns ncclSystemError.
-// A loopback communicator is made from a loopback id (mgx_comm_unique_id with MGX_COMM=loopback, or mgx_comm_loopback_id): the id
+// A loopback communicator is made from a loopback id (mgx_comm_loopback_id): the id
 // carries a magic word, mgx_comm_create reads it and picks this table instead of RCCL's.  Not a transport: nothing here is meant
 // to be fast, and nothing on a product path selects it by itself.
 #pragma once

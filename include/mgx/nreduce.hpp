@@ -38,7 +38,16 @@ constexpr int NR_HOTV = 40000;            // values of the first NR_HOTV layout 
                                           //  stay in LDS -- 64 % of the endpoints at 40 000 values against 51 % -- and 128 registers per lane.)
 constexpr int NR_BIG_UNITS = 64;          // rows of more units than this are folded by a workgroup of their own
 constexpr size_t nr_lds_bytes() { return (size_t)NR_HOTV * 4 + 64; }
-constexpr int NRS_MAX_SLICES = 16;        // hot slices of the sliced long rows (k_nrs_edges): 16 x 40 000 vertices hold 94 % of RMAT-22's long-row endpoints
+constexpr int NRS_MAX_SLICES = 96;        // hot slices of the sliced long rows (k_nrs_edges) at most
+// How many a graph of n vertices gets (nrs_default_slices): 16 x 40 000 vertices hold 94 % of RMAT-22's long-row endpoints, but 82 / 63 % of
+// RMAT-24's / 25's -- the tail behind the hot slices gathers through the L2 -- and every slice costs the fold a range end per long row.
+// Measured (profiles/r06/nr_slices_sweep.txt, ms per call at 16 / 32 / 64 / 96-128 slices): RMAT-22 0.269 / 0.276 / 0.321 / --,
+// RMAT-23 0.705 / 0.644 / 0.621-0.634 / 0.665, RMAT-24 1.917 / 1.594 / 1.438 / 1.449, RMAT-25 5.021 / 4.319 / 3.715 / 3.526.
+inline int nrs_default_slices(long long n) {
+  const long long by_size = n >> 18;                 // 16 / 32 / 64 / 128 at R-MAT 22 / 23 / 24 / 25
+  return (int)(by_size < 16 ? 16 : by_size > NRS_MAX_SLICES ? NRS_MAX_SLICES : by_size);
+}
+constexpr int NRS_FOLD_CHUNK = 17;        // slices (hot + tail) k_nrs_fold takes at a time: a row's range ends of that many sit in registers
 // k_nrs_fold: rows of more than NRS_FOLD_DEG[0] entries are folded by a workgroup each, of more than [1] by a wave, of more than [2] by
 // eight lanes, the others by a thread each (the layout is sorted by degree: the tiers are row ranges)
 constexpr int NRS_FOLD_DEG[3] = {65536, 4096, 256};
@@ -489,44 +498,50 @@ __global__ __launch_bounds__(NT, WPE) void k_nrs_edges(nr_layout_t L, const V* _
 // then every range's first LANES partials (again all in flight at once: for most rows that is everything), then what is left of
 // the long ranges.  The first version walked the slices one after the other -- a dependent pair of round trips per slice, 17 in a
 // row, a workgroup each for 16 515 rows: 93 us.  Fixed strides, fixed order: deterministic.
-template <typename V, typename Op, int LANES>
+template <typename V, typename Op, int LANES, bool MULTI>
 __device__ __forceinline__ V nrs_fold_row(const u32* __restrict__ off, const V* __restrict__ partial, u32 K1, u32 LR, u32 r, u32 lane, V identity, Op op) {
-  constexpr int KM = NRS_MAX_SLICES + 1;
-  u32 a[KM], b[KM];
-#pragma unroll
-  for (int k = 0; k < KM; ++k) {
-    const size_t at = (size_t)((u32)k < K1 ? (u32)k : 0u) * LR + r;
-    a[k] = nr_load_pinned(off + at);
-    b[k] = nr_load_pinned(off + at + 1u);
-  }
-  V first[KM];
-#pragma unroll
-  for (int k = 0; k < KM; ++k) {
-    const u32 j = a[k] + lane;
-    const bool ok = (u32)k < K1 && j < b[k];
-    first[k] = nr_load_pinned(partial + (ok ? j : 0u));
-    if (!ok) first[k] = identity;
-  }
+  // (round 6: the slices in chunks of NRS_FOLD_CHUNK -- a layout of up to 16 hot slices + the tail is one chunk, the fold it always was;
+  //  bigger graphs carry more slices and go round again with the same registers: MULTI, a kernel of its own so that the one-chunk fold
+  //  keeps its code)
+  constexpr int KM = NRS_FOLD_CHUNK;
   V acc = identity;
+  for (u32 kc = 0; kc < (MULTI ? K1 : 1u); kc += (u32)KM) {           // (uniform)
+    u32 a[KM], b[KM];
 #pragma unroll
-  for (int k = 0; k < KM; ++k) acc = op(acc, first[k]);
+    for (int k = 0; k < KM; ++k) {
+      const u32 kk = kc + (u32)k;
+      const size_t at = (size_t)(kk < K1 ? kk : 0u) * LR + r;
+      a[k] = nr_load_pinned(off + at);
+      b[k] = nr_load_pinned(off + at + 1u);
+    }
+    V first[KM];
 #pragma unroll
-  for (int k = 0; k < KM; ++k) {
-    if ((u32)k < K1) {
-      V a0 = identity, a1 = identity;
-      u32 j = a[k] + lane + (u32)LANES;
-      for (; j + (u32)LANES < b[k]; j += 2u * LANES) {
-        const V p0 = partial[j], p1 = partial[j + (u32)LANES];
-        a0 = op(a0, p0); a1 = op(a1, p1);
+    for (int k = 0; k < KM; ++k) {
+      const u32 j = a[k] + lane;
+      const bool ok = kc + (u32)k < K1 && j < b[k];
+      first[k] = nr_load_pinned(partial + (ok ? j : 0u));
+      if (!ok) first[k] = identity;
+    }
+#pragma unroll
+    for (int k = 0; k < KM; ++k) acc = op(acc, first[k]);
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      if (kc + (u32)k < K1) {
+        V a0 = identity, a1 = identity;
+        u32 j = a[k] + lane + (u32)LANES;
+        for (; j + (u32)LANES < b[k]; j += 2u * LANES) {
+          const V p0 = partial[j], p1 = partial[j + (u32)LANES];
+          a0 = op(a0, p0); a1 = op(a1, p1);
+        }
+        if (j < b[k]) a0 = op(a0, partial[j]);
+        acc = op(acc, op(a0, a1));
       }
-      if (j < b[k]) a0 = op(a0, partial[j]);
-      acc = op(acc, op(a0, a1));
     }
   }
   return acc;
 }
 
-template <typename V, typename Op>
+template <typename V, typename Op, bool MULTI>
 __global__ __launch_bounds__(BLOCK) void k_nrs_fold(nr_layout_t L, const V* __restrict__ partial, V* __restrict__ reduced, V identity, Op op,
                                                     const u32* dev_flag, u32 epoch) {
   constexpr int NW = BLOCK / WAVE;
@@ -539,7 +554,7 @@ __global__ __launch_bounds__(BLOCK) void k_nrs_fold(nr_layout_t L, const V* __re
   u32 blk = blockIdx.x;
   if (blk < t0) {                                                  // a workgroup per row
     const u32 r = blk;
-    V acc = nrs_fold_row<V, Op, BLOCK>(off, partial, K1, LR, r, threadIdx.x, identity, op);
+    V acc = nrs_fold_row<V, Op, BLOCK, MULTI>(off, partial, K1, LR, r, threadIdx.x, identity, op);
 #pragma unroll
     for (int sh = 1; sh < WAVE; sh <<= 1) acc = op(acc, __shfl_xor(acc, sh, WAVE));
     if (lane_id() == 0) s_part[threadIdx.x / WAVE] = acc;
@@ -556,7 +571,7 @@ __global__ __launch_bounds__(BLOCK) void k_nrs_fold(nr_layout_t L, const V* __re
   if (blk < b1) {                                                  // a wave per row
     const u32 r = t0 + blk * NW + (u32)__builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     if (r >= t1) return;
-    V acc = nrs_fold_row<V, Op, WAVE>(off, partial, K1, LR, r, (u32)lane_id(), identity, op);
+    V acc = nrs_fold_row<V, Op, WAVE, MULTI>(off, partial, K1, LR, r, (u32)lane_id(), identity, op);
 #pragma unroll
     for (int sh = 1; sh < WAVE; sh <<= 1) acc = op(acc, __shfl_xor(acc, sh, WAVE));
     if (lane_id() == 0) nr_store(L, reduced, r, acc);
@@ -566,7 +581,7 @@ __global__ __launch_bounds__(BLOCK) void k_nrs_fold(nr_layout_t L, const V* __re
   if (blk < b2) {                                                  // eight lanes per row
     const u32 r = t1 + blk * (BLOCK / 8) + threadIdx.x / 8u, sub = threadIdx.x & 7u;
     const bool in = r < t2;
-    V acc = nrs_fold_row<V, Op, 8>(off, partial, K1, LR, in ? r : t1, sub, identity, op);
+    V acc = nrs_fold_row<V, Op, 8, MULTI>(off, partial, K1, LR, in ? r : t1, sub, identity, op);
 #pragma unroll
     for (int sh = 1; sh < 8; sh <<= 1) acc = op(acc, __shfl_xor(acc, sh, WAVE));
     if (in && sub == 0u) nr_store(L, reduced, r, acc);
@@ -575,7 +590,7 @@ __global__ __launch_bounds__(BLOCK) void k_nrs_fold(nr_layout_t L, const V* __re
   blk -= b2;
   const u32 r = t2 + blk * BLOCK + threadIdx.x;                    // a thread per row
   if (r >= LR) return;
-  nr_store(L, reduced, r, nrs_fold_row<V, Op, 1>(off, partial, K1, LR, r, 0u, identity, op));
+  nr_store(L, reduced, r, nrs_fold_row<V, Op, 1, MULTI>(off, partial, K1, LR, r, 0u, identity, op));
 }
 
 // scratch the fast path needs (vals + partials: one per unit, or per mini-unit of the sliced long rows), in bytes
@@ -629,7 +644,10 @@ inline long long nr_full_frontier(const nr_layout_t& L_in, GetValue get, V* redu
                        identity, op, dev_flag, epoch);
     const u32 grid = L.nrs_tier[0] + (L.nrs_tier[1] - L.nrs_tier[0] + BLOCK / WAVE - 1) / (BLOCK / WAVE) + (L.nrs_tier[2] - L.nrs_tier[1] + BLOCK / 8 - 1) / (BLOCK / 8) +
                      (L.nrs_rows - L.nrs_tier[2] + BLOCK - 1) / BLOCK;
-    if (grid) hipLaunchKernelGGL((k_nrs_fold<V, Op>), dim3(grid), dim3(BLOCK), 0, s, L, (const V*)partial, reduced, identity, op, dev_flag, epoch);
+    if (grid && L.nrs_slices + 1u <= (u32)NRS_FOLD_CHUNK)
+      hipLaunchKernelGGL((k_nrs_fold<V, Op, false>), dim3(grid), dim3(BLOCK), 0, s, L, (const V*)partial, reduced, identity, op, dev_flag, epoch);
+    else if (grid)
+      hipLaunchKernelGGL((k_nrs_fold<V, Op, true>), dim3(grid), dim3(BLOCK), 0, s, L, (const V*)partial, reduced, identity, op, dev_flag, epoch);
     return seq;
   }
   const u32 long_rows = L.vs_v[0];

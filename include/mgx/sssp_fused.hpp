@@ -79,17 +79,8 @@ struct sssp_args_t {
   bfs_ctrl_t* ctrl;      // cursor[3] (packed, rotating), sums, done, levels = iterations
   int n;
   u32 hot_min_edges;     // iterations with at least this many edges keep distance bounds of the hubs in LDS
-  // destination-sliced edge list (sssp_sliced_body; NULL: none): all m edges as (src, dst, w), ordered by dst >> slice_shift
-  // and by src inside a slice; slice_off[s] .. slice_off[s + 1] are the edges of slice s; frontier_bits: the frontier as a
-  // bitmap (written by k_sssp_build2); an iteration whose frontier holds >= m / sliced_div edges takes this path
-  const int* e_src;
-  const int* e_dst;
-  const float* e_w;
-  const int* slice_off;
-  int slices, slice_shift;
-  unsigned long long m_edges;
-  u32 sliced_div;
-  u32* frontier_bits;
+  unsigned long long m_edges;   // edges of the graph (the test for a heavy iteration: frontier edges x dense_div >= m_edges)
+  u32* frontier_bits;           // the frontier as a bitmap (k_sssp_build2 writes it, the sweep reads it; NULL: no sweep)
   // heavy iterations over the layout's unit blocks and degree classes (sssp_dense_*; NULL: never): the long rows' entries
   // and weights in 64-entry units of one row each, real entries per unit, the row of every unit; the short rows' classes
   const int* ub_col;
@@ -116,12 +107,6 @@ struct sssp_layout_t {
   const float* weights = nullptr;
   const int* new_of_old = nullptr;
   const int* old_of_new = nullptr;
-  // destination-sliced edge list of this CSR (optional)
-  const int* e_src = nullptr;
-  const int* e_dst = nullptr;
-  const float* e_w = nullptr;
-  const int* slice_off = nullptr;
-  int slices = 0, slice_shift = 0;
   long long m_edges = 0;
   // unit blocks of this CSR with their weights, degree classes (optional: a layout the library built and sorted itself)
   const int* ub_col = nullptr;
@@ -232,32 +217,27 @@ __device__ __forceinline__ u32 sssp_gather_index(u32 d, u32 nd, const unsigned s
   return live ? d : 0u;
 }
 
-// four candidates of a lane.  LIVE: the table holds the first hot_n distances as 32-bit minima the WORKGROUP keeps current
-// (ds_min): a candidate for such a vertex is decided in LDS -- it goes to the global atomicMin only if it lowered the
-// workgroup's minimum (the global value is never above it once those atomics have landed), no gather.  Otherwise the table
-// holds 16-bit upper bounds taken when the workgroup started: a candidate below the bound gathers the distance.
-template <bool LIVE>
-__device__ __forceinline__ void sssp_relax4(const u32 (&dd)[4], const u32 (&nd)[4], void* table, u32 hot_n, u32* dist, unsigned char* mark) {
+// four candidates of a lane.  The table holds 16-bit upper bounds of the first hot_n distances, taken when the workgroup started: a
+// candidate below the bound gathers the distance.  (32-bit minima the workgroup keeps current with ds_min instead -- MGX_SSSP_LIVE of the lab
+// builds until round 6 -- measured 2.56 against 1.88 ms per RMAT-22 source: half the vertices fit, and every hot candidate is an LDS atomic.)
+__device__ __forceinline__ void sssp_relax4(const u32 (&dd)[4], const u32 (&nd)[4], const void* table, u32 hot_n, u32* dist, unsigned char* mark) {
   u32 gi[4], old[4];
-  bool live[4], won[4];
+  bool live[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    won[k] = false;
-    if (LIVE) {
-      const bool none = dd[k] == 0xFFFFFFFFu;
-      const bool hotm = dd[k] < hot_n;
-      if (hotm) won[k] = nd[k] < atomicMin((u32*)table + dd[k], nd[k]);
-      live[k] = !none && !hotm;
-      gi[k] = live[k] ? dd[k] : 0u;
-    } else {
-      gi[k] = sssp_gather_index(dd[k], nd[k], (const unsigned short*)table, hot_n, live[k]);
-    }
+    gi[k] = sssp_gather_index(dd[k], nd[k], (const unsigned short*)table, hot_n, live[k]);
   }
+  // (the gathers stay unconditional: a plain load whose only use sits behind live[k] is sunk under it by the code generator, every gather
+  //  then a round trip of its own behind an s_waitcnt vmcnt(0) inside the branch -- mgx/nreduce.hpp: nr_load_pinned.  The comparison
+  //  is made for every candidate, outside the branch.)
 #pragma unroll
   for (int k = 0; k < 4; ++k) old[k] = dist[gi[k]];
+  bool go[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) go[k] = (nd[k] < old[k]) & live[k];
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    if (won[k] || (live[k] && nd[k] < old[k])) {
+    if (go[k]) {
       atomicMin(dist + dd[k], nd[k]);
       mark[dd[k]] = 1;
     }
@@ -271,7 +251,7 @@ typedef unsigned int sssp_u32x2 __attribute__((ext_vector_type(2)));
 // how many entries of a unit are real.
 // PIDS / PW separately (round 6): a layout that carries the 24-bit copy has dropped the 32-bit entries, whatever the weights are -- real
 // weights then ride as floats beside 24-bit ids (7 bytes per entry).
-template <int NT, bool LIVE, bool PIDS, bool PW>
+template <int NT, bool PIDS, bool PW>
 __device__ __forceinline__ void sssp_dense_long(const sssp_args_t& a, void* table, u32 hot_n, u32 block, u32 nblocks) {
   constexpr int NW = NT / WAVE;
   const int lane = lane_id();
@@ -367,7 +347,7 @@ __device__ __forceinline__ void sssp_dense_long(const sssp_args_t& a, void* tabl
           dd[k] = aC[j] ? e4[k] : 0xFFFFFFFFu;         // (-1 padding entries stay -1)
           nd[k] = __float_as_uint(base + w4[k]);
         }
-        sssp_relax4<LIVE>(dd, nd, table, hot_n, dist, mark);
+        sssp_relax4(dd, nd, table, hot_n, dist, mark);
       }
     }
 #pragma unroll
@@ -378,7 +358,7 @@ __device__ __forceinline__ void sssp_dense_long(const sssp_args_t& a, void* tabl
   }
 }
 
-template <int NT, bool LIVE>
+template <int NT>
 __device__ __forceinline__ void sssp_dense_short(const sssp_args_t& a, void* table, u32 hot_n, u32 block, u32 nblocks) {
   constexpr int NW = NT / WAVE;
   const int lane = lane_id();
@@ -425,7 +405,7 @@ __device__ __forceinline__ void sssp_dense_short(const sssp_args_t& a, void* tab
     dd[2] = pc.cnt > 2u ? dc.z : 0xFFFFFFFFu; dd[3] = pc.cnt > 3u ? dc.w : 0xFFFFFFFFu;
     nd[0] = __float_as_uint(base + wc.x); nd[1] = __float_as_uint(base + wc.y);
     nd[2] = __float_as_uint(base + wc.z); nd[3] = __float_as_uint(base + wc.w);
-    sssp_relax4<LIVE>(dd, nd, table, hot_n, dist, mark);
+    sssp_relax4(dd, nd, table, hot_n, dist, mark);
     pc = pn; dc = dn; wc = wn;
   }
 }
@@ -459,108 +439,10 @@ __global__ __launch_bounds__(BLOCK) void k_sssp_unit_weights16(const float* __re
   if (__ballot(bad) && lane_id() == 0) *exact = 0;
 }
 
-// ---- heavy iterations: the edges by slice of their destination, that slice of the distances in LDS --------------------
-// The relax kernel below gathers the neighbour's distance for every edge: 4 bytes out of a 16 MB array in arbitrary order,
-// 80-100 G/s on this part whatever else the kernel does (profiles/r01/microbench.jsonl) -- the three heavy iterations of an
-// RMAT-22 run (80-100 M relaxations each) take 0.7-1.2 ms each, 2.8 of the run's 3.5 ms.  When most of the graph's edges
-// are in the frontier anyway, it is cheaper to stream ALL edges in an order that makes the destinations local: the
-// destination-sliced list (mgx_layout.hip) holds (src, dst, w) ordered by dst >> 14.  A workgroup takes a contiguous
-// piece of it; for each slice the piece touches it copies the slice's 16 384 distances into LDS, streams the edges (12
-// bytes each, coalesced; the source's frontier bit and distance are gathers too, but the sources ascend inside a slice:
-// neighbouring lanes ask for neighbouring or equal words), folds the candidates with ds_min, and at the end writes back
-// what became smaller (atomicMin on the array, a mark for the next frontier) -- 16 384 coalesced compares instead of a
-// gather per edge.  A slice of which the piece holds only a few edges is not worth the copy: those edges take the
-// gather + atomicMin route of the other kernel.
-// MEASURED (RMAT-22, MGX_SSSP_SLICED=3): distances identical, but no gain -- the first heavy iteration takes 0.89 ms this
-// way too (1.6 GB of triples at 1.8 TB/s: the LDS minima of a slice full of hubs collide, and what a workgroup found only
-// reaches the array at the end of its piece, so the same iteration propagates less: 456 M relaxations instead of 346 M
-// for one source).  Left in as an option (the list is only built when the switch asks for it).
-constexpr int SSSP_SLICE_SHIFT = 14;
-constexpr int SSSP_SLICE_V = 1 << SSSP_SLICE_SHIFT;        // 64 KB of distances: the dynamic LDS of k_sssp_relax
-constexpr u32 SSSP_SLICE_MIN_EDGES = 4096;                  // fewer edges of a slice in a workgroup's piece: no LDS copy
-
-#ifdef MGX_LAB
-template <int NT>
-__device__ __forceinline__ void sssp_sliced_body(const sssp_args_t& a, u32* const lds) {
-  const u32 m = (u32)a.m_edges;                         // (int32 CSR: m < 2^31)
-  const u32 W = gridDim.x;
-  const u32 chunk = ((m + W - 1u) / W + 1023u) & ~1023u;
-  const u64 pb64 = (u64)blockIdx.x * chunk;
-  if (pb64 >= (u64)m) return;
-  const u32 pb = (u32)pb64;
-  const u32 pe = (u64)pb + chunk < (u64)m ? pb + chunk : m;
-  const int* __restrict__ esrc = a.e_src;
-  const int* __restrict__ edst = a.e_dst;
-  const float* __restrict__ ew = a.e_w;
-  const u32* __restrict__ fbits = a.frontier_bits;
-  u32* dist = a.dist;
-  unsigned char* mark = a.mark;
-  // the slice of the first edge: last s with slice_off[s] <= pb (uniform binary search)
-  int sl;
-  {
-    int lo = 0, hi = a.slices;
-    while (hi - lo > 1) { const int mid = lo + (hi - lo) / 2; if ((u32)a.slice_off[mid] <= pb) lo = mid; else hi = mid; }
-    sl = lo;
-  }
-  constexpr int K = 4;
-  u32 pos = pb;
-  while (pos < pe) {
-    while (sl + 1 < a.slices && (u32)a.slice_off[sl + 1] <= pos) ++sl;
-    const u32 s_end = sl + 1 < a.slices ? (u32)a.slice_off[sl + 1] : m;
-    const u32 seg_end = s_end < pe ? s_end : pe;
-    const u32 lo_v = (u32)sl << a.slice_shift;
-    const u32 cnt_v = (u32)a.n - lo_v < (u32)SSSP_SLICE_V ? (u32)a.n - lo_v : (u32)SSSP_SLICE_V;
-    const bool in_lds = seg_end - pos >= SSSP_SLICE_MIN_EDGES;       // (uniform)
-    if (in_lds) {
-      for (u32 j = threadIdx.x; j < (u32)SSSP_SLICE_V; j += NT) lds[j] = j < cnt_v ? dist[lo_v + j] : SSSP_INF_BITS;
-      __syncthreads();
-    }
-    for (u32 r0 = pos; r0 < seg_end; r0 += (u32)NT * K) {
-      u32 sv[K], dv[K];
-      float wv[K];
-      bool in[K];
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const u32 i = r0 + (u32)k * NT + threadIdx.x;
-        in[k] = i < seg_end;
-        const u32 j = in[k] ? i : m;                 // (the padding behind the list: readable)
-        sv[k] = (u32)esrc[j]; dv[k] = (u32)edst[j]; wv[k] = ew[j];
-      }
-      u32 fw[K];
-#pragma unroll
-      for (int k = 0; k < K; ++k) fw[k] = fbits[in[k] ? sv[k] >> 5 : 0u];
-      u32 du[K];
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        in[k] = in[k] && ((fw[k] >> (sv[k] & 31u)) & 1u);
-        du[k] = dist[in[k] ? sv[k] : 0u];
-      }
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        if (in[k] && du[k] != SSSP_INF_BITS) {
-          const u32 cand = __float_as_uint(__uint_as_float(du[k]) + wv[k]);
-          if (in_lds) {
-            atomicMin(&lds[dv[k] - lo_v], cand);
-          } else if (cand < dist[dv[k]]) {
-            if (cand < atomicMin(dist + dv[k], cand)) mark[dv[k]] = 1;
-          }
-        }
-      }
-    }
-    if (in_lds) {
-      __syncthreads();
-      for (u32 j = threadIdx.x; j < cnt_v; j += NT) {
-        const u32 v = lds[j];
-        if (v < dist[lo_v + j]) {
-          if (v < atomicMin(dist + lo_v + j, v)) mark[lo_v + j] = 1;
-        }
-      }
-      __syncthreads();
-    }
-    pos = seg_end;
-  }
-}
-#endif  // MGX_LAB
+// (A destination-sliced list of ALL edges as (src, dst, w) triples with a slice of the distances in LDS was the option MGX_SSSP_SLICED
+// until round 6: distances identical, the first heavy RMAT-22 iteration 0.89 ms that way too -- LDS minima of a slice full of hubs collide,
+// and what a workgroup finds reaches the array only at the end of its piece, so the iteration propagates less: 456 M relaxations
+// instead of 346 M.  Lost twice (rounds 2 and 5), removed; the code is in the history of this file and of mgx_layout.hip.)
 
 // bounds of the first HOTN distances into LDS (two per word); returns how many there are.  All loads first, then the stores
 // (the plain loop compiles to load - wait - store per trip: sixteen dependent round trips at the start of every workgroup;
@@ -588,31 +470,18 @@ __device__ __forceinline__ u32 sssp_load_bounds(const u32* __restrict__ dist, in
 // iteration is heavy -- then k_sssp_relax did (the same grid-uniform test on the same stable sizes).  A launch of its own
 // for the shape that suits a sweep whose cost is its distance gathers (mgx/nreduce.hpp measured the same trade): ONE
 // workgroup per CU, 128 registers per lane, and the bounds of the first SSSP_HOTN_DENSE vertices in LDS.
-constexpr int SSSP_HOTN_DENSE = 73728;             // 144 KB of 16-bit bounds ...
-constexpr int SSSP_HOTN_LIVE = 36864;              // ... or of 32-bit live minima (LIVE)
-template <int NT, bool LIVE>
+constexpr int SSSP_HOTN_DENSE = 73728;             // 144 KB of 16-bit bounds
+template <int NT>
 __global__ __launch_bounds__(NT, 4) void k_sssp_relax_dense(sssp_args_t a, int it) {
   extern __shared__ __attribute__((aligned(16))) u32 s_hot_dense[];
   const u64 cur = a.ctrl->cursor[it % 3];
   const u32 E = (u32)(cur & BFS_EMASK);
   if ((cur >> BFS_VSHIFT) == 0 || !a.ub_w || (u64)E * (u64)a.dense_div < a.m_edges) return;
-  u32 hot_n;
-  if (LIVE) {
-    hot_n = (u32)a.n < (u32)SSSP_HOTN_LIVE ? (u32)a.n : (u32)SSSP_HOTN_LIVE;
-    constexpr int IT = (SSSP_HOTN_LIVE + NT - 1) / NT;
-    u32 dv[IT];
-#pragma unroll
-    for (int k = 0; k < IT; ++k) { const u32 i = (u32)k * NT + threadIdx.x; dv[k] = a.dist[i < hot_n ? i : 0u]; }
-#pragma unroll
-    for (int k = 0; k < IT; ++k) { const u32 i = (u32)k * NT + threadIdx.x; if (i < hot_n) s_hot_dense[i] = dv[k]; }
-    __syncthreads();
-  } else {
-    hot_n = sssp_load_bounds<NT, SSSP_HOTN_DENSE>(a.dist, a.n, s_hot_dense);
-  }
-  if (a.ub_col24 && a.ub_w16) sssp_dense_long<NT, LIVE, true, true>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);      // (grid-uniform)
-  else if (a.ub_col24) sssp_dense_long<NT, LIVE, true, false>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);
-  else sssp_dense_long<NT, LIVE, false, false>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);
-  sssp_dense_short<NT, LIVE>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);
+  const u32 hot_n = sssp_load_bounds<NT, SSSP_HOTN_DENSE>(a.dist, a.n, s_hot_dense);
+  if (a.ub_col24 && a.ub_w16) sssp_dense_long<NT, true, true>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);      // (grid-uniform)
+  else if (a.ub_col24) sssp_dense_long<NT, true, false>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);
+  else sssp_dense_long<NT, false, false>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);
+  sssp_dense_short<NT>(a, s_hot_dense, hot_n, blockIdx.x, gridDim.x);
 }
 
 template <int NT>
@@ -643,12 +512,6 @@ __global__ __launch_bounds__(NT, 8) void k_sssp_relax(sssp_args_t a, int it) {
   unsigned char* mark = a.mark;
 
   extern __shared__ __attribute__((aligned(16))) u32 s_hot[];        // SSSP_HOTN / 2 words: two bounds per word
-#ifdef MGX_LAB   // (MGX_SSSP_SLICED: distances identical, measured no faster -- lab builds only)
-  if (a.e_src && (u64)E * (u64)a.sliced_div >= a.m_edges) {            // a heavy iteration (grid-uniform): the edges by slice
-    sssp_sliced_body<NT>(a, s_hot);
-    return;
-  }
-#endif
   if (a.ub_w && (u64)E * (u64)a.dense_div >= a.m_edges) return;     // a heavy iteration (grid-uniform): k_sssp_relax_dense's
   const bool use_hot = E >= a.hot_min_edges;
   const u32 hot_n = use_hot ? sssp_load_bounds<NT, SSSP_HOTN>(dist, a.n, s_hot) : 0u;
@@ -950,7 +813,7 @@ __global__ __launch_bounds__(NT, 4) void k_sssp_build2(sssp_args_t a, int it) {
       }
       *mp = keep;
     }
-    if (a.frontier_bits) ((unsigned short*)a.frontier_bits)[i0 >> 4] = (unsigned short)new16;    // the next frontier as a bitmap (sssp_sliced_body)
+    if (a.frontier_bits) ((unsigned short*)a.frontier_bits)[i0 >> 4] = (unsigned short)new16;    // the next frontier as a bitmap (the sweep: sssp_dense_*)
   }
   if (a.delta > 0.f) {               // (grid-uniform) what stays behind: count and smallest distance, one atomic pair per wave
     const u32 wn = wave_sum(far_n);
@@ -1016,11 +879,8 @@ struct sssp_fused_state_t {
   mem_t<unsigned char> mark;
   mem_t<u32> dist_layout;            // only with a layout: distances in layout order
   mem_t<u32> q_row[2], q_off[2], q_du[2];
-  mem_t<u32> frontier_bits;          // the frontier as a bitmap (sssp_sliced_body; allocated on demand)
-  bool dense_live = false;           // (lab builds, MGX_SSSP_LIVE=1) the heavy iterations' LDS table as 32-bit minima kept current by the workgroup
+  mem_t<u32> frontier_bits;          // the frontier as a bitmap (the sweep; allocated on demand)
   unsigned dense_div = 4;            // an iteration whose frontier holds >= m / dense_div edges sweeps the unit blocks (sssp_dense_*; 0: never)
-  unsigned sliced_div = 0;           // an iteration whose frontier holds >= m / sliced_div edges streams the sliced edge list (0: never --
-                                     // the default: measured 2.59 ms (div 3) / 2.54 (2) / 2.82 (6) against 2.47 ms without, RMAT-22)
   mem_t<bfs_ctrl_t> ctrl;
   bfs_ctrl_t* host_ctrl = nullptr;
   int n = 0;
@@ -1067,32 +927,12 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   a.delta = st.delta;
   const char* const bl = getenv("MGX_SSSP_BUILD_LIST");            // (=1: the list-based queue build, k_sssp_build)
   const bool build2 = !(bl && atoi(bl) != 0) && ((uintptr_t)a.row_offsets % 16 == 0);
-  // heavy iterations over the destination-sliced edge list (needs the frontier bitmap k_sssp_build2 writes)
-  unsigned sdiv = st.sliced_div;
-#ifdef MGX_LAB
-  if (const char* e = getenv("MGX_SSSP_SLICED")) sdiv = (unsigned)atoi(e);
-#else
-  sdiv = 0;                                                        // (the sliced list is a lab shape: measured no faster)
-#endif
-  const bool sliced = layout && layout->e_src && layout->slices > 0 && layout->slice_shift == SSSP_SLICE_SHIFT && build2 && sdiv > 0 && a.delta == 0.f;
-  if (sliced && !st.frontier_bits.size()) st.frontier_bits = mem_t<u32>(((size_t)st.n + 31) / 32 + 4, ctx);
-  a.e_src = sliced ? layout->e_src : nullptr;
-  a.e_dst = sliced ? layout->e_dst : nullptr;
-  a.e_w = sliced ? layout->e_w : nullptr;
-  a.slice_off = sliced ? layout->slice_off : nullptr;
-  a.slices = sliced ? layout->slices : 0;
-  a.slice_shift = SSSP_SLICE_SHIFT;
-  a.m_edges = sliced ? (unsigned long long)layout->m_edges : 0ull;
-  a.sliced_div = sdiv;
-  a.frontier_bits = sliced ? st.frontier_bits.data() : nullptr;
+  a.m_edges = 0ull;
+  a.frontier_bits = nullptr;
   // heavy iterations as a sweep over the layout's unit blocks and degree classes (sssp_dense_*): needs the frontier as a
   // bitmap (k_sssp_build2 writes it) and the plain loop (near / far buckets park vertices outside the queue)
   unsigned ddiv = st.dense_div;
   if (const char* e = getenv("MGX_SSSP_DENSE")) ddiv = (unsigned)atoi(e);
-  bool live = st.dense_live;
-#ifdef MGX_LAB       // (32-bit minima the workgroup keeps current instead of 16-bit bounds: measured 2.56 against 1.88 ms per RMAT-22 source)
-  if (const char* e = getenv("MGX_SSSP_LIVE")) live = atoi(e) != 0;
-#endif
   const bool dense = layout && layout->ub_w && (layout->ub_col || layout->ub_col24) && layout->ub_cnt && layout->ub_owner && layout->ub_units_pad >= 16 &&
                      layout->vs_v[3] >= layout->vs_v[0] && layout->m_edges > 0 && build2 && ddiv > 0 && a.delta == 0.f;
   if (dense && !st.frontier_bits.size()) st.frontier_bits = mem_t<u32>(((size_t)st.n + 31) / 32 + 4, ctx);
@@ -1118,10 +958,7 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   static unsigned char attr_seen[64] = {};
   if (device_once_t once{attr_seen}) {
     MGX_HIP(hipFuncSetAttribute((const void*)k_sssp_relax<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, SSSP_HOTN * 2));
-    MGX_HIP(hipFuncSetAttribute((const void*)(k_sssp_relax_dense<1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-#ifdef MGX_LAB
-    MGX_HIP(hipFuncSetAttribute((const void*)(k_sssp_relax_dense<1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-#endif
+    MGX_HIP(hipFuncSetAttribute((const void*)(k_sssp_relax_dense<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   }
   int it = 0;
   st.relax_ms = 0.0;
@@ -1133,11 +970,7 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
     for (int i = 0; i < nit; ++i, ++it) {
       if (st.time_kernels) MGX_HIP(hipEventRecord(st.ev[2 * i], s));
       hipLaunchKernelGGL(k_sssp_relax<1024>, dim3(ctx.num_cus * 2), dim3(1024), SSSP_HOTN * 2, s, a, it);
-#ifdef MGX_LAB
-      if (dense && live) hipLaunchKernelGGL((k_sssp_relax_dense<1024, true>), dim3(ctx.num_cus), dim3(1024), SSSP_HOTN_LIVE * 4, s, a, it);
-      else
-#endif
-      if (dense) hipLaunchKernelGGL((k_sssp_relax_dense<1024, false>), dim3(ctx.num_cus), dim3(1024), SSSP_HOTN_DENSE * 2, s, a, it);
+      if (dense) hipLaunchKernelGGL((k_sssp_relax_dense<1024>), dim3(ctx.num_cus), dim3(1024), SSSP_HOTN_DENSE * 2, s, a, it);
       if (st.time_kernels) MGX_HIP(hipEventRecord(st.ev[2 * i + 1], s));
       if (build2) hipLaunchKernelGGL(k_sssp_build2<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, it);
       else hipLaunchKernelGGL(k_sssp_build<512>, dim3(bfs_build_grid(st.n, 512)), dim3(512), 0, s, a, it);

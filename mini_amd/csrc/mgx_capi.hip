@@ -156,9 +156,9 @@ static void ensure_nr_slices(mgx_graph_s* g) {
   standard_context_t& ctx = *g->c->ctx;
   const unsigned S = (unsigned)mgx::NR_HOTV;
   const long long n = G.num_nodes;
-  int slices = (int)((n + S - 1) / S);
-  if (slices > mgx::NRS_MAX_SLICES) slices = mgx::NRS_MAX_SLICES;
-  if (const char* e = getenv("MGX_NR_SLICES")) { const int v = atoi(e); if (v >= 1 && v < slices) slices = v; }     // (tests: a tail on small graphs)
+  const int all = (int)std::min<long long>((n + S - 1) / S, (long long)mgx::NRS_MAX_SLICES);      // (slices the id range has)
+  int slices = std::min(all, mgx::nrs_default_slices(n));
+  if (const char* e = getenv("MGX_NR_SLICES")) { const int v = atoi(e); if (v >= 1) slices = std::min(v, all); }   // (tests: a tail on small graphs, many slices on mid-size ones)
   const int rows = (int)G.vs_v[0];
   void* mu = nullptr;
   unsigned* off = nullptr;
@@ -395,7 +395,6 @@ int mgx_graph_attach_layout(mgx_graph_t g, const int* d_row_offsets, const int* 
   G.d_new_of_old = mem_t<int>::borrow((int*)d_new_of_old, (size_t)G.num_nodes);
   G.d_old_of_new = mem_t<int>::borrow((int*)d_old_of_new, (size_t)G.num_nodes);
   G.has_layout = true;
-  G.sliced_tried = false; G.sliced_slices = 0;
   G.vs_edges = 0; G.vs_dummy = 0; G.vs_long_min = 0;      // (borrowed arrays: no padding behind them, sortedness not checked)
   G.d_cold_owner = mem_t<int>(); G.d_cold_dst = mem_t<int>(); G.d_colds_owner = mem_t<int>(); G.d_colds_dst = mem_t<int>();
   G.d_cold_pk = mem_t<unsigned>(); G.d_cold_cbase = mem_t<unsigned>(); G.cold_pk_mask = 0;
@@ -412,7 +411,6 @@ int mgx_graph_attach_layout_weights(mgx_graph_t g, const float* d_layout_weights
   graph_device_t& G = *g->g;
   G.d_layout_col_values = mem_t<float>::borrow((float*)d_layout_weights, (size_t)G.num_edges);
   G.has_layout_weights = true;
-  G.sliced_tried = false; G.sliced_slices = 0;
   MGX_CATCH
 }
 extern "C" int mgx_layout_build_device(const int* ro, const int* ci, const float* w, int n, long long m, int* lro, int* lci,
@@ -669,11 +667,10 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
   G.d_new_of_old = std::move(n2o);
   G.d_old_of_new = std::move(o2n);
   G.has_layout = true;
-  G.sliced_tried = false; G.sliced_slices = 0;
   if (with_weights) { G.d_layout_col_values = std::move(lw); G.has_layout_weights = true; }
   build_unit_blocks(g);
   // degree classes of the short rows (the layout is sorted by degree): boundaries by binary search on a host copy
-  G.vs_edges = 0; G.vs_dummy = 0; G.vs_long_min = 0; G.d_ss_tab = mem_t<unsigned>();
+  G.vs_edges = 0; G.vs_dummy = 0; G.vs_long_min = 0;
   {
     int long_min = mgx::LONG_MIN_DEFAULT;
     if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
@@ -693,18 +690,6 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
       G.vs_edges = (unsigned)(h[b3] - h[b0]);
       G.vs_dummy = (unsigned)m + 4u;
       G.vs_long_min = long_min;
-#ifdef MGX_LAB
-      // the short rows as one stream (mgx/bfs_fused_sshort.hpp): first entry and first row of every degree's region
-      std::vector<unsigned> tab((size_t)mgx::BFS_SS_TAB_WORDS, 0u);
-      for (int d = 0; d <= mgx::BFS_SS_MAXDEG; ++d) {
-        const unsigned fr = first_below(d + 1);          // first row of degree <= d, i.e. of the region of degree d
-        const unsigned row = d >= long_min ? b0 : std::max(b0, fr);
-        tab[(size_t)d] = (unsigned)h[row];
-        tab[(size_t)(mgx::BFS_SS_MAXDEG + 1 + d)] = row;
-      }
-      G.d_ss_tab = mem_t<unsigned>(tab.size(), ctx);
-      MGX_HIP(mgx::htod(G.d_ss_tab.data(), tab.data(), tab.size()));
-#endif
     }
   }
 build_cold_lists(g);
@@ -762,7 +747,7 @@ int mgx_graph_layout_info(mgx_graph_t g, int64_t* out8) {
   auto bytes = [](auto& m) -> int64_t { return m.owned() ? (int64_t)(m.size() * sizeof(*m.data())) : 0; };
   out8[7] = bytes(G.d_layout_row_offsets) + bytes(G.d_layout_col_indices) + bytes(G.d_layout_col_values) + bytes(G.d_new_of_old) + bytes(G.d_old_of_new) +
             bytes(G.d_ub_col) + bytes(G.d_ub_col24) + bytes(G.d_ub_owner) + bytes(G.d_ubh_col24) + bytes(G.d_ubh_owner) + bytes(G.d_ub_w) + bytes(G.d_ub_w16) +
-            bytes(G.d_ub_cnt) + bytes(G.d_ub_first) + bytes(G.d_ss_tab) + bytes(G.d_cold_owner) + bytes(G.d_cold_dst) + bytes(G.d_cold_pk) + bytes(G.d_cold_cbase) +
+            bytes(G.d_ub_cnt) + bytes(G.d_ub_first) + bytes(G.d_cold_owner) + bytes(G.d_cold_dst) + bytes(G.d_cold_pk) + bytes(G.d_cold_cbase) +
             bytes(G.d_colds_owner) + bytes(G.d_colds_dst) + bytes(G.d_nrs_mu) + bytes(G.d_nrs_off) + bytes(G.d_nr_pos);
   MGX_CATCH
 }
@@ -2115,34 +2100,6 @@ int mgx_sssp_enact(mgx_sssp_t p, float queue_sizing, int64_t* stats) {
   }
   MGX_CATCH
 }
-extern "C" int mgx_sliced_build_device(const int* ro, const int* ci, const float* w, int n, long long m, int shift, int slices,
-                                       int* e_src, int* e_dst, float* e_w, int* slice_off, hipStream_t stream);   // mgx_layout.hip
-// The destination-sliced edge list of the weighted layout, once per graph and only when MGX_SSSP_SLICED=N asks for it: 12 bytes per edge.
-static void ensure_sliced_edges(mgx_graph_s* g) {
-  graph_device_t& G = *g->g;
-  if (G.sliced_tried) return;
-  G.sliced_tried = true;
-  G.sliced_slices = 0;
-#ifndef MGX_LAB
-  G.sliced_tried = false;                                           // (a lab shape: measured no faster, sssp_fused.hpp)
-  return;
-#endif
-  const char* const e = getenv("MGX_SSSP_SLICED");                  // (opt-in)
-  if (!e || atoi(e) <= 0) { G.sliced_tried = false; return; }
-  if (!G.has_layout || !G.has_layout_weights || G.num_edges <= 0 || G.num_nodes <= 0) return;
-  standard_context_t& ctx = *g->c->ctx;
-  const size_t m = (size_t)G.num_edges;
-  const int slices = (int)(((long long)G.num_nodes + mgx::SSSP_SLICE_V - 1) >> mgx::SSSP_SLICE_SHIFT);
-  ctx.synchronize();
-  mem_t<int> es(m + 4096, ctx), ed(m + 4096, ctx), so((size_t)slices + 2, ctx);
-  mem_t<float> ew(m + 4096, ctx);
-  const int rc = mgx_sliced_build_device(G.d_layout_row_offsets.data(), G.d_layout_col_indices.data(), G.d_layout_col_values.data(),
-                                         G.num_nodes, (long long)m, mgx::SSSP_SLICE_SHIFT, slices, es.data(), ed.data(), ew.data(),
-                                         so.data(), ctx.stream());
-  if (rc != 0) throw mgx::mgx_error(MGX_E_HIP, std::string("sliced edge list: ") + hipGetErrorString((hipError_t)rc));
-  G.d_e_src = std::move(es); G.d_e_dst = std::move(ed); G.d_e_w = std::move(ew); G.d_slice_off = std::move(so);
-  G.sliced_slices = slices;
-}
 // Weights of the unit blocks' entries (mgx/sssp_fused.hpp: sssp_dense_long), once per graph at its first fused SSSP run:
 // 4 bytes per padded long-row entry; skipped (the queue walk serves every iteration) when the memory is not there.
 static void ensure_unit_weights(mgx_graph_s* g) {
@@ -2203,12 +2160,6 @@ int mgx_sssp_run_delta(mgx_sssp_t p, int src, float delta, int64_t* stats) {
       layout.ub_units_pad = (unsigned)G.ub_units_pad;
       for (int i = 0; i < 4; ++i) layout.vs_v[i] = G.vs_v[i];
       layout.m_edges = (long long)G.num_edges;
-    }
-    ensure_sliced_edges(p->g);
-    if (G.sliced_slices > 0) {
-      layout.e_src = G.d_e_src.data(); layout.e_dst = G.d_e_dst.data(); layout.e_w = G.d_e_w.data();
-      layout.slice_off = G.d_slice_off.data();
-      layout.slices = G.sliced_slices; layout.slice_shift = mgx::SSSP_SLICE_SHIFT; layout.m_edges = (long long)G.num_edges;
     }
   }
   mgx::sssp_fused_run(*p->fused, G.d_row_offsets.data(), G.d_col_indices.data(), G.d_col_values.data(),

@@ -463,56 +463,6 @@ extern "C" int mgx_csc_build_device(const int* ro, const int* ci, const float* w
   return 0;
 }
 
-// ---- destination-sliced edge list (mgx/sssp_fused.hpp: sssp_sliced_body) ---------------------------------------------
-// All m edges as (src, dst, weight) triples ordered by the SLICE of the id range dst lies in (slice = dst >> shift), and
-// by src inside a slice (a stable sort of the CSR's edge order by slice).  A workgroup that takes edges of one slice can
-// keep that slice of the distance array in LDS: the relaxations of a heavy Bellman-Ford iteration then cost a coalesced
-// stream of 12 bytes per edge instead of a gather from a 16 MB array per edge.
-namespace {
-__global__ void k_slice_keys(const int* __restrict__ ci, long long m, int shift, int* __restrict__ key) {
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < m; e += (long long)gridDim.x * blockDim.x)
-    key[e] = (int)((unsigned)ci[e] >> shift);
-}
-__global__ void k_slice_gather(const int* __restrict__ sorted_edge, const int* __restrict__ row_of_edge, const int* __restrict__ ci,
-                               const float* __restrict__ w, long long m, int* __restrict__ e_src, int* __restrict__ e_dst,
-                               float* __restrict__ e_w) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
-    const int e = sorted_edge[i];
-    e_src[i] = row_of_edge[e];
-    e_dst[i] = ci[e];
-    e_w[i] = w[e];
-  }
-}
-}  // namespace
-
-// e_src / e_dst / e_w: m + 4096 entries each (device, caller-allocated; the tail is padding: src = n, dst = 0, w = 0);
-// slice_off: slices + 1 ints (device, caller-allocated): the edges of slice s are [slice_off[s], slice_off[s + 1]).
-extern "C" int mgx_sliced_build_device(const int* ro, const int* ci, const float* w, int n, long long m, int shift, int slices,
-                                       int* e_src, int* e_dst, float* e_w, int* slice_off, hipStream_t stream) {
-  if (n <= 0 || m <= 0) return 0;
-  tmp_t row_of_edge, edge_id, key, key_sorted, sorted_edge, scratch;
-  LAY_TRY(row_of_edge.alloc((size_t)m * 4)); LAY_TRY(edge_id.alloc((size_t)m * 4)); LAY_TRY(key.alloc((size_t)m * 4));
-  LAY_TRY(key_sorted.alloc((size_t)m * 4)); LAY_TRY(sorted_edge.alloc((size_t)m * 4));
-  hipLaunchKernelGGL(k_edge_rows, dim3(8192), dim3(256), 0, stream, ro, n, m, row_of_edge.as<int>(), edge_id.as<int>());
-  hipLaunchKernelGGL(k_slice_keys, dim3(8192), dim3(256), 0, stream, ci, m, shift, key.as<int>());
-  int bits = 1;
-  while (bits < 32 && (1ll << bits) < (long long)slices) ++bits;
-  size_t bytes = 0;
-  LAY_TRY(rocprim::radix_sort_pairs(nullptr, bytes, key.as<int>(), key_sorted.as<int>(), edge_id.as<int>(), sorted_edge.as<int>(),
-                                    (size_t)m, 0, bits, stream));
-  LAY_TRY(scratch.alloc(bytes));
-  LAY_TRY(rocprim::radix_sort_pairs(scratch.p, bytes, key.as<int>(), key_sorted.as<int>(), edge_id.as<int>(), sorted_edge.as<int>(),
-                                    (size_t)m, 0, bits, stream));
-  hipLaunchKernelGGL(k_slice_gather, dim3(8192), dim3(256), 0, stream, sorted_edge.as<int>(), row_of_edge.as<int>(), ci, w, m, e_src,
-                     e_dst, e_w);
-  hipLaunchKernelGGL(k_csc_offsets, dim3((unsigned)((slices + 1 + 255) / 256)), dim3(256), 0, stream, key_sorted.as<int>(), m, slices,
-                     slice_off);
-  hipLaunchKernelGGL(k_cold_pad, dim3(16), dim3(256), 0, stream, 0, 4096, n, e_src + m, e_dst + m);     // owner = n, dst = -1 ...
-  LAY_TRY(hipMemsetAsync(e_dst + m, 0, 4096 * 4, stream));                                              // ... dst = 0 here
-  LAY_TRY(hipMemsetAsync(e_w + m, 0, 4096 * 4, stream));
-  return (int)hipStreamSynchronize(stream);
-}
-
 // ---- a rank's shard of the partitioned R-MAT graph (mgx/bfs_dist2.hpp; mgx_dbfs2_shard_*) ------------------------------
 // What mini_amd.dist_bfs.rmat_cyclic_shard did with torch device ops, inside the library: the symmetrised R-MAT graph of
 // (scale, edgefactor, seed) under the generation-2 layout -- vertices renumbered hub-first by GLOBAL degree (every rank

@@ -14,8 +14,7 @@ def pytest_configure(config):
                                        "`python __graft_entry__.py --lab`): experiment shapes that are not in the product")
 
 
-LAB_ENV_KEYS = ("MGX_BFS_SSTREAM", "MGX_BFS_FLAGS", "MGX_BFS_DENSE_DIAG",
-                "MGX_BFS_BUILD_DIAG", "MGX_SSSP_SLICED")
+LAB_ENV_KEYS = ("MGX_BFS_FLAGS", "MGX_BFS_DENSE_DIAG", "MGX_BFS_BUILD_DIAG")
 
 
 def needs_lab(env):

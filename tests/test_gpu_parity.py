@@ -716,10 +716,6 @@ VARIANTS = [{}, {"MGX_BFS_COLD_TEST": "1"}, {"MGX_BFS_COLD_TEST": "1", "MGX_BFS_
             {"MGX_BFS_LAZY": "1048576", "MGX_BFS_MERGED_PUSH": "0"},
             # the chain of small levels at the start: inside slot 0's push launch instead of a launch of its own
             {"MGX_BFS_SEED_CHAIN": "0"}, {"MGX_BFS_SEED_CHAIN": "0", "MGX_BFS_DENSE": "1000000", "MGX_BFS_LAZY": "1048576"},
-            # dense short rows as one stream of entries (bfs_fused_sshort.hpp) / vertex by vertex
-            {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_SSTREAM": "1"}, {"MGX_BFS_SSTREAM": "1"},
-            {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_LONG_MIN": "8", "MGX_BFS_DENSE": "1000000", "MGX_BFS_SSTREAM": "1"},
-            {"MGX_BFS_VSHORT": "1000000", "MGX_BFS_LONG_MIN": "1", "MGX_BFS_SSTREAM": "1"},
             {"MGX_BFS_MINI": "2"}, {"MGX_BFS_MINI": "0", "MGX_BFS_TAIL_FRONT": "0"}, {"MGX_BFS_TAIL_CHAIN": "0"}, {"MGX_BFS_CHAIN_BIG_EDGES": "100"}, {"MGX_BFS_CHAIN_MAX_EDGES": "64", "MGX_BFS_CHAIN_BIG_EDGES": "12288", "MGX_BFS_LAZY": "1048576"},
             # round 4: the unit blocks' 32-bit entries instead of the 24-bit copy (every level on them / by the default rule), the deferred
             # range shortened to one run and to a third, the per-source launch plan off / on with M launches forced on small graphs
@@ -766,18 +762,14 @@ def test_bfs_kernel_variants_on_random_graphs(gpu_ctx, oracle, monkeypatch, vari
             assert st["m_t"] == int(deg[want >= 0].sum())
 
 
-@pytest.mark.parametrize("build_list", [0, 1, 2])
+@pytest.mark.parametrize("build_list", [0, 1])
 @pytest.mark.parametrize("hot_min_edges", [0, 1 << 30])
 def test_sssp_fused_with_and_without_lds_distance_bounds(gpu_ctx, oracle, monkeypatch, hot_min_edges, build_list):
     """the bfloat16 upper bounds of the hubs' distances (sssp_fused.hpp) forced on for every iteration, and off; the direct
-    queue build (k_sssp_build2) and the list-based one; the sliced edge list for heavy iterations"""
+    queue build (k_sssp_build2) and the list-based one"""
     import mini_amd
     monkeypatch.setenv("MGX_SSSP_HOT_MIN_EDGES", str(hot_min_edges))
-    monkeypatch.setenv("MGX_SSSP_BUILD_LIST", str(build_list & 1))
-    if build_list == 2:                                     # heavy iterations over the destination-sliced edge list (lab library)
-        from tests.conftest import skip_unless_lab
-        skip_unless_lab()
-        monkeypatch.setenv("MGX_SSSP_SLICED", "4")
+    monkeypatch.setenv("MGX_SSSP_BUILD_LIST", str(build_list))
     rng = np.random.default_rng(5 + (hot_min_edges > 0))
     for trial in range(4):
         n, ro, ci, _ = oracle.rmat_csr(int(rng.integers(8, 15)), int(rng.integers(2, 20)), int(rng.integers(1, 1 << 20)))
@@ -1247,6 +1239,44 @@ def test_sssp_fused_preds_form_a_shortest_path_tree(gpu_ctx, oracle, layout):
             sssp.run(src)
             assert np.array_equal(sssp.preds(), pred), "the predecessors differ between two runs"
         sssp.close()
+
+
+@pytest.mark.parametrize("slices", [0, 20, 52])
+def test_neighbour_reduce_many_slices_on_a_mid_size_graph(gpu_ctx, oracle, torch_mod, monkeypatch, slices):
+    """R-MAT 21 (2 M vertices: 52 slices of 40 000 in its id range) with the library's own cut (16 hot slices + tail: the fold takes a
+    row's ranges in ONE chunk), with 20 and with 52 hot slices (round 6, graphs above R-MAT 22: the fold goes round 2 / 4 times,
+    NRS_FOLD_CHUNK ranges at a time; 52 leaves the tail empty).  Integer min / max exact, float sums of small integers exact, against the
+    oracle's serial reduce on the same CSR."""
+    import mini_amd
+    from mini_amd import rmat
+    torch = torch_mod
+    if slices:
+        monkeypatch.setenv("MGX_NR_SLICES", str(slices))
+    g = rmat.rmat_csr(gpu_ctx, 21, 16, seed=2121)
+    n = g["n"]
+    graph = mini_amd.Graph.from_device(gpu_ctx, n, g["m"], g["row_offsets"], g["col_indices"]).build_layout()
+    ro, ci = g["row_offsets"].cpu().numpy(), g["col_indices"].cpu().numpy()
+    rng = np.random.default_rng(2100 + slices)
+    ids = np.arange(n, dtype=np.int32)
+    f = mini_amd.Frontier(gpu_ctx, n).load(ids)
+    vals = rng.integers(0, 4, size=n).astype(np.float32)
+    red = torch.full((n,), -1, dtype=torch.float32, device="cuda")
+    nz = mini_amd.segreduce(graph, f, torch.from_numpy(vals).cuda(), 0.0, red, "f32_plus")
+    want, wnz = oracle.neighbor_reduce_f32_plus(ro, ci, ids, vals, 0.0)
+    assert nz == wnz == len(ci)
+    assert np.array_equal(red.cpu().numpy(), want)
+    for op in ("i32_min", "i32_max"):
+        ivals = rng.integers(-100000, 100000, size=n).astype(np.int32)
+        ident = 2**31 - 1 if op == "i32_min" else -2**31
+        ired = torch.full((n,), 12345, dtype=torch.int32, device="cuda")
+        nz = mini_amd.segreduce(graph, f, torch.from_numpy(ivals).cuda(), ident, ired, op)
+        want, wnz = oracle.neighbor_reduce_i32(ro, ci, ids, ivals, ident, op == "i32_max")
+        assert nz == wnz
+        assert np.array_equal(ired.cpu().numpy(), want)
+    info = graph.nr_slices_info()
+    if os.environ.get("MGX_NR_SLICED", "1") != "0":
+        assert info["hot_slices"] == (slices if slices else 16)
+        assert (info["tail_mini_units"] > 0) == (slices != 52)
 
 
 @pytest.mark.parametrize("op", ["f32_plus", "i32_min", "i32_max"])

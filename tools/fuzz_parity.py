@@ -174,8 +174,7 @@ for name, n, ro, ci, w in graphs():
                      "MGX_BFS_TAIL_CHAIN": rng.choice(["", "0"]), "MGX_BFS_CHAIN_BIG_EDGES": rng.choice(["", "100", "12288"]),
                      "MGX_BFS_COLD": rng.choice(["", "0", "2", "1"]), "MGX_BFS_DEFER_REACH": rng.choice(["", "0/1", "4/1"]),
                      "MGX_BFS_MERGED_PULL": rng.choice(["", "0"]), "MGX_BFS_DO_CHAIN": rng.choice(["", "0"]),
-                     "MGX_BFS_SSTREAM": rng.choice(["", "1"]), "MGX_SSSP_BUILD_LIST": rng.choice(["", "1"]),
-                     "MGX_SSSP_SLICED": rng.choice(["", "", "3"]), "MGX_BFS_MINI": rng.choice(["", "0", "2"]),
+                     "MGX_SSSP_BUILD_LIST": rng.choice(["", "1"]), "MGX_BFS_MINI": rng.choice(["", "0", "2"]),
                      "MGX_SSSP_DENSE": rng.choice(["", "0", "1000000000"]),
                      # round 4: 24-bit unit blocks on / off, the deferred range, the per-source launch plan
                      "MGX_BFS_PACK24": rng.choice(["", "0"]), "MGX_BFS_DEFER_WORDS": rng.choice(["", "32", "4096", "0"]),
@@ -194,7 +193,7 @@ for name, n, ro, ci, w in graphs():
                 assert np.array_equal(bfs.labels(), want), (name, n, src, "do", alpha, direct, layout)
         for kk in ("MGX_BFS_CHAIN_MAX_EDGES", "MGX_BFS_DENSE", "MGX_BFS_LAZY", "MGX_BFS_VSHORT", "MGX_BFS_DEFER", "MGX_BFS_SEED_CHAIN",
                    "MGX_BFS_TAIL_CHAIN", "MGX_BFS_CHAIN_BIG_EDGES", "MGX_BFS_COLD", "MGX_BFS_DEFER_REACH", "MGX_BFS_MERGED_PULL",
-                   "MGX_BFS_DO_CHAIN", "MGX_BFS_SSTREAM", "MGX_BFS_MINI", "MGX_BFS_PACK24", "MGX_BFS_DEFER_WORDS", "MGX_BFS_SRC_PLAN"):
+                   "MGX_BFS_DO_CHAIN", "MGX_BFS_MINI", "MGX_BFS_PACK24", "MGX_BFS_DEFER_WORDS", "MGX_BFS_SRC_PLAN"):
             os.environ.pop(kk, None)
         if src == srcs[0] and (n <= 150000 or (n >= (1 << 20) and ran % 2 == 0)):
             # the partitioned engine's rank engines in this process: small graphs, and R-MAT 20 / 21 (the ranks' cold-edge pass);
@@ -222,9 +221,9 @@ for name, n, ro, ci, w in graphs():
                 os.environ.pop(kk, None)
             assert np.array_equal(got, want), (name, n, src, "partitioned", G, mode, dd, dknobs)
         dist, _, _ = orc.sssp_enact(ro, ci, w, src, 8.0)
-        sssp.run(src)                                  # (MGX_SSSP_BUILD_LIST / MGX_SSSP_SLICED: whatever the last draw left)
-        assert np.array_equal(sssp.distances(), dist), (name, n, src, "sssp", layout, os.environ.get("MGX_SSSP_BUILD_LIST"), os.environ.get("MGX_SSSP_SLICED"))
-        os.environ.pop("MGX_SSSP_BUILD_LIST", None); os.environ.pop("MGX_SSSP_SLICED", None)
+        sssp.run(src)                                  # (MGX_SSSP_BUILD_LIST: whatever the last draw left)
+        assert np.array_equal(sssp.distances(), dist), (name, n, src, "sssp", layout, os.environ.get("MGX_SSSP_BUILD_LIST"))
+        os.environ.pop("MGX_SSSP_BUILD_LIST", None)
     # a batch of sources (mgx_bfs_run_many): the counters of every traversal, the labels of the last one
     sts, reruns = bfs.run_many(srcs)
     for src, st in zip(srcs, sts):
