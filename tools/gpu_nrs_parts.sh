@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/nrs; mkdir -p $O; rm -f $O/parts.txt
 cd /tmp && export TMPDIR=/tmp
 for v in ${SLICED:-1 0}; do for p in ${PARTS:-1 2 3}; do
-  MGX_NR_SLICED=$v MGX_NR_PARTS=$p timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tp_${v}_$p -- python3 $R/bench.py --mode pr --steps 12 --warmup 2 --no-cpu-baseline --no-check > $O/tp_${v}_$p.log 2>&1
+  MGX_NR_SLICED=$v MGX_NR_PARTS=$p timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tp_${v}_$p -- python3 $R/bench.py --mode pr --scale ${SCALE:-22} --steps 12 --warmup 2 --no-cpu-baseline --no-check > $O/tp_${v}_$p.log 2>&1
   python3 - $O/tp_${v}_$p $v $p >> $O/parts.txt <<'PY'
 import csv, glob, sys
 d, v, p = sys.argv[1:4]
