@@ -76,6 +76,10 @@ for g in "uniform 22 16" "grid2d 22 4" "rmat 23 32" "rmat 24 16" "rmat 25 16" "r
   set -- $g
   timeout 600 python bench.py --graph $1 --scale $2 --steps $3 --warmup 2 --cpu-seconds 5 > $O/bench_$1_$2.log 2>&1
 done
+# (round 6) the neighbour-reduce above RMAT-22: hot slices by graph size
+for sc in 23 24 25; do
+  timeout 600 python bench.py --mode pr --scale $sc --steps 16 --warmup 2 --cpu-seconds 5 > $O/bench_pr_rmat_$sc.log 2>&1
+done
 timeout 600 python tools/dropin_cost.py 20 4 2>&1 | grep -v amdgpu.ids > $O/dropin_cost.log
 timeout 600 python tools/dropin_cost.py 22 4 2>&1 | grep -v amdgpu.ids >> $O/dropin_cost.log
 bash tools/gpu_trace_batch.sh "" 64 > /dev/null 2>&1
@@ -128,5 +132,6 @@ grep '^{' $O/bench.log | tail -1 > $O/keep/bench_line.json
 grep '^{' $O/bench_per_call.log | tail -1 > $O/keep/bench_line_per_call.json
 grep '^{' $O/bench_sssp.log | tail -1 > $O/keep/bench_line_sssp.json
 grep '^{' $O/bench_pr.log | tail -1 > $O/keep/bench_line_pr.json
+for sc in 23 24 25; do grep '^{' $O/bench_pr_rmat_$sc.log | tail -1 > $O/keep/bench_line_pr_rmat_$sc.json; done
 (echo "product library (mini_amd/libmgx.so), python -m pytest tests -q -m gpu:"; grep -E "passed|failed" $O/pytest_gpu.log | tail -1
  echo "lab library (MGX_LIB=mini_amd/libmgx_lab.so), the variant tests:"; grep -E "passed|failed" $O/pytest_gpu_lab.log | tail -1) > $O/keep/pytest_gpu_tail.txt
