@@ -365,6 +365,24 @@ def bench_bfs(args, ctx, stream):
             for f in parts[name]:
                 parts[name][f] += k[name][f]
     bfs.set_kernel_timing(0)
+    # ... and the levels of the PRODUCT launches (merged push, no events on the stream) from the stamps a level's opener takes on the device:
+    # a level's time runs from its opener to the next one's (push + queue build + whatever sits between them); levels are lined up by their
+    # distance from the traversal's biggest one
+    by_rel = {}
+    if mode == mini_amd.MGX_BFS_PUSH:
+        for s in timed[:32]:
+            bfs.run(s, mode, args.alpha)
+            tms, tr = bfs.level_times_ms(), bfs.level_trace()
+            L = min(len(tms), len(tr))
+            if L == 0:
+                continue
+            peak = max(range(L), key=lambda i: tr[i][1])
+            for i in range(L):
+                rel = max(-3, min(3, i - peak))
+                a = by_rel.setdefault(rel, [0, 0.0, 0, 0])
+                a[0] += 1; a[1] += tms[i] * 1e3; a[2] += tr[i][1]; a[3] += tr[i][0]
+    levels = [{"rel_to_peak": ("<=-3" if r == -3 else ">=3" if r == 3 else r), "levels": c, "us": round(us / c, 2), "edges": int(e / c), "vertices": int(v / c),
+               "frac": round((8.0 * e + 20.0 * v) / max(us * 1e-6, 1e-12) / 1e9 / HBM_PEAK_GBPS, 4)} for r, (c, us, e, v) in sorted(by_rel.items())]
 
     m_t = sum(st["m_t"] for st in stats)
     reached = sum(st["reached"] for st in stats)
@@ -420,6 +438,9 @@ def bench_bfs(args, ctx, stream):
                           "short_rows": {"alg_GBps": round((8.0 * parts["wave"]["edges"] + 12.0 * parts["wave"]["vertices"]) / max(short_ns, 1), 2),
                                          "us_per_traversal": round(short_ns / 1e3 / K, 2), "edges_share": round(parts["wave"]["edges"] / max(m_t, 1), 4)},
                           "note": "third pass, the launch split into its parts (k_bfs_push<false, 2> / <false, 3>) with events around each"},
+                "levels": levels or None,
+                "levels_note": "fourth pass (up to 32 of the same sources, one call each, the product's merged launches): mean time from a level's opener to "
+                               "the next one's by distance from the traversal's biggest level, (8 B/edge + 20 B/vertex) / that time / peak",
                 "all_level_kernels_alg_GBps": round(alg_bytes / max(kernel_ns / 1e9, 1e-12) / 1e9, 2),
                 "whole_bfs_alg_GBps": round(alg_bytes / (dev_ms / 1e3) / 1e9, 2),
                 "whole_bfs_frac": round(alg_bytes / (dev_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 5)}
