@@ -569,6 +569,24 @@ def bench_sssp(args, ctx, stream):
         k_launch += kt["launches"]; k_ns += kt["ns"]
         relax2 += st["relaxations"]; ftot2 += st["frontier_total"]
     sssp.set_kernel_timing(False)
+    # ... and the iterations of the product's launches from the device-side stamps (no events on the stream), lined up by their distance from
+    # the run's heaviest one: time from an iteration's opener to the next one's (relax + sweep + queue build)
+    by_rel = {}
+    for s in timed[:32]:
+        sssp.run(s)
+        tr = sssp.iteration_trace()
+        if not tr:
+            continue
+        peak = max(range(len(tr)), key=lambda i: tr[i][1])
+        for i, (nf_i, ne_i, ms_i) in enumerate(tr):
+            if ms_i <= 0:
+                continue
+            rel = max(-3, min(3, i - peak))
+            a = by_rel.setdefault(rel, [0, 0.0, 0, 0])
+            a[0] += 1; a[1] += ms_i * 1e3; a[2] += ne_i; a[3] += nf_i
+    iterations = [{"rel_to_heaviest": ("<=-3" if r == -3 else ">=3" if r == 3 else r), "iterations": c, "us": round(us / c, 2), "edges": int(e / c), "vertices": int(v / c),
+                   "G_relax_per_s": round(e / max(us, 1e-9) / 1e3, 1), "frac": round((12.0 * e + 24.0 * v) / max(us * 1e-6, 1e-12) / 1e9 / HBM_PEAK_GBPS, 4)}
+                  for r, (c, us, e, v) in sorted(by_rel.items())]
     # algorithmic bytes: 12 B per relaxation (column index, weight, dist[dst]) + 24 B per frontier vertex
     # (id, two offsets, dist[src], next-frontier entry, mark); the relax kernel's share: 12 B + 16 B
     alg_bytes = 12.0 * relax + 24.0 * ftot
@@ -585,6 +603,9 @@ def bench_sssp(args, ctx, stream):
                 "alg_bytes": "12 B per edge relaxation + 16 B per frontier vertex (this kernel's share of SURVEY 8d's 12 + 24; the "
                              "queue build moves the other 8 B per vertex)",
                 "timing": "HIP events around every launch of this kernel on the launch stream, second pass over the same %d sources" % len(timed),
+                "iterations": iterations or None,
+                "iterations_note": "third pass (up to 32 of the same sources): mean time from an iteration's opener to the next one's by distance from the "
+                                   "run's heaviest iteration, (12 B/relaxation + 24 B/vertex) / that time / peak",
                 "whole_run_alg_GBps": round(alg_bytes / (dev_ms / 1e3) / 1e9, 2),
                 "whole_run_frac": round(alg_bytes / (dev_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 5)}
     cpu, parity = None, None
