@@ -9,6 +9,7 @@
 #include <type_traits>
 
 #include "../mgx/lbs.hpp"
+#include "../mgx/env.hpp"
 #include "../mgx/nreduce.hpp"
 #include "../mgx/scan.hpp"
 #include "frontier.hxx"
@@ -29,7 +30,7 @@ struct is_pure_gather<F, typename std::enable_if<F::mgx_pure_gather>::type> : st
 
 // MGX_NR_SUBSET=0: frontiers that are not 0 .. n - 1 take the general kernel, as before round 6
 inline bool nr_subset_enabled() {
-  static const bool on = [] { const char* e = std::getenv("MGX_NR_SUBSET"); return !e || std::atoi(e) != 0; }();
+  static const bool on = [] { const char* e = mgx::env("MGX_NR_SUBSET"); return !e || std::atoi(e) != 0; }();
   return on;
 }
 
@@ -80,13 +81,13 @@ int neighborhood_kernel(std::shared_ptr<Problem> problem, std::shared_ptr<fronti
       L.big_rows = graph.nr_big_rows;
       L.n = graph.num_nodes;
       {
-        static const unsigned parts = [] { const char* e = std::getenv("MGX_NR_PARTS"); return e ? (unsigned)std::atoi(e) & 3u : 3u; }();
+        static const unsigned parts = [] { const char* e = mgx::env("MGX_NR_PARTS"); return e ? (unsigned)std::atoi(e) & 3u : 3u; }();
         L.parts = parts ? parts : 3u;
       }
       {
         // the long rows by slice of their destinations (MGX_NR_SLICED=0: the unit blocks, as before round 5), when the graph carries
         // them and the scratch arena holds a partial per mini-unit
-        static const bool sliced = [] { const char* e = std::getenv("MGX_NR_SLICED"); return !e || std::atoi(e) != 0; }();
+        static const bool sliced = [] { const char* e = mgx::env("MGX_NR_SLICED"); return !e || std::atoi(e) != 0; }();
         if (sliced && graph.nrs_units > 0 && graph.nrs_slices > 0 && graph.nrs_rows == graph.vs_v[0] && graph.d_nrs_mu.size() && graph.d_nrs_off.size() &&
             context.scratch_bytes >= mgx::nr_scratch_bytes(graph.num_nodes, graph.nrs_units, sizeof(Value))) {
           L.nrs_mu = (const uint4*)graph.d_nrs_mu.data();

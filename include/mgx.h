@@ -48,6 +48,10 @@ typedef struct mgx_dsssp_s* mgx_dsssp_t;
 typedef struct mgx_comm_s* mgx_comm_t;
 
 MGX_API int mgx_version(void);
+/* The environment switches the library reads (include/mgx/env.hpp: the one table, the one reader): returns how many there are; for
+ * 0 <= index < that, *name / *what (either may be NULL) point at the switch's name and a line about it (static strings).  Every switch
+ * selects between product paths the thresholds pick by size; none changes a result.  An empty value counts as unset. */
+MGX_API int mgx_env_switches(int index, const char** name, const char** what);
 MGX_API int mgx_build_is_lab(void); /* 1: built with -DMGX_LAB (experiment shapes and instrumented kernels compiled in: never the product) */
 MGX_API const char* mgx_strerror(int status);
 MGX_API const char* mgx_last_error(void); /* thread-local detail of the last failure */

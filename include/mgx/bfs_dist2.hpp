@@ -41,6 +41,7 @@
 
 #include "bfs_fused_run.hpp"
 #include "comm.hpp"
+#include "env.hpp"
 
 namespace mgx {
 
@@ -566,16 +567,16 @@ struct d2_state_t {
     fs.reset(new bfs_fused_state_t(n_global, ctx));
     // (a rank's short rows take the queue search, not the vertex-by-vertex walk the single-GPU threshold was re-tuned for in
     //  round 4: the ranks keep 64 unless the switch says otherwise)
-    if (!getenv("MGX_BFS_LONG_MIN")) fs->long_min = 64;
-    if (const char* e = getenv("MGX_BFS_COLD_TEST")) cold_forced = atoi(e);
-    if (const char* e = getenv("MGX_DIST_DECLARE_MUL")) declare_mul = (u32)atoi(e);
-    if (const char* e = getenv("MGX_DIST_SPARSE_PUSH")) sparse_push = atoi(e);
-    if (const char* e = getenv("MGX_DIST_FUSED_MERGE")) fused_merge = atoi(e);
-    if (const char* e = getenv("MGX_DIST_BUILD_LIST")) build_list = atoi(e);
-    if (const char* e = getenv("MGX_DIST_PUSH_SPLIT")) push_split = atoi(e);
+    if (!mgx::env("MGX_BFS_LONG_MIN")) fs->long_min = 64;
+    if (const char* e = mgx::env("MGX_BFS_COLD_TEST")) cold_forced = atoi(e);
+    if (const char* e = mgx::env("MGX_DIST_DECLARE_MUL")) declare_mul = (u32)atoi(e);
+    if (const char* e = mgx::env("MGX_DIST_SPARSE_PUSH")) sparse_push = atoi(e);
+    if (const char* e = mgx::env("MGX_DIST_FUSED_MERGE")) fused_merge = atoi(e);
+    if (const char* e = mgx::env("MGX_DIST_BUILD_LIST")) build_list = atoi(e);
+    if (const char* e = mgx::env("MGX_DIST_PUSH_SPLIT")) push_split = atoi(e);
     {
       int defer = 1;
-      if (const char* e = getenv("MGX_DIST_DEFER")) defer = atoi(e);
+      if (const char* e = mgx::env("MGX_DIST_DEFER")) defer = atoi(e);
       if (defer) defer_buf = mem_t<u32>((size_t)BFS_FLUSH_MAX * BFS_FLUSH_WORDS, ctx);
     }
     slot_marks = mem_t<u32>((size_t)2 * BFS_MARK_CTRS * BFS_MARK_STRIDE, ctx);
@@ -828,7 +829,7 @@ struct d2_run_bufs_t {
   long long spec_runs = 0, spec_frozen = 0, spec_short = 0;
   int last_plan_levels = 0;
   u64 last_plan_sparse = 0;
-  d2_run_bufs_t() { if (const char* e = getenv("MGX_DIST_SPEC")) spec = atoi(e); }
+  d2_run_bufs_t() { if (const char* e = mgx::env("MGX_DIST_SPEC")) spec = atoi(e); }
   void learn(const bfs_ctrl_t* hc, int levels, long long last_new, u32 list_cap) {
     hist_t h;
     h.levels = levels < 64 ? levels : 64;

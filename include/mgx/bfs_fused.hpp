@@ -45,6 +45,7 @@
 #include <cstring>
 
 #include "runtime.hpp"
+#include "env.hpp"
 #include "wave.hpp"
 
 namespace mgx {
@@ -1154,8 +1155,8 @@ struct bfs_run_opts_t {
 #endif
   static bfs_run_opts_t from_env() {
     bfs_run_opts_t o;
-    auto geti = [](const char* name, int& out) { if (const char* e = getenv(name)) out = atoi(e); };
-    auto getll = [](const char* name, long long& out) { if (const char* e = getenv(name)) out = atoll(e); };
+    auto geti = [](const char* name, int& out) { if (const char* e = mgx::env(name)) out = atoi(e); };
+    auto getll = [](const char* name, long long& out) { if (const char* e = mgx::env(name)) out = atoll(e); };
     geti("MGX_BFS_COLD_TEST", o.cold_test);
     geti("MGX_BFS_MERGED_PUSH", o.merged);
     geti("MGX_BFS_DENSE", o.dense);
@@ -1169,7 +1170,7 @@ struct bfs_run_opts_t {
     geti("MGX_BFS_COLD_PACK", o.cold_pack);
     geti("MGX_BFS_HOT_UNITS", o.hot_units);
     geti("MGX_BFS_COLD", o.cold);
-    if (const char* e = getenv("MGX_BFS_DEFER_REACH")) {
+    if (const char* e = mgx::env("MGX_BFS_DEFER_REACH")) {
       o.defer_mul = atoi(e);
       const char* sl = strchr(e, '/');
       o.defer_div = sl ? atoi(sl + 1) : 1;
@@ -1279,8 +1280,8 @@ struct bfs_fused_state_t {
     MGX_HIP(hipEventCreate(&ev0));
     MGX_HIP(hipEventCreate(&ev1));
     for (int i = 0; i < EV_POOL; ++i) MGX_HIP(hipEventCreate(&wev[i]));
-    if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e) > 0 ? atoi(e) : 0;
-    if (const char* e = getenv("MGX_BFS_HOT_MIN_EDGES")) hot_min_edges = (unsigned)atoll(e);
+    if (const char* e = mgx::env("MGX_BFS_LONG_MIN")) long_min = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = mgx::env("MGX_BFS_HOT_MIN_EDGES")) hot_min_edges = (unsigned)atoll(e);
   }
   bfs_fused_state_t(const bfs_fused_state_t&) = delete;
   bfs_fused_state_t& operator=(const bfs_fused_state_t&) = delete;

@@ -35,6 +35,7 @@
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include "env.hpp"
 
 namespace mgx {
 namespace loopback {
@@ -78,7 +79,7 @@ struct lcomm_t {
 };
 
 inline std::chrono::seconds timeout() {
-  static const long s = [] { const char* e = std::getenv("MGX_LOOPBACK_TIMEOUT_S"); const long v = e ? std::atol(e) : 120; return v > 0 ? v : 120; }();
+  static const long s = [] { const char* e = mgx::env("MGX_LOOPBACK_TIMEOUT_S"); const long v = e ? std::atol(e) : 120; return v > 0 ? v : 120; }();
   return std::chrono::seconds(s);
 }
 

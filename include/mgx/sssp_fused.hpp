@@ -925,14 +925,14 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   a.ctrl = st.ctrl.data();
   a.n = st.n;
   a.delta = st.delta;
-  const char* const bl = getenv("MGX_SSSP_BUILD_LIST");            // (=1: the list-based queue build, k_sssp_build)
+  const char* const bl = mgx::env("MGX_SSSP_BUILD_LIST");            // (=1: the list-based queue build, k_sssp_build)
   const bool build2 = !(bl && atoi(bl) != 0) && ((uintptr_t)a.row_offsets % 16 == 0);
   a.m_edges = 0ull;
   a.frontier_bits = nullptr;
   // heavy iterations as a sweep over the layout's unit blocks and degree classes (sssp_dense_*): needs the frontier as a
   // bitmap (k_sssp_build2 writes it) and the plain loop (near / far buckets park vertices outside the queue)
   unsigned ddiv = st.dense_div;
-  if (const char* e = getenv("MGX_SSSP_DENSE")) ddiv = (unsigned)atoi(e);
+  if (const char* e = mgx::env("MGX_SSSP_DENSE")) ddiv = (unsigned)atoi(e);
   const bool dense = layout && layout->ub_w && (layout->ub_col || layout->ub_col24) && layout->ub_cnt && layout->ub_owner && layout->ub_units_pad >= 16 &&
                      layout->vs_v[3] >= layout->vs_v[0] && layout->m_edges > 0 && build2 && ddiv > 0 && a.delta == 0.f;
   if (dense && !st.frontier_bits.size()) st.frontier_bits = mem_t<u32>(((size_t)st.n + 31) / 32 + 4, ctx);
@@ -951,7 +951,7 @@ inline void sssp_fused_run(sssp_fused_state_t& st, const int* row_offsets, const
   for (int i = 0; i < 4; ++i) a.vs_v[i] = dense ? layout->vs_v[i] : 0u;
   a.dense_div = dense ? ddiv : 0u;
   if (dense) { a.m_edges = (unsigned long long)layout->m_edges; a.frontier_bits = st.frontier_bits.data(); }
-  const char* const hme = getenv("MGX_SSSP_HOT_MIN_EDGES");        // (tests force the LDS bounds on small graphs)
+  const char* const hme = mgx::env("MGX_SSSP_HOT_MIN_EDGES");        // (tests force the LDS bounds on small graphs)
   a.hot_min_edges = hme ? (u32)atoll(hme) : SSSP_HOT_MIN_EDGES;
   hipLaunchKernelGGL(k_sssp_init, dim3(grid_for(((long long)st.n + 3) / 4, BLOCK, ctx.num_cus * 8)), dim3(BLOCK), 0, s, a, src,
                      layout ? layout->new_of_old : (const int*)nullptr);

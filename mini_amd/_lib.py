@@ -52,6 +52,7 @@ _pi, _pi64, _pf, _pvp = C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_
 SIGNATURES = {
     "mgx_version": [],
     "mgx_build_is_lab": [],
+    "mgx_env_switches": [_i, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)],
     "mgx_strerror": [_i],
     "mgx_last_error": [],
     "mgx_ctx_create": [_i, _vp, _pvp],

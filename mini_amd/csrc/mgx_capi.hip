@@ -14,6 +14,7 @@
 #include "gunrock/sssp/sssp_enactor.hxx"
 #include "mgx/bfs_dist.hpp"
 #include "mgx/bfs_dist2.hpp"
+#include "mgx/env.hpp"
 #include "mgx/sssp_dist.hpp"
 #include "mgx/rmat.hpp"
 #include "mgx/sssp_fused.hpp"
@@ -150,7 +151,7 @@ static void ensure_nr_slices(mgx_graph_s* g) {
   graph_device_t& G = *g->g;
   if (G.nrs_tried) return;
   G.nrs_tried = true;
-  if (const char* e = getenv("MGX_NR_SLICED")) if (atoi(e) == 0) return;
+  if (const char* e = mgx::env("MGX_NR_SLICED")) if (atoi(e) == 0) return;
   if (!G.has_layout || G.ub_units <= 0 || !G.d_ub_first.size() || G.vs_long_min != G.ub_min_degree || G.vs_long_min < 17 || G.vs_long_min > 64 ||
       G.vs_v[0] == 0 || G.vs_dummy == 0) return;
   standard_context_t& ctx = *g->c->ctx;
@@ -158,7 +159,7 @@ static void ensure_nr_slices(mgx_graph_s* g) {
   const long long n = G.num_nodes;
   const int all = (int)std::min<long long>((n + S - 1) / S, (long long)mgx::NRS_MAX_SLICES);      // (slices the id range has)
   int slices = std::min(all, mgx::nrs_default_slices(n));
-  if (const char* e = getenv("MGX_NR_SLICES")) { const int v = atoi(e); if (v >= 1) slices = std::min(v, all); }   // (tests: a tail on small graphs, many slices on mid-size ones)
+  if (const char* e = mgx::env("MGX_NR_SLICES")) { const int v = atoi(e); if (v >= 1) slices = std::min(v, all); }   // (tests: a tail on small graphs, many slices on mid-size ones)
   const int rows = (int)G.vs_v[0];
   void* mu = nullptr;
   unsigned* off = nullptr;
@@ -186,7 +187,7 @@ static void ensure_nr_slices(mgx_graph_s* g) {
       return (unsigned)lo;
     };
     int degs[3] = {mgx::NRS_FOLD_DEG[0], mgx::NRS_FOLD_DEG[1], mgx::NRS_FOLD_DEG[2]};
-    if (const char* e = getenv("MGX_NR_FOLD_DEGS")) {            // (tests: every tier on small graphs)
+    if (const char* e = mgx::env("MGX_NR_FOLD_DEGS")) {            // (tests: every tier on small graphs)
       int d0 = 0, d1 = 0, d2 = 0;
       if (sscanf(e, "%d/%d/%d", &d0, &d1, &d2) == 3 && d0 >= d1 && d1 >= d2 && d2 >= 0) { degs[0] = d0; degs[1] = d1; degs[2] = d2; }
     }
@@ -441,7 +442,7 @@ static void build_unit_blocks(mgx_graph_s* g) {
   G.d_ub_cnt = mem_t<unsigned char>(); G.d_ub_first = mem_t<int>(); G.nr_big_rows = 0; G.d_ub_w = mem_t<float>(); G.d_ub_w16 = mem_t<unsigned short>(); G.ub_w_tried = false;
   G.d_nrs_mu = mem_t<unsigned>(); G.d_nrs_off = mem_t<unsigned>(); G.nrs_units = 0; G.nrs_slices = G.nrs_rows = 0; G.nrs_tier[0] = G.nrs_tier[1] = G.nrs_tier[2] = 0; G.nrs_tried = false;
   int long_min = mgx::LONG_MIN_DEFAULT;
-  if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
+  if (const char* e = mgx::env("MGX_BFS_LONG_MIN")) long_min = atoi(e);
   if (long_min <= 0 || !G.has_layout || G.num_edges <= 0) return;
   int *owner = nullptr, *ucol = nullptr, *ufirst = nullptr;
   unsigned char* ucnt = nullptr;
@@ -460,7 +461,7 @@ static void build_unit_blocks(mgx_graph_s* g) {
   // 24-bit copy for the fused BFS (ids below 2^23: bit 23 of an entry is free, so a sign-extending unpack turns 0xFFFFFF
   // back into -1); (units_pad * 64 + 4) entries -- the four -1 behind the blocks included -- are whole quads
   bool pack = (long long)G.num_nodes <= (1ll << 23);
-  if (const char* e = getenv("MGX_BFS_PACK24")) pack = pack && atoi(e) != 0;
+  if (const char* e = mgx::env("MGX_BFS_PACK24")) pack = pack && atoi(e) != 0;
   if (pack) {
     const long long quads = ((long long)units_pad << 4) + 1;
     G.d_ub_col24 = mem_t<unsigned>((size_t)quads * 3 + 4, *g->c->ctx);
@@ -489,7 +490,7 @@ static void build_cold_lists(mgx_graph_s* g) {
   // the short rows' list too on graphs of more than 2^23 vertices (equal to marking those entries on RMAT-22, where 6 % of the entries
   // are cold; RMAT-24 -2 %, RMAT-25 -9 % of a traversal); MGX_BFS_COLD_LISTS: 0 no lists at all, 1 the long rows' only, 2 both
   bool with_short = (long long)G.num_nodes > (1ll << 23);
-  if (const char* e = getenv("MGX_BFS_COLD_LISTS")) {
+  if (const char* e = mgx::env("MGX_BFS_COLD_LISTS")) {
     if (atoi(e) == 0) return;
     with_short = atoi(e) == 2;
   }
@@ -520,7 +521,7 @@ static void build_cold_lists(mgx_graph_s* g) {
     // other levels walk their queues and mark untested (few entries: few marks).  MGX_BFS_FLAT_LISTS=0: the probes, as in round 5.
     G.cold_majority = true;
     bool want = (long long)G.num_edges < (1ll << 31) - 512 && (n + (long long)slice_n - 1) / slice_n <= 64;
-    if (const char* e = getenv("MGX_BFS_FLAT_LISTS")) want = want && atoi(e) != 0;
+    if (const char* e = mgx::env("MGX_BFS_FLAT_LISTS")) want = want && atoi(e) != 0;
     if (!want || G.vs_v[3] == 0) return;
     d_owner = mem_t<int>(); d_dst = mem_t<int>();                    // (the long rows' cold entries: superseded)
     slices = (int)((n + (long long)slice_n - 1) / slice_n);
@@ -613,8 +614,8 @@ static void build_cold_lists(mgx_graph_s* g) {
   // blocks' 24-bit copy stops at 2^23 vertices).  MGX_BFS_HOT_UNITS=0: not built.  The full blocks stay: the neighbour-reduce and the
   // fused SSSP read them, and so does a traversal that is told to run without the cold-edge pass.
   bool hot_units = true;
-  if (const char* e = getenv("MGX_BFS_HOT_UNITS")) hot_units = atoi(e) != 0;
-  if (const char* e = getenv("MGX_BFS_PACK24")) hot_units = hot_units && atoi(e) != 0;
+  if (const char* e = mgx::env("MGX_BFS_HOT_UNITS")) hot_units = atoi(e) != 0;
+  if (const char* e = mgx::env("MGX_BFS_PACK24")) hot_units = hot_units && atoi(e) != 0;
   if (hot_units) {
     int *owner2 = nullptr, *ucol2 = nullptr, *ufirst2 = nullptr;
     unsigned char* ucnt2 = nullptr;
@@ -673,7 +674,7 @@ int mgx_graph_build_layout(mgx_graph_t g, int with_weights) {
   G.vs_edges = 0; G.vs_dummy = 0; G.vs_long_min = 0;
   {
     int long_min = mgx::LONG_MIN_DEFAULT;
-    if (const char* e = getenv("MGX_BFS_LONG_MIN")) long_min = atoi(e);
+    if (const char* e = mgx::env("MGX_BFS_LONG_MIN")) long_min = atoi(e);
     if (long_min > 0 && long_min <= 64 && n > 0 && m > 0) {
       std::vector<int> h(n + 1);
       MGX_HIP(mgx::dtoh(h.data(), G.d_layout_row_offsets.data(), n + 1));
@@ -1529,12 +1530,12 @@ int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
                      st.ranks, st.rank, st.n_local, st.n_global);
   h->c->ctx->synchronize();
   st.ub_owner = owner; st.ub_col = ucol; st.ub_units = U; st.ub_units_pad = Up;
-  if (const char* e = getenv("MGX_DIST_DENSE_DIV")) { const int d = atoi(e); if (d >= 0) st.dense_div = (unsigned)d; }
+  if (const char* e = mgx::env("MGX_DIST_DENSE_DIV")) { const int d = atoi(e); if (d >= 0) st.dense_div = (unsigned)d; }
   // the short rows vertex by vertex (MGX_DIST_VSHORT=0: never; N: when a level holds 1 / N of their edges): needs rows by
   // non-increasing degree (hub-first global ids, cyclic ownership: they are) -- checked here, on the host
   {
     int vdiv = 8;
-    if (const char* e = getenv("MGX_DIST_VSHORT")) vdiv = atoi(e);
+    if (const char* e = mgx::env("MGX_DIST_VSHORT")) vdiv = atoi(e);
     standard_context_t& ctx = *h->c->ctx;
     const int n = st.n_local;
     if (n > 0) {
@@ -1542,7 +1543,7 @@ int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
       int m_last = 0;
       MGX_HIP(mgx::dtoh(&m_last, st.row_offsets + n, 1));
       int defer_mode = 1;
-      if (const char* e = getenv("MGX_DIST_DEFER")) defer_mode = atoi(e);
+      if (const char* e = mgx::env("MGX_DIST_DEFER")) defer_mode = atoi(e);
       st.defer_pays = defer_mode == 2 || (long long)m_last >= mgx::d2_state_t::D2_DEFER_MIN_ENTRIES;
     }
     if (vdiv > 0 && n > 0) {
@@ -1576,7 +1577,7 @@ int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
   // only when the destinations behind the LDS prefix span at most 128 slices of which at most BFS_COLD_MAX_SLICES hold pairs,
   // and the cold entries are at most half of the long rows' entries
   bool want_cold = true;
-  if (const char* e = getenv("MGX_DIST_COLD")) want_cold = atoi(e) != 0;
+  if (const char* e = mgx::env("MGX_DIST_COLD")) want_cold = atoi(e) != 0;
   const unsigned hot_n = (unsigned)mgx::BFS_COLD_WORDS * 32u, slice_n = hot_n;
   const long long slices_ll = (unsigned)st.n_global > hot_n ? ((long long)st.n_global - hot_n + slice_n - 1) / slice_n : 0;
   if (want_cold && slices_ll >= 1 && slices_ll <= 128) {
@@ -1614,7 +1615,7 @@ int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
         // (at most 512 on a rank: every cold workgroup costs a copy of its slice into LDS and an 80 KB bitmap to write and to reduce --
         //  RMAT-26 / 8 with 1 024 of them: push 584 us and reduce 87 us per traversal, with 512: 552 and 57, with 256: 575 and 46)
         nwg = std::min<long long>(nwg, 512);
-        if (const char* e = getenv("MGX_DIST_COLD_WGS")) if (atoi(e) > 0) nwg = std::min<long long>(atoi(e), mgx::BFS_COLD_WGS_MAX);      // (measurements)
+        if (const char* e = mgx::env("MGX_DIST_COLD_WGS")) if (atoi(e) > 0) nwg = std::min<long long>(atoi(e), mgx::BFS_COLD_WGS_MAX);      // (measurements)
         nwg = std::max<long long>(nwg, used);
         unsigned left = (unsigned)nwg - (unsigned)used, acc = 0;
         st.cold_wgs[0] = 0;
@@ -1630,13 +1631,13 @@ int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
         st.cold_flush = mem_t<u32>((size_t)acc * mgx::BFS_COLD_WORDS, ctx);
         MGX_HIP(hipMemsetAsync(st.cold_flush.data(), 0, (size_t)acc * mgx::BFS_COLD_WORDS * sizeof(unsigned), ctx.stream()));
         // a launch of its own ORs a slice's bitmaps together in front of the sweep (MGX_DIST_COLD_REDUCE=0: k_d2_newbits reads them all)
-        if (const char* e = getenv("MGX_DIST_COLD_REDUCE")) st.cold_reduce = atoi(e);
+        if (const char* e = mgx::env("MGX_DIST_COLD_REDUCE")) st.cold_reduce = atoi(e);
         ctx.synchronize();
         st.cold_pairs = pairs; st.cold_slices = used;
         // the pairs once more, four bytes each (owners are global ids by now: `ranks` apart inside a list)
         {
           bool pack_pairs = true;
-          if (const char* e = getenv("MGX_BFS_COLD_PACK")) pack_pairs = atoi(e) != 0;
+          if (const char* e = mgx::env("MGX_BFS_COLD_PACK")) pack_pairs = atoi(e) != 0;
           if (pack_pairs) {
             unsigned *pk = nullptr, *cbase = nullptr;
             unsigned long long mask = 0;
@@ -1649,7 +1650,7 @@ int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
         // them: a third of its stream on RMAT-26 / 8) -- and what is left points into the LDS prefix, ids below 2^20: three bytes
         // per entry do (bfs_fused_dense.hpp: ub_col24).  MGX_DIST_HOT_UNITS=0: the full blocks stay.
         bool hot_units = true;
-        if (const char* e = getenv("MGX_DIST_HOT_UNITS")) hot_units = atoi(e) != 0;
+        if (const char* e = mgx::env("MGX_DIST_HOT_UNITS")) hot_units = atoi(e) != 0;
         if (hot_units) {
           int *owner2 = nullptr, *ucol2 = nullptr, *ufirst2 = nullptr;
           unsigned char* ucnt2 = nullptr;
@@ -1667,7 +1668,7 @@ int mgx_dbfs2_build_units(mgx_dbfs2_t h, int64_t* units) {
             st.ub_owner = owner2; st.ub_col = ucol2; st.ub_units = U2; st.ub_units_pad = Up2;
             if (units) *units = U2;
             bool pack = true;
-            if (const char* e = getenv("MGX_BFS_PACK24")) pack = atoi(e) != 0;
+            if (const char* e = mgx::env("MGX_BFS_PACK24")) pack = atoi(e) != 0;
             if (pack) {
               const long long quads = ((long long)Up2 << 4) + 1;
               st.ub_col24 = mem_t<unsigned>((size_t)quads * 3 + 4, ctx);
@@ -1904,6 +1905,12 @@ int mgx_comm_free(mgx_comm_t h) {
   MGX_CATCH
 }
 const char* mgx_comm_library(void) { return mgx::rccl_api_t::get().where.c_str(); }
+int mgx_env_switches(int index, const char** name, const char** what) {
+  int n = 0;
+  const mgx::env_switch_t* t = mgx::env_switches(&n);
+  if (index >= 0 && index < n) { if (name) *name = t[index].name; if (what) *what = t[index].what; }
+  return n;
+}
 int mgx_build_is_lab(void) {
 #ifdef MGX_LAB
   return 1;
@@ -2108,7 +2115,7 @@ static void ensure_unit_weights(mgx_graph_s* g) {
   G.ub_w_tried = true;
   // (the sweep reads the long rows from the unit blocks and walks the short ones by degree class: any threshold the two were cut by together)
   if (!G.has_layout || !G.has_layout_weights || G.ub_units <= 0 || !G.d_ub_first.size() || G.vs_long_min != G.ub_min_degree || G.vs_long_min < 17 || G.vs_long_min > 64) return;
-  if (const char* e = getenv("MGX_SSSP_DENSE")) if (atoi(e) == 0) return;
+  if (const char* e = mgx::env("MGX_SSSP_DENSE")) if (atoi(e) == 0) return;
   standard_context_t& ctx = *g->c->ctx;
   float* w = nullptr;
   const size_t entries = ((size_t)G.ub_units_pad << 6) + 4;

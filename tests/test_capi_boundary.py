@@ -37,6 +37,52 @@ def test_version_and_strerror(built):
     assert b"overflow" in mini_amd.lib.mgx_strerror(mini_amd.MGX_E_FRONTIER_OVERFLOW)
 
 
+def _env_table():
+    import mini_amd
+    name, what = C.c_char_p(), C.c_char_p()
+    n = mini_amd.lib.mgx_env_switches(-1, None, None)
+    out = {}
+    for i in range(n):
+        assert mini_amd.lib.mgx_env_switches(i, C.byref(name), C.byref(what)) == n
+        out[name.value.decode()] = what.value.decode()
+    return out
+
+
+def test_every_switch_the_tests_and_tools_set_is_one_the_library_reads(built):
+    """include/mgx/env.hpp holds the one table of environment switches and the one getenv of the tree.  A variable a test or a tool sets that
+    is not in it would select nothing, silently: every MGX_* name set through os.environ / monkeypatch.setenv / a VARIANTS-style dict /
+    a shell assignment must be in the table, or in the short list of variables the PYTHON layer and the bench scripts read themselves."""
+    table = _env_table()
+    assert len(table) >= 45 and all(k.startswith("MGX_") and v for k, v in table.items())
+    python_side = {"MGX_LIB", "MGX_DATA_DIR", "MGX_DATASET", "MGX_NO_TORCH_PRELOAD",                      # mini_amd/_lib.py, tests/test_gpu_configs.py
+                   "MGX_DIST_FORCE_COLLECTIVES", "MGX_DIST_EXCHANGE", "MGX_DIST_LISTS", "MGX_DIST_NATIVE",   # mini_amd/dist_bfs.py, bench_dist.py
+                   "MGX_DIST_GEN", "MGX_DIST_UNITS",
+                   "MGX_SSSP_LAYOUT",                                                                        # tools/sssp_bench.py
+                   "MGX_TEST_EXPECT_UNIT_LEVELS", "MGX_TEST_EXPECT_COLD_LEVELS", "MGX_TEST_EXPECT_BIG_SPARSE"}   # tests/test_dist.py's own
+    pats = [r'setenv\(\s*"(MGX_\w+)"', r'environ(?:\.get|\.pop|\.setdefault)?[\[(]\s*"(MGX_\w+)"', r'"(MGX_[A-Z0-9_]+)"\s*:', r'\b(MGX_[A-Z0-9_]+)=']
+    used = {}
+    for d in ("tests", "tools", "."):
+        for f in sorted(os.listdir(os.path.join(ROOT, d))):
+            if not f.endswith((".py", ".sh")):
+                continue
+            text = open(os.path.join(ROOT, d, f)).read()
+            for pat in pats:
+                for m in re.findall(pat, text):
+                    used.setdefault(m, os.path.join(d, f))
+    unknown = {k: v for k, v in used.items() if k not in table and k not in python_side and not k.startswith("MGX_BENCH_")}
+    assert not unknown, "set somewhere, read nowhere: %s" % unknown
+    # ... and the sources call getenv in exactly one place
+    hits = []
+    for base in ("include", os.path.join("mini_amd", "csrc")):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            if "moderngpu" in dp:
+                continue
+            for f in fs:
+                if f.endswith((".hpp", ".hxx", ".h", ".hip")) and re.search(r"\bgetenv\s*\(", open(os.path.join(dp, f)).read()):
+                    hits.append(os.path.relpath(os.path.join(dp, f), ROOT))
+    assert hits == [os.path.join("include", "mgx", "env.hpp")], hits
+
+
 def test_no_device_is_a_status_not_a_crash(built):
     import torch
     import mini_amd
